@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- Lanczos iterations/s + CSR-SpMV GB/s (vs the HBM roofline) on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1
+the driver launches it under torch.distributed.run, one rank per GPU.  W untimed warm-up
+Lanczos steps, then EXACTLY K timed steps bracketed by barrier + synchronize, max over ranks,
+rank 0 prints ONE JSON line.
+
+A "step" is one full iteration of the reference's Lanczos loop (src/lanczos.cc:193-264):
+v_m = -b v_{m-2} + H v_{m-1}, a = Re<v_{m-1}, v_m>, v_m -= a v_{m-1}, b = |v_m|, v_m /= b, and
+the host Ritz solve + stop test ("sr_val0").  The Hamiltonian is assembled on the device
+(synthetic: no dataset exists for this path), resident in HBM before the timed region.
+
+Scaling is STRONG: the same operator is row-sharded over the N GPUs.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def workloads():
+    from quantum_basis_amd import lattices
+    return {
+        # BASELINE.json configs[2] / SURVEY 8(d) C3: the >=1e8-dim Hubbard the metric is quoted on
+        "hubbard_4x4_half": dict(kind="hubbard", n_sites=16, n_up=8, n_dn=8, bonds=lattices.square(4, 4), t=1.0, U=1.1),
+        # SURVEY 8(d) C4 substitute (4x5, N_up = N_dn = 5; half filling is 3.4e10-dim)
+        "hubbard_4x5_n5": dict(kind="hubbard", n_sites=20, n_up=5, n_dn=5, bonds=lattices.square(4, 5), t=1.0, U=1.1),
+        "hubbard_4x3_half": dict(kind="hubbard", n_sites=12, n_up=6, n_dn=6, bonds=lattices.square(4, 3), t=1.0, U=1.1),
+        "hubbard_4x2_half": dict(kind="hubbard", n_sites=8, n_up=4, n_dn=4, bonds=lattices.square(4, 2), t=1.0, U=1.1),
+        # BASELINE.json configs[1] / C2
+        "kagome_30": dict(kind="heisenberg", n_sites=30, n_dn=15, bonds=lattices.kagome(5, 2), J=1.0),
+        "kagome_24": dict(kind="heisenberg", n_sites=24, n_dn=12, bonds=lattices.kagome(4, 2), J=1.0),
+        "chain_22": dict(kind="heisenberg", n_sites=22, n_dn=11, bonds=lattices.chain(22), J=1.0),
+    }
+
+
+def dim_of(w):
+    from math import comb
+    if w["kind"] == "hubbard":
+        return comb(w["n_sites"], w["n_up"]) * comb(w["n_sites"], w["n_dn"])
+    return comb(w["n_sites"], w["n_dn"])
+
+
+def build_operator(w, rows, opts):
+    import quantum_basis_amd as q
+    if w["kind"] == "hubbard":
+        return q.csr_mat.hubbard(w["n_sites"], w["n_up"], w["n_dn"], w["bonds"], t=w["t"], U=w["U"], rows=rows, opts=opts)
+    return q.csr_mat.heisenberg(w["n_sites"], w["n_dn"], w["bonds"], J=w["J"], rows=rows, opts=opts)
+
+
+def cpu_baseline(A, dim, budget_rows):
+    """Port baseline: the oracle's OpenMP CSR SpMV + BLAS-1 (oracle/qb_oracle.c) on the host
+    cores, timed on a bounded slab of the SAME operator (first R rows, full-length x), scaled
+    by dim/R to one Lanczos iteration."""
+    from oracle import qb_oracle as qo
+    R = int(min(A.dim, budget_rows))
+    ia, ja, val = A.download(0, R)
+    slab = qo.Csr.__new__(qo.Csr)
+    # the slab is R x dim (rectangular): build the ctypes view by hand
+    slab.dim, slab.ia, slab.ja, slab.val, slab.sym = R, ia, ja.astype(np.int64), val, False
+    slab.nnz = int(ia[-1])
+    slab._c = qo._CSR(R, slab.nnz, 0, slab.ia.ctypes.data, slab.ja.ctypes.data, slab.val.ctypes.data)
+    x = qo.vec_randomize(dim, 1)
+    y = np.zeros(R, dtype=np.complex128)
+    L = qo.lib()
+    import ctypes as C
+    reps, t_spmv, t_blas = 0, 0.0, 0.0
+    t_end = time.time() + 12.0
+    while reps < 3 or (time.time() < t_end and reps < 50):
+        t0 = time.perf_counter()
+        L.qbo_multmv2(slab.ref(), x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p))
+        t1 = time.perf_counter()
+        # the BLAS-1 of one Lanczos step on the same R elements: scale, dot, axpy, nrm2, scale
+        xs = x[:R]
+        y *= -0.5
+        a = qo.dotc(xs, y).real
+        y -= a * xs
+        nrm = qo.nrm2(y)
+        y *= 1.0 / max(nrm, 1e-300)
+        t2 = time.perf_counter()
+        if reps > 0:             # first pass warms the page cache / threads
+            t_spmv += t1 - t0
+            t_blas += t2 - t1
+        reps += 1
+    n = reps - 1
+    scale = dim / R
+    ms_spmv = 1e3 * t_spmv / n * scale
+    ms_iter = 1e3 * (t_spmv + t_blas) / n * scale
+    bytes_alg = slab.nnz * 20 + (R + 1) * 8 + R * 32
+    return {"value": round(1e3 / ms_iter, 4), "unit": "lanczos_iters/s", "cores": qo.num_threads(), "kind": "port",
+            "sample": "first %d of %d rows (%d nnz) of the same operator, full-length x, %d timed passes of "
+                      "oracle qbo_multmv2 (OpenMP, full storage) + the step's BLAS-1; scaled by dim/rows"
+                      % (R, dim, slab.nnz, n),
+            "spmv_ms_scaled": round(ms_spmv, 3), "spmv_GBps": round(bytes_alg / (t_spmv / n) / 1e9, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=os.environ.get("QBH_WORKLOAD", "hubbard_4x4_half"))
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 stream, 2 vector")
+    ap.add_argument("--npb", type=int, default=0)
+    ap.add_argument("--no-swizzle", action="store_true")
+    ap.add_argument("--value-dict", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-converge", action="store_true", help="skip the untimed run to convergence (E0)")
+    ap.add_argument("--cpu-rows", type=int, default=2_000_000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import quantum_basis_amd as q
+    from quantum_basis_amd import _lib, dist as qdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+        args.gpus = world
+    _lib.require_gpu()                      # no CPU fallback: fail loudly
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    W = workloads()[args.workload]
+    dim = dim_of(W)
+    nblk, ranges = qdist.row_partition(dim, world)
+    r0, r1 = ranges[rank]
+    stream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(stream):
+        opts = q.make_opts(device=local_rank, stream=stream.cuda_stream, spmv_kernel=args.kernel,
+                           nnz_per_block=args.npb, xcd_swizzle=0 if args.no_swizzle else 1,
+                           value_dict=args.value_dict, profile=1)
+        t_gen = time.time()
+        A = build_operator(W, (r0, r1), opts)
+        torch.cuda.synchronize()
+        t_gen = time.time() - t_gen
+        if world > 1:
+            comm = qdist.ShardComm(dim, rank=rank, world=world, device=device, stream=stream).attach(A)
+        info = A.info()
+        nnz_total = torch.tensor([info.nnz], dtype=torch.int64, device=device)
+        if world > 1:
+            dist.all_reduce(nnz_total)
+        nnz_total = int(nnz_total.item())
+
+        K, Wm = args.steps, args.warmup
+        maxit = max(K + Wm + 16, 64)
+        n = A.dim
+        v = A.vec(2)
+        hess = np.zeros(2 * maxit)
+
+        def fresh_start(seed):
+            A.randomize(v.at(0), seed)
+            hess[:] = 0.0
+            return 0
+
+        def run_steps(k, nsteps, seed):
+            """Advance nsteps Lanczos steps (restarting from a new start vector if the stop rule
+            fires first); returns (k, seed, steps actually done)."""
+            left, total = nsteps, 0
+            while left > 0:
+                m = q.lanczos(k, left, maxit, n, A, None, hess, "sr_val0", device_v=v)
+                left -= m - k
+                total += m - k
+                k = m
+                if left > 0:          # converged / broke down before np steps: new Krylov space
+                    seed += 1
+                    k = fresh_start(seed)
+            return k, seed, total
+
+        seed = 1
+        k = fresh_start(seed)
+        if Wm > 0:
+            k, seed, _ = run_steps(k, Wm, seed)
+        A.stats(reset=True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k, seed, K_done = run_steps(k, K, seed)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        st = A.stats()
+        el = torch.tensor([elapsed, st.ms_spmv / max(st.n_spmv, 1)], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed, ms_spmv = float(el[0].item()), float(el[1].item())
+
+        # untimed: run the same solver to convergence for E0 (parity across N and vs the small-size oracle tests)
+        e0 = steps_e0 = None
+        if not args.no_converge:
+            maxit2 = 1000
+            hess2 = np.zeros(2 * maxit2)
+            A.randomize(v.at(0), 1)
+            m = q.lanczos(0, maxit2 - 1, maxit2, n, A, None, hess2, "sr_val0", device_v=v)
+            ritz, _ = q.hess_eigen(hess2, maxit2, m, "sr")
+            e0, steps_e0 = float(ritz[0]), int(m)
+
+    # algorithmic bytes of ONE SpMV launch on this rank: nnz*(16+4) + (rows+1)*8 + x once + y once
+    bytes_launch = info.nnz * 20 + (info.nrows + 1) * 8 + (dim if world > 1 else info.nrows) * 16 + info.nrows * 16
+    achieved = bytes_launch / (ms_spmv * 1e-3) / 1e9 if ms_spmv > 0 else 0.0
+    out = {
+        "metric": "lanczos_iters_per_sec", "value": round(K_done / elapsed, 4), "unit": "lanczos_iters/s",
+        "n_gpus": world, "steps": K_done, "warmup": Wm, "ms_per_step": round(1e3 * elapsed / K_done, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "complex128 (f64)",
+        "data": "synthetic", "config": {"workload": args.workload, "dim": dim, "nnz_full": nnz_total,
+                                         "rows_per_gpu": info.nrows, "parallelism": "row-shard x%d" % world,
+                                         "kernel": {1: "stream", 2: "vector"}[info.kernel], "value_dict": info.value_dict,
+                                         "build_s": round(t_gen, 3)},
+        "roofline": {"bound": "hbm", "kernel": "k_spmv_stream" if info.kernel == 1 else "k_spmv_vector",
+                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "bytes_per_launch": bytes_launch, "ms_per_launch": round(ms_spmv, 4), "launches": int(st.n_spmv)},
+        "e0": e0, "lanczos_steps_to_converge": steps_e0,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(A, dim, args.cpu_rows)
+        except Exception as e:      # the baseline is reported, never required
+            out["cpu_baseline"] = {"value": None, "unit": "lanczos_iters/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,251 @@
+/*
+ * qbhip.h -- C ABI of libqbhip.so, the MI355X (gfx950) engine for the sparse
+ * Hamiltonian x vector hot path of wztzjhn/quantum_basis.
+ *
+ * The reference has no FFI layer; its operator boundary is the duck-typed MAT
+ * template parameter of lanczos<T,MAT> / eigenvec_CG<T,MAT> / iram<T,MAT>
+ * (src/qbasis.h:1065-1093), closed at link time over csr_mat<T>
+ * (src/qbasis.h:976-1021).  Every entry point below replaces one reference
+ * function; the citation says which.  Plain pointers and sizes only: no C++
+ * types, no torch types, no exceptions cross this boundary (functions return
+ * 0 or a negative QBH_E* code; qbh_last_error() gives the detail).
+ *
+ * Complex numbers are interleaved (re, im) doubles, layout-compatible with
+ * std::complex<double> and MKL_Complex16.  All index integers are 64-bit on
+ * the host side (the reference builds with -DMKL_ILP64).
+ *
+ * Threading: like the reference (single caller thread, src/model.cc:1177),
+ * calls on one operator handle must not be concurrent.
+ *
+ * There is no CPU fallback: every compute entry point fails with
+ * QBH_ENODEVICE when no HIP device is present.
+ */
+#ifndef QBHIP_H
+#define QBHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QBH_VERSION 100
+
+/* error codes */
+#define QBH_OK          0
+#define QBH_EINVAL     -1   /* invalid argument (reference: std::invalid_argument / assert) */
+#define QBH_ENODEVICE  -2   /* no HIP device / HIP runtime error at init                    */
+#define QBH_EHIP       -3   /* a HIP call failed (reference: std::runtime_error from MKL)   */
+#define QBH_ENOMEM     -4   /* host or device allocation failed                             */
+#define QBH_ENOTHERM   -5   /* full-storage matrix failed the Hermitian check (sparse.cc:235-256, reference exits 99) */
+#define QBH_ECOMM      -6   /* a communicator hook reported failure                         */
+#define QBH_ENOTNORM   -7   /* Lanczos start vector not normalised (assert at lanczos.cc:166) */
+#define QBH_ENOCONV    -8   /* tridiagonal QL failed to converge                            */
+#define QBH_EUNSUPP    -9   /* valid in the reference but not supported here                */
+
+typedef struct qbh_z { double re, im; } qbh_z;
+
+/* opaque device-resident operator: one row shard of H in HBM, its stream, workspace */
+typedef struct qbh_csr qbh_csr;
+
+/* tolerances reused verbatim from src/miscellaneous.cc:44-47 */
+#define QBH_LANCZOS_PRECISION 2e-12
+#define QBH_SPARSE_PRECISION  1e-14
+
+/* ---------------------------------------------------------------- misc --- */
+int         qbh_version(void);
+int         qbh_device_count(void);                 /* 0 when there is no usable GPU */
+const char *qbh_strerror(int code);
+const char *qbh_last_error(void);                   /* thread-local detail of the last failure */
+
+/* ------------------------------------------------------------- options --- */
+#define QBH_KERNEL_AUTO    0
+#define QBH_KERNEL_STREAM  1   /* row-block streaming through LDS (default)        */
+#define QBH_KERNEL_VECTOR  2   /* sub-wavefront per row, shuffle reduction         */
+
+typedef struct qbh_opts {
+    int     device;          /* HIP ordinal; -1 = current device                                  */
+    void   *stream;          /* hipStream_t to enqueue on; NULL = library-owned stream             */
+    int     spmv_kernel;     /* QBH_KERNEL_*                                                       */
+    int     nnz_per_block;   /* streaming kernel: nonzeros staged per workgroup; 0 = default       */
+    int     xcd_swizzle;     /* 1 (default): map workgroups so each XCD walks a contiguous range   */
+    int     value_dict;      /* 0 = store complex128 values; 1 = dictionary-code them when <=256
+                                distinct values exist (exact, lossless)                            */
+    int     profile;         /* 1: bracket every SpMV launch with HIP events (qbh_get_stats)       */
+    int     check_hermitian; /* 1 (default): full-storage host input is checked like sparse.cc:235 */
+} qbh_opts;
+
+void qbh_opts_default(qbh_opts *o);
+
+/* ------------------------------------------------------------ operator --- */
+/* Replaces csr_mat<T>::csr_mat(lil_mat<T>&) + create_handle (src/sparse.cc:202-260).
+ * Host CSR exactly as the reference holds it (src/qbasis.h:979-985): zero-based,
+ * ia[dim+1], ja[nnz] int64, val[nnz] complex128; sym_upper != 0 means only col >= row is
+ * stored (reference default).  The arrays are COPIED (and for sym_upper expanded to both
+ * triangles, columns narrowed to int32) into HBM; the caller keeps ownership and may free
+ * or mutate them afterwards (call_feast does, src/lanczos.cc:626-629). */
+int qbh_csr_create(qbh_csr **out, int64_t dim, int64_t nnz, int sym_upper,
+                   const int64_t *ia, const int64_t *ja, const qbh_z *val,
+                   const qbh_opts *opts);
+
+/* Adopt a row shard that already lives in HBM (device-side generator, multi-GPU row
+ * blocks).  Rows [row_offset, row_offset+nrows) of a global ncols x ncols operator in
+ * FULL storage; d_ia[nrows+1] is local (d_ia[0] == 0); d_ja holds GLOBAL columns.
+ * take_ownership != 0: the arrays were allocated with hipMalloc and are freed by
+ * qbh_csr_destroy. */
+int qbh_csr_create_device(qbh_csr **out, int64_t nrows, int64_t ncols, int64_t row_offset,
+                          int64_t nnz, int64_t *d_ia, int32_t *d_ja, qbh_z *d_val,
+                          int take_ownership, const qbh_opts *opts);
+
+/* Replaces csr_mat<T>::destroy / ~csr_mat (src/sparse.cc:150-186).  NULL is a no-op. */
+void qbh_csr_destroy(qbh_csr *A);
+
+typedef struct qbh_csr_info {
+    int64_t nrows, ncols, row_offset, nnz;   /* nnz as applied (full storage)                 */
+    int64_t n_blocks;                        /* workgroups per SpMV launch                     */
+    int64_t bytes_matrix;                    /* HBM bytes held by the matrix arrays            */
+    int64_t bytes_algorithmic;               /* nnz*20 + (nrows+1)*8 + nrows*16 + nrows*16     */
+    int     kernel;                          /* QBH_KERNEL_* actually selected                 */
+    int     value_dict;                      /* number of dictionary entries, 0 = not coded    */
+    int     device;
+    void   *stream;
+} qbh_csr_info;
+int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info);
+
+/* Level-1 seam, host vectors.  Replace csr_mat<T>::MultMv (y = H x, src/sparse.cc:291-297)
+ * and csr_mat<T>::MultMv2 (y += H x, src/sparse.cc:262-289).  x and y are host pointers of
+ * length dim and may be interior pointers (ARPACK's workd, src/lanczos.cc:476); they are
+ * staged through HBM inside the call. */
+int qbh_multmv(const qbh_csr *A, const qbh_z *x_host, qbh_z *y_host);
+int qbh_multmv2(const qbh_csr *A, const qbh_z *x_host, qbh_z *y_host);
+
+/* ------------------------------------------------------ device vectors --- */
+/* std::vector<T> of the callers (src/model.cc:1158-1164), but in HBM. */
+int qbh_vec_alloc(qbh_z **d_out, int64_t n);
+int qbh_vec_free(qbh_z *d);
+int qbh_vec_upload(const qbh_csr *A, qbh_z *d_dst, const qbh_z *h_src, int64_t n);
+int qbh_vec_download(const qbh_csr *A, qbh_z *h_dst, const qbh_z *d_src, int64_t n);
+int qbh_vec_zero(const qbh_csr *A, qbh_z *d, int64_t n);
+/* Replaces vec_randomize (src/miscellaneous.cc:371-386): element j (GLOBAL index
+ * row_offset + j) gets minstd_rand0 draw number j+1 of `seed`, times 1/2147483647, minus
+ * 0.5, imaginary part 0; then the vector is scaled by 1/||x|| (global norm under a
+ * communicator).  seed == 0 gives the constant vector 1/sqrt(n_global). */
+int qbh_vec_randomize(const qbh_csr *A, qbh_z *d_x, uint32_t seed);
+
+/* ------------------------------------------- device building blocks ------ */
+/* y <- alpha*(H x) + beta*y + gamma*x_local, all vectors device-resident, shard-local
+ * length nrows.  Under a communicator x is gathered first (hook allgather_x).
+ * If red != NULL it receives {Re<x,y>, Im<x,y>, ||y||^2} of the NEW y (global sums).
+ * MultMv is (1,0,0), MultMv2 is (1,1,0), the Lanczos step is (1/b', -b, 0), the CG
+ * step (src/lanczos.cc:320-322) is (1, 0, eps-E0). */
+int qbh_spmv_dev(const qbh_csr *A, const qbh_z *d_x, qbh_z *d_y,
+                 double alpha, double beta, double gamma, double *red /* [3] or NULL */);
+/* conj(x).y (src/lanczos.cc:47-53) -> res[2], global */
+int qbh_dotc_dev(const qbh_csr *A, const qbh_z *d_x, const qbh_z *d_y, double *res);
+/* y += alpha*x then ||y||^2 (cblas_zaxpy + cblas_dznrm2 fused; src/lanczos.cc:206-208) */
+int qbh_axpy_norm_dev(const qbh_csr *A, qbh_z alpha, const qbh_z *d_x, qbh_z *d_y, double *nrm2_sq);
+/* x *= a (src/lanczos.cc:214) */
+int qbh_scal_dev(const qbh_csr *A, double a, qbh_z *d_x);
+/* ||x|| (src/lanczos.cc:28-33), global */
+int qbh_nrm2_dev(const qbh_csr *A, const qbh_z *d_x, double *nrm);
+
+/* ---------------------------------------------------------- solvers ------ */
+/* one row of log_Lanczos_<purpose>.txt (src/lanczos.cc:102-128) */
+typedef struct qbh_lanczos_row {
+    int64_t k;
+    double  ritz[4];
+    double  a_km1, b_k, accuracy, accu_E0, accu_E1;
+} qbh_lanczos_row;
+
+typedef struct qbh_solver_info {
+    qbh_lanczos_row *log;      /* in: caller buffer or NULL; out: filled rows                     */
+    int64_t          log_cap;  /* in: capacity of log (rows); rows beyond it are dropped          */
+    int64_t          log_len;  /* out                                                             */
+    int64_t          n_matvec; /* out: SpMV launches                                              */
+    int64_t          n_reorth; /* out: re-orthogonalisations against phi0 (sr_val1)               */
+    double           ms_total; /* out: wall ms inside the call                                    */
+    double           ms_spmv;  /* out: sum of HIP-event SpMV kernel ms (opts.profile)             */
+    double          *cg_resid; /* in: NULL or room for maxit+1 doubles (log_CG.txt residuals)     */
+} qbh_solver_info;
+
+/* Replaces lanczos<T,MAT> for MAT = csr_mat (src/lanczos.cc:134-266), purposes "sr_val0",
+ * "sr_val1", "dnmcs"; contract of src/qbasis.h:1028-1067: v holds v[k-1], v[k] at
+ * (j%2)*n (phi0 at 2*n for sr_val1), hessenberg has leading dimension maxit with b[j] at
+ * [j] and a[j] at [maxit+j]; same stop rule and tolerances (src/lanczos.cc:216,230-245).
+ * n is the shard-local length (== dim without a communicator).  The _dev form keeps v in
+ * HBM for the whole call (level-2 seam); the host form uploads v on entry and downloads
+ * it on exit.  info may be NULL. */
+int qbh_lanczos(const qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_t *m,
+                qbh_z *v_host, double *hessenberg, const char *purpose, qbh_solver_info *info);
+int qbh_lanczos_dev(const qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_t *m,
+                    qbh_z *d_v, double *hessenberg, const char *purpose, qbh_solver_info *info);
+
+/* Replaces eigenvec_CG<T,MAT> (src/lanczos.cc:281-341): CG on (H-E0)v = 0 with the
+ * reference's restart/renormalise branch and the (machine_prec - E0) shift.  *m is in/out
+ * (steps done), *accu out. */
+int qbh_eigenvec_cg(const qbh_csr *A, int64_t maxit, int64_t *m, double E0, double *accu,
+                    qbh_z *v_host, qbh_z *r_host, qbh_z *p_host, qbh_z *pp_host,
+                    qbh_solver_info *info);
+int qbh_eigenvec_cg_dev(const qbh_csr *A, int64_t maxit, int64_t *m, double E0, double *accu,
+                        qbh_z *d_v, qbh_z *d_r, qbh_z *d_p, qbh_z *d_pp, qbh_solver_info *info);
+
+/* Replaces hess_eigen (src/lanczos.cc:355-390), host only: eigen-decomposition of the
+ * m x m tridiagonal held in hessenberg (ld = maxit), sorted by order ("sr","lr","sm","lm");
+ * ritz[m], s[m*m] column-major. */
+int qbh_hess_eigen(const double *hessenberg, int64_t maxit, int64_t m, const char *order,
+                   double *ritz, double *s);
+
+/* ------------------------------------------------------- communicator ---- */
+/* Row sharding over P ranks, one process per GPU.  Rank r owns global rows
+ * [r*nblk, min((r+1)*nblk, ncols)).  The host side (torch.distributed over RCCL in this
+ * repo) owns the buffers and implements the two exchange steps the path has:
+ *   allgather_x : d_xfull[q*nblk .. (q+1)*nblk) <- d_xsend of rank q, for all q
+ *   allreduce   : in-place sum over ranks of d_scal[off .. off+n)
+ * Both are enqueued on (or ordered with) the operator's stream and return 0 on success. */
+typedef struct qbh_comm {
+    int      rank, nranks;
+    int64_t  nblk;            /* rows per rank block; d_xfull holds nranks*nblk elements    */
+    qbh_z   *d_xsend;         /* [nblk]  device, owned by the host side                     */
+    qbh_z   *d_xfull;         /* [nranks*nblk] device                                       */
+    double  *d_scal;          /* [>= 16] device doubles                                     */
+    void    *ctx;
+    int    (*allgather_x)(void *ctx);
+    int    (*allreduce_sum)(void *ctx, int off, int n);
+} qbh_comm;
+int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm);
+
+/* ------------------------------------------------------------ stats ------ */
+typedef struct qbh_stats {
+    int64_t n_spmv;           /* SpMV launches since the last reset                       */
+    double  ms_spmv;          /* sum of HIP-event kernel times (opts.profile != 0)        */
+    double  ms_spmv_min;      /* fastest single launch                                    */
+    int64_t n_gather;
+    double  ms_gather;        /* time spent in allgather_x (event-timed)                  */
+} qbh_stats;
+int qbh_get_stats(const qbh_csr *A, qbh_stats *s, int reset);
+
+/* ------------------------------------------------ synthetic operators ---- */
+/* Measurement harness: device-side assembly of the benchmark Hamiltonians directly into
+ * HBM (the reference's host pipeline, src/model.cc:619-685, cannot reach dim >= 1e8).
+ * Fermi-Hubbard, H = -t sum_<ij>,s (c+_is c_js + h.c.) + U sum_i n_iup n_idn, on n_sites
+ * sites with the given bond list (pairs, with multiplicity), N_up/N_dn fixed.
+ * Basis index = rank(up config) * C(n_sites, n_dn) + rank(dn config) (colexicographic
+ * ranks); fermion order: all up operators, then all down operators.  Builds FULL storage
+ * for global rows [row_begin, row_end), columns ascending. */
+int qbh_gen_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_bonds,
+                    const int32_t *bonds /* [2*n_bonds] */, double t, double U,
+                    int64_t row_begin, int64_t row_end, const qbh_opts *opts);
+/* Spin-1/2 Heisenberg, H = J sum_<ij> S_i.S_j, fixed number of down spins; basis index =
+ * colexicographic rank of the down-spin bit pattern. */
+int qbh_gen_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bonds,
+                       const int32_t *bonds, double J,
+                       int64_t row_begin, int64_t row_end, const qbh_opts *opts);
+/* Copy the assembled shard back to host arrays (tests, CPU-baseline sample).  Any output
+ * pointer may be NULL.  Rows [r0, r1) local to the shard; ia is rebased to 0. */
+int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1,
+                     int64_t *ia /* [r1-r0+1] */, int32_t *ja, qbh_z *val);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QBHIP_H */

@@ -1,0 +1,9 @@
+"""quantum_basis_amd -- MI355X-native engine for the sparse Hamiltonian x vector hot path of
+wztzjhn/quantum_basis (CSR SpMV inside Lanczos / CG / ARPACK-IRAM).
+
+The product is libqbhip.so (HIP, gfx950) behind the C ABI of include/qbhip.h; this package is
+the host-side mirror of the reference's operator/solver interface plus the ctypes loader.
+"""
+from . import _lib  # noqa: F401
+from .engine import (csr_mat, DeviceVec, lanczos, eigenvec_CG, hess_eigen, iram, vec_randomize,  # noqa: F401
+                     locate_E0_lanczos, locate_E0_iram, make_opts, lanczos_precision, sparse_precision)

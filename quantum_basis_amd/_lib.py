@@ -1,0 +1,158 @@
+"""ctypes binding of libqbhip.so (the C ABI declared in include/qbhip.h).
+
+The library is the product; this module only loads it and declares signatures.
+There is no CPU fallback: if the shared object is missing, or no HIP device is
+visible, every compute entry point raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libqbhip.so")
+
+QBH_OK = 0
+KERNEL_AUTO, KERNEL_STREAM, KERNEL_VECTOR = 0, 1, 2
+
+
+class QbhError(RuntimeError):
+    def __init__(self, code, where, detail):
+        self.code = code
+        super().__init__("%s failed: %s (%d)%s" % (where, _strerror(code), code,
+                                                   (": " + detail) if detail else ""))
+
+
+class Z(C.Structure):
+    """qbh_z: one complex128 passed by value."""
+    _fields_ = [("re", C.c_double), ("im", C.c_double)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("spmv_kernel", C.c_int),
+                ("nnz_per_block", C.c_int), ("xcd_swizzle", C.c_int), ("value_dict", C.c_int),
+                ("profile", C.c_int), ("check_hermitian", C.c_int)]
+
+
+class CsrInfo(C.Structure):
+    _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int64), ("row_offset", C.c_int64),
+                ("nnz", C.c_int64), ("n_blocks", C.c_int64), ("bytes_matrix", C.c_int64),
+                ("bytes_algorithmic", C.c_int64), ("kernel", C.c_int), ("value_dict", C.c_int),
+                ("device", C.c_int), ("stream", C.c_void_p)]
+
+
+class LanczosRow(C.Structure):
+    _fields_ = [("k", C.c_int64), ("ritz", C.c_double * 4), ("a_km1", C.c_double),
+                ("b_k", C.c_double), ("accuracy", C.c_double), ("accu_E0", C.c_double),
+                ("accu_E1", C.c_double)]
+
+
+class SolverInfo(C.Structure):
+    _fields_ = [("log", C.POINTER(LanczosRow)), ("log_cap", C.c_int64), ("log_len", C.c_int64),
+                ("n_matvec", C.c_int64), ("n_reorth", C.c_int64), ("ms_total", C.c_double),
+                ("ms_spmv", C.c_double), ("cg_resid", C.POINTER(C.c_double))]
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
+
+
+class Comm(C.Structure):
+    _fields_ = [("rank", C.c_int), ("nranks", C.c_int), ("nblk", C.c_int64),
+                ("d_xsend", C.c_void_p), ("d_xfull", C.c_void_p), ("d_scal", C.c_void_p),
+                ("ctx", C.c_void_p), ("allgather_x", ALLGATHER_FN), ("allreduce_sum", ALLREDUCE_FN)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_spmv", C.c_int64), ("ms_spmv", C.c_double), ("ms_spmv_min", C.c_double),
+                ("n_gather", C.c_int64), ("ms_gather", C.c_double)]
+
+
+# every symbol include/qbhip.h declares (tests check that the .so exports all of them)
+EXPORTS = [
+    "qbh_version", "qbh_device_count", "qbh_strerror", "qbh_last_error", "qbh_opts_default",
+    "qbh_csr_create", "qbh_csr_create_device", "qbh_csr_destroy", "qbh_csr_get_info",
+    "qbh_multmv", "qbh_multmv2",
+    "qbh_vec_alloc", "qbh_vec_free", "qbh_vec_upload", "qbh_vec_download", "qbh_vec_zero",
+    "qbh_vec_randomize",
+    "qbh_spmv_dev", "qbh_dotc_dev", "qbh_axpy_norm_dev", "qbh_scal_dev", "qbh_nrm2_dev",
+    "qbh_lanczos", "qbh_lanczos_dev", "qbh_eigenvec_cg", "qbh_eigenvec_cg_dev", "qbh_hess_eigen",
+    "qbh_csr_set_comm", "qbh_get_stats",
+    "qbh_gen_hubbard", "qbh_gen_heisenberg", "qbh_csr_download",
+]
+
+_lib = None
+
+
+def _strerror(code):
+    try:
+        return lib().qbh_strerror(code).decode()
+    except Exception:
+        return "error"
+
+
+def lib():
+    """Load libqbhip.so; raise loudly if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError("libqbhip.so not found at %s -- build it with "
+                          "`python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)" % SO_PATH)
+    # torch bundles its own libamdhip64.so.7; import it first so both share one HIP runtime
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(SO_PATH, mode=C.RTLD_GLOBAL)
+    L.qbh_strerror.restype = C.c_char_p
+    L.qbh_last_error.restype = C.c_char_p
+    L.qbh_csr_destroy.restype = None
+    L.qbh_opts_default.restype = None
+    vp, i64, dbl = C.c_void_p, C.c_int64, C.c_double
+    L.qbh_csr_create.argtypes = [C.POINTER(vp), i64, i64, C.c_int, vp, vp, vp, C.POINTER(Opts)]
+    L.qbh_csr_create_device.argtypes = [C.POINTER(vp), i64, i64, i64, i64, vp, vp, vp, C.c_int,
+                                        C.POINTER(Opts)]
+    L.qbh_csr_destroy.argtypes = [vp]
+    L.qbh_csr_get_info.argtypes = [vp, C.POINTER(CsrInfo)]
+    L.qbh_multmv.argtypes = [vp, vp, vp]
+    L.qbh_multmv2.argtypes = [vp, vp, vp]
+    L.qbh_vec_alloc.argtypes = [C.POINTER(vp), i64]
+    L.qbh_vec_free.argtypes = [vp]
+    L.qbh_vec_upload.argtypes = [vp, vp, vp, i64]
+    L.qbh_vec_download.argtypes = [vp, vp, vp, i64]
+    L.qbh_vec_zero.argtypes = [vp, vp, i64]
+    L.qbh_vec_randomize.argtypes = [vp, vp, C.c_uint32]
+    L.qbh_spmv_dev.argtypes = [vp, vp, vp, dbl, dbl, dbl, vp]
+    L.qbh_dotc_dev.argtypes = [vp, vp, vp, vp]
+    L.qbh_axpy_norm_dev.argtypes = [vp, Z, vp, vp, vp]
+    L.qbh_scal_dev.argtypes = [vp, dbl, vp]
+    L.qbh_nrm2_dev.argtypes = [vp, vp, vp]
+    L.qbh_lanczos.argtypes = [vp, i64, i64, i64, C.POINTER(i64), vp, vp, C.c_char_p,
+                              C.POINTER(SolverInfo)]
+    L.qbh_lanczos_dev.argtypes = L.qbh_lanczos.argtypes
+    L.qbh_eigenvec_cg.argtypes = [vp, i64, C.POINTER(i64), dbl, C.POINTER(dbl), vp, vp, vp, vp,
+                                  C.POINTER(SolverInfo)]
+    L.qbh_eigenvec_cg_dev.argtypes = L.qbh_eigenvec_cg.argtypes
+    L.qbh_hess_eigen.argtypes = [vp, i64, i64, C.c_char_p, vp, vp]
+    L.qbh_csr_set_comm.argtypes = [vp, C.POINTER(Comm)]
+    L.qbh_get_stats.argtypes = [vp, C.POINTER(Stats), C.c_int]
+    L.qbh_gen_hubbard.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, vp, dbl, dbl,
+                                  i64, i64, C.POINTER(Opts)]
+    L.qbh_gen_heisenberg.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp, dbl, i64, i64,
+                                     C.POINTER(Opts)]
+    L.qbh_csr_download.argtypes = [vp, i64, i64, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc, where):
+    if rc != QBH_OK:
+        raise QbhError(rc, where, lib().qbh_last_error().decode())
+
+
+def require_gpu():
+    """Fail loudly when the HIP path cannot run (no silent CPU route exists)."""
+    n = lib().qbh_device_count()
+    if n <= 0:
+        raise QbhError(-2, "qbh_device_count", "no MI355X / HIP device visible")
+    return n

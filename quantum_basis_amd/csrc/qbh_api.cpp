@@ -1,0 +1,1004 @@
+// qbh_api.cpp -- the extern "C" surface of libqbhip.so: operator lifetime, the host-vector
+// seam (MultMv / MultMv2), device building blocks, and the device-resident Lanczos and CG
+// drivers.  Each entry point names the reference function it replaces in include/qbhip.h.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <vector>
+
+#include "qbh_internal.hpp"
+
+using qbh::d2;
+
+// ------------------------------------------------------------------ errors -----
+namespace qbh {
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace qbh
+
+extern "C" const char *qbh_last_error(void) { return qbh::g_err; }
+
+extern "C" const char *qbh_strerror(int code)
+{
+    switch (code) {
+    case QBH_OK:        return "success";
+    case QBH_EINVAL:    return "invalid argument";
+    case QBH_ENODEVICE: return "no HIP device available (libqbhip has no CPU fallback)";
+    case QBH_EHIP:      return "HIP runtime call failed";
+    case QBH_ENOMEM:    return "out of memory";
+    case QBH_ENOTHERM:  return "matrix is not Hermitian";
+    case QBH_ECOMM:     return "communicator hook failed";
+    case QBH_ENOTNORM:  return "Lanczos start vector is not normalised";
+    case QBH_ENOCONV:   return "tridiagonal eigen-solver did not converge";
+    case QBH_EUNSUPP:   return "not supported";
+    default:            return "unknown error";
+    }
+}
+
+extern "C" int qbh_version(void) { return QBH_VERSION; }
+
+extern "C" int qbh_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+extern "C" void qbh_opts_default(qbh_opts *o)
+{
+    if (!o) return;
+    o->device = -1;
+    o->stream = nullptr;
+    o->spmv_kernel = QBH_KERNEL_AUTO;
+    o->nnz_per_block = 0;
+    o->xcd_swizzle = 1;
+    o->value_dict = 0;
+    o->profile = 0;
+    o->check_hermitian = 1;
+}
+
+// ------------------------------------------------------------ operator ---------
+namespace {
+
+double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+int require_device(const qbh_opts *opts, int *dev_out)
+{
+    int n = qbh_device_count();
+    if (n <= 0) {
+        qbh::set_error("no HIP device visible; libqbhip has no CPU fallback");
+        return QBH_ENODEVICE;
+    }
+    int dev = -1;
+    if (opts && opts->device >= 0) {
+        if (opts->device >= n) {
+            qbh::set_error("device %d requested but only %d visible", opts->device, n);
+            return QBH_EINVAL;
+        }
+        dev = opts->device;
+        QBH_HIP(hipSetDevice(dev));
+    } else {
+        QBH_HIP(hipGetDevice(&dev));
+    }
+    *dev_out = dev;
+    return QBH_OK;
+}
+
+struct Bind {   // make the operator's device current for the duration of a call
+    int prev = -1;
+    bool ok = true;
+    explicit Bind(const qbh_csr *A)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != A->device) ok = (hipSetDevice(A->device) == hipSuccess);
+    }
+    ~Bind()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// geometry + workspace once the CSR arrays are in HBM
+int finalize(qbh_csr *A)
+{
+    hipStream_t s = A->stream;
+    const qbh_opts &o = A->opts;
+    QBH_HIP(hipMalloc(&A->d_scal, 16 * sizeof(double)));
+    QBH_HIP(hipHostMalloc(&A->h_scal, 16 * sizeof(double)));
+    QBH_HIP(hipEventCreate(&A->ev0));
+    QBH_HIP(hipEventCreate(&A->ev1));
+
+    // longest row -> nnz window of a row block
+    QBH_TRY(qbh::launch_max_rowlen(A->d_ia, A->nrows, (int64_t *)A->d_scal, s));
+    int64_t maxlen = 0;
+    QBH_HIP(hipMemcpyAsync(&maxlen, A->d_scal, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    QBH_HIP(hipStreamSynchronize(s));
+
+    const double avg = A->nrows > 0 ? (double)A->nnz / (double)A->nrows : 0.0;
+    A->kernel = (o.spmv_kernel == QBH_KERNEL_VECTOR) ? QBH_KERNEL_VECTOR : QBH_KERNEL_STREAM;
+    A->npb = o.nnz_per_block > 0 ? o.nnz_per_block : 2048;
+    if (A->npb != 1024 && A->npb != 2048 && A->npb != 4096) {
+        qbh::set_error("nnz_per_block must be 1024, 2048 or 4096");
+        return QBH_EINVAL;
+    }
+    if (A->kernel == QBH_KERNEL_VECTOR) {
+        A->tpr = avg <= 6 ? 4 : avg <= 12 ? 8 : avg <= 40 ? 16 : avg <= 96 ? 32 : 64;
+    } else {
+        A->tpr = avg <= 3 ? 1 : avg <= 8 ? 2 : avg <= 48 ? 4 : avg <= 128 ? 8 : 16;
+    }
+    // a block holds the rows that START inside its window, so it can exceed the window by
+    // one row; keep window + maxlen - 1 <= npb when rows are short, otherwise let the
+    // oversized-block path take the few long rows.
+    if (maxlen <= A->npb / 2) A->window = A->npb - (maxlen > 0 ? maxlen - 1 : 0);
+    else A->window = A->npb / 2;
+    A->n_blocks = std::max<int64_t>(1, (A->nnz + A->window - 1) / A->window);
+    QBH_HIP(hipMalloc(&A->d_rb, (size_t)(A->n_blocks + 1) * sizeof(int32_t)));
+    QBH_TRY(qbh::launch_build_rowblocks(A->d_ia, A->nrows, A->window, A->d_rb, A->n_blocks, s));
+    A->grid = qbh::spmv_grid(A->kernel, A->n_blocks, A->nrows, A->tpr);
+    const size_t nparts = (size_t)std::max(A->grid, qbh::kMaxRedBlocks);
+    QBH_HIP(hipMalloc(&A->d_partials, nparts * 4 * sizeof(double)));
+    QBH_HIP(hipStreamSynchronize(s));
+    A->stats = qbh_stats{};
+    A->stats.ms_spmv_min = std::numeric_limits<double>::infinity();
+    return QBH_OK;
+}
+
+int new_handle(qbh_csr **out, const qbh_opts *opts)
+{
+    int dev = 0;
+    QBH_TRY(require_device(opts, &dev));
+    qbh_csr *A = new (std::nothrow) qbh_csr();
+    if (!A) return QBH_ENOMEM;
+    if (opts) A->opts = *opts;
+    else qbh_opts_default(&A->opts);
+    A->device = dev;
+    if (A->opts.stream) {
+        A->stream = (hipStream_t)A->opts.stream;
+        A->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&A->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            qbh::set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            delete A;
+            return QBH_EHIP;
+        }
+        A->own_stream = true;
+    }
+    *out = A;
+    return QBH_OK;
+}
+
+// dictionary-code the values when there are at most 256 distinct ones (exact).
+int try_value_dict(qbh_csr *A, const std::vector<d2> *host_vals)
+{
+    if (!A->opts.value_dict || !host_vals) return QBH_OK;
+    std::vector<d2> dict;
+    std::vector<uint8_t> code(host_vals->size());
+    for (size_t i = 0; i < host_vals->size(); ++i) {
+        const d2 v = (*host_vals)[i];
+        int found = -1;
+        for (size_t k = 0; k < dict.size(); ++k) {
+            if (memcmp(&dict[k], &v, sizeof(d2)) == 0) {
+                found = (int)k;
+                break;
+            }
+        }
+        if (found < 0) {
+            if (dict.size() == 256) return QBH_OK;   // too many distinct values: stay uncoded
+            dict.push_back(v);
+            found = (int)dict.size() - 1;
+        }
+        code[i] = (uint8_t)found;
+    }
+    A->n_dict = (int)dict.size();
+    dict.resize(256, d2{0.0, 0.0});
+    QBH_HIP(hipMalloc(&A->d_code, std::max<size_t>(code.size(), 1)));
+    QBH_HIP(hipMalloc(&A->d_dict, 256 * sizeof(d2)));
+    QBH_HIP(hipMemcpy(A->d_code, code.data(), code.size(), hipMemcpyHostToDevice));
+    QBH_HIP(hipMemcpy(A->d_dict, dict.data(), 256 * sizeof(d2), hipMemcpyHostToDevice));
+    return QBH_OK;
+}
+
+}  // namespace
+
+extern "C" void qbh_csr_destroy(qbh_csr *A)
+{
+    if (!A) return;
+    Bind bind(A);
+    if (A->stream) (void)hipStreamSynchronize(A->stream);
+    if (A->own_arrays) {
+        if (A->d_ia) (void)hipFree(A->d_ia);
+        if (A->d_ja) (void)hipFree(A->d_ja);
+        if (A->d_val) (void)hipFree(A->d_val);
+    }
+    if (A->d_code) (void)hipFree(A->d_code);
+    if (A->d_dict) (void)hipFree(A->d_dict);
+    if (A->d_rb) (void)hipFree(A->d_rb);
+    if (A->d_partials) (void)hipFree(A->d_partials);
+    if (A->d_scal) (void)hipFree(A->d_scal);
+    if (A->h_scal) (void)hipHostFree(A->h_scal);
+    if (A->d_stage_x) (void)hipFree(A->d_stage_x);
+    if (A->d_stage_y) (void)hipFree(A->d_stage_y);
+    if (A->ev0) (void)hipEventDestroy(A->ev0);
+    if (A->ev1) (void)hipEventDestroy(A->ev1);
+    if (A->own_stream && A->stream) (void)hipStreamDestroy(A->stream);
+    delete A;
+}
+
+extern "C" int qbh_csr_create(qbh_csr **out, int64_t dim, int64_t nnz, int sym_upper, const int64_t *ia,
+                              const int64_t *ja, const qbh_z *val, const qbh_opts *opts)
+{
+    if (!out || !ia || !ja || !val || dim <= 0 || nnz <= 0) {
+        qbh::set_error("qbh_csr_create: null pointer or non-positive size");
+        return QBH_EINVAL;
+    }
+    if (dim >= (int64_t)std::numeric_limits<int32_t>::max()) {
+        qbh::set_error("qbh_csr_create: dim %lld does not fit the int32 column index of one GPU shard",
+                       (long long)dim);
+        return QBH_EUNSUPP;
+    }
+    if (ia[0] != 0 || ia[dim] != nnz) {
+        qbh::set_error("qbh_csr_create: ia[0] must be 0 and ia[dim] must equal nnz (zero-based CSR)");
+        return QBH_EINVAL;
+    }
+    for (int64_t r = 0; r < dim; ++r) {
+        if (ia[r + 1] < ia[r]) {
+            qbh::set_error("qbh_csr_create: ia not monotone at row %lld", (long long)r);
+            return QBH_EINVAL;
+        }
+        for (int64_t p = ia[r]; p < ia[r + 1]; ++p) {
+            if (ja[p] < 0 || ja[p] >= dim || (sym_upper && ja[p] < r)) {
+                qbh::set_error("qbh_csr_create: bad column %lld in row %lld", (long long)ja[p], (long long)r);
+                return QBH_EINVAL;
+            }
+        }
+    }
+    const d2 *hv = reinterpret_cast<const d2 *>(val);
+
+    // full (both-triangle) storage with int32 columns, built on the host.
+    std::vector<int64_t> fia((size_t)dim + 1, 0);
+    std::vector<int32_t> fja;
+    std::vector<d2> fval;
+    if (sym_upper) {
+        // Hermitian-upper -> full: mirrored entries (c, r), r < c, arrive in ascending r, so
+        // writing the lower parts first keeps every row's columns ascending.
+        std::vector<int64_t> cur((size_t)dim, 0);
+        for (int64_t r = 0; r < dim; ++r)
+            for (int64_t p = ia[r]; p < ia[r + 1]; ++p) {
+                cur[r]++;
+                if (ja[p] != r) cur[ja[p]]++;
+            }
+        for (int64_t r = 0; r < dim; ++r) fia[r + 1] = fia[r] + cur[r];
+        fja.resize((size_t)fia[dim]);
+        fval.resize((size_t)fia[dim]);
+        for (int64_t r = 0; r < dim; ++r) cur[r] = fia[r];
+        for (int64_t r = 0; r < dim; ++r)
+            for (int64_t p = ia[r]; p < ia[r + 1]; ++p) {
+                const int64_t c = ja[p];
+                if (c != r) {
+                    const int64_t q = cur[c]++;
+                    fja[q] = (int32_t)r;
+                    fval[q] = d2{hv[p].x, -hv[p].y};
+                }
+            }
+        for (int64_t r = 0; r < dim; ++r)
+            for (int64_t p = ia[r]; p < ia[r + 1]; ++p) {
+                const int64_t q = cur[r]++;
+                fja[q] = (int32_t)ja[p];
+                fval[q] = hv[p];
+            }
+    } else {
+        if (!opts || opts->check_hermitian) {
+            // src/sparse.cc:235-256: every (r,c) needs (c,r) == conj within sparse_precision
+            for (int64_t r = 0; r < dim; ++r)
+                for (int64_t p = ia[r]; p < ia[r + 1]; ++p) {
+                    const int64_t c = ja[p];
+                    if (c == r) continue;
+                    const int64_t *lo = std::lower_bound(ja + ia[c], ja + ia[c + 1], r);
+                    int64_t q = lo - ja;
+                    if (q == ia[c + 1] || ja[q] != r) {           // unsorted row: linear search
+                        for (q = ia[c]; q < ia[c + 1] && ja[q] != r; ++q) {}
+                    }
+                    if (q == ia[c + 1] || std::hypot(hv[p].x - hv[q].x, hv[p].y + hv[q].y) > QBH_SPARSE_PRECISION) {
+                        qbh::set_error("Hermitian check failed at (row, col) = (%lld, %lld)", (long long)r,
+                                       (long long)c);
+                        return QBH_ENOTHERM;
+                    }
+                }
+        }
+        fja.resize((size_t)nnz);
+        fval.resize((size_t)nnz);
+        for (int64_t r = 0; r <= dim; ++r) fia[r] = ia[r];
+        for (int64_t p = 0; p < nnz; ++p) {
+            fja[p] = (int32_t)ja[p];
+            fval[p] = hv[p];
+        }
+    }
+
+    qbh_csr *A = nullptr;
+    QBH_TRY(new_handle(&A, opts));
+    A->nrows = A->ncols = dim;
+    A->row_offset = 0;
+    A->nnz = fia[dim];
+    A->own_arrays = true;
+    int rc = QBH_OK;
+    auto fail = [&](int code) {
+        qbh_csr_destroy(A);
+        return code;
+    };
+#define QBH_HIPF(call)                                                                  \
+    do {                                                                                \
+        hipError_t _e = (call);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            qbh::set_error("%s failed: %s", #call, hipGetErrorString(_e));              \
+            return fail(_e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP);             \
+        }                                                                               \
+    } while (0)
+    QBH_HIPF(hipMalloc(&A->d_ia, (size_t)(dim + 1) * sizeof(int64_t)));
+    QBH_HIPF(hipMalloc(&A->d_ja, (size_t)A->nnz * sizeof(int32_t)));
+    QBH_HIPF(hipMemcpy(A->d_ia, fia.data(), (size_t)(dim + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    QBH_HIPF(hipMemcpy(A->d_ja, fja.data(), (size_t)A->nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+    rc = try_value_dict(A, &fval);
+    if (rc != QBH_OK) return fail(rc);
+    if (!A->d_code) {
+        QBH_HIPF(hipMalloc(&A->d_val, (size_t)A->nnz * sizeof(d2)));
+        QBH_HIPF(hipMemcpy(A->d_val, fval.data(), (size_t)A->nnz * sizeof(d2), hipMemcpyHostToDevice));
+    }
+#undef QBH_HIPF
+    rc = finalize(A);
+    if (rc != QBH_OK) return fail(rc);
+    *out = A;
+    return QBH_OK;
+}
+
+extern "C" int qbh_csr_create_device(qbh_csr **out, int64_t nrows, int64_t ncols, int64_t row_offset,
+                                     int64_t nnz, int64_t *d_ia, int32_t *d_ja, qbh_z *d_val,
+                                     int take_ownership, const qbh_opts *opts)
+{
+    if (!out || !d_ia || !d_ja || !d_val || nrows <= 0 || ncols <= 0 || nnz < 0 || row_offset < 0 ||
+        row_offset + nrows > ncols) {
+        qbh::set_error("qbh_csr_create_device: invalid argument");
+        return QBH_EINVAL;
+    }
+    if (ncols >= (int64_t)std::numeric_limits<int32_t>::max()) {
+        qbh::set_error("ncols %lld does not fit int32 columns", (long long)ncols);
+        return QBH_EUNSUPP;
+    }
+    qbh_csr *A = nullptr;
+    QBH_TRY(new_handle(&A, opts));
+    A->nrows = nrows;
+    A->ncols = ncols;
+    A->row_offset = row_offset;
+    A->nnz = nnz;
+    A->d_ia = d_ia;
+    A->d_ja = d_ja;
+    A->d_val = reinterpret_cast<d2 *>(d_val);
+    A->own_arrays = take_ownership != 0;
+    int rc = finalize(A);
+    if (rc != QBH_OK) {
+        A->own_arrays = false;   // the caller keeps the arrays on failure
+        qbh_csr_destroy(A);
+        return rc;
+    }
+    *out = A;
+    return QBH_OK;
+}
+
+extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
+{
+    if (!A || !info) return QBH_EINVAL;
+    info->nrows = A->nrows;
+    info->ncols = A->ncols;
+    info->row_offset = A->row_offset;
+    info->nnz = A->nnz;
+    info->n_blocks = A->n_blocks;
+    info->bytes_matrix = (A->nrows + 1) * 8 + A->nnz * 4 + (A->d_code ? A->nnz + 256 * 16 : A->nnz * 16) +
+                         (A->n_blocks + 1) * 4;
+    info->bytes_algorithmic = A->nnz * 20 + (A->nrows + 1) * 8 + A->nrows * 32;
+    info->kernel = A->kernel;
+    info->value_dict = A->d_code ? A->n_dict : 0;
+    info->device = A->device;
+    info->stream = (void *)A->stream;
+    return QBH_OK;
+}
+
+extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
+{
+    if (!A) return QBH_EINVAL;
+    if (!comm || comm->nranks <= 1) {
+        A->has_comm = false;
+        return QBH_OK;
+    }
+    if (!comm->d_xsend || !comm->d_xfull || !comm->d_scal || !comm->allgather_x || !comm->allreduce_sum ||
+        comm->rank < 0 || comm->rank >= comm->nranks || comm->nblk < A->nrows ||
+        comm->nblk * comm->rank != A->row_offset || comm->nblk * comm->nranks < A->ncols) {
+        qbh::set_error("qbh_csr_set_comm: inconsistent communicator (rank %d/%d nblk %lld row_offset %lld)",
+                       comm->rank, comm->nranks, (long long)comm->nblk, (long long)A->row_offset);
+        return QBH_EINVAL;
+    }
+    A->comm = *comm;
+    A->has_comm = true;
+    return QBH_OK;
+}
+
+extern "C" int qbh_get_stats(const qbh_csr *Ac, qbh_stats *s, int reset)
+{
+    qbh_csr *A = const_cast<qbh_csr *>(Ac);
+    if (!A) return QBH_EINVAL;
+    if (s) {
+        *s = A->stats;
+        if (A->stats.n_spmv == 0) s->ms_spmv_min = 0.0;
+    }
+    if (reset) {
+        A->stats = qbh_stats{};
+        A->stats.ms_spmv_min = std::numeric_limits<double>::infinity();
+    }
+    return QBH_OK;
+}
+
+// ------------------------------------------------- reductions / scalars --------
+namespace {
+
+inline double *scal_buf(qbh_csr *A) { return A->has_comm ? A->comm.d_scal : A->d_scal; }
+
+// partials[nparts*ncomp] -> host_out[ncomp], summed over ranks under a communicator.
+int finish_reduction(qbh_csr *A, int nparts, int ncomp, double *host_out)
+{
+    double *ds = scal_buf(A);
+    QBH_TRY(qbh::launch_reduce_partials(A->d_partials, nparts, ncomp, ds, A->stream));
+    if (A->has_comm) {
+        if (A->comm.allreduce_sum(A->comm.ctx, 0, ncomp) != 0) {
+            qbh::set_error("allreduce_sum hook failed");
+            return QBH_ECOMM;
+        }
+    }
+    QBH_HIP(hipMemcpyAsync(A->h_scal, ds, (size_t)ncomp * sizeof(double), hipMemcpyDeviceToHost, A->stream));
+    QBH_HIP(hipStreamSynchronize(A->stream));
+    for (int c = 0; c < ncomp; ++c) host_out[c] = A->h_scal[c];
+    return QBH_OK;
+}
+
+void harvest_events(qbh_csr *A)
+{
+    if (!A->ev_pending) return;
+    float ms = 0.f;
+    if (hipEventSynchronize(A->ev1) == hipSuccess && hipEventElapsedTime(&ms, A->ev0, A->ev1) == hipSuccess) {
+        A->stats.ms_spmv += ms;
+        if (ms < A->stats.ms_spmv_min) A->stats.ms_spmv_min = ms;
+    }
+    A->ev_pending = false;
+}
+
+// y <- alpha*H x + beta*y + gamma*x_local ; red (host, 3 doubles) optional.
+// Without a communicator x is the full-length vector (ncols) and the shard-local part is
+// x + row_offset; with one, x is shard-local and is gathered through the hooks first.
+int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double gamma, double *red)
+{
+    const d2 *xg, *xl;
+    if (A->has_comm) {
+        QBH_HIP(hipMemcpyAsync(A->comm.d_xsend, x, (size_t)A->nrows * sizeof(d2), hipMemcpyDeviceToDevice,
+                               A->stream));
+        if (A->comm.allgather_x(A->comm.ctx) != 0) {
+            qbh::set_error("allgather_x hook failed");
+            return QBH_ECOMM;
+        }
+        A->stats.n_gather++;
+        xg = reinterpret_cast<const d2 *>(A->comm.d_xfull);
+        xl = x;
+    } else {
+        xg = x;
+        xl = x + A->row_offset;
+    }
+    qbh::SpmvArgs a{};
+    a.ia = A->d_ia;
+    a.ja = A->d_ja;
+    a.val = A->d_val;
+    a.code = A->d_code;
+    a.dict = A->d_dict;
+    a.rb = A->d_rb;
+    a.n_blocks = A->n_blocks;
+    a.nrows = A->nrows;
+    a.xg = xg;
+    a.xl = xl;
+    a.y = y;
+    a.alpha = alpha;
+    a.beta = beta;
+    a.gamma = gamma;
+    a.partials = red ? A->d_partials : nullptr;
+    a.swizzle = A->opts.xcd_swizzle;
+    const bool prof = A->opts.profile != 0;
+    if (prof) {
+        harvest_events(A);
+        QBH_HIP(hipEventRecord(A->ev0, A->stream));
+    }
+    QBH_TRY(qbh::launch_spmv(a, A->kernel, A->npb, A->tpr, A->grid, A->stream));
+    if (prof) {
+        QBH_HIP(hipEventRecord(A->ev1, A->stream));
+        A->ev_pending = true;
+    }
+    A->stats.n_spmv++;
+    if (red) {
+        QBH_TRY(finish_reduction(A, A->grid, 3, red));
+        if (prof) harvest_events(A);
+    }
+    return QBH_OK;
+}
+
+int dotc_run(qbh_csr *A, const d2 *x, const d2 *y, double *res2)
+{
+    QBH_TRY(qbh::launch_dotc(x, y, A->nrows, A->d_partials, A->stream));
+    return finish_reduction(A, qbh::blas_grid(A->nrows), 2, res2);
+}
+
+int axpy_norm_run(qbh_csr *A, d2 alpha, const d2 *x, d2 *y, double *nrm2sq)
+{
+    QBH_TRY(qbh::launch_axpy_norm(alpha, x, y, A->nrows, A->d_partials, A->stream));
+    return finish_reduction(A, qbh::blas_grid(A->nrows), 1, nrm2sq);
+}
+
+int nrm2_run(qbh_csr *A, const d2 *x, double *nrm)
+{
+    double sq = 0.0;
+    QBH_TRY(qbh::launch_nrm2sq(x, A->nrows, A->d_partials, A->stream));
+    QBH_TRY(finish_reduction(A, qbh::blas_grid(A->nrows), 1, &sq));
+    *nrm = std::sqrt(sq);
+    return QBH_OK;
+}
+
+}  // namespace
+
+// -------------------------------------------------------- device vectors -------
+extern "C" int qbh_vec_alloc(qbh_z **d_out, int64_t n)
+{
+    if (!d_out || n <= 0) return QBH_EINVAL;
+    if (qbh_device_count() <= 0) {
+        qbh::set_error("no HIP device visible");
+        return QBH_ENODEVICE;
+    }
+    QBH_HIP(hipMalloc((void **)d_out, (size_t)n * sizeof(qbh_z)));
+    return QBH_OK;
+}
+
+extern "C" int qbh_vec_free(qbh_z *d)
+{
+    if (d) QBH_HIP(hipFree(d));
+    return QBH_OK;
+}
+
+extern "C" int qbh_vec_upload(const qbh_csr *A, qbh_z *d_dst, const qbh_z *h_src, int64_t n)
+{
+    if (!A || !d_dst || !h_src || n < 0) return QBH_EINVAL;
+    Bind bind(A);
+    QBH_HIP(hipMemcpyAsync(d_dst, h_src, (size_t)n * sizeof(qbh_z), hipMemcpyHostToDevice, A->stream));
+    QBH_HIP(hipStreamSynchronize(A->stream));
+    return QBH_OK;
+}
+
+extern "C" int qbh_vec_download(const qbh_csr *A, qbh_z *h_dst, const qbh_z *d_src, int64_t n)
+{
+    if (!A || !h_dst || !d_src || n < 0) return QBH_EINVAL;
+    Bind bind(A);
+    QBH_HIP(hipMemcpyAsync(h_dst, d_src, (size_t)n * sizeof(qbh_z), hipMemcpyDeviceToHost, A->stream));
+    QBH_HIP(hipStreamSynchronize(A->stream));
+    return QBH_OK;
+}
+
+extern "C" int qbh_vec_zero(const qbh_csr *A, qbh_z *d, int64_t n)
+{
+    if (!A || !d || n < 0) return QBH_EINVAL;
+    Bind bind(A);
+    QBH_HIP(hipMemsetAsync(d, 0, (size_t)n * sizeof(qbh_z), A->stream));
+    return QBH_OK;
+}
+
+extern "C" int qbh_vec_randomize(const qbh_csr *Ac, qbh_z *d_x, uint32_t seed)
+{
+    qbh_csr *A = const_cast<qbh_csr *>(Ac);
+    if (!A || !d_x) return QBH_EINVAL;
+    Bind bind(A);
+    d2 *x = reinterpret_cast<d2 *>(d_x);
+    if (seed == 0) {   // src/miscellaneous.cc:374-376
+        return qbh::launch_fill_const(x, A->nrows, std::sqrt(1.0 / (double)A->ncols), A->stream);
+    }
+    const int64_t nruns = (A->nrows + 15) / 16;
+    QBH_TRY(qbh::launch_randomize(x, A->nrows, A->has_comm ? A->row_offset : 0, seed, A->d_partials, A->stream));
+    double sq = 0.0;
+    QBH_TRY(finish_reduction(A, qbh::blas_grid(nruns), 1, &sq));
+    return qbh::launch_scal(1.0 / std::sqrt(sq), x, A->nrows, A->stream);
+}
+
+// ----------------------------------------------- device building blocks --------
+extern "C" int qbh_spmv_dev(const qbh_csr *Ac, const qbh_z *d_x, qbh_z *d_y, double alpha, double beta,
+                            double gamma, double *red)
+{
+    qbh_csr *A = const_cast<qbh_csr *>(Ac);
+    if (!A || !d_x || !d_y) return QBH_EINVAL;
+    Bind bind(A);
+    return spmv_run(A, reinterpret_cast<const d2 *>(d_x), reinterpret_cast<d2 *>(d_y), alpha, beta, gamma, red);
+}
+
+extern "C" int qbh_dotc_dev(const qbh_csr *Ac, const qbh_z *d_x, const qbh_z *d_y, double *res)
+{
+    qbh_csr *A = const_cast<qbh_csr *>(Ac);
+    if (!A || !d_x || !d_y || !res) return QBH_EINVAL;
+    Bind bind(A);
+    return dotc_run(A, reinterpret_cast<const d2 *>(d_x), reinterpret_cast<const d2 *>(d_y), res);
+}
+
+extern "C" int qbh_axpy_norm_dev(const qbh_csr *Ac, qbh_z alpha, const qbh_z *d_x, qbh_z *d_y, double *nrm2_sq)
+{
+    qbh_csr *A = const_cast<qbh_csr *>(Ac);
+    if (!A || !d_x || !d_y || !nrm2_sq) return QBH_EINVAL;
+    Bind bind(A);
+    return axpy_norm_run(A, d2{alpha.re, alpha.im}, reinterpret_cast<const d2 *>(d_x),
+                         reinterpret_cast<d2 *>(d_y), nrm2_sq);
+}
+
+extern "C" int qbh_scal_dev(const qbh_csr *Ac, double a, qbh_z *d_x)
+{
+    qbh_csr *A = const_cast<qbh_csr *>(Ac);
+    if (!A || !d_x) return QBH_EINVAL;
+    Bind bind(A);
+    return qbh::launch_scal(a, reinterpret_cast<d2 *>(d_x), A->nrows, A->stream);
+}
+
+extern "C" int qbh_nrm2_dev(const qbh_csr *Ac, const qbh_z *d_x, double *nrm)
+{
+    qbh_csr *A = const_cast<qbh_csr *>(Ac);
+    if (!A || !d_x || !nrm) return QBH_EINVAL;
+    Bind bind(A);
+    return nrm2_run(A, reinterpret_cast<const d2 *>(d_x), nrm);
+}
+
+// -------------------------------------------------- host-vector seam -----------
+namespace {
+int multmv_host(qbh_csr *A, const qbh_z *x_host, qbh_z *y_host, double beta)
+{
+    if (!A || !x_host || !y_host) return QBH_EINVAL;
+    if (A->has_comm || A->nrows != A->ncols) {
+        qbh::set_error("qbh_multmv: host-vector seam needs an unsharded operator");
+        return QBH_EUNSUPP;
+    }
+    Bind bind(A);
+    const size_t bytes = (size_t)A->nrows * sizeof(d2);
+    if (!A->d_stage_x) QBH_HIP(hipMalloc(&A->d_stage_x, bytes));
+    if (!A->d_stage_y) QBH_HIP(hipMalloc(&A->d_stage_y, bytes));
+    QBH_HIP(hipMemcpyAsync(A->d_stage_x, x_host, bytes, hipMemcpyHostToDevice, A->stream));
+    if (beta != 0.0) QBH_HIP(hipMemcpyAsync(A->d_stage_y, y_host, bytes, hipMemcpyHostToDevice, A->stream));
+    QBH_TRY(spmv_run(A, A->d_stage_x, A->d_stage_y, 1.0, beta, 0.0, nullptr));
+    QBH_HIP(hipMemcpyAsync(y_host, A->d_stage_y, bytes, hipMemcpyDeviceToHost, A->stream));
+    QBH_HIP(hipStreamSynchronize(A->stream));
+    return QBH_OK;
+}
+}  // namespace
+
+extern "C" int qbh_multmv(const qbh_csr *A, const qbh_z *x_host, qbh_z *y_host)
+{
+    return multmv_host(const_cast<qbh_csr *>(A), x_host, y_host, 0.0);
+}
+
+extern "C" int qbh_multmv2(const qbh_csr *A, const qbh_z *x_host, qbh_z *y_host)
+{
+    return multmv_host(const_cast<qbh_csr *>(A), x_host, y_host, 1.0);
+}
+
+// -------------------------------------------------------------- hess_eigen ------
+extern "C" int qbh_hess_eigen(const double *hessenberg, int64_t maxit, int64_t m, const char *order,
+                              double *ritz, double *s)
+{
+    if (!hessenberg || !order || !ritz || !s || m <= 0 || m >= maxit || strlen(order) < 2) {
+        qbh::set_error("qbh_hess_eigen: invalid argument (need 0 < m < maxit)");
+        return QBH_EINVAL;
+    }
+    std::vector<double> w((size_t)m), z((size_t)m * (size_t)m);
+    QBH_TRY(qbh::tridiag_eigen_full(m, hessenberg + maxit, hessenberg + 1, w.data(), z.data()));
+    const char o0 = (char)std::tolower((unsigned char)order[0]);
+    const char o1 = (char)std::tolower((unsigned char)order[1]);
+    if (!((o0 == 's' || o0 == 'l') && (o1 == 'r' || o1 == 'a' || o1 == 'm'))) {
+        qbh::set_error("qbh_hess_eigen: order must be sr/lr/sm/lm");
+        return QBH_EINVAL;
+    }
+    std::vector<int64_t> idx((size_t)m);
+    for (int64_t j = 0; j < m; ++j) idx[j] = j;
+    auto key = [&](int64_t j) {
+        const double v = (o1 == 'm') ? std::fabs(w[j]) : w[j];
+        return (o0 == 's') ? v : -v;
+    };
+    std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) { return key(a) < key(b); });
+    for (int64_t j = 0; j < m; ++j) {
+        ritz[j] = w[idx[j]];
+        memcpy(s + (size_t)j * m, z.data() + (size_t)idx[j] * m, (size_t)m * sizeof(double));
+    }
+    return QBH_OK;
+}
+
+// ----------------------------------------------------------------- Lanczos ------
+extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t maxit, int64_t *m_out,
+                               qbh_z *d_v, double *hess, const char *purpose, qbh_solver_info *info)
+{
+    qbh_csr *A = const_cast<qbh_csr *>(Ac);
+    if (!A || !m_out || !d_v || !hess || !purpose) return QBH_EINVAL;
+    if (!A->has_comm && A->nrows != A->ncols) {
+        qbh::set_error("qbh_lanczos: a row shard needs a communicator");
+        return QBH_EINVAL;
+    }
+    const std::string pur(purpose);
+    const bool is_val = pur.find("val") != std::string::npos;
+    const bool is_val1 = pur.find("val1") != std::string::npos;
+    const bool is_dn = pur == "dnmcs";
+    if (!(is_val || is_dn)) {
+        // "iram" and "*vec*" are dead branches in the reference (no caller): not provided
+        qbh::set_error("qbh_lanczos: purpose '%s' not supported (sr_val0, sr_val1, dnmcs)", purpose);
+        return QBH_EUNSUPP;
+    }
+    Bind bind(A);
+    const double t_start = now_ms();
+    const double prec = QBH_LANCZOS_PRECISION;
+    const int64_t n = A->nrows;
+    const int64_t mm = k + np;
+    int64_t m = k;
+    *m_out = m;
+    if (!(mm < maxit && k >= 0 && np >= 0)) {              // assert at src/lanczos.cc:147
+        qbh::set_error("qbh_lanczos: need k >= 0, np >= 0, k + np < maxit");
+        return QBH_EINVAL;
+    }
+    if (info) {
+        info->log_len = 0;
+        info->n_matvec = 0;
+        info->n_reorth = 0;
+        info->ms_total = 0.0;
+        info->ms_spmv = 0.0;
+    }
+    if (np == 0) return QBH_OK;                           // :150
+    const int64_t spmv0 = A->stats.n_spmv;
+    const double ms_spmv0 = A->stats.ms_spmv;
+
+    d2 *v = reinterpret_cast<d2 *>(d_v);
+    auto vpt = [&](int64_t j) { return v + (size_t)(j % 2) * (size_t)n; };   // :160
+    d2 *phi = v + 2 * (size_t)n;                                             // :154
+    double *a = hess + maxit, *b = hess;
+
+    double nrm = 0.0;
+    QBH_TRY(nrm2_run(A, vpt(k), &nrm));                   // assert at :166
+    if (!(std::fabs(nrm - 1.0) < prec)) {
+        qbh::set_error("qbh_lanczos: |v[k]| - 1 = %.3e", nrm - 1.0);
+        return QBH_ENOTNORM;
+    }
+
+    double red[3], sq;
+    // one three-term step into vpt(m) given x = vpt(m-1); beta = -b[m-1] (0 at bootstrap)
+    auto step = [&](int64_t mcur, double beta) -> int {
+        QBH_TRY(spmv_run(A, vpt(mcur - 1), vpt(mcur), 1.0, beta, 0.0, red));           // K3+K1+K4
+        a[mcur - 1] = red[0];
+        QBH_TRY(axpy_norm_run(A, d2{-a[mcur - 1], 0.0}, vpt(mcur - 1), vpt(mcur), &sq)); // K5+K6
+        b[mcur] = std::sqrt(sq);
+        QBH_TRY(qbh::launch_scal(1.0 / b[mcur], vpt(mcur), n, A->stream));              // K7
+        return QBH_OK;
+    };
+
+    if (k == 0) {                                          // :167-191
+        b[0] = 0.0;
+        QBH_TRY(step(1, 0.0));
+        m = ++k;
+        --np;
+    }
+
+    double theta0_prev = 0.0, theta1_prev = 0.0, accuracy = 0.0;
+    int cnt_accuE0 = 0;
+    std::vector<double> w((size_t)mm + 2), zl((size_t)mm + 2), ws((size_t)mm + 2);
+    int rc = QBH_OK;
+    do {                                                   // :193
+        m++;
+        rc = step(m, -b[m - 1]);
+        if (rc != QBH_OK) break;
+        if (std::fabs(b[m]) < prec) break;                 // :216
+
+        if (is_val1) {                                     // :218-226
+            double t[2];
+            rc = dotc_run(A, phi, vpt(m), t);
+            if (rc != QBH_OK) break;
+            if (std::hypot(t[0], t[1]) > prec) {
+                rc = axpy_norm_run(A, d2{-t[0], -t[1]}, phi, vpt(m), &sq);
+                if (rc != QBH_OK) break;
+                rc = qbh::launch_scal(1.0 / std::sqrt(sq), vpt(m), n, A->stream);
+                if (rc != QBH_OK) break;
+                if (info) info->n_reorth++;
+            }
+        }
+
+        if (is_val) {                                      // :228-247
+            rc = qbh::tridiag_eigen_lastrow(m, a, b + 1, w.data(), zl.data());
+            if (rc != QBH_OK) break;
+            int64_t imin = 0;
+            for (int64_t j = 1; j < m; ++j)
+                if (w[j] < w[imin]) imin = j;
+            const int64_t nsm = std::min<int64_t>(4, m);
+            std::copy(w.begin(), w.begin() + m, ws.begin());
+            std::partial_sort(ws.begin(), ws.begin() + nsm, ws.begin() + m);
+            const double ritz0 = ws[0], ritz1 = m > 1 ? ws[1] : 0.0;
+            if (m > 3) {
+                accuracy = std::fabs(b[m] * zl[imin]);
+                const double accu_E0 = std::fabs((ritz0 - theta0_prev) / ritz0);
+                const double accu_E1 = std::fabs((ritz1 - theta1_prev) / ritz1);
+                if (info && info->log && info->log_len < info->log_cap) {
+                    qbh_lanczos_row &r = info->log[info->log_len];
+                    r.k = m;
+                    for (int q = 0; q < 4; ++q) r.ritz[q] = ws[q];
+                    r.a_km1 = a[m - 1];
+                    r.b_k = b[m];
+                    r.accuracy = accuracy;
+                    r.accu_E0 = accu_E0;
+                    r.accu_E1 = accu_E1;
+                }
+                if (info) info->log_len++;
+                if (accu_E0 < prec) cnt_accuE0++;
+                else cnt_accuE0 = 0;
+                if (cnt_accuE0 > 15 && accuracy < prec) break;   // :240
+            }
+            theta0_prev = ritz0;
+            theta1_prev = ritz1;
+        }
+    } while (m < mm);
+    if (rc == QBH_OK) {
+        hipError_t e = hipStreamSynchronize(A->stream);
+        if (e != hipSuccess) {
+            qbh::set_error("stream sync failed: %s", hipGetErrorString(e));
+            rc = QBH_EHIP;
+        }
+    }
+    harvest_events(A);
+    *m_out = m;
+    if (info) {
+        if (info->log && info->log_len > info->log_cap) info->log_len = info->log_cap;
+        info->n_matvec = A->stats.n_spmv - spmv0;
+        info->ms_spmv = A->stats.ms_spmv - ms_spmv0;
+        info->ms_total = now_ms() - t_start;
+    }
+    return rc;
+}
+
+extern "C" int qbh_lanczos(const qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_t *m, qbh_z *v_host,
+                           double *hessenberg, const char *purpose, qbh_solver_info *info)
+{
+    if (!A || !v_host || !purpose) return QBH_EINVAL;
+    Bind bind(A);
+    const bool val1 = std::string(purpose).find("val1") != std::string::npos;
+    const int64_t nvec = val1 ? 3 : 2;
+    const size_t bytes = (size_t)nvec * (size_t)A->nrows * sizeof(qbh_z);
+    qbh_z *d_v = nullptr;
+    QBH_HIP(hipMalloc((void **)&d_v, bytes));
+    int rc = QBH_OK;
+    hipError_t e = hipMemcpy(d_v, v_host, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = QBH_EHIP;
+    if (rc == QBH_OK) rc = qbh_lanczos_dev(A, k, np, maxit, m, d_v, hessenberg, purpose, info);
+    if (rc == QBH_OK) {
+        // on exit the last two Lanczos vectors are returned (src/qbasis.h:1056-1058); phi0 is read-only
+        e = hipMemcpy(v_host, d_v, (size_t)2 * (size_t)A->nrows * sizeof(qbh_z), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = QBH_EHIP;
+    }
+    (void)hipFree(d_v);
+    return rc;
+}
+
+// ---------------------------------------------------------------------- CG ------
+extern "C" int qbh_eigenvec_cg_dev(const qbh_csr *Ac, int64_t maxit, int64_t *m_io, double E0, double *accu_out,
+                                   qbh_z *d_v, qbh_z *d_r, qbh_z *d_p, qbh_z *d_pp, qbh_solver_info *info)
+{
+    qbh_csr *A = const_cast<qbh_csr *>(Ac);
+    if (!A || !m_io || !accu_out || !d_v || !d_r || !d_p || !d_pp) return QBH_EINVAL;
+    if (!A->has_comm && A->nrows != A->ncols) return QBH_EINVAL;
+    Bind bind(A);
+    const double t_start = now_ms();
+    const double prec = QBH_LANCZOS_PRECISION;
+    const double machine_prec = std::numeric_limits<double>::epsilon();
+    const int64_t n = A->nrows;
+    d2 *v = reinterpret_cast<d2 *>(d_v), *r = reinterpret_cast<d2 *>(d_r);
+    d2 *p = reinterpret_cast<d2 *>(d_p), *pp = reinterpret_cast<d2 *>(d_pp);
+    int64_t m = *m_io;
+    if (!(m >= 0 && m < maxit)) {                           // assert at src/lanczos.cc:287
+        qbh::set_error("qbh_eigenvec_cg: need 0 <= m < maxit");
+        return QBH_EINVAL;
+    }
+    const int64_t spmv0 = A->stats.n_spmv;
+    const double ms_spmv0 = A->stats.ms_spmv;
+    double accu = 0.0;
+    if (m != 0) QBH_TRY(nrm2_run(A, r, &accu));            // :290
+    double red[3], sq;
+    while (m < maxit) {
+        if (accu < prec) {
+            double rnorm = 0.0;
+            QBH_TRY(nrm2_run(A, v, &rnorm));
+            if (m == 0 || std::fabs(rnorm - 1.0) > prec) {  // re-normalise and restart, :297-317
+                QBH_TRY(qbh::launch_scal(1.0 / rnorm, v, n, A->stream));
+                QBH_TRY(spmv_run(A, v, r, -1.0, 0.0, E0, red));            // r = (E0 - H) v
+                QBH_HIP(hipMemcpyAsync(p, r, (size_t)n * sizeof(d2), hipMemcpyDeviceToDevice, A->stream));
+                accu = std::sqrt(red[2]);
+                m++;
+                if (info && info->cg_resid) info->cg_resid[m] = accu;
+                if (accu < prec) break;
+            } else {
+                break;
+            }
+        } else {
+            // pp = (H - E0) p with the reference's (machine_prec - E0) shift, delta = <p,pp>  :319-323
+            QBH_TRY(spmv_run(A, p, pp, 1.0, 0.0, machine_prec - E0, red));
+            const double den = red[0] * red[0] + red[1] * red[1];
+            const d2 alpha = {accu * accu * red[0] / den, -accu * accu * red[1] / den};
+            QBH_TRY(qbh::launch_cg_update(alpha, p, pp, v, r, n, A->d_partials, A->stream));   // :324-325
+            QBH_TRY(finish_reduction(A, qbh::blas_grid(n), 1, &sq));
+            const double beta = std::sqrt(sq) / accu;                                        // :326
+            QBH_TRY(qbh::launch_xpby(r, beta * beta, p, n, A->stream));                       // :327-328
+            accu *= beta;
+            m++;
+            if (info && info->cg_resid) info->cg_resid[m] = accu;
+        }
+    }
+    QBH_HIP(hipStreamSynchronize(A->stream));
+    harvest_events(A);
+    *m_io = m;
+    *accu_out = accu;
+    if (info) {
+        info->n_matvec = A->stats.n_spmv - spmv0;
+        info->ms_spmv = A->stats.ms_spmv - ms_spmv0;
+        info->ms_total = now_ms() - t_start;
+    }
+    return QBH_OK;
+}
+
+extern "C" int qbh_eigenvec_cg(const qbh_csr *A, int64_t maxit, int64_t *m, double E0, double *accu,
+                               qbh_z *v_host, qbh_z *r_host, qbh_z *p_host, qbh_z *pp_host,
+                               qbh_solver_info *info)
+{
+    if (!A || !v_host || !r_host || !p_host || !pp_host) return QBH_EINVAL;
+    Bind bind(A);
+    const size_t n = (size_t)A->nrows, bytes = n * sizeof(qbh_z);
+    qbh_z *d = nullptr;
+    QBH_HIP(hipMalloc((void **)&d, 4 * bytes));
+    int rc = QBH_OK;
+    qbh_z *hv[4] = {v_host, r_host, p_host, pp_host};
+    for (int i = 0; i < 3 && rc == QBH_OK; ++i)      // pp is scratch on entry
+        if (hipMemcpy(d + i * n, hv[i], bytes, hipMemcpyHostToDevice) != hipSuccess) rc = QBH_EHIP;
+    if (rc == QBH_OK) rc = qbh_eigenvec_cg_dev(A, maxit, m, E0, accu, d, d + n, d + 2 * n, d + 3 * n, info);
+    for (int i = 0; i < 4 && rc == QBH_OK; ++i)
+        if (hipMemcpy(hv[i], d + i * n, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = QBH_EHIP;
+    (void)hipFree(d);
+    return rc;
+}
+
+// ------------------------------------------------------------- download ---------
+extern "C" int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1, int64_t *ia, int32_t *ja, qbh_z *val)
+{
+    if (!A || r0 < 0 || r1 < r0 || r1 > A->nrows) return QBH_EINVAL;
+    if (val && A->d_code) {
+        qbh::set_error("qbh_csr_download: values are dictionary-coded");
+        return QBH_EUNSUPP;
+    }
+    Bind bind(A);
+    QBH_HIP(hipStreamSynchronize(A->stream));
+    std::vector<int64_t> hia((size_t)(r1 - r0 + 1));
+    QBH_HIP(hipMemcpy(hia.data(), A->d_ia + r0, hia.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    const int64_t p0 = hia.front(), p1 = hia.back();
+    if (ia)
+        for (size_t i = 0; i < hia.size(); ++i) ia[i] = hia[i] - p0;
+    if (ja && p1 > p0) QBH_HIP(hipMemcpy(ja, A->d_ja + p0, (size_t)(p1 - p0) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (val && p1 > p0) QBH_HIP(hipMemcpy(val, A->d_val + p0, (size_t)(p1 - p0) * sizeof(qbh_z), hipMemcpyDeviceToHost));
+    return QBH_OK;
+}

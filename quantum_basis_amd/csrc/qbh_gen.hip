@@ -1,0 +1,551 @@
+// qbh_gen.hip -- measurement harness: assemble the benchmark Hamiltonians directly in HBM.
+//
+// The reference builds its CSR on the host (model::generate_Ham_sparse_full,
+// src/model.cc:619-685: brute-force basis enumeration, forward_list LIL, ~48 B/nnz) and
+// cannot reach dim >= 1e8.  These generators produce the same operators (same model
+// definitions as examples/trans_absent/latt_square/square_Fermi_Hubbard.cc and
+// latt_kagome/kagome_Heisenberg_spin_half.cc) in a locality-friendly basis order; spectra
+// are invariant under the basis permutation / sign gauge, and tests/ check the device CSR
+// entry-by-entry against an independent numpy assembly at small sizes.
+//
+// Conventions (documented in include/qbhip.h):
+//   Hubbard   index = rank(up) * C(L, n_dn) + rank(dn), ranks colexicographic (= ascending
+//             bit pattern); operator order: all up, then all down -> hop signs factorise.
+//   Heisenberg index = colex rank of the down-spin bit pattern.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "qbh_internal.hpp"
+
+namespace qbh {
+namespace {
+
+// ------------------------------------------------------------------ Hubbard ----
+struct HopTable {              // per configuration: sorted (target rank, amplitude) lists
+    std::vector<uint32_t> cfg;
+    std::vector<int32_t> ptr, tgt, nlo;
+    std::vector<double> val;
+};
+
+void enumerate_configs(int L, int n, std::vector<uint32_t> &cfg)
+{
+    cfg.clear();
+    if (n == 0) {
+        cfg.push_back(0u);
+        return;
+    }
+    // ascending bit patterns with n bits set among L (Gosper's hack)
+    uint64_t c = (1ULL << n) - 1ULL, lim = 1ULL << L;
+    while (c < lim) {
+        cfg.push_back((uint32_t)c);
+        const uint64_t t = c | (c - 1ULL);
+        c = (t + 1ULL) | (((~t & (t + 1ULL)) - 1ULL) >> (__builtin_ctzll(c) + 1));
+    }
+}
+
+// bonds: unique (a,b) -> weight w.  amplitude of c+_b c_a on |cfg> is -t*w*(-1)^(# set bits between)
+void build_hops(int L, int n, const std::map<std::pair<int, int>, double> &bonds, double t, HopTable &H)
+{
+    enumerate_configs(L, n, H.cfg);
+    const size_t N = H.cfg.size();
+    H.ptr.assign(N + 1, 0);
+    H.nlo.assign(N, 0);
+    H.tgt.clear();
+    H.val.clear();
+    for (size_t i = 0; i < N; ++i) {
+        const uint32_t c = H.cfg[i];
+        std::map<int32_t, double> row;
+        for (const auto &bw : bonds) {
+            const int s0 = bw.first.first, s1 = bw.first.second;
+            for (int dir = 0; dir < 2; ++dir) {
+                const int a = dir ? s1 : s0, b = dir ? s0 : s1;       // particle moves a -> b
+                if (!((c >> a) & 1u) || ((c >> b) & 1u)) continue;
+                const uint32_t nc = (c ^ (1u << a)) | (1u << b);
+                const int lo = std::min(a, b), hi = std::max(a, b);
+                const uint32_t between = (uint32_t)(((1ULL << hi) - 1ULL) & ~((1ULL << (lo + 1)) - 1ULL));
+                const double sign = (__builtin_popcount(c & between) & 1) ? -1.0 : 1.0;
+                const int32_t j = (int32_t)(std::lower_bound(H.cfg.begin(), H.cfg.end(), nc) - H.cfg.begin());
+                row[j] += -t * bw.second * sign;
+            }
+        }
+        for (const auto &e : row) {
+            if (std::fabs(e.second) < QBH_SPARSE_PRECISION) continue;    // lil_mat::add drop rule
+            H.tgt.push_back(e.first);
+            H.val.push_back(e.second);
+            if (e.first < (int32_t)i) H.nlo[i]++;
+        }
+        H.ptr[i + 1] = (int32_t)H.tgt.size();
+    }
+}
+
+struct HubDev {
+    const uint32_t *cfg_u, *cfg_d;
+    const int32_t *ptr_u, *tgt_u, *nlo_u, *ptr_d, *tgt_d, *nlo_d;
+    const double *val_u, *val_d;
+    const int64_t *base_u;   // [Nu+1] nnz before the first row of up-block u
+    const int64_t *pre_d;    // [Nd+1] dn hops before dn config d
+    int64_t Nu, Nd;
+    double U;
+};
+
+__device__ __forceinline__ int64_t hub_rowptr(const HubDev &h, int64_t row)
+{
+    if (row >= h.Nu * h.Nd) return h.base_u[h.Nu];
+    const int64_t u = row / h.Nd, d = row - u * h.Nd;
+    const int64_t nu = h.ptr_u[u + 1] - h.ptr_u[u];
+    return h.base_u[u] + d * (1 + nu) + h.pre_d[d];
+}
+
+// 32 lanes per row: lane l writes entry l, l+32, ... of the row (coalesced 20 B/entry).
+__global__ __launch_bounds__(256) void k_gen_hubbard(HubDev h, int64_t row_begin, int64_t row_end,
+                                                     int64_t *ia, int32_t *ja, d2 *val)
+{
+    const int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
+    const int sub = threadIdx.x & 31;
+    const int64_t ngrp = ((int64_t)gridDim.x * 256) >> 5;
+    const int64_t p_begin = hub_rowptr(h, row_begin);
+    for (int64_t row = row_begin + grp; row < row_end; row += ngrp) {
+        const int64_t u = row / h.Nd, d = row - u * h.Nd;
+        const int pu = h.ptr_u[u], nu = h.ptr_u[u + 1] - pu, lo_u = h.nlo_u[u];
+        const int pd = h.ptr_d[d], nd = h.ptr_d[d + 1] - pd, lo_d = h.nlo_d[d];
+        const int64_t p0 = h.base_u[u] + d * (1 + nu) + h.pre_d[d] - p_begin;
+        if (sub == 0) ia[row - row_begin] = p0;
+        const int n = 1 + nu + nd;
+        for (int l = sub; l < n; l += 32) {
+            int32_t col;
+            d2 v = {0.0, 0.0};
+            if (l < lo_u) {                                   // up hops to lower up-blocks
+                col = (int32_t)((int64_t)h.tgt_u[pu + l] * h.Nd + d);
+                v.x = h.val_u[pu + l];
+            } else if (l < lo_u + lo_d) {                     // dn hops below the diagonal
+                const int q = l - lo_u;
+                col = (int32_t)(u * h.Nd + h.tgt_d[pd + q]);
+                v.x = h.val_d[pd + q];
+            } else if (l == lo_u + lo_d) {                    // diagonal (always stored)
+                col = (int32_t)row;
+                v.x = h.U * (double)__popc(h.cfg_u[u] & h.cfg_d[d]);
+            } else if (l < lo_u + 1 + nd) {                   // dn hops above the diagonal
+                const int q = l - lo_u - 1;
+                col = (int32_t)(u * h.Nd + h.tgt_d[pd + q]);
+                v.x = h.val_d[pd + q];
+            } else {                                          // up hops to higher up-blocks
+                const int q = l - 1 - nd;
+                col = (int32_t)((int64_t)h.tgt_u[pu + q] * h.Nd + d);
+                v.x = h.val_u[pu + q];
+            }
+            ja[p0 + l] = col;
+            val[p0 + l] = v;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ia[row_end - row_begin] = hub_rowptr(h, row_end) - p_begin;
+}
+
+template <typename T>
+int upload(const std::vector<T> &h, T **d, std::vector<void *> &pool)
+{
+    const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+    QBH_HIP(hipMalloc((void **)d, bytes));
+    pool.push_back(*d);
+    if (!h.empty()) QBH_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return QBH_OK;
+}
+
+void free_pool(std::vector<void *> &pool)
+{
+    for (void *p : pool) (void)hipFree(p);
+    pool.clear();
+}
+
+int merge_bonds(int n_sites, int n_bonds, const int32_t *bonds, std::map<std::pair<int, int>, double> &out)
+{
+    for (int i = 0; i < n_bonds; ++i) {
+        int a = bonds[2 * i], b = bonds[2 * i + 1];
+        if (a < 0 || b < 0 || a >= n_sites || b >= n_sites || a == b) {
+            set_error("bond %d = (%d, %d) is invalid for %d sites", i, a, b, n_sites);
+            return QBH_EINVAL;
+        }
+        if (a > b) std::swap(a, b);
+        out[{a, b}] += 1.0;
+    }
+    return QBH_OK;
+}
+
+// ---------------------------------------------------------------- Heisenberg ---
+constexpr int kMaxBonds = 192;
+
+struct HeisDev {
+    uint64_t binom[65][34];       // C(p, k), k <= 33
+    int n_sites, n_dn, n_bonds;
+    int sa[kMaxBonds], sb[kMaxBonds];
+    double offd[kMaxBonds];       // 0.5 * J * w
+    double diag[kMaxBonds];       // 0.25 * J * w
+};
+
+__device__ __forceinline__ uint64_t heis_unrank(const HeisDev &h, uint64_t r)
+{
+    uint64_t bits = 0;
+    int p = h.n_sites - 1;
+    for (int k = h.n_dn; k >= 1; --k) {
+        while (h.binom[p][k] > r) --p;
+        bits |= 1ULL << p;
+        r -= h.binom[p][k];
+        --p;
+    }
+    return bits;
+}
+
+__device__ __forceinline__ uint64_t heis_rank(const HeisDev &h, uint64_t bits)
+{
+    uint64_t r = 0;
+    int k = 1;
+    while (bits) {
+        const int p = __ffsll((long long)bits) - 1;
+        r += h.binom[p][k];
+        bits &= bits - 1;
+        ++k;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_heis_count(const HeisDev *hp, int64_t row_begin, int64_t row_end,
+                                                    int32_t *cnt)
+{
+    const HeisDev &h = *hp;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t row = row_begin + (int64_t)blockIdx.x * 256 + threadIdx.x; row < row_end; row += stride) {
+        const uint64_t s = heis_unrank(h, (uint64_t)row);
+        int c = 1;
+        for (int bnd = 0; bnd < h.n_bonds; ++bnd) c += (int)(((s >> h.sa[bnd]) ^ (s >> h.sb[bnd])) & 1ULL);
+        cnt[row - row_begin] = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_heis_fill(const HeisDev *hp, int64_t row_begin, int64_t row_end,
+                                                   const int64_t *ia, int32_t *ja, d2 *val)
+{
+    const HeisDev &h = *hp;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t row = row_begin + (int64_t)blockIdx.x * 256 + threadIdx.x; row < row_end; row += stride) {
+        const uint64_t s = heis_unrank(h, (uint64_t)row);
+        int32_t cols[kMaxBonds + 1];
+        double vals[kMaxBonds + 1];
+        int n = 0;
+        double dg = 0.0;
+        for (int bnd = 0; bnd < h.n_bonds; ++bnd) {
+            const uint64_t ma = 1ULL << h.sa[bnd], mb = 1ULL << h.sb[bnd];
+            const bool differ = (((s >> h.sa[bnd]) ^ (s >> h.sb[bnd])) & 1ULL) != 0;
+            if (differ) {
+                dg -= h.diag[bnd];
+                const int32_t c = (int32_t)heis_rank(h, s ^ ma ^ mb);
+                int q = n++;                               // insertion sort by column
+                while (q > 0 && cols[q - 1] > c) {
+                    cols[q] = cols[q - 1];
+                    vals[q] = vals[q - 1];
+                    --q;
+                }
+                cols[q] = c;
+                vals[q] = h.offd[bnd];
+            } else {
+                dg += h.diag[bnd];
+            }
+        }
+        {
+            const int32_t c = (int32_t)row;
+            int q = n++;
+            while (q > 0 && cols[q - 1] > c) {
+                cols[q] = cols[q - 1];
+                vals[q] = vals[q - 1];
+                --q;
+            }
+            cols[q] = c;
+            vals[q] = dg;
+        }
+        const int64_t p0 = ia[row - row_begin];
+        for (int q = 0; q < n; ++q) {
+            ja[p0 + q] = cols[q];
+            val[p0 + q] = d2{vals[q], 0.0};
+        }
+    }
+}
+
+// exclusive scan int32 counts -> int64 offsets (three small kernels; one-time setup work)
+constexpr int kScanChunk = 2048;
+
+__global__ __launch_bounds__(256) void k_scan_chunksum(const int32_t *cnt, int64_t n, int64_t *chunk_sum)
+{
+    __shared__ double red_dummy;   // keep LDS layout trivial
+    (void)red_dummy;
+    __shared__ long long sm[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanChunk;
+    long long s = 0;
+    for (int i = threadIdx.x; i < kScanChunk; i += 256)
+        if (base + i < n) s += cnt[base + i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_sum[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ void k_scan_chunks_serial(int64_t *chunk_sum, int64_t nchunks)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int64_t run = 0;
+        for (int64_t i = 0; i < nchunks; ++i) {
+            const int64_t t = chunk_sum[i];
+            chunk_sum[i] = run;
+            run += t;
+        }
+        chunk_sum[nchunks] = run;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const int32_t *cnt, int64_t n, const int64_t *chunk_off,
+                                                    int64_t *ia)
+{
+    // one workgroup per chunk; thread t scans 8 consecutive elements, wave/LDS scan of the sums
+    __shared__ long long wsum[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 8;
+    long long loc[8], tot = 0;
+    for (int i = 0; i < 8; ++i) {
+        loc[i] = tot;
+        if (base + i < n) tot += cnt[base + i];
+    }
+    long long incl = tot;                                // inclusive scan across the wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    long long woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const long long excl = chunk_off[blockIdx.x] + woff + incl - tot;
+    for (int i = 0; i < 8; ++i)
+        if (base + i < n) ia[base + i] = excl + loc[i];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) ia[n] = chunk_off[gridDim.x];
+}
+
+int exclusive_scan(const int32_t *d_cnt, int64_t n, int64_t *d_ia, hipStream_t s)
+{
+    const int64_t nchunks = (n + kScanChunk - 1) / kScanChunk;
+    int64_t *d_chunk = nullptr;
+    QBH_HIP(hipMalloc(&d_chunk, (size_t)(nchunks + 1) * sizeof(int64_t)));
+    hipLaunchKernelGGL(k_scan_chunksum, dim3((unsigned)nchunks), dim3(256), 0, s, d_cnt, n, d_chunk);
+    hipLaunchKernelGGL(k_scan_chunks_serial, dim3(1), dim3(64), 0, s, d_chunk, nchunks);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nchunks), dim3(256), 0, s, d_cnt, n, d_chunk, d_ia);
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(d_chunk);
+    if (e != hipSuccess) {
+        set_error("scan failed: %s", hipGetErrorString(e));
+        return QBH_EHIP;
+    }
+    return QBH_OK;
+}
+
+uint64_t binom_u64(int n, int k)
+{
+    if (k < 0 || k > n) return 0;
+    long double r = 1.0L;
+    uint64_t v = 1;
+    k = std::min(k, n - k);
+    for (int i = 1; i <= k; ++i) {
+        v = v * (uint64_t)(n - k + i) / (uint64_t)i;      // exact: product of i consecutive ints divisible by i!
+        r = r * (n - k + i) / i;
+    }
+    (void)r;
+    return v;
+}
+
+}  // namespace
+}  // namespace qbh
+
+using qbh::d2;
+
+extern "C" int qbh_gen_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_bonds, const int32_t *bonds,
+                               double t, double U, int64_t row_begin, int64_t row_end, const qbh_opts *opts)
+{
+    using namespace qbh;
+    if (!out || !bonds || n_sites <= 0 || n_sites > 31 || n_up < 0 || n_dn < 0 || n_up > n_sites ||
+        n_dn > n_sites || n_bonds <= 0) {
+        set_error("qbh_gen_hubbard: invalid lattice / filling");
+        return QBH_EINVAL;
+    }
+    if (qbh_device_count() <= 0) {
+        set_error("no HIP device visible");
+        return QBH_ENODEVICE;
+    }
+    if (opts && opts->device >= 0) QBH_HIP(hipSetDevice(opts->device));
+    std::map<std::pair<int, int>, double> bmap;
+    QBH_TRY(merge_bonds(n_sites, n_bonds, bonds, bmap));
+    HopTable hu, hd;
+    build_hops(n_sites, n_up, bmap, t, hu);
+    build_hops(n_sites, n_dn, bmap, t, hd);
+    const int64_t Nu = (int64_t)hu.cfg.size(), Nd = (int64_t)hd.cfg.size(), dim = Nu * Nd;
+    if (dim >= 2147483647LL) {
+        set_error("qbh_gen_hubbard: dim %lld exceeds int32 columns", (long long)dim);
+        return QBH_EUNSUPP;
+    }
+    if (row_end < 0) row_end = dim;
+    if (row_begin < 0 || row_begin >= row_end || row_end > dim) {
+        set_error("qbh_gen_hubbard: bad row range");
+        return QBH_EINVAL;
+    }
+    std::vector<int64_t> pre_d((size_t)Nd + 1, 0), base_u((size_t)Nu + 1, 0);
+    for (int64_t d = 0; d < Nd; ++d) pre_d[d + 1] = pre_d[d] + (hd.ptr[d + 1] - hd.ptr[d]);
+    for (int64_t u = 0; u < Nu; ++u)
+        base_u[u + 1] = base_u[u] + Nd * (1 + (hu.ptr[u + 1] - hu.ptr[u])) + pre_d[Nd];
+
+    std::vector<void *> pool;
+    HubDev h{};
+    uint32_t *c1, *c2;
+    int32_t *i1, *i2, *i3, *i4, *i5, *i6;
+    double *v1, *v2;
+    int64_t *b1, *b2;
+    int rc = QBH_OK;
+#define UP(vec, ptr) if (rc == QBH_OK) rc = upload(vec, &ptr, pool)
+    UP(hu.cfg, c1); UP(hd.cfg, c2); UP(hu.ptr, i1); UP(hu.tgt, i2); UP(hu.nlo, i3);
+    UP(hd.ptr, i4); UP(hd.tgt, i5); UP(hd.nlo, i6); UP(hu.val, v1); UP(hd.val, v2);
+    UP(base_u, b1); UP(pre_d, b2);
+#undef UP
+    if (rc != QBH_OK) {
+        free_pool(pool);
+        return rc;
+    }
+    h.cfg_u = c1; h.cfg_d = c2; h.ptr_u = i1; h.tgt_u = i2; h.nlo_u = i3;
+    h.ptr_d = i4; h.tgt_d = i5; h.nlo_d = i6; h.val_u = v1; h.val_d = v2;
+    h.base_u = b1; h.pre_d = b2; h.Nu = Nu; h.Nd = Nd; h.U = U;
+
+    auto rowptr = [&](int64_t row) -> int64_t {
+        if (row >= dim) return base_u[Nu];
+        const int64_t u = row / Nd, d = row - u * Nd;
+        return base_u[u] + d * (1 + (hu.ptr[u + 1] - hu.ptr[u])) + pre_d[d];
+    };
+    const int64_t nrows = row_end - row_begin;
+    const int64_t nnz = rowptr(row_end) - rowptr(row_begin);
+    int64_t *d_ia = nullptr;
+    int32_t *d_ja = nullptr;
+    d2 *d_val = nullptr;
+    hipError_t e = hipMalloc(&d_ia, (size_t)(nrows + 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(&d_ja, (size_t)nnz * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_val, (size_t)nnz * sizeof(d2));
+    if (e == hipSuccess) {
+        const int64_t groups = nrows;
+        int64_t grid = (groups * 32 + 255) / 256;
+        if (grid > 256 * 64) grid = 256 * 64;
+        hipLaunchKernelGGL(k_gen_hubbard, dim3((unsigned)grid), dim3(256), 0, 0, h, row_begin, row_end, d_ia, d_ja,
+                           d_val);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    free_pool(pool);
+    if (e != hipSuccess) {
+        set_error("qbh_gen_hubbard: %s", hipGetErrorString(e));
+        if (d_ia) (void)hipFree(d_ia);
+        if (d_ja) (void)hipFree(d_ja);
+        if (d_val) (void)hipFree(d_val);
+        return e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP;
+    }
+    rc = qbh_csr_create_device(out, nrows, dim, row_begin, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1,
+                               opts);
+    if (rc != QBH_OK) {
+        (void)hipFree(d_ia);
+        (void)hipFree(d_ja);
+        (void)hipFree(d_val);
+    }
+    return rc;
+}
+
+extern "C" int qbh_gen_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bonds, const int32_t *bonds, double J,
+                                  int64_t row_begin, int64_t row_end, const qbh_opts *opts)
+{
+    using namespace qbh;
+    if (!out || !bonds || n_sites <= 0 || n_sites > 63 || n_dn < 0 || n_dn > n_sites || n_dn > 33 || n_bonds <= 0) {
+        set_error("qbh_gen_heisenberg: invalid lattice / magnetisation");
+        return QBH_EINVAL;
+    }
+    if (qbh_device_count() <= 0) {
+        set_error("no HIP device visible");
+        return QBH_ENODEVICE;
+    }
+    if (opts && opts->device >= 0) QBH_HIP(hipSetDevice(opts->device));
+    std::map<std::pair<int, int>, double> bmap;
+    QBH_TRY(merge_bonds(n_sites, n_bonds, bonds, bmap));
+    if ((int)bmap.size() > kMaxBonds) {
+        set_error("qbh_gen_heisenberg: more than %d distinct bonds", kMaxBonds);
+        return QBH_EUNSUPP;
+    }
+    std::vector<HeisDev> hh(1);
+    HeisDev &h = hh[0];
+    memset(&h, 0, sizeof(h));
+    for (int p = 0; p <= 64; ++p)
+        for (int k = 0; k <= 33; ++k) h.binom[p][k] = binom_u64(p, k);
+    h.n_sites = n_sites;
+    h.n_dn = n_dn;
+    h.n_bonds = 0;
+    for (const auto &bw : bmap) {
+        h.sa[h.n_bonds] = bw.first.first;
+        h.sb[h.n_bonds] = bw.first.second;
+        h.offd[h.n_bonds] = 0.5 * J * bw.second;
+        h.diag[h.n_bonds] = 0.25 * J * bw.second;
+        h.n_bonds++;
+    }
+    const uint64_t dim_u = binom_u64(n_sites, n_dn);
+    if (dim_u >= 2147483647ULL) {
+        set_error("qbh_gen_heisenberg: dim %llu exceeds int32 columns", (unsigned long long)dim_u);
+        return QBH_EUNSUPP;
+    }
+    const int64_t dim = (int64_t)dim_u;
+    if (row_end < 0) row_end = dim;
+    if (row_begin < 0 || row_begin >= row_end || row_end > dim) {
+        set_error("qbh_gen_heisenberg: bad row range");
+        return QBH_EINVAL;
+    }
+    const int64_t nrows = row_end - row_begin;
+    std::vector<void *> pool;
+    HeisDev *d_h = nullptr;
+    QBH_TRY(upload(hh, &d_h, pool));
+    int32_t *d_cnt = nullptr;
+    int64_t *d_ia = nullptr;
+    int32_t *d_ja = nullptr;
+    d2 *d_val = nullptr;
+    int64_t nnz = 0;
+    int rc = QBH_OK;
+    hipError_t e = hipMalloc(&d_cnt, (size_t)nrows * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_ia, (size_t)(nrows + 1) * sizeof(int64_t));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_heis_count, dim3(blas_grid(nrows)), dim3(256), 0, 0, d_h, row_begin, row_end, d_cnt);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) rc = exclusive_scan(d_cnt, nrows, d_ia, 0);
+    if (e == hipSuccess && rc == QBH_OK)
+        e = hipMemcpy(&nnz, d_ia + nrows, sizeof(int64_t), hipMemcpyDeviceToHost);
+    if (d_cnt) (void)hipFree(d_cnt);
+    if (e == hipSuccess && rc == QBH_OK) e = hipMalloc(&d_ja, (size_t)nnz * sizeof(int32_t));
+    if (e == hipSuccess && rc == QBH_OK) e = hipMalloc(&d_val, (size_t)nnz * sizeof(d2));
+    if (e == hipSuccess && rc == QBH_OK) {
+        hipLaunchKernelGGL(k_heis_fill, dim3(blas_grid(nrows)), dim3(256), 0, 0, d_h, row_begin, row_end, d_ia, d_ja,
+                           d_val);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    free_pool(pool);
+    if (e != hipSuccess || rc != QBH_OK) {
+        if (e != hipSuccess) set_error("qbh_gen_heisenberg: %s", hipGetErrorString(e));
+        if (d_ia) (void)hipFree(d_ia);
+        if (d_ja) (void)hipFree(d_ja);
+        if (d_val) (void)hipFree(d_val);
+        return rc != QBH_OK ? rc : (e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP);
+    }
+    rc = qbh_csr_create_device(out, nrows, dim, row_begin, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1,
+                               opts);
+    if (rc != QBH_OK) {
+        (void)hipFree(d_ia);
+        (void)hipFree(d_ja);
+        (void)hipFree(d_val);
+    }
+    return rc;
+}

@@ -1,0 +1,121 @@
+// qbh_internal.hpp -- private definitions shared by the translation units of libqbhip.so
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "qbhip.h"
+
+namespace qbh {
+
+typedef double d2 __attribute__((ext_vector_type(2)));   // one complex128 (re, im)
+
+constexpr int kBlock = 256;          // threads per workgroup (4 wavefronts)
+constexpr int kMaxRedBlocks = 2048;  // grid of the BLAS-1 kernels == number of partial sums
+constexpr int kRowCap = 512;         // row offsets staged in LDS per row block
+
+void set_error(const char *fmt, ...);
+
+#define QBH_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (call);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            qbh::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, \
+                           __LINE__);                                                      \
+            return (_e == hipErrorOutOfMemory) ? QBH_ENOMEM : QBH_EHIP;                    \
+        }                                                                                  \
+    } while (0)
+
+#define QBH_TRY(expr)                 \
+    do {                              \
+        int _rc = (expr);             \
+        if (_rc != QBH_OK) return _rc; \
+    } while (0)
+
+// arguments of the SpMV kernels (passed by value)
+struct SpmvArgs {
+    const int64_t *ia;     // [nrows+1] local row pointers
+    const int32_t *ja;     // [nnz] global columns
+    const d2      *val;    // [nnz] values (or nullptr when dictionary-coded)
+    const uint8_t *code;   // [nnz] dictionary codes (value_dict)
+    const d2      *dict;   // [<=256] dictionary
+    const int32_t *rb;     // [n_blocks+1] first row of each row block (stream kernel)
+    int64_t        n_blocks;
+    int64_t        nrows;
+    const d2      *xg;     // gather source (full-length x)
+    const d2      *xl;     // shard-local x (xg + row_offset without a communicator)
+    d2            *y;
+    double         alpha, beta, gamma;
+    double        *partials;   // [grid*3] or nullptr
+    int            swizzle;
+};
+
+// launchers implemented in qbh_kernels.hip (all asynchronous on `s`)
+int launch_spmv(const SpmvArgs &a, int kernel, int npb, int tpr, int grid, hipStream_t s);
+int spmv_grid(int kernel, int64_t n_blocks, int64_t nrows, int tpr);
+int launch_build_rowblocks(const int64_t *d_ia, int64_t nrows, int64_t window, int32_t *d_rb,
+                           int64_t n_blocks, hipStream_t s);
+int launch_block_stats(const int64_t *d_ia, const int32_t *d_rb, int64_t n_blocks, int64_t *d_out2,
+                       hipStream_t s);
+int launch_reduce_partials(const double *partials, int nparts, int ncomp, double *out, hipStream_t s);
+int launch_dotc(const d2 *x, const d2 *y, int64_t n, double *partials, hipStream_t s);
+int launch_axpy_norm(d2 alpha, const d2 *x, d2 *y, int64_t n, double *partials, hipStream_t s);
+int launch_nrm2sq(const d2 *x, int64_t n, double *partials, hipStream_t s);
+int launch_scal(double a, d2 *x, int64_t n, hipStream_t s);
+int launch_xpby(const d2 *x, double b, d2 *y, int64_t n, hipStream_t s);            // y = x + b*y
+int launch_cg_update(d2 alpha, const d2 *p, const d2 *pp, d2 *v, d2 *r, int64_t n, double *partials,
+                     hipStream_t s);                                               // v+=a p; r-=a pp; |r|^2
+int launch_randomize(d2 *x, int64_t n, int64_t global_offset, uint32_t seed, double *partials,
+                     hipStream_t s);
+int launch_fill_const(d2 *x, int64_t n, double re, hipStream_t s);
+int launch_max_rowlen(const int64_t *d_ia, int64_t nrows, int64_t *d_out, hipStream_t s);
+int blas_grid(int64_t n);
+
+// host tridiagonal solver (qbh_hess.cpp)
+int tridiag_eigen_full(int64_t m, const double *a, const double *b1, double *w, double *z);
+int tridiag_eigen_lastrow(int64_t m, const double *a, const double *b1, double *w, double *zlast);
+
+}  // namespace qbh
+
+struct qbh_csr {
+    int          device = 0;
+    hipStream_t  stream = nullptr;
+    bool         own_stream = false;
+    qbh_opts     opts{};
+
+    int64_t nrows = 0, ncols = 0, row_offset = 0, nnz = 0;
+    int64_t *d_ia = nullptr;
+    int32_t *d_ja = nullptr;
+    qbh::d2 *d_val = nullptr;
+    uint8_t *d_code = nullptr;
+    qbh::d2 *d_dict = nullptr;
+    int      n_dict = 0;
+    bool     own_arrays = true;
+
+    // streaming kernel geometry
+    int      kernel = QBH_KERNEL_STREAM;
+    int      npb = 2048;       // LDS product slots per workgroup
+    int      tpr = 4;          // threads cooperating on one row in the reduce phase
+    int64_t  window = 0;       // nnz window that defines a row block
+    int64_t  n_blocks = 0;
+    int32_t *d_rb = nullptr;
+    int      grid = 0;
+
+    // workspace
+    double  *d_partials = nullptr;   // [max(grid, kMaxRedBlocks) * 4]
+    double  *d_scal = nullptr;       // [16] reduction results (library-owned unless comm)
+    double  *h_scal = nullptr;       // pinned mirror
+    qbh::d2 *d_stage_x = nullptr, *d_stage_y = nullptr;   // host-vector seam staging
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // communicator
+    bool     has_comm = false;
+    qbh_comm comm{};
+
+    // stats
+    qbh_stats stats{};
+    bool      ev_pending = false;
+};

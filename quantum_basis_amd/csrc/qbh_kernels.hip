@@ -1,0 +1,597 @@
+// qbh_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the CSR x vector hot path.
+//
+// Everything here is HBM-bound complex128 / int32 work: no MFMA.  What matters is
+// (1) the val/col streams are read once, fully coalesced, non-temporal (so that the
+// gathered x keeps the L2 / Infinity Cache), (2) many independent loads in flight per lane,
+// (3) workgroup -> row-block mapping that lets each XCD's private L2 see a contiguous range
+// of rows (x-gather locality), (4) BLAS-1 work fused into the SpMV epilogue so vectors are
+// not re-read.
+//
+// Replaces mkl_sparse_z_mv (src/sparse.cc:287) and the cblas_z* level-1 calls of the
+// Lanczos / CG loops (src/lanczos.cc:195-214, 296-337).
+#include "qbh_internal.hpp"
+
+namespace qbh {
+
+// ------------------------------------------------------------------ helpers ----
+__device__ __forceinline__ d2 cmul(d2 a, d2 b)
+{
+    d2 r;
+    r.x = a.x * b.x - a.y * b.y;
+    r.y = a.x * b.y + a.y * b.x;
+    return r;
+}
+
+template <typename T>
+__device__ __forceinline__ T ntload(const T *p)
+{
+    return __builtin_nontemporal_load(p);
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// sum NC doubles per thread over the workgroup; result valid in thread 0.
+// `scratch` must hold NC*4 doubles of LDS.  Deterministic (fixed tree).
+template <int NC>
+__device__ __forceinline__ void block_sum(double (&v)[NC], double *scratch)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) v[c] = wave_sum(v[c]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) scratch[c * 4 + wave] = v[c];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            v[c] = (scratch[c * 4 + 0] + scratch[c * 4 + 1]) + (scratch[c * 4 + 2] + scratch[c * 4 + 3]);
+    }
+}
+
+// XCD-aware walk over row blocks: workgroup w runs on XCD w % 8 (observed dispatch
+// order, used for speed only).  With swizzle each XCD walks one contiguous eighth of the
+// row blocks so the x windows it gathers stay in its own 4 MiB L2.
+struct BlockWalk {
+    int64_t per_xcd, xcd, slot, nslot, nb;
+    int swz;
+    __device__ BlockWalk(int64_t n_blocks, int swizzle)
+    {
+        nb = n_blocks;
+        per_xcd = (n_blocks + 7) >> 3;
+        xcd = blockIdx.x & 7;
+        slot = blockIdx.x >> 3;
+        nslot = gridDim.x >> 3;
+        swz = swizzle;
+    }
+    __device__ int64_t block(int64_t lb) const { return swz ? xcd * per_xcd + lb : lb * 8 + xcd; }
+};
+
+// fused epilogue of one row: y <- alpha*(Hx) + beta*y + gamma*x_local, and the running
+// partial sums of <x,y> and |y|^2 (K3, K4 and the CG shift folded into K1).
+__device__ __forceinline__ void row_epilogue(const SpmvArgs &a, int64_t row, d2 sum, double (&acc)[3])
+{
+    d2 yn = a.alpha * sum;
+    if (a.beta != 0.0) yn += a.beta * a.y[row];
+    d2 xi = {0.0, 0.0};
+    if (a.gamma != 0.0 || a.partials != nullptr) xi = a.xl[row];
+    if (a.gamma != 0.0) yn += a.gamma * xi;
+    a.y[row] = yn;
+    acc[0] += xi.x * yn.x + xi.y * yn.y;
+    acc[1] += xi.x * yn.y - xi.y * yn.x;
+    acc[2] += yn.x * yn.x + yn.y * yn.y;
+}
+
+// ------------------------------------------------- streaming SpMV (default) ----
+// One workgroup per row block of <= NPB nonzeros.  Phase 1: all 256 lanes stream the
+// block's col/val ranges (perfectly coalesced, NPB/256 independent 4 B + 16 B + gathered
+// 16 B loads in flight per lane) and park val*x products in LDS.  Phase 2: TPR lanes per
+// row sum the row's LDS segment, shuffle-reduce, run the fused epilogue.
+template <int NPB, int TPR, bool DICT>
+__global__ __launch_bounds__(kBlock) void k_spmv_stream(SpmvArgs a)
+{
+    __shared__ d2 prod[NPB];
+    __shared__ int rowoff[kRowCap + 1];
+    __shared__ double red[12];
+    __shared__ d2 dict_s[DICT ? 256 : 1];
+
+    const int tid = threadIdx.x;
+    double acc[3] = {0.0, 0.0, 0.0};
+
+    if (DICT) {
+        dict_s[tid] = a.dict[tid];
+        __syncthreads();
+    }
+
+    BlockWalk walk(a.n_blocks, a.swizzle);
+    for (int64_t lb = walk.slot; lb < walk.per_xcd; lb += walk.nslot) {
+        const int64_t b = walk.block(lb);
+        if (b >= a.n_blocks) continue;
+        const int r0 = a.rb[b], r1 = a.rb[b + 1];
+        const int nr = r1 - r0;
+        if (nr == 0) continue;
+        const int64_t p0 = a.ia[r0];
+        const int64_t nlong = a.ia[r1] - p0;
+
+        if (nlong <= NPB && nr <= kRowCap) {
+            const int n = (int)nlong;
+            for (int i = tid; i <= nr; i += kBlock) rowoff[i] = (int)(a.ia[r0 + i] - p0);
+            const int32_t *jp = a.ja + p0;
+#pragma unroll
+            for (int u = 0; u < NPB / kBlock; ++u) {
+                const int i = tid + u * kBlock;
+                if (i < n) {
+                    const int c = ntload(jp + i);
+                    d2 v;
+                    if (DICT) v = dict_s[ntload(a.code + p0 + i)];
+                    else      v = ntload(a.val + p0 + i);
+                    prod[i] = cmul(v, a.xg[c]);
+                }
+            }
+            __syncthreads();
+            constexpr int G = kBlock / TPR;
+            const int g = tid / TPR, sub = tid % TPR;
+            for (int r = g; r < nr; r += G) {
+                const int e = rowoff[r + 1];
+                d2 sum = {0.0, 0.0};
+                for (int q = rowoff[r] + sub; q < e; q += TPR) sum += prod[q];
+#pragma unroll
+                for (int off = TPR / 2; off > 0; off >>= 1) {
+                    sum.x += __shfl_xor(sum.x, off, 64);
+                    sum.y += __shfl_xor(sum.y, off, 64);
+                }
+                if (sub == 0) row_epilogue(a, (int64_t)r0 + r, sum, acc);
+            }
+            __syncthreads();
+        } else {
+            // oversized block (a row longer than the LDS tile, or > kRowCap very short
+            // rows): row by row, whole workgroup per row.  Correctness path, not tuned.
+            for (int r = 0; r < nr; ++r) {
+                const int64_t s = a.ia[r0 + r], e = a.ia[r0 + r + 1];
+                double part[2] = {0.0, 0.0};
+                for (int64_t q = s + tid; q < e; q += kBlock) {
+                    d2 v;
+                    if (DICT) v = dict_s[a.code[q]];
+                    else      v = a.val[q];
+                    const d2 t = cmul(v, a.xg[a.ja[q]]);
+                    part[0] += t.x;
+                    part[1] += t.y;
+                }
+                block_sum<2>(part, red);
+                if (tid == 0) {
+                    d2 sum = {part[0], part[1]};
+                    row_epilogue(a, (int64_t)r0 + r, sum, acc);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (a.partials != nullptr) {
+        block_sum<3>(acc, red);
+        if (tid == 0) {
+            a.partials[(size_t)blockIdx.x * 3 + 0] = acc[0];
+            a.partials[(size_t)blockIdx.x * 3 + 1] = acc[1];
+            a.partials[(size_t)blockIdx.x * 3 + 2] = acc[2];
+        }
+    }
+}
+
+// ------------------------------------------- sub-wavefront-per-row SpMV --------
+// G lanes per row, shuffle reduction; no LDS staging.  Kept as the second opinion and for
+// matrices whose rows are long enough to fill a wavefront.
+template <int G, bool DICT>
+__global__ __launch_bounds__(kBlock) void k_spmv_vector(SpmvArgs a)
+{
+    __shared__ double red[12];
+    __shared__ d2 dict_s[DICT ? 256 : 1];
+    const int tid = threadIdx.x;
+    constexpr int RPB = kBlock / G;            // rows per workgroup pass
+    const int g = tid / G, sub = tid % G;
+    double acc[3] = {0.0, 0.0, 0.0};
+    if (DICT) {
+        dict_s[tid] = a.dict[tid];
+        __syncthreads();
+    }
+    const int64_t n_chunks = (a.nrows + RPB - 1) / RPB;
+    BlockWalk walk(n_chunks, a.swizzle);
+    for (int64_t lb = walk.slot; lb < walk.per_xcd; lb += walk.nslot) {
+        const int64_t b = walk.block(lb);
+        if (b >= n_chunks) continue;
+        const int64_t row = b * RPB + g;
+        if (row < a.nrows) {
+            const int64_t s = a.ia[row], e = a.ia[row + 1];
+            d2 sum = {0.0, 0.0};
+            for (int64_t q = s + sub; q < e; q += G) {
+                d2 v;
+                if (DICT) v = dict_s[ntload(a.code + q)];
+                else      v = ntload(a.val + q);
+                sum += cmul(v, a.xg[ntload(a.ja + q)]);
+            }
+#pragma unroll
+            for (int off = G / 2; off > 0; off >>= 1) {
+                sum.x += __shfl_xor(sum.x, off, 64);
+                sum.y += __shfl_xor(sum.y, off, 64);
+            }
+            if (sub == 0) row_epilogue(a, row, sum, acc);
+        }
+    }
+    if (a.partials != nullptr) {
+        block_sum<3>(acc, red);
+        if (tid == 0) {
+            a.partials[(size_t)blockIdx.x * 3 + 0] = acc[0];
+            a.partials[(size_t)blockIdx.x * 3 + 1] = acc[1];
+            a.partials[(size_t)blockIdx.x * 3 + 2] = acc[2];
+        }
+    }
+}
+
+int spmv_grid(int kernel, int64_t n_blocks, int64_t nrows, int tpr)
+{
+    // 256 CUs; the streaming kernel fits 4 workgroups per CU (LDS), the vector kernel 8.
+    int64_t units = n_blocks;
+    int64_t cap = 256 * 4 * 4;
+    if (kernel == QBH_KERNEL_VECTOR) {
+        const int rpb = kBlock / tpr;
+        units = (nrows + rpb - 1) / rpb;
+        cap = 256 * 8 * 2;
+    }
+    int64_t g = units < cap ? units : cap;
+    g = ((g + 7) / 8) * 8;
+    if (g < 8) g = 8;
+    return (int)g;
+}
+
+template <int NPB, bool DICT>
+static int launch_stream_tpr(const SpmvArgs &a, int tpr, int grid, hipStream_t s)
+{
+    switch (tpr) {
+    case 1:  hipLaunchKernelGGL((k_spmv_stream<NPB, 1, DICT>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+    case 2:  hipLaunchKernelGGL((k_spmv_stream<NPB, 2, DICT>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+    case 4:  hipLaunchKernelGGL((k_spmv_stream<NPB, 4, DICT>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+    case 8:  hipLaunchKernelGGL((k_spmv_stream<NPB, 8, DICT>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+    case 16: hipLaunchKernelGGL((k_spmv_stream<NPB, 16, DICT>), dim3(grid), dim3(kBlock), 0, s, a); break;
+    default: set_error("unsupported threads-per-row %d", tpr); return QBH_EINVAL;
+    }
+    return QBH_OK;
+}
+
+template <bool DICT>
+static int launch_spmv_t(const SpmvArgs &a, int kernel, int npb, int tpr, int grid, hipStream_t s)
+{
+    if (kernel == QBH_KERNEL_VECTOR) {
+        switch (tpr) {
+        case 4:  hipLaunchKernelGGL((k_spmv_vector<4, DICT>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 8:  hipLaunchKernelGGL((k_spmv_vector<8, DICT>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((k_spmv_vector<16, DICT>), dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 32: hipLaunchKernelGGL((k_spmv_vector<32, DICT>), dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 64: hipLaunchKernelGGL((k_spmv_vector<64, DICT>), dim3(grid), dim3(kBlock), 0, s, a); break;
+        default: set_error("unsupported lanes-per-row %d", tpr); return QBH_EINVAL;
+        }
+        return QBH_OK;
+    }
+    switch (npb) {
+    case 1024: return launch_stream_tpr<1024, DICT>(a, tpr, grid, s);
+    case 2048: return launch_stream_tpr<2048, DICT>(a, tpr, grid, s);
+    case 4096: return launch_stream_tpr<4096, DICT>(a, tpr, grid, s);
+    default: set_error("unsupported nnz_per_block %d (1024, 2048 or 4096)", npb); return QBH_EINVAL;
+    }
+}
+
+int launch_spmv(const SpmvArgs &a, int kernel, int npb, int tpr, int grid, hipStream_t s)
+{
+    int rc = (a.code != nullptr) ? launch_spmv_t<true>(a, kernel, npb, tpr, grid, s)
+                                 : launch_spmv_t<false>(a, kernel, npb, tpr, grid, s);
+    if (rc != QBH_OK) return rc;
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// ------------------------------------------------------ row-block builder ------
+// Row block w = the rows whose first nonzero falls in the nnz window
+// [w*window, (w+1)*window): rb[w] = lower_bound(ia, w*window).  Embarrassingly parallel
+// and nnz-balanced; block nnz < window + (longest row).
+__global__ void k_build_rowblocks(const int64_t *ia, int64_t nrows, int64_t window, int32_t *rb,
+                                  int64_t n_blocks)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w > n_blocks) return;
+    if (w == n_blocks) {
+        rb[w] = (int32_t)nrows;
+        return;
+    }
+    const int64_t target = w * window;
+    int64_t lo = 0, hi = nrows;          // first r in [0, nrows] with ia[r] >= target
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (ia[mid] < target) lo = mid + 1;
+        else hi = mid;
+    }
+    rb[w] = (int32_t)lo;
+}
+
+int launch_build_rowblocks(const int64_t *d_ia, int64_t nrows, int64_t window, int32_t *d_rb,
+                           int64_t n_blocks, hipStream_t s)
+{
+    const int64_t n = n_blocks + 1;
+    hipLaunchKernelGGL(k_build_rowblocks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_ia, nrows,
+                       window, d_rb, n_blocks);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+__global__ void k_block_stats(const int64_t *ia, const int32_t *rb, int64_t n_blocks,
+                              unsigned long long *out2)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_blocks) return;
+    const int r0 = rb[w], r1 = rb[w + 1];
+    const unsigned long long nn = (unsigned long long)(ia[r1] - ia[r0]);
+    atomicMax(&out2[0], nn);
+    atomicMax(&out2[1], (unsigned long long)(r1 - r0));
+}
+
+int launch_block_stats(const int64_t *d_ia, const int32_t *d_rb, int64_t n_blocks, int64_t *d_out2,
+                       hipStream_t s)
+{
+    QBH_HIP(hipMemsetAsync(d_out2, 0, 2 * sizeof(int64_t), s));
+    hipLaunchKernelGGL(k_block_stats, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, s, d_ia, d_rb,
+                       n_blocks, (unsigned long long *)d_out2);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+__global__ void k_max_rowlen(const int64_t *ia, int64_t nrows, unsigned long long *out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long mx = 0;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += stride) {
+        const unsigned long long len = (unsigned long long)(ia[r + 1] - ia[r]);
+        mx = len > mx ? len : mx;
+    }
+    if (mx) atomicMax(out, mx);
+}
+
+int launch_max_rowlen(const int64_t *d_ia, int64_t nrows, int64_t *d_out, hipStream_t s)
+{
+    QBH_HIP(hipMemsetAsync(d_out, 0, sizeof(int64_t), s));
+    hipLaunchKernelGGL(k_max_rowlen, dim3(blas_grid(nrows)), dim3(kBlock), 0, s, d_ia, nrows,
+                       (unsigned long long *)d_out);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// -------------------------------------------------------------- BLAS-1 ---------
+int blas_grid(int64_t n)
+{
+    int64_t g = (n + kBlock - 1) / kBlock;
+    if (g > kMaxRedBlocks) g = kMaxRedBlocks;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// second stage of every reduction: one workgroup sums `nparts` partials of `ncomp`
+// components in a fixed order (run-to-run reproducible, no atomics).
+__global__ __launch_bounds__(1024) void k_reduce_partials(const double *partials, int nparts, int ncomp,
+                                                          double *out)
+{
+    __shared__ double sm[16];
+    for (int c = 0; c < ncomp; ++c) {
+        double v = 0.0;
+        for (int i = threadIdx.x; i < nparts; i += 1024) v += partials[(size_t)i * ncomp + c];
+        v = wave_sum(v);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < 16; ++w) t += sm[w];
+            out[c] = t;
+        }
+    }
+}
+
+int launch_reduce_partials(const double *partials, int nparts, int ncomp, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, partials, nparts, ncomp, out);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+__global__ __launch_bounds__(kBlock) void k_dotc(const d2 *x, const d2 *y, int64_t n, double *partials)
+{
+    __shared__ double red[8];
+    double acc[2] = {0.0, 0.0};
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const d2 a = x[i], b = y[i];
+        acc[0] += a.x * b.x + a.y * b.y;
+        acc[1] += a.x * b.y - a.y * b.x;
+    }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x * 2 + 0] = acc[0];
+        partials[blockIdx.x * 2 + 1] = acc[1];
+    }
+}
+
+int launch_dotc(const d2 *x, const d2 *y, int64_t n, double *partials, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dotc, dim3(blas_grid(n)), dim3(kBlock), 0, s, x, y, n, partials);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// y += alpha*x ; partial |y|^2   (cblas_zaxpy + cblas_dznrm2 in one pass: K5+K6)
+__global__ __launch_bounds__(kBlock) void k_axpy_norm(d2 alpha, const d2 *x, d2 *y, int64_t n,
+                                                      double *partials)
+{
+    __shared__ double red[4];
+    double acc[1] = {0.0};
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        d2 v = y[i] + cmul(alpha, x[i]);
+        y[i] = v;
+        acc[0] += v.x * v.x + v.y * v.y;
+    }
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+int launch_axpy_norm(d2 alpha, const d2 *x, d2 *y, int64_t n, double *partials, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_axpy_norm, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, x, y, n, partials);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+__global__ __launch_bounds__(kBlock) void k_nrm2sq(const d2 *x, int64_t n, double *partials)
+{
+    __shared__ double red[4];
+    double acc[1] = {0.0};
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const d2 v = x[i];
+        acc[0] += v.x * v.x + v.y * v.y;
+    }
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+int launch_nrm2sq(const d2 *x, int64_t n, double *partials, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_nrm2sq, dim3(blas_grid(n)), dim3(kBlock), 0, s, x, n, partials);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scal(double a, d2 *x, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) x[i] = a * x[i];
+}
+
+int launch_scal(double a, d2 *x, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_scal, dim3(blas_grid(n)), dim3(kBlock), 0, s, a, x, n);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// y = x + b*y   (CG direction update p = r + beta^2 p, src/lanczos.cc:327-328)
+__global__ __launch_bounds__(kBlock) void k_xpby(const d2 *x, double b, d2 *y, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) y[i] = x[i] + b * y[i];
+}
+
+int launch_xpby(const d2 *x, double b, d2 *y, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_xpby, dim3(blas_grid(n)), dim3(kBlock), 0, s, x, b, y, n);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// v += alpha*p ; r -= alpha*pp ; partial |r|^2   (src/lanczos.cc:324-326 in one pass)
+__global__ __launch_bounds__(kBlock) void k_cg_update(d2 alpha, const d2 *p, const d2 *pp, d2 *v, d2 *r,
+                                                      int64_t n, double *partials)
+{
+    __shared__ double red[4];
+    double acc[1] = {0.0};
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        v[i] = v[i] + cmul(alpha, p[i]);
+        const d2 rr = r[i] - cmul(alpha, pp[i]);
+        r[i] = rr;
+        acc[0] += rr.x * rr.x + rr.y * rr.y;
+    }
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+int launch_cg_update(d2 alpha, const d2 *p, const d2 *pp, d2 *v, d2 *r, int64_t n, double *partials,
+                     hipStream_t s)
+{
+    hipLaunchKernelGGL(k_cg_update, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, p, pp, v, r, n, partials);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// ------------------------------------------------------ start vector -----------
+// vec_randomize (src/miscellaneous.cc:371-386): std::minstd_rand0 is the Lehmer
+// generator s <- 16807 s mod (2^31-1); element j takes draw j+1.  Each lane jumps ahead
+// with a modular power and then walks a short run, so the device vector is bit-identical
+// to the host one before normalisation.
+constexpr int kRandRun = 16;
+
+__device__ __forceinline__ uint64_t lehmer_pow(uint64_t e)
+{
+    const uint64_t M = 2147483647ULL;
+    uint64_t base = 16807ULL, r = 1ULL;
+    while (e) {
+        if (e & 1ULL) r = (r * base) % M;
+        base = (base * base) % M;
+        e >>= 1;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(kBlock) void k_randomize(d2 *x, int64_t n, int64_t global_offset, uint32_t seed,
+                                                      double *partials)
+{
+#pragma clang fp contract(off)
+    __shared__ double red[4];
+    const uint64_t M = 2147483647ULL;
+    double acc[1] = {0.0};
+    const int64_t nruns = (n + kRandRun - 1) / kRandRun;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    uint64_t s0 = (uint64_t)seed % M;
+    if (s0 == 0) s0 = 1;
+    for (int64_t run = (int64_t)blockIdx.x * kBlock + threadIdx.x; run < nruns; run += stride) {
+        const int64_t j0 = run * kRandRun;
+        uint64_t state = (s0 * lehmer_pow((uint64_t)(global_offset + j0))) % M;   // state before draw j0+1
+        const int64_t j1 = (j0 + kRandRun < n) ? j0 + kRandRun : n;
+        for (int64_t j = j0; j < j1; ++j) {
+            state = (state * 16807ULL) % M;
+            const double t = (double)state * (1.0 / 2147483647.0);
+            d2 v;
+            v.x = t - 0.5;
+            v.y = 0.0;
+            x[j] = v;
+            acc[0] += v.x * v.x;
+        }
+    }
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+int launch_randomize(d2 *x, int64_t n, int64_t global_offset, uint32_t seed, double *partials, hipStream_t s)
+{
+    const int64_t nruns = (n + kRandRun - 1) / kRandRun;
+    hipLaunchKernelGGL(k_randomize, dim3(blas_grid(nruns)), dim3(kBlock), 0, s, x, n, global_offset, seed,
+                       partials);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill_const(d2 *x, int64_t n, double re)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    d2 v = {re, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) x[i] = v;
+}
+
+int launch_fill_const(d2 *x, int64_t n, double re, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fill_const, dim3(blas_grid(n)), dim3(kBlock), 0, s, x, n, re);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+}  // namespace qbh

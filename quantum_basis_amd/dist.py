@@ -1,0 +1,108 @@
+"""Row sharding of the operator over ranks (one process per GPU) and the two exchange steps
+the path has, implemented with torch.distributed (backend "nccl" == RCCL over xGMI on ROCm):
+
+  * all-gather of the input vector x before every SpMV (each rank owns a contiguous row block)
+  * all-reduce(sum) of <= 3 doubles after each fused reduction (Lanczos a_m, b_m; CG dots)
+
+The reference has no distributed code (single process, OpenMP + MKL); the partition follows
+SURVEY.md section 8(e).  libqbhip.so calls back into this module through the qbh_comm hooks
+(include/qbhip.h), so the Lanczos / CG drivers are the same code for 1 and N GPUs.
+
+torch is plumbing here: device buffers, stream ordering and the collectives.
+"""
+import ctypes as C
+import traceback
+
+from . import _lib
+from ._lib import check, lib
+
+
+def row_partition(ncols, world):
+    """Uniform contiguous row blocks: rank r owns [r*nblk, min((r+1)*nblk, ncols))."""
+    nblk = (ncols + world - 1) // world
+    return nblk, [(min(r * nblk, ncols), min((r + 1) * nblk, ncols)) for r in range(world)]
+
+
+class ShardComm:
+    """Owns the exchange buffers (torch tensors in HBM) and the hook callbacks."""
+
+    def __init__(self, ncols, rank=None, world=None, device=None, stream=None, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.nblk, self.ranges = row_partition(ncols, self.world)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.stream = stream
+        f64 = torch.float64
+        # complex128 stored as interleaved float64 pairs (NCCL has no complex dtype)
+        self.xsend = torch.zeros(2 * self.nblk, dtype=f64, device=self.device)
+        self.xfull = torch.zeros(2 * self.nblk * self.world, dtype=f64, device=self.device)
+        self.scal = torch.zeros(16, dtype=f64, device=self.device)
+        backend = dist.get_backend(group)
+        self.direct = (backend == "nccl") or self.device.type == "cpu"
+        self.errors = []
+        self._ag = _lib.ALLGATHER_FN(self._allgather)
+        self._ar = _lib.ALLREDUCE_FN(self._allreduce)
+        self._struct = None
+
+    # -- hooks: called from inside libqbhip.so on the calling Python thread ------------------
+    def _ctx(self):
+        if self.stream is not None:
+            return self.torch.cuda.stream(self.stream)
+        import contextlib
+        return contextlib.nullcontext()
+
+    def _allgather(self, _ctx):
+        try:
+            with self._ctx():
+                if self.direct:
+                    self.dist.all_gather_into_tensor(self.xfull, self.xsend, group=self.group)
+                else:   # gloo with device tensors (single-GPU test rigs): stage through the host
+                    self.torch.cuda.current_stream().synchronize()
+                    send = self.xsend.cpu()
+                    parts = [self.torch.empty_like(send) for _ in range(self.world)]
+                    self.dist.all_gather(parts, send, group=self.group)
+                    self.xfull.copy_(self.torch.cat(parts))
+            return 0
+        except Exception:            # never let an exception unwind through the C frames
+            self.errors.append(traceback.format_exc())
+            return 1
+
+    def _allreduce(self, _ctx, off, n):
+        try:
+            with self._ctx():
+                view = self.scal[off:off + n]
+                if self.direct:
+                    self.dist.all_reduce(view, group=self.group)
+                else:
+                    self.torch.cuda.current_stream().synchronize()
+                    h = view.cpu()
+                    self.dist.all_reduce(h, group=self.group)
+                    view.copy_(h)
+            return 0
+        except Exception:
+            self.errors.append(traceback.format_exc())
+            return 1
+
+    # -----------------------------------------------------------------------------------------
+    def attach(self, mat):
+        """Install the hooks on a row-shard operator (qbh_csr_set_comm)."""
+        r0, r1 = self.ranges[self.rank]
+        if mat.row_offset != r0 or mat.dim != r1 - r0:
+            raise ValueError("operator rows [%d,%d) do not match rank %d's block [%d,%d)"
+                             % (mat.row_offset, mat.row_offset + mat.dim, self.rank, r0, r1))
+        c = _lib.Comm()
+        c.rank, c.nranks, c.nblk = self.rank, self.world, self.nblk
+        c.d_xsend = self.xsend.data_ptr()
+        c.d_xfull = self.xfull.data_ptr()
+        c.d_scal = self.scal.data_ptr()
+        c.ctx = None
+        c.allgather_x = self._ag
+        c.allreduce_sum = self._ar
+        self._struct = c
+        check(lib().qbh_csr_set_comm(mat.handle, C.byref(c)), "qbh_csr_set_comm")
+        mat._comm = self          # keep the callbacks and buffers alive as long as the operator
+        return self

@@ -1,0 +1,449 @@
+"""Host-side mirror of the reference's operator / solver interface for the hot path.
+
+Same names, argument meaning and error behaviour as the reference so that the
+parity tests read like the reference's own tests:
+
+    csr_mat.MultMv / MultMv2          src/sparse.cc:262-297
+    lanczos(k, np, maxit, ...)        src/lanczos.cc:134-266   (sr_val0, sr_val1, dnmcs)
+    eigenvec_CG(...)                  src/lanczos.cc:281-341
+    hess_eigen(...)                   src/lanczos.cc:355-390
+    iram(...)                         src/lanczos.cc:497-603   (ARPACK reverse communication)
+    vec_randomize(n, seed)            src/miscellaneous.cc:371-386
+    locate_E0_lanczos / locate_E0_iram  src/model.cc:1123-1366 (drivers; here free functions on a csr_mat)
+
+All numerics run in libqbhip.so on the GPU; numpy arrays are only the host
+containers the reference keeps in std::vector<T>.  Nothing here calls oracle/.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+lanczos_precision = 2e-12      # src/miscellaneous.cc:47
+sparse_precision = 1e-14       # src/miscellaneous.cc:46
+machine_prec = np.finfo(np.float64).eps
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _cvec(a, name):
+    if not (isinstance(a, np.ndarray) and a.dtype == np.complex128 and a.flags.c_contiguous):
+        raise ValueError("%s must be a C-contiguous complex128 numpy array" % name)
+    return a
+
+
+def make_opts(device=-1, stream=None, spmv_kernel=_lib.KERNEL_AUTO, nnz_per_block=0, xcd_swizzle=1,
+              value_dict=0, profile=0, check_hermitian=1):
+    o = _lib.Opts()
+    lib().qbh_opts_default(C.byref(o))
+    o.device = device
+    o.stream = stream
+    o.spmv_kernel = spmv_kernel
+    o.nnz_per_block = nnz_per_block
+    o.xcd_swizzle = xcd_swizzle
+    o.value_dict = value_dict
+    o.profile = profile
+    o.check_hermitian = check_hermitian
+    return o
+
+
+class DeviceVec:
+    """n complex128 in HBM (the callers' std::vector<T>, src/model.cc:1158-1164)."""
+
+    def __init__(self, mat, n):
+        self.mat = mat
+        self.n = int(n)
+        self.ptr = C.c_void_p()
+        check(lib().qbh_vec_alloc(C.byref(self.ptr), C.c_int64(self.n)), "qbh_vec_alloc")
+
+    def at(self, offset):
+        """Device address of element `offset` (vectors are packed back to back like v + j*dim)."""
+        return C.c_void_p(self.ptr.value + 16 * int(offset))
+
+    def upload(self, h, offset=0):
+        h = np.ascontiguousarray(h, dtype=np.complex128)
+        check(lib().qbh_vec_upload(self.mat.handle, self.at(offset), _p(h), C.c_int64(h.size)), "qbh_vec_upload")
+
+    def download(self, offset=0, n=None):
+        n = self.n - offset if n is None else n
+        h = np.empty(n, dtype=np.complex128)
+        check(lib().qbh_vec_download(self.mat.handle, _p(h), self.at(offset), C.c_int64(n)), "qbh_vec_download")
+        return h
+
+    def free(self):
+        if self.ptr:
+            lib().qbh_vec_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class csr_mat:
+    """Device-resident counterpart of csr_mat<std::complex<double>> (src/qbasis.h:976-1021).
+
+    Built from the reference's host layout: zero-based ia[dim+1], ja[nnz] (int64),
+    val[nnz] (complex128); sym=True means only the upper triangle is stored.
+    """
+
+    def __init__(self, dim, ia, ja, val, sym=True, opts=None, _handle=None):
+        _lib.require_gpu()
+        self.handle = C.c_void_p()
+        self._opts = opts if opts is not None else make_opts()
+        if _handle is not None:
+            self.handle = _handle
+            self.ia = self.ja = self.val = None
+            self.sym = False
+        else:
+            self.ia = np.ascontiguousarray(ia, dtype=np.int64)
+            self.ja = np.ascontiguousarray(ja, dtype=np.int64)
+            self.val = np.ascontiguousarray(val, dtype=np.complex128)
+            self.sym = bool(sym)
+            nnz = int(self.ia[-1]) if self.ia.size else 0
+            check(lib().qbh_csr_create(C.byref(self.handle), C.c_int64(dim), C.c_int64(nnz), int(self.sym),
+                                       _p(self.ia), _p(self.ja), _p(self.val), C.byref(self._opts)),
+                  "qbh_csr_create")
+        info = self.info()
+        self.dim = info.nrows          # shard-local length (== global dim when unsharded)
+        self.ncols = info.ncols
+        self.row_offset = info.row_offset
+        self.nnz = info.nnz
+        self._comm = None
+
+    # ---- generators (measurement harness) ------------------------------------------------
+    @classmethod
+    def hubbard(cls, n_sites, n_up, n_dn, bonds, t=1.0, U=1.1, rows=None, opts=None):
+        _lib.require_gpu()
+        opts = opts if opts is not None else make_opts()
+        b = np.ascontiguousarray(np.asarray(bonds, dtype=np.int32).reshape(-1, 2))
+        r0, r1 = (0, -1) if rows is None else rows
+        h = C.c_void_p()
+        check(lib().qbh_gen_hubbard(C.byref(h), n_sites, n_up, n_dn, len(b), _p(b), t, U, C.c_int64(r0),
+                                    C.c_int64(r1), C.byref(opts)), "qbh_gen_hubbard")
+        return cls(0, None, None, None, opts=opts, _handle=h)
+
+    @classmethod
+    def heisenberg(cls, n_sites, n_dn, bonds, J=1.0, rows=None, opts=None):
+        _lib.require_gpu()
+        opts = opts if opts is not None else make_opts()
+        b = np.ascontiguousarray(np.asarray(bonds, dtype=np.int32).reshape(-1, 2))
+        r0, r1 = (0, -1) if rows is None else rows
+        h = C.c_void_p()
+        check(lib().qbh_gen_heisenberg(C.byref(h), n_sites, n_dn, len(b), _p(b), J, C.c_int64(r0), C.c_int64(r1),
+                                       C.byref(opts)), "qbh_gen_heisenberg")
+        return cls(0, None, None, None, opts=opts, _handle=h)
+
+    # ---- reference interface -------------------------------------------------------------
+    def dimension(self):
+        return self.dim
+
+    def info(self):
+        i = _lib.CsrInfo()
+        check(lib().qbh_csr_get_info(self.handle, C.byref(i)), "qbh_csr_get_info")
+        return i
+
+    def MultMv2(self, x, y):
+        """y = H * x + y (host vectors; src/sparse.cc:262-289)."""
+        _cvec(x, "x"), _cvec(y, "y")
+        check(lib().qbh_multmv2(self.handle, _p(x), _p(y)), "qbh_multmv2")
+
+    def MultMv(self, x, y):
+        """y = H * x (host vectors; src/sparse.cc:291-297)."""
+        _cvec(x, "x"), _cvec(y, "y")
+        check(lib().qbh_multmv(self.handle, _p(x), _p(y)), "qbh_multmv")
+
+    def to_dense(self):
+        """Column-major dense copy from the host arrays (src/sparse.cc:299-315); only used for dim <= 30."""
+        if self.ia is None:
+            raise RuntimeError("to_dense needs the host CSR arrays")
+        d = np.zeros((self.dim, self.dim), dtype=np.complex128, order="F")
+        for row in range(self.dim):
+            for pt in range(self.ia[row], self.ia[row + 1]):
+                col = self.ja[pt]
+                d[row, col] = self.val[pt]
+                if self.sym and row != col:
+                    d[col, row] = np.conj(self.val[pt])
+        return d
+
+    def destroy(self):
+        if self.handle:
+            lib().qbh_csr_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    # ---- device-level helpers ------------------------------------------------------------
+    def vec(self, nvec=1):
+        return DeviceVec(self, nvec * self.dim)
+
+    def spmv(self, d_x, d_y, alpha=1.0, beta=0.0, gamma=0.0, want_red=False):
+        red = (C.c_double * 3)()
+        check(lib().qbh_spmv_dev(self.handle, d_x, d_y, alpha, beta, gamma, red if want_red else None),
+              "qbh_spmv_dev")
+        return (complex(red[0], red[1]), red[2]) if want_red else None
+
+    def dotc(self, d_x, d_y):
+        r = (C.c_double * 2)()
+        check(lib().qbh_dotc_dev(self.handle, d_x, d_y, r), "qbh_dotc_dev")
+        return complex(r[0], r[1])
+
+    def axpy_norm(self, alpha, d_x, d_y):
+        r = C.c_double()
+        a = complex(alpha)
+        check(lib().qbh_axpy_norm_dev(self.handle, _lib.Z(a.real, a.imag), d_x, d_y, C.byref(r)),
+              "qbh_axpy_norm_dev")
+        return r.value
+
+    def scal(self, a, d_x):
+        check(lib().qbh_scal_dev(self.handle, float(a), d_x), "qbh_scal_dev")
+
+    def nrm2(self, d_x):
+        r = C.c_double()
+        check(lib().qbh_nrm2_dev(self.handle, d_x, C.byref(r)), "qbh_nrm2_dev")
+        return r.value
+
+    def randomize(self, d_x, seed):
+        check(lib().qbh_vec_randomize(self.handle, d_x, C.c_uint32(seed)), "qbh_vec_randomize")
+
+    def stats(self, reset=False):
+        s = _lib.Stats()
+        check(lib().qbh_get_stats(self.handle, C.byref(s), int(reset)), "qbh_get_stats")
+        return s
+
+    def download(self, r0=0, r1=None, values=True):
+        """Copy rows [r0, r1) of the device CSR back (tests / CPU-baseline sample)."""
+        r1 = self.dim if r1 is None else r1
+        ia = np.empty(r1 - r0 + 1, dtype=np.int64)
+        check(lib().qbh_csr_download(self.handle, C.c_int64(r0), C.c_int64(r1), _p(ia), None, None),
+              "qbh_csr_download")
+        nnz = int(ia[-1])
+        ja = np.empty(nnz, dtype=np.int32)
+        val = np.empty(nnz, dtype=np.complex128) if values else None
+        check(lib().qbh_csr_download(self.handle, C.c_int64(r0), C.c_int64(r1), None, _p(ja),
+                                     _p(val) if values else None), "qbh_csr_download")
+        return ia, ja, val
+
+
+# ------------------------------------------------------------------------------------------
+def vec_randomize(mat, n=None, seed=1):
+    """Host start vector produced on the device (src/miscellaneous.cc:371-386)."""
+    dv = mat.vec()
+    mat.randomize(dv.ptr, seed)
+    out = dv.download()
+    dv.free()
+    return out
+
+
+def hess_eigen(hessenberg, maxit, m, order="sr"):
+    """src/lanczos.cc:355-390: returns (ritz[m], s[m*m] column-major)."""
+    h = np.ascontiguousarray(hessenberg, dtype=np.float64)
+    ritz = np.empty(m)
+    s = np.empty(m * m)
+    check(lib().qbh_hess_eigen(_p(h), C.c_int64(maxit), C.c_int64(m), order.encode(), _p(ritz), _p(s)),
+          "qbh_hess_eigen")
+    return ritz, s
+
+
+def _solver_info(maxit, want_log=True, want_resid=False):
+    info = _lib.SolverInfo()
+    keep = []
+    if want_log:
+        buf = (_lib.LanczosRow * int(maxit))()
+        info.log = C.cast(buf, C.POINTER(_lib.LanczosRow))
+        info.log_cap = int(maxit)
+        keep.append(buf)
+    if want_resid:
+        rl = (C.c_double * (int(maxit) + 1))()
+        info.cg_resid = C.cast(rl, C.POINTER(C.c_double))
+        keep.append(rl)
+    return info, keep
+
+
+def _rows(info):
+    return [dict(k=info.log[i].k, ritz=list(info.log[i].ritz), a=info.log[i].a_km1, b=info.log[i].b_k,
+                 accuracy=info.log[i].accuracy, accu_E0=info.log[i].accu_E0, accu_E1=info.log[i].accu_E1)
+            for i in range(info.log_len)]
+
+
+def lanczos(k, np_steps, maxit, dim, mat, v, hessenberg, purpose, device_v=None):
+    """lanczos<T,MAT> (src/lanczos.cc:134): returns m; v and hessenberg are updated in place.
+
+    v is a host array (2*dim, 3*dim for sr_val1) unless device_v (a DeviceVec) is given, in
+    which case the vectors stay in HBM (level-2 seam).  Extra outputs on lanczos.last."""
+    if dim != mat.dim:
+        raise ValueError("dim mismatch")
+    assert hessenberg.dtype == np.float64 and hessenberg.size >= 2 * maxit
+    m = C.c_int64(0)
+    info, keep = _solver_info(maxit)
+    if device_v is not None:
+        rc = lib().qbh_lanczos_dev(mat.handle, k, np_steps, maxit, C.byref(m), device_v.ptr, _p(hessenberg),
+                                   purpose.encode(), C.byref(info))
+    else:
+        _cvec(v, "v")
+        rc = lib().qbh_lanczos(mat.handle, k, np_steps, maxit, C.byref(m), _p(v), _p(hessenberg),
+                               purpose.encode(), C.byref(info))
+    check(rc, "qbh_lanczos")
+    lanczos.last = dict(log=_rows(info), n_matvec=info.n_matvec, n_reorth=info.n_reorth,
+                        ms_total=info.ms_total, ms_spmv=info.ms_spmv)
+    return m.value
+
+
+lanczos.last = {}
+
+
+def eigenvec_CG(dim, maxit, m, mat, E0, v, r, p, pp, device=False):
+    """eigenvec_CG<T,MAT> (src/lanczos.cc:281): returns (m, accu); v, r, p, pp updated in place."""
+    if dim != mat.dim:
+        raise ValueError("dim mismatch")
+    mm = C.c_int64(m)
+    accu = C.c_double(0.0)
+    info, keep = _solver_info(maxit, want_log=False, want_resid=True)
+    if device:
+        rc = lib().qbh_eigenvec_cg_dev(mat.handle, maxit, C.byref(mm), float(np.real(E0)), C.byref(accu),
+                                       v, r, p, pp, C.byref(info))
+    else:
+        for a in (v, r, p, pp):
+            _cvec(a, "vector")
+        rc = lib().qbh_eigenvec_cg(mat.handle, maxit, C.byref(mm), float(np.real(E0)), C.byref(accu),
+                                   _p(v), _p(r), _p(p), _p(pp), C.byref(info))
+    check(rc, "qbh_eigenvec_cg")
+    eigenvec_CG.last = dict(resid=[info.cg_resid[i] for i in range(1, mm.value + 1)],
+                            n_matvec=info.n_matvec, ms_total=info.ms_total)
+    return mm.value, accu.value
+
+
+eigenvec_CG.last = {}
+
+
+def iram(dim, mat, v0, nev, ncv, maxit, order="sr"):
+    """iram<T,MAT> (src/lanczos.cc:497-603): ARPACK IRAM by reverse communication, the matvec
+    being csr_mat.MultMv on the device.  Returns (nconv, eigenvals[nev], eigenvecs[nev*dim]).
+
+    The reference links ARPACK-NG 3.9.0 (znaupd/zneupd, mode 1, bmat='I', tol=0, info=0 so
+    v0 is ignored); here the same ARPACK routines are driven through scipy's bundled copy."""
+    if nev <= 0 or nev >= dim - 1:
+        raise ValueError("0 < nev < N-1 should be satisfied.")          # :502
+    if maxit < 20:
+        raise ValueError("maxit should not be smaller than 20!")        # :504
+    orderC = order.upper()
+    if orderC not in ("SR", "SA", "LR", "LA", "SM", "LM"):
+        raise ValueError("Invalid argument orderC.")
+    key = {"SR": lambda e: e, "SA": lambda e: e, "LR": lambda e: -e, "LA": lambda e: -e,
+           "SM": lambda e: np.abs(e), "LM": lambda e: -np.abs(e)}[orderC]
+    if dim <= 30:                                                        # :508-542 dense fall-back
+        w, z = np.linalg.eigh(mat.to_dense())
+        idx = np.argsort(key(w), kind="stable")[:nev]
+        return nev, w[idx].copy(), np.concatenate([z[:, j] for j in idx])
+    from scipy.sparse.linalg import LinearOperator, eigs
+
+    def matvec(x):
+        x = np.ascontiguousarray(x, dtype=np.complex128).reshape(-1)
+        y = np.empty(dim, dtype=np.complex128)
+        mat.MultMv(x, y)
+        return y
+
+    which = {"SA": "SR", "LA": "LR"}.get(orderC, orderC)
+    op = LinearOperator((dim, dim), matvec=matvec, dtype=np.complex128)
+    w, z = eigs(op, k=nev, ncv=ncv, which=which, maxiter=maxit, tol=0)
+    if np.max(np.abs(w.imag)) > lanczos_precision:                       # :487-492
+        raise RuntimeError("eigenvalue should be real.")
+    w = w.real
+    idx = np.argsort(key(w), kind="stable")
+    return len(idx), w[idx].copy(), np.concatenate([z[:, j] for j in idx])
+
+
+class E0Result:
+    """The fields model<T> exposes after locate_E0_* (src/qbasis.h: eigenvals_full, eigenvecs_full, E0, E1, gap, nconv)."""
+
+    def __init__(self):
+        self.eigenvals = []
+        self.eigenvecs = None
+        self.E0 = self.E1 = self.gap = None
+        self.nconv = 0
+        self.steps = {}
+
+
+def locate_E0_lanczos(mat, nev=1, ncv=1, maxit=1000):
+    """Work-alike of model<T>::locate_E0_lanczos (src/model.cc:1123-1316) for the CSR branch:
+    E0 (Lanczos) -> V0 (CG) -> E1 (Lanczos, re-orthogonalised against phi0) -> V1 (CG),
+    with all vectors resident in HBM for the whole call."""
+    assert 0 < nev <= 2 and nev - 1 <= ncv <= nev
+    dim = mat.dim
+    seed = 1
+    res = E0Result()
+    nv = 5 if (ncv == 2) else (4 if ncv > 0 else 2)
+    v = mat.vec(nv)
+    hess = np.zeros(2 * maxit)
+    try:
+        mat.randomize(v.at(0), seed)                                     # :1165
+        m = lanczos(0, maxit - 1, maxit, dim, mat, None, hess, "sr_val0", device_v=v)   # :1177
+        ritz, s = hess_eigen(hess, maxit, m, "sr")
+        res.eigenvals = [ritz[0]]
+        res.E0 = ritz[0]
+        res.steps["E0"] = m
+        res.steps["E0_accuracy"] = abs(hess[m] * s[m - 1])
+        res.hessenberg_E0 = hess.copy()
+        if ncv == 0:
+            return res
+        mat.randomize(v.at(2 * dim), seed)                               # :1209
+        mcg, accu = eigenvec_CG(dim, maxit, 0, mat, res.E0, v.at(2 * dim), v.at(0), v.at(dim), v.at(3 * dim),
+                                device=True)
+        if not accu < lanczos_precision:
+            raise RuntimeError("CG did not converge (accuracy %g)" % accu)   # assert at :1221
+        res.steps["V0"] = mcg
+        res.nconv = 1
+        if nev == 2:
+            mat.randomize(v.at(0), seed)                                 # :1237-1241
+            alpha = mat.dotc(v.at(2 * dim), v.at(0))
+            nrm = np.sqrt(mat.axpy_norm(-alpha, v.at(2 * dim), v.at(0)))
+            mat.scal(1.0 / nrm, v.at(0))
+            m1 = lanczos(0, maxit - 1, maxit, dim, mat, None, hess, "sr_val1", device_v=v)
+            ritz, s = hess_eigen(hess, maxit, m1, "sr")
+            res.eigenvals.append(ritz[0])
+            res.E1 = ritz[0]
+            res.gap = res.E1 - res.E0
+            res.steps["E1"] = m1
+        if ncv == 1:
+            res.eigenvecs = v.download(2 * dim, dim)                     # :1267-1273
+            return res
+        mat.randomize(v.at(3 * dim), seed + 7)                           # :1280
+        mcg1, accu1 = eigenvec_CG(dim, maxit, 0, mat, res.E1, v.at(3 * dim), v.at(0), v.at(dim), v.at(4 * dim),
+                                  device=True)
+        res.steps["V1"] = mcg1
+        res.nconv = 2
+        if res.gap < lanczos_precision:                                  # :1301-1310
+            alpha = mat.dotc(v.at(2 * dim), v.at(3 * dim))
+            nrm = np.sqrt(mat.axpy_norm(-alpha, v.at(2 * dim), v.at(3 * dim)))
+            mat.scal(1.0 / nrm, v.at(3 * dim))
+        res.eigenvecs = v.download(2 * dim, 2 * dim)
+        return res
+    finally:
+        v.free()
+
+
+def locate_E0_iram(mat, nev=2, ncv=6, maxit=0):
+    """Work-alike of model<T>::locate_E0_iram (src/model.cc:1319-1366)."""
+    assert nev > 0 and ncv > nev + 1
+    if maxit <= 0:
+        maxit = nev * 100
+    res = E0Result()
+    v0 = np.ones(mat.dim, dtype=np.complex128)
+    nconv, w, z = iram(mat.dim, mat, v0, nev, ncv, maxit, "sr")
+    res.nconv = nconv
+    res.eigenvals = list(w)
+    res.eigenvecs = z
+    res.E0 = w[0]
+    if nconv > 1:
+        res.gap = w[1] - w[0]
+    return res

@@ -1,0 +1,56 @@
+"""Bond lists of the benchmark lattices (host-side input of the measurement harness).
+
+Each function returns a list of (i, j) site pairs WITH multiplicity, exactly as the
+reference's example programs add terms in their loops; site numbering is a free choice
+(the spectrum is invariant under site relabelling).
+"""
+
+
+def chain(L, pbc=True):
+    """examples/trans_absent/latt_chain/chain_Heisenberg_spin_half.cc:44-58"""
+    return [(x, (x + 1) % L) for x in range(L if pbc else L - 1)]
+
+
+def square(Lx, Ly, pbc=True):
+    """examples/trans_absent/latt_square/square_Fermi_Hubbard.cc:47-93 (site = x + Lx*y).
+    With Ly == 2 and PBC the y-bond appears twice, as in the reference's loop."""
+    b = []
+    for x in range(Lx):
+        for y in range(Ly):
+            s = x + Lx * y
+            if pbc or x < Lx - 1:
+                b.append((s, (x + 1) % Lx + Lx * y))
+            if pbc or y < Ly - 1:
+                b.append((s, x + Lx * ((y + 1) % Ly)))
+    return b
+
+
+def triangular(Lx, Ly):
+    """examples/trans_absent/latt_triangular/triangular_Heisenberg_spin_half.cc:50-86 (PBC):
+    neighbours (m+1,n), (m+1,n+1), (m,n+1)."""
+    b = []
+    for m in range(Lx):
+        for n in range(Ly):
+            s = m + Lx * n
+            b.append((s, (m + 1) % Lx + Lx * n))
+            b.append((s, (m + 1) % Lx + Lx * ((n + 1) % Ly)))
+            b.append((s, m + Lx * ((n + 1) % Ly)))
+    return b
+
+
+def kagome(Lx, Ly):
+    """examples/trans_absent/latt_kagome/kagome_Heisenberg_spin_half.cc:69-152 (PBC):
+    per unit cell (m,n), sublattices 0,1,2: 0-2(m+1,n), 0-2, 1-0(m,n+1), 1-0, 2-1(m-1,n-1), 2-1."""
+    def site(m, n, sub):
+        return (m % Lx) + Lx * ((n % Ly) + Ly * sub)
+    b = []
+    for m in range(Lx):
+        for n in range(Ly):
+            i0, i1, i2 = site(m, n, 0), site(m, n, 1), site(m, n, 2)
+            b.append((i0, site(m + 1, n, 2)))
+            b.append((i0, i2))
+            b.append((i1, site(m, n + 1, 0)))
+            b.append((i1, i0))
+            b.append((i2, site(m - 1, n - 1, 1)))
+            b.append((i2, i1))
+    return b

@@ -1,0 +1,119 @@
+"""CPU checks of the C-ABI library: it loads, exports every symbol include/qbhip.h declares,
+its host-only pieces (qbh_hess_eigen, argument checking) behave, and the compute entry points
+fail loudly instead of falling back when there is no GPU.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import quantum_basis_amd as q
+from quantum_basis_amd import _lib
+from oracle import qb_oracle as qo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "qbhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(qbh_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(_lib.EXPORTS) == declared
+    assert L.qbh_version() == 100
+
+
+def test_struct_layouts_match_header():
+    # sizes the C compiler gives the header's structs (checked with a tiny C program at build time
+    # would be better; here: the documented field lists, 8-byte aligned)
+    assert C.sizeof(_lib.Z) == 16
+    assert C.sizeof(_lib.LanczosRow) == 8 + 4 * 8 + 5 * 8
+    assert C.sizeof(_lib.Opts) == 4 + 4 + 8 + 6 * 4
+    assert C.sizeof(_lib.Stats) == 5 * 8
+
+
+def test_strerror_and_no_device_is_loud():
+    L = _lib.lib()
+    assert L.qbh_strerror(0) == b"success"
+    assert b"no CPU fallback" in L.qbh_strerror(-2)
+    if L.qbh_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.QbhError) as e:
+        q.csr_mat(2, [0, 1, 2], [0, 1], [1.0, 1.0], sym=True)
+    assert e.value.code == -2
+    # the raw C entry point refuses as well (argument validation runs first, then the device check)
+    h = C.c_void_p()
+    ia = np.array([0, 1, 2], dtype=np.int64)
+    ja = np.array([0, 1], dtype=np.int64)
+    val = np.ones(2, dtype=np.complex128)
+    rc = L.qbh_csr_create(C.byref(h), 2, 2, 1, ia.ctypes.data, ja.ctypes.data, val.ctypes.data, None)
+    assert rc == -2 and not h.value
+    p = C.c_void_p()
+    assert L.qbh_vec_alloc(C.byref(p), 10) == -2
+
+
+def test_create_rejects_bad_csr_before_touching_the_device():
+    L = _lib.lib()
+    h = C.c_void_p()
+    ia = np.array([0, 1, 3], dtype=np.int64)
+    ja = np.array([0, 0, 1], dtype=np.int64)       # row 1 holds column 0 < row: invalid for sym_upper
+    val = np.ones(3, dtype=np.complex128)
+    assert L.qbh_csr_create(C.byref(h), 2, 3, 1, ia.ctypes.data, ja.ctypes.data, val.ctypes.data, None) == -1
+    assert b"bad column" in L.qbh_last_error()
+    assert L.qbh_csr_create(C.byref(h), 2, 2, 1, ia.ctypes.data, ja.ctypes.data, val.ctypes.data, None) == -1
+    assert L.qbh_csr_create(C.byref(h), 0, 0, 1, None, None, None, None) == -1
+    # full storage that is not Hermitian: the reference exits with code 99 (src/sparse.cc:251)
+    ia = np.array([0, 2, 4], dtype=np.int64)
+    ja = np.array([0, 1, 0, 1], dtype=np.int64)
+    val = np.array([1, 2 + 1j, 2 + 1j, 1], dtype=np.complex128)
+    assert L.qbh_csr_create(C.byref(h), 2, 4, 0, ia.ctypes.data, ja.ctypes.data, val.ctypes.data, None) == -5
+
+
+def test_hess_eigen_host_against_oracle_and_numpy():
+    rng = np.random.default_rng(11)
+    maxit = 64
+    for m in (1, 2, 5, 33, 63):
+        h = np.zeros(2 * maxit)
+        h[maxit:maxit + m] = rng.normal(size=m)
+        h[1:m] = rng.uniform(0.1, 3.0, size=max(m - 1, 0))
+        for order in ("sr", "lr", "sm", "lm"):
+            ritz, s = q.hess_eigen(h, maxit, m, order)
+            ritz_o, s_o = qo.hess_eigen(h, maxit, m, order)
+            assert np.allclose(ritz, ritz_o, atol=1e-13)
+            S, So = s.reshape(m, m), s_o.reshape(m, m)
+            # eigenvectors agree up to sign
+            assert np.allclose(np.abs(np.sum(S * So, axis=1)), 1.0, atol=1e-10)
+        T = np.diag(h[maxit:maxit + m]) + np.diag(h[1:m], 1) + np.diag(h[1:m], -1)
+        assert np.allclose(q.hess_eigen(h, maxit, m, "sr")[0], np.linalg.eigvalsh(T), atol=1e-13)
+    with pytest.raises(_lib.QbhError):
+        q.hess_eigen(np.zeros(20), 10, 10, "sr")       # assert(m > 0 && m < maxit), src/lanczos.cc:358
+    with pytest.raises(_lib.QbhError):
+        q.hess_eigen(np.zeros(20), 10, 3, "xx")
+
+
+def test_iram_argument_checks_mirror_reference():
+    class Fake:
+        dim = 100
+    with pytest.raises(ValueError):
+        q.iram(100, Fake(), None, 0, 6, 100)           # src/lanczos.cc:502
+    with pytest.raises(ValueError):
+        q.iram(100, Fake(), None, 2, 6, 10)            # src/lanczos.cc:504
+    with pytest.raises(ValueError):
+        q.iram(100, Fake(), None, 2, 6, 100, "zz")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "quantum_basis_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "qb_oracle" not in text and "import oracle" not in text and "from oracle" not in text, f

@@ -1,0 +1,389 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Tolerances: the path is complex128 floating point; per-element SpMV / BLAS-1 results must
+agree with the oracle to 1e-13 relative (summation order differs, nothing else), Lanczos
+coefficients to 1e-10 for the first steps, ground-state energies to 1e-10 relative
+(BASELINE.json north_star), step counts to +-1."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import fastham
+import helpers
+import quantum_basis_amd as q
+from quantum_basis_amd import _lib, lattices
+from oracle import qb_oracle as qo
+
+pytestmark = pytest.mark.gpu
+
+SPMV_RTOL = 1e-13
+E0_RTOL = 1e-10
+
+CASES = ["chain16_sz0", "hubbard_4x2", "kagome_12", "hubbard_4x2_fast_full", "chain16_k3", "chain12_sz0"]
+
+
+def _both(name, **opts):
+    d, ia, ja, val, sym = helpers.case(name)
+    return q.csr_mat(d, ia, ja, val, sym, opts=q.make_opts(**opts)), qo.Csr(d, ia, ja, val, sym)
+
+
+def _rand(n, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.normal(size=n) + 1j * rng.normal(size=n)).astype(np.complex128)
+
+
+def _close(a, b, rtol=SPMV_RTOL):
+    scale = max(np.abs(b).max(), 1e-300)
+    return np.abs(a - b).max() <= rtol * scale * 8
+
+
+def test_native_library_is_loaded_and_sees_the_gpu():
+    assert _lib.lib().qbh_device_count() >= 1
+    assert _lib.SO_PATH.endswith("quantum_basis_amd/libqbhip.so")
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_STREAM, _lib.KERNEL_VECTOR])
+def test_multmv_and_multmv2_host_seam(name, kernel):
+    A, O = _both(name, spmv_kernel=kernel)
+    x = _rand(A.dim, 1)
+    y = np.empty(A.dim, dtype=np.complex128)
+    A.MultMv(x, y)
+    want = O.multmv(x)
+    assert _close(y, want)
+    y0 = _rand(A.dim, 2)
+    y2 = y0.copy()
+    A.MultMv2(x, y2)                       # accumulates (src/sparse.cc:262)
+    assert _close(y2, y0 + want)
+    info = A.info()
+    assert info.nnz == O.expand_full().nnz
+    assert info.bytes_algorithmic == info.nnz * 20 + (A.dim + 1) * 8 + A.dim * 32
+
+
+@pytest.mark.parametrize("npb,swz", [(1024, 1), (2048, 0), (4096, 1)])
+def test_stream_kernel_geometries(npb, swz):
+    A, O = _both("chain16_sz0", nnz_per_block=npb, xcd_swizzle=swz)
+    x = _rand(A.dim, 5)
+    y = np.empty_like(x)
+    A.MultMv(x, y)
+    assert _close(y, O.multmv(x))
+
+
+def test_survey_vectors_chain16():
+    """y = H x for x = vec_randomize(seed=1) against the vectors captured from the reference."""
+    g = helpers.probe()["chain16_sz0"]
+    A, _ = _both("chain16_sz0")
+    x = q.vec_randomize(A, seed=1)
+    assert np.allclose(x[:3].real, g["x0_2"], rtol=1e-14, atol=0) and np.all(x.imag == 0)
+    y = np.empty_like(x)
+    A.MultMv(x, y)
+    assert np.allclose(y[:3].real, g["y0_2"], rtol=1e-13)
+    assert abs(np.linalg.norm(y) - g["norm_y"]) < 1e-13
+    assert abs(y.sum().real - g["sum_y"]) < 1e-12
+
+
+def test_vec_randomize_bit_identical_before_normalisation():
+    A, _ = _both("hubbard_4x2")
+    x = q.vec_randomize(A, seed=1)
+    xo = qo.vec_randomize(A.dim, 1)
+    assert np.allclose(x, xo, rtol=4e-16, atol=0)
+    x8 = q.vec_randomize(A, seed=8)
+    assert np.allclose(x8, qo.vec_randomize(A.dim, 8), rtol=4e-16, atol=0)
+    x0 = q.vec_randomize(A, seed=0)
+    assert np.allclose(x0, 1.0 / np.sqrt(A.dim))
+
+
+def test_fused_spmv_epilogue_and_reductions():
+    """y <- alpha*Hx + beta*y + gamma*x with <x,y> and |y|^2 produced by the same launch."""
+    A, O = _both("chain16_k3")
+    n = A.dim
+    x, y0 = _rand(n, 3), _rand(n, 4)
+    v = A.vec(2)
+    for alpha, beta, gamma in [(1.0, 0.0, 0.0), (1.0, 1.0, 0.0), (0.7, -1.3, 0.0), (1.0, 0.0, -2.5), (-1.0, 0.0, 3.25)]:
+        v.upload(x, 0)
+        v.upload(y0, n)
+        dot, nrm2 = A.spmv(v.at(0), v.at(n), alpha, beta, gamma, want_red=True)
+        got = v.download(n, n)
+        want = alpha * O.multmv(x) + beta * y0 + gamma * x
+        assert _close(got, want)
+        assert abs(dot - np.vdot(x, want)) <= 1e-12 * abs(np.vdot(x, want)) + 1e-12
+        assert abs(nrm2 - np.vdot(want, want).real) <= 1e-12 * nrm2
+    v.free()
+
+
+def test_blas1_building_blocks():
+    A, _ = _both("hubbard_4x2")
+    n = A.dim
+    x, y = _rand(n, 6), _rand(n, 7)
+    v = A.vec(2)
+    v.upload(x, 0)
+    v.upload(y, n)
+    assert abs(A.dotc(v.at(0), v.at(n)) - np.vdot(x, y)) < 1e-11
+    assert abs(A.nrm2(v.at(0)) - np.linalg.norm(x)) < 1e-11
+    alpha = 0.3 - 0.8j
+    nrm2 = A.axpy_norm(alpha, v.at(0), v.at(n))
+    want = y + alpha * x
+    assert _close(v.download(n, n), want)
+    assert abs(nrm2 - np.vdot(want, want).real) < 1e-10
+    A.scal(0.125, v.at(0))
+    assert _close(v.download(0, n), 0.125 * x)
+    v.free()
+
+
+@pytest.mark.parametrize("name", ["chain16_sz0", "hubbard_4x2"])
+def test_lanczos_coefficients_and_steps(name):
+    """lanczos(..., "sr_val0"): a[], b[] against the oracle AND the reference-captured values."""
+    g = helpers.probe()[name]
+    A, O = _both(name)
+    maxit = 1000
+    dim = A.dim
+    v = np.zeros(2 * dim, dtype=np.complex128)
+    v[:dim] = qo.vec_randomize(dim, 1)
+    vo = v.copy()
+    hess, hess_o = np.zeros(2 * maxit), np.zeros(2 * maxit)
+    m = q.lanczos(0, maxit - 1, maxit, dim, A, v, hess, "sr_val0")
+    mo, rows_o, _ = qo.lanczos(0, maxit - 1, maxit, O, vo, hess_o, "sr_val0")
+    assert abs(m - mo) <= 1 and abs(m - g["lanczos_m"]) <= 1
+    assert np.allclose(hess[maxit:maxit + 10], g["a0_9"], rtol=1e-10)
+    assert np.allclose(hess[1:11], g["b1_10"], rtol=1e-10)
+    assert np.allclose(hess[maxit:maxit + 20], hess_o[maxit:maxit + 20], rtol=1e-9)
+    ritz, s = q.hess_eigen(hess, maxit, m, "sr")
+    assert abs(ritz[0] - g["E0"]) <= E0_RTOL * abs(g["E0"])
+    rows = q.lanczos.last["log"]
+    assert rows[0]["k"] == 4 and len(rows) == m - 3
+    assert np.allclose(rows[0]["ritz"], g["log_row_k4"][1:5], rtol=2e-9)
+    assert q.lanczos.last["n_matvec"] == m
+    # exit contract (src/qbasis.h:1056-1058): v holds the last two normalised Lanczos vectors
+    for j in (0, 1):
+        assert abs(np.linalg.norm(v[j * dim:(j + 1) * dim]) - 1.0) < 1e-12
+    assert abs(np.vdot(v[:dim], v[dim:])) < 1e-6
+
+
+def test_lanczos_continuation_matches_single_run():
+    """lanczos(k, np): 'on entry, assuming k steps of Lanczos already performed' (src/qbasis.h:1030)."""
+    A, _ = _both("kagome_12")
+    maxit, dim = 200, A.dim
+    v1 = np.zeros(2 * dim, dtype=np.complex128)
+    v1[:dim] = qo.vec_randomize(dim, 1)
+    v2 = v1.copy()
+    h1, h2 = np.zeros(2 * maxit), np.zeros(2 * maxit)
+    m1 = q.lanczos(0, 30, maxit, dim, A, v1, h1, "dnmcs")
+    m2 = q.lanczos(0, 12, maxit, dim, A, v2, h2, "dnmcs")
+    assert m2 == 12
+    m2 = q.lanczos(12, 18, maxit, dim, A, v2, h2, "dnmcs")
+    assert m1 == m2 == 30
+    assert np.allclose(h1, h2, rtol=1e-9, atol=1e-12)
+    assert _close(v1, v2, rtol=1e-9)
+
+
+def test_lanczos_rejects_unnormalised_start_and_bad_purpose():
+    A, _ = _both("kagome_12")
+    dim = A.dim
+    v = np.ones(2 * dim, dtype=np.complex128)
+    with pytest.raises(_lib.QbhError) as e:
+        q.lanczos(0, 10, 100, dim, A, v, np.zeros(200), "sr_val0")     # assert at src/lanczos.cc:166
+    assert e.value.code == -7
+    v[:dim] /= np.linalg.norm(v[:dim])
+    with pytest.raises(_lib.QbhError) as e:
+        q.lanczos(0, 10, 100, dim, A, v, np.zeros(200), "iram")
+    assert e.value.code == -9
+    with pytest.raises(_lib.QbhError) as e:
+        q.lanczos(0, 100, 100, dim, A, v, np.zeros(200), "sr_val0")    # assert(mm < maxit)
+    assert e.value.code == -1
+
+
+@pytest.mark.parametrize("name", ["hubbard_4x2", "chain16_k3"])
+def test_eigenvec_cg_against_oracle(name):
+    A, O = _both(name)
+    dim, maxit = A.dim, 1000
+    E0 = qo.locate_E0_lanczos(O, ncv=0)["E0"]
+    bufs = [np.zeros(dim, dtype=np.complex128) for _ in range(8)]
+    v, r, p, pp, vo, ro, po, ppo = bufs
+    v[:] = qo.vec_randomize(dim, 1)
+    vo[:] = v
+    m, accu = q.eigenvec_CG(dim, maxit, 0, A, E0, v, r, p, pp)
+    mo, accu_o, rl_o = qo.eigenvec_cg(maxit, O, E0, vo, ro, po, ppo)
+    assert abs(m - mo) <= 2 and accu < q.lanczos_precision
+    rl = np.array(q.eigenvec_CG.last["resid"])
+    assert np.allclose(rl[:10], rl_o[:10], rtol=1e-8)
+    assert abs(abs(np.vdot(v, vo)) - 1.0) < 1e-9             # same eigenvector up to phase
+    assert abs(np.vdot(v, O.multmv(v)).real - E0) < 1e-10 * abs(E0)
+
+
+def test_locate_E0_lanczos_main_test_known_answers():
+    """src/main_test.cc test 1 on the GPU path: E0 and the three correlators."""
+    k = helpers.known()["chain16_full"]
+    d, ia, ja, val, sym = helpers.case("chain16_full")
+    A = q.csr_mat(d, ia, ja, val, sym)
+    res = q.locate_E0_lanczos(A, nev=1, ncv=1)
+    assert abs(res.E0 - k["E0"]) < k["tol"]
+    assert abs(res.steps["E0"] - 68) <= 1 and abs(res.steps["V0"] - 71) <= 2
+    import refham
+    basis = refham.spin_half_basis(16, None)
+    vec = res.eigenvecs
+    assert abs(helpers.expect_sz_sz(vec, basis, 0, 1) - k["Sz0Sz1"]) < k["tol"]
+    assert abs(helpers.expect_sz_sz(vec, basis, 0, 2) - k["Sz0Sz2"]) < k["tol"]
+    assert abs(helpers.expect_sp_sm(vec, basis, 0, 1).real - k["Sp0Sm1"]) < k["tol"]
+
+
+def test_locate_E0_lanczos_two_states_against_oracle():
+    """E0 -> V0 -> E1 (re-orthogonalised against phi0) -> V1, all four stages."""
+    A, O = _both("chain16_sz0")
+    res = q.locate_E0_lanczos(A, nev=2, ncv=2)
+    ro = qo.locate_E0_lanczos(O, nev=2, ncv=2)
+    assert abs(res.E0 - ro["E0"]) <= E0_RTOL * abs(ro["E0"])
+    assert abs(res.E1 - ro["E1"]) <= 1e-8
+    assert abs(res.E1 - helpers.known()["chain16_momentum"]["E0_k"][8]) < 1e-7
+    assert res.nconv == 2 and res.eigenvecs.size == 2 * A.dim
+    v0, v1 = res.eigenvecs[:A.dim], res.eigenvecs[A.dim:]
+    assert abs(np.vdot(v0, v1)) < 1e-6
+    assert abs(np.vdot(v1, O.multmv(v1)).real - res.E1) < 1e-8
+
+
+@pytest.mark.parametrize("k", [1, 8, 13])
+def test_momentum_sectors_complex_phases_known_answers(k):
+    ans = helpers.known()["chain16_momentum"]
+    A, _ = _both("chain16_k%d" % k)
+    res = q.locate_E0_lanczos(A, nev=1, ncv=0)
+    assert abs(res.E0 - ans["E0_k"][k]) < ans["tol"]
+
+
+def test_gauged_complex_hubbard_energy():
+    d, ia, ja, val, sym = helpers.case("hubbard_4x2")
+    valc, _ = helpers.gauge(d, ia, ja, val)
+    A = q.csr_mat(d, ia, ja, valc, True)
+    res = q.locate_E0_lanczos(A, nev=1, ncv=0)
+    assert abs(res.E0 - helpers.known()["hubbard_4x2"]["E0"]) < 1e-8
+
+
+def test_iram_reverse_communication_matvec():
+    """locate_E0_iram: ARPACK drives csr_mat.MultMv on the device (src/lanczos.cc:473-477)."""
+    A, O = _both("hubbard_4x2")
+    res = q.locate_E0_iram(A, nev=2, ncv=8)
+    assert abs(res.E0 - helpers.known()["hubbard_4x2"]["E0"]) < 1e-8
+    assert abs(res.eigenvals[1] - helpers.probe()["hubbard_4x2"]["ritz1"]) < 1e-8
+    v0 = res.eigenvecs[:A.dim]
+    assert np.linalg.norm(O.multmv(v0) - res.E0 * v0) < 1e-8
+    # dense fall-back for dim <= 30 (src/lanczos.cc:508-542)
+    dd, ia, ja, val, _ = __import__("refham").heisenberg_csr(4, [(0, 1), (1, 2), (2, 3), (3, 0)], n_dn=2)
+    S = q.csr_mat(dd, ia, ja, val, True)
+    nconv, w, z = q.iram(dd, S, None, 2, 4, 100, "sr")
+    assert nconv == 2 and abs(w[0] + 2.0) < 1e-12
+
+
+def test_value_dictionary_is_exact():
+    A, O = _both("hubbard_4x2", value_dict=1)
+    assert 0 < A.info().value_dict <= 256
+    x = _rand(A.dim, 9)
+    y = np.empty_like(x)
+    A.MultMv(x, y)
+    assert _close(y, O.multmv(x))
+    # too many distinct values: silently stays uncoded, still correct
+    B, OB = _both("chain16_k3", value_dict=1)
+    y = np.empty(B.dim, dtype=np.complex128)
+    xb = _rand(B.dim, 10)
+    B.MultMv(xb, y)
+    assert _close(y, OB.multmv(xb))
+
+
+def test_ragged_and_degenerate_shapes():
+    """Empty rows, a row longer than the LDS tile, 1x1, and very short rows."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    import scipy.sparse as sp
+    M = sp.random(n, n, density=0.002, random_state=5, format="lil", dtype=np.float64)
+    M[7, :] = rng.normal(size=n)                      # one dense row (3000 nnz > 2048)
+    M[100:140, :] = 0                                 # empty rows
+    M = M.tocsr()
+    M = M + M.T
+    Mc = sp.csr_matrix(M, dtype=np.complex128)
+    Mc.sort_indices()
+    ia, ja, val = Mc.indptr.astype(np.int64), Mc.indices.astype(np.int64), Mc.data.astype(np.complex128)
+    for kernel in (_lib.KERNEL_STREAM, _lib.KERNEL_VECTOR):
+        A = q.csr_mat(n, ia, ja, val, sym=False, opts=q.make_opts(spmv_kernel=kernel, nnz_per_block=1024))
+        x = _rand(n, 12)
+        y = np.empty_like(x)
+        A.MultMv(x, y)
+        assert _close(y, Mc @ x, rtol=1e-12)
+        y2 = np.ones(n, dtype=np.complex128)
+        A.MultMv2(x, y2)
+        assert _close(y2, 1.0 + Mc @ x, rtol=1e-12)
+    one = q.csr_mat(1, [0, 1], [0], [2.5], sym=True)
+    y = np.empty(1, dtype=np.complex128)
+    one.MultMv(np.array([2.0 + 1j]), y)
+    assert abs(y[0] - (5.0 + 2.5j)) < 1e-15
+
+
+def test_device_generators_match_numpy_assembly():
+    H = fastham.hubbard_full(8, 4, 4, lattices.square(4, 2))
+    A = q.csr_mat.hubbard(8, 4, 4, lattices.square(4, 2), t=1.0, U=1.1)
+    ia, ja, val = A.download()
+    assert A.dim == H.shape[0] and A.nnz == H.nnz
+    assert np.array_equal(ia, H.indptr) and np.array_equal(ja, H.indices)
+    assert np.array_equal(val, H.data.astype(np.complex128))
+    res = q.locate_E0_lanczos(A, nev=1, ncv=0)
+    assert abs(res.E0 - helpers.known()["hubbard_4x2"]["E0"]) < 1e-8
+    # unequal fillings, 3x3 lattice (odd sizes)
+    H = fastham.hubbard_full(9, 4, 3, lattices.square(3, 3), t=0.7, U=4.0)
+    A = q.csr_mat.hubbard(9, 4, 3, lattices.square(3, 3), t=0.7, U=4.0)
+    ia, ja, val = A.download()
+    assert np.array_equal(ia, H.indptr) and np.array_equal(ja, H.indices) and np.allclose(val, H.data, rtol=0, atol=0)
+    for (L, ndn, bonds) in [(12, 6, lattices.kagome(2, 2)), (16, 8, lattices.triangular(4, 4)), (14, 5, lattices.chain(14))]:
+        H = fastham.heisenberg_full(L, ndn, bonds)
+        A = q.csr_mat.heisenberg(L, ndn, bonds, J=1.0)
+        ia, ja, val = A.download()
+        assert np.array_equal(ia, H.indptr) and np.array_equal(ja, H.indices)
+        assert np.array_equal(val, H.data.astype(np.complex128))
+    res = q.locate_E0_lanczos(q.csr_mat.heisenberg(12, 6, lattices.kagome(2, 2)), nev=1, ncv=0)
+    assert abs(res.E0 - helpers.known()["kagome_12"]["E0"]) < 1e-8
+
+
+def test_row_shards_of_the_generator_tile_the_operator():
+    """Rows [r0,r1) built independently equal the slice of the full operator (multi-GPU row blocks)."""
+    bonds = lattices.square(4, 2)
+    full = q.csr_mat.hubbard(8, 4, 4, bonds)
+    ia, ja, val = full.download()
+    dim = full.dim
+    cut = [0, 1700, 3333, dim]
+    x = _rand(dim, 21)
+    xv = full.vec()
+    xv.upload(x)
+    yfull = full.vec()
+    full.spmv(xv.ptr, yfull.ptr)
+    want = yfull.download()
+    for r0, r1 in zip(cut[:-1], cut[1:]):
+        sh = q.csr_mat.hubbard(8, 4, 4, bonds, rows=(r0, r1))
+        sia, sja, sval = sh.download()
+        assert sh.dim == r1 - r0 and sh.ncols == dim and sh.row_offset == r0
+        assert np.array_equal(sia, ia[r0:r1 + 1] - ia[r0])
+        assert np.array_equal(sja, ja[ia[r0]:ia[r1]]) and np.array_equal(sval, val[ia[r0]:ia[r1]])
+        ys = sh.vec()
+        sh.spmv(xv.ptr, ys.ptr)          # unsharded call convention: x is the full-length vector
+        assert _close(ys.download(), want[r0:r1])
+
+
+def test_medium_size_properties_chain22():
+    """A size the oracle still finishes in seconds (dim 705,432): E0 vs the survey's reference value,
+    Hermiticity <x,Hy> = <Hx,y>, and linearity of the device operator."""
+    g = helpers.probe()["chain22_sz0"]
+    A = q.csr_mat.heisenberg(22, 11, lattices.chain(22))
+    assert A.dim == g["dim"] and A.nnz == g["nnz_full"]
+    n = A.dim
+    v = A.vec(4)
+    x, y = _rand(n, 31), _rand(n, 32)
+    v.upload(x, 0)
+    v.upload(y, n)
+    A.spmv(v.at(0), v.at(2 * n))
+    A.spmv(v.at(n), v.at(3 * n))
+    lhs = A.dotc(v.at(0), v.at(3 * n))
+    rhs = A.dotc(v.at(2 * n), v.at(n))
+    assert abs(lhs - rhs) < 1e-9 * abs(lhs)
+    hx, hy = v.download(2 * n, n), v.download(3 * n, n)
+    v.upload(2.0 * x - 0.5j * y, 0)
+    A.spmv(v.at(0), v.at(n))
+    assert _close(v.download(n, n), 2.0 * hx - 0.5j * hy, rtol=1e-12)
+    v.free()
+    res = q.locate_E0_lanczos(A, nev=1, ncv=0)
+    assert abs(res.E0 - g["E0"]) <= E0_RTOL * abs(g["E0"])
+    assert abs(res.steps["E0"] - g["lanczos_m"]) <= 3
