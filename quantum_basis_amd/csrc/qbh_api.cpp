@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -151,7 +152,8 @@ int finalize(qbh_csr *A)
     else A->window = A->npb / 2;
     A->n_blocks = std::max<int64_t>(1, (A->nnz + A->window - 1) / A->window);
     QBH_HIP(hipMalloc(&A->d_rb, (size_t)(A->n_blocks + 1) * sizeof(int32_t)));
-    QBH_TRY(qbh::launch_build_rowblocks(A->d_ia, A->nrows, A->window, A->d_rb, A->n_blocks, s));
+    QBH_HIP(hipMalloc(&A->d_bp, (size_t)(A->n_blocks + 1) * sizeof(int64_t)));
+    QBH_TRY(qbh::launch_build_rowblocks(A->d_ia, A->nrows, A->window, A->d_rb, A->d_bp, A->n_blocks, s));
     A->grid = qbh::spmv_grid(A->kernel, A->n_blocks, A->nrows, A->tpr);
     const size_t nparts = (size_t)std::max(A->grid, qbh::kMaxRedBlocks);
     QBH_HIP(hipMalloc(&A->d_partials, nparts * 4 * sizeof(double)));
@@ -170,6 +172,7 @@ int new_handle(qbh_csr **out, const qbh_opts *opts)
     if (opts) A->opts = *opts;
     else qbh_opts_default(&A->opts);
     A->device = dev;
+    if (const char *dbg = getenv("QBH_DEBUG")) A->debug = atoi(dbg);   // timing experiments only
     if (A->opts.stream) {
         A->stream = (hipStream_t)A->opts.stream;
         A->own_stream = false;
@@ -232,6 +235,7 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
     if (A->d_code) (void)hipFree(A->d_code);
     if (A->d_dict) (void)hipFree(A->d_dict);
     if (A->d_rb) (void)hipFree(A->d_rb);
+    if (A->d_bp) (void)hipFree(A->d_bp);
     if (A->d_partials) (void)hipFree(A->d_partials);
     if (A->d_scal) (void)hipFree(A->d_scal);
     if (A->h_scal) (void)hipHostFree(A->h_scal);
@@ -411,7 +415,7 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->nnz = A->nnz;
     info->n_blocks = A->n_blocks;
     info->bytes_matrix = (A->nrows + 1) * 8 + A->nnz * 4 + (A->d_code ? A->nnz + 256 * 16 : A->nnz * 16) +
-                         (A->n_blocks + 1) * 4;
+                         (A->n_blocks + 1) * 12;
     info->bytes_algorithmic = A->nnz * 20 + (A->nrows + 1) * 8 + A->nrows * 32;
     info->kernel = A->kernel;
     info->value_dict = A->d_code ? A->n_dict : 0;
@@ -514,6 +518,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     a.code = A->d_code;
     a.dict = A->d_dict;
     a.rb = A->d_rb;
+    a.bp = A->d_bp;
     a.n_blocks = A->n_blocks;
     a.nrows = A->nrows;
     a.xg = xg;
@@ -524,6 +529,8 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     a.gamma = gamma;
     a.partials = red ? A->d_partials : nullptr;
     a.swizzle = A->opts.xcd_swizzle;
+    a.colmask = (A->debug & 1) ? 1023 : -1;
+    a.debug2 = (A->debug & 2) ? 1 : 0;
     const bool prof = A->opts.profile != 0;
     if (prof) {
         harvest_events(A);

@@ -43,6 +43,7 @@ struct SpmvArgs {
     const uint8_t *code;   // [nnz] dictionary codes (value_dict)
     const d2      *dict;   // [<=256] dictionary
     const int32_t *rb;     // [n_blocks+1] first row of each row block (stream kernel)
+    const int64_t *bp;     // [n_blocks+1] first nonzero of each row block (= ia[rb[.]])
     int64_t        n_blocks;
     int64_t        nrows;
     const d2      *xg;     // gather source (full-length x)
@@ -51,13 +52,15 @@ struct SpmvArgs {
     double         alpha, beta, gamma;
     double        *partials;   // [grid*3] or nullptr
     int            swizzle;
+    int            debug2;     // QBH_DEBUG bit1: stream loads only, no LDS/reduce (timing experiments only)
+    int            colmask;    // -1; QBH_DEBUG=1 sets 1023 so the gather stays in cache (timing experiments only)
 };
 
 // launchers implemented in qbh_kernels.hip (all asynchronous on `s`)
 int launch_spmv(const SpmvArgs &a, int kernel, int npb, int tpr, int grid, hipStream_t s);
 int spmv_grid(int kernel, int64_t n_blocks, int64_t nrows, int tpr);
 int launch_build_rowblocks(const int64_t *d_ia, int64_t nrows, int64_t window, int32_t *d_rb,
-                           int64_t n_blocks, hipStream_t s);
+                           int64_t *d_bp, int64_t n_blocks, hipStream_t s);
 int launch_block_stats(const int64_t *d_ia, const int32_t *d_rb, int64_t n_blocks, int64_t *d_out2,
                        hipStream_t s);
 int launch_reduce_partials(const double *partials, int nparts, int ncomp, double *out, hipStream_t s);
@@ -102,6 +105,7 @@ struct qbh_csr {
     int64_t  window = 0;       // nnz window that defines a row block
     int64_t  n_blocks = 0;
     int32_t *d_rb = nullptr;
+    int64_t *d_bp = nullptr;
     int      grid = 0;
 
     // workspace
@@ -118,4 +122,5 @@ struct qbh_csr {
     // stats
     qbh_stats stats{};
     bool      ev_pending = false;
+    int       debug = 0;
 };

@@ -76,17 +76,24 @@ struct BlockWalk {
 
 // fused epilogue of one row: y <- alpha*(Hx) + beta*y + gamma*x_local, and the running
 // partial sums of <x,y> and |y|^2 (K3, K4 and the CG shift folded into K1).
-__device__ __forceinline__ void row_epilogue(const SpmvArgs &a, int64_t row, d2 sum, double (&acc)[3])
+// yo / xi are the old y[row] and x_local[row], loaded by the caller (so that the loads can
+// be issued long before the row sum is ready).
+__device__ __forceinline__ void row_epilogue2(const SpmvArgs &a, int64_t row, d2 sum, d2 yo, d2 xi,
+                                              double (&acc)[3])
 {
-    d2 yn = a.alpha * sum;
-    if (a.beta != 0.0) yn += a.beta * a.y[row];
-    d2 xi = {0.0, 0.0};
-    if (a.gamma != 0.0 || a.partials != nullptr) xi = a.xl[row];
-    if (a.gamma != 0.0) yn += a.gamma * xi;
+    d2 yn = a.alpha * sum + a.beta * yo + a.gamma * xi;
     a.y[row] = yn;
     acc[0] += xi.x * yn.x + xi.y * yn.y;
     acc[1] += xi.x * yn.y - xi.y * yn.x;
     acc[2] += yn.x * yn.x + yn.y * yn.y;
+}
+
+__device__ __forceinline__ void row_epilogue(const SpmvArgs &a, int64_t row, d2 sum, double (&acc)[3])
+{
+    d2 yo = {0.0, 0.0}, xi = {0.0, 0.0};
+    if (a.beta != 0.0) yo = a.y[row];
+    if (a.gamma != 0.0 || a.partials != nullptr) xi = a.xl[row];
+    row_epilogue2(a, row, sum, yo, xi, acc);
 }
 
 // ------------------------------------------------- streaming SpMV (default) ----
@@ -94,6 +101,9 @@ __device__ __forceinline__ void row_epilogue(const SpmvArgs &a, int64_t row, d2 
 // block's col/val ranges (perfectly coalesced, NPB/256 independent 4 B + 16 B + gathered
 // 16 B loads in flight per lane) and park val*x products in LDS.  Phase 2: TPR lanes per
 // row sum the row's LDS segment, shuffle-reduce, run the fused epilogue.
+// The block descriptors (first row rb[], first nonzero bp[]) of the NEXT block are fetched
+// while the current one is processed, and the epilogue operands (old y, local x) are
+// requested before the stream loads, so a block's critical path is col -> x -> LDS only.
 template <int NPB, int TPR, bool DICT>
 __global__ __launch_bounds__(kBlock) void k_spmv_stream(SpmvArgs a)
 {
@@ -102,8 +112,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(SpmvArgs a)
     __shared__ double red[12];
     __shared__ d2 dict_s[DICT ? 256 : 1];
 
+    constexpr int U = NPB / kBlock;          // independent load chains per lane
+    constexpr int G = kBlock / TPR;          // rows reduced per pass
     const int tid = threadIdx.x;
+    const int g = tid / TPR, sub = tid % TPR;
     double acc[3] = {0.0, 0.0, 0.0};
+    const bool need_y = a.beta != 0.0;
+    const bool need_x = a.gamma != 0.0 || a.partials != nullptr;
 
     if (DICT) {
         dict_s[tid] = a.dict[tid];
@@ -111,67 +126,118 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(SpmvArgs a)
     }
 
     BlockWalk walk(a.n_blocks, a.swizzle);
-    for (int64_t lb = walk.slot; lb < walk.per_xcd; lb += walk.nslot) {
-        const int64_t b = walk.block(lb);
-        if (b >= a.n_blocks) continue;
-        const int r0 = a.rb[b], r1 = a.rb[b + 1];
+    int64_t lb = walk.slot;
+    int64_t b = walk.block(lb);
+    bool live = lb < walk.per_xcd && b < a.n_blocks;
+    int r0 = 0, r1 = 0;
+    int64_t p0 = 0, p1 = 0;
+    if (live) {
+        r0 = a.rb[b]; r1 = a.rb[b + 1];
+        p0 = a.bp[b]; p1 = a.bp[b + 1];
+    }
+    while (lb < walk.per_xcd) {
+        // descriptors of the next block this workgroup will take (uniform -> scalar loads)
+        const int64_t lb_n = lb + walk.nslot;
+        const int64_t b_n = walk.block(lb_n);
+        const bool live_n = lb_n < walk.per_xcd && b_n < a.n_blocks;
+        int r0_n = 0, r1_n = 0;
+        int64_t p0_n = 0, p1_n = 0;
+        if (live_n) {
+            r0_n = a.rb[b_n]; r1_n = a.rb[b_n + 1];
+            p0_n = a.bp[b_n]; p1_n = a.bp[b_n + 1];
+        }
         const int nr = r1 - r0;
-        if (nr == 0) continue;
-        const int64_t p0 = a.ia[r0];
-        const int64_t nlong = a.ia[r1] - p0;
-
-        if (nlong <= NPB && nr <= kRowCap) {
-            const int n = (int)nlong;
-            for (int i = tid; i <= nr; i += kBlock) rowoff[i] = (int)(a.ia[r0 + i] - p0);
-            const int32_t *jp = a.ja + p0;
+        const int64_t nlong = p1 - p0;
+        if (live && nr > 0) {
+            if (nlong <= NPB && nr <= kRowCap) {
+                const int n = (int)nlong;
+                // row offsets and epilogue operands: requested first, consumed last
+                const int ro = (int)(a.ia[r0 + (tid <= nr ? tid : 0)] - p0);
+                d2 yo = {0.0, 0.0}, xi = {0.0, 0.0};
+                const bool mine = sub == 0 && g < nr;
+                if (mine && need_y) yo = a.y[r0 + g];
+                if (mine && need_x) xi = a.xl[r0 + g];
+                if (n > 0) {
+                    // All U loads of each stream are issued back to back with a clamped index
+                    // (no per-element branch): U col + U val + U gathered-x loads in flight
+                    // per lane -- the memory-level parallelism a branchy loop does not have.
+                    const int32_t *jp = a.ja + p0;
+                    const int nm1 = n - 1;
+                    int c[U];
+                    d2 v[U], xv[U];
+                    uint8_t cb[U];
 #pragma unroll
-            for (int u = 0; u < NPB / kBlock; ++u) {
-                const int i = tid + u * kBlock;
-                if (i < n) {
-                    const int c = ntload(jp + i);
-                    d2 v;
-                    if (DICT) v = dict_s[ntload(a.code + p0 + i)];
-                    else      v = ntload(a.val + p0 + i);
-                    prod[i] = cmul(v, a.xg[c]);
-                }
-            }
-            __syncthreads();
-            constexpr int G = kBlock / TPR;
-            const int g = tid / TPR, sub = tid % TPR;
-            for (int r = g; r < nr; r += G) {
-                const int e = rowoff[r + 1];
-                d2 sum = {0.0, 0.0};
-                for (int q = rowoff[r] + sub; q < e; q += TPR) sum += prod[q];
+                    for (int u = 0; u < U; ++u) {
+                        const int i = tid + u * kBlock;
+                        c[u] = ntload(jp + (i < n ? i : nm1)) & a.colmask;
+                    }
 #pragma unroll
-                for (int off = TPR / 2; off > 0; off >>= 1) {
-                    sum.x += __shfl_xor(sum.x, off, 64);
-                    sum.y += __shfl_xor(sum.y, off, 64);
+                    for (int u = 0; u < U; ++u) {
+                        const int i = tid + u * kBlock;
+                        const int ii = i < n ? i : nm1;
+                        if (DICT) cb[u] = ntload(a.code + p0 + ii);
+                        else      v[u] = ntload(a.val + p0 + ii);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) xv[u] = a.xg[c[u]];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int i = tid + u * kBlock;
+                        if (DICT) v[u] = dict_s[cb[u]];
+                        if (a.debug2) {                    // timing experiment: loads only
+                            const d2 t = cmul(v[u], xv[u]);
+                            acc[2] += t.x + t.y;
+                        } else if (i < n) prod[i] = cmul(v[u], xv[u]);
+                    }
                 }
-                if (sub == 0) row_epilogue(a, (int64_t)r0 + r, sum, acc);
-            }
-            __syncthreads();
-        } else {
-            // oversized block (a row longer than the LDS tile, or > kRowCap very short
-            // rows): row by row, whole workgroup per row.  Correctness path, not tuned.
-            for (int r = 0; r < nr; ++r) {
-                const int64_t s = a.ia[r0 + r], e = a.ia[r0 + r + 1];
-                double part[2] = {0.0, 0.0};
-                for (int64_t q = s + tid; q < e; q += kBlock) {
-                    d2 v;
-                    if (DICT) v = dict_s[a.code[q]];
-                    else      v = a.val[q];
-                    const d2 t = cmul(v, a.xg[a.ja[q]]);
-                    part[0] += t.x;
-                    part[1] += t.y;
+                if (a.debug2) {
+                    acc[2] += ro + yo.x + xi.x;
+                    goto next_block;
                 }
-                block_sum<2>(part, red);
-                if (tid == 0) {
-                    d2 sum = {part[0], part[1]};
-                    row_epilogue(a, (int64_t)r0 + r, sum, acc);
+                if (tid <= nr) rowoff[tid] = ro;
+                for (int i = tid + kBlock; i <= nr; i += kBlock) rowoff[i] = (int)(a.ia[r0 + i] - p0);
+                __syncthreads();
+                for (int r = g; r < nr; r += G) {
+                    const int e = rowoff[r + 1];
+                    d2 sum = {0.0, 0.0};
+                    for (int q = rowoff[r] + sub; q < e; q += TPR) sum += prod[q];
+#pragma unroll
+                    for (int off = TPR / 2; off > 0; off >>= 1) {
+                        sum.x += __shfl_xor(sum.x, off, 64);
+                        sum.y += __shfl_xor(sum.y, off, 64);
+                    }
+                    if (sub == 0) {
+                        if (r == g) row_epilogue2(a, (int64_t)r0 + r, sum, yo, xi, acc);
+                        else        row_epilogue(a, (int64_t)r0 + r, sum, acc);
+                    }
                 }
                 __syncthreads();
+            } else {
+                // oversized block (a row longer than the LDS tile, or > kRowCap very short
+                // rows): row by row, whole workgroup per row.  Correctness path, not tuned.
+                for (int r = 0; r < nr; ++r) {
+                    const int64_t s = a.ia[r0 + r], e = a.ia[r0 + r + 1];
+                    double part[2] = {0.0, 0.0};
+                    for (int64_t q = s + tid; q < e; q += kBlock) {
+                        d2 v;
+                        if (DICT) v = dict_s[a.code[q]];
+                        else      v = a.val[q];
+                        const d2 t = cmul(v, a.xg[a.ja[q] & a.colmask]);
+                        part[0] += t.x;
+                        part[1] += t.y;
+                    }
+                    block_sum<2>(part, red);
+                    if (tid == 0) {
+                        d2 sum = {part[0], part[1]};
+                        row_epilogue(a, (int64_t)r0 + r, sum, acc);
+                    }
+                    __syncthreads();
+                }
             }
         }
+    next_block:
+        lb = lb_n; b = b_n; live = live_n;
+        r0 = r0_n; r1 = r1_n; p0 = p0_n; p1 = p1_n;
     }
     if (a.partials != nullptr) {
         block_sum<3>(acc, red);
@@ -298,12 +364,13 @@ int launch_spmv(const SpmvArgs &a, int kernel, int npb, int tpr, int grid, hipSt
 // [w*window, (w+1)*window): rb[w] = lower_bound(ia, w*window).  Embarrassingly parallel
 // and nnz-balanced; block nnz < window + (longest row).
 __global__ void k_build_rowblocks(const int64_t *ia, int64_t nrows, int64_t window, int32_t *rb,
-                                  int64_t n_blocks)
+                                  int64_t *bp, int64_t n_blocks)
 {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w > n_blocks) return;
     if (w == n_blocks) {
         rb[w] = (int32_t)nrows;
+        bp[w] = ia[nrows];
         return;
     }
     const int64_t target = w * window;
@@ -314,14 +381,15 @@ __global__ void k_build_rowblocks(const int64_t *ia, int64_t nrows, int64_t wind
         else hi = mid;
     }
     rb[w] = (int32_t)lo;
+    bp[w] = ia[lo];
 }
 
 int launch_build_rowblocks(const int64_t *d_ia, int64_t nrows, int64_t window, int32_t *d_rb,
-                           int64_t n_blocks, hipStream_t s)
+                           int64_t *d_bp, int64_t n_blocks, hipStream_t s)
 {
     const int64_t n = n_blocks + 1;
     hipLaunchKernelGGL(k_build_rowblocks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_ia, nrows,
-                       window, d_rb, n_blocks);
+                       window, d_rb, d_bp, n_blocks);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }
