@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 stream, 2 vector")
     ap.add_argument("--npb", type=int, default=0)
     ap.add_argument("--no-swizzle", action="store_true")
-    ap.add_argument("--value-dict", type=int, default=0)
+    ap.add_argument("--value-dict", type=int, default=1, help="1: dictionary-code the value stream when <=256 distinct values (lossless)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed run to convergence (E0)")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)

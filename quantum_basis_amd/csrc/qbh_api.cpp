@@ -117,6 +117,8 @@ struct Bind {   // make the operator's device current for the duration of a call
     }
 };
 
+int try_value_dict(qbh_csr *A);
+
 // geometry + workspace once the CSR arrays are in HBM
 int finalize(qbh_csr *A)
 {
@@ -158,6 +160,7 @@ int finalize(qbh_csr *A)
     const size_t nparts = (size_t)std::max(A->grid, qbh::kMaxRedBlocks);
     QBH_HIP(hipMalloc(&A->d_partials, nparts * 4 * sizeof(double)));
     QBH_HIP(hipStreamSynchronize(s));
+    QBH_TRY(try_value_dict(A));
     A->stats = qbh_stats{};
     A->stats.ms_spmv_min = std::numeric_limits<double>::infinity();
     return QBH_OK;
@@ -189,34 +192,31 @@ int new_handle(qbh_csr **out, const qbh_opts *opts)
     return QBH_OK;
 }
 
-// dictionary-code the values when there are at most 256 distinct ones (exact).
-int try_value_dict(qbh_csr *A, const std::vector<d2> *host_vals)
+// dictionary-code the value stream on the device when there are at most 256 distinct
+// values (exact, lossless); otherwise the operator silently stays uncoded.
+int try_value_dict(qbh_csr *A)
 {
-    if (!A->opts.value_dict || !host_vals) return QBH_OK;
-    std::vector<d2> dict;
-    std::vector<uint8_t> code(host_vals->size());
-    for (size_t i = 0; i < host_vals->size(); ++i) {
-        const d2 v = (*host_vals)[i];
-        int found = -1;
-        for (size_t k = 0; k < dict.size(); ++k) {
-            if (memcmp(&dict[k], &v, sizeof(d2)) == 0) {
-                found = (int)k;
-                break;
-            }
-        }
-        if (found < 0) {
-            if (dict.size() == 256) return QBH_OK;   // too many distinct values: stay uncoded
-            dict.push_back(v);
-            found = (int)dict.size() - 1;
-        }
-        code[i] = (uint8_t)found;
+    if (!A->opts.value_dict || !A->d_val || A->d_code || A->nnz <= 0) return QBH_OK;
+    uint8_t *code = nullptr;
+    d2 *dict = nullptr;
+    QBH_HIP(hipMalloc(&code, (size_t)A->nnz));
+    hipError_t e = hipMalloc(&dict, 256 * sizeof(d2));
+    if (e != hipSuccess) {
+        (void)hipFree(code);
+        return QBH_ENOMEM;
     }
-    A->n_dict = (int)dict.size();
-    dict.resize(256, d2{0.0, 0.0});
-    QBH_HIP(hipMalloc(&A->d_code, std::max<size_t>(code.size(), 1)));
-    QBH_HIP(hipMalloc(&A->d_dict, 256 * sizeof(d2)));
-    QBH_HIP(hipMemcpy(A->d_code, code.data(), code.size(), hipMemcpyHostToDevice));
-    QBH_HIP(hipMemcpy(A->d_dict, dict.data(), 256 * sizeof(d2), hipMemcpyHostToDevice));
+    int n = 0;
+    int rc = qbh::build_value_dict(A->d_val, A->nnz, code, dict, &n, A->stream);
+    if (rc != QBH_OK || n == 0) {
+        (void)hipFree(code);
+        (void)hipFree(dict);
+        return rc;
+    }
+    A->d_code = code;
+    A->d_dict = dict;
+    A->n_dict = n;
+    if (A->own_arrays) (void)hipFree(A->d_val);     // the 16 B/nnz array is no longer needed
+    A->d_val = nullptr;
     return QBH_OK;
 }
 
@@ -360,12 +360,8 @@ extern "C" int qbh_csr_create(qbh_csr **out, int64_t dim, int64_t nnz, int sym_u
     QBH_HIPF(hipMalloc(&A->d_ja, (size_t)A->nnz * sizeof(int32_t)));
     QBH_HIPF(hipMemcpy(A->d_ia, fia.data(), (size_t)(dim + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     QBH_HIPF(hipMemcpy(A->d_ja, fja.data(), (size_t)A->nnz * sizeof(int32_t), hipMemcpyHostToDevice));
-    rc = try_value_dict(A, &fval);
-    if (rc != QBH_OK) return fail(rc);
-    if (!A->d_code) {
-        QBH_HIPF(hipMalloc(&A->d_val, (size_t)A->nnz * sizeof(d2)));
-        QBH_HIPF(hipMemcpy(A->d_val, fval.data(), (size_t)A->nnz * sizeof(d2), hipMemcpyHostToDevice));
-    }
+    QBH_HIPF(hipMalloc(&A->d_val, (size_t)A->nnz * sizeof(d2)));
+    QBH_HIPF(hipMemcpy(A->d_val, fval.data(), (size_t)A->nnz * sizeof(d2), hipMemcpyHostToDevice));
 #undef QBH_HIPF
     rc = finalize(A);
     if (rc != QBH_OK) return fail(rc);
@@ -994,10 +990,6 @@ extern "C" int qbh_eigenvec_cg(const qbh_csr *A, int64_t maxit, int64_t *m, doub
 extern "C" int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1, int64_t *ia, int32_t *ja, qbh_z *val)
 {
     if (!A || r0 < 0 || r1 < r0 || r1 > A->nrows) return QBH_EINVAL;
-    if (val && A->d_code) {
-        qbh::set_error("qbh_csr_download: values are dictionary-coded");
-        return QBH_EUNSUPP;
-    }
     Bind bind(A);
     QBH_HIP(hipStreamSynchronize(A->stream));
     std::vector<int64_t> hia((size_t)(r1 - r0 + 1));
@@ -1006,6 +998,19 @@ extern "C" int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1, int64_
     if (ia)
         for (size_t i = 0; i < hia.size(); ++i) ia[i] = hia[i] - p0;
     if (ja && p1 > p0) QBH_HIP(hipMemcpy(ja, A->d_ja + p0, (size_t)(p1 - p0) * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (val && p1 > p0) QBH_HIP(hipMemcpy(val, A->d_val + p0, (size_t)(p1 - p0) * sizeof(qbh_z), hipMemcpyDeviceToHost));
+    if (val && p1 > p0) {
+        if (A->d_code) {            // decode the dictionary-coded stream
+            std::vector<uint8_t> code((size_t)(p1 - p0));
+            d2 dict[256];
+            QBH_HIP(hipMemcpy(code.data(), A->d_code + p0, code.size(), hipMemcpyDeviceToHost));
+            QBH_HIP(hipMemcpy(dict, A->d_dict, sizeof(dict), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < code.size(); ++i) {
+                val[i].re = dict[code[i]].x;
+                val[i].im = dict[code[i]].y;
+            }
+        } else {
+            QBH_HIP(hipMemcpy(val, A->d_val + p0, (size_t)(p1 - p0) * sizeof(qbh_z), hipMemcpyDeviceToHost));
+        }
+    }
     return QBH_OK;
 }

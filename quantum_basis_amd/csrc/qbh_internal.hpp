@@ -76,6 +76,7 @@ int launch_randomize(d2 *x, int64_t n, int64_t global_offset, uint32_t seed, dou
 int launch_fill_const(d2 *x, int64_t n, double re, hipStream_t s);
 int launch_max_rowlen(const int64_t *d_ia, int64_t nrows, int64_t *d_out, hipStream_t s);
 int blas_grid(int64_t n);
+int build_value_dict(const d2 *d_val, int64_t nnz, uint8_t *d_code, d2 *d_dict, int *n_out, hipStream_t s);
 
 // host tridiagonal solver (qbh_hess.cpp)
 int tridiag_eigen_full(int64_t m, const double *a, const double *b1, double *w, double *z);
