@@ -131,11 +131,18 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
         args.gpus = world
     _lib.require_gpu()                      # no CPU fallback: fail loudly
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # QBH_DIST_BACKEND=gloo lets several ranks share one GPU on a single-GPU test rig (RCCL refuses that)
+    backend = os.environ.get("QBH_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    local_rank = dev_index
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     W = workloads()[args.workload]
     dim = dim_of(W)
@@ -153,10 +160,13 @@ def main():
         if world > 1:
             comm = qdist.ShardComm(dim, rank=rank, world=world, device=device, stream=stream).attach(A)
         info = A.info()
-        nnz_total = torch.tensor([info.nnz], dtype=torch.int64, device=device)
-        if world > 1:
-            dist.all_reduce(nnz_total)
-        nnz_total = int(nnz_total.item())
+        def allreduce_host(vals, op):
+            t = torch.tensor(vals, dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            if world > 1:
+                dist.all_reduce(t, op=op)
+            return [float(z) for z in t.tolist()]
+
+        nnz_total = int(allreduce_host([float(info.nnz)], dist.ReduceOp.SUM)[0])
 
         K, Wm = args.steps, args.warmup
         maxit = max(K + Wm + 16, 64)
@@ -200,10 +210,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         st = A.stats()
-        el = torch.tensor([elapsed, st.ms_spmv / max(st.n_spmv, 1)], dtype=torch.float64, device=device)
-        if world > 1:
-            dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed, ms_spmv = float(el[0].item()), float(el[1].item())
+        elapsed, ms_spmv = allreduce_host([elapsed, st.ms_spmv / max(st.n_spmv, 1)], dist.ReduceOp.MAX)
 
         # untimed: run the same solver to convergence for E0 (parity across N and vs the small-size oracle tests)
         e0 = steps_e0 = None

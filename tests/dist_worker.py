@@ -1,0 +1,114 @@
+"""Worker for the multi-process tests (spawned by test_dist_cpu.py / test_gpu_dist.py)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _init(rank, world, port, backend):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return dist
+
+
+def cpu_sharded_lanczos(rank, world, port, case_name, steps, out_dir):
+    """The sharded three-term recurrence with the real exchange hooks (ShardComm, gloo, CPU
+    tensors); the shard-local arithmetic is done by the ORACLE here (test double for the HIP
+    kernels, which cannot run without a GPU).  Checks the partition, the gather layout and
+    the scalar reductions against the unsharded oracle."""
+    import torch
+    dist = _init(rank, world, port, "gloo")
+    import helpers
+    from oracle import qb_oracle as qo
+    from quantum_basis_amd import dist as qdist
+
+    d, ia, ja, val, sym = helpers.case(case_name)
+    full = qo.Csr(d, ia, ja, val, sym).expand_full()
+    comm = qdist.ShardComm(d, rank=rank, world=world, device=torch.device("cpu"))
+    r0, r1 = comm.ranges[rank]
+    n = r1 - r0
+    # shard-local CSR (rows r0..r1, global columns)
+    sia = full.ia[r0:r1 + 1] - full.ia[r0]
+    sja = full.ja[full.ia[r0]:full.ia[r1]]
+    sval = full.val[full.ia[r0]:full.ia[r1]]
+
+    def gather(x_loc):
+        buf = np.zeros(comm.nblk, dtype=np.complex128)
+        buf[:n] = x_loc
+        comm.xsend.copy_(torch.from_numpy(buf.view(np.float64)))
+        assert comm._allgather(None) == 0, comm.errors
+        return comm.xfull.numpy().view(np.complex128)
+
+    def allreduce(vals):
+        comm.scal[:len(vals)] = torch.tensor(vals, dtype=torch.float64)
+        assert comm._allreduce(None, 0, len(vals)) == 0, comm.errors
+        return comm.scal[:len(vals)].tolist()
+
+    def spmv(x_loc):
+        xf = gather(x_loc)
+        y = np.zeros(n, dtype=np.complex128)
+        for i in range(n):
+            sl = slice(sia[i], sia[i + 1])
+            y[i] = np.dot(sval[sl], xf[sja[sl]])
+        return y
+
+    x_full = qo.vec_randomize(d, 1)
+    v_prev = np.zeros(n, dtype=np.complex128)
+    v = x_full[r0:r1].copy()
+    a, b = [], [0.0]
+    for m in range(steps):
+        w = spmv(v) - b[-1] * v_prev
+        (am,) = allreduce([np.vdot(v, w).real])
+        w -= am * v
+        (nn,) = allreduce([np.vdot(w, w).real])
+        bm = np.sqrt(nn)
+        a.append(am)
+        b.append(bm)
+        v_prev, v = v, w / bm
+    if rank == 0:
+        np.save(os.path.join(out_dir, "ab.npy"), np.array([a, b[1:]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gpu_sharded_solver(rank, world, port, backend, out_dir):
+    """Real thing on the GPU: every rank builds its row shard on cuda:0 (single-GPU rig: the
+    ranks share one device and exchange through gloo + host staging; with backend nccl and one
+    rank the RCCL calls themselves are exercised) and runs qbh_lanczos_dev / CG under the
+    communicator hooks."""
+    import torch
+    dist = _init(rank, world, port, backend)
+    torch.cuda.set_device(0)
+    import quantum_basis_amd as q
+    from quantum_basis_amd import dist as qdist, lattices
+
+    bonds = lattices.square(4, 2)
+    dim = 4900
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        opts = q.make_opts(device=0, stream=stream.cuda_stream)
+        nblk, ranges = qdist.row_partition(dim, world)
+        r0, r1 = ranges[rank]
+        A = q.csr_mat.hubbard(8, 4, 4, bonds, rows=(r0, r1), opts=opts)
+        comm = qdist.ShardComm(dim, rank=rank, world=world, device=torch.device("cuda", 0), stream=stream).attach(A)
+        res = q.locate_E0_lanczos(A, nev=2, ncv=1, maxit=400)
+        assert not comm.errors, comm.errors
+        x = q.vec_randomize(A, seed=1)                 # shard of the global start vector
+        np.save(os.path.join(out_dir, "x_%d.npy" % rank), x)
+        np.save(os.path.join(out_dir, "vec_%d.npy" % rank), res.eigenvecs)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "res.npy"), np.array([res.E0, res.E1, res.steps["E0"], res.steps["V0"], res.steps["E1"]]))
+            np.save(os.path.join(out_dir, "hess.npy"), res.hessenberg_E0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    pass

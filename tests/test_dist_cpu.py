@@ -1,0 +1,50 @@
+"""world_size-2 gloo tests of the N > 1 host logic (runs without a GPU): row partition,
+exchange-buffer layout, the ShardComm hooks that libqbhip.so calls back into, and the sharded
+recurrence built on them."""
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+
+import helpers
+from oracle import qb_oracle as qo
+from quantum_basis_amd import dist as qdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_row_partition_covers_and_pads():
+    for ncols, world in [(10, 1), (10, 3), (4900, 2), (4900, 8), (7, 8), (165636900, 8)]:
+        nblk, ranges = qdist.row_partition(ncols, world)
+        assert nblk * world >= ncols and nblk * (world - 1) < ncols + nblk
+        assert ranges[0][0] == 0 and ranges[-1][1] == ncols
+        for r, (a, b) in enumerate(ranges):
+            assert a == min(r * nblk, ncols) and 0 <= b - a <= nblk
+        assert sum(b - a for a, b in ranges) == ncols
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_lanczos_with_gloo_hooks(world):
+    import torch.multiprocessing as mp
+    import dist_worker
+    steps = 12
+    name = "kagome_12"
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(dist_worker.cpu_sharded_lanczos, args=(world, _free_port(), name, steps, tmp), nprocs=world, join=True)
+        ab = np.load(tmp + "/ab.npy")
+    d, ia, ja, val, sym = helpers.case(name)
+    O = qo.Csr(d, ia, ja, val, sym)
+    maxit = 64
+    v = np.zeros(2 * d, dtype=np.complex128)
+    v[:d] = qo.vec_randomize(d, 1)
+    hess = np.zeros(2 * maxit)
+    qo.lanczos(0, steps, maxit, O, v, hess, "dnmcs")
+    assert np.allclose(ab[0], hess[maxit:maxit + steps], rtol=1e-10)
+    assert np.allclose(ab[1], hess[1:steps + 1], rtol=1e-10)

@@ -8,8 +8,8 @@ import sys
 def main():
     root, cmd = sys.argv[1], sys.argv[2]
     print("# rocprofv3 --kernel-trace --stats -- %s" % cmd)
-    print("# durations in microseconds")
-    print("%-86s %8s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
+    print("# durations in milliseconds")
+    print("%-86s %8s %14s %12s %7s" % ("kernel", "calls", "total_ms", "avg_ms", "pct"))
     for db_path in sorted(glob.glob(root + "/*results.db")):
         db = sqlite3.connect(db_path)
         for name, calls, total, avg, pct in db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
