@@ -1,0 +1,161 @@
+// qbhip_qbasis.hpp -- header-only C++ adaptor: the reference's operator concept on top of the
+// C ABI of libqbhip.so.
+//
+// The reference's solvers are templated on a duck-typed MAT (src/qbasis.h:1065-1093):
+//     void MultMv2(const T *x, T *y) const;   // y += H x   (src/lanczos.cc:170,197,301,322)
+//     void MultMv (const T *x, T *y) const;   // y  = H x   (src/lanczos.cc:426,476; ARPACK workd slices)
+//     std::vector<T> to_dense() const;        // dim <= 30  (src/lanczos.cc:509)
+// and its only sparse model is csr_mat<T> (src/qbasis.h:976-1021).  qbhip::csr_mat below has
+// the same public surface and error behaviour (std::runtime_error where the reference throws,
+// src/sparse.cc:130,259,288), holds the host CSR arrays exactly like the reference does, and
+// keeps a device-resident copy behind the `handle` member -- the slot where the reference
+// stores MKL's sparse_matrix_t.
+//
+// qbhip::lanczos / eigenvec_CG / hess_eigen have the reference's signatures
+// (src/qbasis.h:1065-1082) and forward to the fused device solvers, so a maintainer can
+// replace the bodies of the csr_mat instantiations in src/lanczos.cc by one call each (see
+// INTEGRATION.md).
+#pragma once
+
+#include <complex>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "qbhip.h"
+
+namespace qbhip {
+
+using cplx = std::complex<double>;
+using qint = long long;   // MKL_INT under -DMKL_ILP64
+
+inline void check(int rc, const char *where)
+{
+    if (rc == QBH_OK) return;
+    const std::string msg = std::string(where) + ": " + qbh_strerror(rc) + " (" + qbh_last_error() + ")";
+    if (rc == QBH_EINVAL) throw std::invalid_argument(msg);
+    throw std::runtime_error(msg);
+}
+
+class csr_mat {
+public:
+    qint dim = 0;
+    qint nnz = 0;
+    bool sym = false;          // only the upper triangle stored (reference default)
+    cplx *val = nullptr;       // host arrays, owned, same layout as src/qbasis.h:979-985
+    qint *ja = nullptr;
+    qint *ia = nullptr;
+    qbh_csr *handle = nullptr; // device operator (the reference keeps sparse_matrix_t here)
+
+    csr_mat() = default;
+
+    // adopt host CSR arrays allocated with new[] (what csr_mat(lil_mat&) produces, src/sparse.cc:202-260)
+    csr_mat(qint dim_, qint nnz_, bool sym_, cplx *val_, qint *ja_, qint *ia_, const qbh_opts *opts = nullptr)
+        : dim(dim_), nnz(nnz_), sym(sym_), val(val_), ja(ja_), ia(ia_)
+    {
+        static_assert(sizeof(qint) == sizeof(int64_t) && sizeof(cplx) == sizeof(qbh_z), "ILP64 / complex128 layout");
+        check(qbh_csr_create(&handle, dim, nnz, sym ? 1 : 0, reinterpret_cast<const int64_t *>(ia),
+                             reinterpret_cast<const int64_t *>(ja), reinterpret_cast<const qbh_z *>(val), opts),
+              "create_handle failed");                       // src/sparse.cc:259
+    }
+
+    csr_mat(const csr_mat &old) : dim(old.dim), nnz(old.nnz), sym(old.sym)   // deep copy, src/sparse.cc:114-138
+    {
+        if (nnz > 0) {
+            val = new cplx[nnz];
+            ja = new qint[nnz];
+            ia = new qint[dim + 1];
+            for (qint j = 0; j < nnz; j++) { val[j] = old.val[j]; ja[j] = old.ja[j]; }
+            for (qint j = 0; j <= dim; j++) ia[j] = old.ia[j];
+            check(qbh_csr_create(&handle, dim, nnz, sym ? 1 : 0, reinterpret_cast<const int64_t *>(ia),
+                                 reinterpret_cast<const int64_t *>(ja), reinterpret_cast<const qbh_z *>(val), nullptr),
+                  "create_handle failed");
+        }
+    }
+
+    csr_mat(csr_mat &&old) noexcept
+        : dim(old.dim), nnz(old.nnz), sym(old.sym), val(old.val), ja(old.ja), ia(old.ia), handle(old.handle)
+    {
+        old.val = nullptr; old.ja = nullptr; old.ia = nullptr; old.handle = nullptr;
+    }
+
+    csr_mat &operator=(csr_mat old) { swap(*this, old); return *this; }
+
+    friend void swap(csr_mat &l, csr_mat &r) noexcept
+    {
+        using std::swap;
+        swap(l.dim, r.dim); swap(l.nnz, r.nnz); swap(l.sym, r.sym);
+        swap(l.val, r.val); swap(l.ja, r.ja); swap(l.ia, r.ia); swap(l.handle, r.handle);
+    }
+
+    void destroy()                                           // src/sparse.cc:150-167
+    {
+        delete[] val; val = nullptr;
+        delete[] ja; ja = nullptr;
+        delete[] ia; ia = nullptr;
+        qbh_csr_destroy(handle); handle = nullptr;
+    }
+
+    ~csr_mat() { destroy(); }
+
+    qint dimension() const { return dim; }
+
+    void MultMv2(const cplx *x, cplx *y) const               // y = H * x + y, src/sparse.cc:262-289
+    {
+        check(qbh_multmv2(handle, reinterpret_cast<const qbh_z *>(x), reinterpret_cast<qbh_z *>(y)),
+              "matrix-vector product failed.");
+    }
+
+    void MultMv(const cplx *x, cplx *y) const                // y = H * x, src/sparse.cc:291-297
+    {
+        check(qbh_multmv(handle, reinterpret_cast<const qbh_z *>(x), reinterpret_cast<qbh_z *>(y)),
+              "matrix-vector product failed.");
+    }
+
+    std::vector<cplx> to_dense() const                       // src/sparse.cc:299-315 (host arrays)
+    {
+        std::vector<cplx> res(dim * dim, cplx(0.0));
+        for (qint row = 0; row < dim; row++)
+            for (qint pt = ia[row]; pt < ia[row + 1]; pt++) {
+                const qint col = ja[pt];
+                res[row + col * dim] = val[pt];
+                if (sym && row != col) res[col + row * dim] = std::conj(val[pt]);
+            }
+        return res;
+    }
+};
+
+// lanczos<T, csr_mat<T>> (src/lanczos.cc:134-266): vectors stay in HBM for the whole call.
+inline void lanczos(qint k, qint np, const qint &maxit, qint &m, const qint &dim, const csr_mat &mat, cplx v[],
+                    double hessenberg[], const std::string &purpose)
+{
+    if (dim != mat.dim) throw std::invalid_argument("lanczos: dim mismatch");
+    int64_t mm = 0;
+    check(qbh_lanczos(mat.handle, k, np, maxit, &mm, reinterpret_cast<qbh_z *>(v), hessenberg, purpose.c_str(), nullptr),
+          "lanczos");
+    m = mm;
+}
+
+// eigenvec_CG<T, csr_mat<T>> (src/lanczos.cc:281-341)
+inline void eigenvec_CG(const qint &dim, const qint &maxit, qint &m, const csr_mat &mat, const cplx &E0, double &accu,
+                        cplx v[], cplx r[], cplx p[], cplx pp[])
+{
+    if (dim != mat.dim) throw std::invalid_argument("eigenvec_CG: dim mismatch");
+    int64_t mm = m;
+    check(qbh_eigenvec_cg(mat.handle, maxit, &mm, E0.real(), &accu, reinterpret_cast<qbh_z *>(v),
+                          reinterpret_cast<qbh_z *>(r), reinterpret_cast<qbh_z *>(p), reinterpret_cast<qbh_z *>(pp), nullptr),
+          "eigenvec_CG");
+    m = mm;
+}
+
+// hess_eigen (src/lanczos.cc:355-390)
+inline void hess_eigen(const double hessenberg[], const qint &maxit, const qint &m, const std::string &order,
+                       std::vector<double> &ritz, std::vector<double> &s)
+{
+    ritz.resize(m);
+    s.resize(m * m);
+    check(qbh_hess_eigen(hessenberg, maxit, m, order.c_str(), ritz.data(), s.data()), "hess_eigen");
+}
+
+}  // namespace qbhip

@@ -1,0 +1,60 @@
+"""The C++ adaptor header (include/qbhip_qbasis.hpp) compiles with plain g++, links against
+libqbhip.so, and (on the GPU box) reproduces the oracle's numbers from a C++ host program."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import helpers
+from oracle import qb_oracle as qo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(tmp):
+    exe = os.path.join(tmp, "adaptor_main")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cxx", "adaptor_main.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "quantum_basis_amd"), "-lqbhip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "quantum_basis_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def _dump(tmp, name):
+    d, ia, ja, val, sym = helpers.case(name)
+    x = qo.vec_randomize(d, 1)
+    path = os.path.join(tmp, "csr.bin")
+    with open(path, "wb") as f:
+        np.array([d, len(ja), int(sym)], dtype=np.int64).tofile(f)
+        ia.tofile(f), ja.tofile(f), val.tofile(f), x.tofile(f)
+    return path, qo.Csr(d, ia, ja, val, sym), x
+
+
+def test_adaptor_compiles_links_and_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = _build(tmp)
+        path, _, _ = _dump(tmp, "chain12_sz0")
+        p = subprocess.run([exe, path], capture_output=True, text=True)
+        assert p.returncode == 3 and "no HIP device" in p.stdout     # std::runtime_error, no CPU fallback
+
+
+@pytest.mark.gpu
+def test_adaptor_cxx_host_program_matches_oracle():
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = _build(tmp)
+        path, O, x = _dump(tmp, "hubbard_4x2")
+        p = subprocess.run([exe, path], capture_output=True, text=True)
+        assert p.returncode == 0, p.stdout + p.stderr
+        tok = p.stdout.split()
+        assert tok[0] == "OK"
+        sr, si, sr2, m, E0, mcg, accu, d = [float(t) for t in tok[1:]]
+        y = O.multmv(x)
+        assert abs(sr - y.sum().real) < 1e-11 and abs(si - y.sum().imag) < 1e-11
+        assert abs(sr2 - 2 * y.sum().real) < 1e-11          # MultMv2 accumulated onto MultMv's result
+        assert abs(m - 82) <= 1 and abs(E0 + 14.076058658879278) < 1e-9
+        assert abs(mcg - 83) <= 2 and accu < 2e-12 and d < 1e-9
