@@ -109,9 +109,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("QBH_WORKLOAD", "hubbard_4x4_half"))
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 stream, 2 vector")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto (rows), 1 stream, 2 vector, 3 rows")
     ap.add_argument("--npb", type=int, default=0)
-    ap.add_argument("--no-swizzle", action="store_true")
+    ap.add_argument("--swizzle", type=int, default=2)
     ap.add_argument("--value-dict", type=int, default=1, help="1: dictionary-code the value stream when <=256 distinct values (lossless)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed run to convergence (E0)")
@@ -151,7 +151,7 @@ def main():
     stream = torch.cuda.Stream(device=device)
     with torch.cuda.stream(stream):
         opts = q.make_opts(device=local_rank, stream=stream.cuda_stream, spmv_kernel=args.kernel,
-                           nnz_per_block=args.npb, xcd_swizzle=0 if args.no_swizzle else 1,
+                           nnz_per_block=args.npb, xcd_swizzle=args.swizzle,
                            value_dict=args.value_dict, profile=1)
         t_gen = time.time()
         A = build_operator(W, (r0, r1), opts)
@@ -231,9 +231,9 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "complex128 (f64)",
         "data": "synthetic", "config": {"workload": args.workload, "dim": dim, "nnz_full": nnz_total,
                                          "rows_per_gpu": info.nrows, "parallelism": "row-shard x%d" % world,
-                                         "kernel": {1: "stream", 2: "vector"}[info.kernel], "value_dict": info.value_dict,
+                                         "kernel": {1: "stream", 2: "vector", 3: "rows"}[info.kernel], "value_dict": info.value_dict,
                                          "build_s": round(t_gen, 3)},
-        "roofline": {"bound": "hbm", "kernel": "k_spmv_stream" if info.kernel == 1 else "k_spmv_vector",
+        "roofline": {"bound": "hbm", "kernel": {1: "k_spmv_stream", 2: "k_spmv_vector", 3: "k_spmv_rows"}[info.kernel],
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "bytes_per_launch": bytes_launch, "ms_per_launch": round(ms_spmv, 4), "launches": int(st.n_spmv)},

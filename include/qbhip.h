@@ -59,16 +59,18 @@ const char *qbh_strerror(int code);
 const char *qbh_last_error(void);                   /* thread-local detail of the last failure */
 
 /* ------------------------------------------------------------- options --- */
-#define QBH_KERNEL_AUTO    0
-#define QBH_KERNEL_STREAM  1   /* row-block streaming through LDS (default)        */
-#define QBH_KERNEL_VECTOR  2   /* sub-wavefront per row, shuffle reduction         */
+#define QBH_KERNEL_AUTO    0   /* = QBH_KERNEL_ROWS                                           */
+#define QBH_KERNEL_STREAM  1   /* row blocks, val*x products through LDS, TPR lanes per row   */
+#define QBH_KERNEL_VECTOR  2   /* sub-wavefront per row, shuffle reduction, no LDS            */
+#define QBH_KERNEL_ROWS    3   /* row blocks staged in LDS, lanes mapped to rows (default)    */
 
 typedef struct qbh_opts {
     int     device;          /* HIP ordinal; -1 = current device                                  */
     void   *stream;          /* hipStream_t to enqueue on; NULL = library-owned stream             */
     int     spmv_kernel;     /* QBH_KERNEL_*                                                       */
-    int     nnz_per_block;   /* streaming kernel: nonzeros staged per workgroup; 0 = default       */
-    int     xcd_swizzle;     /* 1 (default): map workgroups so each XCD walks a contiguous range   */
+    int     nnz_per_block;   /* nonzeros staged per workgroup (1024/2048/4096/8192); 0 = auto      */
+    int     xcd_swizzle;     /* workgroup->row-block map: 0 interleaved, 1 one contiguous eighth per
+                                XCD, 2 (default) chunked: neighbouring chunks on the 8 XCDs          */
     int     value_dict;      /* 0 = store complex128 values; 1 = dictionary-code them when <=256
                                 distinct values exist (exact, lossless)                            */
     int     profile;         /* 1: bracket every SpMV launch with HIP events (qbh_get_stats)       */

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libqbhip.so")
 
 QBH_OK = 0
-KERNEL_AUTO, KERNEL_STREAM, KERNEL_VECTOR = 0, 1, 2
+KERNEL_AUTO, KERNEL_STREAM, KERNEL_VECTOR, KERNEL_ROWS = 0, 1, 2, 3
 
 
 class QbhError(RuntimeError):

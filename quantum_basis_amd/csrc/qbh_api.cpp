@@ -66,7 +66,7 @@ extern "C" void qbh_opts_default(qbh_opts *o)
     o->stream = nullptr;
     o->spmv_kernel = QBH_KERNEL_AUTO;
     o->nnz_per_block = 0;
-    o->xcd_swizzle = 1;
+    o->xcd_swizzle = 2;
     o->value_dict = 0;
     o->profile = 0;
     o->check_hermitian = 1;
@@ -135,18 +135,35 @@ int finalize(qbh_csr *A)
     QBH_HIP(hipMemcpyAsync(&maxlen, A->d_scal, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     QBH_HIP(hipStreamSynchronize(s));
 
+    // value dictionary first: it decides how much LDS a row block needs
+    QBH_TRY(try_value_dict(A));
+    const bool coded = A->d_code != nullptr;
+
     const double avg = A->nrows > 0 ? (double)A->nnz / (double)A->nrows : 0.0;
-    A->kernel = (o.spmv_kernel == QBH_KERNEL_VECTOR) ? QBH_KERNEL_VECTOR : QBH_KERNEL_STREAM;
-    A->npb = o.nnz_per_block > 0 ? o.nnz_per_block : 2048;
-    if (A->npb != 1024 && A->npb != 2048 && A->npb != 4096) {
-        qbh::set_error("nnz_per_block must be 1024, 2048 or 4096");
+    A->kernel = (o.spmv_kernel == QBH_KERNEL_VECTOR) ? QBH_KERNEL_VECTOR
+              : (o.spmv_kernel == QBH_KERNEL_STREAM) ? QBH_KERNEL_STREAM : QBH_KERNEL_ROWS;
+    if (A->kernel == QBH_KERNEL_ROWS) {
+        // measured on C3: coded 8192/P=1/8 gathers in flight is HBM-bound on its real
+        // traffic; the plain kernel stages 16-byte values and is limited to 2048 by LDS occupancy.
+        int npb = coded ? 8192 : 2048;
+        const double cap_rows = 0.75 * qbh::kRowCap * (avg > 1.0 ? avg : 1.0);   // keep rows/block under kRowCap
+        while (npb > 1024 && (double)npb > cap_rows) npb >>= 1;
+        A->npb = o.nnz_per_block > 0 ? o.nnz_per_block : npb;
+        A->tpr = avg <= 64 ? 1 : avg <= 128 ? 2 : avg <= 256 ? 4 : 8;
+        if (!coded && avg > 12) A->tpr = avg <= 96 ? 4 : 8;
+        A->unroll = A->tpr == 1 ? 8 : 4;
+    } else {
+        A->npb = o.nnz_per_block > 0 ? o.nnz_per_block : 2048;
+        if (A->kernel == QBH_KERNEL_VECTOR) A->tpr = avg <= 6 ? 4 : avg <= 12 ? 8 : avg <= 40 ? 16 : avg <= 96 ? 32 : 64;
+        else                                A->tpr = avg <= 3 ? 1 : avg <= 8 ? 2 : avg <= 48 ? 4 : avg <= 128 ? 8 : 16;
+    }
+    if (A->npb != 1024 && A->npb != 2048 && A->npb != 4096 && !(A->npb == 8192 && A->kernel == QBH_KERNEL_ROWS && coded)) {
+        qbh::set_error("nnz_per_block must be 1024, 2048 or 4096 (8192: row kernel with value dictionary only)");
         return QBH_EINVAL;
     }
-    if (A->kernel == QBH_KERNEL_VECTOR) {
-        A->tpr = avg <= 6 ? 4 : avg <= 12 ? 8 : avg <= 40 ? 16 : avg <= 96 ? 32 : 64;
-    } else {
-        A->tpr = avg <= 3 ? 1 : avg <= 8 ? 2 : avg <= 48 ? 4 : avg <= 128 ? 8 : 16;
-    }
+    if (const char *e = getenv("QBH_TPR")) A->tpr = atoi(e);            // tuning experiments
+    if (const char *e = getenv("QBH_UNROLL")) A->unroll = atoi(e);
+    if (const char *e = getenv("QBH_FAR")) A->far = atoi(e);
     // a block holds the rows that START inside its window, so it can exceed the window by
     // one row; keep window + maxlen - 1 <= npb when rows are short, otherwise let the
     // oversized-block path take the few long rows.
@@ -160,7 +177,6 @@ int finalize(qbh_csr *A)
     const size_t nparts = (size_t)std::max(A->grid, qbh::kMaxRedBlocks);
     QBH_HIP(hipMalloc(&A->d_partials, nparts * 4 * sizeof(double)));
     QBH_HIP(hipStreamSynchronize(s));
-    QBH_TRY(try_value_dict(A));
     A->stats = qbh_stats{};
     A->stats.ms_spmv_min = std::numeric_limits<double>::infinity();
     return QBH_OK;
@@ -199,7 +215,7 @@ int try_value_dict(qbh_csr *A)
     if (!A->opts.value_dict || !A->d_val || A->d_code || A->nnz <= 0) return QBH_OK;
     uint8_t *code = nullptr;
     d2 *dict = nullptr;
-    QBH_HIP(hipMalloc(&code, (size_t)A->nnz));
+    QBH_HIP(hipMalloc(&code, (size_t)A->nnz + 16));      // k_spmv_rows reads whole 8-byte words
     hipError_t e = hipMalloc(&dict, 256 * sizeof(d2));
     if (e != hipSuccess) {
         (void)hipFree(code);
@@ -525,8 +541,11 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     a.gamma = gamma;
     a.partials = red ? A->d_partials : nullptr;
     a.swizzle = A->opts.xcd_swizzle;
+    a.unroll = A->unroll;
+    a.far = A->far;
+    a.col0 = A->row_offset;
     a.colmask = (A->debug & 1) ? 1023 : -1;
-    a.debug2 = (A->debug & 2) ? 1 : 0;
+    a.debug2 = (A->debug & 2) ? 1 : (A->debug & 4) ? 2 : (A->debug & 8) ? 3 : 0;
     const bool prof = A->opts.profile != 0;
     if (prof) {
         harvest_events(A);

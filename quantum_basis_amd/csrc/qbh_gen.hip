@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <string>
 #include <vector>
 
 #include "qbh_internal.hpp"

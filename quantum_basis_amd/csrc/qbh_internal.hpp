@@ -52,6 +52,9 @@ struct SpmvArgs {
     double         alpha, beta, gamma;
     double        *partials;   // [grid*3] or nullptr
     int            swizzle;
+    int            far;        // k_spmv_rows: |col-row| beyond which x is gathered non-temporal (0: off)
+    int64_t        col0;       // global index of the shard's first row
+    int            unroll;     // k_spmv_rows: gathers in flight per lane and loop trip
     int            debug2;     // QBH_DEBUG bit1: stream loads only, no LDS/reduce (timing experiments only)
     int            colmask;    // -1; QBH_DEBUG=1 sets 1023 so the gather stays in cache (timing experiments only)
 };
@@ -102,6 +105,7 @@ struct qbh_csr {
     // streaming kernel geometry
     int      kernel = QBH_KERNEL_STREAM;
     int      npb = 2048;       // LDS product slots per workgroup
+    int      unroll = 4;
     int      tpr = 4;          // threads cooperating on one row in the reduce phase
     int64_t  window = 0;       // nnz window that defines a row block
     int64_t  n_blocks = 0;
@@ -124,4 +128,5 @@ struct qbh_csr {
     qbh_stats stats{};
     bool      ev_pending = false;
     int       debug = 0;
+    int       far = 0;
 };

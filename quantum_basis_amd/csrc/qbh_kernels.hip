@@ -70,8 +70,20 @@ struct BlockWalk {
         slot = blockIdx.x >> 3;
         nslot = gridDim.x >> 3;
         swz = swizzle;
+        // mode 2 walks chunk-wise; round the per-XCD count up to whole chunks so every block is visited
+        if (swz == 2) per_xcd = ((per_xcd + nslot - 1) / nslot) * nslot;
     }
-    __device__ int64_t block(int64_t lb) const { return swz ? xcd * per_xcd + lb : lb * 8 + xcd; }
+    // lb = this XCD's local sequence number (slot, slot + nslot, ...).
+    //  0: interleaved           block = lb*8 + xcd        (all XCDs sweep the same region)
+    //  1: contiguous eighths    block = xcd*per_xcd + lb  (each XCD owns one eighth of the rows)
+    //  2: chunked               the concurrently resident workgroups of an XCD (nslot of them) take
+    //                           one contiguous chunk; the 8 XCDs take 8 neighbouring chunks
+    __device__ int64_t block(int64_t lb) const
+    {
+        if (swz == 1) return xcd * per_xcd + lb;
+        if (swz == 2) return ((lb / nslot) * 8 + xcd) * nslot + (lb % nslot);
+        return lb * 8 + xcd;
+    }
 };
 
 // fused epilogue of one row: y <- alpha*(Hx) + beta*y + gamma*x_local, and the running
@@ -249,6 +261,209 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(SpmvArgs a)
     }
 }
 
+// ------------------------------------------------ row-aligned SpMV -------------
+// Same row blocks as k_spmv_stream, different use of LDS.  Phase 1 stages only the block's
+// (col, value-or-code) ranges into LDS with coalesced non-temporal loads.  Phase 2 maps LANES
+// TO ROWS: sub-slice s of P handles steps k = s, s+P, ... of each of R = 256/P consecutive
+// rows, so at every step the lanes of a wavefront gather the k-th entries of consecutive rows.
+// For Kronecker-structured Hamiltonians (H = T_up (x) 1 + 1 (x) T_dn + D) the leading and the
+// trailing entries of consecutive rows point at CONSECUTIVE x elements, so stepping alternately
+// from the front and from the back of the row turns those gathers into full-line coalesced
+// loads.  Row sums stay in registers (no 16-byte products through LDS, no shuffle tree);
+// with the value dictionary the LDS footprint is 5 B/nnz and 8 workgroups fit a CU.
+template <int NPB, int P, int UN, bool DICT>
+__global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
+{
+    constexpr int R = kBlock / P;            // rows per pass
+    constexpr int U = NPB / kBlock;          // staged cols per lane
+    constexpr int UC = (NPB / 8 + kBlock - 1) / kBlock;   // 8-byte code words per lane
+    __shared__ int scol[NPB];
+    __shared__ d2 sval[DICT ? 1 : NPB];
+    __shared__ unsigned long long scode8[DICT ? NPB / 8 : 1];
+    __shared__ d2 dict_s[DICT ? 256 : 1];
+    __shared__ int rowoff[kRowCap + 1];
+    __shared__ d2 part[P > 1 ? kBlock : 1];
+    __shared__ double red[12];
+
+    const int tid = threadIdx.x;
+    const int sub = tid / R, rloc = tid % R;
+    double acc[3] = {0.0, 0.0, 0.0};
+    const bool need_y = a.beta != 0.0;
+    const bool need_x = a.gamma != 0.0 || a.partials != nullptr;
+    const uint8_t *scode = reinterpret_cast<const uint8_t *>(scode8);
+
+    if (DICT) {
+        dict_s[tid] = a.dict[tid];
+        __syncthreads();
+    }
+
+    BlockWalk walk(a.n_blocks, a.swizzle);
+    int64_t lb = walk.slot;
+    int64_t b = walk.block(lb);
+    bool live = lb < walk.per_xcd && b < a.n_blocks;
+    int r0 = 0, r1 = 0;
+    int64_t p0 = 0, p1 = 0;
+    if (live) {
+        r0 = a.rb[b]; r1 = a.rb[b + 1];
+        p0 = a.bp[b]; p1 = a.bp[b + 1];
+    }
+    while (lb < walk.per_xcd) {
+        const int64_t lb_n = lb + walk.nslot;
+        const int64_t b_n = walk.block(lb_n);
+        const bool live_n = lb_n < walk.per_xcd && b_n < a.n_blocks;
+        int r0_n = 0, r1_n = 0;
+        int64_t p0_n = 0, p1_n = 0;
+        if (live_n) {
+            r0_n = a.rb[b_n]; r1_n = a.rb[b_n + 1];
+            p0_n = a.bp[b_n]; p1_n = a.bp[b_n + 1];
+        }
+        const int nr = r1 - r0;
+        const int64_t nlong = p1 - p0;
+        if (live && nr > 0) {
+            if (nlong <= NPB && nr <= kRowCap) {
+                const int n = (int)nlong;
+                // ---- phase 1: stage the block's index / value streams ----
+                const int ro = (int)(a.ia[r0 + (tid <= nr ? tid : 0)] - p0);
+                d2 yo = {0.0, 0.0}, xi = {0.0, 0.0};
+                const bool mine = sub == 0 && rloc < nr;
+                if (mine && need_y) yo = a.y[r0 + rloc];
+                if (mine && need_x) xi = a.xl[r0 + rloc];
+                if (n > 0) {
+                    const int32_t *jp = a.ja + p0;
+                    const int nm1 = n - 1;
+                    int c[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int i = tid + u * kBlock;
+                        c[u] = ntload(jp + (i < n ? i : nm1)) & a.colmask;
+                    }
+                    if (DICT) {
+                        unsigned long long w[UC];
+                        const int nw = (n + 7) >> 3;                 // 8-byte words covering the codes
+#pragma unroll
+                        for (int u = 0; u < UC; ++u) {
+                            const int i = tid + u * kBlock;
+                            // unaligned 8-byte global load; the last word may read up to 7 bytes past the
+                            // block's range but never past the code array (padded by 8 bytes at build)
+                            w[u] = ntload(reinterpret_cast<const unsigned long long *>(a.code + p0) + (i < nw ? i : 0));
+                        }
+#pragma unroll
+                        for (int u = 0; u < UC; ++u) {
+                            const int i = tid + u * kBlock;
+                            if (i < NPB / 8) scode8[i] = w[u];
+                        }
+                    } else {
+                        d2 v[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int i = tid + u * kBlock;
+                            v[u] = ntload(a.val + p0 + (i < n ? i : nm1));
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) sval[tid + u * kBlock] = v[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) scol[tid + u * kBlock] = c[u];
+                }
+                if (tid <= nr) rowoff[tid] = ro;
+                for (int i = tid + kBlock; i <= nr; i += kBlock) rowoff[i] = (int)(a.ia[r0 + i] - p0);
+                __syncthreads();
+                // ---- phase 2: lanes <-> rows ----
+                for (int rbase = 0; rbase < nr; rbase += R) {
+                    const int row = rbase + rloc;
+                    const bool rowok = row < nr;
+                    const int grow = (int)a.col0 + r0 + row;          // global row index == diagonal column
+                    const int base = rowok ? rowoff[row] : 0;
+                    const int len = rowok ? rowoff[row + 1] - base : 0;
+                    int wmax = len;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const int o = __shfl_xor(wmax, off, 64);
+                        wmax = o > wmax ? o : wmax;
+                    }
+                    d2 sum = {0.0, 0.0};
+                    for (int k0 = sub; k0 < wmax; k0 += UN * P) {
+                        int cc[UN];
+                        int ix[UN];
+                        bool ok[UN];
+#pragma unroll
+                        for (int j = 0; j < UN; ++j) {
+                            const int k = k0 + j * P;
+                            ok[j] = k < len;
+                            const int f = (k & 1) ? len - 1 - (k >> 1) : (k >> 1);   // front / back alternation
+                            ix[j] = base + (ok[j] ? f : 0);
+                            cc[j] = scol[ix[j]];
+                        }
+                        d2 xv[UN], vv[UN];
+#pragma unroll
+                        for (int j = 0; j < UN; ++j) {
+                            // far columns are use-once streams for this part of the sweep: load them
+                            // non-temporal so they do not evict the near (re-used) window of x from L2
+                            const int dist = cc[j] - grow;
+                            const bool isfar = a.far > 0 && (dist > a.far || dist < -a.far);
+                            if (a.debug2 == 2 && isfar) cc[j] &= 1023;          // experiment: drop far traffic
+                            if (a.debug2 == 3 && !isfar) cc[j] &= 1023;         // experiment: drop near traffic
+                            if (isfar) xv[j] = ntload(a.xg + cc[j]);
+                            else xv[j] = a.xg[cc[j]];
+                        }
+#pragma unroll
+                        for (int j = 0; j < UN; ++j) {
+                            if (DICT) vv[j] = dict_s[scode[ix[j]]];
+                            else      vv[j] = sval[ix[j]];
+                        }
+#pragma unroll
+                        for (int j = 0; j < UN; ++j)
+                            if (ok[j]) sum += cmul(vv[j], xv[j]);
+                    }
+                    if (P > 1) {
+                        part[tid] = sum;
+                        __syncthreads();
+                        if (sub == 0) {
+#pragma unroll
+                            for (int s2 = 1; s2 < P; ++s2) sum += part[s2 * R + rloc];
+                        }
+                    }
+                    if (sub == 0 && rowok) {
+                        if (rbase == 0) row_epilogue2(a, (int64_t)r0 + row, sum, yo, xi, acc);
+                        else            row_epilogue(a, (int64_t)r0 + row, sum, acc);
+                    }
+                    if (P > 1 && rbase + R < nr) __syncthreads();      // part[] is reused by the next pass
+                }
+                if (P == 1) __syncthreads();                           // scol is rewritten by the next block
+            } else {
+                for (int r = 0; r < nr; ++r) {
+                    const int64_t s = a.ia[r0 + r], e = a.ia[r0 + r + 1];
+                    double pr[2] = {0.0, 0.0};
+                    for (int64_t q = s + tid; q < e; q += kBlock) {
+                        d2 v;
+                        if (DICT) v = dict_s[a.code[q]];
+                        else      v = a.val[q];
+                        const d2 t = cmul(v, a.xg[a.ja[q] & a.colmask]);
+                        pr[0] += t.x;
+                        pr[1] += t.y;
+                    }
+                    block_sum<2>(pr, red);
+                    if (tid == 0) {
+                        d2 sum = {pr[0], pr[1]};
+                        row_epilogue(a, (int64_t)r0 + r, sum, acc);
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        lb = lb_n; b = b_n; live = live_n;
+        r0 = r0_n; r1 = r1_n; p0 = p0_n; p1 = p1_n;
+    }
+    if (a.partials != nullptr) {
+        block_sum<3>(acc, red);
+        if (tid == 0) {
+            a.partials[(size_t)blockIdx.x * 3 + 0] = acc[0];
+            a.partials[(size_t)blockIdx.x * 3 + 1] = acc[1];
+            a.partials[(size_t)blockIdx.x * 3 + 2] = acc[2];
+        }
+    }
+}
+
 // ------------------------------------------- sub-wavefront-per-row SpMV --------
 // G lanes per row, shuffle reduction; no LDS staging.  Kept as the second opinion and for
 // matrices whose rows are long enough to fill a wavefront.
@@ -303,6 +518,7 @@ int spmv_grid(int kernel, int64_t n_blocks, int64_t nrows, int tpr)
     // 256 CUs; the streaming kernel fits 4 workgroups per CU (LDS), the vector kernel 8.
     int64_t units = n_blocks;
     int64_t cap = 256 * 4 * 4;
+    if (kernel == QBH_KERNEL_ROWS) cap = 256 * 8 * 2;
     if (kernel == QBH_KERNEL_VECTOR) {
         const int rpb = kBlock / tpr;
         units = (nrows + rpb - 1) / rpb;
@@ -328,9 +544,45 @@ static int launch_stream_tpr(const SpmvArgs &a, int tpr, int grid, hipStream_t s
     return QBH_OK;
 }
 
+template <int NPB, int PP, bool DICT>
+static int launch_rows_un(const SpmvArgs &a, int un, int grid, hipStream_t s)
+{
+    if (un == 8) hipLaunchKernelGGL((k_spmv_rows<NPB, PP, 8, DICT>), dim3(grid), dim3(kBlock), 0, s, a);
+    else         hipLaunchKernelGGL((k_spmv_rows<NPB, PP, 4, DICT>), dim3(grid), dim3(kBlock), 0, s, a);
+    return QBH_OK;
+}
+
+template <int NPB, bool DICT>
+static int launch_rows_p(const SpmvArgs &a, int tpr, int un, int grid, hipStream_t s)
+{
+    switch (tpr) {
+    case 1: return launch_rows_un<NPB, 1, DICT>(a, un, grid, s);
+    case 2: return launch_rows_un<NPB, 2, DICT>(a, un, grid, s);
+    case 4: return launch_rows_un<NPB, 4, DICT>(a, un, grid, s);
+    case 8: return launch_rows_un<NPB, 8, DICT>(a, un, grid, s);
+    default: set_error("k_spmv_rows: unsupported lanes-per-row %d (1, 2, 4, 8)", tpr); return QBH_EINVAL;
+    }
+}
+
+template <bool DICT>
+static int launch_rows(const SpmvArgs &a, int npb, int tpr, int un, int grid, hipStream_t s)
+{
+    switch (npb) {
+    case 1024: return launch_rows_p<1024, DICT>(a, tpr, un, grid, s);
+    case 2048: return launch_rows_p<2048, DICT>(a, tpr, un, grid, s);
+    case 4096: return launch_rows_p<4096, DICT>(a, tpr, un, grid, s);
+    case 8192:
+        if constexpr (DICT) return launch_rows_p<8192, DICT>(a, tpr, un, grid, s);
+        set_error("nnz_per_block 8192 needs the value dictionary");
+        return QBH_EINVAL;
+    default: set_error("k_spmv_rows: unsupported nnz_per_block %d", npb); return QBH_EINVAL;
+    }
+}
+
 template <bool DICT>
 static int launch_spmv_t(const SpmvArgs &a, int kernel, int npb, int tpr, int grid, hipStream_t s)
 {
+    if (kernel == QBH_KERNEL_ROWS) return launch_rows<DICT>(a, npb, tpr, a.unroll, grid, s);
     if (kernel == QBH_KERNEL_VECTOR) {
         switch (tpr) {
         case 4:  hipLaunchKernelGGL((k_spmv_vector<4, DICT>),  dim3(grid), dim3(kBlock), 0, s, a); break;

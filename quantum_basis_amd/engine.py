@@ -36,7 +36,7 @@ def _cvec(a, name):
     return a
 
 
-def make_opts(device=-1, stream=None, spmv_kernel=_lib.KERNEL_AUTO, nnz_per_block=0, xcd_swizzle=1,
+def make_opts(device=-1, stream=None, spmv_kernel=_lib.KERNEL_AUTO, nnz_per_block=0, xcd_swizzle=2,
               value_dict=0, profile=0, check_hermitian=1):
     o = _lib.Opts()
     lib().qbh_opts_default(C.byref(o))

@@ -13,14 +13,13 @@ i=0
 while read -r grp; do
   [ -z "$grp" ] && continue
   i=$((i+1))
-  rocprofv3 --pmc $grp -d $OUT/g$i -o p -- python3 $R/tools/spmv_probe.py --reps 3 "$@" > $OUT/g$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $grp -d $OUT/g$i -o p -- python3 $R/tools/spmv_probe.py --reps 3 "$@" > $OUT/g$i.log 2>&1
   echo "$grp" > $OUT/g$i.counters
 done <<'GROUPS'
 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum
 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_TAG_STALL_sum
 TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum
 SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_RD
-TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TA_BUSY_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
 FETCH_SIZE
 WRITE_SIZE
 GROUPS

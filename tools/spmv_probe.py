@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--npb", type=int, default=0)
     ap.add_argument("--no-swizzle", action="store_true")
+    ap.add_argument("--swizzle", type=int, default=2)
     ap.add_argument("--value-dict", type=int, default=0)
     ap.add_argument("--beta", type=float, default=-0.5)
     ap.add_argument("--red", type=int, default=1)
@@ -26,7 +27,7 @@ def main():
     import quantum_basis_amd as q
     W = bench.workloads()[args.workload]
     dim = bench.dim_of(W)
-    opts = q.make_opts(spmv_kernel=args.kernel, nnz_per_block=args.npb, xcd_swizzle=0 if args.no_swizzle else 1,
+    opts = q.make_opts(spmv_kernel=args.kernel, nnz_per_block=args.npb, xcd_swizzle=0 if args.no_swizzle else args.swizzle,
                        value_dict=args.value_dict, profile=1)
     A = bench.build_operator(W, None, opts)
     info = A.info()
@@ -43,7 +44,7 @@ def main():
     alg = info.bytes_algorithmic
     print(json.dumps({"workload": args.workload, "dim": dim, "nnz": info.nnz, "ms": round(ms, 4), "ms_min": round(st.ms_spmv_min, 4),
                       "alg_GBps": round(alg / ms / 1e6, 1), "frac": round(alg / ms / 1e6 / 8000.0, 4),
-                      "debug": os.environ.get("QBH_DEBUG", "0"), "npb": args.npb, "kernel": info.kernel,
+                      "debug": os.environ.get("QBH_DEBUG", "0"), "tpr": os.environ.get("QBH_TPR", "auto"), "npb": args.npb, "kernel": info.kernel,
                       "dict": info.value_dict}))
 
 
