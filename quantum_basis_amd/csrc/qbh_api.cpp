@@ -806,13 +806,28 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
     }
 
     double red[3], sq;
-    // one three-term step into vpt(m) given x = vpt(m-1); beta = -b[m-1] (0 at bootstrap)
-    auto step = [&](int64_t mcur, double beta) -> int {
-        QBH_TRY(spmv_run(A, vpt(mcur - 1), vpt(mcur), 1.0, beta, 0.0, red));           // K3+K1+K4
-        a[mcur - 1] = red[0];
-        QBH_TRY(axpy_norm_run(A, d2{-a[mcur - 1], 0.0}, vpt(mcur - 1), vpt(mcur), &sq)); // K5+K6
+    // The 1/b normalisation (K7, src/lanczos.cc:214) is never a pass of its own: slot j%2 holds an
+    // unnormalised u_j with v_j = sc[j%2] * u_j, and the scale is folded into the coefficients of the
+    // next SpMV / axpy.  Both slots are scaled to unit norm once, on exit.
+    double sc[2] = {1.0, 1.0};
+    // one three-term step into slot mcur%2 given x = v[mcur-1]; bprev = b[mcur-1] (0 at bootstrap)
+    auto step = [&](int64_t mcur, double bprev) -> int {
+        const int sx = (int)((mcur - 1) % 2), sy = (int)(mcur % 2);
+        // w = H v_{m-1} - b_{m-1} v_{m-2}  and  <u_{m-1}, w>                               K3+K1+K4
+        QBH_TRY(spmv_run(A, vpt(mcur - 1), vpt(mcur), sc[sx], -bprev * sc[sy], 0.0, red));
+        a[mcur - 1] = sc[sx] * red[0];
+        // w -= a v_{m-1} ; b = |w|                                                         K5+K6
+        QBH_TRY(axpy_norm_run(A, d2{-a[mcur - 1] * sc[sx], 0.0}, vpt(mcur - 1), vpt(mcur), &sq));
         b[mcur] = std::sqrt(sq);
-        QBH_TRY(qbh::launch_scal(1.0 / b[mcur], vpt(mcur), n, A->stream));              // K7
+        sc[sy] = 1.0 / b[mcur];
+        return QBH_OK;
+    };
+    auto normalise_slots = [&]() -> int {
+        for (int j = 0; j < 2; ++j)
+            if (sc[j] != 1.0) {
+                QBH_TRY(qbh::launch_scal(sc[j], v + (size_t)j * (size_t)n, n, A->stream));
+                sc[j] = 1.0;
+            }
         return QBH_OK;
     };
 
@@ -829,19 +844,19 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
     int rc = QBH_OK;
     do {                                                   // :193
         m++;
-        rc = step(m, -b[m - 1]);
+        rc = step(m, b[m - 1]);
         if (rc != QBH_OK) break;
         if (std::fabs(b[m]) < prec) break;                 // :216
 
         if (is_val1) {                                     // :218-226
             double t[2];
-            rc = dotc_run(A, phi, vpt(m), t);
+            const int sy = (int)(m % 2);
+            rc = dotc_run(A, phi, vpt(m), t);                  // <phi0, u_m>; <phi0, v_m> = sc * that
             if (rc != QBH_OK) break;
-            if (std::hypot(t[0], t[1]) > prec) {
-                rc = axpy_norm_run(A, d2{-t[0], -t[1]}, phi, vpt(m), &sq);
+            if (sc[sy] * std::hypot(t[0], t[1]) > prec) {
+                rc = axpy_norm_run(A, d2{-t[0], -t[1]}, phi, vpt(m), &sq);   // u_m -= <phi0,u_m> phi0
                 if (rc != QBH_OK) break;
-                rc = qbh::launch_scal(1.0 / std::sqrt(sq), vpt(m), n, A->stream);
-                if (rc != QBH_OK) break;
+                sc[sy] = 1.0 / std::sqrt(sq);                  // renormalise
                 if (info) info->n_reorth++;
             }
         }
@@ -879,6 +894,7 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
             theta1_prev = ritz1;
         }
     } while (m < mm);
+    if (rc == QBH_OK) rc = normalise_slots();
     if (rc == QBH_OK) {
         hipError_t e = hipStreamSynchronize(A->stream);
         if (e != hipSuccess) {
