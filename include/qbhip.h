@@ -225,6 +225,9 @@ typedef struct qbh_stats {
     double  ms_gather;        /* time spent in allgather_x (event-timed)                  */
 } qbh_stats;
 int qbh_get_stats(const qbh_csr *A, qbh_stats *s, int reset);
+/* Block until everything enqueued on the operator's stream has finished (device building blocks
+ * without a reduction are asynchronous; needed before another operator/stream touches the vectors). */
+int qbh_sync(const qbh_csr *A);
 
 /* ------------------------------------------------ synthetic operators ---- */
 /* Measurement harness: device-side assembly of the benchmark Hamiltonians directly into

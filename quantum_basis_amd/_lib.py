@@ -75,7 +75,7 @@ EXPORTS = [
     "qbh_vec_randomize",
     "qbh_spmv_dev", "qbh_dotc_dev", "qbh_axpy_norm_dev", "qbh_scal_dev", "qbh_nrm2_dev",
     "qbh_lanczos", "qbh_lanczos_dev", "qbh_eigenvec_cg", "qbh_eigenvec_cg_dev", "qbh_hess_eigen",
-    "qbh_csr_set_comm", "qbh_get_stats",
+    "qbh_csr_set_comm", "qbh_get_stats", "qbh_sync",
     "qbh_gen_hubbard", "qbh_gen_heisenberg", "qbh_csr_download",
 ]
 
@@ -136,6 +136,7 @@ def lib():
     L.qbh_hess_eigen.argtypes = [vp, i64, i64, C.c_char_p, vp, vp]
     L.qbh_csr_set_comm.argtypes = [vp, C.POINTER(Comm)]
     L.qbh_get_stats.argtypes = [vp, C.POINTER(Stats), C.c_int]
+    L.qbh_sync.argtypes = [vp]
     L.qbh_gen_hubbard.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, vp, dbl, dbl,
                                   i64, i64, C.POINTER(Opts)]
     L.qbh_gen_heisenberg.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp, dbl, i64, i64,

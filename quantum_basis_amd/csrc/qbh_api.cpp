@@ -455,6 +455,14 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
     return QBH_OK;
 }
 
+extern "C" int qbh_sync(const qbh_csr *A)
+{
+    if (!A) return QBH_EINVAL;
+    Bind bind(A);
+    QBH_HIP(hipStreamSynchronize(A->stream));
+    return QBH_OK;
+}
+
 extern "C" int qbh_get_stats(const qbh_csr *Ac, qbh_stats *s, int reset)
 {
     qbh_csr *A = const_cast<qbh_csr *>(Ac);

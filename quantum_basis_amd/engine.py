@@ -216,6 +216,9 @@ class csr_mat:
     def randomize(self, d_x, seed):
         check(lib().qbh_vec_randomize(self.handle, d_x, C.c_uint32(seed)), "qbh_vec_randomize")
 
+    def sync(self):
+        check(lib().qbh_sync(self.handle), "qbh_sync")
+
     def stats(self, reset=False):
         s = _lib.Stats()
         check(lib().qbh_get_stats(self.handle, C.byref(s), int(reset)), "qbh_get_stats")

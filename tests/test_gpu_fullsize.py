@@ -1,0 +1,133 @@
+"""BASELINE.json's full-size single-GPU workload (Fermi-Hubbard 4x4 half filling, dim 165,636,900,
+nnz 5.82e9) checked through size-independent properties -- the oracle cannot run at this size:
+
+ * Hermiticity  <x, H y> = <H x, y>           (exercises both triangles of the full-storage CSR)
+ * linearity     H(ax + by) = a Hx + b Hy
+ * kernel agreement: dictionary-coded vs plain values, row kernel vs stream kernel
+ * shard agreement: two independently generated row shards reproduce the full operator's y
+ * Lanczos: coefficients identical (1e-11) between the plain and the coded operator, vectors stay
+   normalised and orthogonal, Ritz value decreases monotonically
+ * structure: dim, nnz and the diagonal/trace identities of the model."""
+import math
+
+import numpy as np
+import pytest
+
+import quantum_basis_amd as q
+from quantum_basis_amd import _lib, lattices
+
+pytestmark = pytest.mark.gpu
+
+DIM = math.comb(16, 8) ** 2
+
+
+@pytest.fixture(scope="module")
+def ops():
+    bonds = lattices.square(4, 4)
+    coded = q.csr_mat.hubbard(16, 8, 8, bonds, t=1.0, U=1.1, opts=q.make_opts(value_dict=1))
+    plain = q.csr_mat.hubbard(16, 8, 8, bonds, t=1.0, U=1.1, opts=q.make_opts(value_dict=0, spmv_kernel=_lib.KERNEL_STREAM))
+    yield coded, plain
+    coded.destroy()
+    plain.destroy()
+
+
+def test_structure(ops):
+    coded, plain = ops
+    assert coded.dim == DIM == 165636900 and coded.ncols == DIM
+    # nnz = dim * (1 + <hops per row>): every bond contributes 2 * C(14,7) * C(16,8) ordered hops per spin
+    n_bonds = 32
+    hops_per_species = 2 * n_bonds * math.comb(14, 7)
+    nnz = DIM + 2 * hops_per_species * math.comb(16, 8)
+    assert coded.nnz == plain.nnz == nnz == 5819376420
+    assert 0 < coded.info().value_dict <= 256 and plain.info().value_dict == 0
+    # a few rows downloaded from both operators are identical (coded values decode exactly)
+    for r0 in (0, 12345678, DIM - 300):
+        ia1, ja1, v1 = coded.download(r0, r0 + 200)
+        ia2, ja2, v2 = plain.download(r0, r0 + 200)
+        assert np.array_equal(ia1, ia2) and np.array_equal(ja1, ja2) and np.array_equal(v1, v2)
+        for i in range(200):          # columns ascending, diagonal present, off-diagonals are +-t
+            cols, vals = ja1[ia1[i]:ia1[i + 1]], v1[ia1[i]:ia1[i + 1]]
+            assert np.all(np.diff(cols) > 0) and (r0 + i) in cols
+            off = vals[cols != r0 + i]
+            assert np.all(np.abs(np.abs(off.real) - 1.0) < 1e-15) and np.all(off.imag == 0)
+
+
+def test_hermiticity_linearity_and_kernel_agreement(ops):
+    coded, plain = ops
+    n = DIM
+    v = coded.vec(5)
+    coded.randomize(v.at(0), 1)              # x
+    coded.randomize(v.at(n), 2)              # y
+    coded.spmv(v.at(0), v.at(2 * n))         # Hx
+    coded.spmv(v.at(n), v.at(3 * n))         # Hy
+    lhs = coded.dotc(v.at(0), v.at(3 * n))   # <x, Hy>
+    rhs = coded.dotc(v.at(2 * n), v.at(n))   # <Hx, y>
+    assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), 1e-3)
+    # plain/stream kernel produces the same Hx (different summation order only)
+    coded.sync()
+    plain.spmv(v.at(0), v.at(4 * n))
+    plain.sync()                             # each operator owns a stream
+    hx_norm = coded.nrm2(v.at(2 * n))
+    diff = np.sqrt(coded.axpy_norm(-1.0, v.at(2 * n), v.at(4 * n)))
+    assert diff <= 1e-13 * hx_norm
+    # linearity: H(2x - 0.5i y) - 2 Hx + 0.5i Hy = 0   (reuse slot 4 for the combination)
+    coded.spmv(v.at(0), v.at(4 * n), 0.0, 0.0, 0.0)                   # slot4 = 0
+    coded.axpy_norm(2.0, v.at(0), v.at(4 * n))
+    coded.axpy_norm(-0.5j, v.at(n), v.at(4 * n))                       # slot4 = 2x - 0.5i y
+    coded.spmv(v.at(4 * n), v.at(0))                                    # slot0 = H(2x - 0.5i y)   (x no longer needed)
+    coded.axpy_norm(-2.0, v.at(2 * n), v.at(0))
+    res = np.sqrt(coded.axpy_norm(0.5j, v.at(3 * n), v.at(0)))
+    assert res <= 1e-12 * hx_norm
+    v.free()
+
+
+def test_row_shards_reproduce_full_operator(ops):
+    coded, _ = ops
+    n = DIM
+    bonds = lattices.square(4, 4)
+    v = coded.vec(2)
+    coded.randomize(v.at(0), 3)
+    coded.spmv(v.at(0), v.at(n))
+    cut = 4 * (n // 7) + 5
+    for (r0, r1) in ((0, cut), (cut, n)):
+        sh = q.csr_mat.hubbard(16, 8, 8, bonds, rows=(r0, r1), opts=q.make_opts(value_dict=1))
+        ys = sh.vec()
+        coded.sync()
+        sh.spmv(v.at(0), ys.ptr)                       # unsharded convention: x is the full vector
+        sh.sync()
+        h = ys.download(0, 1000)
+        want = v.download(n + r0, 1000)
+        assert np.abs(h - want).max() <= 1e-13 * np.abs(want).max()
+        h2 = ys.download(sh.dim - 1000, 1000)
+        want2 = v.download(n + r1 - 1000, 1000)
+        assert np.abs(h2 - want2).max() <= 1e-13 * np.abs(want2).max()
+        ys.free()
+        sh.destroy()
+    v.free()
+
+
+def test_lanczos_agreement_and_invariants(ops):
+    coded, plain = ops
+    n, maxit, steps = DIM, 64, 24
+    hc, hp = np.zeros(2 * maxit), np.zeros(2 * maxit)
+    vc, vp = coded.vec(2), plain.vec(2)
+    coded.randomize(vc.at(0), 1)
+    plain.randomize(vp.at(0), 1)
+    mc = q.lanczos(0, steps, maxit, n, coded, None, hc, "sr_val0", device_v=vc)
+    rows = q.lanczos.last["log"]
+    mp_ = q.lanczos(0, steps, maxit, n, plain, None, hp, "sr_val0", device_v=vp)
+    assert mc == mp_ == steps
+    assert np.allclose(hc[maxit:maxit + steps], hp[maxit:maxit + steps], rtol=1e-10)
+    assert np.allclose(hc[1:steps + 1], hp[1:steps + 1], rtol=1e-10)
+    # exit contract: last two Lanczos vectors, normalised and orthogonal
+    assert abs(coded.nrm2(vc.at(0)) - 1.0) < 1e-12 and abs(coded.nrm2(vc.at(n)) - 1.0) < 1e-12
+    assert abs(coded.dotc(vc.at(0), vc.at(n))) < 1e-8
+    # the lowest Ritz value decreases monotonically and stays above the exact bound -t*|bonds|*2
+    r0 = [r["ritz"][0] for r in rows]
+    assert all(b <= a + 1e-12 for a, b in zip(r0, r0[1:])) and r0[-1] > -64.0
+    # trace identity: a_0 = <v0|H|v0> for the normalised start vector equals a direct evaluation
+    coded.randomize(vc.at(0), 1)
+    dot, _ = coded.spmv(vc.at(0), vc.at(n), want_red=True)
+    assert abs(dot.real - hc[maxit]) <= 1e-11 * abs(hc[maxit]) and abs(dot.imag) < 1e-12
+    vc.free()
+    vp.free()

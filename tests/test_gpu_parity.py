@@ -363,7 +363,9 @@ def test_row_shards_of_the_generator_tile_the_operator():
         assert np.array_equal(sia, ia[r0:r1 + 1] - ia[r0])
         assert np.array_equal(sja, ja[ia[r0]:ia[r1]]) and np.array_equal(sval, val[ia[r0]:ia[r1]])
         ys = sh.vec()
+        full.sync()
         sh.spmv(xv.ptr, ys.ptr)          # unsharded call convention: x is the full-length vector
+        sh.sync()
         assert _close(ys.download(), want[r0:r1])
 
 
