@@ -225,6 +225,16 @@ def main():
     # algorithmic bytes of ONE SpMV launch on this rank: nnz*(16+4) + (rows+1)*8 + x once + y once
     bytes_launch = info.nnz * 20 + (info.nrows + 1) * 8 + (dim if world > 1 else info.nrows) * 16 + info.nrows * 16
     achieved = bytes_launch / (ms_spmv * 1e-3) / 1e9 if ms_spmv > 0 else 0.0
+    # HBM traffic of one launch: measured in separate rocprofv3 --pmc passes (tools/profile_bench.sh), kept in
+    # profiles/traffic.json and quoted only when it was taken on this exact workload / kernel / value coding
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        key = "%s|%s|%s" % (args.workload, {1: "stream", 2: "vector", 3: "rows"}[info.kernel], "dict" if info.value_dict else "plain")
+        if world == 1 and key in tj:
+            traffic = tj[key]["hbm_bytes"]
+    except Exception:
+        traffic = None
     out = {
         "metric": "lanczos_iters_per_sec", "value": round(K_done / elapsed, 4), "unit": "lanczos_iters/s",
         "n_gpus": world, "steps": K_done, "warmup": Wm, "ms_per_step": round(1e3 * elapsed / K_done, 4),
@@ -235,7 +245,7 @@ def main():
                                          "build_s": round(t_gen, 3)},
         "roofline": {"bound": "hbm", "kernel": {1: "k_spmv_stream", 2: "k_spmv_vector", 3: "k_spmv_rows"}[info.kernel],
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                      "bytes_per_launch": bytes_launch, "ms_per_launch": round(ms_spmv, 4), "launches": int(st.n_spmv)},
         "e0": e0, "lanczos_steps_to_converge": steps_e0,
     }
