@@ -191,6 +191,17 @@ int qbh_eigenvec_cg(const qbh_csr *A, int64_t maxit, int64_t *m, double E0, doub
 int qbh_eigenvec_cg_dev(const qbh_csr *A, int64_t maxit, int64_t *m, double E0, double *accu,
                         qbh_z *d_v, qbh_z *d_r, qbh_z *d_p, qbh_z *d_pp, qbh_solver_info *info);
 
+/* Replaces iram<T,csr_mat<T>> / call_arpack (src/lanczos.cc:438-603) for order "sr"/"sa" (lowest) and
+ * "lr"/"la" (highest) with the Krylov basis resident in HBM (thick-restart Lanczos == implicitly
+ * restarted Lanczos for a Hermitian operator): nev wanted eigenpairs, ncv basis vectors
+ * (nev + 2 <= ncv <= 32), at most maxit restarts, tol <= 0 meaning machine epsilon as in ARPACK
+ * (src/lanczos.cc:452); the start vector is random (ARPACK info = 0, seed selects the Lehmer stream).
+ * Outputs like iram: *nconv, eigenvals[nev] in the requested order, eigenvecs_host[nev*n] (may be
+ * NULL).  info->n_reorth returns the number of restarts.  Other orders ("sm","lm") return
+ * QBH_EUNSUPP: drive ARPACK over qbh_multmv for those. */
+int qbh_iram(const qbh_csr *A, int64_t nev, int64_t ncv, int64_t maxit, const char *order, double tol,
+             uint32_t seed, int64_t *nconv, double *eigenvals, qbh_z *eigenvecs_host, qbh_solver_info *info);
+
 /* Replaces hess_eigen (src/lanczos.cc:355-390), host only: eigen-decomposition of the
  * m x m tridiagonal held in hessenberg (ld = maxit), sorted by order ("sr","lr","sm","lm");
  * ritz[m], s[m*m] column-major. */

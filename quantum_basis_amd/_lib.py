@@ -74,7 +74,7 @@ EXPORTS = [
     "qbh_vec_alloc", "qbh_vec_free", "qbh_vec_upload", "qbh_vec_download", "qbh_vec_zero",
     "qbh_vec_randomize",
     "qbh_spmv_dev", "qbh_dotc_dev", "qbh_axpy_norm_dev", "qbh_scal_dev", "qbh_nrm2_dev",
-    "qbh_lanczos", "qbh_lanczos_dev", "qbh_eigenvec_cg", "qbh_eigenvec_cg_dev", "qbh_hess_eigen",
+    "qbh_lanczos", "qbh_lanczos_dev", "qbh_eigenvec_cg", "qbh_eigenvec_cg_dev", "qbh_hess_eigen", "qbh_iram",
     "qbh_csr_set_comm", "qbh_get_stats", "qbh_sync",
     "qbh_gen_hubbard", "qbh_gen_heisenberg", "qbh_csr_download",
 ]
@@ -134,6 +134,7 @@ def lib():
                                   C.POINTER(SolverInfo)]
     L.qbh_eigenvec_cg_dev.argtypes = L.qbh_eigenvec_cg.argtypes
     L.qbh_hess_eigen.argtypes = [vp, i64, i64, C.c_char_p, vp, vp]
+    L.qbh_iram.argtypes = [vp, i64, i64, i64, C.c_char_p, dbl, C.c_uint32, C.POINTER(i64), vp, vp, C.POINTER(SolverInfo)]
     L.qbh_csr_set_comm.argtypes = [vp, C.POINTER(Comm)]
     L.qbh_get_stats.argtypes = [vp, C.POINTER(Stats), C.c_int]
     L.qbh_sync.argtypes = [vp]

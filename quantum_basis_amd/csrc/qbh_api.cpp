@@ -163,7 +163,6 @@ int finalize(qbh_csr *A)
     }
     if (const char *e = getenv("QBH_TPR")) A->tpr = atoi(e);            // tuning experiments
     if (const char *e = getenv("QBH_UNROLL")) A->unroll = atoi(e);
-    if (const char *e = getenv("QBH_FAR")) A->far = atoi(e);
     // a block holds the rows that START inside its window, so it can exceed the window by
     // one row; keep window + maxlen - 1 <= npb when rows are short, otherwise let the
     // oversized-block path take the few long rows.
@@ -550,10 +549,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     a.partials = red ? A->d_partials : nullptr;
     a.swizzle = A->opts.xcd_swizzle;
     a.unroll = A->unroll;
-    a.far = A->far;
-    a.col0 = A->row_offset;
     a.colmask = (A->debug & 1) ? 1023 : -1;
-    a.debug2 = (A->debug & 2) ? 1 : (A->debug & 4) ? 2 : (A->debug & 8) ? 3 : 0;
     const bool prof = A->opts.profile != 0;
     if (prof) {
         harvest_events(A);
@@ -1026,6 +1022,163 @@ extern "C" int qbh_eigenvec_cg(const qbh_csr *A, int64_t maxit, int64_t *m, doub
     for (int i = 0; i < 4 && rc == QBH_OK; ++i)
         if (hipMemcpy(hv[i], d + i * n, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = QBH_EHIP;
     (void)hipFree(d);
+    return rc;
+}
+
+// -------------------------------------------------------------------- IRAM -------
+// Device-resident replacement of iram<T,csr_mat<T>> -> call_arpack (src/lanczos.cc:438-603).
+// ARPACK's implicitly restarted Arnoldi process applied to a Hermitian operator is a restarted
+// Lanczos process; here it is run as thick-restart Lanczos (Wu & Simon) with the Krylov basis
+// V[ncv+1][n] resident in HBM, two passes of classical Gram-Schmidt against the whole basis
+// (k_multi_dot / k_multi_axpy), the ncv x ncv projected problem on the host (Jacobi), and the
+// restart rotation V <- V S on the device.  Same convergence rule as ARPACK's dsconv/znconv:
+// |beta * s_last,i| <= tol * max(eps^(2/3), |theta_i|), tol <= 0 meaning machine epsilon
+// (src/lanczos.cc:452).  The start vector is random (ARPACK info = 0, src/lanczos.cc:470).
+extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t maxit, const char *order, double tol,
+                        uint32_t seed, int64_t *nconv_out, double *eigenvals, qbh_z *eigenvecs_host,
+                        qbh_solver_info *info)
+{
+    qbh_csr *A = const_cast<qbh_csr *>(Ac);
+    if (!A || !order || !nconv_out || !eigenvals || strlen(order) < 2) return QBH_EINVAL;
+    if (!A->has_comm && A->nrows != A->ncols) return QBH_EINVAL;
+    const int64_t dim = A->ncols, n = A->nrows;
+    if (nev <= 0 || nev >= dim - 1) {                       // src/lanczos.cc:502
+        qbh::set_error("0 < nev < N-1 should be satisfied.");
+        return QBH_EINVAL;
+    }
+    if (ncv < nev + 2 || ncv > dim) {
+        qbh::set_error("qbh_iram: need nev + 2 <= ncv <= dim");
+        return QBH_EINVAL;
+    }
+    if (ncv > 32) {
+        qbh::set_error("qbh_iram: ncv > 32 not supported on the device path");
+        return QBH_EUNSUPP;
+    }
+    if (maxit < 1) return QBH_EINVAL;
+    const char o0 = (char)std::tolower((unsigned char)order[0]), o1 = (char)std::tolower((unsigned char)order[1]);
+    if (!((o0 == 's' || o0 == 'l') && (o1 == 'r' || o1 == 'a'))) {
+        qbh::set_error("qbh_iram: order '%s' not supported on the device path (sr, lr)", order);
+        return QBH_EUNSUPP;
+    }
+    const double sign = (o0 == 's') ? 1.0 : -1.0;            // largest of H = smallest of -H
+    Bind bind(A);
+    const double t_start = now_ms();
+    const int64_t spmv0 = A->stats.n_spmv;
+    const double ms_spmv0 = A->stats.ms_spmv;
+    const int m = (int)ncv;
+    const double eps = std::numeric_limits<double>::epsilon();
+    const double eps23 = std::pow(eps, 2.0 / 3.0);
+    const double tol_eff = tol > 0.0 ? tol : eps;
+
+    d2 *V = nullptr;
+    double *d_S = nullptr;
+    QBH_HIP(hipMalloc(&V, (size_t)(m + 1) * (size_t)n * sizeof(d2)));
+    hipError_t e = hipMalloc(&d_S, 32 * 32 * sizeof(double));
+    if (e != hipSuccess) {
+        (void)hipFree(V);
+        return QBH_ENOMEM;
+    }
+    auto vec = [&](int j) { return V + (size_t)j * (size_t)n; };
+    int rc = qbh_vec_randomize(A, reinterpret_cast<qbh_z *>(vec(0)), seed ? seed : 1u);
+
+    std::vector<double> T((size_t)m * m, 0.0), Tw((size_t)m * m), theta((size_t)m), S((size_t)m * m);
+    int k = 0;                          // vectors kept from the previous restart
+    int64_t restarts = 0, nconv = 0;
+    double beta_last = 0.0;
+    double red[16], sq;
+    // orthogonalise w against V_0..V_{nv-1}, classical Gram-Schmidt, `passes` times
+    auto reorth = [&](d2 *w, int nv, int passes) -> int {
+        for (int p = 0; p < passes; ++p)
+            for (int i0 = 0; i0 < nv; i0 += 8) {
+                const int cnt = std::min(8, nv - i0);
+                QBH_TRY(qbh::launch_multi_dot8(vec(i0), n, w, n, cnt, A->d_partials, A->stream));
+                QBH_TRY(finish_reduction(A, qbh::blas_grid(n), 16, red));
+                qbh::Coef8 c{};
+                for (int i = 0; i < 2 * cnt; ++i) c.v[i] = red[i];
+                QBH_TRY(qbh::launch_multi_axpy8(vec(i0), n, c, cnt, w, n, A->stream));
+            }
+        return QBH_OK;
+    };
+
+    while (rc == QBH_OK) {
+        for (int j = k; j < m && rc == QBH_OK; ++j) {
+            d2 *w = vec(j + 1);
+            rc = spmv_run(A, vec(j), w, sign, 0.0, 0.0, red);            // w = (+-H) v_j ; <v_j, w>
+            if (rc != QBH_OK) break;
+            const double alpha = red[0];
+            T[(size_t)j * m + j] = alpha;
+            if (j == k && k > 0) {                                        // arrowhead coupling after a restart
+                for (int i0 = 0; i0 < k && rc == QBH_OK; i0 += 8) {
+                    const int cnt = std::min(8, k - i0);
+                    qbh::Coef8 c{};
+                    for (int i = 0; i < cnt; ++i) c.v[2 * i] = T[(size_t)k * m + (i0 + i)];
+                    rc = qbh::launch_multi_axpy8(vec(i0), n, c, cnt, w, n, A->stream);
+                }
+            } else if (j > 0) {
+                qbh::Coef8 c{};
+                c.v[0] = T[(size_t)j * m + (j - 1)];
+                rc = qbh::launch_multi_axpy8(vec(j - 1), n, c, 1, w, n, A->stream);
+            }
+            if (rc != QBH_OK) break;
+            rc = axpy_norm_run(A, d2{-alpha, 0.0}, vec(j), w, &sq);
+            if (rc != QBH_OK) break;
+            rc = reorth(w, j + 1, 2);
+            if (rc != QBH_OK) break;
+            double beta = 0.0;
+            rc = nrm2_run(A, w, &beta);
+            if (rc != QBH_OK) break;
+            beta_last = beta;
+            if (j + 1 < m) T[(size_t)j * m + (j + 1)] = T[(size_t)(j + 1) * m + j] = beta;
+            if (beta > 0.0) rc = qbh::launch_scal(1.0 / beta, w, n, A->stream);
+        }
+        if (rc != QBH_OK) break;
+        Tw = T;
+        qbh::symmetric_eigen_jacobi(m, Tw.data(), theta.data(), S.data());
+        nconv = 0;
+        for (int i = 0; i < (int)nev; ++i) {
+            const double resid = std::fabs(beta_last * S[(size_t)i * m + (m - 1)]);
+            if (resid <= tol_eff * std::max(eps23, std::fabs(theta[i]))) nconv++;
+            else break;
+        }
+        restarts++;
+        const bool done = nconv >= nev || restarts >= maxit;
+        const int keep = done ? (int)nev : (int)std::min<int64_t>(m - 1, nev + std::max<int64_t>(1, (m - nev) / 2));
+        // V[:, 0..keep) <- V[:, 0..m) S[:, 0..keep)
+        e = hipMemcpyAsync(d_S, S.data(), (size_t)m * keep * sizeof(double), hipMemcpyHostToDevice, A->stream);
+        if (e != hipSuccess) { rc = QBH_EHIP; break; }
+        e = hipStreamSynchronize(A->stream);                 // S.data() is pageable host memory
+        if (e != hipSuccess) { rc = QBH_EHIP; break; }
+        rc = qbh::launch_basis_rotate(V, n, n, m, keep, d_S, A->stream);
+        if (rc != QBH_OK || done) break;
+        e = hipMemcpyAsync(vec(keep), vec(m), (size_t)n * sizeof(d2), hipMemcpyDeviceToDevice, A->stream);
+        if (e != hipSuccess) { rc = QBH_EHIP; break; }
+        std::fill(T.begin(), T.end(), 0.0);
+        for (int i = 0; i < keep; ++i) {
+            T[(size_t)i * m + i] = theta[i];
+            const double s_i = beta_last * S[(size_t)i * m + (m - 1)];
+            T[(size_t)keep * m + i] = T[(size_t)i * m + keep] = s_i;
+        }
+        k = keep;
+    }
+    if (rc == QBH_OK) {
+        for (int i = 0; i < (int)nev; ++i) eigenvals[i] = sign * theta[i];
+        *nconv_out = nconv;
+        if (eigenvecs_host) {
+            e = hipMemcpyAsync(eigenvecs_host, V, (size_t)nev * (size_t)n * sizeof(d2), hipMemcpyDeviceToHost, A->stream);
+            if (e != hipSuccess) rc = QBH_EHIP;
+        }
+        e = hipStreamSynchronize(A->stream);
+        if (e != hipSuccess) rc = QBH_EHIP;
+    }
+    harvest_events(A);
+    (void)hipFree(V);
+    (void)hipFree(d_S);
+    if (info) {
+        info->n_matvec = A->stats.n_spmv - spmv0;
+        info->ms_spmv = A->stats.ms_spmv - ms_spmv0;
+        info->ms_total = now_ms() - t_start;
+        info->n_reorth = restarts;                           // number of restarts (ARPACK's niter)
+    }
     return rc;
 }
 

@@ -7,6 +7,7 @@
 //   * lastrow: all eigenvalues + only the LAST component of every eigenvector, which is all
 //              the per-step stop test needs (accuracy = |b_m * s[m-1]|, src/lanczos.cc:231);
 //              O(m^2) per call instead of O(m^3).
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -98,6 +99,59 @@ int tridiag_eigen_lastrow(int64_t m, const double *a, const double *b1, double *
     for (int64_t j = 0; j < m; ++j) zlast[j] = 0.0;
     zlast[m - 1] = 1.0;
     return ql_implicit(m, w, e.data(), zlast, 1) ? QBH_ENOCONV : QBH_OK;
+}
+
+
+// Cyclic Jacobi for the small dense real symmetric projected matrix of the thick-restart Lanczos
+// (m <= 32: tridiagonal plus the arrowhead row left by a restart).  a: m*m column-major, destroyed;
+// w[m] ascending eigenvalues; z[m*m] column-major eigenvectors.
+int symmetric_eigen_jacobi(int m, double *a, double *w, double *z)
+{
+    for (int i = 0; i < m * m; ++i) z[i] = 0.0;
+    for (int i = 0; i < m; ++i) z[i * m + i] = 1.0;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int p = 0; p < m; ++p) {
+            diag += a[p * m + p] * a[p * m + p];
+            for (int q = p + 1; q < m; ++q) off += a[q * m + p] * a[q * m + p];
+        }
+        if (off <= 1e-32 * (diag + off) || off == 0.0) break;
+        for (int p = 0; p < m - 1; ++p)
+            for (int q = p + 1; q < m; ++q) {
+                const double apq = a[q * m + p];
+                if (apq == 0.0) continue;
+                const double theta = (a[q * m + q] - a[p * m + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < m; ++k) {                 // rotate columns p, q of A
+                    const double akp = a[p * m + k], akq = a[q * m + k];
+                    a[p * m + k] = c * akp - s * akq;
+                    a[q * m + k] = s * akp + c * akq;
+                }
+                for (int k = 0; k < m; ++k) {                 // rotate rows p, q of A
+                    const double apk = a[k * m + p], aqk = a[k * m + q];
+                    a[k * m + p] = c * apk - s * aqk;
+                    a[k * m + q] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < m; ++k) {                 // accumulate eigenvectors
+                    const double zkp = z[p * m + k], zkq = z[q * m + k];
+                    z[p * m + k] = c * zkp - s * zkq;
+                    z[q * m + k] = s * zkp + c * zkq;
+                }
+            }
+    }
+    // sort ascending (selection sort, m is tiny)
+    for (int i = 0; i < m; ++i) w[i] = a[i * m + i];
+    for (int i = 0; i < m - 1; ++i) {
+        int k = i;
+        for (int j = i + 1; j < m; ++j)
+            if (w[j] < w[k]) k = j;
+        if (k != i) {
+            std::swap(w[i], w[k]);
+            for (int r = 0; r < m; ++r) std::swap(z[i * m + r], z[k * m + r]);
+        }
+    }
+    return QBH_OK;
 }
 
 }  // namespace qbh

@@ -52,10 +52,7 @@ struct SpmvArgs {
     double         alpha, beta, gamma;
     double        *partials;   // [grid*3] or nullptr
     int            swizzle;
-    int            far;        // k_spmv_rows: |col-row| beyond which x is gathered non-temporal (0: off)
-    int64_t        col0;       // global index of the shard's first row
     int            unroll;     // k_spmv_rows: gathers in flight per lane and loop trip
-    int            debug2;     // QBH_DEBUG bit1: stream loads only, no LDS/reduce (timing experiments only)
     int            colmask;    // -1; QBH_DEBUG=1 sets 1023 so the gather stays in cache (timing experiments only)
 };
 
@@ -79,6 +76,11 @@ int launch_randomize(d2 *x, int64_t n, int64_t global_offset, uint32_t seed, dou
 int launch_fill_const(d2 *x, int64_t n, double re, hipStream_t s);
 int launch_max_rowlen(const int64_t *d_ia, int64_t nrows, int64_t *d_out, hipStream_t s);
 int blas_grid(int64_t n);
+struct Coef8 { double v[16]; };   // up to 8 complex coefficients passed by value
+int launch_multi_dot8(const d2 *V, int64_t ldv, const d2 *w, int64_t n, int nv, double *partials, hipStream_t s);
+int launch_multi_axpy8(const d2 *V, int64_t ldv, const Coef8 &c, int nv, d2 *w, int64_t n, hipStream_t s);
+int launch_basis_rotate(d2 *V, int64_t ldv, int64_t n, int m, int keep, const double *d_S, hipStream_t s);
+int symmetric_eigen_jacobi(int m, double *a, double *w, double *z);
 int build_value_dict(const d2 *d_val, int64_t nnz, uint8_t *d_code, d2 *d_dict, int *n_out, hipStream_t s);
 
 // host tridiagonal solver (qbh_hess.cpp)
@@ -128,5 +130,4 @@ struct qbh_csr {
     qbh_stats stats{};
     bool      ev_pending = false;
     int       debug = 0;
-    int       far = 0;
 };

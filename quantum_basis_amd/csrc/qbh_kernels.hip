@@ -196,15 +196,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(SpmvArgs a)
                     for (int u = 0; u < U; ++u) {
                         const int i = tid + u * kBlock;
                         if (DICT) v[u] = dict_s[cb[u]];
-                        if (a.debug2) {                    // timing experiment: loads only
-                            const d2 t = cmul(v[u], xv[u]);
-                            acc[2] += t.x + t.y;
-                        } else if (i < n) prod[i] = cmul(v[u], xv[u]);
+                        if (i < n) prod[i] = cmul(v[u], xv[u]);
                     }
-                }
-                if (a.debug2) {
-                    acc[2] += ro + yo.x + xi.x;
-                    goto next_block;
                 }
                 if (tid <= nr) rowoff[tid] = ro;
                 for (int i = tid + kBlock; i <= nr; i += kBlock) rowoff[i] = (int)(a.ia[r0 + i] - p0);
@@ -247,7 +240,6 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(SpmvArgs a)
                 }
             }
         }
-    next_block:
         lb = lb_n; b = b_n; live = live_n;
         r0 = r0_n; r1 = r1_n; p0 = p0_n; p1 = p1_n;
     }
@@ -372,7 +364,6 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
                 for (int rbase = 0; rbase < nr; rbase += R) {
                     const int row = rbase + rloc;
                     const bool rowok = row < nr;
-                    const int grow = (int)a.col0 + r0 + row;          // global row index == diagonal column
                     const int base = rowok ? rowoff[row] : 0;
                     const int len = rowok ? rowoff[row + 1] - base : 0;
                     int wmax = len;
@@ -396,16 +387,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
                         }
                         d2 xv[UN], vv[UN];
 #pragma unroll
-                        for (int j = 0; j < UN; ++j) {
-                            // far columns are use-once streams for this part of the sweep: load them
-                            // non-temporal so they do not evict the near (re-used) window of x from L2
-                            const int dist = cc[j] - grow;
-                            const bool isfar = a.far > 0 && (dist > a.far || dist < -a.far);
-                            if (a.debug2 == 2 && isfar) cc[j] &= 1023;          // experiment: drop far traffic
-                            if (a.debug2 == 3 && !isfar) cc[j] &= 1023;         // experiment: drop near traffic
-                            if (isfar) xv[j] = ntload(a.xg + cc[j]);
-                            else xv[j] = a.xg[cc[j]];
-                        }
+                        for (int j = 0; j < UN; ++j) xv[j] = a.xg[cc[j]];
 #pragma unroll
                         for (int j = 0; j < UN; ++j) {
                             if (DICT) vv[j] = dict_s[scode[ix[j]]];
@@ -1085,6 +1067,97 @@ __global__ __launch_bounds__(kBlock) void k_fill_const(d2 *x, int64_t n, double 
 int launch_fill_const(d2 *x, int64_t n, double re, hipStream_t s)
 {
     hipLaunchKernelGGL(k_fill_const, dim3(blas_grid(n)), dim3(kBlock), 0, s, x, n, re);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+
+// --------------------------------------------- Krylov-basis kernels (qbh_iram) --
+// h_i = <V_i, w> for NV basis vectors in ONE pass over w (full re-orthogonalisation of the
+// thick-restart Lanczos basis); partials[(block*NV + i)*2 + {re,im}].
+template <int NV>
+__global__ __launch_bounds__(kBlock) void k_multi_dot(const d2 *V, int64_t ldv, const d2 *w, int64_t n, int nv,
+                                                      double *partials)
+{
+    __shared__ double red[2 * NV * 4];
+    double acc[2 * NV];
+#pragma unroll
+    for (int i = 0; i < 2 * NV; ++i) acc[i] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+        const d2 wv = w[e];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (i < nv) {
+                const d2 vi = V[(size_t)i * ldv + e];
+                acc[2 * i] += vi.x * wv.x + vi.y * wv.y;
+                acc[2 * i + 1] += vi.x * wv.y - vi.y * wv.x;
+            }
+        }
+    }
+    block_sum<2 * NV>(acc, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 2 * NV; ++i) partials[(size_t)blockIdx.x * 2 * NV + i] = acc[i];
+    }
+}
+
+int launch_multi_dot8(const d2 *V, int64_t ldv, const d2 *w, int64_t n, int nv, double *partials, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_multi_dot<8>), dim3(blas_grid(n)), dim3(kBlock), 0, s, V, ldv, w, n, nv, partials);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// w -= sum_i c_i V_i  (c complex), one pass
+__global__ __launch_bounds__(kBlock) void k_multi_axpy(const d2 *V, int64_t ldv, Coef8 c, int nv, d2 *w, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+        d2 acc = w[e];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < nv) {
+                const d2 ci = {c.v[2 * i], c.v[2 * i + 1]};
+                acc -= cmul(ci, V[(size_t)i * ldv + e]);
+            }
+        }
+        w[e] = acc;
+    }
+}
+
+int launch_multi_axpy8(const d2 *V, int64_t ldv, const Coef8 &c, int nv, d2 *w, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_multi_axpy, dim3(blas_grid(n)), dim3(kBlock), 0, s, V, ldv, c, nv, w, n);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// Restart rotation, in place: V[:, c] <- sum_i S[i + c*m] V[:, i]  for c < keep (S real, m <= 32).
+__global__ __launch_bounds__(kBlock) void k_basis_rotate(d2 *V, int64_t ldv, int64_t n, int m, int keep, const double *S)
+{
+    __shared__ double Ss[32 * 32];
+    for (int i = threadIdx.x; i < m * keep; i += kBlock) Ss[i] = S[i];
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+        d2 x[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            if (i < m) x[i] = V[(size_t)i * ldv + e];
+        for (int c = 0; c < keep; ++c) {
+            d2 y = {0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                if (i < m) y += Ss[i + c * m] * x[i];
+            V[(size_t)c * ldv + e] = y;
+        }
+    }
+}
+
+int launch_basis_rotate(d2 *V, int64_t ldv, int64_t n, int m, int keep, const double *d_S, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_basis_rotate, dim3(blas_grid(n)), dim3(kBlock), 0, s, V, ldv, n, m, keep, d_S);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }

@@ -329,31 +329,63 @@ def eigenvec_CG(dim, maxit, m, mat, E0, v, r, p, pp, device=False):
 eigenvec_CG.last = {}
 
 
-def iram(dim, mat, v0, nev, ncv, maxit, order="sr"):
-    """iram<T,MAT> (src/lanczos.cc:497-603): ARPACK IRAM by reverse communication, the matvec
-    being csr_mat.MultMv on the device.  Returns (nconv, eigenvals[nev], eigenvecs[nev*dim]).
-
-    The reference links ARPACK-NG 3.9.0 (znaupd/zneupd, mode 1, bmat='I', tol=0, info=0 so
-    v0 is ignored); here the same ARPACK routines are driven through scipy's bundled copy."""
+def _iram_checks(dim, nev, maxit, order):
     if nev <= 0 or nev >= dim - 1:
-        raise ValueError("0 < nev < N-1 should be satisfied.")          # :502
+        raise ValueError("0 < nev < N-1 should be satisfied.")          # src/lanczos.cc:502
     if maxit < 20:
-        raise ValueError("maxit should not be smaller than 20!")        # :504
+        raise ValueError("maxit should not be smaller than 20!")        # src/lanczos.cc:504
     orderC = order.upper()
     if orderC not in ("SR", "SA", "LR", "LA", "SM", "LM"):
         raise ValueError("Invalid argument orderC.")
     key = {"SR": lambda e: e, "SA": lambda e: e, "LR": lambda e: -e, "LA": lambda e: -e,
            "SM": lambda e: np.abs(e), "LM": lambda e: -np.abs(e)}[orderC]
+    return orderC, key
+
+
+def iram(dim, mat, v0, nev, ncv, maxit, order="sr", method="auto", seed=1):
+    """iram<T,MAT> (src/lanczos.cc:497-603).  Returns (nconv, eigenvals[nev], eigenvecs[nev*dim]).
+
+    method "device" (default where applicable: order sr/lr, ncv <= 32): the restarted Lanczos process
+    runs entirely in HBM (qbh_iram, thick restart == implicit restart for a Hermitian operator).
+    method "arpack": the literal reverse-communication loop of call_arpack (src/lanczos.cc:472-477) with
+    ARPACK's znaupd/zneupd (scipy's bundled copy; mode 1, bmat='I', tol=0, info=0 so v0 is ignored) and
+    csr_mat.MultMv on the device as the matvec -- the vectors cross PCIe on every call."""
+    orderC, key = _iram_checks(dim, nev, maxit, order)
     if dim <= 30:                                                        # :508-542 dense fall-back
         w, z = np.linalg.eigh(mat.to_dense())
         idx = np.argsort(key(w), kind="stable")[:nev]
         return nev, w[idx].copy(), np.concatenate([z[:, j] for j in idx])
+    if method == "auto":
+        method = "device" if (orderC in ("SR", "SA", "LR", "LA") and ncv <= 32) else "arpack"
+    if method == "device":
+        nconv = C.c_int64(0)
+        w = np.zeros(nev)
+        z = np.zeros(nev * mat.dim, dtype=np.complex128)
+        info, keep = _solver_info(maxit, want_log=False)
+        check(lib().qbh_iram(mat.handle, nev, ncv, maxit, orderC.lower().encode(), 0.0, C.c_uint32(seed),
+                             C.byref(nconv), _p(w), _p(z), C.byref(info)), "qbh_iram")
+        iram.last = dict(n_matvec=info.n_matvec, restarts=info.n_reorth, ms_total=info.ms_total)
+        if nconv.value <= 0:
+            raise RuntimeError("nconv == 0...")                          # src/lanczos.cc:566
+        return nconv.value, w, z
+    return iram_arpack(dim, mat, v0, nev, ncv, maxit, order)
+
+
+iram.last = {}
+
+
+def iram_arpack(dim, mat, v0, nev, ncv, maxit, order="sr"):
+    """ARPACK by reverse communication over the host-vector seam (csr_mat.MultMv)."""
+    orderC, key = _iram_checks(dim, nev, maxit, order)
     from scipy.sparse.linalg import LinearOperator, eigs
+
+    count = [0]
 
     def matvec(x):
         x = np.ascontiguousarray(x, dtype=np.complex128).reshape(-1)
         y = np.empty(dim, dtype=np.complex128)
         mat.MultMv(x, y)
+        count[0] += 1
         return y
 
     which = {"SA": "SR", "LA": "LR"}.get(orderC, orderC)
@@ -363,6 +395,7 @@ def iram(dim, mat, v0, nev, ncv, maxit, order="sr"):
         raise RuntimeError("eigenvalue should be real.")
     w = w.real
     idx = np.argsort(key(w), kind="stable")
+    iram.last = dict(n_matvec=count[0])
     return len(idx), w[idx].copy(), np.concatenate([z[:, j] for j in idx])
 
 
@@ -435,14 +468,15 @@ def locate_E0_lanczos(mat, nev=1, ncv=1, maxit=1000):
         v.free()
 
 
-def locate_E0_iram(mat, nev=2, ncv=6, maxit=0):
-    """Work-alike of model<T>::locate_E0_iram (src/model.cc:1319-1366)."""
+def locate_E0_iram(mat, nev=2, ncv=6, maxit=0, method="auto", order="sr"):
+    """Work-alike of model<T>::locate_E0_iram (src/model.cc:1319-1366); order="lr" gives
+    locate_Emax_iram (src/model.cc:1369-1422)."""
     assert nev > 0 and ncv > nev + 1
     if maxit <= 0:
         maxit = nev * 100
     res = E0Result()
-    v0 = np.ones(mat.dim, dtype=np.complex128)
-    nconv, w, z = iram(mat.dim, mat, v0, nev, ncv, maxit, "sr")
+    v0 = None                       # ARPACK info = 0: the reference's v0 is never read (src/lanczos.cc:470)
+    nconv, w, z = iram(mat.dim, mat, v0, nev, ncv, maxit, order, method=method)
     res.nconv = nconv
     res.eigenvals = list(w)
     res.eigenvecs = z

@@ -133,3 +133,45 @@ def expect_sp_sm(vec, basis_bits, i, j):
     tgt = basis_bits[ok] ^ ((1 << i) | (1 << j))
     pos = perm[np.searchsorted(sorted_bits, tgt)]
     return complex(np.sum(np.conj(vec[pos]) * vec[ok]))
+
+
+def tj_chain_csr(L=12, n_elec=8, n_up=4, t=1.0, J=1.0):
+    """t-J chain of src/main_test.cc:113-211 (PBC): H = -t sum P c+_is c_js P + h.c. + J sum (S_i.S_j - n_i n_j / 4),
+    local states 0 = empty, 1 = up, 2 = down, fermion order by site.  Full-storage CSR in the reference layout."""
+    import itertools
+
+    import scipy.sparse as sp
+    states = []
+    for occ in itertools.combinations(range(L), n_elec):
+        for ups in itertools.combinations(occ, n_up):
+            s = [0] * L
+            for i in occ:
+                s[i] = 1 if i in ups else 2
+            states.append(tuple(s))
+    index = {s: i for i, s in enumerate(states)}
+    rows, cols, vals = [], [], []
+    diag = np.zeros(len(states))
+    for a, s in enumerate(states):
+        for i in range(L):
+            j = (i + 1) % L
+            si, sj = s[i], s[j]
+            if si and sj:
+                if si != sj:
+                    diag[a] += -0.5 * J                  # J (-1/4) - J/4
+                    ns = list(s)
+                    ns[i], ns[j] = sj, si                 # (S+_i S-_j + h.c.) / 2
+                    rows.append(index[tuple(ns)]), cols.append(a), vals.append(0.5 * J)
+            elif si or sj:                                # one electron hops across the bond
+                src, dst = (i, j) if si else (j, i)
+                ns = list(s)
+                ns[dst], ns[src] = s[src], 0
+                lo, hi = min(src, dst), max(src, dst)
+                nbetween = sum(1 for q in range(lo + 1, hi) if s[q])
+                sign = -1.0 if nbetween % 2 else 1.0
+                rows.append(index[tuple(ns)]), cols.append(a), vals.append(-t * sign)
+    n = len(states)
+    H = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr() + sp.diags(diag + 1e-300)
+    H = H.tocsr()
+    H.sum_duplicates()
+    H.sort_indices()
+    return n, H.indptr.astype(np.int64), H.indices.astype(np.int64), H.data.astype(np.complex128)

@@ -262,9 +262,9 @@ def test_gauged_complex_hubbard_energy():
 
 
 def test_iram_reverse_communication_matvec():
-    """locate_E0_iram: ARPACK drives csr_mat.MultMv on the device (src/lanczos.cc:473-477)."""
+    """locate_E0_iram, literal path: ARPACK drives csr_mat.MultMv on the device (src/lanczos.cc:473-477)."""
     A, O = _both("hubbard_4x2")
-    res = q.locate_E0_iram(A, nev=2, ncv=8)
+    res = q.locate_E0_iram(A, nev=2, ncv=8, method="arpack")
     assert abs(res.E0 - helpers.known()["hubbard_4x2"]["E0"]) < 1e-8
     assert abs(res.eigenvals[1] - helpers.probe()["hubbard_4x2"]["ritz1"]) < 1e-8
     v0 = res.eigenvecs[:A.dim]
@@ -274,6 +274,52 @@ def test_iram_reverse_communication_matvec():
     S = q.csr_mat(dd, ia, ja, val, True)
     nconv, w, z = q.iram(dd, S, None, 2, 4, 100, "sr")
     assert nconv == 2 and abs(w[0] + 2.0) < 1e-12
+
+
+def test_iram_device_resident_against_arpack_and_known_answers():
+    """qbh_iram (Krylov basis in HBM) against ARPACK's eigenvalues and the reference's asserts."""
+    A, O = _both("hubbard_4x2")
+    nconv, w, z = q.iram(A.dim, A, None, 4, 12, 400, "sr", method="device")
+    _, wa, _ = q.iram_arpack(A.dim, A, None, 4, 12, 400, "sr")
+    assert nconv == 4
+    assert np.allclose(w, wa, rtol=0, atol=1e-9)
+    assert abs(w[0] - helpers.known()["hubbard_4x2"]["E0"]) < 1e-8
+    assert abs(w[0] - helpers.probe()["hubbard_4x2"]["E0"]) <= 1e-10 * abs(w[0])
+    Z = z.reshape(4, A.dim)
+    for j in range(4):                                   # residuals and orthonormality
+        assert np.linalg.norm(O.multmv(Z[j]) - w[j] * Z[j]) < 1e-9
+    assert np.allclose(Z.conj() @ Z.T, np.eye(4), atol=1e-10)
+    # largest eigenvalues ("lr", locate_Emax_iram)
+    dense = np.linalg.eigvalsh(O.to_dense()) if A.dim <= 5000 else None
+    nconv, wl, _ = q.iram(A.dim, A, None, 2, 8, 400, "lr", method="device")
+    assert nconv == 2 and np.allclose(wl, dense[::-1][:2], atol=1e-9)
+    assert np.allclose(w, dense[:4], atol=1e-9)
+
+
+def test_iram_main_test_tj_chain_degenerate_pair():
+    """src/main_test.cc:113-211: locate_E0_iram(full, 4, 8) on the t-J chain, E0 = E1 = -9.762087307."""
+    k = helpers.known()["tJ_chain12"]
+    d, ia, ja, val = helpers.tj_chain_csr()
+    assert d == 34650
+    A = q.csr_mat(d, ia, ja, val, sym=False)
+    res = q.locate_E0_iram(A, nev=4, ncv=8)              # device-resident
+    assert abs(res.eigenvals[0] - k["E0"]) < k["tol"] and abs(res.eigenvals[1] - k["E1"]) < k["tol"]
+    res2 = q.locate_E0_iram(A, nev=4, ncv=8, method="arpack")
+    assert abs(res2.eigenvals[0] - k["E0"]) < k["tol"] and abs(res2.eigenvals[1] - k["E1"]) < k["tol"]
+    assert np.allclose(res.eigenvals, res2.eigenvals, atol=1e-8)
+    # the two degenerate eigenvectors span the same plane in both solvers
+    Zd = res.eigenvecs.reshape(4, d)[:2]
+    Za = np.linalg.qr(res2.eigenvecs.reshape(4, d)[:2].T)[0].T       # ARPACK's pair is not exactly orthonormal
+    assert np.allclose(Zd.conj() @ Zd.T, np.eye(2), atol=1e-10)       # the device pair is
+    sv = np.linalg.svd(Zd.conj() @ Za.T, compute_uv=False)
+    assert np.all(np.abs(sv - 1.0) < 1e-6)
+
+
+def test_iram_complex_momentum_sector():
+    ans = helpers.known()["chain16_momentum"]
+    A, _ = _both("chain16_k3")
+    nconv, w, _ = q.iram(A.dim, A, None, 2, 8, 400, "sr")
+    assert abs(w[0] - ans["E0_k"][3]) < ans["tol"]
 
 
 def test_value_dictionary_is_exact():
