@@ -168,6 +168,11 @@ typedef struct qbh_solver_info {
     double           ms_total; /* out: wall ms inside the call                                    */
     double           ms_spmv;  /* out: sum of HIP-event SpMV kernel ms (opts.profile)             */
     double          *cg_resid; /* in: NULL or room for maxit+1 doubles (log_CG.txt residuals)     */
+    /* Lanczos convergence bookkeeping (what the reference checkpoints in lczs_mlns.dat,
+     * src/ckpt.cc:252-257): always written on exit; read on entry when resume != 0.          */
+    int64_t          resume;
+    int64_t          cnt_accuE0;
+    double           accuracy, theta0_prev, theta1_prev;
 } qbh_solver_info;
 
 /* Replaces lanczos<T,MAT> for MAT = csr_mat (src/lanczos.cc:134-266), purposes "sr_val0",

@@ -48,7 +48,9 @@ class LanczosRow(C.Structure):
 class SolverInfo(C.Structure):
     _fields_ = [("log", C.POINTER(LanczosRow)), ("log_cap", C.c_int64), ("log_len", C.c_int64),
                 ("n_matvec", C.c_int64), ("n_reorth", C.c_int64), ("ms_total", C.c_double),
-                ("ms_spmv", C.c_double), ("cg_resid", C.POINTER(C.c_double))]
+                ("ms_spmv", C.c_double), ("cg_resid", C.POINTER(C.c_double)),
+                ("resume", C.c_int64), ("cnt_accuE0", C.c_int64), ("accuracy", C.c_double),
+                ("theta0_prev", C.c_double), ("theta1_prev", C.c_double)]
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)

@@ -1,0 +1,182 @@
+"""Checkpoint / resume of the Lanczos run in the reference's on-disk format.
+
+File-compatible with src/ckpt.cc + src/miscellaneous.cc:439-469 for the "val" purposes:
+
+  out_Qckpt/HessenbergA.dat   vec_disk format, m doubles      a[0..m)
+  out_Qckpt/HessenbergB.dat   vec_disk format, m+1 doubles    b[0..m]
+  out_Qckpt/lanczosV<m-1>.dat, lanczosV<m>.dat   vec_disk format, dim complex128 each
+  out_Qckpt/lanczosY0.dat     (sr_val1 only) phi0
+  out_Qckpt/lczs_mlns.dat     int32 cnt_accuE0, double accuracy, theta0_prev, theta1_prev
+  out_Qckpt/lczs_updt.Qckpt1/2   two-phase commit markers holding the step number (int64)
+
+vec_disk format: int64 n | n * sizeof(T) payload | CRC-32 (reflected 0xEDB88320, i.e. zlib's) of
+the 8 header bytes followed by the payload, stored as uint32.
+
+The device loop is not interrupted per step: `lanczos_checkpointed` advances the run in chunks with
+the continuation form lanczos(k, np, ...) (src/qbasis.h:1030), and after each chunk downloads the two
+live vectors and commits a checkpoint with the same *.new + marker + rename protocol.
+"""
+import os
+import struct
+import zlib
+
+import numpy as np
+
+CKPT_DIR = "out_Qckpt"
+
+
+def vec_disk_write(filename, x):
+    """src/miscellaneous.cc:439-469."""
+    x = np.ascontiguousarray(x)
+    head = struct.pack("<q", x.size)
+    crc = zlib.crc32(head)
+    payload = x.tobytes()
+    for off in range(0, len(payload), 1 << 20):               # 1 MiB chunks like the reference
+        crc = zlib.crc32(payload[off:off + (1 << 20)], crc)
+    with open(filename, "wb") as f:
+        f.write(head)
+        f.write(payload)
+        f.write(struct.pack("<I", crc & 0xFFFFFFFF))
+    return 0
+
+
+def vec_disk_read(filename, n, dtype):
+    """src/miscellaneous.cc:391-436: returns the array, or None where the reference returns 1."""
+    dtype = np.dtype(dtype)
+    if not os.path.exists(filename):
+        return None
+    if os.path.getsize(filename) != 8 + dtype.itemsize * n + 4:
+        return None
+    with open(filename, "rb") as f:
+        head = f.read(8)
+        if struct.unpack("<q", head)[0] != n:
+            return None
+        payload = f.read(dtype.itemsize * n)
+        (crc_file,) = struct.unpack("<I", f.read(4))
+    crc = zlib.crc32(payload, zlib.crc32(head)) & 0xFFFFFFFF
+    if crc != crc_file:
+        return None
+    return np.frombuffer(payload, dtype=dtype).copy()
+
+
+def _p(d, name):
+    return os.path.join(d, name)
+
+
+def ckpt_lanczos_update(m, maxit, dim, state, v_pair, hessenberg, purpose, phi0=None, directory=CKPT_DIR):
+    """ckpt_lanczos_update for the "val" purposes (src/ckpt.cc:178-297).  v_pair: host array holding
+    v[m-1], v[m] in the reference's slots ((j%2)*dim)."""
+    os.makedirs(directory, exist_ok=True)
+    for mk in ("lczs_updt.Qckpt1", "lczs_updt.Qckpt2"):
+        if os.path.exists(_p(directory, mk)):
+            os.remove(_p(directory, mk))
+    with open(_p(directory, "lczs_updt.Qckpt1"), "wb") as f:
+        f.write(struct.pack("<q", m))
+    vec_disk_write(_p(directory, "HessenbergA.dat.new"), hessenberg[maxit:maxit + m])
+    vec_disk_write(_p(directory, "HessenbergB.dat.new"), hessenberg[:m + 1])
+    if m > 0 and not os.path.exists(_p(directory, "lanczosV%d.dat" % (m - 1))):
+        s = ((m - 1) % 2) * dim
+        vec_disk_write(_p(directory, "lanczosV%d.dat" % (m - 1)), v_pair[s:s + dim])
+    s = (m % 2) * dim
+    vec_disk_write(_p(directory, "lanczosV%d.dat" % m), v_pair[s:s + dim])
+    if "val0" not in purpose and phi0 is not None:
+        vec_disk_write(_p(directory, "lanczosY0.dat.new"), phi0)
+    with open(_p(directory, "lczs_mlns.dat.new"), "wb") as f:
+        f.write(struct.pack("<iddd", int(state["cnt_accuE0"]), state["accuracy"], state["theta0_prev"], state["theta1_prev"]))
+    with open(_p(directory, "lczs_updt.Qckpt2"), "wb") as f:      # before / after this point: old / new data
+        f.write(struct.pack("<q", m))
+    for name in ("HessenbergA.dat", "HessenbergB.dat", "lczs_mlns.dat"):
+        if os.path.exists(_p(directory, name)):
+            os.remove(_p(directory, name))
+    for name in os.listdir(directory):
+        if name.startswith("lanczosV") and name.endswith(".dat"):
+            k = int(name[len("lanczosV"):-4])
+            if k < m - 1:
+                os.remove(_p(directory, name))
+    os.replace(_p(directory, "HessenbergA.dat.new"), _p(directory, "HessenbergA.dat"))
+    os.replace(_p(directory, "HessenbergB.dat.new"), _p(directory, "HessenbergB.dat"))
+    if os.path.exists(_p(directory, "lanczosY0.dat.new")):
+        os.replace(_p(directory, "lanczosY0.dat.new"), _p(directory, "lanczosY0.dat"))
+    os.replace(_p(directory, "lczs_mlns.dat.new"), _p(directory, "lczs_mlns.dat"))
+    os.remove(_p(directory, "lczs_updt.Qckpt1"))
+    os.remove(_p(directory, "lczs_updt.Qckpt2"))
+
+
+def ckpt_lanczos_init(maxit, dim, purpose, directory=CKPT_DIR):
+    """ckpt_lanczos_init for the "val" purposes (src/ckpt.cc:38-176), clean-state branch: returns
+    None when there is no usable checkpoint, else dict(k, state, v_pair, hessenberg, phi0).  A torn
+    update (marker files present) is treated as unusable rather than rewound."""
+    if not os.path.isdir(directory):
+        return None
+    if os.path.exists(_p(directory, "lczs_updt.Qckpt1")) or os.path.exists(_p(directory, "lczs_updt.Qckpt2")):
+        return None
+    ks = sorted(int(n[len("lanczosV"):-4]) for n in os.listdir(directory)
+                if n.startswith("lanczosV") and n.endswith(".dat"))
+    if len(ks) < 2 or ks[-1] != ks[-2] + 1:
+        return None
+    m = ks[-1]
+    a = vec_disk_read(_p(directory, "HessenbergA.dat"), m, np.float64)
+    b = vec_disk_read(_p(directory, "HessenbergB.dat"), m + 1, np.float64)
+    v1 = vec_disk_read(_p(directory, "lanczosV%d.dat" % (m - 1)), dim, np.complex128)
+    v2 = vec_disk_read(_p(directory, "lanczosV%d.dat" % m), dim, np.complex128)
+    if a is None or b is None or v1 is None or v2 is None or not os.path.exists(_p(directory, "lczs_mlns.dat")):
+        return None
+    cnt, accuracy, t0, t1 = struct.unpack("<iddd", open(_p(directory, "lczs_mlns.dat"), "rb").read(28))
+    hess = np.zeros(2 * maxit)
+    hess[maxit:maxit + m] = a
+    hess[:m + 1] = b
+    v_pair = np.zeros(2 * dim, dtype=np.complex128)
+    v_pair[((m - 1) % 2) * dim:((m - 1) % 2 + 1) * dim] = v1
+    v_pair[(m % 2) * dim:(m % 2 + 1) * dim] = v2
+    phi0 = None
+    if "val0" not in purpose:
+        phi0 = vec_disk_read(_p(directory, "lanczosY0.dat"), dim, np.complex128)
+    return dict(k=m, state=dict(cnt_accuE0=cnt, accuracy=accuracy, theta0_prev=t0, theta1_prev=t1),
+                v_pair=v_pair, hessenberg=hess, phi0=phi0)
+
+
+def lanczos_checkpointed(mat, maxit, purpose="sr_val0", every=50, directory=CKPT_DIR, v0=None, phi0=None,
+                         max_steps=None):
+    """Run (or resume) lanczos(0, maxit-1, ...) with a checkpoint every `every` steps.
+    Returns (m, hessenberg, v_pair, converged)."""
+    from . import engine
+    dim = mat.dim
+    nvec = 3 if "val1" in purpose else 2
+    ck = ckpt_lanczos_init(maxit, dim, purpose, directory)
+    dv = mat.vec(nvec)
+    if ck is None:
+        hess = np.zeros(2 * maxit)
+        k, state = 0, None
+        if v0 is None:
+            mat.randomize(dv.at(0), 1)
+        else:
+            dv.upload(v0, 0)
+        if nvec == 3:
+            dv.upload(phi0, 2 * dim)
+    else:
+        hess, k, state = ck["hessenberg"], ck["k"], ck["state"]
+        dv.upload(ck["v_pair"], 0)
+        if nvec == 3:
+            dv.upload(ck["phi0"] if ck["phi0"] is not None else phi0, 2 * dim)
+    done_steps, converged, m = 0, False, k
+    try:
+        while m < maxit - 1:
+            np_steps = min(every, maxit - 1 - m)
+            if max_steps is not None:
+                np_steps = min(np_steps, max_steps - done_steps)
+                if np_steps <= 0:
+                    break
+            m_new = engine.lanczos(m, np_steps, maxit, dim, mat, None, hess, purpose, device_v=dv, state=state)
+            state = engine.lanczos.last["state"]
+            done_steps += m_new - m
+            stopped_early = m_new < m + np_steps
+            m = m_new
+            v_pair = dv.download(0, 2 * dim)
+            ckpt_lanczos_update(m, maxit, dim, state, v_pair, hess, purpose,
+                                phi0=dv.download(2 * dim, dim) if nvec == 3 else None, directory=directory)
+            if stopped_early or (state["cnt_accuE0"] > 15 and state["accuracy"] < engine.lanczos_precision):
+                converged = True
+                break
+        return m, hess, dv.download(0, 2 * dim), converged
+    finally:
+        dv.free()

@@ -842,8 +842,21 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
         --np;
     }
 
+    // convergence bookkeeping; restored from / returned in info->state so that a run can be resumed
+    // exactly where a checkpoint left it (what ckpt_lanczos_init restores, src/ckpt.cc:38-176)
     double theta0_prev = 0.0, theta1_prev = 0.0, accuracy = 0.0;
     int cnt_accuE0 = 0;
+    if (info && info->resume) {
+        cnt_accuE0 = (int)info->cnt_accuE0;
+        accuracy = info->accuracy;
+        theta0_prev = info->theta0_prev;
+        theta1_prev = info->theta1_prev;
+        if (cnt_accuE0 > 15 && accuracy < prec) {          // already converged (src/lanczos.cc:149)
+            QBH_TRY(normalise_slots());
+            *m_out = m;
+            return QBH_OK;
+        }
+    }
     std::vector<double> w((size_t)mm + 2), zl((size_t)mm + 2), ws((size_t)mm + 2);
     int rc = QBH_OK;
     do {                                                   // :193
@@ -909,6 +922,10 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
     harvest_events(A);
     *m_out = m;
     if (info) {
+        info->cnt_accuE0 = cnt_accuE0;
+        info->accuracy = accuracy;
+        info->theta0_prev = theta0_prev;
+        info->theta1_prev = theta1_prev;
         if (info->log && info->log_len > info->log_cap) info->log_len = info->log_cap;
         info->n_matvec = A->stats.n_spmv - spmv0;
         info->ms_spmv = A->stats.ms_spmv - ms_spmv0;

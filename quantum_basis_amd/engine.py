@@ -279,7 +279,7 @@ def _rows(info):
             for i in range(info.log_len)]
 
 
-def lanczos(k, np_steps, maxit, dim, mat, v, hessenberg, purpose, device_v=None):
+def lanczos(k, np_steps, maxit, dim, mat, v, hessenberg, purpose, device_v=None, state=None):
     """lanczos<T,MAT> (src/lanczos.cc:134): returns m; v and hessenberg are updated in place.
 
     v is a host array (2*dim, 3*dim for sr_val1) unless device_v (a DeviceVec) is given, in
@@ -289,6 +289,10 @@ def lanczos(k, np_steps, maxit, dim, mat, v, hessenberg, purpose, device_v=None)
     assert hessenberg.dtype == np.float64 and hessenberg.size >= 2 * maxit
     m = C.c_int64(0)
     info, keep = _solver_info(maxit)
+    if state is not None:                      # resume exactly where a checkpoint left the stop test
+        info.resume = 1
+        info.cnt_accuE0 = int(state["cnt_accuE0"])
+        info.accuracy, info.theta0_prev, info.theta1_prev = state["accuracy"], state["theta0_prev"], state["theta1_prev"]
     if device_v is not None:
         rc = lib().qbh_lanczos_dev(mat.handle, k, np_steps, maxit, C.byref(m), device_v.ptr, _p(hessenberg),
                                    purpose.encode(), C.byref(info))
@@ -298,7 +302,9 @@ def lanczos(k, np_steps, maxit, dim, mat, v, hessenberg, purpose, device_v=None)
                                purpose.encode(), C.byref(info))
     check(rc, "qbh_lanczos")
     lanczos.last = dict(log=_rows(info), n_matvec=info.n_matvec, n_reorth=info.n_reorth,
-                        ms_total=info.ms_total, ms_spmv=info.ms_spmv)
+                        ms_total=info.ms_total, ms_spmv=info.ms_spmv,
+                        state=dict(cnt_accuE0=int(info.cnt_accuE0), accuracy=info.accuracy,
+                                   theta0_prev=info.theta0_prev, theta1_prev=info.theta1_prev))
     return m.value
 
 
@@ -397,6 +403,34 @@ def iram_arpack(dim, mat, v0, nev, ncv, maxit, order="sr"):
     idx = np.argsort(key(w), kind="stable")
     iram.last = dict(n_matvec=count[0])
     return len(idx), w[idx].copy(), np.concatenate([z[:, j] for j in idx])
+
+
+def measure_full_dynamic(mat, vec_new, maxit):
+    """The device part of model<T>::measure_full_dynamic (src/model.cc:1696-1712): given
+    vec_new = A_q |phi> (built by the host's moprXvec_full), returns (m, norm, hessenberg) of the
+    "dnmcs" Lanczos run whose continued fraction is the dynamical correlation function."""
+    dim = mat.dim
+    v = np.zeros(2 * dim, dtype=np.complex128)
+    v[:dim] = vec_new
+    norm = float(np.linalg.norm(v[:dim]))
+    hessenberg = np.zeros(2 * maxit)
+    if abs(norm) < lanczos_precision:
+        return 0, norm, hessenberg
+    v[:dim] /= norm
+    m = lanczos(0, maxit - 1, maxit, dim, mat, v, hessenberg, "dnmcs")
+    return m, norm, hessenberg
+
+
+def write_lanczos_log(rows, filename):
+    """Append the rows returned by lanczos() in the format of log_Lanczos_srval (src/lanczos.cc:102-128)."""
+    head1 = "".join("%20s" % s for s in ("#(1)", "(2)", "(3)", "(4)", "(5)", "(6)", "(7)", "(8)", "(9)", "(10)"))
+    head2 = "".join("%20s" % s for s in ("Iter(k)", "Ritz[0]", "Ritz[1]", "Ritz[2]", "Ritz[3]", "a[k-1]", "b[k]",
+                                         "accuracy", "accu_E0", "accu_E1"))
+    with open(filename, "a") as f:
+        for r in rows:
+            vals = [r["k"]] + list(r["ritz"]) + [r["a"], r["b"], r["accuracy"], r["accu_E0"], r["accu_E1"]]
+            f.write(head1 + "\n" + head2 + "\n")
+            f.write("%20d" % vals[0] + "".join("%20.10g" % x for x in vals[1:]) + "\n")
 
 
 class E0Result:

@@ -1,0 +1,86 @@
+"""Checkpoint files in the reference's on-disk format (src/miscellaneous.cc:391-469, src/ckpt.cc:178-297)
+and exact resume of the device Lanczos run."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from quantum_basis_amd import ckpt
+
+
+def test_vec_disk_format_is_the_references(tmp_path):
+    x = (np.arange(70001) * 0.25 - 3j * np.arange(70001)).astype(np.complex128)     # > 1 MiB: several CRC chunks
+    f = str(tmp_path / "lanczosV7.dat")
+    assert ckpt.vec_disk_write(f, x) == 0
+    raw = open(f, "rb").read()
+    # int64 n | payload | CRC-32 over (n, payload); boost::crc_32_type == zlib's CRC-32
+    assert len(raw) == 8 + 16 * x.size + 4
+    assert struct.unpack("<q", raw[:8])[0] == x.size
+    assert raw[8:-4] == x.tobytes()
+    assert struct.unpack("<I", raw[-4:])[0] == zlib.crc32(raw[:-4]) & 0xFFFFFFFF
+    assert np.array_equal(ckpt.vec_disk_read(f, x.size, np.complex128), x)
+    # the reference returns 1 on: missing file, wrong size, wrong n, wrong checksum
+    assert ckpt.vec_disk_read(str(tmp_path / "nope.dat"), x.size, np.complex128) is None
+    assert ckpt.vec_disk_read(f, x.size - 1, np.complex128) is None
+    bad = bytearray(raw)
+    bad[100] ^= 0x40
+    open(f, "wb").write(bytes(bad))
+    assert ckpt.vec_disk_read(f, x.size, np.complex128) is None
+    d = np.linspace(0, 1, 17)
+    g = str(tmp_path / "HessenbergA.dat")
+    ckpt.vec_disk_write(g, d)
+    assert os.path.getsize(g) == 8 + 8 * 17 + 4 and np.array_equal(ckpt.vec_disk_read(g, 17, np.float64), d)
+
+
+def test_checkpoint_directory_protocol(tmp_path):
+    d = str(tmp_path / "out_Qckpt")
+    dim, maxit = 50, 40
+    rng = np.random.default_rng(0)
+    hess = rng.normal(size=2 * maxit)
+    v = (rng.normal(size=2 * dim) + 1j * rng.normal(size=2 * dim)).astype(np.complex128)
+    st = dict(cnt_accuE0=3, accuracy=1.5e-7, theta0_prev=-4.25, theta1_prev=-3.5)
+    assert ckpt.ckpt_lanczos_init(maxit, dim, "sr_val0", d) is None
+    ckpt.ckpt_lanczos_update(6, maxit, dim, st, v, hess, "sr_val0", directory=d)
+    ckpt.ckpt_lanczos_update(7, maxit, dim, st, v, hess, "sr_val0", directory=d)
+    names = sorted(os.listdir(d))
+    assert names == ["HessenbergA.dat", "HessenbergB.dat", "lanczosV6.dat", "lanczosV7.dat", "lczs_mlns.dat"]
+    ck = ckpt.ckpt_lanczos_init(maxit, dim, "sr_val0", d)
+    assert ck["k"] == 7 and ck["state"] == st
+    assert np.array_equal(ck["hessenberg"][maxit:maxit + 7], hess[maxit:maxit + 7])
+    assert np.array_equal(ck["hessenberg"][:8], hess[:8])
+    assert np.array_equal(ck["v_pair"], v)
+    # lczs_mlns.dat layout: int cnt, double accuracy, double theta0_prev, double theta1_prev (src/ckpt.cc:252-257)
+    assert struct.unpack("<iddd", open(os.path.join(d, "lczs_mlns.dat"), "rb").read()) == (3, 1.5e-7, -4.25, -3.5)
+    # a torn update (marker present) is not used
+    open(os.path.join(d, "lczs_updt.Qckpt1"), "wb").write(struct.pack("<q", 8))
+    assert ckpt.ckpt_lanczos_init(maxit, dim, "sr_val0", d) is None
+
+
+@pytest.mark.gpu
+def test_interrupted_run_resumes_to_the_same_answer(tmp_path):
+    import helpers
+    import quantum_basis_amd as q
+    d, ia, ja, val, sym = helpers.case("hubbard_4x2")
+    g = helpers.probe()["hubbard_4x2"]
+    maxit = 1000
+    ckdir = str(tmp_path / "out_Qckpt")
+    A = q.csr_mat(d, ia, ja, val, sym)
+    m1, hess1, _, conv1 = ckpt.lanczos_checkpointed(A, maxit, "sr_val0", every=10, directory=ckdir, max_steps=30)
+    assert m1 == 30 and not conv1
+    A.destroy()
+    B = q.csr_mat(d, ia, ja, val, sym)                    # "new process": everything comes back from the files
+    m2, hess2, v_pair, conv2 = ckpt.lanczos_checkpointed(B, maxit, "sr_val0", every=25, directory=ckdir)
+    assert conv2 and abs(m2 - g["lanczos_m"]) <= 1
+    ritz, _ = q.hess_eigen(hess2, maxit, m2, "sr")
+    assert abs(ritz[0] - g["E0"]) <= 1e-10 * abs(g["E0"])
+    assert np.array_equal(hess2[maxit:maxit + 30], hess1[maxit:maxit + 30])       # the first 30 steps came from disk
+    # uninterrupted reference run on the same device path
+    v = np.zeros(2 * d, dtype=np.complex128)
+    v[:d] = q.vec_randomize(B, seed=1)
+    h0 = np.zeros(2 * maxit)
+    m0 = q.lanczos(0, maxit - 1, maxit, d, B, v, h0, "sr_val0")
+    assert abs(m0 - m2) <= 1
+    assert np.allclose(h0[maxit:maxit + 40], hess2[maxit:maxit + 40], rtol=1e-9)
+    assert abs(np.linalg.norm(v_pair[:d]) - 1.0) < 1e-12
