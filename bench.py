@@ -96,7 +96,24 @@ def cpu_baseline(A, dim, budget_rows):
     ms_spmv = 1e3 * t_spmv / n * scale
     ms_iter = 1e3 * (t_spmv + t_blas) / n * scale
     bytes_alg = slab.nnz * 20 + (R + 1) * 8 + R * 32
-    return {"value": round(1e3 / ms_iter, 4), "unit": "lanczos_iters/s", "cores": qo.num_threads(), "kind": "port",
+    mkl = None
+    try:        # the reference's own SpMV library, when the image has it: mkl_sparse_z_mv on the same slab
+        from oracle import mkl_ref
+        if mkl_ref.load() is not None:
+            M = mkl_ref.MklCsr(R, slab.ia, slab.ja, slab.val, False, ncols=dim)
+            ym = np.zeros(R, dtype=np.complex128)
+            M.multmv2(x, ym)
+            t0 = time.perf_counter()
+            nm = 0
+            while nm < 3 or (time.perf_counter() - t0 < 4.0 and nm < 30):
+                M.multmv2(x, ym)
+                nm += 1
+            tm = (time.perf_counter() - t0) / nm
+            mkl = {"spmv_ms_scaled": round(1e3 * tm * scale, 3), "spmv_GBps": round(bytes_alg / tm / 1e9, 3),
+                   "threads": M.threads(), "call": "mkl_sparse_z_mv, GENERAL descriptor, full storage, no mkl_sparse_optimize (src/sparse.cc:262-289)"}
+    except Exception as e:
+        mkl = {"error": repr(e)}
+    return {"value": round(1e3 / ms_iter, 4), "unit": "lanczos_iters/s", "cores": qo.num_threads(), "kind": "port", "mkl": mkl,
             "sample": "first %d of %d rows (%d nnz) of the same operator, full-length x, %d timed passes of "
                       "oracle qbo_multmv2 (OpenMP, full storage) + the step's BLAS-1; scaled by dim/rows"
                       % (R, dim, slab.nnz, n),
@@ -116,6 +133,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed run to convergence (E0)")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)
+    ap.add_argument("--no-plain", action="store_true", help="skip the extra (untimed-region) measurement of the uncoded complex128 kernel")
     args = ap.parse_args()
 
     import torch
@@ -249,6 +267,28 @@ def main():
                      "bytes_per_launch": bytes_launch, "ms_per_launch": round(ms_spmv, 4), "launches": int(st.n_spmv)},
         "e0": e0, "lanczos_steps_to_converge": steps_e0,
     }
+    if world == 1 and info.value_dict and not args.no_plain:
+        # transparency: the same SpMV with the value stream left as complex128 (16 B/nnz), measured after the
+        # timed region on a second copy of the operator (it needs the full 20 B/nnz in HBM)
+        try:
+            with torch.cuda.stream(stream):
+                P = build_operator(W, (r0, r1), q.make_opts(device=local_rank, stream=stream.cuda_stream,
+                                                             value_dict=0, xcd_swizzle=args.swizzle, profile=1))
+                pv = P.vec(2)
+                P.randomize(pv.at(0), 1)
+                P.spmv(pv.at(0), pv.at(n), 1.0, 0.0, 0.0, want_red=True)
+                P.stats(reset=True)
+                for _ in range(5):
+                    P.spmv(pv.at(0), pv.at(n), 1.0, -0.5, 0.0, want_red=True)
+                ps = P.stats()
+                pms = ps.ms_spmv / max(ps.n_spmv, 1)
+                out["roofline_plain_values"] = {"kernel": "k_spmv_rows (complex128 values)", "ms_per_launch": round(pms, 4),
+                                                "achieved": round(bytes_launch / pms / 1e6, 2), "unit": "GB/s",
+                                                "frac": round(bytes_launch / pms / 1e6 / HBM_PEAK_GBPS, 4), "launches": int(ps.n_spmv)}
+                pv.free()
+                P.destroy()
+        except Exception as e:
+            out["roofline_plain_values"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(A, dim, args.cpu_rows)

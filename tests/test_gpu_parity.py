@@ -439,3 +439,32 @@ def test_medium_size_properties_chain22():
     res = q.locate_E0_lanczos(A, nev=1, ncv=0)
     assert abs(res.E0 - g["E0"]) <= E0_RTOL * abs(g["E0"])
     assert abs(res.steps["E0"] - g["lanczos_m"]) <= 3
+
+
+def test_measure_full_dynamic_and_log_writer(tmp_path):
+    """The device part of model::measure_full_dynamic (src/model.cc:1696-1712: normalise A_q|phi>, then
+    lanczos(..., "dnmcs")) and the log_Lanczos_<purpose>.txt writer (src/lanczos.cc:102-128)."""
+    A, O = _both("kagome_12")
+    dim, maxit = A.dim, 60
+    vec = _rand(dim, 41) * 3.0
+    m, norm, hess = q.measure_full_dynamic(A, vec, maxit)
+    assert m == maxit - 1 and abs(norm - np.linalg.norm(vec)) < 1e-12
+    vo = np.zeros(2 * dim, dtype=np.complex128)
+    vo[:dim] = vec / np.linalg.norm(vec)
+    ho = np.zeros(2 * maxit)
+    mo, _, _ = qo.lanczos(0, maxit - 1, maxit, O, vo, ho, "dnmcs")
+    assert mo == m
+    assert np.allclose(hess[maxit:maxit + 25], ho[maxit:maxit + 25], rtol=1e-8)
+    assert np.allclose(hess[1:26], ho[1:26], rtol=1e-8)
+    assert q.measure_full_dynamic(A, np.zeros(dim, dtype=np.complex128), maxit)[0] == 0      # norm < lanczos_precision: no run
+    v = np.zeros(2 * dim, dtype=np.complex128)
+    v[:dim] = qo.vec_randomize(dim, 1)
+    h = np.zeros(2 * 1000)
+    q.lanczos(0, 999, 1000, dim, A, v, h, "sr_val0")
+    rows = q.lanczos.last["log"]
+    f = str(tmp_path / "log_Lanczos_sr_val0.txt")
+    q.write_lanczos_log(rows, f)
+    lines = open(f).read().splitlines()
+    assert len(lines) == 3 * len(rows) and lines[0].split()[0] == "#(1)" and lines[1].split()[0] == "Iter(k)"
+    first = lines[2].split()
+    assert int(first[0]) == 4 and abs(float(first[1]) - rows[0]["ritz"][0]) < 1e-8 * abs(rows[0]["ritz"][0])
