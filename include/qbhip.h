@@ -218,6 +218,8 @@ int qbh_hess_eigen(const double *hessenberg, int64_t maxit, int64_t m, const cha
  * [r*nblk, min((r+1)*nblk, ncols)).  The host side (torch.distributed over RCCL in this
  * repo) owns the buffers and implements the two exchange steps the path has:
  *   allgather_x : d_xfull[q*nblk .. (q+1)*nblk) <- d_xsend of rank q, for all q
+ *                 (a genuine shard, nrows < ncols, is split at creation into locally-owned and
+ *                 remote columns; qbh_csr_download merges them back)
  *   allreduce   : in-place sum over ranks of d_scal[off .. off+n)
  * Both are enqueued on (or ordered with) the operator's stream and return 0 on success. */
 typedef struct qbh_comm {
@@ -229,6 +231,11 @@ typedef struct qbh_comm {
     void    *ctx;
     int    (*allgather_x)(void *ctx);
     int    (*allreduce_sum)(void *ctx, int off, int n);
+    /* optional split form of allgather_x (NULL = not provided): begin() enqueues the exchange and
+     * returns, wait() orders the operator's stream after its completion.  When both are given, a row
+     * shard applies its locally-owned columns between the two calls (overlap with xGMI traffic). */
+    int    (*allgather_begin)(void *ctx);
+    int    (*allgather_wait)(void *ctx);
 } qbh_comm;
 int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm);
 

@@ -119,6 +119,119 @@ struct Bind {   // make the operator's device current for the duration of a call
 
 int try_value_dict(qbh_csr *A);
 
+// row-block geometry of one part (ia of length nrows+1, nnz entries)
+int setup_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, bool coded, int *npb_o, int *tpr_o, int *unroll_o,
+                   int64_t *window_o, int64_t *n_blocks_o, int32_t **d_rb_o, int64_t **d_bp_o, int *grid_o)
+{
+    hipStream_t s = A->stream;
+    const qbh_opts &o = A->opts;
+    // longest row -> nnz window of a row block
+    QBH_TRY(qbh::launch_max_rowlen(d_ia, A->nrows, (int64_t *)A->d_scal, s));
+    int64_t maxlen = 0;
+    QBH_HIP(hipMemcpyAsync(&maxlen, A->d_scal, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    QBH_HIP(hipStreamSynchronize(s));
+    const double avg = A->nrows > 0 ? (double)nnz / (double)A->nrows : 0.0;
+    int npb, tpr, unroll = 4;
+    if (A->kernel == QBH_KERNEL_ROWS) {
+        // measured on C3 (SURVEY 8d): coded 8192/P=1/8 gathers in flight is HBM-bound on its real
+        // traffic; the plain kernel stages 16-byte values and is limited to 2048 by LDS occupancy.
+        npb = coded ? 8192 : 2048;
+        const double cap_rows = 0.75 * qbh::kRowCap * (avg > 1.0 ? avg : 1.0);   // keep rows/block under kRowCap
+        while (npb > 1024 && (double)npb > cap_rows) npb >>= 1;
+        if (o.nnz_per_block > 0) npb = o.nnz_per_block;
+        tpr = avg <= 64 ? 1 : avg <= 128 ? 2 : avg <= 256 ? 4 : 8;
+        if (!coded && avg > 12) tpr = avg <= 96 ? 4 : 8;
+        unroll = tpr == 1 ? 8 : 4;
+    } else {
+        npb = o.nnz_per_block > 0 ? o.nnz_per_block : 2048;
+        if (A->kernel == QBH_KERNEL_VECTOR) tpr = avg <= 6 ? 4 : avg <= 12 ? 8 : avg <= 40 ? 16 : avg <= 96 ? 32 : 64;
+        else                                tpr = avg <= 3 ? 1 : avg <= 8 ? 2 : avg <= 48 ? 4 : avg <= 128 ? 8 : 16;
+    }
+    if (npb != 1024 && npb != 2048 && npb != 4096 && !(npb == 8192 && A->kernel == QBH_KERNEL_ROWS && coded)) {
+        qbh::set_error("nnz_per_block must be 1024, 2048 or 4096 (8192: row kernel with value dictionary only)");
+        return QBH_EINVAL;
+    }
+    if (const char *e = getenv("QBH_TPR")) tpr = atoi(e);            // tuning experiments
+    if (const char *e = getenv("QBH_UNROLL")) unroll = atoi(e);
+    // a block holds the rows that START inside its window, so it can exceed the window by
+    // one row; keep window + maxlen - 1 <= npb when rows are short, otherwise let the
+    // oversized-block path take the few long rows.
+    int64_t window = (maxlen <= npb / 2) ? npb - (maxlen > 0 ? maxlen - 1 : 0) : npb / 2;
+    int64_t n_blocks = std::max<int64_t>(1, (nnz + window - 1) / window);
+    QBH_HIP(hipMalloc(d_rb_o, (size_t)(n_blocks + 1) * sizeof(int32_t)));
+    QBH_HIP(hipMalloc(d_bp_o, (size_t)(n_blocks + 1) * sizeof(int64_t)));
+    QBH_TRY(qbh::launch_build_rowblocks(d_ia, A->nrows, window, *d_rb_o, *d_bp_o, n_blocks, s));
+    *npb_o = npb;
+    *tpr_o = tpr;
+    *unroll_o = unroll;
+    *window_o = window;
+    *n_blocks_o = n_blocks;
+    *grid_o = qbh::spmv_grid(A->kernel, n_blocks, A->nrows, tpr);
+    return QBH_OK;
+}
+
+// A genuine row shard (nrows < ncols) is split into locally-owned columns and remote columns so the
+// local part can run while the all-gather of x is in flight.
+int split_shard(qbh_csr *A)
+{
+    if (A->nrows == A->ncols || A->nnz == 0) return QBH_OK;
+    if (const char *e = getenv("QBH_NO_SPLIT")) {
+        if (atoi(e)) return QBH_OK;
+    }
+    hipStream_t s = A->stream;
+    const int32_t lo = (int32_t)A->row_offset, hi = (int32_t)(A->row_offset + A->nrows);
+    int32_t *cnt = nullptr;
+    int64_t *ia0 = nullptr, *ia1 = nullptr;
+    QBH_HIP(hipMalloc(&cnt, (size_t)A->nrows * sizeof(int32_t)));
+    QBH_HIP(hipMalloc(&ia0, (size_t)(A->nrows + 1) * sizeof(int64_t)));
+    QBH_HIP(hipMalloc(&ia1, (size_t)(A->nrows + 1) * sizeof(int64_t)));
+    QBH_TRY(qbh::launch_split_count(A->d_ia, A->d_ja, A->nrows, lo, hi, cnt, s));
+    QBH_TRY(qbh::exclusive_scan(cnt, A->nrows, ia0, s));
+    (void)hipFree(cnt);
+    int64_t nnz0 = 0;
+    QBH_HIP(hipMemcpy(&nnz0, ia0 + A->nrows, sizeof(int64_t), hipMemcpyDeviceToHost));
+    const int64_t nnz1 = A->nnz - nnz0;
+    if (nnz1 == 0) {                       // nothing remote (block-diagonal shard): keep one part
+        (void)hipFree(ia0);
+        (void)hipFree(ia1);
+        return QBH_OK;
+    }
+    const bool coded = A->d_code != nullptr;
+    int32_t *ja0 = nullptr, *ja1 = nullptr;
+    d2 *v0 = nullptr, *v1 = nullptr;
+    uint8_t *c0 = nullptr, *c1 = nullptr;
+    QBH_HIP(hipMalloc(&ja0, std::max<size_t>((size_t)nnz0, 1) * sizeof(int32_t)));
+    QBH_HIP(hipMalloc(&ja1, (size_t)nnz1 * sizeof(int32_t)));
+    if (coded) {
+        QBH_HIP(hipMalloc(&c0, (size_t)nnz0 + 16));
+        QBH_HIP(hipMalloc(&c1, (size_t)nnz1 + 16));
+    } else {
+        QBH_HIP(hipMalloc(&v0, std::max<size_t>((size_t)nnz0, 1) * sizeof(d2)));
+        QBH_HIP(hipMalloc(&v1, (size_t)nnz1 * sizeof(d2)));
+    }
+    QBH_TRY(qbh::launch_split_fill(A->d_ia, A->d_ja, A->d_val, A->d_code, A->nrows, lo, hi, ia0, ja0, v0, c0, ia1, ja1, v1, c1, s));
+    QBH_HIP(hipStreamSynchronize(s));
+    if (A->own_arrays) {
+        (void)hipFree(A->d_ia);
+        (void)hipFree(A->d_ja);
+        if (A->d_val) (void)hipFree(A->d_val);
+    }
+    if (A->d_code) (void)hipFree(A->d_code);         // the code array is always library-owned
+    A->own_arrays = true;
+    A->d_ia = ia0;
+    A->d_ja = ja0;
+    A->d_val = v0;
+    A->d_code = c0;
+    A->nnz = nnz0;
+    A->rem.d_ia = ia1;
+    A->rem.d_ja = ja1;
+    A->rem.d_val = v1;
+    A->rem.d_code = c1;
+    A->rem.nnz = nnz1;
+    A->has_rem = true;
+    return QBH_OK;
+}
+
 // geometry + workspace once the CSR arrays are in HBM
 int finalize(qbh_csr *A)
 {
@@ -128,52 +241,27 @@ int finalize(qbh_csr *A)
     QBH_HIP(hipHostMalloc(&A->h_scal, 16 * sizeof(double)));
     QBH_HIP(hipEventCreate(&A->ev0));
     QBH_HIP(hipEventCreate(&A->ev1));
-
-    // longest row -> nnz window of a row block
-    QBH_TRY(qbh::launch_max_rowlen(A->d_ia, A->nrows, (int64_t *)A->d_scal, s));
-    int64_t maxlen = 0;
-    QBH_HIP(hipMemcpyAsync(&maxlen, A->d_scal, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    QBH_HIP(hipStreamSynchronize(s));
+    QBH_HIP(hipEventCreate(&A->ev2));
+    QBH_HIP(hipEventCreate(&A->ev3));
+    A->nnz_total = A->nnz;
+    A->kernel = (o.spmv_kernel == QBH_KERNEL_VECTOR) ? QBH_KERNEL_VECTOR
+              : (o.spmv_kernel == QBH_KERNEL_STREAM) ? QBH_KERNEL_STREAM : QBH_KERNEL_ROWS;
 
     // value dictionary first: it decides how much LDS a row block needs
     QBH_TRY(try_value_dict(A));
     const bool coded = A->d_code != nullptr;
+    QBH_TRY(split_shard(A));
 
-    const double avg = A->nrows > 0 ? (double)A->nnz / (double)A->nrows : 0.0;
-    A->kernel = (o.spmv_kernel == QBH_KERNEL_VECTOR) ? QBH_KERNEL_VECTOR
-              : (o.spmv_kernel == QBH_KERNEL_STREAM) ? QBH_KERNEL_STREAM : QBH_KERNEL_ROWS;
-    if (A->kernel == QBH_KERNEL_ROWS) {
-        // measured on C3 (SURVEY 8d): coded 8192/P=1/8 gathers in flight is HBM-bound on its real
-        // traffic; the plain kernel stages 16-byte values and is limited to 2048 by LDS occupancy.
-        int npb = coded ? 8192 : 2048;
-        const double cap_rows = 0.75 * qbh::kRowCap * (avg > 1.0 ? avg : 1.0);   // keep rows/block under kRowCap
-        while (npb > 1024 && (double)npb > cap_rows) npb >>= 1;
-        A->npb = o.nnz_per_block > 0 ? o.nnz_per_block : npb;
-        A->tpr = avg <= 64 ? 1 : avg <= 128 ? 2 : avg <= 256 ? 4 : 8;
-        if (!coded && avg > 12) A->tpr = avg <= 96 ? 4 : 8;
-        A->unroll = A->tpr == 1 ? 8 : 4;
-    } else {
-        A->npb = o.nnz_per_block > 0 ? o.nnz_per_block : 2048;
-        if (A->kernel == QBH_KERNEL_VECTOR) A->tpr = avg <= 6 ? 4 : avg <= 12 ? 8 : avg <= 40 ? 16 : avg <= 96 ? 32 : 64;
-        else                                A->tpr = avg <= 3 ? 1 : avg <= 8 ? 2 : avg <= 48 ? 4 : avg <= 128 ? 8 : 16;
+    QBH_TRY(setup_geometry(A, A->d_ia, A->nnz, coded, &A->npb, &A->tpr, &A->unroll, &A->window, &A->n_blocks, &A->d_rb,
+                           &A->d_bp, &A->grid));
+    int grid_max = A->grid;
+    if (A->has_rem) {
+        CsrPart &R = A->rem;
+        QBH_TRY(setup_geometry(A, R.d_ia, R.nnz, coded, &R.npb, &R.tpr, &R.unroll, &R.window, &R.n_blocks, &R.d_rb, &R.d_bp,
+                               &R.grid));
+        grid_max = std::max(grid_max, R.grid);
     }
-    if (A->npb != 1024 && A->npb != 2048 && A->npb != 4096 && !(A->npb == 8192 && A->kernel == QBH_KERNEL_ROWS && coded)) {
-        qbh::set_error("nnz_per_block must be 1024, 2048 or 4096 (8192: row kernel with value dictionary only)");
-        return QBH_EINVAL;
-    }
-    if (const char *e = getenv("QBH_TPR")) A->tpr = atoi(e);            // tuning experiments
-    if (const char *e = getenv("QBH_UNROLL")) A->unroll = atoi(e);
-    // a block holds the rows that START inside its window, so it can exceed the window by
-    // one row; keep window + maxlen - 1 <= npb when rows are short, otherwise let the
-    // oversized-block path take the few long rows.
-    if (maxlen <= A->npb / 2) A->window = A->npb - (maxlen > 0 ? maxlen - 1 : 0);
-    else A->window = A->npb / 2;
-    A->n_blocks = std::max<int64_t>(1, (A->nnz + A->window - 1) / A->window);
-    QBH_HIP(hipMalloc(&A->d_rb, (size_t)(A->n_blocks + 1) * sizeof(int32_t)));
-    QBH_HIP(hipMalloc(&A->d_bp, (size_t)(A->n_blocks + 1) * sizeof(int64_t)));
-    QBH_TRY(qbh::launch_build_rowblocks(A->d_ia, A->nrows, A->window, A->d_rb, A->d_bp, A->n_blocks, s));
-    A->grid = qbh::spmv_grid(A->kernel, A->n_blocks, A->nrows, A->tpr);
-    const size_t nparts = (size_t)std::max(A->grid, qbh::kMaxRedBlocks);
+    const size_t nparts = (size_t)std::max(grid_max, qbh::kMaxRedBlocks);
     QBH_HIP(hipMalloc(&A->d_partials, nparts * 4 * sizeof(double)));
     QBH_HIP(hipStreamSynchronize(s));
     A->stats = qbh_stats{};
@@ -251,6 +339,14 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
     if (A->d_dict) (void)hipFree(A->d_dict);
     if (A->d_rb) (void)hipFree(A->d_rb);
     if (A->d_bp) (void)hipFree(A->d_bp);
+    if (A->rem.d_ia) (void)hipFree(A->rem.d_ia);
+    if (A->rem.d_ja) (void)hipFree(A->rem.d_ja);
+    if (A->rem.d_val) (void)hipFree(A->rem.d_val);
+    if (A->rem.d_code) (void)hipFree(A->rem.d_code);
+    if (A->rem.d_rb) (void)hipFree(A->rem.d_rb);
+    if (A->rem.d_bp) (void)hipFree(A->rem.d_bp);
+    if (A->ev2) (void)hipEventDestroy(A->ev2);
+    if (A->ev3) (void)hipEventDestroy(A->ev3);
     if (A->d_partials) (void)hipFree(A->d_partials);
     if (A->d_scal) (void)hipFree(A->d_scal);
     if (A->h_scal) (void)hipHostFree(A->h_scal);
@@ -423,11 +519,12 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->nrows = A->nrows;
     info->ncols = A->ncols;
     info->row_offset = A->row_offset;
-    info->nnz = A->nnz;
-    info->n_blocks = A->n_blocks;
-    info->bytes_matrix = (A->nrows + 1) * 8 + A->nnz * 4 + (A->d_code ? A->nnz + 256 * 16 : A->nnz * 16) +
-                         (A->n_blocks + 1) * 12;
-    info->bytes_algorithmic = A->nnz * 20 + (A->nrows + 1) * 8 + A->nrows * 32;
+    const int64_t nnz = A->nnz_total, nb = A->n_blocks + (A->has_rem ? A->rem.n_blocks : 0);
+    info->nnz = nnz;
+    info->n_blocks = nb;
+    info->bytes_matrix = (A->nrows + 1) * 8 * (A->has_rem ? 2 : 1) + nnz * 4 + (A->d_code ? nnz + 256 * 16 : nnz * 16) +
+                         (nb + 2) * 12;
+    info->bytes_algorithmic = nnz * 20 + (A->nrows + 1) * 8 + A->nrows * 32;
     info->kernel = A->kernel;
     info->value_dict = A->d_code ? A->n_dict : 0;
     info->device = A->device;
@@ -501,26 +598,45 @@ int finish_reduction(qbh_csr *A, int nparts, int ncomp, double *host_out)
 
 void harvest_events(qbh_csr *A)
 {
-    if (!A->ev_pending) return;
-    float ms = 0.f;
-    if (hipEventSynchronize(A->ev1) == hipSuccess && hipEventElapsedTime(&ms, A->ev0, A->ev1) == hipSuccess) {
-        A->stats.ms_spmv += ms;
-        if (ms < A->stats.ms_spmv_min) A->stats.ms_spmv_min = ms;
+    float ms = 0.f, total = 0.f;
+    bool any = false;
+    if (A->ev_pending) {
+        if (hipEventSynchronize(A->ev1) == hipSuccess && hipEventElapsedTime(&ms, A->ev0, A->ev1) == hipSuccess) {
+            total += ms;
+            any = true;
+        }
+        A->ev_pending = false;
     }
-    A->ev_pending = false;
+    if (A->ev_pending2) {
+        if (hipEventSynchronize(A->ev3) == hipSuccess && hipEventElapsedTime(&ms, A->ev2, A->ev3) == hipSuccess) {
+            total += ms;
+            any = true;
+        }
+        A->ev_pending2 = false;
+    }
+    if (any) {
+        A->stats.ms_spmv += total;
+        if (total < A->stats.ms_spmv_min) A->stats.ms_spmv_min = total;
+    }
 }
 
 // y <- alpha*H x + beta*y + gamma*x_local ; red (host, 3 doubles) optional.
 // Without a communicator x is the full-length vector (ncols) and the shard-local part is
 // x + row_offset; with one, x is shard-local and is gathered through the hooks first.
+// A split shard runs two launches: the locally-owned columns (which only need this rank's block of x
+// and therefore overlap with the all-gather), then the remote columns, accumulating into y; the fused
+// reductions are produced by the last launch, on the final y.
 int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double gamma, double *red)
 {
     const d2 *xg, *xl;
+    bool async_gather = false;
     if (A->has_comm) {
         QBH_HIP(hipMemcpyAsync(A->comm.d_xsend, x, (size_t)A->nrows * sizeof(d2), hipMemcpyDeviceToDevice,
                                A->stream));
-        if (A->comm.allgather_x(A->comm.ctx) != 0) {
-            qbh::set_error("allgather_x hook failed");
+        async_gather = A->comm.allgather_begin && A->comm.allgather_wait;
+        const int hrc = async_gather ? A->comm.allgather_begin(A->comm.ctx) : A->comm.allgather_x(A->comm.ctx);
+        if (hrc != 0) {
+            qbh::set_error("allgather hook failed");
             return QBH_ECOMM;
         }
         A->stats.n_gather++;
@@ -540,17 +656,26 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     a.bp = A->d_bp;
     a.n_blocks = A->n_blocks;
     a.nrows = A->nrows;
-    a.xg = xg;
+    // the local part indexes x by GLOBAL column but only touches [row_offset, row_offset + nrows):
+    // serve it from the local block so it does not depend on the gather
+    a.xg = (A->has_rem && A->has_comm) ? xl - A->row_offset : xg;
     a.xl = xl;
     a.y = y;
     a.alpha = alpha;
     a.beta = beta;
     a.gamma = gamma;
-    a.partials = red ? A->d_partials : nullptr;
+    a.partials = (red && !A->has_rem) ? A->d_partials : nullptr;
     a.swizzle = A->opts.xcd_swizzle;
     a.unroll = A->unroll;
     a.colmask = (A->debug & 1) ? 1023 : -1;
     const bool prof = A->opts.profile != 0;
+    if (async_gather && !A->has_rem) {          // nothing to overlap with: the single part needs the gathered x
+        if (A->comm.allgather_wait(A->comm.ctx) != 0) {
+            qbh::set_error("allgather_wait hook failed");
+            return QBH_ECOMM;
+        }
+        async_gather = false;
+    }
     if (prof) {
         harvest_events(A);
         QBH_HIP(hipEventRecord(A->ev0, A->stream));
@@ -560,9 +685,36 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         QBH_HIP(hipEventRecord(A->ev1, A->stream));
         A->ev_pending = true;
     }
+    int grid_last = A->grid;
+    if (A->has_rem) {
+        if (async_gather && A->comm.allgather_wait(A->comm.ctx) != 0) {
+            qbh::set_error("allgather_wait hook failed");
+            return QBH_ECOMM;
+        }
+        const CsrPart &R = A->rem;
+        a.ia = R.d_ia;
+        a.ja = R.d_ja;
+        a.val = R.d_val;
+        a.code = R.d_code;
+        a.rb = R.d_rb;
+        a.bp = R.d_bp;
+        a.n_blocks = R.n_blocks;
+        a.xg = xg;
+        a.beta = 1.0;                       // accumulate onto the local part's result
+        a.gamma = 0.0;
+        a.partials = red ? A->d_partials : nullptr;
+        a.unroll = R.unroll;
+        if (prof) QBH_HIP(hipEventRecord(A->ev2, A->stream));
+        QBH_TRY(qbh::launch_spmv(a, A->kernel, R.npb, R.tpr, R.grid, A->stream));
+        if (prof) {
+            QBH_HIP(hipEventRecord(A->ev3, A->stream));
+            A->ev_pending2 = true;
+        }
+        grid_last = R.grid;
+    }
     A->stats.n_spmv++;
     if (red) {
-        QBH_TRY(finish_reduction(A, A->grid, 3, red));
+        QBH_TRY(finish_reduction(A, grid_last, 3, red));
         if (prof) harvest_events(A);
     }
     return QBH_OK;
@@ -1200,30 +1352,63 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
 }
 
 // ------------------------------------------------------------- download ---------
+namespace {
+// rows [r0, r1) of one part -> host (ia rebased to 0)
+int download_part(const qbh_csr *A, const int64_t *d_ia, const int32_t *d_ja, const d2 *d_val, const uint8_t *d_code, int64_t r0,
+                  int64_t r1, std::vector<int64_t> &ia, std::vector<int32_t> &ja, std::vector<d2> &val, bool want_val)
+{
+    ia.resize((size_t)(r1 - r0 + 1));
+    QBH_HIP(hipMemcpy(ia.data(), d_ia + r0, ia.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    const int64_t p0 = ia.front(), p1 = ia.back();
+    for (auto &v : ia) v -= p0;
+    ja.resize((size_t)(p1 - p0));
+    if (p1 > p0) QBH_HIP(hipMemcpy(ja.data(), d_ja + p0, ja.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (!want_val) return QBH_OK;
+    val.resize((size_t)(p1 - p0));
+    if (p1 == p0) return QBH_OK;
+    if (d_code) {                              // decode the dictionary-coded stream
+        std::vector<uint8_t> code(val.size());
+        d2 dict[256];
+        QBH_HIP(hipMemcpy(code.data(), d_code + p0, code.size(), hipMemcpyDeviceToHost));
+        QBH_HIP(hipMemcpy(dict, A->d_dict, sizeof(dict), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < code.size(); ++i) val[i] = dict[code[i]];
+    } else {
+        QBH_HIP(hipMemcpy(val.data(), d_val + p0, val.size() * sizeof(d2), hipMemcpyDeviceToHost));
+    }
+    return QBH_OK;
+}
+}  // namespace
+
 extern "C" int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1, int64_t *ia, int32_t *ja, qbh_z *val)
 {
     if (!A || r0 < 0 || r1 < r0 || r1 > A->nrows) return QBH_EINVAL;
     Bind bind(A);
     QBH_HIP(hipStreamSynchronize(A->stream));
-    std::vector<int64_t> hia((size_t)(r1 - r0 + 1));
-    QBH_HIP(hipMemcpy(hia.data(), A->d_ia + r0, hia.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
-    const int64_t p0 = hia.front(), p1 = hia.back();
-    if (ia)
-        for (size_t i = 0; i < hia.size(); ++i) ia[i] = hia[i] - p0;
-    if (ja && p1 > p0) QBH_HIP(hipMemcpy(ja, A->d_ja + p0, (size_t)(p1 - p0) * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (val && p1 > p0) {
-        if (A->d_code) {            // decode the dictionary-coded stream
-            std::vector<uint8_t> code((size_t)(p1 - p0));
-            d2 dict[256];
-            QBH_HIP(hipMemcpy(code.data(), A->d_code + p0, code.size(), hipMemcpyDeviceToHost));
-            QBH_HIP(hipMemcpy(dict, A->d_dict, sizeof(dict), hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < code.size(); ++i) {
-                val[i].re = dict[code[i]].x;
-                val[i].im = dict[code[i]].y;
+    std::vector<int64_t> ia0, ia1;
+    std::vector<int32_t> ja0, ja1;
+    std::vector<d2> v0, v1;
+    const bool want_val = val != nullptr;
+    QBH_TRY(download_part(A, A->d_ia, A->d_ja, A->d_val, A->d_code, r0, r1, ia0, ja0, v0, want_val));
+    if (A->has_rem)
+        QBH_TRY(download_part(A, A->rem.d_ia, A->rem.d_ja, A->rem.d_val, A->rem.d_code, r0, r1, ia1, ja1, v1, want_val));
+    // merge the two column-sorted parts of every row back into one ascending row
+    int64_t q = 0;
+    for (int64_t r = 0; r < r1 - r0; ++r) {
+        if (ia) ia[r] = q;
+        int64_t a = ia0[r], ae = ia0[r + 1], b = A->has_rem ? ia1[r] : 0, be = A->has_rem ? ia1[r + 1] : 0;
+        while (a < ae || b < be) {
+            const bool take0 = b >= be || (a < ae && ja0[a] <= ja1[b]);
+            if (ja) ja[q] = take0 ? ja0[a] : ja1[b];
+            if (val) {
+                const d2 v = take0 ? v0[a] : v1[b];
+                val[q].re = v.x;
+                val[q].im = v.y;
             }
-        } else {
-            QBH_HIP(hipMemcpy(val, A->d_val + p0, (size_t)(p1 - p0) * sizeof(qbh_z), hipMemcpyDeviceToHost));
+            if (take0) ++a;
+            else ++b;
+            ++q;
         }
     }
+    if (ia) ia[r1 - r0] = q;
     return QBH_OK;
 }

@@ -272,81 +272,6 @@ __global__ __launch_bounds__(256) void k_heis_fill(const HeisDev *hp, int64_t ro
     }
 }
 
-// exclusive scan int32 counts -> int64 offsets (three small kernels; one-time setup work)
-constexpr int kScanChunk = 2048;
-
-__global__ __launch_bounds__(256) void k_scan_chunksum(const int32_t *cnt, int64_t n, int64_t *chunk_sum)
-{
-    __shared__ double red_dummy;   // keep LDS layout trivial
-    (void)red_dummy;
-    __shared__ long long sm[4];
-    const int64_t base = (int64_t)blockIdx.x * kScanChunk;
-    long long s = 0;
-    for (int i = threadIdx.x; i < kScanChunk; i += 256)
-        if (base + i < n) s += cnt[base + i];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) chunk_sum[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
-}
-
-__global__ void k_scan_chunks_serial(int64_t *chunk_sum, int64_t nchunks)
-{
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        int64_t run = 0;
-        for (int64_t i = 0; i < nchunks; ++i) {
-            const int64_t t = chunk_sum[i];
-            chunk_sum[i] = run;
-            run += t;
-        }
-        chunk_sum[nchunks] = run;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_scan_apply(const int32_t *cnt, int64_t n, const int64_t *chunk_off,
-                                                    int64_t *ia)
-{
-    // one workgroup per chunk; thread t scans 8 consecutive elements, wave/LDS scan of the sums
-    __shared__ long long wsum[4];
-    const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 8;
-    long long loc[8], tot = 0;
-    for (int i = 0; i < 8; ++i) {
-        loc[i] = tot;
-        if (base + i < n) tot += cnt[base + i];
-    }
-    long long incl = tot;                                // inclusive scan across the wave
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int off = 1; off < 64; off <<= 1) {
-        const long long t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    long long woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wsum[w];
-    const long long excl = chunk_off[blockIdx.x] + woff + incl - tot;
-    for (int i = 0; i < 8; ++i)
-        if (base + i < n) ia[base + i] = excl + loc[i];
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) ia[n] = chunk_off[gridDim.x];
-}
-
-int exclusive_scan(const int32_t *d_cnt, int64_t n, int64_t *d_ia, hipStream_t s)
-{
-    const int64_t nchunks = (n + kScanChunk - 1) / kScanChunk;
-    int64_t *d_chunk = nullptr;
-    QBH_HIP(hipMalloc(&d_chunk, (size_t)(nchunks + 1) * sizeof(int64_t)));
-    hipLaunchKernelGGL(k_scan_chunksum, dim3((unsigned)nchunks), dim3(256), 0, s, d_cnt, n, d_chunk);
-    hipLaunchKernelGGL(k_scan_chunks_serial, dim3(1), dim3(64), 0, s, d_chunk, nchunks);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nchunks), dim3(256), 0, s, d_cnt, n, d_chunk, d_ia);
-    hipError_t e = hipStreamSynchronize(s);
-    (void)hipFree(d_chunk);
-    if (e != hipSuccess) {
-        set_error("scan failed: %s", hipGetErrorString(e));
-        return QBH_EHIP;
-    }
-    return QBH_OK;
-}
-
 uint64_t binom_u64(int n, int k)
 {
     if (k < 0 || k > n) return 0;

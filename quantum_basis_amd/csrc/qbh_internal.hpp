@@ -76,6 +76,11 @@ int launch_randomize(d2 *x, int64_t n, int64_t global_offset, uint32_t seed, dou
 int launch_fill_const(d2 *x, int64_t n, double re, hipStream_t s);
 int launch_max_rowlen(const int64_t *d_ia, int64_t nrows, int64_t *d_out, hipStream_t s);
 int blas_grid(int64_t n);
+int exclusive_scan(const int32_t *d_cnt, int64_t n, int64_t *d_ia, hipStream_t s);
+int launch_split_count(const int64_t *ia, const int32_t *ja, int64_t nrows, int32_t lo, int32_t hi, int32_t *cnt0, hipStream_t s);
+int launch_split_fill(const int64_t *ia, const int32_t *ja, const d2 *val, const uint8_t *code, int64_t nrows, int32_t lo,
+                      int32_t hi, const int64_t *ia0, int32_t *ja0, d2 *val0, uint8_t *code0, int64_t *ia1, int32_t *ja1,
+                      d2 *val1, uint8_t *code1, hipStream_t s);
 struct Coef8 { double v[16]; };   // up to 8 complex coefficients passed by value
 int launch_multi_dot8(const d2 *V, int64_t ldv, const d2 *w, int64_t n, int nv, double *partials, hipStream_t s);
 int launch_multi_axpy8(const d2 *V, int64_t ldv, const Coef8 &c, int nv, d2 *w, int64_t n, hipStream_t s);
@@ -88,6 +93,19 @@ int tridiag_eigen_full(int64_t m, const double *a, const double *b1, double *w, 
 int tridiag_eigen_lastrow(int64_t m, const double *a, const double *b1, double *w, double *zlast);
 
 }  // namespace qbh
+
+// second part of a split row shard: the entries whose column is NOT owned by this shard
+struct CsrPart {
+    int64_t  nnz = 0;
+    int64_t *d_ia = nullptr;
+    int32_t *d_ja = nullptr;
+    qbh::d2 *d_val = nullptr;
+    uint8_t *d_code = nullptr;
+    int      npb = 2048, tpr = 1, unroll = 4, grid = 0;
+    int64_t  window = 0, n_blocks = 0;
+    int32_t *d_rb = nullptr;
+    int64_t *d_bp = nullptr;
+};
 
 struct qbh_csr {
     int          device = 0;
@@ -121,6 +139,13 @@ struct qbh_csr {
     double  *h_scal = nullptr;       // pinned mirror
     qbh::d2 *d_stage_x = nullptr, *d_stage_y = nullptr;   // host-vector seam staging
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // split shard: the arrays above hold the locally-owned columns, `rem` the remote ones
+    bool     has_rem = false;
+    int64_t  nnz_total = 0;
+    CsrPart  rem;
+    hipEvent_t ev2 = nullptr, ev3 = nullptr;
+    bool     ev_pending2 = false;
 
     // communicator
     bool     has_comm = false;

@@ -1162,4 +1162,143 @@ int launch_basis_rotate(d2 *V, int64_t ldv, int64_t n, int m, int keep, const do
     return QBH_OK;
 }
 
+
+// ------------------------------------------------------- shard column split -----
+// A row shard is split once, at creation, into the entries whose column lies inside the shard's own
+// row range [lo, hi) and the rest.  The first part needs only the locally owned block of x, so it can
+// run while the all-gather of x is still in flight; the second part runs after it and accumulates.
+__global__ __launch_bounds__(kBlock) void k_split_count(const int64_t *ia, const int32_t *ja, int64_t nrows, int32_t lo,
+                                                        int32_t hi, int32_t *cnt0)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < nrows; r += stride) {
+        int c = 0;
+        for (int64_t p = ia[r]; p < ia[r + 1]; ++p) {
+            const int32_t col = ja[p];
+            c += (col >= lo && col < hi) ? 1 : 0;
+        }
+        cnt0[r] = c;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_split_fill(const int64_t *ia, const int32_t *ja, const d2 *val, const uint8_t *code,
+                                                       int64_t nrows, int32_t lo, int32_t hi, const int64_t *ia0, int32_t *ja0,
+                                                       d2 *val0, uint8_t *code0, int64_t *ia1, int32_t *ja1, d2 *val1,
+                                                       uint8_t *code1)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r <= nrows; r += stride) {
+        ia1[r] = ia[r] - ia0[r];
+        if (r == nrows) break;
+        int64_t q0 = ia0[r], q1 = ia[r] - ia0[r];
+        for (int64_t p = ia[r]; p < ia[r + 1]; ++p) {
+            const int32_t col = ja[p];
+            if (col >= lo && col < hi) {
+                ja0[q0] = col;
+                if (code) code0[q0] = code[p];
+                else      val0[q0] = val[p];
+                ++q0;
+            } else {
+                ja1[q1] = col;
+                if (code) code1[q1] = code[p];
+                else      val1[q1] = val[p];
+                ++q1;
+            }
+        }
+    }
+}
+
+int launch_split_count(const int64_t *ia, const int32_t *ja, int64_t nrows, int32_t lo, int32_t hi, int32_t *cnt0, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_split_count, dim3(blas_grid(nrows)), dim3(kBlock), 0, s, ia, ja, nrows, lo, hi, cnt0);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+int launch_split_fill(const int64_t *ia, const int32_t *ja, const d2 *val, const uint8_t *code, int64_t nrows, int32_t lo,
+                      int32_t hi, const int64_t *ia0, int32_t *ja0, d2 *val0, uint8_t *code0, int64_t *ia1, int32_t *ja1,
+                      d2 *val1, uint8_t *code1, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_split_fill, dim3(blas_grid(nrows + 1)), dim3(kBlock), 0, s, ia, ja, val, code, nrows, lo, hi, ia0, ja0,
+                       val0, code0, ia1, ja1, val1, code1);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// exclusive scan int32 counts -> int64 offsets (three small kernels; one-time setup work)
+constexpr int kScanChunk = 2048;
+
+__global__ __launch_bounds__(256) void k_scan_chunksum(const int32_t *cnt, int64_t n, int64_t *chunk_sum)
+{
+    __shared__ double red_dummy;   // keep LDS layout trivial
+    (void)red_dummy;
+    __shared__ long long sm[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanChunk;
+    long long s = 0;
+    for (int i = threadIdx.x; i < kScanChunk; i += 256)
+        if (base + i < n) s += cnt[base + i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_sum[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ void k_scan_chunks_serial(int64_t *chunk_sum, int64_t nchunks)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int64_t run = 0;
+        for (int64_t i = 0; i < nchunks; ++i) {
+            const int64_t t = chunk_sum[i];
+            chunk_sum[i] = run;
+            run += t;
+        }
+        chunk_sum[nchunks] = run;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const int32_t *cnt, int64_t n, const int64_t *chunk_off,
+                                                    int64_t *ia)
+{
+    // one workgroup per chunk; thread t scans 8 consecutive elements, wave/LDS scan of the sums
+    __shared__ long long wsum[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 8;
+    long long loc[8], tot = 0;
+    for (int i = 0; i < 8; ++i) {
+        loc[i] = tot;
+        if (base + i < n) tot += cnt[base + i];
+    }
+    long long incl = tot;                                // inclusive scan across the wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    long long woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const long long excl = chunk_off[blockIdx.x] + woff + incl - tot;
+    for (int i = 0; i < 8; ++i)
+        if (base + i < n) ia[base + i] = excl + loc[i];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) ia[n] = chunk_off[gridDim.x];
+}
+
+int exclusive_scan(const int32_t *d_cnt, int64_t n, int64_t *d_ia, hipStream_t s)
+{
+    const int64_t nchunks = (n + kScanChunk - 1) / kScanChunk;
+    int64_t *d_chunk = nullptr;
+    QBH_HIP(hipMalloc(&d_chunk, (size_t)(nchunks + 1) * sizeof(int64_t)));
+    hipLaunchKernelGGL(k_scan_chunksum, dim3((unsigned)nchunks), dim3(256), 0, s, d_cnt, n, d_chunk);
+    hipLaunchKernelGGL(k_scan_chunks_serial, dim3(1), dim3(64), 0, s, d_chunk, nchunks);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nchunks), dim3(256), 0, s, d_cnt, n, d_chunk, d_ia);
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(d_chunk);
+    if (e != hipSuccess) {
+        set_error("scan failed: %s", hipGetErrorString(e));
+        return QBH_EHIP;
+    }
+    return QBH_OK;
+}
+
+
 }  // namespace qbh

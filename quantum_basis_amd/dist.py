@@ -46,6 +46,11 @@ class ShardComm:
         self.errors = []
         self._ag = _lib.ALLGATHER_FN(self._allgather)
         self._ar = _lib.ALLREDUCE_FN(self._allreduce)
+        self._ag_begin = _lib.ALLGATHER_FN(self._allgather_begin)
+        self._ag_wait = _lib.ALLGATHER_FN(self._allgather_wait)
+        self._work = None
+        self.n_async = 0             # exchanges started through the begin/wait pair
+        self.overlap = True          # hand the begin/wait pair to the library (local columns overlap the gather)
         self._struct = None
 
     # -- hooks: called from inside libqbhip.so on the calling Python thread ------------------
@@ -68,6 +73,32 @@ class ShardComm:
                     self.xfull.copy_(self.torch.cat(parts))
             return 0
         except Exception:            # never let an exception unwind through the C frames
+            self.errors.append(traceback.format_exc())
+            return 1
+
+    def _allgather_begin(self, _ctx):
+        """Enqueue the exchange and return: RCCL runs it on its own stream, ordered after what the
+        operator's stream has enqueued so far (the copy into xsend)."""
+        try:
+            if not self.direct:                      # host-staged test rigs: no real overlap
+                return self._allgather(_ctx)
+            with self._ctx():
+                self._work = self.dist.all_gather_into_tensor(self.xfull, self.xsend, group=self.group, async_op=True)
+            self.n_async += 1
+            return 0
+        except Exception:
+            self.errors.append(traceback.format_exc())
+            return 1
+
+    def _allgather_wait(self, _ctx):
+        """Order the operator's stream after the exchange started by _allgather_begin."""
+        try:
+            if self._work is not None:
+                with self._ctx():
+                    self._work.wait()
+                self._work = None
+            return 0
+        except Exception:
             self.errors.append(traceback.format_exc())
             return 1
 
@@ -102,6 +133,9 @@ class ShardComm:
         c.ctx = None
         c.allgather_x = self._ag
         c.allreduce_sum = self._ar
+        if self.overlap:
+            c.allgather_begin = self._ag_begin
+            c.allgather_wait = self._ag_wait
         self._struct = c
         check(lib().qbh_csr_set_comm(mat.handle, C.byref(c)), "qbh_csr_set_comm")
         mat._comm = self          # keep the callbacks and buffers alive as long as the operator

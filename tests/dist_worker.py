@@ -100,6 +100,8 @@ def gpu_sharded_solver(rank, world, port, backend, out_dir):
         comm = qdist.ShardComm(dim, rank=rank, world=world, device=torch.device("cuda", 0), stream=stream).attach(A)
         res = q.locate_E0_lanczos(A, nev=2, ncv=1, maxit=400)
         assert not comm.errors, comm.errors
+        if backend == "nccl":
+            assert comm.n_async > 100, comm.n_async      # every SpMV went through the asynchronous RCCL all-gather
         x = q.vec_randomize(A, seed=1)                 # shard of the global start vector
         np.save(os.path.join(out_dir, "x_%d.npy" % rank), x)
         np.save(os.path.join(out_dir, "vec_%d.npy" % rank), res.eigenvecs)
