@@ -535,7 +535,7 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
 extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
 {
     if (!A) return QBH_EINVAL;
-    if (!comm || comm->nranks <= 1) {
+    if (!comm || comm->nranks < 1) {          // NULL detaches; a 1-rank communicator is valid (hooks still run)
         A->has_comm = false;
         return QBH_OK;
     }
