@@ -15,7 +15,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));   // one complex128 (re, 
 
 constexpr int kBlock = 256;          // threads per workgroup (4 wavefronts)
 constexpr int kMaxRedBlocks = 2048;  // grid of the BLAS-1 kernels == number of partial sums
-constexpr int kRowCap = 512;         // row offsets staged in LDS per row block
+constexpr int kRowCap = 1024;        // row offsets staged in LDS per row block
 
 void set_error(const char *fmt, ...);
 
@@ -59,6 +59,7 @@ struct SpmvArgs {
 // launchers implemented in qbh_kernels.hip (all asynchronous on `s`)
 int launch_spmv(const SpmvArgs &a, int kernel, int npb, int tpr, int grid, hipStream_t s);
 int spmv_grid(int kernel, int64_t n_blocks, int64_t nrows, int tpr);
+int rows_kernel_occupancy(int npb, int tpr, int un, bool dict);
 int launch_build_rowblocks(const int64_t *d_ia, int64_t nrows, int64_t window, int32_t *d_rb,
                            int64_t *d_bp, int64_t n_blocks, hipStream_t s);
 int launch_block_stats(const int64_t *d_ia, const int32_t *d_rb, int64_t n_blocks, int64_t *d_out2,

@@ -527,6 +527,48 @@ static int launch_stream_tpr(const SpmvArgs &a, int tpr, int grid, hipStream_t s
 }
 
 template <int NPB, int PP, bool DICT>
+static int occ_rows_un(int un)
+{
+    int n = 0;
+    hipError_t e = (un == 8)
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spmv_rows<NPB, PP, 8, DICT>, kBlock, 0)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spmv_rows<NPB, PP, 4, DICT>, kBlock, 0);
+    return e == hipSuccess ? n : 0;
+}
+
+template <int NPB, bool DICT>
+static int occ_rows_p(int tpr, int un)
+{
+    switch (tpr) {
+    case 1: return occ_rows_un<NPB, 1, DICT>(un);
+    case 2: return occ_rows_un<NPB, 2, DICT>(un);
+    case 4: return occ_rows_un<NPB, 4, DICT>(un);
+    case 8: return occ_rows_un<NPB, 8, DICT>(un);
+    default: return 0;
+    }
+}
+
+template <bool DICT>
+static int occ_rows(int npb, int tpr, int un)
+{
+    switch (npb) {
+    case 1024: return occ_rows_p<1024, DICT>(tpr, un);
+    case 2048: return occ_rows_p<2048, DICT>(tpr, un);
+    case 4096: return occ_rows_p<4096, DICT>(tpr, un);
+    case 8192:
+        if constexpr (DICT) return occ_rows_p<8192, DICT>(tpr, un);
+        return 0;
+    default: return 0;
+    }
+}
+
+// workgroups of the row kernel that are resident per CU (0 if unknown)
+int rows_kernel_occupancy(int npb, int tpr, int un, bool dict)
+{
+    return dict ? occ_rows<true>(npb, tpr, un) : occ_rows<false>(npb, tpr, un);
+}
+
+template <int NPB, int PP, bool DICT>
 static int launch_rows_un(const SpmvArgs &a, int un, int grid, hipStream_t s)
 {
     if (un == 8) hipLaunchKernelGGL((k_spmv_rows<NPB, PP, 8, DICT>), dim3(grid), dim3(kBlock), 0, s, a);
