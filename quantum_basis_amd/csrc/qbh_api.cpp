@@ -1272,48 +1272,53 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
     int k = 0;                          // vectors kept from the previous restart
     int64_t restarts = 0, nconv = 0;
     double beta_last = 0.0;
-    double red[16], sq;
-    // orthogonalise w against V_0..V_{nv-1}, classical Gram-Schmidt, `passes` times
-    auto reorth = [&](d2 *w, int nv, int passes) -> int {
-        for (int p = 0; p < passes; ++p)
-            for (int i0 = 0; i0 < nv; i0 += 8) {
-                const int cnt = std::min(8, nv - i0);
-                QBH_TRY(qbh::launch_multi_dot8(vec(i0), n, w, n, cnt, A->d_partials, A->stream));
-                QBH_TRY(finish_reduction(A, qbh::blas_grid(n), 16, red));
-                qbh::Coef8 c{};
-                for (int i = 0; i < 2 * cnt; ++i) c.v[i] = red[i];
-                QBH_TRY(qbh::launch_multi_axpy8(vec(i0), n, c, cnt, w, n, A->stream));
-            }
+    double red[16];
+    // One classical Gram-Schmidt pass of w against V_0..V_{nv-1}: h = V^H w (8 inner products per sweep over
+    // w), w -= V h, and |w|^2 of the result from the last sweep.  hj receives Re h_{nv-1}.
+    auto cgs_pass = [&](d2 *w, int nv, double *hj, double *nrm2sq) -> int {
+        std::vector<double> h((size_t)2 * nv);
+        for (int i0 = 0; i0 < nv; i0 += 8) {
+            const int cnt = std::min(8, nv - i0);
+            QBH_TRY(qbh::launch_multi_dot8(vec(i0), n, w, n, cnt, A->d_partials, A->stream));
+            QBH_TRY(finish_reduction(A, qbh::blas_grid(n), 16, red));
+            for (int i = 0; i < 2 * cnt; ++i) h[(size_t)2 * i0 + i] = red[i];
+        }
+        for (int i0 = 0; i0 < nv; i0 += 8) {
+            const int cnt = std::min(8, nv - i0);
+            const bool last = i0 + 8 >= nv;
+            qbh::Coef8 c{};
+            for (int i = 0; i < 2 * cnt; ++i) c.v[i] = h[(size_t)2 * i0 + i];
+            QBH_TRY(qbh::launch_multi_axpy8(vec(i0), n, c, cnt, w, n, last ? A->d_partials : nullptr, A->stream));
+        }
+        QBH_TRY(finish_reduction(A, qbh::blas_grid(n), 1, nrm2sq));
+        *hj = h[(size_t)2 * (nv - 1)];
         return QBH_OK;
     };
 
     while (rc == QBH_OK) {
         for (int j = k; j < m && rc == QBH_OK; ++j) {
             d2 *w = vec(j + 1);
-            rc = spmv_run(A, vec(j), w, sign, 0.0, 0.0, red);            // w = (+-H) v_j ; <v_j, w>
+            // w = (+-H) v_j.  The three-term recurrence is not applied separately: h = V^H w contains alpha_j,
+            // beta_{j-1} (or the arrowhead couplings right after a restart) and the rounding-level
+            // components along the older vectors, and all of them are removed in one pass (ARPACK does the
+            // same in its Arnoldi step, followed by one DGKS correction when cancellation was severe).
+            rc = spmv_run(A, vec(j), w, sign, 0.0, 0.0, red);
             if (rc != QBH_OK) break;
-            const double alpha = red[0];
-            T[(size_t)j * m + j] = alpha;
-            if (j == k && k > 0) {                                        // arrowhead coupling after a restart
-                for (int i0 = 0; i0 < k && rc == QBH_OK; i0 += 8) {
-                    const int cnt = std::min(8, k - i0);
-                    qbh::Coef8 c{};
-                    for (int i = 0; i < cnt; ++i) c.v[2 * i] = T[(size_t)k * m + (i0 + i)];
-                    rc = qbh::launch_multi_axpy8(vec(i0), n, c, cnt, w, n, A->stream);
-                }
-            } else if (j > 0) {
-                qbh::Coef8 c{};
-                c.v[0] = T[(size_t)j * m + (j - 1)];
-                rc = qbh::launch_multi_axpy8(vec(j - 1), n, c, 1, w, n, A->stream);
+            const double wnorm2 = red[2];
+            double alpha = 0.0, b2 = 0.0;
+            rc = cgs_pass(w, j + 1, &alpha, &b2);
+            if (rc != QBH_OK) break;
+            // DGKS-style correction, only when the removed components outweigh the remainder by more than
+            // 7x (error amplification |w|/|w'|); a Hamiltonian with a large diagonal would otherwise trigger
+            // it on every step because alpha^2 dominates |w|^2
+            if (b2 < 0.02 * wnorm2) {
+                double corr = 0.0;
+                rc = cgs_pass(w, j + 1, &corr, &b2);
+                if (rc != QBH_OK) break;
+                alpha += corr;
             }
-            if (rc != QBH_OK) break;
-            rc = axpy_norm_run(A, d2{-alpha, 0.0}, vec(j), w, &sq);
-            if (rc != QBH_OK) break;
-            rc = reorth(w, j + 1, 2);
-            if (rc != QBH_OK) break;
-            double beta = 0.0;
-            rc = nrm2_run(A, w, &beta);
-            if (rc != QBH_OK) break;
+            const double beta = std::sqrt(b2);
+            T[(size_t)j * m + j] = alpha;
             beta_last = beta;
             if (j + 1 < m) T[(size_t)j * m + (j + 1)] = T[(size_t)(j + 1) * m + j] = beta;
             if (beta > 0.0) rc = qbh::launch_scal(1.0 / beta, w, n, A->stream);

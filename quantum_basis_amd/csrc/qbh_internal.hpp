@@ -84,7 +84,7 @@ int launch_split_fill(const int64_t *ia, const int32_t *ja, const d2 *val, const
                       d2 *val1, uint8_t *code1, hipStream_t s);
 struct Coef8 { double v[16]; };   // up to 8 complex coefficients passed by value
 int launch_multi_dot8(const d2 *V, int64_t ldv, const d2 *w, int64_t n, int nv, double *partials, hipStream_t s);
-int launch_multi_axpy8(const d2 *V, int64_t ldv, const Coef8 &c, int nv, d2 *w, int64_t n, hipStream_t s);
+int launch_multi_axpy8(const d2 *V, int64_t ldv, const Coef8 &c, int nv, d2 *w, int64_t n, double *partials, hipStream_t s);
 int launch_basis_rotate(d2 *V, int64_t ldv, int64_t n, int m, int keep, const double *d_S, hipStream_t s);
 int symmetric_eigen_jacobi(int m, double *a, double *w, double *z);
 int build_value_dict(const d2 *d_val, int64_t nnz, uint8_t *d_code, d2 *d_dict, int *n_out, hipStream_t s);

@@ -1151,9 +1151,12 @@ int launch_multi_dot8(const d2 *V, int64_t ldv, const d2 *w, int64_t n, int nv, 
     return QBH_OK;
 }
 
-// w -= sum_i c_i V_i  (c complex), one pass
-__global__ __launch_bounds__(kBlock) void k_multi_axpy(const d2 *V, int64_t ldv, Coef8 c, int nv, d2 *w, int64_t n)
+// w -= sum_i c_i V_i  (c complex), one pass; optionally the partial sums of |w|^2 of the result
+__global__ __launch_bounds__(kBlock) void k_multi_axpy(const d2 *V, int64_t ldv, Coef8 c, int nv, d2 *w, int64_t n,
+                                                       double *partials)
 {
+    __shared__ double red[4];
+    double nrm[1] = {0.0};
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
         d2 acc = w[e];
@@ -1165,12 +1168,17 @@ __global__ __launch_bounds__(kBlock) void k_multi_axpy(const d2 *V, int64_t ldv,
             }
         }
         w[e] = acc;
+        nrm[0] += acc.x * acc.x + acc.y * acc.y;
+    }
+    if (partials != nullptr) {
+        block_sum<1>(nrm, red);
+        if (threadIdx.x == 0) partials[blockIdx.x] = nrm[0];
     }
 }
 
-int launch_multi_axpy8(const d2 *V, int64_t ldv, const Coef8 &c, int nv, d2 *w, int64_t n, hipStream_t s)
+int launch_multi_axpy8(const d2 *V, int64_t ldv, const Coef8 &c, int nv, d2 *w, int64_t n, double *partials, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_multi_axpy, dim3(blas_grid(n)), dim3(kBlock), 0, s, V, ldv, c, nv, w, n);
+    hipLaunchKernelGGL(k_multi_axpy, dim3(blas_grid(n)), dim3(kBlock), 0, s, V, ldv, c, nv, w, n, partials);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }
