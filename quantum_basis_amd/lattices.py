@@ -42,7 +42,9 @@ def kagome(Lx, Ly):
     """examples/trans_absent/latt_kagome/kagome_Heisenberg_spin_half.cc:69-152 (PBC):
     per unit cell (m,n), sublattices 0,1,2: 0-2(m+1,n), 0-2, 1-0(m,n+1), 1-0, 2-1(m-1,n-1), 2-1."""
     def site(m, n, sub):
-        return (m % Lx) + Lx * ((n % Ly) + Ly * sub)
+        # x slowest: the two halves of the bit pattern are the two halves of the cluster, so only the bonds
+        # across the cut (and the periodic wrap) flip one spin in each half -- better x-gather locality
+        return sub + 3 * ((n % Ly) + Ly * (m % Lx))
     b = []
     for m in range(Lx):
         for n in range(Ly):
