@@ -17,6 +17,7 @@
 // INTEGRATION.md).
 #pragma once
 
+#include <cmath>
 #include <complex>
 #include <cstdint>
 #include <stdexcept>
@@ -156,6 +157,107 @@ inline void hess_eigen(const double hessenberg[], const qint &maxit, const qint 
     ritz.resize(m);
     s.resize(m * m);
     check(qbh_hess_eigen(hessenberg, maxit, m, order.c_str(), ritz.data(), s.data()), "hess_eigen");
+}
+
+// iram<T, csr_mat<T>> (src/lanczos.cc:497-603) with the Krylov basis resident in HBM (qbh_iram).  Same
+// argument checks and outputs; v0 is ignored exactly as in the reference (ARPACK info = 0, :470).
+inline void iram(const qint &dim, csr_mat &mat, cplx v0[], const qint &nev, const qint &ncv, const qint &maxit,
+                 const std::string &order, qint &nconv, double eigenvals[], cplx eigenvecs[])
+{
+    (void)v0;
+    if (dim != mat.dim) throw std::invalid_argument("iram: dim mismatch");
+    if (nev <= 0 || nev >= dim - 1) throw std::invalid_argument("0 < nev < N-1 should be satisfied.");
+    if (maxit < 20) throw std::invalid_argument("maxit should not be smaller than 20!");
+    if (dim <= 30) throw std::invalid_argument("iram: dim <= 30 uses the dense fall-back of the host code (to_dense)");
+    int64_t nc = 0;
+    check(qbh_iram(mat.handle, nev, ncv, maxit, order.c_str(), 0.0, 1u, &nc, eigenvals,
+                   reinterpret_cast<qbh_z *>(eigenvecs), nullptr), "iram");
+    if (nc <= 0) throw std::runtime_error("nconv == 0...");           // src/lanczos.cc:566
+    nconv = nc;
+}
+
+// vec_randomize (src/miscellaneous.cc:371-386), produced on the device
+inline void vec_randomize(const csr_mat &mat, cplx *x, const uint32_t &seed)
+{
+    qbh_z *d = nullptr;
+    check(qbh_vec_alloc(&d, mat.dim), "vec_randomize");
+    int rc = qbh_vec_randomize(mat.handle, d, seed);
+    if (rc == QBH_OK) rc = qbh_vec_download(mat.handle, reinterpret_cast<qbh_z *>(x), d, mat.dim);
+    qbh_vec_free(d);
+    check(rc, "vec_randomize");
+}
+
+// The four stages of model<T>::locate_E0_lanczos (src/model.cc:1123-1316) for a CSR operator, as a free
+// function with the fields the model object exposes afterwards.
+struct E0_result {
+    std::vector<double> eigenvals;
+    std::vector<cplx> eigenvecs;
+    double E0 = 0.0, E1 = 0.0, gap = 0.0;
+    qint nconv = 0, steps_E0 = 0, steps_V0 = 0, steps_E1 = 0, steps_V1 = 0;
+};
+
+inline E0_result locate_E0_lanczos(const csr_mat &HamMat, const qint &nev = 1, const qint &ncv = 1, qint maxit = 1000)
+{
+    if (!(nev > 0 && nev <= 2 && ncv >= nev - 1 && ncv <= nev)) throw std::invalid_argument("locate_E0_lanczos: nev/ncv");
+    const qint dim = HamMat.dim;
+    const uint32_t seed = 1;
+    E0_result res;
+    const double lanczos_precision = QBH_LANCZOS_PRECISION;
+    std::vector<double> hessenberg(2 * maxit, 0.0), ritz, s;
+    std::vector<cplx> v(ncv > 0 ? dim * 4 : dim * 2);
+    vec_randomize(HamMat, v.data(), seed);                                                  // :1165
+    qint m = 0;
+    lanczos(0, maxit - 1, maxit, m, dim, HamMat, v.data(), hessenberg.data(), "sr_val0");   // :1180
+    hess_eigen(hessenberg.data(), maxit, m, "sr", ritz, s);
+    res.eigenvals = {ritz[0]};
+    res.E0 = ritz[0];
+    res.steps_E0 = m;
+    if (ncv == 0) return res;
+    vec_randomize(HamMat, v.data() + 2 * dim, seed);                                        // :1209
+    double accuracy = 0.0;
+    m = 0;
+    eigenvec_CG(dim, maxit, m, HamMat, cplx(res.E0), accuracy, v.data() + 2 * dim, v.data(), v.data() + dim,
+                v.data() + 3 * dim);
+    if (!(accuracy < lanczos_precision)) throw std::runtime_error("eigenvec_CG did not converge");   // assert :1221
+    res.steps_V0 = m;
+    res.nconv = 1;
+    if (nev == 2) {                                                                         // :1233-1265
+        vec_randomize(HamMat, v.data(), seed);
+        cplx alpha(0.0);
+        for (qint j = 0; j < dim; j++) alpha += std::conj(v[2 * dim + j]) * v[j];
+        double rnorm = 0.0;
+        for (qint j = 0; j < dim; j++) { v[j] -= alpha * v[2 * dim + j]; rnorm += std::norm(v[j]); }
+        rnorm = std::sqrt(rnorm);
+        for (qint j = 0; j < dim; j++) v[j] /= rnorm;
+        m = 0;
+        lanczos(0, maxit - 1, maxit, m, dim, HamMat, v.data(), hessenberg.data(), "sr_val1");
+        hess_eigen(hessenberg.data(), maxit, m, "sr", ritz, s);
+        res.eigenvals.push_back(ritz[0]);
+        res.E1 = ritz[0];
+        res.gap = res.E1 - res.E0;
+        res.steps_E1 = m;
+    }
+    if (ncv == 1) {                                                                         // :1267-1273
+        res.eigenvecs.assign(v.begin() + 2 * dim, v.begin() + 3 * dim);
+        return res;
+    }
+    v.resize(5 * dim);                                                                      // :1279
+    vec_randomize(HamMat, v.data() + 3 * dim, seed + 7);
+    m = 0;
+    eigenvec_CG(dim, maxit, m, HamMat, cplx(res.E1), accuracy, v.data() + 3 * dim, v.data(), v.data() + dim,
+                v.data() + 4 * dim);
+    res.steps_V1 = m;
+    res.nconv = 2;
+    res.eigenvecs.assign(v.begin() + 2 * dim, v.begin() + 4 * dim);
+    if (res.gap < lanczos_precision) {                                                      // :1301-1310
+        cplx alpha(0.0);
+        for (qint j = 0; j < dim; j++) alpha += std::conj(res.eigenvecs[j]) * res.eigenvecs[dim + j];
+        double rnorm = 0.0;
+        for (qint j = 0; j < dim; j++) { res.eigenvecs[dim + j] -= alpha * res.eigenvecs[j]; rnorm += std::norm(res.eigenvecs[dim + j]); }
+        rnorm = std::sqrt(rnorm);
+        for (qint j = 0; j < dim; j++) res.eigenvecs[dim + j] /= rnorm;
+    }
+    return res;
 }
 
 }  // namespace qbhip

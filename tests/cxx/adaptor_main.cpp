@@ -52,6 +52,18 @@ int main(int argc, char **argv)
         double d = 0;
         for (qint j = 0; j < dim; j++) d += std::abs(2.0 * y2[j] - y[j]);
         std::printf("OK %.17g %.17g %.17g %lld %.17g %lld %.3e %.3e\n", sr, si, sr2, (long long)m, E0, (long long)mcg, accu, d);
+        // the four-stage driver and the device-resident IRAM through the C++ mirror
+        qbhip::E0_result r = qbhip::locate_E0_lanczos(H, 2, 1);
+        std::vector<double> ev(3);
+        std::vector<cplx> evec(3 * dim);
+        qint nconv = 0;
+        qbhip::iram(dim, H, nullptr, 3, 10, 300, "sr", nconv, ev.data(), evec.data());
+        double ov = 0;                       // |<phi0(CG) | phi0(IRAM)>|
+        cplx acc(0.0);
+        for (qint j = 0; j < dim; j++) acc += std::conj(r.eigenvecs[j]) * evec[j];
+        ov = std::abs(acc);
+        std::printf("DRV %.17g %.17g %lld %lld %lld %.17g %.17g %.17g %lld %.6e\n", r.E0, r.E1, (long long)r.steps_E0,
+                    (long long)r.steps_V0, (long long)r.nconv, ev[0], ev[1], ev[2], (long long)nconv, ov);
     } catch (const std::exception &e) {
         std::printf("EXC %s\n", e.what());
         return 3;

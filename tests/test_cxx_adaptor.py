@@ -50,7 +50,7 @@ def test_adaptor_cxx_host_program_matches_oracle():
         path, O, x = _dump(tmp, "hubbard_4x2")
         p = subprocess.run([exe, path], capture_output=True, text=True)
         assert p.returncode == 0, p.stdout + p.stderr
-        tok = p.stdout.split()
+        tok = p.stdout.splitlines()[0].split()
         assert tok[0] == "OK"
         sr, si, sr2, m, E0, mcg, accu, d = [float(t) for t in tok[1:]]
         y = O.multmv(x)
@@ -58,3 +58,11 @@ def test_adaptor_cxx_host_program_matches_oracle():
         assert abs(sr2 - 2 * y.sum().real) < 1e-11          # MultMv2 accumulated onto MultMv's result
         assert abs(m - 82) <= 1 and abs(E0 + 14.076058658879278) < 1e-9
         assert abs(mcg - 83) <= 2 and accu < 2e-12 and d < 1e-9
+        drv = p.stdout.splitlines()[1].split()
+        assert drv[0] == "DRV"
+        e0, e1, s_e0, s_v0, nconv_l, w0, w1, w2, nconv_i, ov = [float(t) for t in drv[1:]]
+        dense = np.linalg.eigvalsh(O.to_dense())
+        assert abs(e0 - dense[0]) < 1e-9 and abs(e1 - dense[1]) < 1e-7 and nconv_l == 1
+        assert abs(s_e0 - 82) <= 1 and abs(s_v0 - 83) <= 2
+        assert nconv_i == 3 and np.allclose([w0, w1, w2], dense[:3], atol=1e-9)
+        assert abs(ov - 1.0) < 1e-8
