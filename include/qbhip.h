@@ -228,13 +228,18 @@ typedef struct qbh_comm {
     qbh_z   *d_xsend;         /* [nblk]  device, owned by the host side                     */
     qbh_z   *d_xfull;         /* [nranks*nblk] device                                       */
     double  *d_scal;          /* [>= 16] device doubles                                     */
+    double  *d_xfull_r;       /* [nranks*nblk] device doubles, or NULL: staging of the REAL wire format.
+                                 When the operator and the vectors of a solve are real (exactly zero
+                                 imaginary parts) only the real parts travel: the hook is called with
+                                 packed = 1 and must gather nblk DOUBLES per rank from d_xsend (viewed as
+                                 double[nblk]) into d_xfull_r; the library expands them into d_xfull.   */
     void    *ctx;
-    int    (*allgather_x)(void *ctx);
+    int    (*allgather_x)(void *ctx, int packed);
     int    (*allreduce_sum)(void *ctx, int off, int n);
     /* optional split form of allgather_x (NULL = not provided): begin() enqueues the exchange and
      * returns, wait() orders the operator's stream after its completion.  When both are given, a row
      * shard applies its locally-owned columns between the two calls (overlap with xGMI traffic). */
-    int    (*allgather_begin)(void *ctx);
+    int    (*allgather_begin)(void *ctx, int packed);
     int    (*allgather_wait)(void *ctx);
 } qbh_comm;
 int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm);

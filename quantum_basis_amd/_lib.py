@@ -53,15 +53,17 @@ class SolverInfo(C.Structure):
                 ("theta0_prev", C.c_double), ("theta1_prev", C.c_double)]
 
 
-ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)       # (ctx, packed)
+ALLWAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
 
 
 class Comm(C.Structure):
     _fields_ = [("rank", C.c_int), ("nranks", C.c_int), ("nblk", C.c_int64),
                 ("d_xsend", C.c_void_p), ("d_xfull", C.c_void_p), ("d_scal", C.c_void_p),
+                ("d_xfull_r", C.c_void_p),
                 ("ctx", C.c_void_p), ("allgather_x", ALLGATHER_FN), ("allreduce_sum", ALLREDUCE_FN),
-                ("allgather_begin", ALLGATHER_FN), ("allgather_wait", ALLGATHER_FN)]
+                ("allgather_begin", ALLGATHER_FN), ("allgather_wait", ALLWAIT_FN)]
 
 
 class Stats(C.Structure):

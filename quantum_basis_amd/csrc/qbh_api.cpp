@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <limits>
 #include <new>
 #include <vector>
@@ -268,6 +269,26 @@ int finalize(qbh_csr *A)
     // value dictionary first: it decides how much LDS a row block needs
     QBH_TRY(try_value_dict(A));
     const bool coded = A->d_code != nullptr;
+    // is every stored value real?  (enables the 8-byte wire format of the x exchange)
+    QBH_HIP(hipMalloc(&A->d_flag, sizeof(int)));
+    QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
+    if (coded) {
+        d2 dict[256];
+        QBH_HIP(hipMemcpy(dict, A->d_dict, sizeof(dict), hipMemcpyDeviceToHost));
+        A->values_real = true;
+        for (int i = 0; i < A->n_dict; ++i) A->values_real = A->values_real && dict[i].y == 0.0;
+    } else if (A->d_val && A->nnz > 0) {
+        double *tmp = nullptr;
+        QBH_HIP(hipMalloc(&tmp, (size_t)qbh::kMaxRedBlocks * sizeof(double)));
+        QBH_TRY(qbh::launch_imag_norm(A->d_val, A->nnz, tmp, s));
+        std::vector<double> hp((size_t)qbh::blas_grid(A->nnz));
+        QBH_HIP(hipMemcpyAsync(hp.data(), tmp, hp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        QBH_HIP(hipStreamSynchronize(s));
+        (void)hipFree(tmp);
+        double sum = 0.0;
+        for (double v : hp) sum += v;
+        A->values_real = (sum == 0.0);
+    }
     QBH_TRY(split_shard(A));
 
     QBH_TRY(setup_geometry(A, A->d_ia, A->nnz, coded, &A->npb, &A->tpr, &A->unroll, &A->window, &A->n_blocks, &A->d_rb,
@@ -363,6 +384,7 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
     if (A->rem.d_code) (void)hipFree(A->rem.d_code);
     if (A->rem.d_rb) (void)hipFree(A->rem.d_rb);
     if (A->rem.d_bp) (void)hipFree(A->rem.d_bp);
+    if (A->d_flag) (void)hipFree(A->d_flag);
     if (A->ev2) (void)hipEventDestroy(A->ev2);
     if (A->ev3) (void)hipEventDestroy(A->ev3);
     if (A->d_partials) (void)hipFree(A->d_partials);
@@ -648,15 +670,25 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
 {
     const d2 *xg, *xl;
     bool async_gather = false;
+    const bool packed = A->has_comm && A->real_wire;
+    auto expand_packed = [&]() -> int {          // d_xfull_r (doubles) -> d_xfull (complex, zero imaginary part)
+        return qbh::launch_unpack_real(A->comm.d_xfull_r, reinterpret_cast<d2 *>(A->comm.d_xfull),
+                                       A->comm.nblk * (int64_t)A->comm.nranks, A->stream);
+    };
     if (A->has_comm) {
-        QBH_HIP(hipMemcpyAsync(A->comm.d_xsend, x, (size_t)A->nrows * sizeof(d2), hipMemcpyDeviceToDevice,
-                               A->stream));
+        if (packed)
+            QBH_TRY(qbh::launch_pack_real(x, reinterpret_cast<double *>(A->comm.d_xsend), A->nrows, A->d_flag, A->stream));
+        else
+            QBH_HIP(hipMemcpyAsync(A->comm.d_xsend, x, (size_t)A->nrows * sizeof(d2), hipMemcpyDeviceToDevice,
+                                   A->stream));
         async_gather = A->comm.allgather_begin && A->comm.allgather_wait;
-        const int hrc = async_gather ? A->comm.allgather_begin(A->comm.ctx) : A->comm.allgather_x(A->comm.ctx);
+        const int hrc = async_gather ? A->comm.allgather_begin(A->comm.ctx, packed ? 1 : 0)
+                                     : A->comm.allgather_x(A->comm.ctx, packed ? 1 : 0);
         if (hrc != 0) {
             qbh::set_error("allgather hook failed");
             return QBH_ECOMM;
         }
+        if (!async_gather && packed) QBH_TRY(expand_packed());
         A->stats.n_gather++;
         xg = reinterpret_cast<const d2 *>(A->comm.d_xfull);
         xl = x;
@@ -692,6 +724,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
             qbh::set_error("allgather_wait hook failed");
             return QBH_ECOMM;
         }
+        if (packed) QBH_TRY(expand_packed());
         async_gather = false;
     }
     if (prof) {
@@ -705,9 +738,12 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     }
     int grid_last = A->grid;
     if (A->has_rem) {
-        if (async_gather && A->comm.allgather_wait(A->comm.ctx) != 0) {
-            qbh::set_error("allgather_wait hook failed");
-            return QBH_ECOMM;
+        if (async_gather) {
+            if (A->comm.allgather_wait(A->comm.ctx) != 0) {
+                qbh::set_error("allgather_wait hook failed");
+                return QBH_ECOMM;
+            }
+            if (packed) QBH_TRY(expand_packed());
         }
         const CsrPart &R = A->rem;
         a.ia = R.d_ia;
@@ -737,6 +773,62 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     }
     return QBH_OK;
 }
+
+// Drivers call this at entry with the vectors of their recurrence: when the operator is real and all of them
+// have exactly zero imaginary parts (on every rank), the x exchange carries only real parts for this solve.
+int enable_real_wire(qbh_csr *A, std::initializer_list<const d2 *> vecs)
+{
+    A->real_wire = false;
+    if (!A->has_comm || !A->comm.d_xfull_r) return QBH_OK;
+    if (const char *e = getenv("QBH_NO_REAL_WIRE")) {
+        if (atoi(e)) return QBH_OK;
+    }
+    double total = A->values_real ? 0.0 : 1.0;
+    // every rank must take the same decision: sum the per-vector |Im|^2 (and the operator flag) over ranks
+    for (const d2 *v : vecs) {
+        double sq = 0.0;
+        QBH_TRY(qbh::launch_imag_norm(v, A->nrows, A->d_partials, A->stream));
+        QBH_TRY(finish_reduction(A, qbh::blas_grid(A->nrows), 1, &sq));
+        total += sq;
+    }
+    double flag_sum = 0.0;
+    {   // the operator flag also has to be agreed on
+        const double mine = A->values_real ? 0.0 : 1.0;
+        QBH_HIP(hipMemcpyAsync(A->d_partials, &mine, sizeof(double), hipMemcpyHostToDevice, A->stream));
+        QBH_HIP(hipStreamSynchronize(A->stream));
+        QBH_TRY(finish_reduction(A, 1, 1, &flag_sum));
+    }
+    if (total == 0.0 && flag_sum == 0.0) {
+        QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), A->stream));
+        A->real_wire = true;
+    }
+    return QBH_OK;
+}
+
+// ... and this at exit: a non-zero imaginary part met while packing means results are wrong -> loud error.
+int finish_real_wire(qbh_csr *A)
+{
+    if (!A->real_wire) return QBH_OK;
+    A->real_wire = false;
+    int f = 0;
+    QBH_HIP(hipMemcpyAsync(&f, A->d_flag, sizeof(int), hipMemcpyDeviceToHost, A->stream));
+    QBH_HIP(hipStreamSynchronize(A->stream));
+    const double mine = (double)f;
+    double all = 0.0;
+    QBH_HIP(hipMemcpyAsync(A->d_partials, &mine, sizeof(double), hipMemcpyHostToDevice, A->stream));
+    QBH_HIP(hipStreamSynchronize(A->stream));
+    QBH_TRY(finish_reduction(A, 1, 1, &all));
+    if (all != 0.0) {
+        qbh::set_error("real wire format met a non-zero imaginary part (internal error)");
+        return QBH_EHIP;
+    }
+    return QBH_OK;
+}
+
+struct WireGuard {            // whatever path a driver leaves by, the next call starts with the complex wire
+    qbh_csr *A;
+    ~WireGuard() { A->real_wire = false; }
+};
 
 int dotc_run(qbh_csr *A, const d2 *x, const d2 *y, double *res2)
 {
@@ -979,6 +1071,17 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
         return QBH_ENOTNORM;
     }
 
+    WireGuard wire_guard{A};
+    if (is_val1)     QBH_TRY(enable_real_wire(A, {vpt(k), phi}));
+    else if (k > 0)  QBH_TRY(enable_real_wire(A, {vpt(k), vpt(k + 1)}));
+    else             QBH_TRY(enable_real_wire(A, {vpt(k)}));
+    if (is_val1 && k > 0 && A->real_wire) {       // the second live vector must be real as well
+        double sq0 = 0.0;
+        QBH_TRY(qbh::launch_imag_norm(vpt(k + 1), n, A->d_partials, A->stream));
+        QBH_TRY(finish_reduction(A, qbh::blas_grid(n), 1, &sq0));
+        if (sq0 != 0.0) A->real_wire = false;
+    }
+
     double red[3], sq;
     // The 1/b normalisation (K7, src/lanczos.cc:214) is never a pass of its own: slot j%2 holds an
     // unnormalised u_j with v_j = sc[j%2] * u_j, and the scale is folded into the coefficients of the
@@ -1081,6 +1184,7 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
             theta1_prev = ritz1;
         }
     } while (m < mm);
+    if (rc == QBH_OK) rc = finish_real_wire(A);
     if (rc == QBH_OK) rc = normalise_slots();
     if (rc == QBH_OK) {
         hipError_t e = hipStreamSynchronize(A->stream);
@@ -1148,6 +1252,9 @@ extern "C" int qbh_eigenvec_cg_dev(const qbh_csr *Ac, int64_t maxit, int64_t *m_
     }
     const int64_t spmv0 = A->stats.n_spmv;
     const double ms_spmv0 = A->stats.ms_spmv;
+    WireGuard wire_guard{A};
+    if (m != 0) QBH_TRY(enable_real_wire(A, {v, r, p}));
+    else        QBH_TRY(enable_real_wire(A, {v}));
     double accu = 0.0;
     if (m != 0) QBH_TRY(nrm2_run(A, r, &accu));            // :290
     double red[3], sq;
@@ -1180,6 +1287,7 @@ extern "C" int qbh_eigenvec_cg_dev(const qbh_csr *Ac, int64_t maxit, int64_t *m_
             if (info && info->cg_resid) info->cg_resid[m] = accu;
         }
     }
+    QBH_TRY(finish_real_wire(A));
     QBH_HIP(hipStreamSynchronize(A->stream));
     harvest_events(A);
     *m_io = m;
@@ -1267,6 +1375,8 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
     }
     auto vec = [&](int j) { return V + (size_t)j * (size_t)n; };
     int rc = qbh_vec_randomize(A, reinterpret_cast<qbh_z *>(vec(0)), seed ? seed : 1u);
+    WireGuard wire_guard{A};
+    if (rc == QBH_OK) rc = enable_real_wire(A, {vec(0)});      // the random start vector is real
 
     std::vector<double> T((size_t)m * m, 0.0), Tw((size_t)m * m), theta((size_t)m), S((size_t)m * m);
     int k = 0;                          // vectors kept from the previous restart
@@ -1352,6 +1462,7 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
         }
         k = keep;
     }
+    if (rc == QBH_OK) rc = finish_real_wire(A);
     if (rc == QBH_OK) {
         for (int i = 0; i < (int)nev; ++i) eigenvals[i] = sign * theta[i];
         *nconv_out = nconv;

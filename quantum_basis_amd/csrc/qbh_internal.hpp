@@ -77,6 +77,9 @@ int launch_randomize(d2 *x, int64_t n, int64_t global_offset, uint32_t seed, dou
 int launch_fill_const(d2 *x, int64_t n, double re, hipStream_t s);
 int launch_max_rowlen(const int64_t *d_ia, int64_t nrows, int64_t *d_out, hipStream_t s);
 int blas_grid(int64_t n);
+int launch_pack_real(const d2 *x, double *out, int64_t n, int *flag, hipStream_t s);
+int launch_unpack_real(const double *in, d2 *out, int64_t n, hipStream_t s);
+int launch_imag_norm(const d2 *x, int64_t n, double *partials, hipStream_t s);
 int exclusive_scan(const int32_t *d_cnt, int64_t n, int64_t *d_ia, hipStream_t s);
 int launch_split_count(const int64_t *ia, const int32_t *ja, int64_t nrows, int32_t lo, int32_t hi, int32_t *cnt0, hipStream_t s);
 int launch_split_fill(const int64_t *ia, const int32_t *ja, const d2 *val, const uint8_t *code, int64_t nrows, int32_t lo,
@@ -147,6 +150,11 @@ struct qbh_csr {
     CsrPart  rem;
     hipEvent_t ev2 = nullptr, ev3 = nullptr;
     bool     ev_pending2 = false;
+
+    // real wire format of the x exchange (see k_pack_real)
+    bool     values_real = false;   // every stored value has a zero imaginary part
+    bool     real_wire = false;     // enabled by a driver for the duration of one solve
+    int     *d_flag = nullptr;      // raised by k_pack_real on a non-zero imaginary part
 
     // communicator
     bool     has_comm = false;

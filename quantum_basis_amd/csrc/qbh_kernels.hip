@@ -1351,4 +1351,59 @@ int exclusive_scan(const int32_t *d_cnt, int64_t n, int64_t *d_ia, hipStream_t s
 }
 
 
+
+// ------------------------------------------------- real wire format -------------
+// For a real Hamiltonian and real start vector every Lanczos / CG vector has an exactly zero imaginary
+// part, so the all-gather of x can carry 8 instead of 16 bytes per element (lossless).  pack also raises
+// *flag if it ever meets a non-zero imaginary part (checked by the drivers: never silently wrong).
+__global__ __launch_bounds__(kBlock) void k_pack_real(const d2 *x, double *out, int64_t n, int *flag)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const d2 v = x[i];
+        out[i] = v.x;
+        bad |= (v.y != 0.0);
+    }
+    if (bad) *flag = 1;
+}
+
+__global__ __launch_bounds__(kBlock) void k_unpack_real(const double *in, d2 *out, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = d2{in[i], 0.0};
+}
+
+// partial sums of |Im x|^2 (entry check of the drivers)
+__global__ __launch_bounds__(kBlock) void k_imag_norm(const d2 *x, int64_t n, double *partials)
+{
+    __shared__ double red[4];
+    double acc[1] = {0.0};
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) acc[0] += x[i].y * x[i].y;
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+int launch_pack_real(const d2 *x, double *out, int64_t n, int *flag, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pack_real, dim3(blas_grid(n)), dim3(kBlock), 0, s, x, out, n, flag);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+int launch_unpack_real(const double *in, d2 *out, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_unpack_real, dim3(blas_grid(n)), dim3(kBlock), 0, s, in, out, n);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+int launch_imag_norm(const d2 *x, int64_t n, double *partials, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_imag_norm, dim3(blas_grid(n)), dim3(kBlock), 0, s, x, n, partials);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
 }  // namespace qbh

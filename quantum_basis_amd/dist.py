@@ -41,13 +41,17 @@ class ShardComm:
         self.xsend = torch.zeros(2 * self.nblk, dtype=f64, device=self.device)
         self.xfull = torch.zeros(2 * self.nblk * self.world, dtype=f64, device=self.device)
         self.scal = torch.zeros(16, dtype=f64, device=self.device)
+        # real wire format: when a solve is real only the real parts travel (nblk doubles per rank)
+        self.xfull_r = torch.zeros(self.nblk * self.world, dtype=f64, device=self.device)
+        self.real_wire = True
+        self.n_packed = 0
         backend = dist.get_backend(group)
         self.direct = (backend == "nccl") or self.device.type == "cpu"
         self.errors = []
         self._ag = _lib.ALLGATHER_FN(self._allgather)
         self._ar = _lib.ALLREDUCE_FN(self._allreduce)
         self._ag_begin = _lib.ALLGATHER_FN(self._allgather_begin)
-        self._ag_wait = _lib.ALLGATHER_FN(self._allgather_wait)
+        self._ag_wait = _lib.ALLWAIT_FN(self._allgather_wait)
         self._work = None
         self.n_async = 0             # exchanges started through the begin/wait pair
         self.overlap = True          # hand the begin/wait pair to the library (local columns overlap the gather)
@@ -60,30 +64,39 @@ class ShardComm:
         import contextlib
         return contextlib.nullcontext()
 
-    def _allgather(self, _ctx):
+    def _bufs(self, packed):
+        """(recv, send) of one exchange: complex128 as float64 pairs, or real parts only."""
+        if packed:
+            self.n_packed += 1
+            return self.xfull_r, self.xsend[:self.nblk]
+        return self.xfull, self.xsend
+
+    def _allgather(self, _ctx, packed):
         try:
+            recv, send = self._bufs(packed)
             with self._ctx():
                 if self.direct:
-                    self.dist.all_gather_into_tensor(self.xfull, self.xsend, group=self.group)
+                    self.dist.all_gather_into_tensor(recv, send, group=self.group)
                 else:   # gloo with device tensors (single-GPU test rigs): stage through the host
                     self.torch.cuda.current_stream().synchronize()
-                    send = self.xsend.cpu()
-                    parts = [self.torch.empty_like(send) for _ in range(self.world)]
-                    self.dist.all_gather(parts, send, group=self.group)
-                    self.xfull.copy_(self.torch.cat(parts))
+                    hsend = send.cpu()
+                    parts = [self.torch.empty_like(hsend) for _ in range(self.world)]
+                    self.dist.all_gather(parts, hsend, group=self.group)
+                    recv.copy_(self.torch.cat(parts))
             return 0
         except Exception:            # never let an exception unwind through the C frames
             self.errors.append(traceback.format_exc())
             return 1
 
-    def _allgather_begin(self, _ctx):
+    def _allgather_begin(self, _ctx, packed):
         """Enqueue the exchange and return: RCCL runs it on its own stream, ordered after what the
         operator's stream has enqueued so far (the copy into xsend)."""
         try:
             if not self.direct:                      # host-staged test rigs: no real overlap
-                return self._allgather(_ctx)
+                return self._allgather(_ctx, packed)
+            recv, send = self._bufs(packed)
             with self._ctx():
-                self._work = self.dist.all_gather_into_tensor(self.xfull, self.xsend, group=self.group, async_op=True)
+                self._work = self.dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
             self.n_async += 1
             return 0
         except Exception:
@@ -130,6 +143,7 @@ class ShardComm:
         c.d_xsend = self.xsend.data_ptr()
         c.d_xfull = self.xfull.data_ptr()
         c.d_scal = self.scal.data_ptr()
+        c.d_xfull_r = self.xfull_r.data_ptr() if self.real_wire else None
         c.ctx = None
         c.allgather_x = self._ag
         c.allreduce_sum = self._ar

@@ -43,7 +43,7 @@ def cpu_sharded_lanczos(rank, world, port, case_name, steps, out_dir):
         buf = np.zeros(comm.nblk, dtype=np.complex128)
         buf[:n] = x_loc
         comm.xsend.copy_(torch.from_numpy(buf.view(np.float64)))
-        assert comm._allgather(None) == 0, comm.errors
+        assert comm._allgather(None, 0) == 0, comm.errors
         return comm.xfull.numpy().view(np.complex128)
 
     def allreduce(vals):
@@ -100,6 +100,7 @@ def gpu_sharded_solver(rank, world, port, backend, out_dir):
         comm = qdist.ShardComm(dim, rank=rank, world=world, device=torch.device("cuda", 0), stream=stream).attach(A)
         res = q.locate_E0_lanczos(A, nev=2, ncv=1, maxit=400)
         assert not comm.errors, comm.errors
+        assert comm.n_packed > 100, comm.n_packed        # real operator + real vectors: 8-byte wire format
         if backend == "nccl":
             assert comm.n_async > 100, comm.n_async      # every SpMV went through the asynchronous RCCL all-gather
         x = q.vec_randomize(A, seed=1)                 # shard of the global start vector
@@ -108,6 +109,44 @@ def gpu_sharded_solver(rank, world, port, backend, out_dir):
         if rank == 0:
             np.save(os.path.join(out_dir, "res.npy"), np.array([res.E0, res.E1, res.steps["E0"], res.steps["V0"], res.steps["E1"]]))
             np.save(os.path.join(out_dir, "hess.npy"), res.hessenberg_E0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gpu_sharded_complex(rank, world, port, backend, out_dir):
+    """A genuinely complex Hermitian operator (translation-symmetric sector, helpers.case('chain16_k3')) row-sharded
+    from host arrays through qbh_csr_create_device: the exchange must stay complex (16 B per element)."""
+    import ctypes as C
+
+    import torch
+    dist = _init(rank, world, port, backend)
+    torch.cuda.set_device(0)
+    import helpers
+    import quantum_basis_amd as q
+    from quantum_basis_amd import _lib, dist as qdist
+
+    d, ia, ja, val, sym = helpers.case("chain16_k3")
+    nblk, ranges = qdist.row_partition(d, world)
+    r0, r1 = ranges[rank]
+    dev = torch.device("cuda", 0)
+    sia = torch.from_numpy((ia[r0:r1 + 1] - ia[r0]).astype(np.int64)).to(dev)
+    sja = torch.from_numpy(ja[ia[r0]:ia[r1]].astype(np.int32)).to(dev)
+    sval = torch.from_numpy(val[ia[r0]:ia[r1]].copy().view(np.float64)).to(dev)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        opts = q.make_opts(device=0, stream=stream.cuda_stream)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().qbh_csr_create_device(C.byref(h), r1 - r0, d, r0, int(sia[-1].item()), sia.data_ptr(),
+                                                     sja.data_ptr(), sval.data_ptr(), 0, C.byref(opts)), "qbh_csr_create_device")
+        A = q.csr_mat(0, None, None, None, opts=opts, _handle=h)
+        comm = qdist.ShardComm(d, rank=rank, world=world, device=dev, stream=stream).attach(A)
+        res = q.locate_E0_lanczos(A, nev=1, ncv=1, maxit=600)
+        nconv, w, _ = q.iram(A.dim, A, None, 2, 8, 300, "sr")
+        assert not comm.errors, comm.errors
+        assert comm.n_packed == 0, comm.n_packed           # complex operator: never the real wire format
+        np.save(os.path.join(out_dir, "vec_%d.npy" % rank), res.eigenvecs)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "res.npy"), np.array([res.E0, res.steps["E0"], res.steps["V0"], w[0], w[1]]))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -50,3 +50,21 @@ def test_sharded_solver_matches_single_gpu(world, backend):
     assert np.allclose(x, qo.vec_randomize(4900, 1), rtol=1e-13, atol=0)
     assert abs(abs(np.vdot(vec, ref.eigenvecs)) - 1.0) < 1e-8
     assert abs(np.linalg.norm(vec) - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_complex_operator_from_host_arrays(world):
+    import torch.multiprocessing as mp
+    import dist_worker
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(dist_worker.gpu_sharded_complex, args=(world, _free_port(), "gloo", tmp), nprocs=world, join=True)
+        res = np.load(tmp + "/res.npy")
+        vec = np.concatenate([np.load(tmp + "/vec_%d.npy" % r) for r in range(world)])
+    ans = helpers.known()["chain16_momentum"]
+    d, ia, ja, val, sym = helpers.case("chain16_k3")
+    O = qo.Csr(d, ia, ja, val, sym)
+    ro = qo.locate_E0_lanczos(O, nev=1, ncv=1, maxit=600)
+    assert abs(res[0] - ans["E0_k"][3]) < ans["tol"] and abs(res[0] - ro["E0"]) <= 1e-10 * abs(ro["E0"])
+    assert abs(res[1] - ro["m_E0"]) <= 1 and abs(res[2] - ro["m_V0"]) <= 2
+    assert abs(res[3] - ro["E0"]) < 1e-9                       # device IRAM under the communicator
+    assert abs(abs(np.vdot(vec, ro["eigenvecs"])) - 1.0) < 1e-8 and np.abs(vec.imag).max() > 1e-3
