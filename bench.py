@@ -249,6 +249,8 @@ def main():
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         key = "%s|%s|%s" % (args.workload, {1: "stream", 2: "vector", 3: "rows"}[info.kernel], "dict" if info.value_dict else "plain")
+        if st.n_spmv_real > 0:
+            key += "|real"
         if world == 1 and key in tj:
             traffic = tj[key]["hbm_bytes"]
     except Exception:
@@ -260,11 +262,15 @@ def main():
         "data": "synthetic", "config": {"workload": args.workload, "dim": dim, "nnz_full": nnz_total,
                                          "rows_per_gpu": info.nrows, "parallelism": "row-shard x%d" % world,
                                          "kernel": {1: "stream", 2: "vector", 3: "rows"}[info.kernel], "value_dict": info.value_dict,
+                                         "real_gather": bool(st.n_spmv_real > 0),
                                          "build_s": round(t_gen, 3)},
         "roofline": {"bound": "hbm", "kernel": {1: "k_spmv_stream", 2: "k_spmv_vector", 3: "k_spmv_rows"}[info.kernel],
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                     "bytes_per_launch": bytes_launch, "ms_per_launch": round(ms_spmv, 4), "launches": int(st.n_spmv)},
+                     "bytes_per_launch": bytes_launch, "ms_per_launch": round(ms_spmv, 4), "launches": int(st.n_spmv),
+                     "note": "achieved = ALGORITHMIC bytes (SURVEY 8d: nnz*20 + rows*40) / kernel time; the kernel moves fewer "
+                             "bytes than that (traffic) because values are dictionary-coded (1 B instead of 16 B, lossless) and, for a "
+                             "real operator and real vectors, x is gathered as 8-byte real parts (bit-identical result)"},
         "e0": e0, "lanczos_steps_to_converge": steps_e0,
     }
     if world == 1 and info.value_dict and not args.no_plain:

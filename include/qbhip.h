@@ -251,6 +251,7 @@ typedef struct qbh_stats {
     double  ms_spmv_min;      /* fastest single launch                                    */
     int64_t n_gather;
     double  ms_gather;        /* time spent in allgather_x (event-timed)                  */
+    int64_t n_spmv_real;      /* launches that used the real fast path (8-byte x gathers) */
 } qbh_stats;
 int qbh_get_stats(const qbh_csr *A, qbh_stats *s, int reset);
 /* Block until everything enqueued on the operator's stream has finished (device building blocks

@@ -68,7 +68,7 @@ class Comm(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_spmv", C.c_int64), ("ms_spmv", C.c_double), ("ms_spmv_min", C.c_double),
-                ("n_gather", C.c_int64), ("ms_gather", C.c_double)]
+                ("n_gather", C.c_int64), ("ms_gather", C.c_double), ("n_spmv_real", C.c_int64)]
 
 
 # every symbol include/qbhip.h declares (tests check that the .so exports all of them)

@@ -385,6 +385,7 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
     if (A->rem.d_rb) (void)hipFree(A->rem.d_rb);
     if (A->rem.d_bp) (void)hipFree(A->rem.d_bp);
     if (A->d_flag) (void)hipFree(A->d_flag);
+    if (A->d_xr) (void)hipFree(A->d_xr);
     if (A->ev2) (void)hipEventDestroy(A->ev2);
     if (A->ev3) (void)hipEventDestroy(A->ev3);
     if (A->d_partials) (void)hipFree(A->d_partials);
@@ -671,14 +672,16 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     const d2 *xg, *xl;
     bool async_gather = false;
     const bool packed = A->has_comm && A->real_wire;
+    const bool realm = A->real_mode && A->kernel == QBH_KERNEL_ROWS && (packed || !A->has_comm);
     auto expand_packed = [&]() -> int {          // d_xfull_r (doubles) -> d_xfull (complex, zero imaginary part)
         return qbh::launch_unpack_real(A->comm.d_xfull_r, reinterpret_cast<d2 *>(A->comm.d_xfull),
                                        A->comm.nblk * (int64_t)A->comm.nranks, A->stream);
     };
     if (A->has_comm) {
-        if (packed)
-            QBH_TRY(qbh::launch_pack_real(x, reinterpret_cast<double *>(A->comm.d_xsend), A->nrows, A->d_flag, A->stream));
-        else
+        if (packed) {
+            if (!(realm && A->xr_of == x))
+                QBH_TRY(qbh::launch_pack_real(x, reinterpret_cast<double *>(A->comm.d_xsend), A->nrows, A->d_flag, A->stream));
+        } else
             QBH_HIP(hipMemcpyAsync(A->comm.d_xsend, x, (size_t)A->nrows * sizeof(d2), hipMemcpyDeviceToDevice,
                                    A->stream));
         async_gather = A->comm.allgather_begin && A->comm.allgather_wait;
@@ -688,13 +691,14 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
             qbh::set_error("allgather hook failed");
             return QBH_ECOMM;
         }
-        if (!async_gather && packed) QBH_TRY(expand_packed());
+        if (!async_gather && packed && !realm) QBH_TRY(expand_packed());
         A->stats.n_gather++;
         xg = reinterpret_cast<const d2 *>(A->comm.d_xfull);
         xl = x;
     } else {
         xg = x;
         xl = x + A->row_offset;
+        if (realm && A->xr_of != x) QBH_TRY(qbh::launch_pack_real(x, A->d_xr, A->ncols, A->d_flag, A->stream));
     }
     qbh::SpmvArgs a{};
     a.ia = A->d_ia;
@@ -709,6 +713,12 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     // the local part indexes x by GLOBAL column but only touches [row_offset, row_offset + nrows):
     // serve it from the local block so it does not depend on the gather
     a.xg = (A->has_rem && A->has_comm) ? xl - A->row_offset : xg;
+    a.xr = nullptr;
+    if (realm) {
+        if (!A->has_comm) a.xr = A->d_xr;
+        else if (A->has_rem) a.xr = reinterpret_cast<const double *>(A->comm.d_xsend) - A->row_offset;   // own block, packed
+        else a.xr = A->comm.d_xfull_r;
+    }
     a.xl = xl;
     a.y = y;
     a.alpha = alpha;
@@ -724,7 +734,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
             qbh::set_error("allgather_wait hook failed");
             return QBH_ECOMM;
         }
-        if (packed) QBH_TRY(expand_packed());
+        if (packed && !realm) QBH_TRY(expand_packed());
         async_gather = false;
     }
     if (prof) {
@@ -743,7 +753,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
                 qbh::set_error("allgather_wait hook failed");
                 return QBH_ECOMM;
             }
-            if (packed) QBH_TRY(expand_packed());
+            if (packed && !realm) QBH_TRY(expand_packed());
         }
         const CsrPart &R = A->rem;
         a.ia = R.d_ia;
@@ -754,6 +764,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         a.bp = R.d_bp;
         a.n_blocks = R.n_blocks;
         a.xg = xg;
+        if (realm) a.xr = A->has_comm ? A->comm.d_xfull_r : A->d_xr;
         a.beta = 1.0;                       // accumulate onto the local part's result
         a.gamma = 0.0;
         a.partials = red ? A->d_partials : nullptr;
@@ -766,7 +777,9 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         }
         grid_last = R.grid;
     }
+    A->xr_of = nullptr;                      // the packed copy is consumed by exactly one SpMV
     A->stats.n_spmv++;
+    if (realm) A->stats.n_spmv_real++;
     if (red) {
         QBH_TRY(finish_reduction(A, grid_last, 3, red));
         if (prof) harvest_events(A);
@@ -779,7 +792,9 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
 int enable_real_wire(qbh_csr *A, std::initializer_list<const d2 *> vecs)
 {
     A->real_wire = false;
-    if (!A->has_comm || !A->comm.d_xfull_r) return QBH_OK;
+    A->real_mode = false;
+    A->xr_of = nullptr;
+    if (A->has_comm && !A->comm.d_xfull_r) return QBH_OK;
     if (const char *e = getenv("QBH_NO_REAL_WIRE")) {
         if (atoi(e)) return QBH_OK;
     }
@@ -800,7 +815,13 @@ int enable_real_wire(qbh_csr *A, std::initializer_list<const d2 *> vecs)
     }
     if (total == 0.0 && flag_sum == 0.0) {
         QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), A->stream));
-        A->real_wire = true;
+        A->real_wire = A->has_comm;
+        // the row kernel can then gather 8-byte real parts (bit-identical result, half the x traffic)
+        A->real_mode = A->kernel == QBH_KERNEL_ROWS;
+        if (const char *e = getenv("QBH_NO_REAL_MODE")) {
+            if (atoi(e)) A->real_mode = false;
+        }
+        if (A->real_mode && !A->has_comm && !A->d_xr) QBH_HIP(hipMalloc(&A->d_xr, (size_t)A->ncols * sizeof(double)));
     }
     return QBH_OK;
 }
@@ -808,8 +829,10 @@ int enable_real_wire(qbh_csr *A, std::initializer_list<const d2 *> vecs)
 // ... and this at exit: a non-zero imaginary part met while packing means results are wrong -> loud error.
 int finish_real_wire(qbh_csr *A)
 {
-    if (!A->real_wire) return QBH_OK;
+    A->xr_of = nullptr;
+    if (!A->real_wire && !A->real_mode) return QBH_OK;
     A->real_wire = false;
+    A->real_mode = false;
     int f = 0;
     QBH_HIP(hipMemcpyAsync(&f, A->d_flag, sizeof(int), hipMemcpyDeviceToHost, A->stream));
     QBH_HIP(hipStreamSynchronize(A->stream));
@@ -827,7 +850,7 @@ int finish_real_wire(qbh_csr *A)
 
 struct WireGuard {            // whatever path a driver leaves by, the next call starts with the complex wire
     qbh_csr *A;
-    ~WireGuard() { A->real_wire = false; }
+    ~WireGuard() { A->real_wire = false; A->real_mode = false; A->xr_of = nullptr; }
 };
 
 int dotc_run(qbh_csr *A, const d2 *x, const d2 *y, double *res2)
@@ -836,9 +859,19 @@ int dotc_run(qbh_csr *A, const d2 *x, const d2 *y, double *res2)
     return finish_reduction(A, qbh::blas_grid(A->nrows), 2, res2);
 }
 
+// where the packed real parts of the next gather source go in the real fast path (nullptr: not active)
+inline double *packed_target(qbh_csr *A)
+{
+    if (!A->real_mode || A->kernel != QBH_KERNEL_ROWS) return nullptr;
+    if (A->has_comm) return A->real_wire ? reinterpret_cast<double *>(A->comm.d_xsend) : nullptr;
+    return (A->nrows == A->ncols) ? A->d_xr : nullptr;
+}
+
 int axpy_norm_run(qbh_csr *A, d2 alpha, const d2 *x, d2 *y, double *nrm2sq)
 {
-    QBH_TRY(qbh::launch_axpy_norm(alpha, x, y, A->nrows, A->d_partials, A->stream));
+    double *yr = packed_target(A);          // y is the next SpMV's x in every driver: emit its packed copy here
+    QBH_TRY(qbh::launch_axpy_norm(alpha, x, y, A->nrows, A->d_partials, yr, A->d_flag, A->stream));
+    A->xr_of = yr ? y : nullptr;
     return finish_reduction(A, qbh::blas_grid(A->nrows), 1, nrm2sq);
 }
 
@@ -1104,6 +1137,7 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
             if (sc[j] != 1.0) {
                 QBH_TRY(qbh::launch_scal(sc[j], v + (size_t)j * (size_t)n, n, A->stream));
                 sc[j] = 1.0;
+                A->xr_of = nullptr;
             }
         return QBH_OK;
     };

@@ -47,6 +47,7 @@ struct SpmvArgs {
     int64_t        n_blocks;
     int64_t        nrows;
     const d2      *xg;     // gather source (full-length x)
+    const double  *xr;     // row kernel, real fast path: packed real parts of x (nullptr = complex gather)
     const d2      *xl;     // shard-local x (xg + row_offset without a communicator)
     d2            *y;
     double         alpha, beta, gamma;
@@ -66,7 +67,7 @@ int launch_block_stats(const int64_t *d_ia, const int32_t *d_rb, int64_t n_block
                        hipStream_t s);
 int launch_reduce_partials(const double *partials, int nparts, int ncomp, double *out, hipStream_t s);
 int launch_dotc(const d2 *x, const d2 *y, int64_t n, double *partials, hipStream_t s);
-int launch_axpy_norm(d2 alpha, const d2 *x, d2 *y, int64_t n, double *partials, hipStream_t s);
+int launch_axpy_norm(d2 alpha, const d2 *x, d2 *y, int64_t n, double *partials, double *yr, int *flag, hipStream_t s);
 int launch_nrm2sq(const d2 *x, int64_t n, double *partials, hipStream_t s);
 int launch_scal(double a, d2 *x, int64_t n, hipStream_t s);
 int launch_xpby(const d2 *x, double b, d2 *y, int64_t n, hipStream_t s);            // y = x + b*y
@@ -154,6 +155,9 @@ struct qbh_csr {
     // real wire format of the x exchange (see k_pack_real)
     bool     values_real = false;   // every stored value has a zero imaginary part
     bool     real_wire = false;     // enabled by a driver for the duration of one solve
+    bool     real_mode = false;     // row kernel gathers packed real parts (same conditions, any rank count)
+    double  *d_xr = nullptr;        // [ncols] packed Re(x) when there is no communicator
+    const void *xr_of = nullptr;    // the vector whose real parts the packed buffer currently holds
     int     *d_flag = nullptr;      // raised by k_pack_real on a non-zero imaginary part
 
     // communicator

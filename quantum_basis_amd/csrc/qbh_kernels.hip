@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(SpmvArgs a)
 // from the front and from the back of the row turns those gathers into full-line coalesced
 // loads.  Row sums stay in registers (no 16-byte products through LDS, no shuffle tree);
 // with the value dictionary the LDS footprint is 5 B/nnz and 8 workgroups fit a CU.
-template <int NPB, int P, int UN, bool DICT>
+template <int NPB, int P, int UN, bool DICT, bool REALX>
 __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
 {
     constexpr int R = kBlock / P;            // rows per pass
@@ -385,17 +385,33 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
                             ix[j] = base + (ok[j] ? f : 0);
                             cc[j] = scol[ix[j]];
                         }
-                        d2 xv[UN], vv[UN];
+                        if (REALX) {
+                            // real operator applied to a real vector: gather 8-byte real parts from the packed
+                            // copy of x; (a+0i)(b+0i) = ab+0i exactly, so the result is bit-identical
+                            double xr[UN], vr[UN];
 #pragma unroll
-                        for (int j = 0; j < UN; ++j) xv[j] = a.xg[cc[j]];
+                            for (int j = 0; j < UN; ++j) xr[j] = a.xr[cc[j]];
 #pragma unroll
-                        for (int j = 0; j < UN; ++j) {
-                            if (DICT) vv[j] = dict_s[scode[ix[j]]];
-                            else      vv[j] = sval[ix[j]];
+                            for (int j = 0; j < UN; ++j) {
+                                if (DICT) vr[j] = dict_s[scode[ix[j]]].x;
+                                else      vr[j] = sval[ix[j]].x;
+                            }
+#pragma unroll
+                            for (int j = 0; j < UN; ++j)
+                                if (ok[j]) sum.x += vr[j] * xr[j];
+                        } else {
+                            d2 xv[UN], vv[UN];
+#pragma unroll
+                            for (int j = 0; j < UN; ++j) xv[j] = a.xg[cc[j]];
+#pragma unroll
+                            for (int j = 0; j < UN; ++j) {
+                                if (DICT) vv[j] = dict_s[scode[ix[j]]];
+                                else      vv[j] = sval[ix[j]];
+                            }
+#pragma unroll
+                            for (int j = 0; j < UN; ++j)
+                                if (ok[j]) sum += cmul(vv[j], xv[j]);
                         }
-#pragma unroll
-                        for (int j = 0; j < UN; ++j)
-                            if (ok[j]) sum += cmul(vv[j], xv[j]);
                     }
                     if (P > 1) {
                         part[tid] = sum;
@@ -420,7 +436,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
                         d2 v;
                         if (DICT) v = dict_s[a.code[q]];
                         else      v = a.val[q];
-                        const d2 t = cmul(v, a.xg[a.ja[q] & a.colmask]);
+                        const int cq = a.ja[q] & a.colmask;
+                        const d2 xq = REALX ? d2{a.xr[cq], 0.0} : a.xg[cq];
+                        const d2 t = cmul(v, xq);
                         pr[0] += t.x;
                         pr[1] += t.y;
                     }
@@ -531,8 +549,8 @@ static int occ_rows_un(int un)
 {
     int n = 0;
     hipError_t e = (un == 8)
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spmv_rows<NPB, PP, 8, DICT>, kBlock, 0)
-        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spmv_rows<NPB, PP, 4, DICT>, kBlock, 0);
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spmv_rows<NPB, PP, 8, DICT, false>, kBlock, 0)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spmv_rows<NPB, PP, 4, DICT, false>, kBlock, 0);
     return e == hipSuccess ? n : 0;
 }
 
@@ -571,8 +589,13 @@ int rows_kernel_occupancy(int npb, int tpr, int un, bool dict)
 template <int NPB, int PP, bool DICT>
 static int launch_rows_un(const SpmvArgs &a, int un, int grid, hipStream_t s)
 {
-    if (un == 8) hipLaunchKernelGGL((k_spmv_rows<NPB, PP, 8, DICT>), dim3(grid), dim3(kBlock), 0, s, a);
-    else         hipLaunchKernelGGL((k_spmv_rows<NPB, PP, 4, DICT>), dim3(grid), dim3(kBlock), 0, s, a);
+    if (a.xr != nullptr) {
+        if (un == 8) hipLaunchKernelGGL((k_spmv_rows<NPB, PP, 8, DICT, true>), dim3(grid), dim3(kBlock), 0, s, a);
+        else         hipLaunchKernelGGL((k_spmv_rows<NPB, PP, 4, DICT, true>), dim3(grid), dim3(kBlock), 0, s, a);
+    } else {
+        if (un == 8) hipLaunchKernelGGL((k_spmv_rows<NPB, PP, 8, DICT, false>), dim3(grid), dim3(kBlock), 0, s, a);
+        else         hipLaunchKernelGGL((k_spmv_rows<NPB, PP, 4, DICT, false>), dim3(grid), dim3(kBlock), 0, s, a);
+    }
     return QBH_OK;
 }
 
@@ -948,24 +971,32 @@ int launch_dotc(const d2 *x, const d2 *y, int64_t n, double *partials, hipStream
 }
 
 // y += alpha*x ; partial |y|^2   (cblas_zaxpy + cblas_dznrm2 in one pass: K5+K6)
+// yr (optional): packed real parts of the updated y -- the next SpMV's gather source in the real fast
+// path, produced here instead of by a separate k_pack_real pass; flag as in k_pack_real.
 __global__ __launch_bounds__(kBlock) void k_axpy_norm(d2 alpha, const d2 *x, d2 *y, int64_t n,
-                                                      double *partials)
+                                                      double *partials, double *yr, int *flag)
 {
     __shared__ double red[4];
     double acc[1] = {0.0};
+    bool bad = false;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         d2 v = y[i] + cmul(alpha, x[i]);
         y[i] = v;
+        if (yr != nullptr) {
+            yr[i] = v.x;
+            bad |= (v.y != 0.0);
+        }
         acc[0] += v.x * v.x + v.y * v.y;
     }
+    if (bad) *flag = 1;
     block_sum<1>(acc, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
 }
 
-int launch_axpy_norm(d2 alpha, const d2 *x, d2 *y, int64_t n, double *partials, hipStream_t s)
+int launch_axpy_norm(d2 alpha, const d2 *x, d2 *y, int64_t n, double *partials, double *yr, int *flag, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_axpy_norm, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, x, y, n, partials);
+    hipLaunchKernelGGL(k_axpy_norm, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, x, y, n, partials, yr, flag);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }

@@ -37,7 +37,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.Z) == 16
     assert C.sizeof(_lib.LanczosRow) == 8 + 4 * 8 + 5 * 8
     assert C.sizeof(_lib.Opts) == 4 + 4 + 8 + 6 * 4
-    assert C.sizeof(_lib.Stats) == 5 * 8
+    assert C.sizeof(_lib.Stats) == 6 * 8
 
 
 def test_strerror_and_no_device_is_loud():

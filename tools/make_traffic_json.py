@@ -29,6 +29,12 @@ def main():
         out[key] = {"kernel": v["kernel"] + "<" + v["template"] + ">", "read_bytes": read, "write_bytes": write,
                     "hbm_bytes": read + write, "FETCH_SIZE_KiB": v["FETCH_SIZE"], "WRITE_SIZE_KiB": v["WRITE_SIZE"],
                     "check_TCC_EA0_RDREQ_128B_x128": v.get("TCC_EA0_RDREQ_128B_sum", 0.0) * 128.0, "source": path}
+    try:
+        old = json.load(open("profiles/traffic.json"))
+    except Exception:
+        old = {}
+    old.update(out)
+    out = old
     json.dump(out, open("profiles/traffic.json", "w"), indent=1)
     print(json.dumps(out, indent=1))
 
