@@ -11,7 +11,7 @@ import sys
 def parse(path):
     vals = {}
     for line in open(path):
-        m = re.search(r"(k_spmv_\w+)<([^>]*)>\s+(\w+)\s+n=\d+\s+mean=([0-9.e+]+)", line)
+        m = re.search(r"(k?_?spmv_\w+)<([^>]*)>\s+(\w+)\s+n=\d+\s+mean=([0-9.e+]+)", line)
         if m:
             vals["kernel"] = m.group(1)
             vals["template"] = m.group(2)
