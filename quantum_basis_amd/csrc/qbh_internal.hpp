@@ -63,8 +63,6 @@ int spmv_grid(int kernel, int64_t n_blocks, int64_t nrows, int tpr);
 int rows_kernel_occupancy(int npb, int tpr, int un, bool dict);
 int launch_build_rowblocks(const int64_t *d_ia, int64_t nrows, int64_t window, int32_t *d_rb,
                            int64_t *d_bp, int64_t n_blocks, hipStream_t s);
-int launch_block_stats(const int64_t *d_ia, const int32_t *d_rb, int64_t n_blocks, int64_t *d_out2,
-                       hipStream_t s);
 int launch_reduce_partials(const double *partials, int nparts, int ncomp, double *out, hipStream_t s);
 int launch_dotc(const d2 *x, const d2 *y, int64_t n, double *partials, hipStream_t s);
 int launch_axpy_norm(d2 alpha, const d2 *x, d2 *y, int64_t n, double *partials, double *yr, int *flag, hipStream_t s);

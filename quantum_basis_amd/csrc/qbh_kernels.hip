@@ -693,27 +693,6 @@ int launch_build_rowblocks(const int64_t *d_ia, int64_t nrows, int64_t window, i
     return QBH_OK;
 }
 
-__global__ void k_block_stats(const int64_t *ia, const int32_t *rb, int64_t n_blocks,
-                              unsigned long long *out2)
-{
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_blocks) return;
-    const int r0 = rb[w], r1 = rb[w + 1];
-    const unsigned long long nn = (unsigned long long)(ia[r1] - ia[r0]);
-    atomicMax(&out2[0], nn);
-    atomicMax(&out2[1], (unsigned long long)(r1 - r0));
-}
-
-int launch_block_stats(const int64_t *d_ia, const int32_t *d_rb, int64_t n_blocks, int64_t *d_out2,
-                       hipStream_t s)
-{
-    QBH_HIP(hipMemsetAsync(d_out2, 0, 2 * sizeof(int64_t), s));
-    hipLaunchKernelGGL(k_block_stats, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, s, d_ia, d_rb,
-                       n_blocks, (unsigned long long *)d_out2);
-    QBH_HIP(hipGetLastError());
-    return QBH_OK;
-}
-
 __global__ void k_max_rowlen(const int64_t *ia, int64_t nrows, unsigned long long *out)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
