@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed run to convergence (E0)")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)
+    ap.add_argument("--no-matrix-free", action="store_true", help="skip the extra measurement of the matrix-free Hubbard operator")
     ap.add_argument("--no-plain", action="store_true", help="skip the extra (untimed-region) measurement of the uncoded complex128 kernel")
     args = ap.parse_args()
 
@@ -295,6 +296,34 @@ def main():
                 P.destroy()
         except Exception as e:
             out["roofline_plain_values"] = {"error": repr(e)}
+    if world == 1 and W["kind"] == "hubbard" and not args.no_matrix_free:
+        # SURVEY 8f-1 (next row, NOT the north-star CSR path): the same operator applied from the hop tables without a
+        # stored matrix, same solver code; measured after the timed region, same step definition
+        try:
+            with torch.cuda.stream(stream):
+                M = q.csr_mat.hubbard(W["n_sites"], W["n_up"], W["n_dn"], W["bonds"], t=W["t"], U=W["U"], matrix_free=True,
+                                      opts=q.make_opts(device=local_rank, stream=stream.cuda_stream, profile=1))
+                mv = M.vec(2)
+                mh = np.zeros(2 * maxit)
+                M.randomize(mv.at(0), 1)
+                mk = q.lanczos(0, max(Wm, 2), maxit, n, M, None, mh, "sr_val0", device_v=mv)
+                M.stats(reset=True)
+                torch.cuda.synchronize()
+                tm0 = time.perf_counter()
+                mk2 = q.lanczos(mk, K, maxit, n, M, None, mh, "sr_val0", device_v=mv)
+                torch.cuda.synchronize()
+                tm = time.perf_counter() - tm0
+                ms_ = M.stats()
+                mms = ms_.ms_spmv / max(ms_.n_spmv, 1)
+                out["matrix_free_hubbard"] = {"lanczos_iters_per_s": round((mk2 - mk) / tm, 4), "steps": int(mk2 - mk),
+                                              "spmv_ms_per_launch": round(mms, 4),
+                                              "equivalent_csr_GBps": round(bytes_launch / mms / 1e6, 2),
+                                              "table_bytes": int(M.info().bytes_matrix),
+                                              "note": "no stored matrix; not the CSR north-star path"}
+                mv.free()
+                M.destroy()
+        except Exception as e:
+            out["matrix_free_hubbard"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(A, dim, args.cpu_rows)

@@ -63,6 +63,7 @@ const char *qbh_last_error(void);                   /* thread-local detail of th
 #define QBH_KERNEL_STREAM  1   /* row blocks, val*x products through LDS, TPR lanes per row   */
 #define QBH_KERNEL_VECTOR  2   /* sub-wavefront per row, shuffle reduction, no LDS            */
 #define QBH_KERNEL_ROWS    3   /* row blocks staged in LDS, lanes mapped to rows (default)    */
+#define QBH_KERNEL_MATRIX_FREE 4 /* reported by qbh_csr_get_info for qbh_mf_hubbard operators   */
 
 typedef struct qbh_opts {
     int     device;          /* HIP ordinal; -1 = current device                                  */
@@ -269,6 +270,14 @@ int qbh_sync(const qbh_csr *A);
 int qbh_gen_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_bonds,
                     const int32_t *bonds /* [2*n_bonds] */, double t, double U,
                     int64_t row_begin, int64_t row_end, const qbh_opts *opts);
+/* The same Fermi-Hubbard operator WITHOUT a stored matrix (counterpart of the matrix-free
+ * model<T>::MultMv2, src/model.cc:941-1109): H = T_up (x) 1 + 1 (x) T_dn + U*D is applied from the two hop tables
+ * (a few MB).  Same basis order and signs as qbh_gen_hubbard, so y = Hx is identical up to summation order; every
+ * entry point that takes an operator handle works (SpMV, Lanczos, CG, IRAM, communicator); qbh_csr_download
+ * returns QBH_EUNSUPP; qbh_csr_get_info reports the nnz a CSR of the operator would hold. */
+int qbh_mf_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_bonds,
+                   const int32_t *bonds /* [2*n_bonds] */, double t, double U,
+                   int64_t row_begin, int64_t row_end, const qbh_opts *opts);
 /* Spin-1/2 Heisenberg, H = J sum_<ij> S_i.S_j, fixed number of down spins; basis index =
  * colexicographic rank of the down-spin bit pattern. */
 int qbh_gen_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bonds,

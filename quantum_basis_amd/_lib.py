@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libqbhip.so")
 
 QBH_OK = 0
-KERNEL_AUTO, KERNEL_STREAM, KERNEL_VECTOR, KERNEL_ROWS = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_STREAM, KERNEL_VECTOR, KERNEL_ROWS, KERNEL_MATRIX_FREE = 0, 1, 2, 3, 4
 
 
 class QbhError(RuntimeError):
@@ -81,7 +81,7 @@ EXPORTS = [
     "qbh_spmv_dev", "qbh_dotc_dev", "qbh_axpy_norm_dev", "qbh_scal_dev", "qbh_nrm2_dev",
     "qbh_lanczos", "qbh_lanczos_dev", "qbh_eigenvec_cg", "qbh_eigenvec_cg_dev", "qbh_hess_eigen", "qbh_iram",
     "qbh_csr_set_comm", "qbh_get_stats", "qbh_sync",
-    "qbh_gen_hubbard", "qbh_gen_heisenberg", "qbh_csr_download",
+    "qbh_gen_hubbard", "qbh_mf_hubbard", "qbh_gen_heisenberg", "qbh_csr_download",
 ]
 
 _lib = None
@@ -145,6 +145,7 @@ def lib():
     L.qbh_sync.argtypes = [vp]
     L.qbh_gen_hubbard.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, vp, dbl, dbl,
                                   i64, i64, C.POINTER(Opts)]
+    L.qbh_mf_hubbard.argtypes = L.qbh_gen_hubbard.argtypes
     L.qbh_gen_heisenberg.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp, dbl, i64, i64,
                                      C.POINTER(Opts)]
     L.qbh_csr_download.argtypes = [vp, i64, i64, vp, vp, vp]

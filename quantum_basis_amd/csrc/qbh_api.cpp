@@ -386,6 +386,14 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
     if (A->rem.d_bp) (void)hipFree(A->rem.d_bp);
     if (A->d_flag) (void)hipFree(A->d_flag);
     if (A->d_xr) (void)hipFree(A->d_xr);
+    if (A->kind == 1) {
+        (void)hipFree(A->mf.cfg_u);
+        (void)hipFree(A->mf.cfg_d);
+        (void)hipFree(A->mf.tgt_u);
+        (void)hipFree(A->mf.tgt_d);
+        (void)hipFree(A->mf.val_u);
+        (void)hipFree(A->mf.val_d);
+    }
     if (A->ev2) (void)hipEventDestroy(A->ev2);
     if (A->ev3) (void)hipEventDestroy(A->ev3);
     if (A->d_partials) (void)hipFree(A->d_partials);
@@ -554,6 +562,40 @@ extern "C" int qbh_csr_create_device(qbh_csr **out, int64_t nrows, int64_t ncols
     return QBH_OK;
 }
 
+int qbh::adopt_mf_hubbard(qbh_csr **out, const qbh::MfHubbard &t, int64_t nrows, int64_t ncols, int64_t row_offset,
+                          int64_t nnz_equiv, const qbh_opts *opts)
+{
+    qbh_csr *A = nullptr;
+    QBH_TRY(new_handle(&A, opts));
+    A->kind = 1;
+    A->mf = t;
+    A->nrows = nrows;
+    A->ncols = ncols;
+    A->row_offset = row_offset;
+    A->nnz = A->nnz_total = nnz_equiv;         // what the CSR of the same operator would hold (for the byte accounting)
+    A->kernel = QBH_KERNEL_ROWS;
+    A->values_real = true;                     // t and U are real
+    A->n_blocks = (nrows + qbh::kBlock - 1) / qbh::kBlock;
+    A->grid = (int)std::min<int64_t>(A->n_blocks, 256 * 8);
+    auto fail = [&](int code) {
+        qbh_csr_destroy(A);
+        return code;
+    };
+    if (hipMalloc(&A->d_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (hipHostMalloc(&A->h_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (hipMalloc(&A->d_flag, sizeof(int)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (hipMemset(A->d_flag, 0, sizeof(int)) != hipSuccess) return fail(QBH_EHIP);
+    if (hipEventCreate(&A->ev0) != hipSuccess || hipEventCreate(&A->ev1) != hipSuccess ||
+        hipEventCreate(&A->ev2) != hipSuccess || hipEventCreate(&A->ev3) != hipSuccess)
+        return fail(QBH_EHIP);
+    const size_t nparts = (size_t)std::max(A->grid, qbh::kMaxRedBlocks);
+    if (hipMalloc(&A->d_partials, nparts * 4 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
+    A->stats = qbh_stats{};
+    A->stats.ms_spmv_min = std::numeric_limits<double>::infinity();
+    *out = A;
+    return QBH_OK;
+}
+
 extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
 {
     if (!A || !info) return QBH_EINVAL;
@@ -566,7 +608,9 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->bytes_matrix = (A->nrows + 1) * 8 * (A->has_rem ? 2 : 1) + nnz * 4 + (A->d_code ? nnz + 256 * 16 : nnz * 16) +
                          (nb + 2) * 12;
     info->bytes_algorithmic = nnz * 20 + (A->nrows + 1) * 8 + A->nrows * 32;
-    info->kernel = A->kernel;
+    if (A->kind == 1)
+        info->bytes_matrix = (A->mf.Nu * A->mf.wu + A->mf.Nd * A->mf.wd) * 3 + (A->mf.Nu + A->mf.Nd) * 4;
+    info->kernel = A->kind == 1 ? QBH_KERNEL_MATRIX_FREE : A->kernel;
     info->value_dict = A->d_code ? A->n_dict : 0;
     info->device = A->device;
     info->stream = (void *)A->stream;
@@ -699,6 +743,45 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         xg = x;
         xl = x + A->row_offset;
         if (realm && A->xr_of != x) QBH_TRY(qbh::launch_pack_real(x, A->d_xr, A->ncols, A->d_flag, A->stream));
+    }
+    if (A->kind == 1) {                          // matrix-free operator: one launch, needs the whole gathered x
+        if (async_gather) {
+            if (A->comm.allgather_wait(A->comm.ctx) != 0) {
+                qbh::set_error("allgather_wait hook failed");
+                return QBH_ECOMM;
+            }
+            if (packed && !realm) QBH_TRY(expand_packed());
+        }
+        qbh::MfArgs m{};
+        m.t = A->mf;
+        m.row_begin = A->row_offset;
+        m.nrows = A->nrows;
+        m.xg = xg;
+        m.xl = xl;
+        m.xr = realm ? (A->has_comm ? A->comm.d_xfull_r : A->d_xr) : nullptr;
+        m.y = y;
+        m.alpha = alpha;
+        m.beta = beta;
+        m.gamma = gamma;
+        m.partials = red ? A->d_partials : nullptr;
+        const bool profm = A->opts.profile != 0;
+        if (profm) {
+            harvest_events(A);
+            QBH_HIP(hipEventRecord(A->ev0, A->stream));
+        }
+        QBH_TRY(qbh::launch_mf_hubbard(m, A->grid, A->stream));
+        if (profm) {
+            QBH_HIP(hipEventRecord(A->ev1, A->stream));
+            A->ev_pending = true;
+        }
+        A->xr_of = nullptr;
+        A->stats.n_spmv++;
+        if (realm) A->stats.n_spmv_real++;
+        if (red) {
+            QBH_TRY(finish_reduction(A, A->grid, 3, red));
+            if (profm) harvest_events(A);
+        }
+        return QBH_OK;
     }
     qbh::SpmvArgs a{};
     a.ia = A->d_ia;
@@ -1550,6 +1633,10 @@ int download_part(const qbh_csr *A, const int64_t *d_ia, const int32_t *d_ja, co
 extern "C" int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1, int64_t *ia, int32_t *ja, qbh_z *val)
 {
     if (!A || r0 < 0 || r1 < r0 || r1 > A->nrows) return QBH_EINVAL;
+    if (A->kind == 1) {
+        qbh::set_error("qbh_csr_download: the operator is matrix-free (no stored CSR)");
+        return QBH_EUNSUPP;
+    }
     Bind bind(A);
     QBH_HIP(hipStreamSynchronize(A->stream));
     std::vector<int64_t> ia0, ia1;

@@ -25,6 +25,14 @@ namespace qbh {
 namespace {
 
 // ------------------------------------------------------------------ Hubbard ----
+}  // namespace
+struct HopTableView {
+    int64_t n;
+    const int32_t *ptr, *tgt;
+    const double *val;
+};
+namespace {
+
 struct HopTable {              // per configuration: sorted (target rank, amplitude) lists
     std::vector<uint32_t> cfg;
     std::vector<int32_t> ptr, tgt, nlo;
@@ -383,6 +391,98 @@ extern "C" int qbh_gen_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, i
         (void)hipFree(d_val);
     }
     return rc;
+}
+
+namespace {
+// hop table -> ELL (entry k of configuration c at [k*N + c]), padded to groups of 8 with (c, amplitude 0); targets as
+// uint16, amplitudes as codes into amp[] (shared by both species)
+int upload_ell(const qbh::HopTableView &H, std::vector<double> &amp, int *width, uint16_t **d_tgt, uint8_t **d_val)
+{
+    const int64_t N = H.n;
+    int w = 0;
+    for (int64_t i = 0; i < N; ++i) w = std::max(w, H.ptr[i + 1] - H.ptr[i]);
+    w = std::max(8, ((w + 7) / 8) * 8);
+    std::vector<uint16_t> tgt((size_t)w * N);
+    std::vector<uint8_t> val((size_t)w * N, 0);               // code 0 = amplitude 0.0
+    for (int k = 0; k < w; ++k)
+        for (int64_t i = 0; i < N; ++i) tgt[(size_t)k * N + i] = (uint16_t)i;
+    for (int64_t i = 0; i < N; ++i)
+        for (int q = H.ptr[i]; q < H.ptr[i + 1]; ++q) {
+            int code = -1;
+            for (size_t c = 0; c < amp.size(); ++c)
+                if (amp[c] == H.val[q]) code = (int)c;
+            if (code < 0) {
+                if (amp.size() == 16) {
+                    qbh::set_error("qbh_mf_hubbard: more than 15 distinct hopping amplitudes");
+                    return QBH_EUNSUPP;
+                }
+                amp.push_back(H.val[q]);
+                code = (int)amp.size() - 1;
+            }
+            tgt[(size_t)(q - H.ptr[i]) * N + i] = (uint16_t)H.tgt[q];
+            val[(size_t)(q - H.ptr[i]) * N + i] = (uint8_t)code;
+        }
+    *width = w;
+    QBH_HIP(hipMalloc(d_tgt, tgt.size() * sizeof(uint16_t)));
+    QBH_HIP(hipMalloc(d_val, val.size()));
+    QBH_HIP(hipMemcpy(*d_tgt, tgt.data(), tgt.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    QBH_HIP(hipMemcpy(*d_val, val.data(), val.size(), hipMemcpyHostToDevice));
+    return QBH_OK;
+}
+}  // namespace
+
+extern "C" int qbh_mf_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_bonds, const int32_t *bonds, double t,
+                              double U, int64_t row_begin, int64_t row_end, const qbh_opts *opts)
+{
+    using namespace qbh;
+    if (!out || !bonds || n_sites <= 0 || n_sites > 31 || n_up < 0 || n_dn < 0 || n_up > n_sites || n_dn > n_sites ||
+        n_bonds <= 0) {
+        set_error("qbh_mf_hubbard: invalid lattice / filling");
+        return QBH_EINVAL;
+    }
+    if (qbh_device_count() <= 0) {
+        set_error("no HIP device visible");
+        return QBH_ENODEVICE;
+    }
+    if (opts && opts->device >= 0) QBH_HIP(hipSetDevice(opts->device));
+    std::map<std::pair<int, int>, double> bmap;
+    QBH_TRY(merge_bonds(n_sites, n_bonds, bonds, bmap));
+    HopTable hu, hd;
+    build_hops(n_sites, n_up, bmap, t, hu);
+    build_hops(n_sites, n_dn, bmap, t, hd);
+    const int64_t Nu = (int64_t)hu.cfg.size(), Nd = (int64_t)hd.cfg.size(), dim = Nu * Nd;
+    if (row_end < 0) row_end = dim;
+    if (row_begin < 0 || row_begin >= row_end || row_end > dim) {
+        set_error("qbh_mf_hubbard: bad row range");
+        return QBH_EINVAL;
+    }
+    // nnz of the equivalent CSR shard (closed form, as in qbh_gen_hubbard)
+    std::vector<int64_t> pre_d((size_t)Nd + 1, 0), base_u((size_t)Nu + 1, 0);
+    for (int64_t d = 0; d < Nd; ++d) pre_d[d + 1] = pre_d[d] + (hd.ptr[d + 1] - hd.ptr[d]);
+    for (int64_t u = 0; u < Nu; ++u) base_u[u + 1] = base_u[u] + Nd * (1 + (hu.ptr[u + 1] - hu.ptr[u])) + pre_d[Nd];
+    auto rowptr = [&](int64_t row) -> int64_t {
+        if (row >= dim) return base_u[Nu];
+        const int64_t u = row / Nd, d = row - u * Nd;
+        return base_u[u] + d * (1 + (hu.ptr[u + 1] - hu.ptr[u])) + pre_d[d];
+    };
+    MfHubbard m;
+    m.Nu = Nu;
+    m.Nd = Nd;
+    m.U = U;
+    QBH_HIP(hipMalloc(&m.cfg_u, (size_t)Nu * sizeof(uint32_t)));
+    QBH_HIP(hipMalloc(&m.cfg_d, (size_t)Nd * sizeof(uint32_t)));
+    QBH_HIP(hipMemcpy(m.cfg_u, hu.cfg.data(), (size_t)Nu * sizeof(uint32_t), hipMemcpyHostToDevice));
+    QBH_HIP(hipMemcpy(m.cfg_d, hd.cfg.data(), (size_t)Nd * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HopTableView vu{Nu, hu.ptr.data(), hu.tgt.data(), hu.val.data()}, vd{Nd, hd.ptr.data(), hd.tgt.data(), hd.val.data()};
+    if (Nu > 65535 || Nd > 65535) {
+        set_error("qbh_mf_hubbard: more than 65535 configurations per species");
+        return QBH_EUNSUPP;
+    }
+    std::vector<double> amp(1, 0.0);
+    QBH_TRY(upload_ell(vu, amp, &m.wu, &m.tgt_u, &m.val_u));
+    QBH_TRY(upload_ell(vd, amp, &m.wd, &m.tgt_d, &m.val_d));
+    for (size_t c = 0; c < amp.size(); ++c) m.amp[c] = amp[c];
+    return adopt_mf_hubbard(out, m, row_end - row_begin, dim, row_begin, rowptr(row_end) - rowptr(row_begin), opts);
 }
 
 extern "C" int qbh_gen_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bonds, const int32_t *bonds, double J,

@@ -97,6 +97,38 @@ int tridiag_eigen_lastrow(int64_t m, const double *a, const double *b1, double *
 
 }  // namespace qbh
 
+namespace qbh {
+// matrix-free two-species (Hubbard) operator: H = T_up (x) 1 + 1 (x) T_dn + U * (double occupancy), applied from the
+// two small hop tables instead of a stored CSR (counterpart of the matrix-free model<T>::MultMv2, src/model.cc:941-1109)
+struct MfHubbard {
+    int64_t Nu = 0, Nd = 0;
+    int     wu = 0, wd = 0;          // padded hops per configuration (ELL width)
+    double  U = 0.0;
+    uint32_t *cfg_u = nullptr, *cfg_d = nullptr;
+    // ELL tables, entry k of configuration c at [k*N + c]; padding = (c itself, amplitude 0).  Kept small so that they
+    // stay L2-resident next to the x window: targets as uint16 (N <= 65535 configurations per species), amplitudes as
+    // 1-byte codes into amp[] (<= 16 distinct hopping amplitudes: +-t times the bond multiplicity, and 0)
+    uint16_t *tgt_u = nullptr, *tgt_d = nullptr;
+    uint8_t  *val_u = nullptr, *val_d = nullptr;
+    double    amp[16] = {0};
+};
+
+struct MfArgs {
+    MfHubbard t;
+    int64_t row_begin, nrows;
+    const d2 *xg, *xl;
+    const double *xr;
+    d2 *y;
+    double alpha, beta, gamma;
+    double *partials;
+};
+int launch_mf_hubbard(const MfArgs &a, int grid, hipStream_t s);
+// adopt a matrix-free operator (tables already in HBM) behind a qbh_csr handle (qbh_api.cpp)
+int adopt_mf_hubbard(qbh_csr **out, const MfHubbard &t, int64_t nrows, int64_t ncols, int64_t row_offset,
+                     int64_t nnz_equiv, const qbh_opts *opts);
+
+}  // namespace qbh
+
 // second part of a split row shard: the entries whose column is NOT owned by this shard
 struct CsrPart {
     int64_t  nnz = 0;
@@ -142,6 +174,10 @@ struct qbh_csr {
     double  *h_scal = nullptr;       // pinned mirror
     qbh::d2 *d_stage_x = nullptr, *d_stage_y = nullptr;   // host-vector seam staging
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // matrix-free operator (kind 1) instead of CSR arrays (kind 0)
+    int      kind = 0;
+    qbh::MfHubbard mf;
 
     // split shard: the arrays above hold the locally-owned columns, `rem` the remote ones
     bool     has_rem = false;

@@ -1416,4 +1416,108 @@ int launch_imag_norm(const d2 *x, int64_t n, double *partials, hipStream_t s)
     return QBH_OK;
 }
 
+
+// -------------------------------------------- matrix-free two-species operator --
+// y <- alpha*(H x) + beta*y + gamma*x_local with H = T_up (x) 1 + 1 (x) T_dn + U*D applied from the hop tables
+// (ELL layout, coalesced).  One lane per row (u, d); 256 consecutive rows per workgroup pass.  The up-species
+// hops of consecutive rows read consecutive x elements (full-line coalesced), the down-species hops stay inside
+// the 16*N_dn-byte window of the row's own u.  Same fused epilogue and partial sums as the CSR kernels.
+template <bool REALX>
+__global__ __launch_bounds__(kBlock) void k_mf_hubbard(MfArgs a)
+{
+    __shared__ double red[12];
+    __shared__ double amp_s[16];
+    double acc[3] = {0.0, 0.0, 0.0};
+    const MfHubbard &t = a.t;
+    if (threadIdx.x < 16) amp_s[threadIdx.x] = t.amp[threadIdx.x];
+    __syncthreads();
+    const int64_t n_chunks = (a.nrows + kBlock - 1) / kBlock;
+    const bool need_x = a.gamma != 0.0 || a.partials != nullptr;
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const int64_t lrow = chunk * kBlock + threadIdx.x;
+        if (lrow < a.nrows) {
+            const int64_t grow = a.row_begin + lrow;
+            const int64_t u = grow / t.Nd, d = grow - u * t.Nd;
+            d2 sum = {0.0, 0.0};
+            // diagonal: U * number of doubly occupied sites
+            const double diag = t.U * (double)__popc(t.cfg_u[u] & t.cfg_d[d]);
+            if (REALX) sum.x = diag * a.xr[grow];
+            else       sum = diag * a.xg[grow];
+            // The tables are padded to a multiple of 8 hops with (target = the configuration itself, amplitude 0),
+            // so each group of 8 table reads and 8 gathers is issued without a branch (8 loads in flight per lane).
+            // up-species hops: x[u' * Nd + d], consecutive lanes -> consecutive addresses
+            for (int k0 = 0; k0 < t.wu; k0 += 8) {
+                int64_t c[8];
+                double v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    c[j] = (int64_t)t.tgt_u[(size_t)(k0 + j) * t.Nu + u] * t.Nd + d;
+                    v[j] = amp_s[t.val_u[(size_t)(k0 + j) * t.Nu + u]];
+                }
+                if (REALX) {
+                    double xr[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xr[j] = a.xr[c[j]];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sum.x += v[j] * xr[j];
+                } else {
+                    d2 xv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[j] = a.xg[c[j]];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sum += v[j] * xv[j];
+                }
+            }
+            // down-species hops: x[u * Nd + d'] inside the row's own window
+            const int64_t base = u * t.Nd;
+            for (int k0 = 0; k0 < t.wd; k0 += 8) {
+                int64_t c[8];
+                double v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    c[j] = base + t.tgt_d[(size_t)(k0 + j) * t.Nd + d];
+                    v[j] = amp_s[t.val_d[(size_t)(k0 + j) * t.Nd + d]];
+                }
+                if (REALX) {
+                    double xr[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xr[j] = a.xr[c[j]];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sum.x += v[j] * xr[j];
+                } else {
+                    d2 xv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[j] = a.xg[c[j]];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sum += v[j] * xv[j];
+                }
+            }
+            d2 yo = {0.0, 0.0}, xi = {0.0, 0.0};
+            if (a.beta != 0.0) yo = a.y[lrow];
+            if (need_x) xi = a.xl[lrow];
+            const d2 yn = a.alpha * sum + a.beta * yo + a.gamma * xi;
+            a.y[lrow] = yn;
+            acc[0] += xi.x * yn.x + xi.y * yn.y;
+            acc[1] += xi.x * yn.y - xi.y * yn.x;
+            acc[2] += yn.x * yn.x + yn.y * yn.y;
+        }
+    }
+    if (a.partials != nullptr) {
+        block_sum<3>(acc, red);
+        if (threadIdx.x == 0) {
+            a.partials[(size_t)blockIdx.x * 3 + 0] = acc[0];
+            a.partials[(size_t)blockIdx.x * 3 + 1] = acc[1];
+            a.partials[(size_t)blockIdx.x * 3 + 2] = acc[2];
+        }
+    }
+}
+
+int launch_mf_hubbard(const MfArgs &a, int grid, hipStream_t s)
+{
+    if (a.xr != nullptr) hipLaunchKernelGGL((k_mf_hubbard<true>), dim3(grid), dim3(kBlock), 0, s, a);
+    else                 hipLaunchKernelGGL((k_mf_hubbard<false>), dim3(grid), dim3(kBlock), 0, s, a);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
 }  // namespace qbh

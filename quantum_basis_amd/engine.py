@@ -119,14 +119,17 @@ class csr_mat:
 
     # ---- generators (measurement harness) ------------------------------------------------
     @classmethod
-    def hubbard(cls, n_sites, n_up, n_dn, bonds, t=1.0, U=1.1, rows=None, opts=None):
+    def hubbard(cls, n_sites, n_up, n_dn, bonds, t=1.0, U=1.1, rows=None, opts=None, matrix_free=False):
+        """Device-built Fermi-Hubbard operator: CSR in HBM (default) or, with matrix_free=True, applied from
+        the hop tables without a stored matrix (qbh_mf_hubbard)."""
         _lib.require_gpu()
         opts = opts if opts is not None else make_opts()
         b = np.ascontiguousarray(np.asarray(bonds, dtype=np.int32).reshape(-1, 2))
         r0, r1 = (0, -1) if rows is None else rows
         h = C.c_void_p()
-        check(lib().qbh_gen_hubbard(C.byref(h), n_sites, n_up, n_dn, len(b), _p(b), t, U, C.c_int64(r0),
-                                    C.c_int64(r1), C.byref(opts)), "qbh_gen_hubbard")
+        fn = lib().qbh_mf_hubbard if matrix_free else lib().qbh_gen_hubbard
+        check(fn(C.byref(h), n_sites, n_up, n_dn, len(b), _p(b), t, U, C.c_int64(r0),
+                 C.c_int64(r1), C.byref(opts)), "qbh_mf_hubbard" if matrix_free else "qbh_gen_hubbard")
         return cls(0, None, None, None, opts=opts, _handle=h)
 
     @classmethod

@@ -156,3 +156,21 @@ def test_full_size_ground_state_eigenvector(ops):
     diff = np.sqrt(coded.axpy_norm(-1.0, v.at(n), v.at(2 * n)))
     assert diff < 1e-12 * abs(res.E0)
     v.free()
+
+
+def test_full_size_matrix_free_equals_csr(ops):
+    coded, _ = ops
+    n = DIM
+    M = q.csr_mat.hubbard(16, 8, 8, lattices.square(4, 4), t=1.0, U=1.1, matrix_free=True)
+    assert M.dim == n and M.nnz == coded.nnz and M.info().bytes_matrix < 16 * 2 ** 20
+    v = coded.vec(3)
+    coded.randomize(v.at(0), 5)
+    coded.spmv(v.at(0), v.at(n), 1.0, 0.0, 0.0)
+    coded.sync()
+    M.spmv(v.at(0), v.at(2 * n), 1.0, 0.0, 0.0)
+    M.sync()
+    hx = coded.nrm2(v.at(n))
+    diff = np.sqrt(coded.axpy_norm(-1.0, v.at(n), v.at(2 * n)))
+    assert diff <= 1e-13 * hx
+    v.free()
+    M.destroy()

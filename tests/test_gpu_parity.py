@@ -468,3 +468,40 @@ def test_measure_full_dynamic_and_log_writer(tmp_path):
     assert len(lines) == 3 * len(rows) and lines[0].split()[0] == "#(1)" and lines[1].split()[0] == "Iter(k)"
     first = lines[2].split()
     assert int(first[0]) == 4 and abs(float(first[1]) - rows[0]["ritz"][0]) < 1e-8 * abs(rows[0]["ritz"][0])
+
+
+@pytest.mark.parametrize("geom", [(8, 4, 4, "4x2", 1.0, 1.1), (9, 4, 3, "3x3", 0.7, 4.0), (12, 6, 6, "4x3", 1.0, 1.1)])
+def test_matrix_free_hubbard_equals_csr(geom):
+    """qbh_mf_hubbard: the operator applied from the hop tables is the CSR operator."""
+    L, nu, nd, shape, t, U = geom
+    bonds = {"4x2": lattices.square(4, 2), "3x3": lattices.square(3, 3), "4x3": lattices.square(4, 3)}[shape]
+    A = q.csr_mat.hubbard(L, nu, nd, bonds, t=t, U=U)
+    M = q.csr_mat.hubbard(L, nu, nd, bonds, t=t, U=U, matrix_free=True)
+    assert M.dim == A.dim and M.nnz == A.nnz and M.info().kernel == _lib.KERNEL_MATRIX_FREE
+    n = A.dim
+    x, y0 = _rand(n, 51), _rand(n, 52)
+    va, vm = A.vec(2), M.vec(2)
+    for alpha, beta, gamma in [(1.0, 0.0, 0.0), (1.0, 1.0, 0.0), (0.6, -1.2, 0.0), (1.0, 0.0, -3.0)]:
+        for v in (va, vm):
+            v.upload(x, 0)
+            v.upload(y0, n)
+        da, na = A.spmv(va.at(0), va.at(n), alpha, beta, gamma, want_red=True)
+        dm, nm = M.spmv(vm.at(0), vm.at(n), alpha, beta, gamma, want_red=True)
+        assert _close(vm.download(n, n), va.download(n, n))
+        assert abs(da - dm) <= 1e-12 * max(abs(da), 1.0) and abs(na - nm) <= 1e-12 * na
+    # host-vector seam, Lanczos (real fast path), IRAM
+    y = np.empty(n, dtype=np.complex128)
+    M.MultMv(x, y)
+    ya = np.empty(n, dtype=np.complex128)
+    A.MultMv(x, ya)
+    assert _close(y, ya)
+    ra, rm = q.locate_E0_lanczos(A, nev=1, ncv=1), q.locate_E0_lanczos(M, nev=1, ncv=1)
+    assert abs(ra.E0 - rm.E0) <= 1e-11 * abs(ra.E0) and abs(ra.steps["E0"] - rm.steps["E0"]) <= 1
+    assert abs(abs(np.vdot(ra.eigenvecs, rm.eigenvecs)) - 1.0) < 1e-8
+    assert M.stats().n_spmv_real > 0
+    nconv, w, _ = q.iram(n, M, None, 2, 8, 300, "sr")
+    assert abs(w[0] - ra.E0) < 1e-9
+    with pytest.raises(_lib.QbhError):
+        M.download()
+    if shape == "4x2":
+        assert abs(rm.E0 - helpers.known()["hubbard_4x2"]["E0"]) < 1e-8
