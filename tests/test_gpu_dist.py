@@ -28,12 +28,12 @@ def _single_rank_reference():
     return q.locate_E0_lanczos(A, nev=2, ncv=1, maxit=400)
 
 
-@pytest.mark.parametrize("world,backend", [(2, "gloo"), (3, "gloo"), (1, "nccl")])
-def test_sharded_solver_matches_single_gpu(world, backend):
+@pytest.mark.parametrize("world,backend,mf", [(2, "gloo", False), (3, "gloo", False), (1, "nccl", False), (2, "gloo", True)])
+def test_sharded_solver_matches_single_gpu(world, backend, mf):
     import torch.multiprocessing as mp
     import dist_worker
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(dist_worker.gpu_sharded_solver, args=(world, _free_port(), backend, tmp), nprocs=world, join=True)
+        mp.spawn(dist_worker.gpu_sharded_solver, args=(world, _free_port(), backend, tmp, mf), nprocs=world, join=True)
         res = np.load(tmp + "/res.npy")
         hess = np.load(tmp + "/hess.npy")
         x = np.concatenate([np.load(tmp + "/x_%d.npy" % r) for r in range(world)])
