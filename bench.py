@@ -34,6 +34,8 @@ def workloads():
         "hubbard_4x4_half": dict(kind="hubbard", n_sites=16, n_up=8, n_dn=8, bonds=lattices.square(4, 4), t=1.0, U=1.1),
         # SURVEY 8(d) C4 substitute (4x5, N_up = N_dn = 5; half filling is 3.4e10-dim)
         "hubbard_4x5_n5": dict(kind="hubbard", n_sites=20, n_up=5, n_dn=5, bonds=lattices.square(4, 5), t=1.0, U=1.1),
+        # beyond what a stored CSR can hold on one GPU (nnz ~ 6e10): matrix-free only (--matrix-free)
+        "hubbard_4x5_n6": dict(kind="hubbard", n_sites=20, n_up=6, n_dn=6, bonds=lattices.square(4, 5), t=1.0, U=1.1),
         "hubbard_4x3_half": dict(kind="hubbard", n_sites=12, n_up=6, n_dn=6, bonds=lattices.square(4, 3), t=1.0, U=1.1),
         "hubbard_4x2_half": dict(kind="hubbard", n_sites=8, n_up=4, n_dn=4, bonds=lattices.square(4, 2), t=1.0, U=1.1),
         # BASELINE.json configs[1] / C2
@@ -50,10 +52,11 @@ def dim_of(w):
     return comb(w["n_sites"], w["n_dn"])
 
 
-def build_operator(w, rows, opts):
+def build_operator(w, rows, opts, matrix_free=False):
     import quantum_basis_amd as q
     if w["kind"] == "hubbard":
-        return q.csr_mat.hubbard(w["n_sites"], w["n_up"], w["n_dn"], w["bonds"], t=w["t"], U=w["U"], rows=rows, opts=opts)
+        return q.csr_mat.hubbard(w["n_sites"], w["n_up"], w["n_dn"], w["bonds"], t=w["t"], U=w["U"], rows=rows, opts=opts,
+                                 matrix_free=matrix_free)
     return q.csr_mat.heisenberg(w["n_sites"], w["n_dn"], w["bonds"], J=w["J"], rows=rows, opts=opts)
 
 
@@ -133,6 +136,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed run to convergence (E0)")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)
+    ap.add_argument("--matrix-free", action="store_true", help="use the matrix-free Hubbard operator as THE operator (not the CSR north-star path)")
     ap.add_argument("--no-matrix-free", action="store_true", help="skip the extra measurement of the matrix-free Hubbard operator")
     ap.add_argument("--no-plain", action="store_true", help="skip the extra (untimed-region) measurement of the uncoded complex128 kernel")
     args = ap.parse_args()
@@ -173,7 +177,7 @@ def main():
                            nnz_per_block=args.npb, xcd_swizzle=args.swizzle,
                            value_dict=args.value_dict, profile=1)
         t_gen = time.time()
-        A = build_operator(W, (r0, r1), opts)
+        A = build_operator(W, (r0, r1), opts, matrix_free=args.matrix_free)
         torch.cuda.synchronize()
         t_gen = time.time() - t_gen
         if world > 1:
@@ -249,7 +253,7 @@ def main():
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        key = "%s|%s|%s" % (args.workload, {1: "stream", 2: "vector", 3: "rows"}[info.kernel], "dict" if info.value_dict else "plain")
+        key = "%s|%s|%s" % (args.workload, {1: "stream", 2: "vector", 3: "rows", 4: "matrix_free"}[info.kernel], "dict" if info.value_dict else "plain")
         if st.n_spmv_real > 0:
             key += "|real"
         if world == 1 and key in tj:
@@ -262,10 +266,10 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "complex128 (f64)",
         "data": "synthetic", "config": {"workload": args.workload, "dim": dim, "nnz_full": nnz_total,
                                          "rows_per_gpu": info.nrows, "parallelism": "row-shard x%d" % world,
-                                         "kernel": {1: "stream", 2: "vector", 3: "rows"}[info.kernel], "value_dict": info.value_dict,
+                                         "kernel": {1: "stream", 2: "vector", 3: "rows", 4: "matrix_free"}[info.kernel], "value_dict": info.value_dict,
                                          "real_gather": bool(st.n_spmv_real > 0),
                                          "build_s": round(t_gen, 3)},
-        "roofline": {"bound": "hbm", "kernel": {1: "k_spmv_stream", 2: "k_spmv_vector", 3: "k_spmv_rows"}[info.kernel],
+        "roofline": {"bound": "hbm", "kernel": {1: "k_spmv_stream", 2: "k_spmv_vector", 3: "k_spmv_rows", 4: "k_mf_hubbard"}[info.kernel],
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                      "bytes_per_launch": bytes_launch, "ms_per_launch": round(ms_spmv, 4), "launches": int(st.n_spmv),
@@ -274,6 +278,11 @@ def main():
                              "real operator and real vectors, x is gathered as 8-byte real parts (bit-identical result)"},
         "e0": e0, "lanczos_steps_to_converge": steps_e0,
     }
+    if args.matrix_free:
+        out["config"]["kernel"] = "matrix_free"
+        out["roofline"]["kernel"] = "k_mf_hubbard"
+        out["roofline"]["note"] = ("MATRIX-FREE operator (qbh_mf_hubbard, SURVEY 8f-1): no CSR is stored; achieved = bytes the CSR of the "
+                                   "same operator would move per SpMV / kernel time -- not the north-star CSR measurement")
     if world == 1 and info.value_dict and not args.no_plain:
         # transparency: the same SpMV with the value stream left as complex128 (16 B/nnz), measured after the
         # timed region on a second copy of the operator (it needs the full 20 B/nnz in HBM)
@@ -296,7 +305,7 @@ def main():
                 P.destroy()
         except Exception as e:
             out["roofline_plain_values"] = {"error": repr(e)}
-    if world == 1 and W["kind"] == "hubbard" and not args.no_matrix_free:
+    if world == 1 and W["kind"] == "hubbard" and not args.no_matrix_free and not args.matrix_free:
         # SURVEY 8f-1 (next row, NOT the north-star CSR path): the same operator applied from the hop tables without a
         # stored matrix, same solver code; measured after the timed region, same step definition
         try:
