@@ -283,6 +283,17 @@ int qbh_mf_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_bonds,
 int qbh_gen_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bonds,
                        const int32_t *bonds, double J,
                        int64_t row_begin, int64_t row_end, const qbh_opts *opts);
+/* Translation-symmetric sector of the same Heisenberg model, assembled on the device: counterpart of
+ * model::generate_Ham_sparse_repr (src/model.cc:687-836).  The translation group is given explicitly: perms[g*n_sites
+ * + s] = image of site s under translation g (g = 0 the identity, <= 64 translations), chars[2g], chars[2g+1] =
+ * Re, Im of the momentum character chi_k(g) = exp(-i k.t_g).  Basis: ALL orbit representatives of the n_dn sector,
+ * ascending; zero-norm representatives stay as decoupled rows with the fake diagonal fake_pos + i/dim (the
+ * reference's convention, src/model.cc:735-740, default fake_pos 100).  Values are genuinely complex:
+ * H[a][b] = sum h * conj(chi(g*)) * sqrt(|S_b|/|S_a|) (phase * sqrt(nu_i/nu_j) of src/model.cc:808-814).
+ * *dim_out (may be NULL) receives the sector dimension. */
+int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int n_bonds, const int32_t *bonds, double J,
+                            int n_trans, const int32_t *perms, const double *chars, double fake_pos,
+                            int64_t *dim_out, const qbh_opts *opts);
 /* Copy the assembled shard back to host arrays (tests, CPU-baseline sample).  Any output
  * pointer may be NULL.  Rows [r0, r1) local to the shard; ia is rebased to 0. */
 int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1,

@@ -81,7 +81,7 @@ EXPORTS = [
     "qbh_spmv_dev", "qbh_dotc_dev", "qbh_axpy_norm_dev", "qbh_scal_dev", "qbh_nrm2_dev",
     "qbh_lanczos", "qbh_lanczos_dev", "qbh_eigenvec_cg", "qbh_eigenvec_cg_dev", "qbh_hess_eigen", "qbh_iram",
     "qbh_csr_set_comm", "qbh_get_stats", "qbh_sync",
-    "qbh_gen_hubbard", "qbh_mf_hubbard", "qbh_gen_heisenberg", "qbh_csr_download",
+    "qbh_gen_hubbard", "qbh_mf_hubbard", "qbh_gen_heisenberg", "qbh_gen_heisenberg_repr", "qbh_csr_download",
 ]
 
 _lib = None
@@ -148,6 +148,8 @@ def lib():
     L.qbh_mf_hubbard.argtypes = L.qbh_gen_hubbard.argtypes
     L.qbh_gen_heisenberg.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp, dbl, i64, i64,
                                      C.POINTER(Opts)]
+    L.qbh_gen_heisenberg_repr.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp, dbl, C.c_int, vp, vp, dbl,
+                                          C.POINTER(i64), C.POINTER(Opts)]
     L.qbh_csr_download.argtypes = [vp, i64, i64, vp, vp, vp]
     _lib = L
     return L

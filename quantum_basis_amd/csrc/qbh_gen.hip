@@ -575,3 +575,374 @@ extern "C" int qbh_gen_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bo
     }
     return rc;
 }
+
+// ------------------------------------------------- translation-symmetric sectors --
+// Device counterpart of model::generate_Ham_sparse_repr (src/model.cc:687-836) for spin-1/2 Heisenberg models:
+// the Hamiltonian in the basis of momentum states built on orbit representatives.  The reference reaches the
+// representative of a hopped state through its sublattice (Weisse) tables; here every state is canonicalised
+// directly -- all |G| translations are applied with byte-sliced lookup tables and the smallest image wins.
+//   basis      ALL orbit representatives of the fixed-n_dn sector, ascending bit pattern; a representative whose
+//              norm vanishes at this momentum stays in the basis as a decoupled row with the fake diagonal
+//              fake_pos + i/dim (src/model.cc:735-740)
+//   H[a][b]    sum over bond terms taking |a> to c = l.b of h * conj(chi(g*)) * sqrt(|S_b|/|S_a|), g* c = b
+//              (the phase exp(2 pi i k.d/L) * sqrt(nu_i/nu_j) of src/model.cc:808-814)
+namespace qbh {
+namespace {
+
+constexpr int kReprMaxTrans = 64;
+constexpr int kReprMaxRow = 160;          // distinct columns in one row (unique bonds + diagonal)
+
+struct ReprDev {
+    HeisDev h;                            // binomials, bonds, amplitudes
+    int n_trans, n_chunks;
+    double chr[2 * kReprMaxTrans];        // characters chi(g)
+    double fake_pos;
+};
+
+// image of bit pattern s under translation g; tab[(g*n_chunks + c)*64 + v] = scattered bits of chunk c with value v
+__device__ __forceinline__ uint64_t repr_translate(const uint64_t *tab, int n_chunks, int g, uint64_t s)
+{
+    uint64_t out = 0;
+    const uint64_t *t = tab + (size_t)g * n_chunks * 64;
+    for (int c = 0; c < n_chunks; ++c) out |= t[c * 64 + ((s >> (6 * c)) & 63ULL)];
+    return out;
+}
+
+// smallest image and the translation that produces it
+__device__ __forceinline__ uint64_t repr_canonical(const ReprDev &R, const uint64_t *tab, uint64_t s, int *gstar)
+{
+    uint64_t best = s;
+    int gb = 0;                           // g = 0 is the identity
+    for (int g = 1; g < R.n_trans; ++g) {
+        const uint64_t t = repr_translate(tab, R.n_chunks, g, s);
+        if (t < best) {
+            best = t;
+            gb = g;
+        }
+    }
+    *gstar = gb;
+    return best;
+}
+
+// pass 1: code[r] = 0 if state r (colex rank in the n_dn sector) is not a representative, else |S| | (zero-norm << 7)
+__global__ __launch_bounds__(256) void k_repr_flag(const ReprDev *Rp, const uint64_t *tab, int64_t nstates, uint8_t *code,
+                                                   int32_t *cnt)
+{
+    const ReprDev &R = *Rp;
+    constexpr int RUN = 32;               // consecutive ranks per lane: one unrank, then next-combination steps
+    const int64_t nruns = (nstates + RUN - 1) / RUN;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t run = (int64_t)blockIdx.x * 256 + threadIdx.x; run < nruns; run += stride) {
+        const int64_t r0 = run * RUN, r1 = (r0 + RUN < nstates) ? r0 + RUN : nstates;
+        uint64_t s = heis_unrank(R.h, (uint64_t)r0);
+        for (int64_t r = r0; r < r1; ++r) {
+            uint8_t c = 0;
+            bool rep = true;
+            int nstab = 1;
+            double sr = R.chr[0], si = R.chr[1];
+            for (int g = 1; g < R.n_trans; ++g) {
+                const uint64_t t = repr_translate(tab, R.n_chunks, g, s);
+                if (t < s) {
+                    rep = false;
+                    break;
+                }
+                if (t == s) {
+                    nstab++;
+                    sr += R.chr[2 * g];
+                    si += R.chr[2 * g + 1];
+                }
+            }
+            if (rep) c = (uint8_t)(nstab | ((sr * sr + si * si < 1e-20) ? 0x80 : 0));
+            code[r] = c;
+            cnt[r] = rep ? 1 : 0;
+            // next bit pattern with the same popcount (Gosper)
+            const uint64_t t2 = s | (s - 1ULL);
+            s = (t2 + 1ULL) | (((~t2 & (t2 + 1ULL)) - 1ULL) >> (__ffsll((long long)s)));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_repr_compact(const ReprDev *Rp, int64_t nstates, const uint8_t *code, const int64_t *pos,
+                                                      uint64_t *reps, uint8_t *info)
+{
+    const ReprDev &R = *Rp;
+    constexpr int RUN = 32;
+    const int64_t nruns = (nstates + RUN - 1) / RUN;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t run = (int64_t)blockIdx.x * 256 + threadIdx.x; run < nruns; run += stride) {
+        const int64_t r0 = run * RUN, r1 = (r0 + RUN < nstates) ? r0 + RUN : nstates;
+        uint64_t s = heis_unrank(R.h, (uint64_t)r0);
+        for (int64_t r = r0; r < r1; ++r) {
+            if (code[r]) {
+                reps[pos[r]] = s;
+                info[pos[r]] = code[r];
+            }
+            const uint64_t t2 = s | (s - 1ULL);
+            s = (t2 + 1ULL) | (((~t2 & (t2 + 1ULL)) - 1ULL) >> (__ffsll((long long)s)));
+        }
+    }
+}
+
+// one row of the sector Hamiltonian into (cols, vals), columns ascending, duplicates merged; returns its length
+__device__ int repr_row(const ReprDev &R, const uint64_t *tab, const uint64_t *reps, const uint8_t *info, int64_t dim, int64_t i,
+                        int32_t *cols, d2 *vals)
+{
+    const uint8_t ci = info[i];
+    if (ci & 0x80) {                      // zero norm at this momentum: decoupled row, fake diagonal
+        cols[0] = (int32_t)i;
+        vals[0] = d2{R.fake_pos + (double)i / (double)dim, 0.0};
+        return 1;
+    }
+    const double si = (double)(ci & 0x7f);
+    const uint64_t a = reps[i];
+    int n = 1;
+    cols[0] = (int32_t)i;
+    d2 dg = {0.0, 0.0};
+    for (int bnd = 0; bnd < R.h.n_bonds; ++bnd) {
+        const int x = R.h.sa[bnd], y = R.h.sb[bnd];
+        if (((a >> x) ^ (a >> y)) & 1ULL) {
+            dg.x -= R.h.diag[bnd];
+            const uint64_t c = a ^ (1ULL << x) ^ (1ULL << y);
+            int g = 0;
+            const uint64_t b = repr_canonical(R, tab, c, &g);
+            int64_t lo = 0, hi = dim;     // index of b in the ascending representative list
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (reps[mid] < b) lo = mid + 1;
+                else hi = mid;
+            }
+            const uint8_t cj = info[lo];
+            if (cj & 0x80) continue;      // zero-norm target: dropped (src/model.cc:806)
+            const double f = R.h.offd[bnd] * sqrt((double)(cj & 0x7f) / si);
+            const d2 v = {f * R.chr[2 * g], -f * R.chr[2 * g + 1]};          // h * conj(chi(g*)) * sqrt(|S_b|/|S_a|)
+            if (lo == i) {
+                dg += v;
+                continue;
+            }
+            int q = 1;
+            while (q < n && cols[q] != (int32_t)lo) ++q;
+            if (q < n) {
+                vals[q] += v;
+            } else if (n < kReprMaxRow) {
+                cols[n] = (int32_t)lo;
+                vals[n] = v;
+                ++n;
+            }
+        } else {
+            dg.x += R.h.diag[bnd];
+        }
+    }
+    vals[0] = dg;
+    // drop cancelled off-diagonal entries (lil_mat::add, src/sparse.cc:72-77), then sort by column
+    int m = 1;
+    for (int q = 1; q < n; ++q)
+        if (vals[q].x * vals[q].x + vals[q].y * vals[q].y >= 1e-28) {
+            cols[m] = cols[q];
+            vals[m] = vals[q];
+            ++m;
+        }
+    for (int q = 1; q < m; ++q) {         // insertion sort (rows are short)
+        const int32_t c = cols[q];
+        const d2 v = vals[q];
+        int p = q - 1;
+        while (p >= 0 && cols[p] > c) {
+            cols[p + 1] = cols[p];
+            vals[p + 1] = vals[p];
+            --p;
+        }
+        cols[p + 1] = c;
+        vals[p + 1] = v;
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(128) void k_repr_count(const ReprDev *Rp, const uint64_t *tab, const uint64_t *reps, const uint8_t *info,
+                                                    int64_t dim, int32_t *cnt)
+{
+    int32_t cols[kReprMaxRow];
+    d2 vals[kReprMaxRow];
+    const int64_t stride = (int64_t)gridDim.x * 128;
+    for (int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x; i < dim; i += stride)
+        cnt[i] = repr_row(*Rp, tab, reps, info, dim, i, cols, vals);
+}
+
+__global__ __launch_bounds__(128) void k_repr_fill(const ReprDev *Rp, const uint64_t *tab, const uint64_t *reps, const uint8_t *info,
+                                                   int64_t dim, const int64_t *ia, int32_t *ja, d2 *val)
+{
+    int32_t cols[kReprMaxRow];
+    d2 vals[kReprMaxRow];
+    const int64_t stride = (int64_t)gridDim.x * 128;
+    for (int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x; i < dim; i += stride) {
+        const int m = repr_row(*Rp, tab, reps, info, dim, i, cols, vals);
+        const int64_t p0 = ia[i];
+        for (int q = 0; q < m; ++q) {
+            ja[p0 + q] = cols[q];
+            val[p0 + q] = vals[q];
+        }
+    }
+}
+
+}  // namespace
+}  // namespace qbh
+
+extern "C" int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int n_bonds, const int32_t *bonds, double J,
+                                       int n_trans, const int32_t *perms, const double *chars, double fake_pos,
+                                       int64_t *dim_out, const qbh_opts *opts)
+{
+    using namespace qbh;
+    if (!out || !bonds || !perms || !chars || n_sites <= 0 || n_sites > 62 || n_dn < 0 || n_dn > n_sites || n_dn > 33 ||
+        n_bonds <= 0 || n_trans < 1 || n_trans > kReprMaxTrans) {
+        set_error("qbh_gen_heisenberg_repr: invalid argument (<= 62 sites, <= 64 translations)");
+        return QBH_EINVAL;
+    }
+    if (qbh_device_count() <= 0) {
+        set_error("no HIP device visible");
+        return QBH_ENODEVICE;
+    }
+    if (opts && opts->device >= 0) QBH_HIP(hipSetDevice(opts->device));
+    for (int i = 0; i < n_sites; ++i)
+        if (perms[i] != i) {
+            set_error("qbh_gen_heisenberg_repr: translation 0 must be the identity");
+            return QBH_EINVAL;
+        }
+    std::map<std::pair<int, int>, double> bmap;
+    QBH_TRY(merge_bonds(n_sites, n_bonds, bonds, bmap));
+    if ((int)bmap.size() + 1 > kReprMaxRow || (int)bmap.size() > kMaxBonds) {
+        set_error("qbh_gen_heisenberg_repr: too many distinct bonds");
+        return QBH_EUNSUPP;
+    }
+    std::vector<ReprDev> rr(1);
+    ReprDev &R = rr[0];
+    memset(&R, 0, sizeof(R));
+    for (int p = 0; p <= 64; ++p)
+        for (int k = 0; k <= 33; ++k) R.h.binom[p][k] = binom_u64(p, k);
+    R.h.n_sites = n_sites;
+    R.h.n_dn = n_dn;
+    for (const auto &bw : bmap) {
+        R.h.sa[R.h.n_bonds] = bw.first.first;
+        R.h.sb[R.h.n_bonds] = bw.first.second;
+        R.h.offd[R.h.n_bonds] = 0.5 * J * bw.second;
+        R.h.diag[R.h.n_bonds] = 0.25 * J * bw.second;
+        R.h.n_bonds++;
+    }
+    R.n_trans = n_trans;
+    R.n_chunks = (n_sites + 5) / 6;
+    R.fake_pos = fake_pos;
+    for (int g = 0; g < n_trans; ++g) {
+        R.chr[2 * g] = chars[2 * g];
+        R.chr[2 * g + 1] = chars[2 * g + 1];
+    }
+    std::vector<uint64_t> tab((size_t)n_trans * R.n_chunks * 64, 0ULL);
+    for (int g = 0; g < n_trans; ++g)
+        for (int c = 0; c < R.n_chunks; ++c)
+            for (int v = 0; v < 64; ++v) {
+                uint64_t m = 0;
+                for (int b = 0; b < 6; ++b) {
+                    const int site = 6 * c + b;
+                    if (site < n_sites && ((v >> b) & 1)) {
+                        const int img = perms[(size_t)g * n_sites + site];
+                        if (img < 0 || img >= n_sites) {
+                            set_error("qbh_gen_heisenberg_repr: translation %d is not a site permutation", g);
+                            return QBH_EINVAL;
+                        }
+                        m |= 1ULL << img;
+                    }
+                }
+                tab[((size_t)g * R.n_chunks + c) * 64 + v] = m;
+            }
+    const uint64_t nstates_u = binom_u64(n_sites, n_dn);
+    if (nstates_u >= (1ULL << 40)) {
+        set_error("qbh_gen_heisenberg_repr: sector too large to enumerate");
+        return QBH_EUNSUPP;
+    }
+    const int64_t nstates = (int64_t)nstates_u;
+
+    std::vector<void *> pool;
+    ReprDev *d_R = nullptr;
+    uint64_t *d_tab = nullptr;
+    QBH_TRY(upload(rr, &d_R, pool));
+    QBH_TRY(upload(tab, &d_tab, pool));
+    uint8_t *d_code = nullptr, *d_info = nullptr;
+    int32_t *d_cnt = nullptr;
+    int64_t *d_pos = nullptr, *d_ia = nullptr;
+    uint64_t *d_reps = nullptr;
+    int32_t *d_ja = nullptr;
+    d2 *d_val = nullptr;
+    int rc = QBH_OK;
+    int64_t dim = 0, nnz = 0;
+    auto cleanup = [&](bool all) {
+        free_pool(pool);
+        if (d_code) (void)hipFree(d_code);
+        if (d_cnt) (void)hipFree(d_cnt);
+        if (d_pos) (void)hipFree(d_pos);
+        if (d_reps) (void)hipFree(d_reps);
+        if (d_info) (void)hipFree(d_info);
+        if (all) {
+            if (d_ia) (void)hipFree(d_ia);
+            if (d_ja) (void)hipFree(d_ja);
+            if (d_val) (void)hipFree(d_val);
+        }
+    };
+#define QBH_R(call)                                                                            \
+    do {                                                                                       \
+        hipError_t _e = (call);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            set_error("qbh_gen_heisenberg_repr: %s failed: %s", #call, hipGetErrorString(_e)); \
+            cleanup(true);                                                                     \
+            return _e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP;                          \
+        }                                                                                      \
+    } while (0)
+    // 1. which states are representatives; their stabiliser order and norm
+    QBH_R(hipMalloc(&d_code, (size_t)nstates));
+    QBH_R(hipMalloc(&d_cnt, (size_t)nstates * sizeof(int32_t)));
+    QBH_R(hipMalloc(&d_pos, (size_t)(nstates + 1) * sizeof(int64_t)));
+    hipLaunchKernelGGL(k_repr_flag, dim3(blas_grid((nstates + 31) / 32)), dim3(256), 0, 0, d_R, d_tab, nstates, d_code, d_cnt);
+    QBH_R(hipGetLastError());
+    rc = exclusive_scan(d_cnt, nstates, d_pos, 0);
+    if (rc != QBH_OK) {
+        cleanup(true);
+        return rc;
+    }
+    QBH_R(hipMemcpy(&dim, d_pos + nstates, sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (dim <= 0 || dim >= 2147483647LL) {
+        set_error("qbh_gen_heisenberg_repr: sector dimension %lld out of range", (long long)dim);
+        cleanup(true);
+        return QBH_EUNSUPP;
+    }
+    QBH_R(hipMalloc(&d_reps, (size_t)dim * sizeof(uint64_t)));
+    QBH_R(hipMalloc(&d_info, (size_t)dim));
+    hipLaunchKernelGGL(k_repr_compact, dim3(blas_grid((nstates + 31) / 32)), dim3(256), 0, 0, d_R, nstates, d_code, d_pos, d_reps,
+                       d_info);
+    QBH_R(hipGetLastError());
+    QBH_R(hipDeviceSynchronize());
+    (void)hipFree(d_code); d_code = nullptr;
+    (void)hipFree(d_cnt); d_cnt = nullptr;
+    (void)hipFree(d_pos); d_pos = nullptr;
+    // 2. row lengths -> row pointers -> fill
+    QBH_R(hipMalloc(&d_cnt, (size_t)dim * sizeof(int32_t)));
+    QBH_R(hipMalloc(&d_ia, (size_t)(dim + 1) * sizeof(int64_t)));
+    const int rgrid = (int)std::min<int64_t>((dim + 127) / 128, 256 * 16);
+    hipLaunchKernelGGL(k_repr_count, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, d_cnt);
+    QBH_R(hipGetLastError());
+    rc = exclusive_scan(d_cnt, dim, d_ia, 0);
+    if (rc != QBH_OK) {
+        cleanup(true);
+        return rc;
+    }
+    QBH_R(hipMemcpy(&nnz, d_ia + dim, sizeof(int64_t), hipMemcpyDeviceToHost));
+    QBH_R(hipMalloc(&d_ja, (size_t)nnz * sizeof(int32_t)));
+    QBH_R(hipMalloc(&d_val, (size_t)nnz * sizeof(d2)));
+    hipLaunchKernelGGL(k_repr_fill, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, d_ia, d_ja, d_val);
+    QBH_R(hipGetLastError());
+    QBH_R(hipDeviceSynchronize());
+#undef QBH_R
+    cleanup(false);
+    if (dim_out) *dim_out = dim;
+    rc = qbh_csr_create_device(out, dim, dim, 0, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, opts);
+    if (rc != QBH_OK) {
+        (void)hipFree(d_ia);
+        (void)hipFree(d_ja);
+        (void)hipFree(d_val);
+    }
+    return rc;
+}

@@ -56,3 +56,29 @@ def kagome(Lx, Ly):
             b.append((i2, site(m - 1, n - 1, 1)))
             b.append((i2, i1))
     return b
+
+
+def translations(Lx, Ly=1, n_sub=1, site=None):
+    """All Lx*Ly translations of a periodic cluster as site permutations (first = identity) and their shifts.
+    `site(x, y, sub)` is the numbering used for the bonds (default sub + n_sub*(x + Lx*y))."""
+    if site is None:
+        def site(x, y, s):
+            return s + n_sub * (x + Lx * y)
+    perms, shifts = [], []
+    for tx in range(Lx):
+        for ty in range(Ly):
+            p = [0] * (Lx * Ly * n_sub)
+            for x in range(Lx):
+                for y in range(Ly):
+                    for s in range(n_sub):
+                        p[site(x, y, s)] = site((x + tx) % Lx, (y + ty) % Ly, s)
+            perms.append(p)
+            shifts.append((tx, ty))
+    return perms, shifts
+
+
+def characters(shifts, k, L):
+    """Momentum characters chi_k(g) = exp(-2 pi i sum_d k_d t_d / L_d) for momentum indices k on an L = (Lx, Ly) cluster."""
+    import cmath
+    import math
+    return [cmath.exp(-2j * math.pi * sum(kd * td / Ld for kd, td, Ld in zip(k, t, L))) for t in shifts]

@@ -505,3 +505,51 @@ def test_matrix_free_hubbard_equals_csr(geom):
         M.download()
     if shape == "4x2":
         assert abs(rm.E0 - helpers.known()["hubbard_4x2"]["E0"]) < 1e-8
+
+
+@pytest.mark.parametrize("case", ["chain16_k3", "chain16_k0", "tri4x4_k01", "tri4x4_k00", "tri4x4_k12", "kagome12_k10"])
+def test_device_repr_generator_matches_numpy_and_reference_answers(case):
+    """qbh_gen_heisenberg_repr (counterpart of generate_Ham_sparse_repr) against an independent numpy assembly in
+    the same convention (entry by entry), the reference's per-momentum known answers and the survey's structural
+    pins (dim 822, zero-norm representatives 0 / 22 / 6, nnz_upper)."""
+    import reprham
+    if case.startswith("chain16"):
+        L, k = 16, int(case[-1])
+        n, ndn, bonds = 16, 8, lattices.chain(16)
+        perms, shifts = lattices.translations(16)
+        chars = lattices.characters(shifts, (k, 0), (16, 1))
+        want = helpers.known()["chain16_momentum"]["E0_k"][k]
+        pins = None
+    elif case.startswith("tri4x4"):
+        k = (int(case[-2]), int(case[-1]))
+        n, ndn, bonds = 16, 8, lattices.triangular(4, 4)
+        perms, shifts = lattices.translations(4, 4)
+        chars = lattices.characters(shifts, k, (4, 4))
+        want = {(0, 0): -8.555514918, (0, 1): -8.002263841, (1, 2): -7.588987242}[k]   # examples/trans_symmetric/latt_triangular/...:135-139
+        pins = {(0, 0): (822, 0, 10986), (0, 1): (822, 22, 10738), (1, 2): (822, 22, None)}[k]   # SURVEY.md Appendix B
+    else:
+        n, ndn, bonds = 12, 6, lattices.kagome(2, 2)
+        perms, shifts = lattices.translations(2, 2, n_sub=3, site=lambda x, y, s: s + 3 * (y + 2 * x))
+        chars = lattices.characters(shifts, (1, 0), (2, 2))
+        want, pins = None, None
+    H, reps, stab, zero = reprham.repr_heisenberg_csr(n, ndn, bonds, np.array(perms), np.array(chars))
+    A = q.csr_mat.heisenberg_repr(n, ndn, bonds, perms, chars)
+    ia, ja, val = A.download()
+    assert A.dim == H.shape[0] and A.nnz == H.nnz
+    assert np.array_equal(ia, H.indptr) and np.array_equal(ja, H.indices)
+    assert np.abs(val - H.data).max() < 1e-14
+    if pins:
+        assert A.dim == pins[0] and int(zero.sum()) == pins[1]
+        if pins[2]:
+            assert (A.nnz + A.dim) // 2 == pins[2]
+    dense = np.linalg.eigvalsh(H.toarray())
+    res = q.locate_E0_lanczos(A, nev=1, ncv=1)
+    assert abs(res.E0 - dense[0]) < 1e-9
+    if want is not None:
+        assert abs(res.E0 - want) < 1e-8
+    if case in ("chain16_k3", "tri4x4_k01", "tri4x4_k12"):
+        assert np.abs(val.imag).max() > 0.05                     # genuinely complex sector
+    v = res.eigenvecs
+    assert np.linalg.norm(H @ v - res.E0 * v) < 1e-8
+    nconv, w, _ = q.iram(A.dim, A, None, 2, 8, 300, "sr")
+    assert np.allclose(w, dense[:2], atol=1e-9)
