@@ -42,6 +42,16 @@ def workloads():
         "kagome_30": dict(kind="heisenberg", n_sites=30, n_dn=15, bonds=lattices.kagome(5, 2), J=1.0),
         "kagome_24": dict(kind="heisenberg", n_sites=24, n_dn=12, bonds=lattices.kagome(4, 2), J=1.0),
         "chain_22": dict(kind="heisenberg", n_sites=22, n_dn=11, bonds=lattices.chain(22), J=1.0),
+        # BASELINE.json configs[4] family: triangular 6x6, translation-symmetric sector k = (1,0), complex phases.
+        # Sz = 0 (n_dn = 18, dim ~2.5e8, 285 GB of complex128 CSR) is the 8-GPU case; these fit one GPU.
+        "triangular_6x6_k10_n12": dict(kind="heisenberg_repr", n_sites=36, n_dn=12, bonds=lattices.triangular(6, 6), J=1.0,
+                                       trans=(6, 6), k=(1, 0)),
+        "triangular_6x6_k10_sz0": dict(kind="heisenberg_repr", n_sites=36, n_dn=18, bonds=lattices.triangular(6, 6), J=1.0,
+                                       trans=(6, 6), k=(1, 0)),
+        "triangular_6x6_k10_n15": dict(kind="heisenberg_repr", n_sites=36, n_dn=15, bonds=lattices.triangular(6, 6), J=1.0,
+                                       trans=(6, 6), k=(1, 0)),
+        "triangular_4x4_k01": dict(kind="heisenberg_repr", n_sites=16, n_dn=8, bonds=lattices.triangular(4, 4), J=1.0,
+                                   trans=(4, 4), k=(0, 1)),
     }
 
 
@@ -49,14 +59,21 @@ def dim_of(w):
     from math import comb
     if w["kind"] == "hubbard":
         return comb(w["n_sites"], w["n_up"]) * comb(w["n_sites"], w["n_dn"])
+    if w["kind"] == "heisenberg_repr":
+        return None                      # known only after the representatives have been enumerated
     return comb(w["n_sites"], w["n_dn"])
 
 
-def build_operator(w, rows, opts, matrix_free=False):
+def build_operator(w, rows, opts, matrix_free=False, shard=(0, 1)):
     import quantum_basis_amd as q
     if w["kind"] == "hubbard":
         return q.csr_mat.hubbard(w["n_sites"], w["n_up"], w["n_dn"], w["bonds"], t=w["t"], U=w["U"], rows=rows, opts=opts,
                                  matrix_free=matrix_free)
+    if w["kind"] == "heisenberg_repr":
+        from quantum_basis_amd import lattices
+        perms, shifts = lattices.translations(*w["trans"])
+        return q.csr_mat.heisenberg_repr(w["n_sites"], w["n_dn"], w["bonds"], perms, lattices.characters(shifts, w["k"], w["trans"]),
+                                         J=w["J"], shard=shard, opts=opts)
     return q.csr_mat.heisenberg(w["n_sites"], w["n_dn"], w["bonds"], J=w["J"], rows=rows, opts=opts)
 
 
@@ -169,20 +186,26 @@ def main():
 
     W = workloads()[args.workload]
     dim = dim_of(W)
-    nblk, ranges = qdist.row_partition(dim, world)
-    r0, r1 = ranges[rank]
+    if dim is None:
+        r0, r1 = 0, -1                   # the generator shards by (rank, world) itself
+    else:
+        nblk, ranges = qdist.row_partition(dim, world)
+        r0, r1 = ranges[rank]
     stream = torch.cuda.Stream(device=device)
     with torch.cuda.stream(stream):
         opts = q.make_opts(device=local_rank, stream=stream.cuda_stream, spmv_kernel=args.kernel,
                            nnz_per_block=args.npb, xcd_swizzle=args.swizzle,
                            value_dict=args.value_dict, profile=1)
         t_gen = time.time()
-        A = build_operator(W, (r0, r1), opts, matrix_free=args.matrix_free)
+        A = build_operator(W, (r0, r1), opts, matrix_free=args.matrix_free, shard=(rank, world))
         torch.cuda.synchronize()
         t_gen = time.time() - t_gen
+        info = A.info()
+        if dim is None:
+            dim = int(info.ncols)
         if world > 1:
             comm = qdist.ShardComm(dim, rank=rank, world=world, device=device, stream=stream).attach(A)
-        info = A.info()
+
         def allreduce_host(vals, op):
             t = torch.tensor(vals, dtype=torch.float64, device=device if backend == "nccl" else "cpu")
             if world > 1:
@@ -288,7 +311,7 @@ def main():
         # timed region on a second copy of the operator (it needs the full 20 B/nnz in HBM)
         try:
             with torch.cuda.stream(stream):
-                P = build_operator(W, (r0, r1), q.make_opts(device=local_rank, stream=stream.cuda_stream,
+                P = build_operator(W, (r0, r1), shard=(rank, world), opts=q.make_opts(device=local_rank, stream=stream.cuda_stream,
                                                              value_dict=0, xcd_swizzle=args.swizzle, profile=1))
                 pv = P.vec(2)
                 P.randomize(pv.at(0), 1)

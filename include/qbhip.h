@@ -290,10 +290,15 @@ int qbh_gen_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bonds,
  * ascending; zero-norm representatives stay as decoupled rows with the fake diagonal fake_pos + i/dim (the
  * reference's convention, src/model.cc:735-740, default fake_pos 100).  Values are genuinely complex:
  * H[a][b] = sum h * conj(chi(g*)) * sqrt(|S_b|/|S_a|) (phase * sqrt(nu_i/nu_j) of src/model.cc:808-814).
- * *dim_out (may be NULL) receives the sector dimension. */
+ * The sector dimension is only known after the representatives have been enumerated, so a row shard is named by
+ * (shard, n_shards): rows [shard*nblk, min(dim, (shard+1)*nblk)), nblk = ceil(dim / n_shards) -- the partition of
+ * qbh_comm; (0, 1) = the whole sector.  *dim_out (may be NULL) receives the sector dimension.
+ * When opts->value_dict is on and the sector holds at most 256 distinct values, the value stream is emitted
+ * directly as 1-byte codes: the 16 B/nnz complex128 array is never materialised, which is what lets the 36-site
+ * Sz = 0 sector (nnz 1.4e10) live on one GPU. */
 int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int n_bonds, const int32_t *bonds, double J,
                             int n_trans, const int32_t *perms, const double *chars, double fake_pos,
-                            int64_t *dim_out, const qbh_opts *opts);
+                            int shard, int n_shards, int64_t *dim_out, const qbh_opts *opts);
 /* Copy the assembled shard back to host arrays (tests, CPU-baseline sample).  Any output
  * pointer may be NULL.  Rows [r0, r1) local to the shard; ia is rebased to 0. */
 int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1,

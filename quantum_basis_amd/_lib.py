@@ -149,7 +149,7 @@ def lib():
     L.qbh_gen_heisenberg.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp, dbl, i64, i64,
                                      C.POINTER(Opts)]
     L.qbh_gen_heisenberg_repr.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp, dbl, C.c_int, vp, vp, dbl,
-                                          C.POINTER(i64), C.POINTER(Opts)]
+                                          C.c_int, C.c_int, C.POINTER(i64), C.POINTER(Opts)]
     L.qbh_csr_download.argtypes = [vp, i64, i64, vp, vp, vp]
     _lib = L
     return L

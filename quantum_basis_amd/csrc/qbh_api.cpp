@@ -562,6 +562,38 @@ extern "C" int qbh_csr_create_device(qbh_csr **out, int64_t nrows, int64_t ncols
     return QBH_OK;
 }
 
+int qbh::adopt_coded_csr(qbh_csr **out, int64_t nrows, int64_t ncols, int64_t row_offset, int64_t nnz, int64_t *d_ia,
+                         int32_t *d_ja, uint8_t *d_code, qbh::d2 *d_dict, int n_dict, const qbh_opts *opts)
+{
+    if (!out || !d_ia || !d_ja || !d_code || !d_dict || n_dict <= 0 || n_dict > 256 || nrows <= 0 || nnz < 0 ||
+        row_offset < 0 || row_offset + nrows > ncols || ncols >= (int64_t)std::numeric_limits<int32_t>::max()) {
+        qbh::set_error("adopt_coded_csr: invalid argument");
+        return QBH_EINVAL;
+    }
+    qbh_csr *A = nullptr;
+    QBH_TRY(new_handle(&A, opts));
+    A->nrows = nrows;
+    A->ncols = ncols;
+    A->row_offset = row_offset;
+    A->nnz = nnz;
+    A->d_ia = d_ia;
+    A->d_ja = d_ja;
+    A->d_code = d_code;
+    A->d_dict = d_dict;
+    A->n_dict = n_dict;
+    A->own_arrays = true;
+    int rc = finalize(A);
+    if (rc != QBH_OK) {
+        A->own_arrays = false;   // the caller keeps the arrays on failure
+        A->d_code = nullptr;
+        A->d_dict = nullptr;
+        qbh_csr_destroy(A);
+        return rc;
+    }
+    *out = A;
+    return QBH_OK;
+}
+
 int qbh::adopt_mf_hubbard(qbh_csr **out, const qbh::MfHubbard &t, int64_t nrows, int64_t ncols, int64_t row_offset,
                           int64_t nnz_equiv, const qbh_opts *opts)
 {

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "qbh_internal.hpp"
+#include "qbh_dict.hpp"
 
 namespace qbh {
 namespace {
@@ -756,28 +757,59 @@ __device__ int repr_row(const ReprDev &R, const uint64_t *tab, const uint64_t *r
     return m;
 }
 
+// row lengths of rows [r0, r1); with gf != nullptr the distinct values met on the way are collected for the value
+// dictionary, so that the fill pass can emit 1-byte codes and the 16 B/nnz value array never exists
 __global__ __launch_bounds__(128) void k_repr_count(const ReprDev *Rp, const uint64_t *tab, const uint64_t *reps, const uint8_t *info,
-                                                    int64_t dim, int32_t *cnt)
+                                                    int64_t dim, int64_t r0, int64_t r1, int32_t *cnt, unsigned long long *gf, d2 *gv,
+                                                    int *flags)
 {
+    __shared__ DictCollect D;
     int32_t cols[kReprMaxRow];
     d2 vals[kReprMaxRow];
+    const bool collect = gf != nullptr;
+    if (collect) dict_collect_init(D);
     const int64_t stride = (int64_t)gridDim.x * 128;
-    for (int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x; i < dim; i += stride)
-        cnt[i] = repr_row(*Rp, tab, reps, info, dim, i, cols, vals);
+    for (int64_t i = r0 + (int64_t)blockIdx.x * 128 + threadIdx.x; i < r1; i += stride) {
+        const int m = repr_row(*Rp, tab, reps, info, dim, i, cols, vals);
+        cnt[i - r0] = m;
+        if (collect && dict_collect_ok(D))
+            for (int q = 0; q < m; ++q) dict_collect_insert(D, vals[q], flags);
+    }
+    if (collect) dict_collect_flush(D, gf, gv, flags);
 }
 
+// ia is local to the shard (ia[0] = 0 at row r0)
 __global__ __launch_bounds__(128) void k_repr_fill(const ReprDev *Rp, const uint64_t *tab, const uint64_t *reps, const uint8_t *info,
-                                                   int64_t dim, const int64_t *ia, int32_t *ja, d2 *val)
+                                                   int64_t dim, int64_t r0, int64_t r1, const int64_t *ia, int32_t *ja, d2 *val)
 {
     int32_t cols[kReprMaxRow];
     d2 vals[kReprMaxRow];
     const int64_t stride = (int64_t)gridDim.x * 128;
-    for (int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x; i < dim; i += stride) {
+    for (int64_t i = r0 + (int64_t)blockIdx.x * 128 + threadIdx.x; i < r1; i += stride) {
         const int m = repr_row(*Rp, tab, reps, info, dim, i, cols, vals);
-        const int64_t p0 = ia[i];
+        const int64_t p0 = ia[i - r0];
         for (int q = 0; q < m; ++q) {
             ja[p0 + q] = cols[q];
             val[p0 + q] = vals[q];
+        }
+    }
+}
+
+__global__ __launch_bounds__(128) void k_repr_fill_coded(const ReprDev *Rp, const uint64_t *tab, const uint64_t *reps,
+                                                         const uint8_t *info, int64_t dim, int64_t r0, int64_t r1, const int64_t *ia,
+                                                         int32_t *ja, uint8_t *code, const d2 *dict, int n_dict, int *flags)
+{
+    __shared__ DictEncode E;
+    int32_t cols[kReprMaxRow];
+    d2 vals[kReprMaxRow];
+    dict_encode_init(E, dict, n_dict);
+    const int64_t stride = (int64_t)gridDim.x * 128;
+    for (int64_t i = r0 + (int64_t)blockIdx.x * 128 + threadIdx.x; i < r1; i += stride) {
+        const int m = repr_row(*Rp, tab, reps, info, dim, i, cols, vals);
+        const int64_t p0 = ia[i - r0];
+        for (int q = 0; q < m; ++q) {
+            ja[p0 + q] = cols[q];
+            code[p0 + q] = dict_encode_one(E, vals[q], flags);
         }
     }
 }
@@ -787,11 +819,11 @@ __global__ __launch_bounds__(128) void k_repr_fill(const ReprDev *Rp, const uint
 
 extern "C" int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int n_bonds, const int32_t *bonds, double J,
                                        int n_trans, const int32_t *perms, const double *chars, double fake_pos,
-                                       int64_t *dim_out, const qbh_opts *opts)
+                                       int shard, int n_shards, int64_t *dim_out, const qbh_opts *opts)
 {
     using namespace qbh;
     if (!out || !bonds || !perms || !chars || n_sites <= 0 || n_sites > 62 || n_dn < 0 || n_dn > n_sites || n_dn > 33 ||
-        n_bonds <= 0 || n_trans < 1 || n_trans > kReprMaxTrans) {
+        n_bonds <= 0 || n_trans < 1 || n_trans > kReprMaxTrans || n_shards < 1 || shard < 0 || shard >= n_shards) {
         set_error("qbh_gen_heisenberg_repr: invalid argument (<= 62 sites, <= 64 translations)");
         return QBH_EINVAL;
     }
@@ -867,12 +899,14 @@ extern "C" int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int
     int64_t *d_pos = nullptr, *d_ia = nullptr;
     uint64_t *d_reps = nullptr;
     int32_t *d_ja = nullptr;
-    d2 *d_val = nullptr;
+    d2 *d_val = nullptr, *d_dict = nullptr;
+    DictBuild db;
     int rc = QBH_OK;
     int64_t dim = 0, nnz = 0;
     auto cleanup = [&](bool all) {
         free_pool(pool);
-        if (d_code) (void)hipFree(d_code);
+        dict_build_end(&db);
+        if (all && d_code) (void)hipFree(d_code);
         if (d_cnt) (void)hipFree(d_cnt);
         if (d_pos) (void)hipFree(d_pos);
         if (d_reps) (void)hipFree(d_reps);
@@ -881,6 +915,7 @@ extern "C" int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int
             if (d_ia) (void)hipFree(d_ia);
             if (d_ja) (void)hipFree(d_ja);
             if (d_val) (void)hipFree(d_val);
+            if (d_dict) (void)hipFree(d_dict);
         }
     };
 #define QBH_R(call)                                                                            \
@@ -918,31 +953,88 @@ extern "C" int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int
     (void)hipFree(d_code); d_code = nullptr;
     (void)hipFree(d_cnt); d_cnt = nullptr;
     (void)hipFree(d_pos); d_pos = nullptr;
-    // 2. row lengths -> row pointers -> fill
-    QBH_R(hipMalloc(&d_cnt, (size_t)dim * sizeof(int32_t)));
-    QBH_R(hipMalloc(&d_ia, (size_t)(dim + 1) * sizeof(int64_t)));
-    const int rgrid = (int)std::min<int64_t>((dim + 127) / 128, 256 * 16);
-    hipLaunchKernelGGL(k_repr_count, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, d_cnt);
+    // 2. this shard's rows: lengths (+ the distinct values) -> row pointers -> fill
+    const int64_t nblk = (dim + n_shards - 1) / n_shards;          // same uniform partition as the communicator's
+    const int64_t r0 = std::min<int64_t>((int64_t)shard * nblk, dim), r1 = std::min<int64_t>(r0 + nblk, dim);
+    const int64_t nloc = r1 - r0;
+    if (nloc <= 0) {
+        set_error("qbh_gen_heisenberg_repr: shard %d of %d is empty (dim %lld)", shard, n_shards, (long long)dim);
+        cleanup(true);
+        return QBH_EINVAL;
+    }
+    const bool want_dict = !opts || opts->value_dict;
+    if (want_dict) {
+        rc = dict_build_begin(&db, 0);
+        if (rc != QBH_OK) {
+            cleanup(true);
+            return rc;
+        }
+    }
+    QBH_R(hipMalloc(&d_cnt, (size_t)nloc * sizeof(int32_t)));
+    QBH_R(hipMalloc(&d_ia, (size_t)(nloc + 1) * sizeof(int64_t)));
+    const int rgrid = (int)std::min<int64_t>((nloc + 127) / 128, 256 * 16);
+    hipLaunchKernelGGL(k_repr_count, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_cnt, db.gf, db.gv,
+                       db.flags);
     QBH_R(hipGetLastError());
-    rc = exclusive_scan(d_cnt, dim, d_ia, 0);
+    rc = exclusive_scan(d_cnt, nloc, d_ia, 0);
     if (rc != QBH_OK) {
         cleanup(true);
         return rc;
     }
-    QBH_R(hipMemcpy(&nnz, d_ia + dim, sizeof(int64_t), hipMemcpyDeviceToHost));
+    QBH_R(hipMemcpy(&nnz, d_ia + nloc, sizeof(int64_t), hipMemcpyDeviceToHost));
+    (void)hipFree(d_cnt); d_cnt = nullptr;
     QBH_R(hipMalloc(&d_ja, (size_t)nnz * sizeof(int32_t)));
-    QBH_R(hipMalloc(&d_val, (size_t)nnz * sizeof(d2)));
-    hipLaunchKernelGGL(k_repr_fill, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, d_ia, d_ja, d_val);
-    QBH_R(hipGetLastError());
+    int n_dict = 0;
+    if (want_dict) {
+        QBH_R(hipMalloc(&d_dict, 256 * sizeof(d2)));
+        rc = dict_build_finalize(&db, d_dict, &n_dict, 0);
+        if (rc != QBH_OK) {
+            cleanup(true);
+            return rc;
+        }
+    }
+    if (n_dict > 0) {
+        // at most 256 distinct values: emit codes directly (5 B/nnz instead of 20)
+        QBH_R(hipMalloc(&d_code, (size_t)nnz + 16));
+        QBH_R(hipMemset(d_code + nnz, 0, 16));
+        hipLaunchKernelGGL(k_repr_fill_coded, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_ia, d_ja,
+                           d_code, d_dict, n_dict, db.flags);
+        QBH_R(hipGetLastError());
+        int bad = 0;
+        rc = dict_build_mismatch(&db, &bad, 0);
+        if (rc == QBH_OK && bad) {
+            set_error("qbh_gen_heisenberg_repr: value dictionary mismatch between the count and fill passes");
+            rc = QBH_EHIP;
+        }
+        if (rc != QBH_OK) {
+            cleanup(true);
+            return rc;
+        }
+    } else {
+        if (d_dict) (void)hipFree(d_dict);
+        d_dict = nullptr;
+        hipError_t e = hipMalloc(&d_val, (size_t)nnz * sizeof(d2));
+        if (e != hipSuccess) {
+            set_error("qbh_gen_heisenberg_repr: %lld nonzeros with more than 256 distinct values do not fit this GPU "
+                      "uncoded (%.1f GB); shard the sector over more GPUs", (long long)nnz, 20e-9 * (double)nnz);
+            cleanup(true);
+            return QBH_ENOMEM;
+        }
+        hipLaunchKernelGGL(k_repr_fill, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_ia, d_ja, d_val);
+        QBH_R(hipGetLastError());
+    }
     QBH_R(hipDeviceSynchronize());
 #undef QBH_R
     cleanup(false);
     if (dim_out) *dim_out = dim;
-    rc = qbh_csr_create_device(out, dim, dim, 0, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, opts);
+    if (d_code) rc = adopt_coded_csr(out, nloc, dim, r0, nnz, d_ia, d_ja, d_code, d_dict, n_dict, opts);
+    else rc = qbh_csr_create_device(out, nloc, dim, r0, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, opts);
     if (rc != QBH_OK) {
         (void)hipFree(d_ia);
         (void)hipFree(d_ja);
-        (void)hipFree(d_val);
+        if (d_val) (void)hipFree(d_val);
+        if (d_code) (void)hipFree(d_code);
+        if (d_dict) (void)hipFree(d_dict);
     }
     return rc;
 }

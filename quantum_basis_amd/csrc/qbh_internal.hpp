@@ -126,6 +126,10 @@ int launch_mf_hubbard(const MfArgs &a, int grid, hipStream_t s);
 // adopt a matrix-free operator (tables already in HBM) behind a qbh_csr handle (qbh_api.cpp)
 int adopt_mf_hubbard(qbh_csr **out, const MfHubbard &t, int64_t nrows, int64_t ncols, int64_t row_offset,
                      int64_t nnz_equiv, const qbh_opts *opts);
+// adopt a CSR whose value stream was generated directly in dictionary-coded form (the handle owns every array;
+// d_code holds nnz + 16 bytes, d_dict 256 entries)
+int adopt_coded_csr(qbh_csr **out, int64_t nrows, int64_t ncols, int64_t row_offset, int64_t nnz, int64_t *d_ia,
+                    int32_t *d_ja, uint8_t *d_code, d2 *d_dict, int n_dict, const qbh_opts *opts);
 
 }  // namespace qbh
 

@@ -10,6 +10,7 @@
 // Replaces mkl_sparse_z_mv (src/sparse.cc:287) and the cblas_z* level-1 calls of the
 // Lanczos / CG loops (src/lanczos.cc:195-214, 296-337).
 #include "qbh_internal.hpp"
+#include "qbh_dict.hpp"
 
 namespace qbh {
 
@@ -719,67 +720,18 @@ int launch_max_rowlen(const int64_t *d_ia, int64_t nrows, int64_t *d_out, hipStr
 // amplitudes, exchange constants and a handful of diagonal sums), each value is replaced by
 // a 1-byte index into a dictionary that lives in LDS during SpMV.  The stream shrinks from
 // 20 to 5 bytes per nonzero; products are computed from the exact original doubles.
-constexpr int kDictLocal = 512;      // LDS hash slots per workgroup (power of two)
-constexpr int kDictGlobal = 1024;    // global hash slots
-
-__device__ __forceinline__ unsigned long long dict_fp(d2 v)
-{
-    unsigned long long a = (unsigned long long)__double_as_longlong(v.x);
-    unsigned long long b = (unsigned long long)__double_as_longlong(v.y);
-    unsigned long long x = a * 0x9E3779B97F4A7C15ULL ^ ((b << 31) | (b >> 33)) * 0xC2B2AE3D27D4EB4FULL;
-    x ^= x >> 29;
-    x *= 0xBF58476D1CE4E5B9ULL;
-    x ^= x >> 32;
-    return x ? x : 1ULL;
-}
-
-// flags: [0] overflow (>256 distinct), [1] global entries claimed, [2] final count, [3] verify mismatch
+// (device helpers: qbh_dict.hpp)
 __global__ __launch_bounds__(kBlock) void k_dict_collect(const d2 *val, int64_t nnz, unsigned long long *gf, d2 *gv,
                                                          int *flags)
 {
-    __shared__ unsigned long long lf[kDictLocal];
-    __shared__ d2 lv[kDictLocal];
-    __shared__ int lcount;
-    for (int i = threadIdx.x; i < kDictLocal; i += kBlock) lf[i] = 0ULL;
-    if (threadIdx.x == 0) lcount = 0;
-    __syncthreads();
+    __shared__ DictCollect D;
+    dict_collect_init(D);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += stride) {
-        const d2 v = val[i];
-        const unsigned long long f = dict_fp(v);
-        int s = (int)(f & (kDictLocal - 1));
-        for (int probe = 0; probe < kDictLocal; ++probe) {
-            const unsigned long long cur = ((volatile unsigned long long *)lf)[s];
-            if (cur == f) break;
-            if (cur == 0ULL) {
-                const unsigned long long old = atomicCAS(&lf[s], 0ULL, f);
-                if (old == 0ULL) {
-                    lv[s] = v;
-                    if (atomicAdd(&lcount, 1) >= 256) flags[0] = 1;
-                    break;
-                }
-                if (old == f) break;
-            }
-            s = (s + 1) & (kDictLocal - 1);
-        }
-        if (((volatile int *)&lcount)[0] > 256) break;
+        dict_collect_insert(D, val[i], flags);
+        if (!dict_collect_ok(D)) break;
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kDictLocal; i += kBlock) {
-        const unsigned long long f = lf[i];
-        if (f == 0ULL) continue;
-        int s = (int)(f & (kDictGlobal - 1));
-        for (int probe = 0; probe < kDictGlobal; ++probe) {
-            const unsigned long long old = atomicCAS(&gf[s], 0ULL, f);
-            if (old == 0ULL) {
-                gv[s] = lv[i];
-                if (atomicAdd(&flags[1], 1) >= 256) flags[0] = 1;
-                break;
-            }
-            if (old == f) break;
-            s = (s + 1) & (kDictGlobal - 1);
-        }
-    }
+    dict_collect_flush(D, gf, gv, flags);
 }
 
 // one thread: compact the global table, order entries by their bit patterns (so the codes do
@@ -813,48 +765,50 @@ __global__ void k_dict_finalize(const unsigned long long *gf, const d2 *gv, d2 *
 __global__ __launch_bounds__(kBlock) void k_dict_encode(const d2 *val, int64_t nnz, const d2 *dict, uint8_t *code,
                                                         int *flags)
 {
-    __shared__ unsigned long long lf[kDictLocal];
-    __shared__ int lc[kDictLocal];
-    __shared__ d2 ds[256];
-    const int n = flags[2];
-    for (int i = threadIdx.x; i < kDictLocal; i += kBlock) lf[i] = 0ULL;
-    ds[threadIdx.x] = dict[threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int c = 0; c < n; ++c) {
-            const unsigned long long f = dict_fp(ds[c]);
-            int s = (int)(f & (kDictLocal - 1));
-            while (lf[s] != 0ULL) s = (s + 1) & (kDictLocal - 1);
-            lf[s] = f;
-            lc[s] = c;
-        }
-    }
-    __syncthreads();
+    __shared__ DictEncode E;
+    dict_encode_init(E, dict, flags[2]);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += stride) {
-        const d2 v = val[i];
-        const unsigned long long f = dict_fp(v);
-        int s = (int)(f & (kDictLocal - 1));
-        int c = -1;
-        for (int probe = 0; probe < kDictLocal; ++probe) {
-            if (lf[s] == f) {
-                c = lc[s];
-                break;
-            }
-            if (lf[s] == 0ULL) break;
-            s = (s + 1) & (kDictLocal - 1);
-        }
-        bool ok = c >= 0;
-        if (ok) {
-            const d2 w = ds[c];
-            ok = __double_as_longlong(w.x) == __double_as_longlong(v.x) && __double_as_longlong(w.y) == __double_as_longlong(v.y);
-        }
-        if (!ok) {
-            flags[3] = 1;
-            c = 0;
-        }
-        code[i] = (uint8_t)c;
-    }
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += stride) code[i] = dict_encode_one(E, val[i], flags);
+}
+
+int dict_build_begin(DictBuild *b, hipStream_t s)
+{
+    QBH_HIP(hipMalloc(&b->gf, kDictGlobal * sizeof(unsigned long long)));
+    QBH_HIP(hipMalloc(&b->gv, kDictGlobal * sizeof(d2)));
+    QBH_HIP(hipMalloc(&b->flags, 4 * sizeof(int)));
+    QBH_HIP(hipMemsetAsync(b->gf, 0, kDictGlobal * sizeof(unsigned long long), s));
+    QBH_HIP(hipMemsetAsync(b->flags, 0, 4 * sizeof(int), s));
+    return QBH_OK;
+}
+
+int dict_build_finalize(DictBuild *b, d2 *d_dict, int *n_out, hipStream_t s)
+{
+    *n_out = 0;
+    hipLaunchKernelGGL(k_dict_finalize, dim3(1), dim3(64), 0, s, b->gf, b->gv, d_dict, b->flags);
+    int h[4] = {0, 0, 0, 0};
+    QBH_HIP(hipMemcpyAsync(h, b->flags, sizeof(h), hipMemcpyDeviceToHost, s));
+    QBH_HIP(hipStreamSynchronize(s));
+    if (!h[0] && h[2] > 0) *n_out = h[2];
+    return QBH_OK;
+}
+
+int dict_build_mismatch(DictBuild *b, int *bad, hipStream_t s)
+{
+    int h[4] = {0, 0, 0, 0};
+    QBH_HIP(hipMemcpyAsync(h, b->flags, sizeof(h), hipMemcpyDeviceToHost, s));
+    QBH_HIP(hipStreamSynchronize(s));
+    *bad = h[3];
+    return QBH_OK;
+}
+
+void dict_build_end(DictBuild *b)
+{
+    if (b->gf) (void)hipFree(b->gf);
+    if (b->gv) (void)hipFree(b->gv);
+    if (b->flags) (void)hipFree(b->flags);
+    b->gf = nullptr;
+    b->gv = nullptr;
+    b->flags = nullptr;
 }
 
 // returns n_dict (>0) in *n_out when the matrix was coded, 0 when it has too many distinct
@@ -862,30 +816,22 @@ __global__ __launch_bounds__(kBlock) void k_dict_encode(const d2 *val, int64_t n
 int build_value_dict(const d2 *d_val, int64_t nnz, uint8_t *d_code, d2 *d_dict, int *n_out, hipStream_t s)
 {
     *n_out = 0;
-    unsigned long long *gf = nullptr;
-    d2 *gv = nullptr;
-    int *flags = nullptr;
-    QBH_HIP(hipMalloc(&gf, kDictGlobal * sizeof(unsigned long long)));
-    QBH_HIP(hipMalloc(&gv, kDictGlobal * sizeof(d2)));
-    QBH_HIP(hipMalloc(&flags, 4 * sizeof(int)));
-    QBH_HIP(hipMemsetAsync(gf, 0, kDictGlobal * sizeof(unsigned long long), s));
-    QBH_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));
-    int grid = blas_grid(nnz);
-    hipLaunchKernelGGL(k_dict_collect, dim3(grid), dim3(kBlock), 0, s, d_val, nnz, gf, gv, flags);
-    hipLaunchKernelGGL(k_dict_finalize, dim3(1), dim3(64), 0, s, gf, gv, d_dict, flags);
-    int h[4] = {0, 0, 0, 0};
-    QBH_HIP(hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, s));
-    QBH_HIP(hipStreamSynchronize(s));
-    if (!h[0] && h[2] > 0) {
-        hipLaunchKernelGGL(k_dict_encode, dim3(grid), dim3(kBlock), 0, s, d_val, nnz, d_dict, d_code, flags);
-        QBH_HIP(hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, s));
-        QBH_HIP(hipStreamSynchronize(s));
-        if (!h[3]) *n_out = h[2];
+    DictBuild b;
+    int rc = dict_build_begin(&b, s);
+    if (rc == QBH_OK) {
+        const int grid = blas_grid(nnz);
+        hipLaunchKernelGGL(k_dict_collect, dim3(grid), dim3(kBlock), 0, s, d_val, nnz, b.gf, b.gv, b.flags);
+        int n = 0;
+        rc = dict_build_finalize(&b, d_dict, &n, s);
+        if (rc == QBH_OK && n > 0) {
+            hipLaunchKernelGGL(k_dict_encode, dim3(grid), dim3(kBlock), 0, s, d_val, nnz, d_dict, d_code, b.flags);
+            int bad = 0;
+            rc = dict_build_mismatch(&b, &bad, s);
+            if (rc == QBH_OK && !bad) *n_out = n;
+        }
     }
-    (void)hipFree(gf);
-    (void)hipFree(gv);
-    (void)hipFree(flags);
-    return QBH_OK;
+    dict_build_end(&b);
+    return rc;
 }
 
 // -------------------------------------------------------------- BLAS-1 ---------

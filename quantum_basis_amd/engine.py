@@ -144,10 +144,11 @@ class csr_mat:
         return cls(0, None, None, None, opts=opts, _handle=h)
 
     @classmethod
-    def heisenberg_repr(cls, n_sites, n_dn, bonds, perms, chars, J=1.0, fake_pos=100.0, opts=None):
+    def heisenberg_repr(cls, n_sites, n_dn, bonds, perms, chars, J=1.0, fake_pos=100.0, shard=(0, 1), opts=None):
         """Translation-symmetric sector assembled on the device (qbh_gen_heisenberg_repr, counterpart of
         model::generate_Ham_sparse_repr): perms[g] = site images under translation g (g = 0 identity), chars[g] =
-        momentum character chi_k(g)."""
+        momentum character chi_k(g).  shard = (rank, world) selects a uniform row block of the sector (its dimension
+        is only known after enumeration: read it from .info().ncols)."""
         _lib.require_gpu()
         opts = opts if opts is not None else make_opts()
         b = np.ascontiguousarray(np.asarray(bonds, dtype=np.int32).reshape(-1, 2))
@@ -157,7 +158,8 @@ class csr_mat:
         h = C.c_void_p()
         dim = C.c_int64(0)
         check(lib().qbh_gen_heisenberg_repr(C.byref(h), n_sites, n_dn, len(b), _p(b), J, len(c), _p(p), _p(c), fake_pos,
-                                            C.byref(dim), C.byref(opts)), "qbh_gen_heisenberg_repr")
+                                            int(shard[0]), int(shard[1]), C.byref(dim), C.byref(opts)),
+              "qbh_gen_heisenberg_repr")
         return cls(0, None, None, None, opts=opts, _handle=h)
 
     # ---- reference interface -------------------------------------------------------------

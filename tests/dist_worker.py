@@ -151,5 +151,34 @@ def gpu_sharded_complex(rank, world, port, backend, out_dir):
     dist.destroy_process_group()
 
 
+def gpu_sharded_repr(rank, world, port, backend, out_dir):
+    """Translation-symmetric sector generated shard by shard on the device (qbh_gen_heisenberg_repr with
+    (shard, n_shards) = (rank, world)): triangular 4x4, k = (0, 1), complex phases, 22 zero-norm rows."""
+    import torch
+    dist = _init(rank, world, port, backend)
+    torch.cuda.set_device(0)
+    import quantum_basis_amd as q
+    from quantum_basis_amd import dist as qdist, lattices
+
+    perms, shifts = lattices.translations(4, 4)
+    chars = lattices.characters(shifts, (0, 1), (4, 4))
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        opts = q.make_opts(device=0, stream=stream.cuda_stream)
+        A = q.csr_mat.heisenberg_repr(16, 8, lattices.triangular(4, 4), perms, chars, shard=(rank, world), opts=opts)
+        d = int(A.info().ncols)
+        assert A.info().row_offset == qdist.row_partition(d, world)[1][rank][0]
+        comm = qdist.ShardComm(d, rank=rank, world=world, device=dev, stream=stream).attach(A)
+        res = q.locate_E0_lanczos(A, nev=1, ncv=1, maxit=600)
+        assert not comm.errors, comm.errors
+        assert comm.n_packed == 0, comm.n_packed
+        np.save(os.path.join(out_dir, "vec_%d.npy" % rank), res.eigenvecs)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "res.npy"), np.array([res.E0, res.steps["E0"], res.steps["V0"], d]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     pass

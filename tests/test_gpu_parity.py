@@ -553,3 +553,23 @@ def test_device_repr_generator_matches_numpy_and_reference_answers(case):
     assert np.linalg.norm(H @ v - res.E0 * v) < 1e-8
     nconv, w, _ = q.iram(A.dim, A, None, 2, 8, 300, "sr")
     assert np.allclose(w, dense[:2], atol=1e-9)
+    # the directly-coded sector (codes emitted by the generator, no complex128 array) and the uncoded one hold
+    # the same bits; row shards named by (rank, world) tile the sector
+    coded = A.info().value_dict
+    B = q.csr_mat.heisenberg_repr(n, ndn, bonds, perms, chars, opts=q.make_opts(value_dict=0))
+    assert B.info().value_dict == 0
+    _, jb, vb = B.download()
+    assert np.array_equal(jb, ja) and np.array_equal(vb.view(np.uint64), val.view(np.uint64))
+    if case != "kagome12_k10":
+        assert 0 < coded <= 256
+    parts = [q.csr_mat.heisenberg_repr(n, ndn, bonds, perms, chars, shard=(r, 3)) for r in range(3)]
+    rows = 0
+    for r, P in enumerate(parts):
+        i = P.info()
+        assert i.ncols == A.dim and i.row_offset == rows
+        pa, pj, pv = P.download()
+        assert np.array_equal(pa + ia[rows], ia[rows:rows + i.nrows + 1])
+        assert np.array_equal(pj, ja[ia[rows]:ia[rows + i.nrows]])
+        assert np.array_equal(pv.view(np.uint64), val[ia[rows]:ia[rows + i.nrows]].view(np.uint64))
+        rows += i.nrows
+    assert rows == A.dim
