@@ -72,8 +72,9 @@ typedef struct qbh_opts {
     int     nnz_per_block;   /* nonzeros staged per workgroup (1024/2048/4096/8192); 0 = auto      */
     int     xcd_swizzle;     /* workgroup->row-block map: 0 interleaved, 1 one contiguous eighth per
                                 XCD, 2 (default) chunked: neighbouring chunks on the 8 XCDs          */
-    int     value_dict;      /* 0 = store complex128 values; 1 = dictionary-code them when <=256
-                                distinct values exist (exact, lossless)                            */
+    int     value_dict;      /* 0 = store complex128 values; 1 = dictionary-code them (exact, lossless):
+                                1-byte codes when <= 256 distinct values exist, 2-byte codes when
+                                <= 65536 (row kernel only); 2 = 1-byte codes only                  */
     int     profile;         /* 1: bracket every SpMV launch with HIP events (qbh_get_stats)       */
     int     check_hermitian; /* 1 (default): full-storage host input is checked like sparse.cc:235 */
 } qbh_opts;

@@ -68,7 +68,7 @@ extern "C" void qbh_opts_default(qbh_opts *o)
     o->spmv_kernel = QBH_KERNEL_AUTO;
     o->nnz_per_block = 0;
     o->xcd_swizzle = 2;
-    o->value_dict = 0;
+    o->value_dict = 1;      // lossless; falls back to plain storage by itself
     o->profile = 0;
     o->check_hermitian = 1;
 }
@@ -121,7 +121,7 @@ struct Bind {   // make the operator's device current for the duration of a call
 int try_value_dict(qbh_csr *A);
 
 // row-block geometry of one part (ia of length nrows+1, nnz entries)
-int setup_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, bool coded, int *npb_o, int *tpr_o, int *unroll_o,
+int setup_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, int dict_mode, int *npb_o, int *tpr_o, int *unroll_o,
                    int64_t *window_o, int64_t *n_blocks_o, int32_t **d_rb_o, int64_t **d_bp_o, int *grid_o)
 {
     hipStream_t s = A->stream;
@@ -133,10 +133,12 @@ int setup_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, bool coded, int
     QBH_HIP(hipStreamSynchronize(s));
     const double avg = A->nrows > 0 ? (double)nnz / (double)A->nrows : 0.0;
     int npb, tpr, unroll = 4;
+    const bool coded = dict_mode != 0;
     if (A->kernel == QBH_KERNEL_ROWS) {
         // measured on C3: coded 8192/P=1/8 gathers in flight is HBM-bound on its real
         // traffic; the plain kernel stages 16-byte values and is limited to 2048 by LDS occupancy.
-        npb = coded ? 8192 : 2048;
+        // two-byte codes: 4096 keeps three workgroups per CU next to the 16 KB LDS dictionary
+        npb = dict_mode == 1 ? 8192 : dict_mode >= 2 ? 4096 : 2048;
         const double cap_rows = 0.75 * qbh::kRowCap * (avg > 1.0 ? avg : 1.0);   // keep rows/block under kRowCap
         while (npb > 1024 && (double)npb > cap_rows) npb >>= 1;
         if (o.nnz_per_block > 0) npb = o.nnz_per_block;
@@ -148,7 +150,7 @@ int setup_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, bool coded, int
         if (A->kernel == QBH_KERNEL_VECTOR) tpr = avg <= 6 ? 4 : avg <= 12 ? 8 : avg <= 40 ? 16 : avg <= 96 ? 32 : 64;
         else                                tpr = avg <= 3 ? 1 : avg <= 8 ? 2 : avg <= 48 ? 4 : avg <= 128 ? 8 : 16;
     }
-    if (npb != 1024 && npb != 2048 && npb != 4096 && !(npb == 8192 && A->kernel == QBH_KERNEL_ROWS && coded)) {
+    if (npb != 1024 && npb != 2048 && npb != 4096 && !(npb == 8192 && A->kernel == QBH_KERNEL_ROWS && dict_mode == 1)) {
         qbh::set_error("nnz_per_block must be 1024, 2048 or 4096 (8192: row kernel with value dictionary only)");
         return QBH_EINVAL;
     }
@@ -172,7 +174,7 @@ int setup_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, bool coded, int
         // persistent launch: exactly the workgroups that are resident at once (measured on C3: 768 = 3 per
         // CU runs 8 % faster than an oversubscribed 4096 because the chunked XCD walk then keeps every
         // XCD on ONE contiguous chunk of row blocks)
-        const int occ = qbh::rows_kernel_occupancy(npb, tpr, unroll, coded);
+        const int occ = qbh::rows_kernel_occupancy(npb, tpr, unroll, dict_mode);
         int ncu = 256;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, A->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
@@ -222,13 +224,16 @@ int split_shard(qbh_csr *A)
     QBH_HIP(hipMalloc(&ja0, std::max<size_t>((size_t)nnz0, 1) * sizeof(int32_t)));
     QBH_HIP(hipMalloc(&ja1, (size_t)nnz1 * sizeof(int32_t)));
     if (coded) {
-        QBH_HIP(hipMalloc(&c0, (size_t)nnz0 + 16));
-        QBH_HIP(hipMalloc(&c1, (size_t)nnz1 + 16));
+        QBH_HIP(hipMalloc(&c0, (size_t)nnz0 * A->code_w + 16));
+        QBH_HIP(hipMalloc(&c1, (size_t)nnz1 * A->code_w + 16));
+        QBH_HIP(hipMemsetAsync(c0 + (size_t)nnz0 * A->code_w, 0, 16, s));
+        QBH_HIP(hipMemsetAsync(c1 + (size_t)nnz1 * A->code_w, 0, 16, s));
     } else {
         QBH_HIP(hipMalloc(&v0, std::max<size_t>((size_t)nnz0, 1) * sizeof(d2)));
         QBH_HIP(hipMalloc(&v1, (size_t)nnz1 * sizeof(d2)));
     }
-    QBH_TRY(qbh::launch_split_fill(A->d_ia, A->d_ja, A->d_val, A->d_code, A->nrows, lo, hi, ia0, ja0, v0, c0, ia1, ja1, v1, c1, s));
+    QBH_TRY(qbh::launch_split_fill(A->d_ia, A->d_ja, A->d_val, A->d_code, A->nrows, lo, hi, ia0, ja0, v0, c0, ia1, ja1, v1, c1,
+                                    A->code_w, s));
     QBH_HIP(hipStreamSynchronize(s));
     if (A->own_arrays) {
         (void)hipFree(A->d_ia);
@@ -273,10 +278,12 @@ int finalize(qbh_csr *A)
     QBH_HIP(hipMalloc(&A->d_flag, sizeof(int)));
     QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
     if (coded) {
-        d2 dict[256];
-        QBH_HIP(hipMemcpy(dict, A->d_dict, sizeof(dict), hipMemcpyDeviceToHost));
+        A->code_w = A->n_dict <= 256 ? 1 : 2;
+        A->dict_mode = A->n_dict <= 256 ? 1 : A->n_dict <= qbh::kDictLds ? 2 : 3;
+        std::vector<d2> dict((size_t)A->n_dict);
+        QBH_HIP(hipMemcpy(dict.data(), A->d_dict, dict.size() * sizeof(d2), hipMemcpyDeviceToHost));
         A->values_real = true;
-        for (int i = 0; i < A->n_dict; ++i) A->values_real = A->values_real && dict[i].y == 0.0;
+        for (int i = 0; i < A->n_dict; ++i) A->values_real = A->values_real && dict[(size_t)i].y == 0.0;
     } else if (A->d_val && A->nnz > 0) {
         double *tmp = nullptr;
         QBH_HIP(hipMalloc(&tmp, (size_t)qbh::kMaxRedBlocks * sizeof(double)));
@@ -291,12 +298,12 @@ int finalize(qbh_csr *A)
     }
     QBH_TRY(split_shard(A));
 
-    QBH_TRY(setup_geometry(A, A->d_ia, A->nnz, coded, &A->npb, &A->tpr, &A->unroll, &A->window, &A->n_blocks, &A->d_rb,
+    QBH_TRY(setup_geometry(A, A->d_ia, A->nnz, A->dict_mode, &A->npb, &A->tpr, &A->unroll, &A->window, &A->n_blocks, &A->d_rb,
                            &A->d_bp, &A->grid));
     int grid_max = A->grid;
     if (A->has_rem) {
         CsrPart &R = A->rem;
-        QBH_TRY(setup_geometry(A, R.d_ia, R.nnz, coded, &R.npb, &R.tpr, &R.unroll, &R.window, &R.n_blocks, &R.d_rb, &R.d_bp,
+        QBH_TRY(setup_geometry(A, R.d_ia, R.nnz, A->dict_mode, &R.npb, &R.tpr, &R.unroll, &R.window, &R.n_blocks, &R.d_rb, &R.d_bp,
                                &R.grid));
         grid_max = std::max(grid_max, R.grid);
     }
@@ -339,21 +346,13 @@ int new_handle(qbh_csr **out, const qbh_opts *opts)
 int try_value_dict(qbh_csr *A)
 {
     if (!A->opts.value_dict || !A->d_val || A->d_code || A->nnz <= 0) return QBH_OK;
+    // two-byte codes (<= 65536 distinct values) are a feature of the row kernel
+    const int cap = (A->kernel == QBH_KERNEL_ROWS && A->opts.value_dict != 2) ? 65536 : 256;
     uint8_t *code = nullptr;
     d2 *dict = nullptr;
-    QBH_HIP(hipMalloc(&code, (size_t)A->nnz + 16));      // k_spmv_rows reads whole 8-byte words
-    hipError_t e = hipMalloc(&dict, 256 * sizeof(d2));
-    if (e != hipSuccess) {
-        (void)hipFree(code);
-        return QBH_ENOMEM;
-    }
     int n = 0;
-    int rc = qbh::build_value_dict(A->d_val, A->nnz, code, dict, &n, A->stream);
-    if (rc != QBH_OK || n == 0) {
-        (void)hipFree(code);
-        (void)hipFree(dict);
-        return rc;
-    }
+    int rc = qbh::build_value_dict(A->d_val, A->nnz, cap, &code, &dict, &n, A->stream);
+    if (rc != QBH_OK || n == 0) return rc;
     A->d_code = code;
     A->d_dict = dict;
     A->n_dict = n;
@@ -565,7 +564,7 @@ extern "C" int qbh_csr_create_device(qbh_csr **out, int64_t nrows, int64_t ncols
 int qbh::adopt_coded_csr(qbh_csr **out, int64_t nrows, int64_t ncols, int64_t row_offset, int64_t nnz, int64_t *d_ia,
                          int32_t *d_ja, uint8_t *d_code, qbh::d2 *d_dict, int n_dict, const qbh_opts *opts)
 {
-    if (!out || !d_ia || !d_ja || !d_code || !d_dict || n_dict <= 0 || n_dict > 256 || nrows <= 0 || nnz < 0 ||
+    if (!out || !d_ia || !d_ja || !d_code || !d_dict || n_dict <= 0 || n_dict > 65536 || nrows <= 0 || nnz < 0 ||
         row_offset < 0 || row_offset + nrows > ncols || ncols >= (int64_t)std::numeric_limits<int32_t>::max()) {
         qbh::set_error("adopt_coded_csr: invalid argument");
         return QBH_EINVAL;
@@ -821,6 +820,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     a.val = A->d_val;
     a.code = A->d_code;
     a.dict = A->d_dict;
+    a.dict_mode = A->dict_mode;
     a.rb = A->d_rb;
     a.bp = A->d_bp;
     a.n_blocks = A->n_blocks;
@@ -1650,11 +1650,17 @@ int download_part(const qbh_csr *A, const int64_t *d_ia, const int32_t *d_ja, co
     val.resize((size_t)(p1 - p0));
     if (p1 == p0) return QBH_OK;
     if (d_code) {                              // decode the dictionary-coded stream
-        std::vector<uint8_t> code(val.size());
-        d2 dict[256];
-        QBH_HIP(hipMemcpy(code.data(), d_code + p0, code.size(), hipMemcpyDeviceToHost));
-        QBH_HIP(hipMemcpy(dict, A->d_dict, sizeof(dict), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < code.size(); ++i) val[i] = dict[code[i]];
+        std::vector<d2> dict((size_t)A->n_dict);
+        QBH_HIP(hipMemcpy(dict.data(), A->d_dict, dict.size() * sizeof(d2), hipMemcpyDeviceToHost));
+        if (A->code_w == 2) {
+            std::vector<uint16_t> code(val.size());
+            QBH_HIP(hipMemcpy(code.data(), d_code + 2 * p0, code.size() * 2, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < code.size(); ++i) val[i] = dict[code[i]];
+        } else {
+            std::vector<uint8_t> code(val.size());
+            QBH_HIP(hipMemcpy(code.data(), d_code + p0, code.size(), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < code.size(); ++i) val[i] = dict[code[i]];
+        }
     } else {
         QBH_HIP(hipMemcpy(val.data(), d_val + p0, val.size() * sizeof(d2), hipMemcpyDeviceToHost));
     }

@@ -760,22 +760,19 @@ __device__ int repr_row(const ReprDev &R, const uint64_t *tab, const uint64_t *r
 // row lengths of rows [r0, r1); with gf != nullptr the distinct values met on the way are collected for the value
 // dictionary, so that the fill pass can emit 1-byte codes and the 16 B/nnz value array never exists
 __global__ __launch_bounds__(128) void k_repr_count(const ReprDev *Rp, const uint64_t *tab, const uint64_t *reps, const uint8_t *info,
-                                                    int64_t dim, int64_t r0, int64_t r1, int32_t *cnt, unsigned long long *gf, d2 *gv,
-                                                    int *flags)
+                                                    int64_t dim, int64_t r0, int64_t r1, int32_t *cnt, DictTab T)
 {
     __shared__ DictCollect D;
     int32_t cols[kReprMaxRow];
     d2 vals[kReprMaxRow];
-    const bool collect = gf != nullptr;
-    if (collect) dict_collect_init(D);
+    bool collect = T.fp != nullptr;
+    if (T.fp != nullptr) dict_collect_init(D);
     const int64_t stride = (int64_t)gridDim.x * 128;
     for (int64_t i = r0 + (int64_t)blockIdx.x * 128 + threadIdx.x; i < r1; i += stride) {
         const int m = repr_row(*Rp, tab, reps, info, dim, i, cols, vals);
         cnt[i - r0] = m;
-        if (collect && dict_collect_ok(D))
-            for (int q = 0; q < m; ++q) dict_collect_insert(D, vals[q], flags);
+        for (int q = 0; collect && q < m; ++q) collect = dict_collect_insert(D, T, vals[q]);
     }
-    if (collect) dict_collect_flush(D, gf, gv, flags);
 }
 
 // ia is local to the shard (ia[0] = 0 at row r0)
@@ -795,21 +792,22 @@ __global__ __launch_bounds__(128) void k_repr_fill(const ReprDev *Rp, const uint
     }
 }
 
+template <typename CT>
 __global__ __launch_bounds__(128) void k_repr_fill_coded(const ReprDev *Rp, const uint64_t *tab, const uint64_t *reps,
                                                          const uint8_t *info, int64_t dim, int64_t r0, int64_t r1, const int64_t *ia,
-                                                         int32_t *ja, uint8_t *code, const d2 *dict, int n_dict, int *flags)
+                                                         int32_t *ja, CT *code, const d2 *dict, DictTab T)
 {
     __shared__ DictEncode E;
     int32_t cols[kReprMaxRow];
     d2 vals[kReprMaxRow];
-    dict_encode_init(E, dict, n_dict);
+    dict_encode_init(E);
     const int64_t stride = (int64_t)gridDim.x * 128;
     for (int64_t i = r0 + (int64_t)blockIdx.x * 128 + threadIdx.x; i < r1; i += stride) {
         const int m = repr_row(*Rp, tab, reps, info, dim, i, cols, vals);
         const int64_t p0 = ia[i - r0];
         for (int q = 0; q < m; ++q) {
             ja[p0 + q] = cols[q];
-            code[p0 + q] = dict_encode_one(E, vals[q], flags);
+            code[p0 + q] = (CT)dict_encode_one(E, T, dict, vals[q]);
         }
     }
 }
@@ -964,7 +962,8 @@ extern "C" int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int
     }
     const bool want_dict = !opts || opts->value_dict;
     if (want_dict) {
-        rc = dict_build_begin(&db, 0);
+        const bool rows_kernel = !opts || opts->spmv_kernel == QBH_KERNEL_AUTO || opts->spmv_kernel == QBH_KERNEL_ROWS;
+        rc = dict_build_begin(&db, (opts && opts->value_dict == 2) || !rows_kernel ? 256 : kDictMax, 0);
         if (rc != QBH_OK) {
             cleanup(true);
             return rc;
@@ -973,8 +972,7 @@ extern "C" int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int
     QBH_R(hipMalloc(&d_cnt, (size_t)nloc * sizeof(int32_t)));
     QBH_R(hipMalloc(&d_ia, (size_t)(nloc + 1) * sizeof(int64_t)));
     const int rgrid = (int)std::min<int64_t>((nloc + 127) / 128, 256 * 16);
-    hipLaunchKernelGGL(k_repr_count, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_cnt, db.gf, db.gv,
-                       db.flags);
+    hipLaunchKernelGGL(k_repr_count, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_cnt, db.tab);
     QBH_R(hipGetLastError());
     rc = exclusive_scan(d_cnt, nloc, d_ia, 0);
     if (rc != QBH_OK) {
@@ -986,19 +984,23 @@ extern "C" int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int
     QBH_R(hipMalloc(&d_ja, (size_t)nnz * sizeof(int32_t)));
     int n_dict = 0;
     if (want_dict) {
-        QBH_R(hipMalloc(&d_dict, 256 * sizeof(d2)));
-        rc = dict_build_finalize(&db, d_dict, &n_dict, 0);
+        rc = dict_build_finalize(&db, &d_dict, &n_dict, 0);
         if (rc != QBH_OK) {
             cleanup(true);
             return rc;
         }
     }
     if (n_dict > 0) {
-        // at most 256 distinct values: emit codes directly (5 B/nnz instead of 20)
-        QBH_R(hipMalloc(&d_code, (size_t)nnz + 16));
-        QBH_R(hipMemset(d_code + nnz, 0, 16));
-        hipLaunchKernelGGL(k_repr_fill_coded, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_ia, d_ja,
-                           d_code, d_dict, n_dict, db.flags);
+        // few distinct values: emit 1- or 2-byte codes directly (5 or 6 B/nnz instead of 20)
+        const int w = dict_code_width(n_dict);
+        QBH_R(hipMalloc(&d_code, (size_t)nnz * w + 16));
+        QBH_R(hipMemset(d_code + (size_t)nnz * w, 0, 16));
+        if (w == 1)
+            hipLaunchKernelGGL(k_repr_fill_coded<uint8_t>, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_ia,
+                               d_ja, d_code, d_dict, db.tab);
+        else
+            hipLaunchKernelGGL(k_repr_fill_coded<uint16_t>, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1,
+                               d_ia, d_ja, reinterpret_cast<uint16_t *>(d_code), d_dict, db.tab);
         QBH_R(hipGetLastError());
         int bad = 0;
         rc = dict_build_mismatch(&db, &bad, 0);
@@ -1015,7 +1017,7 @@ extern "C" int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int
         d_dict = nullptr;
         hipError_t e = hipMalloc(&d_val, (size_t)nnz * sizeof(d2));
         if (e != hipSuccess) {
-            set_error("qbh_gen_heisenberg_repr: %lld nonzeros with more than 256 distinct values do not fit this GPU "
+            set_error("qbh_gen_heisenberg_repr: %lld nonzeros with more than 65536 distinct values do not fit this GPU "
                       "uncoded (%.1f GB); shard the sector over more GPUs", (long long)nnz, 20e-9 * (double)nnz);
             cleanup(true);
             return QBH_ENOMEM;

@@ -14,6 +14,7 @@ namespace qbh {
 typedef double d2 __attribute__((ext_vector_type(2)));   // one complex128 (re, im)
 
 constexpr int kBlock = 256;          // threads per workgroup (4 wavefronts)
+constexpr int kDictLds = 1024;          // largest value dictionary the row kernel keeps in LDS (2-byte codes)
 constexpr int kMaxRedBlocks = 2048;  // grid of the BLAS-1 kernels == number of partial sums
 constexpr int kRowCap = 1024;        // row offsets staged in LDS per row block
 
@@ -40,8 +41,9 @@ struct SpmvArgs {
     const int64_t *ia;     // [nrows+1] local row pointers
     const int32_t *ja;     // [nnz] global columns
     const d2      *val;    // [nnz] values (or nullptr when dictionary-coded)
-    const uint8_t *code;   // [nnz] dictionary codes (value_dict)
-    const d2      *dict;   // [<=256] dictionary
+    const uint8_t *code;   // [nnz] dictionary codes (value_dict): 1 byte each, or 2 bytes when dict_mode >= 2
+    const d2      *dict;   // dictionary (>= kDictLds entries allocated)
+    int            dict_mode;   // 1: <= 256 values | 2: <= kDictLds values, 2-byte codes | 3: <= 65536, 2-byte codes
     const int32_t *rb;     // [n_blocks+1] first row of each row block (stream kernel)
     const int64_t *bp;     // [n_blocks+1] first nonzero of each row block (= ia[rb[.]])
     int64_t        n_blocks;
@@ -60,7 +62,7 @@ struct SpmvArgs {
 // launchers implemented in qbh_kernels.hip (all asynchronous on `s`)
 int launch_spmv(const SpmvArgs &a, int kernel, int npb, int tpr, int grid, hipStream_t s);
 int spmv_grid(int kernel, int64_t n_blocks, int64_t nrows, int tpr);
-int rows_kernel_occupancy(int npb, int tpr, int un, bool dict);
+int rows_kernel_occupancy(int npb, int tpr, int un, int dict_mode);
 int launch_build_rowblocks(const int64_t *d_ia, int64_t nrows, int64_t window, int32_t *d_rb,
                            int64_t *d_bp, int64_t n_blocks, hipStream_t s);
 int launch_reduce_partials(const double *partials, int nparts, int ncomp, double *out, hipStream_t s);
@@ -83,13 +85,13 @@ int exclusive_scan(const int32_t *d_cnt, int64_t n, int64_t *d_ia, hipStream_t s
 int launch_split_count(const int64_t *ia, const int32_t *ja, int64_t nrows, int32_t lo, int32_t hi, int32_t *cnt0, hipStream_t s);
 int launch_split_fill(const int64_t *ia, const int32_t *ja, const d2 *val, const uint8_t *code, int64_t nrows, int32_t lo,
                       int32_t hi, const int64_t *ia0, int32_t *ja0, d2 *val0, uint8_t *code0, int64_t *ia1, int32_t *ja1,
-                      d2 *val1, uint8_t *code1, hipStream_t s);
+                      d2 *val1, uint8_t *code1, int code_w, hipStream_t s);
 struct Coef8 { double v[16]; };   // up to 8 complex coefficients passed by value
 int launch_multi_dot8(const d2 *V, int64_t ldv, const d2 *w, int64_t n, int nv, double *partials, hipStream_t s);
 int launch_multi_axpy8(const d2 *V, int64_t ldv, const Coef8 &c, int nv, d2 *w, int64_t n, double *partials, hipStream_t s);
 int launch_basis_rotate(d2 *V, int64_t ldv, int64_t n, int m, int keep, const double *d_S, hipStream_t s);
 int symmetric_eigen_jacobi(int m, double *a, double *w, double *z);
-int build_value_dict(const d2 *d_val, int64_t nnz, uint8_t *d_code, d2 *d_dict, int *n_out, hipStream_t s);
+int build_value_dict(const d2 *d_val, int64_t nnz, int cap, uint8_t **d_code_out, d2 **d_dict_out, int *n_out, hipStream_t s);
 
 // host tridiagonal solver (qbh_hess.cpp)
 int tridiag_eigen_full(int64_t m, const double *a, const double *b1, double *w, double *z);
@@ -159,6 +161,8 @@ struct qbh_csr {
     uint8_t *d_code = nullptr;
     qbh::d2 *d_dict = nullptr;
     int      n_dict = 0;
+    int      code_w = 1;            // bytes per value code (2 when n_dict > 256)
+    int      dict_mode = 0;         // k_spmv_rows' DICT
     bool     own_arrays = true;
 
     // streaming kernel geometry

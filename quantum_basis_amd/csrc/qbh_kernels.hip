@@ -9,6 +9,10 @@
 //
 // Replaces mkl_sparse_z_mv (src/sparse.cc:287) and the cblas_z* level-1 calls of the
 // Lanczos / CG loops (src/lanczos.cc:195-214, 296-337).
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
 #include "qbh_internal.hpp"
 #include "qbh_dict.hpp"
 
@@ -264,16 +268,19 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(SpmvArgs a)
 // from the front and from the back of the row turns those gathers into full-line coalesced
 // loads.  Row sums stay in registers (no 16-byte products through LDS, no shuffle tree);
 // with the value dictionary the LDS footprint is 5 B/nnz and 8 workgroups fit a CU.
-template <int NPB, int P, int UN, bool DICT, bool REALX>
+// DICT: 0 complex128 values | 1 one-byte codes, dictionary (<= 256) in LDS | 2 two-byte codes, dictionary
+// (<= kDictLds) in LDS | 3 two-byte codes, dictionary (<= 65536) read through the caches
+template <int NPB, int P, int UN, int DICT, bool REALX>
 __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
 {
     constexpr int R = kBlock / P;            // rows per pass
     constexpr int U = NPB / kBlock;          // staged cols per lane
-    constexpr int UC = (NPB / 8 + kBlock - 1) / kBlock;   // 8-byte code words per lane
+    constexpr int CPW = DICT >= 2 ? 4 : 8;   // codes per 8-byte word
+    constexpr int UC = (NPB / CPW + kBlock - 1) / kBlock;   // 8-byte code words per lane
     __shared__ int scol[NPB];
     __shared__ d2 sval[DICT ? 1 : NPB];
-    __shared__ unsigned long long scode8[DICT ? NPB / 8 : 1];
-    __shared__ d2 dict_s[DICT ? 256 : 1];
+    __shared__ unsigned long long scode8[DICT ? NPB / CPW : 1];
+    __shared__ d2 dict_s[DICT == 1 ? 256 : DICT == 2 ? kDictLds : 1];
     __shared__ int rowoff[kRowCap + 1];
     __shared__ d2 part[P > 1 ? kBlock : 1];
     __shared__ double red[12];
@@ -284,9 +291,20 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
     const bool need_y = a.beta != 0.0;
     const bool need_x = a.gamma != 0.0 || a.partials != nullptr;
     const uint8_t *scode = reinterpret_cast<const uint8_t *>(scode8);
+    const uint16_t *scode16 = reinterpret_cast<const uint16_t *>(scode8);
+    const uint16_t *gcode16 = reinterpret_cast<const uint16_t *>(a.code);
+    auto coded_value = [&](int i) -> d2 {          // value of staged element i
+        if (DICT == 1) return dict_s[scode[i]];
+        if (DICT == 2) return dict_s[scode16[i]];
+        return a.dict[scode16[i]];
+    };
 
-    if (DICT) {
+    if (DICT == 1) {
         dict_s[tid] = a.dict[tid];
+        __syncthreads();
+    }
+    if (DICT == 2) {
+        for (int i = tid; i < kDictLds; i += kBlock) dict_s[i] = a.dict[i];
         __syncthreads();
     }
 
@@ -332,18 +350,18 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
                     }
                     if (DICT) {
                         unsigned long long w[UC];
-                        const int nw = (n + 7) >> 3;                 // 8-byte words covering the codes
+                        const int nw = (n + CPW - 1) / CPW;          // 8-byte words covering the codes
 #pragma unroll
                         for (int u = 0; u < UC; ++u) {
                             const int i = tid + u * kBlock;
                             // unaligned 8-byte global load; the last word may read up to 7 bytes past the
-                            // block's range but never past the code array (padded by 8 bytes at build)
-                            w[u] = ntload(reinterpret_cast<const unsigned long long *>(a.code + p0) + (i < nw ? i : 0));
+                            // block's range but never past the code array (padded by 16 bytes at build)
+                            w[u] = ntload(reinterpret_cast<const unsigned long long *>(a.code + p0 * (8 / CPW)) + (i < nw ? i : 0));
                         }
 #pragma unroll
                         for (int u = 0; u < UC; ++u) {
                             const int i = tid + u * kBlock;
-                            if (i < NPB / 8) scode8[i] = w[u];
+                            if (i < NPB / CPW) scode8[i] = w[u];
                         }
                     } else {
                         d2 v[U];
@@ -394,7 +412,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
                             for (int j = 0; j < UN; ++j) xr[j] = a.xr[cc[j]];
 #pragma unroll
                             for (int j = 0; j < UN; ++j) {
-                                if (DICT) vr[j] = dict_s[scode[ix[j]]].x;
+                                if (DICT) vr[j] = coded_value(ix[j]).x;
                                 else      vr[j] = sval[ix[j]].x;
                             }
 #pragma unroll
@@ -406,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
                             for (int j = 0; j < UN; ++j) xv[j] = a.xg[cc[j]];
 #pragma unroll
                             for (int j = 0; j < UN; ++j) {
-                                if (DICT) vv[j] = dict_s[scode[ix[j]]];
+                                if (DICT) vv[j] = coded_value(ix[j]);
                                 else      vv[j] = sval[ix[j]];
                             }
 #pragma unroll
@@ -435,8 +453,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
                     double pr[2] = {0.0, 0.0};
                     for (int64_t q = s + tid; q < e; q += kBlock) {
                         d2 v;
-                        if (DICT) v = dict_s[a.code[q]];
-                        else      v = a.val[q];
+                        if (DICT == 1)      v = dict_s[a.code[q]];
+                        else if (DICT == 2) v = dict_s[gcode16[q]];
+                        else if (DICT == 3) v = a.dict[gcode16[q]];
+                        else                v = a.val[q];
                         const int cq = a.ja[q] & a.colmask;
                         const d2 xq = REALX ? d2{a.xr[cq], 0.0} : a.xg[cq];
                         const d2 t = cmul(v, xq);
@@ -545,7 +565,7 @@ static int launch_stream_tpr(const SpmvArgs &a, int tpr, int grid, hipStream_t s
     return QBH_OK;
 }
 
-template <int NPB, int PP, bool DICT>
+template <int NPB, int PP, int DICT>
 static int occ_rows_un(int un)
 {
     int n = 0;
@@ -555,7 +575,7 @@ static int occ_rows_un(int un)
     return e == hipSuccess ? n : 0;
 }
 
-template <int NPB, bool DICT>
+template <int NPB, int DICT>
 static int occ_rows_p(int tpr, int un)
 {
     switch (tpr) {
@@ -567,7 +587,7 @@ static int occ_rows_p(int tpr, int un)
     }
 }
 
-template <bool DICT>
+template <int DICT>
 static int occ_rows(int npb, int tpr, int un)
 {
     switch (npb) {
@@ -575,19 +595,24 @@ static int occ_rows(int npb, int tpr, int un)
     case 2048: return occ_rows_p<2048, DICT>(tpr, un);
     case 4096: return occ_rows_p<4096, DICT>(tpr, un);
     case 8192:
-        if constexpr (DICT) return occ_rows_p<8192, DICT>(tpr, un);
+        if constexpr (DICT == 1) return occ_rows_p<8192, DICT>(tpr, un);
         return 0;
     default: return 0;
     }
 }
 
-// workgroups of the row kernel that are resident per CU (0 if unknown)
-int rows_kernel_occupancy(int npb, int tpr, int un, bool dict)
+// workgroups of the row kernel that are resident per CU (0 if unknown); dict_mode as k_spmv_rows' DICT
+int rows_kernel_occupancy(int npb, int tpr, int un, int dict_mode)
 {
-    return dict ? occ_rows<true>(npb, tpr, un) : occ_rows<false>(npb, tpr, un);
+    switch (dict_mode) {
+    case 0: return occ_rows<0>(npb, tpr, un);
+    case 1: return occ_rows<1>(npb, tpr, un);
+    case 2: return occ_rows<2>(npb, tpr, un);
+    default: return occ_rows<3>(npb, tpr, un);
+    }
 }
 
-template <int NPB, int PP, bool DICT>
+template <int NPB, int PP, int DICT>
 static int launch_rows_un(const SpmvArgs &a, int un, int grid, hipStream_t s)
 {
     if (a.xr != nullptr) {
@@ -600,7 +625,7 @@ static int launch_rows_un(const SpmvArgs &a, int un, int grid, hipStream_t s)
     return QBH_OK;
 }
 
-template <int NPB, bool DICT>
+template <int NPB, int DICT>
 static int launch_rows_p(const SpmvArgs &a, int tpr, int un, int grid, hipStream_t s)
 {
     switch (tpr) {
@@ -612,7 +637,7 @@ static int launch_rows_p(const SpmvArgs &a, int tpr, int un, int grid, hipStream
     }
 }
 
-template <bool DICT>
+template <int DICT>
 static int launch_rows(const SpmvArgs &a, int npb, int tpr, int un, int grid, hipStream_t s)
 {
     switch (npb) {
@@ -620,8 +645,8 @@ static int launch_rows(const SpmvArgs &a, int npb, int tpr, int un, int grid, hi
     case 2048: return launch_rows_p<2048, DICT>(a, tpr, un, grid, s);
     case 4096: return launch_rows_p<4096, DICT>(a, tpr, un, grid, s);
     case 8192:
-        if constexpr (DICT) return launch_rows_p<8192, DICT>(a, tpr, un, grid, s);
-        set_error("nnz_per_block 8192 needs the value dictionary");
+        if constexpr (DICT == 1) return launch_rows_p<8192, DICT>(a, tpr, un, grid, s);
+        set_error("nnz_per_block 8192 needs the one-byte value dictionary");
         return QBH_EINVAL;
     default: set_error("k_spmv_rows: unsupported nnz_per_block %d", npb); return QBH_EINVAL;
     }
@@ -630,7 +655,6 @@ static int launch_rows(const SpmvArgs &a, int npb, int tpr, int un, int grid, hi
 template <bool DICT>
 static int launch_spmv_t(const SpmvArgs &a, int kernel, int npb, int tpr, int grid, hipStream_t s)
 {
-    if (kernel == QBH_KERNEL_ROWS) return launch_rows<DICT>(a, npb, tpr, a.unroll, grid, s);
     if (kernel == QBH_KERNEL_VECTOR) {
         switch (tpr) {
         case 4:  hipLaunchKernelGGL((k_spmv_vector<4, DICT>),  dim3(grid), dim3(kBlock), 0, s, a); break;
@@ -652,8 +676,21 @@ static int launch_spmv_t(const SpmvArgs &a, int kernel, int npb, int tpr, int gr
 
 int launch_spmv(const SpmvArgs &a, int kernel, int npb, int tpr, int grid, hipStream_t s)
 {
-    int rc = (a.code != nullptr) ? launch_spmv_t<true>(a, kernel, npb, tpr, grid, s)
+    int rc;
+    if (kernel == QBH_KERNEL_ROWS) {
+        switch (a.code == nullptr ? 0 : a.dict_mode) {
+        case 0: rc = launch_rows<0>(a, npb, tpr, a.unroll, grid, s); break;
+        case 1: rc = launch_rows<1>(a, npb, tpr, a.unroll, grid, s); break;
+        case 2: rc = launch_rows<2>(a, npb, tpr, a.unroll, grid, s); break;
+        default: rc = launch_rows<3>(a, npb, tpr, a.unroll, grid, s); break;
+        }
+    } else if (a.code != nullptr && a.dict_mode != 1) {
+        set_error("two-byte value codes need the row kernel");
+        return QBH_EUNSUPP;
+    } else {
+        rc = (a.code != nullptr) ? launch_spmv_t<true>(a, kernel, npb, tpr, grid, s)
                                  : launch_spmv_t<false>(a, kernel, npb, tpr, grid, s);
+    }
     if (rc != QBH_OK) return rc;
     QBH_HIP(hipGetLastError());
     return QBH_OK;
@@ -721,81 +758,98 @@ int launch_max_rowlen(const int64_t *d_ia, int64_t nrows, int64_t *d_out, hipStr
 // a 1-byte index into a dictionary that lives in LDS during SpMV.  The stream shrinks from
 // 20 to 5 bytes per nonzero; products are computed from the exact original doubles.
 // (device helpers: qbh_dict.hpp)
-__global__ __launch_bounds__(kBlock) void k_dict_collect(const d2 *val, int64_t nnz, unsigned long long *gf, d2 *gv,
-                                                         int *flags)
+__global__ __launch_bounds__(kBlock) void k_dict_collect(const d2 *val, int64_t nnz, DictTab T)
 {
     __shared__ DictCollect D;
     dict_collect_init(D);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += stride) {
-        dict_collect_insert(D, val[i], flags);
-        if (!dict_collect_ok(D)) break;
-    }
-    dict_collect_flush(D, gf, gv, flags);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += stride)
+        if (!dict_collect_insert(D, T, val[i])) break;
 }
 
-// one thread: compact the global table, order entries by their bit patterns (so the codes do
-// not depend on which workgroup won an atomic), emit dict[0..n).
-__global__ void k_dict_finalize(const unsigned long long *gf, const d2 *gv, d2 *dict, int *flags)
-{
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    int n = 0;
-    for (int s = 0; s < kDictGlobal; ++s) {
-        if (gf[s] == 0ULL) continue;
-        if (n == 256) {
-            flags[0] = 1;
-            break;
-        }
-        const d2 v = gv[s];
-        int q = n++;
-        while (q > 0) {
-            const d2 w = dict[q - 1];
-            const unsigned long long wa = (unsigned long long)__double_as_longlong(w.x), va = (unsigned long long)__double_as_longlong(v.x);
-            const unsigned long long wb = (unsigned long long)__double_as_longlong(w.y), vb = (unsigned long long)__double_as_longlong(v.y);
-            if (wa < va || (wa == va && wb <= vb)) break;
-            dict[q] = w;
-            --q;
-        }
-        dict[q] = v;
-    }
-    for (int q = n; q < 256; ++q) dict[q] = d2{0.0, 0.0};
-    flags[2] = n;
-}
-
-__global__ __launch_bounds__(kBlock) void k_dict_encode(const d2 *val, int64_t nnz, const d2 *dict, uint8_t *code,
-                                                        int *flags)
+template <typename CT>
+__global__ __launch_bounds__(kBlock) void k_dict_encode(const d2 *val, int64_t nnz, DictTab T, const d2 *dict, CT *code)
 {
     __shared__ DictEncode E;
-    dict_encode_init(E, dict, flags[2]);
+    dict_encode_init(E);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += stride) code[i] = dict_encode_one(E, val[i], flags);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += stride)
+        code[i] = (CT)dict_encode_one(E, T, dict, val[i]);
 }
 
-int dict_build_begin(DictBuild *b, hipStream_t s)
+int dict_build_begin(DictBuild *b, int cap, hipStream_t s)
 {
-    QBH_HIP(hipMalloc(&b->gf, kDictGlobal * sizeof(unsigned long long)));
-    QBH_HIP(hipMalloc(&b->gv, kDictGlobal * sizeof(d2)));
-    QBH_HIP(hipMalloc(&b->flags, 4 * sizeof(int)));
-    QBH_HIP(hipMemsetAsync(b->gf, 0, kDictGlobal * sizeof(unsigned long long), s));
-    QBH_HIP(hipMemsetAsync(b->flags, 0, 4 * sizeof(int), s));
+    DictTab &T = b->tab;
+    T.cap = cap < kDictMax ? cap : kDictMax;
+    QBH_HIP(hipMalloc(&T.fp, (size_t)kDictSlots * sizeof(unsigned long long)));
+    QBH_HIP(hipMalloc(&T.val, (size_t)kDictSlots * sizeof(d2)));
+    QBH_HIP(hipMalloc(&T.code, (size_t)kDictSlots * sizeof(uint32_t)));
+    QBH_HIP(hipMalloc(&T.flags, 4 * sizeof(int)));
+    QBH_HIP(hipMemsetAsync(T.fp, 0, (size_t)kDictSlots * sizeof(unsigned long long), s));
+    QBH_HIP(hipMemsetAsync(T.flags, 0, 4 * sizeof(int), s));
     return QBH_OK;
 }
 
-int dict_build_finalize(DictBuild *b, d2 *d_dict, int *n_out, hipStream_t s)
+int dict_build_finalize(DictBuild *b, d2 **d_dict_out, int *n_out, hipStream_t s)
 {
+    DictTab &T = b->tab;
     *n_out = 0;
-    hipLaunchKernelGGL(k_dict_finalize, dim3(1), dim3(64), 0, s, b->gf, b->gv, d_dict, b->flags);
+    *d_dict_out = nullptr;
     int h[4] = {0, 0, 0, 0};
-    QBH_HIP(hipMemcpyAsync(h, b->flags, sizeof(h), hipMemcpyDeviceToHost, s));
+    QBH_HIP(hipMemcpyAsync(h, T.flags, sizeof(h), hipMemcpyDeviceToHost, s));
     QBH_HIP(hipStreamSynchronize(s));
-    if (!h[0] && h[2] > 0) *n_out = h[2];
+    if (getenv("QBH_DEBUG_DICT")) fprintf(stderr, "dict: overflow %d claimed %d cap %d\n", h[0], h[1], T.cap);
+    if (h[0] || h[1] <= 0 || h[1] > T.cap) return QBH_OK;
+    std::vector<unsigned long long> fp((size_t)kDictSlots);
+    std::vector<d2> val((size_t)kDictSlots);
+    QBH_HIP(hipMemcpy(fp.data(), T.fp, fp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    QBH_HIP(hipMemcpy(val.data(), T.val, val.size() * sizeof(d2), hipMemcpyDeviceToHost));
+    struct Ent {
+        unsigned long long a, b;
+        int slot;
+    };
+    std::vector<Ent> ents;
+    ents.reserve((size_t)h[1]);
+    for (int sl = 0; sl < kDictSlots; ++sl)
+        if (fp[(size_t)sl] != 0ULL) {
+            Ent e;
+            const double vx = val[(size_t)sl].x, vy = val[(size_t)sl].y;
+            memcpy(&e.a, &vx, 8);
+            memcpy(&e.b, &vy, 8);
+            e.slot = sl;
+            ents.push_back(e);
+        }
+    // order by bit pattern: the codes do not depend on which workgroup won an atomic
+    std::sort(ents.begin(), ents.end(), [](const Ent &x, const Ent &y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
+    // two different values with one fingerprint would share a slot: the count would not add up
+    const int n = (int)ents.size();
+    if (getenv("QBH_DEBUG_DICT")) fprintf(stderr, "dict: %d entries\n", n);
+    if (n != h[1] || n > T.cap) return QBH_OK;
+    const size_t n_alloc = (size_t)std::max(n, kDictLds);
+    std::vector<d2> dict(n_alloc, d2{0.0, 0.0});
+    std::vector<uint32_t> code((size_t)kDictSlots, 0u);
+    for (int c = 0; c < n; ++c) {
+        dict[(size_t)c] = val[(size_t)ents[(size_t)c].slot];
+        code[(size_t)ents[(size_t)c].slot] = (uint32_t)c;
+    }
+    d2 *d_dict = nullptr;
+    QBH_HIP(hipMalloc(&d_dict, n_alloc * sizeof(d2)));
+    hipError_t e1 = hipMemcpy(d_dict, dict.data(), n_alloc * sizeof(d2), hipMemcpyHostToDevice);
+    hipError_t e2 = hipMemcpy(T.code, code.data(), code.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        (void)hipFree(d_dict);
+        set_error("value dictionary upload failed");
+        return QBH_EHIP;
+    }
+    *d_dict_out = d_dict;
+    *n_out = n;
     return QBH_OK;
 }
 
 int dict_build_mismatch(DictBuild *b, int *bad, hipStream_t s)
 {
     int h[4] = {0, 0, 0, 0};
-    QBH_HIP(hipMemcpyAsync(h, b->flags, sizeof(h), hipMemcpyDeviceToHost, s));
+    QBH_HIP(hipMemcpyAsync(h, b->tab.flags, sizeof(h), hipMemcpyDeviceToHost, s));
     QBH_HIP(hipStreamSynchronize(s));
     *bad = h[3];
     return QBH_OK;
@@ -803,31 +857,52 @@ int dict_build_mismatch(DictBuild *b, int *bad, hipStream_t s)
 
 void dict_build_end(DictBuild *b)
 {
-    if (b->gf) (void)hipFree(b->gf);
-    if (b->gv) (void)hipFree(b->gv);
-    if (b->flags) (void)hipFree(b->flags);
-    b->gf = nullptr;
-    b->gv = nullptr;
-    b->flags = nullptr;
+    DictTab &T = b->tab;
+    if (T.fp) (void)hipFree(T.fp);
+    if (T.val) (void)hipFree(T.val);
+    if (T.code) (void)hipFree(T.code);
+    if (T.flags) (void)hipFree(T.flags);
+    T = DictTab{nullptr, nullptr, nullptr, nullptr, 0};
 }
 
-// returns n_dict (>0) in *n_out when the matrix was coded, 0 when it has too many distinct
-// values (code/dict contents are then unspecified).
-int build_value_dict(const d2 *d_val, int64_t nnz, uint8_t *d_code, d2 *d_dict, int *n_out, hipStream_t s)
+// Codes the value stream when it holds at most `cap` distinct values: *d_code_out (nnz * width + 16 bytes),
+// *d_dict_out and *n_out > 0 on success; n = 0 (nothing allocated) when there are too many distinct values.
+int build_value_dict(const d2 *d_val, int64_t nnz, int cap, uint8_t **d_code_out, d2 **d_dict_out, int *n_out, hipStream_t s)
 {
     *n_out = 0;
+    *d_code_out = nullptr;
+    *d_dict_out = nullptr;
     DictBuild b;
-    int rc = dict_build_begin(&b, s);
+    int rc = dict_build_begin(&b, cap, s);
+    uint8_t *code = nullptr;
+    d2 *dict = nullptr;
     if (rc == QBH_OK) {
         const int grid = blas_grid(nnz);
-        hipLaunchKernelGGL(k_dict_collect, dim3(grid), dim3(kBlock), 0, s, d_val, nnz, b.gf, b.gv, b.flags);
+        hipLaunchKernelGGL(k_dict_collect, dim3(grid), dim3(kBlock), 0, s, d_val, nnz, b.tab);
         int n = 0;
-        rc = dict_build_finalize(&b, d_dict, &n, s);
+        rc = dict_build_finalize(&b, &dict, &n, s);
         if (rc == QBH_OK && n > 0) {
-            hipLaunchKernelGGL(k_dict_encode, dim3(grid), dim3(kBlock), 0, s, d_val, nnz, d_dict, d_code, b.flags);
-            int bad = 0;
-            rc = dict_build_mismatch(&b, &bad, s);
-            if (rc == QBH_OK && !bad) *n_out = n;
+            const int w = dict_code_width(n);
+            if (hipMalloc(&code, (size_t)nnz * w + 16) != hipSuccess) {
+                (void)hipGetLastError();
+                n = 0;                                   // no room for the codes: stay uncoded
+            } else {
+                (void)hipMemsetAsync(code + (size_t)nnz * w, 0, 16, s);
+                if (w == 1) hipLaunchKernelGGL(k_dict_encode<uint8_t>, dim3(grid), dim3(kBlock), 0, s, d_val, nnz, b.tab, dict, code);
+                else hipLaunchKernelGGL(k_dict_encode<uint16_t>, dim3(grid), dim3(kBlock), 0, s, d_val, nnz, b.tab, dict,
+                                        reinterpret_cast<uint16_t *>(code));
+                int bad = 0;
+                rc = dict_build_mismatch(&b, &bad, s);
+                if (rc != QBH_OK || bad) n = 0;
+            }
+        }
+        if (n > 0) {
+            *n_out = n;
+            *d_code_out = code;
+            *d_dict_out = dict;
+        } else {
+            if (code) (void)hipFree(code);
+            if (dict) (void)hipFree(dict);
         }
     }
     dict_build_end(&b);
@@ -1190,8 +1265,10 @@ __global__ __launch_bounds__(kBlock) void k_split_count(const int64_t *ia, const
 __global__ __launch_bounds__(kBlock) void k_split_fill(const int64_t *ia, const int32_t *ja, const d2 *val, const uint8_t *code,
                                                        int64_t nrows, int32_t lo, int32_t hi, const int64_t *ia0, int32_t *ja0,
                                                        d2 *val0, uint8_t *code0, int64_t *ia1, int32_t *ja1, d2 *val1,
-                                                       uint8_t *code1)
+                                                       uint8_t *code1, int code_w)
 {
+    const uint16_t *wcode = reinterpret_cast<const uint16_t *>(code);
+    uint16_t *wcode0 = reinterpret_cast<uint16_t *>(code0), *wcode1 = reinterpret_cast<uint16_t *>(code1);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r <= nrows; r += stride) {
         ia1[r] = ia[r] - ia0[r];
@@ -1201,12 +1278,14 @@ __global__ __launch_bounds__(kBlock) void k_split_fill(const int64_t *ia, const 
             const int32_t col = ja[p];
             if (col >= lo && col < hi) {
                 ja0[q0] = col;
-                if (code) code0[q0] = code[p];
+                if (code && code_w == 2) wcode0[q0] = wcode[p];
+                else if (code) code0[q0] = code[p];
                 else      val0[q0] = val[p];
                 ++q0;
             } else {
                 ja1[q1] = col;
-                if (code) code1[q1] = code[p];
+                if (code && code_w == 2) wcode1[q1] = wcode[p];
+                else if (code) code1[q1] = code[p];
                 else      val1[q1] = val[p];
                 ++q1;
             }
@@ -1223,10 +1302,10 @@ int launch_split_count(const int64_t *ia, const int32_t *ja, int64_t nrows, int3
 
 int launch_split_fill(const int64_t *ia, const int32_t *ja, const d2 *val, const uint8_t *code, int64_t nrows, int32_t lo,
                       int32_t hi, const int64_t *ia0, int32_t *ja0, d2 *val0, uint8_t *code0, int64_t *ia1, int32_t *ja1,
-                      d2 *val1, uint8_t *code1, hipStream_t s)
+                      d2 *val1, uint8_t *code1, int code_w, hipStream_t s)
 {
     hipLaunchKernelGGL(k_split_fill, dim3(blas_grid(nrows + 1)), dim3(kBlock), 0, s, ia, ja, val, code, nrows, lo, hi, ia0, ja0,
-                       val0, code0, ia1, ja1, val1, code1);
+                       val0, code0, ia1, ja1, val1, code1, code_w);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }

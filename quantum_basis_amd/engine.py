@@ -37,7 +37,7 @@ def _cvec(a, name):
 
 
 def make_opts(device=-1, stream=None, spmv_kernel=_lib.KERNEL_AUTO, nnz_per_block=0, xcd_swizzle=2,
-              value_dict=0, profile=0, check_hermitian=1):
+              value_dict=1, profile=0, check_hermitian=1):
     o = _lib.Opts()
     lib().qbh_opts_default(C.byref(o))
     o.device = device

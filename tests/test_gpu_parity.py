@@ -329,12 +329,68 @@ def test_value_dictionary_is_exact():
     y = np.empty_like(x)
     A.MultMv(x, y)
     assert _close(y, O.multmv(x))
-    # too many distinct values: silently stays uncoded, still correct
+    # a genuinely complex sector: coded and uncoded operators hold the same bits
     B, OB = _both("chain16_k3", value_dict=1)
+    assert 0 < B.info().value_dict <= 256
     y = np.empty(B.dim, dtype=np.complex128)
     xb = _rand(B.dim, 10)
     B.MultMv(xb, y)
     assert _close(y, OB.multmv(xb))
+    C2, _ = _both("chain16_k3", value_dict=0)
+    assert C2.info().value_dict == 0
+    y2 = np.empty_like(y)
+    C2.MultMv(xb, y2)
+    assert np.abs(y2 - y).max() <= 1e-13 * np.abs(y).max()             # same products, different summation order
+    _, _, vb = B.download()
+    _, _, vc = C2.download()
+    assert np.array_equal(vb.view(np.uint64), vc.view(np.uint64))
+
+
+@pytest.mark.parametrize("n_values,real", [(300, False), (1024, True), (1025, False), (5000, False), (70000, False)])
+def test_two_byte_value_codes(n_values, real):
+    """Matrices with 257..65536 distinct values are stored with 2-byte codes (dictionary in LDS up to 1024
+    entries, read through the caches beyond); results carry the same bits as the uncoded operator."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(n_values)
+    n, per_row = 6000, 24
+    pool = rng.normal(size=n_values) + (0 if real else 1j) * rng.normal(size=n_values)
+    rows = np.repeat(np.arange(n), per_row)
+    cols = rng.integers(0, n, size=n * per_row)
+    keep = rows < cols
+    U = sp.csr_matrix((pool[rng.integers(0, n_values, size=keep.sum())], (rows[keep], cols[keep])), shape=(n, n), dtype=np.complex128)
+    U.sum_duplicates()
+    U.data = pool[np.arange(U.nnz) % n_values]                      # duplicates summed: re-draw from the pool
+    dg = sp.diags(pool.real[np.arange(n) % n_values]).astype(np.complex128)
+    M = (U + U.getH() + dg).tocsr()
+    M.sort_indices()
+    ia, ja, val = M.indptr.astype(np.int64), M.indices.astype(np.int64), M.data.astype(np.complex128)
+    distinct = len(np.unique(val))
+    A = q.csr_mat(n, ia, ja, val, sym=False, opts=q.make_opts(value_dict=1))
+    P = q.csr_mat(n, ia, ja, val, sym=False, opts=q.make_opts(value_dict=0))
+    if distinct <= 65536:
+        assert A.info().value_dict == distinct
+    else:
+        assert A.info().value_dict == 0
+    one_byte = q.csr_mat(n, ia, ja, val, sym=False, opts=q.make_opts(value_dict=2))
+    assert one_byte.info().value_dict == 0                           # value_dict=2: one-byte codes or nothing
+    one_byte.destroy()
+    x = _rand(n, 3)
+    if real:
+        x = x.real.astype(np.complex128)
+    ya, yp = np.empty_like(x), np.empty_like(x)
+    A.MultMv(x, ya)
+    P.MultMv(x, yp)
+    assert np.abs(ya - M @ x).max() <= 1e-12 * np.abs(ya).max()
+    # the coded kernel stages 4096 nonzeros per workgroup, the uncoded one 2048 with 4 lanes per row: the
+    # summation order differs, the values multiplied do not
+    assert np.abs(ya - yp).max() <= 1e-13 * np.abs(ya).max()
+    _, ja_d, va = A.download()
+    assert np.array_equal(ja_d, ja) and np.array_equal(va.view(np.uint64), val.view(np.uint64))
+    ra = q.locate_E0_lanczos(A, nev=1, ncv=1, maxit=600)
+    rp = q.locate_E0_lanczos(P, nev=1, ncv=1, maxit=600)
+    assert abs(ra.E0 - rp.E0) <= 1e-10 * abs(rp.E0)
+    if real and distinct <= 65536:
+        assert A.stats().n_spmv_real > 0                              # real fast path also with 2-byte codes
 
 
 def test_ragged_and_degenerate_shapes():
