@@ -392,6 +392,7 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
         (void)hipFree(A->mf.tgt_d);
         (void)hipFree(A->mf.val_u);
         (void)hipFree(A->mf.val_d);
+        if (A->mf.pk_d) (void)hipFree(A->mf.pk_d);
     }
     if (A->ev2) (void)hipEventDestroy(A->ev2);
     if (A->ev3) (void)hipEventDestroy(A->ev3);
@@ -800,7 +801,8 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
             harvest_events(A);
             QBH_HIP(hipEventRecord(A->ev0, A->stream));
         }
-        QBH_TRY(qbh::launch_mf_hubbard(m, A->grid, A->stream));
+        int mf_parts = A->grid;
+        QBH_TRY(qbh::launch_mf_hubbard(m, A->grid, A->stream, &mf_parts));
         if (profm) {
             QBH_HIP(hipEventRecord(A->ev1, A->stream));
             A->ev_pending = true;
@@ -809,7 +811,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         A->stats.n_spmv++;
         if (realm) A->stats.n_spmv_real++;
         if (red) {
-            QBH_TRY(finish_reduction(A, A->grid, 3, red));
+            QBH_TRY(finish_reduction(A, mf_parts, 3, red));
             if (profm) harvest_events(A);
         }
         return QBH_OK;

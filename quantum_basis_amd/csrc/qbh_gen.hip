@@ -483,6 +483,21 @@ extern "C" int qbh_mf_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, in
     QBH_TRY(upload_ell(vu, amp, &m.wu, &m.tgt_u, &m.val_u));
     QBH_TRY(upload_ell(vd, amp, &m.wd, &m.tgt_d, &m.val_d));
     for (size_t c = 0; c < amp.size(); ++c) m.amp[c] = amp[c];
+    {   // packed copy of the down-species table for the row-staged kernel
+        std::vector<uint32_t> pk((size_t)m.wd * Nd, 0u);
+        for (int64_t d = 0; d < Nd; ++d)
+            for (int k = 0; k < m.wd; ++k) pk[((size_t)(k / 4) * Nd + d) * 4 + (k & 3)] = (uint32_t)d;     // padding: self, code 0
+        for (int64_t d = 0; d < Nd; ++d)
+            for (int q = hd.ptr[d]; q < hd.ptr[d + 1]; ++q) {
+                const int k = q - hd.ptr[d];
+                int code = 0;
+                for (size_t c = 0; c < amp.size(); ++c)
+                    if (amp[c] == hd.val[q]) code = (int)c;
+                pk[((size_t)(k / 4) * Nd + d) * 4 + (k & 3)] = (uint32_t)hd.tgt[q] | ((uint32_t)code << 16);
+            }
+        QBH_HIP(hipMalloc(&m.pk_d, pk.size() * sizeof(uint32_t)));
+        QBH_HIP(hipMemcpy(m.pk_d, pk.data(), pk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     return adopt_mf_hubbard(out, m, row_end - row_begin, dim, row_begin, rowptr(row_end) - rowptr(row_begin), opts);
 }
 

@@ -112,6 +112,9 @@ struct MfHubbard {
     // 1-byte codes into amp[] (<= 16 distinct hopping amplitudes: +-t times the bond multiplicity, and 0)
     uint16_t *tgt_u = nullptr, *tgt_d = nullptr;
     uint8_t  *val_u = nullptr, *val_d = nullptr;
+    // down-species table once more as packed words {target | code << 16}, hops 4j..4j+3 of configuration c in the
+    // 16 bytes at [(j * N + c) * 4] (one coalesced load per four hops in the row-staged kernel)
+    uint32_t *pk_d = nullptr;
     double    amp[16] = {0};
 };
 
@@ -124,7 +127,7 @@ struct MfArgs {
     double alpha, beta, gamma;
     double *partials;
 };
-int launch_mf_hubbard(const MfArgs &a, int grid, hipStream_t s);
+int launch_mf_hubbard(const MfArgs &a, int grid, hipStream_t s, int *nparts_out);
 // adopt a matrix-free operator (tables already in HBM) behind a qbh_csr handle (qbh_api.cpp)
 int adopt_mf_hubbard(qbh_csr **out, const MfHubbard &t, int64_t nrows, int64_t ncols, int64_t row_offset,
                      int64_t nnz_equiv, const qbh_opts *opts);

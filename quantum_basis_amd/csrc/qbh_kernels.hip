@@ -1537,11 +1537,152 @@ __global__ __launch_bounds__(kBlock) void k_mf_hubbard(MfArgs a)
     }
 }
 
-int launch_mf_hubbard(const MfArgs &a, int grid, hipStream_t s)
+// Row-staged variant for real vectors: X is the N_up x N_dn matrix x[u * N_dn + d].  One 1024-lane workgroup owns one
+// up-configuration u at a time and keeps the whole row X[u][:] (8 * N_dn bytes) in LDS, so
+//   * the down-species hops  Y[u][d] += sum_k a_k X[u][d'_k]  gather from LDS instead of through the texture path
+//     (scattered 8-byte gathers are what bounds the lane-per-row kernel: one cache line per lane per cycle),
+//   * the up-species hops  Y[u][:] += sum_j a_j X[u'_j][:]  are row AXPYs: fully coalesced 512-byte wave loads, the
+//     ~17 neighbour rows shared through L2 / Infinity Cache with the workgroups working on nearby u,
+//   * x_local of the fused epilogue comes from the staged row for free.
+// The down-hop table is read as packed {target:16 | amplitude code:8} words, four hops per 16-byte load.
+constexpr int kMfRowBlock = 1024;
+constexpr int kMfMaxUp = 64;
+
+__global__ __launch_bounds__(kMfRowBlock) void k_mf_hubbard_row(MfArgs a)
 {
+    extern __shared__ double xs[];                 // [Nd]
+    __shared__ double amp_s[16];
+    __shared__ long long up_off[kMfMaxUp + 8];
+    __shared__ double up_amp[kMfMaxUp + 8];
+    __shared__ int up_n;
+    __shared__ double red[3 * (kMfRowBlock / 64)];
+    const MfHubbard &t = a.t;
+    const int tid = threadIdx.x;
+    const int64_t Nd = t.Nd;
+    double acc[3] = {0.0, 0.0, 0.0};
+    if (tid < 16) amp_s[tid] = t.amp[tid];
+    const int64_t u_first = a.row_begin / Nd, u_last = (a.row_begin + a.nrows - 1) / Nd;
+    const bool need_y = a.beta != 0.0;
+    const uint4 *pk = reinterpret_cast<const uint4 *>(t.pk_d);
+    const int nk4 = t.wd / 4;
+    for (int64_t u = u_first + blockIdx.x; u <= u_last; u += gridDim.x) {
+        const double *xrow = a.xr + u * Nd;
+        for (int64_t d = tid; d < Nd; d += kMfRowBlock) xs[d] = xrow[d];
+        if (tid < 64) {
+            // the up-neighbours of u with a non-zero amplitude, compacted by one wavefront and padded to a group of 8
+            // with (u itself, amplitude 0) so that the row loop below is branch-free
+            const bool in = tid < t.wu;
+            const int code = in ? t.val_u[(size_t)tid * t.Nu + u] : 0;
+            const bool live = in && code != 0;
+            const unsigned long long mask = __ballot(live);
+            const int pos = __popcll(mask & ((1ULL << tid) - 1ULL));
+            const int n = __popcll(mask);
+            if (live) {
+                up_off[pos] = (long long)t.tgt_u[(size_t)tid * t.Nu + u] * Nd;
+                up_amp[pos] = amp_s[code];
+            }
+            const int npad = (n + 7) & ~7;
+            if (tid >= n && tid < npad) {
+                up_off[tid] = (long long)u * Nd;
+                up_amp[tid] = 0.0;
+            }
+            if (tid == 0) up_n = npad;
+        }
+        __syncthreads();
+        const int64_t d_lo = a.row_begin > u * Nd ? a.row_begin - u * Nd : 0;
+        const int64_t d_hi = (a.row_begin + a.nrows - u * Nd) < Nd ? (a.row_begin + a.nrows - u * Nd) : Nd;
+        const uint32_t cu = t.cfg_u[u];
+        const int nu = up_n;
+        for (int64_t d = d_lo + tid; d < d_hi; d += kMfRowBlock) {
+            const double xd = xs[d];
+            double sum = t.U * (double)__popc(cu & t.cfg_d[d]) * xd;
+            // up-species hops first (global, longest latency): 8 coalesced row loads in flight
+            for (int j0 = 0; j0 < nu; j0 += 8) {
+                double xv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[j] = a.xr[up_off[j0 + j] + d];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += up_amp[j0 + j] * xv[j];
+            }
+            // down-species hops from the staged row
+            for (int k4 = 0; k4 < nk4; k4 += 2) {
+                const uint4 e0 = pk[(size_t)k4 * Nd + d], e1 = pk[(size_t)(k4 + 1) * Nd + d];
+                const uint32_t w[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+                double xv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[j] = xs[w[j] & 0xFFFFu];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += amp_s[w[j] >> 16] * xv[j];
+            }
+            const int64_t lrow = u * Nd + d - a.row_begin;
+            d2 yo = {0.0, 0.0};
+            if (need_y) yo = a.y[lrow];
+            d2 yn;
+            yn.x = a.alpha * sum + a.beta * yo.x + a.gamma * xd;
+            yn.y = a.beta * yo.y;
+            a.y[lrow] = yn;
+            acc[0] += xd * yn.x;
+            acc[1] += xd * yn.y;
+            acc[2] += yn.x * yn.x + yn.y * yn.y;
+        }
+        __syncthreads();                           // the row and the neighbour list are rewritten next
+    }
+    if (a.partials != nullptr) {
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = wave_sum(acc[c]);
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) red[c * (kMfRowBlock / 64) + wave] = acc[c];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int c = 0; c < 3; ++c) {
+                double v = 0.0;
+                for (int w2 = 0; w2 < kMfRowBlock / 64; ++w2) v += red[c * (kMfRowBlock / 64) + w2];
+                a.partials[(size_t)blockIdx.x * 3 + c] = v;
+            }
+        }
+    }
+}
+
+// true when the row-staged kernel applies: real vectors, the row fits LDS, the neighbour list fits one wavefront
+bool mf_row_kernel_ok(const MfArgs &a)
+{
+    if (a.xr == nullptr || a.t.pk_d == nullptr) return false;
+    if (const char *e = getenv("QBH_MF_ROW")) {
+        if (!atoi(e)) return false;
+    }
+    return a.t.Nd >= 256 && a.t.Nd * 8 <= 150 * 1024 && a.t.wu <= kMfMaxUp && (a.t.wd % 8) == 0;
+}
+
+// *nparts_out = number of partial-sum triples written (workgroups launched)
+int launch_mf_hubbard(const MfArgs &a, int grid, hipStream_t s, int *nparts_out)
+{
+    if (mf_row_kernel_ok(a)) {
+        static int ncu = 0;
+        if (ncu == 0) {
+            hipDeviceProp_t prop;
+            int dev = 0;
+            ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                      ? prop.multiProcessorCount : 256;
+        }
+        const size_t lds = (size_t)a.t.Nd * sizeof(double);
+        QBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_hubbard_row), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        const int64_t n_u = (a.row_begin + a.nrows - 1) / a.t.Nd - a.row_begin / a.t.Nd + 1;
+        // one workgroup per CU when the row takes most of the LDS, more when several rows fit
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (size_t)(150 * 1024) / (lds + 2048)));
+        const int g = (int)std::min<int64_t>(n_u, (int64_t)ncu * per_cu);
+        hipLaunchKernelGGL(k_mf_hubbard_row, dim3(g), dim3(kMfRowBlock), lds, s, a);
+        QBH_HIP(hipGetLastError());
+        if (nparts_out) *nparts_out = g;
+        return QBH_OK;
+    }
     if (a.xr != nullptr) hipLaunchKernelGGL((k_mf_hubbard<true>), dim3(grid), dim3(kBlock), 0, s, a);
     else                 hipLaunchKernelGGL((k_mf_hubbard<false>), dim3(grid), dim3(kBlock), 0, s, a);
     QBH_HIP(hipGetLastError());
+    if (nparts_out) *nparts_out = grid;
     return QBH_OK;
 }
 

@@ -78,7 +78,7 @@ def cpu_sharded_lanczos(rank, world, port, case_name, steps, out_dir):
     dist.destroy_process_group()
 
 
-def gpu_sharded_solver(rank, world, port, backend, out_dir, matrix_free=False):
+def gpu_sharded_solver(rank, world, port, backend, out_dir, matrix_free=False, shape="4x2"):
     """Real thing on the GPU: every rank builds its row shard on cuda:0 (single-GPU rig: the
     ranks share one device and exchange through gloo + host staging; with backend nccl and one
     rank the RCCL calls themselves are exercised) and runs qbh_lanczos_dev / CG under the
@@ -89,14 +89,15 @@ def gpu_sharded_solver(rank, world, port, backend, out_dir, matrix_free=False):
     import quantum_basis_amd as q
     from quantum_basis_amd import dist as qdist, lattices
 
-    bonds = lattices.square(4, 2)
-    dim = 4900
+    # 4x3 (924 x 924 configurations) is large enough for the row-staged matrix-free kernel; with 5 ranks the shard
+    # boundaries fall inside a row of the N_up x N_dn layout
+    L, ne, bonds, dim = (8, 4, lattices.square(4, 2), 4900) if shape == "4x2" else (12, 6, lattices.square(4, 3), 853776)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         opts = q.make_opts(device=0, stream=stream.cuda_stream)
         nblk, ranges = qdist.row_partition(dim, world)
         r0, r1 = ranges[rank]
-        A = q.csr_mat.hubbard(8, 4, 4, bonds, rows=(r0, r1), opts=opts, matrix_free=matrix_free)
+        A = q.csr_mat.hubbard(L, ne, ne, bonds, rows=(r0, r1), opts=opts, matrix_free=matrix_free)
         comm = qdist.ShardComm(dim, rank=rank, world=world, device=torch.device("cuda", 0), stream=stream).attach(A)
         res = q.locate_E0_lanczos(A, nev=2, ncv=1, maxit=400)
         assert not comm.errors, comm.errors

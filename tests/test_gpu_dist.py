@@ -86,3 +86,20 @@ def test_sharded_repr_sector_generated_per_rank(world):
     # (the 22 decoupled rows at 100 + i/dim stretch the spectrum: the stop rule fires within a few steps, not +-1)
     assert abs(res[0] - ref.E0) <= 1e-10 * abs(ref.E0) and abs(res[1] - ref.steps["E0"]) <= 4
     assert abs(abs(np.vdot(vec, ref.eigenvecs)) - 1.0) < 1e-8 and np.abs(vec.imag).max() > 1e-3
+
+
+def test_sharded_matrix_free_row_kernel_with_ragged_shards():
+    """Hubbard 4x3 (dim 853,776), matrix-free, 5 ranks: every shard starts and ends inside a row of the
+    N_up x N_dn layout, and the real Lanczos vectors take the row-staged kernel."""
+    import torch.multiprocessing as mp
+    import dist_worker
+    world = 5
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(dist_worker.gpu_sharded_solver, args=(world, _free_port(), "gloo", tmp, True, "4x3"), nprocs=world, join=True)
+        res = np.load(tmp + "/res.npy")
+        vec = np.concatenate([np.load(tmp + "/vec_%d.npy" % r) for r in range(world)])
+    A = q.csr_mat.hubbard(12, 6, 6, lattices.square(4, 3))
+    ref = q.locate_E0_lanczos(A, nev=2, ncv=1, maxit=400)
+    assert abs(res[0] - ref.E0) <= 1e-10 * abs(ref.E0) and abs(res[1] - ref.E1) < 1e-8
+    assert abs(res[2] - ref.steps["E0"]) <= 1
+    assert abs(abs(np.vdot(vec, ref.eigenvecs)) - 1.0) < 1e-8
