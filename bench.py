@@ -55,6 +55,14 @@ def workloads():
     }
 
 
+def traffic_of(key):
+    """HBM bytes per launch measured in separate rocprofv3 --pmc passes (profiles/traffic.json), or None"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[key]["hbm_bytes"]
+    except Exception:
+        return None
+
+
 def dim_of(w):
     from math import comb
     if w["kind"] == "hubbard":
@@ -323,7 +331,8 @@ def main():
                 pms = ps.ms_spmv / max(ps.n_spmv, 1)
                 out["roofline_plain_values"] = {"kernel": "k_spmv_rows (complex128 values)", "ms_per_launch": round(pms, 4),
                                                 "achieved": round(bytes_launch / pms / 1e6, 2), "unit": "GB/s",
-                                                "frac": round(bytes_launch / pms / 1e6 / HBM_PEAK_GBPS, 4), "launches": int(ps.n_spmv)}
+                                                "frac": round(bytes_launch / pms / 1e6 / HBM_PEAK_GBPS, 4), "launches": int(ps.n_spmv),
+                                                "traffic": traffic_of("%s|rows|plain" % args.workload)}
                 pv.free()
                 P.destroy()
         except Exception as e:
@@ -351,7 +360,10 @@ def main():
                                               "spmv_ms_per_launch": round(mms, 4),
                                               "equivalent_csr_GBps": round(bytes_launch / mms / 1e6, 2),
                                               "table_bytes": int(M.info().bytes_matrix),
-                                              "note": "no stored matrix; not the CSR north-star path"}
+                                              "kernel": "k_mf_hubbard_row" if ms_.n_spmv_real > 0 else "k_mf_hubbard",
+                                              "traffic": traffic_of("%s|matrix_free|plain%s" % (args.workload, "|real" if ms_.n_spmv_real > 0 else "")),
+                                              "note": "no stored matrix; not the CSR north-star path; traffic = HBM bytes per "
+                                                      "apply from the rocprofv3 --pmc passes under profiles/"}
                 mv.free()
                 M.destroy()
         except Exception as e:
