@@ -308,7 +308,7 @@ int finalize(qbh_csr *A)
         grid_max = std::max(grid_max, R.grid);
     }
     const size_t nparts = (size_t)std::max(grid_max, qbh::kMaxRedBlocks);
-    QBH_HIP(hipMalloc(&A->d_partials, nparts * 4 * sizeof(double)));
+    QBH_HIP(hipMalloc(&A->d_partials, nparts * 16 * sizeof(double)));
     QBH_HIP(hipStreamSynchronize(s));
     A->stats = qbh_stats{};
     A->stats.ms_spmv_min = std::numeric_limits<double>::infinity();
@@ -621,7 +621,7 @@ int qbh::adopt_mf_hubbard(qbh_csr **out, const qbh::MfHubbard &t, int64_t nrows,
         hipEventCreate(&A->ev2) != hipSuccess || hipEventCreate(&A->ev3) != hipSuccess)
         return fail(QBH_EHIP);
     const size_t nparts = (size_t)std::max(A->grid, qbh::kMaxRedBlocks);
-    if (hipMalloc(&A->d_partials, nparts * 4 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (hipMalloc(&A->d_partials, nparts * 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
     A->stats = qbh_stats{};
     A->stats.ms_spmv_min = std::numeric_limits<double>::infinity();
     *out = A;

@@ -180,7 +180,7 @@ struct qbh_csr {
     int      grid = 0;
 
     // workspace
-    double  *d_partials = nullptr;   // [max(grid, kMaxRedBlocks) * 4]
+    double  *d_partials = nullptr;   // [max(grid, kMaxRedBlocks) * 16]: up to 16 partial sums per workgroup (k_multi_dot<8>)
     double  *d_scal = nullptr;       // [16] reduction results (library-owned unless comm)
     double  *h_scal = nullptr;       // pinned mirror
     qbh::d2 *d_stage_x = nullptr, *d_stage_y = nullptr;   // host-vector seam staging

@@ -1548,9 +1548,14 @@ __global__ __launch_bounds__(kBlock) void k_mf_hubbard(MfArgs a)
 constexpr int kMfRowBlock = 1024;
 constexpr int kMfMaxUp = 64;
 
-__global__ __launch_bounds__(kMfRowBlock) void k_mf_hubbard_row(MfArgs a)
+// WINDOWED = false: the whole row X[u][:] is staged (8 * N_dn <= LDS).  WINDOWED = true (longer rows): a work item is
+// (u, chunk of `chunk` consecutive d); LDS holds the window of `wcap` elements of the row centred on the chunk.  Hops
+// in the colex order mostly move a configuration's rank a little (4x5 lattice, 6 particles: 84 % of the hops stay
+// within +-8192), so most down-hop gathers still come from LDS; the rest read the row through L2.
+template <bool WINDOWED>
+__global__ __launch_bounds__(kMfRowBlock) void k_mf_hubbard_row(MfArgs a, int chunk, int wcap)
 {
-    extern __shared__ double xs[];                 // [Nd]
+    extern __shared__ double xs[];                 // [Nd] or [wcap]
     __shared__ double amp_s[16];
     __shared__ long long up_off[kMfMaxUp + 8];
     __shared__ double up_amp[kMfMaxUp + 8];
@@ -1565,9 +1570,25 @@ __global__ __launch_bounds__(kMfRowBlock) void k_mf_hubbard_row(MfArgs a)
     const bool need_y = a.beta != 0.0;
     const uint4 *pk = reinterpret_cast<const uint4 *>(t.pk_d);
     const int nk4 = t.wd / 4;
-    for (int64_t u = u_first + blockIdx.x; u <= u_last; u += gridDim.x) {
+    const int64_t n_chunks = WINDOWED ? (Nd + chunk - 1) / chunk : 1;
+    const int64_t n_items = (u_last - u_first + 1) * n_chunks;
+    for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int64_t u = u_first + item / n_chunks;
+        const int64_t c_lo = WINDOWED ? (item % n_chunks) * chunk : 0;
+        const int64_t c_hi = WINDOWED ? (c_lo + chunk < Nd ? c_lo + chunk : Nd) : Nd;
+        // window [w_lo, w_hi) of the row kept in LDS
+        int64_t w_lo = 0, w_hi = Nd;
+        if (WINDOWED) {
+            w_lo = c_lo - (wcap - (c_hi - c_lo)) / 2;
+            if (w_lo < 0) w_lo = 0;
+            w_hi = w_lo + wcap;
+            if (w_hi > Nd) {
+                w_hi = Nd;
+                w_lo = w_hi - wcap > 0 ? w_hi - wcap : 0;
+            }
+        }
         const double *xrow = a.xr + u * Nd;
-        for (int64_t d = tid; d < Nd; d += kMfRowBlock) xs[d] = xrow[d];
+        for (int64_t d = w_lo + tid; d < w_hi; d += kMfRowBlock) xs[d - w_lo] = xrow[d];
         if (tid < 64) {
             // the up-neighbours of u with a non-zero amplitude, compacted by one wavefront and padded to a group of 8
             // with (u itself, amplitude 0) so that the row loop below is branch-free
@@ -1589,12 +1610,14 @@ __global__ __launch_bounds__(kMfRowBlock) void k_mf_hubbard_row(MfArgs a)
             if (tid == 0) up_n = npad;
         }
         __syncthreads();
-        const int64_t d_lo = a.row_begin > u * Nd ? a.row_begin - u * Nd : 0;
-        const int64_t d_hi = (a.row_begin + a.nrows - u * Nd) < Nd ? (a.row_begin + a.nrows - u * Nd) : Nd;
+        int64_t d_lo = a.row_begin > u * Nd ? a.row_begin - u * Nd : 0;
+        int64_t d_hi = (a.row_begin + a.nrows - u * Nd) < Nd ? (a.row_begin + a.nrows - u * Nd) : Nd;
+        if (d_lo < c_lo) d_lo = c_lo;
+        if (d_hi > c_hi) d_hi = c_hi;
         const uint32_t cu = t.cfg_u[u];
         const int nu = up_n;
         for (int64_t d = d_lo + tid; d < d_hi; d += kMfRowBlock) {
-            const double xd = xs[d];
+            const double xd = xs[d - w_lo];
             double sum = t.U * (double)__popc(cu & t.cfg_d[d]) * xd;
             // up-species hops first (global, longest latency): 8 coalesced row loads in flight
             for (int j0 = 0; j0 < nu; j0 += 8) {
@@ -1609,8 +1632,25 @@ __global__ __launch_bounds__(kMfRowBlock) void k_mf_hubbard_row(MfArgs a)
                 const uint4 e0 = pk[(size_t)k4 * Nd + d], e1 = pk[(size_t)(k4 + 1) * Nd + d];
                 const uint32_t w[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
                 double xv[8];
+                if (WINDOWED) {
+                    bool miss[8];
+                    bool any_miss = false;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xv[j] = xs[w[j] & 0xFFFFu];
+                    for (int j = 0; j < 8; ++j) {
+                        const int64_t tg = (int64_t)(w[j] & 0xFFFFu);
+                        miss[j] = tg < w_lo || tg >= w_hi;
+                        any_miss = any_miss || miss[j];
+                        xv[j] = xs[miss[j] ? 0 : tg - w_lo];
+                    }
+                    if (any_miss) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (miss[j]) xv[j] = xrow[w[j] & 0xFFFFu];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[j] = xs[w[j] & 0xFFFFu];
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) sum += amp_s[w[j] >> 16] * xv[j];
             }
@@ -1646,14 +1686,14 @@ __global__ __launch_bounds__(kMfRowBlock) void k_mf_hubbard_row(MfArgs a)
     }
 }
 
-// true when the row-staged kernel applies: real vectors, the row fits LDS, the neighbour list fits one wavefront
+// true when a row-staged kernel applies: real vectors, the neighbour list fits one wavefront
 bool mf_row_kernel_ok(const MfArgs &a)
 {
     if (a.xr == nullptr || a.t.pk_d == nullptr) return false;
     if (const char *e = getenv("QBH_MF_ROW")) {
         if (!atoi(e)) return false;
     }
-    return a.t.Nd >= 256 && a.t.Nd * 8 <= 150 * 1024 && a.t.wu <= kMfMaxUp && (a.t.wd % 8) == 0;
+    return a.t.Nd >= 256 && a.t.Nd <= 65535 && a.t.wu <= kMfMaxUp && (a.t.wd % 8) == 0;
 }
 
 // *nparts_out = number of partial-sum triples written (workgroups launched)
@@ -1667,14 +1707,31 @@ int launch_mf_hubbard(const MfArgs &a, int grid, hipStream_t s, int *nparts_out)
             ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                       ? prop.multiProcessorCount : 256;
         }
-        const size_t lds = (size_t)a.t.Nd * sizeof(double);
-        QBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_hubbard_row), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
+        const size_t lds_cap = (size_t)150 * 1024;
+        const bool windowed = (size_t)a.t.Nd * sizeof(double) > lds_cap;
         const int64_t n_u = (a.row_begin + a.nrows - 1) / a.t.Nd - a.row_begin / a.t.Nd + 1;
-        // one workgroup per CU when the row takes most of the LDS, more when several rows fit
-        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (size_t)(150 * 1024) / (lds + 2048)));
-        const int g = (int)std::min<int64_t>(n_u, (int64_t)ncu * per_cu);
-        hipLaunchKernelGGL(k_mf_hubbard_row, dim3(g), dim3(kMfRowBlock), lds, s, a);
+        if (!windowed) {
+            const size_t lds = (size_t)a.t.Nd * sizeof(double);
+            QBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_hubbard_row<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            // one workgroup per CU when the row takes most of the LDS, more when several rows fit
+            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, lds_cap / (lds + 2048)));
+            const int g = (int)std::min<int64_t>(n_u, (int64_t)ncu * per_cu);
+            hipLaunchKernelGGL(k_mf_hubbard_row<false>, dim3(g), dim3(kMfRowBlock), lds, s, a, 0, 0);
+            QBH_HIP(hipGetLastError());
+            if (nparts_out) *nparts_out = g;
+            return QBH_OK;
+        }
+        int chunk = 4096, wcap = 18432;                // 144 KB window around a 4096-element chunk
+        if (const char *e = getenv("QBH_MF_CHUNK")) chunk = std::max(1024, atoi(e));
+        if (const char *e = getenv("QBH_MF_WINDOW")) wcap = std::max(chunk, std::min(18432, atoi(e)));
+        const size_t lds = (size_t)wcap * sizeof(double);
+        QBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_hubbard_row<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int64_t n_items = n_u * ((a.t.Nd + chunk - 1) / chunk);
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, lds_cap / (lds + 2048)));
+        const int g = (int)std::min<int64_t>(n_items, (int64_t)ncu * per_cu);
+        hipLaunchKernelGGL(k_mf_hubbard_row<true>, dim3(g), dim3(kMfRowBlock), lds, s, a, chunk, wcap);
         QBH_HIP(hipGetLastError());
         if (nparts_out) *nparts_out = g;
         return QBH_OK;
