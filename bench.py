@@ -305,7 +305,7 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                      "bytes_per_launch": bytes_launch, "ms_per_launch": round(ms_spmv, 4), "launches": int(st.n_spmv),
                      "note": "achieved = ALGORITHMIC bytes (SURVEY 8d: nnz*20 + rows*40) / kernel time; the kernel moves fewer "
-                             "bytes than that (traffic) because values are dictionary-coded (1 B instead of 16 B, lossless) and, for a "
+                             "bytes than that (traffic) because values are dictionary-coded (1 or 2 B instead of 16 B, lossless) and, for a "
                              "real operator and real vectors, x is gathered as 8-byte real parts (bit-identical result)"},
         "e0": e0, "lanczos_steps_to_converge": steps_e0,
     }

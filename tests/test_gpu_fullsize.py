@@ -174,3 +174,43 @@ def test_full_size_matrix_free_equals_csr(ops):
     assert diff <= 1e-13 * hx
     v.free()
     M.destroy()
+
+
+def test_momentum_sector_at_scale_coded_equals_uncoded():
+    """Triangular 6x6, N_dn = 12, k = (1,0): dim 34,770,492, nnz 1.75e9, genuinely complex, 2262 distinct values.
+    Size-independent properties: Hermiticity with complex vectors, linearity, 2-byte-coded operator = uncoded operator,
+    same E0 from both (and the value the first measured run gave)."""
+    perms, shifts = lattices.translations(6, 6)
+    chars = lattices.characters(shifts, (1, 0), (6, 6))
+    bonds = lattices.triangular(6, 6)
+    A = q.csr_mat.heisenberg_repr(36, 12, bonds, perms, chars)
+    P = q.csr_mat.heisenberg_repr(36, 12, bonds, perms, chars, opts=q.make_opts(value_dict=0))
+    n = A.dim
+    assert n == P.dim == 34770492 and A.nnz == P.nnz == 1751243532
+    assert 256 < A.info().value_dict <= 65536 and P.info().value_dict == 0
+    ia1, ja1, v1 = A.download(1000000, 1000100)
+    ia2, ja2, v2 = P.download(1000000, 1000100)
+    assert np.array_equal(ia1, ia2) and np.array_equal(ja1, ja2) and np.array_equal(v1.view(np.uint64), v2.view(np.uint64))
+    assert np.abs(v1.imag).max() > 0.05
+    v = A.vec(5)
+    A.randomize(v.at(0), 1)
+    A.randomize(v.at(n), 2)
+    A.axpy_norm(0.75j, v.at(n), v.at(0))                 # x = r1 + 0.75i r2: complex
+    A.spmv(v.at(0), v.at(2 * n))                         # Hx
+    A.spmv(v.at(n), v.at(3 * n))                         # Hy
+    lhs = A.dotc(v.at(0), v.at(3 * n))                   # <x, Hy>
+    rhs = A.dotc(v.at(2 * n), v.at(n))                   # <Hx, y>
+    assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), 1e-3)
+    assert abs(lhs.imag) > 1e-6                          # the sector really is complex
+    A.sync()
+    P.spmv(v.at(0), v.at(4 * n))
+    P.sync()
+    hx = A.nrm2(v.at(2 * n))
+    assert np.sqrt(A.axpy_norm(-1.0, v.at(2 * n), v.at(4 * n))) <= 1e-13 * hx
+    v.free()
+    ra = q.locate_E0_lanczos(A, nev=1, ncv=1, maxit=600)
+    assert abs(ra.E0 - (-13.816629006229)) < 1e-9
+    x = ra.eigenvecs
+    assert abs(np.linalg.norm(x) - 1.0) < 1e-12 and np.abs(x.imag).max() > 1e-6
+    A.destroy()
+    P.destroy()
