@@ -253,6 +253,37 @@ def test_momentum_sectors_complex_phases_known_answers(k):
     assert abs(res.E0 - ans["E0_k"][k]) < ans["tol"]
 
 
+@pytest.mark.parametrize("name", ["bose_hubbard_3x3", "spinless_honeycomb", "spin1_chain"])
+def test_more_example_model_families(name):
+    """Three more of the reference's example programs on the GPU path: the spin-1 chain runs all four stages
+    (E0 -> V0 -> E1 -> V1, examples/trans_absent/latt_chain/chain_Heisenberg_spin_one.cc:92-97), the honeycomb
+    spinless-fermion model arrives in FULL storage (generate_Ham_sparse_full(0, false)), Bose-Hubbard has
+    sqrt(n) amplitudes (many distinct values)."""
+    import refmodels
+    k = refmodels.KNOWN[name]
+    d, ia, ja, val, sym = refmodels.CASES[name]()
+    A = q.csr_mat(d, ia, ja, val, sym)
+    O = qo.Csr(d, ia, ja, val, sym)
+    x = _rand(d, 21)
+    y = np.empty_like(x)
+    A.MultMv(x, y)
+    assert _close(y, O.multmv(x))
+    if "E1" in k:
+        res = q.locate_E0_lanczos(A, nev=2, ncv=2)
+        ro = qo.locate_E0_lanczos(O, nev=2, ncv=2)
+        assert abs(res.E1 - k["E1"]) < k["tol"] and abs(res.E1 - ro["E1"]) < 1e-8
+        v0, v1 = res.eigenvecs[:d], res.eigenvecs[d:]
+        assert abs(np.vdot(v0, v1)) < 1e-8
+        assert np.linalg.norm(O.multmv(v1) - res.E1 * v1) < 1e-6
+    else:
+        res = q.locate_E0_lanczos(A, nev=1, ncv=1)
+        ro = qo.locate_E0_lanczos(O, nev=1, ncv=1)
+    assert abs(res.E0 - k["E0"]) < k["tol"] and abs(res.E0 - ro["E0"]) <= E0_RTOL * abs(ro["E0"])
+    assert abs(res.steps["E0"] - ro["m_E0"]) <= 2
+    v0 = res.eigenvecs[:d]
+    assert np.linalg.norm(O.multmv(v0) - res.E0 * v0) < 1e-7
+
+
 def test_gauged_complex_hubbard_energy():
     d, ia, ja, val, sym = helpers.case("hubbard_4x2")
     valc, _ = helpers.gauge(d, ia, ja, val)

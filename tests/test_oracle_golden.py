@@ -116,6 +116,23 @@ def test_example_ground_state_energies(name):
     assert abs(r["E0"] - k["E0"]) < k["tol"]
 
 
+@pytest.mark.parametrize("name", ["bose_hubbard_3x3", "spinless_honeycomb", "spin1_chain"])
+def test_more_example_model_families(name):
+    """Spin-1 chain (E0 and E1: the two-state path the example runs, locate_E0_lanczos(full, 2, 2)), truncated
+    Bose-Hubbard and spinless fermions on the honeycomb lattice (FULL storage, as the example generates it)."""
+    import refmodels
+    k = refmodels.KNOWN[name]
+    d, ia, ja, val, sym = refmodels.CASES[name]()
+    assert sym == (name != "spinless_honeycomb")
+    A = qo.Csr(d, ia, ja, val, sym)
+    if "E1" in k:
+        r = qo.locate_E0_lanczos(A, nev=2, ncv=2)
+        assert abs(r["E1"] - k["E1"]) < k["tol"]
+    else:
+        r = qo.locate_E0_lanczos(A, ncv=0)
+    assert abs(r["E0"] - k["E0"]) < k["tol"]
+
+
 @pytest.mark.parametrize("k", [0, 1, 3, 8, 13])
 def test_momentum_sector_energies_complex_phases(k):
     """examples/trans_symmetric/latt_chain/...:102-117: per-momentum E0, complex Hermitian CSR."""
