@@ -1303,17 +1303,26 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
         }
 
         if (is_val) {                                      // :228-247
-            rc = qbh::tridiag_eigen_lastrow(m, a, b + 1, w.data(), zl.data());
+            // the four lowest Ritz values and the last component of the lowest Ritz vector: all the test below
+            // uses of hess_eigen's full decomposition (src/lanczos.cc:229-231), in O(m) instead of O(m^2..m^3)
+            double zl0 = 0.0;
+            const int nsm = (int)std::min<int64_t>(4, m);
+            for (int q = 0; q < 4; ++q) ws[(size_t)q] = 0.0;
+            rc = qbh::tridiag_lowest(m, a, b + 1, nsm, ws.data(), &zl0);
+            if (rc == QBH_ENOCONV) {           // overflow guard of the twisted factorisation: fall back to QL
+                rc = qbh::tridiag_eigen_lastrow(m, a, b + 1, w.data(), zl.data());
+                if (rc != QBH_OK) break;
+                int64_t imin = 0;
+                for (int64_t j = 1; j < m; ++j)
+                    if (w[j] < w[imin]) imin = j;
+                std::copy(w.begin(), w.begin() + m, ws.begin());
+                std::partial_sort(ws.begin(), ws.begin() + nsm, ws.begin() + m);
+                zl0 = zl[(size_t)imin];
+            }
             if (rc != QBH_OK) break;
-            int64_t imin = 0;
-            for (int64_t j = 1; j < m; ++j)
-                if (w[j] < w[imin]) imin = j;
-            const int64_t nsm = std::min<int64_t>(4, m);
-            std::copy(w.begin(), w.begin() + m, ws.begin());
-            std::partial_sort(ws.begin(), ws.begin() + nsm, ws.begin() + m);
             const double ritz0 = ws[0], ritz1 = m > 1 ? ws[1] : 0.0;
             if (m > 3) {
-                accuracy = std::fabs(b[m] * zl[imin]);
+                accuracy = std::fabs(b[m] * zl0);
                 const double accu_E0 = std::fabs((ritz0 - theta0_prev) / ritz0);
                 const double accu_E1 = std::fabs((ritz1 - theta1_prev) / ritz1);
                 if (info && info->log && info->log_len < info->log_cap) {

@@ -102,6 +102,141 @@ int tridiag_eigen_lastrow(int64_t m, const double *a, const double *b1, double *
 }
 
 
+// The per-step stop test of lanczos() (src/lanczos.cc:228-247) needs only the few lowest Ritz values and the LAST
+// component of the lowest Ritz vector (accuracy = |b_m s_{m-1}|).  The reference solves the whole m x m problem with
+// dstedc every step (K9 in SURVEY 2.3); even the O(m^2) QL above costs 4 ms at m = 300 and 40 ms at m = 1000 per
+// step on the host -- as much as the device work of a step.  Here: bisection on the Sturm count for the nev lowest
+// eigenvalues (O(m) per evaluation, ~55 evaluations each, to ~1 ulp of the spectrum's scale) and the eigenvector's
+// last component from the twisted factorisation (top-down and bottom-up pivots meeting at the smallest |gamma|,
+// as LAPACK's dlar1v does), O(m).  ritz[0..nev) ascending; *zlast0 = |last component| of the unit eigenvector of ritz[0].
+int tridiag_lowest(int64_t m, const double *a, const double *b1, int nev, double *ritz, double *zlast0)
+{
+    if (m <= 0 || nev <= 0) return QBH_EINVAL;
+    if (nev > m) nev = (int)m;
+    double gl = a[0], gu = a[0], bmax = 0.0;
+    for (int64_t i = 0; i < m; ++i) {
+        const double r = (i > 0 ? std::fabs(b1[i - 1]) : 0.0) + (i + 1 < m ? std::fabs(b1[i]) : 0.0);
+        gl = std::min(gl, a[i] - r);
+        gu = std::max(gu, a[i] + r);
+        if (i + 1 < m) bmax = std::max(bmax, b1[i] * b1[i]);
+    }
+    const double eps = 2.220446049250313e-16;
+    const double scale = std::max(std::fabs(gl), std::fabs(gu));
+    const double pivmin = std::max(2.2250738585072014e-308 * std::max(1.0, bmax) * 4.0, 1e-300);
+    gl -= 2.0 * eps * scale * (double)m + 2.0 * pivmin;
+    gu += 2.0 * eps * scale * (double)m + 2.0 * pivmin;
+    auto count_below = [&](double x) -> int64_t {          // number of eigenvalues < x
+        int64_t cnt = 0;
+        double q = a[0] - x;
+        if (std::fabs(q) < pivmin) q = -pivmin;
+        if (q < 0.0) cnt++;
+        for (int64_t k = 1; k < m; ++k) {
+            q = a[k] - x - b1[k - 1] * b1[k - 1] / q;
+            if (std::fabs(q) < pivmin) q = -pivmin;
+            if (q < 0.0) cnt++;
+        }
+        return cnt;
+    };
+    // eight Sturm sequences per sweep (independent division chains: the loop is latency-bound, so eight cost what
+    // one does): each sweep cuts the bracket ninefold
+    constexpr int NS = 8;
+    auto count_below8 = [&](const double *x, int64_t *cnt) {
+        double q[NS];
+        for (int s2 = 0; s2 < NS; ++s2) {
+            q[s2] = a[0] - x[s2];
+            if (std::fabs(q[s2]) < pivmin) q[s2] = -pivmin;
+            cnt[s2] = q[s2] < 0.0 ? 1 : 0;
+        }
+        for (int64_t k = 1; k < m; ++k) {
+            const double ak = a[k], bb = b1[k - 1] * b1[k - 1];
+            for (int s2 = 0; s2 < NS; ++s2) {
+                double t = ak - x[s2] - bb / q[s2];
+                if (std::fabs(t) < pivmin) t = -pivmin;
+                q[s2] = t;
+                cnt[s2] += t < 0.0 ? 1 : 0;
+            }
+        }
+    };
+    double lo_prev = gl;
+    for (int j = 0; j < nev; ++j) {
+        double lo = lo_prev, hi = gu;
+        for (int it = 0; it < 64; ++it) {
+            if (hi - lo <= eps * std::max(std::fabs(lo), std::fabs(hi))) break;
+            double x[NS];
+            int64_t cnt[NS];
+            const double h = (hi - lo) / (NS + 1);
+            for (int s2 = 0; s2 < NS; ++s2) x[s2] = lo + h * (s2 + 1);
+            if (!(x[0] > lo && x[NS - 1] < hi)) {          // bracket only a few ulps wide: finish by plain bisection
+                const double mid = 0.5 * (lo + hi);
+                if (!(mid > lo && mid < hi)) break;
+                if (count_below(mid) >= j + 1) hi = mid;
+                else lo = mid;
+                continue;
+            }
+            count_below8(x, cnt);
+            // eigenvalue j lies between the last point with count <= j and the first with count >= j + 1
+            int first = NS;
+            for (int s2 = 0; s2 < NS; ++s2)
+                if (cnt[s2] >= j + 1) {
+                    first = s2;
+                    break;
+                }
+            if (first < NS) hi = x[first];
+            if (first > 0) lo = x[first - 1];
+        }
+        ritz[j] = 0.5 * (lo + hi);
+        lo_prev = lo;                                      // the next eigenvalue is not below this one
+    }
+    if (zlast0) {
+        const double th = ritz[0];
+        if (m == 1) {
+            *zlast0 = 1.0;
+            return QBH_OK;
+        }
+        std::vector<double> qp((size_t)m), qm((size_t)m);
+        qp[0] = a[0] - th;
+        for (int64_t k = 1; k < m; ++k) {
+            double d = qp[(size_t)k - 1];
+            if (std::fabs(d) < pivmin) d = d < 0.0 ? -pivmin : pivmin;
+            qp[(size_t)k] = (a[k] - th) - b1[k - 1] * b1[k - 1] / d;
+        }
+        qm[(size_t)m - 1] = a[m - 1] - th;
+        for (int64_t k = m - 2; k >= 0; --k) {
+            double d = qm[(size_t)k + 1];
+            if (std::fabs(d) < pivmin) d = d < 0.0 ? -pivmin : pivmin;
+            qm[(size_t)k] = (a[k] - th) - b1[k] * b1[k] / d;
+        }
+        int64_t r = 0;
+        double gbest = std::fabs(qp[0] + qm[0] - (a[0] - th));
+        for (int64_t k = 1; k < m; ++k) {
+            const double g = std::fabs(qp[(size_t)k] + qm[(size_t)k] - (a[k] - th));
+            if (g < gbest) {
+                gbest = g;
+                r = k;
+            }
+        }
+        // z_r = 1; upwards with the top-down pivots, downwards with the bottom-up pivots; rescale against overflow
+        double nrm2 = 1.0, z = 1.0, zm = (r == m - 1) ? 1.0 : 0.0;
+        for (int64_t k = r - 1; k >= 0; --k) {
+            double d = qp[(size_t)k];
+            if (std::fabs(d) < pivmin) d = d < 0.0 ? -pivmin : pivmin;
+            z = -b1[k] * z / d;
+            nrm2 += z * z;
+            if (!(nrm2 < 1e280)) return QBH_ENOCONV;
+        }
+        z = 1.0;
+        for (int64_t k = r + 1; k < m; ++k) {
+            double d = qm[(size_t)k];
+            if (std::fabs(d) < pivmin) d = d < 0.0 ? -pivmin : pivmin;
+            z = -b1[k - 1] * z / d;
+            nrm2 += z * z;
+            if (k == m - 1) zm = z;
+        }
+        *zlast0 = std::fabs(zm) / std::sqrt(nrm2);
+    }
+    return QBH_OK;
+}
+
 // Cyclic Jacobi for the small dense real symmetric projected matrix of the thick-restart Lanczos
 // (m <= 32: tridiagonal plus the arrowhead row left by a restart).  a: m*m column-major, destroyed;
 // w[m] ascending eigenvalues; z[m*m] column-major eigenvectors.

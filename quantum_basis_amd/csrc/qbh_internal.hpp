@@ -96,6 +96,7 @@ int build_value_dict(const d2 *d_val, int64_t nnz, int cap, uint8_t **d_code_out
 // host tridiagonal solver (qbh_hess.cpp)
 int tridiag_eigen_full(int64_t m, const double *a, const double *b1, double *w, double *z);
 int tridiag_eigen_lastrow(int64_t m, const double *a, const double *b1, double *w, double *zlast);
+int tridiag_lowest(int64_t m, const double *a, const double *b1, int nev, double *ritz, double *zlast0);
 
 }  // namespace qbh
 
