@@ -810,7 +810,9 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         A->xr_of = nullptr;
         A->stats.n_spmv++;
         if (realm) A->stats.n_spmv_real++;
-        if (red) {
+        if (red && A->defer_red) {
+            QBH_TRY(qbh::launch_reduce_partials(A->d_partials, mf_parts, 3, A->d_scal, A->stream));
+        } else if (red) {
             QBH_TRY(finish_reduction(A, mf_parts, 3, red));
             if (profm) harvest_events(A);
         }
@@ -897,7 +899,9 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     A->xr_of = nullptr;                      // the packed copy is consumed by exactly one SpMV
     A->stats.n_spmv++;
     if (realm) A->stats.n_spmv_real++;
-    if (red) {
+    if (red && A->defer_red) {
+        QBH_TRY(qbh::launch_reduce_partials(A->d_partials, grid_last, 3, A->d_scal, A->stream));
+    } else if (red) {
         QBH_TRY(finish_reduction(A, grid_last, 3, red));
         if (prof) harvest_events(A);
     }
@@ -987,9 +991,25 @@ inline double *packed_target(qbh_csr *A)
 int axpy_norm_run(qbh_csr *A, d2 alpha, const d2 *x, d2 *y, double *nrm2sq)
 {
     double *yr = packed_target(A);          // y is the next SpMV's x in every driver: emit its packed copy here
-    QBH_TRY(qbh::launch_axpy_norm(alpha, x, y, A->nrows, A->d_partials, yr, A->d_flag, A->stream));
+    QBH_TRY(qbh::launch_axpy_norm(alpha, nullptr, x, y, A->nrows, A->d_partials, yr, A->d_flag, A->stream));
     A->xr_of = yr ? y : nullptr;
     return finish_reduction(A, qbh::blas_grid(A->nrows), 1, nrm2sq);
+}
+
+// Single-GPU Lanczos step tail: y += (scale * d_scal[0]) x with d_scal[0] = <x, w> left on the device by a deferred
+// spmv_run, then |y|^2; ONE copy + synchronisation returns both scalars (dot_out = d_scal[0], *nrm2sq).
+int axpy_norm_deferred(qbh_csr *A, double scale, const d2 *x, d2 *y, double *dot_out, double *nrm2sq)
+{
+    double *yr = packed_target(A);
+    QBH_TRY(qbh::launch_axpy_norm(d2{scale, 0.0}, A->d_scal, x, y, A->nrows, A->d_partials, yr, A->d_flag, A->stream));
+    A->xr_of = yr ? y : nullptr;
+    QBH_TRY(qbh::launch_reduce_partials(A->d_partials, qbh::blas_grid(A->nrows), 1, A->d_scal + 4, A->stream));
+    QBH_HIP(hipMemcpyAsync(A->h_scal, A->d_scal, 5 * sizeof(double), hipMemcpyDeviceToHost, A->stream));
+    QBH_HIP(hipStreamSynchronize(A->stream));
+    *dot_out = A->h_scal[0];
+    *nrm2sq = A->h_scal[4];
+    if (A->opts.profile) harvest_events(A);
+    return QBH_OK;
 }
 
 int nrm2_run(qbh_csr *A, const d2 *x, double *nrm)
@@ -1241,6 +1261,20 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
     auto step = [&](int64_t mcur, double bprev) -> int {
         const int sx = (int)((mcur - 1) % 2), sy = (int)(mcur % 2);
         // w = H v_{m-1} - b_{m-1} v_{m-2}  and  <u_{m-1}, w>                               K3+K1+K4
+        static const bool no_defer = getenv("QBH_NO_DEFER") != nullptr;       // A/B switch
+        if (!A->has_comm && !no_defer) {
+            // one GPU: <u, w> stays on the device and feeds the axpy directly; one host synchronisation per step
+            A->defer_red = true;
+            const int rc1 = spmv_run(A, vpt(mcur - 1), vpt(mcur), sc[sx], -bprev * sc[sy], 0.0, red);
+            A->defer_red = false;
+            QBH_TRY(rc1);
+            double dot = 0.0;
+            QBH_TRY(axpy_norm_deferred(A, -sc[sx] * sc[sx], vpt(mcur - 1), vpt(mcur), &dot, &sq));
+            a[mcur - 1] = sc[sx] * dot;
+            b[mcur] = std::sqrt(sq);
+            sc[sy] = 1.0 / b[mcur];
+            return QBH_OK;
+        }
         QBH_TRY(spmv_run(A, vpt(mcur - 1), vpt(mcur), sc[sx], -bprev * sc[sy], 0.0, red));
         a[mcur - 1] = sc[sx] * red[0];
         // w -= a v_{m-1} ; b = |w|                                                         K5+K6

@@ -67,7 +67,8 @@ int launch_build_rowblocks(const int64_t *d_ia, int64_t nrows, int64_t window, i
                            int64_t *d_bp, int64_t n_blocks, hipStream_t s);
 int launch_reduce_partials(const double *partials, int nparts, int ncomp, double *out, hipStream_t s);
 int launch_dotc(const d2 *x, const d2 *y, int64_t n, double *partials, hipStream_t s);
-int launch_axpy_norm(d2 alpha, const d2 *x, d2 *y, int64_t n, double *partials, double *yr, int *flag, hipStream_t s);
+int launch_axpy_norm(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, int64_t n, double *partials, double *yr, int *flag,
+                     hipStream_t s);
 int launch_nrm2sq(const d2 *x, int64_t n, double *partials, hipStream_t s);
 int launch_scal(double a, d2 *x, int64_t n, hipStream_t s);
 int launch_xpby(const d2 *x, double b, d2 *y, int64_t n, hipStream_t s);            // y = x + b*y
@@ -214,4 +215,5 @@ struct qbh_csr {
     qbh_stats stats{};
     bool      ev_pending = false;
     int       debug = 0;
+    bool      defer_red = false;     // spmv_run leaves its three reduced scalars in d_scal[0..2] (no copy, no sync)
 };

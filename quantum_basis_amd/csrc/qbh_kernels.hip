@@ -973,12 +973,15 @@ int launch_dotc(const d2 *x, const d2 *y, int64_t n, double *partials, hipStream
 // y += alpha*x ; partial |y|^2   (cblas_zaxpy + cblas_dznrm2 in one pass: K5+K6)
 // yr (optional): packed real parts of the updated y -- the next SpMV's gather source in the real fast
 // path, produced here instead of by a separate k_pack_real pass; flag as in k_pack_real.
-__global__ __launch_bounds__(kBlock) void k_axpy_norm(d2 alpha, const d2 *x, d2 *y, int64_t n,
+// alpha_dev != nullptr: the coefficient is alpha.x * alpha_dev[0] (a scalar a previous kernel of the same stream left
+// on the device -- the Lanczos step then needs one host synchronisation instead of two)
+__global__ __launch_bounds__(kBlock) void k_axpy_norm(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, int64_t n,
                                                       double *partials, double *yr, int *flag)
 {
     __shared__ double red[4];
     double acc[1] = {0.0};
     bool bad = false;
+    if (alpha_dev != nullptr) alpha = d2{alpha.x * alpha_dev[0], 0.0};
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         d2 v = y[i] + cmul(alpha, x[i]);
@@ -994,9 +997,10 @@ __global__ __launch_bounds__(kBlock) void k_axpy_norm(d2 alpha, const d2 *x, d2 
     if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
 }
 
-int launch_axpy_norm(d2 alpha, const d2 *x, d2 *y, int64_t n, double *partials, double *yr, int *flag, hipStream_t s)
+int launch_axpy_norm(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, int64_t n, double *partials, double *yr, int *flag,
+                     hipStream_t s)
 {
-    hipLaunchKernelGGL(k_axpy_norm, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, x, y, n, partials, yr, flag);
+    hipLaunchKernelGGL(k_axpy_norm, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, alpha_dev, x, y, n, partials, yr, flag);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }
