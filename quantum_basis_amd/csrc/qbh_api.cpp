@@ -1475,7 +1475,11 @@ extern "C" int qbh_eigenvec_cg_dev(const qbh_csr *Ac, int64_t maxit, int64_t *m_
             QBH_TRY(qbh::launch_cg_update(alpha, p, pp, v, r, n, A->d_partials, A->stream));   // :324-325
             QBH_TRY(finish_reduction(A, qbh::blas_grid(n), 1, &sq));
             const double beta = std::sqrt(sq) / accu;                                        // :326
-            QBH_TRY(qbh::launch_xpby(r, beta * beta, p, n, A->stream));                       // :327-328
+            {
+                double *pr = packed_target(A);      // p is the next SpMV's x: emit its packed real copy in the same pass
+                QBH_TRY(qbh::launch_xpby(r, beta * beta, p, n, pr, A->d_flag, A->stream));   // :327-328
+                A->xr_of = pr ? p : nullptr;
+            }
             accu *= beta;
             m++;
             if (info && info->cg_resid) info->cg_resid[m] = accu;

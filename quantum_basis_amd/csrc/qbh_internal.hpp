@@ -71,7 +71,7 @@ int launch_axpy_norm(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, int6
                      hipStream_t s);
 int launch_nrm2sq(const d2 *x, int64_t n, double *partials, hipStream_t s);
 int launch_scal(double a, d2 *x, int64_t n, hipStream_t s);
-int launch_xpby(const d2 *x, double b, d2 *y, int64_t n, hipStream_t s);            // y = x + b*y
+int launch_xpby(const d2 *x, double b, d2 *y, int64_t n, double *yr, int *flag, hipStream_t s);            // y = x + b*y
 int launch_cg_update(d2 alpha, const d2 *p, const d2 *pp, d2 *v, d2 *r, int64_t n, double *partials,
                      hipStream_t s);                                               // v+=a p; r-=a pp; |r|^2
 int launch_randomize(d2 *x, int64_t n, int64_t global_offset, uint32_t seed, double *partials,

@@ -1039,15 +1039,25 @@ int launch_scal(double a, d2 *x, int64_t n, hipStream_t s)
 }
 
 // y = x + b*y   (CG direction update p = r + beta^2 p, src/lanczos.cc:327-328)
-__global__ __launch_bounds__(kBlock) void k_xpby(const d2 *x, double b, d2 *y, int64_t n)
+// yr != nullptr: also the packed real parts of the result (it is the next SpMV's gather source in the real fast path)
+__global__ __launch_bounds__(kBlock) void k_xpby(const d2 *x, double b, d2 *y, int64_t n, double *yr, int *flag)
 {
+    bool bad = false;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) y[i] = x[i] + b * y[i];
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const d2 v = x[i] + b * y[i];
+        y[i] = v;
+        if (yr != nullptr) {
+            yr[i] = v.x;
+            bad |= (v.y != 0.0);
+        }
+    }
+    if (bad) *flag = 1;
 }
 
-int launch_xpby(const d2 *x, double b, d2 *y, int64_t n, hipStream_t s)
+int launch_xpby(const d2 *x, double b, d2 *y, int64_t n, double *yr, int *flag, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_xpby, dim3(blas_grid(n)), dim3(kBlock), 0, s, x, b, y, n);
+    hipLaunchKernelGGL(k_xpby, dim3(blas_grid(n)), dim3(kBlock), 0, s, x, b, y, n, yr, flag);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }
