@@ -771,11 +771,18 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         A->stats.n_gather++;
         xg = reinterpret_cast<const d2 *>(A->comm.d_xfull);
         xl = x;
+    } else if (A->ovr_yr != nullptr) {           // all-real operation on packed vectors (driver-internal)
+        if (!realm || A->nrows != A->ncols) {
+            qbh::set_error("all-real SpMV needs the real fast path on an unsharded operator");
+            return QBH_EINVAL;
+        }
+        xg = xl = nullptr;
     } else {
         xg = x;
         xl = x + A->row_offset;
         if (realm && A->xr_of != x) QBH_TRY(qbh::launch_pack_real(x, A->d_xr, A->ncols, A->d_flag, A->stream));
     }
+    const double *xr_nocomm = A->ovr_yr != nullptr ? A->ovr_xr : A->d_xr;
     if (A->kind == 1) {                          // matrix-free operator: one launch, needs the whole gathered x
         if (async_gather) {
             if (A->comm.allgather_wait(A->comm.ctx) != 0) {
@@ -790,8 +797,9 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         m.nrows = A->nrows;
         m.xg = xg;
         m.xl = xl;
-        m.xr = realm ? (A->has_comm ? A->comm.d_xfull_r : A->d_xr) : nullptr;
+        m.xr = realm ? (A->has_comm ? A->comm.d_xfull_r : xr_nocomm) : nullptr;
         m.y = y;
+        m.y_re = A->has_comm ? nullptr : A->ovr_yr;
         m.alpha = alpha;
         m.beta = beta;
         m.gamma = gamma;
@@ -833,8 +841,10 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     // serve it from the local block so it does not depend on the gather
     a.xg = (A->has_rem && A->has_comm) ? xl - A->row_offset : xg;
     a.xr = nullptr;
+    a.y_re = A->has_comm ? nullptr : A->ovr_yr;
+    a.xl_re = a.y_re ? xr_nocomm : nullptr;
     if (realm) {
-        if (!A->has_comm) a.xr = A->d_xr;
+        if (!A->has_comm) a.xr = xr_nocomm;
         else if (A->has_rem) a.xr = reinterpret_cast<const double *>(A->comm.d_xsend) - A->row_offset;   // own block, packed
         else a.xr = A->comm.d_xfull_r;
     }
@@ -883,7 +893,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         a.bp = R.d_bp;
         a.n_blocks = R.n_blocks;
         a.xg = xg;
-        if (realm) a.xr = A->has_comm ? A->comm.d_xfull_r : A->d_xr;
+        if (realm) a.xr = A->has_comm ? A->comm.d_xfull_r : xr_nocomm;
         a.beta = 1.0;                       // accumulate onto the local part's result
         a.gamma = 0.0;
         a.partials = red ? A->d_partials : nullptr;
@@ -1252,6 +1262,33 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
         if (sq0 != 0.0) A->real_wire = false;
     }
 
+    // All-real vectors (one GPU, real operator, real Lanczos vectors, no phi0): the two slots live as packed doubles
+    // for the whole solve -- the SpMV gathers from, reads and writes 8-byte elements and the axpy pass moves half the
+    // bytes; (a+0i)(b+0i) = ab+0i exactly, so the coefficients are the same numbers.  Expanded back into v on exit.
+    double *rv = nullptr;
+    struct RvGuard {
+        double **p;
+        ~RvGuard() { if (*p) (void)hipFree(*p); }
+    } rv_guard{&rv};
+    {
+        static const bool no_realvec = getenv("QBH_NO_REALVEC") != nullptr;      // A/B switch
+        if (!A->has_comm && A->real_mode && A->kernel == QBH_KERNEL_ROWS && !is_val1 && A->nrows == A->ncols && !no_realvec) {
+            if (hipMalloc(&rv, (size_t)2 * (size_t)n * sizeof(double)) != hipSuccess) {
+                (void)hipGetLastError();
+                rv = nullptr;                         // no room: stay on the complex vectors
+            } else {
+                // live on entry: v_k, and v_{k-1} when the run continues (k > 0); the other slot is not read before
+                // it is written (the bootstrap step runs with beta = 0)
+                for (int j = 0; j < 2; ++j)
+                    if (k > 0 || j == 0)
+                        QBH_TRY(qbh::launch_pack_real(v + (size_t)j * (size_t)n, rv + (size_t)j * (size_t)n, n, A->d_flag, A->stream));
+                    else
+                        QBH_HIP(hipMemsetAsync(rv + (size_t)j * (size_t)n, 0, (size_t)n * sizeof(double), A->stream));
+                A->xr_of = nullptr;
+            }
+        }
+    }
+    auto rpt = [&](int64_t j) { return rv + (size_t)(j % 2) * (size_t)n; };
     double red[3], sq;
     // The 1/b normalisation (K7, src/lanczos.cc:214) is never a pass of its own: slot j%2 holds an
     // unnormalised u_j with v_j = sc[j%2] * u_j, and the scale is folded into the coefficients of the
@@ -1261,6 +1298,25 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
     auto step = [&](int64_t mcur, double bprev) -> int {
         const int sx = (int)((mcur - 1) % 2), sy = (int)(mcur % 2);
         // w = H v_{m-1} - b_{m-1} v_{m-2}  and  <u_{m-1}, w>                               K3+K1+K4
+        if (rv != nullptr) {
+            A->defer_red = true;
+            A->ovr_xr = rpt(mcur - 1);
+            A->ovr_yr = rpt(mcur);
+            const int rc1 = spmv_run(A, nullptr, nullptr, sc[sx], -bprev * sc[sy], 0.0, red);
+            A->defer_red = false;
+            A->ovr_xr = nullptr;
+            A->ovr_yr = nullptr;
+            QBH_TRY(rc1);
+            QBH_TRY(qbh::launch_axpy_norm_re(-sc[sx] * sc[sx], A->d_scal, rpt(mcur - 1), rpt(mcur), n, A->d_partials, A->stream));
+            QBH_TRY(qbh::launch_reduce_partials(A->d_partials, qbh::blas_grid(n), 1, A->d_scal + 4, A->stream));
+            QBH_HIP(hipMemcpyAsync(A->h_scal, A->d_scal, 5 * sizeof(double), hipMemcpyDeviceToHost, A->stream));
+            QBH_HIP(hipStreamSynchronize(A->stream));
+            if (A->opts.profile) harvest_events(A);
+            a[mcur - 1] = sc[sx] * A->h_scal[0];
+            b[mcur] = std::sqrt(A->h_scal[4]);
+            sc[sy] = 1.0 / b[mcur];
+            return QBH_OK;
+        }
         static const bool no_defer = getenv("QBH_NO_DEFER") != nullptr;       // A/B switch
         if (!A->has_comm && !no_defer) {
             // one GPU: <u, w> stays on the device and feeds the axpy directly; one host synchronisation per step
@@ -1284,6 +1340,13 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
         return QBH_OK;
     };
     auto normalise_slots = [&]() -> int {
+        if (rv != nullptr) {                               // back to the caller's complex vectors
+            for (int j = 0; j < 2; ++j)
+                QBH_TRY(qbh::launch_unpack_real(rv + (size_t)j * (size_t)n, v + (size_t)j * (size_t)n, n, A->stream));
+            QBH_HIP(hipStreamSynchronize(A->stream));
+            (void)hipFree(rv);
+            rv = nullptr;
+        }
         for (int j = 0; j < 2; ++j)
             if (sc[j] != 1.0) {
                 QBH_TRY(qbh::launch_scal(sc[j], v + (size_t)j * (size_t)n, n, A->stream));

@@ -57,6 +57,10 @@ struct SpmvArgs {
     int            swizzle;
     int            unroll;     // k_spmv_rows: gathers in flight per lane and loop trip
     int            colmask;    // -1; QBH_DEBUG=1 sets 1023 so the gather stays in cache (timing experiments only)
+    // all-real operation (real operator, real vectors, one GPU): y_re is the in/out vector stored as doubles, xl_re
+    // the shard-local x as doubles (xr then is both the gather source and x_local); y / xl are unused
+    double        *y_re;
+    const double  *xl_re;
 };
 
 // launchers implemented in qbh_kernels.hip (all asynchronous on `s`)
@@ -71,6 +75,7 @@ int launch_axpy_norm(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, int6
                      hipStream_t s);
 int launch_nrm2sq(const d2 *x, int64_t n, double *partials, hipStream_t s);
 int launch_scal(double a, d2 *x, int64_t n, hipStream_t s);
+int launch_axpy_norm_re(double alpha, const double *alpha_dev, const double *x, double *y, int64_t n, double *partials, hipStream_t s);
 int launch_xpby(const d2 *x, double b, d2 *y, int64_t n, double *yr, int *flag, hipStream_t s);            // y = x + b*y
 int launch_cg_update(d2 alpha, const d2 *p, const d2 *pp, d2 *v, d2 *r, int64_t n, double *partials,
                      hipStream_t s);                                               // v+=a p; r-=a pp; |r|^2
@@ -128,6 +133,7 @@ struct MfArgs {
     d2 *y;
     double alpha, beta, gamma;
     double *partials;
+    double *y_re;                // all-real operation: y stored as doubles (x_local = xr)
 };
 int launch_mf_hubbard(const MfArgs &a, int grid, hipStream_t s, int *nparts_out);
 // adopt a matrix-free operator (tables already in HBM) behind a qbh_csr handle (qbh_api.cpp)
@@ -215,5 +221,7 @@ struct qbh_csr {
     qbh_stats stats{};
     bool      ev_pending = false;
     int       debug = 0;
+    const double *ovr_xr = nullptr;  // all-real operation requested by a driver for the next spmv_run: x and ...
+    double       *ovr_yr = nullptr;  // ... y as packed doubles (the complex pointer arguments are ignored)
     bool      defer_red = false;     // spmv_run leaves its three reduced scalars in d_scal[0..2] (no copy, no sync)
 };

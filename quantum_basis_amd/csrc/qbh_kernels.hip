@@ -95,11 +95,21 @@ struct BlockWalk {
 // partial sums of <x,y> and |y|^2 (K3, K4 and the CG shift folded into K1).
 // yo / xi are the old y[row] and x_local[row], loaded by the caller (so that the loads can
 // be issued long before the row sum is ready).
+__device__ __forceinline__ d2 load_y_old(const SpmvArgs &a, int64_t row)
+{
+    return a.y_re != nullptr ? d2{a.y_re[row], 0.0} : a.y[row];
+}
+__device__ __forceinline__ d2 load_x_local(const SpmvArgs &a, int64_t row)
+{
+    return a.y_re != nullptr ? d2{a.xl_re[row], 0.0} : a.xl[row];
+}
+
 __device__ __forceinline__ void row_epilogue2(const SpmvArgs &a, int64_t row, d2 sum, d2 yo, d2 xi,
                                               double (&acc)[3])
 {
     d2 yn = a.alpha * sum + a.beta * yo + a.gamma * xi;
-    a.y[row] = yn;
+    if (a.y_re != nullptr) a.y_re[row] = yn.x;
+    else                   a.y[row] = yn;
     acc[0] += xi.x * yn.x + xi.y * yn.y;
     acc[1] += xi.x * yn.y - xi.y * yn.x;
     acc[2] += yn.x * yn.x + yn.y * yn.y;
@@ -108,8 +118,8 @@ __device__ __forceinline__ void row_epilogue2(const SpmvArgs &a, int64_t row, d2
 __device__ __forceinline__ void row_epilogue(const SpmvArgs &a, int64_t row, d2 sum, double (&acc)[3])
 {
     d2 yo = {0.0, 0.0}, xi = {0.0, 0.0};
-    if (a.beta != 0.0) yo = a.y[row];
-    if (a.gamma != 0.0 || a.partials != nullptr) xi = a.xl[row];
+    if (a.beta != 0.0) yo = load_y_old(a, row);
+    if (a.gamma != 0.0 || a.partials != nullptr) xi = load_x_local(a, row);
     row_epilogue2(a, row, sum, yo, xi, acc);
 }
 
@@ -172,8 +182,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(SpmvArgs a)
                 const int ro = (int)(a.ia[r0 + (tid <= nr ? tid : 0)] - p0);
                 d2 yo = {0.0, 0.0}, xi = {0.0, 0.0};
                 const bool mine = sub == 0 && g < nr;
-                if (mine && need_y) yo = a.y[r0 + g];
-                if (mine && need_x) xi = a.xl[r0 + g];
+                if (mine && need_y) yo = load_y_old(a, r0 + g);
+                if (mine && need_x) xi = load_x_local(a, r0 + g);
                 if (n > 0) {
                     // All U loads of each stream are issued back to back with a clamped index
                     // (no per-element branch): U col + U val + U gathered-x loads in flight
@@ -337,8 +347,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
                 const int ro = (int)(a.ia[r0 + (tid <= nr ? tid : 0)] - p0);
                 d2 yo = {0.0, 0.0}, xi = {0.0, 0.0};
                 const bool mine = sub == 0 && rloc < nr;
-                if (mine && need_y) yo = a.y[r0 + rloc];
-                if (mine && need_x) xi = a.xl[r0 + rloc];
+                if (mine && need_y) yo = load_y_old(a, r0 + rloc);
+                if (mine && need_x) xi = load_x_local(a, r0 + rloc);
                 if (n > 0) {
                     const int32_t *jp = a.ja + p0;
                     const int nm1 = n - 1;
@@ -1039,6 +1049,30 @@ int launch_scal(double a, d2 *x, int64_t n, hipStream_t s)
 }
 
 // y = x + b*y   (CG direction update p = r + beta^2 p, src/lanczos.cc:327-328)
+// all-real Lanczos: y += alpha * x on vectors stored as doubles, partial |y|^2 (alpha_dev as in k_axpy_norm)
+__global__ __launch_bounds__(kBlock) void k_axpy_norm_re(double alpha, const double *alpha_dev, const double *x, double *y,
+                                                         int64_t n, double *partials)
+{
+    __shared__ double red[4];
+    double acc[1] = {0.0};
+    if (alpha_dev != nullptr) alpha *= alpha_dev[0];
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const double v = y[i] + alpha * x[i];
+        y[i] = v;
+        acc[0] += v * v;
+    }
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+int launch_axpy_norm_re(double alpha, const double *alpha_dev, const double *x, double *y, int64_t n, double *partials, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_axpy_norm_re, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, alpha_dev, x, y, n, partials);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
 // yr != nullptr: also the packed real parts of the result (it is the next SpMV's gather source in the real fast path)
 __global__ __launch_bounds__(kBlock) void k_xpby(const d2 *x, double b, d2 *y, int64_t n, double *yr, int *flag)
 {
@@ -1532,10 +1566,16 @@ __global__ __launch_bounds__(kBlock) void k_mf_hubbard(MfArgs a)
                 }
             }
             d2 yo = {0.0, 0.0}, xi = {0.0, 0.0};
-            if (a.beta != 0.0) yo = a.y[lrow];
-            if (need_x) xi = a.xl[lrow];
+            if (a.y_re != nullptr) {                  // all-real operation (REALX): y and x_local as doubles
+                if (a.beta != 0.0) yo.x = a.y_re[lrow];
+                if (need_x) xi.x = a.xr[grow];
+            } else {
+                if (a.beta != 0.0) yo = a.y[lrow];
+                if (need_x) xi = a.xl[lrow];
+            }
             const d2 yn = a.alpha * sum + a.beta * yo + a.gamma * xi;
-            a.y[lrow] = yn;
+            if (a.y_re != nullptr) a.y_re[lrow] = yn.x;
+            else                   a.y[lrow] = yn;
             acc[0] += xi.x * yn.x + xi.y * yn.y;
             acc[1] += xi.x * yn.y - xi.y * yn.x;
             acc[2] += yn.x * yn.x + yn.y * yn.y;
@@ -1670,11 +1710,15 @@ __global__ __launch_bounds__(kMfRowBlock) void k_mf_hubbard_row(MfArgs a, int ch
             }
             const int64_t lrow = u * Nd + d - a.row_begin;
             d2 yo = {0.0, 0.0};
-            if (need_y) yo = a.y[lrow];
+            if (need_y) {
+                if (a.y_re != nullptr) yo.x = a.y_re[lrow];
+                else                   yo = a.y[lrow];
+            }
             d2 yn;
             yn.x = a.alpha * sum + a.beta * yo.x + a.gamma * xd;
             yn.y = a.beta * yo.y;
-            a.y[lrow] = yn;
+            if (a.y_re != nullptr) a.y_re[lrow] = yn.x;
+            else                   a.y[lrow] = yn;
             acc[0] += xd * yn.x;
             acc[1] += xd * yn.y;
             acc[2] += yn.x * yn.x + yn.y * yn.y;
