@@ -1513,9 +1513,86 @@ extern "C" int qbh_eigenvec_cg_dev(const qbh_csr *Ac, int64_t maxit, int64_t *m_
     if (m != 0) QBH_TRY(enable_real_wire(A, {v, r, p}));
     else        QBH_TRY(enable_real_wire(A, {v}));
     double accu = 0.0;
-    if (m != 0) QBH_TRY(nrm2_run(A, r, &accu));            // :290
     double red[3], sq;
-    while (m < maxit) {
+    // All-real vectors, as in qbh_lanczos_dev: one GPU, real operator, real v (and r, p when the run continues): the
+    // four CG vectors live as packed doubles for the whole solve and are expanded back on exit.
+    double *rv = nullptr;
+    struct RvGuard {
+        double **p;
+        ~RvGuard() { if (*p) (void)hipFree(*p); }
+    } rv_guard{&rv};
+    {
+        static const bool no_realvec = getenv("QBH_NO_REALVEC") != nullptr;
+        if (!A->has_comm && A->real_mode && A->kernel == QBH_KERNEL_ROWS && A->nrows == A->ncols && !no_realvec) {
+            if (hipMalloc(&rv, (size_t)4 * (size_t)n * sizeof(double)) != hipSuccess) {
+                (void)hipGetLastError();
+                rv = nullptr;
+            }
+        }
+    }
+    if (rv != nullptr) {
+        double *vr = rv, *rr = rv + (size_t)n, *pr = rv + 2 * (size_t)n, *ppr = rv + 3 * (size_t)n;
+        QBH_TRY(qbh::launch_pack_real(v, vr, n, A->d_flag, A->stream));
+        if (m != 0) {
+            QBH_TRY(qbh::launch_pack_real(r, rr, n, A->d_flag, A->stream));
+            QBH_TRY(qbh::launch_pack_real(p, pr, n, A->d_flag, A->stream));
+        }
+        A->xr_of = nullptr;
+        auto nrm2_re = [&](const double *x, double *out) -> int {
+            double s2 = 0.0;
+            QBH_TRY(qbh::launch_nrm2sq_re(x, n, A->d_partials, A->stream));
+            QBH_TRY(finish_reduction(A, qbh::blas_grid(n), 1, &s2));
+            *out = std::sqrt(s2);
+            return QBH_OK;
+        };
+        auto spmv_re = [&](const double *x, double *y, double al, double be, double ga) -> int {
+            A->ovr_xr = x;
+            A->ovr_yr = y;
+            const int rc1 = spmv_run(A, nullptr, nullptr, al, be, ga, red);
+            A->ovr_xr = nullptr;
+            A->ovr_yr = nullptr;
+            return rc1;
+        };
+        if (m != 0) QBH_TRY(nrm2_re(rr, &accu));           // :290
+        while (m < maxit) {
+            if (accu < prec) {
+                double rnorm = 0.0;
+                QBH_TRY(nrm2_re(vr, &rnorm));
+                if (m == 0 || std::fabs(rnorm - 1.0) > prec) {  // re-normalise and restart, :297-317
+                    QBH_TRY(qbh::launch_scal_re(1.0 / rnorm, vr, n, A->stream));
+                    QBH_TRY(spmv_re(vr, rr, -1.0, 0.0, E0));                 // r = (E0 - H) v
+                    QBH_HIP(hipMemcpyAsync(pr, rr, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, A->stream));
+                    accu = std::sqrt(red[2]);
+                    m++;
+                    if (info && info->cg_resid) info->cg_resid[m] = accu;
+                    if (accu < prec) break;
+                } else {
+                    break;
+                }
+            } else {
+                QBH_TRY(spmv_re(pr, ppr, 1.0, 0.0, machine_prec - E0));      // pp = (H - E0) p, delta = <p,pp>  :319-323
+                const double alpha = accu * accu / red[0];
+                QBH_TRY(qbh::launch_cg_update_re(alpha, pr, ppr, vr, rr, n, A->d_partials, A->stream));   // :324-325
+                QBH_TRY(finish_reduction(A, qbh::blas_grid(n), 1, &sq));
+                const double beta = std::sqrt(sq) / accu;                    // :326
+                QBH_TRY(qbh::launch_xpby_re(rr, beta * beta, pr, n, A->stream));   // :327-328
+                accu *= beta;
+                m++;
+                if (info && info->cg_resid) info->cg_resid[m] = accu;
+            }
+        }
+        QBH_TRY(qbh::launch_unpack_real(vr, v, n, A->stream));
+        QBH_TRY(qbh::launch_unpack_real(rr, r, n, A->stream));
+        QBH_TRY(qbh::launch_unpack_real(pr, p, n, A->stream));
+        QBH_HIP(hipStreamSynchronize(A->stream));
+        (void)hipFree(rv);
+        rv = nullptr;
+        m = -m - 1;                                         // done: skip the complex loop below
+    }
+    if (m >= 0 && m != 0) QBH_TRY(nrm2_run(A, r, &accu));  // :290
+    const bool did_real = m < 0;
+    if (did_real) m = -m - 1;
+    while (!did_real && m < maxit) {
         if (accu < prec) {
             double rnorm = 0.0;
             QBH_TRY(nrm2_run(A, v, &rnorm));

@@ -76,6 +76,10 @@ int launch_axpy_norm(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, int6
 int launch_nrm2sq(const d2 *x, int64_t n, double *partials, hipStream_t s);
 int launch_scal(double a, d2 *x, int64_t n, hipStream_t s);
 int launch_axpy_norm_re(double alpha, const double *alpha_dev, const double *x, double *y, int64_t n, double *partials, hipStream_t s);
+int launch_cg_update_re(double alpha, const double *p, const double *pp, double *v, double *r, int64_t n, double *partials, hipStream_t s);
+int launch_xpby_re(const double *x, double b, double *y, int64_t n, hipStream_t s);
+int launch_nrm2sq_re(const double *x, int64_t n, double *partials, hipStream_t s);
+int launch_scal_re(double a, double *x, int64_t n, hipStream_t s);
 int launch_xpby(const d2 *x, double b, d2 *y, int64_t n, double *yr, int *flag, hipStream_t s);            // y = x + b*y
 int launch_cg_update(d2 alpha, const d2 *p, const d2 *pp, d2 *v, d2 *r, int64_t n, double *partials,
                      hipStream_t s);                                               // v+=a p; r-=a pp; |r|^2

@@ -1121,6 +1121,70 @@ int launch_cg_update(d2 alpha, const d2 *p, const d2 *pp, d2 *v, d2 *r, int64_t 
     return QBH_OK;
 }
 
+// ---- the same passes on vectors stored as doubles (all-real CG, see qbh_eigenvec_cg_dev) ----
+__global__ __launch_bounds__(kBlock) void k_cg_update_re(double alpha, const double *p, const double *pp, double *v, double *r,
+                                                         int64_t n, double *partials)
+{
+    __shared__ double red[4];
+    double acc[1] = {0.0};
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        v[i] = v[i] + alpha * p[i];
+        const double rr = r[i] - alpha * pp[i];
+        r[i] = rr;
+        acc[0] += rr * rr;
+    }
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+__global__ __launch_bounds__(kBlock) void k_xpby_re(const double *x, double b, double *y, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) y[i] = x[i] + b * y[i];
+}
+
+__global__ __launch_bounds__(kBlock) void k_nrm2sq_re(const double *x, int64_t n, double *partials)
+{
+    __shared__ double red[4];
+    double acc[1] = {0.0};
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) acc[0] += x[i] * x[i];
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+__global__ __launch_bounds__(kBlock) void k_scal_re(double a, double *x, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) x[i] *= a;
+}
+
+int launch_cg_update_re(double alpha, const double *p, const double *pp, double *v, double *r, int64_t n, double *partials, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_cg_update_re, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, p, pp, v, r, n, partials);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+int launch_xpby_re(const double *x, double b, double *y, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_xpby_re, dim3(blas_grid(n)), dim3(kBlock), 0, s, x, b, y, n);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+int launch_nrm2sq_re(const double *x, int64_t n, double *partials, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_nrm2sq_re, dim3(blas_grid(n)), dim3(kBlock), 0, s, x, n, partials);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+int launch_scal_re(double a, double *x, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_scal_re, dim3(blas_grid(n)), dim3(kBlock), 0, s, a, x, n);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
 // ------------------------------------------------------ start vector -----------
 // vec_randomize (src/miscellaneous.cc:371-386): std::minstd_rand0 is the Lehmer
 // generator s <- 16807 s mod (2^31-1); element j takes draw j+1.  Each lane jumps ahead
