@@ -1262,7 +1262,7 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
         if (sq0 != 0.0) A->real_wire = false;
     }
 
-    // All-real vectors (one GPU, real operator, real Lanczos vectors, no phi0): the two slots live as packed doubles
+    // All-real vectors (one GPU, real operator, real Lanczos vectors and phi0): the slots (and phi0) live as packed doubles
     // for the whole solve -- the SpMV gathers from, reads and writes 8-byte elements and the axpy pass moves half the
     // bytes; (a+0i)(b+0i) = ab+0i exactly, so the coefficients are the same numbers.  Expanded back into v on exit.
     double *rv = nullptr;
@@ -1272,8 +1272,8 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
     } rv_guard{&rv};
     {
         static const bool no_realvec = getenv("QBH_NO_REALVEC") != nullptr;      // A/B switch
-        if (!A->has_comm && A->real_mode && A->kernel == QBH_KERNEL_ROWS && !is_val1 && A->nrows == A->ncols && !no_realvec) {
-            if (hipMalloc(&rv, (size_t)2 * (size_t)n * sizeof(double)) != hipSuccess) {
+        if (!A->has_comm && A->real_mode && A->kernel == QBH_KERNEL_ROWS && A->nrows == A->ncols && !no_realvec) {
+            if (hipMalloc(&rv, (size_t)(is_val1 ? 3 : 2) * (size_t)n * sizeof(double)) != hipSuccess) {
                 (void)hipGetLastError();
                 rv = nullptr;                         // no room: stay on the complex vectors
             } else {
@@ -1284,6 +1284,7 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
                         QBH_TRY(qbh::launch_pack_real(v + (size_t)j * (size_t)n, rv + (size_t)j * (size_t)n, n, A->d_flag, A->stream));
                     else
                         QBH_HIP(hipMemsetAsync(rv + (size_t)j * (size_t)n, 0, (size_t)n * sizeof(double), A->stream));
+                if (is_val1) QBH_TRY(qbh::launch_pack_real(phi, rv + 2 * (size_t)n, n, A->d_flag, A->stream));   // phi0
                 A->xr_of = nullptr;
             }
         }
@@ -1389,10 +1390,21 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
         if (is_val1) {                                     // :218-226
             double t[2];
             const int sy = (int)(m % 2);
-            rc = dotc_run(A, phi, vpt(m), t);                  // <phi0, u_m>; <phi0, v_m> = sc * that
+            if (rv != nullptr) {
+                t[1] = 0.0;
+                rc = qbh::launch_dot_re(rv + 2 * (size_t)n, rpt(m), n, A->d_partials, A->stream);
+                if (rc == QBH_OK) rc = finish_reduction(A, qbh::blas_grid(n), 1, t);
+            } else {
+                rc = dotc_run(A, phi, vpt(m), t);              // <phi0, u_m>; <phi0, v_m> = sc * that
+            }
             if (rc != QBH_OK) break;
             if (sc[sy] * std::hypot(t[0], t[1]) > prec) {
-                rc = axpy_norm_run(A, d2{-t[0], -t[1]}, phi, vpt(m), &sq);   // u_m -= <phi0,u_m> phi0
+                if (rv != nullptr) {
+                    rc = qbh::launch_axpy_norm_re(-t[0], nullptr, rv + 2 * (size_t)n, rpt(m), n, A->d_partials, A->stream);
+                    if (rc == QBH_OK) rc = finish_reduction(A, qbh::blas_grid(n), 1, &sq);
+                } else {
+                    rc = axpy_norm_run(A, d2{-t[0], -t[1]}, phi, vpt(m), &sq);   // u_m -= <phi0,u_m> phi0
+                }
                 if (rc != QBH_OK) break;
                 sc[sy] = 1.0 / std::sqrt(sq);                  // renormalise
                 if (info) info->n_reorth++;

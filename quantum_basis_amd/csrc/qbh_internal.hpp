@@ -78,6 +78,7 @@ int launch_scal(double a, d2 *x, int64_t n, hipStream_t s);
 int launch_axpy_norm_re(double alpha, const double *alpha_dev, const double *x, double *y, int64_t n, double *partials, hipStream_t s);
 int launch_cg_update_re(double alpha, const double *p, const double *pp, double *v, double *r, int64_t n, double *partials, hipStream_t s);
 int launch_xpby_re(const double *x, double b, double *y, int64_t n, hipStream_t s);
+int launch_dot_re(const double *x, const double *y, int64_t n, double *partials, hipStream_t s);
 int launch_nrm2sq_re(const double *x, int64_t n, double *partials, hipStream_t s);
 int launch_scal_re(double a, double *x, int64_t n, hipStream_t s);
 int launch_xpby(const d2 *x, double b, d2 *y, int64_t n, double *yr, int *flag, hipStream_t s);            // y = x + b*y

@@ -1144,6 +1144,23 @@ __global__ __launch_bounds__(kBlock) void k_xpby_re(const double *x, double b, d
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) y[i] = x[i] + b * y[i];
 }
 
+__global__ __launch_bounds__(kBlock) void k_dot_re(const double *x, const double *y, int64_t n, double *partials)
+{
+    __shared__ double red[4];
+    double acc[1] = {0.0};
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) acc[0] += x[i] * y[i];
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+int launch_dot_re(const double *x, const double *y, int64_t n, double *partials, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dot_re, dim3(blas_grid(n)), dim3(kBlock), 0, s, x, y, n, partials);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
 __global__ __launch_bounds__(kBlock) void k_nrm2sq_re(const double *x, int64_t n, double *partials)
 {
     __shared__ double red[4];
