@@ -1715,18 +1715,52 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
     const double eps23 = std::pow(eps, 2.0 / 3.0);
     const double tol_eff = tol > 0.0 ? tol : eps;
 
+    // The start vector is real; when the operator is real too (one GPU, row kernel) the whole Krylov basis is kept
+    // as packed doubles: a vector of n doubles (padded to an even count) IS a complex vector of n/2 elements for every
+    // BLAS-1 kernel below (real inner products = real parts, real coefficients), the SpMV runs all-real, and the
+    // orthogonalisation -- the dominant cost at ncv = 32 -- moves half the bytes.
     d2 *V = nullptr;
     double *d_S = nullptr;
-    QBH_HIP(hipMalloc(&V, (size_t)(m + 1) * (size_t)n * sizeof(d2)));
+    WireGuard wire_guard{A};
+    int rc = QBH_OK;
+    bool all_real = false;
+    int64_t nc = n, ldr = 0;                  // complex length / leading dimension the BLAS-1 kernels see
+    {
+        d2 *v0 = nullptr;
+        QBH_HIP(hipMalloc(&v0, (size_t)n * sizeof(d2)));
+        rc = qbh_vec_randomize(A, reinterpret_cast<qbh_z *>(v0), seed ? seed : 1u);
+        if (rc == QBH_OK) rc = enable_real_wire(A, {v0});      // the random start vector is real
+        static const bool no_realvec = getenv("QBH_NO_REALVEC") != nullptr;
+        all_real = rc == QBH_OK && !A->has_comm && A->real_mode && A->kernel == QBH_KERNEL_ROWS && A->nrows == A->ncols && !no_realvec;
+        hipError_t e0 = hipSuccess;
+        if (all_real) {
+            ldr = n + (n & 1);
+            nc = ldr / 2;
+            e0 = hipMalloc(&V, (size_t)(m + 1) * (size_t)ldr * sizeof(double));
+            if (e0 == hipSuccess) e0 = hipMemsetAsync(V, 0, (size_t)(m + 1) * (size_t)ldr * sizeof(double), A->stream);
+            if (e0 == hipSuccess && rc == QBH_OK)
+                rc = qbh::launch_pack_real(v0, reinterpret_cast<double *>(V), n, A->d_flag, A->stream);
+        } else {
+            e0 = hipMalloc(&V, (size_t)(m + 1) * (size_t)n * sizeof(d2));
+            if (e0 == hipSuccess)
+                e0 = hipMemcpyAsync(V, v0, (size_t)n * sizeof(d2), hipMemcpyDeviceToDevice, A->stream);
+        }
+        if (e0 == hipSuccess) e0 = hipStreamSynchronize(A->stream);
+        (void)hipFree(v0);
+        if (e0 != hipSuccess) {
+            if (V) (void)hipFree(V);
+            qbh::set_error("qbh_iram: Krylov basis allocation failed: %s", hipGetErrorString(e0));
+            return e0 == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP;
+        }
+    }
     hipError_t e = hipMalloc(&d_S, 32 * 32 * sizeof(double));
     if (e != hipSuccess) {
         (void)hipFree(V);
         return QBH_ENOMEM;
     }
-    auto vec = [&](int j) { return V + (size_t)j * (size_t)n; };
-    int rc = qbh_vec_randomize(A, reinterpret_cast<qbh_z *>(vec(0)), seed ? seed : 1u);
-    WireGuard wire_guard{A};
-    if (rc == QBH_OK) rc = enable_real_wire(A, {vec(0)});      // the random start vector is real
+    const int64_t ldc = all_real ? nc : n;     // in complex elements
+    auto vec = [&](int j) { return V + (size_t)j * (size_t)ldc; };
+    auto rvec = [&](int j) { return reinterpret_cast<double *>(V) + (size_t)j * (size_t)ldr; };
 
     std::vector<double> T((size_t)m * m, 0.0), Tw((size_t)m * m), theta((size_t)m), S((size_t)m * m);
     int k = 0;                          // vectors kept from the previous restart
@@ -1739,18 +1773,18 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
         std::vector<double> h((size_t)2 * nv);
         for (int i0 = 0; i0 < nv; i0 += 8) {
             const int cnt = std::min(8, nv - i0);
-            QBH_TRY(qbh::launch_multi_dot8(vec(i0), n, w, n, cnt, A->d_partials, A->stream));
-            QBH_TRY(finish_reduction(A, qbh::blas_grid(n), 16, red));
-            for (int i = 0; i < 2 * cnt; ++i) h[(size_t)2 * i0 + i] = red[i];
+            QBH_TRY(qbh::launch_multi_dot8(vec(i0), ldc, w, nc, cnt, A->d_partials, A->stream));
+            QBH_TRY(finish_reduction(A, qbh::blas_grid(nc), 16, red));
+            for (int i = 0; i < 2 * cnt; ++i) h[(size_t)2 * i0 + i] = (all_real && (i & 1)) ? 0.0 : red[i];
         }
         for (int i0 = 0; i0 < nv; i0 += 8) {
             const int cnt = std::min(8, nv - i0);
             const bool last = i0 + 8 >= nv;
             qbh::Coef8 c{};
             for (int i = 0; i < 2 * cnt; ++i) c.v[i] = h[(size_t)2 * i0 + i];
-            QBH_TRY(qbh::launch_multi_axpy8(vec(i0), n, c, cnt, w, n, last ? A->d_partials : nullptr, A->stream));
+            QBH_TRY(qbh::launch_multi_axpy8(vec(i0), ldc, c, cnt, w, nc, last ? A->d_partials : nullptr, A->stream));
         }
-        QBH_TRY(finish_reduction(A, qbh::blas_grid(n), 1, nrm2sq));
+        QBH_TRY(finish_reduction(A, qbh::blas_grid(nc), 1, nrm2sq));
         *hj = h[(size_t)2 * (nv - 1)];
         return QBH_OK;
     };
@@ -1762,7 +1796,15 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
             // beta_{j-1} (or the arrowhead couplings right after a restart) and the rounding-level
             // components along the older vectors, and all of them are removed in one pass (ARPACK does the
             // same in its Arnoldi step, followed by one DGKS correction when cancellation was severe).
-            rc = spmv_run(A, vec(j), w, sign, 0.0, 0.0, red);
+            if (all_real) {
+                A->ovr_xr = rvec(j);
+                A->ovr_yr = rvec(j + 1);
+                rc = spmv_run(A, nullptr, nullptr, sign, 0.0, 0.0, red);
+                A->ovr_xr = nullptr;
+                A->ovr_yr = nullptr;
+            } else {
+                rc = spmv_run(A, vec(j), w, sign, 0.0, 0.0, red);
+            }
             if (rc != QBH_OK) break;
             const double wnorm2 = red[2];
             double alpha = 0.0, b2 = 0.0;
@@ -1781,7 +1823,7 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
             T[(size_t)j * m + j] = alpha;
             beta_last = beta;
             if (j + 1 < m) T[(size_t)j * m + (j + 1)] = T[(size_t)(j + 1) * m + j] = beta;
-            if (beta > 0.0) rc = qbh::launch_scal(1.0 / beta, w, n, A->stream);
+            if (beta > 0.0) rc = qbh::launch_scal(1.0 / beta, w, nc, A->stream);
         }
         if (rc != QBH_OK) break;
         Tw = T;
@@ -1800,9 +1842,9 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
         if (e != hipSuccess) { rc = QBH_EHIP; break; }
         e = hipStreamSynchronize(A->stream);                 // S.data() is pageable host memory
         if (e != hipSuccess) { rc = QBH_EHIP; break; }
-        rc = qbh::launch_basis_rotate(V, n, n, m, keep, d_S, A->stream);
+        rc = qbh::launch_basis_rotate(V, ldc, nc, m, keep, d_S, A->stream);
         if (rc != QBH_OK || done) break;
-        e = hipMemcpyAsync(vec(keep), vec(m), (size_t)n * sizeof(d2), hipMemcpyDeviceToDevice, A->stream);
+        e = hipMemcpyAsync(vec(keep), vec(m), (size_t)ldc * sizeof(d2), hipMemcpyDeviceToDevice, A->stream);
         if (e != hipSuccess) { rc = QBH_EHIP; break; }
         std::fill(T.begin(), T.end(), 0.0);
         for (int i = 0; i < keep; ++i) {
@@ -1816,7 +1858,18 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
     if (rc == QBH_OK) {
         for (int i = 0; i < (int)nev; ++i) eigenvals[i] = sign * theta[i];
         *nconv_out = nconv;
-        if (eigenvecs_host) {
+        if (eigenvecs_host && all_real) {
+            d2 *tmp = nullptr;
+            if (hipMalloc(&tmp, (size_t)n * sizeof(d2)) != hipSuccess) rc = QBH_ENOMEM;
+            for (int i = 0; rc == QBH_OK && i < (int)nev; ++i) {
+                rc = qbh::launch_unpack_real(rvec(i), tmp, n, A->stream);
+                if (rc == QBH_OK && hipMemcpyAsync(eigenvecs_host + (size_t)i * (size_t)n, tmp, (size_t)n * sizeof(d2),
+                                                   hipMemcpyDeviceToHost, A->stream) != hipSuccess)
+                    rc = QBH_EHIP;
+                if (rc == QBH_OK && hipStreamSynchronize(A->stream) != hipSuccess) rc = QBH_EHIP;
+            }
+            if (tmp) (void)hipFree(tmp);
+        } else if (eigenvecs_host) {
             e = hipMemcpyAsync(eigenvecs_host, V, (size_t)nev * (size_t)n * sizeof(d2), hipMemcpyDeviceToHost, A->stream);
             if (e != hipSuccess) rc = QBH_EHIP;
         }
