@@ -294,9 +294,9 @@ int qbh_gen_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bonds,
  * The sector dimension is only known after the representatives have been enumerated, so a row shard is named by
  * (shard, n_shards): rows [shard*nblk, min(dim, (shard+1)*nblk)), nblk = ceil(dim / n_shards) -- the partition of
  * qbh_comm; (0, 1) = the whole sector.  *dim_out (may be NULL) receives the sector dimension.
- * When opts->value_dict is on and the sector holds at most 256 distinct values, the value stream is emitted
- * directly as 1-byte codes: the 16 B/nnz complex128 array is never materialised, which is what lets the 36-site
- * Sz = 0 sector (nnz 1.4e10) live on one GPU. */
+ * When opts->value_dict is on and the sector holds at most 65536 distinct values, the value stream is emitted
+ * directly as 1- or 2-byte codes: the 16 B/nnz complex128 array is never materialised, which is what lets the
+ * 36-site Sz = 0 sector (nnz 1.4e10, 5712 distinct values) live on one GPU. */
 int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int n_bonds, const int32_t *bonds, double J,
                             int n_trans, const int32_t *perms, const double *chars, double fake_pos,
                             int shard, int n_shards, int64_t *dim_out, const qbh_opts *opts);

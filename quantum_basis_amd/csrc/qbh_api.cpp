@@ -341,8 +341,8 @@ int new_handle(qbh_csr **out, const qbh_opts *opts)
     return QBH_OK;
 }
 
-// dictionary-code the value stream on the device when there are at most 256 distinct
-// values (exact, lossless); otherwise the operator silently stays uncoded.
+// dictionary-code the value stream on the device when there are at most 256 (1-byte codes) or
+// 65536 (2-byte codes, row kernel) distinct values (exact, lossless); otherwise the operator silently stays uncoded.
 int try_value_dict(qbh_csr *A)
 {
     if (!A->opts.value_dict || !A->d_val || A->d_code || A->nnz <= 0) return QBH_OK;

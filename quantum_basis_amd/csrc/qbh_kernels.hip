@@ -765,8 +765,9 @@ int launch_max_rowlen(const int64_t *d_ia, int64_t nrows, int64_t *d_out, hipStr
 // Lossless coding of the value stream: when a matrix holds at most 256 distinct complex128
 // values (every full-basis Hamiltonian of the reference's model families does: hopping
 // amplitudes, exchange constants and a handful of diagonal sums), each value is replaced by
-// a 1-byte index into a dictionary that lives in LDS during SpMV.  The stream shrinks from
-// 20 to 5 bytes per nonzero; products are computed from the exact original doubles.
+// a 1-byte index into a dictionary that lives in LDS during SpMV; up to 65536 distinct values
+// (momentum sectors) by a 2-byte index.  The stream shrinks from 20 to 5 or 6 bytes per
+// nonzero; products are computed from the exact original doubles.
 // (device helpers: qbh_dict.hpp)
 __global__ __launch_bounds__(kBlock) void k_dict_collect(const d2 *val, int64_t nnz, DictTab T)
 {
