@@ -99,3 +99,29 @@ def test_random_matrix_ground_state_against_dense(seed):
     assert nconv == 3 and np.allclose(wi, w[:3], atol=1e-9)
     nconv, wl, _ = q.iram(n, A, None, 2, 10, 300, "lr")
     assert np.allclose(wl, w[::-1][:2], atol=1e-9)
+
+
+@pytest.mark.parametrize("n", [401, 1000, 3001])
+def test_real_symmetric_matrices_take_the_all_real_solvers(n):
+    """Real symmetric operators (odd and even dimension) with the reference's real start vector: Lanczos (E0, E1),
+    CG and IRAM keep their vectors as packed doubles; results against the dense spectrum."""
+    M = _random_hermitian(n, 8.0 / n, 900 + n, complex_vals=False)
+    nn, ia, ja, val = _to_ref(M, True)
+    w, U = np.linalg.eigh(M.toarray().real)
+    A = q.csr_mat(nn, ia, ja, val, sym=True)
+    res = q.locate_E0_lanczos(A, nev=2, ncv=2, maxit=1000)
+    assert abs(res.E0 - w[0]) <= 1e-10 * max(abs(w[0]), 1.0) and abs(res.E1 - w[1]) < 1e-8
+    v0, v1 = res.eigenvecs[:n], res.eigenvecs[n:]
+    assert np.abs(v0.imag).max() == 0.0 and abs(np.linalg.norm(v0) - 1.0) < 1e-12
+    assert abs(abs(np.vdot(v0, U[:, 0])) - 1.0) < 1e-8 and abs(abs(np.vdot(v1, U[:, 1])) - 1.0) < 1e-6
+    st = A.stats()
+    assert st.n_spmv_real == st.n_spmv > 0
+    nconv, wi, z = q.iram(n, A, None, 3, 12, 400, "sr")
+    assert nconv == 3 and np.allclose(wi, w[:3], atol=1e-9)
+    Z = z.reshape(3, n)
+    assert np.abs(Z.imag).max() == 0.0
+    for j in range(3):
+        assert np.linalg.norm(M @ Z[j] - wi[j] * Z[j]) < 1e-8
+    assert np.allclose(Z.conj() @ Z.T, np.eye(3), atol=1e-10)
+    nconv, wl, _ = q.iram(n, A, None, 2, 10, 400, "lr")
+    assert np.allclose(wl, w[::-1][:2], atol=1e-9)
