@@ -1282,8 +1282,6 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
                 for (int j = 0; j < 2; ++j)
                     if (k > 0 || j == 0)
                         QBH_TRY(qbh::launch_pack_real(v + (size_t)j * (size_t)n, rv + (size_t)j * (size_t)n, n, A->d_flag, A->stream));
-                    else
-                        QBH_HIP(hipMemsetAsync(rv + (size_t)j * (size_t)n, 0, (size_t)n * sizeof(double), A->stream));
                 if (is_val1) QBH_TRY(qbh::launch_pack_real(phi, rv + 2 * (size_t)n, n, A->d_flag, A->stream));   // phi0
                 A->xr_of = nullptr;
             }
@@ -1737,7 +1735,10 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
             ldr = n + (n & 1);
             nc = ldr / 2;
             e0 = hipMalloc(&V, (size_t)(m + 1) * (size_t)ldr * sizeof(double));
-            if (e0 == hipSuccess) e0 = hipMemsetAsync(V, 0, (size_t)(m + 1) * (size_t)ldr * sizeof(double), A->stream);
+            // every vector is written in full by the SpMV (beta = 0) before it is read; only the padding element
+            // of an odd dimension has to be zero
+            for (int j = 0; e0 == hipSuccess && (n & 1) && j <= m; ++j)
+                e0 = hipMemsetAsync(reinterpret_cast<double *>(V) + (size_t)j * (size_t)ldr + n, 0, sizeof(double), A->stream);
             if (e0 == hipSuccess && rc == QBH_OK)
                 rc = qbh::launch_pack_real(v0, reinterpret_cast<double *>(V), n, A->d_flag, A->stream);
         } else {
