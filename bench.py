@@ -40,6 +40,9 @@ def workloads():
         "hubbard_4x2_half": dict(kind="hubbard", n_sites=8, n_up=4, n_dn=4, bonds=lattices.square(4, 2), t=1.0, U=1.1),
         # BASELINE.json configs[1] / C2
         "kagome_30": dict(kind="heisenberg", n_sites=30, n_dn=15, bonds=lattices.kagome(5, 2), J=1.0),
+        # BASELINE.json configs[1]: the 36-site kagome torus (4 x 3 cells).  Sz = 0 has dim 9,075,135,300: no CSR can be
+        # stored; it runs matrix-free with real-packed vectors (tools/kagome36.py).  n_dn = 9 is the same lattice at dim 9.4e7.
+        "kagome_36_n9": dict(kind="heisenberg", n_sites=36, n_dn=9, bonds=lattices.kagome(4, 3), J=1.0),
         "kagome_24": dict(kind="heisenberg", n_sites=24, n_dn=12, bonds=lattices.kagome(4, 2), J=1.0),
         "chain_22": dict(kind="heisenberg", n_sites=22, n_dn=11, bonds=lattices.chain(22), J=1.0),
         # BASELINE.json configs[4] family: triangular 6x6, translation-symmetric sector k = (1,0), complex phases.
@@ -82,7 +85,7 @@ def build_operator(w, rows, opts, matrix_free=False, shard=(0, 1)):
         perms, shifts = lattices.translations(*w["trans"])
         return q.csr_mat.heisenberg_repr(w["n_sites"], w["n_dn"], w["bonds"], perms, lattices.characters(shifts, w["k"], w["trans"]),
                                          J=w["J"], shard=shard, opts=opts)
-    return q.csr_mat.heisenberg(w["n_sites"], w["n_dn"], w["bonds"], J=w["J"], rows=rows, opts=opts)
+    return q.csr_mat.heisenberg(w["n_sites"], w["n_dn"], w["bonds"], J=w["J"], rows=rows, opts=opts, matrix_free=matrix_free)
 
 
 def cpu_baseline(A, dim, budget_rows):
@@ -337,13 +340,13 @@ def main():
                 P.destroy()
         except Exception as e:
             out["roofline_plain_values"] = {"error": repr(e)}
-    if world == 1 and W["kind"] == "hubbard" and not args.no_matrix_free and not args.matrix_free:
+    if world == 1 and W["kind"] in ("hubbard", "heisenberg") and not args.no_matrix_free and not args.matrix_free:
         # SURVEY 8f-1 (next row, NOT the north-star CSR path): the same operator applied from the hop tables without a
         # stored matrix, same solver code; measured after the timed region, same step definition
         try:
             with torch.cuda.stream(stream):
-                M = q.csr_mat.hubbard(W["n_sites"], W["n_up"], W["n_dn"], W["bonds"], t=W["t"], U=W["U"], matrix_free=True,
-                                      opts=q.make_opts(device=local_rank, stream=stream.cuda_stream, profile=1))
+                M = build_operator(W, (0, -1), q.make_opts(device=local_rank, stream=stream.cuda_stream, profile=1),
+                                   matrix_free=True)
                 mv = M.vec(2)
                 mh = np.zeros(2 * maxit)
                 M.randomize(mv.at(0), 1)
@@ -356,18 +359,18 @@ def main():
                 tm = time.perf_counter() - tm0
                 ms_ = M.stats()
                 mms = ms_.ms_spmv / max(ms_.n_spmv, 1)
-                out["matrix_free_hubbard"] = {"lanczos_iters_per_s": round((mk2 - mk) / tm, 4), "steps": int(mk2 - mk),
+                out["matrix_free_" + W["kind"]] = {"lanczos_iters_per_s": round((mk2 - mk) / tm, 4), "steps": int(mk2 - mk),
                                               "spmv_ms_per_launch": round(mms, 4),
                                               "equivalent_csr_GBps": round(bytes_launch / mms / 1e6, 2),
                                               "table_bytes": int(M.info().bytes_matrix),
-                                              "kernel": "k_mf_hubbard_row" if ms_.n_spmv_real > 0 else "k_mf_hubbard",
+                                              "kernel": ("k_mf_hubbard_row" if ms_.n_spmv_real > 0 else "k_mf_hubbard") if W["kind"] == "hubbard" else "k_mf_heis",
                                               "traffic": traffic_of("%s|matrix_free|plain%s" % (args.workload, "|real" if ms_.n_spmv_real > 0 else "")),
                                               "note": "no stored matrix; not the CSR north-star path; traffic = HBM bytes per "
                                                       "apply from the rocprofv3 --pmc passes under profiles/"}
                 mv.free()
                 M.destroy()
         except Exception as e:
-            out["matrix_free_hubbard"] = {"error": repr(e)}
+            out["matrix_free_" + W["kind"]] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(A, dim, args.cpu_rows)

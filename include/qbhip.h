@@ -188,6 +188,13 @@ int qbh_lanczos(const qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_t 
                 qbh_z *v_host, double *hessenberg, const char *purpose, qbh_solver_info *info);
 int qbh_lanczos_dev(const qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_t *m,
                     qbh_z *d_v, double *hessenberg, const char *purpose, qbh_solver_info *info);
+/* The same recurrence on vectors stored as PACKED DOUBLES (d_v: two slots of n doubles, v[k-1], v[k] at (j%2)*n) for a
+ * real operator on one GPU, purposes "sr_val0" and "dnmcs": nothing complex is allocated, so a sector whose complex
+ * vectors would not fit (kagome 36 sites, Sz = 0: dim 9,075,135,300, 2 x 72.6 GB as doubles) runs on one MI355X with
+ * a matrix-free operator.  qbh_vec_randomize_real fills a packed vector with the stream of vec_randomize. */
+int qbh_lanczos_real_dev(const qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_t *m,
+                         double *d_v, double *hessenberg, const char *purpose, qbh_solver_info *info);
+int qbh_vec_randomize_real(const qbh_csr *A, double *d_x, uint32_t seed);
 
 /* Replaces eigenvec_CG<T,MAT> (src/lanczos.cc:281-341): CG on (H-E0)v = 0 with the
  * reference's restart/renormalise branch and the (machine_prec - E0) shift.  *m is in/out
@@ -284,6 +291,12 @@ int qbh_mf_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_bonds,
 int qbh_gen_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bonds,
                        const int32_t *bonds, double J,
                        int64_t row_begin, int64_t row_end, const qbh_opts *opts);
+/* The same Heisenberg operator WITHOUT a stored matrix (matrix-free model<T>::MultMv2, src/model.cc:941-1109): every
+ * row is unranked, its bonds flipped and the flipped patterns re-ranked on the fly from tables held in LDS.  Same
+ * basis as qbh_gen_heisenberg; the dimension may exceed 2^31 (no column index is stored). */
+int qbh_mf_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bonds,
+                      const int32_t *bonds, double J,
+                      int64_t row_begin, int64_t row_end, const qbh_opts *opts);
 /* Translation-symmetric sector of the same Heisenberg model, assembled on the device: counterpart of
  * model::generate_Ham_sparse_repr (src/model.cc:687-836).  The translation group is given explicitly: perms[g*n_sites
  * + s] = image of site s under translation g (g = 0 the identity, <= 64 translations), chars[2g], chars[2g+1] =

@@ -79,9 +79,9 @@ EXPORTS = [
     "qbh_vec_alloc", "qbh_vec_free", "qbh_vec_upload", "qbh_vec_download", "qbh_vec_zero",
     "qbh_vec_randomize",
     "qbh_spmv_dev", "qbh_dotc_dev", "qbh_axpy_norm_dev", "qbh_scal_dev", "qbh_nrm2_dev",
-    "qbh_lanczos", "qbh_lanczos_dev", "qbh_eigenvec_cg", "qbh_eigenvec_cg_dev", "qbh_hess_eigen", "qbh_iram",
+    "qbh_lanczos", "qbh_lanczos_dev", "qbh_lanczos_real_dev", "qbh_vec_randomize_real", "qbh_eigenvec_cg", "qbh_eigenvec_cg_dev", "qbh_hess_eigen", "qbh_iram",
     "qbh_csr_set_comm", "qbh_get_stats", "qbh_sync",
-    "qbh_gen_hubbard", "qbh_mf_hubbard", "qbh_gen_heisenberg", "qbh_gen_heisenberg_repr", "qbh_csr_download",
+    "qbh_gen_hubbard", "qbh_mf_hubbard", "qbh_gen_heisenberg", "qbh_mf_heisenberg", "qbh_gen_heisenberg_repr", "qbh_csr_download",
 ]
 
 _lib = None
@@ -135,6 +135,8 @@ def lib():
     L.qbh_lanczos.argtypes = [vp, i64, i64, i64, C.POINTER(i64), vp, vp, C.c_char_p,
                               C.POINTER(SolverInfo)]
     L.qbh_lanczos_dev.argtypes = L.qbh_lanczos.argtypes
+    L.qbh_lanczos_real_dev.argtypes = L.qbh_lanczos.argtypes
+    L.qbh_vec_randomize_real.argtypes = [vp, vp, C.c_uint32]
     L.qbh_eigenvec_cg.argtypes = [vp, i64, C.POINTER(i64), dbl, C.POINTER(dbl), vp, vp, vp, vp,
                                   C.POINTER(SolverInfo)]
     L.qbh_eigenvec_cg_dev.argtypes = L.qbh_eigenvec_cg.argtypes
@@ -148,6 +150,7 @@ def lib():
     L.qbh_mf_hubbard.argtypes = L.qbh_gen_hubbard.argtypes
     L.qbh_gen_heisenberg.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp, dbl, i64, i64,
                                      C.POINTER(Opts)]
+    L.qbh_mf_heisenberg.argtypes = L.qbh_gen_heisenberg.argtypes
     L.qbh_gen_heisenberg_repr.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp, dbl, C.c_int, vp, vp, dbl,
                                           C.c_int, C.c_int, C.POINTER(i64), C.POINTER(Opts)]
     L.qbh_csr_download.argtypes = [vp, i64, i64, vp, vp, vp]

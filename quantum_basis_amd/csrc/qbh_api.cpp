@@ -394,6 +394,13 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
         (void)hipFree(A->mf.val_d);
         if (A->mf.pk_d) (void)hipFree(A->mf.pk_d);
     }
+    if (A->kind == 2) {
+        (void)hipFree(A->mfh.binom);
+        (void)hipFree(A->mfh.chunk);
+        (void)hipFree(A->mfh.mask);
+        (void)hipFree(A->mfh.offd);
+        (void)hipFree(A->mfh.diag);
+    }
     if (A->ev2) (void)hipEventDestroy(A->ev2);
     if (A->ev3) (void)hipEventDestroy(A->ev3);
     if (A->d_partials) (void)hipFree(A->d_partials);
@@ -628,6 +635,40 @@ int qbh::adopt_mf_hubbard(qbh_csr **out, const qbh::MfHubbard &t, int64_t nrows,
     return QBH_OK;
 }
 
+int qbh::adopt_mf_heis(qbh_csr **out, const qbh::MfHeis &t, int64_t nrows, int64_t ncols, int64_t row_offset,
+                          int64_t nnz_equiv, const qbh_opts *opts)
+{
+    qbh_csr *A = nullptr;
+    QBH_TRY(new_handle(&A, opts));
+    A->kind = 2;
+    A->mfh = t;
+    A->nrows = nrows;
+    A->ncols = ncols;
+    A->row_offset = row_offset;
+    A->nnz = A->nnz_total = nnz_equiv;         // what the CSR of the same operator would hold (for the byte accounting)
+    A->kernel = QBH_KERNEL_ROWS;
+    A->values_real = true;                     // J is real
+    A->n_blocks = (nrows + qbh::kBlock - 1) / qbh::kBlock;
+    A->grid = (int)std::min<int64_t>(A->n_blocks, 256 * 8);
+    auto fail = [&](int code) {
+        qbh_csr_destroy(A);
+        return code;
+    };
+    if (hipMalloc(&A->d_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (hipHostMalloc(&A->h_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (hipMalloc(&A->d_flag, sizeof(int)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (hipMemset(A->d_flag, 0, sizeof(int)) != hipSuccess) return fail(QBH_EHIP);
+    if (hipEventCreate(&A->ev0) != hipSuccess || hipEventCreate(&A->ev1) != hipSuccess ||
+        hipEventCreate(&A->ev2) != hipSuccess || hipEventCreate(&A->ev3) != hipSuccess)
+        return fail(QBH_EHIP);
+    const size_t nparts = (size_t)std::max(A->grid, qbh::kMaxRedBlocks);
+    if (hipMalloc(&A->d_partials, nparts * 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
+    A->stats = qbh_stats{};
+    A->stats.ms_spmv_min = std::numeric_limits<double>::infinity();
+    *out = A;
+    return QBH_OK;
+}
+
 extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
 {
     if (!A || !info) return QBH_EINVAL;
@@ -642,7 +683,10 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->bytes_algorithmic = nnz * 20 + (A->nrows + 1) * 8 + A->nrows * 32;
     if (A->kind == 1)
         info->bytes_matrix = (A->mf.Nu * A->mf.wu + A->mf.Nd * A->mf.wd) * 3 + (A->mf.Nu + A->mf.Nd) * 4;
-    info->kernel = A->kind == 1 ? QBH_KERNEL_MATRIX_FREE : A->kernel;
+    if (A->kind == 2)
+        info->bytes_matrix = ((int64_t)(A->mfh.n_sites + 1) * (A->mfh.n_dn + 1) + (int64_t)A->mfh.n_chunks * (A->mfh.n_dn + 1) * 64 +
+                              3 * (int64_t)A->mfh.n_bonds) * 8;
+    info->kernel = A->kind != 0 ? QBH_KERNEL_MATRIX_FREE : A->kernel;
     info->value_dict = A->d_code ? A->n_dict : 0;
     info->device = A->device;
     info->stream = (void *)A->stream;
@@ -783,7 +827,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         if (realm && A->xr_of != x) QBH_TRY(qbh::launch_pack_real(x, A->d_xr, A->ncols, A->d_flag, A->stream));
     }
     const double *xr_nocomm = A->ovr_yr != nullptr ? A->ovr_xr : A->d_xr;
-    if (A->kind == 1) {                          // matrix-free operator: one launch, needs the whole gathered x
+    if (A->kind != 0) {                          // matrix-free operator: one launch, needs the whole gathered x
         if (async_gather) {
             if (A->comm.allgather_wait(A->comm.ctx) != 0) {
                 qbh::set_error("allgather_wait hook failed");
@@ -810,7 +854,24 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
             QBH_HIP(hipEventRecord(A->ev0, A->stream));
         }
         int mf_parts = A->grid;
-        QBH_TRY(qbh::launch_mf_hubbard(m, A->grid, A->stream, &mf_parts));
+        if (A->kind == 2) {
+            qbh::MfHeisArgs h{};
+            h.t = A->mfh;
+            h.row_begin = m.row_begin;
+            h.nrows = m.nrows;
+            h.xg = m.xg;
+            h.xl = m.xl;
+            h.xr = m.xr;
+            h.y = m.y;
+            h.y_re = m.y_re;
+            h.alpha = alpha;
+            h.beta = beta;
+            h.gamma = gamma;
+            h.partials = m.partials;
+            QBH_TRY(qbh::launch_mf_heis(h, A->stream, &mf_parts));
+        } else {
+            QBH_TRY(qbh::launch_mf_hubbard(m, A->grid, A->stream, &mf_parts));
+        }
         if (profm) {
             QBH_HIP(hipEventRecord(A->ev1, A->stream));
             A->ev_pending = true;
@@ -1087,7 +1148,7 @@ extern "C" int qbh_vec_randomize(const qbh_csr *Ac, qbh_z *d_x, uint32_t seed)
         return qbh::launch_fill_const(x, A->nrows, std::sqrt(1.0 / (double)A->ncols), A->stream);
     }
     const int64_t nruns = (A->nrows + 15) / 16;
-    QBH_TRY(qbh::launch_randomize(x, A->nrows, A->has_comm ? A->row_offset : 0, seed, A->d_partials, A->stream));
+    QBH_TRY(qbh::launch_randomize(x, nullptr, A->nrows, A->has_comm ? A->row_offset : 0, seed, A->d_partials, A->stream));
     double sq = 0.0;
     QBH_TRY(finish_reduction(A, qbh::blas_grid(nruns), 1, &sq));
     return qbh::launch_scal(1.0 / std::sqrt(sq), x, A->nrows, A->stream);
@@ -1199,11 +1260,12 @@ extern "C" int qbh_hess_eigen(const double *hessenberg, int64_t maxit, int64_t m
 }
 
 // ----------------------------------------------------------------- Lanczos ------
-extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t maxit, int64_t *m_out,
-                               qbh_z *d_v, double *hess, const char *purpose, qbh_solver_info *info)
+// ext_rv != nullptr: the caller's vectors ARE packed doubles (two slots of nrows doubles; qbh_lanczos_real_dev) -- the
+// all-real path runs in place, nothing complex is ever allocated.  Otherwise d_v holds the reference's complex slots.
+static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_t *m_out, qbh_z *d_v, double *ext_rv,
+                        double *hess, const char *purpose, qbh_solver_info *info)
 {
-    qbh_csr *A = const_cast<qbh_csr *>(Ac);
-    if (!A || !m_out || !d_v || !hess || !purpose) return QBH_EINVAL;
+    if (!A || !m_out || (!d_v && !ext_rv) || !hess || !purpose) return QBH_EINVAL;
     if (!A->has_comm && A->nrows != A->ncols) {
         qbh::set_error("qbh_lanczos: a row shard needs a communicator");
         return QBH_EINVAL;
@@ -1245,14 +1307,31 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
     double *a = hess + maxit, *b = hess;
 
     double nrm = 0.0;
-    QBH_TRY(nrm2_run(A, vpt(k), &nrm));                   // assert at :166
+    if (ext_rv) {
+        if (is_val1 || A->has_comm || !A->values_real || A->kernel != QBH_KERNEL_ROWS || A->nrows != A->ncols) {
+            qbh::set_error("qbh_lanczos_real: needs a real operator on one GPU (row kernel / matrix-free), purpose sr_val0 or dnmcs");
+            return QBH_EINVAL;
+        }
+        double sq0 = 0.0;
+        QBH_TRY(qbh::launch_nrm2sq_re(ext_rv + (size_t)(k % 2) * (size_t)n, n, A->d_partials, A->stream));
+        QBH_TRY(finish_reduction(A, qbh::blas_grid(n), 1, &sq0));
+        nrm = std::sqrt(sq0);
+    } else {
+        QBH_TRY(nrm2_run(A, vpt(k), &nrm));               // assert at :166
+    }
     if (!(std::fabs(nrm - 1.0) < prec)) {
         qbh::set_error("qbh_lanczos: |v[k]| - 1 = %.3e", nrm - 1.0);
         return QBH_ENOTNORM;
     }
 
     WireGuard wire_guard{A};
-    if (is_val1)     QBH_TRY(enable_real_wire(A, {vpt(k), phi}));
+    if (ext_rv) {
+        A->real_wire = false;
+        A->real_mode = true;                               // no packed side buffer is needed: the vectors are the packed form
+        A->xr_of = nullptr;
+        QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), A->stream));
+    }
+    else if (is_val1) QBH_TRY(enable_real_wire(A, {vpt(k), phi}));
     else if (k > 0)  QBH_TRY(enable_real_wire(A, {vpt(k), vpt(k + 1)}));
     else             QBH_TRY(enable_real_wire(A, {vpt(k)}));
     if (is_val1 && k > 0 && A->real_wire) {       // the second live vector must be real as well
@@ -1266,13 +1345,16 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
     // for the whole solve -- the SpMV gathers from, reads and writes 8-byte elements and the axpy pass moves half the
     // bytes; (a+0i)(b+0i) = ab+0i exactly, so the coefficients are the same numbers.  Expanded back into v on exit.
     double *rv = nullptr;
+    const bool rv_external = ext_rv != nullptr;
     struct RvGuard {
         double **p;
-        ~RvGuard() { if (*p) (void)hipFree(*p); }
-    } rv_guard{&rv};
+        const bool *ext;
+        ~RvGuard() { if (*p && !*ext) (void)hipFree(*p); }
+    } rv_guard{&rv, &rv_external};
+    if (rv_external) rv = ext_rv;
     {
         static const bool no_realvec = getenv("QBH_NO_REALVEC") != nullptr;      // A/B switch
-        if (!A->has_comm && A->real_mode && A->kernel == QBH_KERNEL_ROWS && A->nrows == A->ncols && !no_realvec) {
+        if (!rv_external && !A->has_comm && A->real_mode && A->kernel == QBH_KERNEL_ROWS && A->nrows == A->ncols && !no_realvec) {
             if (hipMalloc(&rv, (size_t)(is_val1 ? 3 : 2) * (size_t)n * sizeof(double)) != hipSuccess) {
                 (void)hipGetLastError();
                 rv = nullptr;                         // no room: stay on the complex vectors
@@ -1339,6 +1421,14 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
         return QBH_OK;
     };
     auto normalise_slots = [&]() -> int {
+        if (rv != nullptr && rv_external) {                // the caller's vectors are the packed doubles themselves
+            for (int j = 0; j < 2; ++j)
+                if (sc[j] != 1.0) {
+                    QBH_TRY(qbh::launch_scal_re(sc[j], rv + (size_t)j * (size_t)n, n, A->stream));
+                    sc[j] = 1.0;
+                }
+            return QBH_OK;
+        }
         if (rv != nullptr) {                               // back to the caller's complex vectors
             for (int j = 0; j < 2; ++j)
                 QBH_TRY(qbh::launch_unpack_real(rv + (size_t)j * (size_t)n, v + (size_t)j * (size_t)n, n, A->stream));
@@ -1473,6 +1563,32 @@ extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t
         info->ms_total = now_ms() - t_start;
     }
     return rc;
+}
+
+extern "C" int qbh_lanczos_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t maxit, int64_t *m_out,
+                               qbh_z *d_v, double *hess, const char *purpose, qbh_solver_info *info)
+{
+    if (!d_v) return QBH_EINVAL;
+    return lanczos_core(const_cast<qbh_csr *>(Ac), k, np, maxit, m_out, d_v, nullptr, hess, purpose, info);
+}
+
+extern "C" int qbh_lanczos_real_dev(const qbh_csr *Ac, int64_t k, int64_t np, int64_t maxit, int64_t *m_out,
+                                    double *d_v, double *hess, const char *purpose, qbh_solver_info *info)
+{
+    if (!d_v) return QBH_EINVAL;
+    return lanczos_core(const_cast<qbh_csr *>(Ac), k, np, maxit, m_out, nullptr, d_v, hess, purpose, info);
+}
+
+extern "C" int qbh_vec_randomize_real(const qbh_csr *Ac, double *d_x, uint32_t seed)
+{
+    qbh_csr *A = const_cast<qbh_csr *>(Ac);
+    if (!A || !d_x || seed == 0) return QBH_EINVAL;
+    Bind bind(A);
+    const int64_t nruns = (A->nrows + 15) / 16;
+    QBH_TRY(qbh::launch_randomize(nullptr, d_x, A->nrows, A->has_comm ? A->row_offset : 0, seed, A->d_partials, A->stream));
+    double sq = 0.0;
+    QBH_TRY(finish_reduction(A, qbh::blas_grid(nruns), 1, &sq));
+    return qbh::launch_scal_re(1.0 / std::sqrt(sq), d_x, A->nrows, A->stream);
 }
 
 extern "C" int qbh_lanczos(const qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_t *m, qbh_z *v_host,
@@ -1926,7 +2042,7 @@ int download_part(const qbh_csr *A, const int64_t *d_ia, const int32_t *d_ja, co
 extern "C" int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1, int64_t *ia, int32_t *ja, qbh_z *val)
 {
     if (!A || r0 < 0 || r1 < r0 || r1 > A->nrows) return QBH_EINVAL;
-    if (A->kind == 1) {
+    if (A->kind != 0) {
         qbh::set_error("qbh_csr_download: the operator is matrix-free (no stored CSR)");
         return QBH_EUNSUPP;
     }

@@ -592,6 +592,87 @@ extern "C" int qbh_gen_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bo
     return rc;
 }
 
+// ---------------------------------------------- matrix-free Heisenberg operator --
+extern "C" int qbh_mf_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bonds, const int32_t *bonds, double J,
+                                 int64_t row_begin, int64_t row_end, const qbh_opts *opts)
+{
+    using namespace qbh;
+    if (!out || !bonds || n_sites <= 0 || n_sites > 62 || n_dn < 0 || n_dn > n_sites || n_dn > 33 || n_bonds <= 0) {
+        set_error("qbh_mf_heisenberg: invalid lattice / magnetisation");
+        return QBH_EINVAL;
+    }
+    if (qbh_device_count() <= 0) {
+        set_error("no HIP device visible");
+        return QBH_ENODEVICE;
+    }
+    if (opts && opts->device >= 0) QBH_HIP(hipSetDevice(opts->device));
+    std::map<std::pair<int, int>, double> bmap;
+    QBH_TRY(merge_bonds(n_sites, n_bonds, bonds, bmap));
+    const uint64_t dim_u = binom_u64(n_sites, n_dn);
+    if (dim_u >= (1ULL << 62)) return QBH_EUNSUPP;
+    const int64_t dim = (int64_t)dim_u;
+    if (row_end < 0) row_end = dim;
+    if (row_begin < 0 || row_begin >= row_end || row_end > dim) {
+        set_error("qbh_mf_heisenberg: bad row range");
+        return QBH_EINVAL;
+    }
+    const int nk = n_dn + 1, n_chunks = (n_sites + 5) / 6;
+    std::vector<uint64_t> binom((size_t)(n_sites + 1) * nk), chunk((size_t)n_chunks * nk * 64, 0ULL);
+    for (int p = 0; p <= n_sites; ++p)
+        for (int k = 0; k < nk; ++k) binom[(size_t)p * nk + k] = binom_u64(p, k);
+    // chunk[c][j][bits]: the t-th set bit of `bits` (site 6c + b) is the (j + t + 1)-th particle of the pattern
+    for (int c = 0; c < n_chunks; ++c)
+        for (int j = 0; j < nk; ++j)
+            for (int bits = 0; bits < 64; ++bits) {
+                uint64_t r = 0;
+                int k = j;
+                bool ok = true;
+                for (int b = 0; b < 6; ++b)
+                    if ((bits >> b) & 1) {
+                        const int site = 6 * c + b;
+                        ++k;
+                        if (site >= n_sites || k > n_dn) {
+                            ok = false;
+                            break;
+                        }
+                        r += binom_u64(site, k);
+                    }
+                chunk[((size_t)c * nk + j) * 64 + bits] = ok ? r : 0ULL;
+            }
+    const int nb = (int)bmap.size(), nbp = ((nb + 7) / 8) * 8;
+    std::vector<uint64_t> mask((size_t)nbp, 0ULL);
+    std::vector<double> offd((size_t)nbp, 0.0), diag((size_t)nbp, 0.0);
+    int i = 0;
+    int64_t nnz_full = dim;
+    for (const auto &bw : bmap) {
+        mask[(size_t)i] = (1ULL << bw.first.first) | (1ULL << bw.first.second);
+        offd[(size_t)i] = 0.5 * J * bw.second;
+        diag[(size_t)i] = 0.25 * J * bw.second;
+        if (n_sites >= 2 && n_dn >= 1 && n_dn <= n_sites - 1) nnz_full += 2 * (int64_t)binom_u64(n_sites - 2, n_dn - 1);
+        ++i;
+    }
+    MfHeis t;
+    t.n_sites = n_sites;
+    t.n_dn = n_dn;
+    t.n_bonds = nbp;
+    t.n_chunks = n_chunks;
+    std::vector<void *> pool;
+    int rc = upload(binom, &t.binom, pool);
+    if (rc == QBH_OK) rc = upload(chunk, &t.chunk, pool);
+    if (rc == QBH_OK) rc = upload(mask, &t.mask, pool);
+    if (rc == QBH_OK) rc = upload(offd, &t.offd, pool);
+    if (rc == QBH_OK) rc = upload(diag, &t.diag, pool);
+    if (rc != QBH_OK) {
+        free_pool(pool);
+        return rc;
+    }
+    const int64_t nrows = row_end - row_begin;
+    const int64_t nnz_equiv = (int64_t)((double)nnz_full * ((double)nrows / (double)dim));
+    rc = adopt_mf_heis(out, t, nrows, dim, row_begin, nnz_equiv, opts);
+    if (rc != QBH_OK) free_pool(pool);
+    return rc;
+}
+
 // ------------------------------------------------- translation-symmetric sectors --
 // Device counterpart of model::generate_Ham_sparse_repr (src/model.cc:687-836) for spin-1/2 Heisenberg models:
 // the Hamiltonian in the basis of momentum states built on orbit representatives.  The reference reaches the

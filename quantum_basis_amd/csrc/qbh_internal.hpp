@@ -84,8 +84,7 @@ int launch_scal_re(double a, double *x, int64_t n, hipStream_t s);
 int launch_xpby(const d2 *x, double b, d2 *y, int64_t n, double *yr, int *flag, hipStream_t s);            // y = x + b*y
 int launch_cg_update(d2 alpha, const d2 *p, const d2 *pp, d2 *v, d2 *r, int64_t n, double *partials,
                      hipStream_t s);                                               // v+=a p; r-=a pp; |r|^2
-int launch_randomize(d2 *x, int64_t n, int64_t global_offset, uint32_t seed, double *partials,
-                     hipStream_t s);
+int launch_randomize(d2 *x, double *xr, int64_t n, int64_t global_offset, uint32_t seed, double *partials, hipStream_t s);
 int launch_fill_const(d2 *x, int64_t n, double re, hipStream_t s);
 int launch_max_rowlen(const int64_t *d_ia, int64_t nrows, int64_t *d_out, hipStream_t s);
 int blas_grid(int64_t n);
@@ -141,6 +140,31 @@ struct MfArgs {
     double *y_re;                // all-real operation: y stored as doubles (x_local = xr)
 };
 int launch_mf_hubbard(const MfArgs &a, int grid, hipStream_t s, int *nparts_out);
+
+// matrix-free spin-1/2 Heisenberg operator in a fixed-n_dn sector, basis = colexicographic rank of the down-spin bit
+// pattern (the basis of qbh_gen_heisenberg): H = sum_bonds J_b (S+S- + S-S+)/2 + J_b SzSz applied on the fly --
+// unrank the row, flip every bond with opposite spins, re-rank the flipped pattern through 6-bit chunk tables in LDS.
+struct MfHeis {
+    int       n_sites = 0, n_dn = 0, n_bonds = 0, n_chunks = 0;   // n_bonds padded to a multiple of 8 (mask 0)
+    uint64_t *binom = nullptr;     // [(n_sites+1) * (n_dn+1)]  C(p, k)
+    uint64_t *chunk = nullptr;     // [n_chunks][n_dn+1][64]: colex-rank contribution of the bits of chunk c when j bits lie below it
+    uint64_t *mask = nullptr;      // [n_bonds] (1 << a) | (1 << b)
+    double   *offd = nullptr;      // [n_bonds] J_b / 2
+    double   *diag = nullptr;      // [n_bonds] J_b / 4
+};
+struct MfHeisArgs {
+    MfHeis t;
+    int64_t row_begin, nrows;
+    const d2 *xg, *xl;
+    const double *xr;
+    d2 *y;
+    double alpha, beta, gamma;
+    double *partials;
+    double *y_re;
+};
+int launch_mf_heis(const MfHeisArgs &a, hipStream_t s, int *nparts_out);
+int adopt_mf_heis(qbh_csr **out, const MfHeis &t, int64_t nrows, int64_t ncols, int64_t row_offset, int64_t nnz_equiv,
+                  const qbh_opts *opts);
 // adopt a matrix-free operator (tables already in HBM) behind a qbh_csr handle (qbh_api.cpp)
 int adopt_mf_hubbard(qbh_csr **out, const MfHubbard &t, int64_t nrows, int64_t ncols, int64_t row_offset,
                      int64_t nnz_equiv, const qbh_opts *opts);
@@ -200,8 +224,9 @@ struct qbh_csr {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // matrix-free operator (kind 1) instead of CSR arrays (kind 0)
-    int      kind = 0;
+    int      kind = 0;               // 0 stored CSR | 1 matrix-free Hubbard | 2 matrix-free Heisenberg
     qbh::MfHubbard mf;
+    qbh::MfHeis    mfh;
 
     // split shard: the arrays above hold the locally-owned columns, `rem` the remote ones
     bool     has_rem = false;

@@ -1222,7 +1222,8 @@ __device__ __forceinline__ uint64_t lehmer_pow(uint64_t e)
     return r;
 }
 
-__global__ __launch_bounds__(kBlock) void k_randomize(d2 *x, int64_t n, int64_t global_offset, uint32_t seed,
+// xr != nullptr: the vector is stored as packed doubles (qbh_vec_randomize_real), same stream of numbers
+__global__ __launch_bounds__(kBlock) void k_randomize(d2 *x, double *xr, int64_t n, int64_t global_offset, uint32_t seed,
                                                       double *partials)
 {
 #pragma clang fp contract(off)
@@ -1243,7 +1244,8 @@ __global__ __launch_bounds__(kBlock) void k_randomize(d2 *x, int64_t n, int64_t 
             d2 v;
             v.x = t - 0.5;
             v.y = 0.0;
-            x[j] = v;
+            if (xr != nullptr) xr[j] = v.x;
+            else               x[j] = v;
             acc[0] += v.x * v.x;
         }
     }
@@ -1251,10 +1253,10 @@ __global__ __launch_bounds__(kBlock) void k_randomize(d2 *x, int64_t n, int64_t 
     if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
 }
 
-int launch_randomize(d2 *x, int64_t n, int64_t global_offset, uint32_t seed, double *partials, hipStream_t s)
+int launch_randomize(d2 *x, double *xr, int64_t n, int64_t global_offset, uint32_t seed, double *partials, hipStream_t s)
 {
     const int64_t nruns = (n + kRandRun - 1) / kRandRun;
-    hipLaunchKernelGGL(k_randomize, dim3(blas_grid(nruns)), dim3(kBlock), 0, s, x, n, global_offset, seed,
+    hipLaunchKernelGGL(k_randomize, dim3(blas_grid(nruns)), dim3(kBlock), 0, s, x, xr, n, global_offset, seed,
                        partials);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
@@ -1824,6 +1826,153 @@ __global__ __launch_bounds__(kMfRowBlock) void k_mf_hubbard_row(MfArgs a, int ch
             }
         }
     }
+}
+
+// -------------------------------------------- matrix-free Heisenberg operator --
+// One lane per row.  LDS holds the binomials (unranking), the chunk tables (re-ranking a flipped pattern costs one
+// lookup per 6 bits) and the bond list; the only global traffic is the x gather, y and the epilogue operands.
+constexpr int kMfHeisBlock = 512;
+
+template <bool REALX>
+__global__ __launch_bounds__(kMfHeisBlock) void k_mf_heis(MfHeisArgs a)
+{
+    extern __shared__ unsigned long long lds_u64[];
+    __shared__ double red[3 * (kMfHeisBlock / 64)];
+    const MfHeis &t = a.t;
+    const int nk = t.n_dn + 1;
+    unsigned long long *binom = lds_u64;                                  // [(n_sites+1) * nk]
+    unsigned long long *chunk = binom + (size_t)(t.n_sites + 1) * nk;     // [n_chunks * nk * 64]
+    unsigned long long *mask = chunk + (size_t)t.n_chunks * nk * 64;      // [n_bonds]
+    double *offd = reinterpret_cast<double *>(mask + t.n_bonds);          // [n_bonds]
+    double *diag = offd + t.n_bonds;                                      // [n_bonds]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (t.n_sites + 1) * nk; i += kMfHeisBlock) binom[i] = t.binom[i];
+    for (int i = tid; i < t.n_chunks * nk * 64; i += kMfHeisBlock) chunk[i] = t.chunk[i];
+    for (int i = tid; i < t.n_bonds; i += kMfHeisBlock) {
+        mask[i] = t.mask[i];
+        offd[i] = t.offd[i];
+        diag[i] = t.diag[i];
+    }
+    __syncthreads();
+    double acc[3] = {0.0, 0.0, 0.0};
+    const int64_t stride = (int64_t)gridDim.x * kMfHeisBlock;
+    for (int64_t lrow = (int64_t)blockIdx.x * kMfHeisBlock + tid; lrow < a.nrows; lrow += stride) {
+        const int64_t grow = a.row_begin + lrow;
+        // unrank (colexicographic): largest p with C(p, k) <= r, for k = n_dn .. 1
+        unsigned long long s = 0, r = (unsigned long long)grow;
+        int p = t.n_sites - 1;
+        for (int k = t.n_dn; k >= 1; --k) {
+            while (binom[p * nk + k] > r) --p;
+            s |= 1ULL << p;
+            r -= binom[p * nk + k];
+            --p;
+        }
+        // (a per-lane walk over only the flipping bonds was measured: 7 % faster at 39 % flipping bonds, 9 % slower at
+        // Sz = 0 where half of them flip -- the uniform loop stays)
+        double dg = 0.0;
+        d2 sum = {0.0, 0.0};
+        for (int b0 = 0; b0 < t.n_bonds; b0 += 8) {
+            long long idx[8];
+            double amp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned long long m = mask[b0 + j];
+                const bool differ = __popcll(s & m) == 1;
+                dg += differ ? -diag[b0 + j] : diag[b0 + j];
+                amp[j] = differ ? offd[b0 + j] : 0.0;
+                long long q = grow;
+                if (differ) {
+                    const unsigned long long f = s ^ m;
+                    unsigned long long rk = 0;
+                    int below = 0;
+                    for (int c = 0; c < t.n_chunks; ++c) {
+                        const int bits = (int)((f >> (6 * c)) & 63ULL);
+                        rk += chunk[((size_t)c * nk + below) * 64 + bits];
+                        below += __popc(bits);
+                    }
+                    q = (long long)rk;
+                }
+                idx[j] = q;
+            }
+            if (REALX) {
+                double xv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[j] = a.xr[idx[j]];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum.x += amp[j] * xv[j];
+            } else {
+                d2 xv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[j] = a.xg[idx[j]];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += amp[j] * xv[j];
+            }
+        }
+        d2 yo = {0.0, 0.0}, xi = {0.0, 0.0};
+        if (a.y_re != nullptr) {
+            if (a.beta != 0.0) yo.x = a.y_re[lrow];
+            xi.x = a.xr[grow];
+        } else {
+            if (a.beta != 0.0) yo = a.y[lrow];
+            if (REALX) xi.x = a.xr[grow];
+            else       xi = a.xg[grow];
+        }
+        sum += dg * xi;                                // diagonal: sum_b +-J_b/4
+        const d2 yn = a.alpha * sum + a.beta * yo + a.gamma * xi;
+        if (a.y_re != nullptr) a.y_re[lrow] = yn.x;
+        else                   a.y[lrow] = yn;
+        acc[0] += xi.x * yn.x + xi.y * yn.y;
+        acc[1] += xi.x * yn.y - xi.y * yn.x;
+        acc[2] += yn.x * yn.x + yn.y * yn.y;
+    }
+    if (a.partials != nullptr) {
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = wave_sum(acc[c]);
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) red[c * (kMfHeisBlock / 64) + wave] = acc[c];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int c = 0; c < 3; ++c) {
+                double v = 0.0;
+                for (int w2 = 0; w2 < kMfHeisBlock / 64; ++w2) v += red[c * (kMfHeisBlock / 64) + w2];
+                a.partials[(size_t)blockIdx.x * 3 + c] = v;
+            }
+        }
+    }
+}
+
+int launch_mf_heis(const MfHeisArgs &a, hipStream_t s, int *nparts_out)
+{
+    static int ncu = 0;
+    if (ncu == 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
+    const MfHeis &t = a.t;
+    const size_t nk = (size_t)t.n_dn + 1;
+    const size_t lds = ((size_t)(t.n_sites + 1) * nk + (size_t)t.n_chunks * nk * 64 + (size_t)t.n_bonds) * 8 + (size_t)t.n_bonds * 16;
+    if (lds > (size_t)150 * 1024) {
+        set_error("qbh_mf_heisenberg: tables (%zu bytes) do not fit LDS", lds);
+        return QBH_EUNSUPP;
+    }
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, ((size_t)158 * 1024) / (lds + 1024)));
+    const int64_t nblk = (a.nrows + kMfHeisBlock - 1) / kMfHeisBlock;
+    const int g = (int)std::min<int64_t>(nblk, (int64_t)ncu * per_cu);
+    if (a.xr != nullptr) {
+        QBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_heis<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_mf_heis<true>, dim3(g), dim3(kMfHeisBlock), lds, s, a);
+    } else {
+        QBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_heis<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_mf_heis<false>, dim3(g), dim3(kMfHeisBlock), lds, s, a);
+    }
+    QBH_HIP(hipGetLastError());
+    if (nparts_out) *nparts_out = g;
+    return QBH_OK;
 }
 
 // true when a row-staged kernel applies: real vectors, the neighbour list fits one wavefront

@@ -133,14 +133,17 @@ class csr_mat:
         return cls(0, None, None, None, opts=opts, _handle=h)
 
     @classmethod
-    def heisenberg(cls, n_sites, n_dn, bonds, J=1.0, rows=None, opts=None):
+    def heisenberg(cls, n_sites, n_dn, bonds, J=1.0, rows=None, opts=None, matrix_free=False):
+        """Spin-1/2 Heisenberg sector with n_dn down spins, assembled on the device (qbh_gen_heisenberg) or applied
+        without a stored matrix (matrix_free=True: qbh_mf_heisenberg, same basis)."""
         _lib.require_gpu()
         opts = opts if opts is not None else make_opts()
         b = np.ascontiguousarray(np.asarray(bonds, dtype=np.int32).reshape(-1, 2))
         r0, r1 = (0, -1) if rows is None else rows
         h = C.c_void_p()
-        check(lib().qbh_gen_heisenberg(C.byref(h), n_sites, n_dn, len(b), _p(b), J, C.c_int64(r0), C.c_int64(r1),
-                                       C.byref(opts)), "qbh_gen_heisenberg")
+        fn = lib().qbh_mf_heisenberg if matrix_free else lib().qbh_gen_heisenberg
+        check(fn(C.byref(h), n_sites, n_dn, len(b), _p(b), J, C.c_int64(r0), C.c_int64(r1), C.byref(opts)),
+              "qbh_mf_heisenberg" if matrix_free else "qbh_gen_heisenberg")
         return cls(0, None, None, None, opts=opts, _handle=h)
 
     @classmethod
@@ -331,6 +334,27 @@ def lanczos(k, np_steps, maxit, dim, mat, v, hessenberg, purpose, device_v=None,
 
 
 lanczos.last = {}
+
+
+def lanczos_real(k, np_steps, maxit, mat, device_v, hessenberg, purpose="sr_val0", state=None):
+    """qbh_lanczos_real_dev: the recurrence on vectors stored as packed doubles (device_v: a DeviceVec whose memory is
+    read as two slots of mat.dim doubles).  Real operator, one GPU; see include/qbhip.h."""
+    assert hessenberg.dtype == np.float64 and hessenberg.size >= 2 * maxit
+    m = C.c_int64(0)
+    info, keep = _solver_info(maxit)
+    if state is not None:
+        info.resume = 1
+        info.cnt_accuE0 = int(state["cnt_accuE0"])
+        info.accuracy, info.theta0_prev, info.theta1_prev = state["accuracy"], state["theta0_prev"], state["theta1_prev"]
+    check(lib().qbh_lanczos_real_dev(mat.handle, k, np_steps, maxit, C.byref(m), device_v.ptr, _p(hessenberg),
+                                     purpose.encode(), C.byref(info)), "qbh_lanczos_real_dev")
+    lanczos_real.last = dict(log=_rows(info), n_matvec=info.n_matvec, ms_total=info.ms_total, ms_spmv=info.ms_spmv,
+                             state=dict(cnt_accuE0=int(info.cnt_accuE0), accuracy=info.accuracy,
+                                        theta0_prev=info.theta0_prev, theta1_prev=info.theta1_prev))
+    return m.value
+
+
+lanczos_real.last = {}
 
 
 def eigenvec_CG(dim, maxit, m, mat, E0, v, r, p, pp, device=False):

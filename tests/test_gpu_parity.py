@@ -668,3 +668,71 @@ def test_device_repr_generator_matches_numpy_and_reference_answers(case):
         assert np.array_equal(pv.view(np.uint64), val[ia[rows]:ia[rows + i.nrows]].view(np.uint64))
         rows += i.nrows
     assert rows == A.dim
+
+
+@pytest.mark.parametrize("geom", [("chain", 16, 8), ("kagome12", 12, 6), ("tri4x4", 16, 7), ("chain", 22, 11), ("tri6x6", 36, 2)])
+def test_matrix_free_heisenberg_equals_csr(geom):
+    """qbh_mf_heisenberg: rows unranked, bonds flipped and re-ranked on the fly; same operator as the device-built CSR
+    (complex x, fused epilogue and reductions, host seam, Lanczos in the all-real path, IRAM)."""
+    name, L, ndn = geom
+    bonds = {"chain": lattices.chain(L), "kagome12": lattices.kagome(2, 2), "tri4x4": lattices.triangular(4, 4),
+             "tri6x6": lattices.triangular(6, 6)}[name]
+    A = q.csr_mat.heisenberg(L, ndn, bonds, J=1.0)
+    M = q.csr_mat.heisenberg(L, ndn, bonds, J=1.0, matrix_free=True)
+    assert M.dim == A.dim and M.nnz == A.nnz and M.info().kernel == _lib.KERNEL_MATRIX_FREE
+    n = A.dim
+    x, y0 = _rand(n, 61), _rand(n, 62)
+    va, vm = A.vec(2), M.vec(2)
+    for alpha, beta, gamma in [(1.0, 0.0, 0.0), (1.0, 1.0, 0.0), (0.6, -1.2, 0.0), (1.0, 0.0, -3.0)]:
+        for v in (va, vm):
+            v.upload(x, 0)
+            v.upload(y0, n)
+        da, na = A.spmv(va.at(0), va.at(n), alpha, beta, gamma, want_red=True)
+        dm, nm = M.spmv(vm.at(0), vm.at(n), alpha, beta, gamma, want_red=True)
+        assert _close(vm.download(n, n), va.download(n, n))
+        assert abs(da - dm) <= 1e-12 * max(abs(da), 1.0) and abs(na - nm) <= 1e-12 * na
+    ra, rm = q.locate_E0_lanczos(A, nev=1, ncv=1), q.locate_E0_lanczos(M, nev=1, ncv=1)
+    assert abs(ra.E0 - rm.E0) <= 1e-11 * abs(ra.E0) and abs(ra.steps["E0"] - rm.steps["E0"]) <= 1
+    hv = np.empty(n, dtype=np.complex128)
+    A.MultMv(rm.eigenvecs, hv)
+    assert np.linalg.norm(hv - rm.E0 * rm.eigenvecs) < 1e-8
+    assert M.stats().n_spmv_real > 0
+    nconv, w, _ = q.iram(n, M, None, 1, 16, 300, "sr")
+    assert abs(w[0] - ra.E0) < 1e-9
+    if name == "kagome12":
+        assert abs(rm.E0 - helpers.known()["kagome_12"]["E0"]) < 1e-8
+    if name == "chain" and L == 16:
+        assert abs(rm.E0 - helpers.known()["chain16_full"]["E0"]) < 1e-8      # the Sz = 0 sector holds the ground state
+    with pytest.raises(_lib.QbhError):
+        M.download()
+
+
+@pytest.mark.parametrize("mf", [False, True])
+def test_lanczos_on_real_packed_vectors(mf):
+    """qbh_lanczos_real_dev / qbh_vec_randomize_real: the caller's vectors are packed doubles (nothing complex is
+    allocated); same coefficients, step count and E0 as the complex interface, continuation included."""
+    import ctypes as C
+    bonds = lattices.kagome(2, 2)
+    A = q.csr_mat.heisenberg(12, 6, bonds, J=1.0, matrix_free=mf)
+    n, maxit = A.dim, 300
+    # complex interface
+    vc = A.vec(2)
+    A.randomize(vc.at(0), 1)
+    hc = np.zeros(2 * maxit)
+    mc = q.lanczos(0, maxit - 1, maxit, n, A, None, hc, "sr_val0", device_v=vc)
+    # packed doubles: n complex = 2n doubles = the two slots
+    vr = A.vec(1)
+    _lib.check(_lib.lib().qbh_vec_randomize_real(A.handle, vr.ptr, C.c_uint32(1)), "qbh_vec_randomize_real")
+    x0 = vr.download(0, n // 2).view(np.float64)                              # n doubles = the first slot
+    assert np.allclose(x0, qo.vec_randomize(n, 1).real, rtol=1e-13, atol=0)
+    hr = np.zeros(2 * maxit)
+    m1 = q.lanczos_real(0, 40, maxit, A, vr, hr)                              # 40 steps, then continue to convergence
+    assert m1 == 40
+    m2 = q.lanczos_real(m1, maxit - 1 - m1, maxit, A, vr, hr, state=q.lanczos_real.last["state"])
+    assert abs(m2 - mc) <= 1
+    assert np.allclose(hr[maxit:maxit + 30], hc[maxit:maxit + 30], rtol=1e-9, atol=1e-11)     # a_0 .. a_29
+    assert np.allclose(hr[1:31], hc[1:31], rtol=1e-9, atol=1e-11)                               # b_1 .. b_30
+    e_r, _ = q.hess_eigen(hr, maxit, m2, "sr")
+    assert abs(e_r[0] - helpers.known()["kagome_12"]["E0"]) < 1e-8
+    st = A.stats()
+    assert st.n_spmv_real > 0
