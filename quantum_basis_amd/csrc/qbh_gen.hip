@@ -654,6 +654,12 @@ extern "C" int qbh_mf_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bon
     MfHeis t;
     t.n_sites = n_sites;
     t.n_dn = n_dn;
+    t.n_real = nb;
+    t.uniform = 1;
+    for (int q = 1; q < nb; ++q)
+        if (offd[(size_t)q] != offd[0]) t.uniform = 0;
+    t.offd0 = nb > 0 ? offd[0] : 0.0;
+    t.diag0 = nb > 0 ? diag[0] : 0.0;
     t.n_bonds = nbp;
     t.n_chunks = n_chunks;
     std::vector<void *> pool;

@@ -151,6 +151,9 @@ struct MfHeis {
     uint64_t *mask = nullptr;      // [n_bonds] (1 << a) | (1 << b)
     double   *offd = nullptr;      // [n_bonds] J_b / 2
     double   *diag = nullptr;      // [n_bonds] J_b / 4
+    int       n_real = 0;          // bonds before padding
+    int       uniform = 0;         // 1: every bond has the same weight (offd0, diag0): no per-bond amplitude reads
+    double    offd0 = 0.0, diag0 = 0.0;
 };
 struct MfHeisArgs {
     MfHeis t;

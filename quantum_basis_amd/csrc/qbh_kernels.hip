@@ -1833,7 +1833,8 @@ __global__ __launch_bounds__(kMfRowBlock) void k_mf_hubbard_row(MfArgs a, int ch
 // lookup per 6 bits) and the bond list; the only global traffic is the x gather, y and the epilogue operands.
 constexpr int kMfHeisBlock = 512;
 
-template <bool REALX>
+// NCH > 0: the number of chunks as a compile-time constant (re-ranking loop fully unrolled, 32-bit index arithmetic)
+template <bool REALX, int NCH>
 __global__ __launch_bounds__(kMfHeisBlock) void k_mf_heis(MfHeisArgs a)
 {
     extern __shared__ unsigned long long lds_u64[];
@@ -1855,6 +1856,8 @@ __global__ __launch_bounds__(kMfHeisBlock) void k_mf_heis(MfHeisArgs a)
     }
     __syncthreads();
     double acc[3] = {0.0, 0.0, 0.0};
+    const bool uniform = t.uniform != 0;
+    const double offd0 = t.offd0, diag0 = t.diag0;
     const int64_t stride = (int64_t)gridDim.x * kMfHeisBlock;
     for (int64_t lrow = (int64_t)blockIdx.x * kMfHeisBlock + tid; lrow < a.nrows; lrow += stride) {
         const int64_t grow = a.row_begin + lrow;
@@ -1870,6 +1873,7 @@ __global__ __launch_bounds__(kMfHeisBlock) void k_mf_heis(MfHeisArgs a)
         // (a per-lane walk over only the flipping bonds was measured: 7 % faster at 39 % flipping bonds, 9 % slower at
         // Sz = 0 where half of them flip -- the uniform loop stays)
         double dg = 0.0;
+        int ndiff = 0;
         d2 sum = {0.0, 0.0};
         for (int b0 = 0; b0 < t.n_bonds; b0 += 8) {
             long long idx[8];
@@ -1878,17 +1882,33 @@ __global__ __launch_bounds__(kMfHeisBlock) void k_mf_heis(MfHeisArgs a)
             for (int j = 0; j < 8; ++j) {
                 const unsigned long long m = mask[b0 + j];
                 const bool differ = __popcll(s & m) == 1;
-                dg += differ ? -diag[b0 + j] : diag[b0 + j];
-                amp[j] = differ ? offd[b0 + j] : 0.0;
+                if (uniform) {
+                    ndiff += differ ? 1 : 0;
+                    amp[j] = differ ? offd0 : 0.0;
+                } else {
+                    dg += differ ? -diag[b0 + j] : diag[b0 + j];
+                    amp[j] = differ ? offd[b0 + j] : 0.0;
+                }
                 long long q = grow;
                 if (differ) {
                     const unsigned long long f = s ^ m;
                     unsigned long long rk = 0;
-                    int below = 0;
-                    for (int c = 0; c < t.n_chunks; ++c) {
-                        const int bits = (int)((f >> (6 * c)) & 63ULL);
-                        rk += chunk[((size_t)c * nk + below) * 64 + bits];
-                        below += __popc(bits);
+                    if (NCH > 0) {
+                        const uint32_t flo = (uint32_t)f, fhi = (uint32_t)(f >> 30);      // chunks 0-4 | chunks 5-9
+                        int below64 = 0;                                               // 64 * (particles below)
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) {
+                            const int bits = (int)(((c < 5 ? flo >> (6 * c) : fhi >> (6 * (c - 5)))) & 63u);
+                            rk += chunk[c * nk * 64 + below64 + bits];
+                            below64 += __popc(bits) << 6;
+                        }
+                    } else {
+                        int below = 0;
+                        for (int c = 0; c < t.n_chunks; ++c) {
+                            const int bits = (int)((f >> (6 * c)) & 63ULL);
+                            rk += chunk[((size_t)c * nk + below) * 64 + bits];
+                            below += __popc(bits);
+                        }
                     }
                     q = (long long)rk;
                 }
@@ -1917,6 +1937,7 @@ __global__ __launch_bounds__(kMfHeisBlock) void k_mf_heis(MfHeisArgs a)
             if (REALX) xi.x = a.xr[grow];
             else       xi = a.xg[grow];
         }
+        if (uniform) dg = diag0 * (double)(t.n_real - 2 * ndiff);
         sum += dg * xi;                                // diagonal: sum_b +-J_b/4
         const d2 yn = a.alpha * sum + a.beta * yo + a.gamma * xi;
         if (a.y_re != nullptr) a.y_re[lrow] = yn.x;
@@ -1963,13 +1984,20 @@ int launch_mf_heis(const MfHeisArgs &a, hipStream_t s, int *nparts_out)
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, ((size_t)158 * 1024) / (lds + 1024)));
     const int64_t nblk = (a.nrows + kMfHeisBlock - 1) / kMfHeisBlock;
     const int g = (int)std::min<int64_t>(nblk, (int64_t)ncu * per_cu);
-    if (a.xr != nullptr) {
-        QBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_heis<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_mf_heis<true>, dim3(g), dim3(kMfHeisBlock), lds, s, a);
-    } else {
-        QBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_heis<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_mf_heis<false>, dim3(g), dim3(kMfHeisBlock), lds, s, a);
+#define QBH_HEIS_LAUNCH(RX, NC)                                                                                                    \
+    do {                                                                                                                          \
+        QBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_heis<RX, NC>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds));                                                                                   \
+        hipLaunchKernelGGL((k_mf_heis<RX, NC>), dim3(g), dim3(kMfHeisBlock), lds, s, a);                                           \
+    } while (0)
+    const bool rx = a.xr != nullptr;
+    switch (t.n_chunks) {                                   // 24..36 sites get the unrolled forms
+    case 4: if (rx) QBH_HEIS_LAUNCH(true, 4); else QBH_HEIS_LAUNCH(false, 4); break;
+    case 5: if (rx) QBH_HEIS_LAUNCH(true, 5); else QBH_HEIS_LAUNCH(false, 5); break;
+    case 6: if (rx) QBH_HEIS_LAUNCH(true, 6); else QBH_HEIS_LAUNCH(false, 6); break;
+    default: if (rx) QBH_HEIS_LAUNCH(true, 0); else QBH_HEIS_LAUNCH(false, 0); break;
     }
+#undef QBH_HEIS_LAUNCH
     QBH_HIP(hipGetLastError());
     if (nparts_out) *nparts_out = g;
     return QBH_OK;
