@@ -41,7 +41,7 @@ def workloads():
         # BASELINE.json configs[1] / C2
         "kagome_30": dict(kind="heisenberg", n_sites=30, n_dn=15, bonds=lattices.kagome(5, 2), J=1.0),
         # BASELINE.json configs[1]: the 36-site kagome torus (4 x 3 cells).  Sz = 0 has dim 9,075,135,300: no CSR can be
-        # stored; it runs matrix-free with real-packed vectors (tools/kagome36.py).  n_dn = 9 is the same lattice at dim 9.4e7.
+        # stored; it runs matrix-free with real-packed vectors (tools/big_lanczos.py kagome36).  n_dn = 9 is the same lattice at dim 9.4e7.
         "kagome_36_n9": dict(kind="heisenberg", n_sites=36, n_dn=9, bonds=lattices.kagome(4, 3), J=1.0),
         "kagome_24": dict(kind="heisenberg", n_sites=24, n_dn=12, bonds=lattices.kagome(4, 2), J=1.0),
         "chain_22": dict(kind="heisenberg", n_sites=22, n_dn=11, bonds=lattices.chain(22), J=1.0),

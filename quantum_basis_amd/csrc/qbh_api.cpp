@@ -682,7 +682,7 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
                          (nb + 2) * 12;
     info->bytes_algorithmic = nnz * 20 + (A->nrows + 1) * 8 + A->nrows * 32;
     if (A->kind == 1)
-        info->bytes_matrix = (A->mf.Nu * A->mf.wu + A->mf.Nd * A->mf.wd) * 3 + (A->mf.Nu + A->mf.Nd) * 4;
+        info->bytes_matrix = (A->mf.Nu * A->mf.wu + A->mf.Nd * A->mf.wd) * 5 + A->mf.Nd * A->mf.wd * 4 + (A->mf.Nu + A->mf.Nd) * 4;
     if (A->kind == 2)
         info->bytes_matrix = ((int64_t)(A->mfh.n_sites + 1) * (A->mfh.n_dn + 1) + (int64_t)A->mfh.n_chunks * (A->mfh.n_dn + 1) * 64 +
                               3 * (int64_t)A->mfh.n_bonds) * 8;

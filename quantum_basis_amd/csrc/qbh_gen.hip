@@ -396,17 +396,17 @@ extern "C" int qbh_gen_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, i
 
 namespace {
 // hop table -> ELL (entry k of configuration c at [k*N + c]), padded to groups of 8 with (c, amplitude 0); targets as
-// uint16, amplitudes as codes into amp[] (shared by both species)
-int upload_ell(const qbh::HopTableView &H, std::vector<double> &amp, int *width, uint16_t **d_tgt, uint8_t **d_val)
+// uint32, amplitudes as codes into amp[] (shared by both species)
+int upload_ell(const qbh::HopTableView &H, std::vector<double> &amp, int *width, uint32_t **d_tgt, uint8_t **d_val)
 {
     const int64_t N = H.n;
     int w = 0;
     for (int64_t i = 0; i < N; ++i) w = std::max(w, H.ptr[i + 1] - H.ptr[i]);
     w = std::max(8, ((w + 7) / 8) * 8);
-    std::vector<uint16_t> tgt((size_t)w * N);
+    std::vector<uint32_t> tgt((size_t)w * N);
     std::vector<uint8_t> val((size_t)w * N, 0);               // code 0 = amplitude 0.0
     for (int k = 0; k < w; ++k)
-        for (int64_t i = 0; i < N; ++i) tgt[(size_t)k * N + i] = (uint16_t)i;
+        for (int64_t i = 0; i < N; ++i) tgt[(size_t)k * N + i] = (uint32_t)i;
     for (int64_t i = 0; i < N; ++i)
         for (int q = H.ptr[i]; q < H.ptr[i + 1]; ++q) {
             int code = -1;
@@ -420,13 +420,13 @@ int upload_ell(const qbh::HopTableView &H, std::vector<double> &amp, int *width,
                 amp.push_back(H.val[q]);
                 code = (int)amp.size() - 1;
             }
-            tgt[(size_t)(q - H.ptr[i]) * N + i] = (uint16_t)H.tgt[q];
+            tgt[(size_t)(q - H.ptr[i]) * N + i] = (uint32_t)H.tgt[q];
             val[(size_t)(q - H.ptr[i]) * N + i] = (uint8_t)code;
         }
     *width = w;
-    QBH_HIP(hipMalloc(d_tgt, tgt.size() * sizeof(uint16_t)));
+    QBH_HIP(hipMalloc(d_tgt, tgt.size() * sizeof(uint32_t)));
     QBH_HIP(hipMalloc(d_val, val.size()));
-    QBH_HIP(hipMemcpy(*d_tgt, tgt.data(), tgt.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    QBH_HIP(hipMemcpy(*d_tgt, tgt.data(), tgt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     QBH_HIP(hipMemcpy(*d_val, val.data(), val.size(), hipMemcpyHostToDevice));
     return QBH_OK;
 }
@@ -475,8 +475,8 @@ extern "C" int qbh_mf_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, in
     QBH_HIP(hipMemcpy(m.cfg_u, hu.cfg.data(), (size_t)Nu * sizeof(uint32_t), hipMemcpyHostToDevice));
     QBH_HIP(hipMemcpy(m.cfg_d, hd.cfg.data(), (size_t)Nd * sizeof(uint32_t), hipMemcpyHostToDevice));
     HopTableView vu{Nu, hu.ptr.data(), hu.tgt.data(), hu.val.data()}, vd{Nd, hd.ptr.data(), hd.tgt.data(), hd.val.data()};
-    if (Nu > 65535 || Nd > 65535) {
-        set_error("qbh_mf_hubbard: more than 65535 configurations per species");
+    if (Nu >= (1 << 24) || Nd >= (1 << 24)) {
+        set_error("qbh_mf_hubbard: more than 2^24 configurations per species");
         return QBH_EUNSUPP;
     }
     std::vector<double> amp(1, 0.0);
@@ -493,7 +493,7 @@ extern "C" int qbh_mf_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, in
                 int code = 0;
                 for (size_t c = 0; c < amp.size(); ++c)
                     if (amp[c] == hd.val[q]) code = (int)c;
-                pk[((size_t)(k / 4) * Nd + d) * 4 + (k & 3)] = (uint32_t)hd.tgt[q] | ((uint32_t)code << 16);
+                pk[((size_t)(k / 4) * Nd + d) * 4 + (k & 3)] = (uint32_t)hd.tgt[q] | ((uint32_t)code << 24);
             }
         QBH_HIP(hipMalloc(&m.pk_d, pk.size() * sizeof(uint32_t)));
         QBH_HIP(hipMemcpy(m.pk_d, pk.data(), pk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));

@@ -119,11 +119,11 @@ struct MfHubbard {
     double  U = 0.0;
     uint32_t *cfg_u = nullptr, *cfg_d = nullptr;
     // ELL tables, entry k of configuration c at [k*N + c]; padding = (c itself, amplitude 0).  Kept small so that they
-    // stay L2-resident next to the x window: targets as uint16 (N <= 65535 configurations per species), amplitudes as
+    // stay L2-resident next to the x window: targets as uint32 (N < 2^24 configurations per species), amplitudes as
     // 1-byte codes into amp[] (<= 16 distinct hopping amplitudes: +-t times the bond multiplicity, and 0)
-    uint16_t *tgt_u = nullptr, *tgt_d = nullptr;
+    uint32_t *tgt_u = nullptr, *tgt_d = nullptr;
     uint8_t  *val_u = nullptr, *val_d = nullptr;
-    // down-species table once more as packed words {target | code << 16}, hops 4j..4j+3 of configuration c in the
+    // down-species table once more as packed words {target | code << 24}, hops 4j..4j+3 of configuration c in the
     // 16 bytes at [(j * N + c) * 4] (one coalesced load per four hops in the row-staged kernel)
     uint32_t *pk_d = nullptr;
     double    amp[16] = {0};

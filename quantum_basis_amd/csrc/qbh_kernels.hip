@@ -1682,7 +1682,7 @@ __global__ __launch_bounds__(kBlock) void k_mf_hubbard(MfArgs a)
 //   * the up-species hops  Y[u][:] += sum_j a_j X[u'_j][:]  are row AXPYs: fully coalesced 512-byte wave loads, the
 //     ~17 neighbour rows shared through L2 / Infinity Cache with the workgroups working on nearby u,
 //   * x_local of the fused epilogue comes from the staged row for free.
-// The down-hop table is read as packed {target:16 | amplitude code:8} words, four hops per 16-byte load.
+// The down-hop table is read as packed {target:24 | amplitude code:8} words, four hops per 16-byte load.
 constexpr int kMfRowBlock = 1024;
 constexpr int kMfMaxUp = 64;
 
@@ -1775,7 +1775,7 @@ __global__ __launch_bounds__(kMfRowBlock) void k_mf_hubbard_row(MfArgs a, int ch
                     bool any_miss = false;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const int64_t tg = (int64_t)(w[j] & 0xFFFFu);
+                        const int64_t tg = (int64_t)(w[j] & 0xFFFFFFu);
                         miss[j] = tg < w_lo || tg >= w_hi;
                         any_miss = any_miss || miss[j];
                         xv[j] = xs[miss[j] ? 0 : tg - w_lo];
@@ -1783,14 +1783,14 @@ __global__ __launch_bounds__(kMfRowBlock) void k_mf_hubbard_row(MfArgs a, int ch
                     if (any_miss) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
-                            if (miss[j]) xv[j] = xrow[w[j] & 0xFFFFu];
+                            if (miss[j]) xv[j] = xrow[w[j] & 0xFFFFFFu];
                     }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) xv[j] = xs[w[j] & 0xFFFFu];
+                    for (int j = 0; j < 8; ++j) xv[j] = xs[w[j] & 0xFFFFFFu];
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sum += amp_s[w[j] >> 16] * xv[j];
+                for (int j = 0; j < 8; ++j) sum += amp_s[w[j] >> 24] * xv[j];
             }
             const int64_t lrow = u * Nd + d - a.row_begin;
             d2 yo = {0.0, 0.0};
@@ -2010,7 +2010,7 @@ bool mf_row_kernel_ok(const MfArgs &a)
     if (const char *e = getenv("QBH_MF_ROW")) {
         if (!atoi(e)) return false;
     }
-    return a.t.Nd >= 256 && a.t.Nd <= 65535 && a.t.wu <= kMfMaxUp && (a.t.wd % 8) == 0;
+    return a.t.Nd >= 256 && a.t.Nd < (1 << 24) && a.t.wu <= kMfMaxUp && (a.t.wd % 8) == 0;
 }
 
 // *nparts_out = number of partial-sum triples written (workgroups launched)
