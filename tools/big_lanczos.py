@@ -4,6 +4,8 @@ vectors stored as packed doubles (qbh_lanczos_real_dev), nothing else in HBM.
 
   kagome36   BASELINE.json configs[1]: spin-1/2 Heisenberg, 36-site kagome torus (4 x 3 cells), Sz = 0:
              dim = C(36,18) = 9,075,135,300 (no CSR can be stored: 3.4e11 nonzeros; complex vectors: 2 x 145 GB)
+  triangular36  the 6 x 6 triangular torus of BASELINE.json configs[4] WITHOUT the translation symmetry, Sz = 0 (same dim);
+             its E0 must be the minimum over the momentum sectors (literature: E0/N = -0.5604 for N = 36)
   hubbard4x5 BASELINE.json configs[3] family: Fermi-Hubbard 4 x 5, t = 1, U = 1.1, N_up = N_dn = n (n = 7: dim 6.0e9)
 
 usage: python tools/big_lanczos.py kagome36 [n_dn=18] [max_steps=400] [chunk=25]
@@ -18,12 +20,12 @@ import quantum_basis_amd as q  # noqa: E402
 from quantum_basis_amd import _lib, lattices  # noqa: E402
 
 model = sys.argv[1] if len(sys.argv) > 1 else "kagome36"
-npart = int(sys.argv[2]) if len(sys.argv) > 2 else (18 if model == "kagome36" else 7)
+npart = int(sys.argv[2]) if len(sys.argv) > 2 else (7 if model == "hubbard4x5" else 18)
 max_steps = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 25
 t0 = time.time()
-if model == "kagome36":
-    bonds, n_sites = lattices.kagome(4, 3), 36
+if model in ("kagome36", "triangular36"):
+    bonds, n_sites = (lattices.kagome(4, 3) if model == "kagome36" else lattices.triangular(6, 6)), 36
     A = q.csr_mat.heisenberg(36, npart, bonds, J=1.0, matrix_free=True, opts=q.make_opts(profile=1))
 else:
     bonds, n_sites = lattices.square(4, 5), 20
