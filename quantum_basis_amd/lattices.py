@@ -58,6 +58,33 @@ def kagome(Lx, Ly):
     return b
 
 
+def kagome_torus(T1, T2):
+    """The same kagome bond pattern on the torus spanned by T1 = (a, b), T2 = (c, d) (in unit cells): a*d - b*c cells.
+    In this bond convention the two cell vectors are 120 degrees apart, so the six-fold symmetric 12-cell (36-site)
+    cluster of the literature is T1 = (4, 2), T2 = (2, 4)."""
+    (a, b), (c, d) = T1, T2
+    det = a * d - b * c
+    assert det > 0
+    cells = {}
+    for m in range(abs(det) + 1):
+        for n in range(abs(det) + 1):
+            key = ((d * m - c * n) % det, (-b * m + a * n) % det)
+            if key not in cells:
+                cells[key] = len(cells)
+    assert len(cells) == det
+
+    def site(m, n, sub):
+        return sub + 3 * cells[((d * m - c * n) % det, (-b * m + a * n) % det)]
+    bonds = set()
+    for m in range(abs(det) + 1):
+        for n in range(abs(det) + 1):
+            i0, i1, i2 = site(m, n, 0), site(m, n, 1), site(m, n, 2)
+            for p, q2 in ((i0, site(m + 1, n, 2)), (i0, i2), (i1, site(m, n + 1, 0)), (i1, i0), (i2, site(m - 1, n - 1, 1)), (i2, i1)):
+                bonds.add((min(p, q2), max(p, q2)))
+    assert len(bonds) == 6 * det
+    return sorted(bonds)
+
+
 def translations(Lx, Ly=1, n_sub=1, site=None):
     """All Lx*Ly translations of a periodic cluster as site permutations (first = identity) and their shifts.
     `site(x, y, sub)` is the numbering used for the bonds (default sub + n_sub*(x + Lx*y))."""

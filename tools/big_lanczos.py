@@ -4,6 +4,7 @@ vectors stored as packed doubles (qbh_lanczos_real_dev), nothing else in HBM.
 
   kagome36   BASELINE.json configs[1]: spin-1/2 Heisenberg, 36-site kagome torus (4 x 3 cells), Sz = 0:
              dim = C(36,18) = 9,075,135,300 (no CSR can be stored: 3.4e11 nonzeros; complex vectors: 2 x 145 GB)
+  kagome36a  the six-fold symmetric 36-site kagome cluster of the literature (torus (4,2) x (2,4) in unit cells)
   triangular36  the 6 x 6 triangular torus of BASELINE.json configs[4] WITHOUT the translation symmetry, Sz = 0 (same dim);
              its E0 must be the minimum over the momentum sectors (literature: E0/N = -0.5604 for N = 36)
   hubbard4x5 BASELINE.json configs[3] family: Fermi-Hubbard 4 x 5, t = 1, U = 1.1, N_up = N_dn = n (n = 7: dim 6.0e9)
@@ -24,8 +25,10 @@ npart = int(sys.argv[2]) if len(sys.argv) > 2 else (7 if model == "hubbard4x5" e
 max_steps = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 25
 t0 = time.time()
-if model in ("kagome36", "triangular36"):
-    bonds, n_sites = (lattices.kagome(4, 3) if model == "kagome36" else lattices.triangular(6, 6)), 36
+if model in ("kagome36", "kagome36a", "triangular36"):
+    bonds = {"kagome36": lambda: lattices.kagome(4, 3), "kagome36a": lambda: lattices.kagome_torus((4, 2), (2, 4)),
+             "triangular36": lambda: lattices.triangular(6, 6)}[model]()
+    n_sites = 36
     A = q.csr_mat.heisenberg(36, npart, bonds, J=1.0, matrix_free=True, opts=q.make_opts(profile=1))
 else:
     bonds, n_sites = lattices.square(4, 5), 20
