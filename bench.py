@@ -42,6 +42,11 @@ def workloads():
         "kagome_30": dict(kind="heisenberg", n_sites=30, n_dn=15, bonds=lattices.kagome(5, 2), J=1.0),
         # BASELINE.json configs[1]: the 36-site kagome torus (4 x 3 cells).  Sz = 0 has dim 9,075,135,300: no CSR can be
         # stored; it runs matrix-free with real-packed vectors (tools/big_lanczos.py kagome36).  n_dn = 9 is the same lattice at dim 9.4e7.
+        "kagome_36": dict(kind="heisenberg", n_sites=36, n_dn=18, bonds=lattices.kagome(4, 3), J=1.0, packed_real=True),
+        "kagome_36a": dict(kind="heisenberg", n_sites=36, n_dn=18, bonds=lattices.kagome_torus((4, 2), (2, 4)), J=1.0, packed_real=True),
+        "triangular_36": dict(kind="heisenberg", n_sites=36, n_dn=18, bonds=lattices.triangular(6, 6), J=1.0, packed_real=True),
+        "hubbard_4x5_n7": dict(kind="hubbard", n_sites=20, n_up=7, n_dn=7, bonds=lattices.square(4, 5), t=1.0, U=1.1, packed_real=True),
+        "hubbard_4x5_n8": dict(kind="hubbard", n_sites=20, n_up=8, n_dn=8, bonds=lattices.square(4, 5), t=1.0, U=1.1, packed_real=True),
         "kagome_36_n9": dict(kind="heisenberg", n_sites=36, n_dn=9, bonds=lattices.kagome(4, 3), J=1.0),
         "kagome_24": dict(kind="heisenberg", n_sites=24, n_dn=12, bonds=lattices.kagome(4, 2), J=1.0),
         "chain_22": dict(kind="heisenberg", n_sites=22, n_dn=11, bonds=lattices.chain(22), J=1.0),
@@ -166,6 +171,9 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)
     ap.add_argument("--matrix-free", action="store_true", help="use the matrix-free Hubbard operator as THE operator (not the CSR north-star path)")
     ap.add_argument("--no-matrix-free", action="store_true", help="skip the extra measurement of the matrix-free Hubbard operator")
+    ap.add_argument("--packed-real", action="store_true", help="matrix-free operator + Lanczos vectors as packed doubles (qbh_lanczos_real_dev); "
+                    "forced for the workloads whose complex vectors do not fit one GPU")
+    ap.add_argument("--converge", action="store_true", help="run to convergence also for the dim > 1e9 packed-real workloads")
     ap.add_argument("--no-plain", action="store_true", help="skip the extra (untimed-region) measurement of the uncoded complex128 kernel")
     args = ap.parse_args()
 
@@ -196,6 +204,14 @@ def main():
             dist.init_process_group(backend=backend)
 
     W = workloads()[args.workload]
+    packed_real = bool(args.packed_real or W.get("packed_real"))
+    if packed_real:
+        if world > 1:
+            raise SystemExit("--packed-real is a single-GPU mode")
+        args.matrix_free = True
+        args.no_plain = args.no_matrix_free = args.no_cpu_baseline = True
+        if W.get("packed_real") and not args.converge:
+            args.no_converge = True          # hundreds of ~1 s steps: tools/big_lanczos.py does that run (logs under profiles/)
     dim = dim_of(W)
     if dim is None:
         r0, r1 = 0, -1                   # the generator shards by (rank, world) itself
@@ -228,20 +244,29 @@ def main():
         K, Wm = args.steps, args.warmup
         maxit = max(K + Wm + 16, 64)
         n = A.dim
-        v = A.vec(2)
+        v = A.vec(1 if packed_real else 2)           # packed doubles: n complex128 = the two slots of n doubles
         hess = np.zeros(2 * maxit)
 
         def fresh_start(seed):
-            A.randomize(v.at(0), seed)
+            if packed_real:
+                import ctypes
+                _lib.check(_lib.lib().qbh_vec_randomize_real(A.handle, v.ptr, ctypes.c_uint32(seed)), "qbh_vec_randomize_real")
+            else:
+                A.randomize(v.at(0), seed)
             hess[:] = 0.0
             return 0
+
+        def lanczos_call(k0, nsteps, mx, hs):
+            if packed_real:
+                return q.lanczos_real(k0, nsteps, mx, A, v, hs)
+            return q.lanczos(k0, nsteps, mx, n, A, None, hs, "sr_val0", device_v=v)
 
         def run_steps(k, nsteps, seed):
             """Advance nsteps Lanczos steps (restarting from a new start vector if the stop rule
             fires first); returns (k, seed, steps actually done)."""
             left, total = nsteps, 0
             while left > 0:
-                m = q.lanczos(k, left, maxit, n, A, None, hess, "sr_val0", device_v=v)
+                m = lanczos_call(k, left, maxit, hess)
                 left -= m - k
                 total += m - k
                 k = m
@@ -274,8 +299,8 @@ def main():
         if not args.no_converge:
             maxit2 = 1000
             hess2 = np.zeros(2 * maxit2)
-            A.randomize(v.at(0), 1)
-            m = q.lanczos(0, maxit2 - 1, maxit2, n, A, None, hess2, "sr_val0", device_v=v)
+            fresh_start(1)
+            m = lanczos_call(0, maxit2 - 1, maxit2, hess2)
             ritz, _ = q.hess_eigen(hess2, maxit2, m, "sr")
             e0, steps_e0 = float(ritz[0]), int(m)
 
@@ -312,10 +337,13 @@ def main():
                              "real operator and real vectors, x is gathered as 8-byte real parts (bit-identical result)"},
         "e0": e0, "lanczos_steps_to_converge": steps_e0,
     }
+    if packed_real:
+        out["dtype"] = "f64 (real operator, Lanczos vectors stored as packed doubles)"
+        out["config"]["vectors"] = "2 x %.1f GB packed doubles (qbh_lanczos_real_dev)" % (dim * 8e-9)
     if args.matrix_free:
         out["config"]["kernel"] = "matrix_free"
-        out["roofline"]["kernel"] = "k_mf_hubbard"
-        out["roofline"]["note"] = ("MATRIX-FREE operator (qbh_mf_hubbard, SURVEY 8f-1): no CSR is stored; achieved = bytes the CSR of the "
+        out["roofline"]["kernel"] = "k_mf_hubbard" if W["kind"] == "hubbard" else "k_mf_heis"
+        out["roofline"]["note"] = ("MATRIX-FREE operator (qbh_mf_hubbard / qbh_mf_heisenberg, SURVEY 8f-1): no CSR is stored; achieved = bytes the CSR of the "
                                    "same operator would move per SpMV / kernel time -- not the north-star CSR measurement")
     if world == 1 and info.value_dict and not args.no_plain:
         # transparency: the same SpMV with the value stream left as complex128 (16 B/nnz), measured after the
