@@ -1467,7 +1467,7 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
             return QBH_OK;
         }
     }
-    std::vector<double> w((size_t)mm + 2), zl((size_t)mm + 2), ws((size_t)mm + 2);
+    std::vector<double> w((size_t)mm + 8), zl((size_t)mm + 8), ws((size_t)mm + 8);     // ws always holds four Ritz values
     int rc = QBH_OK;
     do {                                                   // :193
         m++;

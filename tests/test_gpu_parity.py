@@ -736,3 +736,25 @@ def test_lanczos_on_real_packed_vectors(mf):
     assert abs(e_r[0] - helpers.known()["kagome_12"]["E0"]) < 1e-8
     st = A.stats()
     assert st.n_spmv_real > 0
+
+
+def test_lanczos_single_step_calls():
+    """k + np <= 2: the driver's Ritz scratch must not depend on the step count (bench.py --warmup 1 does this)."""
+    A, O = _both("hubbard_4x2")
+    n, maxit = A.dim, 40
+    v = A.vec(2)
+    A.randomize(v.at(0), 1)
+    hess = np.zeros(2 * maxit)
+    # (k = 0, np = 1) runs TWO steps, as the reference's do-while does after the bootstrap step (src/lanczos.cc:167-193)
+    k = q.lanczos(0, 1, maxit, n, A, None, hess, "sr_val0", device_v=v)
+    assert k == 2
+    for step in (1, 1, 1):
+        k2 = q.lanczos(k, step, maxit, n, A, None, hess, "sr_val0", device_v=v)
+        assert k2 == k + step
+        k = k2
+    ref = np.zeros(2 * maxit)
+    vr = qo.vec_randomize(n, 1)
+    vv = np.zeros(2 * n, dtype=np.complex128)
+    vv[:n] = vr
+    m = qo.lanczos(0, 5, maxit, O, vv, ref, "sr_val0")[0]
+    assert m == 5 and np.allclose(hess[maxit:maxit + 5], ref[maxit:maxit + 5], rtol=1e-11) and np.allclose(hess[1:6], ref[1:6], rtol=1e-11)
