@@ -9,6 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libqbhip.so")
+if os.environ.get("QBHIP_LIBRARY"):      # e.g. a host-AddressSanitizer build of the same sources (tools/asan_build/)
+    SO_PATH = os.path.abspath(os.environ["QBHIP_LIBRARY"])
 
 QBH_OK = 0
 KERNEL_AUTO, KERNEL_STREAM, KERNEL_VECTOR, KERNEL_ROWS, KERNEL_MATRIX_FREE = 0, 1, 2, 3, 4
