@@ -214,3 +214,21 @@ def test_momentum_sector_at_scale_coded_equals_uncoded():
     assert abs(np.linalg.norm(x) - 1.0) < 1e-12 and np.abs(x.imag).max() > 1e-6
     A.destroy()
     P.destroy()
+
+
+def test_full_size_packed_double_lanczos_matrix_free():
+    """C3 through the interface used for the dim > 1e9 sectors: matrix-free operator, Lanczos vectors as packed doubles
+    (qbh_lanczos_real_dev).  Same E0 and step count as the stored-CSR complex run (-20.497352266554, 273 steps)."""
+    import ctypes as C
+    M = q.csr_mat.hubbard(16, 8, 8, lattices.square(4, 4), t=1.0, U=1.1, matrix_free=True)
+    v = M.vec(1)                                              # DIM complex128 = the two slots of DIM doubles
+    _lib.check(_lib.lib().qbh_vec_randomize_real(M.handle, v.ptr, C.c_uint32(1)), "qbh_vec_randomize_real")
+    maxit = 400
+    hess = np.zeros(2 * maxit)
+    m = q.lanczos_real(0, maxit - 1, maxit, M, v, hess)
+    ritz, _ = q.hess_eigen(hess, maxit, m, "sr")
+    assert abs(ritz[0] - (-20.497352266554)) < 1e-10 and abs(m - 273) <= 1
+    st = M.stats()
+    assert st.n_spmv == st.n_spmv_real == m
+    v.free()
+    M.destroy()
