@@ -195,6 +195,9 @@ int qbh_lanczos_dev(const qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int6
 int qbh_lanczos_real_dev(const qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_t *m,
                          double *d_v, double *hessenberg, const char *purpose, qbh_solver_info *info);
 int qbh_vec_randomize_real(const qbh_csr *A, double *d_x, uint32_t seed);
+/* eigenvec_CG (src/lanczos.cc:281-341) on four vectors stored as packed doubles; same contract as qbh_eigenvec_cg_dev. */
+int qbh_eigenvec_cg_real_dev(const qbh_csr *A, int64_t maxit, int64_t *m, double E0, double *accu,
+                             double *d_v, double *d_r, double *d_p, double *d_pp, qbh_solver_info *info);
 
 /* Replaces eigenvec_CG<T,MAT> (src/lanczos.cc:281-341): CG on (H-E0)v = 0 with the
  * reference's restart/renormalise branch and the (machine_prec - E0) shift.  *m is in/out

@@ -81,7 +81,7 @@ EXPORTS = [
     "qbh_vec_alloc", "qbh_vec_free", "qbh_vec_upload", "qbh_vec_download", "qbh_vec_zero",
     "qbh_vec_randomize",
     "qbh_spmv_dev", "qbh_dotc_dev", "qbh_axpy_norm_dev", "qbh_scal_dev", "qbh_nrm2_dev",
-    "qbh_lanczos", "qbh_lanczos_dev", "qbh_lanczos_real_dev", "qbh_vec_randomize_real", "qbh_eigenvec_cg", "qbh_eigenvec_cg_dev", "qbh_hess_eigen", "qbh_iram",
+    "qbh_lanczos", "qbh_lanczos_dev", "qbh_lanczos_real_dev", "qbh_vec_randomize_real", "qbh_eigenvec_cg_real_dev", "qbh_eigenvec_cg", "qbh_eigenvec_cg_dev", "qbh_hess_eigen", "qbh_iram",
     "qbh_csr_set_comm", "qbh_get_stats", "qbh_sync",
     "qbh_gen_hubbard", "qbh_mf_hubbard", "qbh_gen_heisenberg", "qbh_mf_heisenberg", "qbh_gen_heisenberg_repr", "qbh_csr_download",
 ]
@@ -142,6 +142,7 @@ def lib():
     L.qbh_eigenvec_cg.argtypes = [vp, i64, C.POINTER(i64), dbl, C.POINTER(dbl), vp, vp, vp, vp,
                                   C.POINTER(SolverInfo)]
     L.qbh_eigenvec_cg_dev.argtypes = L.qbh_eigenvec_cg.argtypes
+    L.qbh_eigenvec_cg_real_dev.argtypes = L.qbh_eigenvec_cg.argtypes
     L.qbh_hess_eigen.argtypes = [vp, i64, i64, C.c_char_p, vp, vp]
     L.qbh_iram.argtypes = [vp, i64, i64, i64, C.c_char_p, dbl, C.c_uint32, C.POINTER(i64), vp, vp, C.POINTER(SolverInfo)]
     L.qbh_csr_set_comm.argtypes = [vp, C.POINTER(Comm)]

@@ -1615,11 +1615,11 @@ extern "C" int qbh_lanczos(const qbh_csr *A, int64_t k, int64_t np, int64_t maxi
 }
 
 // ---------------------------------------------------------------------- CG ------
-extern "C" int qbh_eigenvec_cg_dev(const qbh_csr *Ac, int64_t maxit, int64_t *m_io, double E0, double *accu_out,
-                                   qbh_z *d_v, qbh_z *d_r, qbh_z *d_p, qbh_z *d_pp, qbh_solver_info *info)
+// ext != nullptr: the caller's four vectors are packed doubles (qbh_eigenvec_cg_real_dev): the all-real loop runs in place
+static int cg_core(qbh_csr *A, int64_t maxit, int64_t *m_io, double E0, double *accu_out, qbh_z *d_v, qbh_z *d_r, qbh_z *d_p,
+                   qbh_z *d_pp, double *const *ext, qbh_solver_info *info)
 {
-    qbh_csr *A = const_cast<qbh_csr *>(Ac);
-    if (!A || !m_io || !accu_out || !d_v || !d_r || !d_p || !d_pp) return QBH_EINVAL;
+    if (!A || !m_io || !accu_out || (!ext && (!d_v || !d_r || !d_p || !d_pp))) return QBH_EINVAL;
     if (!A->has_comm && A->nrows != A->ncols) return QBH_EINVAL;
     Bind bind(A);
     const double t_start = now_ms();
@@ -1636,8 +1636,18 @@ extern "C" int qbh_eigenvec_cg_dev(const qbh_csr *Ac, int64_t maxit, int64_t *m_
     const int64_t spmv0 = A->stats.n_spmv;
     const double ms_spmv0 = A->stats.ms_spmv;
     WireGuard wire_guard{A};
-    if (m != 0) QBH_TRY(enable_real_wire(A, {v, r, p}));
-    else        QBH_TRY(enable_real_wire(A, {v}));
+    if (ext) {
+        if (A->has_comm || !A->values_real || A->kernel != QBH_KERNEL_ROWS || A->nrows != A->ncols) {
+            qbh::set_error("qbh_eigenvec_cg_real: needs a real operator on one GPU (row kernel / matrix-free)");
+            return QBH_EINVAL;
+        }
+        A->real_wire = false;
+        A->real_mode = true;
+        A->xr_of = nullptr;
+        QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), A->stream));
+    }
+    else if (m != 0) QBH_TRY(enable_real_wire(A, {v, r, p}));
+    else             QBH_TRY(enable_real_wire(A, {v}));
     double accu = 0.0;
     double red[3], sq;
     // All-real vectors, as in qbh_lanczos_dev: one GPU, real operator, real v (and r, p when the run continues): the
@@ -1649,19 +1659,22 @@ extern "C" int qbh_eigenvec_cg_dev(const qbh_csr *Ac, int64_t maxit, int64_t *m_
     } rv_guard{&rv};
     {
         static const bool no_realvec = getenv("QBH_NO_REALVEC") != nullptr;
-        if (!A->has_comm && A->real_mode && A->kernel == QBH_KERNEL_ROWS && A->nrows == A->ncols && !no_realvec) {
+        if (!ext && !A->has_comm && A->real_mode && A->kernel == QBH_KERNEL_ROWS && A->nrows == A->ncols && !no_realvec) {
             if (hipMalloc(&rv, (size_t)4 * (size_t)n * sizeof(double)) != hipSuccess) {
                 (void)hipGetLastError();
                 rv = nullptr;
             }
         }
     }
-    if (rv != nullptr) {
-        double *vr = rv, *rr = rv + (size_t)n, *pr = rv + 2 * (size_t)n, *ppr = rv + 3 * (size_t)n;
-        QBH_TRY(qbh::launch_pack_real(v, vr, n, A->d_flag, A->stream));
-        if (m != 0) {
-            QBH_TRY(qbh::launch_pack_real(r, rr, n, A->d_flag, A->stream));
-            QBH_TRY(qbh::launch_pack_real(p, pr, n, A->d_flag, A->stream));
+    if (rv != nullptr || ext) {
+        double *vr = ext ? ext[0] : rv, *rr = ext ? ext[1] : rv + (size_t)n, *pr = ext ? ext[2] : rv + 2 * (size_t)n,
+               *ppr = ext ? ext[3] : rv + 3 * (size_t)n;
+        if (!ext) {
+            QBH_TRY(qbh::launch_pack_real(v, vr, n, A->d_flag, A->stream));
+            if (m != 0) {
+                QBH_TRY(qbh::launch_pack_real(r, rr, n, A->d_flag, A->stream));
+                QBH_TRY(qbh::launch_pack_real(p, pr, n, A->d_flag, A->stream));
+            }
         }
         A->xr_of = nullptr;
         auto nrm2_re = [&](const double *x, double *out) -> int {
@@ -1707,12 +1720,14 @@ extern "C" int qbh_eigenvec_cg_dev(const qbh_csr *Ac, int64_t maxit, int64_t *m_
                 if (info && info->cg_resid) info->cg_resid[m] = accu;
             }
         }
-        QBH_TRY(qbh::launch_unpack_real(vr, v, n, A->stream));
-        QBH_TRY(qbh::launch_unpack_real(rr, r, n, A->stream));
-        QBH_TRY(qbh::launch_unpack_real(pr, p, n, A->stream));
-        QBH_HIP(hipStreamSynchronize(A->stream));
-        (void)hipFree(rv);
-        rv = nullptr;
+        if (!ext) {
+            QBH_TRY(qbh::launch_unpack_real(vr, v, n, A->stream));
+            QBH_TRY(qbh::launch_unpack_real(rr, r, n, A->stream));
+            QBH_TRY(qbh::launch_unpack_real(pr, p, n, A->stream));
+            QBH_HIP(hipStreamSynchronize(A->stream));
+            (void)hipFree(rv);
+            rv = nullptr;
+        }
         m = -m - 1;                                         // done: skip the complex loop below
     }
     if (m >= 0 && m != 0) QBH_TRY(nrm2_run(A, r, &accu));  // :290
@@ -1762,6 +1777,20 @@ extern "C" int qbh_eigenvec_cg_dev(const qbh_csr *Ac, int64_t maxit, int64_t *m_
         info->ms_total = now_ms() - t_start;
     }
     return QBH_OK;
+}
+
+extern "C" int qbh_eigenvec_cg_dev(const qbh_csr *Ac, int64_t maxit, int64_t *m_io, double E0, double *accu_out,
+                                   qbh_z *d_v, qbh_z *d_r, qbh_z *d_p, qbh_z *d_pp, qbh_solver_info *info)
+{
+    return cg_core(const_cast<qbh_csr *>(Ac), maxit, m_io, E0, accu_out, d_v, d_r, d_p, d_pp, nullptr, info);
+}
+
+extern "C" int qbh_eigenvec_cg_real_dev(const qbh_csr *Ac, int64_t maxit, int64_t *m_io, double E0, double *accu_out,
+                                        double *d_v, double *d_r, double *d_p, double *d_pp, qbh_solver_info *info)
+{
+    if (!d_v || !d_r || !d_p || !d_pp) return QBH_EINVAL;
+    double *ext[4] = {d_v, d_r, d_p, d_pp};
+    return cg_core(const_cast<qbh_csr *>(Ac), maxit, m_io, E0, accu_out, nullptr, nullptr, nullptr, nullptr, ext, info);
 }
 
 extern "C" int qbh_eigenvec_cg(const qbh_csr *A, int64_t maxit, int64_t *m, double E0, double *accu,

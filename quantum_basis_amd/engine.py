@@ -381,6 +381,22 @@ def eigenvec_CG(dim, maxit, m, mat, E0, v, r, p, pp, device=False):
 eigenvec_CG.last = {}
 
 
+def eigenvec_CG_real(maxit, m, mat, E0, v, r, p, pp):
+    """qbh_eigenvec_cg_real_dev: eigenvec_CG on four device vectors of mat.dim PACKED DOUBLES (device addresses);
+    returns (m, accu)."""
+    mm = C.c_int64(m)
+    accu = C.c_double(0.0)
+    info, keep = _solver_info(maxit, want_log=False, want_resid=True)
+    check(lib().qbh_eigenvec_cg_real_dev(mat.handle, maxit, C.byref(mm), float(np.real(E0)), C.byref(accu), v, r, p, pp,
+                                         C.byref(info)), "qbh_eigenvec_cg_real_dev")
+    eigenvec_CG_real.last = dict(resid=[info.cg_resid[i] for i in range(1, mm.value + 1)], n_matvec=info.n_matvec,
+                                 ms_total=info.ms_total)
+    return mm.value, accu.value
+
+
+eigenvec_CG_real.last = {}
+
+
 def _iram_checks(dim, nev, maxit, order):
     if nev <= 0 or nev >= dim - 1:
         raise ValueError("0 < nev < N-1 should be satisfied.")          # src/lanczos.cc:502

@@ -758,3 +758,29 @@ def test_lanczos_single_step_calls():
     vv[:n] = vr
     m = qo.lanczos(0, 5, maxit, O, vv, ref, "sr_val0")[0]
     assert m == 5 and np.allclose(hess[maxit:maxit + 5], ref[maxit:maxit + 5], rtol=1e-11) and np.allclose(hess[1:6], ref[1:6], rtol=1e-11)
+
+
+@pytest.mark.parametrize("mf", [False, True])
+def test_cg_on_real_packed_vectors(mf):
+    """qbh_eigenvec_cg_real_dev after qbh_lanczos_real_dev: the whole E0 -> V0 pipeline without a complex vector;
+    the eigenvector equals the one of the complex interface."""
+    import ctypes as C
+    bonds = lattices.square(4, 2)
+    A = q.csr_mat.hubbard(8, 4, 4, bonds, t=1.0, U=1.1, matrix_free=mf)
+    n, maxit = A.dim, 400
+    ref = q.locate_E0_lanczos(A, nev=1, ncv=1, maxit=maxit)
+    buf = A.vec(2)                                             # 2n complex128 = 4n doubles: v, r, p, pp
+    at = lambda j: C.c_void_p(buf.ptr.value + 8 * n * j)
+    _lib.check(_lib.lib().qbh_vec_randomize_real(A.handle, at(0), C.c_uint32(1)), "qbh_vec_randomize_real")
+    hess = np.zeros(2 * maxit)
+    lan = type("V", (), {"ptr": at(0)})()                      # slots 0, 1 of the buffer are the two Lanczos vectors
+    m = q.lanczos_real(0, maxit - 1, maxit, A, lan, hess)
+    ritz, _ = q.hess_eigen(hess, maxit, m, "sr")
+    assert abs(ritz[0] - ref.E0) <= 1e-11 * abs(ref.E0) and abs(m - ref.steps["E0"]) <= 1
+    _lib.check(_lib.lib().qbh_vec_randomize_real(A.handle, at(0), C.c_uint32(1)), "qbh_vec_randomize_real")   # CG start vector, :1205
+    mcg, accu = q.eigenvec_CG_real(maxit, 0, A, ritz[0], at(0), at(1), at(2), at(3))
+    assert accu < 2e-12 and abs(mcg - ref.steps["V0"]) <= 2
+    vec = buf.download(0, n // 2).view(np.float64)             # n doubles
+    assert abs(np.linalg.norm(vec) - 1.0) < 1e-10
+    assert abs(abs(np.dot(vec, ref.eigenvecs.real)) - 1.0) < 1e-8
+    assert abs(ritz[0] - helpers.known()["hubbard_4x2"]["E0"]) < 1e-8

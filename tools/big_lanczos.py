@@ -10,7 +10,8 @@ vectors stored as packed doubles (qbh_lanczos_real_dev), nothing else in HBM.
   hubbard4x5 BASELINE.json configs[3] family: Fermi-Hubbard 4 x 5, t = 1, U = 1.1, N_up = N_dn = n (n = 7: dim 6.0e9)
 
 usage: python tools/big_lanczos.py kagome36 [n_dn=18] [max_steps=400] [chunk=25]
-       python tools/big_lanczos.py hubbard4x5 [n=7] [max_steps=400] [chunk=25]"""
+       python tools/big_lanczos.py hubbard4x5 [n=7] [max_steps=400] [chunk=25] [vector]
+"vector": also the ground-state vector by eigenvec_CG on packed doubles (four vectors must fit: 4 x 8 x dim bytes)."""
 import ctypes as C
 import sys
 import time
@@ -24,6 +25,7 @@ model = sys.argv[1] if len(sys.argv) > 1 else "kagome36"
 npart = int(sys.argv[2]) if len(sys.argv) > 2 else (7 if model == "hubbard4x5" else 18)
 max_steps = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 25
+want_vector = len(sys.argv) > 5 and sys.argv[5] == "vector"
 t0 = time.time()
 if model in ("kagome36", "kagome36a", "triangular36"):
     bonds = {"kagome36": lambda: lattices.kagome(4, 3), "kagome36a": lambda: lattices.kagome_torus((4, 2), (2, 4)),
@@ -36,7 +38,7 @@ else:
 n = A.dim
 print("%s: dim %d, %d bonds, equivalent CSR nnz %d (%.2f TB as complex128 CSR); vectors: 2 x %.1f GB as doubles"
       % (model, n, len(bonds), A.nnz, A.nnz * 20e-12, n * 8e-9), flush=True)
-v = A.vec(1)                                   # n complex128 = 2n doubles = the two Lanczos slots
+v = A.vec(2 if want_vector else 1)             # n complex128 = 2n doubles = the two Lanczos slots (4n: v, r, p, pp of CG)
 _lib.check(_lib.lib().qbh_vec_randomize_real(A.handle, v.ptr, C.c_uint32(1)), "qbh_vec_randomize_real")
 A.sync()
 print("start vector %.1f s" % (time.time() - t0), flush=True)
@@ -58,3 +60,10 @@ while k < max_steps:
     if done:
         break
 print("done: %d Lanczos steps, E0 = %.12f, %.1f s" % (k, ritz[0], time.time() - t1), flush=True)
+if want_vector:
+    at = lambda j: C.c_void_p(v.ptr.value + 8 * n * j)
+    _lib.check(_lib.lib().qbh_vec_randomize_real(A.handle, at(0), C.c_uint32(1)), "qbh_vec_randomize_real")   # src/model.cc:1205
+    t2 = time.time()
+    mcg, accu = q.eigenvec_CG_real(1000, 0, A, ritz[0], at(0), at(1), at(2), at(3))
+    print("ground-state vector: %d CG steps, |(H - E0) v| = %.3e, %.1f s (%.3f s/step)"
+          % (mcg, accu, time.time() - t2, (time.time() - t2) / max(mcg, 1)), flush=True)
