@@ -232,3 +232,36 @@ def test_full_size_packed_double_lanczos_matrix_free():
     assert st.n_spmv == st.n_spmv_real == m
     v.free()
     M.destroy()
+
+
+def test_kagome36_lattice_matrix_free_equals_csr_at_dim_9e7():
+    """The 36-site kagome torus of BASELINE configs[1] at N_dn = 9 (dim 94,143,280: the largest filling whose CSR is
+    cheap to build next to the matrix-free operator): y = Hx agrees, and the packed-double Lanczos of the matrix-free
+    operator gives the stored CSR's E0."""
+    import ctypes as C
+    bonds = lattices.kagome(4, 3)
+    A = q.csr_mat.heisenberg(36, 9, bonds, J=1.0)
+    M = q.csr_mat.heisenberg(36, 9, bonds, J=1.0, matrix_free=True)
+    n = A.dim
+    assert n == M.dim == math.comb(36, 9) and A.nnz == M.nnz
+    v = A.vec(3)
+    A.randomize(v.at(0), 5)
+    A.spmv(v.at(0), v.at(n))
+    A.sync()
+    M.spmv(v.at(0), v.at(2 * n))
+    M.sync()
+    hx = A.nrm2(v.at(n))
+    assert np.sqrt(A.axpy_norm(-1.0, v.at(n), v.at(2 * n))) <= 1e-13 * hx
+    v.free()
+    vr = M.vec(1)
+    _lib.check(_lib.lib().qbh_vec_randomize_real(M.handle, vr.ptr, C.c_uint32(1)), "qbh_vec_randomize_real")
+    maxit = 500
+    hess = np.zeros(2 * maxit)
+    m = q.lanczos_real(0, maxit - 1, maxit, M, vr, hess)
+    ritz, _ = q.hess_eigen(hess, maxit, m, "sr")
+    ref = q.locate_E0_lanczos(A, nev=1, ncv=0)
+    assert abs(ritz[0] - ref.E0) <= 1e-11 * abs(ref.E0) and abs(m - ref.steps["E0"]) <= 1
+    assert abs(ritz[0] - (-7.224480305678)) < 1e-9
+    vr.free()
+    A.destroy()
+    M.destroy()
