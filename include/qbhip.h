@@ -77,6 +77,9 @@ typedef struct qbh_opts {
                                 <= 65536 (row kernel only); 2 = 1-byte codes only                  */
     int     profile;         /* 1: bracket every SpMV launch with HIP events (qbh_get_stats)       */
     int     check_hermitian; /* 1 (default): full-storage host input is checked like sparse.cc:235 */
+    int     real_fast_path;  /* 1 (default): a real operator applied to vectors with exactly zero imaginary
+                                parts gathers / exchanges 8-byte real parts (bit-identical results);
+                                0: always the complex128 arithmetic of the reference (north-star format)   */
 } qbh_opts;
 
 void qbh_opts_default(qbh_opts *o);
@@ -91,6 +94,21 @@ void qbh_opts_default(qbh_opts *o);
 int qbh_csr_create(qbh_csr **out, int64_t dim, int64_t nnz, int sym_upper,
                    const int64_t *ia, const int64_t *ja, const qbh_z *val,
                    const qbh_opts *opts);
+
+/* The same constructor for ONE row block of the operator (the CSR that the unchanged host code
+ * assembles, src/model.cc:619-685, sharded over the GPUs of a node).  Every rank passes the SAME host arrays and its
+ * own [row_begin, row_end); the handle holds those rows of the FULL operator (for Hermitian-upper input that includes
+ * the mirrored entries whose upper-triangle twin lives in an earlier row) with global columns.  The host arrays are
+ * streamed through pinned staging buffers; no second host copy is made. */
+int qbh_csr_create_rows(qbh_csr **out, int64_t dim, int64_t nnz, int sym_upper,
+                        const int64_t *ia, const int64_t *ja, const qbh_z *val,
+                        int64_t row_begin, int64_t row_end, const qbh_opts *opts);
+
+/* Row cuts for nranks row blocks balanced by the nonzeros of the FULL operator (momentum-sector matrices hold
+ * decoupled one-entry rows, src/model.cc:737-740, so uniform row blocks are not work-balanced): cuts[0] = 0 <=
+ * cuts[1] <= ... <= cuts[nranks] = dim.  Host only. */
+int qbh_balanced_row_cuts(int64_t dim, int64_t nnz, int sym_upper, const int64_t *ia, const int64_t *ja,
+                          int nranks, int64_t *cuts /* [nranks+1] */);
 
 /* Adopt a row shard that already lives in HBM (device-side generator, multi-GPU row
  * blocks).  Rows [row_offset, row_offset+nrows) of a global ncols x ncols operator in
@@ -113,6 +131,9 @@ typedef struct qbh_csr_info {
     int     value_dict;                      /* number of dictionary entries, 0 = not coded    */
     int     device;
     void   *stream;
+    double  create_ms;                       /* wall ms of qbh_csr_create(_rows): validation + upload + expansion +
+                                                geometry (0 for device-built operators)                          */
+    int64_t create_bytes_in;                 /* host bytes that call read: nnz*24 + (dim+1)*8                     */
 } qbh_csr_info;
 int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info);
 

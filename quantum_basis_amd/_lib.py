@@ -31,14 +31,15 @@ class Z(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("spmv_kernel", C.c_int),
                 ("nnz_per_block", C.c_int), ("xcd_swizzle", C.c_int), ("value_dict", C.c_int),
-                ("profile", C.c_int), ("check_hermitian", C.c_int)]
+                ("profile", C.c_int), ("check_hermitian", C.c_int), ("real_fast_path", C.c_int)]
 
 
 class CsrInfo(C.Structure):
     _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int64), ("row_offset", C.c_int64),
                 ("nnz", C.c_int64), ("n_blocks", C.c_int64), ("bytes_matrix", C.c_int64),
                 ("bytes_algorithmic", C.c_int64), ("kernel", C.c_int), ("value_dict", C.c_int),
-                ("device", C.c_int), ("stream", C.c_void_p)]
+                ("device", C.c_int), ("stream", C.c_void_p), ("create_ms", C.c_double),
+                ("create_bytes_in", C.c_int64)]
 
 
 class LanczosRow(C.Structure):
@@ -76,7 +77,7 @@ class Stats(C.Structure):
 # every symbol include/qbhip.h declares (tests check that the .so exports all of them)
 EXPORTS = [
     "qbh_version", "qbh_device_count", "qbh_strerror", "qbh_last_error", "qbh_opts_default",
-    "qbh_csr_create", "qbh_csr_create_device", "qbh_csr_destroy", "qbh_csr_get_info",
+    "qbh_csr_create", "qbh_csr_create_rows", "qbh_balanced_row_cuts", "qbh_csr_create_device", "qbh_csr_destroy", "qbh_csr_get_info",
     "qbh_multmv", "qbh_multmv2",
     "qbh_vec_alloc", "qbh_vec_free", "qbh_vec_upload", "qbh_vec_download", "qbh_vec_zero",
     "qbh_vec_randomize",
@@ -117,6 +118,8 @@ def lib():
     L.qbh_opts_default.restype = None
     vp, i64, dbl = C.c_void_p, C.c_int64, C.c_double
     L.qbh_csr_create.argtypes = [C.POINTER(vp), i64, i64, C.c_int, vp, vp, vp, C.POINTER(Opts)]
+    L.qbh_csr_create_rows.argtypes = [C.POINTER(vp), i64, i64, C.c_int, vp, vp, vp, i64, i64, C.POINTER(Opts)]
+    L.qbh_balanced_row_cuts.argtypes = [i64, i64, C.c_int, vp, vp, C.c_int, vp]
     L.qbh_csr_create_device.argtypes = [C.POINTER(vp), i64, i64, i64, i64, vp, vp, vp, C.c_int,
                                         C.POINTER(Opts)]
     L.qbh_csr_destroy.argtypes = [vp]

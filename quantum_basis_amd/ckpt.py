@@ -74,7 +74,9 @@ def ckpt_lanczos_update(m, maxit, dim, state, v_pair, hessenberg, purpose, phi0=
         f.write(struct.pack("<q", m))
     vec_disk_write(_p(directory, "HessenbergA.dat.new"), hessenberg[maxit:maxit + m])
     vec_disk_write(_p(directory, "HessenbergB.dat.new"), hessenberg[:m + 1])
-    if m > 0 and not os.path.exists(_p(directory, "lanczosV%d.dat" % (m - 1))):
+    # the reference skips V(m-1) when the file exists (it was written by the previous update of the same run);
+    # here updates are `every` steps apart, so an existing V(m-1) can only be a stale file: always rewrite it
+    if m > 0:
         s = ((m - 1) % 2) * dim
         vec_disk_write(_p(directory, "lanczosV%d.dat" % (m - 1)), v_pair[s:s + dim])
     s = (m % 2) * dim
@@ -91,7 +93,7 @@ def ckpt_lanczos_update(m, maxit, dim, state, v_pair, hessenberg, purpose, phi0=
     for name in os.listdir(directory):
         if name.startswith("lanczosV") and name.endswith(".dat"):
             k = int(name[len("lanczosV"):-4])
-            if k < m - 1:
+            if k < m - 1 or k > m:          # older steps (reference) and stale higher indices of an earlier run
                 os.remove(_p(directory, name))
     os.replace(_p(directory, "HessenbergA.dat.new"), _p(directory, "HessenbergA.dat"))
     os.replace(_p(directory, "HessenbergB.dat.new"), _p(directory, "HessenbergB.dat"))
@@ -102,19 +104,75 @@ def ckpt_lanczos_update(m, maxit, dim, state, v_pair, hessenberg, purpose, phi0=
     os.remove(_p(directory, "lczs_updt.Qckpt2"))
 
 
+def _rm(path):
+    if os.path.exists(path):
+        os.remove(path)
+
+
+def _lanczos_vec_indices(directory):
+    return sorted(int(n[len("lanczosV"):-4]) for n in os.listdir(directory)
+                  if n.startswith("lanczosV") and n.endswith(".dat") and n[len("lanczosV"):-4].isdigit())
+
+
+def ckpt_purge(directory=CKPT_DIR):
+    """Start from scratch: no file of an earlier run (other operator, other start vector, higher step index)
+    may survive, or a later resume would pair it with fresh data."""
+    if not os.path.isdir(directory):
+        return
+    for name in os.listdir(directory):
+        if (name.startswith("lanczosV") or name.startswith("lanczosY") or name.startswith("Hessenberg")
+                or name.startswith("lczs_")):
+            os.remove(_p(directory, name))
+
+
+def _recover_torn_update(directory, purpose):
+    """The two branches of src/ckpt.cc:40-100 for an update that was interrupted (marker lczs_updt.Qckpt1 of the
+    right size present).  Qckpt2 present: every new file was completely written -> finish the renames and the
+    clean-up.  Otherwise rewind to step k-1: drop the *.new files and every lanczosV<kk>, kk >= k."""
+    mk1, mk2 = _p(directory, "lczs_updt.Qckpt1"), _p(directory, "lczs_updt.Qckpt2")
+    if not (os.path.exists(mk1) and os.path.getsize(mk1) == 8):
+        _rm(mk1)
+        _rm(mk2)
+        return
+    (k,) = struct.unpack("<q", open(mk1, "rb").read(8))
+    renames = ("HessenbergA.dat", "HessenbergB.dat", "lanczosY0.dat", "lanczosY1.dat", "lczs_mlns.dat")
+    if os.path.exists(mk2):                                           # src/ckpt.cc:50-79
+        for name in renames:
+            if os.path.exists(_p(directory, name + ".new")):
+                _rm(_p(directory, name))
+                os.replace(_p(directory, name + ".new"), _p(directory, name))
+        if purpose != "iram":
+            for kk in _lanczos_vec_indices(directory):
+                if kk < k - 1:
+                    os.remove(_p(directory, "lanczosV%d.dat" % kk))
+        _rm(mk1)
+        _rm(mk2)
+    else:                                                             # src/ckpt.cc:80-97 (rewind)
+        k -= 1
+        for name in renames:
+            _rm(_p(directory, name + ".new"))
+        for kk in _lanczos_vec_indices(directory):
+            if kk > k:
+                os.remove(_p(directory, "lanczosV%d.dat" % kk))
+        _rm(mk1)
+
+
 def ckpt_lanczos_init(maxit, dim, purpose, directory=CKPT_DIR):
-    """ckpt_lanczos_init for the "val" purposes (src/ckpt.cc:38-176), clean-state branch: returns
-    None when there is no usable checkpoint, else dict(k, state, v_pair, hessenberg, phi0).  A torn
-    update (marker files present) is treated as unusable rather than rewound."""
+    """ckpt_lanczos_init for the "val" purposes (src/ckpt.cc:38-176): returns None when there is no usable
+    checkpoint, else dict(k, state, v_pair, hessenberg, phi0).  An interrupted update is finished or rewound
+    exactly as the reference does; where the reference asserts on unreadable files this returns None."""
     if not os.path.isdir(directory):
         return None
-    if os.path.exists(_p(directory, "lczs_updt.Qckpt1")) or os.path.exists(_p(directory, "lczs_updt.Qckpt2")):
+    _recover_torn_update(directory, purpose)
+    ks = _lanczos_vec_indices(directory)
+    if not ks:
         return None
-    ks = sorted(int(n[len("lanczosV"):-4]) for n in os.listdir(directory)
-                if n.startswith("lanczosV") and n.endswith(".dat"))
-    if len(ks) < 2 or ks[-1] != ks[-2] + 1:
+    # src/ckpt.cc:101-111: first existing index, then the end of the consecutive run that starts there
+    m = ks[0]
+    while m + 1 in ks:
+        m += 1
+    if m == 0 or (m - 1) not in ks:
         return None
-    m = ks[-1]
     a = vec_disk_read(_p(directory, "HessenbergA.dat"), m, np.float64)
     b = vec_disk_read(_p(directory, "HessenbergB.dat"), m + 1, np.float64)
     v1 = vec_disk_read(_p(directory, "lanczosV%d.dat" % (m - 1)), dim, np.complex128)
@@ -131,6 +189,8 @@ def ckpt_lanczos_init(maxit, dim, purpose, directory=CKPT_DIR):
     phi0 = None
     if "val0" not in purpose:
         phi0 = vec_disk_read(_p(directory, "lanczosY0.dat"), dim, np.complex128)
+        if phi0 is None:
+            return None
     return dict(k=m, state=dict(cnt_accuE0=cnt, accuracy=accuracy, theta0_prev=t0, theta1_prev=t1),
                 v_pair=v_pair, hessenberg=hess, phi0=phi0)
 
@@ -145,6 +205,7 @@ def lanczos_checkpointed(mat, maxit, purpose="sr_val0", every=50, directory=CKPT
     ck = ckpt_lanczos_init(maxit, dim, purpose, directory)
     dv = mat.vec(nvec)
     if ck is None:
+        ckpt_purge(directory)
         hess = np.zeros(2 * maxit)
         k, state = 0, None
         if v0 is None:

@@ -71,6 +71,7 @@ extern "C" void qbh_opts_default(qbh_opts *o)
     o->value_dict = 1;      // lossless; falls back to plain storage by itself
     o->profile = 0;
     o->check_hermitian = 1;
+    o->real_fast_path = 1;
 }
 
 // ------------------------------------------------------------ operator ---------
@@ -325,6 +326,7 @@ int new_handle(qbh_csr **out, const qbh_opts *opts)
     else qbh_opts_default(&A->opts);
     A->device = dev;
     if (const char *dbg = getenv("QBH_DEBUG")) A->debug = atoi(dbg);   // timing experiments only
+    if (const char *e = getenv("QBH_CHUNK_MULT")) A->chunk_mult = std::max(1, atoi(e));
     if (A->opts.stream) {
         A->stream = (hipStream_t)A->opts.stream;
         A->own_stream = false;
@@ -414,126 +416,69 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
     delete A;
 }
 
-extern "C" int qbh_csr_create(qbh_csr **out, int64_t dim, int64_t nnz, int sym_upper, const int64_t *ia,
-                              const int64_t *ja, const qbh_z *val, const qbh_opts *opts)
+// Shared body of qbh_csr_create / qbh_csr_create_rows: validation on the host (threads), then the chunked upload and the
+// upper -> full expansion on the device (qbh_build.hip); no second host copy of the matrix is made.
+static int create_from_host(qbh_csr **out, int64_t dim, int64_t nnz, int sym_upper, const int64_t *ia, const int64_t *ja,
+                            const qbh_z *val, int64_t r0, int64_t r1, const qbh_opts *opts, const char *who)
 {
     if (!out || !ia || !ja || !val || dim <= 0 || nnz <= 0) {
-        qbh::set_error("qbh_csr_create: null pointer or non-positive size");
+        qbh::set_error("%s: null pointer or non-positive size", who);
         return QBH_EINVAL;
     }
     if (dim >= (int64_t)std::numeric_limits<int32_t>::max()) {
-        qbh::set_error("qbh_csr_create: dim %lld does not fit the int32 column index of one GPU shard",
-                       (long long)dim);
+        qbh::set_error("%s: dim %lld does not fit the int32 column index of one GPU shard", who, (long long)dim);
         return QBH_EUNSUPP;
     }
-    if (ia[0] != 0 || ia[dim] != nnz) {
-        qbh::set_error("qbh_csr_create: ia[0] must be 0 and ia[dim] must equal nnz (zero-based CSR)");
+    if (r0 < 0 || r1 > dim || r0 >= r1) {
+        qbh::set_error("%s: row range [%lld, %lld) outside [0, %lld)", who, (long long)r0, (long long)r1, (long long)dim);
         return QBH_EINVAL;
     }
-    for (int64_t r = 0; r < dim; ++r) {
-        if (ia[r + 1] < ia[r]) {
-            qbh::set_error("qbh_csr_create: ia not monotone at row %lld", (long long)r);
-            return QBH_EINVAL;
-        }
-        for (int64_t p = ia[r]; p < ia[r + 1]; ++p) {
-            if (ja[p] < 0 || ja[p] >= dim || (sym_upper && ja[p] < r)) {
-                qbh::set_error("qbh_csr_create: bad column %lld in row %lld", (long long)ja[p], (long long)r);
-                return QBH_EINVAL;
-            }
-        }
-    }
+    const double t0 = now_ms();
+    QBH_TRY(qbh::validate_host_csr(dim, nnz, sym_upper, ia, ja));
     const d2 *hv = reinterpret_cast<const d2 *>(val);
-
-    // full (both-triangle) storage with int32 columns, built on the host.
-    std::vector<int64_t> fia((size_t)dim + 1, 0);
-    std::vector<int32_t> fja;
-    std::vector<d2> fval;
-    if (sym_upper) {
-        // Hermitian-upper -> full: mirrored entries (c, r), r < c, arrive in ascending r, so
-        // writing the lower parts first keeps every row's columns ascending.
-        std::vector<int64_t> cur((size_t)dim, 0);
-        for (int64_t r = 0; r < dim; ++r)
-            for (int64_t p = ia[r]; p < ia[r + 1]; ++p) {
-                cur[r]++;
-                if (ja[p] != r) cur[ja[p]]++;
-            }
-        for (int64_t r = 0; r < dim; ++r) fia[r + 1] = fia[r] + cur[r];
-        fja.resize((size_t)fia[dim]);
-        fval.resize((size_t)fia[dim]);
-        for (int64_t r = 0; r < dim; ++r) cur[r] = fia[r];
-        for (int64_t r = 0; r < dim; ++r)
-            for (int64_t p = ia[r]; p < ia[r + 1]; ++p) {
-                const int64_t c = ja[p];
-                if (c != r) {
-                    const int64_t q = cur[c]++;
-                    fja[q] = (int32_t)r;
-                    fval[q] = d2{hv[p].x, -hv[p].y};
-                }
-            }
-        for (int64_t r = 0; r < dim; ++r)
-            for (int64_t p = ia[r]; p < ia[r + 1]; ++p) {
-                const int64_t q = cur[r]++;
-                fja[q] = (int32_t)ja[p];
-                fval[q] = hv[p];
-            }
-    } else {
-        if (!opts || opts->check_hermitian) {
-            // src/sparse.cc:235-256: every (r,c) needs (c,r) == conj within sparse_precision
-            for (int64_t r = 0; r < dim; ++r)
-                for (int64_t p = ia[r]; p < ia[r + 1]; ++p) {
-                    const int64_t c = ja[p];
-                    if (c == r) continue;
-                    const int64_t *lo = std::lower_bound(ja + ia[c], ja + ia[c + 1], r);
-                    int64_t q = lo - ja;
-                    if (q == ia[c + 1] || ja[q] != r) {           // unsorted row: linear search
-                        for (q = ia[c]; q < ia[c + 1] && ja[q] != r; ++q) {}
-                    }
-                    if (q == ia[c + 1] || std::hypot(hv[p].x - hv[q].x, hv[p].y + hv[q].y) > QBH_SPARSE_PRECISION) {
-                        qbh::set_error("Hermitian check failed at (row, col) = (%lld, %lld)", (long long)r,
-                                       (long long)c);
-                        return QBH_ENOTHERM;
-                    }
-                }
-        }
-        fja.resize((size_t)nnz);
-        fval.resize((size_t)nnz);
-        for (int64_t r = 0; r <= dim; ++r) fia[r] = ia[r];
-        for (int64_t p = 0; p < nnz; ++p) {
-            fja[p] = (int32_t)ja[p];
-            fval[p] = hv[p];
-        }
-    }
+    if (!sym_upper && (!opts || opts->check_hermitian)) QBH_TRY(qbh::check_hermitian_host(dim, ia, ja, hv));
 
     qbh_csr *A = nullptr;
     QBH_TRY(new_handle(&A, opts));
-    A->nrows = A->ncols = dim;
-    A->row_offset = 0;
-    A->nnz = fia[dim];
+    A->nrows = r1 - r0;
+    A->ncols = dim;
+    A->row_offset = r0;
     A->own_arrays = true;
-    int rc = QBH_OK;
-    auto fail = [&](int code) {
+    int rc = qbh::build_shard_from_host(dim, nnz, sym_upper, ia, ja, hv, r0, r1, A->stream, &A->d_ia, &A->d_ja, &A->d_val, &A->nnz,
+                                        &A->create_ms_upload);
+    if (rc == QBH_OK) rc = finalize(A);
+    if (rc != QBH_OK) {
         qbh_csr_destroy(A);
-        return code;
-    };
-#define QBH_HIPF(call)                                                                  \
-    do {                                                                                \
-        hipError_t _e = (call);                                                         \
-        if (_e != hipSuccess) {                                                         \
-            qbh::set_error("%s failed: %s", #call, hipGetErrorString(_e));              \
-            return fail(_e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP);             \
-        }                                                                               \
-    } while (0)
-    QBH_HIPF(hipMalloc(&A->d_ia, (size_t)(dim + 1) * sizeof(int64_t)));
-    QBH_HIPF(hipMalloc(&A->d_ja, (size_t)A->nnz * sizeof(int32_t)));
-    QBH_HIPF(hipMemcpy(A->d_ia, fia.data(), (size_t)(dim + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-    QBH_HIPF(hipMemcpy(A->d_ja, fja.data(), (size_t)A->nnz * sizeof(int32_t), hipMemcpyHostToDevice));
-    QBH_HIPF(hipMalloc(&A->d_val, (size_t)A->nnz * sizeof(d2)));
-    QBH_HIPF(hipMemcpy(A->d_val, fval.data(), (size_t)A->nnz * sizeof(d2), hipMemcpyHostToDevice));
-#undef QBH_HIPF
-    rc = finalize(A);
-    if (rc != QBH_OK) return fail(rc);
+        return rc;
+    }
+    A->create_ms = now_ms() - t0;
+    A->create_bytes_in = nnz * 24 + (dim + 1) * 8;
     *out = A;
     return QBH_OK;
+}
+
+extern "C" int qbh_csr_create(qbh_csr **out, int64_t dim, int64_t nnz, int sym_upper, const int64_t *ia,
+                              const int64_t *ja, const qbh_z *val, const qbh_opts *opts)
+{
+    return create_from_host(out, dim, nnz, sym_upper, ia, ja, val, 0, dim, opts, "qbh_csr_create");
+}
+
+extern "C" int qbh_csr_create_rows(qbh_csr **out, int64_t dim, int64_t nnz, int sym_upper, const int64_t *ia,
+                                   const int64_t *ja, const qbh_z *val, int64_t row_begin, int64_t row_end,
+                                   const qbh_opts *opts)
+{
+    return create_from_host(out, dim, nnz, sym_upper, ia, ja, val, row_begin, row_end, opts, "qbh_csr_create_rows");
+}
+
+extern "C" int qbh_balanced_row_cuts(int64_t dim, int64_t nnz, int sym_upper, const int64_t *ia, const int64_t *ja,
+                                     int nranks, int64_t *cuts)
+{
+    if (!ia || !ja || !cuts || dim <= 0 || nnz <= 0 || nranks < 1) {
+        qbh::set_error("qbh_balanced_row_cuts: invalid argument");
+        return QBH_EINVAL;
+    }
+    QBH_TRY(qbh::validate_host_csr(dim, nnz, sym_upper, ia, ja));
+    return qbh::balanced_row_cuts(dim, nnz, sym_upper, ia, ja, nranks, cuts);
 }
 
 extern "C" int qbh_csr_create_device(qbh_csr **out, int64_t nrows, int64_t ncols, int64_t row_offset,
@@ -690,6 +635,8 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->value_dict = A->d_code ? A->n_dict : 0;
     info->device = A->device;
     info->stream = (void *)A->stream;
+    info->create_ms = A->create_ms;
+    info->create_bytes_in = A->create_bytes_in;
     return QBH_OK;
 }
 
@@ -916,8 +863,12 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     a.gamma = gamma;
     a.partials = (red && !A->has_rem) ? A->d_partials : nullptr;
     a.swizzle = A->opts.xcd_swizzle;
+    a.chunk_mult = A->chunk_mult;
     a.unroll = A->unroll;
     a.colmask = (A->debug & 1) ? 1023 : -1;
+    if (A->debug & 1) {
+        if (const char *e = getenv("QBH_COLMASK")) a.colmask = atoi(e);      // gather-window experiments (results wrong by design)
+    }
     const bool prof = A->opts.profile != 0;
     if (async_gather && !A->has_rem) {          // nothing to overlap with: the single part needs the gathered x
         if (A->comm.allgather_wait(A->comm.ctx) != 0) {
@@ -987,6 +938,7 @@ int enable_real_wire(qbh_csr *A, std::initializer_list<const d2 *> vecs)
     A->real_mode = false;
     A->xr_of = nullptr;
     if (A->has_comm && !A->comm.d_xfull_r) return QBH_OK;
+    if (!A->opts.real_fast_path) return QBH_OK;
     if (const char *e = getenv("QBH_NO_REAL_WIRE")) {
         if (atoi(e)) return QBH_OK;
     }

@@ -55,6 +55,7 @@ struct SpmvArgs {
     double         alpha, beta, gamma;
     double        *partials;   // [grid*3] or nullptr
     int            swizzle;
+    int            chunk_mult; // xcd_swizzle 2: rounds of an XCD's resident workgroups per contiguous chunk of row blocks
     int            unroll;     // k_spmv_rows: gathers in flight per lane and loop trip
     int            colmask;    // -1; QBH_DEBUG=1 sets 1023 so the gather stays in cache (timing experiments only)
     // all-real operation (real operator, real vectors, one GPU): y_re is the in/out vector stored as doubles, xl_re
@@ -102,6 +103,15 @@ int launch_multi_axpy8(const d2 *V, int64_t ldv, const Coef8 &c, int nv, d2 *w, 
 int launch_basis_rotate(d2 *V, int64_t ldv, int64_t n, int m, int keep, const double *d_S, hipStream_t s);
 int symmetric_eigen_jacobi(int m, double *a, double *w, double *z);
 int build_value_dict(const d2 *d_val, int64_t nnz, int cap, uint8_t **d_code_out, d2 **d_dict_out, int *n_out, hipStream_t s);
+
+// host CSR -> device row shard (qbh_build.hip)
+int host_threads();
+int validate_host_csr(int64_t dim, int64_t nnz, int sym_upper, const int64_t *ia, const int64_t *ja);
+int check_hermitian_host(int64_t dim, const int64_t *ia, const int64_t *ja, const d2 *hv);
+int build_shard_from_host(int64_t dim, int64_t nnz, int sym, const int64_t *ia, const int64_t *ja, const d2 *val, int64_t r0,
+                          int64_t r1, hipStream_t s, int64_t **d_ia_out, int32_t **d_ja_out, d2 **d_val_out, int64_t *nnz_out,
+                          double *ms_out);
+int balanced_row_cuts(int64_t dim, int64_t nnz, int sym, const int64_t *ia, const int64_t *ja, int nranks, int64_t *cuts);
 
 // host tridiagonal solver (qbh_hess.cpp)
 int tridiag_eigen_full(int64_t m, const double *a, const double *b1, double *w, double *z);
@@ -218,6 +228,7 @@ struct qbh_csr {
     int32_t *d_rb = nullptr;
     int64_t *d_bp = nullptr;
     int      grid = 0;
+    int      chunk_mult = 1;   // see BlockWalk (xcd_swizzle 2)
 
     // workspace
     double  *d_partials = nullptr;   // [max(grid, kMaxRedBlocks) * 16]: up to 16 partial sums per workgroup (k_multi_dot<8>)
@@ -249,6 +260,10 @@ struct qbh_csr {
     // communicator
     bool     has_comm = false;
     qbh_comm comm{};
+
+    // creation from host arrays: wall ms of the whole qbh_csr_create call / of the upload + expansion, host bytes read
+    double    create_ms = 0.0, create_ms_upload = 0.0;
+    int64_t   create_bytes_in = 0;
 
     // stats
     qbh_stats stats{};

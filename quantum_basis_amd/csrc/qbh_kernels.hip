@@ -65,9 +65,9 @@ __device__ __forceinline__ void block_sum(double (&v)[NC], double *scratch)
 // order, used for speed only).  With swizzle each XCD walks one contiguous eighth of the
 // row blocks so the x windows it gathers stay in its own 4 MiB L2.
 struct BlockWalk {
-    int64_t per_xcd, xcd, slot, nslot, nb;
+    int64_t per_xcd, xcd, slot, nslot, nb, chunk;
     int swz;
-    __device__ BlockWalk(int64_t n_blocks, int swizzle)
+    __device__ BlockWalk(int64_t n_blocks, int swizzle, int chunk_mult = 1)
     {
         nb = n_blocks;
         per_xcd = (n_blocks + 7) >> 3;
@@ -75,18 +75,20 @@ struct BlockWalk {
         slot = blockIdx.x >> 3;
         nslot = gridDim.x >> 3;
         swz = swizzle;
-        // mode 2 walks chunk-wise; round the per-XCD count up to whole chunks so every block is visited
-        if (swz == 2) per_xcd = ((per_xcd + nslot - 1) / nslot) * nslot;
+        // mode 2 walks chunk-wise (a chunk = chunk_mult rounds of the XCD's resident workgroups); round the per-XCD
+        // count up to whole chunks so every block is visited
+        chunk = nslot * (chunk_mult > 0 ? chunk_mult : 1);
+        if (swz == 2) per_xcd = ((per_xcd + chunk - 1) / chunk) * chunk;
     }
     // lb = this XCD's local sequence number (slot, slot + nslot, ...).
     //  0: interleaved           block = lb*8 + xcd        (all XCDs sweep the same region)
     //  1: contiguous eighths    block = xcd*per_xcd + lb  (each XCD owns one eighth of the rows)
     //  2: chunked               the concurrently resident workgroups of an XCD (nslot of them) take
-    //                           one contiguous chunk; the 8 XCDs take 8 neighbouring chunks
+    //                           one contiguous chunk (chunk_mult rounds long); the 8 XCDs take 8 neighbouring chunks
     __device__ int64_t block(int64_t lb) const
     {
         if (swz == 1) return xcd * per_xcd + lb;
-        if (swz == 2) return ((lb / nslot) * 8 + xcd) * nslot + (lb % nslot);
+        if (swz == 2) return ((lb / chunk) * 8 + xcd) * chunk + (lb % chunk);
         return lb * 8 + xcd;
     }
 };
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
         __syncthreads();
     }
 
-    BlockWalk walk(a.n_blocks, a.swizzle);
+    BlockWalk walk(a.n_blocks, a.swizzle, a.chunk_mult);
     int64_t lb = walk.slot;
     int64_t b = walk.block(lb);
     bool live = lb < walk.per_xcd && b < a.n_blocks;

@@ -37,7 +37,7 @@ def _cvec(a, name):
 
 
 def make_opts(device=-1, stream=None, spmv_kernel=_lib.KERNEL_AUTO, nnz_per_block=0, xcd_swizzle=2,
-              value_dict=1, profile=0, check_hermitian=1):
+              value_dict=1, profile=0, check_hermitian=1, real_fast_path=1):
     o = _lib.Opts()
     lib().qbh_opts_default(C.byref(o))
     o.device = device
@@ -48,6 +48,7 @@ def make_opts(device=-1, stream=None, spmv_kernel=_lib.KERNEL_AUTO, nnz_per_bloc
     o.value_dict = value_dict
     o.profile = profile
     o.check_hermitian = check_hermitian
+    o.real_fast_path = real_fast_path
     return o
 
 
@@ -93,7 +94,9 @@ class csr_mat:
     val[nnz] (complex128); sym=True means only the upper triangle is stored.
     """
 
-    def __init__(self, dim, ia, ja, val, sym=True, opts=None, _handle=None):
+    def __init__(self, dim, ia, ja, val, sym=True, opts=None, _handle=None, rows=None):
+        """rows=(r0, r1): build only that row block of the operator from the same host arrays (qbh_csr_create_rows,
+        one rank of a row-sharded run); None: the whole operator (qbh_csr_create)."""
         _lib.require_gpu()
         self.handle = C.c_void_p()
         self._opts = opts if opts is not None else make_opts()
@@ -107,9 +110,14 @@ class csr_mat:
             self.val = np.ascontiguousarray(val, dtype=np.complex128)
             self.sym = bool(sym)
             nnz = int(self.ia[-1]) if self.ia.size else 0
-            check(lib().qbh_csr_create(C.byref(self.handle), C.c_int64(dim), C.c_int64(nnz), int(self.sym),
-                                       _p(self.ia), _p(self.ja), _p(self.val), C.byref(self._opts)),
-                  "qbh_csr_create")
+            if rows is None:
+                check(lib().qbh_csr_create(C.byref(self.handle), C.c_int64(dim), C.c_int64(nnz), int(self.sym),
+                                           _p(self.ia), _p(self.ja), _p(self.val), C.byref(self._opts)),
+                      "qbh_csr_create")
+            else:
+                check(lib().qbh_csr_create_rows(C.byref(self.handle), C.c_int64(dim), C.c_int64(nnz), int(self.sym),
+                                                _p(self.ia), _p(self.ja), _p(self.val), C.c_int64(rows[0]),
+                                                C.c_int64(rows[1]), C.byref(self._opts)), "qbh_csr_create_rows")
         info = self.info()
         self.dim = info.nrows          # shard-local length (== global dim when unsharded)
         self.ncols = info.ncols
@@ -264,6 +272,16 @@ class csr_mat:
 
 
 # ------------------------------------------------------------------------------------------
+def balanced_row_cuts(dim, ia, ja, sym, nranks):
+    """Row cuts of nranks blocks balanced by the nonzeros of the full operator (qbh_balanced_row_cuts)."""
+    ia = np.ascontiguousarray(ia, dtype=np.int64)
+    ja = np.ascontiguousarray(ja, dtype=np.int64)
+    cuts = np.zeros(nranks + 1, dtype=np.int64)
+    check(lib().qbh_balanced_row_cuts(C.c_int64(dim), C.c_int64(int(ia[-1])), int(bool(sym)), _p(ia), _p(ja), int(nranks),
+                                      _p(cuts)), "qbh_balanced_row_cuts")
+    return cuts
+
+
 def vec_randomize(mat, n=None, seed=1):
     """Host start vector produced on the device (src/miscellaneous.cc:371-386)."""
     dv = mat.vec()

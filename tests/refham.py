@@ -64,13 +64,29 @@ def _assemble(dim, rows, cols, vals, upper):
     return A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data.astype(np.complex128)
 
 
+def bit_patterns(nbits, k):
+    """All nbits-bit integers with k bits set, ascending (vectorised: patterns(n, k) = patterns(n-1, k) followed by
+    patterns(n-1, k-1) with bit n-1 set)."""
+    table = {}
+
+    def rec(n, j):
+        if j < 0 or j > n:
+            return np.zeros(0, dtype=np.int64)
+        if j == 0:
+            return np.zeros(1, dtype=np.int64)
+        if (n, j) not in table:
+            table[(n, j)] = np.concatenate([rec(n - 1, j), rec(n - 1, j - 1) | (np.int64(1) << (n - 1))])
+        return table[(n, j)]
+
+    return rec(nbits, k)
+
+
 def spin_half_basis(nsites, n_dn=None):
     """All spin-1/2 states (bit=1: down), optionally with a fixed number of down spins, Lin order."""
     if n_dn is None:
         states = np.arange(1 << nsites, dtype=np.int64)
     else:
-        states = np.array([sum(1 << s for s in c) for c in itertools.combinations(range(nsites), n_dn)],
-                          dtype=np.int64)
+        states = bit_patterns(nsites, n_dn)
     return lin_order(states, nsites, 1)
 
 
@@ -125,9 +141,14 @@ def square_bonds(Lx, Ly, pbc=True):
 
 def electron_basis(nsites, n_up, n_dn):
     """Electron states, 2 bits per site (bit0: up, bit1: down), fixed particle numbers, Lin order."""
-    ups = [sum(1 << (2 * s) for s in c) for c in itertools.combinations(range(nsites), n_up)]
-    dns = [sum(1 << (2 * s + 1) for s in c) for c in itertools.combinations(range(nsites), n_dn)]
-    states = (np.array(ups, dtype=np.int64)[:, None] | np.array(dns, dtype=np.int64)[None, :]).ravel()
+    def spread(x):                        # bit s -> bit 2s
+        out = np.zeros_like(x)
+        for s_ in range(nsites):
+            out |= ((x >> s_) & 1) << (2 * s_)
+        return out
+    ups = spread(bit_patterns(nsites, n_up))
+    dns = spread(bit_patterns(nsites, n_dn)) << 1
+    states = (ups[:, None] | dns[None, :]).ravel()
     return lin_order(states, nsites, 2)
 
 

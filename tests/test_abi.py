@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
     # would be better; here: the documented field lists, 8-byte aligned)
     assert C.sizeof(_lib.Z) == 16
     assert C.sizeof(_lib.LanczosRow) == 8 + 4 * 8 + 5 * 8
-    assert C.sizeof(_lib.Opts) == 4 + 4 + 8 + 6 * 4
+    assert C.sizeof(_lib.Opts) == 4 + 4 + 8 + 7 * 4 + 4        # 7 ints after the stream pointer, padded to 8
     assert C.sizeof(_lib.Stats) == 6 * 8
 
 

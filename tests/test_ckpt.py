@@ -53,9 +53,70 @@ def test_checkpoint_directory_protocol(tmp_path):
     assert np.array_equal(ck["v_pair"], v)
     # lczs_mlns.dat layout: int cnt, double accuracy, double theta0_prev, double theta1_prev (src/ckpt.cc:252-257)
     assert struct.unpack("<iddd", open(os.path.join(d, "lczs_mlns.dat"), "rb").read()) == (3, 1.5e-7, -4.25, -3.5)
-    # a torn update (marker present) is not used
+
+
+def _snapshot(d, dim, maxit, seed, m):
+    rng = np.random.default_rng(seed)
+    hess = rng.normal(size=2 * maxit)
+    v = (rng.normal(size=2 * dim) + 1j * rng.normal(size=2 * dim)).astype(np.complex128)
+    st = dict(cnt_accuE0=seed, accuracy=1e-7 * seed, theta0_prev=-4.0 - seed, theta1_prev=-3.0 - seed)
+    return hess, v, st
+
+
+def test_torn_update_is_rewound_or_finished_like_the_reference(tmp_path):
+    """src/ckpt.cc:40-100: marker Qckpt1 alone -> rewind one step (old data stays valid); Qckpt1 + Qckpt2 -> every new
+    file was complete, finish the renames and the clean-up."""
+    dim, maxit = 30, 40
+    # --- interrupted BEFORE the second marker: the update to step 8 is discarded, step 7 is resumed
+    d = str(tmp_path / "a")
+    h6, v6, s6 = _snapshot(d, dim, maxit, 1, 6)
+    ckpt.ckpt_lanczos_update(6, maxit, dim, s6, v6, h6, "sr_val0", directory=d)
+    h7, v7, s7 = _snapshot(d, dim, maxit, 2, 7)
+    ckpt.ckpt_lanczos_update(7, maxit, dim, s7, v7, h7, "sr_val0", directory=d)
+    h8, v8, s8 = _snapshot(d, dim, maxit, 3, 8)
     open(os.path.join(d, "lczs_updt.Qckpt1"), "wb").write(struct.pack("<q", 8))
-    assert ckpt.ckpt_lanczos_init(maxit, dim, "sr_val0", d) is None
+    ckpt.vec_disk_write(os.path.join(d, "HessenbergA.dat.new"), h8[maxit:maxit + 8])
+    ckpt.vec_disk_write(os.path.join(d, "HessenbergB.dat.new"), h8[:9])
+    ckpt.vec_disk_write(os.path.join(d, "lanczosV8.dat"), v8[:dim])
+    open(os.path.join(d, "lczs_mlns.dat.new"), "wb").write(b"torn")           # half-written
+    ck = ckpt.ckpt_lanczos_init(maxit, dim, "sr_val0", d)
+    assert ck["k"] == 7 and ck["state"] == s7
+    assert np.array_equal(ck["hessenberg"][maxit:maxit + 7], h7[maxit:maxit + 7]) and np.array_equal(ck["v_pair"], v7)
+    assert sorted(os.listdir(d)) == ["HessenbergA.dat", "HessenbergB.dat", "lanczosV6.dat", "lanczosV7.dat", "lczs_mlns.dat"]
+    # --- interrupted AFTER the second marker, in the middle of the clean-up: step 8 is complete and is used
+    d = str(tmp_path / "b")
+    ckpt.ckpt_lanczos_update(6, maxit, dim, s6, v6, h6, "sr_val0", directory=d)
+    ckpt.ckpt_lanczos_update(7, maxit, dim, s7, v7, h7, "sr_val0", directory=d)
+    v78 = np.concatenate([v8[:dim], v7[dim:]])                                # slot 0 = v[8], slot 1 = v[7]
+    open(os.path.join(d, "lczs_updt.Qckpt1"), "wb").write(struct.pack("<q", 8))
+    ckpt.vec_disk_write(os.path.join(d, "HessenbergA.dat.new"), h8[maxit:maxit + 8])
+    ckpt.vec_disk_write(os.path.join(d, "HessenbergB.dat.new"), h8[:9])
+    ckpt.vec_disk_write(os.path.join(d, "lanczosV8.dat"), v78[:dim])
+    open(os.path.join(d, "lczs_mlns.dat.new"), "wb").write(struct.pack("<iddd", 3, s8["accuracy"], s8["theta0_prev"], s8["theta1_prev"]))
+    open(os.path.join(d, "lczs_updt.Qckpt2"), "wb").write(struct.pack("<q", 8))
+    os.remove(os.path.join(d, "HessenbergA.dat"))                             # the clean-up had started
+    ck = ckpt.ckpt_lanczos_init(maxit, dim, "sr_val0", d)
+    assert ck["k"] == 8 and ck["state"] == s8
+    assert np.array_equal(ck["hessenberg"][:9], h8[:9]) and np.array_equal(ck["v_pair"], v78)
+    assert sorted(os.listdir(d)) == ["HessenbergA.dat", "HessenbergB.dat", "lanczosV7.dat", "lanczosV8.dat", "lczs_mlns.dat"]
+
+
+def test_stale_files_of_an_earlier_run_never_mix_with_a_new_one(tmp_path):
+    d = str(tmp_path / "out_Qckpt")
+    dim, maxit = 20, 40
+    h, v, st = _snapshot(d, dim, maxit, 5, 30)
+    ckpt.ckpt_lanczos_update(30, maxit, dim, st, v, h, "sr_val0", directory=d)       # earlier run stopped at step 30
+    # a restart from scratch purges everything ...
+    ckpt.ckpt_purge(d)
+    assert os.listdir(d) == []
+    # ... and an update at a lower step removes stale higher indices and rewrites V(m-1) even if a file of that name exists
+    ckpt.ckpt_lanczos_update(30, maxit, dim, st, v, h, "sr_val0", directory=d)
+    open(os.path.join(d, "lanczosV9.dat"), "wb").write(b"stale vector of another run")
+    h2, v2, st2 = _snapshot(d, dim, maxit, 6, 10)
+    ckpt.ckpt_lanczos_update(10, maxit, dim, st2, v2, h2, "sr_val0", directory=d)
+    assert sorted(n for n in os.listdir(d) if n.startswith("lanczosV")) == ["lanczosV10.dat", "lanczosV9.dat"]
+    ck = ckpt.ckpt_lanczos_init(maxit, dim, "sr_val0", d)
+    assert ck["k"] == 10 and np.array_equal(ck["v_pair"], v2)
 
 
 @pytest.mark.gpu
