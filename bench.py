@@ -11,6 +11,17 @@ v_m = -b v_{m-2} + H v_{m-1}, a = Re<v_{m-1}, v_m>, v_m -= a v_{m-1}, b = |v_m|,
 the host Ritz solve + stop test ("sr_val0").  The Hamiltonian is assembled on the device
 (synthetic: no dataset exists for this path), resident in HBM before the timed region.
 
+What the blocks of the JSON line are measured on:
+  value / roofline   THE NORTH-STAR FORMAT (default --format complex128): CSR with complex128 values (16 B) + int32
+                     columns, complex128 vectors, complex arithmetic -- the format SURVEY 8(d)'s algorithmic bytes
+                     (nnz*20 + rows*40) describe, semantics of csr_mat::MultMv2 (src/sparse.cc:262-289).
+                     roofline.frac = algorithmic bytes / kernel time / 8 TB/s and cannot exceed 1.
+  fast_path          the library's default for a real operator (lossless, bit-identical results): 1-byte value codes,
+                     vectors and gathers as packed doubles.  Its roofline block is defined on ITS OWN format bytes
+                     (nnz*(4+code bytes) + rows*24), so that fraction cannot exceed 1 either.
+  matrix_free_*      SURVEY 8f-1, no stored matrix (not the CSR path).
+  cpu_baseline       the oracle port and the reference's own MKL SpMV on the host cores (reported, not a target).
+
 Scaling is STRONG: the same operator is row-sharded over the N GPUs.
 """
 import argparse
@@ -25,6 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+KERNEL_NAME = {1: "k_spmv_stream", 2: "k_spmv_vector", 3: "k_spmv_rows", 4: "matrix_free"}
+KERNEL_KEY = {1: "stream", 2: "vector", 3: "rows", 4: "matrix_free"}
 
 
 def workloads():
@@ -36,6 +49,7 @@ def workloads():
         "hubbard_4x5_n5": dict(kind="hubbard", n_sites=20, n_up=5, n_dn=5, bonds=lattices.square(4, 5), t=1.0, U=1.1),
         # beyond what a stored CSR can hold on one GPU (nnz ~ 6e10): matrix-free only (--matrix-free)
         "hubbard_4x5_n6": dict(kind="hubbard", n_sites=20, n_up=6, n_dn=6, bonds=lattices.square(4, 5), t=1.0, U=1.1),
+        "hubbard_4x5_n4": dict(kind="hubbard", n_sites=20, n_up=4, n_dn=4, bonds=lattices.square(4, 5), t=1.0, U=1.1),
         "hubbard_4x3_half": dict(kind="hubbard", n_sites=12, n_up=6, n_dn=6, bonds=lattices.square(4, 3), t=1.0, U=1.1),
         "hubbard_4x2_half": dict(kind="hubbard", n_sites=8, n_up=4, n_dn=4, bonds=lattices.square(4, 2), t=1.0, U=1.1),
         # BASELINE.json configs[1] / C2
@@ -50,6 +64,8 @@ def workloads():
         "kagome_36_n9": dict(kind="heisenberg", n_sites=36, n_dn=9, bonds=lattices.kagome(4, 3), J=1.0),
         "kagome_24": dict(kind="heisenberg", n_sites=24, n_dn=12, bonds=lattices.kagome(4, 2), J=1.0),
         "chain_22": dict(kind="heisenberg", n_sites=22, n_dn=11, bonds=lattices.chain(22), J=1.0),
+        "chain_24": dict(kind="heisenberg", n_sites=24, n_dn=12, bonds=lattices.chain(24), J=1.0),
+        "chain_26": dict(kind="heisenberg", n_sites=26, n_dn=13, bonds=lattices.chain(26), J=1.0),
         # BASELINE.json configs[4] family: triangular 6x6, translation-symmetric sector k = (1,0), complex phases.
         # Sz = 0 (n_dn = 18, dim ~2.5e8, 285 GB of complex128 CSR) is the 8-GPU case; these fit one GPU.
         "triangular_6x6_k10_n12": dict(kind="heisenberg_repr", n_sites=36, n_dn=12, bonds=lattices.triangular(6, 6), J=1.0,
@@ -64,11 +80,13 @@ def workloads():
 
 
 def traffic_of(key):
-    """HBM bytes per launch measured in separate rocprofv3 --pmc passes (profiles/traffic.json), or None"""
+    """(HBM bytes per launch, source file) measured in separate rocprofv3 --pmc passes and kept in profiles/traffic.json;
+    (None, None) when that exact workload / kernel / value coding was never profiled.  NOT measured in this run."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[key]["hbm_bytes"]
+        e = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[key]
+        return e["hbm_bytes"], e.get("source")
     except Exception:
-        return None
+        return None, None
 
 
 def dim_of(w):
@@ -93,89 +111,238 @@ def build_operator(w, rows, opts, matrix_free=False, shard=(0, 1)):
     return q.csr_mat.heisenberg(w["n_sites"], w["n_dn"], w["bonds"], J=w["J"], rows=rows, opts=opts, matrix_free=matrix_free)
 
 
-def cpu_baseline(A, dim, budget_rows):
-    """Port baseline: the oracle's OpenMP CSR SpMV + BLAS-1 (oracle/qb_oracle.c) on the host
-    cores, timed on a bounded slab of the SAME operator (first R rows, full-length x), scaled
-    by dim/R to one Lanczos iteration."""
-    from oracle import qb_oracle as qo
+def reference_order_host_csr(name, w):
+    """Host CSR exactly as the unchanged reference host code hands it over (src/model.cc:619-685): Hermitian-upper, int64
+    ia/ja, complex128 values, basis in the reference's Lin order j = Ja[i_a] + Jb[i_b] (src/model.cc:665-670,
+    src/basis.cc:1144-1190).  Assembled by the numpy re-derivation tests/refham.py (test helper, pinned against the
+    survey's index checksums of the reference's own matrices)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import refham
+    if w["kind"] == "hubbard":
+        lx = 4
+        ly = w["n_sites"] // 4
+        d, ia, ja, val, _ = refham.hubbard_csr(lx, ly, w["n_up"], w["n_dn"], t=w["t"], U=w["U"])
+    elif w["kind"] == "heisenberg":
+        d, ia, ja, val, _ = refham.heisenberg_csr(w["n_sites"], [tuple(b) for b in np.asarray(w["bonds"]).reshape(-1, 2)],
+                                                  J=w["J"], n_dn=w["n_dn"])
+    else:
+        raise SystemExit("--host-csr supports the hubbard and heisenberg workloads")
+    return d, ia, ja, val
+
+
+# ------------------------------------------------------------------------------------------ CPU baseline ----
+def _slab_sample(A, dim, budget_rows, n_slabs=16):
+    """budget_rows rows of the operator as n_slabs slabs of consecutive rows spread evenly over the WHOLE operator
+    (a rectangular R x dim CSR).  Returns (ia, ja(int64), val, row_index)."""
     R = int(min(A.dim, budget_rows))
-    ia, ja, val = A.download(0, R)
+    n_slabs = max(1, min(n_slabs, R))
+    per = R // n_slabs
+    ias, jas, vals, rows = [np.zeros(1, dtype=np.int64)], [], [], []
+    base = 0
+    for s in range(n_slabs):
+        r0 = int(s * (A.dim - per) // max(n_slabs - 1, 1)) if n_slabs > 1 else 0
+        ia, ja, val = A.download(r0, r0 + per)
+        ias.append(ia[1:] + base)
+        base += int(ia[-1])
+        jas.append(ja.astype(np.int64))
+        vals.append(val)
+        rows.append(np.arange(r0, r0 + per, dtype=np.int64))
+    return np.concatenate(ias), np.concatenate(jas), np.concatenate(vals), np.concatenate(rows)
+
+
+def _time_loop(fn, min_reps, budget_s, max_reps):
+    fn()                                   # warm (threads, page cache)
+    t0 = time.perf_counter()
+    n = 0
+    while n < min_reps or (time.perf_counter() - t0 < budget_s and n < max_reps):
+        fn()
+        n += 1
+    return (time.perf_counter() - t0) / n, n
+
+
+def cpu_baseline(A, dim, budget_rows, W, q, stream):
+    """CPU legs, all on the GPU box's host cores, all on bounded samples:
+    (1) port: the oracle's OpenMP full-storage SpMV + the step's BLAS-1 on 16 row slabs spread over the whole operator
+        (full-length x, NUMA first-touch by the OpenMP threads), scaled by dim/rows to one Lanczos iteration;
+    (2) the reference's own library call mkl_sparse_z_mv on the same slab (GENERAL descriptor);
+    (3) a mid-size operator of the same family run IN FULL on the CPU: Lanczos to convergence with the oracle
+        (E0_cpu -> e0_rel_err_vs_cpu against the GPU path on the same operator), mkl_sparse_z_mv with the reference's
+        default HERMITIAN-upper descriptor (src/sparse.cc:269-285) beside GENERAL, and scipy's ARPACK eigs() wall time
+        beside qbh_iram."""
+    import ctypes as C
+    from oracle import qb_oracle as qo
+    L = qo.lib()
+    ia, ja, val, rows = _slab_sample(A, dim, budget_rows)
+    R = len(rows)
+    ia, ja, val = qo.first_touch(ia), qo.first_touch(ja), qo.first_touch(val)
     slab = qo.Csr.__new__(qo.Csr)
-    # the slab is R x dim (rectangular): build the ctypes view by hand
-    slab.dim, slab.ia, slab.ja, slab.val, slab.sym = R, ia, ja.astype(np.int64), val, False
+    slab.dim, slab.ia, slab.ja, slab.val, slab.sym = R, ia, ja, val, False      # rectangular R x dim view
     slab.nnz = int(ia[-1])
     slab._c = qo._CSR(R, slab.nnz, 0, slab.ia.ctypes.data, slab.ja.ctypes.data, slab.val.ctypes.data)
-    x = qo.vec_randomize(dim, 1)
-    y = np.zeros(R, dtype=np.complex128)
-    L = qo.lib()
-    import ctypes as C
-    reps, t_spmv, t_blas = 0, 0.0, 0.0
-    t_end = time.time() + 12.0
-    while reps < 3 or (time.time() < t_end and reps < 50):
+    x = qo.first_touch(qo.vec_randomize(dim, 1))
+    y = qo.first_touch(np.zeros(R, dtype=np.complex128))
+    xs = qo.first_touch(x[:R].copy())
+    t = {"spmv": 0.0, "blas": 0.0, "n": 0}
+
+    def step():
         t0 = time.perf_counter()
         L.qbo_multmv2(slab.ref(), x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p))
         t1 = time.perf_counter()
         # the BLAS-1 of one Lanczos step on the same R elements: scale, dot, axpy, nrm2, scale
-        xs = x[:R]
-        y *= -0.5
+        np.multiply(y, -0.5, out=y)
         a = qo.dotc(xs, y).real
-        y -= a * xs
+        y.__isub__(a * xs)
         nrm = qo.nrm2(y)
-        y *= 1.0 / max(nrm, 1e-300)
+        np.multiply(y, 1.0 / max(nrm, 1e-300), out=y)
         t2 = time.perf_counter()
-        if reps > 0:             # first pass warms the page cache / threads
-            t_spmv += t1 - t0
-            t_blas += t2 - t1
-        reps += 1
-    n = reps - 1
+        t["spmv"] += t1 - t0
+        t["blas"] += t2 - t1
+        t["n"] += 1
+
+    step()
+    t.update(spmv=0.0, blas=0.0, n=0)
+    t_end = time.time() + 8.0
+    while t["n"] < 3 or (time.time() < t_end and t["n"] < 50):
+        step()
+    n = t["n"]
     scale = dim / R
-    ms_spmv = 1e3 * t_spmv / n * scale
-    ms_iter = 1e3 * (t_spmv + t_blas) / n * scale
+    ms_spmv = 1e3 * t["spmv"] / n * scale
+    ms_iter = 1e3 * (t["spmv"] + t["blas"]) / n * scale
     bytes_alg = slab.nnz * 20 + (R + 1) * 8 + R * 32
-    mkl = None
+    out = {"value": round(1e3 / ms_iter, 4), "unit": "lanczos_iters/s", "cores": qo.num_threads(), "kind": "port",
+           "sample": "%d rows in 16 slabs spread over all %d rows (%d nnz) of the same operator, full-length x, arrays "
+                     "first-touched by the OpenMP threads; %d timed passes of oracle qbo_multmv2 (OpenMP, full storage) + the "
+                     "step's BLAS-1; scaled by dim/rows" % (R, dim, slab.nnz, n),
+           "spmv_ms_scaled": round(ms_spmv, 3), "spmv_GBps": round(bytes_alg / (t["spmv"] / n) / 1e9, 3)}
     try:        # the reference's own SpMV library, when the image has it: mkl_sparse_z_mv on the same slab
         from oracle import mkl_ref
         if mkl_ref.load() is not None:
             M = mkl_ref.MklCsr(R, slab.ia, slab.ja, slab.val, False, ncols=dim)
-            ym = np.zeros(R, dtype=np.complex128)
-            M.multmv2(x, ym)
-            t0 = time.perf_counter()
-            nm = 0
-            while nm < 3 or (time.perf_counter() - t0 < 4.0 and nm < 30):
-                M.multmv2(x, ym)
-                nm += 1
-            tm = (time.perf_counter() - t0) / nm
-            mkl = {"spmv_ms_scaled": round(1e3 * tm * scale, 3), "spmv_GBps": round(bytes_alg / tm / 1e9, 3),
-                   "threads": M.threads(), "call": "mkl_sparse_z_mv, GENERAL descriptor, full storage, no mkl_sparse_optimize (src/sparse.cc:262-289)"}
+            ym = qo.first_touch(np.zeros(R, dtype=np.complex128))
+            tm, nm = _time_loop(lambda: M.multmv2(x, ym), 3, 3.0, 30)
+            out["mkl"] = {"spmv_ms_scaled": round(1e3 * tm * scale, 3), "spmv_GBps": round(bytes_alg / tm / 1e9, 3),
+                          "threads": M.threads(),
+                          "call": "mkl_sparse_z_mv, GENERAL descriptor, full storage, no mkl_sparse_optimize (src/sparse.cc:262-289)"}
     except Exception as e:
-        mkl = {"error": repr(e)}
-    return {"value": round(1e3 / ms_iter, 4), "unit": "lanczos_iters/s", "cores": qo.num_threads(), "kind": "port", "mkl": mkl,
-            "sample": "first %d of %d rows (%d nnz) of the same operator, full-length x, %d timed passes of "
-                      "oracle qbo_multmv2 (OpenMP, full storage) + the step's BLAS-1; scaled by dim/rows"
-                      % (R, dim, slab.nnz, n),
-            "spmv_ms_scaled": round(ms_spmv, 3), "spmv_GBps": round(bytes_alg / (t_spmv / n) / 1e9, 3)}
+        out["mkl"] = {"error": repr(e)}
+    try:
+        out["midsize"] = cpu_midsize_full_run(W, q, stream)
+    except Exception as e:
+        out["midsize"] = {"error": repr(e)}
+    return out
 
 
+def cpu_midsize_full_run(W, q, stream):
+    """A whole (not sampled) operator of the same family small enough for the CPU: the reference pipeline end to end on
+    the host (oracle Lanczos, MKL both descriptors, scipy ARPACK) beside the GPU path on the SAME matrix."""
+    import scipy.sparse as sp
+    import torch
+    from oracle import qb_oracle as qo
+    name = "hubbard_4x3_half" if W["kind"] == "hubbard" else "chain_22"
+    Wm = workloads()[name]
+    with torch.cuda.stream(stream):
+        G = build_operator(Wm, (0, -1), q.make_opts(stream=stream.cuda_stream, value_dict=0, real_fast_path=0))
+        d = G.dim
+        fia, fja, fval = G.download()
+        Fm = sp.csr_matrix((fval, fja, fia), shape=(d, d))
+        rows = np.repeat(np.arange(d), np.diff(fia))
+        keep = fja >= rows
+        uia = np.zeros(d + 1, dtype=np.int64)
+        np.cumsum(np.bincount(rows[keep], minlength=d), out=uia[1:])
+        uja, uval = fja[keep].astype(np.int64), fval[keep]
+        res = {"workload": name, "dim": int(d), "nnz_full": int(fia[-1]), "nnz_upper": int(uia[-1])}
+        # GPU: Lanczos to convergence on this operator (north-star format)
+        maxit = 1000
+        hess = np.zeros(2 * maxit)
+        v = G.vec(2)
+        G.randomize(v.at(0), 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m_gpu = q.lanczos(0, maxit - 1, maxit, d, G, None, hess, "sr_val0", device_v=v)
+        torch.cuda.synchronize()
+        t_gpu = time.perf_counter() - t0
+        e0_gpu = float(q.hess_eigen(hess, maxit, m_gpu, "sr")[0][0])
+        v.free()
+        # CPU: the same solve with the oracle on the reference's default storage (Hermitian upper)
+        O = qo.Csr(d, qo.first_touch(uia), qo.first_touch(uja), qo.first_touch(uval), True)
+        vc = np.zeros(2 * d, dtype=np.complex128)
+        vc[:d] = qo.vec_randomize(d, 1)
+        hc = np.zeros(2 * maxit)
+        t0 = time.perf_counter()
+        m_cpu = qo.lanczos(0, maxit - 1, maxit, O, vc, hc, "sr_val0")[0]
+        t_cpu = time.perf_counter() - t0
+        e0_cpu = float(qo.hess_eigen(hc, maxit, m_cpu, "sr")[0][0])
+        res.update(gpu_lanczos_steps=int(m_gpu), gpu_s=round(t_gpu, 4), gpu_iters_per_s=round(m_gpu / t_gpu, 2),
+                   cpu_lanczos_steps=int(m_cpu), cpu_s=round(t_cpu, 3), cpu_iters_per_s=round(m_cpu / t_cpu, 3),
+                   cpu_threads=qo.num_threads(), e0_gpu=e0_gpu, e0_cpu=e0_cpu,
+                   e0_rel_err_vs_cpu=abs(e0_gpu - e0_cpu) / abs(e0_cpu))
+        b_spmv = int(fia[-1]) * 20 + (d + 1) * 8 + d * 32
+        x = qo.first_touch(qo.vec_randomize(d, 2))
+        try:
+            from oracle import mkl_ref
+            if mkl_ref.load() is not None:
+                y = qo.first_touch(np.zeros(d, dtype=np.complex128))
+                MU = mkl_ref.MklCsr(d, O.ia, O.ja, O.val, True)
+                tu, _ = _time_loop(lambda: MU.multmv2(x, y), 3, 2.0, 40)
+                MG = mkl_ref.MklCsr(d, qo.first_touch(fia), qo.first_touch(fja.astype(np.int64)), qo.first_touch(fval), False)
+                tg, _ = _time_loop(lambda: MG.multmv2(x, y), 3, 2.0, 40)
+                res["mkl_hermitian_upper"] = {"spmv_ms": round(1e3 * tu, 3), "spmv_GBps": round(b_spmv / tu / 1e9, 2),
+                                              "call": "mkl_sparse_z_mv, descr {HERMITIAN, UPPER, NON_UNIT}: the reference default (src/sparse.cc:269-285)"}
+                res["mkl_general"] = {"spmv_ms": round(1e3 * tg, 3), "spmv_GBps": round(b_spmv / tg / 1e9, 2), "threads": MG.threads()}
+        except Exception as e:
+            res["mkl_hermitian_upper"] = {"error": repr(e)}
+        # IRAM: scipy's bundled ARPACK (znaupd/zneupd, mode 1, which='SR', tol=0) on the host vs qbh_iram on the device
+        try:
+            from scipy.sparse.linalg import eigs
+            t0 = time.perf_counter()
+            w_cpu = eigs(Fm, k=2, which="SR", ncv=20, tol=0, return_eigenvectors=False)
+            t_eigs = time.perf_counter() - t0
+            w_cpu = np.sort(w_cpu.real)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, w_gpu, _ = q.iram(d, G, None, 2, 20, 300, "sr")
+            torch.cuda.synchronize()
+            t_iram = time.perf_counter() - t0
+            res["iram"] = {"scipy_eigs_s": round(t_eigs, 3), "qbh_iram_s": round(t_iram, 4), "nev": 2, "ncv": 20,
+                           "eig_rel_diff": float(np.max(np.abs(np.sort(w_gpu) - w_cpu) / np.abs(w_cpu)))}
+        except Exception as e:
+            res["iram"] = {"error": repr(e)}
+        G.destroy()
+    return res
+
+
+# ------------------------------------------------------------------------------------------------- main ----
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("QBH_WORKLOAD", "hubbard_4x4_half"))
+    ap.add_argument("--format", default="complex128", choices=["complex128", "fast"],
+                    help="what the HEADLINE is timed on: complex128 = north-star format (complex128 CSR values, complex vectors); "
+                         "fast = the library default (value dictionary + real fast path where the operator allows)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto (rows), 1 stream, 2 vector, 3 rows")
     ap.add_argument("--npb", type=int, default=0)
     ap.add_argument("--swizzle", type=int, default=2)
-    ap.add_argument("--value-dict", type=int, default=1, help="1: dictionary-code the value stream when <=256 distinct values (lossless)")
+    ap.add_argument("--value-dict", type=int, default=None, help="override --format: 1 dictionary-code the value stream (lossless), 0 keep complex128")
+    ap.add_argument("--real-fast-path", type=int, default=None, help="override --format: 1 allow 8-byte real gathers / packed-double vectors")
+    ap.add_argument("--host-csr", default=None, choices=[None, "reference-order"],
+                    help="assemble the operator on the HOST in the reference's Lin order (Hermitian-upper int64 CSR) and hand it to "
+                         "qbh_csr_create, as the unchanged reference host code would (workloads up to a few 1e7 nnz)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed run to convergence (E0)")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)
-    ap.add_argument("--matrix-free", action="store_true", help="use the matrix-free Hubbard operator as THE operator (not the CSR north-star path)")
-    ap.add_argument("--no-matrix-free", action="store_true", help="skip the extra measurement of the matrix-free Hubbard operator")
+    ap.add_argument("--matrix-free", action="store_true", help="use the matrix-free operator as THE operator (not the CSR north-star path)")
+    ap.add_argument("--no-matrix-free", action="store_true", help="skip the extra measurement of the matrix-free operator")
     ap.add_argument("--packed-real", action="store_true", help="matrix-free operator + Lanczos vectors as packed doubles (qbh_lanczos_real_dev); "
                     "forced for the workloads whose complex vectors do not fit one GPU")
     ap.add_argument("--converge", action="store_true", help="run to convergence also for the dim > 1e9 packed-real workloads")
-    ap.add_argument("--no-plain", action="store_true", help="skip the extra (untimed-region) measurement of the uncoded complex128 kernel")
+    ap.add_argument("--no-fast-path", action="store_true", help="skip the extra measurement of the coded / real fast path")
+    ap.add_argument("--no-plain", action="store_true", help="(kept for older command lines; the uncoded kernel is the headline now)")
     args = ap.parse_args()
+    fmt_fast = args.format == "fast"
+    value_dict = args.value_dict if args.value_dict is not None else (1 if fmt_fast else 0)
+    real_fp = args.real_fast_path if args.real_fast_path is not None else (1 if fmt_fast else 0)
 
     import torch
     import torch.distributed as dist
@@ -209,9 +376,11 @@ def main():
         if world > 1:
             raise SystemExit("--packed-real is a single-GPU mode")
         args.matrix_free = True
-        args.no_plain = args.no_matrix_free = args.no_cpu_baseline = True
+        args.no_fast_path = args.no_matrix_free = args.no_cpu_baseline = True
         if W.get("packed_real") and not args.converge:
             args.no_converge = True          # hundreds of ~1 s steps: tools/big_lanczos.py does that run (logs under profiles/)
+    if args.matrix_free:
+        real_fp = 1                          # the matrix-free operators are real; their row-staged kernel is the real form
     dim = dim_of(W)
     if dim is None:
         r0, r1 = 0, -1                   # the generator shards by (rank, world) itself
@@ -219,39 +388,25 @@ def main():
         nblk, ranges = qdist.row_partition(dim, world)
         r0, r1 = ranges[rank]
     stream = torch.cuda.Stream(device=device)
-    with torch.cuda.stream(stream):
-        opts = q.make_opts(device=local_rank, stream=stream.cuda_stream, spmv_kernel=args.kernel,
-                           nnz_per_block=args.npb, xcd_swizzle=args.swizzle,
-                           value_dict=args.value_dict, profile=1)
-        t_gen = time.time()
-        A = build_operator(W, (r0, r1), opts, matrix_free=args.matrix_free, shard=(rank, world))
-        torch.cuda.synchronize()
-        t_gen = time.time() - t_gen
-        info = A.info()
-        if dim is None:
-            dim = int(info.ncols)
+    K, Wm = args.steps, max(args.warmup, 2)
+    maxit = max(K + Wm + 16, 64)
+
+    def allreduce_host(vals, op):
+        t = torch.tensor(vals, dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         if world > 1:
-            comm = qdist.ShardComm(dim, rank=rank, world=world, device=device, stream=stream).attach(A)
+            dist.all_reduce(t, op=op)
+        return [float(z) for z in t.tolist()]
 
-        def allreduce_host(vals, op):
-            t = torch.tensor(vals, dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-            if world > 1:
-                dist.all_reduce(t, op=op)
-            return [float(z) for z in t.tolist()]
-
-        nnz_total = int(allreduce_host([float(info.nnz)], dist.ReduceOp.SUM)[0])
-
-        # lanczos() cannot make a single step from k = 0 (the reference's do-while runs once more after the bootstrap step,
-        # src/lanczos.cc:167-193), so the recurrence is always started by at least two untimed steps: the timed region
-        # then is EXACTLY K steps
-        K, Wm = args.steps, max(args.warmup, 2)
-        maxit = max(K + Wm + 16, 64)
+    def timed_lanczos(A, packed):
+        """Wm untimed + exactly K timed Lanczos steps on operator A.  lanczos() cannot make a single step from k = 0 (the
+        reference's do-while runs once more after the bootstrap step, src/lanczos.cc:167-193), so the recurrence is always
+        started by at least two untimed steps.  Returns dict(elapsed, steps, ms_spmv, n_spmv, n_real)."""
         n = A.dim
-        v = A.vec(1 if packed_real else 2)           # packed doubles: n complex128 = the two slots of n doubles
+        v = A.vec(1 if packed else 2)           # packed doubles: n complex128 = the two slots of n doubles
         hess = np.zeros(2 * maxit)
 
         def fresh_start(seed):
-            if packed_real:
+            if packed:
                 import ctypes
                 _lib.check(_lib.lib().qbh_vec_randomize_real(A.handle, v.ptr, ctypes.c_uint32(seed)), "qbh_vec_randomize_real")
             else:
@@ -259,17 +414,15 @@ def main():
             hess[:] = 0.0
             return 0
 
-        def lanczos_call(k0, nsteps, mx, hs):
-            if packed_real:
+        def call(k0, nsteps, mx, hs):
+            if packed:
                 return q.lanczos_real(k0, nsteps, mx, A, v, hs)
             return q.lanczos(k0, nsteps, mx, n, A, None, hs, "sr_val0", device_v=v)
 
         def run_steps(k, nsteps, seed):
-            """Advance nsteps Lanczos steps (restarting from a new start vector if the stop rule
-            fires first); returns (k, seed, steps actually done)."""
             left, total = nsteps, 0
             while left > 0:
-                m = lanczos_call(k, left, maxit, hess)
+                m = call(k, left, maxit, hess)
                 left -= m - k
                 total += m - k
                 k = m
@@ -280,15 +433,14 @@ def main():
 
         seed = 1
         k = fresh_start(seed)
-        if Wm > 0:
-            k, seed, _ = run_steps(k, Wm, seed)
+        k, seed, _ = run_steps(k, Wm, seed)
         A.stats(reset=True)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        k, seed, K_done = run_steps(k, K, seed)
+        k, seed, done = run_steps(k, K, seed)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -296,50 +448,91 @@ def main():
         elapsed = time.perf_counter() - t0
         st = A.stats()
         elapsed, ms_spmv = allreduce_host([elapsed, st.ms_spmv / max(st.n_spmv, 1)], dist.ReduceOp.MAX)
-
-        # untimed: run the same solver to convergence for E0 (parity across N and vs the small-size oracle tests)
         e0 = steps_e0 = None
-        if not args.no_converge:
+        if not args.no_converge:      # untimed: the same solver to convergence (E0 parity across N / formats / vs the oracle tests)
             maxit2 = 1000
             hess2 = np.zeros(2 * maxit2)
             fresh_start(1)
-            m = lanczos_call(0, maxit2 - 1, maxit2, hess2)
+            m = call(0, maxit2 - 1, maxit2, hess2)
             ritz, _ = q.hess_eigen(hess2, maxit2, m, "sr")
             e0, steps_e0 = float(ritz[0]), int(m)
+        v.free()
+        return dict(elapsed=elapsed, steps=done, ms_spmv=ms_spmv, n_spmv=int(st.n_spmv), n_real=int(st.n_spmv_real), e0=e0,
+                    steps_e0=steps_e0)
+
+    create = None
+    with torch.cuda.stream(stream):
+        opts = q.make_opts(device=local_rank, stream=stream.cuda_stream, spmv_kernel=args.kernel,
+                           nnz_per_block=args.npb, xcd_swizzle=args.swizzle,
+                           value_dict=value_dict, real_fast_path=real_fp, profile=1)
+        t_gen = time.time()
+        if args.host_csr:
+            hd, hia, hja, hval = reference_order_host_csr(args.workload, W)
+            t_host = time.time() - t_gen
+            assert hd == dim
+            t_gen = time.time()
+            A = q.csr_mat(dim, hia, hja, hval, sym=True, opts=opts, rows=None if world == 1 else (r0, r1))
+            ci = A.info()
+            create = {"create_s": round(ci.create_ms * 1e-3, 4), "input_bytes": int(ci.create_bytes_in),
+                      "create_GBps_of_input": round(ci.create_bytes_in / ci.create_ms / 1e6, 2),
+                      "host_assembly_s (numpy, not the product)": round(t_host, 2),
+                      "entry": "qbh_csr_create" if world == 1 else "qbh_csr_create_rows", "storage": "Hermitian-upper, int64 ia/ja, complex128",
+                      "order": "reference Lin order (src/model.cc:665-670)", "nnz_upper": int(hia[-1])}
+        else:
+            A = build_operator(W, (r0, r1), opts, matrix_free=args.matrix_free, shard=(rank, world))
+        torch.cuda.synchronize()
+        t_gen = time.time() - t_gen
+        info = A.info()
+        if dim is None:
+            dim = int(info.ncols)
+        if world > 1:
+            comm = qdist.ShardComm(dim, rank=rank, world=world, device=device, stream=stream).attach(A)  # noqa: F841
+        nnz_total = int(allreduce_host([float(info.nnz)], dist.ReduceOp.SUM)[0])
+        head = timed_lanczos(A, packed_real)
 
     # algorithmic bytes of ONE SpMV launch on this rank: nnz*(16+4) + (rows+1)*8 + x once + y once
     bytes_launch = info.nnz * 20 + (info.nrows + 1) * 8 + (dim if world > 1 else info.nrows) * 16 + info.nrows * 16
+    ms_spmv = head["ms_spmv"]
     achieved = bytes_launch / (ms_spmv * 1e-3) / 1e9 if ms_spmv > 0 else 0.0
-    # HBM traffic of one launch: measured in separate rocprofv3 --pmc passes (tools/profile_bench.sh), kept in
-    # profiles/traffic.json and quoted only when it was taken on this exact workload / kernel / value coding
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        key = "%s|%s|%s" % (args.workload, {1: "stream", 2: "vector", 3: "rows", 4: "matrix_free"}[info.kernel], "dict" if info.value_dict else "plain")
-        if st.n_spmv_real > 0:
-            key += "|real"
-        if world == 1 and key in tj:
-            traffic = tj[key]["hbm_bytes"]
-    except Exception:
-        traffic = None
+    coded = bool(info.value_dict)
+    real_used = head["n_real"] > 0
+    code_w = 0 if not coded else (1 if info.value_dict <= 256 else 2)
+    tkey = "%s|%s|%s" % (args.workload, KERNEL_KEY[info.kernel], "dict" if coded else "plain") + ("|real" if real_used else "")
+    traffic, tsrc = traffic_of(tkey) if world == 1 and not args.host_csr else (None, None)
+    if coded or real_used:
+        # the kernel moves its own format's bytes, not SURVEY 8(d)'s: the fraction is defined on those (cannot exceed 1)
+        vec_b = 8 if real_used else 16
+        fmt_bytes = info.nnz * (4 + (code_w if coded else 16)) + (info.nrows + 1) * 8 + info.nrows * 2 * vec_b
+        roof = {"bound": "hbm", "kernel": KERNEL_NAME[info.kernel], "achieved": round(fmt_bytes / ms_spmv / 1e6, 2), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(fmt_bytes / ms_spmv / 1e6 / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                "bytes_per_launch": fmt_bytes, "ms_per_launch": round(ms_spmv, 4), "launches": head["n_spmv"],
+                "bytes_definition": "this format's bytes: nnz*(4 + %d) + (rows+1)*8 + rows*%d" % (code_w if coded else 16, 2 * vec_b),
+                "survey_8d_bytes_per_launch": bytes_launch, "survey_8d_equivalent_GBps": round(achieved, 2)}
+        dtype = "f64 real (1-byte value codes, packed-double vectors; bit-identical to complex128)" if real_used else \
+                "complex128 vectors, %d-byte value codes" % code_w
+    else:
+        roof = {"bound": "hbm", "kernel": KERNEL_NAME[info.kernel], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                "bytes_per_launch": bytes_launch, "ms_per_launch": round(ms_spmv, 4), "launches": head["n_spmv"],
+                "bytes_definition": "SURVEY 8(d) algorithmic bytes: nnz*(16+4) + (rows+1)*8 + rows*16 (x once) + rows*16 (y once)",
+                "note": "traffic (HBM bytes per launch from separate rocprofv3 --pmc passes, NOT measured in this run; see traffic_source) "
+                        "exceeds the algorithmic bytes by the x gathers that miss the caches"}
+        dtype = "complex128"
     out = {
-        "metric": "lanczos_iters_per_sec", "value": round(K_done / elapsed, 4), "unit": "lanczos_iters/s",
-        "n_gpus": world, "steps": K_done, "warmup": Wm, "ms_per_step": round(1e3 * elapsed / K_done, 4),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "complex128 (f64)",
+        "metric": "lanczos_iters_per_sec", "value": round(head["steps"] / head["elapsed"], 4), "unit": "lanczos_iters/s",
+        "n_gpus": world, "steps": head["steps"], "warmup": Wm, "ms_per_step": round(1e3 * head["elapsed"] / head["steps"], 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype,
         "data": "synthetic", "config": {"workload": args.workload, "dim": dim, "nnz_full": nnz_total,
                                          "rows_per_gpu": info.nrows, "parallelism": "row-shard x%d" % world,
-                                         "kernel": {1: "stream", 2: "vector", 3: "rows", 4: "matrix_free"}[info.kernel], "value_dict": info.value_dict,
-                                         "real_gather": bool(st.n_spmv_real > 0),
+                                         "kernel": KERNEL_KEY[info.kernel], "format": "complex128 CSR values + int32 columns, complex128 vectors"
+                                         if not (coded or real_used) else "value codes %s, real fast path %s" % (coded, real_used),
+                                         "value_dict": info.value_dict, "real_gather": real_used,
+                                         "operator_source": "host CSR in reference order through qbh_csr_create" if args.host_csr else "device generator",
                                          "build_s": round(t_gen, 3)},
-        "roofline": {"bound": "hbm", "kernel": {1: "k_spmv_stream", 2: "k_spmv_vector", 3: "k_spmv_rows", 4: "k_mf_hubbard"}[info.kernel],
-                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                     "bytes_per_launch": bytes_launch, "ms_per_launch": round(ms_spmv, 4), "launches": int(st.n_spmv),
-                     "note": "achieved = ALGORITHMIC bytes (SURVEY 8d: nnz*20 + rows*40) / kernel time; the kernel moves fewer "
-                             "bytes than that (traffic) because values are dictionary-coded (1 or 2 B instead of 16 B, lossless) and, for a "
-                             "real operator and real vectors, x is gathered as 8-byte real parts (bit-identical result)"},
-        "e0": e0, "lanczos_steps_to_converge": steps_e0,
+        "roofline": roof, "e0": head["e0"], "lanczos_steps_to_converge": head["steps_e0"],
     }
+    if create:
+        out["create"] = create
     if packed_real:
         out["dtype"] = "f64 (real operator, Lanczos vectors stored as packed doubles)"
         out["config"]["vectors"] = "2 x %.1f GB packed doubles (qbh_lanczos_real_dev)" % (dim * 8e-9)
@@ -348,30 +541,39 @@ def main():
         out["roofline"]["kernel"] = "k_mf_hubbard" if W["kind"] == "hubbard" else "k_mf_heis"
         out["roofline"]["note"] = ("MATRIX-FREE operator (qbh_mf_hubbard / qbh_mf_heisenberg, SURVEY 8f-1): no CSR is stored; achieved = bytes the CSR of the "
                                    "same operator would move per SpMV / kernel time -- not the north-star CSR measurement")
-    if world == 1 and info.value_dict and not args.no_plain:
-        # transparency: the same SpMV with the value stream left as complex128 (16 B/nnz), measured after the
-        # timed region on a second copy of the operator (it needs the full 20 B/nnz in HBM)
+    n = A.dim
+    if world == 1 and not (coded or real_used) and not args.no_fast_path and not args.matrix_free and not args.host_csr:
+        # the library's default path for this operator (lossless value codes; real operator + real vectors -> packed doubles):
+        # same step definition, same K, its own roofline on its own format's bytes
         try:
             with torch.cuda.stream(stream):
-                P = build_operator(W, (r0, r1), shard=(rank, world), opts=q.make_opts(device=local_rank, stream=stream.cuda_stream,
-                                                             value_dict=0, xcd_swizzle=args.swizzle, profile=1))
-                pv = P.vec(2)
-                P.randomize(pv.at(0), 1)
-                P.spmv(pv.at(0), pv.at(n), 1.0, 0.0, 0.0, want_red=True)
-                P.stats(reset=True)
-                for _ in range(5):
-                    P.spmv(pv.at(0), pv.at(n), 1.0, -0.5, 0.0, want_red=True)
-                ps = P.stats()
-                pms = ps.ms_spmv / max(ps.n_spmv, 1)
-                out["roofline_plain_values"] = {"kernel": "k_spmv_rows (complex128 values)", "ms_per_launch": round(pms, 4),
-                                                "achieved": round(bytes_launch / pms / 1e6, 2), "unit": "GB/s",
-                                                "frac": round(bytes_launch / pms / 1e6 / HBM_PEAK_GBPS, 4), "launches": int(ps.n_spmv),
-                                                "traffic": traffic_of("%s|rows|plain" % args.workload)}
-                pv.free()
-                P.destroy()
+                F = build_operator(W, (r0, r1), q.make_opts(device=local_rank, stream=stream.cuda_stream, xcd_swizzle=args.swizzle, profile=1),
+                                   shard=(rank, world))
+                fi = F.info()
+                fp = timed_lanczos(F, False)
+                f_coded = bool(fi.value_dict)
+                f_real = fp["n_real"] > 0
+                f_cw = 0 if not f_coded else (1 if fi.value_dict <= 256 else 2)
+                vec_b = 8 if f_real else 16
+                fbytes = fi.nnz * (4 + (f_cw if f_coded else 16)) + (fi.nrows + 1) * 8 + fi.nrows * 2 * vec_b
+                ftr, fsrc = traffic_of("%s|%s|%s" % (args.workload, KERNEL_KEY[fi.kernel], "dict" if f_coded else "plain") + ("|real" if f_real else ""))
+                out["fast_path"] = {
+                    "value": round(fp["steps"] / fp["elapsed"], 4), "unit": "lanczos_iters/s", "steps": fp["steps"],
+                    "ms_per_step": round(1e3 * fp["elapsed"] / fp["steps"], 4),
+                    "dtype": "f64 real (1-byte value codes, packed-double vectors; bit-identical to complex128)" if f_real
+                             else "complex128 vectors, %d-byte value codes" % f_cw,
+                    "value_dict": fi.value_dict, "real_gather": f_real, "e0": fp["e0"],
+                    "e0_rel_diff_vs_complex128": (abs(fp["e0"] - head["e0"]) / abs(head["e0"])) if (fp["e0"] is not None and head["e0"]) else None,
+                    "roofline": {"bound": "hbm", "kernel": KERNEL_NAME[fi.kernel], "achieved": round(fbytes / fp["ms_spmv"] / 1e6, 2),
+                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(fbytes / fp["ms_spmv"] / 1e6 / HBM_PEAK_GBPS, 4),
+                                 "traffic": ftr, "traffic_source": fsrc, "bytes_per_launch": fbytes,
+                                 "ms_per_launch": round(fp["ms_spmv"], 4), "launches": fp["n_spmv"],
+                                 "bytes_definition": "this format's bytes: nnz*(4 + %d) + (rows+1)*8 + rows*%d" % (f_cw if f_coded else 16, 2 * vec_b)},
+                    "note": "lossless: values are dictionary-coded, and a real operator applied to real vectors gathers 8-byte real parts"}
+                F.destroy()
         except Exception as e:
-            out["roofline_plain_values"] = {"error": repr(e)}
-    if world == 1 and W["kind"] in ("hubbard", "heisenberg") and not args.no_matrix_free and not args.matrix_free:
+            out["fast_path"] = {"error": repr(e)}
+    if world == 1 and W["kind"] in ("hubbard", "heisenberg") and not args.no_matrix_free and not args.matrix_free and not args.host_csr:
         # SURVEY 8f-1 (next row, NOT the north-star CSR path): the same operator applied from the hop tables without a
         # stored matrix, same solver code; measured after the timed region, same step definition
         try:
@@ -390,21 +592,24 @@ def main():
                 tm = time.perf_counter() - tm0
                 ms_ = M.stats()
                 mms = ms_.ms_spmv / max(ms_.n_spmv, 1)
+                mtr, msrc = traffic_of("%s|matrix_free|plain%s" % (args.workload, "|real" if ms_.n_spmv_real > 0 else ""))
                 out["matrix_free_" + W["kind"]] = {"lanczos_iters_per_s": round((mk2 - mk) / tm, 4), "steps": int(mk2 - mk),
-                                              "spmv_ms_per_launch": round(mms, 4),
-                                              "equivalent_csr_GBps": round(bytes_launch / mms / 1e6, 2),
-                                              "table_bytes": int(M.info().bytes_matrix),
-                                              "kernel": ("k_mf_hubbard_row" if ms_.n_spmv_real > 0 else "k_mf_hubbard") if W["kind"] == "hubbard" else "k_mf_heis",
-                                              "traffic": traffic_of("%s|matrix_free|plain%s" % (args.workload, "|real" if ms_.n_spmv_real > 0 else "")),
-                                              "note": "no stored matrix; not the CSR north-star path; traffic = HBM bytes per "
-                                                      "apply from the rocprofv3 --pmc passes under profiles/"}
+                                                   "spmv_ms_per_launch": round(mms, 4),
+                                                   "dtype": "f64 real (packed-double vectors)" if ms_.n_spmv_real > 0 else "complex128",
+                                                   "table_bytes": int(M.info().bytes_matrix),
+                                                   "kernel": ("k_mf_hubbard_row" if ms_.n_spmv_real > 0 else "k_mf_hubbard") if W["kind"] == "hubbard" else "k_mf_heis",
+                                                   "traffic": mtr, "traffic_source": msrc,
+                                                   "note": "no stored matrix; not the CSR north-star path"}
                 mv.free()
                 M.destroy()
         except Exception as e:
             out["matrix_free_" + W["kind"]] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.matrix_free:
         try:
-            out["cpu_baseline"] = cpu_baseline(A, dim, args.cpu_rows)
+            out["cpu_baseline"] = cpu_baseline(A, dim, args.cpu_rows, W, q, stream)
+            mid = out["cpu_baseline"].get("midsize", {})
+            if "e0_rel_err_vs_cpu" in mid:
+                out["e0_rel_err_vs_cpu"] = mid["e0_rel_err_vs_cpu"]
         except Exception as e:      # the baseline is reported, never required
             out["cpu_baseline"] = {"value": None, "unit": "lanczos_iters/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     if rank == 0:

@@ -30,6 +30,21 @@ int qbo_num_threads(void)
 #endif
 }
 
+/* Parallel copy whose only purpose is NUMA placement for the timed CPU baseline: dst must be freshly
+ * allocated (untouched pages); every thread copies -- and thereby first-touches -- one contiguous slice, the
+ * same static partition the SpMV and BLAS-1 loops below use, so pages end up spread over the memory
+ * controllers of all sockets instead of on the node of the one thread that filled the array. */
+void qbo_first_touch_copy(int64_t nbytes, const void *src, void *dst)
+{
+    const int64_t page = 4096, npages = (nbytes + page - 1) / page;
+    int64_t i;
+    #pragma omp parallel for schedule(static)
+    for (i = 0; i < npages; ++i) {
+        const int64_t b = i * page, e = (b + page < nbytes) ? b + page : nbytes;
+        memcpy((char *)dst + b, (const char *)src + b, (size_t)(e - b));
+    }
+}
+
 /* ------------------------------------------------------------------------- */
 /* BLAS-1 (src/lanczos.cc:10-53 wrap cblas_zaxpy/zcopy/dznrm2/zscal/zdotc)    */
 /* ------------------------------------------------------------------------- */

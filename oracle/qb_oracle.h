@@ -92,6 +92,8 @@ double qbo_nrm2(int64_t n, const double *x);
 void   qbo_dotc(int64_t n, const double *x, const double *y, double *res /*[2]*/);
 
 int qbo_num_threads(void);
+/* NUMA first-touch placement helper of the timed CPU baseline (bench.py) */
+void qbo_first_touch_copy(int64_t nbytes, const void *src, void *dst);
 
 #ifdef __cplusplus
 }

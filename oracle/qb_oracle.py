@@ -212,5 +212,14 @@ def locate_E0_lanczos(csr, nev=1, ncv=1, maxit=1000):
     return out
 
 
+def first_touch(a):
+    """Copy of `a` whose pages were first touched by the OpenMP threads (static slices): on a multi-socket host the
+    array is then spread over all memory controllers instead of sitting on one NUMA node (CPU baseline only)."""
+    a = np.ascontiguousarray(a)
+    out = np.empty_like(a)
+    lib().qbo_first_touch_copy(C.c_int64(a.nbytes), _p(a), _p(out))
+    return out
+
+
 def num_threads():
     return lib().qbo_num_threads()
