@@ -148,7 +148,7 @@ int setup_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, int dict_mode, 
         unroll = tpr == 1 ? 8 : 4;
     } else {
         npb = o.nnz_per_block > 0 ? o.nnz_per_block : 2048;
-        if (A->kernel == QBH_KERNEL_VECTOR) tpr = avg <= 6 ? 4 : avg <= 12 ? 8 : avg <= 40 ? 16 : avg <= 96 ? 32 : 64;
+        if (A->kernel == QBH_KERNEL_VECTOR) tpr = avg <= 24 ? 2 : avg <= 96 ? 4 : avg <= 192 ? 8 : avg <= 512 ? 16 : avg <= 2048 ? 32 : 64;
         else                                tpr = avg <= 3 ? 1 : avg <= 8 ? 2 : avg <= 48 ? 4 : avg <= 128 ? 8 : 16;
     }
     if (npb != 1024 && npb != 2048 && npb != 4096 && !(npb == 8192 && A->kernel == QBH_KERNEL_ROWS && dict_mode == 1)) {
@@ -182,6 +182,19 @@ int setup_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, int dict_mode, 
         if (occ > 0) {
             int64_t g = (int64_t)occ * ncu;
             g = std::min<int64_t>(g, ((n_blocks + 7) / 8) * 8);
+            *grid_o = (int)std::max<int64_t>(8, (g / 8) * 8);
+        }
+    }
+    if (A->kernel == QBH_KERNEL_VECTOR) {
+        // persistent launch as well: resident workgroups only, so that the chunked XCD walk applies
+        const int occ = qbh::vector_kernel_occupancy(tpr, unroll, coded);
+        int ncu = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, A->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        if (occ > 0) {
+            const int rpb = qbh::kBlock / tpr;
+            const int64_t units = (A->nrows + rpb - 1) / rpb;
+            int64_t g = std::min<int64_t>((int64_t)occ * ncu, ((units + 7) / 8) * 8);
             *grid_o = (int)std::max<int64_t>(8, (g / 8) * 8);
         }
     }

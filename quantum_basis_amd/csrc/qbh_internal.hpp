@@ -68,6 +68,7 @@ struct SpmvArgs {
 int launch_spmv(const SpmvArgs &a, int kernel, int npb, int tpr, int grid, hipStream_t s);
 int spmv_grid(int kernel, int64_t n_blocks, int64_t nrows, int tpr);
 int rows_kernel_occupancy(int npb, int tpr, int un, int dict_mode);
+int vector_kernel_occupancy(int tpr, int un, bool dict);
 int launch_build_rowblocks(const int64_t *d_ia, int64_t nrows, int64_t window, int32_t *d_rb,
                            int64_t *d_bp, int64_t n_blocks, hipStream_t s);
 int launch_reduce_partials(const double *partials, int nparts, int ncomp, double *out, hipStream_t s);

@@ -498,9 +498,15 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
 }
 
 // ------------------------------------------- sub-wavefront-per-row SpMV --------
-// G lanes per row, shuffle reduction; no LDS staging.  Kept as the second opinion and for
-// matrices whose rows are long enough to fill a wavefront.
-template <int G, bool DICT>
+// G lanes per row, NO LDS staging and no workgroup barrier: a wavefront owns 64/G consecutive rows and every lane walks
+// its row in strides of G, UN entries at a time -- UN column loads, UN value loads and then UN x gathers in flight per
+// lane.  Nothing limits occupancy but registers (the row kernel's 20 B/nnz of LDS hold it at 3 workgroups per CU), so
+// the chain row pointer -> (column, value) -> x -> FMA of one wavefront hides behind up to 8 wavefronts per SIMD.
+// The matrix stream is read straight from global memory: the G lanes of a row take G consecutive entries (64 B of
+// values at G = 4), consecutive steps touch the same 128-byte lines again while they are still in L1, so HBM sees each
+// line once.  Entries are taken alternately from the front and the back of the row, as in k_spmv_rows: for the
+// Kronecker-structured Hamiltonians the k-th entries of consecutive rows then point at consecutive x elements.
+template <int G, int UN, bool DICT>
 __global__ __launch_bounds__(kBlock) void k_spmv_vector(SpmvArgs a)
 {
     __shared__ double red[12];
@@ -509,32 +515,66 @@ __global__ __launch_bounds__(kBlock) void k_spmv_vector(SpmvArgs a)
     constexpr int RPB = kBlock / G;            // rows per workgroup pass
     const int g = tid / G, sub = tid % G;
     double acc[3] = {0.0, 0.0, 0.0};
+    const bool need_y = a.beta != 0.0;
+    const bool need_x = a.gamma != 0.0 || a.partials != nullptr;
     if (DICT) {
         dict_s[tid] = a.dict[tid];
         __syncthreads();
     }
     const int64_t n_chunks = (a.nrows + RPB - 1) / RPB;
-    BlockWalk walk(n_chunks, a.swizzle);
+    const int64_t last = a.ia[a.nrows] - 1;    // clamp for the masked lanes (nnz > 0)
+    BlockWalk walk(n_chunks, a.swizzle, a.chunk_mult);
     for (int64_t lb = walk.slot; lb < walk.per_xcd; lb += walk.nslot) {
         const int64_t b = walk.block(lb);
         if (b >= n_chunks) continue;
         const int64_t row = b * RPB + g;
-        if (row < a.nrows) {
-            const int64_t s = a.ia[row], e = a.ia[row + 1];
-            d2 sum = {0.0, 0.0};
-            for (int64_t q = s + sub; q < e; q += G) {
-                d2 v;
-                if (DICT) v = dict_s[ntload(a.code + q)];
-                else      v = ntload(a.val + q);
-                sum += cmul(v, a.xg[ntload(a.ja + q)]);
+        const bool rowok = row < a.nrows;
+        const int64_t s = rowok ? a.ia[row] : 0;
+        const int len = rowok ? (int)(a.ia[row + 1] - s) : 0;
+        d2 yo = {0.0, 0.0}, xi = {0.0, 0.0};
+        const bool mine = sub == 0 && rowok;
+        if (mine && need_y) yo = load_y_old(a, row);
+        if (mine && need_x) xi = load_x_local(a, row);
+        int wmax = len;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int o = __shfl_xor(wmax, off, 64);
+            wmax = o > wmax ? o : wmax;
+        }
+        d2 sum = {0.0, 0.0};
+        for (int k0 = sub; k0 < wmax; k0 += G * UN) {
+            int c[UN];
+            bool ok[UN];
+            int64_t q[UN];
+            d2 v[UN], xv[UN];
+            uint8_t cb[UN];
+#pragma unroll
+            for (int j = 0; j < UN; ++j) {
+                const int k = k0 + j * G;
+                ok[j] = k < len;
+                const int f = (k & 1) ? len - 1 - (k >> 1) : (k >> 1);     // front / back alternation
+                q[j] = ok[j] ? s + f : last;
+                c[j] = ntload(a.ja + q[j]) & a.colmask;
             }
 #pragma unroll
-            for (int off = G / 2; off > 0; off >>= 1) {
-                sum.x += __shfl_xor(sum.x, off, 64);
-                sum.y += __shfl_xor(sum.y, off, 64);
+            for (int j = 0; j < UN; ++j) {
+                if (DICT) cb[j] = ntload(a.code + q[j]);
+                else      v[j] = ntload(a.val + q[j]);
             }
-            if (sub == 0) row_epilogue(a, row, sum, acc);
+#pragma unroll
+            for (int j = 0; j < UN; ++j) xv[j] = a.xg[c[j]];
+#pragma unroll
+            for (int j = 0; j < UN; ++j) {
+                if (DICT) v[j] = dict_s[cb[j]];
+                if (ok[j]) sum += cmul(v[j], xv[j]);
+            }
         }
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) {
+            sum.x += __shfl_xor(sum.x, off, 64);
+            sum.y += __shfl_xor(sum.y, off, 64);
+        }
+        if (mine) row_epilogue2(a, row, sum, yo, xi, acc);
     }
     if (a.partials != nullptr) {
         block_sum<3>(acc, red);
@@ -544,6 +584,38 @@ __global__ __launch_bounds__(kBlock) void k_spmv_vector(SpmvArgs a)
             a.partials[(size_t)blockIdx.x * 3 + 2] = acc[2];
         }
     }
+}
+
+template <int G, bool DICT>
+static int occ_vector_un(int un)
+{
+    int n = 0;
+    hipError_t e = (un == 8) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spmv_vector<G, 8, DICT>, kBlock, 0)
+                 : (un == 2) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spmv_vector<G, 2, DICT>, kBlock, 0)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spmv_vector<G, 4, DICT>, kBlock, 0);
+    return e == hipSuccess ? n : 0;
+}
+
+// workgroups of the lanes-per-row kernel resident per CU (0 if unknown)
+int vector_kernel_occupancy(int tpr, int un, bool dict)
+{
+    switch (tpr) {
+    case 2:  return dict ? occ_vector_un<2, true>(un)  : occ_vector_un<2, false>(un);
+    case 4:  return dict ? occ_vector_un<4, true>(un)  : occ_vector_un<4, false>(un);
+    case 8:  return dict ? occ_vector_un<8, true>(un)  : occ_vector_un<8, false>(un);
+    case 16: return dict ? occ_vector_un<16, true>(un) : occ_vector_un<16, false>(un);
+    case 32: return dict ? occ_vector_un<32, true>(un) : occ_vector_un<32, false>(un);
+    case 64: return dict ? occ_vector_un<64, true>(un) : occ_vector_un<64, false>(un);
+    default: return 0;
+    }
+}
+
+template <int G, bool DICT>
+static void launch_vector_un(const SpmvArgs &a, int grid, hipStream_t s)
+{
+    if (a.unroll == 8)      hipLaunchKernelGGL((k_spmv_vector<G, 8, DICT>), dim3(grid), dim3(kBlock), 0, s, a);
+    else if (a.unroll == 2) hipLaunchKernelGGL((k_spmv_vector<G, 2, DICT>), dim3(grid), dim3(kBlock), 0, s, a);
+    else                    hipLaunchKernelGGL((k_spmv_vector<G, 4, DICT>), dim3(grid), dim3(kBlock), 0, s, a);
 }
 
 int spmv_grid(int kernel, int64_t n_blocks, int64_t nrows, int tpr)
@@ -669,11 +741,12 @@ static int launch_spmv_t(const SpmvArgs &a, int kernel, int npb, int tpr, int gr
 {
     if (kernel == QBH_KERNEL_VECTOR) {
         switch (tpr) {
-        case 4:  hipLaunchKernelGGL((k_spmv_vector<4, DICT>),  dim3(grid), dim3(kBlock), 0, s, a); break;
-        case 8:  hipLaunchKernelGGL((k_spmv_vector<8, DICT>),  dim3(grid), dim3(kBlock), 0, s, a); break;
-        case 16: hipLaunchKernelGGL((k_spmv_vector<16, DICT>), dim3(grid), dim3(kBlock), 0, s, a); break;
-        case 32: hipLaunchKernelGGL((k_spmv_vector<32, DICT>), dim3(grid), dim3(kBlock), 0, s, a); break;
-        case 64: hipLaunchKernelGGL((k_spmv_vector<64, DICT>), dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 2:  launch_vector_un<2, DICT>(a, grid, s); break;
+        case 4:  launch_vector_un<4, DICT>(a, grid, s); break;
+        case 8:  launch_vector_un<8, DICT>(a, grid, s); break;
+        case 16: launch_vector_un<16, DICT>(a, grid, s); break;
+        case 32: launch_vector_un<32, DICT>(a, grid, s); break;
+        case 64: launch_vector_un<64, DICT>(a, grid, s); break;
         default: set_error("unsupported lanes-per-row %d", tpr); return QBH_EINVAL;
         }
         return QBH_OK;
