@@ -486,7 +486,11 @@ def main():
         if dim is None:
             dim = int(info.ncols)
         if world > 1:
-            comm = qdist.ShardComm(dim, rank=rank, world=world, device=device, stream=stream).attach(A)  # noqa: F841
+            if backend == "nccl" and not os.environ.get("QBH_PY_HOOKS"):
+                # the library's own RCCL communicator (qbh_comm_create_rccl): no Python in the SpMV loop
+                comm = qdist.NativeComm(dim, rank=rank, world=world).attach(A)  # noqa: F841
+            else:
+                comm = qdist.ShardComm(dim, rank=rank, world=world, device=device, stream=stream).attach(A)  # noqa: F841
         nnz_total = int(allreduce_host([float(info.nnz)], dist.ReduceOp.SUM)[0])
         head = timed_lanczos(A, packed_real)
 
@@ -524,6 +528,8 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype,
         "data": "synthetic", "config": {"workload": args.workload, "dim": dim, "nnz_full": nnz_total,
                                          "rows_per_gpu": info.nrows, "parallelism": "row-shard x%d" % world,
+                                         "exchange": None if world == 1 else ("native RCCL (qbh_comm_create_rccl)" if (backend == "nccl" and not os.environ.get("QBH_PY_HOOKS"))
+                                                                              else "torch.distributed hooks (%s)" % backend),
                                          "kernel": KERNEL_KEY[info.kernel], "format": "complex128 CSR values + int32 columns, complex128 vectors"
                                          if not (coded or real_used) else "value codes %s, real fast path %s" % (coded, real_used),
                                          "value_dict": info.value_dict, "real_gather": real_used,

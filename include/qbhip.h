@@ -113,8 +113,8 @@ int qbh_balanced_row_cuts(int64_t dim, int64_t nnz, int sym_upper, const int64_t
 /* Adopt a row shard that already lives in HBM (device-side generator, multi-GPU row
  * blocks).  Rows [row_offset, row_offset+nrows) of a global ncols x ncols operator in
  * FULL storage; d_ia[nrows+1] is local (d_ia[0] == 0); d_ja holds GLOBAL columns.
- * take_ownership != 0: the arrays were allocated with hipMalloc and are freed by
- * qbh_csr_destroy. */
+ * take_ownership != 0: the arrays were allocated with hipMalloc and belong to the library from the
+ * moment of the call: they are freed by qbh_csr_destroy, or before returning when the call fails. */
 int qbh_csr_create_device(qbh_csr **out, int64_t nrows, int64_t ncols, int64_t row_offset,
                           int64_t nnz, int64_t *d_ia, int32_t *d_ja, qbh_z *d_val,
                           int take_ownership, const qbh_opts *opts);
@@ -274,8 +274,25 @@ typedef struct qbh_comm {
      * shard applies its locally-owned columns between the two calls (overlap with xGMI traffic). */
     int    (*allgather_begin)(void *ctx, int packed);
     int    (*allgather_wait)(void *ctx);
+    /* NULL: uniform blocks, rank q owns [q*nblk, (q+1)*nblk).  Otherwise the global row cuts of an nnz-balanced (ragged)
+     * partition, row_cuts[0] = 0 <= ... <= row_cuts[nranks] = ncols (qbh_balanced_row_cuts): rank q owns
+     * [row_cuts[q], row_cuts[q+1]), nblk is the longest block (the size of d_xsend), d_xfull / d_xfull_r hold ncols
+     * elements indexed by GLOBAL column and the gather hook places rank q's block at offset row_cuts[q].  The array is
+     * copied by qbh_csr_set_comm. */
+    const int64_t *row_cuts;
 } qbh_comm;
 int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm);
+
+/* The same two exchange steps implemented natively on RCCL (xGMI), no host-language callback in the SpMV loop: what a
+ * C++ host such as the reference (one process per GPU, src/model.cc:1177-1181 calling lanczos()) links against.
+ * qbh_rccl_unique_id: rank 0 obtains the 128-byte ncclUniqueId and hands it to the other ranks by whatever means the
+ * host program has (MPI_Bcast, a file, torch.distributed).  qbh_comm_create_rccl: collective over all ranks; creates
+ * the RCCL communicator, the exchange buffers, a side stream + events (the gather overlaps the locally-owned columns of
+ * a split shard) and attaches them to the row-shard operator A.  row_cuts[nranks+1]: global row cuts (ragged allowed),
+ * NULL = uniform blocks ceil(ncols / nranks).  qbh_comm_destroy detaches and frees (also done by qbh_csr_destroy). */
+int qbh_rccl_unique_id(void *uid128);
+int qbh_comm_create_rccl(qbh_csr *A, const void *uid128, int rank, int nranks, const int64_t *row_cuts);
+int qbh_comm_destroy(qbh_csr *A);
 
 /* ------------------------------------------------------------ stats ------ */
 typedef struct qbh_stats {

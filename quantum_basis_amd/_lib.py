@@ -66,7 +66,7 @@ class Comm(C.Structure):
                 ("d_xsend", C.c_void_p), ("d_xfull", C.c_void_p), ("d_scal", C.c_void_p),
                 ("d_xfull_r", C.c_void_p),
                 ("ctx", C.c_void_p), ("allgather_x", ALLGATHER_FN), ("allreduce_sum", ALLREDUCE_FN),
-                ("allgather_begin", ALLGATHER_FN), ("allgather_wait", ALLWAIT_FN)]
+                ("allgather_begin", ALLGATHER_FN), ("allgather_wait", ALLWAIT_FN), ("row_cuts", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -83,7 +83,7 @@ EXPORTS = [
     "qbh_vec_randomize",
     "qbh_spmv_dev", "qbh_dotc_dev", "qbh_axpy_norm_dev", "qbh_scal_dev", "qbh_nrm2_dev",
     "qbh_lanczos", "qbh_lanczos_dev", "qbh_lanczos_real_dev", "qbh_vec_randomize_real", "qbh_eigenvec_cg_real_dev", "qbh_eigenvec_cg", "qbh_eigenvec_cg_dev", "qbh_hess_eigen", "qbh_iram",
-    "qbh_csr_set_comm", "qbh_get_stats", "qbh_sync",
+    "qbh_csr_set_comm", "qbh_rccl_unique_id", "qbh_comm_create_rccl", "qbh_comm_destroy", "qbh_get_stats", "qbh_sync",
     "qbh_gen_hubbard", "qbh_mf_hubbard", "qbh_gen_heisenberg", "qbh_mf_heisenberg", "qbh_gen_heisenberg_repr", "qbh_csr_download",
 ]
 
@@ -149,6 +149,9 @@ def lib():
     L.qbh_hess_eigen.argtypes = [vp, i64, i64, C.c_char_p, vp, vp]
     L.qbh_iram.argtypes = [vp, i64, i64, i64, C.c_char_p, dbl, C.c_uint32, C.POINTER(i64), vp, vp, C.POINTER(SolverInfo)]
     L.qbh_csr_set_comm.argtypes = [vp, C.POINTER(Comm)]
+    L.qbh_rccl_unique_id.argtypes = [vp]
+    L.qbh_comm_create_rccl.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    L.qbh_comm_destroy.argtypes = [vp]
     L.qbh_get_stats.argtypes = [vp, C.POINTER(Stats), C.c_int]
     L.qbh_sync.argtypes = [vp]
     L.qbh_gen_hubbard.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, vp, dbl, dbl,

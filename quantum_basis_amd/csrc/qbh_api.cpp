@@ -398,6 +398,7 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
     if (A->rem.d_code) (void)hipFree(A->rem.d_code);
     if (A->rem.d_rb) (void)hipFree(A->rem.d_rb);
     if (A->rem.d_bp) (void)hipFree(A->rem.d_bp);
+    qbh::release_native_comm(A);
     if (A->d_flag) (void)hipFree(A->d_flag);
     if (A->d_xr) (void)hipFree(A->d_xr);
     if (A->kind == 1) {
@@ -519,7 +520,11 @@ extern "C" int qbh_csr_create_device(qbh_csr **out, int64_t nrows, int64_t ncols
     A->own_arrays = take_ownership != 0;
     int rc = finalize(A);
     if (rc != QBH_OK) {
-        A->own_arrays = false;   // the caller keeps the arrays on failure
+        // take_ownership: the arrays belong to the library from the moment of the call (finalize may already have replaced
+        // them by the split shard), so they are released here and the caller must not free them.  Borrowed arrays that
+        // finalize left untouched stay with the caller.
+        if (!take_ownership && A->d_ia == d_ia) A->own_arrays = false;
+        if (!take_ownership && A->d_ia == d_ia) A->d_ia = nullptr, A->d_ja = nullptr, A->d_val = nullptr;
         qbh_csr_destroy(A);
         return rc;
     }
@@ -549,10 +554,7 @@ int qbh::adopt_coded_csr(qbh_csr **out, int64_t nrows, int64_t ncols, int64_t ro
     A->own_arrays = true;
     int rc = finalize(A);
     if (rc != QBH_OK) {
-        A->own_arrays = false;   // the caller keeps the arrays on failure
-        A->d_code = nullptr;
-        A->d_dict = nullptr;
-        qbh_csr_destroy(A);
+        qbh_csr_destroy(A);      // the handle owned every array from the moment of the call: all released here
         return rc;
     }
     *out = A;
@@ -564,8 +566,6 @@ int qbh::adopt_mf_hubbard(qbh_csr **out, const qbh::MfHubbard &t, int64_t nrows,
 {
     qbh_csr *A = nullptr;
     QBH_TRY(new_handle(&A, opts));
-    A->kind = 1;
-    A->mf = t;
     A->nrows = nrows;
     A->ncols = ncols;
     A->row_offset = row_offset;
@@ -589,6 +589,8 @@ int qbh::adopt_mf_hubbard(qbh_csr **out, const qbh::MfHubbard &t, int64_t nrows,
     if (hipMalloc(&A->d_partials, nparts * 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
     A->stats = qbh_stats{};
     A->stats.ms_spmv_min = std::numeric_limits<double>::infinity();
+    A->kind = 1;                // from here on the handle owns the tables (on any failure above the caller still does)
+    A->mf = t;
     *out = A;
     return QBH_OK;
 }
@@ -598,8 +600,6 @@ int qbh::adopt_mf_heis(qbh_csr **out, const qbh::MfHeis &t, int64_t nrows, int64
 {
     qbh_csr *A = nullptr;
     QBH_TRY(new_handle(&A, opts));
-    A->kind = 2;
-    A->mfh = t;
     A->nrows = nrows;
     A->ncols = ncols;
     A->row_offset = row_offset;
@@ -623,6 +623,8 @@ int qbh::adopt_mf_heis(qbh_csr **out, const qbh::MfHeis &t, int64_t nrows, int64
     if (hipMalloc(&A->d_partials, nparts * 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
     A->stats = qbh_stats{};
     A->stats.ms_spmv_min = std::numeric_limits<double>::infinity();
+    A->kind = 2;                // from here on the handle owns the tables (on any failure above the caller still does)
+    A->mfh = t;
     *out = A;
     return QBH_OK;
 }
@@ -661,13 +663,34 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
         return QBH_OK;
     }
     if (!comm->d_xsend || !comm->d_xfull || !comm->d_scal || !comm->allgather_x || !comm->allreduce_sum ||
-        comm->rank < 0 || comm->rank >= comm->nranks || comm->nblk < A->nrows ||
-        comm->nblk * comm->rank != A->row_offset || comm->nblk * comm->nranks < A->ncols) {
-        qbh::set_error("qbh_csr_set_comm: inconsistent communicator (rank %d/%d nblk %lld row_offset %lld)",
-                       comm->rank, comm->nranks, (long long)comm->nblk, (long long)A->row_offset);
+        comm->rank < 0 || comm->rank >= comm->nranks || comm->nblk < A->nrows) {
+        qbh::set_error("qbh_csr_set_comm: incomplete communicator (rank %d/%d nblk %lld nrows %lld)", comm->rank, comm->nranks,
+                       (long long)comm->nblk, (long long)A->nrows);
         return QBH_EINVAL;
     }
+    if (comm->row_cuts) {
+        const int64_t *c = comm->row_cuts;
+        bool ok = c[0] == 0 && c[comm->nranks] == A->ncols && c[comm->rank] == A->row_offset &&
+                  c[comm->rank + 1] - c[comm->rank] == A->nrows;
+        for (int q = 0; q < comm->nranks && ok; ++q) ok = c[q + 1] >= c[q] && c[q + 1] - c[q] <= comm->nblk;
+        if (!ok) {
+            qbh::set_error("qbh_csr_set_comm: row_cuts do not describe this shard (rank %d/%d rows [%lld, %lld))", comm->rank,
+                           comm->nranks, (long long)A->row_offset, (long long)(A->row_offset + A->nrows));
+            return QBH_EINVAL;
+        }
+        A->comm_cuts.assign(c, c + comm->nranks + 1);
+        A->comm_full = A->ncols;
+    } else {
+        if (comm->nblk * comm->rank != A->row_offset || comm->nblk * comm->nranks < A->ncols) {
+            qbh::set_error("qbh_csr_set_comm: inconsistent communicator (rank %d/%d nblk %lld row_offset %lld)",
+                           comm->rank, comm->nranks, (long long)comm->nblk, (long long)A->row_offset);
+            return QBH_EINVAL;
+        }
+        A->comm_cuts.clear();
+        A->comm_full = comm->nblk * (int64_t)comm->nranks;
+    }
     A->comm = *comm;
+    A->comm.row_cuts = A->comm_cuts.empty() ? nullptr : A->comm_cuts.data();
     A->has_comm = true;
     return QBH_OK;
 }
@@ -754,8 +777,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     const bool packed = A->has_comm && A->real_wire;
     const bool realm = A->real_mode && A->kernel == QBH_KERNEL_ROWS && (packed || !A->has_comm);
     auto expand_packed = [&]() -> int {          // d_xfull_r (doubles) -> d_xfull (complex, zero imaginary part)
-        return qbh::launch_unpack_real(A->comm.d_xfull_r, reinterpret_cast<d2 *>(A->comm.d_xfull),
-                                       A->comm.nblk * (int64_t)A->comm.nranks, A->stream);
+        return qbh::launch_unpack_real(A->comm.d_xfull_r, reinterpret_cast<d2 *>(A->comm.d_xfull), A->comm_full, A->stream);
     };
     if (A->has_comm) {
         if (packed) {
@@ -1410,13 +1432,6 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
         return QBH_OK;
     };
 
-    if (k == 0) {                                          // :167-191
-        b[0] = 0.0;
-        QBH_TRY(step(1, 0.0));
-        m = ++k;
-        --np;
-    }
-
     // convergence bookkeeping; restored from / returned in info->state so that a run can be resumed
     // exactly where a checkpoint left it (what ckpt_lanczos_init restores, src/ckpt.cc:38-176)
     double theta0_prev = 0.0, theta1_prev = 0.0, accuracy = 0.0;
@@ -1432,6 +1447,13 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
             return QBH_OK;
         }
     }
+    if (k == 0) {                                          // :167-191
+        b[0] = 0.0;
+        QBH_TRY(step(1, 0.0));
+        m = ++k;
+        --np;
+    }
+
     std::vector<double> w((size_t)mm + 8), zl((size_t)mm + 8), ws((size_t)mm + 8);     // ws always holds four Ritz values
     int rc = QBH_OK;
     do {                                                   // :193
@@ -1689,6 +1711,7 @@ static int cg_core(qbh_csr *A, int64_t maxit, int64_t *m_io, double E0, double *
             QBH_TRY(qbh::launch_unpack_real(vr, v, n, A->stream));
             QBH_TRY(qbh::launch_unpack_real(rr, r, n, A->stream));
             QBH_TRY(qbh::launch_unpack_real(pr, p, n, A->stream));
+            QBH_TRY(qbh::launch_unpack_real(ppr, pp, n, A->stream));   // the reference leaves pp = (H - E0) p there (:322)
             QBH_HIP(hipStreamSynchronize(A->stream));
             (void)hipFree(rv);
             rv = nullptr;

@@ -1,0 +1,296 @@
+// qbh_comm.cpp -- the native communicator: the two exchange steps of the row-sharded path on RCCL over
+// xGMI, implemented in C++ behind the same qbh_comm hooks the library already drives, so that a C++ host -- which is
+// what the reference is (src/model.cc:1177-1181 calls lanczos() from one host thread) -- can run N > 1 ranks without
+// any Python in the SpMV loop:
+//   all-gather of x      ncclAllGather for uniform row blocks; for nnz-balanced (ragged) cuts one ncclBroadcast per
+//                        owner inside a group call, i.e. the direct schedule in which every xGMI link carries exactly
+//                        one peer block.  Runs on a side stream; begin() / wait() bracket it with events so the
+//                        locally-owned columns of a split shard are applied while the links are busy.
+//   all-reduce(sum)      <= 16 doubles (Lanczos a_m / b_m, CG dots, the real-wire flags), same side stream.
+// librccl is resolved at run time (dlopen), so libqbhip.so still loads where RCCL is absent; then
+// qbh_comm_create_rccl fails loudly with QBH_EUNSUPP.  Types come from the real <rccl/rccl.h>.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "qbh_internal.hpp"
+
+namespace {
+
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+};
+
+RcclApi *rccl()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.handle ? &api : nullptr;
+    tried = true;
+    // a copy that is already mapped (e.g. the one torch bundles) is reused: same soname
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (api.handle) break;
+    }
+    if (!api.handle) return nullptr;
+#define QBH_SYM(field, sym)                                                   \
+    api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, sym)); \
+    if (!api.field) {                                                         \
+        api.handle = nullptr;                                                 \
+        return nullptr;                                                       \
+    }
+    QBH_SYM(GetUniqueId, "ncclGetUniqueId")
+    QBH_SYM(CommInitRank, "ncclCommInitRank")
+    QBH_SYM(CommDestroy, "ncclCommDestroy")
+    QBH_SYM(GetErrorString, "ncclGetErrorString")
+    QBH_SYM(AllGather, "ncclAllGather")
+    QBH_SYM(AllReduce, "ncclAllReduce")
+    QBH_SYM(Broadcast, "ncclBroadcast")
+    QBH_SYM(GroupStart, "ncclGroupStart")
+    QBH_SYM(GroupEnd, "ncclGroupEnd")
+#undef QBH_SYM
+    return &api;
+}
+
+}  // namespace
+
+// everything the hooks need; owned by the operator handle (qbh_csr::native)
+struct qbh_native_comm {
+    RcclApi    *api = nullptr;
+    ncclComm_t  comm = nullptr;
+    int         rank = 0, nranks = 1;
+    bool        ragged = false;
+    std::vector<int64_t> cuts;        // [nranks+1]
+    int64_t     nblk = 0;             // longest block (size of d_xsend)
+    hipStream_t op = nullptr;         // the operator's stream
+    hipStream_t side = nullptr;       // RCCL's stream
+    hipEvent_t  ready = nullptr, done = nullptr;
+    double     *d_xsend = nullptr, *d_xfull = nullptr, *d_xfull_r = nullptr, *d_scal = nullptr;
+    bool        in_flight = false;
+    char        err[256] = "";
+};
+
+namespace {
+
+int fail(qbh_native_comm *c, const char *what, ncclResult_t r)
+{
+    snprintf(c->err, sizeof(c->err), "%s: %s", what, c->api->GetErrorString(r));
+    qbh::set_error("RCCL %s", c->err);
+    return 1;
+}
+
+// the exchange itself, enqueued on the side stream after everything the operator's stream has enqueued so far
+int enqueue_gather(qbh_native_comm *c, int packed)
+{
+    if (hipEventRecord(c->ready, c->op) != hipSuccess || hipStreamWaitEvent(c->side, c->ready, 0) != hipSuccess) return 1;
+    const size_t w = packed ? 1 : 2;                               // doubles per element on the wire
+    double *recv = packed ? c->d_xfull_r : c->d_xfull;
+    ncclResult_t r;
+    if (!c->ragged) {
+        r = c->api->AllGather(c->d_xsend, recv, (size_t)c->nblk * w, ncclDouble, c->comm, c->side);
+        if (r != ncclSuccess) return fail(c, "ncclAllGather", r);
+    } else {
+        if ((r = c->api->GroupStart()) != ncclSuccess) return fail(c, "ncclGroupStart", r);
+        for (int q = 0; q < c->nranks; ++q) {
+            const size_t len = (size_t)(c->cuts[(size_t)q + 1] - c->cuts[(size_t)q]);
+            if (len == 0) continue;
+            r = c->api->Broadcast(c->d_xsend, recv + (size_t)c->cuts[(size_t)q] * w, len * w, ncclDouble, q, c->comm, c->side);
+            if (r != ncclSuccess) {
+                (void)c->api->GroupEnd();
+                return fail(c, "ncclBroadcast", r);
+            }
+        }
+        if ((r = c->api->GroupEnd()) != ncclSuccess) return fail(c, "ncclGroupEnd", r);
+    }
+    if (hipEventRecord(c->done, c->side) != hipSuccess) return 1;
+    c->in_flight = true;
+    return 0;
+}
+
+int hook_wait(void *ctx)
+{
+    auto *c = static_cast<qbh_native_comm *>(ctx);
+    if (!c->in_flight) return 0;
+    c->in_flight = false;
+    return hipStreamWaitEvent(c->op, c->done, 0) == hipSuccess ? 0 : 1;
+}
+
+int hook_begin(void *ctx, int packed) { return enqueue_gather(static_cast<qbh_native_comm *>(ctx), packed); }
+
+int hook_gather(void *ctx, int packed)
+{
+    if (enqueue_gather(static_cast<qbh_native_comm *>(ctx), packed) != 0) return 1;
+    return hook_wait(ctx);
+}
+
+int hook_allreduce(void *ctx, int off, int n)
+{
+    auto *c = static_cast<qbh_native_comm *>(ctx);
+    if (hipEventRecord(c->ready, c->op) != hipSuccess || hipStreamWaitEvent(c->side, c->ready, 0) != hipSuccess) return 1;
+    ncclResult_t r = c->api->AllReduce(c->d_scal + off, c->d_scal + off, (size_t)n, ncclDouble, ncclSum, c->comm, c->side);
+    if (r != ncclSuccess) return fail(c, "ncclAllReduce", r);
+    if (hipEventRecord(c->done, c->side) != hipSuccess || hipStreamWaitEvent(c->op, c->done, 0) != hipSuccess) return 1;
+    return 0;
+}
+
+void destroy_native(qbh_native_comm *c)
+{
+    if (!c) return;
+    if (c->side) (void)hipStreamSynchronize(c->side);
+    if (c->comm && c->api) (void)c->api->CommDestroy(c->comm);
+    if (c->d_xsend) (void)hipFree(c->d_xsend);
+    if (c->d_xfull) (void)hipFree(c->d_xfull);
+    if (c->d_xfull_r) (void)hipFree(c->d_xfull_r);
+    if (c->d_scal) (void)hipFree(c->d_scal);
+    if (c->ready) (void)hipEventDestroy(c->ready);
+    if (c->done) (void)hipEventDestroy(c->done);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    delete c;
+}
+
+}  // namespace
+
+void qbh::release_native_comm(qbh_csr *A)
+{
+    if (A && A->native) {
+        destroy_native(A->native);
+        A->native = nullptr;
+    }
+}
+
+extern "C" int qbh_rccl_unique_id(void *uid128)
+{
+    if (!uid128) return QBH_EINVAL;
+    RcclApi *api = rccl();
+    if (!api) {
+        qbh::set_error("librccl could not be loaded (%s)", dlerror() ? dlerror() : "no such library");
+        return QBH_EUNSUPP;
+    }
+    ncclUniqueId id;
+    ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) {
+        qbh::set_error("ncclGetUniqueId: %s", api->GetErrorString(r));
+        return QBH_ECOMM;
+    }
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(uid128, &id, sizeof(id));
+    return QBH_OK;
+}
+
+extern "C" int qbh_comm_create_rccl(qbh_csr *A, const void *uid128, int rank, int nranks, const int64_t *row_cuts)
+{
+    if (!A || !uid128 || nranks < 1 || rank < 0 || rank >= nranks) {
+        qbh::set_error("qbh_comm_create_rccl: invalid argument");
+        return QBH_EINVAL;
+    }
+    RcclApi *api = rccl();
+    if (!api) {
+        qbh::set_error("librccl could not be loaded: the native communicator is unavailable");
+        return QBH_EUNSUPP;
+    }
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (prev != A->device) QBH_HIP(hipSetDevice(A->device));
+    qbh::release_native_comm(A);
+    qbh_native_comm *c = new (std::nothrow) qbh_native_comm();
+    if (!c) return QBH_ENOMEM;
+    c->api = api;
+    c->rank = rank;
+    c->nranks = nranks;
+    c->op = A->stream;
+    c->cuts.resize((size_t)nranks + 1);
+    const int64_t uni = (A->ncols + nranks - 1) / nranks;
+    c->ragged = false;
+    for (int q = 0; q <= nranks; ++q) {
+        const int64_t u = std::min<int64_t>((int64_t)q * uni, A->ncols);
+        c->cuts[(size_t)q] = row_cuts ? row_cuts[q] : u;
+        if (c->cuts[(size_t)q] != u) c->ragged = true;
+    }
+    if (const char *e = getenv("QBH_COMM_FORCE_RAGGED")) {      // test rigs: take the ragged (grouped broadcast) path even for uniform cuts
+        if (atoi(e)) c->ragged = true;
+    }
+    c->nblk = uni;
+    for (int q = 0; q < nranks; ++q) c->nblk = std::max(c->nblk, c->cuts[(size_t)q + 1] - c->cuts[(size_t)q]);
+    int rc = QBH_OK;
+    auto bail = [&](int code) {
+        destroy_native(c);
+        if (prev >= 0 && prev != A->device) (void)hipSetDevice(prev);
+        return code;
+    };
+    if (c->cuts[0] != 0 || c->cuts[(size_t)nranks] != A->ncols || c->cuts[(size_t)rank] != A->row_offset ||
+        c->cuts[(size_t)rank + 1] - c->cuts[(size_t)rank] != A->nrows) {
+        qbh::set_error("qbh_comm_create_rccl: rank %d owns rows [%lld, %lld) but the cuts say [%lld, %lld) of %lld", rank,
+                       (long long)A->row_offset, (long long)(A->row_offset + A->nrows), (long long)c->cuts[(size_t)rank],
+                       (long long)c->cuts[(size_t)rank + 1], (long long)A->ncols);
+        return bail(QBH_EINVAL);
+    }
+    // uniform blocks are gathered with one ncclAllGather into nranks * nblk slots; ragged cuts land at their global offsets
+    const size_t full = c->ragged ? (size_t)A->ncols : (size_t)c->nblk * (size_t)nranks;
+#define QBH_C(call)                                                                       \
+    if ((call) != hipSuccess) {                                                           \
+        qbh::set_error("%s failed (qbh_comm_create_rccl)", #call);                        \
+        return bail(QBH_EHIP);                                                            \
+    }
+    QBH_C(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    QBH_C(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+    QBH_C(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    QBH_C(hipMalloc(&c->d_xsend, (size_t)c->nblk * 2 * sizeof(double)));
+    QBH_C(hipMalloc(&c->d_xfull, full * 2 * sizeof(double)));
+    QBH_C(hipMalloc(&c->d_xfull_r, full * sizeof(double)));
+    QBH_C(hipMalloc(&c->d_scal, 16 * sizeof(double)));
+    QBH_C(hipMemset(c->d_xsend, 0, (size_t)c->nblk * 2 * sizeof(double)));
+    QBH_C(hipMemset(c->d_xfull, 0, full * 2 * sizeof(double)));
+    QBH_C(hipMemset(c->d_scal, 0, 16 * sizeof(double)));
+#undef QBH_C
+    ncclUniqueId id;
+    std::memcpy(&id, uid128, sizeof(id));
+    ncclResult_t r = api->CommInitRank(&c->comm, nranks, id, rank);
+    if (r != ncclSuccess) {
+        qbh::set_error("ncclCommInitRank: %s", api->GetErrorString(r));
+        c->comm = nullptr;
+        return bail(QBH_ECOMM);
+    }
+    qbh_comm h{};
+    h.rank = rank;
+    h.nranks = nranks;
+    h.nblk = c->nblk;
+    h.d_xsend = reinterpret_cast<qbh_z *>(c->d_xsend);
+    h.d_xfull = reinterpret_cast<qbh_z *>(c->d_xfull);
+    h.d_scal = c->d_scal;
+    h.d_xfull_r = c->d_xfull_r;
+    h.ctx = c;
+    h.allgather_x = hook_gather;
+    h.allreduce_sum = hook_allreduce;
+    h.allgather_begin = hook_begin;
+    h.allgather_wait = hook_wait;
+    h.row_cuts = c->ragged ? c->cuts.data() : nullptr;
+    rc = qbh_csr_set_comm(A, &h);
+    if (rc != QBH_OK) return bail(rc);
+    A->native = c;
+    if (prev >= 0 && prev != A->device) (void)hipSetDevice(prev);
+    return QBH_OK;
+}
+
+extern "C" int qbh_comm_destroy(qbh_csr *A)
+{
+    if (!A) return QBH_EINVAL;
+    (void)qbh_csr_set_comm(A, nullptr);
+    qbh::release_native_comm(A);
+    return QBH_OK;
+}

@@ -384,14 +384,8 @@ extern "C" int qbh_gen_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, i
         if (d_val) (void)hipFree(d_val);
         return e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP;
     }
-    rc = qbh_csr_create_device(out, nrows, dim, row_begin, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1,
-                               opts);
-    if (rc != QBH_OK) {
-        (void)hipFree(d_ia);
-        (void)hipFree(d_ja);
-        (void)hipFree(d_val);
-    }
-    return rc;
+    // ownership passes with the call: on failure the arrays have already been released
+    return qbh_csr_create_device(out, nrows, dim, row_begin, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, opts);
 }
 
 namespace {
@@ -466,19 +460,24 @@ extern "C" int qbh_mf_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, in
         const int64_t u = row / Nd, d = row - u * Nd;
         return base_u[u] + d * (1 + (hu.ptr[u + 1] - hu.ptr[u])) + pre_d[d];
     };
+    if (Nu >= (1 << 24) || Nd >= (1 << 24)) {              // before anything is allocated
+        set_error("qbh_mf_hubbard: more than 2^24 configurations per species");
+        return QBH_EUNSUPP;
+    }
     MfHubbard m;
     m.Nu = Nu;
     m.Nd = Nd;
     m.U = U;
+    auto free_tables = [&]() {
+        for (void *q : {(void *)m.cfg_u, (void *)m.cfg_d, (void *)m.tgt_u, (void *)m.tgt_d, (void *)m.val_u, (void *)m.val_d, (void *)m.pk_d})
+            if (q) (void)hipFree(q);
+    };
+    auto build = [&]() -> int {
     QBH_HIP(hipMalloc(&m.cfg_u, (size_t)Nu * sizeof(uint32_t)));
     QBH_HIP(hipMalloc(&m.cfg_d, (size_t)Nd * sizeof(uint32_t)));
     QBH_HIP(hipMemcpy(m.cfg_u, hu.cfg.data(), (size_t)Nu * sizeof(uint32_t), hipMemcpyHostToDevice));
     QBH_HIP(hipMemcpy(m.cfg_d, hd.cfg.data(), (size_t)Nd * sizeof(uint32_t), hipMemcpyHostToDevice));
     HopTableView vu{Nu, hu.ptr.data(), hu.tgt.data(), hu.val.data()}, vd{Nd, hd.ptr.data(), hd.tgt.data(), hd.val.data()};
-    if (Nu >= (1 << 24) || Nd >= (1 << 24)) {
-        set_error("qbh_mf_hubbard: more than 2^24 configurations per species");
-        return QBH_EUNSUPP;
-    }
     std::vector<double> amp(1, 0.0);
     QBH_TRY(upload_ell(vu, amp, &m.wu, &m.tgt_u, &m.val_u));
     QBH_TRY(upload_ell(vd, amp, &m.wd, &m.tgt_d, &m.val_d));
@@ -498,7 +497,12 @@ extern "C" int qbh_mf_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, in
         QBH_HIP(hipMalloc(&m.pk_d, pk.size() * sizeof(uint32_t)));
         QBH_HIP(hipMemcpy(m.pk_d, pk.data(), pk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    return adopt_mf_hubbard(out, m, row_end - row_begin, dim, row_begin, rowptr(row_end) - rowptr(row_begin), opts);
+    return QBH_OK;
+    };
+    int rc = build();
+    if (rc == QBH_OK) rc = adopt_mf_hubbard(out, m, row_end - row_begin, dim, row_begin, rowptr(row_end) - rowptr(row_begin), opts);
+    if (rc != QBH_OK) free_tables();         // the handle takes the tables only when adoption succeeds
+    return rc;
 }
 
 extern "C" int qbh_gen_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bonds, const int32_t *bonds, double J,
@@ -582,14 +586,8 @@ extern "C" int qbh_gen_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bo
         if (d_val) (void)hipFree(d_val);
         return rc != QBH_OK ? rc : (e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP);
     }
-    rc = qbh_csr_create_device(out, nrows, dim, row_begin, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1,
-                               opts);
-    if (rc != QBH_OK) {
-        (void)hipFree(d_ia);
-        (void)hipFree(d_ja);
-        (void)hipFree(d_val);
-    }
-    return rc;
+    // ownership passes with the call: on failure the arrays have already been released
+    return qbh_csr_create_device(out, nrows, dim, row_begin, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, opts);
 }
 
 // ---------------------------------------------- matrix-free Heisenberg operator --
@@ -1133,12 +1131,5 @@ extern "C" int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int
     if (dim_out) *dim_out = dim;
     if (d_code) rc = adopt_coded_csr(out, nloc, dim, r0, nnz, d_ia, d_ja, d_code, d_dict, n_dict, opts);
     else rc = qbh_csr_create_device(out, nloc, dim, r0, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, opts);
-    if (rc != QBH_OK) {
-        (void)hipFree(d_ia);
-        (void)hipFree(d_ja);
-        if (d_val) (void)hipFree(d_val);
-        if (d_code) (void)hipFree(d_code);
-        if (d_dict) (void)hipFree(d_dict);
-    }
-    return rc;
+    return rc;                  // ownership passed with the call: on failure the arrays have already been released
 }

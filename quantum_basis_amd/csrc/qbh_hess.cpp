@@ -230,9 +230,11 @@ int tridiag_lowest(int64_t m, const double *a, const double *b1, int nev, double
             if (std::fabs(d) < pivmin) d = d < 0.0 ? -pivmin : pivmin;
             z = -b1[k - 1] * z / d;
             nrm2 += z * z;
+            if (!(nrm2 < 1e280)) return QBH_ENOCONV;       // same guard as the upward sweep: the caller falls back to QL
             if (k == m - 1) zm = z;
         }
         *zlast0 = std::fabs(zm) / std::sqrt(nrm2);
+        if (!std::isfinite(*zlast0)) return QBH_ENOCONV;
     }
     return QBH_OK;
 }

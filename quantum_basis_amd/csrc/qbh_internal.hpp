@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "qbhip.h"
 
@@ -113,6 +114,9 @@ int build_shard_from_host(int64_t dim, int64_t nnz, int sym, const int64_t *ia, 
                           int64_t r1, hipStream_t s, int64_t **d_ia_out, int32_t **d_ja_out, d2 **d_val_out, int64_t *nnz_out,
                           double *ms_out);
 int balanced_row_cuts(int64_t dim, int64_t nnz, int sym, const int64_t *ia, const int64_t *ja, int nranks, int64_t *cuts);
+
+// native RCCL communicator (qbh_comm.cpp)
+void release_native_comm(qbh_csr *A);
 
 // host tridiagonal solver (qbh_hess.cpp)
 int tridiag_eigen_full(int64_t m, const double *a, const double *b1, double *w, double *z);
@@ -261,6 +265,9 @@ struct qbh_csr {
     // communicator
     bool     has_comm = false;
     qbh_comm comm{};
+    std::vector<int64_t> comm_cuts;          // copy of comm.row_cuts (ragged partition) or empty
+    int64_t  comm_full = 0;                  // elements of d_xfull: nranks * nblk (uniform) or ncols (ragged)
+    struct qbh_native_comm *native = nullptr; // RCCL communicator owned by the handle (qbh_comm_create_rccl)
 
     // creation from host arrays: wall ms of the whole qbh_csr_create call / of the upload + expansion, host bytes read
     double    create_ms = 0.0, create_ms_upload = 0.0;

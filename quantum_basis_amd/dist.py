@@ -23,26 +23,79 @@ def row_partition(ncols, world):
     return nblk, [(min(r * nblk, ncols), min((r + 1) * nblk, ncols)) for r in range(world)]
 
 
-class ShardComm:
-    """Owns the exchange buffers (torch tensors in HBM) and the hook callbacks."""
+def partition_from_cuts(cuts):
+    """(longest block, [(r0, r1)...]) of a ragged partition given by its global row cuts (qbh_balanced_row_cuts)."""
+    cuts = [int(c) for c in cuts]
+    ranges = list(zip(cuts[:-1], cuts[1:]))
+    return max(b - a for a, b in ranges), ranges
 
-    def __init__(self, ncols, rank=None, world=None, device=None, stream=None, group=None):
+
+class NativeComm:
+    """The exchange steps on the library's own RCCL communicator (qbh_comm_create_rccl): no Python in the SpMV loop.
+    torch.distributed is used once, to hand rank 0's ncclUniqueId to the other ranks."""
+
+    def __init__(self, ncols, rank=None, world=None, cuts=None, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group) if (rank is None and dist.is_initialized()) else (rank or 0)
+        self.world = dist.get_world_size(group) if (world is None and dist.is_initialized()) else (world or 1)
+        self.cuts = None if cuts is None else [int(c) for c in cuts]
+        if self.cuts is None:
+            self.nblk, self.ranges = row_partition(ncols, self.world)
+        else:
+            self.nblk, self.ranges = partition_from_cuts(self.cuts)
+
+    def attach(self, mat):
+        import numpy as np
+        uid = np.zeros(128, dtype=np.uint8)
+        if self.rank == 0:
+            check(lib().qbh_rccl_unique_id(uid.ctypes.data_as(C.c_void_p)), "qbh_rccl_unique_id")
+        if self.world > 1:
+            box = [uid.tobytes()]
+            self.dist.broadcast_object_list(box, src=0, group=self.group)
+            uid = np.frombuffer(box[0], dtype=np.uint8).copy()
+        cuts = None
+        if self.cuts is not None:
+            cuts = np.asarray(self.cuts, dtype=np.int64)
+        check(lib().qbh_comm_create_rccl(mat.handle, uid.ctypes.data_as(C.c_void_p), self.rank, self.world,
+                                         None if cuts is None else cuts.ctypes.data_as(C.c_void_p)), "qbh_comm_create_rccl")
+        mat._comm = self
+        return self
+
+    def detach(self, mat):
+        check(lib().qbh_comm_destroy(mat.handle), "qbh_comm_destroy")
+
+
+class ShardComm:
+    """Owns the exchange buffers (torch tensors in HBM) and the hook callbacks.  cuts: global row cuts of a ragged
+    (nnz-balanced) partition, or None for uniform blocks."""
+
+    def __init__(self, ncols, rank=None, world=None, device=None, stream=None, group=None, cuts=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
-        self.nblk, self.ranges = row_partition(ncols, self.world)
+        self.cuts = None if cuts is None else [int(c) for c in cuts]
+        if self.cuts is None:
+            self.nblk, self.ranges = row_partition(ncols, self.world)
+            full = self.nblk * self.world
+        else:
+            self.nblk, self.ranges = partition_from_cuts(self.cuts)
+            full = int(ncols)
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.stream = stream
         f64 = torch.float64
         # complex128 stored as interleaved float64 pairs (NCCL has no complex dtype)
         self.xsend = torch.zeros(2 * self.nblk, dtype=f64, device=self.device)
-        self.xfull = torch.zeros(2 * self.nblk * self.world, dtype=f64, device=self.device)
+        self.xfull = torch.zeros(2 * full, dtype=f64, device=self.device)
         self.scal = torch.zeros(16, dtype=f64, device=self.device)
         # real wire format: when a solve is real only the real parts travel (nblk doubles per rank)
-        self.xfull_r = torch.zeros(self.nblk * self.world, dtype=f64, device=self.device)
+        self.xfull_r = torch.zeros(full, dtype=f64, device=self.device)
+        # ragged partition: equal-sized slots are gathered into a scratch buffer and copied to their global offsets
+        self.scratch = torch.zeros(2 * self.nblk * self.world, dtype=f64, device=self.device) if self.cuts is not None else None
         self.real_wire = True
         self.n_packed = 0
         backend = dist.get_backend(group)
@@ -71,18 +124,29 @@ class ShardComm:
             return self.xfull_r, self.xsend[:self.nblk]
         return self.xfull, self.xsend
 
+    def _place_ragged(self, recv, w):
+        """scratch holds world slots of nblk*w doubles; copy block q to its global offset cuts[q]*w in recv"""
+        slot = self.nblk * w
+        for q, (a, b) in enumerate(self.ranges):
+            if b > a:
+                recv[a * w:b * w].copy_(self.scratch[q * slot:q * slot + (b - a) * w])
+
     def _allgather(self, _ctx, packed):
         try:
             recv, send = self._bufs(packed)
+            w = 1 if packed else 2
             with self._ctx():
+                target = recv if self.cuts is None else self.scratch[:self.nblk * self.world * w]
                 if self.direct:
-                    self.dist.all_gather_into_tensor(recv, send, group=self.group)
+                    self.dist.all_gather_into_tensor(target, send, group=self.group)
                 else:   # gloo with device tensors (single-GPU test rigs): stage through the host
                     self.torch.cuda.current_stream().synchronize()
                     hsend = send.cpu()
                     parts = [self.torch.empty_like(hsend) for _ in range(self.world)]
                     self.dist.all_gather(parts, hsend, group=self.group)
-                    recv.copy_(self.torch.cat(parts))
+                    target.copy_(self.torch.cat(parts))
+                if self.cuts is not None:
+                    self._place_ragged(recv, w)
             return 0
         except Exception:            # never let an exception unwind through the C frames
             self.errors.append(traceback.format_exc())
@@ -92,7 +156,7 @@ class ShardComm:
         """Enqueue the exchange and return: RCCL runs it on its own stream, ordered after what the
         operator's stream has enqueued so far (the copy into xsend)."""
         try:
-            if not self.direct:                      # host-staged test rigs: no real overlap
+            if not self.direct or self.cuts is not None:   # host-staged test rigs / ragged cuts: no real overlap here
                 return self._allgather(_ctx, packed)
             recv, send = self._bufs(packed)
             with self._ctx():
@@ -135,6 +199,16 @@ class ShardComm:
     def attach(self, mat):
         """Install the hooks on a row-shard operator (qbh_csr_set_comm)."""
         r0, r1 = self.ranges[self.rank]
+        # The collectives below are enqueued on torch's current stream; the library launches on the operator's stream.
+        # They must be the SAME stream (include/qbhip.h: "enqueued on / ordered with the operator's stream"), or the
+        # pack -> gather -> SpMV and reduce -> all-reduce sequences race silently.
+        if self.device.type == "cuda":
+            op_stream = mat.info().stream or 0
+            if self.stream is None:
+                self.stream = self.torch.cuda.ExternalStream(op_stream, device=self.device)
+            elif int(self.stream.cuda_stream) != int(op_stream):
+                raise ValueError("ShardComm stream %#x is not the operator's stream %#x: create both with the same stream"
+                                 % (int(self.stream.cuda_stream), int(op_stream)))
         if mat.row_offset != r0 or mat.dim != r1 - r0:
             raise ValueError("operator rows [%d,%d) do not match rank %d's block [%d,%d)"
                              % (mat.row_offset, mat.row_offset + mat.dim, self.rank, r0, r1))
@@ -147,6 +221,10 @@ class ShardComm:
         c.ctx = None
         c.allgather_x = self._ag
         c.allreduce_sum = self._ar
+        if self.cuts is not None:
+            import numpy as np
+            self._cuts_arr = np.asarray(self.cuts, dtype=np.int64)
+            c.row_cuts = self._cuts_arr.ctypes.data
         if self.overlap:
             c.allgather_begin = self._ag_begin
             c.allgather_wait = self._ag_wait

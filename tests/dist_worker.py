@@ -18,7 +18,7 @@ def _init(rank, world, port, backend):
     return dist
 
 
-def cpu_sharded_lanczos(rank, world, port, case_name, steps, out_dir):
+def cpu_sharded_lanczos(rank, world, port, case_name, steps, out_dir, cuts=None):
     """The sharded three-term recurrence with the real exchange hooks (ShardComm, gloo, CPU
     tensors); the shard-local arithmetic is done by the ORACLE here (test double for the HIP
     kernels, which cannot run without a GPU).  Checks the partition, the gather layout and
@@ -31,7 +31,7 @@ def cpu_sharded_lanczos(rank, world, port, case_name, steps, out_dir):
 
     d, ia, ja, val, sym = helpers.case(case_name)
     full = qo.Csr(d, ia, ja, val, sym).expand_full()
-    comm = qdist.ShardComm(d, rank=rank, world=world, device=torch.device("cpu"))
+    comm = qdist.ShardComm(d, rank=rank, world=world, device=torch.device("cpu"), cuts=cuts)
     r0, r1 = comm.ranges[rank]
     n = r1 - r0
     # shard-local CSR (rows r0..r1, global columns)
@@ -177,6 +177,48 @@ def gpu_sharded_repr(rank, world, port, backend, out_dir):
         np.save(os.path.join(out_dir, "vec_%d.npy" % rank), res.eigenvecs)
         if rank == 0:
             np.save(os.path.join(out_dir, "res.npy"), np.array([res.E0, res.steps["E0"], res.steps["V0"], d]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gpu_sharded_hostcsr(rank, world, port, backend, out_dir, native=False, case_name="hubbard_4x2"):
+    """The unchanged host code's CSR (reference order, Hermitian-upper, int64) sharded over the ranks: every rank calls
+    qbh_csr_create_rows on the SAME host arrays with its nnz-balanced (ragged) row block (qbh_balanced_row_cuts) and
+    exchanges through either the native RCCL communicator (qbh_comm_create_rccl) or the gloo hooks with row_cuts."""
+    import torch
+    dist = _init(rank, world, port, backend)
+    torch.cuda.set_device(0)
+    import helpers
+    import quantum_basis_amd as q
+    from quantum_basis_amd import dist as qdist
+
+    d, ia, ja, val, sym = helpers.case(case_name)
+    cuts = q.balanced_row_cuts(d, ia, ja, sym, world)
+    if world > 1:
+        cuts = cuts.copy()
+        cuts[1] += 3                                  # make sure the blocks are not the uniform ones
+    r0, r1 = int(cuts[rank]), int(cuts[rank + 1])
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        opts = q.make_opts(device=0, stream=stream.cuda_stream)
+        A = q.csr_mat(d, ia, ja, val, sym=sym, opts=opts, rows=(r0, r1))
+        assert (A.info().row_offset, A.dim) == (r0, r1 - r0)
+        if native:
+            comm = qdist.NativeComm(d, rank=rank, world=world, cuts=cuts if world > 1 else None).attach(A)
+        else:
+            comm = qdist.ShardComm(d, rank=rank, world=world, device=torch.device("cuda", 0), stream=stream, cuts=cuts).attach(A)
+        res = q.locate_E0_lanczos(A, nev=1, ncv=1, maxit=600)
+        if not native:
+            assert not comm.errors, comm.errors
+        x = q.vec_randomize(A, seed=1)
+        np.save(os.path.join(out_dir, "x_%d.npy" % rank), x)
+        np.save(os.path.join(out_dir, "vec_%d.npy" % rank), res.eigenvecs)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "res.npy"), np.array([res.E0, res.steps["E0"], res.steps["V0"]]))
+            np.save(os.path.join(out_dir, "cuts.npy"), np.asarray(cuts))
+        if native:
+            comm.detach(A)
+            A.destroy()
     dist.barrier()
     dist.destroy_process_group()
 

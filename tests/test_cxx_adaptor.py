@@ -13,10 +13,10 @@ from oracle import qb_oracle as qo
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(tmp):
-    exe = os.path.join(tmp, "adaptor_main")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cxx", "adaptor_main.cpp"), "-o", exe,
+def _build(tmp, name="adaptor_main"):
+    exe = os.path.join(tmp, name)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cxx", name + ".cpp"), "-o", exe,
                            "-L", os.path.join(ROOT, "quantum_basis_amd"), "-lqbhip",
                            "-Wl,-rpath," + os.path.join(ROOT, "quantum_basis_amd"), "-Wl,-rpath,/opt/rocm/lib"])
     return exe
@@ -66,3 +66,29 @@ def test_adaptor_cxx_host_program_matches_oracle():
         assert abs(s_e0 - 82) <= 1 and abs(s_v0 - 83) <= 2
         assert nconv_i == 3 and np.allclose([w0, w1, w2], dense[:3], atol=1e-9)
         assert abs(ov - 1.0) < 1e-8
+
+
+def test_sharded_host_program_compiles_and_links():
+    with tempfile.TemporaryDirectory() as tmp:
+        assert os.path.exists(_build(tmp, "sharded_main"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_ragged", [0, 1])
+def test_sharded_cxx_host_rank_over_native_rccl(force_ragged):
+    """A C++ host process as one rank of the row-sharded run: qbh_balanced_row_cuts -> qbh_csr_create_rows ->
+    qbh_comm_create_rccl (1 rank on this one-GPU box; QBH_COMM_FORCE_RAGGED=1 takes the grouped-broadcast gather of
+    ragged partitions) -> qbh_lanczos_dev / qbh_eigenvec_cg_dev.  No Python anywhere in the SpMV loop."""
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = _build(tmp, "sharded_main")
+        path, O, x = _dump(tmp, "hubbard_4x2")
+        env = dict(os.environ, QBH_COMM_FORCE_RAGGED=str(force_ragged))
+        p = subprocess.run([exe, path, "0", "1", os.path.join(tmp, "uid.bin")], capture_output=True, text=True, env=env)
+        assert p.returncode == 0, p.stdout + p.stderr
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("OK ")]      # RCCL prints a version banner first
+        assert len(line) == 1, p.stdout
+        tok = line[0].split()
+        assert tok[0] == "OK" and tok[1:5] == ["0", "1", "0", "4900"]
+        m, E0, mcg, accu, nrm = int(tok[5]), float(tok[6]), int(tok[7]), float(tok[8]), float(tok[9])
+        assert abs(m - 82) <= 1 and abs(E0 + 14.076058658879278) < 1e-9
+        assert abs(mcg - 83) <= 2 and accu < 2e-12 and abs(nrm - 1.0) < 1e-10

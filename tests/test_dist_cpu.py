@@ -20,6 +20,11 @@ def _free_port():
     return p
 
 
+def test_partition_from_cuts():
+    nblk, ranges = qdist.partition_from_cuts([0, 5, 5, 12, 20])
+    assert nblk == 8 and ranges == [(0, 5), (5, 5), (5, 12), (12, 20)]
+
+
 def test_row_partition_covers_and_pads():
     for ncols, world in [(10, 1), (10, 3), (4900, 2), (4900, 8), (7, 8), (165636900, 8)]:
         nblk, ranges = qdist.row_partition(ncols, world)
@@ -30,14 +35,18 @@ def test_row_partition_covers_and_pads():
         assert sum(b - a for a, b in ranges) == ncols
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_lanczos_with_gloo_hooks(world):
+@pytest.mark.parametrize("world,ragged", [(2, False), (3, False), (2, True), (3, True)])
+def test_sharded_lanczos_with_gloo_hooks(world, ragged):
     import torch.multiprocessing as mp
     import dist_worker
     steps = 12
     name = "kagome_12"
+    cuts = None
+    if ragged:                 # nnz-balanced style partition: blocks of different lengths at their global offsets
+        d = helpers.case(name)[0]
+        cuts = [0, d // 3, d] if world == 2 else [0, d // 5, d // 5 + 7, d]
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(dist_worker.cpu_sharded_lanczos, args=(world, _free_port(), name, steps, tmp), nprocs=world, join=True)
+        mp.spawn(dist_worker.cpu_sharded_lanczos, args=(world, _free_port(), name, steps, tmp, cuts), nprocs=world, join=True)
         ab = np.load(tmp + "/ab.npy")
     d, ia, ja, val, sym = helpers.case(name)
     O = qo.Csr(d, ia, ja, val, sym)

@@ -103,3 +103,28 @@ def test_sharded_matrix_free_row_kernel_with_ragged_shards():
     assert abs(res[0] - ref.E0) <= 1e-10 * abs(ref.E0) and abs(res[1] - ref.E1) < 1e-8
     assert abs(res[2] - ref.steps["E0"]) <= 1
     assert abs(abs(np.vdot(vec, ref.eigenvecs)) - 1.0) < 1e-8
+
+
+@pytest.mark.parametrize("world,backend,native", [(2, "gloo", False), (3, "gloo", False), (1, "gloo", True)])
+def test_host_csr_sharded_with_balanced_cuts(world, backend, native):
+    """qbh_csr_create_rows + ragged row cuts + (world 1) the native RCCL communicator, on the reference-ordered host CSR."""
+    import torch.multiprocessing as mp
+    import dist_worker
+    name = "hubbard_4x2"
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(dist_worker.gpu_sharded_hostcsr, args=(world, _free_port(), backend, tmp, native, name), nprocs=world, join=True)
+        res = np.load(tmp + "/res.npy")
+        cuts = np.load(tmp + "/cuts.npy")
+        x = np.concatenate([np.load(tmp + "/x_%d.npy" % r) for r in range(world)])
+        vec = np.concatenate([np.load(tmp + "/vec_%d.npy" % r) for r in range(world)])
+    d, ia, ja, val, sym = helpers.case(name)
+    assert cuts[0] == 0 and cuts[-1] == d
+    if world > 1:
+        assert len(set(np.diff(cuts))) > 1                       # genuinely ragged
+    O = qo.Csr(d, ia, ja, val, sym)
+    ro = qo.locate_E0_lanczos(O, nev=1, ncv=1, maxit=600)
+    k = helpers.known()["hubbard_4x2"]
+    assert abs(res[0] - k["E0"]) < k["tol"] and abs(res[0] - ro["E0"]) <= 1e-10 * abs(ro["E0"])
+    assert abs(res[1] - ro["m_E0"]) <= 1 and abs(res[2] - ro["m_V0"]) <= 2
+    assert np.allclose(x, qo.vec_randomize(d, 1), rtol=1e-13, atol=0)
+    assert abs(abs(np.vdot(vec, ro["eigenvecs"])) - 1.0) < 1e-8
