@@ -91,7 +91,8 @@ def gpu_sharded_solver(rank, world, port, backend, out_dir, matrix_free=False, s
 
     # 4x3 (924 x 924 configurations) is large enough for the row-staged matrix-free kernel; with 5 ranks the shard
     # boundaries fall inside a row of the N_up x N_dn layout
-    L, ne, bonds, dim = (8, 4, lattices.square(4, 2), 4900) if shape == "4x2" else (12, 6, lattices.square(4, 3), 853776)
+    L, ne, bonds, dim = {"4x2": (8, 4, lattices.square(4, 2), 4900), "4x3": (12, 6, lattices.square(4, 3), 853776),
+                         "4x5n3": (20, 3, lattices.square(4, 5), 1299600)}[shape]
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         opts = q.make_opts(device=0, stream=stream.cuda_stream)
