@@ -240,6 +240,30 @@ int qbh_eigenvec_cg_dev(const qbh_csr *A, int64_t maxit, int64_t *m, double E0, 
 int qbh_iram(const qbh_csr *A, int64_t nev, int64_t ncv, int64_t maxit, const char *order, double tol,
              uint32_t seed, int64_t *nconv, double *eigenvals, qbh_z *eigenvecs_host, qbh_solver_info *info);
 
+/* --------------------------------------------------------- checkpoints --- */
+/* The reference's checkpoint files from the C ABI, host only.
+ * qbh_vec_disk_write / _read: vec_disk_write / vec_disk_read (src/miscellaneous.cc:391-469): int64 n | n * elem_size
+ * bytes | CRC-32 (boost::crc_32_type) of header + payload; read returns 0, or 1 where the reference returns 1.
+ * qbh_crc32(running, data, nbytes): that CRC, start with 0.
+ * qbh_ckpt_lanczos_update / _init: ckpt_lanczos_update / ckpt_lanczos_init for the "val" purposes
+ * (src/ckpt.cc:23-297) on directory `dir` (the reference uses "out_Qckpt"), including the finish / rewind branches of
+ * an interrupted update; *k_out = 0 means "nothing usable, start from scratch".  v / hessenberg: host arrays laid out
+ * as lanczos() expects them.
+ * qbh_lanczos_ckpt: lanczos(0, maxit - 1, ...) with enable_ckpt = true: resumes from `dir` when it holds a usable
+ * step, commits a checkpoint every `every` steps (the two live Lanczos vectors are downloaded for it) and at the end;
+ * max_steps > 0 stops after that many new steps; *converged (may be NULL) = the stop rule fired. */
+uint32_t qbh_crc32(uint32_t crc, const void *data, int64_t nbytes);
+int qbh_vec_disk_write(const char *filename, int64_t n, int elem_size, const void *x);
+int qbh_vec_disk_read(const char *filename, int64_t n, int elem_size, void *x);
+int qbh_ckpt_lanczos_update(const char *dir, int64_t m, int64_t maxit, int64_t dim, int cnt_accuE0, double accuracy,
+                            double theta0_prev, double theta1_prev, const qbh_z *v, const double *hessenberg,
+                            const char *purpose);
+int qbh_ckpt_lanczos_init(const char *dir, int64_t *k_out, int64_t maxit, int64_t dim, int *cnt_accuE0, double *accuracy,
+                          double *theta0_prev, double *theta1_prev, qbh_z *v, double *hessenberg, const char *purpose);
+int qbh_lanczos_ckpt(const qbh_csr *A, int64_t maxit, int64_t *m, qbh_z *v_host, double *hessenberg,
+                     const char *purpose, int64_t every, int64_t max_steps, const char *dir, int *converged,
+                     qbh_solver_info *info);
+
 /* Replaces hess_eigen (src/lanczos.cc:355-390), host only: eigen-decomposition of the
  * m x m tridiagonal held in hessenberg (ld = maxit), sorted by order ("sr","lr","sm","lm");
  * ritz[m], s[m*m] column-major. */

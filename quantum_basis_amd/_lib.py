@@ -83,6 +83,7 @@ EXPORTS = [
     "qbh_vec_randomize",
     "qbh_spmv_dev", "qbh_dotc_dev", "qbh_axpy_norm_dev", "qbh_scal_dev", "qbh_nrm2_dev",
     "qbh_lanczos", "qbh_lanczos_dev", "qbh_lanczos_real_dev", "qbh_vec_randomize_real", "qbh_eigenvec_cg_real_dev", "qbh_eigenvec_cg", "qbh_eigenvec_cg_dev", "qbh_hess_eigen", "qbh_iram",
+    "qbh_crc32", "qbh_vec_disk_write", "qbh_vec_disk_read", "qbh_ckpt_lanczos_update", "qbh_ckpt_lanczos_init", "qbh_lanczos_ckpt",
     "qbh_csr_set_comm", "qbh_rccl_unique_id", "qbh_comm_create_rccl", "qbh_comm_destroy", "qbh_get_stats", "qbh_sync",
     "qbh_gen_hubbard", "qbh_mf_hubbard", "qbh_gen_heisenberg", "qbh_mf_heisenberg", "qbh_gen_heisenberg_repr", "qbh_csr_download",
 ]
@@ -149,6 +150,15 @@ def lib():
     L.qbh_hess_eigen.argtypes = [vp, i64, i64, C.c_char_p, vp, vp]
     L.qbh_iram.argtypes = [vp, i64, i64, i64, C.c_char_p, dbl, C.c_uint32, C.POINTER(i64), vp, vp, C.POINTER(SolverInfo)]
     L.qbh_csr_set_comm.argtypes = [vp, C.POINTER(Comm)]
+    L.qbh_crc32.argtypes = [C.c_uint32, vp, i64]
+    L.qbh_crc32.restype = C.c_uint32
+    L.qbh_vec_disk_write.argtypes = [C.c_char_p, i64, C.c_int, vp]
+    L.qbh_vec_disk_read.argtypes = [C.c_char_p, i64, C.c_int, vp]
+    L.qbh_ckpt_lanczos_update.argtypes = [C.c_char_p, i64, i64, i64, C.c_int, dbl, dbl, dbl, vp, vp, C.c_char_p]
+    L.qbh_ckpt_lanczos_init.argtypes = [C.c_char_p, C.POINTER(i64), i64, i64, C.POINTER(C.c_int), C.POINTER(dbl), C.POINTER(dbl),
+                                        C.POINTER(dbl), vp, vp, C.c_char_p]
+    L.qbh_lanczos_ckpt.argtypes = [vp, i64, C.POINTER(i64), vp, vp, C.c_char_p, i64, i64, C.c_char_p, C.POINTER(C.c_int),
+                                   C.POINTER(SolverInfo)]
     L.qbh_rccl_unique_id.argtypes = [vp]
     L.qbh_comm_create_rccl.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     L.qbh_comm_destroy.argtypes = [vp]

@@ -241,3 +241,69 @@ def lanczos_checkpointed(mat, maxit, purpose="sr_val0", every=50, directory=CKPT
         return m, hess, dv.download(0, 2 * dim), converged
     finally:
         dv.free()
+
+
+# ---- the same protocol inside libqbhip.so (qbh_ckpt.cpp): what a C++ host calls -------------------------------------
+def native_vec_disk_write(filename, x):
+    import ctypes as C
+    from ._lib import check, lib
+    x = np.ascontiguousarray(x)
+    check(lib().qbh_vec_disk_write(filename.encode(), C.c_int64(x.size), int(x.dtype.itemsize), x.ctypes.data_as(C.c_void_p)),
+          "qbh_vec_disk_write")
+    return 0
+
+
+def native_vec_disk_read(filename, n, dtype):
+    import ctypes as C
+    from ._lib import lib
+    out = np.empty(n, dtype=np.dtype(dtype))
+    rc = lib().qbh_vec_disk_read(filename.encode(), C.c_int64(n), int(out.dtype.itemsize), out.ctypes.data_as(C.c_void_p))
+    return out if rc == 0 else None
+
+
+def native_ckpt_update(m, maxit, dim, state, v, hessenberg, purpose, directory=CKPT_DIR):
+    import ctypes as C
+    from ._lib import check, lib
+    v = np.ascontiguousarray(v, dtype=np.complex128)
+    h = np.ascontiguousarray(hessenberg, dtype=np.float64)
+    check(lib().qbh_ckpt_lanczos_update(directory.encode(), m, maxit, dim, int(state["cnt_accuE0"]), float(state["accuracy"]),
+                                        float(state["theta0_prev"]), float(state["theta1_prev"]), v.ctypes.data_as(C.c_void_p),
+                                        h.ctypes.data_as(C.c_void_p), purpose.encode()), "qbh_ckpt_lanczos_update")
+
+
+def native_ckpt_init(maxit, dim, purpose, directory=CKPT_DIR):
+    """qbh_ckpt_lanczos_init: same return convention as ckpt_lanczos_init above (None = start from scratch)."""
+    import ctypes as C
+    from ._lib import check, lib
+    nvec = 2 if "val0" in purpose else 3
+    v = np.zeros(nvec * dim, dtype=np.complex128)
+    h = np.zeros(2 * maxit)
+    k, cnt = C.c_int64(0), C.c_int(0)
+    acc, t0, t1 = C.c_double(0), C.c_double(0), C.c_double(0)
+    check(lib().qbh_ckpt_lanczos_init(directory.encode(), C.byref(k), maxit, dim, C.byref(cnt), C.byref(acc), C.byref(t0), C.byref(t1),
+                                      v.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p), purpose.encode()),
+          "qbh_ckpt_lanczos_init")
+    if k.value == 0:
+        return None
+    return dict(k=k.value, state=dict(cnt_accuE0=cnt.value, accuracy=acc.value, theta0_prev=t0.value, theta1_prev=t1.value),
+                v_pair=v[:2 * dim].copy(), hessenberg=h, phi0=v[2 * dim:].copy() if nvec == 3 else None)
+
+
+def native_lanczos_checkpointed(mat, maxit, purpose="sr_val0", every=50, directory=CKPT_DIR, v0=None, phi0=None, max_steps=0):
+    """qbh_lanczos_ckpt: the whole checkpointed run inside the library.  Returns (m, hessenberg, v_pair, converged)."""
+    import ctypes as C
+    from ._lib import SolverInfo, check, lib
+    from . import engine
+    dim = mat.dim
+    nvec = 3 if "val1" in purpose else 2
+    v = np.zeros(nvec * dim, dtype=np.complex128)
+    v[:dim] = engine.vec_randomize(mat, seed=1) if v0 is None else v0
+    if nvec == 3:
+        v[2 * dim:] = phi0
+    hess = np.zeros(2 * maxit)
+    m, conv = C.c_int64(0), C.c_int(0)
+    info = SolverInfo()
+    os.makedirs(directory, exist_ok=True)
+    check(lib().qbh_lanczos_ckpt(mat.handle, maxit, C.byref(m), v.ctypes.data_as(C.c_void_p), hess.ctypes.data_as(C.c_void_p),
+                                 purpose.encode(), every, max_steps, directory.encode(), C.byref(conv), C.byref(info)), "qbh_lanczos_ckpt")
+    return m.value, hess, v[:2 * dim].copy(), bool(conv.value)

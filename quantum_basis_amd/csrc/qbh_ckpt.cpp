@@ -1,0 +1,328 @@
+// qbh_ckpt.cpp -- the reference's Lanczos checkpoints from the C ABI: file format of vec_disk_write /
+// vec_disk_read (src/miscellaneous.cc:391-469: int64 n | n * sizeof(T) payload | CRC-32 of header + payload) and the
+// two-phase directory protocol of ckpt_lanczos_init / ckpt_lanczos_update for the "val" purposes
+// (src/ckpt.cc:23-297), so that a C++ host can checkpoint and resume the long runs; a run written by either side is
+// readable by the other.  The CRC-32 here is an independent table implementation (reflected polynomial 0xEDB88320,
+// initial value and final xor 0xFFFFFFFF = boost::crc_32_type); the Python mirror uses zlib's, tests compare the two.
+//
+// The device loop is not interrupted per step: qbh_lanczos_ckpt advances the recurrence in chunks through the
+// continuation form lanczos(k, np, ...) (src/qbasis.h:1030) and commits a checkpoint after every chunk.
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "qbh_internal.hpp"
+
+namespace fs = std::filesystem;
+
+namespace {
+
+struct Crc32 {
+    uint32_t table[256];
+    Crc32()
+    {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+            table[i] = c;
+        }
+    }
+    uint32_t update(uint32_t crc, const void *data, size_t n) const       // crc: running value, start with 0
+    {
+        const unsigned char *p = static_cast<const unsigned char *>(data);
+        uint32_t c = crc ^ 0xFFFFFFFFu;
+        for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+        return c ^ 0xFFFFFFFFu;
+    }
+};
+const Crc32 g_crc;
+
+constexpr size_t kChunk = 1024 * 1024;       // 1 MiB pieces, as the reference streams them
+
+std::string P(const std::string &dir, const std::string &name) { return (fs::path(dir) / name).string(); }
+
+bool write_pod(const std::string &file, const void *data, size_t n)
+{
+    std::ofstream f(file, std::ios::out | std::ios::binary);
+    f.write(static_cast<const char *>(data), (std::streamsize)n);
+    return (bool)f;
+}
+
+void rm(const std::string &file)
+{
+    std::error_code ec;
+    fs::remove(fs::path(file), ec);
+}
+
+std::vector<int64_t> lanczos_vec_indices(const std::string &dir)
+{
+    std::vector<int64_t> ks;
+    std::error_code ec;
+    for (auto &e : fs::directory_iterator(dir, ec)) {
+        const std::string n = e.path().filename().string();
+        if (n.size() > 12 && n.compare(0, 8, "lanczosV") == 0 && n.compare(n.size() - 4, 4, ".dat") == 0) {
+            const std::string mid = n.substr(8, n.size() - 12);
+            if (!mid.empty() && mid.find_first_not_of("0123456789") == std::string::npos) ks.push_back(std::stoll(mid));
+        }
+    }
+    std::sort(ks.begin(), ks.end());
+    return ks;
+}
+
+}  // namespace
+
+extern "C" uint32_t qbh_crc32(uint32_t crc, const void *data, int64_t nbytes)
+{
+    return (data && nbytes > 0) ? g_crc.update(crc, data, (size_t)nbytes) : crc;
+}
+
+// src/miscellaneous.cc:439-469
+extern "C" int qbh_vec_disk_write(const char *filename, int64_t n, int elem_size, const void *x)
+{
+    if (!filename || n < 0 || elem_size <= 0 || (n > 0 && !x)) return QBH_EINVAL;
+    std::ofstream f(filename, std::ios::out | std::ios::binary);
+    if (!f) {
+        qbh::set_error("qbh_vec_disk_write: cannot open %s", filename);
+        return QBH_EINVAL;
+    }
+    uint32_t crc = g_crc.update(0, &n, sizeof(int64_t));
+    f.write(reinterpret_cast<const char *>(&n), sizeof(int64_t));
+    const char *p = static_cast<const char *>(x);
+    size_t left = (size_t)n * (size_t)elem_size;
+    while (left > 0) {
+        const size_t c = left < kChunk ? left : kChunk;
+        f.write(p, (std::streamsize)c);
+        crc = g_crc.update(crc, p, c);
+        p += c;
+        left -= c;
+    }
+    f.write(reinterpret_cast<const char *>(&crc), sizeof(uint32_t));
+    f.close();
+    return f ? QBH_OK : QBH_EINVAL;
+}
+
+// src/miscellaneous.cc:391-436: 0 on success, 1 where the reference returns 1 (missing file, wrong size, wrong n, bad CRC)
+extern "C" int qbh_vec_disk_read(const char *filename, int64_t n, int elem_size, void *x)
+{
+    if (!filename || n < 0 || elem_size <= 0 || (n > 0 && !x)) return QBH_EINVAL;
+    std::error_code ec;
+    if (!fs::exists(fs::path(filename), ec)) return 1;
+    const uint64_t ideal = sizeof(int64_t) + (uint64_t)n * (uint64_t)elem_size + sizeof(uint32_t);
+    if (fs::file_size(fs::path(filename), ec) != ideal) return 1;
+    std::ifstream f(filename, std::ios::in | std::ios::binary);
+    int64_t n_check = 0;
+    f.read(reinterpret_cast<char *>(&n_check), sizeof(int64_t));
+    if (!f || n_check != n) return 1;
+    uint32_t crc = g_crc.update(0, &n, sizeof(int64_t));
+    char *p = static_cast<char *>(x);
+    size_t left = (size_t)n * (size_t)elem_size;
+    while (left > 0) {
+        const size_t c = left < kChunk ? left : kChunk;
+        f.read(p, (std::streamsize)c);
+        if (!f) return 1;
+        crc = g_crc.update(crc, p, c);
+        p += c;
+        left -= c;
+    }
+    uint32_t stored = 0;
+    f.read(reinterpret_cast<char *>(&stored), sizeof(uint32_t));
+    return (f && stored == crc) ? 0 : 1;
+}
+
+// ckpt_lanczos_update, "val" purposes (src/ckpt.cc:178-297).  v: host vectors in the reference's slots (v[j] at
+// (j%2)*dim, phi0 at 2*dim for sr_val1).
+extern "C" int qbh_ckpt_lanczos_update(const char *dir, int64_t m, int64_t maxit, int64_t dim, int cnt_accuE0, double accuracy,
+                                       double theta0_prev, double theta1_prev, const qbh_z *v, const double *hessenberg,
+                                       const char *purpose)
+{
+    if (!dir || !v || !hessenberg || !purpose || m < 0 || m >= maxit || dim <= 0) return QBH_EINVAL;
+    const std::string d(dir), pur(purpose);
+    if (pur.find("val") == std::string::npos) {
+        qbh::set_error("qbh_ckpt_lanczos_update: only the \"val\" purposes are checkpointed (got %s)", purpose);
+        return QBH_EUNSUPP;
+    }
+    std::error_code ec;
+    if (fs::exists(d, ec) && !fs::is_directory(d, ec)) fs::remove_all(d, ec);
+    fs::create_directories(d, ec);
+    rm(P(d, "lczs_updt.Qckpt1"));
+    rm(P(d, "lczs_updt.Qckpt2"));
+    if (!write_pod(P(d, "lczs_updt.Qckpt1"), &m, sizeof(int64_t))) return QBH_EINVAL;
+    QBH_TRY(qbh_vec_disk_write(P(d, "HessenbergA.dat.new").c_str(), m, 8, hessenberg + maxit));
+    QBH_TRY(qbh_vec_disk_write(P(d, "HessenbergB.dat.new").c_str(), m + 1, 8, hessenberg));
+    // The reference skips V(m-1) when a file of that name exists (it wrote it one step earlier).  Here updates are many
+    // steps apart, so an existing V(m-1) can only be a stale file of another run: always rewritten.
+    if (m > 0) QBH_TRY(qbh_vec_disk_write(P(d, "lanczosV" + std::to_string(m - 1) + ".dat").c_str(), dim, 16, v + ((m - 1) % 2) * dim));
+    QBH_TRY(qbh_vec_disk_write(P(d, "lanczosV" + std::to_string(m) + ".dat").c_str(), dim, 16, v + (m % 2) * dim));
+    const bool val0 = pur.find("val0") != std::string::npos;
+    if (!val0) QBH_TRY(qbh_vec_disk_write(P(d, "lanczosY0.dat.new").c_str(), dim, 16, v + 2 * dim));
+    {
+        char buf[28];
+        std::memcpy(buf, &cnt_accuE0, 4);
+        std::memcpy(buf + 4, &accuracy, 8);
+        std::memcpy(buf + 12, &theta0_prev, 8);
+        std::memcpy(buf + 20, &theta1_prev, 8);
+        if (!write_pod(P(d, "lczs_mlns.dat.new"), buf, sizeof(buf))) return QBH_EINVAL;
+    }
+    if (!write_pod(P(d, "lczs_updt.Qckpt2"), &m, sizeof(int64_t))) return QBH_EINVAL;   // before / after this point: old / new data
+    rm(P(d, "HessenbergA.dat"));
+    rm(P(d, "HessenbergB.dat"));
+    for (int64_t k : lanczos_vec_indices(d))
+        if (k < m - 1 || k > m) rm(P(d, "lanczosV" + std::to_string(k) + ".dat"));      // older steps, and stale higher ones
+    rm(P(d, "lanczosY0.dat"));
+    rm(P(d, "lanczosY1.dat"));
+    rm(P(d, "lczs_mlns.dat"));
+    fs::rename(P(d, "HessenbergA.dat.new"), P(d, "HessenbergA.dat"), ec);
+    fs::rename(P(d, "HessenbergB.dat.new"), P(d, "HessenbergB.dat"), ec);
+    if (!val0) fs::rename(P(d, "lanczosY0.dat.new"), P(d, "lanczosY0.dat"), ec);
+    fs::rename(P(d, "lczs_mlns.dat.new"), P(d, "lczs_mlns.dat"), ec);
+    rm(P(d, "lczs_updt.Qckpt1"));
+    rm(P(d, "lczs_updt.Qckpt2"));
+    return QBH_OK;
+}
+
+// ckpt_lanczos_init, "val" purposes (src/ckpt.cc:23-176): finishes or rewinds an interrupted update, finds the last
+// step on disk and loads it.  *k_out = 0 when there is nothing usable (start from scratch); otherwise v, hessenberg
+// and the bookkeeping scalars hold step *k_out.
+extern "C" int qbh_ckpt_lanczos_init(const char *dir, int64_t *k_out, int64_t maxit, int64_t dim, int *cnt_accuE0, double *accuracy,
+                                     double *theta0_prev, double *theta1_prev, qbh_z *v, double *hessenberg, const char *purpose)
+{
+    if (!dir || !k_out || !cnt_accuE0 || !accuracy || !theta0_prev || !theta1_prev || !v || !hessenberg || !purpose) return QBH_EINVAL;
+    *k_out = 0;
+    const std::string d(dir), pur(purpose);
+    std::error_code ec;
+    if (!fs::is_directory(d, ec)) return QBH_OK;
+    const std::string mk1 = P(d, "lczs_updt.Qckpt1"), mk2 = P(d, "lczs_updt.Qckpt2");
+    const char *renames[] = {"HessenbergA.dat", "HessenbergB.dat", "lanczosY0.dat", "lanczosY1.dat", "lczs_mlns.dat"};
+    if (fs::exists(mk1, ec) && fs::file_size(mk1, ec) == sizeof(int64_t)) {
+        int64_t k = 0;
+        {
+            std::ifstream f(mk1, std::ios::in | std::ios::binary);
+            f.read(reinterpret_cast<char *>(&k), sizeof(int64_t));
+        }
+        if (fs::exists(mk2, ec)) {                               // src/ckpt.cc:50-79: new data complete, finish the clean-up
+            for (const char *n : renames)
+                if (fs::exists(P(d, std::string(n) + ".new"), ec)) {
+                    rm(P(d, n));
+                    fs::rename(P(d, std::string(n) + ".new"), P(d, n), ec);
+                }
+            for (int64_t kk : lanczos_vec_indices(d))
+                if (kk < k - 1) rm(P(d, "lanczosV" + std::to_string(kk) + ".dat"));
+            rm(mk1);
+            rm(mk2);
+        } else {                                                 // src/ckpt.cc:80-97: rewind one step
+            k -= 1;
+            for (const char *n : renames) rm(P(d, std::string(n) + ".new"));
+            for (int64_t kk : lanczos_vec_indices(d))
+                if (kk > k) rm(P(d, "lanczosV" + std::to_string(kk) + ".dat"));
+            rm(mk1);
+        }
+    } else {
+        rm(mk1);
+        rm(mk2);
+    }
+    const std::vector<int64_t> ks = lanczos_vec_indices(d);
+    if (ks.empty()) return QBH_OK;
+    int64_t m = ks[0];                                           // src/ckpt.cc:101-111
+    for (size_t i = 1; i < ks.size() && ks[i] == m + 1; ++i) m = ks[i];
+    if (m == 0 || m >= maxit || std::find(ks.begin(), ks.end(), m - 1) == ks.end()) return QBH_OK;
+    // where the reference asserts on unreadable files, nothing is loaded and the caller starts from scratch
+    std::vector<double> a((size_t)m), b((size_t)m + 1);
+    std::vector<qbh_z> v1((size_t)dim), v2((size_t)dim);
+    if (qbh_vec_disk_read(P(d, "HessenbergA.dat").c_str(), m, 8, a.data()) != 0) return QBH_OK;
+    if (qbh_vec_disk_read(P(d, "HessenbergB.dat").c_str(), m + 1, 8, b.data()) != 0) return QBH_OK;
+    if (qbh_vec_disk_read(P(d, "lanczosV" + std::to_string(m - 1) + ".dat").c_str(), dim, 16, v1.data()) != 0) return QBH_OK;
+    if (qbh_vec_disk_read(P(d, "lanczosV" + std::to_string(m) + ".dat").c_str(), dim, 16, v2.data()) != 0) return QBH_OK;
+    std::vector<qbh_z> y0;
+    if (pur.find("val0") == std::string::npos) {
+        y0.resize((size_t)dim);
+        if (qbh_vec_disk_read(P(d, "lanczosY0.dat").c_str(), dim, 16, y0.data()) != 0) return QBH_OK;
+    }
+    char buf[28];
+    {
+        std::ifstream f(P(d, "lczs_mlns.dat"), std::ios::in | std::ios::binary);
+        f.read(buf, sizeof(buf));
+        if (!f) return QBH_OK;
+    }
+    std::memcpy(cnt_accuE0, buf, 4);
+    std::memcpy(accuracy, buf + 4, 8);
+    std::memcpy(theta0_prev, buf + 12, 8);
+    std::memcpy(theta1_prev, buf + 20, 8);
+    std::memcpy(hessenberg + maxit, a.data(), (size_t)m * 8);
+    std::memcpy(hessenberg, b.data(), ((size_t)m + 1) * 8);
+    std::memcpy(v + ((m - 1) % 2) * dim, v1.data(), (size_t)dim * 16);
+    std::memcpy(v + (m % 2) * dim, v2.data(), (size_t)dim * 16);
+    if (!y0.empty()) std::memcpy(v + 2 * dim, y0.data(), (size_t)dim * 16);
+    *k_out = m;
+    return QBH_OK;
+}
+
+// lanczos(0, maxit - 1, ...) of the reference with enable_ckpt = true: resume from `dir` if it holds a usable step,
+// otherwise start from v (v[0] normalised, phi0 at 2*dim for sr_val1); a checkpoint is committed every `every` steps
+// and at the end.  max_steps > 0 stops after that many new steps (an "interrupted" run for tests and time-sliced
+// jobs).  *converged reports whether the stop rule fired.  v and hessenberg are host arrays as in qbh_lanczos.
+extern "C" int qbh_lanczos_ckpt(const qbh_csr *A, int64_t maxit, int64_t *m_out, qbh_z *v_host, double *hessenberg,
+                                const char *purpose, int64_t every, int64_t max_steps, const char *dir, int *converged,
+                                qbh_solver_info *info_out)
+{
+    if (!A || !m_out || !v_host || !hessenberg || !purpose || !dir || maxit < 3 || every < 1) return QBH_EINVAL;
+    const std::string pur(purpose);
+    const int nvec = pur.find("val1") != std::string::npos ? 3 : 2;
+    qbh_csr_info ci;
+    QBH_TRY(qbh_csr_get_info(A, &ci));
+    const int64_t n = ci.nrows;
+    int cnt = 0;
+    double accuracy = 0.0, t0 = 0.0, t1 = 0.0;
+    int64_t k = 0;
+    QBH_TRY(qbh_ckpt_lanczos_init(dir, &k, maxit, n, &cnt, &accuracy, &t0, &t1, v_host, hessenberg, purpose));
+    if (k == 0) {                                  // from scratch: nothing of an earlier run may survive
+        std::error_code ec;
+        for (auto &e : fs::directory_iterator(dir, ec)) {
+            const std::string nm = e.path().filename().string();
+            if (nm.compare(0, 8, "lanczosV") == 0 || nm.compare(0, 8, "lanczosY") == 0 || nm.compare(0, 10, "Hessenberg") == 0 ||
+                nm.compare(0, 5, "lczs_") == 0)
+                rm(e.path().string());
+        }
+    }
+    qbh_z *d_v = nullptr;
+    QBH_TRY(qbh_vec_alloc(&d_v, (int64_t)nvec * n));
+    int rc = qbh_vec_upload(A, d_v, v_host, (int64_t)nvec * n);
+    qbh_solver_info info{};
+    info.resume = k > 0 ? 1 : 0;
+    info.cnt_accuE0 = cnt;
+    info.accuracy = accuracy;
+    info.theta0_prev = t0;
+    info.theta1_prev = t1;
+    int64_t m = k, done = 0;
+    bool conv = false;
+    while (rc == QBH_OK && m < maxit - 1) {
+        int64_t np = std::min<int64_t>(every, maxit - 1 - m);
+        if (max_steps > 0) np = std::min<int64_t>(np, max_steps - done);
+        if (np <= 0) break;
+        int64_t m_new = m;
+        rc = qbh_lanczos_dev(A, m, np, maxit, &m_new, d_v, hessenberg, purpose, &info);
+        if (rc != QBH_OK) break;
+        info.resume = 1;                            // the bookkeeping returned in info seeds the next chunk
+        done += m_new - m;
+        const bool early = m_new < m + np;
+        m = m_new;
+        rc = qbh_vec_download(A, v_host, d_v, (int64_t)nvec * n);
+        if (rc != QBH_OK) break;
+        rc = qbh_ckpt_lanczos_update(dir, m, maxit, n, (int)info.cnt_accuE0, info.accuracy, info.theta0_prev, info.theta1_prev, v_host,
+                                     hessenberg, purpose);
+        if (early || (info.cnt_accuE0 > 15 && info.accuracy < QBH_LANCZOS_PRECISION)) {
+            conv = true;
+            break;
+        }
+    }
+    (void)qbh_vec_free(d_v);
+    if (rc != QBH_OK) return rc;
+    *m_out = m;
+    if (converged) *converged = conv ? 1 : 0;
+    if (info_out) *info_out = info;
+    return QBH_OK;
+}

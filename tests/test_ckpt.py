@@ -119,6 +119,78 @@ def test_stale_files_of_an_earlier_run_never_mix_with_a_new_one(tmp_path):
     assert ck["k"] == 10 and np.array_equal(ck["v_pair"], v2)
 
 
+def test_native_checkpoint_code_is_file_compatible_with_the_python_mirror(tmp_path):
+    """qbh_ckpt.cpp (own table CRC-32) against ckpt.py (zlib): each side reads what the other wrote; the CRC matches the
+    published check value of CRC-32/ISO-HDLC ("123456789" -> 0xCBF43926), which neither implementation was derived from."""
+    import ctypes as C
+    from quantum_basis_amd import _lib
+    L = _lib.lib()
+    assert L.qbh_crc32(0, b"123456789", 9) == 0xCBF43926 == zlib.crc32(b"123456789")
+    assert L.qbh_crc32(L.qbh_crc32(0, b"1234", 4), b"56789", 5) == 0xCBF43926          # running form
+    x = (np.arange(70001) * 0.5 + 2j * np.arange(70001)).astype(np.complex128)
+    f1, f2 = str(tmp_path / "a.dat"), str(tmp_path / "b.dat")
+    ckpt.native_vec_disk_write(f1, x)
+    ckpt.vec_disk_write(f2, x)
+    assert open(f1, "rb").read() == open(f2, "rb").read()
+    assert np.array_equal(ckpt.vec_disk_read(f1, x.size, np.complex128), x)
+    assert np.array_equal(ckpt.native_vec_disk_read(f2, x.size, np.complex128), x)
+    assert ckpt.native_vec_disk_read(f2, x.size - 1, np.complex128) is None
+    bad = bytearray(open(f2, "rb").read())
+    bad[1000] ^= 1
+    open(f2, "wb").write(bytes(bad))
+    assert ckpt.native_vec_disk_read(f2, x.size, np.complex128) is None
+    # directory protocol: written natively, read by the Python mirror, and the other way round
+    dim, maxit = 30, 40
+    h7, v7, s7 = _snapshot(None, dim, maxit, 2, 7)
+    d1, d2 = str(tmp_path / "n"), str(tmp_path / "p")
+    ckpt.native_ckpt_update(7, maxit, dim, s7, v7, h7, "sr_val0", directory=d1)
+    ckpt.ckpt_lanczos_update(7, maxit, dim, s7, v7, h7, "sr_val0", directory=d2)
+    assert sorted(os.listdir(d1)) == sorted(os.listdir(d2)) == ["HessenbergA.dat", "HessenbergB.dat", "lanczosV6.dat", "lanczosV7.dat", "lczs_mlns.dat"]
+    for n in os.listdir(d1):
+        assert open(os.path.join(d1, n), "rb").read() == open(os.path.join(d2, n), "rb").read(), n
+    a, b = ckpt.ckpt_lanczos_init(maxit, dim, "sr_val0", d1), ckpt.native_ckpt_init(maxit, dim, "sr_val0", d2)
+    assert a["k"] == b["k"] == 7 and a["state"] == b["state"] == s7
+    assert np.array_equal(a["v_pair"], v7) and np.array_equal(b["v_pair"], v7)
+    assert np.array_equal(a["hessenberg"][:8], b["hessenberg"][:8]) and np.array_equal(a["hessenberg"][maxit:maxit + 7], b["hessenberg"][maxit:maxit + 7])
+    # the native init finishes / rewinds a torn update exactly like the Python mirror (src/ckpt.cc:40-100)
+    h8, v8, s8 = _snapshot(None, dim, maxit, 3, 8)
+    open(os.path.join(d2, "lczs_updt.Qckpt1"), "wb").write(struct.pack("<q", 8))
+    ckpt.vec_disk_write(os.path.join(d2, "HessenbergA.dat.new"), h8[maxit:maxit + 8])
+    ckpt.vec_disk_write(os.path.join(d2, "lanczosV8.dat"), v8[:dim])
+    b = ckpt.native_ckpt_init(maxit, dim, "sr_val0", d2)                      # no second marker: rewound to step 7
+    assert b["k"] == 7 and np.array_equal(b["v_pair"], v7)
+    assert sorted(os.listdir(d2)) == ["HessenbergA.dat", "HessenbergB.dat", "lanczosV6.dat", "lanczosV7.dat", "lczs_mlns.dat"]
+    assert ckpt.native_ckpt_init(maxit, dim, "sr_val0", str(tmp_path / "missing")) is None
+
+
+@pytest.mark.gpu
+def test_native_checkpointed_run_interrupted_and_resumed(tmp_path):
+    """qbh_lanczos_ckpt (C ABI): 30 steps, "crash", resume from the files in a new operator -- and a run started by the
+    Python mirror is continued by the native code."""
+    import helpers
+    import quantum_basis_amd as q
+    d, ia, ja, val, sym = helpers.case("hubbard_4x2")
+    g = helpers.probe()["hubbard_4x2"]
+    maxit = 1000
+    for starter in ("native", "python"):
+        ckdir = str(tmp_path / ("ck_" + starter))
+        A = q.csr_mat(d, ia, ja, val, sym)
+        if starter == "native":
+            m1, hess1, _, conv1 = ckpt.native_lanczos_checkpointed(A, maxit, "sr_val0", every=10, directory=ckdir, max_steps=30)
+        else:
+            m1, hess1, _, conv1 = ckpt.lanczos_checkpointed(A, maxit, "sr_val0", every=10, directory=ckdir, max_steps=30)
+        assert m1 == 30 and not conv1
+        A.destroy()
+        B = q.csr_mat(d, ia, ja, val, sym)
+        m2, hess2, v_pair, conv2 = ckpt.native_lanczos_checkpointed(B, maxit, "sr_val0", every=25, directory=ckdir)
+        assert conv2 and abs(m2 - g["lanczos_m"]) <= 1
+        ritz, _ = q.hess_eigen(hess2, maxit, m2, "sr")
+        assert abs(ritz[0] - g["E0"]) <= 1e-10 * abs(g["E0"])
+        assert np.array_equal(hess2[maxit:maxit + 30], hess1[maxit:maxit + 30])       # the first 30 steps came from disk
+        assert abs(np.linalg.norm(v_pair[:d]) - 1.0) < 1e-12
+        B.destroy()
+
+
 @pytest.mark.gpu
 def test_interrupted_run_resumes_to_the_same_answer(tmp_path):
     import helpers
