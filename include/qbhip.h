@@ -240,6 +240,20 @@ int qbh_eigenvec_cg_dev(const qbh_csr *A, int64_t maxit, int64_t *m, double E0, 
 int qbh_iram(const qbh_csr *A, int64_t nev, int64_t ncv, int64_t maxit, const char *order, double tol,
              uint32_t seed, int64_t *nconv, double *eigenvals, qbh_z *eigenvecs_host, qbh_solver_info *info);
 
+/* ---------------------------------------------- operator x vector (8f-3) --- */
+/* Counterpart of model<T>::moprXvec_full (src/model.cc:1468-1538), vec_new = A |vec_old>, on device vectors in the
+ * basis order of the device generators; the step that feeds lanczos(..., "dnmcs") in measure_full_dynamic
+ * (src/model.cc:1696-1712).  Every target row gathers its contributions (no atomics, deterministic).
+ * qbh_mopr_spin_dev: spin-1/2 sector with n_dn_old down spins (basis of qbh_gen_heisenberg).  kind 0: S^z_q = sum_s
+ * coef[s] S^z_s (same sector); kind -1: S^-_q = sum_s coef[s] S^-_s (result lives in the sector with n_dn_old + 1 down
+ * spins); kind +1: S^+_q (n_dn_old - 1).  d_vec_new must hold C(n_sites, n_dn_old - kind) elements.
+ * qbh_mopr_onebody_dev: two-species fermions (basis of qbh_gen_hubbard), A = sum_k w[k] c+_{a[k], spin[k]} c_{b[k],
+ * spin[k]} (spin 0 = up, 1 = down; a == b is the density n_{a,spin}); same sector. */
+int qbh_mopr_spin_dev(int n_sites, int n_dn_old, int kind, const qbh_z *coef /* [n_sites] */, const qbh_z *d_vec_old,
+                      qbh_z *d_vec_new, void *stream);
+int qbh_mopr_onebody_dev(int n_sites, int n_up, int n_dn, int n_terms, const int32_t *a, const int32_t *b, const int32_t *spin,
+                         const qbh_z *w, const qbh_z *d_vec_old, qbh_z *d_vec_new, void *stream);
+
 /* --------------------------------------------------------- checkpoints --- */
 /* The reference's checkpoint files from the C ABI, host only.
  * qbh_vec_disk_write / _read: vec_disk_write / vec_disk_read (src/miscellaneous.cc:391-469): int64 n | n * elem_size

@@ -501,6 +501,46 @@ def measure_full_dynamic(mat, vec_new, maxit):
     return m, norm, hessenberg
 
 
+def moprXvec_spin(n_sites, n_dn_old, kind, coef, d_vec_old, d_vec_new, stream=None):
+    """moprXvec_full (src/model.cc:1468-1538) on the device for S^z_q (kind 0), S^-_q (kind -1) and S^+_q (kind +1) on a
+    spin-1/2 sector with n_dn_old down spins; d_vec_old / d_vec_new are device addresses (DeviceVec.at(...))."""
+    c = np.ascontiguousarray(coef, dtype=np.complex128)
+    assert c.size == n_sites
+    check(lib().qbh_mopr_spin_dev(n_sites, n_dn_old, kind, _p(c), d_vec_old, d_vec_new, stream), "qbh_mopr_spin_dev")
+
+
+def moprXvec_onebody(n_sites, n_up, n_dn, terms, d_vec_old, d_vec_new, stream=None):
+    """A = sum_k w_k c+_{a_k, s_k} c_{b_k, s_k} applied on the device in the basis of qbh_gen_hubbard;
+    terms: iterable of (a, b, spin, w)."""
+    terms = list(terms)
+    a = np.array([t[0] for t in terms], dtype=np.int32)
+    b = np.array([t[1] for t in terms], dtype=np.int32)
+    sp = np.array([t[2] for t in terms], dtype=np.int32)
+    w = np.array([t[3] for t in terms], dtype=np.complex128)
+    check(lib().qbh_mopr_onebody_dev(n_sites, n_up, n_dn, len(terms), _p(a), _p(b), _p(sp), _p(w), d_vec_old, d_vec_new, stream),
+          "qbh_mopr_onebody_dev")
+
+
+def measure_full_dynamic_dev(mat_new, apply_mopr, maxit):
+    """model<T>::measure_full_dynamic (src/model.cc:1696-1712) end to end in HBM: apply_mopr(d_vec_new) writes
+    A_q |phi> into the first slot of a two-slot device vector of the target sector (moprXvec_spin / moprXvec_onebody on
+    the resident ground state), then norm, normalisation and the "dnmcs" Lanczos run on mat_new.
+    Returns (m, norm, hessenberg)."""
+    dim = mat_new.dim
+    v = mat_new.vec(2)
+    try:
+        apply_mopr(v.at(0))
+        norm = mat_new.nrm2(v.at(0))                               # sqrt(<phi| Aq^+ Aq |phi>)
+        hessenberg = np.zeros(2 * maxit)
+        if abs(norm) < lanczos_precision:
+            return 0, norm, hessenberg
+        mat_new.scal(1.0 / norm, v.at(0))
+        m = lanczos(0, maxit - 1, maxit, dim, mat_new, None, hessenberg, "dnmcs", device_v=v)
+        return m, norm, hessenberg
+    finally:
+        v.free()
+
+
 def write_lanczos_log(rows, filename):
     """Append the rows returned by lanczos() in the format of log_Lanczos_srval (src/lanczos.cc:102-128)."""
     head1 = "".join("%20s" % s for s in ("#(1)", "(2)", "(3)", "(4)", "(5)", "(6)", "(7)", "(8)", "(9)", "(10)"))
