@@ -379,6 +379,7 @@ extern "C" int qbh_gen_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, i
     free_pool(pool);
     if (e != hipSuccess) {
         set_error("qbh_gen_hubbard: %s", hipGetErrorString(e));
+        (void)hipGetLastError();      // reported: not left sticky for the next call
         if (d_ia) (void)hipFree(d_ia);
         if (d_ja) (void)hipFree(d_ja);
         if (d_val) (void)hipFree(d_val);
@@ -581,6 +582,7 @@ extern "C" int qbh_gen_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bo
     free_pool(pool);
     if (e != hipSuccess || rc != QBH_OK) {
         if (e != hipSuccess) set_error("qbh_gen_heisenberg: %s", hipGetErrorString(e));
+        (void)hipGetLastError();      // reported: not left sticky for the next call
         if (d_ia) (void)hipFree(d_ia);
         if (d_ja) (void)hipFree(d_ja);
         if (d_val) (void)hipFree(d_val);

@@ -27,6 +27,7 @@ void set_error(const char *fmt, ...);
         if (_e != hipSuccess) {                                                            \
             qbh::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, \
                            __LINE__);                                                      \
+            (void)hipGetLastError(); /* the error is reported here: do not leave it sticky for the next call */ \
             return (_e == hipErrorOutOfMemory) ? QBH_ENOMEM : QBH_EHIP;                    \
         }                                                                                  \
     } while (0)
