@@ -253,6 +253,13 @@ int qbh_mopr_spin_dev(int n_sites, int n_dn_old, int kind, const qbh_z *coef /* 
                       qbh_z *d_vec_new, void *stream);
 int qbh_mopr_onebody_dev(int n_sites, int n_up, int n_dn, int n_terms, const int32_t *a, const int32_t *b, const int32_t *spin,
                          const qbh_z *w, const qbh_z *d_vec_old, qbh_z *d_vec_new, void *stream);
+/* Counterpart of model<T>::moprXvec_repr (src/model.cc:1715-1846) for S^z_q = sum_s coef[s] S^z_s between two momentum
+ * sectors of the same n_dn (basis of qbh_gen_heisenberg_repr: all representatives, ascending; perms as there).  coef must
+ * transform like a character, coef[g(s)] = eta(g) coef[s] (e.g. exp(i q.r_s)/sqrt(N)), and chars_new are the characters
+ * of the TARGET momentum chi_new = chi_old * eta.  vec_new[a] = (sum_s coef[s] s^z_s(a)) * vec_old[a] for representatives
+ * whose norm does not vanish at the target momentum, 0 for the others.  *dim_out (may be NULL) = number of representatives. */
+int qbh_mopr_sz_repr_dev(int n_sites, int n_dn, int n_trans, const int32_t *perms, const double *chars_new,
+                         const qbh_z *coef, const qbh_z *d_vec_old, qbh_z *d_vec_new, int64_t *dim_out);
 
 /* --------------------------------------------------------- checkpoints --- */
 /* The reference's checkpoint files from the C ABI, host only.

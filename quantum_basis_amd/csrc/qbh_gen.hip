@@ -786,6 +786,44 @@ __global__ __launch_bounds__(256) void k_repr_compact(const ReprDev *Rp, int64_t
     }
 }
 
+// moprXvec_repr for S^z_q (src/model.cc:1715-1846, diagonal branch :1756-1759): in the basis of ALL representatives the
+// operator sum_s c_s S^z_s with c_{g(s)} = eta(g) c_s maps |a, k> to z_a |a, k * eta>, z_a = sum_s c_s s^z_s(a) evaluated on
+// the representative itself (the stabiliser, hence the normalisation, does not depend on the momentum); representatives
+// whose norm vanishes at the NEW momentum get 0.  code[] comes from k_repr_flag run with the new characters.
+struct SpinCoefR { double re[64], im[64]; };
+__global__ __launch_bounds__(256) void k_repr_apply_sz(const ReprDev *Rp, int64_t nstates, const uint8_t *code, const int64_t *pos,
+                                                       SpinCoefR cf, const d2 *x_old, d2 *y_new)
+{
+    const ReprDev &R = *Rp;
+    constexpr int RUN = 32;
+    const int64_t nruns = (nstates + RUN - 1) / RUN;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t run = (int64_t)blockIdx.x * 256 + threadIdx.x; run < nruns; run += stride) {
+        const int64_t r0 = run * RUN, r1 = (r0 + RUN < nstates) ? r0 + RUN : nstates;
+        uint64_t s = heis_unrank(R.h, (uint64_t)r0);
+        for (int64_t r = r0; r < r1; ++r) {
+            const uint8_t c = code[r];
+            if (c) {
+                const int64_t p = pos[r];
+                d2 out = {0.0, 0.0};
+                if (!(c & 0x80)) {
+                    double zr = 0.0, zi = 0.0;
+                    for (int site = 0; site < R.h.n_sites; ++site) {
+                        const double sz = ((s >> site) & 1ULL) ? -0.5 : 0.5;
+                        zr += sz * cf.re[site];
+                        zi += sz * cf.im[site];
+                    }
+                    const d2 x = x_old[p];
+                    out = d2{zr * x.x - zi * x.y, zr * x.y + zi * x.x};
+                }
+                y_new[p] = out;
+            }
+            const uint64_t t2 = s | (s - 1ULL);
+            s = (t2 + 1ULL) | (((~t2 & (t2 + 1ULL)) - 1ULL) >> (__ffsll((long long)s)));
+        }
+    }
+}
+
 // one row of the sector Hamiltonian into (cols, vals), columns ascending, duplicates merged; returns its length
 __device__ int repr_row(const ReprDev &R, const uint64_t *tab, const uint64_t *reps, const uint8_t *info, int64_t dim, int64_t i,
                         int32_t *cols, d2 *vals)
@@ -1134,4 +1172,98 @@ extern "C" int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int
     if (d_code) rc = adopt_coded_csr(out, nloc, dim, r0, nnz, d_ia, d_ja, d_code, d_dict, n_dict, opts);
     else rc = qbh_csr_create_device(out, nloc, dim, r0, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, opts);
     return rc;                  // ownership passed with the call: on failure the arrays have already been released
+}
+
+
+// S^z_q on a translation-symmetric sector (see k_repr_apply_sz).  perms / chars_new as in qbh_gen_heisenberg_repr, with
+// the characters of the TARGET momentum; the vectors are indexed like the rows of the sector operators (all
+// representatives of the n_dn sector, ascending).
+extern "C" int qbh_mopr_sz_repr_dev(int n_sites, int n_dn, int n_trans, const int32_t *perms, const double *chars_new,
+                                    const qbh_z *coef, const qbh_z *d_vec_old, qbh_z *d_vec_new, int64_t *dim_out)
+{
+    using namespace qbh;
+    if (!perms || !chars_new || !coef || !d_vec_old || !d_vec_new || n_sites <= 0 || n_sites > 62 || n_dn < 0 || n_dn > n_sites ||
+        n_dn > 33 || n_trans < 1 || n_trans > kReprMaxTrans) {
+        set_error("qbh_mopr_sz_repr_dev: invalid argument");
+        return QBH_EINVAL;
+    }
+    if (qbh_device_count() <= 0) {
+        set_error("no HIP device visible");
+        return QBH_ENODEVICE;
+    }
+    std::vector<ReprDev> rr(1);
+    ReprDev &R = rr[0];
+    memset(&R, 0, sizeof(R));
+    for (int p = 0; p <= 64; ++p)
+        for (int k = 0; k <= 33; ++k) R.h.binom[p][k] = binom_u64(p, k);
+    R.h.n_sites = n_sites;
+    R.h.n_dn = n_dn;
+    R.n_trans = n_trans;
+    R.n_chunks = (n_sites + 5) / 6;
+    for (int g = 0; g < n_trans; ++g) {
+        R.chr[2 * g] = chars_new[2 * g];
+        R.chr[2 * g + 1] = chars_new[2 * g + 1];
+    }
+    std::vector<uint64_t> tab((size_t)n_trans * R.n_chunks * 64, 0ULL);
+    for (int g = 0; g < n_trans; ++g)
+        for (int c = 0; c < R.n_chunks; ++c)
+            for (int v = 0; v < 64; ++v) {
+                uint64_t m = 0;
+                for (int b = 0; b < 6; ++b) {
+                    const int site = 6 * c + b;
+                    if (site < n_sites && ((v >> b) & 1)) {
+                        const int img = perms[(size_t)g * n_sites + site];
+                        if (img < 0 || img >= n_sites) {
+                            set_error("qbh_mopr_sz_repr_dev: translation %d is not a site permutation", g);
+                            return QBH_EINVAL;
+                        }
+                        m |= 1ULL << img;
+                    }
+                }
+                tab[((size_t)g * R.n_chunks + c) * 64 + v] = m;
+            }
+    const int64_t nstates = (int64_t)binom_u64(n_sites, n_dn);
+    SpinCoefR cf{};
+    for (int sidx = 0; sidx < n_sites; ++sidx) {
+        cf.re[sidx] = coef[sidx].re;
+        cf.im[sidx] = coef[sidx].im;
+    }
+    std::vector<void *> pool;
+    ReprDev *d_R = nullptr;
+    uint64_t *d_tab = nullptr;
+    uint8_t *d_code = nullptr;
+    int32_t *d_cnt = nullptr;
+    int64_t *d_pos = nullptr;
+    int rc = upload(rr, &d_R, pool);
+    if (rc == QBH_OK) rc = upload(tab, &d_tab, pool);
+    hipError_t e = hipSuccess;
+    int64_t dim = 0;
+    if (rc == QBH_OK) {
+        e = hipMalloc(&d_code, (size_t)nstates);
+        if (e == hipSuccess) e = hipMalloc(&d_cnt, (size_t)nstates * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc(&d_pos, (size_t)(nstates + 1) * sizeof(int64_t));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_repr_flag, dim3(blas_grid((nstates + 31) / 32)), dim3(256), 0, 0, d_R, d_tab, nstates, d_code, d_cnt);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) rc = exclusive_scan(d_cnt, nstates, d_pos, 0);
+        if (e == hipSuccess && rc == QBH_OK) e = hipMemcpy(&dim, d_pos + nstates, sizeof(int64_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && rc == QBH_OK) {
+            hipLaunchKernelGGL(k_repr_apply_sz, dim3(blas_grid((nstates + 31) / 32)), dim3(256), 0, 0, d_R, nstates, d_code, d_pos, cf,
+                               reinterpret_cast<const d2 *>(d_vec_old), reinterpret_cast<d2 *>(d_vec_new));
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+    }
+    free_pool(pool);
+    for (void *q : {(void *)d_code, (void *)d_cnt, (void *)d_pos})
+        if (q) (void)hipFree(q);
+    if (rc != QBH_OK) return rc;
+    if (e != hipSuccess) {
+        set_error("qbh_mopr_sz_repr_dev: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP;
+    }
+    if (dim_out) *dim_out = dim;
+    return QBH_OK;
 }

@@ -521,6 +521,19 @@ def moprXvec_onebody(n_sites, n_up, n_dn, terms, d_vec_old, d_vec_new, stream=No
           "qbh_mopr_onebody_dev")
 
 
+def moprXvec_sz_repr(n_sites, n_dn, perms, chars_new, coef, d_vec_old, d_vec_new):
+    """moprXvec_repr (src/model.cc:1715-1846) for S^z_q between momentum sectors of qbh_gen_heisenberg_repr; returns the
+    number of representatives."""
+    p = np.ascontiguousarray(np.asarray(perms, dtype=np.int32))
+    ch = np.ascontiguousarray(np.asarray(chars_new, dtype=np.complex128))
+    c = np.ascontiguousarray(coef, dtype=np.complex128)
+    assert p.shape == (len(ch), n_sites) and c.size == n_sites
+    dim = C.c_int64(0)
+    check(lib().qbh_mopr_sz_repr_dev(n_sites, n_dn, len(ch), _p(p), _p(ch), _p(c), d_vec_old, d_vec_new, C.byref(dim)),
+          "qbh_mopr_sz_repr_dev")
+    return dim.value
+
+
 def measure_full_dynamic_dev(mat_new, apply_mopr, maxit):
     """model<T>::measure_full_dynamic (src/model.cc:1696-1712) end to end in HBM: apply_mopr(d_vec_new) writes
     A_q |phi> into the first slot of a two-slot device vector of the target sector (moprXvec_spin / moprXvec_onebody on

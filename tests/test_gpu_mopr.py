@@ -160,3 +160,82 @@ def test_measure_full_dynamic_end_to_end_against_the_oracle():
     vy.free()
     vphi.free()
     A.destroy()
+
+
+def _momentum_states(n_sites, n_dn, perms, chars, conj):
+    """Explicit momentum states as columns in the FULL n_dn basis: |a, k> = (1/sqrt(|G||S_a|)) sum_g chi_k(g)^(*) T_g |a> for
+    every representative a (ascending); zero columns for representatives whose norm vanishes.  Returns (P, reps, zero)."""
+    import reprham
+    full = _patterns(n_sites, n_dn)
+    index = {int(p): i for i, p in enumerate(full)}
+    reps, stab, zero = reprham.repr_basis(n_sites, n_dn, perms, chars)
+    G = len(perms)
+    P = np.zeros((len(full), len(reps)), dtype=np.complex128)
+    for j, a in enumerate(reps):
+        if zero[j]:
+            continue
+        for g in range(G):
+            t = reprham.apply_perm(int(a), perms[g])
+            P[index[t], j] += (np.conj(chars[g]) if conj else chars[g]) / np.sqrt(G * stab[j])
+    return P, reps, zero
+
+
+def test_sz_q_between_momentum_sectors_matches_the_explicit_projection():
+    """moprXvec_repr for S^z_q (src/model.cc:1715-1846): device result against P_new^+ A_q P_old built from explicit momentum
+    states in the full basis.  The convention of those states is first pinned against the device-assembled sector
+    Hamiltonian (P^+ H_full P = H_repr), so the check does not depend on a hand-derived formula."""
+    import reprham
+    n_sites, n_dn, L = 12, 6, (12, 1)
+    bonds = lattices.chain(n_sites)
+    perms, shifts = lattices.translations(12, 1)
+    perms = np.asarray(perms)
+    k_old, qk = 2, 3
+    k_new = (k_old + qk) % n_sites
+    ch_old = np.asarray(lattices.characters(shifts, (k_old, 0), L))
+    ch_new = np.asarray(lattices.characters(shifts, (k_new, 0), L))
+    # full-basis Hamiltonian in the pattern-ascending basis (device generator order)
+    F = q.csr_mat.heisenberg(n_sites, n_dn, bonds)
+    ia, ja, val = F.download()
+    import scipy.sparse as sp
+    Hfull = sp.csr_matrix((val, ja, ia), shape=(F.dim, F.dim)).toarray()
+    A_old = q.csr_mat.heisenberg_repr(n_sites, n_dn, bonds, perms, ch_old, opts=q.make_opts(value_dict=0))
+    ia, ja, val = A_old.download()
+    Hrepr = sp.csr_matrix((val, ja, ia), shape=(A_old.dim, A_old.dim)).toarray()
+    conj = None
+    for c in (False, True):
+        P, reps, zero = _momentum_states(n_sites, n_dn, perms, ch_old, c)
+        M = P.conj().T @ Hfull @ P
+        ok = ~zero
+        if np.abs(M[np.ix_(ok, ok)] - Hrepr[np.ix_(ok, ok)]).max() < 1e-12:
+            conj = c
+    assert conj is not None                                   # one of the two conventions reproduces the sector operator
+    P_old, reps, zero_old = _momentum_states(n_sites, n_dn, perms, ch_old, conj)
+    P_new, _, zero_new = _momentum_states(n_sites, n_dn, perms, ch_new, conj)
+    # A_q = sum_s c_s S^z_s with c_s = exp(+-i q r_s)/sqrt(N): the sign that maps k_old to k_new in this convention
+    full = _patterns(n_sites, n_dn)
+    rng = np.random.default_rng(3)
+    x = (rng.normal(size=len(reps)) + 1j * rng.normal(size=len(reps))) * (~zero_old)
+    found = False
+    for sign in (+1, -1):
+        coef = np.exp(sign * 2j * np.pi * qk * np.arange(n_sites) / n_sites) / np.sqrt(n_sites)
+        sz = np.array([[(-0.5 if (int(p) >> s) & 1 else 0.5) for s in range(n_sites)] for p in full])
+        Aq = sz @ coef                                        # diagonal of A_q in the full basis
+        phi = Aq * (P_old @ x)
+        want = P_new.conj().T @ phi
+        # completeness: A_q maps the k_old subspace into the k_new subspace only for the right sign
+        if abs(np.linalg.norm(want) - np.linalg.norm(phi)) > 1e-10 * max(np.linalg.norm(phi), 1e-30):
+            continue
+        found = True
+        vx = q.DeviceVec(A_old, len(reps))
+        vy = q.DeviceVec(A_old, len(reps))
+        vx.upload(x)
+        dim = q.moprXvec_sz_repr(n_sites, n_dn, perms, ch_new, coef, vx.ptr, vy.ptr)
+        got = vy.download()
+        assert dim == len(reps) == A_old.dim
+        assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max()
+        assert np.all(got[zero_new] == 0)
+        vx.free()
+        vy.free()
+    assert found
+    F.destroy()
+    A_old.destroy()
