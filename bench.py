@@ -447,7 +447,8 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         st = A.stats()
-        elapsed, ms_spmv = allreduce_host([elapsed, st.ms_spmv / max(st.n_spmv, 1)], dist.ReduceOp.MAX)
+        elapsed, ms_spmv, ms_gather = allreduce_host([elapsed, st.ms_spmv / max(st.n_spmv, 1), st.ms_gather / max(st.n_gather, 1)],
+                                                     dist.ReduceOp.MAX)
         e0 = steps_e0 = None
         if not args.no_converge:      # untimed: the same solver to convergence (E0 parity across N / formats / vs the oracle tests)
             maxit2 = 1000
@@ -458,7 +459,7 @@ def main():
             e0, steps_e0 = float(ritz[0]), int(m)
         v.free()
         return dict(elapsed=elapsed, steps=done, ms_spmv=ms_spmv, n_spmv=int(st.n_spmv), n_real=int(st.n_spmv_real), e0=e0,
-                    steps_e0=steps_e0)
+                    steps_e0=steps_e0, ms_gather=ms_gather, n_gather=int(st.n_gather))
 
     create = None
     with torch.cuda.stream(stream):
@@ -537,6 +538,14 @@ def main():
                                          "build_s": round(t_gen, 3)},
         "roofline": roof, "e0": head["e0"], "lanczos_steps_to_converge": head["steps_e0"],
     }
+    if world > 1:
+        # link bytes per GPU reported separately from the HBM bytes.  ms_per_gather is the event-timed duration of
+        # the all-gather on RCCL's side stream (native communicator), max over ranks; it overlaps the locally-owned columns.
+        elem = 8 if real_used else 16
+        out["exchange"] = {"bytes_received_per_gpu_per_spmv": int(elem * dim * (world - 1) / world), "element_bytes": elem,
+                           "ms_per_gather": round(head["ms_gather"], 4) if head["ms_gather"] > 0 else None,
+                           "gathers": head["n_gather"],
+                           "allreduce": "<= 3 doubles per reduction point"}
     if create:
         out["create"] = create
     if packed_real:

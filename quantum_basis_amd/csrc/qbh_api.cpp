@@ -707,6 +707,7 @@ extern "C" int qbh_get_stats(const qbh_csr *Ac, qbh_stats *s, int reset)
 {
     qbh_csr *A = const_cast<qbh_csr *>(Ac);
     if (!A) return QBH_EINVAL;
+    qbh::harvest_native_comm(A);
     if (s) {
         *s = A->stats;
         if (A->stats.n_spmv == 0) s->ms_spmv_min = 0.0;

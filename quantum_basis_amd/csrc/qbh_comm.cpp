@@ -84,6 +84,10 @@ struct qbh_native_comm {
     double     *d_xsend = nullptr, *d_xfull = nullptr, *d_xfull_r = nullptr, *d_scal = nullptr;
     bool        in_flight = false;
     char        err[256] = "";
+    // event timing of the gather on the side stream (harvested at the next gather / by qbh_get_stats)
+    qbh_csr    *owner = nullptr;
+    hipEvent_t  t0 = nullptr, t1 = nullptr;
+    bool        timing_pending = false;
 };
 
 namespace {
@@ -95,10 +99,22 @@ int fail(qbh_native_comm *c, const char *what, ncclResult_t r)
     return 1;
 }
 
+void harvest_gather_time(qbh_native_comm *c)
+{
+    if (!c->timing_pending) return;
+    c->timing_pending = false;
+    float ms = 0.f;
+    if (hipEventSynchronize(c->t1) == hipSuccess && hipEventElapsedTime(&ms, c->t0, c->t1) == hipSuccess && c->owner)
+        c->owner->stats.ms_gather += ms;
+}
+
 // the exchange itself, enqueued on the side stream after everything the operator's stream has enqueued so far
 int enqueue_gather(qbh_native_comm *c, int packed)
 {
+    harvest_gather_time(c);                     // the previous exchange finished long ago: no stall
     if (hipEventRecord(c->ready, c->op) != hipSuccess || hipStreamWaitEvent(c->side, c->ready, 0) != hipSuccess) return 1;
+    const bool timed = c->owner && c->owner->opts.profile != 0;
+    if (timed && hipEventRecord(c->t0, c->side) != hipSuccess) return 1;
     const size_t w = packed ? 1 : 2;                               // doubles per element on the wire
     double *recv = packed ? c->d_xfull_r : c->d_xfull;
     ncclResult_t r;
@@ -117,6 +133,10 @@ int enqueue_gather(qbh_native_comm *c, int packed)
             }
         }
         if ((r = c->api->GroupEnd()) != ncclSuccess) return fail(c, "ncclGroupEnd", r);
+    }
+    if (timed) {
+        if (hipEventRecord(c->t1, c->side) != hipSuccess) return 1;
+        c->timing_pending = true;
     }
     if (hipEventRecord(c->done, c->side) != hipSuccess) return 1;
     c->in_flight = true;
@@ -160,11 +180,18 @@ void destroy_native(qbh_native_comm *c)
     if (c->d_scal) (void)hipFree(c->d_scal);
     if (c->ready) (void)hipEventDestroy(c->ready);
     if (c->done) (void)hipEventDestroy(c->done);
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
 }
 
 }  // namespace
+
+void qbh::harvest_native_comm(qbh_csr *A)
+{
+    if (A && A->native) harvest_gather_time(A->native);
+}
 
 void qbh::release_native_comm(qbh_csr *A)
 {
@@ -250,6 +277,9 @@ extern "C" int qbh_comm_create_rccl(qbh_csr *A, const void *uid128, int rank, in
     QBH_C(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     QBH_C(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
     QBH_C(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    QBH_C(hipEventCreate(&c->t0));
+    QBH_C(hipEventCreate(&c->t1));
+    c->owner = A;
     QBH_C(hipMalloc(&c->d_xsend, (size_t)c->nblk * 2 * sizeof(double)));
     QBH_C(hipMalloc(&c->d_xfull, full * 2 * sizeof(double)));
     QBH_C(hipMalloc(&c->d_xfull_r, full * sizeof(double)));

@@ -118,6 +118,7 @@ int balanced_row_cuts(int64_t dim, int64_t nnz, int sym, const int64_t *ia, cons
 
 // native RCCL communicator (qbh_comm.cpp)
 void release_native_comm(qbh_csr *A);
+void harvest_native_comm(qbh_csr *A);      // adds the event-timed duration of the last gather to stats.ms_gather
 
 // host tridiagonal solver (qbh_hess.cpp)
 int tridiag_eigen_full(int64_t m, const double *a, const double *b1, double *w, double *z);
