@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QBH_VERSION 100
+#define QBH_VERSION 200
 
 /* error codes */
 #define QBH_OK          0
@@ -260,6 +260,15 @@ int qbh_mopr_onebody_dev(int n_sites, int n_up, int n_dn, int n_terms, const int
  * whose norm does not vanish at the target momentum, 0 for the others.  *dim_out (may be NULL) = number of representatives. */
 int qbh_mopr_sz_repr_dev(int n_sites, int n_dn, int n_trans, const int32_t *perms, const double *chars_new,
                          const qbh_z *coef, const qbh_z *d_vec_old, qbh_z *d_vec_new, int64_t *dim_out);
+/* The off-diagonal branch of moprXvec_repr (src/model.cc:1760-1830): S^-_q (kind -1, n_dn_old -> n_dn_old + 1) and S^+_q
+ * (kind +1, n_dn_old -> n_dn_old - 1) from the momentum sector chars_old to chars_new = chars_old * eta, coef as above.
+ * vec_new[b] = sum over (a, s): coef[s] chi_new(g*) sqrt(|S_b|/|S_a|) vec_old[a], g* the translation that takes the
+ * flipped pattern to its representative b.  Contributions are accumulated with fp64 atomics (the reference uses a
+ * critical section), so the result is reproducible only to rounding.  d_vec_new must hold the target sector's
+ * representatives (*dim_new_out). */
+int qbh_mopr_flip_repr_dev(int n_sites, int n_dn_old, int kind, int n_trans, const int32_t *perms, const double *chars_old,
+                           const double *chars_new, const qbh_z *coef, const qbh_z *d_vec_old, qbh_z *d_vec_new,
+                           int64_t *dim_old_out, int64_t *dim_new_out);
 
 /* --------------------------------------------------------- checkpoints --- */
 /* The reference's checkpoint files from the C ABI, host only.

@@ -824,6 +824,49 @@ __global__ __launch_bounds__(256) void k_repr_apply_sz(const ReprDev *Rp, int64_
     }
 }
 
+// moprXvec_repr, off-diagonal branch (src/model.cc:1760-1830), for S^-_q / S^+_q = sum_s c_s S^-+_s with c_{g(s)} = eta(g) c_s:
+//   A_q |a, k> = sum_s c_s chi_k'(g*) sqrt(|S_b| / |S_a|) |b, k'>,   c = a with spin s flipped,  b = g* c its representative,
+// k' = k * eta, in the convention |a, k> = (|G| |S_a|)^(-1/2) sum_g chi_k(g) T_g |a> of the sector generator (H[a][b] =
+// h conj(chi(g*)) sqrt(|S_b|/|S_a|) is the conjugate-transposed statement of the same formula).  One lane per SOURCE
+// representative; contributions are added with fp64 atomics (the reference adds them inside a critical section).
+__global__ __launch_bounds__(128) void k_repr_apply_flip(const ReprDev *Rnew, const uint64_t *tab, const uint64_t *reps_old,
+                                                         const uint8_t *info_old, int64_t dim_old, const uint64_t *reps_new,
+                                                         const uint8_t *info_new, int64_t dim_new, int lower, SpinCoefR cf,
+                                                         const d2 *x_old, double *y_new)
+{
+    const ReprDev &R = *Rnew;                  // characters of the TARGET momentum
+    const int64_t stride = (int64_t)gridDim.x * 128;
+    for (int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x; i < dim_old; i += stride) {
+        const uint8_t ci = info_old[i];
+        if (ci & 0x80) continue;               // zero norm at the source momentum
+        const d2 x = x_old[i];
+        if (x.x == 0.0 && x.y == 0.0) continue;
+        const uint64_t a = reps_old[i];
+        const double sa = (double)(ci & 0x7f);
+        for (int site = 0; site < R.h.n_sites; ++site) {
+            const bool down = (a >> site) & 1ULL;
+            if (lower ? down : !down) continue;   // S^- acts on an up spin (bit 0), S^+ on a down spin (bit 1)
+            const uint64_t c = a ^ (1ULL << site);
+            int g = 0;
+            const uint64_t b = repr_canonical(R, tab, c, &g);
+            int64_t lo = 0, hi = dim_new;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (reps_new[mid] < b) lo = mid + 1;
+                else hi = mid;
+            }
+            const uint8_t cj = info_new[lo];
+            if (cj & 0x80) continue;           // zero norm at the target momentum
+            const double f = sqrt((double)(cj & 0x7f) / sa);
+            // w = coef[site] * chi_k'(g*) * f
+            const double wr = f * (cf.re[site] * R.chr[2 * g] - cf.im[site] * R.chr[2 * g + 1]);
+            const double wi = f * (cf.re[site] * R.chr[2 * g + 1] + cf.im[site] * R.chr[2 * g]);
+            atomicAdd(&y_new[2 * lo], wr * x.x - wi * x.y);
+            atomicAdd(&y_new[2 * lo + 1], wr * x.y + wi * x.x);
+        }
+    }
+}
+
 // one row of the sector Hamiltonian into (cols, vals), columns ascending, duplicates merged; returns its length
 __device__ int repr_row(const ReprDev &R, const uint64_t *tab, const uint64_t *reps, const uint8_t *info, int64_t dim, int64_t i,
                         int32_t *cols, d2 *vals)
@@ -1265,5 +1308,134 @@ extern "C" int qbh_mopr_sz_repr_dev(int n_sites, int n_dn, int n_trans, const in
         return e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP;
     }
     if (dim_out) *dim_out = dim;
+    return QBH_OK;
+}
+
+
+namespace qbh {
+namespace {
+// representatives of one (n_dn, characters) sector on the device: d_reps (ascending) and d_info (|S| | zero-norm << 7)
+int enumerate_sector(int n_sites, int n_dn, int n_trans, const int32_t *perms, const double *chars, ReprDev **d_R_out,
+                     uint64_t **d_tab_out, uint64_t **d_reps_out, uint8_t **d_info_out, int64_t *dim_out, std::vector<void *> &pool,
+                     const char *who)
+{
+    std::vector<ReprDev> rr(1);
+    ReprDev &R = rr[0];
+    memset(&R, 0, sizeof(R));
+    for (int p = 0; p <= 64; ++p)
+        for (int k = 0; k <= 33; ++k) R.h.binom[p][k] = binom_u64(p, k);
+    R.h.n_sites = n_sites;
+    R.h.n_dn = n_dn;
+    R.n_trans = n_trans;
+    R.n_chunks = (n_sites + 5) / 6;
+    for (int g = 0; g < n_trans; ++g) {
+        R.chr[2 * g] = chars[2 * g];
+        R.chr[2 * g + 1] = chars[2 * g + 1];
+    }
+    std::vector<uint64_t> tab((size_t)n_trans * R.n_chunks * 64, 0ULL);
+    for (int g = 0; g < n_trans; ++g)
+        for (int c = 0; c < R.n_chunks; ++c)
+            for (int v = 0; v < 64; ++v) {
+                uint64_t m = 0;
+                for (int b = 0; b < 6; ++b) {
+                    const int site = 6 * c + b;
+                    if (site < n_sites && ((v >> b) & 1)) {
+                        const int img = perms[(size_t)g * n_sites + site];
+                        if (img < 0 || img >= n_sites) {
+                            set_error("%s: translation %d is not a site permutation", who, g);
+                            return QBH_EINVAL;
+                        }
+                        m |= 1ULL << img;
+                    }
+                }
+                tab[((size_t)g * R.n_chunks + c) * 64 + v] = m;
+            }
+    const int64_t nstates = (int64_t)binom_u64(n_sites, n_dn);
+    QBH_TRY(upload(rr, d_R_out, pool));
+    QBH_TRY(upload(tab, d_tab_out, pool));
+    uint8_t *d_code = nullptr;
+    int32_t *d_cnt = nullptr;
+    int64_t *d_pos = nullptr;
+    QBH_HIP(hipMalloc(&d_code, (size_t)nstates));
+    pool.push_back(d_code);
+    QBH_HIP(hipMalloc(&d_cnt, (size_t)nstates * sizeof(int32_t)));
+    pool.push_back(d_cnt);
+    QBH_HIP(hipMalloc(&d_pos, (size_t)(nstates + 1) * sizeof(int64_t)));
+    pool.push_back(d_pos);
+    hipLaunchKernelGGL(k_repr_flag, dim3(blas_grid((nstates + 31) / 32)), dim3(256), 0, 0, *d_R_out, *d_tab_out, nstates, d_code, d_cnt);
+    QBH_HIP(hipGetLastError());
+    QBH_TRY(exclusive_scan(d_cnt, nstates, d_pos, 0));
+    int64_t dim = 0;
+    QBH_HIP(hipMemcpy(&dim, d_pos + nstates, sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (dim <= 0) {
+        set_error("%s: empty sector", who);
+        return QBH_EINVAL;
+    }
+    QBH_HIP(hipMalloc(d_reps_out, (size_t)dim * sizeof(uint64_t)));
+    pool.push_back(*d_reps_out);
+    QBH_HIP(hipMalloc(d_info_out, (size_t)dim));
+    pool.push_back(*d_info_out);
+    hipLaunchKernelGGL(k_repr_compact, dim3(blas_grid((nstates + 31) / 32)), dim3(256), 0, 0, *d_R_out, nstates, d_code, d_pos, *d_reps_out,
+                       *d_info_out);
+    QBH_HIP(hipGetLastError());
+    QBH_HIP(hipDeviceSynchronize());
+    *dim_out = dim;
+    return QBH_OK;
+}
+}  // namespace
+}  // namespace qbh
+
+// S^-_q (kind -1: n_dn -> n_dn + 1) and S^+_q (kind +1: n_dn -> n_dn - 1) between momentum sectors; see k_repr_apply_flip.
+extern "C" int qbh_mopr_flip_repr_dev(int n_sites, int n_dn_old, int kind, int n_trans, const int32_t *perms, const double *chars_old,
+                                      const double *chars_new, const qbh_z *coef, const qbh_z *d_vec_old, qbh_z *d_vec_new,
+                                      int64_t *dim_old_out, int64_t *dim_new_out)
+{
+    using namespace qbh;
+    const int n_new = n_dn_old - kind;
+    if (!perms || !chars_old || !chars_new || !coef || !d_vec_old || !d_vec_new || (kind != -1 && kind != 1) || n_sites <= 0 ||
+        n_sites > 62 || n_dn_old < 0 || n_dn_old > n_sites || n_new < 0 || n_new > n_sites || n_dn_old > 33 || n_new > 33 || n_trans < 1 ||
+        n_trans > kReprMaxTrans) {
+        set_error("qbh_mopr_flip_repr_dev: invalid argument");
+        return QBH_EINVAL;
+    }
+    if (qbh_device_count() <= 0) {
+        set_error("no HIP device visible");
+        return QBH_ENODEVICE;
+    }
+    SpinCoefR cf{};
+    for (int sidx = 0; sidx < n_sites; ++sidx) {
+        cf.re[sidx] = coef[sidx].re;
+        cf.im[sidx] = coef[sidx].im;
+    }
+    std::vector<void *> pool;
+    ReprDev *R_old = nullptr, *R_new = nullptr;
+    uint64_t *tab_old = nullptr, *tab_new = nullptr, *reps_old = nullptr, *reps_new = nullptr;
+    uint8_t *info_old = nullptr, *info_new = nullptr;
+    int64_t dim_old = 0, dim_new = 0;
+    int rc = enumerate_sector(n_sites, n_dn_old, n_trans, perms, chars_old, &R_old, &tab_old, &reps_old, &info_old, &dim_old, pool,
+                              "qbh_mopr_flip_repr_dev");
+    if (rc == QBH_OK)
+        rc = enumerate_sector(n_sites, n_new, n_trans, perms, chars_new, &R_new, &tab_new, &reps_new, &info_new, &dim_new, pool,
+                              "qbh_mopr_flip_repr_dev");
+    hipError_t e = hipSuccess;
+    if (rc == QBH_OK) {
+        e = hipMemset(d_vec_new, 0, (size_t)dim_new * sizeof(d2));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_repr_apply_flip, dim3(blas_grid(dim_old)), dim3(128), 0, 0, R_new, tab_new, reps_old, info_old, dim_old,
+                               reps_new, info_new, dim_new, kind < 0 ? 1 : 0, cf, reinterpret_cast<const d2 *>(d_vec_old),
+                               reinterpret_cast<double *>(d_vec_new));
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+    }
+    free_pool(pool);
+    if (rc != QBH_OK) return rc;
+    if (e != hipSuccess) {
+        set_error("qbh_mopr_flip_repr_dev: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP;
+    }
+    if (dim_old_out) *dim_old_out = dim_old;
+    if (dim_new_out) *dim_new_out = dim_new;
     return QBH_OK;
 }

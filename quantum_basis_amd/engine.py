@@ -534,6 +534,19 @@ def moprXvec_sz_repr(n_sites, n_dn, perms, chars_new, coef, d_vec_old, d_vec_new
     return dim.value
 
 
+def moprXvec_flip_repr(n_sites, n_dn_old, kind, perms, chars_old, chars_new, coef, d_vec_old, d_vec_new):
+    """moprXvec_repr for S^-_q (kind -1) / S^+_q (kind +1) between momentum sectors; returns (dim_old, dim_new)."""
+    p = np.ascontiguousarray(np.asarray(perms, dtype=np.int32))
+    co = np.ascontiguousarray(np.asarray(chars_old, dtype=np.complex128))
+    cn = np.ascontiguousarray(np.asarray(chars_new, dtype=np.complex128))
+    c = np.ascontiguousarray(coef, dtype=np.complex128)
+    assert p.shape == (len(co), n_sites) and len(cn) == len(co) and c.size == n_sites
+    d0, d1 = C.c_int64(0), C.c_int64(0)
+    check(lib().qbh_mopr_flip_repr_dev(n_sites, n_dn_old, kind, len(co), _p(p), _p(co), _p(cn), _p(c), d_vec_old, d_vec_new,
+                                       C.byref(d0), C.byref(d1)), "qbh_mopr_flip_repr_dev")
+    return d0.value, d1.value
+
+
 def measure_full_dynamic_dev(mat_new, apply_mopr, maxit):
     """model<T>::measure_full_dynamic (src/model.cc:1696-1712) end to end in HBM: apply_mopr(d_vec_new) writes
     A_q |phi> into the first slot of a two-slot device vector of the target sector (moprXvec_spin / moprXvec_onebody on

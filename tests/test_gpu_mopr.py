@@ -239,3 +239,58 @@ def test_sz_q_between_momentum_sectors_matches_the_explicit_projection():
     assert found
     F.destroy()
     A_old.destroy()
+
+
+@pytest.mark.parametrize("kind", [-1, +1])
+def test_spin_flip_operators_between_momentum_sectors_match_the_explicit_projection(kind):
+    """The off-diagonal branch of moprXvec_repr (src/model.cc:1760-1830): S^-_q / S^+_q from (n_dn, k) to (n_dn -+ 1... , k + q)
+    against P_new^+ A_q P_old with explicit momentum states; convention pinned by P^+ H P = H_repr as above."""
+    import scipy.sparse as sp
+    n_sites, n_dn, L = 12, 5, (12, 1)
+    n_new = n_dn - kind
+    bonds = lattices.chain(n_sites)
+    perms, shifts = lattices.translations(12, 1)
+    perms = np.asarray(perms)
+    k_old, qk = 1, 4
+    ch_old = np.asarray(lattices.characters(shifts, (k_old, 0), L))
+    F = q.csr_mat.heisenberg(n_sites, n_dn, bonds)
+    ia, ja, val = F.download()
+    Hfull = sp.csr_matrix((val, ja, ia), shape=(F.dim, F.dim)).toarray()
+    A_old = q.csr_mat.heisenberg_repr(n_sites, n_dn, bonds, perms, ch_old, opts=q.make_opts(value_dict=0))
+    ia, ja, val = A_old.download()
+    Hrepr = sp.csr_matrix((val, ja, ia), shape=(A_old.dim, A_old.dim)).toarray()
+    conj = None
+    for c in (False, True):
+        P, reps, zero = _momentum_states(n_sites, n_dn, perms, ch_old, c)
+        ok = ~zero
+        if np.abs((P.conj().T @ Hfull @ P)[np.ix_(ok, ok)] - Hrepr[np.ix_(ok, ok)]).max() < 1e-12:
+            conj = c
+    assert conj is not None
+    P_old, reps_old, zero_old = _momentum_states(n_sites, n_dn, perms, ch_old, conj)
+    rng = np.random.default_rng(11 + kind)
+    x = (rng.normal(size=len(reps_old)) + 1j * rng.normal(size=len(reps_old))) * (~zero_old)
+    found = False
+    for sign in (+1, -1):
+        k_new = (k_old + sign * qk) % n_sites
+        ch_new = np.asarray(lattices.characters(shifts, (k_new, 0), L))
+        P_new, reps_new, zero_new = _momentum_states(n_sites, n_new, perms, ch_new, conj)
+        for csign in (+1, -1):
+            coef = np.exp(csign * 2j * np.pi * qk * np.arange(n_sites) / n_sites) / np.sqrt(n_sites)
+            phi = _np_spin_apply(n_sites, n_dn, kind, coef, P_old @ x)
+            want = P_new.conj().T @ phi
+            if abs(np.linalg.norm(want) - np.linalg.norm(phi)) > 1e-10 * max(np.linalg.norm(phi), 1e-30):
+                continue                                  # this (coef sign, target momentum) pair does not match: A_q |k> is not in k_new
+            found = True
+            vx = q.DeviceVec(A_old, len(reps_old))
+            vy = q.DeviceVec(A_old, len(reps_new))
+            vx.upload(x)
+            d0, d1 = q.moprXvec_flip_repr(n_sites, n_dn, kind, perms, ch_old, ch_new, coef, vx.ptr, vy.ptr)
+            got = vy.download()
+            assert (d0, d1) == (len(reps_old), len(reps_new))
+            assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max(), (kind, sign, csign)
+            assert np.all(got[zero_new] == 0)
+            vx.free()
+            vy.free()
+    assert found
+    F.destroy()
+    A_old.destroy()
