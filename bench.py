@@ -486,12 +486,27 @@ def main():
         info = A.info()
         if dim is None:
             dim = int(info.ncols)
+        exchange_kind = None
         if world > 1:
-            if backend == "nccl" and not os.environ.get("QBH_PY_HOOKS"):
-                # the library's own RCCL communicator (qbh_comm_create_rccl): no Python in the SpMV loop
-                comm = qdist.NativeComm(dim, rank=rank, world=world).attach(A)  # noqa: F841
+            want_native = backend == "nccl" and not os.environ.get("QBH_PY_HOOKS")
+            native_err = None
+            if want_native:
+                # the library's own RCCL communicator (qbh_comm_create_rccl): no Python in the SpMV loop.  Every rank must
+                # end up on the same path, so the outcome is agreed on before anything is exchanged through it.
+                try:
+                    comm = qdist.NativeComm(dim, rank=rank, world=world).attach(A)
+                    ok = 1.0
+                except Exception as e:          # e.g. librccl not loadable: all ranks fall back together
+                    comm, ok, native_err = None, 0.0, repr(e)
+                if allreduce_host([ok], dist.ReduceOp.MIN)[0] < 1.0:
+                    if comm is not None:
+                        comm.detach(A)
+                    want_native = False
+            if want_native:
+                exchange_kind = "native RCCL (qbh_comm_create_rccl)"
             else:
                 comm = qdist.ShardComm(dim, rank=rank, world=world, device=device, stream=stream).attach(A)  # noqa: F841
+                exchange_kind = "torch.distributed hooks (%s)" % backend + (" [native communicator failed: %s]" % native_err if native_err else "")
         nnz_total = int(allreduce_host([float(info.nnz)], dist.ReduceOp.SUM)[0])
         head = timed_lanczos(A, packed_real)
 
@@ -529,8 +544,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype,
         "data": "synthetic", "config": {"workload": args.workload, "dim": dim, "nnz_full": nnz_total,
                                          "rows_per_gpu": info.nrows, "parallelism": "row-shard x%d" % world,
-                                         "exchange": None if world == 1 else ("native RCCL (qbh_comm_create_rccl)" if (backend == "nccl" and not os.environ.get("QBH_PY_HOOKS"))
-                                                                              else "torch.distributed hooks (%s)" % backend),
+                                         "exchange": exchange_kind,
                                          "kernel": KERNEL_KEY[info.kernel], "format": "complex128 CSR values + int32 columns, complex128 vectors"
                                          if not (coded or real_used) else "value codes %s, real fast path %s" % (coded, real_used),
                                          "value_dict": info.value_dict, "real_gather": real_used,
