@@ -176,6 +176,52 @@ inline void iram(const qint &dim, csr_mat &mat, cplx v0[], const qint &nev, cons
     nconv = nc;
 }
 
+// lanczos() with the reference's checkpoints enabled (enable_ckpt, src/lanczos.cc:144,190,242,263 -> src/ckpt.cc): resumes
+// from `dir` when it holds a usable step, commits every `every` steps; returns true when the stop rule fired.
+inline bool lanczos_ckpt(const qint &maxit, qint &m, const csr_mat &mat, cplx v[], double hessenberg[], const std::string &purpose,
+                         qint every = 50, const std::string &dir = "out_Qckpt", qint max_steps = 0)
+{
+    int64_t mm = 0;
+    int conv = 0;
+    check(qbh_lanczos_ckpt(mat.handle, maxit, &mm, reinterpret_cast<qbh_z *>(v), hessenberg, purpose.c_str(), every, max_steps,
+                           dir.c_str(), &conv, nullptr), "lanczos_ckpt");
+    m = mm;
+    return conv != 0;
+}
+
+// vec_disk_write / vec_disk_read (src/miscellaneous.cc:391-469)
+template <typename T> inline int vec_disk_write(const std::string &filename, qint n, T *x)
+{
+    check(qbh_vec_disk_write(filename.c_str(), n, (int)sizeof(T), x), "vec_disk_write");
+    return 0;
+}
+template <typename T> inline int vec_disk_read(const std::string &filename, qint n, T *x)
+{
+    return qbh_vec_disk_read(filename.c_str(), n, (int)sizeof(T), x);           // 0, or 1 where the reference returns 1
+}
+
+// One rank of a row-sharded run: this rank's rows of the full operator from the host CSR every rank holds, on
+// the native RCCL communicator.  `uid` is the 128-byte id of qbh_rccl_unique_id() from rank 0.  The returned handle is a
+// plain qbh_csr*: the device-vector entry points (qbh_lanczos_dev, qbh_eigenvec_cg_dev, qbh_iram, ...) take it as is,
+// with vectors of the shard-local length cuts[rank+1] - cuts[rank].
+inline qbh_csr *create_row_shard(qint dim, qint nnz, bool sym, const cplx *val, const qint *ja, const qint *ia, int rank, int nranks,
+                                 const void *uid, std::vector<qint> *cuts_out = nullptr, const qbh_opts *opts = nullptr)
+{
+    std::vector<int64_t> cuts((size_t)nranks + 1);
+    check(qbh_balanced_row_cuts(dim, nnz, sym ? 1 : 0, reinterpret_cast<const int64_t *>(ia), reinterpret_cast<const int64_t *>(ja),
+                                nranks, cuts.data()), "balanced_row_cuts");
+    qbh_csr *h = nullptr;
+    check(qbh_csr_create_rows(&h, dim, nnz, sym ? 1 : 0, reinterpret_cast<const int64_t *>(ia), reinterpret_cast<const int64_t *>(ja),
+                              reinterpret_cast<const qbh_z *>(val), cuts[(size_t)rank], cuts[(size_t)rank + 1], opts), "create_row_shard");
+    const int rc = qbh_comm_create_rccl(h, uid, rank, nranks, cuts.data());
+    if (rc != QBH_OK) {
+        qbh_csr_destroy(h);
+        check(rc, "comm_create_rccl");
+    }
+    if (cuts_out) cuts_out->assign(cuts.begin(), cuts.end());
+    return h;
+}
+
 // vec_randomize (src/miscellaneous.cc:371-386), produced on the device
 inline void vec_randomize(const csr_mat &mat, cplx *x, const uint32_t &seed)
 {
