@@ -547,6 +547,28 @@ def moprXvec_flip_repr(n_sites, n_dn_old, kind, perms, chars_old, chars_new, coe
     return d0.value, d1.value
 
 
+def measure_full_static_spin_dev(mat, n_sites, n_dn, d_phi, ops):
+    """model<T>::measure_full_static (src/model.cc:1660-1694) for a product of spin operators on a fixed-N_dn sector, on the
+    device: <phi| O_1 O_2 ... O_k |phi> with O_j = (kind_j, coef_j) as in moprXvec_spin, applied right to left (the
+    rightmost operator acts first, src/basis.cc:2767); the product must return to the sector of phi.  mat: any operator
+    handle of that sector (used for the reduction); d_phi: device address of the state."""
+    import math
+    cur_n, src, bufs = n_dn, d_phi, []
+    try:
+        for kind, coef in reversed(list(ops)):
+            new_n = cur_n - kind
+            dst = DeviceVec(mat, math.comb(n_sites, new_n))
+            bufs.append(dst)
+            moprXvec_spin(n_sites, cur_n, kind, coef, src, dst.ptr)
+            cur_n, src = new_n, dst.ptr
+        if cur_n != n_dn:
+            raise ValueError("the operator product does not return to the sector of phi")
+        return mat.dotc(d_phi, src)
+    finally:
+        for b in bufs:
+            b.free()
+
+
 def measure_full_dynamic_dev(mat_new, apply_mopr, maxit):
     """model<T>::measure_full_dynamic (src/model.cc:1696-1712) end to end in HBM: apply_mopr(d_vec_new) writes
     A_q |phi> into the first slot of a two-slot device vector of the target sector (moprXvec_spin / moprXvec_onebody on

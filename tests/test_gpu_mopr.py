@@ -294,3 +294,31 @@ def test_spin_flip_operators_between_momentum_sectors_match_the_explicit_project
     assert found
     F.destroy()
     A_old.destroy()
+
+
+def test_measure_full_static_reproduces_the_references_asserted_correlators():
+    """src/main_test.cc:94-108: <Sz0 Sz1>, <Sz0 Sz2>, <S+0 S-1> in the ground state of the L = 16 chain, here with the ground
+    state, the operator products and the inner product all on the device (the ground state lies in the Sz = 0 sector)."""
+    import helpers
+    k = helpers.known()["chain16_full"]
+    L, n_dn = 16, 8
+    A = q.csr_mat.heisenberg(L, n_dn, lattices.chain(L))
+    res = q.locate_E0_lanczos(A, nev=1, ncv=1)
+    assert abs(res.E0 - k["E0"]) < k["tol"]
+    v = q.DeviceVec(A, A.dim)
+    v.upload(res.eigenvecs)
+
+    def at(site):
+        c = np.zeros(L, dtype=np.complex128)
+        c[site] = 1.0
+        return c
+    m1 = q.measure_full_static_spin_dev(A, L, n_dn, v.ptr, [(0, at(0)), (0, at(1))])
+    m2 = q.measure_full_static_spin_dev(A, L, n_dn, v.ptr, [(0, at(0)), (0, at(2))])
+    m3 = q.measure_full_static_spin_dev(A, L, n_dn, v.ptr, [(+1, at(0)), (-1, at(1))])        # S+_0 S-_1: S-_1 acts first
+    assert abs(m1 - k["Sz0Sz1"]) < k["tol"] and abs(m1.imag) < 1e-12
+    assert abs(m2 - k["Sz0Sz2"]) < k["tol"]
+    assert abs(m3 - k["Sp0Sm1"]) < k["tol"]
+    with pytest.raises(ValueError):
+        q.measure_full_static_spin_dev(A, L, n_dn, v.ptr, [(-1, at(1))])
+    v.free()
+    A.destroy()
