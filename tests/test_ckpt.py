@@ -192,6 +192,34 @@ def test_native_checkpointed_run_interrupted_and_resumed(tmp_path):
 
 
 @pytest.mark.gpu
+def test_native_checkpoint_of_the_first_excited_state_run(tmp_path):
+    """purpose "sr_val1" (src/model.cc:1233-1265): three live vectors, phi0 travels through lanczosY0.dat; interrupted after 20
+    steps and resumed by a new operator object, E1 equals the uncheckpointed two-state solve."""
+    import helpers
+    import quantum_basis_amd as q
+    d, ia, ja, val, sym = helpers.case("hubbard_4x2")
+    maxit = 600
+    A = q.csr_mat(d, ia, ja, val, sym)
+    ref = q.locate_E0_lanczos(A, nev=2, ncv=1, maxit=maxit)
+    phi0 = ref.eigenvecs[:d]
+    v0 = q.vec_randomize(A, seed=1)
+    v0 = v0 - np.vdot(phi0, v0) * phi0
+    v0 /= np.linalg.norm(v0)
+    ckdir = str(tmp_path / "ck1")
+    m1, _, _, conv1 = ckpt.native_lanczos_checkpointed(A, maxit, "sr_val1", every=10, directory=ckdir, v0=v0, phi0=phi0, max_steps=20)
+    assert m1 == 20 and not conv1
+    assert os.path.exists(os.path.join(ckdir, "lanczosY0.dat"))
+    assert np.array_equal(ckpt.vec_disk_read(os.path.join(ckdir, "lanczosY0.dat"), d, np.complex128), phi0)
+    A.destroy()
+    B = q.csr_mat(d, ia, ja, val, sym)
+    m2, hess2, _, conv2 = ckpt.native_lanczos_checkpointed(B, maxit, "sr_val1", every=50, directory=ckdir, v0=np.zeros(d), phi0=np.zeros(d))
+    assert conv2 and abs(m2 - ref.steps["E1"]) <= 2
+    ritz, _ = q.hess_eigen(hess2, maxit, m2, "sr")
+    assert abs(ritz[0] - ref.E1) < 1e-9
+    B.destroy()
+
+
+@pytest.mark.gpu
 def test_interrupted_run_resumes_to_the_same_answer(tmp_path):
     import helpers
     import quantum_basis_amd as q
