@@ -39,6 +39,9 @@ inline void check(int rc, const char *where)
     throw std::runtime_error(msg);
 }
 
+class csr_mat;
+inline void vec_randomize(const csr_mat &mat, cplx *x, const uint32_t &seed);
+
 class csr_mat {
 public:
     qint dim = 0;
@@ -174,6 +177,23 @@ inline void iram(const qint &dim, csr_mat &mat, cplx v0[], const qint &nev, cons
                    reinterpret_cast<qbh_z *>(eigenvecs), nullptr), "iram");
     if (nc <= 0) throw std::runtime_error("nconv == 0...");           // src/lanczos.cc:566
     nconv = nc;
+}
+
+// energy_scale<T, csr_mat<T>> (src/kpm.cc:45-88): spectral bounds from iters - 1 Lanczos steps without a stop rule
+inline void energy_scale(const qint &dim, const csr_mat &mat, cplx v[], double &lo, double &hi, const double &extend = 0.1,
+                         const qint &iters = 128)
+{
+    const qint mm = iters - 1;
+    std::vector<double> hessenberg(2 * iters, 0.0), ritz, s;
+    vec_randomize(mat, v, 1);
+    qint m = 0;
+    lanczos(0, mm, iters, m, dim, mat, v, hessenberg.data(), "dnmcs");
+    hess_eigen(hessenberg.data(), iters, m, "sr", ritz, s);
+    lo = ritz[0];
+    hi = ritz[m - 1];
+    const double slack = extend * (hi - lo);
+    lo -= slack;
+    hi += slack;
 }
 
 // lanczos() with the reference's checkpoints enabled (enable_ckpt, src/lanczos.cc:144,190,242,263 -> src/ckpt.cc): resumes

@@ -501,6 +501,25 @@ def measure_full_dynamic(mat, vec_new, maxit):
     return m, norm, hessenberg
 
 
+def energy_scale(dim, mat, extend=0.1, iters=128, seed=1):
+    """energy_scale<T,MAT> (src/kpm.cc:45-88): spectral bounds for the kernel polynomial method from `iters - 1` Lanczos
+    steps without a stop rule ("dnmcs" recurrence), lo / hi = extreme Ritz values widened by extend * (hi - lo)."""
+    if dim != mat.dim:
+        raise ValueError("dim mismatch")
+    mm = iters - 1
+    v = mat.vec(2)
+    try:
+        mat.randomize(v.at(0), seed)                                      # :60
+        hess = np.zeros(2 * iters)
+        m = lanczos(0, mm, iters, dim, mat, None, hess, "dnmcs", device_v=v)   # :62-76
+        ritz, _ = hess_eigen(hess, iters, m, "sr")                        # :77
+    finally:
+        v.free()
+    lo, hi = float(ritz[0]), float(ritz[m - 1])
+    slack = extend * (hi - lo)
+    return lo - slack, hi + slack
+
+
 def moprXvec_spin(n_sites, n_dn_old, kind, coef, d_vec_old, d_vec_new, stream=None):
     """moprXvec_full (src/model.cc:1468-1538) on the device for S^z_q (kind 0), S^-_q (kind -1) and S^+_q (kind +1) on a
     spin-1/2 sector with n_dn_old down spins; d_vec_old / d_vec_new are device addresses (DeviceVec.at(...))."""

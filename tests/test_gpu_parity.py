@@ -784,3 +784,23 @@ def test_cg_on_real_packed_vectors(mf):
     assert abs(np.linalg.norm(vec) - 1.0) < 1e-10
     assert abs(abs(np.dot(vec, ref.eigenvecs.real)) - 1.0) < 1e-8
     assert abs(ritz[0] - helpers.known()["hubbard_4x2"]["E0"]) < 1e-8
+
+
+def test_energy_scale_matches_the_oracle_recurrence():
+    """energy_scale<T,MAT> (src/kpm.cc:45-88): iters - 1 Lanczos steps without a stop rule, bounds from the extreme Ritz values."""
+    d, ia, ja, val, sym = helpers.case("hubbard_4x2")
+    A = q.csr_mat(d, ia, ja, val, sym)
+    iters, extend = 64, 0.1
+    lo, hi = q.energy_scale(d, A, extend=extend, iters=iters)
+    O = qo.Csr(d, ia, ja, val, sym)
+    v = np.zeros(2 * d, dtype=np.complex128)
+    v[:d] = qo.vec_randomize(d, 1)
+    h = np.zeros(2 * iters)
+    m = qo.lanczos(0, iters - 1, iters, O, v, h, "dnmcs")[0]
+    ritz, _ = qo.hess_eigen(h, iters, m, "sr")
+    assert m == iters - 1
+    lo_o, hi_o = ritz[0] - extend * (ritz[m - 1] - ritz[0]), ritz[m - 1] + extend * (ritz[m - 1] - ritz[0])
+    assert abs(lo - lo_o) < 1e-9 * abs(lo_o) and abs(hi - hi_o) < 1e-9 * abs(hi_o)
+    w = np.linalg.eigvalsh(O.to_dense())
+    assert lo < w[0] and hi > w[-1]                     # the bounds bracket the spectrum
+    A.destroy()
