@@ -448,7 +448,9 @@ static int create_from_host(qbh_csr **out, int64_t dim, int64_t nnz, int sym_upp
         return QBH_EINVAL;
     }
     const double t0 = now_ms();
+    const bool trace = getenv("QBH_CREATE_TRACE") != nullptr;
     QBH_TRY(qbh::validate_host_csr(dim, nnz, sym_upper, ia, ja));
+    if (trace) fprintf(stderr, "[qbh_csr_create] %-22s %8.2f ms\n", "host validation", now_ms() - t0);
     const d2 *hv = reinterpret_cast<const d2 *>(val);
     if (!sym_upper && (!opts || opts->check_hermitian)) QBH_TRY(qbh::check_hermitian_host(dim, ia, ja, hv));
 
@@ -460,11 +462,13 @@ static int create_from_host(qbh_csr **out, int64_t dim, int64_t nnz, int sym_upp
     A->own_arrays = true;
     int rc = qbh::build_shard_from_host(dim, nnz, sym_upper, ia, ja, hv, r0, r1, A->stream, &A->d_ia, &A->d_ja, &A->d_val, &A->nnz,
                                         &A->create_ms_upload);
+    const double t1 = now_ms();
     if (rc == QBH_OK) rc = finalize(A);
     if (rc != QBH_OK) {
         qbh_csr_destroy(A);
         return rc;
     }
+    if (trace) fprintf(stderr, "[qbh_csr_create] %-22s %8.2f ms\n", "finalize (geometry)", now_ms() - t1);
     A->create_ms = now_ms() - t0;
     A->create_bytes_in = nnz * 24 + (dim + 1) * 8;
     *out = A;

@@ -318,11 +318,23 @@ int build_shard_from_host(int64_t dim, int64_t nnz, int sym, const int64_t *ia, 
     QBH_B(hipMemcpyAsync(d_ia, ia + row0, (size_t)n_ia * sizeof(int64_t), hipMemcpyHostToDevice, s));
     const int64_t *d_ia_own = d_ia + (r0 - row0);        // pointers of the shard's own rows
 
-    int64_t chunk = 4 << 20;
+    // staging chunk: 4 M nonzeros for large matrices; small ones use ~1/8 of their range so that pinning the staging
+    // buffers (the fixed cost of a small create) stays cheap and the upload still pipelines
+    int64_t chunk = std::min<int64_t>(4 << 20, std::max<int64_t>(256 << 10, (g_end - g_begin + 7) / 8));
     if (const char *e = getenv("QBH_CREATE_CHUNK")) chunk = std::max<int64_t>(1024, atoll(e));
     chunk = std::min<int64_t>(chunk, std::max<int64_t>(g_end - g_begin, 1));
+    const bool trace = getenv("QBH_CREATE_TRACE") != nullptr;
+    double t_mark = wall_ms();
+    auto mark = [&](const char *what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(s);
+        const double t = wall_ms();
+        fprintf(stderr, "[qbh_csr_create] %-22s %8.2f ms\n", what, t - t_mark);
+        t_mark = t;
+    };
     Stager st;
     QBH_BT(st.init(chunk, true));
+    mark("staging buffers");
 
     // one streaming pass over the host nonzeros [g_begin, g_end): stage(b, g, n) fills the pinned buffers, launch(b, g, n)
     // enqueues copy + kernel
@@ -368,6 +380,7 @@ int build_shard_from_host(int64_t dim, int64_t nnz, int sym, const int64_t *ia, 
                                row0, r0, r1, d_low);
         }));
     }
+    mark("pass 1 (mirror count)");
     QBH_B(hipMalloc(&d_cnt, (size_t)nloc * sizeof(int32_t)));
     hipLaunchKernelGGL(k_row_total, dim3(blas_grid(nloc)), dim3(kBlock), 0, s, d_ia_own, d_low, nloc, d_cnt);
     QBH_B(hipGetLastError());
@@ -387,6 +400,7 @@ int build_shard_from_host(int64_t dim, int64_t nnz, int sym, const int64_t *ia, 
         hipLaunchKernelGGL(k_fill, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, st.d_ja[b], st.d_val[b], g, n, d_ia, rlo, rhi,
                            row0, r0, r1, sym, d_ia_f, d_low, d_cur, d_ja_f, d_val_f);
     }));
+    mark("scan + pass 2 (fill)");
     if (sym) {
         constexpr int kShortCap = 96;
         hipLaunchKernelGGL(k_sort_lower_short, dim3(blas_grid(nloc)), dim3(kBlock), 0, s, d_ia_f, d_low, nloc, d_ja_f, d_val_f, kShortCap);
@@ -425,6 +439,7 @@ int build_shard_from_host(int64_t dim, int64_t nnz, int sym, const int64_t *ia, 
         }
     }
     QBH_B(hipStreamSynchronize(s));
+    mark("sort mirrored parts");
     cleanup(false);
 #undef QBH_B
 #undef QBH_BT
