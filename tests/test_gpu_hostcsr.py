@@ -130,3 +130,24 @@ def test_invalid_host_arrays_are_rejected_at_scale():
     with pytest.raises(_lib.QbhError) as e:
         q.csr_mat(d, F.indptr.astype(np.int64), F.indices.astype(np.int64), fv, sym=False)
     assert e.value.code == -5
+
+
+def test_chunk_boundaries_of_the_staged_upload(monkeypatch):
+    """The host arrays are streamed in chunks that start and end inside rows; with a 1,000-nonzero chunk every kind of
+    boundary occurs thousands of times: the expansion must not depend on the chunk size."""
+    d, ia, ja, val, sym = helpers.case("hubbard_4x2")
+    A = q.csr_mat(d, ia, ja, val, sym=sym, opts=q.make_opts(value_dict=0))
+    want = A.download()
+    A.destroy()
+    for chunk in ("1000", "1024", "77777"):
+        monkeypatch.setenv("QBH_CREATE_CHUNK", chunk)
+        B = q.csr_mat(d, ia, ja, val, sym=sym, opts=q.make_opts(value_dict=0))
+        got = B.download()
+        assert all(np.array_equal(a, b) for a, b in zip(want, got)), chunk
+        r0, r1 = d // 3, d // 3 + 1234
+        C = q.csr_mat(d, ia, ja, val, sym=sym, rows=(r0, r1), opts=q.make_opts(value_dict=0))
+        cia, cja, cval = C.download()
+        lo, hi = want[0][r0], want[0][r1]
+        assert np.array_equal(cia, want[0][r0:r1 + 1] - lo) and np.array_equal(cja, want[1][lo:hi]) and np.array_equal(cval, want[2][lo:hi])
+        B.destroy()
+        C.destroy()
