@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Time the bare SpMV launch (y = alpha*H*x + beta*y + gamma*x, the Lanczos form) of one benchmark operator under several
+environment settings (measurement tool: kernel experiments read their switches from the environment when the operator
+is created).  Usage: python tools/spmv_time.py hubbard_4x4_half "QBH_DMA=1024" "QBH_DMA=1024 QBH_GRID=512" ...
+An empty string is the default configuration.  Prints ms per launch from the library's own HIP events."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import quantum_basis_amd as q  # noqa: E402
+
+
+def main():
+    name = sys.argv[1]
+    cfgs = sys.argv[2:] or [""]
+    W = bench.workloads()[name]
+    fmt = os.environ.get("SPMV_FORMAT", "complex128")
+    for cfg in cfgs:
+        saved = {}
+        for kv in cfg.split():
+            k, v = kv.split("=", 1)
+            saved[k] = os.environ.get(k)
+            os.environ[k] = v
+        opts = q.make_opts(profile=1, value_dict=0 if fmt == "complex128" else 1, real_fast_path=0 if fmt == "complex128" else 1)
+        A = bench.build_operator(W, (0, bench.dim_of(W)), opts)
+        v = A.vec(2)
+        A.randomize(v.at(0), 1)
+        A.randomize(v.at(A.dim), 2)
+        reps = int(os.environ.get("SPMV_REPS", "8"))
+        for _ in range(2):
+            A.spmv(v.at(0), v.at(A.dim), 1.0, -0.3, 0.0, want_red=True)
+        A.stats(reset=True)
+        for _ in range(reps):
+            A.spmv(v.at(0), v.at(A.dim), 1.0, -0.3, 0.0, want_red=True)
+        A.sync()
+        s = A.stats()
+        print("%-70s %8.3f ms/launch (%d launches)" % (cfg or "(default)", s.ms_spmv / max(1, s.n_spmv), s.n_spmv), flush=True)
+        v.free()
+        A.destroy()
+        for k, old in saved.items():
+            if old is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = old
+
+
+if __name__ == "__main__":
+    main()
