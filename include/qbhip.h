@@ -408,6 +408,20 @@ int qbh_mf_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bonds,
 int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int n_bonds, const int32_t *bonds, double J,
                             int n_trans, const int32_t *perms, const double *chars, double fake_pos,
                             int shard, int n_shards, int64_t *dim_out, const qbh_opts *opts);
+
+/* The Hubbard family in a translation-symmetric (momentum) sector, assembled on the device: counterpart of
+ * model::enumerate_basis_repr + generate_Ham_sparse_repr (src/model.cc:687-836) for two-species fermions, the path of
+ * examples/trans_symmetric/latt_square/square_Fermi_Hubbard.cc.  The operator is
+ *     sum_t ( amp_up[t] c^dag_{i_t,up} c_{j_t,up} + amp_dn[t] c^dag_{i_t,dn} c_{j_t,dn} )  +  U sum_i n_{i,up} n_{i,dn},
+ * term_sites = (i_0, j_0, i_1, j_1, ...); terms on the same (i, j) are summed; i == j is a number operator.  It has to
+ * commute with the translations: a Hamiltonian does; a one-body observable is translation-averaged first, as
+ * model::measure_repr_static does (src/model.cc:1874-1888).  A non-Hermitian operator is accepted (rows are filled as
+ * O[a][b]).  perms / chars / fake_pos / shard / n_shards / dim_out as in qbh_gen_heisenberg_repr.  Basis: all orbit
+ * representatives of the words u | d << n_sites (operator order: all up, then all down), ascending; n_sites <= 31. */
+int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_terms, const int32_t *term_sites,
+                         const qbh_z *amp_up, const qbh_z *amp_dn, double U, int n_trans, const int32_t *perms,
+                         const double *chars, double fake_pos, int shard, int n_shards, int64_t *dim_out,
+                         const qbh_opts *opts);
 /* Copy the assembled shard back to host arrays (tests, CPU-baseline sample).  Any output
  * pointer may be NULL.  Rows [r0, r1) local to the shard; ia is rebased to 0. */
 int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1,

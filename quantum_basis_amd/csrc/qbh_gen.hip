@@ -13,6 +13,7 @@
 //             bit pattern); operator order: all up, then all down -> hop signs factorise.
 //   Heisenberg index = colex rank of the down-spin bit pattern.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -1438,4 +1439,447 @@ extern "C" int qbh_mopr_flip_repr_dev(int n_sites, int n_dn_old, int kind, int n
     if (dim_old_out) *dim_old_out = dim_old;
     if (dim_new_out) *dim_new_out = dim_new;
     return QBH_OK;
+}
+
+// ------------------------------------ Hubbard family in translation-symmetric sectors --
+// Device counterpart of model::enumerate_basis_repr + generate_Ham_sparse_repr (src/model.cc:687-836) for two-species
+// fermions (the reference's examples/trans_symmetric/latt_square/square_Fermi_Hubbard.cc).  A basis state is the pair of
+// occupation patterns (u, d) with the operator order "all up (ascending site), then all down", stored as the word
+// s = u | d << n_sites; a translation g maps c^dag_{i,sigma} to c^dag_{g(i),sigma}, so
+//     T_g |u, d> = sgn(g, u) sgn(g, d) |g(u), g(d)>,   sgn = parity of the inversions among the images of the occupied sites.
+// Basis: ALL orbit representatives (smallest word), ascending; a representative whose signed character sum over its
+// stabiliser vanishes has zero norm at this momentum and stays as a decoupled row with the fake diagonal (as in
+// qbh_gen_heisenberg_repr).  The operator is a list of directed one-body terms  amp_sigma * c^dag_{i,sigma} c_{j,sigma}
+// plus U sum_i n_{i,up} n_{i,dn}; it must commute with the translations (a Hamiltonian does; a single-site operator has to
+// be translation-averaged first, exactly as measure_repr_static does, src/model.cc:1874-1888).  With |a,k> =
+// (|G||S_a|)^(-1/2) sum_g chi_k(g) T_g |a>, row a holds
+//     O[a][b] = sum over terms that move a particle of a from i to j, giving c with T_{g*} |c> = sigma |b>:
+//               amp * (hop sign) * sigma * conj(chi_k(g*)) * sqrt(|S_b| / |S_a|).
+namespace qbh {
+namespace {
+
+constexpr int kHubReprMaxTerms = 512;
+
+struct HubReprDev {
+    uint64_t binom[65][34];
+    int n_sites, n_up, n_dn, n_terms, n_trans, n_chunks;
+    int8_t ti[kHubReprMaxTerms], tj[kHubReprMaxTerms];     // term t: amp * c^dag_{ti} c_{tj}
+    double aup[kHubReprMaxTerms][2], adn[kHubReprMaxTerms][2];
+    double U, fake_pos;
+    double chr[2 * kReprMaxTrans];
+    int8_t perm[kReprMaxTrans * 32];                       // perm[g * n_sites + site]
+};
+
+__device__ __forceinline__ uint64_t unrank_k(const uint64_t (*binom)[34], int n_sites, int k, uint64_t r)
+{
+    uint64_t bits = 0;
+    int p = n_sites - 1;
+    for (; k >= 1; --k) {
+        while (binom[p][k] > r) --p;
+        bits |= 1ULL << p;
+        r -= binom[p][k];
+        --p;
+    }
+    return bits;
+}
+
+__device__ __forceinline__ uint64_t next_same_popcount(uint64_t s)
+{
+    const uint64_t t2 = s | (s - 1ULL);
+    return (t2 + 1ULL) | (((~t2 & (t2 + 1ULL)) - 1ULL) >> (__ffsll((long long)s)));
+}
+
+// parity (0 / 1) of the permutation that sorts the images of the occupied sites of `occ` under translation g
+__device__ __forceinline__ int hubrepr_parity(const HubReprDev &R, int g, uint64_t occ)
+{
+    const int8_t *p = R.perm + g * R.n_sites;
+    uint64_t seen = 0;
+    int par = 0;
+    while (occ) {
+        const int i = __ffsll((long long)occ) - 1;
+        occ &= occ - 1;
+        const int img = p[i];
+        par ^= __popcll(seen >> img) & 1;                  // images placed so far that lie above this one
+        seen |= 1ULL << img;
+    }
+    return par;
+}
+
+__device__ __forceinline__ uint64_t hubrepr_translate(const HubReprDev &R, const uint64_t *tab, int g, uint64_t s)
+{
+    const uint64_t m = (1ULL << R.n_sites) - 1ULL;
+    const uint64_t u = repr_translate(tab, R.n_chunks, g, s & m), d = repr_translate(tab, R.n_chunks, g, s >> R.n_sites);
+    return u | (d << R.n_sites);
+}
+
+// smallest image, the translation that produces it and the sign of T_{g*}
+__device__ __forceinline__ uint64_t hubrepr_canonical(const HubReprDev &R, const uint64_t *tab, uint64_t s, int *gstar, int *parity)
+{
+    uint64_t best = s;
+    int gb = 0;
+    for (int g = 1; g < R.n_trans; ++g) {
+        const uint64_t t = hubrepr_translate(R, tab, g, s);
+        if (t < best) {
+            best = t;
+            gb = g;
+        }
+    }
+    *gstar = gb;
+    const uint64_t m = (1ULL << R.n_sites) - 1ULL;
+    *parity = gb ? (hubrepr_parity(R, gb, s & m) ^ hubrepr_parity(R, gb, s >> R.n_sites)) : 0;
+    return best;
+}
+
+// pass 1 over all C(n, n_up) * C(n, n_dn) words in ascending order (rank = rank(d) * C(n, n_up) + rank(u)):
+// code = 0 if not a representative, else |S| | (zero-norm << 7)
+__global__ __launch_bounds__(256) void k_hubrepr_flag(const HubReprDev *Rp, const uint64_t *tab, int64_t nstates, uint8_t *code,
+                                                      int32_t *cnt)
+{
+    const HubReprDev &R = *Rp;
+    constexpr int RUN = 16;
+    const uint64_t cu = R.binom[R.n_sites][R.n_up];
+    const uint64_t mlow = (1ULL << R.n_sites) - 1ULL;
+    const int64_t nruns = (nstates + RUN - 1) / RUN;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t run = (int64_t)blockIdx.x * 256 + threadIdx.x; run < nruns; run += stride) {
+        const int64_t r0 = run * RUN, r1 = (r0 + RUN < nstates) ? r0 + RUN : nstates;
+        uint64_t ru = (uint64_t)r0 % cu;
+        uint64_t u = unrank_k(R.binom, R.n_sites, R.n_up, ru), d = unrank_k(R.binom, R.n_sites, R.n_dn, (uint64_t)r0 / cu);
+        for (int64_t r = r0; r < r1; ++r) {
+            const uint64_t s = u | (d << R.n_sites);
+            bool rep = true;
+            int nstab = 1;
+            double sr = R.chr[0], si = R.chr[1];
+            for (int g = 1; g < R.n_trans; ++g) {
+                const uint64_t t = hubrepr_translate(R, tab, g, s);
+                if (t < s) {
+                    rep = false;
+                    break;
+                }
+                if (t == s) {
+                    const double sg = (hubrepr_parity(R, g, u) ^ hubrepr_parity(R, g, d)) ? -1.0 : 1.0;
+                    nstab++;
+                    sr += sg * R.chr[2 * g];
+                    si += sg * R.chr[2 * g + 1];
+                }
+            }
+            code[r] = rep ? (uint8_t)(nstab | ((sr * sr + si * si < 1e-20) ? 0x80 : 0)) : 0;
+            cnt[r] = rep ? 1 : 0;
+            if (++ru == cu) {                              // next down pattern, up patterns start over
+                ru = 0;
+                u = (R.n_up > 0) ? ((1ULL << R.n_up) - 1ULL) : 0ULL;
+                d = R.n_dn > 0 ? next_same_popcount(d) & mlow : 0ULL;
+            } else {
+                u = next_same_popcount(u);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hubrepr_compact(const HubReprDev *Rp, int64_t nstates, const uint8_t *code, const int64_t *pos,
+                                                         uint64_t *reps, uint8_t *info)
+{
+    const HubReprDev &R = *Rp;
+    const uint64_t cu = R.binom[R.n_sites][R.n_up];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < nstates; r += stride) {
+        if (!code[r]) continue;
+        const uint64_t u = unrank_k(R.binom, R.n_sites, R.n_up, (uint64_t)r % cu), d = unrank_k(R.binom, R.n_sites, R.n_dn, (uint64_t)r / cu);
+        reps[pos[r]] = u | (d << R.n_sites);
+        info[pos[r]] = code[r];
+    }
+}
+
+// one row of the sector operator into (cols, vals), columns ascending, duplicates merged; returns its length
+__device__ int hubrepr_row(const HubReprDev &R, const uint64_t *tab, const uint64_t *reps, const uint8_t *info, int64_t dim, int64_t i,
+                           int32_t *cols, d2 *vals)
+{
+    const uint8_t ci = info[i];
+    if (ci & 0x80) {
+        cols[0] = (int32_t)i;
+        vals[0] = d2{R.fake_pos + (double)i / (double)dim, 0.0};
+        return 1;
+    }
+    const double sa = (double)(ci & 0x7f);
+    const uint64_t a = reps[i];
+    const uint64_t mlow = (1ULL << R.n_sites) - 1ULL;
+    const uint64_t au = a & mlow, ad = a >> R.n_sites;
+    int n = 1;
+    cols[0] = (int32_t)i;
+    d2 dg = {R.U * (double)__popcll(au & ad), 0.0};
+    for (int t = 0; t < R.n_terms; ++t) {
+        const int ti = R.ti[t], tj = R.tj[t];
+        for (int sp = 0; sp < 2; ++sp) {
+            const double ar = sp ? R.adn[t][0] : R.aup[t][0], ai = sp ? R.adn[t][1] : R.aup[t][1];
+            if (ar == 0.0 && ai == 0.0) continue;
+            const uint64_t occ = sp ? ad : au;
+            if (ti == tj) {                                // number operator: diagonal
+                if ((occ >> ti) & 1ULL) dg += d2{ar, ai};
+                continue;
+            }
+            // row a of O = conj of O^dag |a>: the particle moves from ti to tj
+            if (!((occ >> ti) & 1ULL) || ((occ >> tj) & 1ULL)) continue;
+            const int lo_s = ti < tj ? ti : tj, hi_s = ti < tj ? tj : ti;
+            const uint64_t between = ((1ULL << hi_s) - 1ULL) & ~((2ULL << lo_s) - 1ULL);
+            int par = __popcll(occ & between) & 1;
+            const uint64_t occ2 = occ ^ (1ULL << ti) ^ (1ULL << tj);
+            const uint64_t c = sp ? (au | (occ2 << R.n_sites)) : (occ2 | (ad << R.n_sites));
+            int g = 0, pt = 0;
+            const uint64_t b = hubrepr_canonical(R, tab, c, &g, &pt);
+            par ^= pt;
+            int64_t lo = 0, hi = dim;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (reps[mid] < b) lo = mid + 1;
+                else hi = mid;
+            }
+            const uint8_t cj = info[lo];
+            if (cj & 0x80) continue;                       // zero-norm target
+            const double f = (par ? -1.0 : 1.0) * sqrt((double)(cj & 0x7f) / sa);
+            // amp * conj(chi(g*)) * f
+            const double cr = R.chr[2 * g], cim = -R.chr[2 * g + 1];
+            const d2 v = {f * (ar * cr - ai * cim), f * (ar * cim + ai * cr)};
+            if (lo == i) {
+                dg += v;
+                continue;
+            }
+            int q = 1;
+            while (q < n && cols[q] != (int32_t)lo) ++q;
+            if (q < n) {
+                vals[q] += v;
+            } else if (n < kReprMaxRow) {
+                cols[n] = (int32_t)lo;
+                vals[n] = v;
+                ++n;
+            }
+        }
+    }
+    vals[0] = dg;
+    int m = 1;
+    for (int q = 1; q < n; ++q)
+        if (vals[q].x * vals[q].x + vals[q].y * vals[q].y >= 1e-28) {
+            cols[m] = cols[q];
+            vals[m] = vals[q];
+            ++m;
+        }
+    for (int q = 1; q < m; ++q) {
+        const int32_t c = cols[q];
+        const d2 v = vals[q];
+        int p = q - 1;
+        while (p >= 0 && cols[p] > c) {
+            cols[p + 1] = cols[p];
+            vals[p + 1] = vals[p];
+            --p;
+        }
+        cols[p + 1] = c;
+        vals[p + 1] = v;
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(128) void k_hubrepr_count(const HubReprDev *Rp, const uint64_t *tab, const uint64_t *reps,
+                                                       const uint8_t *info, int64_t dim, int64_t r0, int64_t r1, int32_t *cnt)
+{
+    int32_t cols[kReprMaxRow];
+    d2 vals[kReprMaxRow];
+    const int64_t stride = (int64_t)gridDim.x * 128;
+    for (int64_t i = r0 + (int64_t)blockIdx.x * 128 + threadIdx.x; i < r1; i += stride)
+        cnt[i - r0] = hubrepr_row(*Rp, tab, reps, info, dim, i, cols, vals);
+}
+
+__global__ __launch_bounds__(128) void k_hubrepr_fill(const HubReprDev *Rp, const uint64_t *tab, const uint64_t *reps,
+                                                      const uint8_t *info, int64_t dim, int64_t r0, int64_t r1, const int64_t *ia,
+                                                      int32_t *ja, d2 *val)
+{
+    int32_t cols[kReprMaxRow];
+    d2 vals[kReprMaxRow];
+    const int64_t stride = (int64_t)gridDim.x * 128;
+    for (int64_t i = r0 + (int64_t)blockIdx.x * 128 + threadIdx.x; i < r1; i += stride) {
+        const int m = hubrepr_row(*Rp, tab, reps, info, dim, i, cols, vals);
+        const int64_t p0 = ia[i - r0];
+        for (int q = 0; q < m; ++q) {
+            ja[p0 + q] = cols[q];
+            val[p0 + q] = vals[q];
+        }
+    }
+}
+
+}  // namespace
+}  // namespace qbh
+
+extern "C" int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_terms, const int32_t *term_sites,
+                                    const qbh_z *amp_up, const qbh_z *amp_dn, double U, int n_trans, const int32_t *perms,
+                                    const double *chars, double fake_pos, int shard, int n_shards, int64_t *dim_out,
+                                    const qbh_opts *opts)
+{
+    using namespace qbh;
+    if (!out || !term_sites || !amp_up || !amp_dn || !perms || !chars || n_sites <= 0 || n_sites > 31 || n_up < 0 || n_up > n_sites ||
+        n_dn < 0 || n_dn > n_sites || n_terms < 0 || n_trans < 1 || n_trans > kReprMaxTrans || n_shards < 1 || shard < 0 ||
+        shard >= n_shards) {
+        set_error("qbh_gen_hubbard_repr: invalid argument (<= 31 sites, <= 64 translations)");
+        return QBH_EINVAL;
+    }
+    if (qbh_device_count() <= 0) {
+        set_error("no HIP device visible");
+        return QBH_ENODEVICE;
+    }
+    if (opts && opts->device >= 0) QBH_HIP(hipSetDevice(opts->device));
+    for (int i = 0; i < n_sites; ++i)
+        if (perms[i] != i) {
+            set_error("qbh_gen_hubbard_repr: translation 0 must be the identity");
+            return QBH_EINVAL;
+        }
+    // merge terms on the same (i, j)
+    std::map<std::pair<int, int>, std::array<double, 4>> tmap;
+    for (int t = 0; t < n_terms; ++t) {
+        const int i = term_sites[2 * t], j = term_sites[2 * t + 1];
+        if (i < 0 || i >= n_sites || j < 0 || j >= n_sites) {
+            set_error("qbh_gen_hubbard_repr: term %d acts on a site outside the lattice", t);
+            return QBH_EINVAL;
+        }
+        auto &a = tmap[{i, j}];
+        a[0] += amp_up[t].re;
+        a[1] += amp_up[t].im;
+        a[2] += amp_dn[t].re;
+        a[3] += amp_dn[t].im;
+    }
+    if ((int)tmap.size() > kHubReprMaxTerms || 2 * (int)tmap.size() + 1 > kReprMaxRow) {
+        set_error("qbh_gen_hubbard_repr: too many distinct one-body terms (%d)", (int)tmap.size());
+        return QBH_EUNSUPP;
+    }
+    std::vector<HubReprDev> rr(1);
+    HubReprDev &R = rr[0];
+    memset(&R, 0, sizeof(R));
+    for (int p = 0; p <= 64; ++p)
+        for (int k = 0; k <= 33; ++k) R.binom[p][k] = binom_u64(p, k);
+    R.n_sites = n_sites;
+    R.n_up = n_up;
+    R.n_dn = n_dn;
+    for (const auto &kv : tmap) {
+        R.ti[R.n_terms] = (int8_t)kv.first.first;
+        R.tj[R.n_terms] = (int8_t)kv.first.second;
+        R.aup[R.n_terms][0] = kv.second[0];
+        R.aup[R.n_terms][1] = kv.second[1];
+        R.adn[R.n_terms][0] = kv.second[2];
+        R.adn[R.n_terms][1] = kv.second[3];
+        R.n_terms++;
+    }
+    R.U = U;
+    R.fake_pos = fake_pos;
+    R.n_trans = n_trans;
+    R.n_chunks = (n_sites + 5) / 6;
+    for (int g = 0; g < n_trans; ++g) {
+        R.chr[2 * g] = chars[2 * g];
+        R.chr[2 * g + 1] = chars[2 * g + 1];
+        std::vector<int> seen((size_t)n_sites, 0);
+        for (int s = 0; s < n_sites; ++s) {
+            const int img = perms[(size_t)g * n_sites + s];
+            if (img < 0 || img >= n_sites || seen[(size_t)img]++) {
+                set_error("qbh_gen_hubbard_repr: translation %d is not a site permutation", g);
+                return QBH_EINVAL;
+            }
+            R.perm[g * n_sites + s] = (int8_t)img;
+        }
+    }
+    std::vector<uint64_t> tab((size_t)n_trans * R.n_chunks * 64, 0ULL);
+    for (int g = 0; g < n_trans; ++g)
+        for (int c = 0; c < R.n_chunks; ++c)
+            for (int v = 0; v < 64; ++v) {
+                uint64_t m = 0;
+                for (int b = 0; b < 6; ++b) {
+                    const int site = 6 * c + b;
+                    if (site < n_sites && ((v >> b) & 1)) m |= 1ULL << perms[(size_t)g * n_sites + site];
+                }
+                tab[((size_t)g * R.n_chunks + c) * 64 + v] = m;
+            }
+    const long double nst = (long double)binom_u64(n_sites, n_up) * (long double)binom_u64(n_sites, n_dn);
+    if (nst >= (long double)(1ULL << 40)) {
+        set_error("qbh_gen_hubbard_repr: sector too large to enumerate");
+        return QBH_EUNSUPP;
+    }
+    const int64_t nstates = (int64_t)(binom_u64(n_sites, n_up) * binom_u64(n_sites, n_dn));
+
+    std::vector<void *> pool;
+    HubReprDev *d_R = nullptr;
+    uint64_t *d_tab = nullptr;
+    QBH_TRY(upload(rr, &d_R, pool));
+    QBH_TRY(upload(tab, &d_tab, pool));
+    uint8_t *d_code = nullptr, *d_info = nullptr;
+    int32_t *d_cnt = nullptr;
+    int64_t *d_pos = nullptr, *d_ia = nullptr;
+    uint64_t *d_reps = nullptr;
+    int32_t *d_ja = nullptr;
+    d2 *d_val = nullptr;
+    int rc = QBH_OK;
+    int64_t dim = 0, nnz = 0;
+    auto cleanup = [&](bool all) {
+        free_pool(pool);
+        for (void *q : {(void *)d_code, (void *)d_cnt, (void *)d_pos, (void *)d_reps, (void *)d_info})
+            if (q) (void)hipFree(q);
+        if (all)
+            for (void *q : {(void *)d_ia, (void *)d_ja, (void *)d_val})
+                if (q) (void)hipFree(q);
+    };
+#define QBH_R(call)                                                                         \
+    do {                                                                                    \
+        hipError_t _e = (call);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            set_error("qbh_gen_hubbard_repr: %s failed: %s", #call, hipGetErrorString(_e)); \
+            (void)hipGetLastError();                                                        \
+            cleanup(true);                                                                  \
+            return _e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP;                       \
+        }                                                                                   \
+    } while (0)
+    QBH_R(hipMalloc(&d_code, (size_t)nstates));
+    QBH_R(hipMalloc(&d_cnt, (size_t)nstates * sizeof(int32_t)));
+    QBH_R(hipMalloc(&d_pos, (size_t)(nstates + 1) * sizeof(int64_t)));
+    hipLaunchKernelGGL(k_hubrepr_flag, dim3(blas_grid((nstates + 15) / 16)), dim3(256), 0, 0, d_R, d_tab, nstates, d_code, d_cnt);
+    QBH_R(hipGetLastError());
+    rc = exclusive_scan(d_cnt, nstates, d_pos, 0);
+    if (rc != QBH_OK) {
+        cleanup(true);
+        return rc;
+    }
+    QBH_R(hipMemcpy(&dim, d_pos + nstates, sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (dim <= 0 || dim >= 2147483647LL) {
+        set_error("qbh_gen_hubbard_repr: sector dimension %lld out of range", (long long)dim);
+        cleanup(true);
+        return QBH_EUNSUPP;
+    }
+    QBH_R(hipMalloc(&d_reps, (size_t)dim * sizeof(uint64_t)));
+    QBH_R(hipMalloc(&d_info, (size_t)dim));
+    hipLaunchKernelGGL(k_hubrepr_compact, dim3(blas_grid(nstates)), dim3(256), 0, 0, d_R, nstates, d_code, d_pos, d_reps, d_info);
+    QBH_R(hipGetLastError());
+    QBH_R(hipDeviceSynchronize());
+    (void)hipFree(d_code); d_code = nullptr;
+    (void)hipFree(d_cnt); d_cnt = nullptr;
+    (void)hipFree(d_pos); d_pos = nullptr;
+    const int64_t nblk = (dim + n_shards - 1) / n_shards;
+    const int64_t r0 = std::min<int64_t>((int64_t)shard * nblk, dim), r1 = std::min<int64_t>(r0 + nblk, dim);
+    const int64_t nloc = r1 - r0;
+    if (nloc <= 0) {
+        set_error("qbh_gen_hubbard_repr: shard %d of %d is empty (dim %lld)", shard, n_shards, (long long)dim);
+        cleanup(true);
+        return QBH_EINVAL;
+    }
+    QBH_R(hipMalloc(&d_cnt, (size_t)nloc * sizeof(int32_t)));
+    QBH_R(hipMalloc(&d_ia, (size_t)(nloc + 1) * sizeof(int64_t)));
+    const int rgrid = (int)std::min<int64_t>((nloc + 127) / 128, 256 * 16);
+    hipLaunchKernelGGL(k_hubrepr_count, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_cnt);
+    QBH_R(hipGetLastError());
+    rc = exclusive_scan(d_cnt, nloc, d_ia, 0);
+    if (rc != QBH_OK) {
+        cleanup(true);
+        return rc;
+    }
+    QBH_R(hipMemcpy(&nnz, d_ia + nloc, sizeof(int64_t), hipMemcpyDeviceToHost));
+    QBH_R(hipMalloc(&d_ja, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t)));
+    QBH_R(hipMalloc(&d_val, (size_t)std::max<int64_t>(nnz, 1) * sizeof(d2)));
+    hipLaunchKernelGGL(k_hubrepr_fill, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_ia, d_ja, d_val);
+    QBH_R(hipGetLastError());
+    QBH_R(hipDeviceSynchronize());
+#undef QBH_R
+    cleanup(false);
+    if (dim_out) *dim_out = dim;
+    return qbh_csr_create_device(out, nloc, dim, r0, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, opts);
 }

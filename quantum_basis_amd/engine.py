@@ -173,6 +173,35 @@ class csr_mat:
               "qbh_gen_heisenberg_repr")
         return cls(0, None, None, None, opts=opts, _handle=h)
 
+    @classmethod
+    def hubbard_repr(cls, n_sites, n_up, n_dn, bonds, perms, chars, t=1.0, U=1.1, fake_pos=100.0, shard=(0, 1), opts=None,
+                     terms=None):
+        """Hubbard family in a translation-symmetric sector, assembled on the device (qbh_gen_hubbard_repr; counterpart of
+        model::enumerate_basis_repr + generate_Ham_sparse_repr for the reference's
+        examples/trans_symmetric/latt_square/square_Fermi_Hubbard.cc).  Default operator: -t sum_<ij>,sigma (c+_i c_j + h.c.)
+        + U sum_i n_up n_dn over `bonds` (a bond listed twice counts twice, as in the reference's 4x2 torus).  terms =
+        [(i, j, amp_up, amp_dn), ...] replaces the hopping part by explicit directed one-body terms amp * c+_i c_j (they
+        must form a translation-invariant operator; U still applies -- pass U=0 for a pure one-body observable)."""
+        _lib.require_gpu()
+        opts = opts if opts is not None else make_opts()
+        if terms is None:
+            terms = []
+            for (i, j) in np.asarray(bonds, dtype=np.int64).reshape(-1, 2):
+                terms.append((int(i), int(j), -t, -t))
+                terms.append((int(j), int(i), -t, -t))
+        sites = np.ascontiguousarray(np.array([[a[0], a[1]] for a in terms], dtype=np.int32).reshape(-1, 2))
+        aup = np.ascontiguousarray(np.array([a[2] for a in terms], dtype=np.complex128))
+        adn = np.ascontiguousarray(np.array([a[3] for a in terms], dtype=np.complex128))
+        p = np.ascontiguousarray(np.asarray(perms, dtype=np.int32))
+        c = np.ascontiguousarray(np.asarray(chars, dtype=np.complex128))
+        assert p.shape == (len(c), n_sites)
+        h = C.c_void_p()
+        dim = C.c_int64(0)
+        check(lib().qbh_gen_hubbard_repr(C.byref(h), n_sites, n_up, n_dn, len(terms), _p(sites), _p(aup), _p(adn), float(U), len(c),
+                                         _p(p), _p(c), fake_pos, int(shard[0]), int(shard[1]), C.byref(dim), C.byref(opts)),
+              "qbh_gen_hubbard_repr")
+        return cls(0, None, None, None, opts=opts, _handle=h)
+
     # ---- reference interface -------------------------------------------------------------
     def dimension(self):
         return self.dim

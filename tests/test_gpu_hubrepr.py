@@ -1,0 +1,244 @@
+"""qbh_gen_hubbard_repr: the Hubbard family in translation-symmetric (momentum) sectors, assembled on the device --
+counterpart of model::enumerate_basis_repr + generate_Ham_sparse_repr (src/model.cc:687-836) on the path of
+examples/trans_symmetric/latt_square/square_Fermi_Hubbard.cc.
+
+Pinned three ways:
+  * entry by entry against an explicit projection in numpy: the full fermionic operator (operator order all-up then
+    all-down, hop signs from the occupied sites in between), the translation operators WITH their fermion signs, and
+    the momentum states |a,k> = (|G||S_a|)^(-1/2) sum_g chi_k(g) T_g |a> built from them;
+  * against the reference's own asserted numbers: the eight sector ground-state energies of the 4x2 torus with 4+4
+    electrons (square_Fermi_Hubbard.cc:146-153) and <c+_{1,up} c_{5,up}> = 0.3957690742 in the k = (0,0) ground state
+    (:182, through the translation-averaged operator of model::measure_repr_static, src/model.cc:1874-1888);
+  * row shards of a sector against the whole.
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+import quantum_basis_amd as q
+from quantum_basis_amd import lattices
+
+pytestmark = pytest.mark.gpu
+
+
+def _words(n, nu, nd):
+    """all (u, d) occupation words u | d << n, ascending"""
+    ups = [sum(1 << i for i in c) for c in itertools.combinations(range(n), nu)]
+    dns = [sum(1 << i for i in c) for c in itertools.combinations(range(n), nd)]
+    return sorted(u | (d << n) for u in ups for d in dns)
+
+
+def _hop(occ, i, j):
+    """c+_i c_j on one species' occupation word: (sign, new word) or None"""
+    if not (occ >> j) & 1 or ((occ >> i) & 1 and i != j):
+        return None
+    if i == j:
+        return 1, occ
+    lo, hi = min(i, j), max(i, j)
+    between = ((1 << hi) - 1) & ~((2 << lo) - 1)
+    return (-1) ** bin(occ & between).count("1"), occ ^ (1 << i) ^ (1 << j)
+
+
+def _full_operator(n, words, index, terms, U):
+    """dense matrix O[b][a] of sum_t amp_up c+_i c_j (up) + amp_dn c+_i c_j (dn) + U sum n_up n_dn"""
+    m = (1 << n) - 1
+    O = np.zeros((len(words), len(words)), dtype=np.complex128)
+    for a, w in enumerate(words):
+        u, d = w & m, w >> n
+        O[a, a] += U * bin(u & d).count("1")
+        for (i, j, au, ad) in terms:
+            if au != 0:
+                r = _hop(u, i, j)
+                if r:
+                    O[index[r[1] | (d << n)], a] += au * r[0]
+            if ad != 0:
+                r = _hop(d, i, j)
+                if r:
+                    O[index[u | (r[1] << n)], a] += ad * r[0]
+    return O
+
+
+def _image(n, perm, occ):
+    """image word and the parity of sorting the images of the occupied sites"""
+    imgs = [perm[i] for i in range(n) if (occ >> i) & 1]
+    inv = sum(1 for x in range(len(imgs)) for y in range(x + 1, len(imgs)) if imgs[x] > imgs[y])
+    return sum(1 << p for p in imgs), (-1) ** inv
+
+
+def _translation(n, words, index, perm):
+    m = (1 << n) - 1
+    T = np.zeros((len(words), len(words)))
+    for a, w in enumerate(words):
+        iu, su = _image(n, perm, w & m)
+        idn, sd = _image(n, perm, w >> n)
+        T[index[iu | (idn << n)], a] = su * sd
+    return T
+
+
+def _sector_reference(n, nu, nd, terms, U, perms, chars, fake_pos=100.0):
+    """(representatives ascending, explicit sector matrix with the generator's conventions)"""
+    words = _words(n, nu, nd)
+    index = {w: i for i, w in enumerate(words)}
+    O = _full_operator(n, words, index, terms, U)
+    Ts = [_translation(n, words, index, p) for p in perms]
+    m = (1 << n) - 1
+    reps = []
+    for w in words:
+        imgs = [_image(n, p, w & m)[0] | (_image(n, p, w >> n)[0] << n) for p in perms]
+        if min(imgs) == w:
+            reps.append(w)
+    P = sum(c * T for c, T in zip(chars, Ts)) / len(perms)
+    dim = len(reps)
+    psi = np.zeros((len(words), dim), dtype=np.complex128)
+    alive = np.zeros(dim, dtype=bool)
+    for r, w in enumerate(reps):
+        v = P[:, index[w]]
+        nv = np.linalg.norm(v)
+        if nv > 1e-10:
+            psi[:, r] = v / nv
+            alive[r] = True
+    Hk = psi.conj().T @ O @ psi
+    for r in range(dim):
+        if not alive[r]:
+            Hk[r, :] = 0
+            Hk[:, r] = 0
+            Hk[r, r] = fake_pos + r / dim
+    return reps, alive, Hk
+
+
+def _dense(A):
+    ia, ja, val = A.download()
+    dim = A.info().ncols
+    M = np.zeros((len(ia) - 1, dim), dtype=np.complex128)
+    for r in range(len(ia) - 1):
+        M[r, ja[ia[r]:ia[r + 1]]] = val[ia[r]:ia[r + 1]]
+    return M
+
+
+def _hubbard_terms(bonds, t):
+    out = []
+    for (i, j) in bonds:
+        out += [(i, j, -t, -t), (j, i, -t, -t)]
+    return out
+
+
+CASES = [
+    # (Lx, Ly, n_up, n_dn): odd and even particle numbers (the sign of a cyclic shift depends on them), a stabilised
+    # sector with zero-norm representatives, a two-dimensional torus with the doubled y bond
+    (6, 1, 3, 3),
+    (6, 1, 2, 3),
+    (4, 1, 2, 2),
+    (3, 2, 2, 3),
+    (4, 2, 2, 1),
+    (2, 2, 2, 2),
+]
+
+
+@pytest.mark.parametrize("Lx,Ly,nu,nd", CASES)
+def test_sector_matrix_matches_explicit_projection(Lx, Ly, nu, nd):
+    n = Lx * Ly
+    bonds = lattices.chain(Lx) if Ly == 1 else lattices.square(Lx, Ly)
+    perms, shifts = lattices.translations(Lx, Ly)
+    t, U = 1.0, 1.1
+    total = 0
+    for k in itertools.product(range(Lx), range(Ly)):
+        chars = lattices.characters(shifts, k, (Lx, Ly))
+        reps, alive, Hk = _sector_reference(n, nu, nd, _hubbard_terms(bonds, t), U, perms, chars)
+        A = q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, chars, t=t, U=U, opts=q.make_opts(value_dict=0))
+        M = _dense(A)
+        assert M.shape == Hk.shape, (k, M.shape, Hk.shape)
+        assert np.abs(M - Hk).max() < 1e-12, (k, np.abs(M - Hk).max())
+        assert np.abs(M - M.conj().T).max() < 1e-13
+        total += int(alive.sum())
+        A.destroy()
+    # the momentum sectors together span the whole fixed-particle-number space
+    assert total == len(_words(n, nu, nd))
+
+
+def test_non_hermitian_one_body_operator():
+    """a directed, translation-averaged hop (what measure_repr_static builds) is filled as O[a][b], not as its adjoint"""
+    Lx, Ly, nu, nd = 4, 2, 2, 2
+    n = Lx * Ly
+    perms, shifts = lattices.translations(Lx, Ly)
+    terms = [(p[1], p[4], 1.0 / len(perms) * (1 + 0.5j), 0.25 / len(perms)) for p in perms]
+    for k in [(0, 0), (1, 0), (2, 1)]:
+        chars = lattices.characters(shifts, k, (Lx, Ly))
+        reps, alive, Ok = _sector_reference(n, nu, nd, terms, 0.0, perms, chars, fake_pos=7.0)
+        A = q.csr_mat.hubbard_repr(n, nu, nd, None, perms, chars, U=0.0, terms=terms, fake_pos=7.0, opts=q.make_opts(value_dict=0))
+        M = _dense(A)
+        assert np.abs(M - Ok).max() < 1e-12
+        A.destroy()
+
+
+def test_reference_asserted_sector_energies_and_correlator():
+    """examples/trans_symmetric/latt_square/square_Fermi_Hubbard.cc:146-153 and :182"""
+    Lx, Ly, nu, nd = 4, 2, 4, 4
+    n = Lx * Ly
+    bonds = lattices.square(Lx, Ly)
+    perms, shifts = lattices.translations(Lx, Ly)
+    want = {(0, 0): -14.07605866, (0, 1): -10.50470669, (1, 0): -12.16861094, (1, 1): -12.19847764,
+            (2, 0): -10.54300366, (2, 1): -14.03137587, (3, 0): -12.16861094, (3, 1): -12.19847764}
+    dims = 0
+    for k, e_ref in want.items():
+        chars = lattices.characters(shifts, k, (Lx, Ly))
+        A = q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, chars, t=1.0, U=1.1)
+        dim = A.info().ncols
+        M = _dense(A)
+        ev = np.linalg.eigvalsh(M)
+        assert abs(ev[0] - e_ref) < 1e-8, (k, ev[0], e_ref)
+        dims += int(np.sum(np.abs(np.diag(M)) < 50.0))
+        if k == (0, 0):
+            w, vec = np.linalg.eigh(M)
+            psi = np.ascontiguousarray(vec[:, 0])
+            # O_t = (1/N) sum_R c+_{R(1),up} c_{R(5),up}
+            terms = [(p[1], p[5], 1.0 / len(perms), 0.0) for p in perms]
+            Ot = q.csr_mat.hubbard_repr(n, nu, nd, None, perms, chars, U=0.0, terms=terms, fake_pos=0.0)
+            y = np.zeros(dim, dtype=np.complex128)
+            Ot.MultMv(psi, y)
+            m1 = np.vdot(psi, y)
+            assert abs(m1 - 0.3957690742) < 1e-8, m1
+            Ot.destroy()
+            # and the device Lanczos driver on the sector operator, as locate_E0_lanczos(which_sym::repr) runs it
+            e0 = _lanczos_e0(A, dim)
+            assert abs(e0 - e_ref) < 1e-8, (e0, e_ref)
+        A.destroy()
+    assert dims == 4900          # C(8,4)^2 states in all sectors together
+
+
+def _lanczos_e0(A, dim):
+    maxit = 300
+    dv = A.vec(3)
+    A.randomize(dv.at(0), 7)
+    hess = np.zeros(2 * maxit)
+    m = q.lanczos(0, maxit - 1, maxit, dim, A, None, hess, "sr_val0", device_v=dv)
+    ritz, _ = q.hess_eigen(hess, maxit, m, "sr")
+    dv.free()
+    return ritz[0]
+
+
+def test_row_shards_of_a_sector():
+    Lx, Ly, nu, nd = 4, 2, 3, 2
+    n = Lx * Ly
+    bonds = lattices.square(Lx, Ly)
+    perms, shifts = lattices.translations(Lx, Ly)
+    chars = lattices.characters(shifts, (1, 1), (Lx, Ly))
+    A = q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, chars, opts=q.make_opts(value_dict=0))
+    whole = _dense(A)
+    parts = [q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, chars, shard=(r, 3), opts=q.make_opts(value_dict=0)) for r in range(3)]
+    stacked = np.vstack([_dense(p) for p in parts])
+    assert stacked.shape == whole.shape and np.abs(stacked - whole).max() == 0.0
+    for p in parts:
+        p.destroy()
+    A.destroy()
+
+
+def test_rejects_bad_arguments():
+    perms, shifts = lattices.translations(4, 1)
+    chars = lattices.characters(shifts, (0, 0), (4, 1))
+    with pytest.raises(q._lib.QbhError):
+        q.csr_mat.hubbard_repr(4, 2, 2, [(0, 7)], perms, chars)                       # site outside the lattice
+    bad = [list(p) for p in perms]
+    bad[1][0] = bad[1][1]
+    with pytest.raises(q._lib.QbhError):
+        q.csr_mat.hubbard_repr(4, 2, 2, lattices.chain(4), bad, chars)                # not a permutation
