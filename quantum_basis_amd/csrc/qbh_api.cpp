@@ -270,6 +270,31 @@ int split_shard(qbh_csr *A)
     return QBH_OK;
 }
 
+// row-block geometry of the part(s) and the partial-sum workspace; callable again after the shard has been split
+int build_geometry(qbh_csr *A)
+{
+    for (void *q : {(void *)A->d_rb, (void *)A->d_bp, (void *)A->rem.d_rb, (void *)A->rem.d_bp})
+        if (q) (void)hipFree(q);
+    A->d_rb = nullptr;
+    A->d_bp = nullptr;
+    A->rem.d_rb = nullptr;
+    A->rem.d_bp = nullptr;
+    QBH_TRY(setup_geometry(A, A->d_ia, A->nnz, A->dict_mode, &A->npb, &A->tpr, &A->unroll, &A->window, &A->n_blocks, &A->d_rb,
+                           &A->d_bp, &A->grid));
+    int grid_max = A->grid;
+    if (A->has_rem) {
+        CsrPart &R = A->rem;
+        QBH_TRY(setup_geometry(A, R.d_ia, R.nnz, A->dict_mode, &R.npb, &R.tpr, &R.unroll, &R.window, &R.n_blocks, &R.d_rb, &R.d_bp,
+                               &R.grid));
+        grid_max = std::max(grid_max, R.grid);
+    }
+    const size_t nparts = (size_t)std::max(grid_max, qbh::kMaxRedBlocks);
+    if (A->d_partials) (void)hipFree(A->d_partials);
+    A->d_partials = nullptr;
+    QBH_HIP(hipMalloc(&A->d_partials, nparts * 16 * sizeof(double)));
+    return QBH_OK;
+}
+
 // geometry + workspace once the CSR arrays are in HBM
 int finalize(qbh_csr *A)
 {
@@ -310,19 +335,10 @@ int finalize(qbh_csr *A)
         for (double v : hp) sum += v;
         A->values_real = (sum == 0.0);
     }
-    QBH_TRY(split_shard(A));
-
-    QBH_TRY(setup_geometry(A, A->d_ia, A->nnz, A->dict_mode, &A->npb, &A->tpr, &A->unroll, &A->window, &A->n_blocks, &A->d_rb,
-                           &A->d_bp, &A->grid));
-    int grid_max = A->grid;
-    if (A->has_rem) {
-        CsrPart &R = A->rem;
-        QBH_TRY(setup_geometry(A, R.d_ia, R.nnz, A->dict_mode, &R.npb, &R.tpr, &R.unroll, &R.window, &R.n_blocks, &R.d_rb, &R.d_bp,
-                               &R.grid));
-        grid_max = std::max(grid_max, R.grid);
-    }
-    const size_t nparts = (size_t)std::max(grid_max, qbh::kMaxRedBlocks);
-    QBH_HIP(hipMalloc(&A->d_partials, nparts * 16 * sizeof(double)));
+    // The local / remote column split of a row shard only pays under a communicator (the local part runs while the
+    // all-gather is in flight): it is made when one is attached (qbh_csr_set_comm), not here -- a shard that is driven
+    // with a full-length x and no communicator keeps ONE part and one launch per SpMV.
+    QBH_TRY(build_geometry(A));
     QBH_HIP(hipStreamSynchronize(s));
     A->stats = qbh_stats{};
     A->stats.ms_spmv_min = std::numeric_limits<double>::infinity();
@@ -696,6 +712,13 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
     A->comm = *comm;
     A->comm.row_cuts = A->comm_cuts.empty() ? nullptr : A->comm_cuts.data();
     A->has_comm = true;
+    if (A->kind == 0 && !A->has_rem && A->nrows < A->ncols) {      // first communicator on a stored row shard: split it now
+        Bind bind(A);
+        QBH_HIP(hipStreamSynchronize(A->stream));
+        QBH_TRY(split_shard(A));
+        if (A->has_rem) QBH_TRY(build_geometry(A));
+        QBH_HIP(hipStreamSynchronize(A->stream));
+    }
     return QBH_OK;
 }
 

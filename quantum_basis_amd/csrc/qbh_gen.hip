@@ -1459,6 +1459,7 @@ namespace qbh {
 namespace {
 
 constexpr int kHubReprMaxTerms = 512;
+constexpr int kHubReprMaxRow = 100;       // distinct columns in one row: one move per bond and species + the diagonal
 
 struct HubReprDev {
     uint64_t binom[65][34];
@@ -1530,63 +1531,92 @@ __device__ __forceinline__ uint64_t hubrepr_canonical(const HubReprDev &R, const
     return best;
 }
 
-// pass 1 over all C(n, n_up) * C(n, n_dn) words in ascending order (rank = rank(d) * C(n, n_up) + rank(u)):
-// code = 0 if not a representative, else |S| | (zero-norm << 7)
+// pass 1 over all C(n, n_up) * C(n, n_dn) words in ascending order (rank = rank(d) * C(n, n_up) + rank(u)), one workgroup
+// per chunk of kHubChunk consecutive words: code = 0 if not a representative, else |S| | (zero-norm << 7); the number of
+// representatives per CHUNK (no per-word arrays besides the code byte: 4x5 at half filling has 3.4e10 words)
+constexpr int kHubRun = 16, kHubChunk = kHubRun * 256;
+
 __global__ __launch_bounds__(256) void k_hubrepr_flag(const HubReprDev *Rp, const uint64_t *tab, int64_t nstates, uint8_t *code,
-                                                      int32_t *cnt)
+                                                      int32_t *chunk_cnt, int64_t nchunks)
 {
     const HubReprDev &R = *Rp;
-    constexpr int RUN = 16;
+    __shared__ int wsum[4];
     const uint64_t cu = R.binom[R.n_sites][R.n_up];
     const uint64_t mlow = (1ULL << R.n_sites) - 1ULL;
-    const int64_t nruns = (nstates + RUN - 1) / RUN;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t run = (int64_t)blockIdx.x * 256 + threadIdx.x; run < nruns; run += stride) {
-        const int64_t r0 = run * RUN, r1 = (r0 + RUN < nstates) ? r0 + RUN : nstates;
-        uint64_t ru = (uint64_t)r0 % cu;
-        uint64_t u = unrank_k(R.binom, R.n_sites, R.n_up, ru), d = unrank_k(R.binom, R.n_sites, R.n_dn, (uint64_t)r0 / cu);
-        for (int64_t r = r0; r < r1; ++r) {
-            const uint64_t s = u | (d << R.n_sites);
-            bool rep = true;
-            int nstab = 1;
-            double sr = R.chr[0], si = R.chr[1];
-            for (int g = 1; g < R.n_trans; ++g) {
-                const uint64_t t = hubrepr_translate(R, tab, g, s);
-                if (t < s) {
-                    rep = false;
-                    break;
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int64_t r0 = chunk * kHubChunk + (int64_t)threadIdx.x * kHubRun;
+        const int64_t r1 = (r0 + kHubRun < nstates) ? r0 + kHubRun : nstates;
+        int mine = 0;
+        if (r0 < nstates) {
+            uint64_t ru = (uint64_t)r0 % cu;
+            uint64_t u = unrank_k(R.binom, R.n_sites, R.n_up, ru), d = unrank_k(R.binom, R.n_sites, R.n_dn, (uint64_t)r0 / cu);
+            for (int64_t r = r0; r < r1; ++r) {
+                const uint64_t s = u | (d << R.n_sites);
+                bool rep = true;
+                int nstab = 1;
+                double sr = R.chr[0], si = R.chr[1];
+                for (int g = 1; g < R.n_trans; ++g) {
+                    const uint64_t t = hubrepr_translate(R, tab, g, s);
+                    if (t < s) {
+                        rep = false;
+                        break;
+                    }
+                    if (t == s) {
+                        const double sg = (hubrepr_parity(R, g, u) ^ hubrepr_parity(R, g, d)) ? -1.0 : 1.0;
+                        nstab++;
+                        sr += sg * R.chr[2 * g];
+                        si += sg * R.chr[2 * g + 1];
+                    }
                 }
-                if (t == s) {
-                    const double sg = (hubrepr_parity(R, g, u) ^ hubrepr_parity(R, g, d)) ? -1.0 : 1.0;
-                    nstab++;
-                    sr += sg * R.chr[2 * g];
-                    si += sg * R.chr[2 * g + 1];
+                code[r] = rep ? (uint8_t)(nstab | ((sr * sr + si * si < 1e-20) ? 0x80 : 0)) : 0;
+                mine += rep ? 1 : 0;
+                if (++ru == cu) {                          // next down pattern, up patterns start over
+                    ru = 0;
+                    u = (R.n_up > 0) ? ((1ULL << R.n_up) - 1ULL) : 0ULL;
+                    d = R.n_dn > 0 ? next_same_popcount(d) & mlow : 0ULL;
+                } else {
+                    u = next_same_popcount(u);
                 }
-            }
-            code[r] = rep ? (uint8_t)(nstab | ((sr * sr + si * si < 1e-20) ? 0x80 : 0)) : 0;
-            cnt[r] = rep ? 1 : 0;
-            if (++ru == cu) {                              // next down pattern, up patterns start over
-                ru = 0;
-                u = (R.n_up > 0) ? ((1ULL << R.n_up) - 1ULL) : 0ULL;
-                d = R.n_dn > 0 ? next_same_popcount(d) & mlow : 0ULL;
-            } else {
-                u = next_same_popcount(u);
             }
         }
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) chunk_cnt[chunk] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
 }
 
-__global__ __launch_bounds__(256) void k_hubrepr_compact(const HubReprDev *Rp, int64_t nstates, const uint8_t *code, const int64_t *pos,
-                                                         uint64_t *reps, uint8_t *info)
+// pass 2: the representatives of a chunk go to reps[chunk_pos[chunk] ...] in ascending order
+__global__ __launch_bounds__(256) void k_hubrepr_compact(const HubReprDev *Rp, int64_t nstates, const uint8_t *code,
+                                                         const int64_t *chunk_pos, int64_t nchunks, uint64_t *reps, uint8_t *info)
 {
     const HubReprDev &R = *Rp;
+    __shared__ int scan[256];
     const uint64_t cu = R.binom[R.n_sites][R.n_up];
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < nstates; r += stride) {
-        if (!code[r]) continue;
-        const uint64_t u = unrank_k(R.binom, R.n_sites, R.n_up, (uint64_t)r % cu), d = unrank_k(R.binom, R.n_sites, R.n_dn, (uint64_t)r / cu);
-        reps[pos[r]] = u | (d << R.n_sites);
-        info[pos[r]] = code[r];
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int64_t r0 = chunk * kHubChunk + (int64_t)threadIdx.x * kHubRun;
+        const int64_t r1 = (r0 + kHubRun < nstates) ? r0 + kHubRun : nstates;
+        int mine = 0;
+        for (int64_t r = r0; r < r1; ++r) mine += code[r] ? 1 : 0;
+        __syncthreads();
+        scan[threadIdx.x] = mine;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {          // inclusive Hillis-Steele scan
+            const int v = threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
+            __syncthreads();
+            scan[threadIdx.x] += v;
+            __syncthreads();
+        }
+        int64_t at = chunk_pos[chunk] + scan[threadIdx.x] - mine;
+        for (int64_t r = r0; r < r1; ++r) {
+            if (!code[r]) continue;
+            const uint64_t u = unrank_k(R.binom, R.n_sites, R.n_up, (uint64_t)r % cu);
+            const uint64_t d = unrank_k(R.binom, R.n_sites, R.n_dn, (uint64_t)r / cu);
+            reps[at] = u | (d << R.n_sites);
+            info[at] = code[r];
+            ++at;
+        }
     }
 }
 
@@ -1647,7 +1677,7 @@ __device__ int hubrepr_row(const HubReprDev &R, const uint64_t *tab, const uint6
             while (q < n && cols[q] != (int32_t)lo) ++q;
             if (q < n) {
                 vals[q] += v;
-            } else if (n < kReprMaxRow) {
+            } else if (n < kHubReprMaxRow) {
                 cols[n] = (int32_t)lo;
                 vals[n] = v;
                 ++n;
@@ -1678,21 +1708,27 @@ __device__ int hubrepr_row(const HubReprDev &R, const uint64_t *tab, const uint6
 }
 
 __global__ __launch_bounds__(128) void k_hubrepr_count(const HubReprDev *Rp, const uint64_t *tab, const uint64_t *reps,
-                                                       const uint8_t *info, int64_t dim, int64_t r0, int64_t r1, int32_t *cnt)
+                                                       const uint8_t *info, int64_t dim, int64_t r0, int64_t r1, int32_t *cnt, DictTab T)
 {
-    int32_t cols[kReprMaxRow];
-    d2 vals[kReprMaxRow];
+    __shared__ DictCollect D;
+    int32_t cols[kHubReprMaxRow];
+    d2 vals[kHubReprMaxRow];
+    bool collect = T.fp != nullptr;
+    if (T.fp != nullptr) dict_collect_init(D);
     const int64_t stride = (int64_t)gridDim.x * 128;
-    for (int64_t i = r0 + (int64_t)blockIdx.x * 128 + threadIdx.x; i < r1; i += stride)
-        cnt[i - r0] = hubrepr_row(*Rp, tab, reps, info, dim, i, cols, vals);
+    for (int64_t i = r0 + (int64_t)blockIdx.x * 128 + threadIdx.x; i < r1; i += stride) {
+        const int m = hubrepr_row(*Rp, tab, reps, info, dim, i, cols, vals);
+        cnt[i - r0] = m;
+        for (int q = 0; collect && q < m; ++q) collect = dict_collect_insert(D, T, vals[q]);
+    }
 }
 
 __global__ __launch_bounds__(128) void k_hubrepr_fill(const HubReprDev *Rp, const uint64_t *tab, const uint64_t *reps,
                                                       const uint8_t *info, int64_t dim, int64_t r0, int64_t r1, const int64_t *ia,
                                                       int32_t *ja, d2 *val)
 {
-    int32_t cols[kReprMaxRow];
-    d2 vals[kReprMaxRow];
+    int32_t cols[kHubReprMaxRow];
+    d2 vals[kHubReprMaxRow];
     const int64_t stride = (int64_t)gridDim.x * 128;
     for (int64_t i = r0 + (int64_t)blockIdx.x * 128 + threadIdx.x; i < r1; i += stride) {
         const int m = hubrepr_row(*Rp, tab, reps, info, dim, i, cols, vals);
@@ -1700,6 +1736,26 @@ __global__ __launch_bounds__(128) void k_hubrepr_fill(const HubReprDev *Rp, cons
         for (int q = 0; q < m; ++q) {
             ja[p0 + q] = cols[q];
             val[p0 + q] = vals[q];
+        }
+    }
+}
+
+template <typename CT>
+__global__ __launch_bounds__(128) void k_hubrepr_fill_coded(const HubReprDev *Rp, const uint64_t *tab, const uint64_t *reps,
+                                                            const uint8_t *info, int64_t dim, int64_t r0, int64_t r1, const int64_t *ia,
+                                                            int32_t *ja, CT *code, const d2 *dict, DictTab T)
+{
+    __shared__ DictEncode E;
+    int32_t cols[kHubReprMaxRow];
+    d2 vals[kHubReprMaxRow];
+    dict_encode_init(E);
+    const int64_t stride = (int64_t)gridDim.x * 128;
+    for (int64_t i = r0 + (int64_t)blockIdx.x * 128 + threadIdx.x; i < r1; i += stride) {
+        const int m = hubrepr_row(*Rp, tab, reps, info, dim, i, cols, vals);
+        const int64_t p0 = ia[i - r0];
+        for (int q = 0; q < m; ++q) {
+            ja[p0 + q] = cols[q];
+            code[p0 + q] = (CT)dict_encode_one(E, T, dict, vals[q]);
         }
     }
 }
@@ -1743,9 +1799,14 @@ extern "C" int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_
         a[2] += amp_dn[t].re;
         a[3] += amp_dn[t].im;
     }
-    if ((int)tmap.size() > kHubReprMaxTerms || 2 * (int)tmap.size() + 1 > kReprMaxRow) {
-        set_error("qbh_gen_hubbard_repr: too many distinct one-body terms (%d)", (int)tmap.size());
-        return QBH_EUNSUPP;
+    {   // a row holds at most one move per unordered site pair and species, plus the diagonal
+        std::map<std::pair<int, int>, int> pairs;
+        for (const auto &kv : tmap)
+            if (kv.first.first != kv.first.second) pairs[{std::min(kv.first.first, kv.first.second), std::max(kv.first.first, kv.first.second)}] = 1;
+        if ((int)tmap.size() > kHubReprMaxTerms || 2 * (int)pairs.size() + 1 > kHubReprMaxRow) {
+            set_error("qbh_gen_hubbard_repr: too many distinct one-body terms (%d on %d site pairs)", (int)tmap.size(), (int)pairs.size());
+            return QBH_EUNSUPP;
+        }
     }
     std::vector<HubReprDev> rr(1);
     HubReprDev &R = rr[0];
@@ -1809,15 +1870,17 @@ extern "C" int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_
     int64_t *d_pos = nullptr, *d_ia = nullptr;
     uint64_t *d_reps = nullptr;
     int32_t *d_ja = nullptr;
-    d2 *d_val = nullptr;
+    d2 *d_val = nullptr, *d_dict = nullptr;
+    DictBuild db;
     int rc = QBH_OK;
     int64_t dim = 0, nnz = 0;
     auto cleanup = [&](bool all) {
         free_pool(pool);
-        for (void *q : {(void *)d_code, (void *)d_cnt, (void *)d_pos, (void *)d_reps, (void *)d_info})
+        dict_build_end(&db);
+        for (void *q : {(void *)d_cnt, (void *)d_pos, (void *)d_reps, (void *)d_info})
             if (q) (void)hipFree(q);
         if (all)
-            for (void *q : {(void *)d_ia, (void *)d_ja, (void *)d_val})
+            for (void *q : {(void *)d_code, (void *)d_ia, (void *)d_ja, (void *)d_val, (void *)d_dict})
                 if (q) (void)hipFree(q);
     };
 #define QBH_R(call)                                                                         \
@@ -1830,17 +1893,20 @@ extern "C" int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_
             return _e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP;                       \
         }                                                                                   \
     } while (0)
+    // 1. which words are representatives (one code byte per word, counts per chunk of 4096 words)
+    const int64_t nchunks = (nstates + kHubChunk - 1) / kHubChunk;
+    const int egrid = (int)std::min<int64_t>(nchunks, 256 * 32);
     QBH_R(hipMalloc(&d_code, (size_t)nstates));
-    QBH_R(hipMalloc(&d_cnt, (size_t)nstates * sizeof(int32_t)));
-    QBH_R(hipMalloc(&d_pos, (size_t)(nstates + 1) * sizeof(int64_t)));
-    hipLaunchKernelGGL(k_hubrepr_flag, dim3(blas_grid((nstates + 15) / 16)), dim3(256), 0, 0, d_R, d_tab, nstates, d_code, d_cnt);
+    QBH_R(hipMalloc(&d_cnt, (size_t)nchunks * sizeof(int32_t)));
+    QBH_R(hipMalloc(&d_pos, (size_t)(nchunks + 1) * sizeof(int64_t)));
+    hipLaunchKernelGGL(k_hubrepr_flag, dim3(egrid), dim3(256), 0, 0, d_R, d_tab, nstates, d_code, d_cnt, nchunks);
     QBH_R(hipGetLastError());
-    rc = exclusive_scan(d_cnt, nstates, d_pos, 0);
+    rc = exclusive_scan(d_cnt, nchunks, d_pos, 0);
     if (rc != QBH_OK) {
         cleanup(true);
         return rc;
     }
-    QBH_R(hipMemcpy(&dim, d_pos + nstates, sizeof(int64_t), hipMemcpyDeviceToHost));
+    QBH_R(hipMemcpy(&dim, d_pos + nchunks, sizeof(int64_t), hipMemcpyDeviceToHost));
     if (dim <= 0 || dim >= 2147483647LL) {
         set_error("qbh_gen_hubbard_repr: sector dimension %lld out of range", (long long)dim);
         cleanup(true);
@@ -1848,12 +1914,13 @@ extern "C" int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_
     }
     QBH_R(hipMalloc(&d_reps, (size_t)dim * sizeof(uint64_t)));
     QBH_R(hipMalloc(&d_info, (size_t)dim));
-    hipLaunchKernelGGL(k_hubrepr_compact, dim3(blas_grid(nstates)), dim3(256), 0, 0, d_R, nstates, d_code, d_pos, d_reps, d_info);
+    hipLaunchKernelGGL(k_hubrepr_compact, dim3(egrid), dim3(256), 0, 0, d_R, nstates, d_code, d_pos, nchunks, d_reps, d_info);
     QBH_R(hipGetLastError());
     QBH_R(hipDeviceSynchronize());
     (void)hipFree(d_code); d_code = nullptr;
     (void)hipFree(d_cnt); d_cnt = nullptr;
     (void)hipFree(d_pos); d_pos = nullptr;
+    // 2. this shard's rows: lengths (+ the distinct values) -> row pointers -> fill
     const int64_t nblk = (dim + n_shards - 1) / n_shards;
     const int64_t r0 = std::min<int64_t>((int64_t)shard * nblk, dim), r1 = std::min<int64_t>(r0 + nblk, dim);
     const int64_t nloc = r1 - r0;
@@ -1862,10 +1929,19 @@ extern "C" int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_
         cleanup(true);
         return QBH_EINVAL;
     }
+    const bool want_dict = !opts || opts->value_dict;
+    if (want_dict) {
+        const bool rows_kernel = !opts || opts->spmv_kernel == QBH_KERNEL_AUTO || opts->spmv_kernel == QBH_KERNEL_ROWS;
+        rc = dict_build_begin(&db, (opts && opts->value_dict == 2) || !rows_kernel ? 256 : kDictMax, 0);
+        if (rc != QBH_OK) {
+            cleanup(true);
+            return rc;
+        }
+    }
     QBH_R(hipMalloc(&d_cnt, (size_t)nloc * sizeof(int32_t)));
     QBH_R(hipMalloc(&d_ia, (size_t)(nloc + 1) * sizeof(int64_t)));
     const int rgrid = (int)std::min<int64_t>((nloc + 127) / 128, 256 * 16);
-    hipLaunchKernelGGL(k_hubrepr_count, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_cnt);
+    hipLaunchKernelGGL(k_hubrepr_count, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_cnt, db.tab);
     QBH_R(hipGetLastError());
     rc = exclusive_scan(d_cnt, nloc, d_ia, 0);
     if (rc != QBH_OK) {
@@ -1873,13 +1949,50 @@ extern "C" int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_
         return rc;
     }
     QBH_R(hipMemcpy(&nnz, d_ia + nloc, sizeof(int64_t), hipMemcpyDeviceToHost));
+    (void)hipFree(d_cnt); d_cnt = nullptr;
     QBH_R(hipMalloc(&d_ja, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t)));
-    QBH_R(hipMalloc(&d_val, (size_t)std::max<int64_t>(nnz, 1) * sizeof(d2)));
-    hipLaunchKernelGGL(k_hubrepr_fill, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_ia, d_ja, d_val);
-    QBH_R(hipGetLastError());
+    int n_dict = 0;
+    if (want_dict) {
+        rc = dict_build_finalize(&db, &d_dict, &n_dict, 0);
+        if (rc != QBH_OK) {
+            cleanup(true);
+            return rc;
+        }
+    }
+    if (n_dict > 0) {
+        // few distinct values (hopping amplitude x sign x phase x sqrt of stabiliser ratios, the U ladder): 1- or 2-byte codes
+        // are emitted directly and the 16 B/nnz value array never exists
+        const int w = dict_code_width(n_dict);
+        QBH_R(hipMalloc(&d_code, (size_t)nnz * w + 16));
+        QBH_R(hipMemset(d_code + (size_t)nnz * w, 0, 16));
+        if (w == 1)
+            hipLaunchKernelGGL(k_hubrepr_fill_coded<uint8_t>, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_ia,
+                               d_ja, d_code, d_dict, db.tab);
+        else
+            hipLaunchKernelGGL(k_hubrepr_fill_coded<uint16_t>, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1,
+                               d_ia, d_ja, reinterpret_cast<uint16_t *>(d_code), d_dict, db.tab);
+        QBH_R(hipGetLastError());
+        int bad = 0;
+        rc = dict_build_mismatch(&db, &bad, 0);
+        if (rc == QBH_OK && bad) {
+            set_error("qbh_gen_hubbard_repr: value dictionary mismatch between the count and fill passes");
+            rc = QBH_EHIP;
+        }
+        if (rc != QBH_OK) {
+            cleanup(true);
+            return rc;
+        }
+    } else {
+        if (d_dict) (void)hipFree(d_dict);
+        d_dict = nullptr;
+        QBH_R(hipMalloc(&d_val, (size_t)std::max<int64_t>(nnz, 1) * sizeof(d2)));
+        hipLaunchKernelGGL(k_hubrepr_fill, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_ia, d_ja, d_val);
+        QBH_R(hipGetLastError());
+    }
     QBH_R(hipDeviceSynchronize());
 #undef QBH_R
     cleanup(false);
     if (dim_out) *dim_out = dim;
+    if (d_code) return adopt_coded_csr(out, nloc, dim, r0, nnz, d_ia, d_ja, d_code, d_dict, n_dict, opts);
     return qbh_csr_create_device(out, nloc, dim, r0, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, opts);
 }

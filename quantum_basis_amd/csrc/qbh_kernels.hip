@@ -343,10 +343,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
         const int nr = r1 - r0;
         const int64_t nlong = p1 - p0;
         if (live && nr > 0) {
-            if (nlong <= NPB && nr <= kRowCap) {
+            if (nlong <= NPB) {
                 const int n = (int)nlong;
                 // ---- phase 1: stage the block's index / value streams ----
-                const int ro = (int)(a.ia[r0 + (tid <= nr ? tid : 0)] - p0);
+                // (a block of very short rows can hold more than kRowCap of them: their offsets are staged and their sums
+                // formed kRowCap rows at a time, nrg = rows of the current group)
+                const int nrg0 = nr < kRowCap ? nr : kRowCap;
+                const int ro = (int)(a.ia[r0 + (tid <= nrg0 ? tid : 0)] - p0);
                 d2 yo = {0.0, 0.0}, xi = {0.0, 0.0};
                 const bool mine = sub == 0 && rloc < nr;
                 if (mine && need_y) yo = load_y_old(a, r0 + rloc);
@@ -388,13 +391,20 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
 #pragma unroll
                     for (int u = 0; u < U; ++u) scol[tid + u * kBlock] = c[u];
                 }
-                if (tid <= nr) rowoff[tid] = ro;
-                for (int i = tid + kBlock; i <= nr; i += kBlock) rowoff[i] = (int)(a.ia[r0 + i] - p0);
+                if (tid <= nrg0) rowoff[tid] = ro;
+                for (int i = tid + kBlock; i <= nrg0; i += kBlock) rowoff[i] = (int)(a.ia[r0 + i] - p0);
                 __syncthreads();
+                for (int rg = 0; rg < nr; rg += kRowCap) {
+                const int nrg = nr - rg < kRowCap ? nr - rg : kRowCap;
+                if (rg > 0) {                                          // next group of rows of the same staged block
+                    __syncthreads();
+                    for (int i = tid; i <= nrg; i += kBlock) rowoff[i] = (int)(a.ia[r0 + rg + i] - p0);
+                    __syncthreads();
+                }
                 // ---- phase 2: lanes <-> rows ----
-                for (int rbase = 0; rbase < nr; rbase += R) {
+                for (int rbase = 0; rbase < nrg; rbase += R) {
                     const int row = rbase + rloc;
-                    const bool rowok = row < nr;
+                    const bool rowok = row < nrg;
                     const int base = rowok ? rowoff[row] : 0;
                     const int len = rowok ? rowoff[row + 1] - base : 0;
                     int wmax = len;
@@ -453,10 +463,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
                         }
                     }
                     if (sub == 0 && rowok) {
-                        if (rbase == 0) row_epilogue2(a, (int64_t)r0 + row, sum, yo, xi, acc);
-                        else            row_epilogue(a, (int64_t)r0 + row, sum, acc);
+                        if (rbase == 0 && rg == 0) row_epilogue2(a, (int64_t)r0 + row, sum, yo, xi, acc);
+                        else                       row_epilogue(a, (int64_t)r0 + rg + row, sum, acc);
                     }
-                    if (P > 1 && rbase + R < nr) __syncthreads();      // part[] is reused by the next pass
+                    if (P > 1 && rbase + R < nrg) __syncthreads();     // part[] is reused by the next pass
+                }
                 }
                 if (P == 1) __syncthreads();                           // scol is rewritten by the next block
             } else {

@@ -151,6 +151,9 @@ def test_sector_matrix_matches_explicit_projection(Lx, Ly, nu, nd):
         assert np.abs(M - Hk).max() < 1e-12, (k, np.abs(M - Hk).max())
         assert np.abs(M - M.conj().T).max() < 1e-13
         total += int(alive.sum())
+        B = q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, chars, t=t, U=U)        # value codes emitted by the generator
+        assert B.info().value_dict > 0 and np.array_equal(_dense(B), M)
+        B.destroy()
         A.destroy()
     # the momentum sectors together span the whole fixed-particle-number space
     assert total == len(_words(n, nu, nd))
