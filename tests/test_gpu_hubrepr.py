@@ -277,3 +277,33 @@ def test_c3_ground_state_through_its_momentum_sectors_full_size():
     assert all(x > e_full - 1e-9 for x in e.values()), e
     assert abs(e[(1, 0)] - e[(0, 1)]) < 1e-9 and abs(e[(1, 0)] - e[(3, 0)]) < 1e-9      # x <-> y, k <-> -k
     assert abs(e[(2, 0)] - e[(1, 1)]) < 1e-9                                              # the 4x4 torus is the hypercube
+
+
+def test_c4_substitute_ground_state_through_its_momentum_sectors_full_size():
+    """Hubbard 4x5 with 5+5 electrons (the C4 substitute of test_gpu_configs, dim 240,374,016): the lowest of the nine
+    inequivalent momentum sectors (12,018,806 representatives each) is the full-basis ground state (matrix-free,
+    packed-double Lanczos), and no sector lies below it."""
+    Lx, Ly, n = 4, 5, 20
+    bonds = lattices.square(Lx, Ly)
+    perms, shifts = lattices.translations(Lx, Ly)
+    full = q.csr_mat.hubbard(n, 5, 5, bonds, t=1.0, U=1.1, matrix_free=True)
+    maxit = 800
+    v = full.vec(1)
+    q._lib.check(q._lib.lib().qbh_vec_randomize_real(full.handle, v.ptr, 5), "qbh_vec_randomize_real")
+    h = np.zeros(2 * maxit)
+    m = q.lanczos_real(0, maxit - 1, maxit, full, v, h)
+    e_full = q.hess_eigen(h, maxit, m, "sr")[0][0]
+    v.free()
+    full.destroy()
+    e = {}
+    dims = set()
+    for k in [(kx, ky) for kx in range(3) for ky in range(3)]:
+        chars = lattices.characters(shifts, k, (Lx, Ly))
+        A = q.csr_mat.hubbard_repr(n, 5, 5, bonds, perms, chars, t=1.0, U=1.1)
+        dims.add(A.info().ncols)
+        e[k] = _lanczos_e0(A, A.info().ncols, maxit=800)
+        A.destroy()
+    assert len(dims) == 1                                  # all representatives are kept in every sector
+    lowest = min(e.values())
+    assert abs(lowest - e_full) < 1e-11 * abs(e_full), (e, e_full)
+    assert all(x > e_full - 1e-9 for x in e.values())
