@@ -76,6 +76,19 @@ def workloads():
                                        trans=(6, 6), k=(1, 0)),
         "triangular_4x4_k01": dict(kind="heisenberg_repr", n_sites=16, n_dn=8, bonds=lattices.triangular(4, 4), J=1.0,
                                    trans=(4, 4), k=(0, 1)),
+        # The Hubbard family through momentum sectors (qbh_gen_hubbard_repr).  BASELINE configs[3] AS WRITTEN -- 4x5 at half
+        # filling, 3.4e10 basis states -- is its k = (0,0) sector: 1,706,742,160 representatives, 7.4e10 nonzeros, ~100 GB per
+        # GPU as columns + 1-byte value codes on FOUR GPUs (python bench.py --gpus 4 --workload hubbard_4x5_half_k00;
+        # per-rank shards generated and timed on one GPU: profiles/r2_sectors/).
+        "hubbard_4x5_half_k00": dict(kind="hubbard_repr", n_sites=20, n_up=10, n_dn=10, bonds=lattices.square(4, 5), t=1.0, U=1.1,
+                                     trans=(4, 5), k=(0, 0), format="fast"),
+        # 4x5 with 8+8 electrons: the ground-state sector k = (pi,0), 171 GB on one GPU (full basis: dim 1.59e10)
+        "hubbard_4x5_n8_k20": dict(kind="hubbard_repr", n_sites=20, n_up=8, n_dn=8, bonds=lattices.square(4, 5), t=1.0, U=1.1,
+                                   trans=(4, 5), k=(2, 0), format="fast"),
+        "hubbard_4x5_n6_k00": dict(kind="hubbard_repr", n_sites=20, n_up=6, n_dn=6, bonds=lattices.square(4, 5), t=1.0, U=1.1,
+                                   trans=(4, 5), k=(0, 0)),
+        "hubbard_4x4_half_k00": dict(kind="hubbard_repr", n_sites=16, n_up=8, n_dn=8, bonds=lattices.square(4, 4), t=1.0, U=1.1,
+                                     trans=(4, 4), k=(0, 0)),
     }
 
 
@@ -93,7 +106,7 @@ def dim_of(w):
     from math import comb
     if w["kind"] == "hubbard":
         return comb(w["n_sites"], w["n_up"]) * comb(w["n_sites"], w["n_dn"])
-    if w["kind"] == "heisenberg_repr":
+    if w["kind"] in ("heisenberg_repr", "hubbard_repr"):
         return None                      # known only after the representatives have been enumerated
     return comb(w["n_sites"], w["n_dn"])
 
@@ -103,6 +116,11 @@ def build_operator(w, rows, opts, matrix_free=False, shard=(0, 1)):
     if w["kind"] == "hubbard":
         return q.csr_mat.hubbard(w["n_sites"], w["n_up"], w["n_dn"], w["bonds"], t=w["t"], U=w["U"], rows=rows, opts=opts,
                                  matrix_free=matrix_free)
+    if w["kind"] == "hubbard_repr":
+        from quantum_basis_amd import lattices
+        perms, shifts = lattices.translations(*w["trans"])
+        return q.csr_mat.hubbard_repr(w["n_sites"], w["n_up"], w["n_dn"], w["bonds"], perms, lattices.characters(shifts, w["k"], w["trans"]),
+                                      t=w["t"], U=w["U"], shard=shard, opts=opts)
     if w["kind"] == "heisenberg_repr":
         from quantum_basis_amd import lattices
         perms, shifts = lattices.translations(*w["trans"])
@@ -318,7 +336,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("QBH_WORKLOAD", "hubbard_4x4_half"))
-    ap.add_argument("--format", default="complex128", choices=["complex128", "fast"],
+    ap.add_argument("--format", default=None, choices=["complex128", "fast"],
                     help="what the HEADLINE is timed on: complex128 = north-star format (complex128 CSR values, complex vectors); "
                          "fast = the library default (value dictionary + real fast path where the operator allows)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto (rows), 1 stream, 2 vector, 3 rows")
@@ -340,6 +358,8 @@ def main():
     ap.add_argument("--no-fast-path", action="store_true", help="skip the extra measurement of the coded / real fast path")
     ap.add_argument("--no-plain", action="store_true", help="(kept for older command lines; the uncoded kernel is the headline now)")
     args = ap.parse_args()
+    if args.format is None:                  # workloads whose complex128 CSR cannot be stored name their own default
+        args.format = workloads()[args.workload].get("format", "complex128")
     fmt_fast = args.format == "fast"
     value_dict = args.value_dict if args.value_dict is not None else (1 if fmt_fast else 0)
     real_fp = args.real_fast_path if args.real_fast_path is not None else (1 if fmt_fast else 0)
