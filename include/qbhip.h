@@ -422,6 +422,15 @@ int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_t
                          const qbh_z *amp_up, const qbh_z *amp_dn, double U, int n_trans, const int32_t *perms,
                          const double *chars, double fake_pos, int shard, int n_shards, int64_t *dim_out,
                          const qbh_opts *opts);
+
+/* moprXvec_repr (src/model.cc:1715-1846, diagonal branch) between two momentum sectors of qbh_gen_hubbard_repr for
+ * O = sum_s ( coef_up[s] n_{s,up} + coef_dn[s] n_{s,dn} ), e.g. the density N_q (coef_up = coef_dn = e^{iq.r_s}) or S^z_q
+ * (coef_up = -coef_dn = e^{iq.r_s}/2).  The coefficients must transform with a character, c_{g(s)} = eta(g) c_s (checked);
+ * chars_new are the characters of the TARGET momentum chi_old * eta.  Both vectors are indexed like the rows of the sector
+ * operators (all representatives, ascending) and live in HBM. */
+int qbh_mopr_diag_hubrepr_dev(int n_sites, int n_up, int n_dn, int n_trans, const int32_t *perms, const double *chars_new,
+                              const qbh_z *coef_up, const qbh_z *coef_dn, const qbh_z *d_vec_old, qbh_z *d_vec_new,
+                              int64_t *dim_out);
 /* Copy the assembled shard back to host arrays (tests, CPU-baseline sample).  Any output
  * pointer may be NULL.  Rows [r0, r1) local to the shard; ia is rebased to 0. */
 int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1,

@@ -1996,3 +1996,227 @@ extern "C" int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_
     if (d_code) return adopt_coded_csr(out, nloc, dim, r0, nnz, d_ia, d_ja, d_code, d_dict, n_dict, opts);
     return qbh_csr_create_device(out, nloc, dim, r0, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, opts);
 }
+
+// ------------------------- diagonal one-body operators between Hubbard momentum sectors --
+// moprXvec_repr (src/model.cc:1715-1846, diagonal branch :1756-1759) for the sectors of qbh_gen_hubbard_repr:
+// O = sum_s ( c_up[s] n_{s,up} + c_dn[s] n_{s,dn} ) with c_{g(s)} = eta(g) c_s (a density or S^z Fourier component).  Then
+// O T_g = eta(g) T_g O, so O |a, k> = z_a |a, k*eta> with z_a evaluated on the representative itself: the basis keeps ALL
+// representatives in every sector and |S_a| does not depend on the momentum (the fermion signs sit inside T_g on both
+// sides).  Representatives whose norm vanishes at the TARGET momentum get 0.
+namespace qbh {
+namespace {
+
+struct HubCoef { double up_re[32], up_im[32], dn_re[32], dn_im[32]; };
+
+// fills the symmetry part of R (binomials, permutations, characters, chunk tables); `who` prefixes error messages
+int hubrepr_symmetry(HubReprDev &R, std::vector<uint64_t> &tab, int n_sites, int n_up, int n_dn, int n_trans, const int32_t *perms,
+                     const double *chars, const char *who)
+{
+    memset(&R, 0, sizeof(R));
+    for (int p = 0; p <= 64; ++p)
+        for (int k = 0; k <= 33; ++k) R.binom[p][k] = binom_u64(p, k);
+    R.n_sites = n_sites;
+    R.n_up = n_up;
+    R.n_dn = n_dn;
+    R.n_trans = n_trans;
+    R.n_chunks = (n_sites + 5) / 6;
+    for (int i = 0; i < n_sites; ++i)
+        if (perms[i] != i) {
+            set_error("%s: translation 0 must be the identity", who);
+            return QBH_EINVAL;
+        }
+    for (int g = 0; g < n_trans; ++g) {
+        R.chr[2 * g] = chars[2 * g];
+        R.chr[2 * g + 1] = chars[2 * g + 1];
+        std::vector<int> seen((size_t)n_sites, 0);
+        for (int s = 0; s < n_sites; ++s) {
+            const int img = perms[(size_t)g * n_sites + s];
+            if (img < 0 || img >= n_sites || seen[(size_t)img]++) {
+                set_error("%s: translation %d is not a site permutation", who, g);
+                return QBH_EINVAL;
+            }
+            R.perm[g * n_sites + s] = (int8_t)img;
+        }
+    }
+    tab.assign((size_t)n_trans * R.n_chunks * 64, 0ULL);
+    for (int g = 0; g < n_trans; ++g)
+        for (int c = 0; c < R.n_chunks; ++c)
+            for (int v = 0; v < 64; ++v) {
+                uint64_t m = 0;
+                for (int b = 0; b < 6; ++b) {
+                    const int site = 6 * c + b;
+                    if (site < n_sites && ((v >> b) & 1)) m |= 1ULL << perms[(size_t)g * n_sites + site];
+                }
+                tab[((size_t)g * R.n_chunks + c) * 64 + v] = m;
+            }
+    return QBH_OK;
+}
+
+// representatives (ascending) and their info bytes for the sector described by R; device arrays owned by the caller
+int hubrepr_enumerate(const HubReprDev &R, const std::vector<uint64_t> &tab, std::vector<void *> &pool, HubReprDev **d_R_out,
+                      uint64_t **d_tab_out, uint64_t **d_reps_out, uint8_t **d_info_out, int64_t *dim_out, const char *who)
+{
+    const long double nst = (long double)binom_u64(R.n_sites, R.n_up) * (long double)binom_u64(R.n_sites, R.n_dn);
+    if (nst >= (long double)(1ULL << 40)) {
+        set_error("%s: sector too large to enumerate", who);
+        return QBH_EUNSUPP;
+    }
+    const int64_t nstates = (int64_t)(binom_u64(R.n_sites, R.n_up) * binom_u64(R.n_sites, R.n_dn));
+    std::vector<HubReprDev> rr(1, R);
+    HubReprDev *d_R = nullptr;
+    uint64_t *d_tab = nullptr;
+    QBH_TRY(upload(rr, &d_R, pool));
+    QBH_TRY(upload(tab, &d_tab, pool));
+    uint8_t *d_code = nullptr, *d_info = nullptr;
+    int32_t *d_cnt = nullptr;
+    int64_t *d_pos = nullptr;
+    uint64_t *d_reps = nullptr;
+    int64_t dim = 0;
+    const int64_t nchunks = (nstates + kHubChunk - 1) / kHubChunk;
+    const int egrid = (int)std::min<int64_t>(nchunks, 256 * 32);
+    hipError_t e = hipMalloc(&d_code, (size_t)nstates);
+    if (e == hipSuccess) e = hipMalloc(&d_cnt, (size_t)nchunks * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_pos, (size_t)(nchunks + 1) * sizeof(int64_t));
+    int rc = QBH_OK;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_hubrepr_flag, dim3(egrid), dim3(256), 0, 0, d_R, d_tab, nstates, d_code, d_cnt, nchunks);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) rc = exclusive_scan(d_cnt, nchunks, d_pos, 0);
+    if (e == hipSuccess && rc == QBH_OK) e = hipMemcpy(&dim, d_pos + nchunks, sizeof(int64_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && rc == QBH_OK && (dim <= 0 || dim >= 2147483647LL)) {
+        set_error("%s: sector dimension %lld out of range", who, (long long)dim);
+        rc = QBH_EUNSUPP;
+    }
+    if (e == hipSuccess && rc == QBH_OK) e = hipMalloc(&d_reps, (size_t)dim * sizeof(uint64_t));
+    if (e == hipSuccess && rc == QBH_OK) e = hipMalloc(&d_info, (size_t)dim);
+    if (e == hipSuccess && rc == QBH_OK) {
+        hipLaunchKernelGGL(k_hubrepr_compact, dim3(egrid), dim3(256), 0, 0, d_R, nstates, d_code, d_pos, nchunks, d_reps, d_info);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    for (void *q : {(void *)d_code, (void *)d_cnt, (void *)d_pos})
+        if (q) (void)hipFree(q);
+    if (e != hipSuccess || rc != QBH_OK) {
+        if (d_reps) (void)hipFree(d_reps);
+        if (d_info) (void)hipFree(d_info);
+        if (e != hipSuccess) {
+            set_error("%s: %s", who, hipGetErrorString(e));
+            (void)hipGetLastError();
+            return e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP;
+        }
+        return rc;
+    }
+    *d_R_out = d_R;
+    *d_tab_out = d_tab;
+    *d_reps_out = d_reps;
+    *d_info_out = d_info;
+    *dim_out = dim;
+    return QBH_OK;
+}
+
+__global__ __launch_bounds__(256) void k_hubrepr_apply_diag(int n_sites, const uint64_t *reps, const uint8_t *info_new, int64_t dim,
+                                                            HubCoef cf, const d2 *x_old, d2 *y_new)
+{
+    const uint64_t mlow = (1ULL << n_sites) - 1ULL;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < dim; i += stride) {
+        d2 y = {0.0, 0.0};
+        if (!(info_new[i] & 0x80)) {
+            const uint64_t a = reps[i];
+            uint64_t u = a & mlow, d = a >> n_sites;
+            double zr = 0.0, zi = 0.0;
+            while (u) {
+                const int s = __ffsll((long long)u) - 1;
+                u &= u - 1;
+                zr += cf.up_re[s];
+                zi += cf.up_im[s];
+            }
+            while (d) {
+                const int s = __ffsll((long long)d) - 1;
+                d &= d - 1;
+                zr += cf.dn_re[s];
+                zi += cf.dn_im[s];
+            }
+            const d2 x = x_old[i];
+            y = d2{zr * x.x - zi * x.y, zr * x.y + zi * x.x};
+        }
+        y_new[i] = y;
+    }
+}
+
+}  // namespace
+}  // namespace qbh
+
+extern "C" int qbh_mopr_diag_hubrepr_dev(int n_sites, int n_up, int n_dn, int n_trans, const int32_t *perms, const double *chars_new,
+                                         const qbh_z *coef_up, const qbh_z *coef_dn, const qbh_z *d_vec_old, qbh_z *d_vec_new,
+                                         int64_t *dim_out)
+{
+    using namespace qbh;
+    if (!perms || !chars_new || !coef_up || !coef_dn || !d_vec_old || !d_vec_new || n_sites <= 0 || n_sites > 31 || n_up < 0 ||
+        n_up > n_sites || n_dn < 0 || n_dn > n_sites || n_trans < 1 || n_trans > kReprMaxTrans) {
+        set_error("qbh_mopr_diag_hubrepr_dev: invalid argument");
+        return QBH_EINVAL;
+    }
+    // the coefficients must transform with a one-dimensional representation: c_{g(s)} = eta(g) c_s for both species
+    for (int g = 0; g < n_trans; ++g) {
+        bool have = false;
+        double er = 0.0, ei = 0.0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int sp = 0; sp < 2; ++sp)
+                for (int s = 0; s < n_sites; ++s) {
+                    const qbh_z *c = sp ? coef_dn : coef_up;
+                    const int img = perms[(size_t)g * n_sites + s];
+                    if (img < 0 || img >= n_sites) continue;          // reported by hubrepr_symmetry below
+                    const double a2 = c[s].re * c[s].re + c[s].im * c[s].im;
+                    if (pass == 0) {
+                        if (!have && a2 > 1e-24) {                    // eta(g) = c_{g(s)} / c_s
+                            er = (c[img].re * c[s].re + c[img].im * c[s].im) / a2;
+                            ei = (c[img].im * c[s].re - c[img].re * c[s].im) / a2;
+                            have = true;
+                        }
+                    } else {
+                        const double wr = (have ? er : 1.0) * c[s].re - (have ? ei : 0.0) * c[s].im;
+                        const double wi = (have ? er : 1.0) * c[s].im + (have ? ei : 0.0) * c[s].re;
+                        if (std::fabs(wr - c[img].re) > 1e-10 || std::fabs(wi - c[img].im) > 1e-10) {
+                            set_error("qbh_mopr_diag_hubrepr_dev: the coefficients do not transform with a character under translation %d", g);
+                            return QBH_EINVAL;
+                        }
+                    }
+                }
+    }
+    std::vector<HubReprDev> rr(1);
+    std::vector<uint64_t> tab;
+    QBH_TRY(hubrepr_symmetry(rr[0], tab, n_sites, n_up, n_dn, n_trans, perms, chars_new, "qbh_mopr_diag_hubrepr_dev"));
+    std::vector<void *> pool;
+    HubReprDev *d_R = nullptr;
+    uint64_t *d_tab = nullptr, *d_reps = nullptr;
+    uint8_t *d_info = nullptr;
+    int64_t dim = 0;
+    int rc = hubrepr_enumerate(rr[0], tab, pool, &d_R, &d_tab, &d_reps, &d_info, &dim, "qbh_mopr_diag_hubrepr_dev");
+    hipError_t e = hipSuccess;
+    if (rc == QBH_OK) {
+        HubCoef cf{};
+        for (int s = 0; s < n_sites; ++s) {
+            cf.up_re[s] = coef_up[s].re;
+            cf.up_im[s] = coef_up[s].im;
+            cf.dn_re[s] = coef_dn[s].re;
+            cf.dn_im[s] = coef_dn[s].im;
+        }
+        hipLaunchKernelGGL(k_hubrepr_apply_diag, dim3(blas_grid(dim)), dim3(256), 0, 0, n_sites, d_reps, d_info, dim, cf,
+                           reinterpret_cast<const d2 *>(d_vec_old), reinterpret_cast<d2 *>(d_vec_new));
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    free_pool(pool);
+    if (d_reps) (void)hipFree(d_reps);
+    if (d_info) (void)hipFree(d_info);
+    if (rc != QBH_OK) return rc;
+    if (e != hipSuccess) {
+        set_error("qbh_mopr_diag_hubrepr_dev: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return QBH_EHIP;
+    }
+    if (dim_out) *dim_out = dim;
+    return QBH_OK;
+}

@@ -582,6 +582,21 @@ def moprXvec_sz_repr(n_sites, n_dn, perms, chars_new, coef, d_vec_old, d_vec_new
     return dim.value
 
 
+def moprXvec_diag_hubrepr(n_sites, n_up, n_dn, perms, chars_new, coef_up, coef_dn, d_vec_old, d_vec_new):
+    """moprXvec_repr (src/model.cc:1715-1846) for sum_s (coef_up[s] n_{s,up} + coef_dn[s] n_{s,dn}) between momentum sectors
+    of qbh_gen_hubbard_repr (density N_q, S^z_q); chars_new = characters of the target momentum.  Returns the number of
+    representatives."""
+    p = np.ascontiguousarray(np.asarray(perms, dtype=np.int32))
+    ch = np.ascontiguousarray(np.asarray(chars_new, dtype=np.complex128))
+    cu = np.ascontiguousarray(coef_up, dtype=np.complex128)
+    cd = np.ascontiguousarray(coef_dn, dtype=np.complex128)
+    assert p.shape == (len(ch), n_sites) and cu.size == n_sites and cd.size == n_sites
+    dim = C.c_int64(0)
+    check(lib().qbh_mopr_diag_hubrepr_dev(n_sites, n_up, n_dn, len(ch), _p(p), _p(ch), _p(cu), _p(cd), d_vec_old, d_vec_new,
+                                          C.byref(dim)), "qbh_mopr_diag_hubrepr_dev")
+    return dim.value
+
+
 def moprXvec_flip_repr(n_sites, n_dn_old, kind, perms, chars_old, chars_new, coef, d_vec_old, d_vec_new):
     """moprXvec_repr for S^-_q (kind -1) / S^+_q (kind +1) between momentum sectors; returns (dim_old, dim_new)."""
     p = np.ascontiguousarray(np.asarray(perms, dtype=np.int32))

@@ -307,3 +307,113 @@ def test_c4_substitute_ground_state_through_its_momentum_sectors_full_size():
     lowest = min(e.values())
     assert abs(lowest - e_full) < 1e-11 * abs(e_full), (e, e_full)
     assert all(x > e_full - 1e-9 for x in e.values())
+
+
+def test_density_and_sz_fourier_components_between_sectors():
+    """qbh_mopr_diag_hubrepr_dev = moprXvec_repr for N_q and S^z_q: against the explicit matrix <b,k+q| O |a,k> built from
+    the projected momentum states."""
+    Lx, Ly, nu, nd = 4, 2, 3, 2
+    n = Lx * Ly
+    bonds = lattices.square(Lx, Ly)
+    perms, shifts = lattices.translations(Lx, Ly)
+    terms = _hubbard_terms(bonds, 1.0)
+    words = _words(n, nu, nd)
+    index = {w: i for i, w in enumerate(words)}
+    m = (1 << n) - 1
+    rng = np.random.default_rng(5)
+    for k_old, qv, spin in [((0, 0), (1, 0), False), ((1, 1), (2, 1), True), ((3, 0), (1, 1), False), ((2, 0), (0, 0), True)]:
+        k_new = ((k_old[0] + qv[0]) % Lx, (k_old[1] + qv[1]) % Ly)
+        ch_old = lattices.characters(shifts, k_old, (Lx, Ly))
+        ch_new = lattices.characters(shifts, k_new, (Lx, Ly))
+        # e^{-i q.r_s}: translating the site by t multiplies the coefficient by chi_q(t), so the target character is chi_k * chi_q
+        phase = np.array([np.exp(-2j * np.pi * (qv[0] * (s % Lx) / Lx + qv[1] * (s // Lx) / Ly)) for s in range(n)])
+        cu, cd = (0.5 * phase, -0.5 * phase) if spin else (phase, phase)
+        O = np.zeros((len(words), len(words)), dtype=np.complex128)
+        for a, w in enumerate(words):
+            u, d = w & m, w >> n
+            O[a, a] = sum(cu[s] for s in range(n) if (u >> s) & 1) + sum(cd[s] for s in range(n) if (d >> s) & 1)
+
+        def states(chars):
+            Ts = [_translation(n, words, index, p) for p in perms]
+            P = sum(c * T for c, T in zip(chars, Ts)) / len(perms)
+            reps = [w for w in words if min(_image(n, p, w & m)[0] | (_image(n, p, w >> n)[0] << n) for p in perms) == w]
+            psi = np.zeros((len(words), len(reps)), dtype=np.complex128)
+            for r, w in enumerate(reps):
+                v = P[:, index[w]]
+                if np.linalg.norm(v) > 1e-10:
+                    psi[:, r] = v / np.linalg.norm(v)
+            return psi
+        psi_old, psi_new = states(ch_old), states(ch_new)
+        Okk = psi_new.conj().T @ O @ psi_old
+        dim = psi_old.shape[1]
+        x = rng.standard_normal(dim) + 1j * rng.standard_normal(dim)
+        x[np.abs(psi_old).sum(axis=0) == 0] = 0.0          # no weight on zero-norm representatives of the old sector
+        A = q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, ch_new)
+        assert A.info().ncols == dim
+        dv = A.vec(2)
+        dv.upload(x, 0)
+        got_dim = q.moprXvec_diag_hubrepr(n, nu, nd, perms, ch_new, cu, cd, dv.at(0), dv.at(dim))
+        assert got_dim == dim
+        y = dv.download(dim, dim)
+        assert np.abs(y - Okk @ x).max() < 1e-12, (k_old, qv, np.abs(y - Okk @ x).max())
+        dv.free()
+        A.destroy()
+    # coefficients that do not transform with a character are refused
+    A = q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, lattices.characters(shifts, (0, 0), (Lx, Ly)))
+    dv = A.vec(2)
+    bad = np.arange(1, n + 1).astype(np.complex128)
+    with pytest.raises(q._lib.QbhError):
+        q.moprXvec_diag_hubrepr(n, nu, nd, perms, lattices.characters(shifts, (1, 0), (Lx, Ly)), bad, bad, dv.at(0), dv.at(A.dim))
+    dv.free()
+    A.destroy()
+
+
+def test_density_structure_factor_in_sectors_end_to_end():
+    """measure_repr_dynamic (src/model.cc:1896-1935) for the Hubbard family: ground state of the k = (0,0) sector of the 4x2
+    torus (4+4 electrons, the reference's example), N_q |psi0> on the device, lanczos("dnmcs") on the k + q sector operator;
+    the continued fraction of the coefficients against the resolvent from a dense diagonalisation of that sector."""
+    Lx, Ly, nu, nd = 4, 2, 4, 4
+    n = Lx * Ly
+    bonds = lattices.square(Lx, Ly)
+    perms, shifts = lattices.translations(Lx, Ly)
+    ch0 = lattices.characters(shifts, (0, 0), (Lx, Ly))
+    A0 = q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, ch0)
+    M0 = _dense(A0)
+    w0, v0 = np.linalg.eigh(M0)
+    assert abs(w0[0] + 14.07605866) < 1e-8
+    psi0 = np.ascontiguousarray(v0[:, 0])
+    dim = A0.info().ncols
+    vphi = q.DeviceVec(A0, dim)
+    vphi.upload(psi0)
+    maxit = 200
+    for qv in [(1, 0), (2, 1)]:
+        chq = lattices.characters(shifts, qv, (Lx, Ly))
+        phase = np.array([np.exp(-2j * np.pi * (qv[0] * (s % Lx) / Lx + qv[1] * (s // Lx) / Ly)) for s in range(n)]) / np.sqrt(n)
+        B = q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, chq)
+        m, norm, hess = q.measure_full_dynamic_dev(
+            B, lambda dst: q.moprXvec_diag_hubrepr(n, nu, nd, perms, chq, phase, phase, vphi.ptr, dst), maxit)
+        Mq = _dense(B)
+        wq, vq = np.linalg.eigh(Mq)
+        # N_q psi0 in the new sector's basis: diagonal on the shared representative list
+        tmp = q.DeviceVec(B, dim)
+        q.moprXvec_diag_hubrepr(n, nu, nd, perms, chq, phase, phase, vphi.ptr, tmp.ptr)
+        phi = tmp.download(0, dim)
+        tmp.free()
+        assert abs(np.linalg.norm(phi) - norm) < 1e-12
+        weights = np.abs(vq.conj().T @ phi) ** 2
+        assert weights[wq > 50.0].sum() < 1e-24          # nothing on the decoupled zero-norm rows
+
+        def green(h, mm, z):
+            g = 0.0
+            for j in range(mm - 1, -1, -1):
+                g = 1.0 / (z - h[maxit + j] - (h[j + 1] ** 2) * g)
+            return g
+
+        for w in np.linspace(0.0, 6.0, 13):
+            z = w0[0] + w + 0.1j
+            g_dev = norm ** 2 * green(hess, m - 1, z)
+            g_ref = np.sum(weights / (z - wq))
+            assert abs(g_dev - g_ref) <= 1e-8 * max(abs(g_ref), 1e-3), (qv, w, g_dev, g_ref)
+        B.destroy()
+    vphi.free()
+    A0.destroy()
