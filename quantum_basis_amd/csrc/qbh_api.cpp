@@ -214,6 +214,13 @@ int split_shard(qbh_csr *A)
         if (atoi(e)) return QBH_OK;
     }
     hipStream_t s = A->stream;
+    {   // the split holds a second copy of the shard until the original is released: skip it (one launch per SpMV, no
+        // overlap with the gather) rather than fail when HBM cannot hold both
+        size_t free_b = 0, total_b = 0;
+        const size_t per_nnz = 4 + (A->d_code ? (size_t)A->code_w : sizeof(d2));
+        const size_t need = (size_t)A->nnz * per_nnz + (size_t)A->nrows * 20 + ((size_t)1 << 30);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < need) return QBH_OK;
+    }
     const int32_t lo = (int32_t)A->row_offset, hi = (int32_t)(A->row_offset + A->nrows);
     int32_t *cnt = nullptr;
     int64_t *ia0 = nullptr, *ia1 = nullptr;
