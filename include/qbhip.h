@@ -431,6 +431,14 @@ int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_t
 int qbh_mopr_diag_hubrepr_dev(int n_sites, int n_up, int n_dn, int n_trans, const int32_t *perms, const double *chars_new,
                               const qbh_z *coef_up, const qbh_z *coef_dn, const qbh_z *d_vec_old, qbh_z *d_vec_new,
                               int64_t *dim_out);
+
+/* moprXvec_repr (general branch) for the single-fermion operators  sum_s coef[s] c_{s,sigma}  (kind -1) and
+ * sum_s coef[s] c^dag_{s,sigma}  (kind +1), species 0 = up / 1 = down, between the momentum sector (n_up_old, n_dn_old,
+ * chars_old) and the sector with one particle less / more at chars_new = chars_old * eta, coef_{g(s)} = eta(g) coef_s: the
+ * operators of the single-particle spectral function.  d_vec_new (dim_new elements, HBM) is overwritten. */
+int qbh_mopr_c_hubrepr_dev(int n_sites, int n_up_old, int n_dn_old, int species, int kind, int n_trans, const int32_t *perms,
+                           const double *chars_old, const double *chars_new, const qbh_z *coef, const qbh_z *d_vec_old,
+                           qbh_z *d_vec_new, int64_t *dim_old_out, int64_t *dim_new_out);
 /* Copy the assembled shard back to host arrays (tests, CPU-baseline sample).  Any output
  * pointer may be NULL.  Rows [r0, r1) local to the shard; ia is rebased to 0. */
 int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1,

@@ -2220,3 +2220,121 @@ extern "C" int qbh_mopr_diag_hubrepr_dev(int n_sites, int n_up, int n_dn, int n_
     if (dim_out) *dim_out = dim;
     return QBH_OK;
 }
+
+// --------------------- single-fermion operators between Hubbard momentum sectors ---------
+// moprXvec_repr (src/model.cc:1715-1846, general branch) for  O = sum_s coef[s] c_{s,sigma}  (kind -1) or
+// sum_s coef[s] c^dag_{s,sigma} (kind +1) with coef_{g(s)} = eta(g) coef_s -- the operators of the single-particle spectral
+// function.  O T_g = eta(g) T_g O, so with chi' = chi * eta
+//     O |a, k> = sum_s coef_s sgn_s(a) sigma(g_c) chi'(g_c) sqrt(|S_b| / |S_a|) |b, k'>,   c = a -/+ s,  T_{g_c} |c> = sigma |b>,
+// sgn_s = (-1)^(operators left of (s, sigma) in the word's operator string: all up ascending, then all down ascending).
+// One lane per old representative scatters into the new sector with fp64 atomics.
+namespace qbh {
+namespace {
+
+__global__ __launch_bounds__(128) void k_hubrepr_apply_c(const HubReprDev *Rnew, const uint64_t *tab, const uint64_t *reps_old,
+                                                         const uint8_t *info_old, int64_t dim_old, const uint64_t *reps_new,
+                                                         const uint8_t *info_new, int64_t dim_new, int species, int create,
+                                                         HubCoef cf, const d2 *x_old, double *y_new)
+{
+    const HubReprDev &R = *Rnew;
+    const int n = R.n_sites;
+    const uint64_t mlow = (1ULL << n) - 1ULL;
+    const int64_t stride = (int64_t)gridDim.x * 128;
+    for (int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x; i < dim_old; i += stride) {
+        const uint8_t ci = info_old[i];
+        if (ci & 0x80) continue;
+        const d2 x = x_old[i];
+        if (x.x == 0.0 && x.y == 0.0) continue;
+        const double sa = (double)(ci & 0x7f);
+        const uint64_t a = reps_old[i];
+        const uint64_t au = a & mlow, ad = a >> n;
+        const uint64_t occ = species ? ad : au;
+        const int left0 = species ? __popcll(au) : 0;      // the whole up block stands left of every down operator
+        for (int s = 0; s < n; ++s) {
+            const bool has = (occ >> s) & 1ULL;
+            if (create ? has : !has) continue;
+            const double cr0 = species ? cf.dn_re[s] : cf.up_re[s], ci0 = species ? cf.dn_im[s] : cf.up_im[s];
+            if (cr0 == 0.0 && ci0 == 0.0) continue;
+            int par = (left0 + __popcll(occ & ((1ULL << s) - 1ULL))) & 1;
+            const uint64_t occ2 = occ ^ (1ULL << s);
+            const uint64_t c = species ? (au | (occ2 << n)) : (occ2 | (ad << n));
+            int g = 0, pt = 0;
+            const uint64_t b = hubrepr_canonical(R, tab, c, &g, &pt);
+            par ^= pt;
+            int64_t lo = 0, hi = dim_new;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (reps_new[mid] < b) lo = mid + 1;
+                else hi = mid;
+            }
+            const uint8_t cj = info_new[lo];
+            if (cj & 0x80) continue;
+            const double f = (par ? -1.0 : 1.0) * sqrt((double)(cj & 0x7f) / sa);
+            // w = coef * chi'(g_c) * f
+            const double wr = f * (cr0 * R.chr[2 * g] - ci0 * R.chr[2 * g + 1]);
+            const double wi = f * (cr0 * R.chr[2 * g + 1] + ci0 * R.chr[2 * g]);
+            atomicAdd(&y_new[2 * lo], wr * x.x - wi * x.y);
+            atomicAdd(&y_new[2 * lo + 1], wr * x.y + wi * x.x);
+        }
+    }
+}
+
+}  // namespace
+}  // namespace qbh
+
+extern "C" int qbh_mopr_c_hubrepr_dev(int n_sites, int n_up_old, int n_dn_old, int species, int kind, int n_trans, const int32_t *perms,
+                                      const double *chars_old, const double *chars_new, const qbh_z *coef, const qbh_z *d_vec_old,
+                                      qbh_z *d_vec_new, int64_t *dim_old_out, int64_t *dim_new_out)
+{
+    using namespace qbh;
+    if (!perms || !chars_old || !chars_new || !coef || !d_vec_old || !d_vec_new || n_sites <= 0 || n_sites > 31 || n_up_old < 0 ||
+        n_up_old > n_sites || n_dn_old < 0 || n_dn_old > n_sites || n_trans < 1 || n_trans > kReprMaxTrans ||
+        (species != 0 && species != 1) || (kind != 1 && kind != -1)) {
+        set_error("qbh_mopr_c_hubrepr_dev: invalid argument (species 0 up / 1 down, kind -1 annihilate / +1 create)");
+        return QBH_EINVAL;
+    }
+    const int n_up_new = n_up_old + (species == 0 ? kind : 0), n_dn_new = n_dn_old + (species == 1 ? kind : 0);
+    if (n_up_new < 0 || n_up_new > n_sites || n_dn_new < 0 || n_dn_new > n_sites) {
+        set_error("qbh_mopr_c_hubrepr_dev: the target sector does not exist");
+        return QBH_EINVAL;
+    }
+    std::vector<HubReprDev> ro(1), rn(1);
+    std::vector<uint64_t> tab_o, tab_n;
+    QBH_TRY(hubrepr_symmetry(ro[0], tab_o, n_sites, n_up_old, n_dn_old, n_trans, perms, chars_old, "qbh_mopr_c_hubrepr_dev"));
+    QBH_TRY(hubrepr_symmetry(rn[0], tab_n, n_sites, n_up_new, n_dn_new, n_trans, perms, chars_new, "qbh_mopr_c_hubrepr_dev"));
+    std::vector<void *> pool;
+    HubReprDev *d_Ro = nullptr, *d_Rn = nullptr;
+    uint64_t *d_tab_o = nullptr, *d_tab_n = nullptr, *reps_o = nullptr, *reps_n = nullptr;
+    uint8_t *info_o = nullptr, *info_n = nullptr;
+    int64_t dim_o = 0, dim_n = 0;
+    int rc = hubrepr_enumerate(ro[0], tab_o, pool, &d_Ro, &d_tab_o, &reps_o, &info_o, &dim_o, "qbh_mopr_c_hubrepr_dev");
+    if (rc == QBH_OK) rc = hubrepr_enumerate(rn[0], tab_n, pool, &d_Rn, &d_tab_n, &reps_n, &info_n, &dim_n, "qbh_mopr_c_hubrepr_dev");
+    hipError_t e = hipSuccess;
+    if (rc == QBH_OK) {
+        HubCoef cf{};
+        for (int s = 0; s < n_sites; ++s) {
+            cf.up_re[s] = cf.dn_re[s] = coef[s].re;
+            cf.up_im[s] = cf.dn_im[s] = coef[s].im;
+        }
+        e = hipMemset(d_vec_new, 0, (size_t)dim_n * sizeof(d2));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_hubrepr_apply_c, dim3(blas_grid(dim_o)), dim3(128), 0, 0, d_Rn, d_tab_n, reps_o, info_o, dim_o, reps_n,
+                               info_n, dim_n, species, kind > 0 ? 1 : 0, cf, reinterpret_cast<const d2 *>(d_vec_old),
+                               reinterpret_cast<double *>(d_vec_new));
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+    }
+    free_pool(pool);
+    for (void *q : {(void *)reps_o, (void *)reps_n, (void *)info_o, (void *)info_n})
+        if (q) (void)hipFree(q);
+    if (rc != QBH_OK) return rc;
+    if (e != hipSuccess) {
+        set_error("qbh_mopr_c_hubrepr_dev: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP;
+    }
+    if (dim_old_out) *dim_old_out = dim_o;
+    if (dim_new_out) *dim_new_out = dim_n;
+    return QBH_OK;
+}

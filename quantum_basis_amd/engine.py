@@ -597,6 +597,20 @@ def moprXvec_diag_hubrepr(n_sites, n_up, n_dn, perms, chars_new, coef_up, coef_d
     return dim.value
 
 
+def moprXvec_c_hubrepr(n_sites, n_up_old, n_dn_old, species, kind, perms, chars_old, chars_new, coef, d_vec_old, d_vec_new):
+    """moprXvec_repr for sum_s coef[s] c_{s,sigma} (kind -1) / c^dag_{s,sigma} (kind +1), species 0 up / 1 down, between
+    momentum sectors of qbh_gen_hubbard_repr with one particle less / more; returns (dim_old, dim_new)."""
+    p = np.ascontiguousarray(np.asarray(perms, dtype=np.int32))
+    co = np.ascontiguousarray(np.asarray(chars_old, dtype=np.complex128))
+    cn = np.ascontiguousarray(np.asarray(chars_new, dtype=np.complex128))
+    c = np.ascontiguousarray(coef, dtype=np.complex128)
+    assert p.shape == (len(co), n_sites) and len(cn) == len(co) and c.size == n_sites
+    d0, d1 = C.c_int64(0), C.c_int64(0)
+    check(lib().qbh_mopr_c_hubrepr_dev(n_sites, n_up_old, n_dn_old, int(species), int(kind), len(co), _p(p), _p(co), _p(cn), _p(c),
+                                       d_vec_old, d_vec_new, C.byref(d0), C.byref(d1)), "qbh_mopr_c_hubrepr_dev")
+    return d0.value, d1.value
+
+
 def moprXvec_flip_repr(n_sites, n_dn_old, kind, perms, chars_old, chars_new, coef, d_vec_old, d_vec_new):
     """moprXvec_repr for S^-_q (kind -1) / S^+_q (kind +1) between momentum sectors; returns (dim_old, dim_new)."""
     p = np.ascontiguousarray(np.asarray(perms, dtype=np.int32))

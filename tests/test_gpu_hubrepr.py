@@ -417,3 +417,106 @@ def test_density_structure_factor_in_sectors_end_to_end():
         B.destroy()
     vphi.free()
     A0.destroy()
+
+
+def _opstring(w, n):
+    """the word's operator string: all up (ascending site), then all down"""
+    return [(0, i) for i in range(n) if (w >> i) & 1] + [(1, i) for i in range(n) if (w >> (n + i)) & 1]
+
+
+def _apply_fermion(w, n, s, sp, create):
+    """c_{s,sp} / c^dag_{s,sp} on the word by anticommuting through its operator string: (sign, new word) or None"""
+    ops = _opstring(w, n)
+    if create:
+        if (sp, s) in ops:
+            return None
+        p = sum(1 for o in ops if o < (sp, s))
+        return (-1) ** p, w | (1 << (s + n * sp))
+    if (sp, s) not in ops:
+        return None
+    return (-1) ** ops.index((sp, s)), w & ~(1 << (s + n * sp))
+
+
+def _momentum_states(n, nu, nd, perms, chars):
+    words = _words(n, nu, nd)
+    index = {w: i for i, w in enumerate(words)}
+    m = (1 << n) - 1
+    Ts = [_translation(n, words, index, p) for p in perms]
+    P = sum(c * T for c, T in zip(chars, Ts)) / len(perms)
+    reps = [w for w in words if min(_image(n, p, w & m)[0] | (_image(n, p, w >> n)[0] << n) for p in perms) == w]
+    psi = np.zeros((len(words), len(reps)), dtype=np.complex128)
+    for r, w in enumerate(reps):
+        v = P[:, index[w]]
+        if np.linalg.norm(v) > 1e-10:
+            psi[:, r] = v / np.linalg.norm(v)
+    return words, index, psi
+
+
+def test_single_fermion_operators_between_sectors():
+    """qbh_mopr_c_hubrepr_dev (c_q / c^dag_q, both species) against the explicit matrix <b, k+q; N -/+ 1| O |a, k; N> built by
+    anticommuting through operator strings and projecting onto momentum states."""
+    Lx, Ly, nu, nd = 4, 2, 3, 2
+    n = Lx * Ly
+    bonds = lattices.square(Lx, Ly)
+    perms, shifts = lattices.translations(Lx, Ly)
+    rng = np.random.default_rng(11)
+    for species, kind, k_old, qv in [(0, -1, (0, 0), (1, 0)), (1, -1, (1, 1), (2, 1)), (0, +1, (3, 0), (1, 1)), (1, +1, (2, 1), (0, 0)),
+                                     (0, -1, (2, 0), (2, 0))]:
+        k_new = ((k_old[0] + qv[0]) % Lx, (k_old[1] + qv[1]) % Ly)
+        ch_old = lattices.characters(shifts, k_old, (Lx, Ly))
+        ch_new = lattices.characters(shifts, k_new, (Lx, Ly))
+        coef = np.array([np.exp(-2j * np.pi * (qv[0] * (s % Lx) / Lx + qv[1] * (s // Lx) / Ly)) for s in range(n)]) / np.sqrt(n)
+        nu2, nd2 = nu + (kind if species == 0 else 0), nd + (kind if species == 1 else 0)
+        w_old, i_old, psi_old = _momentum_states(n, nu, nd, perms, ch_old)
+        w_new, i_new, psi_new = _momentum_states(n, nu2, nd2, perms, ch_new)
+        O = np.zeros((len(w_new), len(w_old)), dtype=np.complex128)
+        for a, w in enumerate(w_old):
+            for s_ in range(n):
+                r = _apply_fermion(w, n, s_, species, kind > 0)
+                if r:
+                    O[i_new[r[1]], a] += coef[s_] * r[0]
+        Okk = psi_new.conj().T @ O @ psi_old
+        d_old, d_new = psi_old.shape[1], psi_new.shape[1]
+        x = rng.standard_normal(d_old) + 1j * rng.standard_normal(d_old)
+        x[np.abs(psi_old).sum(axis=0) == 0] = 0.0
+        A = q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, ch_old)
+        B = q.csr_mat.hubbard_repr(n, nu2, nd2, bonds, perms, ch_new)
+        assert A.info().ncols == d_old and B.info().ncols == d_new
+        vx, vy = q.DeviceVec(A, d_old), q.DeviceVec(B, d_new)
+        vx.upload(x)
+        got = q.moprXvec_c_hubrepr(n, nu, nd, species, kind, perms, ch_old, ch_new, coef, vx.ptr, vy.ptr)
+        assert got == (d_old, d_new)
+        y = vy.download(0, d_new)
+        assert np.abs(y - Okk @ x).max() < 1e-12, (species, kind, k_old, qv, np.abs(y - Okk @ x).max())
+        vx.free()
+        vy.free()
+        A.destroy()
+        B.destroy()
+
+
+def test_photoemission_sum_rule_in_sectors():
+    """sum_q | c_{q,up} |psi0> |^2 = N_up for the ground state of the reference's 4x2 example (k = (0,0), 4+4 electrons)"""
+    Lx, Ly, nu, nd = 4, 2, 4, 4
+    n = Lx * Ly
+    bonds = lattices.square(Lx, Ly)
+    perms, shifts = lattices.translations(Lx, Ly)
+    ch0 = lattices.characters(shifts, (0, 0), (Lx, Ly))
+    A0 = q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, ch0)
+    w0, v0 = np.linalg.eigh(_dense(A0))
+    dim = A0.info().ncols
+    vphi = q.DeviceVec(A0, dim)
+    vphi.upload(np.ascontiguousarray(v0[:, 0]))
+    total = {0: 0.0, 1: 0.0}
+    for species in (0, 1):
+        for qv in [(kx, ky) for kx in range(Lx) for ky in range(Ly)]:
+            chq = lattices.characters(shifts, qv, (Lx, Ly))
+            coef = np.array([np.exp(-2j * np.pi * (qv[0] * (s % Lx) / Lx + qv[1] * (s // Lx) / Ly)) for s in range(n)]) / np.sqrt(n)
+            B = q.csr_mat.hubbard_repr(n, nu - (species == 0), nd - (species == 1), bonds, perms, chq)
+            vy = q.DeviceVec(B, B.info().ncols)
+            q.moprXvec_c_hubrepr(n, nu, nd, species, -1, perms, ch0, chq, coef, vphi.ptr, vy.ptr)
+            total[species] += B.nrm2(vy.ptr) ** 2
+            vy.free()
+            B.destroy()
+    assert abs(total[0] - nu) < 1e-10 and abs(total[1] - nd) < 1e-10, total
+    vphi.free()
+    A0.destroy()
