@@ -520,3 +520,39 @@ def test_photoemission_sum_rule_in_sectors():
     assert abs(total[0] - nu) < 1e-10 and abs(total[1] - nd) < 1e-10, total
     vphi.free()
     A0.destroy()
+
+
+def test_photoemission_sum_rule_full_size_c3():
+    """The same chain at full size: ground state of C3 in its k = (0,0) sector (10,353,252 representatives; Lanczos + CG on
+    the device), c_{q,up}|psi0> into each of the 16 (7 up, 8 down) sectors (9,202,050 representatives):
+    sum_q |c_q psi0|^2 = N_up = 8, momenta related by the lattice symmetries carry equal weight, and the momentum
+    distribution is exactly 1/2 on the Fermi surface |kx| + |ky| = pi (particle-hole symmetry of the half-filled bipartite
+    cluster)."""
+    Lx = Ly = 4
+    n, nu, nd = 16, 8, 8
+    bonds = lattices.square(Lx, Ly)
+    perms, shifts = lattices.translations(Lx, Ly)
+    ch0 = lattices.characters(shifts, (0, 0), (Lx, Ly))
+    A0 = q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, ch0)
+    res = q.locate_E0_lanczos(A0, nev=1, ncv=1)
+    assert abs(res.E0 + 20.497352266554) < 1e-9
+    dim0 = A0.info().ncols
+    vphi = q.DeviceVec(A0, dim0)
+    vphi.upload(res.eigenvecs)
+    wt = {}
+    for qv in [(kx, ky) for kx in range(Lx) for ky in range(Ly)]:
+        chq = lattices.characters(shifts, qv, (Lx, Ly))
+        coef = np.array([np.exp(-2j * np.pi * (qv[0] * (s % Lx) / Lx + qv[1] * (s // Lx) / Ly)) for s in range(n)]) / np.sqrt(n)
+        vy = q.DeviceVec(A0, dim0)                       # at least as long as the smaller target sector
+        d_old, d_new = q.moprXvec_c_hubrepr(n, nu, nd, 0, -1, perms, ch0, chq, coef, vphi.ptr, vy.ptr)
+        assert d_old == dim0 and d_new == 9202050
+        y = vy.download(0, d_new)
+        wt[qv] = float(np.vdot(y, y).real)
+        vy.free()
+    assert abs(sum(wt.values()) - nu) < 1e-9, sum(wt.values())
+    assert abs(wt[(1, 0)] - wt[(0, 1)]) < 1e-9 and abs(wt[(1, 0)] - wt[(3, 0)]) < 1e-9 and abs(wt[(1, 2)] - wt[(2, 1)]) < 1e-9
+    for qv in [(2, 0), (0, 2), (1, 1), (1, 3), (3, 1), (3, 3)]:
+        assert abs(wt[qv] - 0.5) < 1e-9, (qv, wt[qv])
+    assert abs(wt[(0, 0)] + wt[(2, 2)] - 1.0) < 1e-9          # n(k) + n(k + (pi,pi)) = 1
+    vphi.free()
+    A0.destroy()
