@@ -132,6 +132,8 @@ CASES = [
     (3, 2, 2, 3),
     (4, 2, 2, 1),
     (2, 2, 2, 2),
+    (5, 1, 2, 0),          # one species only (spinless fermions)
+    (4, 2, 0, 3),
 ]
 
 
