@@ -416,12 +416,15 @@ int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int n_bonds, c
  * term_sites = (i_0, j_0, i_1, j_1, ...); terms on the same (i, j) are summed; i == j is a number operator.  It has to
  * commute with the translations: a Hamiltonian does; a one-body observable is translation-averaged first, as
  * model::measure_repr_static does (src/model.cc:1874-1888).  A non-Hermitian operator is accepted (rows are filled as
- * O[a][b]).  perms / chars / fake_pos / shard / n_shards / dim_out as in qbh_gen_heisenberg_repr.  Basis: all orbit
+ * O[a][b]).  Density-density terms: pair_sites = (i_0, j_0, ...), pair_v[4p..4p+3] = the coefficients of n_{i,up} n_{j,up},
+ * n_{i,up} n_{j,dn}, n_{i,dn} n_{j,up}, n_{i,dn} n_{j,dn} (extended Hubbard; with n_dn = 0 the spinless t-V model of
+ * examples/trans_symmetric/latt_honeycomb/honeycomb_Spinless_Fermion.cc).  perms / chars / fake_pos / shard / n_shards /
+ * dim_out as in qbh_gen_heisenberg_repr.  Basis: all orbit
  * representatives of the words u | d << n_sites (operator order: all up, then all down), ascending; n_sites <= 31. */
 int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_terms, const int32_t *term_sites,
-                         const qbh_z *amp_up, const qbh_z *amp_dn, double U, int n_trans, const int32_t *perms,
-                         const double *chars, double fake_pos, int shard, int n_shards, int64_t *dim_out,
-                         const qbh_opts *opts);
+                         const qbh_z *amp_up, const qbh_z *amp_dn, double U, int n_pairs, const int32_t *pair_sites,
+                         const double *pair_v, int n_trans, const int32_t *perms, const double *chars, double fake_pos,
+                         int shard, int n_shards, int64_t *dim_out, const qbh_opts *opts);
 
 /* moprXvec_repr (src/model.cc:1715-1846, diagonal branch) between two momentum sectors of qbh_gen_hubbard_repr for
  * O = sum_s ( coef_up[s] n_{s,up} + coef_dn[s] n_{s,dn} ), e.g. the density N_q (coef_up = coef_dn = e^{iq.r_s}) or S^z_q

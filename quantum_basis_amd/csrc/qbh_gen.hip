@@ -1459,6 +1459,7 @@ namespace qbh {
 namespace {
 
 constexpr int kHubReprMaxTerms = 512;
+constexpr int kHubReprMaxPairs = 256;
 constexpr int kHubReprMaxRow = 100;       // distinct columns in one row: one move per bond and species + the diagonal
 
 struct HubReprDev {
@@ -1466,6 +1467,9 @@ struct HubReprDev {
     int n_sites, n_up, n_dn, n_terms, n_trans, n_chunks;
     int8_t ti[kHubReprMaxTerms], tj[kHubReprMaxTerms];     // term t: amp * c^dag_{ti} c_{tj}
     double aup[kHubReprMaxTerms][2], adn[kHubReprMaxTerms][2];
+    int n_pairs;                                           // density-density terms v * n_{pi,s} n_{pj,s'}
+    int8_t pi[kHubReprMaxPairs], pj[kHubReprMaxPairs];
+    double pv[kHubReprMaxPairs][4];                        // (up,up) (up,dn) (dn,up) (dn,dn)
     double U, fake_pos;
     double chr[2 * kReprMaxTrans];
     int8_t perm[kReprMaxTrans * 32];                       // perm[g * n_sites + site]
@@ -1637,6 +1641,11 @@ __device__ int hubrepr_row(const HubReprDev &R, const uint64_t *tab, const uint6
     int n = 1;
     cols[0] = (int32_t)i;
     d2 dg = {R.U * (double)__popcll(au & ad), 0.0};
+    for (int p = 0; p < R.n_pairs; ++p) {
+        const int iu = (int)((au >> R.pi[p]) & 1ULL), id = (int)((ad >> R.pi[p]) & 1ULL);
+        const int ju = (int)((au >> R.pj[p]) & 1ULL), jd = (int)((ad >> R.pj[p]) & 1ULL);
+        dg.x += R.pv[p][0] * (iu & ju) + R.pv[p][1] * (iu & jd) + R.pv[p][2] * (id & ju) + R.pv[p][3] * (id & jd);
+    }
     for (int t = 0; t < R.n_terms; ++t) {
         const int ti = R.ti[t], tj = R.tj[t];
         for (int sp = 0; sp < 2; ++sp) {
@@ -1764,13 +1773,14 @@ __global__ __launch_bounds__(128) void k_hubrepr_fill_coded(const HubReprDev *Rp
 }  // namespace qbh
 
 extern "C" int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_terms, const int32_t *term_sites,
-                                    const qbh_z *amp_up, const qbh_z *amp_dn, double U, int n_trans, const int32_t *perms,
-                                    const double *chars, double fake_pos, int shard, int n_shards, int64_t *dim_out,
-                                    const qbh_opts *opts)
+                                    const qbh_z *amp_up, const qbh_z *amp_dn, double U, int n_pairs, const int32_t *pair_sites,
+                                    const double *pair_v, int n_trans, const int32_t *perms, const double *chars, double fake_pos,
+                                    int shard, int n_shards, int64_t *dim_out, const qbh_opts *opts)
 {
     using namespace qbh;
-    if (!out || !term_sites || !amp_up || !amp_dn || !perms || !chars || n_sites <= 0 || n_sites > 31 || n_up < 0 || n_up > n_sites ||
-        n_dn < 0 || n_dn > n_sites || n_terms < 0 || n_trans < 1 || n_trans > kReprMaxTrans || n_shards < 1 || shard < 0 ||
+    if (!out || (n_terms > 0 && (!term_sites || !amp_up || !amp_dn)) || !perms || !chars || n_sites <= 0 || n_sites > 31 || n_up < 0 ||
+        n_up > n_sites || n_dn < 0 || n_dn > n_sites || n_terms < 0 || n_pairs < 0 || n_pairs > kHubReprMaxPairs ||
+        (n_pairs > 0 && (!pair_sites || !pair_v)) || n_trans < 1 || n_trans > kReprMaxTrans || n_shards < 1 || shard < 0 ||
         shard >= n_shards) {
         set_error("qbh_gen_hubbard_repr: invalid argument (<= 31 sites, <= 64 translations)");
         return QBH_EINVAL;
@@ -1827,6 +1837,17 @@ extern "C" int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_
     }
     R.U = U;
     R.fake_pos = fake_pos;
+    for (int p = 0; p < n_pairs; ++p) {
+        const int i = pair_sites[2 * p], j = pair_sites[2 * p + 1];
+        if (i < 0 || i >= n_sites || j < 0 || j >= n_sites) {
+            set_error("qbh_gen_hubbard_repr: density-density term %d acts on a site outside the lattice", p);
+            return QBH_EINVAL;
+        }
+        R.pi[p] = (int8_t)i;
+        R.pj[p] = (int8_t)j;
+        for (int c = 0; c < 4; ++c) R.pv[p][c] = pair_v[4 * p + c];
+    }
+    R.n_pairs = n_pairs;
     R.n_trans = n_trans;
     R.n_chunks = (n_sites + 5) / 6;
     for (int g = 0; g < n_trans; ++g) {

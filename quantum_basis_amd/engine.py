@@ -175,13 +175,15 @@ class csr_mat:
 
     @classmethod
     def hubbard_repr(cls, n_sites, n_up, n_dn, bonds, perms, chars, t=1.0, U=1.1, fake_pos=100.0, shard=(0, 1), opts=None,
-                     terms=None):
+                     terms=None, pairs=None):
         """Hubbard family in a translation-symmetric sector, assembled on the device (qbh_gen_hubbard_repr; counterpart of
         model::enumerate_basis_repr + generate_Ham_sparse_repr for the reference's
         examples/trans_symmetric/latt_square/square_Fermi_Hubbard.cc).  Default operator: -t sum_<ij>,sigma (c+_i c_j + h.c.)
         + U sum_i n_up n_dn over `bonds` (a bond listed twice counts twice, as in the reference's 4x2 torus).  terms =
         [(i, j, amp_up, amp_dn), ...] replaces the hopping part by explicit directed one-body terms amp * c+_i c_j (they
-        must form a translation-invariant operator; U still applies -- pass U=0 for a pure one-body observable)."""
+        must form a translation-invariant operator; U still applies -- pass U=0 for a pure one-body observable).  pairs =
+        [(i, j, v_uu, v_ud, v_du, v_dd), ...] adds density-density terms v * n_{i,s} n_{j,s'} (extended Hubbard; spinless t-V
+        with n_dn = 0)."""
         _lib.require_gpu()
         opts = opts if opts is not None else make_opts()
         if terms is None:
@@ -189,6 +191,9 @@ class csr_mat:
             for (i, j) in np.asarray(bonds, dtype=np.int64).reshape(-1, 2):
                 terms.append((int(i), int(j), -t, -t))
                 terms.append((int(j), int(i), -t, -t))
+        pairs = pairs or []
+        psites = np.ascontiguousarray(np.array([[a[0], a[1]] for a in pairs], dtype=np.int32).reshape(-1, 2))
+        pv = np.ascontiguousarray(np.array([a[2:6] for a in pairs], dtype=np.float64).reshape(-1, 4))
         sites = np.ascontiguousarray(np.array([[a[0], a[1]] for a in terms], dtype=np.int32).reshape(-1, 2))
         aup = np.ascontiguousarray(np.array([a[2] for a in terms], dtype=np.complex128))
         adn = np.ascontiguousarray(np.array([a[3] for a in terms], dtype=np.complex128))
@@ -197,7 +202,8 @@ class csr_mat:
         assert p.shape == (len(c), n_sites)
         h = C.c_void_p()
         dim = C.c_int64(0)
-        check(lib().qbh_gen_hubbard_repr(C.byref(h), n_sites, n_up, n_dn, len(terms), _p(sites), _p(aup), _p(adn), float(U), len(c),
+        check(lib().qbh_gen_hubbard_repr(C.byref(h), n_sites, n_up, n_dn, len(terms), _p(sites), _p(aup), _p(adn), float(U),
+                                         len(pairs), _p(psites) if pairs else None, _p(pv) if pairs else None, len(c),
                                          _p(p), _p(c), fake_pos, int(shard[0]), int(shard[1]), C.byref(dim), C.byref(opts)),
               "qbh_gen_hubbard_repr")
         return cls(0, None, None, None, opts=opts, _handle=h)

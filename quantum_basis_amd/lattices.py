@@ -25,6 +25,18 @@ def square(Lx, Ly, pbc=True):
     return b
 
 
+def honeycomb(Lx, Ly):
+    """examples/trans_symmetric/latt_honeycomb/honeycomb_Spinless_Fermion.cc:51-99 (PBC): site = sub + 2*(x + Lx*y); the
+    sublattice-0 site of cell (x, y) is bonded to the sublattice-1 sites of cells (x, y), (x-1, y) and (x, y-1)."""
+    b = []
+    for x in range(Lx):
+        for y in range(Ly):
+            i = 2 * (x + Lx * y)
+            for (cx, cy) in ((x, y), ((x - 1) % Lx, y), (x, (y - 1) % Ly)):
+                b.append((i, 1 + 2 * (cx + Lx * cy)))
+    return b
+
+
 def triangular(Lx, Ly):
     """examples/trans_absent/latt_triangular/triangular_Heisenberg_spin_half.cc:50-86 (PBC):
     neighbours (m+1,n), (m+1,n+1), (m,n+1)."""

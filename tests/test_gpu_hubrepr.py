@@ -558,3 +558,63 @@ def test_photoemission_sum_rule_full_size_c3():
     assert abs(wt[(0, 0)] + wt[(2, 2)] - 1.0) < 1e-9          # n(k) + n(k + (pi,pi)) = 1
     vphi.free()
     A0.destroy()
+
+
+def _add_pairs(O, n, words, pairs):
+    m = (1 << n) - 1
+    for a, w in enumerate(words):
+        u, d = w & m, w >> n
+        for (i, j, vuu, vud, vdu, vdd) in pairs:
+            iu, idn, ju, jd = (u >> i) & 1, (d >> i) & 1, (u >> j) & 1, (d >> j) & 1
+            O[a, a] += vuu * iu * ju + vud * iu * jd + vdu * idn * ju + vdd * idn * jd
+    return O
+
+
+def test_extended_hubbard_density_density_terms():
+    """density-density terms v n_{i,s} n_{j,s'} (extended Hubbard) against the explicit projection"""
+    Lx, Ly, nu, nd = 3, 2, 2, 2
+    n = Lx * Ly
+    bonds = lattices.square(Lx, Ly)
+    perms, shifts = lattices.translations(Lx, Ly)
+    pairs = [(i, j, 0.7, 0.3, 0.3, 0.7) for (i, j) in bonds]
+    terms = _hubbard_terms(bonds, 1.0)
+    words = _words(n, nu, nd)
+    index = {w: i for i, w in enumerate(words)}
+    for k in [(0, 0), (1, 0), (2, 1)]:
+        chars = lattices.characters(shifts, k, (Lx, Ly))
+        O = _add_pairs(_full_operator(n, words, index, terms, 1.1), n, words, pairs)
+        _, _, psi = _momentum_states(n, nu, nd, perms, chars)
+        Hk = psi.conj().T @ O @ psi
+        dead = np.abs(psi).sum(axis=0) == 0
+        A = q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, chars, t=1.0, U=1.1, pairs=pairs, opts=q.make_opts(value_dict=0))
+        M = _dense(A)
+        for r in np.nonzero(dead)[0]:
+            Hk[r, r] = M[r, r]                             # the fake diagonal of a zero-norm representative
+        assert np.abs(M - Hk).max() < 1e-12
+        A.destroy()
+
+
+def test_reference_asserted_spinless_fermion_honeycomb_energies():
+    """examples/trans_symmetric/latt_honeycomb/honeycomb_Spinless_Fermion.cc:146-151: t-V model (t = 1, V1 = 4) on the 3x2
+    honeycomb torus (12 sites, two per cell), 4 fermions, all six momenta -- the generator with one species, a two-site
+    unit cell, density-density and number terms."""
+    Lx, Ly, t, V1 = 3, 2, 1.0, 4.0
+    n = 2 * Lx * Ly
+    bonds = lattices.honeycomb(Lx, Ly)
+    assert len(bonds) == 18 and len(set(bonds)) == 18
+    perms, shifts = lattices.translations(Lx, Ly, n_sub=2)
+    terms, pairs = [], []
+    for (i, j) in bonds:
+        terms += [(i, j, -t, 0.0), (j, i, -t, 0.0), (i, i, -0.5 * V1, 0.0), (j, j, -0.5 * V1, 0.0)]
+        pairs.append((i, j, V1, 0.0, 0.0, 0.0))
+    want = [-28.60363167, -28.27163215, -28.60363167, -28.27163215, -28.60363167, -28.27163215]
+    got = []
+    for m in range(Lx):
+        for nn in range(Ly):
+            chars = lattices.characters(shifts, (m, nn), (Lx, Ly))
+            A = q.csr_mat.hubbard_repr(n, 4, 0, None, perms, chars, U=0.0, terms=terms, pairs=pairs)     # N = Lx*Ly - 2 (:17)
+            got.append(np.linalg.eigvalsh(_dense(A))[0])
+            if (m, nn) == (0, 0):
+                assert abs(_lanczos_e0(A, A.info().ncols) - want[0]) < 1e-8      # and through the device Lanczos driver
+            A.destroy()
+    assert np.abs(np.array(got) - np.array(want)).max() < 1e-8, got
