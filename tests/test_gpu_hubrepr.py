@@ -618,3 +618,7 @@ def test_reference_asserted_spinless_fermion_honeycomb_energies():
                 assert abs(_lanczos_e0(A, A.info().ncols) - want[0]) < 1e-8      # and through the device Lanczos driver
             A.destroy()
     assert np.abs(np.array(got) - np.array(want)).max() < 1e-8, got
+    # with the trivial group the "sector" is the full fixed-N basis: examples/trans_absent/latt_honeycomb/...:129
+    A = q.csr_mat.hubbard_repr(n, 4, 0, None, [list(range(n))], [1.0], U=0.0, terms=terms, pairs=pairs)
+    assert A.info().ncols == 495 and abs(np.linalg.eigvalsh(_dense(A))[0] + 28.60363167) < 1e-8
+    A.destroy()
