@@ -418,12 +418,16 @@ int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int n_bonds, c
  * model::measure_repr_static does (src/model.cc:1874-1888).  A non-Hermitian operator is accepted (rows are filled as
  * O[a][b]).  Density-density terms: pair_sites = (i_0, j_0, ...), pair_v[4p..4p+3] = the coefficients of n_{i,up} n_{j,up},
  * n_{i,up} n_{j,dn}, n_{i,dn} n_{j,up}, n_{i,dn} n_{j,dn} (extended Hubbard; with n_dn = 0 the spinless t-V model of
- * examples/trans_symmetric/latt_honeycomb/honeycomb_Spinless_Fermion.cc).  perms / chars / fake_pos / shard / n_shards /
- * dim_out as in qbh_gen_heisenberg_repr.  Basis: all orbit
+ * examples/trans_symmetric/latt_honeycomb/honeycomb_Spinless_Fermion.cc).  Spin exchange: exch_sites = (i_0, j_0, ...),
+ * exch_amp[e] * (S+_i S-_j + S-_i S+_j).  no_double != 0 restricts the space to words without doubly occupied sites and
+ * projects the hopping accordingly: with hops -t, exchange J/2 and pair_v = (0, -J/2, -J/2, 0) this is the t-J model of
+ * examples/trans_symmetric/latt_kagome/kagome_tJ.cc.  perms / chars / fake_pos / shard / n_shards / dim_out as in
+ * qbh_gen_heisenberg_repr.  Basis: all orbit
  * representatives of the words u | d << n_sites (operator order: all up, then all down), ascending; n_sites <= 31. */
 int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_terms, const int32_t *term_sites,
                          const qbh_z *amp_up, const qbh_z *amp_dn, double U, int n_pairs, const int32_t *pair_sites,
-                         const double *pair_v, int n_trans, const int32_t *perms, const double *chars, double fake_pos,
+                         const double *pair_v, int n_exch, const int32_t *exch_sites, const double *exch_amp, int no_double,
+                         int n_trans, const int32_t *perms, const double *chars, double fake_pos,
                          int shard, int n_shards, int64_t *dim_out, const qbh_opts *opts);
 
 /* moprXvec_repr (src/model.cc:1715-1846, diagonal branch) between two momentum sectors of qbh_gen_hubbard_repr for

@@ -178,7 +178,8 @@ def lib():
     L.qbh_gen_heisenberg_repr.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp, dbl, C.c_int, vp, vp, dbl,
                                           C.c_int, C.c_int, C.POINTER(i64), C.POINTER(Opts)]
     L.qbh_gen_hubbard_repr.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, dbl, C.c_int, vp, vp,
-                                       C.c_int, vp, vp, dbl, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(Opts)]
+                                       C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, dbl, C.c_int, C.c_int, C.POINTER(i64),
+                                       C.POINTER(Opts)]
     L.qbh_mopr_diag_hubrepr_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
     L.qbh_mopr_c_hubrepr_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp,
                                          C.POINTER(i64), C.POINTER(i64)]

@@ -1460,7 +1460,7 @@ namespace {
 
 constexpr int kHubReprMaxTerms = 512;
 constexpr int kHubReprMaxPairs = 256;
-constexpr int kHubReprMaxRow = 100;       // distinct columns in one row: one move per bond and species + the diagonal
+constexpr int kHubReprMaxRow = 160;       // distinct columns in one row: one move per bond and species, one exchange, the diagonal
 
 struct HubReprDev {
     uint64_t binom[65][34];
@@ -1470,6 +1470,9 @@ struct HubReprDev {
     int n_pairs;                                           // density-density terms v * n_{pi,s} n_{pj,s'}
     int8_t pi[kHubReprMaxPairs], pj[kHubReprMaxPairs];
     double pv[kHubReprMaxPairs][4];                        // (up,up) (up,dn) (dn,up) (dn,dn)
+    int n_exch, no_double;                                 // spin-exchange terms xa * (S+_i S-_j + S-_i S+_j); t-J constraint
+    int8_t xi[kHubReprMaxPairs], xj[kHubReprMaxPairs];
+    double xa[kHubReprMaxPairs];
     double U, fake_pos;
     double chr[2 * kReprMaxTrans];
     int8_t perm[kReprMaxTrans * 32];                       // perm[g * n_sites + site]
@@ -1556,10 +1559,10 @@ __global__ __launch_bounds__(256) void k_hubrepr_flag(const HubReprDev *Rp, cons
             uint64_t u = unrank_k(R.binom, R.n_sites, R.n_up, ru), d = unrank_k(R.binom, R.n_sites, R.n_dn, (uint64_t)r0 / cu);
             for (int64_t r = r0; r < r1; ++r) {
                 const uint64_t s = u | (d << R.n_sites);
-                bool rep = true;
+                bool rep = !(R.no_double && (u & d));     // t-J: words with a doubly occupied site are not in the space
                 int nstab = 1;
                 double sr = R.chr[0], si = R.chr[1];
-                for (int g = 1; g < R.n_trans; ++g) {
+                for (int g = 1; rep && g < R.n_trans; ++g) {
                     const uint64_t t = hubrepr_translate(R, tab, g, s);
                     if (t < s) {
                         rep = false;
@@ -1658,6 +1661,7 @@ __device__ int hubrepr_row(const HubReprDev &R, const uint64_t *tab, const uint6
             }
             // row a of O = conj of O^dag |a>: the particle moves from ti to tj
             if (!((occ >> ti) & 1ULL) || ((occ >> tj) & 1ULL)) continue;
+            if (R.no_double && (((sp ? au : ad) >> tj) & 1ULL)) continue;      // projected hopping
             const int lo_s = ti < tj ? ti : tj, hi_s = ti < tj ? tj : ti;
             const uint64_t between = ((1ULL << hi_s) - 1ULL) & ~((2ULL << lo_s) - 1ULL);
             int par = __popcll(occ & between) & 1;
@@ -1678,6 +1682,46 @@ __device__ int hubrepr_row(const HubReprDev &R, const uint64_t *tab, const uint6
             // amp * conj(chi(g*)) * f
             const double cr = R.chr[2 * g], cim = -R.chr[2 * g + 1];
             const d2 v = {f * (ar * cr - ai * cim), f * (ar * cim + ai * cr)};
+            if (lo == i) {
+                dg += v;
+                continue;
+            }
+            int q = 1;
+            while (q < n && cols[q] != (int32_t)lo) ++q;
+            if (q < n) {
+                vals[q] += v;
+            } else if (n < kHubReprMaxRow) {
+                cols[n] = (int32_t)lo;
+                vals[n] = v;
+                ++n;
+            }
+        }
+    }
+    // spin exchange xa * (S+_i S-_j + S-_i S+_j): the up particle of one site and the down particle of the other trade
+    // places.  S+_i S-_j = -(c^dag_{i,up} c_{j,up})(c^dag_{j,dn} c_{i,dn}): the product of the two hop signs, times -1.
+    for (int e = 0; e < R.n_exch; ++e) {
+        const int xi = R.xi[e], xj = R.xj[e];
+        for (int dir = 0; dir < 2; ++dir) {
+            const int su = dir ? xj : xi, sd = dir ? xi : xj;           // su carries the up particle, sd the down particle
+            if (!((au >> su) & 1ULL) || ((ad >> su) & 1ULL) || !((ad >> sd) & 1ULL) || ((au >> sd) & 1ULL)) continue;
+            const int lo_s = su < sd ? su : sd, hi_s = su < sd ? sd : su;
+            const uint64_t between = ((1ULL << hi_s) - 1ULL) & ~((2ULL << lo_s) - 1ULL);
+            int par = 1 ^ ((__popcll(au & between) + __popcll(ad & between)) & 1);
+            const uint64_t u2 = au ^ (1ULL << su) ^ (1ULL << sd), d2w = ad ^ (1ULL << su) ^ (1ULL << sd);
+            const uint64_t c = u2 | (d2w << R.n_sites);
+            int g = 0, pt = 0;
+            const uint64_t b = hubrepr_canonical(R, tab, c, &g, &pt);
+            par ^= pt;
+            int64_t lo = 0, hi = dim;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (reps[mid] < b) lo = mid + 1;
+                else hi = mid;
+            }
+            const uint8_t cj = info[lo];
+            if (cj & 0x80) continue;
+            const double f = (par ? -1.0 : 1.0) * R.xa[e] * sqrt((double)(cj & 0x7f) / sa);
+            const d2 v = {f * R.chr[2 * g], -f * R.chr[2 * g + 1]};
             if (lo == i) {
                 dg += v;
                 continue;
@@ -1774,10 +1818,15 @@ __global__ __launch_bounds__(128) void k_hubrepr_fill_coded(const HubReprDev *Rp
 
 extern "C" int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_terms, const int32_t *term_sites,
                                     const qbh_z *amp_up, const qbh_z *amp_dn, double U, int n_pairs, const int32_t *pair_sites,
-                                    const double *pair_v, int n_trans, const int32_t *perms, const double *chars, double fake_pos,
+                                    const double *pair_v, int n_exch, const int32_t *exch_sites, const double *exch_amp,
+                                    int no_double, int n_trans, const int32_t *perms, const double *chars, double fake_pos,
                                     int shard, int n_shards, int64_t *dim_out, const qbh_opts *opts)
 {
     using namespace qbh;
+    if (n_exch < 0 || n_exch > kHubReprMaxPairs || (n_exch > 0 && (!exch_sites || !exch_amp))) {
+        set_error("qbh_gen_hubbard_repr: invalid spin-exchange term list");
+        return QBH_EINVAL;
+    }
     if (!out || (n_terms > 0 && (!term_sites || !amp_up || !amp_dn)) || !perms || !chars || n_sites <= 0 || n_sites > 31 || n_up < 0 ||
         n_up > n_sites || n_dn < 0 || n_dn > n_sites || n_terms < 0 || n_pairs < 0 || n_pairs > kHubReprMaxPairs ||
         (n_pairs > 0 && (!pair_sites || !pair_v)) || n_trans < 1 || n_trans > kReprMaxTrans || n_shards < 1 || shard < 0 ||
@@ -1813,7 +1862,7 @@ extern "C" int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_
         std::map<std::pair<int, int>, int> pairs;
         for (const auto &kv : tmap)
             if (kv.first.first != kv.first.second) pairs[{std::min(kv.first.first, kv.first.second), std::max(kv.first.first, kv.first.second)}] = 1;
-        if ((int)tmap.size() > kHubReprMaxTerms || 2 * (int)pairs.size() + 1 > kHubReprMaxRow) {
+        if ((int)tmap.size() > kHubReprMaxTerms || 2 * (int)pairs.size() + n_exch + 1 > kHubReprMaxRow) {
             set_error("qbh_gen_hubbard_repr: too many distinct one-body terms (%d on %d site pairs)", (int)tmap.size(), (int)pairs.size());
             return QBH_EUNSUPP;
         }
@@ -1848,6 +1897,18 @@ extern "C" int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_
         for (int c = 0; c < 4; ++c) R.pv[p][c] = pair_v[4 * p + c];
     }
     R.n_pairs = n_pairs;
+    for (int e = 0; e < n_exch; ++e) {
+        const int i = exch_sites[2 * e], j = exch_sites[2 * e + 1];
+        if (i < 0 || i >= n_sites || j < 0 || j >= n_sites || i == j) {
+            set_error("qbh_gen_hubbard_repr: spin-exchange term %d needs two different sites of the lattice", e);
+            return QBH_EINVAL;
+        }
+        R.xi[e] = (int8_t)i;
+        R.xj[e] = (int8_t)j;
+        R.xa[e] = exch_amp[e];
+    }
+    R.n_exch = n_exch;
+    R.no_double = no_double ? 1 : 0;
     R.n_trans = n_trans;
     R.n_chunks = (n_sites + 5) / 6;
     for (int g = 0; g < n_trans; ++g) {

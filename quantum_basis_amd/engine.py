@@ -175,7 +175,7 @@ class csr_mat:
 
     @classmethod
     def hubbard_repr(cls, n_sites, n_up, n_dn, bonds, perms, chars, t=1.0, U=1.1, fake_pos=100.0, shard=(0, 1), opts=None,
-                     terms=None, pairs=None):
+                     terms=None, pairs=None, exchange=None, no_double=False):
         """Hubbard family in a translation-symmetric sector, assembled on the device (qbh_gen_hubbard_repr; counterpart of
         model::enumerate_basis_repr + generate_Ham_sparse_repr for the reference's
         examples/trans_symmetric/latt_square/square_Fermi_Hubbard.cc).  Default operator: -t sum_<ij>,sigma (c+_i c_j + h.c.)
@@ -183,9 +183,13 @@ class csr_mat:
         [(i, j, amp_up, amp_dn), ...] replaces the hopping part by explicit directed one-body terms amp * c+_i c_j (they
         must form a translation-invariant operator; U still applies -- pass U=0 for a pure one-body observable).  pairs =
         [(i, j, v_uu, v_ud, v_du, v_dd), ...] adds density-density terms v * n_{i,s} n_{j,s'} (extended Hubbard; spinless t-V
-        with n_dn = 0)."""
+        with n_dn = 0).  exchange = [(i, j, a), ...] adds a * (S+_i S-_j + S-_i S+_j); no_double=True removes the words
+        with doubly occupied sites and projects the hopping (t-J model: see tj_repr)."""
         _lib.require_gpu()
         opts = opts if opts is not None else make_opts()
+        exchange = exchange or []
+        xs = np.ascontiguousarray(np.array([[a[0], a[1]] for a in exchange], dtype=np.int32).reshape(-1, 2))
+        xa = np.ascontiguousarray(np.array([a[2] for a in exchange], dtype=np.float64))
         if terms is None:
             terms = []
             for (i, j) in np.asarray(bonds, dtype=np.int64).reshape(-1, 2):
@@ -203,10 +207,21 @@ class csr_mat:
         h = C.c_void_p()
         dim = C.c_int64(0)
         check(lib().qbh_gen_hubbard_repr(C.byref(h), n_sites, n_up, n_dn, len(terms), _p(sites), _p(aup), _p(adn), float(U),
-                                         len(pairs), _p(psites) if pairs else None, _p(pv) if pairs else None, len(c),
+                                         len(pairs), _p(psites) if pairs else None, _p(pv) if pairs else None,
+                                         len(exchange), _p(xs) if exchange else None, _p(xa) if exchange else None,
+                                         int(bool(no_double)), len(c),
                                          _p(p), _p(c), fake_pos, int(shard[0]), int(shard[1]), C.byref(dim), C.byref(opts)),
               "qbh_gen_hubbard_repr")
         return cls(0, None, None, None, opts=opts, _handle=h)
+
+    @classmethod
+    def tj_repr(cls, n_sites, n_up, n_dn, bonds, perms, chars, t=1.0, J=1.0, **kw):
+        """t-J model in a momentum sector: -t P sum (c+_i c_j + h.c.) P + J sum (S_i.S_j - n_i n_j / 4) without doubly
+        occupied sites (examples/trans_symmetric/latt_kagome/kagome_tJ.cc:98-104)."""
+        b = [(int(i), int(j)) for (i, j) in np.asarray(bonds, dtype=np.int64).reshape(-1, 2)]
+        pairs = [(i, j, 0.0, -0.5 * J, -0.5 * J, 0.0) for (i, j) in b]            # J Sz Sz - J n n / 4
+        exch = [(i, j, 0.5 * J) for (i, j) in b]
+        return cls.hubbard_repr(n_sites, n_up, n_dn, b, perms, chars, t=t, U=0.0, pairs=pairs, exchange=exch, no_double=True, **kw)
 
     # ---- reference interface -------------------------------------------------------------
     def dimension(self):

@@ -622,3 +622,103 @@ def test_reference_asserted_spinless_fermion_honeycomb_energies():
     A = q.csr_mat.hubbard_repr(n, 4, 0, None, [list(range(n))], [1.0], U=0.0, terms=terms, pairs=pairs)
     assert A.info().ncols == 495 and abs(np.linalg.eigvalsh(_dense(A))[0] + 28.60363167) < 1e-8
     A.destroy()
+
+
+def _exchange_operator(n, words, index, exch):
+    """xa (S+_i S-_j + S-_i S+_j) by four successive fermion operators on the operator string"""
+    O = np.zeros((len(words), len(words)), dtype=np.complex128)
+    for a, w in enumerate(words):
+        for (i, j, xa) in exch:
+            for (p, m_) in ((i, j), (j, i)):                # S+_p S-_m = c+_{p,up} c_{p,dn} c+_{m,dn} c_{m,up}
+                sign, cur = 1, w
+                for (site, sp, create) in ((m_, 0, False), (m_, 1, True), (p, 1, False), (p, 0, True)):
+                    r = _apply_fermion(cur, n, site, sp, create)
+                    if r is None:
+                        cur = None
+                        break
+                    sign *= r[0]
+                    cur = r[1]
+                if cur is not None and cur in index:
+                    O[index[cur], a] += xa * sign
+    return O
+
+
+def test_spin_exchange_terms_and_the_tj_constraint_against_explicit_projection():
+    rng = np.random.default_rng(3)
+    for (Lx, Ly, nu, nd, no_double) in [(3, 2, 2, 2, False), (6, 1, 3, 2, False), (6, 1, 2, 2, True), (3, 2, 2, 1, True), (4, 2, 3, 3, True)]:
+        n = Lx * Ly
+        bonds = lattices.chain(Lx) if Ly == 1 else lattices.square(Lx, Ly)
+        perms, shifts = lattices.translations(Lx, Ly)
+        exch = [(i, j, 0.5 * (1.0 + 0.1 * b)) for b, (i, j) in enumerate(bonds[:1])] * 0 + [(i, j, 0.35) for (i, j) in bonds]
+        pairs = [(i, j, 0.0, -0.25, -0.25, 0.0) for (i, j) in bonds]
+        terms = _hubbard_terms(bonds, 1.0)
+        words = [w for w in _words(n, nu, nd) if not (no_double and (w & ((1 << n) - 1)) & (w >> n))]
+        index = {w: i for i, w in enumerate(words)}
+        m = (1 << n) - 1
+        # the hopping restricted to the (possibly constrained) space
+        O = np.zeros((len(words), len(words)), dtype=np.complex128)
+        for a, w in enumerate(words):
+            u, d = w & m, w >> n
+            O[a, a] += (0.0 if no_double else 0.9) * bin(u & d).count("1")
+            for (i, j, au, ad) in terms:
+                r = _hop(u, i, j)
+                if r and (r[1] | (d << n)) in index:
+                    O[index[r[1] | (d << n)], a] += au * r[0]
+                r = _hop(d, i, j)
+                if r and (u | (r[1] << n)) in index:
+                    O[index[u | (r[1] << n)], a] += ad * r[0]
+        O = _add_pairs(O, n, words, pairs) + _exchange_operator(n, words, index, exch)
+        assert np.abs(O - O.conj().T).max() < 1e-14
+        for k in [(0, 0), (1, 0), (Lx - 1, Ly - 1)]:
+            chars = lattices.characters(shifts, k, (Lx, Ly))
+            Ts = [_translation(n, words, index, p) for p in perms]
+            P = sum(c * T for c, T in zip(chars, Ts)) / len(perms)
+            reps = [w for w in words if min(_image(n, p, w & m)[0] | (_image(n, p, w >> n)[0] << n) for p in perms) == w]
+            psi = np.zeros((len(words), len(reps)), dtype=np.complex128)
+            for r, w in enumerate(reps):
+                v = P[:, index[w]]
+                if np.linalg.norm(v) > 1e-10:
+                    psi[:, r] = v / np.linalg.norm(v)
+            Hk = psi.conj().T @ O @ psi
+            A = q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, chars, t=1.0, U=0.0 if no_double else 0.9, pairs=pairs, exchange=exch,
+                                       no_double=no_double, opts=q.make_opts(value_dict=0))
+            M = _dense(A)
+            assert M.shape == Hk.shape, (Lx, Ly, nu, nd, no_double, k, M.shape, Hk.shape)
+            for r in np.nonzero(np.abs(psi).sum(axis=0) == 0)[0]:
+                Hk[r, r] = M[r, r]
+            assert np.abs(M - Hk).max() < 1e-12, (Lx, Ly, nu, nd, no_double, k, np.abs(M - Hk).max())
+            A.destroy()
+
+
+def test_reference_asserted_tj_energies():
+    """examples/trans_symmetric/latt_kagome/kagome_tJ.cc:237-240 (2x2 kagome torus, 12 sites, 4 up + 4 down, t = J = 1: the four
+    momentum sectors), its trans_absent twin (:232, trivial group) and examples/trans_absent/latt_chain/chain_tJ.cc:100-101
+    (L = 12 ring, 4 up + 4 down: doubly degenerate ground state, found here in two momentum sectors)."""
+    kb = lattices.kagome(2, 2)
+    perms, shifts = lattices.translations(2, 2, n_sub=3)
+    want = {(0, 0): -15.41931496, (0, 1): -14.40277723, (1, 0): -14.40277723, (1, 1): -14.40277723}
+    total = 0
+    for k, e_ref in want.items():
+        A = q.csr_mat.tj_repr(12, 4, 4, kb, perms, lattices.characters(shifts, k, (2, 2)), t=1.0, J=1.0)
+        e0 = _lanczos_e0(A, A.info().ncols, maxit=600)
+        assert abs(e0 - e_ref) < 1e-8, (k, e0)
+        ia, ja, val = A.download()
+        rows = np.repeat(np.arange(len(ia) - 1), np.diff(ia))
+        total += int(np.sum(np.abs(val[rows == ja]) < 50.0))          # representatives with non-zero norm at this momentum
+        A.destroy()
+    from math import comb
+    assert total == comb(12, 4) * comb(8, 4)               # 4 up on 12 sites, 4 down on the remaining 8
+    A = q.csr_mat.tj_repr(12, 4, 4, kb, [list(range(12))], [1.0], t=1.0, J=1.0)
+    assert A.info().ncols == comb(12, 4) * comb(8, 4)
+    assert abs(_lanczos_e0(A, A.info().ncols, maxit=600) + 15.41931496) < 1e-8
+    A.destroy()
+    # the ring
+    cb = lattices.chain(12)
+    perms, shifts = lattices.translations(12, 1)
+    e = []
+    for kx in range(12):
+        A = q.csr_mat.tj_repr(12, 4, 4, cb, perms, lattices.characters(shifts, (kx, 0), (12, 1)), t=1.0, J=1.0)
+        e.append(_lanczos_e0(A, A.info().ncols, maxit=600))
+        A.destroy()
+    e = sorted(e)
+    assert abs(e[0] + 9.762087307) < 1e-8 and abs(e[1] + 9.762087307) < 1e-8, e[:3]
