@@ -182,6 +182,33 @@ def gpu_sharded_repr(rank, world, port, backend, out_dir):
     dist.destroy_process_group()
 
 
+def gpu_sharded_hubbard_repr(rank, world, port, backend, out_dir, k=(1, 1)):
+    """A Hubbard momentum sector generated shard by shard (qbh_gen_hubbard_repr with (shard, n_shards) = (rank, world)): the
+    reference's 4x2 torus with 4+4 electrons; the local / remote split is made when the communicator is attached."""
+    import torch
+    dist = _init(rank, world, port, backend)
+    torch.cuda.set_device(0)
+    import quantum_basis_amd as q
+    from quantum_basis_amd import dist as qdist, lattices
+
+    perms, shifts = lattices.translations(4, 2)
+    chars = lattices.characters(shifts, k, (4, 2))
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        opts = q.make_opts(device=0, stream=stream.cuda_stream)
+        A = q.csr_mat.hubbard_repr(8, 4, 4, lattices.square(4, 2), perms, chars, t=1.0, U=1.1, shard=(rank, world), opts=opts)
+        d = int(A.info().ncols)
+        assert A.info().row_offset == qdist.row_partition(d, world)[1][rank][0]
+        comm = qdist.ShardComm(d, rank=rank, world=world, device=torch.device("cuda", 0), stream=stream).attach(A)
+        res = q.locate_E0_lanczos(A, nev=1, ncv=1, maxit=600)
+        assert not comm.errors, comm.errors
+        np.save(os.path.join(out_dir, "vec_%d.npy" % rank), res.eigenvecs)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "res.npy"), np.array([res.E0, res.steps["E0"], res.steps["V0"], d]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def gpu_sharded_hostcsr(rank, world, port, backend, out_dir, native=False, case_name="hubbard_4x2"):
     """The unchanged host code's CSR (reference order, Hermitian-upper, int64) sharded over the ranks: every rank calls
     qbh_csr_create_rows on the SAME host arrays with its nnz-balanced (ragged) row block (qbh_balanced_row_cuts) and

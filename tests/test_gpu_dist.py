@@ -88,6 +88,23 @@ def test_sharded_repr_sector_generated_per_rank(world):
     assert abs(abs(np.vdot(vec, ref.eigenvecs)) - 1.0) < 1e-8 and np.abs(vec.imag).max() > 1e-3
 
 
+@pytest.mark.parametrize("world,k,e_ref", [(2, (1, 1), -12.19847764), (3, (0, 0), -14.07605866)])
+def test_sharded_hubbard_sector_generated_per_rank(world, k, e_ref):
+    """examples/trans_symmetric/latt_square/square_Fermi_Hubbard.cc:146-153 with the sector row-sharded over the ranks"""
+    import torch.multiprocessing as mp
+    import dist_worker
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(dist_worker.gpu_sharded_hubbard_repr, args=(world, _free_port(), "gloo", tmp, k), nprocs=world, join=True)
+        res = np.load(tmp + "/res.npy")
+        vec = np.concatenate([np.load(tmp + "/vec_%d.npy" % r) for r in range(world)])
+    perms, shifts = lattices.translations(4, 2)
+    A = q.csr_mat.hubbard_repr(8, 4, 4, lattices.square(4, 2), perms, lattices.characters(shifts, k, (4, 2)), t=1.0, U=1.1)
+    ref = q.locate_E0_lanczos(A, nev=1, ncv=1, maxit=600)
+    assert int(res[3]) == A.dim
+    assert abs(res[0] - e_ref) < 1e-8 and abs(res[0] - ref.E0) <= 1e-10 * abs(ref.E0)
+    assert abs(abs(np.vdot(vec, ref.eigenvecs)) - 1.0) < 1e-8
+
+
 def test_sharded_matrix_free_row_kernel_with_ragged_shards():
     """Hubbard 4x3 (dim 853,776), matrix-free, 5 ranks: every shard starts and ends inside a row of the
     N_up x N_dn layout, and the real Lanczos vectors take the row-staged kernel."""
