@@ -722,3 +722,36 @@ def test_reference_asserted_tj_energies():
         A.destroy()
     e = sorted(e)
     assert abs(e[0] + 9.762087307) < 1e-8 and abs(e[1] + 9.762087307) < 1e-8, e[:3]
+
+
+def test_no_device_memory_is_leaked_by_the_sector_entry_points():
+    import torch
+    Lx, Ly, nu, nd = 4, 2, 3, 3
+    n = Lx * Ly
+    bonds = lattices.square(Lx, Ly)
+    perms, shifts = lattices.translations(Lx, Ly)
+    ch0 = lattices.characters(shifts, (0, 0), (Lx, Ly))
+    ch1 = lattices.characters(shifts, (1, 0), (Lx, Ly))
+    phase = np.array([np.exp(-2j * np.pi * (s % Lx) / Lx) for s in range(n)])
+
+    def cycle():
+        A = q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, ch0, pairs=[(i, j, 0.1, 0.2, 0.2, 0.1) for (i, j) in bonds],
+                                   exchange=[(i, j, 0.3) for (i, j) in bonds])
+        B = q.csr_mat.tj_repr(n, nu, nd, bonds, perms, ch1, shard=(1, 2))
+        dim = A.info().ncols
+        v = A.vec(2)
+        A.randomize(v.at(0), 1)
+        q.moprXvec_diag_hubrepr(n, nu, nd, perms, ch1, phase, phase, v.at(0), v.at(dim))
+        q.moprXvec_c_hubrepr(n, nu, nd, 0, -1, perms, ch0, ch1, phase, v.at(0), v.at(dim))
+        v.free()
+        A.destroy()
+        B.destroy()
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(40):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (8 << 20), (free0 - free1)
