@@ -232,7 +232,7 @@ int qbh_eigenvec_cg_dev(const qbh_csr *A, int64_t maxit, int64_t *m, double E0, 
 /* Replaces iram<T,csr_mat<T>> / call_arpack (src/lanczos.cc:438-603) for order "sr"/"sa" (lowest) and
  * "lr"/"la" (highest) with the Krylov basis resident in HBM (thick-restart Lanczos == implicitly
  * restarted Lanczos for a Hermitian operator): nev wanted eigenpairs, ncv basis vectors
- * (nev + 2 <= ncv <= 32), at most maxit restarts, tol <= 0 meaning machine epsilon as in ARPACK
+ * (nev + 2 <= ncv <= 64), at most maxit restarts, tol <= 0 meaning machine epsilon as in ARPACK
  * (src/lanczos.cc:452); the start vector is random (ARPACK info = 0, seed selects the Lehmer stream).
  * Outputs like iram: *nconv, eigenvals[nev] in the requested order, eigenvecs_host[nev*n] (may be
  * NULL).  info->n_reorth returns the number of restarts.  Other orders ("sm","lm") return

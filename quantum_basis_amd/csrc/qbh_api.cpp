@@ -1861,8 +1861,8 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
         qbh::set_error("qbh_iram: need nev + 2 <= ncv <= dim");
         return QBH_EINVAL;
     }
-    if (ncv > 32) {
-        qbh::set_error("qbh_iram: ncv > 32 not supported on the device path");
+    if (ncv > 64) {
+        qbh::set_error("qbh_iram: ncv > 64 not supported on the device path");
         return QBH_EUNSUPP;
     }
     if (maxit < 1) return QBH_EINVAL;
@@ -1922,7 +1922,7 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
             return e0 == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP;
         }
     }
-    hipError_t e = hipMalloc(&d_S, 32 * 32 * sizeof(double));
+    hipError_t e = hipMalloc(&d_S, 64 * 64 * sizeof(double));
     if (e != hipSuccess) {
         (void)hipFree(V);
         return QBH_ENOMEM;

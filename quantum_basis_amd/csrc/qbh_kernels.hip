@@ -1433,30 +1433,36 @@ int launch_multi_axpy8(const d2 *V, int64_t ldv, const Coef8 &c, int nv, d2 *w, 
 }
 
 // Restart rotation, in place: V[:, c] <- sum_i S[i + c*m] V[:, i]  for c < keep (S real, m <= 32).
-__global__ __launch_bounds__(kBlock) void k_basis_rotate(d2 *V, int64_t ldv, int64_t n, int m, int keep, const double *S)
+// S is real, so the rotation acts on the real and imaginary parts independently: the basis is treated as vectors of
+// doubles (2n per complex vector; n for the packed-real basis).  MMAX = 32 or 64 basis vectors are held in registers.
+template <int MMAX>
+__global__ __launch_bounds__(kBlock) void k_basis_rotate(double *V, int64_t ldv, int64_t n, int m, int keep, const double *S)
 {
-    __shared__ double Ss[32 * 32];
+    __shared__ double Ss[MMAX * MMAX];
     for (int i = threadIdx.x; i < m * keep; i += kBlock) Ss[i] = S[i];
     __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
-        d2 x[32];
+        double x[MMAX];
 #pragma unroll
-        for (int i = 0; i < 32; ++i)
+        for (int i = 0; i < MMAX; ++i)
             if (i < m) x[i] = V[(size_t)i * ldv + e];
         for (int c = 0; c < keep; ++c) {
-            d2 y = {0.0, 0.0};
+            double y = 0.0;
 #pragma unroll
-            for (int i = 0; i < 32; ++i)
+            for (int i = 0; i < MMAX; ++i)
                 if (i < m) y += Ss[i + c * m] * x[i];
             V[(size_t)c * ldv + e] = y;
         }
     }
 }
 
+// V (complex view: leading dimension ldv and length n in complex elements) <- V S[:, 0..keep), m <= 64
 int launch_basis_rotate(d2 *V, int64_t ldv, int64_t n, int m, int keep, const double *d_S, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_basis_rotate, dim3(blas_grid(n)), dim3(kBlock), 0, s, V, ldv, n, m, keep, d_S);
+    double *Vd = reinterpret_cast<double *>(V);
+    if (m <= 32) hipLaunchKernelGGL(k_basis_rotate<32>, dim3(blas_grid(2 * n)), dim3(kBlock), 0, s, Vd, 2 * ldv, 2 * n, m, keep, d_S);
+    else         hipLaunchKernelGGL(k_basis_rotate<64>, dim3(blas_grid(2 * n)), dim3(kBlock), 0, s, Vd, 2 * ldv, 2 * n, m, keep, d_S);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }

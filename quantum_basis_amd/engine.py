@@ -481,7 +481,7 @@ def _iram_checks(dim, nev, maxit, order):
 def iram(dim, mat, v0, nev, ncv, maxit, order="sr", method="auto", seed=1):
     """iram<T,MAT> (src/lanczos.cc:497-603).  Returns (nconv, eigenvals[nev], eigenvecs[nev*dim]).
 
-    method "device" (default where applicable: order sr/lr, ncv <= 32): the restarted Lanczos process
+    method "device" (default where applicable: order sr/lr, ncv <= 64): the restarted Lanczos process
     runs entirely in HBM (qbh_iram, thick restart == implicit restart for a Hermitian operator).
     method "arpack": the literal reverse-communication loop of call_arpack (src/lanczos.cc:472-477) with
     ARPACK's znaupd/zneupd (scipy's bundled copy; mode 1, bmat='I', tol=0, info=0 so v0 is ignored) and
@@ -492,7 +492,7 @@ def iram(dim, mat, v0, nev, ncv, maxit, order="sr", method="auto", seed=1):
         idx = np.argsort(key(w), kind="stable")[:nev]
         return nev, w[idx].copy(), np.concatenate([z[:, j] for j in idx])
     if method == "auto":
-        method = "device" if (orderC in ("SR", "SA", "LR", "LA") and ncv <= 32) else "arpack"
+        method = "device" if (orderC in ("SR", "SA", "LR", "LA") and ncv <= 64) else "arpack"
     if method == "device":
         nconv = C.c_int64(0)
         w = np.zeros(nev)

@@ -327,6 +327,20 @@ def test_iram_device_resident_against_arpack_and_known_answers():
     assert np.allclose(w, dense[:4], atol=1e-9)
 
 
+def test_iram_device_resident_with_a_large_basis():
+    """the reference's largest calls: iram(20, 30) (examples/trans_symmetric/latt_square/square_Kondo.cc:172) and
+    iram(30, 40) (src/model.cc:2211) -- 40 basis vectors in HBM, eigenvalues against the dense spectrum"""
+    A, O = _both("hubbard_4x2")
+    dense = np.linalg.eigvalsh(O.to_dense())
+    for nev, ncv in ((20, 30), (30, 40), (10, 64)):
+        nconv, w, z = q.iram(A.dim, A, None, nev, ncv, 2000, "sr", method="device")
+        assert nconv == nev and np.allclose(w, dense[:nev], atol=1e-8), (nev, ncv, np.abs(w - dense[:nev]).max())
+        Z = z.reshape(nev, A.dim)
+        assert np.allclose(Z.conj() @ Z.T, np.eye(nev), atol=1e-8)
+        for j in (0, nev - 1):
+            assert np.linalg.norm(O.multmv(Z[j]) - w[j] * Z[j]) < 1e-7
+
+
 def test_iram_main_test_tj_chain_degenerate_pair():
     """src/main_test.cc:113-211: locate_E0_iram(full, 4, 8) on the t-J chain, E0 = E1 = -9.762087307."""
     k = helpers.known()["tJ_chain12"]
