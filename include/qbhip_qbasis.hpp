@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "qbhip.h"
@@ -62,6 +63,18 @@ public:
         check(qbh_csr_create(&handle, dim, nnz, sym ? 1 : 0, reinterpret_cast<const int64_t *>(ia),
                              reinterpret_cast<const int64_t *>(ja), reinterpret_cast<const qbh_z *>(val), opts),
               "create_handle failed");                       // src/sparse.cc:259
+    }
+
+    // wrap an operator that was assembled on the device (qbh_gen_*): there are no host arrays; dim = its row count
+    static csr_mat from_device(qbh_csr *h)
+    {
+        csr_mat m;
+        qbh_csr_info info;
+        check(qbh_csr_get_info(h, &info), "qbh_csr_get_info failed");
+        m.dim = info.nrows;
+        m.nnz = info.nnz;
+        m.handle = h;
+        return m;
     }
 
     csr_mat(const csr_mat &old) : dim(old.dim), nnz(old.nnz), sym(old.sym)   // deep copy, src/sparse.cc:114-138
@@ -251,6 +264,31 @@ inline void vec_randomize(const csr_mat &mat, cplx *x, const uint32_t &seed)
     if (rc == QBH_OK) rc = qbh_vec_download(mat.handle, reinterpret_cast<qbh_z *>(x), d, mat.dim);
     qbh_vec_free(d);
     check(rc, "vec_randomize");
+}
+
+// A translation-symmetric sector of the Hubbard family assembled on the device: what
+// model::enumerate_basis_repr + generate_Ham_sparse_repr produce for
+// examples/trans_symmetric/latt_square/square_Fermi_Hubbard.cc (see qbh_gen_hubbard_repr in qbhip.h).  bonds: (i, j) pairs,
+// each giving -t (c+_i c_j + h.c.) for both species; perms[g * n_sites + s] = image of site s under translation g
+// (lattice::translation_plan), chars[g] = exp(-i k.t_g).
+inline csr_mat hubbard_sector(int n_sites, int n_up, int n_dn, const std::vector<std::pair<int, int>> &bonds, double t, double U,
+                              const std::vector<int32_t> &perms, const std::vector<cplx> &chars, const qbh_opts *opts = nullptr)
+{
+    std::vector<int32_t> sites;
+    std::vector<cplx> amp;
+    for (const auto &b : bonds) {
+        sites.insert(sites.end(), {b.first, b.second, b.second, b.first});
+        amp.push_back(cplx(-t));
+        amp.push_back(cplx(-t));
+    }
+    qbh_csr *h = nullptr;
+    int64_t dim = 0;
+    check(qbh_gen_hubbard_repr(&h, n_sites, n_up, n_dn, (int)amp.size(), sites.data(), reinterpret_cast<const qbh_z *>(amp.data()),
+                               reinterpret_cast<const qbh_z *>(amp.data()), U, 0, nullptr, nullptr, 0, nullptr, nullptr, 0,
+                               (int)chars.size(), perms.data(), reinterpret_cast<const double *>(chars.data()), 100.0, 0, 1, &dim,
+                               opts),
+          "qbh_gen_hubbard_repr failed");
+    return csr_mat::from_device(h);
 }
 
 // The four stages of model<T>::locate_E0_lanczos (src/model.cc:1123-1316) for a CSR operator, as a free

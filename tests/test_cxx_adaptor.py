@@ -92,3 +92,16 @@ def test_sharded_cxx_host_rank_over_native_rccl(force_ragged):
         m, E0, mcg, accu, nrm = int(tok[5]), float(tok[6]), int(tok[7]), float(tok[8]), float(tok[9])
         assert abs(m - 82) <= 1 and abs(E0 + 14.076058658879278) < 1e-9
         assert abs(mcg - 83) <= 2 and accu < 2e-12 and abs(nrm - 1.0) < 1e-10
+
+
+@pytest.mark.gpu
+def test_cxx_program_following_the_reference_example_reproduces_its_asserted_sector_energies():
+    """tests/cxx/sectors_main.cpp = examples/trans_symmetric/latt_square/square_Fermi_Hubbard.cc through the C++ header:
+    eight momentum sectors assembled on the device, locate_E0_lanczos in each, the reference's asserts (:146-153)."""
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = _build(tmp, "sectors_main")
+        p = subprocess.run([exe], capture_output=True, text=True)
+        assert p.returncode == 0, p.stdout + p.stderr
+        last = [ln for ln in p.stdout.splitlines() if ln.startswith("OK ")][-1]
+        assert float(last.split()[1]) < 1e-8
+        assert p.stdout.count("k=(") == 8
