@@ -430,6 +430,17 @@ int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_t
                          int n_trans, const int32_t *perms, const double *chars, double fake_pos,
                          int shard, int n_shards, int64_t *dim_out, const qbh_opts *opts);
 
+/* The same sector operator in MATRIX-FREE form with a small stored remainder (single GPU; no spin-exchange terms, real
+ * up-species and number-operator amplitudes).  Representatives are ordered by the down pattern first: in a down block whose
+ * pattern is trivially stabilised every up pattern is a representative, the up hops are the full-basis up-hop table applied
+ * inside the block and each down hop is (target block, translation, coefficient); only the rows in or next to stabilised
+ * blocks (< 1 %) are stored as CSR.  4x5 at half filling: ~40 MB of tables + ~1 GB instead of 364 GB.  The handle works with
+ * every solver entry point; qbh_csr_download and qbh_csr_set_comm refuse it. */
+int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_terms, const int32_t *term_sites,
+                        const qbh_z *amp_up, const qbh_z *amp_dn, double U, int n_pairs, const int32_t *pair_sites,
+                        const double *pair_v, int n_trans, const int32_t *perms, const double *chars, double fake_pos,
+                        int64_t *dim_out, const qbh_opts *opts);
+
 /* moprXvec_repr (src/model.cc:1715-1846, diagonal branch) between two momentum sectors of qbh_gen_hubbard_repr for
  * O = sum_s ( coef_up[s] n_{s,up} + coef_dn[s] n_{s,dn} ), e.g. the density N_q (coef_up = coef_dn = e^{iq.r_s}) or S^z_q
  * (coef_up = -coef_dn = e^{iq.r_s}/2).  The coefficients must transform with a character, c_{g(s)} = eta(g) c_s (checked);

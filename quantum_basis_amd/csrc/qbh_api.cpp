@@ -433,6 +433,13 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
         (void)hipFree(A->mf.val_d);
         if (A->mf.pk_d) (void)hipFree(A->mf.pk_d);
     }
+    if (A->mfsec) {
+        for (void *q : {(void *)A->mfsec->blk, (void *)A->mfsec->hop, (void *)A->mfsec->item, (void *)A->mfsec->ucfg,
+                        (void *)A->mfsec->upell, (void *)A->mfsec->prank, (void *)A->d_mfsec})
+            if (q) (void)hipFree(q);
+        delete A->mfsec;
+        A->mfsec = nullptr;
+    }
     if (A->kind == 2) {
         (void)hipFree(A->mfh.binom);
         (void)hipFree(A->mfh.chunk);
@@ -688,6 +695,10 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
     if (!comm || comm->nranks < 1) {          // NULL detaches; a 1-rank communicator is valid (hooks still run)
         A->has_comm = false;
         return QBH_OK;
+    }
+    if (A->mfsec) {
+        qbh::set_error("qbh_csr_set_comm: the matrix-free sector operator is a single-GPU form");
+        return QBH_EUNSUPP;
     }
     if (!comm->d_xsend || !comm->d_xfull || !comm->d_scal || !comm->allgather_x || !comm->allreduce_sum ||
         comm->rank < 0 || comm->rank >= comm->nranks || comm->nblk < A->nrows) {
@@ -951,6 +962,25 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     if (prof) {
         harvest_events(A);
         QBH_HIP(hipEventRecord(A->ev0, A->stream));
+    }
+    if (A->mfsec) {
+        // Hubbard momentum sector in matrix-free form: y <- alpha MF(x) + beta y + gamma x first, then the stored remainder
+        // accumulates onto it (and forms the reductions on the final y)
+        qbh::MfSecArgs ms{};
+        ms.t = A->d_mfsec;
+        ms.n_items = A->mfsec->n_items;
+        ms.xg = a.xg;
+        ms.xl = a.xl;
+        ms.xr = a.xr;
+        ms.xl_re = a.xl_re;
+        ms.y = a.y;
+        ms.y_re = a.y_re;
+        ms.alpha = alpha;
+        ms.beta = beta;
+        ms.gamma = gamma;
+        QBH_TRY(qbh::launch_mf_sector(ms, A->stream));
+        a.beta = 1.0;
+        a.gamma = 0.0;
     }
     QBH_TRY(qbh::launch_spmv(a, A->kernel, A->npb, A->tpr, A->grid, A->stream));
     if (prof) {
@@ -2094,7 +2124,7 @@ int download_part(const qbh_csr *A, const int64_t *d_ia, const int32_t *d_ja, co
 extern "C" int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1, int64_t *ia, int32_t *ja, qbh_z *val)
 {
     if (!A || r0 < 0 || r1 < r0 || r1 > A->nrows) return QBH_EINVAL;
-    if (A->kind != 0) {
+    if (A->kind != 0 || A->mfsec) {
         qbh::set_error("qbh_csr_download: the operator is matrix-free (no stored CSR)");
         return QBH_EUNSUPP;
     }

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "qbh_internal.hpp"
@@ -2418,5 +2419,536 @@ extern "C" int qbh_mopr_c_hubrepr_dev(int n_sites, int n_up_old, int n_dn_old, i
     }
     if (dim_old_out) *dim_old_out = dim_o;
     if (dim_new_out) *dim_new_out = dim_n;
+    return QBH_OK;
+}
+
+// ---------------------- Hubbard momentum sector, matrix-free with a stored remainder --------
+// qbh_mf_hubbard_repr: see MfSec in qbh_internal.hpp.  The operator is  y = MF(x) + R x : MF covers, for every row of a
+// regular down block, the diagonal, all up hops (inside the block, g* = identity) and every down hop whose target block is
+// regular; R (ordinary CSR, the handle's arrays) holds the complete rows of stabilised blocks and the few entries of
+// regular rows that land in a stabilised block.  4x5 at half filling: 364 GB of CSR become ~40 MB of tables + ~1 GB of
+// remainder, and the sector runs on ONE GPU.
+namespace qbh {
+namespace {
+
+constexpr int kSecTile = 1024;
+
+// row i of the remainder: full row for a stabilised block, otherwise only the flagged down hops (bit t of flags[blk])
+__device__ int hubrepr_row_rem(const HubReprDev &R, const uint64_t *tab, const uint64_t *reps, const uint8_t *info, int64_t dim,
+                               int64_t i, const MfSecBlock *blk, int64_t n_blocks, const uint64_t *flags, int32_t *cols, d2 *vals)
+{
+    const uint64_t a = reps[i];
+    const uint32_t d = (uint32_t)(a >> R.n_sites);
+    int64_t lo = 0, hi = n_blocks;                     // block of this row: ascending down patterns
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (blk[mid].d < d) lo = mid + 1;
+        else hi = mid;
+    }
+    if (!blk[lo].regular) return hubrepr_row(R, tab, reps, info, dim, i, cols, vals);
+    const uint64_t *fl = flags + lo * 8;
+    bool any = false;
+    for (int w = 0; w < 8; ++w) any = any || fl[w] != 0;
+    if (!any) return 0;
+    const double sa = (double)(info[i] & 0x7f);
+    const uint64_t mlow = (1ULL << R.n_sites) - 1ULL;
+    const uint64_t au = a & mlow, ad = a >> R.n_sites;
+    int n = 0;
+    for (int t = 0; t < R.n_terms; ++t) {
+        if (!((fl[t >> 6] >> (t & 63)) & 1ULL)) continue;
+        const int ti = R.ti[t], tj = R.tj[t];
+        const double ar = R.adn[t][0], ai = R.adn[t][1];
+        if ((ar == 0.0 && ai == 0.0) || ti == tj) continue;
+        if (!((ad >> ti) & 1ULL) || ((ad >> tj) & 1ULL)) continue;
+        const int lo_s = ti < tj ? ti : tj, hi_s = ti < tj ? tj : ti;
+        const uint64_t between = ((1ULL << hi_s) - 1ULL) & ~((2ULL << lo_s) - 1ULL);
+        int par = __popcll(ad & between) & 1;
+        const uint64_t occ2 = ad ^ (1ULL << ti) ^ (1ULL << tj);
+        const uint64_t c = au | (occ2 << R.n_sites);
+        int g = 0, pt = 0;
+        const uint64_t b = hubrepr_canonical(R, tab, c, &g, &pt);
+        par ^= pt;
+        int64_t l2 = 0, h2 = dim;
+        while (l2 < h2) {
+            const int64_t mid = (l2 + h2) >> 1;
+            if (reps[mid] < b) l2 = mid + 1;
+            else h2 = mid;
+        }
+        const uint8_t cj = info[l2];
+        if (cj & 0x80) continue;
+        const double f = (par ? -1.0 : 1.0) * sqrt((double)(cj & 0x7f) / sa);
+        const double cr = R.chr[2 * g], cim = -R.chr[2 * g + 1];
+        const d2 v = {f * (ar * cr - ai * cim), f * (ar * cim + ai * cr)};
+        int q = 0;
+        while (q < n && cols[q] != (int32_t)l2) ++q;
+        if (q < n) {
+            vals[q] += v;
+        } else if (n < kHubReprMaxRow) {
+            cols[n] = (int32_t)l2;
+            vals[n] = v;
+            ++n;
+        }
+    }
+    for (int q = 1; q < n; ++q) {                      // ascending columns
+        const int32_t c = cols[q];
+        const d2 v = vals[q];
+        int p = q - 1;
+        while (p >= 0 && cols[p] > c) {
+            cols[p + 1] = cols[p];
+            vals[p + 1] = vals[p];
+            --p;
+        }
+        cols[p + 1] = c;
+        vals[p + 1] = v;
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(128) void k_secrem_count(const HubReprDev *Rp, const uint64_t *tab, const uint64_t *reps, const uint8_t *info,
+                                                      int64_t dim, const MfSecBlock *blk, int64_t n_blocks, const uint64_t *flags,
+                                                      int32_t *cnt)
+{
+    int32_t cols[kHubReprMaxRow];
+    d2 vals[kHubReprMaxRow];
+    const int64_t stride = (int64_t)gridDim.x * 128;
+    for (int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x; i < dim; i += stride)
+        cnt[i] = hubrepr_row_rem(*Rp, tab, reps, info, dim, i, blk, n_blocks, flags, cols, vals);
+}
+
+__global__ __launch_bounds__(128) void k_secrem_fill(const HubReprDev *Rp, const uint64_t *tab, const uint64_t *reps, const uint8_t *info,
+                                                     int64_t dim, const MfSecBlock *blk, int64_t n_blocks, const uint64_t *flags,
+                                                     const int64_t *ia, int32_t *ja, d2 *val)
+{
+    int32_t cols[kHubReprMaxRow];
+    d2 vals[kHubReprMaxRow];
+    const int64_t stride = (int64_t)gridDim.x * 128;
+    for (int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x; i < dim; i += stride) {
+        if (ia[i + 1] == ia[i]) continue;
+        const int m = hubrepr_row_rem(*Rp, tab, reps, info, dim, i, blk, n_blocks, flags, cols, vals);
+        const int64_t p0 = ia[i];
+        for (int q = 0; q < m; ++q) {
+            ja[p0 + q] = cols[q];
+            val[p0 + q] = vals[q];
+        }
+    }
+}
+
+template <bool REALX>
+__global__ __launch_bounds__(256) void k_mf_sector(MfSecArgs a)
+{
+    const MfSec &T = *a.t;
+    const int64_t cu = T.cu;
+    for (int64_t it = blockIdx.x; it < a.n_items; it += gridDim.x) {
+        const int64_t w = T.item[it];
+        const MfSecBlock B = T.blk[w >> 20];
+        const int tile = (int)(w & 0xFFFFF);
+        for (int j = 0; j < kSecTile / 256; ++j) {
+            const int r = tile * kSecTile + j * 256 + (int)threadIdx.x;
+            if (r >= B.nrows) break;
+            const int64_t row = B.row0 + r;
+            d2 sum = {0.0, 0.0};
+            if (B.regular) {
+                const uint32_t u = T.ucfg[r], d = B.d;
+                double dr = T.U * (double)__popc(u & d), di = 0.0;
+                for (int p = 0; p < T.n_pairs; ++p) {
+                    const int iu = (u >> T.pi[p]) & 1, id = (d >> T.pi[p]) & 1, ju = (u >> T.pj[p]) & 1, jd = (d >> T.pj[p]) & 1;
+                    dr += T.pv[p][0] * (iu & ju) + T.pv[p][1] * (iu & jd) + T.pv[p][2] * (id & ju) + T.pv[p][3] * (id & jd);
+                }
+                for (uint32_t m = u; m; m &= m - 1) { const int s = __ffs(m) - 1; dr += T.nup[s]; }
+                for (uint32_t m = d; m; m &= m - 1) { const int s = __ffs(m) - 1; dr += T.ndn[s]; }
+                const d2 x0 = REALX ? d2{a.xr[row], 0.0} : a.xg[row];
+                sum = d2{dr * x0.x - di * x0.y, dr * x0.y + di * x0.x};
+                for (int k = 0; k < T.w_up; ++k) {         // up hops: inside the block
+                    const uint32_t e = T.upell[(size_t)k * cu + r];
+                    if (e == 0xFFFFFFFFu) break;
+                    const double am = T.updict[e >> 24];
+                    const int64_t c = B.row0 + (e & 0xFFFFFFu);
+                    if (REALX) sum.x += am * a.xr[c];
+                    else       sum += am * a.xg[c];
+                }
+                for (int h = 0; h < B.nhop; ++h) {         // down hops into regular blocks
+                    const MfSecHop H = T.hop[B.hop0 + h];
+                    const uint32_t pr = T.prank[(size_t)H.g * cu + r];
+                    const double sg = (pr >> 31) ? -1.0 : 1.0;
+                    const int64_t c = H.off + (pr & 0x7FFFFFFFu);
+                    if (REALX) {
+                        sum.x += sg * H.cr * a.xr[c];
+                    } else {
+                        const d2 xv = a.xg[c];
+                        sum += d2{sg * (H.cr * xv.x - H.ci * xv.y), sg * (H.cr * xv.y + H.ci * xv.x)};
+                    }
+                }
+            }
+            d2 yo = {0.0, 0.0}, xi = {0.0, 0.0};
+            if (a.beta != 0.0) yo = a.y_re ? d2{a.y_re[row], 0.0} : a.y[row];
+            if (a.gamma != 0.0) xi = a.y_re ? d2{a.xl_re[row], 0.0} : a.xl[row];
+            const d2 yn = a.alpha * sum + a.beta * yo + a.gamma * xi;
+            if (a.y_re) a.y_re[row] = yn.x;
+            else        a.y[row] = yn;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_mf_sector(const MfSecArgs &a, hipStream_t s)
+{
+    const int grid = (int)std::min<int64_t>(a.n_items, 256 * 8);
+    if (a.xr != nullptr) hipLaunchKernelGGL(k_mf_sector<true>, dim3(grid), dim3(256), 0, s, a);
+    else                 hipLaunchKernelGGL(k_mf_sector<false>, dim3(grid), dim3(256), 0, s, a);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+}  // namespace qbh
+
+extern "C" int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_terms, const int32_t *term_sites,
+                                   const qbh_z *amp_up, const qbh_z *amp_dn, double U, int n_pairs, const int32_t *pair_sites,
+                                   const double *pair_v, int n_trans, const int32_t *perms, const double *chars, double fake_pos,
+                                   int64_t *dim_out, const qbh_opts *opts)
+{
+    using namespace qbh;
+    const char *who = "qbh_mf_hubbard_repr";
+    if (!out || (n_terms > 0 && (!term_sites || !amp_up || !amp_dn)) || !perms || !chars || n_sites <= 0 || n_sites > 24 || n_up < 0 ||
+        n_up > n_sites || n_dn < 0 || n_dn > n_sites || n_terms < 0 || n_pairs < 0 || n_pairs > 128 ||
+        (n_pairs > 0 && (!pair_sites || !pair_v)) || n_trans < 1 || n_trans > kReprMaxTrans) {
+        set_error("%s: invalid argument (<= 24 sites, <= 128 density-density terms, <= 64 translations)", who);
+        return QBH_EINVAL;
+    }
+    if (qbh_device_count() <= 0) {
+        set_error("no HIP device visible");
+        return QBH_ENODEVICE;
+    }
+    if (opts && opts->device >= 0) QBH_HIP(hipSetDevice(opts->device));
+    // ---- the operator, exactly as qbh_gen_hubbard_repr merges it
+    std::map<std::pair<int, int>, std::array<double, 4>> tmap;
+    for (int t = 0; t < n_terms; ++t) {
+        const int i = term_sites[2 * t], j = term_sites[2 * t + 1];
+        if (i < 0 || i >= n_sites || j < 0 || j >= n_sites) {
+            set_error("%s: term %d acts on a site outside the lattice", who, t);
+            return QBH_EINVAL;
+        }
+        auto &a = tmap[{i, j}];
+        a[0] += amp_up[t].re;
+        a[1] += amp_up[t].im;
+        a[2] += amp_dn[t].re;
+        a[3] += amp_dn[t].im;
+    }
+    if ((int)tmap.size() > kHubReprMaxTerms) {
+        set_error("%s: too many distinct one-body terms", who);
+        return QBH_EUNSUPP;
+    }
+    std::vector<HubReprDev> rr(1);
+    std::vector<uint64_t> tab;
+    QBH_TRY(hubrepr_symmetry(rr[0], tab, n_sites, n_up, n_dn, n_trans, perms, chars, who));
+    HubReprDev &R = rr[0];
+    for (const auto &kv : tmap) {
+        R.ti[R.n_terms] = (int8_t)kv.first.first;
+        R.tj[R.n_terms] = (int8_t)kv.first.second;
+        R.aup[R.n_terms][0] = kv.second[0];
+        R.aup[R.n_terms][1] = kv.second[1];
+        R.adn[R.n_terms][0] = kv.second[2];
+        R.adn[R.n_terms][1] = kv.second[3];
+        if (kv.second[1] != 0.0 || (kv.first.first == kv.first.second && kv.second[3] != 0.0)) {
+            set_error("%s: complex up-species or number-operator amplitudes are not supported by the matrix-free form", who);
+            return QBH_EUNSUPP;
+        }
+        R.n_terms++;
+    }
+    R.U = U;
+    R.fake_pos = fake_pos;
+    for (int p = 0; p < n_pairs; ++p) {
+        const int i = pair_sites[2 * p], j = pair_sites[2 * p + 1];
+        if (i < 0 || i >= n_sites || j < 0 || j >= n_sites) {
+            set_error("%s: density-density term %d acts on a site outside the lattice", who, p);
+            return QBH_EINVAL;
+        }
+        R.pi[p] = (int8_t)i;
+        R.pj[p] = (int8_t)j;
+        for (int c = 0; c < 4; ++c) R.pv[p][c] = pair_v[4 * p + c];
+    }
+    R.n_pairs = n_pairs;
+
+    // ---- host tables
+    std::vector<uint32_t> ucfg, dcfg;
+    enumerate_configs(n_sites, n_up, ucfg);
+    enumerate_configs(n_sites, n_dn, dcfg);
+    const int64_t cu = (int64_t)ucfg.size();
+    if (cu >= (1 << 24)) {
+        set_error("%s: more than 2^24 up configurations", who);
+        return QBH_EUNSUPP;
+    }
+    auto image = [&](int g, uint32_t s) {
+        uint32_t o = 0;
+        for (uint32_t m = s; m; m &= m - 1) o |= 1u << perms[(size_t)g * n_sites + __builtin_ctz(m)];
+        return o;
+    };
+    auto parity = [&](int g, uint32_t s) {
+        uint32_t seen = 0;
+        int par = 0;
+        for (uint32_t m = s; m; m &= m - 1) {
+            const int img = perms[(size_t)g * n_sites + __builtin_ctz(m)];
+            par ^= __builtin_popcount(seen >> img) & 1;
+            seen |= 1u << img;
+        }
+        return par;
+    };
+    auto between_par = [](uint32_t occ, int i, int j) {
+        const int lo = std::min(i, j), hi = std::max(i, j);
+        const uint32_t between = (uint32_t)(((1ULL << hi) - 1ULL) & ~((2ULL << lo) - 1ULL));
+        return __builtin_popcount(occ & between) & 1;
+    };
+    // translated up patterns: rank and parity
+    std::vector<uint32_t> prank((size_t)n_trans * (size_t)cu), uimg((size_t)n_trans * (size_t)cu);
+    for (int g = 0; g < n_trans; ++g)
+        for (int64_t r = 0; r < cu; ++r) {
+            const uint32_t im = image(g, ucfg[(size_t)r]);
+            uimg[(size_t)g * cu + r] = im;
+            const uint32_t rk = (uint32_t)(std::lower_bound(ucfg.begin(), ucfg.end(), im) - ucfg.begin());
+            prank[(size_t)g * cu + r] = rk | ((uint32_t)parity(g, ucfg[(size_t)r]) << 31);
+        }
+    // up-hop table (ELL) with a dictionary of signed amplitudes
+    std::vector<std::vector<std::pair<uint32_t, double>>> uprow((size_t)cu);
+    int w_up = 0;
+    for (int64_t r = 0; r < cu; ++r) {
+        const uint32_t u = ucfg[(size_t)r];
+        std::map<uint32_t, double> row;
+        for (int t = 0; t < R.n_terms; ++t) {
+            const int ti = R.ti[t], tj = R.tj[t];
+            if (ti == tj || R.aup[t][0] == 0.0) continue;
+            if (!((u >> ti) & 1u) || ((u >> tj) & 1u)) continue;
+            const uint32_t u2 = u ^ (1u << ti) ^ (1u << tj);
+            const uint32_t rk = (uint32_t)(std::lower_bound(ucfg.begin(), ucfg.end(), u2) - ucfg.begin());
+            row[rk] += R.aup[t][0] * (between_par(u, ti, tj) ? -1.0 : 1.0);
+        }
+        for (const auto &e : row)
+            if (e.second * e.second >= 1e-28) uprow[(size_t)r].push_back(e);
+        w_up = std::max(w_up, (int)uprow[(size_t)r].size());
+    }
+    std::vector<double> updict;
+    std::vector<uint32_t> upell((size_t)std::max(w_up, 1) * (size_t)cu, 0xFFFFFFFFu);
+    for (int64_t r = 0; r < cu; ++r)
+        for (size_t k = 0; k < uprow[(size_t)r].size(); ++k) {
+            const double v = uprow[(size_t)r][k].second;
+            size_t code = std::find(updict.begin(), updict.end(), v) - updict.begin();
+            if (code == updict.size()) {
+                if (updict.size() >= 255) {
+                    set_error("%s: more than 255 distinct up-hop amplitudes", who);
+                    return QBH_EUNSUPP;
+                }
+                updict.push_back(v);
+            }
+            upell[k * (size_t)cu + (size_t)r] = ((uint32_t)code << 24) | uprow[(size_t)r][k].first;
+        }
+    // canonical down patterns, their stabilisers, the rows of every block
+    struct HostBlock { uint32_t d; std::vector<int> stab; int64_t nrows, row0; };
+    std::vector<HostBlock> hb;
+    for (uint32_t d : dcfg) {
+        bool canon = true;
+        std::vector<int> stab;
+        for (int g = 1; g < n_trans && canon; ++g) {
+            const uint32_t im = image(g, d);
+            if (im < d) canon = false;
+            else if (im == d) stab.push_back(g);
+        }
+        if (!canon) continue;
+        HostBlock b{d, stab, 0, 0};
+        if (stab.empty()) {
+            b.nrows = cu;
+        } else {
+            for (int64_t r = 0; r < cu; ++r) {
+                bool rep = true;
+                for (int g : stab)
+                    if (uimg[(size_t)g * cu + r] < ucfg[(size_t)r]) {
+                        rep = false;
+                        break;
+                    }
+                b.nrows += rep ? 1 : 0;
+            }
+        }
+        hb.push_back(b);
+    }
+    int64_t dim = 0;
+    for (auto &b : hb) {
+        b.row0 = dim;
+        dim += b.nrows;
+    }
+    if (dim <= 0 || dim >= 2147483647LL) {
+        set_error("%s: sector dimension %lld out of range", who, (long long)dim);
+        return QBH_EUNSUPP;
+    }
+    const int64_t n_blocks = (int64_t)hb.size();
+    auto block_of = [&](uint32_t d) {
+        int64_t lo = 0, hi = n_blocks;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (hb[(size_t)mid].d < d) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo;
+    };
+    std::vector<MfSecBlock> blk((size_t)n_blocks);
+    std::vector<MfSecHop> hops;
+    std::vector<uint64_t> flags((size_t)n_blocks * 8, 0ULL);
+    std::vector<int64_t> items;
+    bool all_real = true;
+    for (int64_t bi = 0; bi < n_blocks; ++bi) {
+        const HostBlock &b = hb[(size_t)bi];
+        MfSecBlock &B = blk[(size_t)bi];
+        B.row0 = b.row0;
+        B.d = b.d;
+        B.nrows = (int32_t)b.nrows;
+        B.regular = b.stab.empty() ? 1 : 0;
+        B.hop0 = (int32_t)hops.size();
+        B.nhop = 0;
+        for (int64_t tl = 0; tl * kSecTile < b.nrows; ++tl) items.push_back((bi << 20) | tl);
+        if (!B.regular) continue;
+        std::map<std::pair<int64_t, int>, std::pair<double, double>> acc;     // (target row0, g) -> coefficient
+        for (int t = 0; t < R.n_terms; ++t) {
+            const int ti = R.ti[t], tj = R.tj[t];
+            const double ar = R.adn[t][0], ai = R.adn[t][1];
+            if (ti == tj || (ar == 0.0 && ai == 0.0)) continue;
+            if (!((b.d >> ti) & 1u) || ((b.d >> tj) & 1u)) continue;
+            const uint32_t d2p = b.d ^ (1u << ti) ^ (1u << tj);
+            uint32_t best = d2p;
+            int gb = 0;
+            for (int g = 1; g < n_trans; ++g) {
+                const uint32_t im = image(g, d2p);
+                if (im < best) {
+                    best = im;
+                    gb = g;
+                }
+            }
+            const int64_t tb = block_of(best);
+            if (!hb[(size_t)tb].stab.empty()) {             // stabilised target: the entry goes to the stored remainder
+                flags[(size_t)bi * 8 + (size_t)(t >> 6)] |= 1ULL << (t & 63);
+                continue;
+            }
+            const double sg = ((between_par(b.d, ti, tj) ^ (gb ? parity(gb, d2p) : 0)) ? -1.0 : 1.0);
+            const double cr = chars[2 * gb], cim = -chars[2 * gb + 1];                 // conj(chi(g*))
+            auto &c = acc[{hb[(size_t)tb].row0, gb}];
+            c.first += sg * (ar * cr - ai * cim);
+            c.second += sg * (ar * cim + ai * cr);
+        }
+        for (const auto &e : acc) {
+            if (e.second.first * e.second.first + e.second.second * e.second.second < 1e-28) continue;
+            hops.push_back(MfSecHop{e.first.first, e.first.second, 0, e.second.first, e.second.second});
+            if (e.second.second != 0.0) all_real = false;
+            B.nhop++;
+        }
+    }
+    if (hb.size() >= (1u << 20) * 2048ULL) {
+        set_error("%s: too many blocks", who);
+        return QBH_EUNSUPP;
+    }
+
+    // ---- device: representatives (for the remainder), tables, remainder CSR
+    std::vector<void *> pool;
+    HubReprDev *d_R = nullptr;
+    uint64_t *d_tab = nullptr, *d_reps = nullptr, *d_flags = nullptr;
+    uint8_t *d_info = nullptr;
+    int64_t dim_dev = 0;
+    MfSec *ms = new MfSec();
+    auto drop_tables = [&]() {
+        for (void *q : {(void *)ms->blk, (void *)ms->hop, (void *)ms->item, (void *)ms->ucfg, (void *)ms->upell, (void *)ms->prank})
+            if (q) (void)hipFree(q);
+        delete ms;
+    };
+    int rc = hubrepr_enumerate(R, tab, pool, &d_R, &d_tab, &d_reps, &d_info, &dim_dev, who);
+    if (rc == QBH_OK && dim_dev != dim) {
+        set_error("%s: block table (%lld rows) and enumeration (%lld representatives) disagree", who, (long long)dim, (long long)dim_dev);
+        rc = QBH_EHIP;
+    }
+    int32_t *d_cnt = nullptr, *d_ja = nullptr;
+    int64_t *d_ia = nullptr;
+    d2 *d_val = nullptr;
+    int64_t nnz = 0;
+    hipError_t e = hipSuccess;
+    auto up = [&](auto **dst, const auto &h) {
+        using T = typename std::remove_reference<decltype(h)>::type::value_type;
+        if (e != hipSuccess || rc != QBH_OK) return;
+        e = hipMalloc((void **)dst, std::max<size_t>(h.size(), 1) * sizeof(T));
+        if (e == hipSuccess && !h.empty()) e = hipMemcpy(*dst, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    };
+    up(&ms->blk, blk);
+    up(&ms->hop, hops);
+    up(&ms->item, items);
+    up(&ms->ucfg, ucfg);
+    up(&ms->upell, upell);
+    up(&ms->prank, prank);
+    up(&d_flags, flags);
+    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&d_cnt, (size_t)dim * sizeof(int32_t));
+    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&d_ia, (size_t)(dim + 1) * sizeof(int64_t));
+    const int rgrid = (int)std::min<int64_t>((dim + 127) / 128, 256 * 16);
+    if (rc == QBH_OK && e == hipSuccess) {
+        hipLaunchKernelGGL(k_secrem_count, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, ms->blk, n_blocks, d_flags, d_cnt);
+        e = hipGetLastError();
+    }
+    if (rc == QBH_OK && e == hipSuccess) rc = exclusive_scan(d_cnt, dim, d_ia, 0);
+    if (rc == QBH_OK && e == hipSuccess) e = hipMemcpy(&nnz, d_ia + dim, sizeof(int64_t), hipMemcpyDeviceToHost);
+    if (d_cnt) (void)hipFree(d_cnt);
+    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&d_ja, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t));
+    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&d_val, (size_t)std::max<int64_t>(nnz, 1) * sizeof(d2));
+    if (rc == QBH_OK && e == hipSuccess && nnz > 0) {
+        hipLaunchKernelGGL(k_secrem_fill, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, ms->blk, n_blocks, d_flags, d_ia, d_ja,
+                           d_val);
+        e = hipGetLastError();
+    }
+    if (rc == QBH_OK && e == hipSuccess) e = hipDeviceSynchronize();
+    free_pool(pool);
+    for (void *q : {(void *)d_reps, (void *)d_info, (void *)d_flags})
+        if (q) (void)hipFree(q);
+    if (rc != QBH_OK || e != hipSuccess) {
+        for (void *q : {(void *)d_ia, (void *)d_ja, (void *)d_val})
+            if (q) (void)hipFree(q);
+        drop_tables();
+        if (rc != QBH_OK) return rc;
+        set_error("%s: %s", who, hipGetErrorString(e));
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP;
+    }
+    ms->n_sites = n_sites;
+    ms->n_up = n_up;
+    ms->n_dn = n_dn;
+    ms->n_trans = n_trans;
+    ms->w_up = w_up;
+    ms->n_pairs = n_pairs;
+    ms->dim = dim;
+    ms->cu = cu;
+    ms->n_blocks = n_blocks;
+    ms->n_items = (int64_t)items.size();
+    ms->U = U;
+    for (size_t c = 0; c < updict.size(); ++c) ms->updict[c] = updict[c];
+    for (int t = 0; t < R.n_terms; ++t)
+        if (R.ti[t] == R.tj[t]) {
+            ms->nup[(int)R.ti[t]] += R.aup[t][0];
+            ms->ndn[(int)R.ti[t]] += R.adn[t][0];
+        }
+    for (int p = 0; p < n_pairs; ++p) {
+        ms->pi[p] = R.pi[p];
+        ms->pj[p] = R.pj[p];
+        for (int c = 0; c < 4; ++c) ms->pv[p][c] = R.pv[p][c];
+    }
+    ms->all_real = all_real;
+    rc = qbh_csr_create_device(out, dim, dim, 0, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, opts);
+    if (rc != QBH_OK) {                     // the CSR arrays were released by the failed adopting call
+        drop_tables();
+        return rc;
+    }
+    qbh_csr *A = *out;
+    MfSec *d_ms = nullptr;
+    if (hipMalloc(&d_ms, sizeof(MfSec)) != hipSuccess || hipMemcpy(d_ms, ms, sizeof(MfSec), hipMemcpyHostToDevice) != hipSuccess) {
+        if (d_ms) (void)hipFree(d_ms);
+        drop_tables();
+        qbh_csr_destroy(A);
+        *out = nullptr;
+        set_error("%s: could not place the operator tables", who);
+        return QBH_ENOMEM;
+    }
+    A->mfsec = ms;
+    A->d_mfsec = d_ms;
+    A->values_real = A->values_real && all_real;
+    A->nnz_total = nnz;
+    if (dim_out) *dim_out = dim;
     return QBH_OK;
 }

@@ -146,6 +146,49 @@ struct MfHubbard {
     double    amp[16] = {0};
 };
 
+// Matrix-free part of a Hubbard momentum-sector operator (qbh_mf_hubbard_repr).  Representatives are ordered by the down
+// pattern first; a "regular" down block (trivially stabilised down pattern) holds EVERY up pattern, its up hops are the
+// full-basis up-hop table applied inside the block and each allowed down hop is (target block, translation, coefficient).
+// Rows in or next to stabilised blocks are a small stored CSR remainder (the handle's ordinary CSR arrays).
+struct MfSecBlock {
+    int64_t  row0;               // first row of the block
+    uint32_t d;                  // down pattern
+    int32_t  hop0, nhop;         // its regular down hops in hop[]
+    int32_t  nrows;              // C(N, n_up) for a regular block
+    int32_t  regular;
+};
+struct MfSecHop {
+    int64_t off;                 // first row of the target block
+    int32_t g, pad;              // canonicalising translation
+    double  cr, ci;              // amplitude * hop sign * sign(g, down part) * conj(chi(g))
+};
+struct MfSec {
+    int      n_sites = 0, n_up = 0, n_dn = 0, n_trans = 0, w_up = 0, n_pairs = 0;
+    int64_t  dim = 0, cu = 0, n_blocks = 0, n_items = 0;
+    double   U = 0.0;
+    MfSecBlock *blk = nullptr;   // [n_blocks], ascending down pattern
+    MfSecHop   *hop = nullptr;
+    int64_t    *item = nullptr;  // [n_items] work items: block << 20 | tile (1024 rows per tile)
+    uint32_t   *ucfg = nullptr;  // [cu] up patterns
+    uint32_t   *upell = nullptr; // [w_up][cu]: code << 24 | target rank, 0xFFFFFFFF = none
+    uint32_t   *prank = nullptr; // [n_trans][cu]: parity << 31 | rank of the translated up pattern
+    double      updict[256] = {0};
+    double      nup[32] = {0}, ndn[32] = {0};          // number-operator terms per site
+    int8_t      pi[128] = {0}, pj[128] = {0};
+    double      pv[128][4] = {{0}};
+    bool        all_real = true;
+};
+struct MfSecArgs {
+    const MfSec *t;              // device copy
+    int64_t n_items;
+    const d2 *xg, *xl;
+    const double *xr, *xl_re;
+    d2 *y;
+    double *y_re;
+    double alpha, beta, gamma;
+};
+int launch_mf_sector(const MfSecArgs &a, hipStream_t s);
+
 struct MfArgs {
     MfHubbard t;
     int64_t row_begin, nrows;
@@ -246,6 +289,8 @@ struct qbh_csr {
 
     // matrix-free operator (kind 1) instead of CSR arrays (kind 0)
     int      kind = 0;               // 0 stored CSR | 1 matrix-free Hubbard | 2 matrix-free Heisenberg
+    qbh::MfSec *mfsec = nullptr;     // kind 0 only: matrix-free pre-pass of a Hubbard momentum sector (the CSR arrays hold the remainder)
+    qbh::MfSec *d_mfsec = nullptr;   // its device copy (kernel argument)
     qbh::MfHubbard mf;
     qbh::MfHeis    mfh;
 

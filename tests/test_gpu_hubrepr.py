@@ -755,3 +755,46 @@ def test_no_device_memory_is_leaked_by_the_sector_entry_points():
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < (8 << 20), (free0 - free1)
+
+
+MF_CASES = [
+    # (Lx, Ly, n_up, n_dn): clusters with many stabilised down blocks (4x2), with none (5x1 with 2 down: prime length), two
+    # dimensions, pairs of very different species counts
+    (4, 2, 4, 4), (4, 2, 3, 2), (5, 1, 2, 2), (6, 1, 3, 3), (3, 2, 2, 3), (4, 3, 3, 2), (4, 2, 1, 0), (4, 2, 0, 2),
+]
+
+
+@pytest.mark.parametrize("Lx,Ly,nu,nd", MF_CASES)
+def test_matrix_free_sector_operator_equals_the_stored_one(Lx, Ly, nu, nd):
+    """qbh_mf_hubbard_repr (block tables + stored remainder) against qbh_gen_hubbard_repr (stored CSR of the same sector):
+    y = alpha H x + beta y + gamma x on random complex vectors for every momentum, and the packed-real Lanczos path."""
+    n = Lx * Ly
+    bonds = lattices.chain(Lx) if Ly == 1 else lattices.square(Lx, Ly)
+    perms, shifts = lattices.translations(Lx, Ly)
+    pairs = [(i, j, 0.2, 0.1, 0.1, 0.2) for (i, j) in bonds]
+    rng = np.random.default_rng(17)
+    for k in itertools.product(range(Lx), range(Ly)):
+        chars = lattices.characters(shifts, k, (Lx, Ly))
+        A = q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, chars, t=1.0, U=1.3, pairs=pairs)
+        M = q.csr_mat.hubbard_repr_mf(n, nu, nd, bonds, perms, chars, t=1.0, U=1.3, pairs=pairs)
+        dim = A.info().ncols
+        assert M.info().ncols == dim
+        x = rng.standard_normal(dim) + 1j * rng.standard_normal(dim)
+        y0 = rng.standard_normal(dim) + 1j * rng.standard_normal(dim)
+        out = []
+        for op in (A, M):
+            v = op.vec(2)
+            v.upload(x, 0)
+            v.upload(y0, dim)
+            red = op.spmv(v.at(0), v.at(dim), 0.7, -0.4, 0.25, want_red=True)
+            out.append((v.download(dim, dim), red))
+            v.free()
+        ref, got = out
+        scale = np.abs(ref[0]).max()
+        assert np.abs(got[0] - ref[0]).max() < 1e-12 * scale, (k, np.abs(got[0] - ref[0]).max())
+        assert abs(got[1][0] - ref[1][0]) < 1e-10 * abs(ref[1][0]) and abs(got[1][1] - ref[1][1]) < 1e-10 * ref[1][1]
+        if dim > 40:
+            e_a, e_m = _lanczos_e0(A, dim), _lanczos_e0(M, dim)
+            assert abs(e_a - e_m) < 1e-10 * max(1.0, abs(e_a)), (k, e_a, e_m)
+        A.destroy()
+        M.destroy()
