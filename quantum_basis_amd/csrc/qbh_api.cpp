@@ -435,7 +435,8 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
     }
     if (A->mfsec) {
         for (void *q : {(void *)A->mfsec->blk, (void *)A->mfsec->hop, (void *)A->mfsec->item, (void *)A->mfsec->ucfg,
-                        (void *)A->mfsec->upell, (void *)A->mfsec->prank, (void *)A->d_mfsec})
+                        (void *)A->mfsec->upell, (void *)A->mfsec->prank, (void *)A->mfsec->rrow, (void *)A->mfsec->ria,
+                        (void *)A->mfsec->rja, (void *)A->mfsec->rval, (void *)A->d_mfsec})
             if (q) (void)hipFree(q);
         delete A->mfsec;
         A->mfsec = nullptr;
@@ -595,6 +596,39 @@ int qbh::adopt_coded_csr(qbh_csr **out, int64_t nrows, int64_t ncols, int64_t ro
     return QBH_OK;
 }
 
+int qbh::adopt_mf_sector(qbh_csr **out, qbh::MfSec *host_tables, qbh::MfSec *dev_tables, int64_t dim, int64_t nnz_equiv,
+                         const qbh_opts *opts)
+{
+    qbh_csr *A = nullptr;
+    QBH_TRY(new_handle(&A, opts));
+    A->nrows = A->ncols = dim;
+    A->row_offset = 0;
+    A->nnz = A->nnz_total = nnz_equiv;
+    A->kernel = QBH_KERNEL_ROWS;
+    A->values_real = host_tables->all_real;
+    A->n_blocks = (dim + qbh::kBlock - 1) / qbh::kBlock;
+    A->grid = (int)std::min<int64_t>(A->n_blocks, 256 * 8);
+    auto fail = [&](int code) {
+        qbh_csr_destroy(A);
+        return code;
+    };
+    if (hipMalloc(&A->d_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (hipHostMalloc(&A->h_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (hipMalloc(&A->d_flag, sizeof(int)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (hipMemset(A->d_flag, 0, sizeof(int)) != hipSuccess) return fail(QBH_EHIP);
+    if (hipEventCreate(&A->ev0) != hipSuccess || hipEventCreate(&A->ev1) != hipSuccess ||
+        hipEventCreate(&A->ev2) != hipSuccess || hipEventCreate(&A->ev3) != hipSuccess)
+        return fail(QBH_EHIP);
+    if (hipMalloc(&A->d_partials, (size_t)qbh::kMaxRedBlocks * 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
+    A->stats = qbh_stats{};
+    A->stats.ms_spmv_min = std::numeric_limits<double>::infinity();
+    A->kind = 3;                // from here on the handle owns the tables (on any failure above the caller still does)
+    A->mfsec = host_tables;
+    A->d_mfsec = dev_tables;
+    *out = A;
+    return QBH_OK;
+}
+
 int qbh::adopt_mf_hubbard(qbh_csr **out, const qbh::MfHubbard &t, int64_t nrows, int64_t ncols, int64_t row_offset,
                           int64_t nnz_equiv, const qbh_opts *opts)
 {
@@ -680,6 +714,11 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     if (A->kind == 2)
         info->bytes_matrix = ((int64_t)(A->mfh.n_sites + 1) * (A->mfh.n_dn + 1) + (int64_t)A->mfh.n_chunks * (A->mfh.n_dn + 1) * 64 +
                               3 * (int64_t)A->mfh.n_bonds) * 8;
+    if (A->kind == 3 && A->mfsec) {
+        const qbh::MfSec &m = *A->mfsec;
+        info->bytes_matrix = m.n_blocks * (int64_t)sizeof(qbh::MfSecBlock) + m.n_items * 8 + m.cu * 4 * (1 + m.w_up + m.n_trans) +
+                             m.n_rrows * 12 + m.rnnz * 20;
+    }
     info->kernel = A->kind != 0 ? QBH_KERNEL_MATRIX_FREE : A->kernel;
     info->value_dict = A->d_code ? A->n_dict : 0;
     info->device = A->device;
@@ -696,7 +735,7 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
         A->has_comm = false;
         return QBH_OK;
     }
-    if (A->mfsec) {
+    if (A->kind == 3) {
         qbh::set_error("qbh_csr_set_comm: the matrix-free sector operator is a single-GPU form");
         return QBH_EUNSUPP;
     }
@@ -882,7 +921,28 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
             QBH_HIP(hipEventRecord(A->ev0, A->stream));
         }
         int mf_parts = A->grid;
-        if (A->kind == 2) {
+        if (A->kind == 3) {
+            qbh::MfSecArgs ms{};
+            ms.t = A->d_mfsec;
+            ms.n_items = A->mfsec->n_items;
+            ms.dim = A->nrows;
+            ms.n_rrows = A->mfsec->n_rrows;
+            ms.rrow = A->mfsec->rrow;
+            ms.ria = A->mfsec->ria;
+            ms.rja = A->mfsec->rja;
+            ms.rval = A->mfsec->rval;
+            ms.xg = m.xg;
+            ms.xl = m.xl;
+            ms.xr = m.xr;
+            ms.xl_re = m.y_re ? xr_nocomm : nullptr;
+            ms.y = m.y;
+            ms.y_re = m.y_re;
+            ms.alpha = alpha;
+            ms.beta = beta;
+            ms.gamma = gamma;
+            ms.partials = m.partials;
+            QBH_TRY(qbh::launch_mf_sector(ms, A->stream, &mf_parts));
+        } else if (A->kind == 2) {
             qbh::MfHeisArgs h{};
             h.t = A->mfh;
             h.row_begin = m.row_begin;
@@ -962,25 +1022,6 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     if (prof) {
         harvest_events(A);
         QBH_HIP(hipEventRecord(A->ev0, A->stream));
-    }
-    if (A->mfsec) {
-        // Hubbard momentum sector in matrix-free form: y <- alpha MF(x) + beta y + gamma x first, then the stored remainder
-        // accumulates onto it (and forms the reductions on the final y)
-        qbh::MfSecArgs ms{};
-        ms.t = A->d_mfsec;
-        ms.n_items = A->mfsec->n_items;
-        ms.xg = a.xg;
-        ms.xl = a.xl;
-        ms.xr = a.xr;
-        ms.xl_re = a.xl_re;
-        ms.y = a.y;
-        ms.y_re = a.y_re;
-        ms.alpha = alpha;
-        ms.beta = beta;
-        ms.gamma = gamma;
-        QBH_TRY(qbh::launch_mf_sector(ms, A->stream));
-        a.beta = 1.0;
-        a.gamma = 0.0;
     }
     QBH_TRY(qbh::launch_spmv(a, A->kernel, A->npb, A->tpr, A->grid, A->stream));
     if (prof) {
@@ -2124,7 +2165,7 @@ int download_part(const qbh_csr *A, const int64_t *d_ia, const int32_t *d_ja, co
 extern "C" int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1, int64_t *ia, int32_t *ja, qbh_z *val)
 {
     if (!A || r0 < 0 || r1 < r0 || r1 > A->nrows) return QBH_EINVAL;
-    if (A->kind != 0 || A->mfsec) {
+    if (A->kind != 0) {
         qbh::set_error("qbh_csr_download: the operator is matrix-free (no stored CSR)");
         return QBH_EUNSUPP;
     }

@@ -2515,33 +2515,57 @@ __global__ __launch_bounds__(128) void k_secrem_count(const HubReprDev *Rp, cons
         cnt[i] = hubrepr_row_rem(*Rp, tab, reps, info, dim, i, blk, n_blocks, flags, cols, vals);
 }
 
+__global__ __launch_bounds__(256) void k_secrem_flag(const int32_t *cnt, int64_t dim, int32_t *flag)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < dim; i += stride) flag[i] = cnt[i] > 0 ? 1 : 0;
+}
+
+// compact remainder: the p-th row with entries is row rrow[p], its entries sit at [ria[p], ria[p+1])
 __global__ __launch_bounds__(128) void k_secrem_fill(const HubReprDev *Rp, const uint64_t *tab, const uint64_t *reps, const uint8_t *info,
                                                      int64_t dim, const MfSecBlock *blk, int64_t n_blocks, const uint64_t *flags,
-                                                     const int64_t *ia, int32_t *ja, d2 *val)
+                                                     const int64_t *ia_full, const int64_t *pos, int32_t *rrow, int64_t *ria,
+                                                     int32_t *rja, d2 *rval)
 {
     int32_t cols[kHubReprMaxRow];
     d2 vals[kHubReprMaxRow];
     const int64_t stride = (int64_t)gridDim.x * 128;
     for (int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x; i < dim; i += stride) {
-        if (ia[i + 1] == ia[i]) continue;
+        if (i == 0) ria[pos[dim]] = ia_full[dim];
+        if (ia_full[i + 1] == ia_full[i]) continue;
         const int m = hubrepr_row_rem(*Rp, tab, reps, info, dim, i, blk, n_blocks, flags, cols, vals);
-        const int64_t p0 = ia[i];
+        const int64_t p = pos[i], p0 = ia_full[i];
+        rrow[p] = (int32_t)i;
+        ria[p] = p0;
         for (int q = 0; q < m; ++q) {
-            ja[p0 + q] = cols[q];
-            val[p0 + q] = vals[q];
+            rja[p0 + q] = cols[q];
+            rval[p0 + q] = vals[q];
         }
     }
 }
 
+constexpr int kSecMaxHops = 128, kSecUnroll = 8;
+
+// y <- alpha MF(x) + beta y + gamma x for every row.  One work item = 1024 rows of one down block; an XCD takes a
+// contiguous run of items, so the workgroups that share an L2 sweep the same block -- and, hop by hop, the same target
+// blocks -- at the same time.
 template <bool REALX>
 __global__ __launch_bounds__(256) void k_mf_sector(MfSecArgs a)
 {
     const MfSec &T = *a.t;
+    __shared__ MfSecHop sh[kSecMaxHops];
     const int64_t cu = T.cu;
-    for (int64_t it = blockIdx.x; it < a.n_items; it += gridDim.x) {
+    const int nslot = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
+    for (int64_t base = 0; base < a.n_items; base += gridDim.x) {
+        const int64_t it = base + (int64_t)xcd * nslot + slot;
+        __syncthreads();
+        if (it >= a.n_items) continue;
         const int64_t w = T.item[it];
         const MfSecBlock B = T.blk[w >> 20];
         const int tile = (int)(w & 0xFFFFF);
+        if (B.regular)
+            for (int h = threadIdx.x; h < B.nhop; h += 256) sh[h] = T.hop[B.hop0 + h];
+        __syncthreads();
         for (int j = 0; j < kSecTile / 256; ++j) {
             const int r = tile * kSecTile + j * 256 + (int)threadIdx.x;
             if (r >= B.nrows) break;
@@ -2549,33 +2573,61 @@ __global__ __launch_bounds__(256) void k_mf_sector(MfSecArgs a)
             d2 sum = {0.0, 0.0};
             if (B.regular) {
                 const uint32_t u = T.ucfg[r], d = B.d;
-                double dr = T.U * (double)__popc(u & d), di = 0.0;
+                double dr = T.U * (double)__popc(u & d);
                 for (int p = 0; p < T.n_pairs; ++p) {
                     const int iu = (u >> T.pi[p]) & 1, id = (d >> T.pi[p]) & 1, ju = (u >> T.pj[p]) & 1, jd = (d >> T.pj[p]) & 1;
                     dr += T.pv[p][0] * (iu & ju) + T.pv[p][1] * (iu & jd) + T.pv[p][2] * (id & ju) + T.pv[p][3] * (id & jd);
                 }
-                for (uint32_t m = u; m; m &= m - 1) { const int s = __ffs(m) - 1; dr += T.nup[s]; }
-                for (uint32_t m = d; m; m &= m - 1) { const int s = __ffs(m) - 1; dr += T.ndn[s]; }
-                const d2 x0 = REALX ? d2{a.xr[row], 0.0} : a.xg[row];
-                sum = d2{dr * x0.x - di * x0.y, dr * x0.y + di * x0.x};
-                for (int k = 0; k < T.w_up; ++k) {         // up hops: inside the block
-                    const uint32_t e = T.upell[(size_t)k * cu + r];
-                    if (e == 0xFFFFFFFFu) break;
-                    const double am = T.updict[e >> 24];
-                    const int64_t c = B.row0 + (e & 0xFFFFFFu);
-                    if (REALX) sum.x += am * a.xr[c];
-                    else       sum += am * a.xg[c];
+                if (T.has_number_terms) {
+                    for (uint32_t m = u; m; m &= m - 1) dr += T.nup[__ffs(m) - 1];
+                    for (uint32_t m = d; m; m &= m - 1) dr += T.ndn[__ffs(m) - 1];
                 }
-                for (int h = 0; h < B.nhop; ++h) {         // down hops into regular blocks
-                    const MfSecHop H = T.hop[B.hop0 + h];
-                    const uint32_t pr = T.prank[(size_t)H.g * cu + r];
-                    const double sg = (pr >> 31) ? -1.0 : 1.0;
-                    const int64_t c = H.off + (pr & 0x7FFFFFFFu);
+                if (REALX) sum.x = dr * a.xr[row];
+                else       sum = dr * a.xg[row];
+                for (int k0 = 0; k0 < T.w_up; k0 += kSecUnroll) {          // up hops: inside the block
+                    uint32_t e[kSecUnroll];
+#pragma unroll
+                    for (int q = 0; q < kSecUnroll; ++q) e[q] = k0 + q < T.w_up ? T.upell[(size_t)(k0 + q) * cu + r] : 0xFFFFFFFFu;
                     if (REALX) {
-                        sum.x += sg * H.cr * a.xr[c];
+                        double xv[kSecUnroll];
+#pragma unroll
+                        for (int q = 0; q < kSecUnroll; ++q) xv[q] = e[q] != 0xFFFFFFFFu ? a.xr[B.row0 + (e[q] & 0xFFFFFFu)] : 0.0;
+#pragma unroll
+                        for (int q = 0; q < kSecUnroll; ++q)
+                            if (e[q] != 0xFFFFFFFFu) sum.x += T.updict[e[q] >> 24] * xv[q];
                     } else {
-                        const d2 xv = a.xg[c];
-                        sum += d2{sg * (H.cr * xv.x - H.ci * xv.y), sg * (H.cr * xv.y + H.ci * xv.x)};
+                        d2 xv[kSecUnroll];
+#pragma unroll
+                        for (int q = 0; q < kSecUnroll; ++q) xv[q] = e[q] != 0xFFFFFFFFu ? a.xg[B.row0 + (e[q] & 0xFFFFFFu)] : d2{0.0, 0.0};
+#pragma unroll
+                        for (int q = 0; q < kSecUnroll; ++q)
+                            if (e[q] != 0xFFFFFFFFu) sum += T.updict[e[q] >> 24] * xv[q];
+                    }
+                    if (e[kSecUnroll - 1] == 0xFFFFFFFFu) break;
+                }
+                for (int h0 = 0; h0 < B.nhop; h0 += kSecUnroll) {          // down hops into regular blocks
+                    uint32_t pr[kSecUnroll];
+#pragma unroll
+                    for (int q = 0; q < kSecUnroll; ++q) pr[q] = h0 + q < B.nhop ? T.prank[(size_t)sh[h0 + q].g * cu + r] : 0u;
+                    if (REALX) {
+                        double xv[kSecUnroll];
+#pragma unroll
+                        for (int q = 0; q < kSecUnroll; ++q) xv[q] = h0 + q < B.nhop ? a.xr[sh[h0 + q].off + (pr[q] & 0x7FFFFFFFu)] : 0.0;
+#pragma unroll
+                        for (int q = 0; q < kSecUnroll; ++q)
+                            if (h0 + q < B.nhop) sum.x += ((pr[q] >> 31) ? -sh[h0 + q].cr : sh[h0 + q].cr) * xv[q];
+                    } else {
+                        d2 xv[kSecUnroll];
+#pragma unroll
+                        for (int q = 0; q < kSecUnroll; ++q)
+                            xv[q] = h0 + q < B.nhop ? a.xg[sh[h0 + q].off + (pr[q] & 0x7FFFFFFFu)] : d2{0.0, 0.0};
+#pragma unroll
+                        for (int q = 0; q < kSecUnroll; ++q)
+                            if (h0 + q < B.nhop) {
+                                const double sg = (pr[q] >> 31) ? -1.0 : 1.0;
+                                const double cr = sg * sh[h0 + q].cr, ci = sg * sh[h0 + q].ci;
+                                sum += d2{cr * xv[q].x - ci * xv[q].y, cr * xv[q].y + ci * xv[q].x};
+                            }
                     }
                 }
             }
@@ -2589,14 +2641,71 @@ __global__ __launch_bounds__(256) void k_mf_sector(MfSecArgs a)
     }
 }
 
+// the stored remainder: one lane per row that has entries
+template <bool REALX>
+__global__ __launch_bounds__(256) void k_sec_remainder(MfSecArgs a)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < a.n_rrows; p += stride) {
+        const int64_t row = a.rrow[p];
+        d2 sum = {0.0, 0.0};
+        for (int64_t q = a.ria[p]; q < a.ria[p + 1]; ++q) {
+            const d2 v = a.rval[q];
+            if (REALX) {
+                sum.x += v.x * a.xr[a.rja[q]];
+            } else {
+                const d2 xv = a.xg[a.rja[q]];
+                sum += d2{v.x * xv.x - v.y * xv.y, v.x * xv.y + v.y * xv.x};
+            }
+        }
+        if (a.y_re) a.y_re[row] += a.alpha * sum.x;
+        else        a.y[row] += a.alpha * sum;
+    }
+}
+
+// <x, y> and |y|^2 of the finished product
+__global__ __launch_bounds__(256) void k_sec_reduce(MfSecArgs a)
+{
+    __shared__ double red[12];
+    double acc[3] = {0.0, 0.0, 0.0};
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.dim; i += stride) {
+        const d2 xi = a.y_re ? d2{a.xl_re[i], 0.0} : a.xl[i];
+        const d2 yn = a.y_re ? d2{a.y_re[i], 0.0} : a.y[i];
+        acc[0] += xi.x * yn.x + xi.y * yn.y;
+        acc[1] += xi.x * yn.y - xi.y * yn.x;
+        acc[2] += yn.x * yn.x + yn.y * yn.y;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = 0; c < 3; ++c)
+        for (int off = 32; off > 0; off >>= 1) acc[c] += __shfl_xor(acc[c], off, 64);
+    if (lane == 0)
+        for (int c = 0; c < 3; ++c) red[c * 4 + wave] = acc[c];
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int c = 0; c < 3; ++c) a.partials[(size_t)blockIdx.x * 3 + c] = (red[c * 4] + red[c * 4 + 1]) + (red[c * 4 + 2] + red[c * 4 + 3]);
+}
+
 }  // namespace
 
-int launch_mf_sector(const MfSecArgs &a, hipStream_t s)
+int launch_mf_sector(const MfSecArgs &a, hipStream_t s, int *nparts_out)
 {
-    const int grid = (int)std::min<int64_t>(a.n_items, 256 * 8);
+    const int grid = 256 * 8;
     if (a.xr != nullptr) hipLaunchKernelGGL(k_mf_sector<true>, dim3(grid), dim3(256), 0, s, a);
     else                 hipLaunchKernelGGL(k_mf_sector<false>, dim3(grid), dim3(256), 0, s, a);
     QBH_HIP(hipGetLastError());
+    if (a.n_rrows > 0) {
+        const int rg = blas_grid(a.n_rrows);
+        if (a.xr != nullptr) hipLaunchKernelGGL(k_sec_remainder<true>, dim3(rg), dim3(256), 0, s, a);
+        else                 hipLaunchKernelGGL(k_sec_remainder<false>, dim3(rg), dim3(256), 0, s, a);
+        QBH_HIP(hipGetLastError());
+    }
+    const int parts = blas_grid(a.dim);
+    if (a.partials != nullptr) {
+        hipLaunchKernelGGL(k_sec_reduce, dim3(parts), dim3(256), 0, s, a);
+        QBH_HIP(hipGetLastError());
+    }
+    if (nparts_out) *nparts_out = parts;
     return QBH_OK;
 }
 
@@ -2859,10 +2968,9 @@ extern "C" int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_d
         set_error("%s: block table (%lld rows) and enumeration (%lld representatives) disagree", who, (long long)dim, (long long)dim_dev);
         rc = QBH_EHIP;
     }
-    int32_t *d_cnt = nullptr, *d_ja = nullptr;
-    int64_t *d_ia = nullptr;
-    d2 *d_val = nullptr;
-    int64_t nnz = 0;
+    int32_t *d_cnt = nullptr, *d_flg = nullptr;
+    int64_t *d_ia = nullptr, *d_pos = nullptr;
+    int64_t nnz = 0, n_rrows = 0;
     hipError_t e = hipSuccess;
     auto up = [&](auto **dst, const auto &h) {
         using T = typename std::remove_reference<decltype(h)>::type::value_type;
@@ -2878,30 +2986,41 @@ extern "C" int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_d
     up(&ms->prank, prank);
     up(&d_flags, flags);
     if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&d_cnt, (size_t)dim * sizeof(int32_t));
+    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&d_flg, (size_t)dim * sizeof(int32_t));
     if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&d_ia, (size_t)(dim + 1) * sizeof(int64_t));
+    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&d_pos, (size_t)(dim + 1) * sizeof(int64_t));
     const int rgrid = (int)std::min<int64_t>((dim + 127) / 128, 256 * 16);
     if (rc == QBH_OK && e == hipSuccess) {
         hipLaunchKernelGGL(k_secrem_count, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, ms->blk, n_blocks, d_flags, d_cnt);
+        hipLaunchKernelGGL(k_secrem_flag, dim3(blas_grid(dim)), dim3(256), 0, 0, d_cnt, dim, d_flg);
         e = hipGetLastError();
     }
     if (rc == QBH_OK && e == hipSuccess) rc = exclusive_scan(d_cnt, dim, d_ia, 0);
+    if (rc == QBH_OK && e == hipSuccess) rc = exclusive_scan(d_flg, dim, d_pos, 0);
     if (rc == QBH_OK && e == hipSuccess) e = hipMemcpy(&nnz, d_ia + dim, sizeof(int64_t), hipMemcpyDeviceToHost);
+    if (rc == QBH_OK && e == hipSuccess) e = hipMemcpy(&n_rrows, d_pos + dim, sizeof(int64_t), hipMemcpyDeviceToHost);
     if (d_cnt) (void)hipFree(d_cnt);
-    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&d_ja, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t));
-    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&d_val, (size_t)std::max<int64_t>(nnz, 1) * sizeof(d2));
-    if (rc == QBH_OK && e == hipSuccess && nnz > 0) {
-        hipLaunchKernelGGL(k_secrem_fill, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, ms->blk, n_blocks, d_flags, d_ia, d_ja,
-                           d_val);
+    if (d_flg) (void)hipFree(d_flg);
+    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&ms->rrow, (size_t)std::max<int64_t>(n_rrows, 1) * sizeof(int32_t));
+    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&ms->ria, (size_t)(n_rrows + 1) * sizeof(int64_t));
+    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&ms->rja, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t));
+    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&ms->rval, (size_t)std::max<int64_t>(nnz, 1) * sizeof(d2));
+    if (rc == QBH_OK && e == hipSuccess) {
+        hipLaunchKernelGGL(k_secrem_fill, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, ms->blk, n_blocks, d_flags, d_ia, d_pos,
+                           ms->rrow, ms->ria, ms->rja, ms->rval);
         e = hipGetLastError();
     }
     if (rc == QBH_OK && e == hipSuccess) e = hipDeviceSynchronize();
     free_pool(pool);
-    for (void *q : {(void *)d_reps, (void *)d_info, (void *)d_flags})
+    for (void *q : {(void *)d_reps, (void *)d_info, (void *)d_flags, (void *)d_ia, (void *)d_pos})
         if (q) (void)hipFree(q);
-    if (rc != QBH_OK || e != hipSuccess) {
-        for (void *q : {(void *)d_ia, (void *)d_ja, (void *)d_val})
+    auto drop_all = [&]() {
+        for (void *q : {(void *)ms->rrow, (void *)ms->ria, (void *)ms->rja, (void *)ms->rval})
             if (q) (void)hipFree(q);
         drop_tables();
+    };
+    if (rc != QBH_OK || e != hipSuccess) {
+        drop_all();
         if (rc != QBH_OK) return rc;
         set_error("%s: %s", who, hipGetErrorString(e));
         (void)hipGetLastError();
@@ -2918,37 +3037,63 @@ extern "C" int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_d
     ms->n_blocks = n_blocks;
     ms->n_items = (int64_t)items.size();
     ms->U = U;
+    ms->n_rrows = n_rrows;
+    ms->rnnz = nnz;
     for (size_t c = 0; c < updict.size(); ++c) ms->updict[c] = updict[c];
     for (int t = 0; t < R.n_terms; ++t)
         if (R.ti[t] == R.tj[t]) {
             ms->nup[(int)R.ti[t]] += R.aup[t][0];
             ms->ndn[(int)R.ti[t]] += R.adn[t][0];
+            if (R.aup[t][0] != 0.0 || R.adn[t][0] != 0.0) ms->has_number_terms = true;
         }
     for (int p = 0; p < n_pairs; ++p) {
         ms->pi[p] = R.pi[p];
         ms->pj[p] = R.pj[p];
         for (int c = 0; c < 4; ++c) ms->pv[p][c] = R.pv[p][c];
     }
-    ms->all_real = all_real;
-    rc = qbh_csr_create_device(out, dim, dim, 0, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, opts);
-    if (rc != QBH_OK) {                     // the CSR arrays were released by the failed adopting call
-        drop_tables();
-        return rc;
+    // real operator: real hop coefficients and a real remainder
+    if (all_real && nnz > 0) {
+        double *tmp = nullptr;
+        std::vector<double> hp((size_t)blas_grid(nnz));
+        if (hipMalloc(&tmp, (size_t)kMaxRedBlocks * sizeof(double)) == hipSuccess) {
+            if (launch_imag_norm(ms->rval, nnz, tmp, 0) == QBH_OK &&
+                hipMemcpy(hp.data(), tmp, hp.size() * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) {
+                double sum = 0.0;
+                for (double v : hp) sum += v;
+                all_real = sum == 0.0;
+            } else {
+                all_real = false;
+            }
+            (void)hipFree(tmp);
+        } else {
+            all_real = false;
+        }
     }
-    qbh_csr *A = *out;
+    ms->all_real = all_real;
+    if ((int)hops.size() > 0) {
+        int mx = 0;
+        for (const auto &bq : blk) mx = std::max(mx, (int)bq.nhop);
+        if (mx > kSecMaxHops) {
+            drop_all();
+            set_error("%s: more than %d down hops per block", who, kSecMaxHops);
+            return QBH_EUNSUPP;
+        }
+    }
     MfSec *d_ms = nullptr;
     if (hipMalloc(&d_ms, sizeof(MfSec)) != hipSuccess || hipMemcpy(d_ms, ms, sizeof(MfSec), hipMemcpyHostToDevice) != hipSuccess) {
         if (d_ms) (void)hipFree(d_ms);
-        drop_tables();
-        qbh_csr_destroy(A);
-        *out = nullptr;
+        drop_all();
         set_error("%s: could not place the operator tables", who);
         return QBH_ENOMEM;
     }
-    A->mfsec = ms;
-    A->d_mfsec = d_ms;
-    A->values_real = A->values_real && all_real;
-    A->nnz_total = nnz;
+    // nnz the stored CSR of the same sector would hold (~ one entry per allowed hop): for the byte accounting only
+    const int64_t nnz_equiv = nnz + (int64_t)((double)dim * (double)(1 + w_up));
+    rc = adopt_mf_sector(out, ms, d_ms, dim, nnz_equiv, opts);
+    if (rc != QBH_OK) {
+        (void)hipFree(d_ms);
+        drop_all();
+        return rc;
+    }
     if (dim_out) *dim_out = dim;
     return QBH_OK;
 }

@@ -176,18 +176,31 @@ struct MfSec {
     double      nup[32] = {0}, ndn[32] = {0};          // number-operator terms per site
     int8_t      pi[128] = {0}, pj[128] = {0};
     double      pv[128][4] = {{0}};
-    bool        all_real = true;
+    bool        all_real = true, has_number_terms = false;
+    // stored remainder, compact: only the rows that have entries
+    int64_t     n_rrows = 0, rnnz = 0;
+    int32_t    *rrow = nullptr;  // [n_rrows] row index
+    int64_t    *ria = nullptr;   // [n_rrows + 1]
+    int32_t    *rja = nullptr;
+    d2         *rval = nullptr;
 };
 struct MfSecArgs {
     const MfSec *t;              // device copy
-    int64_t n_items;
+    int64_t n_items, dim, n_rrows;
+    const int32_t *rrow;
+    const int64_t *ria;
+    const int32_t *rja;
+    const d2 *rval;
     const d2 *xg, *xl;
     const double *xr, *xl_re;
     d2 *y;
     double *y_re;
     double alpha, beta, gamma;
+    double *partials;            // [nparts * 3] or nullptr
 };
-int launch_mf_sector(const MfSecArgs &a, hipStream_t s);
+// y <- alpha H x + beta y + gamma x in three launches (block tables, remainder rows, reductions); *nparts_out = partial sums
+int launch_mf_sector(const MfSecArgs &a, hipStream_t s, int *nparts_out);
+int adopt_mf_sector(qbh_csr **out, MfSec *host_tables, MfSec *dev_tables, int64_t dim, int64_t nnz_equiv, const qbh_opts *opts);
 
 struct MfArgs {
     MfHubbard t;
@@ -288,8 +301,8 @@ struct qbh_csr {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // matrix-free operator (kind 1) instead of CSR arrays (kind 0)
-    int      kind = 0;               // 0 stored CSR | 1 matrix-free Hubbard | 2 matrix-free Heisenberg
-    qbh::MfSec *mfsec = nullptr;     // kind 0 only: matrix-free pre-pass of a Hubbard momentum sector (the CSR arrays hold the remainder)
+    int      kind = 0;               // 0 stored CSR | 1 matrix-free Hubbard | 2 matrix-free Heisenberg | 3 matrix-free Hubbard momentum sector
+    qbh::MfSec *mfsec = nullptr;     // kind 3: block tables + compact remainder (host copy of the descriptor, device arrays)
     qbh::MfSec *d_mfsec = nullptr;   // its device copy (kernel argument)
     qbh::MfHubbard mf;
     qbh::MfHeis    mfh;

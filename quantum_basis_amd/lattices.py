@@ -135,4 +135,11 @@ def characters(shifts, k, L):
     """Momentum characters chi_k(g) = exp(-2 pi i sum_d k_d t_d / L_d) for momentum indices k on an L = (Lx, Ly) cluster."""
     import cmath
     import math
-    return [cmath.exp(-2j * math.pi * sum(kd * td / Ld for kd, td, Ld in zip(k, t, L))) for t in shifts]
+    from fractions import Fraction
+    exact = {Fraction(0): 1.0 + 0.0j, Fraction(1, 4): 0.0 - 1.0j, Fraction(1, 2): -1.0 + 0.0j, Fraction(3, 4): 0.0 + 1.0j}
+    out = []
+    for t in shifts:
+        f = sum(Fraction(int(kd) * int(td), int(Ld)) for kd, td, Ld in zip(k, t, L)) % 1
+        # multiples of pi/2 exactly: a sector at k = 0 or pi is then a REAL operator (packed-double Lanczos vectors)
+        out.append(exact[f] if f in exact else cmath.exp(-2j * math.pi * float(f)))
+    return out

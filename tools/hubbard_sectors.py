@@ -15,6 +15,9 @@ from quantum_basis_amd import lattices  # noqa: E402
 
 
 def main():
+    mf = "--mf" in sys.argv                     # matrix-free sector operator (qbh_mf_hubbard_repr) instead of the stored CSR
+    if mf:
+        sys.argv.remove("--mf")
     Lx, Ly, nu, nd = (int(a) for a in sys.argv[1:5])
     n = Lx * Ly
     if len(sys.argv) > 6:
@@ -26,17 +29,24 @@ def main():
     for k in ks:
         chars = lattices.characters(shifts, k, (Lx, Ly))
         t0 = time.time()
-        A = q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, chars, t=1.0, U=1.1)
+        A = (q.csr_mat.hubbard_repr_mf if mf else q.csr_mat.hubbard_repr)(n, nu, nd, bonds, perms, chars, t=1.0, U=1.1)
         i = A.info()
         t1 = time.time()
         maxit = 1000
-        dv = A.vec(3)
-        A.randomize(dv.at(0), 7)
         hess = np.zeros(2 * maxit)
-        m = q.lanczos(0, maxit - 1, maxit, i.ncols, A, None, hess, "sr_val0", device_v=dv)
+        if mf and np.abs(np.imag(np.asarray(chars))).max() < 1e-14:
+            # real sector: the Lanczos vectors are kept as packed doubles by the caller (two slots of dim doubles)
+            import ctypes
+            dv = A.vec(1)
+            q._lib.check(q._lib.lib().qbh_vec_randomize_real(A.handle, dv.ptr, ctypes.c_uint32(7)), "qbh_vec_randomize_real")
+            m = q.lanczos_real(0, maxit - 1, maxit, A, dv, hess)
+        else:
+            dv = A.vec(3)
+            A.randomize(dv.at(0), 7)
+            m = q.lanczos(0, maxit - 1, maxit, i.ncols, A, None, hess, "sr_val0", device_v=dv)
         ritz, _ = q.hess_eigen(hess, maxit, m, "sr")
         t2 = time.time()
-        print("k=%s dim %d nnz %d (%.1f GB, value_dict %d) build %.1f s; lanczos %d steps in %.1f s (%.1f ms/step); E0 = %.12f" %
+        print(("matrix-free " if mf else "") + "k=%s dim %d nnz %d (%.1f GB, value_dict %d) build %.1f s; lanczos %d steps in %.1f s (%.1f ms/step); E0 = %.12f" %
               (k, i.ncols, i.nnz, i.bytes_matrix * 1e-9, i.value_dict, t1 - t0, m, t2 - t1, 1e3 * (t2 - t1) / max(1, m), ritz[0]), flush=True)
         dv.free()
         A.destroy()
