@@ -87,6 +87,11 @@ def workloads():
                                    trans=(4, 5), k=(2, 0), format="fast"),
         "hubbard_4x5_n6_k00": dict(kind="hubbard_repr", n_sites=20, n_up=6, n_dn=6, bonds=lattices.square(4, 5), t=1.0, U=1.1,
                                    trans=(4, 5), k=(0, 0)),
+        # ... and the same sector on ONE GPU in matrix-free form (qbh_mf_hubbard_repr: 3.5 GB instead of 364 GB)
+        "hubbard_4x5_half_k00_mf": dict(kind="hubbard_repr_mf", n_sites=20, n_up=10, n_dn=10, bonds=lattices.square(4, 5), t=1.0, U=1.1,
+                                        trans=(4, 5), k=(0, 0), packed_real=True),
+        "hubbard_4x5_n6_k00_mf": dict(kind="hubbard_repr_mf", n_sites=20, n_up=6, n_dn=6, bonds=lattices.square(4, 5), t=1.0, U=1.1,
+                                      trans=(4, 5), k=(0, 0), packed_real=True),
         "hubbard_4x4_half_k00": dict(kind="hubbard_repr", n_sites=16, n_up=8, n_dn=8, bonds=lattices.square(4, 4), t=1.0, U=1.1,
                                      trans=(4, 4), k=(0, 0)),
     }
@@ -106,7 +111,7 @@ def dim_of(w):
     from math import comb
     if w["kind"] == "hubbard":
         return comb(w["n_sites"], w["n_up"]) * comb(w["n_sites"], w["n_dn"])
-    if w["kind"] in ("heisenberg_repr", "hubbard_repr"):
+    if w["kind"] in ("heisenberg_repr", "hubbard_repr", "hubbard_repr_mf"):
         return None                      # known only after the representatives have been enumerated
     return comb(w["n_sites"], w["n_dn"])
 
@@ -116,6 +121,11 @@ def build_operator(w, rows, opts, matrix_free=False, shard=(0, 1)):
     if w["kind"] == "hubbard":
         return q.csr_mat.hubbard(w["n_sites"], w["n_up"], w["n_dn"], w["bonds"], t=w["t"], U=w["U"], rows=rows, opts=opts,
                                  matrix_free=matrix_free)
+    if w["kind"] == "hubbard_repr_mf":
+        from quantum_basis_amd import lattices
+        perms, shifts = lattices.translations(*w["trans"])
+        return q.csr_mat.hubbard_repr_mf(w["n_sites"], w["n_up"], w["n_dn"], w["bonds"], perms, lattices.characters(shifts, w["k"], w["trans"]),
+                                         t=w["t"], U=w["U"], opts=opts)
     if w["kind"] == "hubbard_repr":
         from quantum_basis_amd import lattices
         perms, shifts = lattices.translations(*w["trans"])
@@ -587,7 +597,7 @@ def main():
         out["config"]["vectors"] = "2 x %.1f GB packed doubles (qbh_lanczos_real_dev)" % (dim * 8e-9)
     if args.matrix_free:
         out["config"]["kernel"] = "matrix_free"
-        out["roofline"]["kernel"] = "k_mf_hubbard" if W["kind"] == "hubbard" else "k_mf_heis"
+        out["roofline"]["kernel"] = {"hubbard": "k_mf_hubbard", "hubbard_repr_mf": "k_mf_sector"}.get(W["kind"], "k_mf_heis")
         out["roofline"]["note"] = ("MATRIX-FREE operator (qbh_mf_hubbard / qbh_mf_heisenberg, SURVEY 8f-1): no CSR is stored; achieved = bytes the CSR of the "
                                    "same operator would move per SpMV / kernel time -- not the north-star CSR measurement")
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.matrix_free:
