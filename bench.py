@@ -90,6 +90,8 @@ def workloads():
         # ... and the same sector on ONE GPU in matrix-free form (qbh_mf_hubbard_repr: 3.5 GB instead of 364 GB)
         "hubbard_4x5_half_k00_mf": dict(kind="hubbard_repr_mf", n_sites=20, n_up=10, n_dn=10, bonds=lattices.square(4, 5), t=1.0, U=1.1,
                                         trans=(4, 5), k=(0, 0), packed_real=True),
+        "hubbard_4x5_n8_k20_mf": dict(kind="hubbard_repr_mf", n_sites=20, n_up=8, n_dn=8, bonds=lattices.square(4, 5), t=1.0, U=1.1,
+                                      trans=(4, 5), k=(2, 0), packed_real=True),
         "hubbard_4x5_n6_k00_mf": dict(kind="hubbard_repr_mf", n_sites=20, n_up=6, n_dn=6, bonds=lattices.square(4, 5), t=1.0, U=1.1,
                                       trans=(4, 5), k=(0, 0), packed_real=True),
         "hubbard_4x4_half_k00": dict(kind="hubbard_repr", n_sites=16, n_up=8, n_dn=8, bonds=lattices.square(4, 4), t=1.0, U=1.1,

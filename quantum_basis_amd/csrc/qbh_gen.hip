@@ -2544,12 +2544,12 @@ __global__ __launch_bounds__(128) void k_secrem_fill(const HubReprDev *Rp, const
     }
 }
 
-constexpr int kSecMaxHops = 128, kSecUnroll = 8;
+constexpr int kSecMaxHops = 128;
 
 // y <- alpha MF(x) + beta y + gamma x for every row.  One work item = 1024 rows of one down block; an XCD takes a
 // contiguous run of items, so the workgroups that share an L2 sweep the same block -- and, hop by hop, the same target
 // blocks -- at the same time.
-template <bool REALX>
+template <bool REALX, int kSecUnroll>
 __global__ __launch_bounds__(256) void k_mf_sector(MfSecArgs a)
 {
     const MfSec &T = *a.t;
@@ -2688,11 +2688,40 @@ __global__ __launch_bounds__(256) void k_sec_reduce(MfSecArgs a)
 
 }  // namespace
 
+template <bool REALX, int UN>
+static int sector_launch_t(const MfSecArgs &a, hipStream_t s)
+{
+    // persistent grid: exactly the resident workgroups (a multiple of 8), so that the XCD-contiguous item order holds
+    static int occ = 0;
+    if (occ == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mf_sector<REALX, UN>, 256, 0) != hipSuccess || n <= 0) n = 4;
+        occ = n;
+    }
+    int grid = 256 * occ;
+    if (const char *e = getenv("QBH_SEC_GRID")) {
+        const int g = atoi(e);
+        if (g >= 8) grid = (g / 8) * 8;
+    }
+    hipLaunchKernelGGL((k_mf_sector<REALX, UN>), dim3(grid), dim3(256), 0, s, a);
+    return QBH_OK;
+}
+
 int launch_mf_sector(const MfSecArgs &a, hipStream_t s, int *nparts_out)
 {
-    const int grid = 256 * 8;
-    if (a.xr != nullptr) hipLaunchKernelGGL(k_mf_sector<true>, dim3(grid), dim3(256), 0, s, a);
-    else                 hipLaunchKernelGGL(k_mf_sector<false>, dim3(grid), dim3(256), 0, s, a);
+    static int un = 0;
+    if (un == 0) {
+        un = 8;
+        if (const char *e = getenv("QBH_SEC_UNROLL")) un = atoi(e);          // tuning experiments: 4, 8, 16
+    }
+    if (a.xr != nullptr) {
+        if (un == 4)       sector_launch_t<true, 4>(a, s);
+        else if (un == 16) sector_launch_t<true, 16>(a, s);
+        else               sector_launch_t<true, 8>(a, s);
+    } else {
+        if (un == 4)       sector_launch_t<false, 4>(a, s);
+        else               sector_launch_t<false, 8>(a, s);
+    }
     QBH_HIP(hipGetLastError());
     if (a.n_rrows > 0) {
         const int rg = blas_grid(a.n_rrows);

@@ -738,6 +738,12 @@ def test_no_device_memory_is_leaked_by_the_sector_entry_points():
         A = q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, ch0, pairs=[(i, j, 0.1, 0.2, 0.2, 0.1) for (i, j) in bonds],
                                    exchange=[(i, j, 0.3) for (i, j) in bonds])
         B = q.csr_mat.tj_repr(n, nu, nd, bonds, perms, ch1, shard=(1, 2))
+        M = q.csr_mat.hubbard_repr_mf(n, nu, nd, bonds, perms, ch1, pairs=[(i, j, 0.1, 0.2, 0.2, 0.1) for (i, j) in bonds])
+        w = M.vec(2)
+        M.randomize(w.at(0), 2)
+        M.spmv(w.at(0), w.at(M.dim), want_red=True)
+        w.free()
+        M.destroy()
         dim = A.info().ncols
         v = A.vec(2)
         A.randomize(v.at(0), 1)
