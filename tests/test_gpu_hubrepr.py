@@ -843,3 +843,17 @@ def test_matrix_free_sector_operator_at_scale():
             e_m = _lanczos_e0(M, dim, maxit=600)
         M.destroy()
         assert abs(e_a - e_m) < 1e-11 * abs(e_a), (k, e_a, e_m)
+
+
+def test_matrix_free_sector_operator_refuses_what_it_cannot_do():
+    perms, shifts = lattices.translations(4, 2)
+    chars = lattices.characters(shifts, (0, 0), (4, 2))
+    M = q.csr_mat.hubbard_repr_mf(8, 3, 3, lattices.square(4, 2), perms, chars)
+    assert M.info().kernel == q._lib.KERNEL_MATRIX_FREE
+    with pytest.raises(q._lib.QbhError):
+        M.download()                                        # no stored CSR
+    with pytest.raises(q._lib.QbhError):                    # complex up-species amplitudes are not covered by the block tables
+        q.csr_mat.hubbard_repr_mf(8, 3, 3, None, perms, chars, terms=[(0, 1, 1j, 1.0), (1, 0, -1j, 1.0)])
+    with pytest.raises(q._lib.QbhError):
+        q.csr_mat.hubbard_repr_mf(25, 3, 3, lattices.square(5, 5), *[lattices.translations(5, 5)[0], lattices.characters(lattices.translations(5, 5)[1], (0, 0), (5, 5))])
+    M.destroy()
