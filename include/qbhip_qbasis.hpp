@@ -271,8 +271,10 @@ inline void vec_randomize(const csr_mat &mat, cplx *x, const uint32_t &seed)
 // examples/trans_symmetric/latt_square/square_Fermi_Hubbard.cc (see qbh_gen_hubbard_repr in qbhip.h).  bonds: (i, j) pairs,
 // each giving -t (c+_i c_j + h.c.) for both species; perms[g * n_sites + s] = image of site s under translation g
 // (lattice::translation_plan), chars[g] = exp(-i k.t_g).
+// matrix_free = true: the same operator without the matrix (qbh_mf_hubbard_repr: block tables + a small stored remainder).
 inline csr_mat hubbard_sector(int n_sites, int n_up, int n_dn, const std::vector<std::pair<int, int>> &bonds, double t, double U,
-                              const std::vector<int32_t> &perms, const std::vector<cplx> &chars, const qbh_opts *opts = nullptr)
+                              const std::vector<int32_t> &perms, const std::vector<cplx> &chars, const qbh_opts *opts = nullptr,
+                              bool matrix_free = false)
 {
     std::vector<int32_t> sites;
     std::vector<cplx> amp;
@@ -283,6 +285,13 @@ inline csr_mat hubbard_sector(int n_sites, int n_up, int n_dn, const std::vector
     }
     qbh_csr *h = nullptr;
     int64_t dim = 0;
+    if (matrix_free) {
+        check(qbh_mf_hubbard_repr(&h, n_sites, n_up, n_dn, (int)amp.size(), sites.data(), reinterpret_cast<const qbh_z *>(amp.data()),
+                                  reinterpret_cast<const qbh_z *>(amp.data()), U, 0, nullptr, nullptr, (int)chars.size(), perms.data(),
+                                  reinterpret_cast<const double *>(chars.data()), 100.0, &dim, opts),
+              "qbh_mf_hubbard_repr failed");
+        return csr_mat::from_device(h);
+    }
     check(qbh_gen_hubbard_repr(&h, n_sites, n_up, n_dn, (int)amp.size(), sites.data(), reinterpret_cast<const qbh_z *>(amp.data()),
                                reinterpret_cast<const qbh_z *>(amp.data()), U, 0, nullptr, nullptr, 0, nullptr, nullptr, 0,
                                (int)chars.size(), perms.data(), reinterpret_cast<const double *>(chars.data()), 100.0, 0, 1, &dim,

@@ -40,6 +40,10 @@ int main()
                 qbhip::csr_mat H = qbhip::hubbard_sector(n, 4, 4, bonds, t, U, perms, chars);
                 auto res = qbhip::locate_E0_lanczos(H, 1, 1);
                 worst = std::max(worst, std::fabs(res.E0 - want[idx]));
+                // the same sector without the stored matrix
+                qbhip::csr_mat M = qbhip::hubbard_sector(n, 4, 4, bonds, t, U, perms, chars, nullptr, true);
+                auto resm = qbhip::locate_E0_lanczos(M, 1, 1);
+                worst = std::max(worst, std::fabs(resm.E0 - want[idx]));
                 std::printf("k=(%d,%d) dim %lld E0 %.10f (reference %.8f)\n", m, nn, (long long)H.dimension(), res.E0, want[idx]);
             }
         std::printf("OK %.3e\n", worst);
