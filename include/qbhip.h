@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QBH_VERSION 200
+#define QBH_VERSION 210
 
 /* error codes */
 #define QBH_OK          0
