@@ -36,8 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-KERNEL_NAME = {1: "k_spmv_stream", 2: "k_spmv_vector", 3: "k_spmv_rows", 4: "matrix_free"}
-KERNEL_KEY = {1: "stream", 2: "vector", 3: "rows", 4: "matrix_free"}
+KERNEL_NAME = {1: "k_spmv_stream", 2: "k_spmv_vector", 3: "k_spmv_rows", 4: "matrix_free", 5: "k_spmv_wave"}
+KERNEL_KEY = {1: "stream", 2: "vector", 3: "rows", 4: "matrix_free", 5: "wave"}
 
 
 def workloads():

@@ -59,10 +59,12 @@ const char *qbh_strerror(int code);
 const char *qbh_last_error(void);                   /* thread-local detail of the last failure */
 
 /* ------------------------------------------------------------- options --- */
-#define QBH_KERNEL_AUTO    0   /* = QBH_KERNEL_ROWS                                           */
+#define QBH_KERNEL_AUTO    0   /* coded values: QBH_KERNEL_ROWS; complex128 values: QBH_KERNEL_WAVE */
 #define QBH_KERNEL_STREAM  1   /* row blocks, val*x products through LDS, TPR lanes per row   */
 #define QBH_KERNEL_VECTOR  2   /* sub-wavefront per row, shuffle reduction, no LDS            */
 #define QBH_KERNEL_ROWS    3   /* row blocks staged in LDS, lanes mapped to rows (default)    */
+#define QBH_KERNEL_WAVE    5   /* one wavefront per block of whole rows (<= 512 nonzeros), no workgroup barrier:
+                                  complex128 values only (coded operators use the row kernel)            */
 #define QBH_KERNEL_MATRIX_FREE 4 /* reported by qbh_csr_get_info for qbh_mf_hubbard operators   */
 
 typedef struct qbh_opts {

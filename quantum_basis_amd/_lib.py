@@ -13,7 +13,7 @@ if os.environ.get("QBHIP_LIBRARY"):      # e.g. a host-AddressSanitizer build of
     SO_PATH = os.path.abspath(os.environ["QBHIP_LIBRARY"])
 
 QBH_OK = 0
-KERNEL_AUTO, KERNEL_STREAM, KERNEL_VECTOR, KERNEL_ROWS, KERNEL_MATRIX_FREE = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_STREAM, KERNEL_VECTOR, KERNEL_ROWS, KERNEL_MATRIX_FREE, KERNEL_WAVE = 0, 1, 2, 3, 4, 5
 
 
 class QbhError(RuntimeError):

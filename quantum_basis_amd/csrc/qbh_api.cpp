@@ -277,15 +277,53 @@ int split_shard(qbh_csr *A)
     return QBH_OK;
 }
 
+// wave-block geometry of one part for k_spmv_wave (uncoded complex128 values)
+int setup_wave_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, qbh::WaveDesc **d_wd_o, int64_t *n_wb_o, int *tpr_o, int *grid_o)
+{
+    hipStream_t s = A->stream;
+    QBH_TRY(qbh::launch_max_rowlen(d_ia, A->nrows, (int64_t *)A->d_scal, s));
+    int64_t maxlen = 0;
+    QBH_HIP(hipMemcpyAsync(&maxlen, A->d_scal, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    QBH_HIP(hipStreamSynchronize(s));
+    // a block holds the rows that START inside its window: window + maxlen - 1 <= 512 when rows are short; rows longer
+    // than half a tile make some blocks exceed it and those take the row-at-a-time path of the kernel
+    const int64_t window = (maxlen <= 256) ? 512 - (maxlen > 0 ? maxlen - 1 : 0) : 256;
+    const int64_t n_wb = std::max<int64_t>(1, (nnz + window - 1) / window);
+    QBH_HIP(hipMalloc(d_wd_o, (size_t)(n_wb + 2) * sizeof(qbh::WaveDesc)));
+    QBH_TRY(qbh::launch_build_wavedesc(d_ia, A->nrows, window, *d_wd_o, n_wb, s));
+    const double avg = A->nrows > 0 ? (double)nnz / (double)A->nrows : 0.0;
+    int tpr = avg <= 32 ? 2 : avg <= 64 ? 4 : avg <= 128 ? 8 : 16;      // rows per pass = 64 / tpr >= rows per block
+    if (const char *e = getenv("QBH_WAVE_TPR")) {
+        const int t = atoi(e);
+        if (t == 2 || t == 4 || t == 8 || t == 16) tpr = t;
+    }
+    int ncu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, A->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    const int occ = std::max(1, qbh::wave_kernel_occupancy(tpr));
+    int64_t g = std::min<int64_t>((int64_t)occ * ncu, ((((n_wb + 3) >> 2) + 7) / 8) * 8);
+    g = std::max<int64_t>(8, (g / 8) * 8);
+    if (const char *e = getenv("QBH_GRID")) {
+        const int gg = atoi(e);
+        if (gg >= 8) g = (gg / 8) * 8;
+    }
+    *n_wb_o = n_wb;
+    *tpr_o = tpr;
+    *grid_o = (int)g;
+    return QBH_OK;
+}
+
 // row-block geometry of the part(s) and the partial-sum workspace; callable again after the shard has been split
 int build_geometry(qbh_csr *A)
 {
-    for (void *q : {(void *)A->d_rb, (void *)A->d_bp, (void *)A->rem.d_rb, (void *)A->rem.d_bp})
+    for (void *q : {(void *)A->d_rb, (void *)A->d_bp, (void *)A->rem.d_rb, (void *)A->rem.d_bp, (void *)A->d_wd, (void *)A->rem.d_wd})
         if (q) (void)hipFree(q);
     A->d_rb = nullptr;
     A->d_bp = nullptr;
     A->rem.d_rb = nullptr;
     A->rem.d_bp = nullptr;
+    A->d_wd = nullptr;
+    A->rem.d_wd = nullptr;
     QBH_TRY(setup_geometry(A, A->d_ia, A->nnz, A->dict_mode, &A->npb, &A->tpr, &A->unroll, &A->window, &A->n_blocks, &A->d_rb,
                            &A->d_bp, &A->grid));
     int grid_max = A->grid;
@@ -294,6 +332,20 @@ int build_geometry(qbh_csr *A)
         QBH_TRY(setup_geometry(A, R.d_ia, R.nnz, A->dict_mode, &R.npb, &R.tpr, &R.unroll, &R.window, &R.n_blocks, &R.d_rb, &R.d_bp,
                                &R.grid));
         grid_max = std::max(grid_max, R.grid);
+    }
+    // complex128 values (no dictionary): the wave kernel, unless the row kernel was asked for by name
+    A->use_wave = A->kernel == QBH_KERNEL_ROWS && A->dict_mode == 0 && A->d_val != nullptr && A->opts.spmv_kernel != QBH_KERNEL_ROWS;
+    if (const char *e = getenv("QBH_NO_WAVE")) {
+        if (atoi(e)) A->use_wave = false;
+    }
+    if (A->use_wave) {
+        QBH_TRY(setup_wave_geometry(A, A->d_ia, A->nnz, &A->d_wd, &A->n_wb, &A->wtpr, &A->wgrid));
+        grid_max = std::max(grid_max, A->wgrid);
+        if (A->has_rem) {
+            CsrPart &R = A->rem;
+            QBH_TRY(setup_wave_geometry(A, R.d_ia, R.nnz, &R.d_wd, &R.n_wb, &R.wtpr, &R.wgrid));
+            grid_max = std::max(grid_max, R.wgrid);
+        }
     }
     const size_t nparts = (size_t)std::max(grid_max, qbh::kMaxRedBlocks);
     if (A->d_partials) (void)hipFree(A->d_partials);
@@ -314,6 +366,7 @@ int finalize(qbh_csr *A)
     QBH_HIP(hipEventCreate(&A->ev2));
     QBH_HIP(hipEventCreate(&A->ev3));
     A->nnz_total = A->nnz;
+    // QBH_KERNEL_WAVE is the uncoded member of the row-kernel family (coded values and the real gather stay on k_spmv_rows)
     A->kernel = (o.spmv_kernel == QBH_KERNEL_VECTOR) ? QBH_KERNEL_VECTOR
               : (o.spmv_kernel == QBH_KERNEL_STREAM) ? QBH_KERNEL_STREAM : QBH_KERNEL_ROWS;
 
@@ -415,6 +468,8 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
     if (A->d_dict) (void)hipFree(A->d_dict);
     if (A->d_rb) (void)hipFree(A->d_rb);
     if (A->d_bp) (void)hipFree(A->d_bp);
+    if (A->d_wd) (void)hipFree(A->d_wd);
+    if (A->rem.d_wd) (void)hipFree(A->rem.d_wd);
     if (A->rem.d_ia) (void)hipFree(A->rem.d_ia);
     if (A->rem.d_ja) (void)hipFree(A->rem.d_ja);
     if (A->rem.d_val) (void)hipFree(A->rem.d_val);
@@ -719,7 +774,7 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
         info->bytes_matrix = m.n_blocks * (int64_t)sizeof(qbh::MfSecBlock) + m.n_items * 8 + m.cu * 4 * (1 + m.w_up + m.n_trans) +
                              m.n_rrows * 12 + m.rnnz * 20;
     }
-    info->kernel = A->kind != 0 ? QBH_KERNEL_MATRIX_FREE : A->kernel;
+    info->kernel = A->kind != 0 ? QBH_KERNEL_MATRIX_FREE : A->use_wave ? QBH_KERNEL_WAVE : A->kernel;
     info->value_dict = A->d_code ? A->n_dict : 0;
     info->device = A->device;
     info->stream = (void *)A->stream;
@@ -1023,12 +1078,20 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         harvest_events(A);
         QBH_HIP(hipEventRecord(A->ev0, A->stream));
     }
-    QBH_TRY(qbh::launch_spmv(a, A->kernel, A->npb, A->tpr, A->grid, A->stream));
+    // complex128 values, complex vectors: the wave kernel; the real gather / all-real forms stay on the row kernel
+    const bool wave = A->use_wave && a.xr == nullptr && a.y_re == nullptr;
+    if (wave) {
+        a.wd = A->d_wd;
+        a.n_wb = A->n_wb;
+        QBH_TRY(qbh::launch_spmv_wave(a, A->wtpr, A->wgrid, A->stream));
+    } else {
+        QBH_TRY(qbh::launch_spmv(a, A->kernel, A->npb, A->tpr, A->grid, A->stream));
+    }
     if (prof) {
         QBH_HIP(hipEventRecord(A->ev1, A->stream));
         A->ev_pending = true;
     }
-    int grid_last = A->grid;
+    int grid_last = wave ? A->wgrid : A->grid;
     if (A->has_rem) {
         if (async_gather) {
             if (A->comm.allgather_wait(A->comm.ctx) != 0) {
@@ -1052,12 +1115,19 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         a.partials = red ? A->d_partials : nullptr;
         a.unroll = R.unroll;
         if (prof) QBH_HIP(hipEventRecord(A->ev2, A->stream));
-        QBH_TRY(qbh::launch_spmv(a, A->kernel, R.npb, R.tpr, R.grid, A->stream));
+        const bool wave_r = A->use_wave && a.xr == nullptr && a.y_re == nullptr;
+        if (wave_r) {
+            a.wd = R.d_wd;
+            a.n_wb = R.n_wb;
+            QBH_TRY(qbh::launch_spmv_wave(a, R.wtpr, R.wgrid, A->stream));
+        } else {
+            QBH_TRY(qbh::launch_spmv(a, A->kernel, R.npb, R.tpr, R.grid, A->stream));
+        }
         if (prof) {
             QBH_HIP(hipEventRecord(A->ev3, A->stream));
             A->ev_pending2 = true;
         }
-        grid_last = R.grid;
+        grid_last = wave_r ? R.wgrid : R.grid;
     }
     A->xr_of = nullptr;                      // the packed copy is consumed by exactly one SpMV
     A->stats.n_spmv++;

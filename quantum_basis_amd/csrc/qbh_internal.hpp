@@ -38,6 +38,14 @@ void set_error(const char *fmt, ...);
         if (_rc != QBH_OK) return _rc; \
     } while (0)
 
+// descriptor of one wave block of k_spmv_wave: the whole rows [r0, r0(next)) holding the nonzeros [p0, p0(next));
+// entry n_wb is a sentinel {nnz, nrows}
+struct WaveDesc {
+    int64_t p0;
+    int32_t r0;
+    int32_t pad;
+};
+
 // arguments of the SpMV kernels (passed by value)
 struct SpmvArgs {
     const int64_t *ia;     // [nrows+1] local row pointers
@@ -64,12 +72,18 @@ struct SpmvArgs {
     // the shard-local x as doubles (xr then is both the gather source and x_local); y / xl are unused
     double        *y_re;
     const double  *xl_re;
+    // wave kernel (k_spmv_wave): one wavefront per block of whole rows with <= 512 nonzeros
+    const WaveDesc *wd;
+    int64_t        n_wb;
 };
 
 // launchers implemented in qbh_kernels.hip (all asynchronous on `s`)
 int launch_spmv(const SpmvArgs &a, int kernel, int npb, int tpr, int grid, hipStream_t s);
 int spmv_grid(int kernel, int64_t n_blocks, int64_t nrows, int tpr);
 int rows_kernel_occupancy(int npb, int tpr, int un, int dict_mode);
+int launch_spmv_wave(const SpmvArgs &a, int tpr, int grid, hipStream_t s);
+int wave_kernel_occupancy(int tpr);
+int launch_build_wavedesc(const int64_t *d_ia, int64_t nrows, int64_t window, WaveDesc *d_wd, int64_t n_wb, hipStream_t s);
 int vector_kernel_occupancy(int tpr, int un, bool dict);
 int launch_build_rowblocks(const int64_t *d_ia, int64_t nrows, int64_t window, int32_t *d_rb,
                            int64_t *d_bp, int64_t n_blocks, hipStream_t s);
@@ -262,6 +276,9 @@ struct CsrPart {
     int64_t  window = 0, n_blocks = 0;
     int32_t *d_rb = nullptr;
     int64_t *d_bp = nullptr;
+    qbh::WaveDesc *d_wd = nullptr;   // wave kernel geometry (uncoded complex128 values)
+    int64_t  n_wb = 0;
+    int      wtpr = 2, wgrid = 0;
 };
 
 struct qbh_csr {
@@ -292,6 +309,11 @@ struct qbh_csr {
     int64_t *d_bp = nullptr;
     int      grid = 0;
     int      chunk_mult = 1;   // see BlockWalk (xcd_swizzle 2)
+    // wave kernel geometry (uncoded complex128 values; QBH_KERNEL_WAVE)
+    bool     use_wave = false;
+    qbh::WaveDesc *d_wd = nullptr;
+    int64_t  n_wb = 0;
+    int      wtpr = 2, wgrid = 0;
 
     // workspace
     double  *d_partials = nullptr;   // [max(grid, kMaxRedBlocks) * 16]: up to 16 partial sums per workgroup (k_multi_dot<8>)

@@ -44,7 +44,8 @@ def test_native_library_is_loaded_and_sees_the_gpu():
 
 
 @pytest.mark.parametrize("name", CASES)
-@pytest.mark.parametrize("kernel,vd", [(_lib.KERNEL_STREAM, 0), (_lib.KERNEL_VECTOR, 0), (_lib.KERNEL_ROWS, 0), (_lib.KERNEL_ROWS, 1), (_lib.KERNEL_STREAM, 1)])
+@pytest.mark.parametrize("kernel,vd", [(_lib.KERNEL_STREAM, 0), (_lib.KERNEL_VECTOR, 0), (_lib.KERNEL_ROWS, 0), (_lib.KERNEL_ROWS, 1), (_lib.KERNEL_STREAM, 1),
+                                       (_lib.KERNEL_WAVE, 0), (_lib.KERNEL_AUTO, 0)])
 def test_multmv_and_multmv2_host_seam(name, kernel, vd):
     A, O = _both(name, spmv_kernel=kernel, value_dict=vd)
     x = _rand(A.dim, 1)
@@ -61,7 +62,7 @@ def test_multmv_and_multmv2_host_seam(name, kernel, vd):
     assert info.bytes_algorithmic == info.nnz * 20 + (A.dim + 1) * 8 + A.dim * 32
 
 
-@pytest.mark.parametrize("kernel", [_lib.KERNEL_STREAM, _lib.KERNEL_ROWS])
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_STREAM, _lib.KERNEL_ROWS, _lib.KERNEL_WAVE])
 @pytest.mark.parametrize("npb,swz", [(1024, 1), (2048, 0), (4096, 2), (2048, 2)])
 def test_kernel_geometries(npb, swz, kernel):
     A, O = _both("chain16_sz0", nnz_per_block=npb, xcd_swizzle=swz, spmv_kernel=kernel)
@@ -451,7 +452,7 @@ def test_ragged_and_degenerate_shapes():
     Mc = sp.csr_matrix(M, dtype=np.complex128)
     Mc.sort_indices()
     ia, ja, val = Mc.indptr.astype(np.int64), Mc.indices.astype(np.int64), Mc.data.astype(np.complex128)
-    for kernel in (_lib.KERNEL_STREAM, _lib.KERNEL_VECTOR, _lib.KERNEL_ROWS):
+    for kernel in (_lib.KERNEL_STREAM, _lib.KERNEL_VECTOR, _lib.KERNEL_ROWS, _lib.KERNEL_WAVE):
         A = q.csr_mat(n, ia, ja, val, sym=False, opts=q.make_opts(spmv_kernel=kernel, nnz_per_block=1024))
         x = _rand(n, 12)
         y = np.empty_like(x)

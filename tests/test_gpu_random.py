@@ -70,7 +70,7 @@ def test_random_matrices_all_kernels(shape, upper):
     y0 = (rng.normal(size=n) + 1j * rng.normal(size=n)).astype(np.complex128)
     want = M @ x
     scale = max(np.abs(want).max(), 1e-300)
-    for kernel in (_lib.KERNEL_ROWS, _lib.KERNEL_STREAM, _lib.KERNEL_VECTOR):
+    for kernel in (_lib.KERNEL_ROWS, _lib.KERNEL_STREAM, _lib.KERNEL_VECTOR, _lib.KERNEL_WAVE):
         for vd in (0, 1):
             for npb in (0, 1024):
                 A = q.csr_mat(n, ia, ja, val, sym=upper, opts=q.make_opts(spmv_kernel=kernel, value_dict=vd, nnz_per_block=npb))
