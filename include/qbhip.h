@@ -283,7 +283,11 @@ int qbh_mopr_flip_repr_dev(int n_sites, int n_dn_old, int kind, int n_trans, con
  * as lanczos() expects them.
  * qbh_lanczos_ckpt: lanczos(0, maxit - 1, ...) with enable_ckpt = true: resumes from `dir` when it holds a usable
  * step, commits a checkpoint every `every` steps (the two live Lanczos vectors are downloaded for it) and at the end;
- * max_steps > 0 stops after that many new steps; *converged (may be NULL) = the stop rule fired. */
+ * max_steps > 0 stops after that many new steps; *converged (may be NULL) = the stop rule fired.
+ * An update interrupted before its second marker is rewound to the last COMMITTED step (the reference's "one step back",
+ * src/ckpt.cc:80-97, generalised to updates that are `every` steps apart); the two vectors are written under a temporary
+ * name and renamed, so a committed file is never rewritten in place.  qbh_lanczos_ckpt needs the whole operator on one
+ * GPU: a row shard returns QBH_EUNSUPP (every rank would write the same file names with its shard-local length). */
 uint32_t qbh_crc32(uint32_t crc, const void *data, int64_t nbytes);
 int qbh_vec_disk_write(const char *filename, int64_t n, int elem_size, const void *x);
 int qbh_vec_disk_read(const char *filename, int64_t n, int elem_size, void *x);

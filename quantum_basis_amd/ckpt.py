@@ -75,12 +75,14 @@ def ckpt_lanczos_update(m, maxit, dim, state, v_pair, hessenberg, purpose, phi0=
     vec_disk_write(_p(directory, "HessenbergA.dat.new"), hessenberg[maxit:maxit + m])
     vec_disk_write(_p(directory, "HessenbergB.dat.new"), hessenberg[:m + 1])
     # the reference skips V(m-1) when the file exists (it was written by the previous update of the same run);
-    # here updates are `every` steps apart, so an existing V(m-1) can only be a stale file: always rewrite it
-    if m > 0:
-        s = ((m - 1) % 2) * dim
-        vec_disk_write(_p(directory, "lanczosV%d.dat" % (m - 1)), v_pair[s:s + dim])
-    s = (m % 2) * dim
-    vec_disk_write(_p(directory, "lanczosV%d.dat" % m), v_pair[s:s + dim])
+    # here updates are `every` steps apart, so an existing V(m-1) may be a stale file and is rewritten -- but with
+    # every == 1 it also belongs to the last COMMITTED checkpoint, which must stay readable until Qckpt2 exists:
+    # temporary name + atomic rename (old or new content, never a torn file)
+    for k in ((m - 1, m) if m > 0 else (m,)):
+        s = (k % 2) * dim
+        fin = _p(directory, "lanczosV%d.dat" % k)
+        vec_disk_write(fin + ".tmp", v_pair[s:s + dim])
+        os.replace(fin + ".tmp", fin)
     if "val0" not in purpose and phi0 is not None:
         vec_disk_write(_p(directory, "lanczosY0.dat.new"), phi0)
     with open(_p(directory, "lczs_mlns.dat.new"), "wb") as f:
@@ -128,7 +130,7 @@ def ckpt_purge(directory=CKPT_DIR):
 def _recover_torn_update(directory, purpose):
     """The two branches of src/ckpt.cc:40-100 for an update that was interrupted (marker lczs_updt.Qckpt1 of the
     right size present).  Qckpt2 present: every new file was completely written -> finish the renames and the
-    clean-up.  Otherwise rewind to step k-1: drop the *.new files and every lanczosV<kk>, kk >= k."""
+    clean-up.  Otherwise rewind to the last COMMITTED step (not k-1: updates are `every` steps apart here)."""
     mk1, mk2 = _p(directory, "lczs_updt.Qckpt1"), _p(directory, "lczs_updt.Qckpt2")
     if not (os.path.exists(mk1) and os.path.getsize(mk1) == 8):
         _rm(mk1)
@@ -143,24 +145,34 @@ def _recover_torn_update(directory, purpose):
                 os.replace(_p(directory, name + ".new"), _p(directory, name))
         if purpose != "iram":
             for kk in _lanczos_vec_indices(directory):
-                if kk < k - 1:
+                if kk < k - 1 or kk > k:
                     os.remove(_p(directory, "lanczosV%d.dat" % kk))
         _rm(mk1)
         _rm(mk2)
-    else:                                                             # src/ckpt.cc:80-97 (rewind)
-        k -= 1
+    else:
+        # src/ckpt.cc:80-97 rewinds ONE step because the reference's updates are one step apart.  Here they are
+        # `every` steps apart: the committed step is the one the old HessenbergA.dat was written for (its int64
+        # header); only its two vectors may survive (a torn 2-step update has already written V(m_old+1)).
+        m_old = -1
+        ha = _p(directory, "HessenbergA.dat")
+        if os.path.exists(ha) and os.path.getsize(ha) >= 8:
+            (m_old,) = struct.unpack("<q", open(ha, "rb").read(8))
         for name in renames:
             _rm(_p(directory, name + ".new"))
         for kk in _lanczos_vec_indices(directory):
-            if kk > k:
+            if m_old < 1 or kk not in (m_old - 1, m_old):
                 os.remove(_p(directory, "lanczosV%d.dat" % kk))
         _rm(mk1)
+    for name in os.listdir(directory):                                # temporary names of an interrupted vector write
+        if name.endswith(".tmp"):
+            os.remove(_p(directory, name))
 
 
 def ckpt_lanczos_init(maxit, dim, purpose, directory=CKPT_DIR):
     """ckpt_lanczos_init for the "val" purposes (src/ckpt.cc:38-176): returns None when there is no usable
-    checkpoint, else dict(k, state, v_pair, hessenberg, phi0).  An interrupted update is finished or rewound
-    exactly as the reference does; where the reference asserts on unreadable files this returns None."""
+    checkpoint, else dict(k, state, v_pair, hessenberg, phi0).  An interrupted update is finished as the reference
+    does, or rewound to the last committed step (the reference's "one step back" generalised to updates that are
+    `every` steps apart); where the reference asserts on unreadable files this returns None."""
     if not os.path.isdir(directory):
         return None
     _recover_torn_update(directory, purpose)

@@ -215,7 +215,8 @@ int split_shard(qbh_csr *A)
     }
     hipStream_t s = A->stream;
     {   // the split holds a second copy of the shard until the original is released: skip it (one launch per SpMV, no
-        // overlap with the gather) rather than fail when HBM cannot hold both
+        // overlap with the gather) rather than fail when HBM cannot hold both.  The decision is per rank (ranks whose
+        // shard does not fit keep the single launch); both forms take part in the same collectives, so ranks may differ
         size_t free_b = 0, total_b = 0;
         const size_t per_nnz = 4 + (A->d_code ? (size_t)A->code_w : sizeof(d2));
         const size_t need = (size_t)A->nnz * per_nnz + (size_t)A->nrows * 20 + ((size_t)1 << 30);
@@ -224,38 +225,56 @@ int split_shard(qbh_csr *A)
     const int32_t lo = (int32_t)A->row_offset, hi = (int32_t)(A->row_offset + A->nrows);
     int32_t *cnt = nullptr;
     int64_t *ia0 = nullptr, *ia1 = nullptr;
-    QBH_HIP(hipMalloc(&cnt, (size_t)A->nrows * sizeof(int32_t)));
-    QBH_HIP(hipMalloc(&ia0, (size_t)(A->nrows + 1) * sizeof(int64_t)));
-    QBH_HIP(hipMalloc(&ia1, (size_t)(A->nrows + 1) * sizeof(int64_t)));
-    QBH_TRY(qbh::launch_split_count(A->d_ia, A->d_ja, A->nrows, lo, hi, cnt, s));
-    QBH_TRY(qbh::exclusive_scan(cnt, A->nrows, ia0, s));
-    (void)hipFree(cnt);
-    int64_t nnz0 = 0;
-    QBH_HIP(hipMemcpy(&nnz0, ia0 + A->nrows, sizeof(int64_t), hipMemcpyDeviceToHost));
-    const int64_t nnz1 = A->nnz - nnz0;
-    if (nnz1 == 0) {                       // nothing remote (block-diagonal shard): keep one part
-        (void)hipFree(ia0);
-        (void)hipFree(ia1);
-        return QBH_OK;
-    }
-    const bool coded = A->d_code != nullptr;
     int32_t *ja0 = nullptr, *ja1 = nullptr;
     d2 *v0 = nullptr, *v1 = nullptr;
     uint8_t *c0 = nullptr, *c1 = nullptr;
-    QBH_HIP(hipMalloc(&ja0, std::max<size_t>((size_t)nnz0, 1) * sizeof(int32_t)));
-    QBH_HIP(hipMalloc(&ja1, (size_t)nnz1 * sizeof(int32_t)));
+    auto drop = [&](int code) {                 // nothing of a failed split survives (the operator keeps its one part)
+        for (void *q : {(void *)cnt, (void *)ia0, (void *)ia1, (void *)ja0, (void *)ja1, (void *)v0, (void *)v1, (void *)c0, (void *)c1})
+            if (q) (void)hipFree(q);
+        return code;
+    };
+#define SPLIT_HIP(call)                                                                                      \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess) {                                                                              \
+            qbh::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);       \
+            (void)hipGetLastError();                                                                         \
+            return drop(e_ == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP);                                  \
+        }                                                                                                    \
+    } while (0)
+#define SPLIT_TRY(expr)                        \
+    do {                                       \
+        const int rc_ = (expr);                \
+        if (rc_ != QBH_OK) return drop(rc_);   \
+    } while (0)
+    SPLIT_HIP(hipMalloc(&cnt, (size_t)A->nrows * sizeof(int32_t)));
+    SPLIT_HIP(hipMalloc(&ia0, (size_t)(A->nrows + 1) * sizeof(int64_t)));
+    SPLIT_HIP(hipMalloc(&ia1, (size_t)(A->nrows + 1) * sizeof(int64_t)));
+    SPLIT_TRY(qbh::launch_split_count(A->d_ia, A->d_ja, A->nrows, lo, hi, cnt, s));
+    SPLIT_TRY(qbh::exclusive_scan(cnt, A->nrows, ia0, s));
+    (void)hipFree(cnt);
+    cnt = nullptr;
+    int64_t nnz0 = 0;
+    SPLIT_HIP(hipMemcpy(&nnz0, ia0 + A->nrows, sizeof(int64_t), hipMemcpyDeviceToHost));
+    const int64_t nnz1 = A->nnz - nnz0;
+    if (nnz1 == 0) return drop(QBH_OK);        // nothing remote (block-diagonal shard): keep one part
+    const bool coded = A->d_code != nullptr;
+    SPLIT_HIP(hipMalloc(&ja0, std::max<size_t>((size_t)nnz0, 1) * sizeof(int32_t)));
+    SPLIT_HIP(hipMalloc(&ja1, (size_t)nnz1 * sizeof(int32_t)));
     if (coded) {
-        QBH_HIP(hipMalloc(&c0, (size_t)nnz0 * A->code_w + 16));
-        QBH_HIP(hipMalloc(&c1, (size_t)nnz1 * A->code_w + 16));
-        QBH_HIP(hipMemsetAsync(c0 + (size_t)nnz0 * A->code_w, 0, 16, s));
-        QBH_HIP(hipMemsetAsync(c1 + (size_t)nnz1 * A->code_w, 0, 16, s));
+        SPLIT_HIP(hipMalloc(&c0, (size_t)nnz0 * A->code_w + 16));
+        SPLIT_HIP(hipMalloc(&c1, (size_t)nnz1 * A->code_w + 16));
+        SPLIT_HIP(hipMemsetAsync(c0 + (size_t)nnz0 * A->code_w, 0, 16, s));
+        SPLIT_HIP(hipMemsetAsync(c1 + (size_t)nnz1 * A->code_w, 0, 16, s));
     } else {
-        QBH_HIP(hipMalloc(&v0, std::max<size_t>((size_t)nnz0, 1) * sizeof(d2)));
-        QBH_HIP(hipMalloc(&v1, (size_t)nnz1 * sizeof(d2)));
+        SPLIT_HIP(hipMalloc(&v0, std::max<size_t>((size_t)nnz0, 1) * sizeof(d2)));
+        SPLIT_HIP(hipMalloc(&v1, (size_t)nnz1 * sizeof(d2)));
     }
-    QBH_TRY(qbh::launch_split_fill(A->d_ia, A->d_ja, A->d_val, A->d_code, A->nrows, lo, hi, ia0, ja0, v0, c0, ia1, ja1, v1, c1,
-                                    A->code_w, s));
-    QBH_HIP(hipStreamSynchronize(s));
+    SPLIT_TRY(qbh::launch_split_fill(A->d_ia, A->d_ja, A->d_val, A->d_code, A->nrows, lo, hi, ia0, ja0, v0, c0, ia1, ja1, v1, c1,
+                                      A->code_w, s));
+    SPLIT_HIP(hipStreamSynchronize(s));
+#undef SPLIT_HIP
+#undef SPLIT_TRY
     if (A->own_arrays) {
         (void)hipFree(A->d_ia);
         (void)hipFree(A->d_ja);
@@ -821,16 +840,24 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
         A->comm_cuts.clear();
         A->comm_full = comm->nblk * (int64_t)comm->nranks;
     }
-    A->comm = *comm;
-    A->comm.row_cuts = A->comm_cuts.empty() ? nullptr : A->comm_cuts.data();
-    A->has_comm = true;
     if (A->kind == 0 && !A->has_rem && A->nrows < A->ncols) {      // first communicator on a stored row shard: split it now
+        // the split comes FIRST and the communicator is committed only when it succeeded: a failure (out of memory)
+        // leaves the operator exactly as it was, unattached, with its single-part geometry
         Bind bind(A);
         QBH_HIP(hipStreamSynchronize(A->stream));
         QBH_TRY(split_shard(A));
-        if (A->has_rem) QBH_TRY(build_geometry(A));
+        if (A->has_rem) {
+            const int rc = build_geometry(A);
+            if (rc != QBH_OK) {
+                A->has_comm = false;
+                return rc;
+            }
+        }
         QBH_HIP(hipStreamSynchronize(A->stream));
     }
+    A->comm = *comm;
+    A->comm.row_cuts = A->comm_cuts.empty() ? nullptr : A->comm_cuts.data();
+    A->has_comm = true;
     return QBH_OK;
 }
 

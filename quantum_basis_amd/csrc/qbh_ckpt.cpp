@@ -154,10 +154,19 @@ extern "C" int qbh_ckpt_lanczos_update(const char *dir, int64_t m, int64_t maxit
     if (!write_pod(P(d, "lczs_updt.Qckpt1"), &m, sizeof(int64_t))) return QBH_EINVAL;
     QBH_TRY(qbh_vec_disk_write(P(d, "HessenbergA.dat.new").c_str(), m, 8, hessenberg + maxit));
     QBH_TRY(qbh_vec_disk_write(P(d, "HessenbergB.dat.new").c_str(), m + 1, 8, hessenberg));
-    // The reference skips V(m-1) when a file of that name exists (it wrote it one step earlier).  Here updates are many
-    // steps apart, so an existing V(m-1) can only be a stale file of another run: always rewritten.
-    if (m > 0) QBH_TRY(qbh_vec_disk_write(P(d, "lanczosV" + std::to_string(m - 1) + ".dat").c_str(), dim, 16, v + ((m - 1) % 2) * dim));
-    QBH_TRY(qbh_vec_disk_write(P(d, "lanczosV" + std::to_string(m) + ".dat").c_str(), dim, 16, v + (m % 2) * dim));
+    // The reference skips V(m-1) when a file of that name exists (it wrote it one step earlier).  Here updates are
+    // `every` steps apart, so an existing V(m-1) may be a stale file of another run and is rewritten -- but with
+    // every == 1 it is also a file of the LAST COMMITTED checkpoint, which must stay readable until Qckpt2 exists:
+    // both vectors go to a temporary name and are renamed over the final one (atomic: old or new, never torn).
+    auto write_vec_atomic = [&](int64_t k) -> int {
+        const std::string fin = P(d, "lanczosV" + std::to_string(k) + ".dat"), tmp = fin + ".tmp";
+        QBH_TRY(qbh_vec_disk_write(tmp.c_str(), dim, 16, v + (k % 2) * dim));
+        std::error_code e2;
+        fs::rename(tmp, fin, e2);
+        return e2 ? QBH_EINVAL : QBH_OK;
+    };
+    if (m > 0) QBH_TRY(write_vec_atomic(m - 1));
+    QBH_TRY(write_vec_atomic(m));
     const bool val0 = pur.find("val0") != std::string::npos;
     if (!val0) QBH_TRY(qbh_vec_disk_write(P(d, "lanczosY0.dat.new").c_str(), dim, 16, v + 2 * dim));
     {
@@ -211,15 +220,29 @@ extern "C" int qbh_ckpt_lanczos_init(const char *dir, int64_t *k_out, int64_t ma
                     fs::rename(P(d, std::string(n) + ".new"), P(d, n), ec);
                 }
             for (int64_t kk : lanczos_vec_indices(d))
-                if (kk < k - 1) rm(P(d, "lanczosV" + std::to_string(kk) + ".dat"));
+                if (kk < k - 1 || kk > k) rm(P(d, "lanczosV" + std::to_string(kk) + ".dat"));
             rm(mk1);
             rm(mk2);
-        } else {                                                 // src/ckpt.cc:80-97: rewind one step
-            k -= 1;
+        } else {
+            // src/ckpt.cc:80-97 rewinds ONE step because its updates are one step apart.  Here they are `every` steps
+            // apart: the committed step is the one the old HessenbergA.dat was written for (its int64 header); only its
+            // two vectors may survive, whatever the torn update had already written (V(m_old+1) for a 2-step chunk).
+            int64_t m_old = -1;
+            {
+                std::ifstream f(P(d, "HessenbergA.dat"), std::ios::in | std::ios::binary);
+                int64_t h = 0;
+                f.read(reinterpret_cast<char *>(&h), sizeof(int64_t));
+                if (f) m_old = h;
+            }
             for (const char *n : renames) rm(P(d, std::string(n) + ".new"));
             for (int64_t kk : lanczos_vec_indices(d))
-                if (kk > k) rm(P(d, "lanczosV" + std::to_string(kk) + ".dat"));
+                if (m_old < 1 || (kk != m_old - 1 && kk != m_old)) rm(P(d, "lanczosV" + std::to_string(kk) + ".dat"));
             rm(mk1);
+        }
+        std::error_code e3;                                      // temporary names of an interrupted vector write
+        for (auto &e : fs::directory_iterator(d, e3)) {
+            const std::string nm = e.path().filename().string();
+            if (nm.size() > 4 && nm.compare(nm.size() - 4, 4, ".tmp") == 0) rm(e.path().string());
         }
     } else {
         rm(mk1);
@@ -275,6 +298,10 @@ extern "C" int qbh_lanczos_ckpt(const qbh_csr *A, int64_t maxit, int64_t *m_out,
     qbh_csr_info ci;
     QBH_TRY(qbh_csr_get_info(A, &ci));
     const int64_t n = ci.nrows;
+    if (ci.nrows != ci.ncols) {       // every rank would write the same file names into `dir` with its shard-local length
+        qbh::set_error("qbh_lanczos_ckpt: row-sharded operators are not supported (checkpoint files hold whole vectors)");
+        return QBH_EUNSUPP;
+    }
     int cnt = 0;
     double accuracy = 0.0, t0 = 0.0, t1 = 0.0;
     int64_t k = 0;

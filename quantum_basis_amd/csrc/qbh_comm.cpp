@@ -2,10 +2,12 @@
 // xGMI, implemented in C++ behind the same qbh_comm hooks the library already drives, so that a C++ host -- which is
 // what the reference is (src/model.cc:1177-1181 calls lanczos() from one host thread) -- can run N > 1 ranks without
 // any Python in the SpMV loop:
-//   all-gather of x      ncclAllGather for uniform row blocks; for nnz-balanced (ragged) cuts one ncclBroadcast per
-//                        owner inside a group call, i.e. the direct schedule in which every xGMI link carries exactly
-//                        one peer block.  Runs on a side stream; begin() / wait() bracket it with events so the
-//                        locally-owned columns of a split shard are applied while the links are busy.
+//   all-gather of x      ncclAllGather for uniform row blocks; for nnz-balanced (ragged) cuts an all-gather-v made of
+//                        grouped point-to-point calls: every rank posts one ncclSend of its block and one ncclRecv
+//                        of the peer's block per peer inside ONE group, so each xGMI link carries exactly one peer
+//                        block in each direction (round 2 issued P grouped ncclBroadcasts here, which RCCL runs one
+//                        after the other over its own rings).  Runs on a side stream; begin() / wait() bracket it
+//                        with events so the locally-owned columns of a split shard are applied while the links are busy.
 //   all-reduce(sum)      <= 16 doubles (Lanczos a_m / b_m, CG dots, the real-wire flags), same side stream.
 // librccl is resolved at run time (dlopen), so libqbhip.so still loads where RCCL is absent; then
 // qbh_comm_create_rccl fails loudly with QBH_EUNSUPP.  Types come from the real <rccl/rccl.h>.
@@ -15,7 +17,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include <rccl/rccl.h>
@@ -32,28 +36,30 @@ struct RcclApi {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
 };
 
-RcclApi *rccl()
+std::string g_rccl_error;          // why the loader failed (written once, under the call_once below)
+
+void load_rccl(RcclApi &api)
 {
-    static RcclApi api;
-    static bool tried = false;
-    if (tried) return api.handle ? &api : nullptr;
-    tried = true;
     // a copy that is already mapped (e.g. the one torch bundles) is reused: same soname
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (api.handle) break;
+        const char *e = dlerror();          // dlerror() clears the message: read it exactly once per failure
+        g_rccl_error = e ? e : "no such library";
     }
-    if (!api.handle) return nullptr;
+    if (!api.handle) return;
 #define QBH_SYM(field, sym)                                                   \
     api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, sym)); \
     if (!api.field) {                                                         \
+        g_rccl_error = std::string("symbol missing: ") + sym;                 \
         api.handle = nullptr;                                                 \
-        return nullptr;                                                       \
+        return;                                                               \
     }
     QBH_SYM(GetUniqueId, "ncclGetUniqueId")
     QBH_SYM(CommInitRank, "ncclCommInitRank")
@@ -61,11 +67,19 @@ RcclApi *rccl()
     QBH_SYM(GetErrorString, "ncclGetErrorString")
     QBH_SYM(AllGather, "ncclAllGather")
     QBH_SYM(AllReduce, "ncclAllReduce")
-    QBH_SYM(Broadcast, "ncclBroadcast")
+    QBH_SYM(Send, "ncclSend")
+    QBH_SYM(Recv, "ncclRecv")
     QBH_SYM(GroupStart, "ncclGroupStart")
     QBH_SYM(GroupEnd, "ncclGroupEnd")
 #undef QBH_SYM
-    return &api;
+}
+
+RcclApi *rccl()
+{
+    static RcclApi api;
+    static std::once_flag once;             // two host threads may create their first communicator at the same time
+    std::call_once(once, [] { load_rccl(api); });
+    return api.handle ? &api : nullptr;
 }
 
 }  // namespace
@@ -122,17 +136,31 @@ int enqueue_gather(qbh_native_comm *c, int packed)
         r = c->api->AllGather(c->d_xsend, recv, (size_t)c->nblk * w, ncclDouble, c->comm, c->side);
         if (r != ncclSuccess) return fail(c, "ncclAllGather", r);
     } else {
+        // all-gather-v: one send + one receive per peer in a single group; the own block is a device copy
+        const size_t mine = (size_t)(c->cuts[(size_t)c->rank + 1] - c->cuts[(size_t)c->rank]);
         if ((r = c->api->GroupStart()) != ncclSuccess) return fail(c, "ncclGroupStart", r);
         for (int q = 0; q < c->nranks; ++q) {
+            if (q == c->rank) continue;
             const size_t len = (size_t)(c->cuts[(size_t)q + 1] - c->cuts[(size_t)q]);
-            if (len == 0) continue;
-            r = c->api->Broadcast(c->d_xsend, recv + (size_t)c->cuts[(size_t)q] * w, len * w, ncclDouble, q, c->comm, c->side);
-            if (r != ncclSuccess) {
-                (void)c->api->GroupEnd();
-                return fail(c, "ncclBroadcast", r);
+            if (len > 0) {
+                r = c->api->Recv(recv + (size_t)c->cuts[(size_t)q] * w, len * w, ncclDouble, q, c->comm, c->side);
+                if (r != ncclSuccess) {
+                    (void)c->api->GroupEnd();
+                    return fail(c, "ncclRecv", r);
+                }
+            }
+            if (mine > 0) {
+                r = c->api->Send(c->d_xsend, mine * w, ncclDouble, q, c->comm, c->side);
+                if (r != ncclSuccess) {
+                    (void)c->api->GroupEnd();
+                    return fail(c, "ncclSend", r);
+                }
             }
         }
         if ((r = c->api->GroupEnd()) != ncclSuccess) return fail(c, "ncclGroupEnd", r);
+        if (mine > 0 && hipMemcpyAsync(recv + (size_t)c->cuts[(size_t)c->rank] * w, c->d_xsend, mine * w * sizeof(double),
+                                       hipMemcpyDeviceToDevice, c->side) != hipSuccess)
+            return 1;
     }
     if (timed) {
         if (hipEventRecord(c->t1, c->side) != hipSuccess) return 1;
@@ -206,7 +234,7 @@ extern "C" int qbh_rccl_unique_id(void *uid128)
     if (!uid128) return QBH_EINVAL;
     RcclApi *api = rccl();
     if (!api) {
-        qbh::set_error("librccl could not be loaded (%s)", dlerror() ? dlerror() : "no such library");
+        qbh::set_error("librccl could not be loaded (%s)", g_rccl_error.c_str());
         return QBH_EUNSUPP;
     }
     ncclUniqueId id;

@@ -2772,9 +2772,16 @@ extern "C" int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_d
         a[2] += amp_dn[t].re;
         a[3] += amp_dn[t].im;
     }
-    if ((int)tmap.size() > kHubReprMaxTerms) {
-        set_error("%s: too many distinct one-body terms", who);
-        return QBH_EUNSUPP;
+    {   // the non-regular blocks and the remainder rows go through hubrepr_row, which holds at most kHubReprMaxRow
+        // distinct columns per row (one move per unordered site pair and species, plus the diagonal): refuse what
+        // would be silently truncated, as qbh_gen_hubbard_repr does
+        std::map<std::pair<int, int>, int> pairs;
+        for (const auto &kv : tmap)
+            if (kv.first.first != kv.first.second) pairs[{std::min(kv.first.first, kv.first.second), std::max(kv.first.first, kv.first.second)}] = 1;
+        if ((int)tmap.size() > kHubReprMaxTerms || 2 * (int)pairs.size() + 1 > kHubReprMaxRow) {
+            set_error("%s: too many distinct one-body terms (%d on %d site pairs)", who, (int)tmap.size(), (int)pairs.size());
+            return QBH_EUNSUPP;
+        }
     }
     std::vector<HubReprDev> rr(1);
     std::vector<uint64_t> tab;

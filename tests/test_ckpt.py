@@ -101,6 +101,52 @@ def test_torn_update_is_rewound_or_finished_like_the_reference(tmp_path):
     assert sorted(os.listdir(d)) == ["HessenbergA.dat", "HessenbergB.dat", "lanczosV7.dat", "lanczosV8.dat", "lczs_mlns.dat"]
 
 
+@pytest.mark.parametrize("every", [1, 2, 3])
+@pytest.mark.parametrize("native", [False, True])
+def test_torn_chunked_update_rewinds_to_the_committed_step(tmp_path, every, native):
+    """Updates are `every` steps apart (the reference's are one).  A crash before the second marker of the update to step
+    m_old + every must resume at m_old whatever the torn update had already written: for every = 2 that is the file
+    lanczosV<m_old+1>, which made the consecutive run end one step past the committed Hessenberg data (advisor, round 2)."""
+    dim, maxit, m_old = 24, 60, 10
+    d = str(tmp_path / "ck")
+    init = ckpt.native_ckpt_init if native else ckpt.ckpt_lanczos_init
+    update = ckpt.native_ckpt_update if native else ckpt.ckpt_lanczos_update
+    h0, v0, s0 = _snapshot(d, dim, maxit, 4, m_old)
+    update(m_old, maxit, dim, s0, v0, h0, "sr_val0", directory=d)
+    committed = {n: open(os.path.join(d, n), "rb").read() for n in os.listdir(d)}
+    m = m_old + every
+    h1, v1, s1 = _snapshot(d, dim, maxit, 5, m)
+    # the torn update: first marker, the new Hessenberg files, both vectors under their final names, then the crash
+    open(os.path.join(d, "lczs_updt.Qckpt1"), "wb").write(struct.pack("<q", m))
+    ckpt.vec_disk_write(os.path.join(d, "HessenbergA.dat.new"), h1[maxit:maxit + m])
+    ckpt.vec_disk_write(os.path.join(d, "HessenbergB.dat.new"), h1[:m + 1])
+    if every > 1:              # with every == 1 V(m-1) IS the committed V(m_old): written via a temporary name, renamed
+        ckpt.vec_disk_write(os.path.join(d, "lanczosV%d.dat" % (m - 1)), v1[((m - 1) % 2) * dim:((m - 1) % 2 + 1) * dim])
+    ckpt.vec_disk_write(os.path.join(d, "lanczosV%d.dat.tmp" % m), v1[(m % 2) * dim:(m % 2 + 1) * dim])     # interrupted mid-write
+    ck = init(maxit, dim, "sr_val0", d)
+    assert ck is not None and ck["k"] == m_old and ck["state"] == s0
+    assert np.array_equal(ck["v_pair"], v0) and np.array_equal(ck["hessenberg"][:m_old + 1], h0[:m_old + 1])
+    assert {n: open(os.path.join(d, n), "rb").read() for n in os.listdir(d)} == committed
+
+
+@pytest.mark.parametrize("native", [False, True])
+def test_vectors_of_the_committed_step_are_never_rewritten_in_place(tmp_path, native):
+    """every = 1: V(m-1) of the new update is V(m_old) of the committed checkpoint.  It is replaced by rename, so a
+    reader (or a crash) never sees a partly written file under the final name: the inode changes, the bytes do not."""
+    dim, maxit = 16, 40
+    d = str(tmp_path / "ck")
+    update = ckpt.native_ckpt_update if native else ckpt.ckpt_lanczos_update
+    h0, v0, s0 = _snapshot(d, dim, maxit, 7, 5)
+    update(5, maxit, dim, s0, v0, h0, "sr_val0", directory=d)
+    f = os.path.join(d, "lanczosV5.dat")
+    before, ino = open(f, "rb").read(), os.stat(f).st_ino
+    h1, v1, s1 = _snapshot(d, dim, maxit, 8, 6)
+    v1[dim:2 * dim] = v0[dim:2 * dim]                 # slot 1 = v[5], unchanged between the two steps
+    update(6, maxit, dim, s1, v1, h1, "sr_val0", directory=d)
+    assert open(f, "rb").read() == before and os.stat(f).st_ino != ino
+    assert not [n for n in os.listdir(d) if n.endswith(".tmp")]
+
+
 def test_stale_files_of_an_earlier_run_never_mix_with_a_new_one(tmp_path):
     d = str(tmp_path / "out_Qckpt")
     dim, maxit = 20, 40
