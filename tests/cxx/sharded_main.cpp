@@ -2,12 +2,14 @@
 // the SAME host CSR (the unchanged model::generate_Ham_sparse_full output), takes its nnz-balanced row block
 // (qbh_balanced_row_cuts), builds only that block on its GPU (qbh_csr_create_rows) and joins the native RCCL
 // communicator (qbh_comm_create_rccl); then the unchanged solver call: lanczos("sr_val0") + hess_eigen, eigenvec_CG.
-// usage: sharded_main csr.bin rank nranks uid_file      (rank 0 writes the ncclUniqueId to uid_file, the others wait)
+// usage: sharded_main csr.bin rank nranks uid_file [uniform]   (rank 0 writes the ncclUniqueId to uid_file, the others wait;
+//        "uniform": equal row blocks -> ncclAllGather instead of the send/recv all-gather-v of nnz-balanced cuts)
 #include <chrono>
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -50,14 +52,19 @@ int main(int argc, char **argv)
         }
     }
     std::vector<int64_t> cuts(nranks + 1);
-    must(qbh_balanced_row_cuts(dim, nnz, (int)sym, ia.data(), ja.data(), nranks, cuts.data()), "qbh_balanced_row_cuts");
+    const bool uniform = argc > 5 && std::string(argv[5]) == "uniform" && dim % nranks == 0;
+    if (uniform) {
+        for (int q = 0; q <= nranks; ++q) cuts[q] = dim / nranks * q;
+    } else {
+        must(qbh_balanced_row_cuts(dim, nnz, (int)sym, ia.data(), ja.data(), nranks, cuts.data()), "qbh_balanced_row_cuts");
+    }
     qbh_opts opts;
     qbh_opts_default(&opts);
     opts.device = rank % (qbh_device_count() > 0 ? qbh_device_count() : 1);          // one process per GPU
     qbh_csr *A = nullptr;
     must(qbh_csr_create_rows(&A, dim, nnz, (int)sym, ia.data(), ja.data(), reinterpret_cast<const qbh_z *>(val.data()), cuts[rank],
                              cuts[rank + 1], &opts), "qbh_csr_create_rows");
-    must(qbh_comm_create_rccl(A, uid, rank, nranks, cuts.data()), "qbh_comm_create_rccl");
+    must(qbh_comm_create_rccl(A, uid, rank, nranks, uniform ? nullptr : cuts.data()), "qbh_comm_create_rccl");
     const int64_t n = cuts[rank + 1] - cuts[rank], maxit = 1000;
     qbh_z *d_v = nullptr;
     must(qbh_vec_alloc(&d_v, 4 * n), "qbh_vec_alloc");

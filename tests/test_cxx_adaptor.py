@@ -94,6 +94,82 @@ def test_sharded_cxx_host_rank_over_native_rccl(force_ragged):
         assert abs(mcg - 83) <= 2 and accu < 2e-12 and abs(nrm - 1.0) < 1e-10
 
 
+def _visible_gpus():
+    import torch
+    return torch.cuda.device_count()          # does not initialise the GPU on this image
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [2, 4])
+@pytest.mark.parametrize("cuts", ["ragged", "uniform"])
+def test_sharded_cxx_host_ranks_over_native_rccl_on_real_gpus(nranks, cuts):
+    """SURVEY 8(e) on hardware: N C++ host processes, one per GPU, row blocks of the same host CSR, the native RCCL
+    communicator over xGMI (ncclAllGather for uniform blocks, grouped ncclSend/ncclRecv for nnz-balanced ones) and the
+    all-reduce of the Lanczos scalars.  Skipped -- visibly -- on a box with fewer GPUs; every rank must report the
+    single-GPU answer."""
+    if _visible_gpus() < nranks:
+        pytest.skip("needs %d GPUs, %d visible" % (nranks, _visible_gpus()))
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = _build(tmp, "sharded_main")
+        path, O, x = _dump(tmp, "hubbard_4x2")
+        uid = os.path.join(tmp, "uid.bin")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = [subprocess.Popen([exe, path, str(r), str(nranks), uid] + (["uniform"] if cuts == "uniform" else []),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(nranks)]
+        outs = []
+        for p in procs:
+            try:
+                out, _ = p.communicate(timeout=300)
+            except subprocess.TimeoutExpired:
+                for q_ in procs:
+                    q_.kill()
+                raise
+            outs.append(out)
+            assert p.returncode == 0, out
+        covered = []
+        for r, out in enumerate(outs):
+            line = [ln for ln in out.splitlines() if ln.startswith("OK ")]
+            assert len(line) == 1, out
+            tok = line[0].split()
+            assert tok[1:3] == [str(r), str(nranks)]
+            covered.append((int(tok[3]), int(tok[4])))
+            m, E0, mcg, accu, nrm = int(tok[5]), float(tok[6]), int(tok[7]), float(tok[8]), float(tok[9])
+            assert abs(m - 82) <= 1 and abs(E0 + 14.076058658879278) < 1e-9          # SURVEY App. E, every rank
+            assert abs(mcg - 83) <= 2 and accu < 2e-12 and abs(nrm - 1.0) < 1e-10
+        assert covered[0][0] == 0 and covered[-1][1] == 4900 and all(covered[i][1] == covered[i + 1][0] for i in range(nranks - 1))
+        if cuts == "uniform":
+            assert all(b - a == 4900 // nranks for a, b in covered)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_bench_under_torch_distributed_run_uses_the_native_communicator(nranks):
+    """The driver's own launch line (python -m torch.distributed.run ... bench.py --gpus N) on a multi-GPU box: the JSON
+    line must say the exchange ran on the native RCCL communicator and E0 must equal the one-rank value."""
+    if _visible_gpus() < nranks:
+        pytest.skip("needs %d GPUs, %d visible" % (nranks, _visible_gpus()))
+    import json
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "5", "--warmup", "2", "--workload", "hubbard_4x3_half", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True,
+                         env=env, cwd=ROOT, timeout=600)
+    assert one.returncode == 0, one.stdout + one.stderr
+    ref = json.loads(one.stdout.strip().splitlines()[-1])
+    many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                           "--gpus", str(nranks)] + common, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert many.returncode == 0, many.stdout + many.stderr
+    got = json.loads([ln for ln in many.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert got["n_gpus"] == nranks and "native RCCL" in got["config"]["exchange"], got["config"]
+    assert abs(got["e0"] - ref["e0"]) <= 1e-10 * abs(ref["e0"])
+
+
 @pytest.mark.gpu
 def test_cxx_program_following_the_reference_example_reproduces_its_asserted_sector_energies():
     """tests/cxx/sectors_main.cpp = examples/trans_symmetric/latt_square/square_Fermi_Hubbard.cc through the C++ header:

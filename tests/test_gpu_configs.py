@@ -183,3 +183,51 @@ def test_c5_triangular_6x6_sz0_momentum_sector_full_size():
     assert abs(rb.E0 - (-20.173442240311)) < 1e-9
     assert rb.E0 < e_k10                                   # the k = (1,0) minimum lies above the ground state
     B.destroy()
+
+
+def test_c4_as_written_half_filling_sector_full_size():
+    """BASELINE configs[3] AS WRITTEN: Fermi-Hubbard 4x5 at half filling (N_up = N_dn = 10, 3.4e10 basis states) through its
+    k = (0,0) momentum sector, 1,706,742,160 representatives, on ONE GPU in matrix-free form (qbh_mf_hubbard_repr).
+      * y = Hx of the matrix-free operator against ONE stored row shard of the same sector (qbh_gen_hubbard_repr, shard 0 of
+        4: 4.3e8 rows, 1.7e10 nonzeros as columns + 1-byte codes) on the shard's rows, to 1e-13 |y|;
+      * the packed-double Lanczos to E0, which must equal the round-2 builder run (profiles/r2_sectors/
+        c4_hubbard_4x5_half_all_sectors_ONE_gpu_matrix_free.txt) to 1e-11, lie below the ground-state energy recorded there
+        for every other sector class, and inside the two rigorous bounds that need no computation of ours:
+        2 E_free <= E0 <= 2 E_free + U N_up N_dn / N   (U >= 0; the paramagnetic plane-wave Slater determinant)."""
+    Lx, Ly, n, nu = 4, 5, 20, 10
+    bonds = lattices.square(Lx, Ly)
+    perms, shifts = lattices.translations(Lx, Ly)
+    chars = lattices.characters(shifts, (0, 0), (Lx, Ly))
+    M = q.csr_mat.hubbard_repr_mf(n, nu, nu, bonds, perms, chars, t=1.0, U=1.1)
+    dim = M.info().ncols
+    assert dim == 1706742160
+    S = q.csr_mat.hubbard_repr(n, nu, nu, bonds, perms, chars, t=1.0, U=1.1, shard=(0, 4))
+    i = S.info()
+    assert i.ncols == dim and i.row_offset == 0 and i.nrows == 426685540
+    v = M.vec(2)
+    M.randomize(v.at(0), 11)
+    M.spmv(v.at(0), v.at(dim))
+    M.sync()
+    ys = S.vec()
+    S.spmv(v.at(0), ys.ptr)                      # unsharded convention: x is the full-length vector
+    S.sync()
+    hy = S.nrm2(ys.ptr)
+    assert hy > 0.0
+    assert np.sqrt(S.axpy_norm(-1.0, ys.ptr, v.at(dim))) <= 1e-13 * hy          # rows [0, nrows) of the matrix-free result
+    ys.free()
+    v.free()
+    S.destroy()
+    e0, m = _packed_lanczos_e0(M, maxit=600)
+    M.destroy()
+    recorded = -27.029212101320                  # k = (0,0), 195 steps (round 2, same operator, same start vector)
+    assert abs(e0 - recorded) <= 1e-11 * abs(recorded), (e0, m)
+    others = {(2, 0): -26.652254639705, (0, 1): -26.993024675302, (0, 2): -26.623567801498, (1, 0): -26.431798738331,
+              (2, 1): -26.337053630786, (2, 2): -26.674629340360, (1, 1): -26.823077903905, (1, 2): -26.811730670669}
+    assert all(e0 < e for e in others.values())
+    # one-particle levels of the 4x5 torus with the bond list actually used (H = -t sum over bonds of c+c + h.c.)
+    h1 = np.zeros((n, n))
+    for a, b in bonds:
+        h1[a, b] -= 1.0
+        h1[b, a] -= 1.0
+    e_free = 2.0 * np.sort(np.linalg.eigvalsh(h1))[:nu].sum()
+    assert e_free - 1e-9 <= e0 <= e_free + 1.1 * nu * nu / n + 1e-9, (e_free, e0)
