@@ -141,23 +141,31 @@ def build_operator(w, rows, opts, matrix_free=False, shard=(0, 1)):
     return q.csr_mat.heisenberg(w["n_sites"], w["n_dn"], w["bonds"], J=w["J"], rows=rows, opts=opts, matrix_free=matrix_free)
 
 
-def reference_order_host_csr(name, w):
+def _reforder_args(w):
+    if w["kind"] == "hubbard":
+        return 1, w["n_sites"], w["n_up"], w["n_dn"]
+    if w["kind"] == "heisenberg":
+        return 0, w["n_sites"], 0, w["n_dn"]
+    raise SystemExit("reference order is defined for the hubbard and heisenberg (full-basis) workloads")
+
+
+def reference_order_host_csr(name, w, q, stream):
     """Host CSR exactly as the unchanged reference host code hands it over (src/model.cc:619-685): Hermitian-upper, int64
     ia/ja, complex128 values, basis in the reference's Lin order j = Ja[i_a] + Jb[i_b] (src/model.cc:665-670,
-    src/basis.cc:1144-1190).  Assembled by the numpy re-derivation tests/refham.py (test helper, pinned against the
-    survey's index checksums of the reference's own matrices)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import refham
-    if w["kind"] == "hubbard":
-        lx = 4
-        ly = w["n_sites"] // 4
-        d, ia, ja, val, _ = refham.hubbard_csr(lx, ly, w["n_up"], w["n_dn"], t=w["t"], U=w["U"])
-    elif w["kind"] == "heisenberg":
-        d, ia, ja, val, _ = refham.heisenberg_csr(w["n_sites"], [tuple(b) for b in np.asarray(w["bonds"]).reshape(-1, 2)],
-                                                  J=w["J"], n_dn=w["n_dn"])
-    else:
-        raise SystemExit("--host-csr supports the hubbard and heisenberg workloads")
-    return d, ia, ja, val
+    src/basis.cc:1144-1190).  Produced by the device generator + the device permutation qbh_csr_reference_order (checked entry
+    by entry against the numpy re-derivation of the reference's pipeline in tests/test_gpu_reforder.py) and downloaded."""
+    o = q.make_opts(stream=stream.cuda_stream, value_dict=0, real_fast_path=0)
+    G = build_operator(w, (0, -1), o)
+    R = G.reference_order(*_reforder_args(w), opts=o)
+    G.destroy()
+    d = R.dim
+    ia, ja, val = R.download()
+    R.destroy()
+    rows = np.repeat(np.arange(d, dtype=np.int64), np.diff(ia))
+    keep = ja >= rows
+    uia = np.zeros(d + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows[keep], minlength=d), out=uia[1:])
+    return d, uia, ja[keep].astype(np.int64), val[keep]
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline ----
@@ -359,6 +367,9 @@ def main():
     ap.add_argument("--host-csr", default=None, choices=[None, "reference-order"],
                     help="assemble the operator on the HOST in the reference's Lin order (Hermitian-upper int64 CSR) and hand it to "
                          "qbh_csr_create, as the unchanged reference host code would (workloads up to a few 1e7 nnz)")
+    ap.add_argument("--order", default="generator", choices=["generator", "reference"],
+                    help="reference: permute the generated operator ON THE DEVICE into the reference's Lin order and fermion convention "
+                         "(qbh_csr_reference_order; src/basis.cc:1144-1190) before timing -- the order the unchanged host code hands over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed run to convergence (E0)")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)
@@ -500,7 +511,7 @@ def main():
                            value_dict=value_dict, real_fast_path=real_fp, profile=1)
         t_gen = time.time()
         if args.host_csr:
-            hd, hia, hja, hval = reference_order_host_csr(args.workload, W)
+            hd, hia, hja, hval = reference_order_host_csr(args.workload, W, q, stream)
             t_host = time.time() - t_gen
             assert hd == dim
             t_gen = time.time()
@@ -508,9 +519,15 @@ def main():
             ci = A.info()
             create = {"create_s": round(ci.create_ms * 1e-3, 4), "input_bytes": int(ci.create_bytes_in),
                       "create_GBps_of_input": round(ci.create_bytes_in / ci.create_ms / 1e6, 2),
-                      "host_assembly_s (numpy, not the product)": round(t_host, 2),
+                      "host_arrays_s (device generator + device permutation + download, not the product)": round(t_host, 2),
                       "entry": "qbh_csr_create" if world == 1 else "qbh_csr_create_rows", "storage": "Hermitian-upper, int64 ia/ja, complex128",
                       "order": "reference Lin order (src/model.cc:665-670)", "nnz_upper": int(hia[-1])}
+        elif args.order == "reference":
+            if world != 1 or args.matrix_free or value_dict != 0:
+                raise SystemExit("--order reference: one GPU, stored operator, --format complex128")
+            G = build_operator(W, (r0, r1), opts)
+            A = G.reference_order(*_reforder_args(W), opts=opts)
+            G.destroy()
         else:
             A = build_operator(W, (r0, r1), opts, matrix_free=args.matrix_free, shard=(rank, world))
         torch.cuda.synchronize()
@@ -550,7 +567,7 @@ def main():
     real_used = head["n_real"] > 0
     code_w = 0 if not coded else (1 if info.value_dict <= 256 else 2)
     tkey = "%s|%s|%s" % (args.workload, KERNEL_KEY[info.kernel], "dict" if coded else "plain") + ("|real" if real_used else "")
-    traffic, tsrc = traffic_of(tkey) if world == 1 and not args.host_csr else (None, None)
+    traffic, tsrc = traffic_of(tkey + ("|reforder" if args.order == "reference" else "")) if world == 1 and not args.host_csr else (None, None)
     if coded or real_used:
         # the kernel moves its own format's bytes, not SURVEY 8(d)'s: the fraction is defined on those (cannot exceed 1)
         vec_b = 8 if real_used else 16
@@ -580,7 +597,9 @@ def main():
                                          "kernel": KERNEL_KEY[info.kernel], "format": "complex128 CSR values + int32 columns, complex128 vectors"
                                          if not (coded or real_used) else "value codes %s, real fast path %s" % (coded, real_used),
                                          "value_dict": info.value_dict, "real_gather": real_used,
-                                         "operator_source": "host CSR in reference order through qbh_csr_create" if args.host_csr else "device generator",
+                                         "operator_source": "host CSR in reference order through qbh_csr_create" if args.host_csr else
+                                         "device generator, permuted on the device into the reference's Lin order and fermion convention "
+                                         "(qbh_csr_reference_order)" if args.order == "reference" else "device generator",
                                          "build_s": round(t_gen, 3)},
         "roofline": roof, "e0": head["e0"], "lanczos_steps_to_converge": head["steps_e0"],
     }
@@ -613,7 +632,7 @@ def main():
     n = A.dim
     if world == 1:
         A.destroy()          # the extra blocks below build their own operators: give the HBM back first (C4 substitute: 157 GB)
-    if world == 1 and not (coded or real_used) and not args.no_fast_path and not args.matrix_free and not args.host_csr:
+    if world == 1 and not (coded or real_used) and not args.no_fast_path and not args.matrix_free and not args.host_csr and args.order != "reference":
         # the library's default path for this operator (lossless value codes; real operator + real vectors -> packed doubles):
         # same step definition, same K, its own roofline on its own format's bytes
         try:
@@ -644,7 +663,7 @@ def main():
                 F.destroy()
         except Exception as e:
             out["fast_path"] = {"error": repr(e)}
-    if world == 1 and W["kind"] in ("hubbard", "heisenberg") and not args.no_matrix_free and not args.matrix_free and not args.host_csr:
+    if world == 1 and W["kind"] in ("hubbard", "heisenberg") and not args.no_matrix_free and not args.matrix_free and not args.host_csr and args.order != "reference":
         # SURVEY 8f-1 (next row, NOT the north-star CSR path): the same operator applied from the hop tables without a
         # stored matrix, same solver code; measured after the timed region, same step definition
         try:

@@ -463,6 +463,13 @@ int qbh_mopr_diag_hubrepr_dev(int n_sites, int n_up, int n_dn, int n_trans, cons
 int qbh_mopr_c_hubrepr_dev(int n_sites, int n_up_old, int n_dn_old, int species, int kind, int n_trans, const int32_t *perms,
                            const double *chars_old, const double *chars_new, const qbh_z *coef, const qbh_z *d_vec_old,
                            qbh_z *d_vec_new, int64_t *dim_old_out, int64_t *dim_new_out);
+/* Measurement harness (SURVEY 7 hard-part 1): the operator of qbh_gen_heisenberg (kind 0) / qbh_gen_hubbard (kind 1), built with
+ * complex128 values on one GPU, re-expressed ON THE DEVICE in the reference's own basis order and fermion convention, i.e.
+ * exactly the matrix the unchanged host code assembles (src/model.cc:619-685) at sizes that code cannot reach: basis sorted
+ * by (odd sites, even sites) -- sort_basis_Lin_order, src/basis.cc:1144-1190, row index j = Lin_Ja[i_a] + Lin_Jb[i_b],
+ * src/model.cc:665-670 -- electron states as two bits per site with operators ordered by site (src/basis.cc:2650-2664), so
+ * H_ref = P D H_gen D P^T.  Full storage, columns ascending.  *out is a new handle; A is left untouched. */
+int qbh_csr_reference_order(qbh_csr **out, const qbh_csr *A, int kind, int n_sites, int n_up, int n_dn, const qbh_opts *opts);
 /* Copy the assembled shard back to host arrays (tests, CPU-baseline sample).  Any output
  * pointer may be NULL.  Rows [r0, r1) local to the shard; ia is rebased to 0. */
 int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1,

@@ -1,0 +1,236 @@
+// qbh_reorder.hip -- a device-generated benchmark operator re-expressed in the REFERENCE's basis order and fermion
+// convention, on the device (measurement harness, SURVEY 7 hard-part 1: the CSR kernel must be measured on the order the
+// unchanged reference host code would hand over, at the sizes that code cannot assemble).
+//
+// The reference sorts its basis by (sub_b, sub_a): the odd sites compacted into one integer, then the even sites
+// (sort_basis_Lin_order, src/basis.cc:1144-1190; split unzipper_basis, :971-996); a state's row index is its position in
+// that order (j = Lin_Ja[i_a] + Lin_Jb[i_b], src/model.cc:665-670).  Local states (src/basis.cc:52-83): spin-1/2 one bit
+// per site (1 = down); electron two bits per site (bit 0 up, bit 1 down), fermion operators ordered by site
+// (src/basis.cc:2650-2664).  The generators (qbh_gen.hip) index by colexicographic rank and put all up operators before
+// all down operators, so H_ref = P D H_gen D P^T with a permutation P and a diagonal of signs D.
+//
+//   keys     one 64-bit key (sub_b, sub_a) per generator index          k_ref_keys
+//   sort     radix sort of (key, generator index) pairs                  hipcub::DeviceRadixSort
+//   pos      position of every generator index in the sorted order, sign in bit 31
+//   fill     one thread per reference row: columns mapped through pos, ranked inside the row through a transposed LDS tile
+//            (rows are <= 64 entries for every benchmark family; longer rows take an insertion sort in place)
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "qbh_internal.hpp"
+
+namespace qbh {
+
+namespace {
+
+struct RefOrderArgs {
+    int kind;          // 0 spin-1/2 (one pattern of n_dn bits), 1 electron (n_up, n_dn patterns)
+    int n_sites, n_up, n_dn;
+    int64_t dim, n_minor;              // n_minor = C(n_sites, n_dn): generator index = rank_up * n_minor + rank_dn
+    const uint64_t *binom;             // [33 * 33] C(p, k) at p * 33 + k (device)
+};
+
+__device__ __forceinline__ uint32_t colex_unrank(const RefOrderArgs &a, int64_t r, int k)
+{
+    uint32_t bits = 0;
+    for (int p = a.n_sites - 1; p >= 0 && k > 0; --p) {
+        const int64_t c = (int64_t)a.binom[p * 33 + k];
+        if (c <= r) {
+            bits |= 1u << p;
+            r -= c;
+            --k;
+        }
+    }
+    return bits;
+}
+
+// sites of one parity compacted (bps bits per site)
+__device__ __forceinline__ uint64_t compact_sites(uint64_t word, int n_sites, int bps, int parity)
+{
+    uint64_t out = 0;
+    const uint64_t mask = (1ull << bps) - 1;
+    int k = 0;
+    for (int s = parity; s < n_sites; s += 2, ++k) out |= ((word >> (s * bps)) & mask) << (k * bps);
+    return out;
+}
+
+__global__ __launch_bounds__(256) void k_ref_keys(RefOrderArgs a, uint64_t *keys, int32_t *vals, uint8_t *sign)
+{
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.dim; g += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t word;
+        int bps;
+        uint8_t sg = 0;
+        if (a.kind == 0) {
+            word = colex_unrank(a, g, a.n_dn);
+            bps = 1;
+        } else {
+            const uint32_t up = colex_unrank(a, g / a.n_minor, a.n_up), dn = colex_unrank(a, g % a.n_minor, a.n_dn);
+            word = 0;
+            for (int s = 0; s < a.n_sites; ++s) word |= ((uint64_t)((up >> s) & 1) << (2 * s)) | ((uint64_t)((dn >> s) & 1) << (2 * s + 1));
+            bps = 2;
+            // all-up-then-all-down ordering -> site ordering: every down operator at site i passes the up operators at sites j > i
+            int swaps = 0;
+            for (int i = 0; i < a.n_sites; ++i)
+                if ((dn >> i) & 1) swaps += __popc(up >> (i + 1));
+            sg = (uint8_t)(swaps & 1);
+        }
+        const int na = (a.n_sites + 1) / 2;                          // even sites
+        const uint64_t sub_a = compact_sites(word, a.n_sites, bps, 0), sub_b = compact_sites(word, a.n_sites, bps, 1);
+        keys[g] = (sub_b << (na * bps)) | sub_a;
+        vals[g] = (int32_t)g;
+        sign[g] = sg;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ref_pos(const int32_t *order, const uint8_t *sign, int64_t dim, uint32_t *pos, const int64_t *ia,
+                                                 int32_t *cnt)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < dim; r += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t g = order[r];
+        pos[g] = (uint32_t)r | ((uint32_t)sign[g] << 31);
+        cnt[r] = (int32_t)(ia[g + 1] - ia[g]);
+    }
+}
+
+constexpr int kRefMaxRow = 64;
+
+__global__ __launch_bounds__(256) void k_ref_fill(const int32_t *order, const uint32_t *pos, int64_t dim, const int64_t *ia, const int32_t *ja,
+                                                  const d2 *val, const int64_t *ia_r, int32_t *ja_r, d2 *val_r)
+{
+    __shared__ uint32_t tile[kRefMaxRow * 256];                      // element k of thread t at [k * 256 + t]: conflict-free
+    const int t = threadIdx.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + t; r < dim; r += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t g = order[r];
+        const uint32_t pg = pos[g];
+        const int64_t src = ia[g], dst = ia_r[r];
+        const int len = (int)(ia[g + 1] - src);
+        if (len <= kRefMaxRow) {
+            for (int k = 0; k < len; ++k) tile[k * 256 + t] = pos[ja[src + k]];
+            for (int k = 0; k < len; ++k) {
+                const uint32_t mine = tile[k * 256 + t], mc = mine & 0x7FFFFFFFu;
+                int rank = 0;
+                for (int j = 0; j < len; ++j) rank += (tile[j * 256 + t] & 0x7FFFFFFFu) < mc;
+                const d2 v = val[src + k];
+                ja_r[dst + rank] = (int32_t)mc;
+                val_r[dst + rank] = ((mine ^ pg) >> 31) ? -v : v;
+            }
+        } else {
+            for (int k = 0; k < len; ++k) {                          // insertion sort in place (long rows: not a benchmark case)
+                const uint32_t p = pos[ja[src + k]];
+                const int32_t c = (int32_t)(p & 0x7FFFFFFFu);
+                d2 v = val[src + k];
+                if ((p ^ pg) >> 31) v = -v;
+                int64_t q = dst + k;
+                while (q > dst && ja_r[q - 1] > c) {
+                    ja_r[q] = ja_r[q - 1];
+                    val_r[q] = val_r[q - 1];
+                    --q;
+                }
+                ja_r[q] = c;
+                val_r[q] = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+}  // namespace qbh
+
+#define RO_HIP(call)                                                                                      \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            qbh::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);    \
+            (void)hipGetLastError();                                                                      \
+            return drop(e_ == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP);                               \
+        }                                                                                                 \
+    } while (0)
+
+extern "C" int qbh_csr_reference_order(qbh_csr **out, const qbh_csr *A, int kind, int n_sites, int n_up, int n_dn, const qbh_opts *opts)
+{
+    using namespace qbh;
+    if (!out || !A || (kind != 0 && kind != 1) || n_sites < 1 || n_sites > 32 || n_dn < 0 || n_dn > n_sites || n_up < 0 || n_up > n_sites) {
+        set_error("qbh_csr_reference_order: invalid argument");
+        return QBH_EINVAL;
+    }
+    if (A->kind != 0 || A->d_val == nullptr || A->has_rem || A->nrows != A->ncols || A->row_offset != 0) {
+        set_error("qbh_csr_reference_order: needs an unsharded stored operator with complex128 values (create it with value_dict = 0)");
+        return QBH_EUNSUPP;
+    }
+    RefOrderArgs a{};
+    a.kind = kind;
+    a.n_sites = n_sites;
+    a.n_up = n_up;
+    a.n_dn = n_dn;
+    std::vector<uint64_t> hb(33 * 33, 0);
+    for (int p = 0; p <= 32; ++p)
+        for (int k = 0; k <= 32; ++k) hb[(size_t)p * 33 + k] = (k == 0) ? 1 : (p == 0 ? 0 : hb[(size_t)(p - 1) * 33 + k - 1] + hb[(size_t)(p - 1) * 33 + k]);
+    a.n_minor = (int64_t)hb[(size_t)n_sites * 33 + n_dn];
+    a.dim = kind == 0 ? a.n_minor : (int64_t)hb[(size_t)n_sites * 33 + n_up] * a.n_minor;
+    if (a.dim != A->nrows) {
+        set_error("qbh_csr_reference_order: the operator has %lld rows, the basis described has %lld", (long long)A->nrows, (long long)a.dim);
+        return QBH_EINVAL;
+    }
+    const int64_t dim = a.dim, nnz = A->nnz;
+    hipStream_t s = A->stream;
+    uint64_t *k0 = nullptr, *k1 = nullptr;
+    int32_t *v0 = nullptr, *v1 = nullptr, *cnt = nullptr, *ja_r = nullptr;
+    uint8_t *sign = nullptr;
+    uint32_t *pos = nullptr;
+    void *tmp = nullptr;
+    uint64_t *d_binom = nullptr;
+    int64_t *ia_r = nullptr;
+    d2 *val_r = nullptr;
+    auto drop = [&](int code) {
+        for (void *q : {(void *)k0, (void *)k1, (void *)v0, (void *)v1, (void *)cnt, (void *)sign, (void *)pos, tmp, (void *)d_binom})
+            if (q) (void)hipFree(q);
+        if (code != QBH_OK)
+            for (void *q : {(void *)ia_r, (void *)ja_r, (void *)val_r})
+                if (q) (void)hipFree(q);
+        return code;
+    };
+    RO_HIP(hipMalloc(&d_binom, hb.size() * 8));
+    RO_HIP(hipMemcpy(d_binom, hb.data(), hb.size() * 8, hipMemcpyHostToDevice));
+    a.binom = d_binom;
+    RO_HIP(hipMalloc(&k0, (size_t)dim * 8));
+    RO_HIP(hipMalloc(&k1, (size_t)dim * 8));
+    RO_HIP(hipMalloc(&v0, (size_t)dim * 4));
+    RO_HIP(hipMalloc(&v1, (size_t)dim * 4));
+    RO_HIP(hipMalloc(&sign, (size_t)dim));
+    hipLaunchKernelGGL(k_ref_keys, dim3(2048), dim3(256), 0, s, a, k0, v0, sign);
+    RO_HIP(hipGetLastError());
+    size_t tmp_bytes = 0;
+    const int key_bits = (kind == 0 ? 1 : 2) * n_sites;
+    RO_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0, k1, v0, v1, dim, 0, key_bits, s));
+    RO_HIP(hipMalloc(&tmp, tmp_bytes));
+    RO_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k0, k1, v0, v1, dim, 0, key_bits, s));
+    RO_HIP(hipStreamSynchronize(s));
+    (void)hipFree(tmp);
+    tmp = nullptr;
+    (void)hipFree(k0);
+    k0 = nullptr;
+    (void)hipFree(k1);
+    k1 = nullptr;
+    (void)hipFree(v0);
+    v0 = nullptr;
+    RO_HIP(hipMalloc(&pos, (size_t)dim * 4));
+    RO_HIP(hipMalloc(&cnt, (size_t)dim * 4));
+    hipLaunchKernelGGL(k_ref_pos, dim3(2048), dim3(256), 0, s, v1, sign, dim, pos, A->d_ia, cnt);
+    RO_HIP(hipGetLastError());
+    RO_HIP(hipMalloc(&ia_r, (size_t)(dim + 1) * 8));
+    {
+        const int rc = exclusive_scan(cnt, dim, ia_r, s);
+        if (rc != QBH_OK) return drop(rc);
+    }
+    RO_HIP(hipMalloc(&ja_r, (size_t)std::max<int64_t>(nnz, 1) * 4));
+    RO_HIP(hipMalloc(&val_r, (size_t)std::max<int64_t>(nnz, 1) * 16));
+    hipLaunchKernelGGL(k_ref_fill, dim3(4096), dim3(256), 0, s, v1, pos, dim, A->d_ia, A->d_ja, A->d_val, ia_r, ja_r, val_r);
+    RO_HIP(hipGetLastError());
+    RO_HIP(hipStreamSynchronize(s));
+    (void)drop(QBH_OK);                       // scratch only; the three result arrays go to the new handle
+    const int rc = qbh_csr_create_device(out, dim, dim, 0, nnz, ia_r, ja_r, reinterpret_cast<qbh_z *>(val_r), 1, opts);
+    return rc;
+}

@@ -334,6 +334,16 @@ class csr_mat:
         check(lib().qbh_get_stats(self.handle, C.byref(s), int(reset)), "qbh_get_stats")
         return s
 
+    def reference_order(self, kind, n_sites, n_up, n_dn, opts=None):
+        """The same operator in the reference's basis order and fermion convention, permuted on the device
+        (qbh_csr_reference_order; kind 0 = spin-1/2 basis of csr_mat.heisenberg, 1 = electron basis of csr_mat.hubbard;
+        src/basis.cc:1144-1190, src/model.cc:665-670).  Needs complex128 values (value_dict = 0)."""
+        h = C.c_void_p()
+        o = opts if opts is not None else make_opts(value_dict=0, real_fast_path=0)
+        check(lib().qbh_csr_reference_order(C.byref(h), self.handle, int(kind), int(n_sites), int(n_up), int(n_dn), C.byref(o)),
+              "qbh_csr_reference_order")
+        return csr_mat(self.dim, None, None, None, _handle=h)
+
     def download(self, r0=0, r1=None, values=True):
         """Copy rows [r0, r1) of the device CSR back (tests / CPU-baseline sample)."""
         r1 = self.dim if r1 is None else r1

@@ -1,0 +1,97 @@
+"""qbh_csr_reference_order: a device-generated operator permuted ON THE DEVICE into the reference's Lin order and fermion
+convention (src/basis.cc:1144-1190, src/model.cc:665-670, src/basis.cc:2650-2664) must be, entry by entry, the matrix the
+numpy re-derivation of the reference's host pipeline (tests/refham.py, pinned by the survey's index checksums of the
+reference's own matrices) assembles -- and must have the spectrum of the operator it came from."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import quantum_basis_amd as q
+from quantum_basis_amd import lattices
+
+import refham
+
+pytestmark = pytest.mark.gpu
+PLAIN = dict(value_dict=0, real_fast_path=0)
+
+
+class _Full:
+    """Both triangles of a Hermitian-upper CSR, every stored entry kept (the reference stores the diagonal even when it is
+    zero, src/sparse.cc:45-54; a scipy sum would drop those)."""
+
+    def __init__(self, dim, ia, ja, val):
+        rows = np.repeat(np.arange(dim, dtype=np.int64), np.diff(ia))
+        off = ja > rows
+        r = np.concatenate([rows, ja[off]])
+        c = np.concatenate([ja, rows[off]])
+        v = np.concatenate([val, np.conj(val[off])])
+        order = np.lexsort((c, r))
+        self.indices, self.data = c[order], v[order]
+        self.indptr = np.zeros(dim + 1, dtype=np.int64)
+        np.cumsum(np.bincount(r, minlength=dim), out=self.indptr[1:])
+        self.nnz = len(self.indices)
+
+
+def _full(dim, ia, ja, val):
+    return _Full(dim, ia, ja, val)
+
+
+@pytest.mark.parametrize("ly", [2, 3])
+def test_hubbard_in_reference_order_entry_by_entry(ly):
+    n = 4 * ly
+    G = q.csr_mat.hubbard(n, n // 2, n // 2, lattices.square(4, ly), t=1.0, U=1.1, opts=q.make_opts(**PLAIN))
+    R = G.reference_order(1, n, n // 2, n // 2)
+    dim, ia, ja, val, _ = refham.hubbard_csr(4, ly, n // 2, n // 2, t=1.0, U=1.1)
+    F = _full(dim, ia, ja, val)
+    ria, rja, rval = R.download()
+    assert R.dim == dim and ria[-1] == F.nnz
+    assert np.array_equal(ria, F.indptr) and np.array_equal(rja, F.indices)          # pattern and column order exactly
+    assert np.abs(rval - F.data).max() < 1e-13
+    if ly == 2:          # the survey's checksums of the reference's own matrix, on the upper triangle
+        rows = np.repeat(np.arange(dim), np.diff(ria))
+        keep = rja >= rows
+        uia = np.zeros(dim + 1, dtype=np.int64)
+        np.cumsum(np.bincount(rows[keep], minlength=dim), out=uia[1:])
+        cs = refham.csr_checksums(uia, rja[keep].astype(np.int64), rval[keep])
+        assert cs["sum_ia"] == 104757230 and cs["sum_ja_w"] == 419558689
+    e_g = q.locate_E0_lanczos(G).E0
+    e_r = q.locate_E0_lanczos(R).E0
+    assert abs(e_g - e_r) < 1e-11 * abs(e_g)
+    G.destroy()
+    R.destroy()
+
+
+def test_heisenberg_in_reference_order_entry_by_entry():
+    L = 16
+    G = q.csr_mat.heisenberg(L, L // 2, lattices.chain(L), J=1.0, opts=q.make_opts(**PLAIN))
+    R = G.reference_order(0, L, 0, L // 2)
+    dim, ia, ja, val, _ = refham.heisenberg_csr(L, refham.chain_bonds(L), J=1.0, n_dn=L // 2)
+    F = _full(dim, ia, ja, val)
+    ria, rja, rval = R.download()
+    assert np.array_equal(ria, F.indptr) and np.array_equal(rja, F.indices) and np.abs(rval - F.data).max() < 1e-14
+    rows = np.repeat(np.arange(dim), np.diff(ria))
+    keep = rja >= rows
+    uia = np.zeros(dim + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows[keep], minlength=dim), out=uia[1:])
+    cs = refham.csr_checksums(uia, rja[keep].astype(np.int64), rval[keep])
+    assert (cs["sum_ia"], cs["sum_ja_w"]) == (483762205, 1934832532)
+    # the survey's y = Hx on vec_randomize(1) in the reference order
+    x = R.vec(2)
+    R.randomize(x.at(0), 1)
+    R.spmv(x.at(0), x.at(dim), 1.0, 0.0, 0.0)
+    y = x.download(dim, 3)
+    assert np.allclose(y.real, [0.067126123683761876, 0.030954161484316456, -0.00367655572169668], atol=1e-14)
+    x.free()
+    G.destroy()
+    R.destroy()
+
+
+def test_reference_order_refuses_what_it_cannot_do():
+    G = q.csr_mat.heisenberg(12, 6, lattices.chain(12), J=1.0)            # default options: dictionary-coded values
+    with pytest.raises(q._lib.QbhError):
+        G.reference_order(0, 12, 0, 6)
+    G.destroy()
+    G = q.csr_mat.heisenberg(12, 6, lattices.chain(12), J=1.0, opts=q.make_opts(**PLAIN))
+    with pytest.raises(q._lib.QbhError):
+        G.reference_order(0, 14, 0, 7)                                   # another basis
+    G.destroy()
