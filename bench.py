@@ -263,11 +263,48 @@ def cpu_baseline(A, dim, budget_rows, W, q, stream):
                           "call": "mkl_sparse_z_mv, GENERAL descriptor, full storage, no mkl_sparse_optimize (src/sparse.cc:262-289)"}
     except Exception as e:
         out["mkl"] = {"error": repr(e)}
+    try:        # the reference's DEFAULT storage at headline scale: mkl_sparse_z_mv with the HERMITIAN-upper descriptor
+        from oracle import mkl_ref
+        if mkl_ref.load() is not None:
+            out["mkl_hermitian_upper"] = _mkl_hermitian_block(A, dim, budget_rows, qo, mkl_ref)
+    except Exception as e:
+        out["mkl_hermitian_upper"] = {"error": repr(e)}
     try:
         out["midsize"] = cpu_midsize_full_run(W, q, stream)
     except Exception as e:
         out["midsize"] = {"error": repr(e)}
     return out
+
+
+def _mkl_hermitian_block(A, dim, budget_rows, qo, mkl_ref):
+    """mkl_sparse_z_mv with descr {HERMITIAN, UPPER, NON_UNIT} -- the reference's default call (src/sparse.cc:269-285) -- on a
+    SQUARE sample of the headline operator: the principal block of `budget_rows` consecutive rows in the middle of the
+    operator (entries whose column leaves the block are dropped, the upper triangle of the rest is what the reference would
+    store).  Scaled to the whole operator by the nonzeros the block represents: full-storage nnz of the operator / full-storage
+    nnz of the block."""
+    Rb = int(min(dim, budget_rows))
+    r0 = int((dim - Rb) // 2)
+    ia, ja, val = A.download(r0, r0 + Rb)
+    rows = np.repeat(np.arange(Rb, dtype=np.int64), np.diff(ia))
+    c = ja.astype(np.int64) - r0
+    inside = (c >= 0) & (c < Rb)
+    nnz_block_full = int(inside.sum())
+    keep = inside & (c >= rows)
+    uia = np.zeros(Rb + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows[keep], minlength=Rb), out=uia[1:])
+    uia, uja, uval = qo.first_touch(uia), qo.first_touch(c[keep]), qo.first_touch(val[keep])
+    M = mkl_ref.MklCsr(Rb, uia, uja, uval, True)
+    x = qo.first_touch(qo.vec_randomize(Rb, 1))
+    y = qo.first_touch(np.zeros(Rb, dtype=np.complex128))
+    tm, nm = _time_loop(lambda: M.multmv2(x, y), 3, 3.0, 30)
+    nnz_full = int(A.info().nnz)
+    scale = nnz_full / max(nnz_block_full, 1)
+    b_alg = nnz_block_full * 20 + (Rb + 1) * 8 + Rb * 32
+    return {"spmv_ms_scaled": round(1e3 * tm * scale, 3), "spmv_GBps": round(b_alg / tm / 1e9, 3), "threads": M.threads(),
+            "sample": "principal block of %d rows [%d, %d): %d of its %d full-storage nonzeros stay inside the block, %d stored "
+                      "(upper triangle); %d timed passes; scaled by nnz_full(operator) / nnz_full(block) = %.1f"
+                      % (Rb, r0, r0 + Rb, nnz_block_full, int(ia[-1]), int(uia[-1]), nm, scale),
+            "call": "mkl_sparse_z_mv, descr {HERMITIAN, UPPER, NON_UNIT}, int64 indices: the reference default (src/sparse.cc:269-285)"}
 
 
 def cpu_midsize_full_run(W, q, stream):
@@ -573,7 +610,8 @@ def main():
         vec_b = 8 if real_used else 16
         fmt_bytes = info.nnz * (4 + (code_w if coded else 16)) + (info.nrows + 1) * 8 + info.nrows * 2 * vec_b
         roof = {"bound": "hbm", "kernel": KERNEL_NAME[info.kernel], "achieved": round(fmt_bytes / ms_spmv / 1e6, 2), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(fmt_bytes / ms_spmv / 1e6 / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                "unit": "GB/s", "frac": round(fmt_bytes / ms_spmv / 1e6 / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_ratio": (round(traffic / fmt_bytes, 3) if traffic else None), "traffic_source": tsrc,
                 "bytes_per_launch": fmt_bytes, "ms_per_launch": round(ms_spmv, 4), "launches": head["n_spmv"],
                 "bytes_definition": "this format's bytes: nnz*(4 + %d) + (rows+1)*8 + rows*%d" % (code_w if coded else 16, 2 * vec_b),
                 "survey_8d_bytes_per_launch": bytes_launch, "survey_8d_equivalent_GBps": round(achieved, 2)}
@@ -581,7 +619,7 @@ def main():
                 "complex128 vectors, %d-byte value codes" % code_w
     else:
         roof = {"bound": "hbm", "kernel": KERNEL_NAME[info.kernel], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_ratio": (round(traffic / bytes_launch, 3) if traffic else None), "traffic_source": tsrc,
                 "bytes_per_launch": bytes_launch, "ms_per_launch": round(ms_spmv, 4), "launches": head["n_spmv"],
                 "bytes_definition": "SURVEY 8(d) algorithmic bytes: nnz*(16+4) + (rows+1)*8 + rows*16 (x once) + rows*16 (y once)",
                 "note": "traffic (HBM bytes per launch from separate rocprofv3 --pmc passes, NOT measured in this run; see traffic_source) "
@@ -616,11 +654,25 @@ def main():
     if packed_real:
         out["dtype"] = "f64 (real operator, Lanczos vectors stored as packed doubles)"
         out["config"]["vectors"] = "2 x %.1f GB packed doubles (qbh_lanczos_real_dev)" % (dim * 8e-9)
-    if args.matrix_free:
+    if args.matrix_free or W["kind"].endswith("_mf"):
+        # A matrix-free operator streams no matrix: its algorithmic bytes are the VECTORS of y <- a H x + b y (x read once,
+        # old y read once, new y written once) -- never the bytes a CSR of the operator would move.
+        vb = 8 if (real_used or packed_real) else 16
+        vec_bytes = int(info.nrows) * vb * 3
+        mf_key = "%s|matrix_free|plain" % args.workload + ("|real" if vb == 8 else "")
+        mtr, msrc = traffic_of(mf_key) if world == 1 else (None, None)
         out["config"]["kernel"] = "matrix_free"
-        out["roofline"]["kernel"] = {"hubbard": "k_mf_hubbard", "hubbard_repr_mf": "k_mf_sector"}.get(W["kind"], "k_mf_heis")
-        out["roofline"]["note"] = ("MATRIX-FREE operator (qbh_mf_hubbard / qbh_mf_heisenberg, SURVEY 8f-1): no CSR is stored; achieved = bytes the CSR of the "
-                                   "same operator would move per SpMV / kernel time -- not the north-star CSR measurement")
+        out["roofline"] = {"bound": "hbm", "kernel": {"hubbard": "k_mf_hubbard", "hubbard_repr_mf": "k_mf_sector"}.get(W["kind"], "k_mf_heis"),
+                           "achieved": round(vec_bytes / ms_spmv / 1e6, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": round(vec_bytes / ms_spmv / 1e6 / HBM_PEAK_GBPS, 4), "traffic": mtr,
+                           "traffic_ratio": (round(mtr / vec_bytes, 2) if mtr else None), "traffic_source": msrc,
+                           "bytes_per_launch": vec_bytes, "ms_per_launch": round(ms_spmv, 4), "launches": head["n_spmv"],
+                           "bytes_definition": "matrix-free operator: vectors only, rows * %d B * 3 (x once, old y once, new y once); "
+                                               "the hop / block tables are a few MB" % vb,
+                           "csr_equivalent_GBps": round(achieved, 2),
+                           "note": "MATRIX-FREE operator (SURVEY 8f-1): no CSR is stored.  frac is on the vector bytes; the traffic "
+                                   "ratio says how far the gathers are from touching every vector line once.  csr_equivalent_GBps "
+                                   "(bytes a CSR of the same operator would move / kernel time) is informational, not a roofline"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.matrix_free:
         try:
             out["cpu_baseline"] = cpu_baseline(A, dim, args.cpu_rows, W, q, stream)

@@ -326,13 +326,20 @@ extern "C" int qbh_lanczos_ckpt(const qbh_csr *A, int64_t maxit, int64_t *m_out,
     info.theta1_prev = t1;
     int64_t m = k, done = 0;
     bool conv = false;
+    // per-iteration log rows (src/lanczos.cc:102-128) of all chunks, in the caller's buffer
+    qbh_lanczos_row *log_base = info_out ? info_out->log : nullptr;
+    const int64_t log_cap = info_out ? info_out->log_cap : 0;
+    int64_t log_total = 0;
     while (rc == QBH_OK && m < maxit - 1) {
         int64_t np = std::min<int64_t>(every, maxit - 1 - m);
         if (max_steps > 0) np = std::min<int64_t>(np, max_steps - done);
         if (np <= 0) break;
         int64_t m_new = m;
+        info.log = (log_base && log_total < log_cap) ? log_base + log_total : nullptr;
+        info.log_cap = info.log ? log_cap - log_total : 0;
         rc = qbh_lanczos_dev(A, m, np, maxit, &m_new, d_v, hessenberg, purpose, &info);
         if (rc != QBH_OK) break;
+        log_total += info.log ? std::min<int64_t>(info.log_len, info.log_cap) : 0;
         info.resume = 1;                            // the bookkeeping returned in info seeds the next chunk
         done += m_new - m;
         const bool early = m_new < m + np;
@@ -350,6 +357,11 @@ extern "C" int qbh_lanczos_ckpt(const qbh_csr *A, int64_t maxit, int64_t *m_out,
     if (rc != QBH_OK) return rc;
     *m_out = m;
     if (converged) *converged = conv ? 1 : 0;
-    if (info_out) *info_out = info;
+    if (info_out) {
+        *info_out = info;
+        info_out->log = log_base;
+        info_out->log_cap = log_cap;
+        info_out->log_len = log_total;
+    }
     return QBH_OK;
 }
