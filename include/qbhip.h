@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QBH_VERSION 210
+#define QBH_VERSION 300
 
 /* error codes */
 #define QBH_OK          0
@@ -414,6 +414,14 @@ int qbh_mf_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bonds,
 int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int n_bonds, const int32_t *bonds, double J,
                             int n_trans, const int32_t *perms, const double *chars, double fake_pos,
                             int shard, int n_shards, int64_t *dim_out, const qbh_opts *opts);
+/* The same with the caller's row cuts, row_cuts[n_shards + 1] rising from 0 to the sector dimension (ragged allowed; the
+ * same array goes to qbh_comm.row_cuts / qbh_comm_create_rccl): shard q holds rows [row_cuts[q], row_cuts[q+1]).  Uniform
+ * blocks of a momentum sector are unbalanced in work (4x5 half filling, 4 ranks: 63 to 98 ms per SpMV at +-5 % nonzeros):
+ * time one SpMV per rank on uniform cuts, pass the times to quantum_basis_amd.dist.rebalance_cuts and generate again.
+ * A first call with row_cuts = NULL (uniform) and dim_out returns the dimension the cuts have to add up to. */
+int qbh_gen_heisenberg_repr_cuts(qbh_csr **out, int n_sites, int n_dn, int n_bonds, const int32_t *bonds, double J,
+                                 int n_trans, const int32_t *perms, const double *chars, double fake_pos,
+                                 int shard, int n_shards, const int64_t *row_cuts, int64_t *dim_out, const qbh_opts *opts);
 
 /* The Hubbard family in a translation-symmetric (momentum) sector, assembled on the device: counterpart of
  * model::enumerate_basis_repr + generate_Ham_sparse_repr (src/model.cc:687-836) for two-species fermions, the path of
@@ -435,6 +443,12 @@ int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_t
                          const double *pair_v, int n_exch, const int32_t *exch_sites, const double *exch_amp, int no_double,
                          int n_trans, const int32_t *perms, const double *chars, double fake_pos,
                          int shard, int n_shards, int64_t *dim_out, const qbh_opts *opts);
+/* ... with the caller's row cuts (see qbh_gen_heisenberg_repr_cuts) */
+int qbh_gen_hubbard_repr_cuts(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_terms, const int32_t *term_sites,
+                              const qbh_z *amp_up, const qbh_z *amp_dn, double U, int n_pairs, const int32_t *pair_sites,
+                              const double *pair_v, int n_exch, const int32_t *exch_sites, const double *exch_amp, int no_double,
+                              int n_trans, const int32_t *perms, const double *chars, double fake_pos,
+                              int shard, int n_shards, const int64_t *row_cuts, int64_t *dim_out, const qbh_opts *opts);
 
 /* The same sector operator in MATRIX-FREE form with a small stored remainder (single GPU; no spin-exchange terms, real
  * up-species and number-operator amplitudes).  Representatives are ordered by the down pattern first: in a down block whose

@@ -86,7 +86,7 @@ EXPORTS = [
     "qbh_mopr_spin_dev", "qbh_mopr_onebody_dev", "qbh_mopr_sz_repr_dev", "qbh_mopr_flip_repr_dev",
     "qbh_crc32", "qbh_vec_disk_write", "qbh_vec_disk_read", "qbh_ckpt_lanczos_update", "qbh_ckpt_lanczos_init", "qbh_lanczos_ckpt",
     "qbh_csr_set_comm", "qbh_rccl_unique_id", "qbh_comm_create_rccl", "qbh_comm_destroy", "qbh_get_stats", "qbh_sync",
-    "qbh_gen_hubbard", "qbh_mf_hubbard", "qbh_gen_heisenberg", "qbh_mf_heisenberg", "qbh_gen_heisenberg_repr", "qbh_gen_hubbard_repr", "qbh_mf_hubbard_repr", "qbh_mopr_diag_hubrepr_dev", "qbh_mopr_c_hubrepr_dev", "qbh_csr_download", "qbh_csr_reference_order",
+    "qbh_gen_hubbard", "qbh_mf_hubbard", "qbh_gen_heisenberg", "qbh_mf_heisenberg", "qbh_gen_heisenberg_repr", "qbh_gen_hubbard_repr", "qbh_gen_heisenberg_repr_cuts", "qbh_gen_hubbard_repr_cuts", "qbh_mf_hubbard_repr", "qbh_mopr_diag_hubrepr_dev", "qbh_mopr_c_hubrepr_dev", "qbh_csr_download", "qbh_csr_reference_order",
 ]
 
 _lib = None
@@ -180,6 +180,11 @@ def lib():
     L.qbh_gen_hubbard_repr.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, dbl, C.c_int, vp, vp,
                                        C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, dbl, C.c_int, C.c_int, C.POINTER(i64),
                                        C.POINTER(Opts)]
+    L.qbh_gen_heisenberg_repr_cuts.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp, dbl, C.c_int, vp, vp, dbl,
+                                               C.c_int, C.c_int, vp, C.POINTER(i64), C.POINTER(Opts)]
+    L.qbh_gen_hubbard_repr_cuts.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, dbl, C.c_int, vp, vp,
+                                            C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, dbl, C.c_int, C.c_int, vp, C.POINTER(i64),
+                                            C.POINTER(Opts)]
     L.qbh_mf_hubbard_repr.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, dbl, C.c_int, vp, vp,
                                       C.c_int, vp, vp, dbl, C.POINTER(i64), C.POINTER(Opts)]
     L.qbh_mopr_diag_hubrepr_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]

@@ -1000,9 +1000,29 @@ __global__ __launch_bounds__(128) void k_repr_fill_coded(const ReprDev *Rp, cons
 }  // namespace
 }  // namespace qbh
 
-extern "C" int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int n_bonds, const int32_t *bonds, double J,
+// row range of shard `shard`: the uniform partition of qbh_comm, or the caller's cuts (nnz- or cost-balanced)
+static int sector_row_range(const char *who, int64_t dim, int shard, int n_shards, const int64_t *row_cuts, int64_t *r0, int64_t *r1)
+{
+    if (row_cuts) {
+        bool ok = row_cuts[0] == 0 && row_cuts[n_shards] == dim;
+        for (int q = 0; q < n_shards && ok; ++q) ok = row_cuts[q + 1] >= row_cuts[q];
+        if (!ok) {
+            qbh::set_error("%s: row_cuts must rise from 0 to the sector dimension %lld", who, (long long)dim);
+            return QBH_EINVAL;
+        }
+        *r0 = row_cuts[shard];
+        *r1 = row_cuts[shard + 1];
+    } else {
+        const int64_t nblk = (dim + n_shards - 1) / n_shards;
+        *r0 = std::min<int64_t>((int64_t)shard * nblk, dim);
+        *r1 = std::min<int64_t>(*r0 + nblk, dim);
+    }
+    return QBH_OK;
+}
+
+static int gen_heisenberg_repr_impl(qbh_csr **out, int n_sites, int n_dn, int n_bonds, const int32_t *bonds, double J,
                                        int n_trans, const int32_t *perms, const double *chars, double fake_pos,
-                                       int shard, int n_shards, int64_t *dim_out, const qbh_opts *opts)
+                                       int shard, int n_shards, const int64_t *row_cuts, int64_t *dim_out, const qbh_opts *opts)
 {
     using namespace qbh;
     if (!out || !bonds || !perms || !chars || n_sites <= 0 || n_sites > 62 || n_dn < 0 || n_dn > n_sites || n_dn > 33 ||
@@ -1137,8 +1157,12 @@ extern "C" int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int
     (void)hipFree(d_cnt); d_cnt = nullptr;
     (void)hipFree(d_pos); d_pos = nullptr;
     // 2. this shard's rows: lengths (+ the distinct values) -> row pointers -> fill
-    const int64_t nblk = (dim + n_shards - 1) / n_shards;          // same uniform partition as the communicator's
-    const int64_t r0 = std::min<int64_t>((int64_t)shard * nblk, dim), r1 = std::min<int64_t>(r0 + nblk, dim);
+    int64_t r0 = 0, r1 = 0;
+    rc = sector_row_range("qbh_gen_heisenberg_repr", dim, shard, n_shards, row_cuts, &r0, &r1);
+    if (rc != QBH_OK) {
+        cleanup(true);
+        return rc;
+    }
     const int64_t nloc = r1 - r0;
     if (nloc <= 0) {
         set_error("qbh_gen_heisenberg_repr: shard %d of %d is empty (dim %lld)", shard, n_shards, (long long)dim);
@@ -1817,11 +1841,11 @@ __global__ __launch_bounds__(128) void k_hubrepr_fill_coded(const HubReprDev *Rp
 }  // namespace
 }  // namespace qbh
 
-extern "C" int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_terms, const int32_t *term_sites,
+static int gen_hubbard_repr_impl(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_terms, const int32_t *term_sites,
                                     const qbh_z *amp_up, const qbh_z *amp_dn, double U, int n_pairs, const int32_t *pair_sites,
                                     const double *pair_v, int n_exch, const int32_t *exch_sites, const double *exch_amp,
                                     int no_double, int n_trans, const int32_t *perms, const double *chars, double fake_pos,
-                                    int shard, int n_shards, int64_t *dim_out, const qbh_opts *opts)
+                                    int shard, int n_shards, const int64_t *row_cuts, int64_t *dim_out, const qbh_opts *opts)
 {
     using namespace qbh;
     if (n_exch < 0 || n_exch > kHubReprMaxPairs || (n_exch > 0 && (!exch_sites || !exch_amp))) {
@@ -2004,8 +2028,12 @@ extern "C" int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_
     (void)hipFree(d_cnt); d_cnt = nullptr;
     (void)hipFree(d_pos); d_pos = nullptr;
     // 2. this shard's rows: lengths (+ the distinct values) -> row pointers -> fill
-    const int64_t nblk = (dim + n_shards - 1) / n_shards;
-    const int64_t r0 = std::min<int64_t>((int64_t)shard * nblk, dim), r1 = std::min<int64_t>(r0 + nblk, dim);
+    int64_t r0 = 0, r1 = 0;
+    rc = sector_row_range("qbh_gen_hubbard_repr", dim, shard, n_shards, row_cuts, &r0, &r1);
+    if (rc != QBH_OK) {
+        cleanup(true);
+        return rc;
+    }
     const int64_t nloc = r1 - r0;
     if (nloc <= 0) {
         set_error("qbh_gen_hubbard_repr: shard %d of %d is empty (dim %lld)", shard, n_shards, (long long)dim);
@@ -3132,4 +3160,38 @@ extern "C" int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_d
     }
     if (dim_out) *dim_out = dim;
     return QBH_OK;
+}
+
+// ---- public entry points of the sector generators: uniform row blocks, or the caller's row cuts ----
+extern "C" int qbh_gen_heisenberg_repr(qbh_csr **out, int n_sites, int n_dn, int n_bonds, const int32_t *bonds, double J,
+                                       int n_trans, const int32_t *perms, const double *chars, double fake_pos,
+                                       int shard, int n_shards, int64_t *dim_out, const qbh_opts *opts)
+{
+    return gen_heisenberg_repr_impl(out, n_sites, n_dn, n_bonds, bonds, J, n_trans, perms, chars, fake_pos, shard, n_shards, nullptr,
+                                    dim_out, opts);
+}
+extern "C" int qbh_gen_heisenberg_repr_cuts(qbh_csr **out, int n_sites, int n_dn, int n_bonds, const int32_t *bonds, double J,
+                                            int n_trans, const int32_t *perms, const double *chars, double fake_pos,
+                                            int shard, int n_shards, const int64_t *row_cuts, int64_t *dim_out, const qbh_opts *opts)
+{
+    return gen_heisenberg_repr_impl(out, n_sites, n_dn, n_bonds, bonds, J, n_trans, perms, chars, fake_pos, shard, n_shards, row_cuts,
+                                    dim_out, opts);
+}
+extern "C" int qbh_gen_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_terms, const int32_t *term_sites,
+                                    const qbh_z *amp_up, const qbh_z *amp_dn, double U, int n_pairs, const int32_t *pair_sites,
+                                    const double *pair_v, int n_exch, const int32_t *exch_sites, const double *exch_amp,
+                                    int no_double, int n_trans, const int32_t *perms, const double *chars, double fake_pos,
+                                    int shard, int n_shards, int64_t *dim_out, const qbh_opts *opts)
+{
+    return gen_hubbard_repr_impl(out, n_sites, n_up, n_dn, n_terms, term_sites, amp_up, amp_dn, U, n_pairs, pair_sites, pair_v, n_exch,
+                                 exch_sites, exch_amp, no_double, n_trans, perms, chars, fake_pos, shard, n_shards, nullptr, dim_out, opts);
+}
+extern "C" int qbh_gen_hubbard_repr_cuts(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_terms, const int32_t *term_sites,
+                                         const qbh_z *amp_up, const qbh_z *amp_dn, double U, int n_pairs, const int32_t *pair_sites,
+                                         const double *pair_v, int n_exch, const int32_t *exch_sites, const double *exch_amp,
+                                         int no_double, int n_trans, const int32_t *perms, const double *chars, double fake_pos,
+                                         int shard, int n_shards, const int64_t *row_cuts, int64_t *dim_out, const qbh_opts *opts)
+{
+    return gen_hubbard_repr_impl(out, n_sites, n_up, n_dn, n_terms, term_sites, amp_up, amp_dn, U, n_pairs, pair_sites, pair_v, n_exch,
+                                 exch_sites, exch_amp, no_double, n_trans, perms, chars, fake_pos, shard, n_shards, row_cuts, dim_out, opts);
 }

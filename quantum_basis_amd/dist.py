@@ -13,6 +13,8 @@ torch is plumbing here: device buffers, stream ordering and the collectives.
 import ctypes as C
 import traceback
 
+import numpy as np
+
 from . import _lib
 from ._lib import check, lib
 
@@ -232,3 +234,23 @@ class ShardComm:
         check(lib().qbh_csr_set_comm(mat.handle, C.byref(c)), "qbh_csr_set_comm")
         mat._comm = self          # keep the callbacks and buffers alive as long as the operator
         return self
+
+
+def rebalance_cuts(cuts, cost):
+    """Row cuts that equalise a measured per-shard cost (e.g. ms per SpMV of each rank on the current cuts), assuming the
+    cost density is constant inside every current shard: cuts [0, ..., dim] (world + 1 entries), cost one number per shard.
+    Uniform row blocks of a momentum sector are unbalanced in work although their nonzero counts agree to a few per cent
+    (BASELINE configs[3], 4 ranks: 63 to 98 ms), so the balancing quantity is the measured time, not nnz.  One or two
+    rounds (generate, time, rebalance, generate with row_cuts=) bring the ranks together."""
+    cuts = np.asarray(cuts, dtype=np.int64)
+    cost = np.asarray(cost, dtype=np.float64)
+    world = cost.size
+    assert cuts.size == world + 1 and np.all(np.diff(cuts) > 0) and np.all(cost > 0)
+    cum = np.concatenate([[0.0], np.cumsum(cost)])             # cumulative cost at the current cuts
+    want = cum[-1] * np.arange(1, world) / world
+    new = np.interp(want, cum, cuts.astype(np.float64))        # piecewise-linear inverse of the cumulative cost
+    out = np.concatenate([[cuts[0]], np.round(new).astype(np.int64), [cuts[-1]]])
+    for q in range(1, world + 1):                              # strictly increasing
+        out[q] = max(out[q], out[q - 1] + 1)
+    out[-1] = cuts[-1]
+    return out

@@ -155,11 +155,12 @@ class csr_mat:
         return cls(0, None, None, None, opts=opts, _handle=h)
 
     @classmethod
-    def heisenberg_repr(cls, n_sites, n_dn, bonds, perms, chars, J=1.0, fake_pos=100.0, shard=(0, 1), opts=None):
+    def heisenberg_repr(cls, n_sites, n_dn, bonds, perms, chars, J=1.0, fake_pos=100.0, shard=(0, 1), opts=None, row_cuts=None):
         """Translation-symmetric sector assembled on the device (qbh_gen_heisenberg_repr, counterpart of
         model::generate_Ham_sparse_repr): perms[g] = site images under translation g (g = 0 identity), chars[g] =
         momentum character chi_k(g).  shard = (rank, world) selects a uniform row block of the sector (its dimension
-        is only known after enumeration: read it from .info().ncols)."""
+        is only known after enumeration: read it from .info().ncols); row_cuts = [0, ..., dim] (world + 1 entries) replaces
+        the uniform blocks by the caller's (qbh_gen_heisenberg_repr_cuts; see dist.rebalance_cuts)."""
         _lib.require_gpu()
         opts = opts if opts is not None else make_opts()
         b = np.ascontiguousarray(np.asarray(bonds, dtype=np.int32).reshape(-1, 2))
@@ -168,14 +169,17 @@ class csr_mat:
         assert p.shape == (len(c), n_sites)
         h = C.c_void_p()
         dim = C.c_int64(0)
-        check(lib().qbh_gen_heisenberg_repr(C.byref(h), n_sites, n_dn, len(b), _p(b), J, len(c), _p(p), _p(c), fake_pos,
-                                            int(shard[0]), int(shard[1]), C.byref(dim), C.byref(opts)),
+        cuts = None if row_cuts is None else np.ascontiguousarray(row_cuts, dtype=np.int64)
+        assert cuts is None or cuts.size == int(shard[1]) + 1
+        check(lib().qbh_gen_heisenberg_repr_cuts(C.byref(h), n_sites, n_dn, len(b), _p(b), J, len(c), _p(p), _p(c), fake_pos,
+                                                 int(shard[0]), int(shard[1]), _p(cuts) if cuts is not None else None,
+                                                 C.byref(dim), C.byref(opts)),
               "qbh_gen_heisenberg_repr")
         return cls(0, None, None, None, opts=opts, _handle=h)
 
     @classmethod
     def hubbard_repr(cls, n_sites, n_up, n_dn, bonds, perms, chars, t=1.0, U=1.1, fake_pos=100.0, shard=(0, 1), opts=None,
-                     terms=None, pairs=None, exchange=None, no_double=False):
+                     terms=None, pairs=None, exchange=None, no_double=False, row_cuts=None):
         """Hubbard family in a translation-symmetric sector, assembled on the device (qbh_gen_hubbard_repr; counterpart of
         model::enumerate_basis_repr + generate_Ham_sparse_repr for the reference's
         examples/trans_symmetric/latt_square/square_Fermi_Hubbard.cc).  Default operator: -t sum_<ij>,sigma (c+_i c_j + h.c.)
@@ -206,11 +210,14 @@ class csr_mat:
         assert p.shape == (len(c), n_sites)
         h = C.c_void_p()
         dim = C.c_int64(0)
-        check(lib().qbh_gen_hubbard_repr(C.byref(h), n_sites, n_up, n_dn, len(terms), _p(sites), _p(aup), _p(adn), float(U),
-                                         len(pairs), _p(psites) if pairs else None, _p(pv) if pairs else None,
-                                         len(exchange), _p(xs) if exchange else None, _p(xa) if exchange else None,
-                                         int(bool(no_double)), len(c),
-                                         _p(p), _p(c), fake_pos, int(shard[0]), int(shard[1]), C.byref(dim), C.byref(opts)),
+        cuts = None if row_cuts is None else np.ascontiguousarray(row_cuts, dtype=np.int64)      # see heisenberg_repr
+        assert cuts is None or cuts.size == int(shard[1]) + 1
+        check(lib().qbh_gen_hubbard_repr_cuts(C.byref(h), n_sites, n_up, n_dn, len(terms), _p(sites), _p(aup), _p(adn), float(U),
+                                              len(pairs), _p(psites) if pairs else None, _p(pv) if pairs else None,
+                                              len(exchange), _p(xs) if exchange else None, _p(xa) if exchange else None,
+                                              int(bool(no_double)), len(c),
+                                              _p(p), _p(c), fake_pos, int(shard[0]), int(shard[1]),
+                                              _p(cuts) if cuts is not None else None, C.byref(dim), C.byref(opts)),
               "qbh_gen_hubbard_repr")
         return cls(0, None, None, None, opts=opts, _handle=h)
 
