@@ -604,6 +604,8 @@ def main():
     real_used = head["n_real"] > 0
     code_w = 0 if not coded else (1 if info.value_dict <= 256 else 2)
     tkey = "%s|%s|%s" % (args.workload, KERNEL_KEY[info.kernel], "dict" if coded else "plain") + ("|real" if real_used else "")
+    if info.kron_minor:
+        tkey += "|kron"
     traffic, tsrc = traffic_of(tkey + ("|reforder" if args.order == "reference" else "")) if world == 1 and not args.host_csr else (None, None)
     if coded or real_used:
         # the kernel moves its own format's bytes, not SURVEY 8(d)'s: the fraction is defined on those (cannot exceed 1)
@@ -618,7 +620,8 @@ def main():
         dtype = "f64 real (1-byte value codes, packed-double vectors; bit-identical to complex128)" if real_used else \
                 "complex128 vectors, %d-byte value codes" % code_w
     else:
-        roof = {"bound": "hbm", "kernel": KERNEL_NAME[info.kernel], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        roof = {"bound": "hbm", "kernel": ("k_spmv_wave2 (Kronecker split: tile + far + near launches)" if info.kron_minor else KERNEL_NAME[info.kernel]),
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_ratio": (round(traffic / bytes_launch, 3) if traffic else None), "traffic_source": tsrc,
                 "bytes_per_launch": bytes_launch, "ms_per_launch": round(ms_spmv, 4), "launches": head["n_spmv"],
                 "bytes_definition": "SURVEY 8(d) algorithmic bytes: nnz*(16+4) + (rows+1)*8 + rows*16 (x once) + rows*16 (y once)",
@@ -635,6 +638,9 @@ def main():
                                          "kernel": KERNEL_KEY[info.kernel], "format": "complex128 CSR values + int32 columns, complex128 vectors"
                                          if not (coded or real_used) else "value codes %s, real fast path %s" % (coded, real_used),
                                          "value_dict": info.value_dict, "real_gather": real_used,
+                                         "kron_split": ({"minor": int(info.kron_minor), "band": int(info.kron_band), "far_nnz": int(info.kron_far_nnz),
+                                                         "launches_per_spmv": "k_kron_tile + k_spmv_wave2<.,0> (far) + k_spmv_wave2<.,2> (near)"}
+                                                        if info.kron_minor else None),
                                          "operator_source": "host CSR in reference order through qbh_csr_create" if args.host_csr else
                                          "device generator, permuted on the device into the reference's Lin order and fermion convention "
                                          "(qbh_csr_reference_order)" if args.order == "reference" else "device generator",

@@ -82,6 +82,13 @@ typedef struct qbh_opts {
     int     real_fast_path;  /* 1 (default): a real operator applied to vectors with exactly zero imaginary
                                 parts gathers / exchanges 8-byte real parts (bit-identical results);
                                 0: always the complex128 arithmetic of the reference (north-star format)   */
+    int     kron_split;      /* 1 (default): an unsharded complex128 operator on a product basis (index = major * S + minor,
+                                every entry changes one of the two: the two-species Hubbard family in the generator's order)
+                                is also kept as H_near + H_far with the far part band-major over the minor index (same values,
+                                same 20 B per nonzero; verified on the device, skipped when HBM cannot hold the second copy);
+                                0: never                                                                      */
+    int64_t kron_minor;      /* S for an operator created from host / device arrays (0: unknown -> no split); the generators
+                                announce their own                                                            */
 } qbh_opts;
 
 void qbh_opts_default(qbh_opts *o);
@@ -136,6 +143,9 @@ typedef struct qbh_csr_info {
     double  create_ms;                       /* wall ms of qbh_csr_create(_rows): validation + upload + expansion +
                                                 geometry (0 for device-built operators)                          */
     int64_t create_bytes_in;                 /* host bytes that call read: nnz*24 + (dim+1)*8                     */
+    int64_t kron_minor;                      /* Kronecker split active (qbh_opts.kron_split): minor size S, else 0  */
+    int64_t kron_far_nnz;                    /* nonzeros of the far part (band-major)                               */
+    int     kron_band;                       /* band width of the tiling                                            */
 } qbh_csr_info;
 int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info);
 

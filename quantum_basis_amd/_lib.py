@@ -31,7 +31,8 @@ class Z(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("spmv_kernel", C.c_int),
                 ("nnz_per_block", C.c_int), ("xcd_swizzle", C.c_int), ("value_dict", C.c_int),
-                ("profile", C.c_int), ("check_hermitian", C.c_int), ("real_fast_path", C.c_int)]
+                ("profile", C.c_int), ("check_hermitian", C.c_int), ("real_fast_path", C.c_int),
+                ("kron_split", C.c_int), ("kron_minor", C.c_int64)]
 
 
 class CsrInfo(C.Structure):
@@ -39,7 +40,7 @@ class CsrInfo(C.Structure):
                 ("nnz", C.c_int64), ("n_blocks", C.c_int64), ("bytes_matrix", C.c_int64),
                 ("bytes_algorithmic", C.c_int64), ("kernel", C.c_int), ("value_dict", C.c_int),
                 ("device", C.c_int), ("stream", C.c_void_p), ("create_ms", C.c_double),
-                ("create_bytes_in", C.c_int64)]
+                ("create_bytes_in", C.c_int64), ("kron_minor", C.c_int64), ("kron_far_nnz", C.c_int64), ("kron_band", C.c_int)]
 
 
 class LanczosRow(C.Structure):

@@ -72,6 +72,8 @@ extern "C" void qbh_opts_default(qbh_opts *o)
     o->profile = 0;
     o->check_hermitian = 1;
     o->real_fast_path = 1;
+    o->kron_split = 1;
+    o->kron_minor = 0;
 }
 
 // ------------------------------------------------------------ operator ---------
@@ -296,6 +298,133 @@ int split_shard(qbh_csr *A)
     return QBH_OK;
 }
 
+
+// ---------------------------------------------------------------------------------- Kronecker split ----
+void kron_release(qbh_csr *A)
+{
+    qbh_csr::KronSplit &K = A->kron;
+    for (void *q : {(void *)K.ia_n, (void *)K.ia_f, (void *)K.ja_n, (void *)K.ja_f, (void *)K.val_n, (void *)K.val_f, (void *)K.wd_n,
+                    (void *)K.wd_f, (void *)K.d_xt, (void *)K.d_far})
+        if (q) (void)hipFree(q);
+    K = qbh_csr::KronSplit{};
+}
+
+// H = H_near + H_far for an operator on a product basis (index = major * S + minor) whose entries change either the
+// minor index (near: inside the row's own block of S columns, an L2-sized window of x) or the major index alone (far:
+// same minor index).  The far part is what makes a row-major sweep re-read x: every major index pulls in the x rows of
+// all its neighbours (C3: 17 x 2.65 GB per SpMV).  Stored band-major over the minor index -- rows and columns in the
+// tiled order of KronTile -- a band of 8 minor indices needs ONE 128-byte line per major index, and 8 consecutive far
+// rows share every line they gather.  Per SpMV: x -> tiled copy, far pass (row sums, tiled order), near pass (+ far
+// result, fused epilogue).  Same values, same columns, same 20 B per nonzero: an acceleration structure beside the CSR
+// the handle keeps for qbh_csr_download / qbh_csr_set_comm; skipped when HBM cannot hold both.
+int kron_build(qbh_csr *A)
+{
+    kron_release(A);
+    if (!A->use_wave || A->kind != 0 || A->has_rem || A->nrows != A->ncols || A->row_offset != 0 || A->nnz <= 0) return QBH_OK;
+    if (A->opts.kron_split == 0) return QBH_OK;
+    if (const char *e = getenv("QBH_NO_KRON")) {
+        if (atoi(e)) return QBH_OK;
+    }
+    const int64_t S = A->opts.kron_minor;
+    if (S <= 1 || S >= A->nrows || A->nrows % S != 0) return QBH_OK;
+    const int64_t NU = A->nrows / S;
+    hipStream_t s = A->stream;
+    {   // second copy of the matrix + two vectors + descriptors
+        size_t free_b = 0, total_b = 0;
+        const size_t need = (size_t)A->nnz * 20 + (size_t)A->nrows * (16 + 16 + 16 + 8) + ((size_t)2 << 30);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < need) return QBH_OK;
+    }
+    // the structure is verified, never assumed: one entry that changes both indices and the operator stays unsplit
+    QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
+    QBH_TRY(qbh::launch_kron_check(A->d_ia, A->d_ja, A->nrows, S, A->d_flag, s));
+    int bad = 0;
+    QBH_HIP(hipMemcpyAsync(&bad, A->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    QBH_HIP(hipStreamSynchronize(s));
+    QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
+    if (bad) return QBH_OK;
+    qbh_csr::KronSplit &K = A->kron;
+    int B = 8;                                       // one 128-byte line of complex128 per (band, major index)
+    while (B > 2 && (double)NU * B * 16 > 2.5e6) B >>= 1;              // keep a band of x inside an XCD's L2
+    if (const char *e = getenv("QBH_KRON_BAND")) {
+        const int b = atoi(e);
+        if (b == 2 || b == 4 || b == 8 || b == 16) B = b;
+    }
+    K.t = qbh::KronTile{S, NU, B};
+    int32_t *cn = nullptr, *cf = nullptr;
+    auto fail = [&](int code) {
+        if (cn) (void)hipFree(cn);
+        if (cf) (void)hipFree(cf);
+        kron_release(A);
+        return code;
+    };
+#define KRON_HIP(call)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) {                                                                          \
+            (void)hipGetLastError();                                                                     \
+            return fail(e_ == hipErrorOutOfMemory ? QBH_OK : QBH_EHIP); /* out of memory: stay unsplit */ \
+        }                                                                                                \
+    } while (0)
+#define KRON_TRY(expr)                         \
+    do {                                       \
+        const int rc_ = (expr);                \
+        if (rc_ != QBH_OK) return fail(rc_);   \
+    } while (0)
+    const int64_t n = A->nrows;
+    KRON_HIP(hipMalloc(&cn, (size_t)n * sizeof(int32_t)));
+    KRON_HIP(hipMalloc(&cf, (size_t)n * sizeof(int32_t)));
+    KRON_TRY(qbh::launch_kron_count(A->d_ia, A->d_ja, n, K.t, cn, cf, s));
+    KRON_HIP(hipMalloc(&K.ia_n, (size_t)(n + 1) * sizeof(int64_t)));
+    KRON_HIP(hipMalloc(&K.ia_f, (size_t)(n + 1) * sizeof(int64_t)));
+    KRON_TRY(qbh::exclusive_scan(cn, n, K.ia_n, s));
+    KRON_TRY(qbh::exclusive_scan(cf, n, K.ia_f, s));
+    (void)hipFree(cn);
+    cn = nullptr;
+    (void)hipFree(cf);
+    cf = nullptr;
+    KRON_HIP(hipMemcpy(&K.nnz_n, K.ia_n + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+    KRON_HIP(hipMemcpy(&K.nnz_f, K.ia_f + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (K.nnz_f == 0 || K.nnz_n + K.nnz_f != A->nnz) return fail(QBH_OK);       // nothing far: the split buys nothing
+    KRON_HIP(hipMalloc(&K.ja_n, std::max<size_t>((size_t)K.nnz_n, 1) * sizeof(int32_t)));
+    KRON_HIP(hipMalloc(&K.ja_f, (size_t)K.nnz_f * sizeof(int32_t)));
+    KRON_HIP(hipMalloc(&K.val_n, std::max<size_t>((size_t)K.nnz_n, 1) * sizeof(d2)));
+    KRON_HIP(hipMalloc(&K.val_f, (size_t)K.nnz_f * sizeof(d2)));
+    KRON_TRY(qbh::launch_kron_fill(A->d_ia, A->d_ja, A->d_val, n, K.t, K.ia_n, K.ja_n, K.val_n, K.ia_f, K.ja_f, K.val_f, s));
+    KRON_HIP(hipMalloc(&K.d_xt, (size_t)n * sizeof(d2)));
+    KRON_HIP(hipMalloc(&K.d_far, (size_t)n * sizeof(d2)));
+    // wave-block geometry of the two parts (pipelined kernel)
+    for (int part = 0; part < 2; ++part) {
+        const int64_t *ia = part ? K.ia_f : K.ia_n;
+        const int64_t nnz = part ? K.nnz_f : K.nnz_n;
+        KRON_TRY(qbh::launch_max_rowlen(ia, n, (int64_t *)A->d_scal, s));
+        int64_t maxlen = 0;
+        KRON_HIP(hipMemcpyAsync(&maxlen, A->d_scal, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        KRON_HIP(hipStreamSynchronize(s));
+        const int64_t window = (maxlen <= 256) ? 512 - (maxlen > 0 ? maxlen - 1 : 0) : 256;
+        const int64_t n_wb = std::max<int64_t>(1, (nnz + window - 1) / window);
+        qbh::WaveDesc *wd = nullptr;
+        KRON_HIP(hipMalloc(&wd, (size_t)(n_wb + 2) * sizeof(qbh::WaveDesc)));
+        (part ? K.wd_f : K.wd_n) = wd;
+        KRON_TRY(qbh::launch_build_wavedesc(ia, n, window, wd, n_wb, s));
+        const double avg = (double)nnz / (double)n;
+        const int tpr = avg <= 32 ? 2 : avg <= 64 ? 4 : 8;
+        int ncu = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, A->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        const int occ = std::max(1, qbh::wave2_kernel_occupancy(tpr, part ? 0 : 2));
+        int64_t g = std::min<int64_t>((int64_t)occ * ncu, ((((n_wb + 3) >> 2) + 7) / 8) * 8);
+        g = std::max<int64_t>(8, (g / 8) * 8);
+        (part ? K.nwb_f : K.nwb_n) = n_wb;
+        (part ? K.tpr_f : K.tpr_n) = tpr;
+        (part ? K.grid_f : K.grid_n) = (int)g;
+    }
+    KRON_HIP(hipStreamSynchronize(s));
+#undef KRON_HIP
+#undef KRON_TRY
+    K.active = true;
+    return QBH_OK;
+}
+
 // wave-block geometry of one part for k_spmv_wave (uncoded complex128 values)
 int setup_wave_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, qbh::WaveDesc **d_wd_o, int64_t *n_wb_o, int *tpr_o, int *grid_o)
 {
@@ -366,6 +495,8 @@ int build_geometry(qbh_csr *A)
             grid_max = std::max(grid_max, R.wgrid);
         }
     }
+    QBH_TRY(kron_build(A));
+    if (A->kron.active) grid_max = std::max(grid_max, std::max(A->kron.grid_n, A->kron.grid_f));
     const size_t nparts = (size_t)std::max(grid_max, qbh::kMaxRedBlocks);
     if (A->d_partials) (void)hipFree(A->d_partials);
     A->d_partials = nullptr;
@@ -489,6 +620,7 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
     if (A->d_bp) (void)hipFree(A->d_bp);
     if (A->d_wd) (void)hipFree(A->d_wd);
     if (A->rem.d_wd) (void)hipFree(A->rem.d_wd);
+    kron_release(A);
     if (A->rem.d_ia) (void)hipFree(A->rem.d_ia);
     if (A->rem.d_ja) (void)hipFree(A->rem.d_ja);
     if (A->rem.d_val) (void)hipFree(A->rem.d_val);
@@ -799,6 +931,9 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->stream = (void *)A->stream;
     info->create_ms = A->create_ms;
     info->create_bytes_in = A->create_bytes_in;
+    info->kron_minor = A->kron.active ? A->kron.t.S : 0;
+    info->kron_far_nnz = A->kron.active ? A->kron.nnz_f : 0;
+    info->kron_band = A->kron.active ? A->kron.t.B : 0;
     return QBH_OK;
 }
 
@@ -1107,7 +1242,34 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     }
     // complex128 values, complex vectors: the wave kernel; the real gather / all-real forms stay on the row kernel
     const bool wave = A->use_wave && a.xr == nullptr && a.y_re == nullptr;
-    if (wave) {
+    const bool kron = wave && A->kron.active && !A->has_comm && !A->has_rem && !(A->debug & 1);
+    if (kron) {
+        // Kronecker split: tiled copy of x, far pass (plain row sums in tiled order), near pass with the fused epilogue
+        const qbh_csr::KronSplit &K = A->kron;
+        QBH_TRY(qbh::launch_kron_tile(xg, K.d_xt, A->nrows, K.t, A->stream));
+        qbh::SpmvArgs f = a;
+        f.ia = K.ia_f;
+        f.ja = K.ja_f;
+        f.val = K.val_f;
+        f.wd = K.wd_f;
+        f.n_wb = K.nwb_f;
+        f.xg = K.d_xt;
+        f.y = K.d_far;
+        f.partials = nullptr;
+        f.swizzle = 1;              // one contiguous eighth of the bands per XCD: a band of x stays in that XCD's L2
+        QBH_TRY(qbh::launch_spmv_wave2(f, K.tpr_f, 0, K.grid_f, A->stream));
+        qbh::SpmvArgs nr = a;
+        nr.ia = K.ia_n;
+        nr.ja = K.ja_n;
+        nr.val = K.val_n;
+        nr.wd = K.wd_n;
+        nr.n_wb = K.nwb_n;
+        nr.far = K.d_far;
+        nr.kS = K.t.S;
+        nr.kNU = K.t.NU;
+        nr.kB = K.t.B;
+        QBH_TRY(qbh::launch_spmv_wave2(nr, K.tpr_n, 2, K.grid_n, A->stream));
+    } else if (wave) {
         a.wd = A->d_wd;
         a.n_wb = A->n_wb;
         QBH_TRY(qbh::launch_spmv_wave(a, A->wtpr, A->wgrid, A->stream));
@@ -1118,7 +1280,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         QBH_HIP(hipEventRecord(A->ev1, A->stream));
         A->ev_pending = true;
     }
-    int grid_last = wave ? A->wgrid : A->grid;
+    int grid_last = kron ? A->kron.grid_n : wave ? A->wgrid : A->grid;
     if (A->has_rem) {
         if (async_gather) {
             if (A->comm.allgather_wait(A->comm.ctx) != 0) {

@@ -387,8 +387,13 @@ extern "C" int qbh_gen_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, i
         if (d_val) (void)hipFree(d_val);
         return e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP;
     }
-    // ownership passes with the call: on failure the arrays have already been released
-    return qbh_csr_create_device(out, nrows, dim, row_begin, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, opts);
+    // ownership passes with the call: on failure the arrays have already been released.  The basis is the product
+    // (up configuration) x (down configuration): announce the minor size for the Kronecker split (qbh_opts.kron_split)
+    qbh_opts o2;
+    if (opts) o2 = *opts;
+    else qbh_opts_default(&o2);
+    if (o2.kron_minor == 0 && nrows == dim) o2.kron_minor = Nd;
+    return qbh_csr_create_device(out, nrows, dim, row_begin, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, &o2);
 }
 
 namespace {

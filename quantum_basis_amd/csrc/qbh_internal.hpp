@@ -75,6 +75,34 @@ struct SpmvArgs {
     // wave kernel (k_spmv_wave): one wavefront per block of whole rows with <= 512 nonzeros
     const WaveDesc *wd;
     int64_t        n_wb;
+    // Kronecker split (H = H_near + H_far, see KronSplit): the far pass stores plain row sums, the near pass adds them
+    // back, reading the far result at the TILED index of its row
+    const d2      *far;        // near pass: far-part row sums in tiled order (nullptr: none)
+    int64_t        kS, kNU;    // minor size / major count of the product basis
+    int            kB;         // band width of the tiling
+};
+
+// element (u, d) of the product basis <-> its position in the band-major ("tiled") order (band, u, d % B): the B minor
+// indices of one band are contiguous for every major index, so 8 consecutive far rows gather one 128-byte line per entry
+struct KronTile {
+    int64_t S, NU;
+    int     B;
+    __host__ __device__ int64_t tile(int64_t r) const
+    {
+        const int64_t u = r / S, d = r - u * S;
+        const int64_t b = d / B, j = d - b * B;
+        const int64_t wB = (S - b * B) < B ? (S - b * B) : B;
+        return b * B * NU + u * wB + j;
+    }
+    __host__ __device__ int64_t orig(int64_t f) const
+    {
+        const int64_t full = (int64_t)B * NU;
+        const int64_t b = f / full;
+        const int64_t wB = (S - b * B) < B ? (S - b * B) : B;
+        const int64_t rem = f - b * full;
+        const int64_t u = rem / wB, j = rem - u * wB;
+        return u * S + b * B + j;
+    }
 };
 
 // launchers implemented in qbh_kernels.hip (all asynchronous on `s`)
@@ -82,6 +110,13 @@ int launch_spmv(const SpmvArgs &a, int kernel, int npb, int tpr, int grid, hipSt
 int spmv_grid(int kernel, int64_t n_blocks, int64_t nrows, int tpr);
 int rows_kernel_occupancy(int npb, int tpr, int un, int dict_mode);
 int launch_spmv_wave(const SpmvArgs &a, int tpr, int grid, hipStream_t s);
+int launch_spmv_wave2(const SpmvArgs &a, int tpr, int ops, int grid, hipStream_t s);   // pipelined; ops 0 plain store, 2 epilogue + far addend
+int wave2_kernel_occupancy(int tpr, int ops);
+int launch_kron_tile(const d2 *x, d2 *xt, int64_t n, const KronTile &t, hipStream_t s);
+int launch_kron_check(const int64_t *ia, const int32_t *ja, int64_t nrows, int64_t S, int *d_flag, hipStream_t s);
+int launch_kron_count(const int64_t *ia, const int32_t *ja, int64_t nrows, const KronTile &t, int32_t *cnt_near, int32_t *cnt_far, hipStream_t s);
+int launch_kron_fill(const int64_t *ia, const int32_t *ja, const d2 *val, int64_t nrows, const KronTile &t, const int64_t *ia_n, int32_t *ja_n,
+                     d2 *val_n, const int64_t *ia_f, int32_t *ja_f, d2 *val_f, hipStream_t s);
 int wave_kernel_occupancy(int tpr);
 int launch_build_wavedesc(const int64_t *d_ia, int64_t nrows, int64_t window, WaveDesc *d_wd, int64_t n_wb, hipStream_t s);
 int vector_kernel_occupancy(int tpr, int un, bool dict);
@@ -309,6 +344,21 @@ struct qbh_csr {
     int64_t *d_bp = nullptr;
     int      grid = 0;
     int      chunk_mult = 1;   // see BlockWalk (xcd_swizzle 2)
+    // Kronecker split of a product-basis operator H = T_major (x) 1 + 1 (x) T_minor + D (two-species Hubbard in the
+    // generator's order): "far" = entries that change the major index (same minor index), stored band-major over the
+    // minor index with TILED columns and applied first from a tiled copy of x; "near" = the rest in the original row order
+    struct KronSplit {
+        bool     active = false;
+        qbh::KronTile t{0, 0, 8};
+        int64_t  nnz_n = 0, nnz_f = 0;
+        int64_t *ia_n = nullptr, *ia_f = nullptr;
+        int32_t *ja_n = nullptr, *ja_f = nullptr;
+        qbh::d2 *val_n = nullptr, *val_f = nullptr;
+        qbh::WaveDesc *wd_n = nullptr, *wd_f = nullptr;
+        int64_t  nwb_n = 0, nwb_f = 0;
+        int      tpr_n = 2, tpr_f = 2, grid_n = 0, grid_f = 0;
+        qbh::d2 *d_xt = nullptr, *d_far = nullptr;      // tiled copy of x, far-part row sums (tiled order)
+    } kron;
     // wave kernel geometry (uncoded complex128 values; QBH_KERNEL_WAVE)
     bool     use_wave = false;
     qbh::WaveDesc *d_wd = nullptr;

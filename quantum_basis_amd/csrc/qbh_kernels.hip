@@ -709,6 +709,306 @@ int launch_build_wavedesc(const int64_t *d_ia, int64_t nrows, int64_t window, Wa
     return QBH_OK;
 }
 
+
+// ------------------------------------ pipelined wave kernel (Kronecker split) ----
+// The same decomposition as k_spmv_wave, software-pipelined per wavefront for the two passes of a split operator, whose
+// gathers hit the L2: the gathers of block i are issued, THEN the 16 stream loads of block i+1, and only the gathers are
+// waited for (vector-memory results return in order, so the order of issue is what keeps a block's stream in flight
+// while the previous block is reduced).  Every load of the steady state is unconditional (clamped addresses): the
+// compiler's s_waitcnt counts are then exact.  Descriptors are fetched two blocks ahead.
+// OPS 0: plain store of the row sums (far pass; y is the far buffer, rows are far rows)
+// OPS 2: fused epilogue, the far result of the row added first (read at the row's tiled index)
+template <int TPR, int OPS>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0 ? 3 : 2, OPS == 0 ? 3 : 2))) void k_spmv_wave2(SpmvArgs a)
+{
+    constexpr int NW = 512, RP = 64 / TPR;
+    __shared__ d2 prod_s[4 * NW];
+    __shared__ double red[12];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    d2 *prod = prod_s + wv * NW;
+    const int sub = lane % TPR, rloc = lane / TPR;
+    double acc[3] = {0.0, 0.0, 0.0};
+    const bool need_y = a.beta != 0.0;
+    const KronTile kt{a.kS, a.kNU, a.kB};
+
+    BlockWalk walk((a.n_wb + 3) >> 2, a.swizzle, a.chunk_mult);
+    auto load_desc = [&](int64_t lb) -> int {
+        int64_t w = a.n_wb;
+        if (lb < walk.per_xcd) {
+            w = walk.block(lb) * 4 + wv;
+            if (w > a.n_wb) w = a.n_wb;
+        }
+        return reinterpret_cast<const int *>(a.wd + w)[lane & 7];
+    };
+    struct Blk {
+        int64_t p0;
+        int r0, nr, n;           // n = -1: a row longer than the tile (row-at-a-time path)
+    };
+    auto decode = [&](int dq) -> Blk {
+        const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane(dq, 0), q1 = (uint32_t)__builtin_amdgcn_readlane(dq, 1);
+        const uint32_t q4 = (uint32_t)__builtin_amdgcn_readlane(dq, 4), q5 = (uint32_t)__builtin_amdgcn_readlane(dq, 5);
+        Blk b;
+        b.p0 = (int64_t)(((uint64_t)q1 << 32) | q0);
+        const int64_t p1 = (int64_t)(((uint64_t)q5 << 32) | q4);
+        b.r0 = __builtin_amdgcn_readlane(dq, 2);
+        b.nr = __builtin_amdgcn_readlane(dq, 6) - b.r0;
+        b.n = (p1 - b.p0) <= NW ? (int)(p1 - b.p0) : -1;
+        return b;
+    };
+    struct Ops {
+        int s, e;
+        d2 yo, xi, fr;
+    };
+    // stream + first-pass operands of a block; an empty / oversized block reads entry 0 of its range (clamped)
+    auto issue = [&](const Blk &b, int (&c)[8], d2 (&v)[8], Ops &o) {
+        const int nn = b.n > 0 ? b.n : 1;
+        const int nm1 = nn - 1;
+        // p0 of the sentinel is nnz: clamp the base so that even an empty block loads inside the arrays
+        const int64_t base = b.n > 0 ? b.p0 : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = lane + u * 64;
+            c[u] = ntload(a.ja + base + (i < nn ? i : nm1)) & a.colmask;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = lane + u * 64;
+            v[u] = ntload(a.val + base + (i < nn ? i : nm1));
+        }
+        const bool mine = rloc < b.nr;
+        const int64_t row = mine ? (int64_t)b.r0 + rloc : 0;
+        o.s = (int)(a.ia[row] - base);
+        o.e = (int)(a.ia[row + 1] - base);
+        if (!mine) o.s = o.e = 0;
+        if (OPS == 2) {
+            o.yo = a.y[row];
+            o.xi = a.xl[row];
+            o.fr = a.far[kt.tile(row)];
+            if (!need_y) o.yo = d2{0.0, 0.0};
+        }
+    };
+    auto finish_row = [&](int64_t row, d2 sum, d2 yo, d2 xi, d2 fr) {
+        if (OPS == 0) {
+            a.y[row] = sum;
+        } else {
+            sum += fr;
+            const d2 yn = a.alpha * sum + a.beta * yo + a.gamma * xi;
+            a.y[row] = yn;
+            acc[0] += xi.x * yn.x + xi.y * yn.y;
+            acc[1] += xi.x * yn.y - xi.y * yn.x;
+            acc[2] += yn.x * yn.x + yn.y * yn.y;
+        }
+    };
+
+    int64_t lb = walk.slot;
+    int dq0 = load_desc(lb), dq1 = load_desc(lb + walk.nslot);
+    Blk b0 = decode(dq0), b1 = decode(dq1);
+    int cA[8];
+    d2 vA[8];
+    Ops oA;
+    issue(b0, cA, vA, oA);
+    while (lb < walk.per_xcd) {
+        const int dq2 = load_desc(lb + 2 * walk.nslot);
+        d2 xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = a.xg[cA[u]];
+        __builtin_amdgcn_sched_barrier(0);      // the gathers go out BEFORE the next block's stream (in-order return)
+        int cB[8];
+        d2 vB[8];
+        Ops oB;
+        issue(b1, cB, vB, oB);
+        __builtin_amdgcn_sched_barrier(0);
+        if (b0.n >= 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) prod[lane + u * 64] = cmul(vA[u], xv[u]);
+            wave_lds_fence();
+            for (int rbase = 0; rbase < b0.nr; rbase += RP) {
+                const int row = rbase + rloc;
+                int s_ = oA.s, e_ = oA.e;
+                d2 yo = oA.yo, xi = oA.xi, fr = oA.fr;
+                if (rbase > 0) {
+                    s_ = e_ = 0;
+                    if (row < b0.nr) {
+                        s_ = (int)(a.ia[b0.r0 + row] - b0.p0);
+                        e_ = (int)(a.ia[b0.r0 + row + 1] - b0.p0);
+                        if (OPS == 2 && sub == 0) {
+                            yo = need_y ? a.y[b0.r0 + row] : d2{0.0, 0.0};
+                            xi = a.xl[b0.r0 + row];
+                            fr = a.far[kt.tile((int64_t)b0.r0 + row)];
+                        }
+                    }
+                }
+                d2 sum = {0.0, 0.0};
+                for (int k = s_ + sub; k < e_; k += TPR) sum += prod[k];
+#pragma unroll
+                for (int off = TPR / 2; off > 0; off >>= 1) {
+                    sum.x += __shfl_xor(sum.x, off, 64);
+                    sum.y += __shfl_xor(sum.y, off, 64);
+                }
+                if (sub == 0 && row < b0.nr) finish_row((int64_t)b0.r0 + row, sum, yo, xi, fr);
+            }
+            wave_lds_fence();
+        } else {
+            for (int r = 0; r < b0.nr; ++r) {     // a row longer than the tile: row at a time (correctness path)
+                const int64_t row = (int64_t)b0.r0 + r;
+                const int64_t s_ = a.ia[row], e_ = a.ia[row + 1];
+                d2 sum = {0.0, 0.0};
+                for (int64_t k = s_ + lane; k < e_; k += 64) sum += cmul(a.val[k], a.xg[a.ja[k] & a.colmask]);
+                sum.x = wave_sum(sum.x);
+                sum.y = wave_sum(sum.y);
+                if (lane == 0) {
+                    d2 yo = {0.0, 0.0}, xi = {0.0, 0.0}, fr = {0.0, 0.0};
+                    if (OPS == 2) {
+                        if (need_y) yo = a.y[row];
+                        xi = a.xl[row];
+                        fr = a.far[kt.tile(row)];
+                    }
+                    finish_row(row, sum, yo, xi, fr);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            cA[u] = cB[u];
+            vA[u] = vB[u];
+        }
+        oA = oB;
+        b0 = b1;
+        b1 = decode(dq2);
+        lb += walk.nslot;
+    }
+    if (a.partials != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = wave_sum(acc[c]);
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) red[c * 4 + wv] = acc[c];
+        }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                a.partials[(size_t)blockIdx.x * 3 + c] = (red[c * 4 + 0] + red[c * 4 + 1]) + (red[c * 4 + 2] + red[c * 4 + 3]);
+        }
+    }
+}
+
+template <int OPS>
+static void launch_wave2_tpr(const SpmvArgs &a, int tpr, int grid, hipStream_t s)
+{
+    switch (tpr) {
+    case 2:  hipLaunchKernelGGL((k_spmv_wave2<2, OPS>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+    case 4:  hipLaunchKernelGGL((k_spmv_wave2<4, OPS>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+    default: hipLaunchKernelGGL((k_spmv_wave2<8, OPS>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+    }
+}
+
+int launch_spmv_wave2(const SpmvArgs &a, int tpr, int ops, int grid, hipStream_t s)
+{
+    if (ops == 0) launch_wave2_tpr<0>(a, tpr, grid, s);
+    else          launch_wave2_tpr<2>(a, tpr, grid, s);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+template <int OPS>
+static int occ_wave2(int tpr)
+{
+    int occ = 0;
+    hipError_t e;
+    switch (tpr) {
+    case 2:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_wave2<2, OPS>, kBlock, 0); break;
+    case 4:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_wave2<4, OPS>, kBlock, 0); break;
+    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_wave2<8, OPS>, kBlock, 0); break;
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return occ;
+}
+int wave2_kernel_occupancy(int tpr, int ops) { return ops == 0 ? occ_wave2<0>(tpr) : occ_wave2<2>(tpr); }
+
+// ---- Kronecker split: tiled copy of x, structure check, count / fill of the two parts ----
+__global__ __launch_bounds__(kBlock) void k_kron_tile(const d2 *x, d2 *xt, int64_t n, KronTile t)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) xt[t.tile(r)] = x[r];
+}
+int launch_kron_tile(const d2 *x, d2 *xt, int64_t n, const KronTile &t, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kron_tile, dim3(2048), dim3(kBlock), 0, s, x, xt, n, t);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// product structure with minor size S: every entry keeps the major index (near) or keeps the minor index (far)
+__global__ __launch_bounds__(kBlock) void k_kron_check(const int64_t *ia, const int32_t *ja, int64_t nrows, int64_t S, int *flag)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t maj = r / S, mnr = r - maj * S;
+        bool bad = false;
+        for (int64_t k = ia[r]; k < ia[r + 1]; ++k) {
+            const int64_t c = ja[k], cm = c / S;
+            bad = bad || (cm != maj && c - cm * S != mnr);
+        }
+        if (bad) *flag = 1;
+    }
+}
+int launch_kron_check(const int64_t *ia, const int32_t *ja, int64_t nrows, int64_t S, int *d_flag, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kron_check, dim3(4096), dim3(kBlock), 0, s, ia, ja, nrows, S, d_flag);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+__global__ __launch_bounds__(kBlock) void k_kron_count(const int64_t *ia, const int32_t *ja, int64_t nrows, KronTile t, int32_t *cnt_near,
+                                                       int32_t *cnt_far)
+{
+    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < nrows; f += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t.orig(f);
+        const int64_t maj = r / t.S;
+        int nf = 0;
+        const int64_t s0 = ia[r], e0 = ia[r + 1];
+        for (int64_t k = s0; k < e0; ++k) nf += (ja[k] / t.S) != maj;
+        cnt_far[f] = nf;
+        cnt_near[r] = (int)(e0 - s0) - nf;
+    }
+}
+int launch_kron_count(const int64_t *ia, const int32_t *ja, int64_t nrows, const KronTile &t, int32_t *cnt_near, int32_t *cnt_far, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kron_count, dim3(4096), dim3(kBlock), 0, s, ia, ja, nrows, t, cnt_near, cnt_far);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// near entries keep their row and column; far entries go to the tiled row with the tiled column (ascending in both)
+__global__ __launch_bounds__(kBlock) void k_kron_fill(const int64_t *ia, const int32_t *ja, const d2 *val, int64_t nrows, KronTile t,
+                                                      const int64_t *ia_n, int32_t *ja_n, d2 *val_n, const int64_t *ia_f, int32_t *ja_f, d2 *val_f)
+{
+    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < nrows; f += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t.orig(f);
+        const int64_t maj = r / t.S;
+        int64_t pn = ia_n[r], pf = ia_f[f];
+        for (int64_t k = ia[r]; k < ia[r + 1]; ++k) {
+            const int32_t c = ja[k];
+            if ((c / t.S) != maj) {
+                ja_f[pf] = (int32_t)t.tile(c);
+                val_f[pf++] = val[k];
+            } else {
+                ja_n[pn] = c;
+                val_n[pn++] = val[k];
+            }
+        }
+    }
+}
+int launch_kron_fill(const int64_t *ia, const int32_t *ja, const d2 *val, int64_t nrows, const KronTile &t, const int64_t *ia_n, int32_t *ja_n,
+                     d2 *val_n, const int64_t *ia_f, int32_t *ja_f, d2 *val_f, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kron_fill, dim3(4096), dim3(kBlock), 0, s, ia, ja, val, nrows, t, ia_n, ja_n, val_n, ia_f, ja_f, val_f);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
 // ------------------------------------------- sub-wavefront-per-row SpMV --------
 // G lanes per row, NO LDS staging and no workgroup barrier: a wavefront owns 64/G consecutive rows and every lane walks
 // its row in strides of G, UN entries at a time -- UN column loads, UN value loads and then UN x gathers in flight per

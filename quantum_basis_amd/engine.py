@@ -37,7 +37,7 @@ def _cvec(a, name):
 
 
 def make_opts(device=-1, stream=None, spmv_kernel=_lib.KERNEL_AUTO, nnz_per_block=0, xcd_swizzle=2,
-              value_dict=1, profile=0, check_hermitian=1, real_fast_path=1):
+              value_dict=1, profile=0, check_hermitian=1, real_fast_path=1, kron_split=1, kron_minor=0):
     o = _lib.Opts()
     lib().qbh_opts_default(C.byref(o))
     o.device = device
@@ -49,6 +49,8 @@ def make_opts(device=-1, stream=None, spmv_kernel=_lib.KERNEL_AUTO, nnz_per_bloc
     o.profile = profile
     o.check_hermitian = check_hermitian
     o.real_fast_path = real_fast_path
+    o.kron_split = kron_split
+    o.kron_minor = kron_minor
     return o
 
 

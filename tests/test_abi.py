@@ -32,12 +32,28 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    # sizes the C compiler gives the header's structs (checked with a tiny C program at build time
-    # would be better; here: the documented field lists, 8-byte aligned)
-    assert C.sizeof(_lib.Z) == 16
-    assert C.sizeof(_lib.LanczosRow) == 8 + 4 * 8 + 5 * 8
-    assert C.sizeof(_lib.Opts) == 4 + 4 + 8 + 7 * 4 + 4        # 7 ints after the stream pointer, padded to 8
-    assert C.sizeof(_lib.Stats) == 6 * 8
+    """sizeof / offsetof as the C compiler sees include/qbhip.h against the ctypes mirrors in _lib.py"""
+    import subprocess
+    import tempfile
+    src = r"""
+#include <stdio.h>
+#include <stddef.h>
+#include "qbhip.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(qbh_z), sizeof(qbh_lanczos_row), sizeof(qbh_opts), sizeof(qbh_stats),
+           sizeof(qbh_csr_info), sizeof(qbh_solver_info), offsetof(qbh_opts, kron_split), offsetof(qbh_opts, kron_minor),
+           offsetof(qbh_csr_info, kron_minor), offsetof(qbh_csr_info, kron_band));
+    return 0;
+}
+"""
+    with tempfile.TemporaryDirectory() as tmp:
+        open(os.path.join(tmp, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(tmp, "t.c"), "-o", os.path.join(tmp, "t")])
+        got = [int(t) for t in subprocess.check_output([os.path.join(tmp, "t")], text=True).split()]
+    want = [C.sizeof(_lib.Z), C.sizeof(_lib.LanczosRow), C.sizeof(_lib.Opts), C.sizeof(_lib.Stats), C.sizeof(_lib.CsrInfo),
+            C.sizeof(_lib.SolverInfo), _lib.Opts.kron_split.offset, _lib.Opts.kron_minor.offset, _lib.CsrInfo.kron_minor.offset,
+            _lib.CsrInfo.kron_band.offset]
+    assert got == want
 
 
 def test_strerror_and_no_device_is_loud():
