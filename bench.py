@@ -527,8 +527,14 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         st = A.stats()
-        elapsed, ms_spmv, ms_gather = allreduce_host([elapsed, st.ms_spmv / max(st.n_spmv, 1), st.ms_gather / max(st.n_gather, 1)],
-                                                     dist.ReduceOp.MAX)
+        mine = [st.ms_spmv / max(st.n_spmv, 1), st.ms_gather / max(st.n_gather, 1)]
+        per_rank = None
+        if world > 1:            # every rank's own kernel and exchange time (the headline takes the slowest rank)
+            slots = [0.0] * (2 * world)
+            slots[2 * rank], slots[2 * rank + 1] = mine
+            slots = allreduce_host(slots, dist.ReduceOp.SUM)
+            per_rank = [(slots[2 * r], slots[2 * r + 1]) for r in range(world)]
+        elapsed, ms_spmv, ms_gather = allreduce_host([elapsed] + mine, dist.ReduceOp.MAX)
         e0 = steps_e0 = None
         if not args.no_converge:      # untimed: the same solver to convergence (E0 parity across N / formats / vs the oracle tests)
             maxit2 = 1000
@@ -539,7 +545,7 @@ def main():
             e0, steps_e0 = float(ritz[0]), int(m)
         v.free()
         return dict(elapsed=elapsed, steps=done, ms_spmv=ms_spmv, n_spmv=int(st.n_spmv), n_real=int(st.n_spmv_real), e0=e0,
-                    steps_e0=steps_e0, ms_gather=ms_gather, n_gather=int(st.n_gather))
+                    steps_e0=steps_e0, ms_gather=ms_gather, n_gather=int(st.n_gather), per_rank=per_rank)
 
     create = None
     with torch.cuda.stream(stream):
@@ -655,6 +661,24 @@ def main():
                            "ms_per_gather": round(head["ms_gather"], 4) if head["ms_gather"] > 0 else None,
                            "gathers": head["n_gather"],
                            "allreduce": "<= 3 doubles per reduction point"}
+        # per rank: SpMV kernel ms (both parts of a split shard), gather ms on the side stream, how much of the gather the
+        # locally-owned columns hide, and the rank's own roofline on ITS algorithmic bytes (local nnz, rows, the whole x)
+        loc = [0.0] * (2 * world)
+        loc[2 * rank], loc[2 * rank + 1] = float(info.nnz), float(info.nrows)
+        loc = allreduce_host(loc, dist.ReduceOp.SUM)
+        step_ms = 1e3 * head["elapsed"] / max(head["steps"], 1)
+        ranks = []
+        for r in range(world):
+            ms_k, ms_g = head["per_rank"][r]
+            b_r = loc[2 * r] * 20 + (loc[2 * r + 1] + 1) * 8 + dim * 16 + loc[2 * r + 1] * 16
+            exposed = max(0.0, step_ms - ms_k - 96.0 * loc[2 * r + 1] / 6.0e9)      # what the step waits beyond kernel + BLAS-1 at ~6 TB/s
+            ranks.append({"rank": r, "rows": int(loc[2 * r + 1]), "nnz": int(loc[2 * r]), "ms_spmv": round(ms_k, 4),
+                          "ms_gather": round(ms_g, 4) if ms_g > 0 else None,
+                          "gather_hidden_frac": (round(max(0.0, min(1.0, 1.0 - exposed / ms_g)), 3) if ms_g > 0 else None),
+                          "roofline_frac": round(b_r / max(ms_k, 1e-9) / 1e6 / HBM_PEAK_GBPS, 4)})
+        out["per_rank"] = ranks
+        ms_all = [r_["ms_spmv"] for r_ in ranks]
+        out["exchange"]["spmv_ms_imbalance_max_over_min"] = round(max(ms_all) / max(min(ms_all), 1e-9), 3)
     if create:
         out["create"] = create
     if packed_real:

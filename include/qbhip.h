@@ -86,7 +86,8 @@ typedef struct qbh_opts {
                                 every entry changes one of the two: the two-species Hubbard family in the generator's order)
                                 is also kept as H_near + H_far with the far part band-major over the minor index (same values,
                                 same 20 B per nonzero; verified on the device, skipped when HBM cannot hold the second copy);
-                                0: never                                                                      */
+                                the split, the wave kernel and the row kernel are timed at creation and the fastest is kept
+                                (operators above 1e7 nonzeros; QBH_KERNEL_AUTO); 2: always when it applies; 0: never      */
     int64_t kron_minor;      /* S for an operator created from host / device arrays (0: unknown -> no split); the generators
                                 announce their own                                                            */
 } qbh_opts;

@@ -483,6 +483,7 @@ int build_geometry(qbh_csr *A)
     }
     // complex128 values (no dictionary): the wave kernel, unless the row kernel was asked for by name
     A->use_wave = A->kernel == QBH_KERNEL_ROWS && A->dict_mode == 0 && A->d_val != nullptr && A->opts.spmv_kernel != QBH_KERNEL_ROWS;
+    if (A->tuned == 0) A->use_wave = false;            // timed at creation (autotune_kernel): the row kernel won
     if (const char *e = getenv("QBH_NO_WAVE")) {
         if (atoi(e)) A->use_wave = false;
     }
@@ -502,6 +503,72 @@ int build_geometry(qbh_csr *A)
     A->d_partials = nullptr;
     QBH_HIP(hipMalloc(&A->d_partials, nparts * 16 * sizeof(double)));
     return QBH_OK;
+}
+
+int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double gamma, double *red);
+
+// QBH_KERNEL_AUTO on complex128 values: the wave kernel wins where the gathers hit the caches (1-D and Kronecker-structured
+// operators), the row kernel where they miss (momentum sectors: its lanes-to-rows gathers and larger blocks cost fewer line
+// fetches), the Kronecker split where it applies and fits -- so the three forms are TIMED on the operator itself, two launches
+// each, and the fastest one is kept (the structures of the others are released).  Below 1e7 nonzeros nothing is timed (the wave
+// kernel is kept: results stay bit-reproducible from run to run for every operator a CPU can check).
+int autotune_kernel(qbh_csr *A)
+{
+    if (A->opts.spmv_kernel != QBH_KERNEL_AUTO || !A->use_wave || A->kind != 0 || A->has_rem || A->has_comm || A->nnz < 10000000) return QBH_OK;
+    if (const char *e = getenv("QBH_NO_AUTOTUNE")) {
+        if (atoi(e)) return QBH_OK;
+    }
+    hipStream_t s = A->stream;
+    d2 *x = nullptr, *y = nullptr;
+    if (hipMalloc(&x, (size_t)A->ncols * sizeof(d2)) != hipSuccess || hipMalloc(&y, (size_t)A->nrows * sizeof(d2)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (x) (void)hipFree(x);
+        return QBH_OK;                     // no room for the trial vectors: keep the default choice
+    }
+    auto done = [&](int code) {
+        (void)hipFree(x);
+        (void)hipFree(y);
+        return code;
+    };
+    if (qbh::launch_fill_const(x, A->ncols, 0.5, s) != QBH_OK) return done(QBH_OK);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return done(QBH_OK);
+    const bool have_kron = A->kron.active;
+    const int saved_profile = A->opts.profile;
+    A->opts.profile = 0;
+    double best = 1e300;
+    int best_mode = 1;
+    if (have_kron && A->opts.kron_split == 2) {                         // asked for by name: nothing to decide
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        A->opts.profile = saved_profile;
+        return done(QBH_OK);
+    }
+    for (int mode = 0; mode < (have_kron ? 3 : 2); ++mode) {          // 0 row kernel | 1 wave kernel | 2 Kronecker split
+        A->use_wave = mode != 0;
+        A->kron.active = mode == 2;
+        float ms = 0.f;
+        bool ok = spmv_run(A, x, y, 1.0, 0.0, 0.0, nullptr) == QBH_OK;                                 // warm
+        ok = ok && hipEventRecord(e0, s) == hipSuccess;
+        for (int r = 0; r < 2 && ok; ++r) ok = spmv_run(A, x, y, 1.0, 0.0, 0.0, nullptr) == QBH_OK;
+        ok = ok && hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+             hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+        if (ok && ms < best) {
+            best = ms;
+            best_mode = mode;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    A->opts.profile = saved_profile;
+    A->use_wave = best_mode != 0;
+    A->tuned = best_mode != 0 ? 1 : 0;
+    A->kron.active = have_kron;
+    if (best_mode != 2) kron_release(A);
+    A->stats = qbh_stats{};
+    A->stats.ms_spmv_min = std::numeric_limits<double>::infinity();
+    A->xr_of = nullptr;
+    return done(QBH_OK);
 }
 
 // geometry + workspace once the CSR arrays are in HBM
@@ -552,6 +619,7 @@ int finalize(qbh_csr *A)
     QBH_HIP(hipStreamSynchronize(s));
     A->stats = qbh_stats{};
     A->stats.ms_spmv_min = std::numeric_limits<double>::infinity();
+    QBH_TRY(autotune_kernel(A));
     return QBH_OK;
 }
 

@@ -361,6 +361,7 @@ struct qbh_csr {
     } kron;
     // wave kernel geometry (uncoded complex128 values; QBH_KERNEL_WAVE)
     bool     use_wave = false;
+    int      tuned = -1;             // kernel timed best at creation: -1 not timed, 0 row kernel, 1 wave kernel (kept across rebuilds)
     qbh::WaveDesc *d_wd = nullptr;
     int64_t  n_wb = 0;
     int      wtpr = 2, wgrid = 0;

@@ -691,6 +691,36 @@ def moprXvec_flip_repr(n_sites, n_dn_old, kind, perms, chars_old, chars_new, coe
     return d0.value, d1.value
 
 
+def measure_repr_static_hubbard(n_sites, n_up, n_dn, perms, chars, d_psi, one_body=(), two_body=(), spin_exchange=(), opts=None):
+    """model::measure_repr_static (src/model.cc:1860-1891) for the two-species fermion family in a momentum sector:
+    <psi| O_t |psi> with O_t = (1/N) sum_R T(R) O T(-R), the translation average of
+        O = sum (a_up c+_{i,up} c_{j,up} + a_dn c+_{i,dn} c_{j,dn})                        one_body  = [(i, j, a_up, a_dn), ...]
+          + sum (v_uu n_{i,up} n_{j,up} + v_ud n_{i,up} n_{j,dn} + v_du n_{i,dn} n_{j,up} + v_dd n_{i,dn} n_{j,dn})
+                                                                                         two_body  = [(i, j, v_uu, v_ud, v_du, v_dd), ...]
+          + sum a (S+_i S-_j + S-_i S+_j)                                                  spin_exchange = [(i, j, a), ...]
+    e.g. the density-density correlator <n_i n_j> (two_body = [(i, j, 1, 1, 1, 1)]), the double occupancy
+    (two_body = [(i, i, 0, 1, 0, 0)]) or <S^z_i S^z_j> (two_body = [(i, j, .25, -.25, -.25, .25)]); with spin_exchange a/2 = 1/2
+    on top of the last one <S_i . S_j>.  The reference transforms the operator with every translation plan and applies the
+    averaged mopr through moprXvec_repr; here the averaged operator is assembled as a sector operator on the device
+    (qbh_gen_hubbard_repr: same rows, same representatives as the Hamiltonian of the sector) and applied once.
+    d_psi: device vector of the sector (e.g. the eigenvector of locate_E0_lanczos on the sector operator)."""
+    perms = np.asarray(perms, dtype=np.int64)
+    w = 1.0 / len(perms)
+    terms, pairs, exch = [], [], []
+    for g in perms:                                   # O -> T(R) O T(-R): every site index through the translation plan
+        terms += [(int(g[i]), int(g[j]), au * w, ad * w) for (i, j, au, ad) in one_body]
+        pairs += [(int(g[i]), int(g[j]), vuu * w, vud * w, vdu * w, vdd * w) for (i, j, vuu, vud, vdu, vdd) in two_body]
+        exch += [(int(g[i]), int(g[j]), a * w) for (i, j, a) in spin_exchange]
+    Ot = csr_mat.hubbard_repr(n_sites, n_up, n_dn, None, perms, chars, U=0.0, terms=terms, pairs=pairs or None,
+                              exchange=exch or None, fake_pos=0.0, opts=opts)
+    y = Ot.vec(1)
+    Ot.spmv(d_psi, y.ptr, 1.0, 0.0, 0.0)
+    val = Ot.dotc(d_psi, y.ptr)
+    y.free()
+    Ot.destroy()
+    return val
+
+
 def measure_full_static_spin_dev(mat, n_sites, n_dn, d_phi, ops):
     """model<T>::measure_full_static (src/model.cc:1660-1694) for a product of spin operators on a fixed-N_dn sector, on the
     device: <phi| O_1 O_2 ... O_k |phi> with O_j = (kind_j, coef_j) as in moprXvec_spin, applied right to left (the

@@ -22,7 +22,7 @@ def test_split_operator_equals_the_unsplit_one(shape):
     lx, ly, nu, nd = shape
     n = lx * ly
     bonds = lattices.square(lx, ly)
-    K = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(**PLAIN))
+    K = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_split=2, **PLAIN))     # 2: no timing, always split
     P = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_split=0, **PLAIN))
     ik, ip = K.info(), P.info()
     assert ik.kron_minor == ik.ncols // int(round(ik.ncols / ik.kron_minor)) > 0 and ip.kron_minor == 0
@@ -71,7 +71,7 @@ def test_split_from_host_arrays_needs_the_hint_and_is_verified():
     x = _rand(dim, 3)
     want = qo.Csr(dim, ia, ja.astype(np.int64), val, False).multmv(x)
     for minor, expect in [(0, 0), (S, S), (28, 0), (7, 0)]:
-        A = q.csr_mat(dim, ia, ja.astype(np.int64), val, sym=False, opts=q.make_opts(kron_minor=minor, **PLAIN))
+        A = q.csr_mat(dim, ia, ja.astype(np.int64), val, sym=False, opts=q.make_opts(kron_minor=minor, kron_split=2, **PLAIN))
         assert A.info().kron_minor == expect, minor
         y = np.empty(dim, dtype=np.complex128)
         A.MultMv(x, y)
