@@ -75,6 +75,7 @@ struct SpmvArgs {
     // wave kernel (k_spmv_wave): one wavefront per block of whole rows with <= 512 nonzeros
     const WaveDesc *wd;
     int64_t        n_wb;
+    unsigned long long *wctr;  // swizzle 3 (dynamic ordered walk): one counter per XCD, 16 apart, zeroed before the launch
     // Kronecker split (H = H_near + H_far, see KronSplit): the far pass stores plain row sums, the near pass adds them
     // back, reading the far result at the TILED index of its row
     const d2      *far;        // near pass: far-part row sums in tiled order (nullptr: none)
@@ -361,6 +362,7 @@ struct qbh_csr {
     } kron;
     // wave kernel geometry (uncoded complex128 values; QBH_KERNEL_WAVE)
     bool     use_wave = false;
+    unsigned long long *d_wctr = nullptr;   // [3 * 128] work counters of the dynamic walk (main / far / near launch)
     int      tuned = -1;             // kernel timed best at creation: -1 not timed, 0 row kernel, 1 wave kernel (kept across rebuilds)
     qbh::WaveDesc *d_wd = nullptr;
     int64_t  n_wb = 0;

@@ -93,6 +93,52 @@ struct BlockWalk {
     }
 };
 
+// Dynamic ORDERED walk of the wave kernels (xcd_swizzle 3).  A persistent static walk lets the workgroups of an XCD drift apart
+// (nothing synchronises them over thousands of blocks): on C3 their union of x windows then no longer fits the L2 -- 45 % of
+// the gathers of the band-major far part missed a 1.65 MB window that the L2 holds perfectly in isolation, and the count did
+// not depend on the band width (narrower bands, proportionally more of them in flight).  Here every XCD owns one contiguous
+// eighth of the wave blocks and ALL its wavefronts draw chunks of kDynChunk consecutive blocks from one counter, so the eighth
+// is consumed in order and the blocks in flight on an XCD are always neighbours.  blockIdx % 8 names the counter (the observed
+// dispatch order puts those workgroups on one XCD; if it did not, only the locality would suffer).
+constexpr int kDynChunk = 4;
+struct DynWalk {
+    int64_t xbase, xend, ck_even, ck_odd, n_wb;
+    unsigned long long *ctr;
+    __device__ int64_t grab(int lane)
+    {
+        unsigned long long c = 0;
+        if (lane == 0) c = atomicAdd(ctr, (unsigned long long)kDynChunk);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)c), hi = __builtin_amdgcn_readfirstlane((uint32_t)(c >> 32));
+        return xbase + (int64_t)(((uint64_t)hi << 32) | lo);
+    }
+    __device__ void init(int64_t n_blocks, unsigned long long *counters, int lane)
+    {
+        n_wb = n_blocks;
+        const int xcd = blockIdx.x & 7;
+        const int64_t per = (n_blocks + 7) >> 3;
+        xbase = xcd * per;
+        xend = xbase + per < n_blocks ? xbase + per : n_blocks;
+        ctr = counters + xcd * 16;
+        ck_even = grab(lane);
+        ck_odd = grab(lane);
+    }
+    // wave block of this wavefront's n-th turn (n in the current or the next chunk); n_wb = the sentinel (past the end)
+    __device__ int64_t block(int64_t n) const
+    {
+        const int64_t w = (((n / kDynChunk) & 1) ? ck_odd : ck_even) + n % kDynChunk;
+        return w < xend ? w : n_wb;
+    }
+    __device__ bool live(int64_t n) const { return (((n / kDynChunk) & 1) ? ck_odd : ck_even) + n % kDynChunk < xend; }
+    // after moving on to turn n: entering a chunk draws the one after it (needed two turns later at the earliest)
+    __device__ void advance(int64_t n, int lane)
+    {
+        if (n % kDynChunk == 0) {
+            if ((n / kDynChunk) & 1) ck_even = grab(lane);
+            else                     ck_odd = grab(lane);
+        }
+    }
+};
+
 // fused epilogue of one row: y <- alpha*(Hx) + beta*y + gamma*x_local, and the running
 // partial sums of <x,y> and |y|^2 (K3, K4 and the CG shift folded into K1).
 // yo / xi are the old y[row] and x_local[row], loaded by the caller (so that the loads can
@@ -525,7 +571,7 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int TPR>
+template <int TPR, bool DYN>
 __global__ __launch_bounds__(kBlock) void k_spmv_wave(SpmvArgs a)
 {
     constexpr int U = 8, NW = 64 * U, RP = 64 / TPR;
@@ -544,23 +590,30 @@ __global__ __launch_bounds__(kBlock) void k_spmv_wave(SpmvArgs a)
     // dword j -- and broadcast with readlane when the trip starts: the compiler tracks it like any other load (an
     // explicit s_load would be faster still, but nothing stops the register allocator from copying its destination
     // SGPRs while the load is in flight).  A block past the end reads the sentinel pair (n_wb, n_wb + 1): zero rows.
+    constexpr bool dyn = DYN;            // compile-time: the atomic of the dynamic walk must not leak into the static kernel's waits
+    DynWalk dw;
+    if constexpr (dyn) dw.init(a.n_wb, a.wctr, lane);
     auto load_desc = [&](int64_t lb) -> int {
         int64_t w = a.n_wb;
-        if (lb < walk.per_xcd) {
+        if (dyn) {
+            w = dw.block(lb);
+        } else if (lb < walk.per_xcd) {
             w = walk.block(lb) * 4 + wv;
             if (w > a.n_wb) w = a.n_wb;
         }
         return reinterpret_cast<const int *>(a.wd + w)[lane & 7];
     };
-    int64_t lb = walk.slot;
+    const int64_t step = dyn ? 1 : walk.nslot;
+    int64_t lb = dyn ? 0 : walk.slot;
     int dq = load_desc(lb);
-    while (lb < walk.per_xcd) {
+    while (dyn ? dw.live(lb) : (lb < walk.per_xcd)) {
         const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane(dq, 0), q1 = (uint32_t)__builtin_amdgcn_readlane(dq, 1);
         const uint32_t q4 = (uint32_t)__builtin_amdgcn_readlane(dq, 4), q5 = (uint32_t)__builtin_amdgcn_readlane(dq, 5);
         const int r0 = __builtin_amdgcn_readlane(dq, 2), nr = __builtin_amdgcn_readlane(dq, 6) - r0;
         const int64_t p0 = (int64_t)(((uint64_t)q1 << 32) | q0);
         const int64_t p1 = (int64_t)(((uint64_t)q5 << 32) | q4);
-        lb += walk.nslot;
+        lb += step;
+        if constexpr (dyn) dw.advance(lb, lane);
         dq = load_desc(lb);                                                 // next block's descriptors, used one trip later
         if (nr <= 0) continue;
         const int64_t nlong = p1 - p0;
@@ -650,11 +703,20 @@ __global__ __launch_bounds__(kBlock) void k_spmv_wave(SpmvArgs a)
 
 int launch_spmv_wave(const SpmvArgs &a, int tpr, int grid, hipStream_t s)
 {
-    switch (tpr) {
-    case 2:  hipLaunchKernelGGL((k_spmv_wave<2>),  dim3(grid), dim3(kBlock), 0, s, a); break;
-    case 4:  hipLaunchKernelGGL((k_spmv_wave<4>),  dim3(grid), dim3(kBlock), 0, s, a); break;
-    case 8:  hipLaunchKernelGGL((k_spmv_wave<8>),  dim3(grid), dim3(kBlock), 0, s, a); break;
-    default: hipLaunchKernelGGL((k_spmv_wave<16>), dim3(grid), dim3(kBlock), 0, s, a); break;
+    if (a.swizzle == 3) {
+        switch (tpr) {
+        case 2:  hipLaunchKernelGGL((k_spmv_wave<2, true>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 4:  hipLaunchKernelGGL((k_spmv_wave<4, true>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 8:  hipLaunchKernelGGL((k_spmv_wave<8, true>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_spmv_wave<16, true>), dim3(grid), dim3(kBlock), 0, s, a); break;
+        }
+    } else {
+        switch (tpr) {
+        case 2:  hipLaunchKernelGGL((k_spmv_wave<2, false>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 4:  hipLaunchKernelGGL((k_spmv_wave<4, false>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 8:  hipLaunchKernelGGL((k_spmv_wave<8, false>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_spmv_wave<16, false>), dim3(grid), dim3(kBlock), 0, s, a); break;
+        }
     }
     QBH_HIP(hipGetLastError());
     return QBH_OK;
@@ -665,10 +727,10 @@ int wave_kernel_occupancy(int tpr)
     int occ = 0;
     hipError_t e;
     switch (tpr) {
-    case 2:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_wave<2>, kBlock, 0); break;
-    case 4:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_wave<4>, kBlock, 0); break;
-    case 8:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_wave<8>, kBlock, 0); break;
-    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_wave<16>, kBlock, 0); break;
+    case 2:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_wave<2, false>, kBlock, 0); break;
+    case 4:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_wave<4, false>, kBlock, 0); break;
+    case 8:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_wave<8, false>, kBlock, 0); break;
+    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_wave<16, false>, kBlock, 0); break;
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -718,7 +780,7 @@ int launch_build_wavedesc(const int64_t *d_ia, int64_t nrows, int64_t window, Wa
 // compiler's s_waitcnt counts are then exact.  Descriptors are fetched two blocks ahead.
 // OPS 0: plain store of the row sums (far pass; y is the far buffer, rows are far rows)
 // OPS 2: fused epilogue, the far result of the row added first (read at the row's tiled index)
-template <int TPR, int OPS>
+template <int TPR, int OPS, bool DYN>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0 ? 3 : 2, OPS == 0 ? 3 : 2))) void k_spmv_wave2(SpmvArgs a)
 {
     constexpr int NW = 512, RP = 64 / TPR;
@@ -732,14 +794,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0
     const KronTile kt{a.kS, a.kNU, a.kB};
 
     BlockWalk walk((a.n_wb + 3) >> 2, a.swizzle, a.chunk_mult);
+    constexpr bool dyn = DYN;
+    DynWalk dw;
+    if constexpr (dyn) dw.init(a.n_wb, a.wctr, lane);
     auto load_desc = [&](int64_t lb) -> int {
         int64_t w = a.n_wb;
-        if (lb < walk.per_xcd) {
+        if (dyn) {
+            w = dw.block(lb);
+        } else if (lb < walk.per_xcd) {
             w = walk.block(lb) * 4 + wv;
             if (w > a.n_wb) w = a.n_wb;
         }
         return reinterpret_cast<const int *>(a.wd + w)[lane & 7];
     };
+    const int64_t step = dyn ? 1 : walk.nslot;
     struct Blk {
         int64_t p0;
         int r0, nr, n;           // n = -1: a row longer than the tile (row-at-a-time path)
@@ -800,15 +868,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0
         }
     };
 
-    int64_t lb = walk.slot;
-    int dq0 = load_desc(lb), dq1 = load_desc(lb + walk.nslot);
+    int64_t lb = dyn ? 0 : walk.slot;
+    int dq0 = load_desc(lb), dq1 = load_desc(lb + step);
     Blk b0 = decode(dq0), b1 = decode(dq1);
     int cA[8];
     d2 vA[8];
     Ops oA;
     issue(b0, cA, vA, oA);
-    while (lb < walk.per_xcd) {
-        const int dq2 = load_desc(lb + 2 * walk.nslot);
+    while (dyn ? dw.live(lb) : (lb < walk.per_xcd)) {
+        const int dq2 = load_desc(lb + 2 * step);
         d2 xv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) xv[u] = a.xg[cA[u]];
@@ -875,7 +943,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0
         oA = oB;
         b0 = b1;
         b1 = decode(dq2);
-        lb += walk.nslot;
+        lb += step;
+        if constexpr (dyn) dw.advance(lb, lane);
     }
     if (a.partials != nullptr) {
 #pragma unroll
@@ -896,10 +965,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0
 template <int OPS>
 static void launch_wave2_tpr(const SpmvArgs &a, int tpr, int grid, hipStream_t s)
 {
-    switch (tpr) {
-    case 2:  hipLaunchKernelGGL((k_spmv_wave2<2, OPS>),  dim3(grid), dim3(kBlock), 0, s, a); break;
-    case 4:  hipLaunchKernelGGL((k_spmv_wave2<4, OPS>),  dim3(grid), dim3(kBlock), 0, s, a); break;
-    default: hipLaunchKernelGGL((k_spmv_wave2<8, OPS>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+    if (a.swizzle == 3) {
+        switch (tpr) {
+        case 2:  hipLaunchKernelGGL((k_spmv_wave2<2, OPS, true>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 4:  hipLaunchKernelGGL((k_spmv_wave2<4, OPS, true>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_spmv_wave2<8, OPS, true>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        }
+    } else {
+        switch (tpr) {
+        case 2:  hipLaunchKernelGGL((k_spmv_wave2<2, OPS, false>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 4:  hipLaunchKernelGGL((k_spmv_wave2<4, OPS, false>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_spmv_wave2<8, OPS, false>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        }
     }
 }
 
@@ -917,9 +994,9 @@ static int occ_wave2(int tpr)
     int occ = 0;
     hipError_t e;
     switch (tpr) {
-    case 2:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_wave2<2, OPS>, kBlock, 0); break;
-    case 4:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_wave2<4, OPS>, kBlock, 0); break;
-    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_wave2<8, OPS>, kBlock, 0); break;
+    case 2:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_wave2<2, OPS, true>, kBlock, 0); break;
+    case 4:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_wave2<4, OPS, true>, kBlock, 0); break;
+    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_wave2<8, OPS, true>, kBlock, 0); break;
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();

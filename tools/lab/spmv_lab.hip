@@ -77,7 +77,8 @@ struct WArgs {
     int plain;             // 1: y[perm[row]] = sum, no epilogue
     double alpha, beta, gamma;
     double *partials;
-    int swizzle, chunk;
+    int swizzle, chunk;      // swizzle 3 (k_wave2): dynamic, ordered per XCD -- chunks of 4 wave blocks from a counter per XCD
+    unsigned long long *ctr; // [8 * 16] one counter per XCD, 128 bytes apart, zero before the launch
     int ntstore;           // plain pass stores non-temporally
     int tiled;             // tmp is indexed by the tiled row (bands)
     Bands bd;
@@ -328,12 +329,34 @@ __global__ __launch_bounds__(256) void k_wave2(WArgs a)
     const int64_t chunk = nslot * (a.chunk > 0 ? a.chunk : 1);
     if (a.swizzle == 2) per_xcd = ((per_xcd + chunk - 1) / chunk) * chunk;
 
+    // dynamic walk: the wavefronts of an XCD draw chunks of CH consecutive wave blocks from that XCD's counter, so the XCD's
+    // eighth of the blocks is consumed IN ORDER by all its wavefronts (a static persistent walk lets workgroups drift many
+    // bands apart, and the union of their windows no longer fits the L2)
+    const bool dyn = a.swizzle == 3;
+    constexpr int CH = 4;
+    const int64_t bpx = (a.nwb + 7) >> 3;
+    const int64_t xbase = (int64_t)xcd * bpx, xend = (xbase + bpx) < a.nwb ? (xbase + bpx) : a.nwb;
+    int64_t ci0 = 0, ck0 = a.nwb, ck1 = a.nwb;
+    auto grab = [&]() -> int64_t {
+        unsigned long long c = 0;
+        if (lane == 0) c = atomicAdd(a.ctr + xcd * 16, (unsigned long long)CH);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)c), hi = __builtin_amdgcn_readfirstlane((uint32_t)(c >> 32));
+        return xbase + (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    if (dyn) {
+        ck0 = grab();
+        ck1 = grab();
+    }
     // descriptors come through the scalar cache (explicit s_load: the compiler would use a vector load + full wait because
     // the kernel also stores); an out-of-range block reads descriptor nwb, an empty block appended by the builder
     typedef int v4i __attribute__((ext_vector_type(4)));
     auto load_desc = [&](int64_t lb) -> v4i {
         int64_t w = a.nwb;
-        if (lb < per_xcd) {
+        if (dyn) {
+            const int64_t st = (lb / CH) == ci0 ? ck0 : ck1;
+            const int64_t wd_ = st + lb % CH;
+            w = wd_ < xend ? wd_ : a.nwb;
+        } else if (lb < per_xcd) {
             const int64_t unit = unit_of(lb, per_xcd, chunk, xcd, a.swizzle);
             w = unit * 4 + wv;
             if (w > a.nwb) w = a.nwb;
@@ -358,10 +381,19 @@ __global__ __launch_bounds__(256) void k_wave2(WArgs a)
     auto issue = [&](const WDesc &d, int (&c)[8], d2 (&v)[8], Ops &o) {
         const int n = d.nrn & 0xFFFF, nr = d.nrn >> 16;
         const int nn = (n == 0 || n == 0xFFFF) ? 1 : n;
-        stream_loads8<POL>(a.ja, a.val, d.p0, nn, lane, c, v);
+        if (ABL != 4) stream_loads8<POL>(a.ja, a.val, d.p0, nn, lane, c, v);
         if (ABL == 3) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) c[u] = 0;
+        }
+        if (ABL == 4) {          // gathers kept, value stream not read: 4 B/nnz instead of 20
+            const int nm1 = nn - 1;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = lane + u * 64;
+                c[u] = ntload(a.ja + d.p0 + (i < nn ? i : nm1));
+                v[u] = d2{1.0, 0.25};
+            }
         }
         const int rr = rloc < nr ? rloc : 0;
         o.s = (int)(a.ia[d.r0 + rr] - d.p0);
@@ -388,21 +420,22 @@ __global__ __launch_bounds__(256) void k_wave2(WArgs a)
         }
     };
 
-    int64_t lb = blockIdx.x >> 3;
-    v4i r0 = load_desc(lb), r1 = load_desc(lb + nslot);
+    int64_t lb = dyn ? 0 : (blockIdx.x >> 3);
+    const int64_t step = dyn ? 1 : nslot;
+    v4i r0 = load_desc(lb), r1 = load_desc(lb + step);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r0), "+s"(r1) : : "memory");   // ties the uses of r0/r1 behind the wait
     WDesc d0 = desc_of(r0), d1 = desc_of(r1);
     int cA[8];
     d2 vA[8];
     Ops oA;
     issue(d0, cA, vA, oA);
-    while (lb < per_xcd) {
-        v4i r2 = load_desc(lb + 2 * nslot);
+    while (dyn ? (ck0 + lb % CH < xend) : (lb < per_xcd)) {
+        v4i r2 = load_desc(lb + 2 * step);
         const int n = d0.nrn & 0xFFFF, nr = d0.nrn >> 16;
         d2 xv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            if (ABL == 0) {
+            if (ABL == 0 || ABL == 4) {
                 if constexpr (GPOL < 0) {
                     xv[u] = a.xg[cA[u]];
                 } else {   // gather through a buffer resource over x (< 4 GB) with an explicit cache policy
@@ -488,7 +521,12 @@ __global__ __launch_bounds__(256) void k_wave2(WArgs a)
         d0 = d1;
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r2) : : "memory");
         d1 = desc_of(r2);
-        lb += nslot;
+        lb += step;
+        if (dyn && lb % CH == 0) {          // entering the next chunk: draw the one after it (used two blocks from now at the earliest)
+            ci0 = lb / CH;
+            ck0 = ck1;
+            ck1 = grab();
+        }
     }
     if (a.partials != nullptr) {
 #pragma unroll
@@ -547,10 +585,29 @@ __global__ __launch_bounds__(256) void k_wave3(WArgs a)
     const int64_t chunk = nslot * (a.chunk > 0 ? a.chunk : 1);
     if (a.swizzle == 2) per_xcd = ((per_xcd + chunk - 1) / chunk) * chunk;
 
+    const bool dyn = a.swizzle == 3;          // dynamic ordered walk per XCD (see k_wave2)
+    constexpr int CH = 4;
+    const int64_t bpx = (a.nwb + 7) >> 3;
+    const int64_t xbase = (int64_t)xcd * bpx, xend = (xbase + bpx) < a.nwb ? (xbase + bpx) : a.nwb;
+    int64_t ci0 = 0, ck0 = a.nwb, ck1 = a.nwb;
+    auto grab = [&]() -> int64_t {
+        unsigned long long c = 0;
+        if (lane == 0) c = atomicAdd(a.ctr + xcd * 16, (unsigned long long)CH);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)c), hi = __builtin_amdgcn_readfirstlane((uint32_t)(c >> 32));
+        return xbase + (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    if (dyn) {
+        ck0 = grab();
+        ck1 = grab();
+    }
     typedef int v4i __attribute__((ext_vector_type(4)));
     auto load_desc = [&](int64_t lb) -> v4i {
         int64_t w = a.nwb;
-        if (lb < per_xcd) {
+        if (dyn) {
+            const int64_t st = (lb / CH) == ci0 ? ck0 : ck1;
+            const int64_t wd_ = st + lb % CH;
+            w = wd_ < xend ? wd_ : a.nwb;
+        } else if (lb < per_xcd) {
             const int64_t unit = unit_of(lb, per_xcd, chunk, xcd, a.swizzle);
             w = unit * 4 + wv;
             if (w > a.nwb) w = a.nwb;
@@ -588,16 +645,17 @@ __global__ __launch_bounds__(256) void k_wave3(WArgs a)
         }
     };
 
-    int64_t lb = blockIdx.x >> 3;
-    v4i q0 = load_desc(lb), q1 = load_desc(lb + nslot);
+    int64_t lb = dyn ? 0 : (blockIdx.x >> 3);
+    const int64_t step = dyn ? 1 : nslot;
+    v4i q0 = load_desc(lb), q1 = load_desc(lb + step);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q0), "+s"(q1) : : "memory");
     WDesc d0 = desc_of(q0), d1 = desc_of(q1);
     int cA[8];
     d2 vA[8];
     int roA;
     issue(d0, cA, vA, roA);
-    while (lb < per_xcd) {
-        v4i q2 = load_desc(lb + 2 * nslot);
+    while (dyn ? (ck0 + lb % CH < xend) : (lb < per_xcd)) {
+        v4i q2 = load_desc(lb + 2 * step);
         const bool slow = d0.nrn < 0;
         const int nr = slow ? 0 : (d0.nrn >> 10) & 63;
         const int maxlen = (d0.nrn >> 16) & 1023;
@@ -736,7 +794,12 @@ __global__ __launch_bounds__(256) void k_wave3(WArgs a)
         d0 = d1;
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q2) : : "memory");
         d1 = desc_of(q2);
-        lb += nslot;
+        lb += step;
+        if (dyn && lb % CH == 0) {
+            ci0 = lb / CH;
+            ck0 = ck1;
+            ck1 = grab();
+        }
     }
     if (a.partials != nullptr) {
 #pragma unroll
@@ -964,15 +1027,23 @@ static float run_wave2(WArgs a, int reps, const char *tag)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
+    unsigned long long *ctr = nullptr;
+    CK(hipMalloc(&ctr, 8 * 16 * 8));
+    a.ctr = ctr;
+    CK(hipMemsetAsync(ctr, 0, 8 * 16 * 8));
     k_wave2<TPR, OPS, POL, ABL, GPOL><<<grid, 256>>>(a);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) k_wave2<TPR, OPS, POL, ABL, GPOL><<<grid, 256>>>(a);
+    for (int i = 0; i < reps; ++i) {
+        if (a.swizzle == 3) CK(hipMemsetAsync(ctr, 0, 8 * 16 * 8));
+        k_wave2<TPR, OPS, POL, ABL, GPOL><<<grid, 256>>>(a);
+    }
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipFree(d_part));
+    CK(hipFree(ctr));
     printf("    %-28s pipelined TPR%d occ %d grid %d swz %d: %.3f ms\n", tag, TPR, occ, grid, a.swizzle, ms / reps);
     fflush(stdout);
     return ms / reps;
@@ -990,10 +1061,17 @@ static float run_wave3(WArgs a, int reps, const char *tag)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
+    unsigned long long *ctr = nullptr;
+    CK(hipMalloc(&ctr, 8 * 16 * 8));
+    a.ctr = ctr;
+    CK(hipMemsetAsync(ctr, 0, 8 * 16 * 8));
     k_wave3<OPS, POL, ABL><<<grid, 256>>>(a);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) k_wave3<OPS, POL, ABL><<<grid, 256>>>(a);
+    for (int i = 0; i < reps; ++i) {
+        if (a.swizzle == 3) CK(hipMemsetAsync(ctr, 0, 8 * 16 * 8));
+        k_wave3<OPS, POL, ABL><<<grid, 256>>>(a);
+    }
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms = 0;
@@ -1269,6 +1347,11 @@ int main(int argc, char **argv)
                 if (tiled) k_tile<<<2048, 256>>>(x, xt, n, bd);
                 CK(hipDeviceSynchronize());
                 fprintf(stderr, "[%s] far...\n", pol);
+                unsigned long long *ctr2 = nullptr;
+                CK(hipMalloc(&ctr2, 2 * 8 * 16 * 8));
+                CK(hipMemset(ctr2, 0, 2 * 8 * 16 * 8));
+                f.ctr = ctr2;
+                nc.ctr = ctr2 + 8 * 16;
                 kf<<<1024, 256>>>(f);
                 CK(hipDeviceSynchronize());
                 fprintf(stderr, "[%s] near...\n", pol);
@@ -1309,6 +1392,7 @@ int main(int argc, char **argv)
                 nr = nsave;
             }
             if (want("gpol")) {
+                run_wave2<2, 0, -2, 4, -1>(f, reps, "far ABL4 columns + gathers, no values");
                 run_wave2<2, 0, -2, 0, -1>(f, reps, "far gathers plain");
                 run_wave2<2, 0, -2, 0, 0>(f, reps, "far gathers buffer");
                 run_wave2<2, 0, -2, 0, 1>(f, reps, "far gathers buffer sc0");
@@ -1338,6 +1422,31 @@ int main(int argc, char **argv)
                 run_wave2<2, 0, -2, 3>(f2, reps, "far ABL3 swz2");
                 f2.swizzle = 0;
                 run_wave2<2, 0, -2, 3>(f2, reps, "far ABL3 swz0");
+            }
+            if (want("g3dyn")) {
+                const WArgs fsave = f, nsave = nr;
+                f = with_wd3(f, Lf.wd3);
+                f.swizzle = 3;
+                nr.swizzle = 3;
+                one(k_wave3<0, -2>, k_wave2<2, 2, -2>, [&](WArgs q, int r, int, const char *t) { return run_wave3<0, -2>(q, r, t); },
+                    [&](WArgs q, int r, int, const char *t) { return run_wave2<2, 2, -2>(q, r, t); }, "g3dyn far");
+                nr = with_wd3(nr, Ln.wd3);
+                nr.swizzle = 3;
+                one(k_wave3<0, -2>, k_wave3<2, -2>, [&](WArgs q, int r, int, const char *t) { return run_wave3<0, -2>(q, r, t); },
+                    [&](WArgs q, int r, int, const char *t) { return run_wave3<2, -2>(q, r, t); }, "g3dyn both");
+                f = fsave;
+                nr = nsave;
+            }
+            if (want("dyn")) {
+                const WArgs fsave = f, nsave = nr;
+                f.swizzle = 3;
+                nr.swizzle = 3;
+                POLICY2(-2, 2, "dyn");
+                nr = nsave;
+                nr.swizzle = 2;
+                POLICY2(-2, 2, "dyn");       // far dynamic, near static chunked
+                f = fsave;
+                nr = nsave;
             }
             POLICY2(-2, 2, "p2nt");
             POLICY2(-2, 4, "p4nt");
