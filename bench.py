@@ -714,6 +714,9 @@ def main():
     n = A.dim
     if world == 1:
         A.destroy()          # the extra blocks below build their own operators: give the HBM back first (C4 substitute: 157 GB)
+        torch.cuda.synchronize()
+        time.sleep(3.0)      # the driver returns > 200 GB (CSR + split copy) in the background; host-side calls of the next
+                             # block were seen to stall behind it (0.6 s per step at 11.7 ms per launch) when it started at once
     if world == 1 and not (coded or real_used) and not args.no_fast_path and not args.matrix_free and not args.host_csr and args.order != "reference":
         # the library's default path for this operator (lossless value codes; real operator + real vectors -> packed doubles):
         # same step definition, same K, its own roofline on its own format's bytes
