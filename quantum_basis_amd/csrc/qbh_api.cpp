@@ -400,7 +400,7 @@ int kron_build(qbh_csr *A)
         int64_t maxlen = 0;
         KRON_HIP(hipMemcpyAsync(&maxlen, A->d_scal, sizeof(int64_t), hipMemcpyDeviceToHost, s));
         KRON_HIP(hipStreamSynchronize(s));
-        const int64_t window = (maxlen <= 256) ? 512 - (maxlen > 0 ? maxlen - 1 : 0) : 256;
+        const int64_t window = (maxlen <= 256) ? 505 - (maxlen > 0 ? maxlen - 1 : 0) : 249;
         const int64_t n_wb = std::max<int64_t>(1, (nnz + window - 1) / window);
         qbh::WaveDesc *wd = nullptr;
         KRON_HIP(hipMalloc(&wd, (size_t)(n_wb + 2) * sizeof(qbh::WaveDesc)));
@@ -435,7 +435,8 @@ int setup_wave_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, qbh::WaveD
     QBH_HIP(hipStreamSynchronize(s));
     // a block holds the rows that START inside its window: window + maxlen - 1 <= 512 when rows are short; rows longer
     // than half a tile make some blocks exceed it and those take the row-at-a-time path of the kernel
-    const int64_t window = (maxlen <= 256) ? 512 - (maxlen > 0 ? maxlen - 1 : 0) : 256;
+    // (7 slots of the tile are kept free: the kernel reads the stream from the 128-byte boundary below the block)
+    const int64_t window = (maxlen <= 256) ? 505 - (maxlen > 0 ? maxlen - 1 : 0) : 249;
     const int64_t n_wb = std::max<int64_t>(1, (nnz + window - 1) / window);
     QBH_HIP(hipMalloc(d_wd_o, (size_t)(n_wb + 2) * sizeof(qbh::WaveDesc)));
     QBH_TRY(qbh::launch_build_wavedesc(d_ia, A->nrows, window, *d_wd_o, n_wb, s));

@@ -616,15 +616,19 @@ __global__ __launch_bounds__(kBlock) void k_spmv_wave(SpmvArgs a)
         if constexpr (dyn) dw.advance(lb, lane);
         dq = load_desc(lb);                                                 // next block's descriptors, used one trip later
         if (nr <= 0) continue;
-        const int64_t nlong = p1 - p0;
+        // the stream is read from the 128-byte boundary below the block's first value (8 entries): every 1 KB value load then
+        // covers exactly 8 lines instead of 9, the tile holds sh + n <= 512 entries (the builder leaves the room)
+        const int sh = (int)(p0 & 7);
+        const int64_t base = p0 - sh;
+        const int64_t nlong = p1 - base;
         if (nlong <= NW) {
             const int n = (int)nlong;
             // first pass row offsets + epilogue operands: requested before the streams, consumed last
             int s0 = 0, e0 = 0;
             d2 yo = {0.0, 0.0}, xi = {0.0, 0.0};
             if (rloc < nr) {
-                s0 = (int)(a.ia[r0 + rloc] - p0);
-                e0 = (int)(a.ia[r0 + rloc + 1] - p0);
+                s0 = (int)(a.ia[r0 + rloc] - base);
+                e0 = (int)(a.ia[r0 + rloc + 1] - base);
                 if (sub == 0) {
                     if (need_y) yo = a.y[r0 + rloc];
                     if (need_x) xi = a.xl[r0 + rloc];
@@ -637,12 +641,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv_wave(SpmvArgs a)
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int i = lane + u * 64;
-                    c[u] = ntload(a.ja + p0 + (i < n ? i : nm1)) & a.colmask;
+                    c[u] = ntload(a.ja + base + (i < n ? i : nm1)) & a.colmask;
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int i = lane + u * 64;
-                    v[u] = ntload(a.val + p0 + (i < n ? i : nm1));
+                    v[u] = ntload(a.val + base + (i < n ? i : nm1));
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) xv[u] = a.xg[c[u]];
@@ -656,8 +660,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_wave(SpmvArgs a)
                 if (rbase > 0) {
                     s = e = 0;
                     if (row < nr) {
-                        s = (int)(a.ia[r0 + row] - p0);
-                        e = (int)(a.ia[r0 + row + 1] - p0);
+                        s = (int)(a.ia[r0 + row] - base);
+                        e = (int)(a.ia[r0 + row + 1] - base);
                     }
                 }
                 d2 sum = {0.0, 0.0};
@@ -780,8 +784,12 @@ int launch_build_wavedesc(const int64_t *d_ia, int64_t nrows, int64_t window, Wa
 // compiler's s_waitcnt counts are then exact.  Descriptors are fetched two blocks ahead.
 // OPS 0: plain store of the row sums (far pass; y is the far buffer, rows are far rows)
 // OPS 2: fused epilogue, the far result of the row added first (read at the row's tiled index)
+// wavefronts per SIMD of the near pass: 2 = 204 VGPRs, no spill; 3 = 168 VGPRs with 17 spilled (measured: see DESIGN 4.1c)
+#ifndef QBH_NEAR_WAVES
+#define QBH_NEAR_WAVES 2
+#endif
 template <int TPR, int OPS, bool DYN>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0 ? 3 : 2, OPS == 0 ? 3 : 2))) void k_spmv_wave2(SpmvArgs a)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0 ? 3 : QBH_NEAR_WAVES, OPS == 0 ? 3 : QBH_NEAR_WAVES))) void k_spmv_wave2(SpmvArgs a)
 {
     constexpr int NW = 512, RP = 64 / TPR;
     __shared__ d2 prod_s[4 * NW];
@@ -809,14 +817,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0
     };
     const int64_t step = dyn ? 1 : walk.nslot;
     struct Blk {
-        int64_t p0;
-        int r0, nr, n;           // n = -1: a row longer than the tile (row-at-a-time path)
+        int64_t p0;              // the 128-byte boundary below the block's first value (the stream is read from there: 8 lines per
+                                 // 1 KB value load instead of 9); row offsets are taken relative to it
+        int r0, nr, n;           // n = entries from p0 to the block's end; -1: a row longer than the tile (row-at-a-time path)
     };
     auto decode = [&](int dq) -> Blk {
         const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane(dq, 0), q1 = (uint32_t)__builtin_amdgcn_readlane(dq, 1);
         const uint32_t q4 = (uint32_t)__builtin_amdgcn_readlane(dq, 4), q5 = (uint32_t)__builtin_amdgcn_readlane(dq, 5);
         Blk b;
-        b.p0 = (int64_t)(((uint64_t)q1 << 32) | q0);
+        const int64_t pfirst = (int64_t)(((uint64_t)q1 << 32) | q0);
+        b.p0 = pfirst - (pfirst & 7);
         const int64_t p1 = (int64_t)(((uint64_t)q5 << 32) | q4);
         b.r0 = __builtin_amdgcn_readlane(dq, 2);
         b.nr = __builtin_amdgcn_readlane(dq, 6) - b.r0;
@@ -848,7 +858,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0
         o.s = (int)(a.ia[row] - base);
         o.e = (int)(a.ia[row + 1] - base);
         if (!mine) o.s = o.e = 0;
+    };
+    // epilogue operands of the CURRENT block's first pass: issued after its gathers and before the next block's stream (they
+    // are not carried across a block as a second register set; the wait for the gathers still leaves them in flight)
+    auto issue_ops = [&](const Blk &b, Ops &o) {
         if (OPS == 2) {
+            const int64_t row = rloc < b.nr ? (int64_t)b.r0 + rloc : 0;
             o.yo = a.y[row];
             o.xi = a.xl[row];
             o.fr = a.far[kt.tile(row)];
@@ -880,6 +895,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0
         d2 xv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) xv[u] = a.xg[cA[u]];
+        issue_ops(b0, oA);
         __builtin_amdgcn_sched_barrier(0);      // the gathers go out BEFORE the next block's stream (in-order return)
         int cB[8];
         d2 vB[8];
@@ -940,7 +956,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0
             cA[u] = cB[u];
             vA[u] = vB[u];
         }
-        oA = oB;
+        oA.s = oB.s;
+        oA.e = oB.e;
         b0 = b1;
         b1 = decode(dq2);
         lb += step;
