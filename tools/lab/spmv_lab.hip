@@ -1408,6 +1408,20 @@ int main(int argc, char **argv)
                 f4.swizzle = 2;
                 run_wave3<0, -2, 0>(f4, reps, "far g3 full swz2");
             }
+            if (want("abldyn")) {      // the same ablation under the dynamic ordered walk (gather misses out of the way)
+                WArgs fd = f;
+                fd.swizzle = 3;
+                run_wave2<2, 0, -2, 0>(fd, reps, "far dyn ABL0 full");
+                run_wave2<2, 0, -2, 1>(fd, reps, "far dyn ABL1 no gathers");
+                run_wave2<2, 0, -2, 2>(fd, reps, "far dyn ABL2 stream only");
+                run_wave2<2, 0, -2, 3>(fd, reps, "far dyn ABL3 values only");
+                run_wave2<2, 0, -2, 4>(fd, reps, "far dyn ABL4 columns + gathers");
+                WArgs nd = nr;
+                nd.swizzle = 3;
+                run_wave2<2, 2, -2, 0>(nd, reps, "near dyn ABL0 full");
+                run_wave2<2, 2, -2, 1>(nd, reps, "near dyn ABL1 no gathers");
+                run_wave2<2, 2, -2, 2>(nd, reps, "near dyn ABL2 stream only");
+            }
             if (want("abl")) {
                 run_wave2<2, 0, -2, 0>(f, reps, "far ABL0 full");
                 run_wave2<2, 0, -2, 1>(f, reps, "far ABL1 no gathers");
