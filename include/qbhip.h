@@ -147,6 +147,7 @@ typedef struct qbh_csr_info {
     int64_t kron_minor;                      /* Kronecker split active (qbh_opts.kron_split): minor size S, else 0  */
     int64_t kron_far_nnz;                    /* nonzeros of the far part (band-major)                               */
     int     kron_band;                       /* band width of the tiling                                            */
+    int     kron_sliced;                     /* 1: far part interleaved inside groups of 8 rows (one x line per 8 lanes) */
 } qbh_csr_info;
 int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info);
 

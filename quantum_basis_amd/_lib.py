@@ -40,7 +40,7 @@ class CsrInfo(C.Structure):
                 ("nnz", C.c_int64), ("n_blocks", C.c_int64), ("bytes_matrix", C.c_int64),
                 ("bytes_algorithmic", C.c_int64), ("kernel", C.c_int), ("value_dict", C.c_int),
                 ("device", C.c_int), ("stream", C.c_void_p), ("create_ms", C.c_double),
-                ("create_bytes_in", C.c_int64), ("kron_minor", C.c_int64), ("kron_far_nnz", C.c_int64), ("kron_band", C.c_int)]
+                ("create_bytes_in", C.c_int64), ("kron_minor", C.c_int64), ("kron_far_nnz", C.c_int64), ("kron_band", C.c_int), ("kron_sliced", C.c_int)]
 
 
 class LanczosRow(C.Structure):

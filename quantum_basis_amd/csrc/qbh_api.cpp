@@ -378,40 +378,83 @@ int kron_build(qbh_csr *A)
     KRON_HIP(hipMalloc(&K.ia_f, (size_t)(n + 1) * sizeof(int64_t)));
     KRON_TRY(qbh::exclusive_scan(cn, n, K.ia_n, s));
     KRON_TRY(qbh::exclusive_scan(cf, n, K.ia_f, s));
+    KRON_HIP(hipMemcpy(&K.nnz_n, K.ia_n + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+    KRON_HIP(hipMemcpy(&K.nnz_f, K.ia_f + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (K.nnz_f == 0 || K.nnz_n + K.nnz_f != A->nnz) return fail(QBH_OK);       // nothing far: the split buys nothing
+    // Sliced far part: the 8 far rows of a (band, major index) pair hold the SAME major-index moves in the same order, so
+    // interleaving them entry by entry makes every 8 consecutive stream elements one 128-byte line of the tiled x.  Groups
+    // are padded to their longest row (none for a product operator: only at ragged band edges); kept while the padding
+    // stays under 1/8 of the far entries and a group fits the wave tile.
+    K.sliced = false;
+    K.n_groups = (n + 7) / 8;
+    K.far_slots = K.nnz_f;
+    int want_sliced = 1;                             // QBH_KRON_SLICED: 0 never, 1 when the padding is small, 2 whenever a group fits
+    if (const char *e = getenv("QBH_KRON_SLICED")) want_sliced = atoi(e);
+    if (want_sliced && B == 8) {
+        int32_t *gw = nullptr;
+        int64_t *gia = nullptr;
+        KRON_HIP(hipMalloc(&gw, (size_t)K.n_groups * sizeof(int32_t)));
+        int rc = qbh::launch_kron_group_width(cf, n, K.n_groups, gw, s);
+        hipError_t he = rc == QBH_OK ? hipMalloc(&gia, (size_t)(K.n_groups + 1) * sizeof(int64_t)) : hipSuccess;
+        if (rc == QBH_OK && he == hipSuccess) rc = qbh::exclusive_scan(gw, K.n_groups, gia, s);
+        int64_t slots = 0, maxgw = 0;
+        if (rc == QBH_OK && he == hipSuccess) he = hipMemcpy(&slots, gia + K.n_groups, sizeof(int64_t), hipMemcpyDeviceToHost);
+        if (rc == QBH_OK && he == hipSuccess) rc = qbh::launch_max_rowlen(gia, K.n_groups, (int64_t *)A->d_scal, s);
+        if (rc == QBH_OK && he == hipSuccess) he = hipMemcpyAsync(&maxgw, A->d_scal, sizeof(int64_t), hipMemcpyDeviceToHost, s);
+        if (rc == QBH_OK && he == hipSuccess) he = hipStreamSynchronize(s);
+        (void)hipFree(gw);
+        if (rc != QBH_OK || he != hipSuccess) {
+            if (gia) (void)hipFree(gia);
+            (void)hipGetLastError();
+            return fail(rc != QBH_OK ? rc : he == hipErrorOutOfMemory ? QBH_OK : QBH_EHIP);
+        }
+        if ((want_sliced == 2 || slots - K.nnz_f <= K.nnz_f / 8) && maxgw <= 504 && slots < ((int64_t)1 << 40)) {
+            (void)hipFree(K.ia_f);
+            K.ia_f = gia;
+            K.sliced = true;
+            K.far_slots = slots;
+        } else {
+            (void)hipFree(gia);
+        }
+    }
     (void)hipFree(cn);
     cn = nullptr;
     (void)hipFree(cf);
     cf = nullptr;
-    KRON_HIP(hipMemcpy(&K.nnz_n, K.ia_n + n, sizeof(int64_t), hipMemcpyDeviceToHost));
-    KRON_HIP(hipMemcpy(&K.nnz_f, K.ia_f + n, sizeof(int64_t), hipMemcpyDeviceToHost));
-    if (K.nnz_f == 0 || K.nnz_n + K.nnz_f != A->nnz) return fail(QBH_OK);       // nothing far: the split buys nothing
     KRON_HIP(hipMalloc(&K.ja_n, std::max<size_t>((size_t)K.nnz_n, 1) * sizeof(int32_t)));
-    KRON_HIP(hipMalloc(&K.ja_f, (size_t)K.nnz_f * sizeof(int32_t)));
+    KRON_HIP(hipMalloc(&K.ja_f, (size_t)K.far_slots * sizeof(int32_t)));
     KRON_HIP(hipMalloc(&K.val_n, std::max<size_t>((size_t)K.nnz_n, 1) * sizeof(d2)));
-    KRON_HIP(hipMalloc(&K.val_f, (size_t)K.nnz_f * sizeof(d2)));
-    KRON_TRY(qbh::launch_kron_fill(A->d_ia, A->d_ja, A->d_val, n, K.t, K.ia_n, K.ja_n, K.val_n, K.ia_f, K.ja_f, K.val_f, s));
+    KRON_HIP(hipMalloc(&K.val_f, (size_t)K.far_slots * sizeof(d2)));
+    if (K.sliced)
+        KRON_TRY(qbh::launch_kron_fill_sliced(A->d_ia, A->d_ja, A->d_val, n, K.t, K.ia_n, K.ja_n, K.val_n, K.ia_f, K.n_groups, K.ja_f, K.val_f, s));
+    else
+        KRON_TRY(qbh::launch_kron_fill(A->d_ia, A->d_ja, A->d_val, n, K.t, K.ia_n, K.ja_n, K.val_n, K.ia_f, K.ja_f, K.val_f, s));
     KRON_HIP(hipMalloc(&K.d_xt, (size_t)n * sizeof(d2)));
     KRON_HIP(hipMalloc(&K.d_far, (size_t)n * sizeof(d2)));
     // wave-block geometry of the two parts (pipelined kernel)
     for (int part = 0; part < 2; ++part) {
+        const bool sl = part && K.sliced;                    // sliced far part: blocks of whole groups, ia_f = group pointers
         const int64_t *ia = part ? K.ia_f : K.ia_n;
-        const int64_t nnz = part ? K.nnz_f : K.nnz_n;
-        KRON_TRY(qbh::launch_max_rowlen(ia, n, (int64_t *)A->d_scal, s));
+        const int64_t nnz = part ? K.far_slots : K.nnz_n;
+        const int64_t nr = sl ? K.n_groups : n;
+        KRON_TRY(qbh::launch_max_rowlen(ia, nr, (int64_t *)A->d_scal, s));
         int64_t maxlen = 0;
         KRON_HIP(hipMemcpyAsync(&maxlen, A->d_scal, sizeof(int64_t), hipMemcpyDeviceToHost, s));
         KRON_HIP(hipStreamSynchronize(s));
-        const int64_t window = (maxlen <= 256) ? 505 - (maxlen > 0 ? maxlen - 1 : 0) : 249;
+        // sliced: blocks are 512 consecutive slots of the stream, whatever the groups (cut groups are added atomically)
+        const int64_t window = sl ? 512 : (maxlen <= 256) ? 505 - (maxlen > 0 ? maxlen - 1 : 0) : 249;
         const int64_t n_wb = std::max<int64_t>(1, (nnz + window - 1) / window);
         qbh::WaveDesc *wd = nullptr;
         KRON_HIP(hipMalloc(&wd, (size_t)(n_wb + 2) * sizeof(qbh::WaveDesc)));
         (part ? K.wd_f : K.wd_n) = wd;
-        KRON_TRY(qbh::launch_build_wavedesc(ia, n, window, wd, n_wb, s));
-        const double avg = (double)nnz / (double)n;
+        if (sl) KRON_TRY(qbh::launch_build_slotdesc(ia, nr, nnz, wd, n_wb, s));
+        else    KRON_TRY(qbh::launch_build_wavedesc(ia, nr, window, wd, n_wb, s));
+        const double avg = (double)(part ? K.nnz_f : K.nnz_n) / (double)n;
         const int tpr = avg <= 32 ? 2 : avg <= 64 ? 4 : 8;
         int ncu = 256;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, A->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-        const int occ = std::max(1, qbh::wave2_kernel_occupancy(tpr, part ? 0 : 2));
+        const int occ = std::max(1, qbh::wave2_kernel_occupancy(tpr, part ? (sl ? 3 : 0) : 2));
         int64_t g = std::min<int64_t>((int64_t)occ * ncu, ((((n_wb + 3) >> 2) + 7) / 8) * 8);
         g = std::max<int64_t>(8, (g / 8) * 8);
         (part ? K.nwb_f : K.nwb_n) = n_wb;
@@ -1012,6 +1055,7 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->kron_minor = A->kron.active ? A->kron.t.S : 0;
     info->kron_far_nnz = A->kron.active ? A->kron.nnz_f : 0;
     info->kron_band = A->kron.active ? A->kron.t.B : 0;
+    info->kron_sliced = A->kron.active && A->kron.sliced ? 1 : 0;
     return QBH_OK;
 }
 
@@ -1345,7 +1389,9 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         f.partials = nullptr;
         f.swizzle = kron_swz == 3 ? 3 : 1;      // one contiguous eighth of the bands per XCD: a band of x stays in that XCD's L2
         f.wctr = A->d_wctr + 128;
-        QBH_TRY(qbh::launch_spmv_wave2(f, K.tpr_f, 0, K.grid_f, A->stream));
+        f.nrows = A->nrows;                       // sliced: the last group may reach past the last far row
+        if (K.sliced) QBH_TRY(qbh::launch_zero_cut_groups(K.wd_f, K.nwb_f, A->nrows, K.d_far, A->stream));
+        QBH_TRY(qbh::launch_spmv_wave2(f, K.tpr_f, K.sliced ? 3 : 0, K.grid_f, A->stream));
         qbh::SpmvArgs nr = a;
         nr.ia = K.ia_n;
         nr.ja = K.ja_n;

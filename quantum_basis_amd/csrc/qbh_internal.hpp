@@ -116,6 +116,11 @@ int wave2_kernel_occupancy(int tpr, int ops);
 int launch_kron_tile(const d2 *x, d2 *xt, int64_t n, const KronTile &t, hipStream_t s);
 int launch_kron_check(const int64_t *ia, const int32_t *ja, int64_t nrows, int64_t S, int *d_flag, hipStream_t s);
 int launch_kron_count(const int64_t *ia, const int32_t *ja, int64_t nrows, const KronTile &t, int32_t *cnt_near, int32_t *cnt_far, hipStream_t s);
+int launch_build_slotdesc(const int64_t *gia, int64_t ngroups, int64_t slots, WaveDesc *wd, int64_t n_wb, hipStream_t s);
+int launch_zero_cut_groups(const WaveDesc *wd, int64_t n_wb, int64_t nrows, d2 *far, hipStream_t s);
+int launch_kron_group_width(const int32_t *cnt_far, int64_t nrows, int64_t ngroups, int32_t *gw, hipStream_t s);
+int launch_kron_fill_sliced(const int64_t *ia, const int32_t *ja, const d2 *val, int64_t nrows, const KronTile &t, const int64_t *ia_n,
+                            int32_t *ja_n, d2 *val_n, const int64_t *gia, int64_t ngroups, int32_t *ja_f, d2 *val_f, hipStream_t s);
 int launch_kron_fill(const int64_t *ia, const int32_t *ja, const d2 *val, int64_t nrows, const KronTile &t, const int64_t *ia_n, int32_t *ja_n,
                      d2 *val_n, const int64_t *ia_f, int32_t *ja_f, d2 *val_f, hipStream_t s);
 int wave_kernel_occupancy(int tpr);
@@ -352,6 +357,8 @@ struct qbh_csr {
         bool     active = false;
         qbh::KronTile t{0, 0, 8};
         int64_t  nnz_n = 0, nnz_f = 0;
+        bool     sliced = false;        // far part interleaved inside groups of 8 rows (ia_f = group pointers, n_groups + 1 entries)
+        int64_t  n_groups = 0, far_slots = 0;   // far_slots = entries stored in the far arrays (nnz_f + padding)
         int64_t *ia_n = nullptr, *ia_f = nullptr;
         int32_t *ja_n = nullptr, *ja_f = nullptr;
         qbh::d2 *val_n = nullptr, *val_f = nullptr;

@@ -102,15 +102,20 @@ struct BlockWalk {
 // dispatch order puts those workgroups on one XCD; if it did not, only the locality would suffer).
 constexpr int kDynChunk = 4;
 struct DynWalk {
-    int64_t xbase, xend, ck_even, ck_odd, n_wb;
-    unsigned long long *ctr;
-    __device__ int64_t grab(int lane)
+    // cur: first block of the chunk the wavefront is in (turns n0 .. n0 + kDynChunk - 1); nxt: of the chunk after it.  The
+    // counter is asked (ask) in the first turn of a chunk BEFORE that turn's gathers and read (take) after they have been
+    // waited for: results return in order, so the reply costs no wait of its own and never drains the stream loads issued
+    // behind it.  (An atomic add would be rewritten by the compiler into a wave reduction that reads the reply at once;
+    // the wrapping increment is left alone, and the counter counts chunks.)
+    int64_t xbase, xend, n_wb, cur, nxt, n0;
+    unsigned int *ctr;
+    __device__ unsigned int ask(int lane) const
     {
-        unsigned long long c = 0;
-        if (lane == 0) c = atomicAdd(ctr, (unsigned long long)kDynChunk);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)c), hi = __builtin_amdgcn_readfirstlane((uint32_t)(c >> 32));
-        return xbase + (int64_t)(((uint64_t)hi << 32) | lo);
+        unsigned int c = 0;
+        if (lane == 0) c = atomicInc(ctr, 0xFFFFFFFFu);
+        return c;
     }
+    __device__ int64_t take(unsigned int c) const { return xbase + (int64_t)__builtin_amdgcn_readfirstlane(c) * kDynChunk; }
     __device__ void init(int64_t n_blocks, unsigned long long *counters, int lane)
     {
         n_wb = n_blocks;
@@ -118,23 +123,26 @@ struct DynWalk {
         const int64_t per = (n_blocks + 7) >> 3;
         xbase = xcd * per;
         xend = xbase + per < n_blocks ? xbase + per : n_blocks;
-        ctr = counters + xcd * 16;
-        ck_even = grab(lane);
-        ck_odd = grab(lane);
+        ctr = reinterpret_cast<unsigned int *>(counters + xcd * 16);
+        cur = take(ask(lane));
+        nxt = xend;
+        n0 = 0;
     }
-    // wave block of this wavefront's n-th turn (n in the current or the next chunk); n_wb = the sentinel (past the end)
+    __device__ bool asks(int64_t n) const { return n == n0; }        // the turn that draws the next chunk
+    __device__ int64_t at(int64_t n) const { return (n < n0 + kDynChunk ? cur : nxt) + n % kDynChunk; }
+    // wave block of this wavefront's n-th turn (n = the current turn .. two turns ahead); n_wb = the sentinel (past the end)
     __device__ int64_t block(int64_t n) const
     {
-        const int64_t w = (((n / kDynChunk) & 1) ? ck_odd : ck_even) + n % kDynChunk;
+        const int64_t w = at(n);
         return w < xend ? w : n_wb;
     }
-    __device__ bool live(int64_t n) const { return (((n / kDynChunk) & 1) ? ck_odd : ck_even) + n % kDynChunk < xend; }
-    // after moving on to turn n: entering a chunk draws the one after it (needed two turns later at the earliest)
-    __device__ void advance(int64_t n, int lane)
+    __device__ bool live(int64_t n) const { return at(n) < xend; }
+    // after moving on to turn n
+    __device__ void advance(int64_t n)
     {
         if (n % kDynChunk == 0) {
-            if ((n / kDynChunk) & 1) ck_even = grab(lane);
-            else                     ck_odd = grab(lane);
+            cur = nxt;
+            n0 = n;
         }
     }
 };
@@ -612,8 +620,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv_wave(SpmvArgs a)
         const int r0 = __builtin_amdgcn_readlane(dq, 2), nr = __builtin_amdgcn_readlane(dq, 6) - r0;
         const int64_t p0 = (int64_t)(((uint64_t)q1 << 32) | q0);
         const int64_t p1 = (int64_t)(((uint64_t)q5 << 32) | q4);
+        if constexpr (dyn) {
+            if (dw.asks(lb)) dw.nxt = dw.take(dw.ask(lane));
+        }
         lb += step;
-        if constexpr (dyn) dw.advance(lb, lane);
+        if constexpr (dyn) dw.advance(lb);
         dq = load_desc(lb);                                                 // next block's descriptors, used one trip later
         if (nr <= 0) continue;
         // the stream is read from the 128-byte boundary below the block's first value (8 entries): every 1 KB value load then
@@ -783,13 +794,18 @@ int launch_build_wavedesc(const int64_t *d_ia, int64_t nrows, int64_t window, Wa
 // while the previous block is reduced).  Every load of the steady state is unconditional (clamped addresses): the
 // compiler's s_waitcnt counts are then exact.  Descriptors are fetched two blocks ahead.
 // OPS 0: plain store of the row sums (far pass; y is the far buffer, rows are far rows)
+// OPS 3: the same for the far part stored SLICED: inside every group of 8 consecutive far rows the entries are interleaved
+//        (entry k of rows 8g..8g+7 contiguous, the group padded to its longest row -- no padding where the 8 rows are the
+//        8 minor indices of one major index), so the coalesced stream ALREADY has consecutive lanes on consecutive rows with
+//        the same entry number: every gather instruction reads full 128-byte lines of the tiled x.  ia holds the group
+//        pointers, the descriptor's row fields count groups.
 // OPS 2: fused epilogue, the far result of the row added first (read at the row's tiled index)
 // wavefronts per SIMD of the near pass: 2 = 204 VGPRs, no spill; 3 = 168 VGPRs with 17 spilled (measured: see DESIGN 4.1c)
 #ifndef QBH_NEAR_WAVES
 #define QBH_NEAR_WAVES 2
 #endif
 template <int TPR, int OPS, bool DYN>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0 ? 3 : QBH_NEAR_WAVES, OPS == 0 ? 3 : QBH_NEAR_WAVES))) void k_spmv_wave2(SpmvArgs a)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS != 2 ? 3 : QBH_NEAR_WAVES, OPS != 2 ? 3 : QBH_NEAR_WAVES))) void k_spmv_wave2(SpmvArgs a)
 {
     constexpr int NW = 512, RP = 64 / TPR;
     __shared__ d2 prod_s[4 * NW];
@@ -821,6 +837,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0
                                  // 1 KB value load instead of 9); row offsets are taken relative to it
         int r0, nr, n;           // n = entries from p0 to the block's end; -1: a row longer than the tile (row-at-a-time path)
     };
+    // OPS 3: a block is 512 consecutive SLOTS of the sliced stream whatever the groups are (descriptor: first slot, first
+    // group that overlaps, pad = 1 when that group began in the previous block); a group cut by a block boundary gets its
+    // row sums from both blocks by atomic add into rows zeroed before the pass (two addends: the result does not depend
+    // on their order), every other row a plain store
     auto decode = [&](int dq) -> Blk {
         const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane(dq, 0), q1 = (uint32_t)__builtin_amdgcn_readlane(dq, 1);
         const uint32_t q4 = (uint32_t)__builtin_amdgcn_readlane(dq, 4), q5 = (uint32_t)__builtin_amdgcn_readlane(dq, 5);
@@ -830,12 +850,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0
         const int64_t p1 = (int64_t)(((uint64_t)q5 << 32) | q4);
         b.r0 = __builtin_amdgcn_readlane(dq, 2);
         b.nr = __builtin_amdgcn_readlane(dq, 6) - b.r0;
+        if (OPS == 3) b.nr += __builtin_amdgcn_readlane(dq, 7) & 1;
         b.n = (p1 - b.p0) <= NW ? (int)(p1 - b.p0) : -1;
         return b;
     };
     struct Ops {
-        int s, e;
+        int s, e;                // OPS 3: s = the group pointer of group `lane` of the block, relative to the block's first slot
         d2 yo, xi, fr;
+    };
+    // OPS 3: a block overlaps at most 64 groups (a group holds 8 slots or more), so ONE load per lane, issued with the block's
+    // stream, brings every group pointer the block needs; the reduction passes read them by cross-lane moves.  (A load
+    // issued later would have to be waited for with the whole next stream in front of it: results return in order.)
+    auto group_range = [&](const Blk &b, int gp, int row, int &s_, int &e_, bool &clip) {     // row = 8 * group + j inside the block
+        const int gi = row >> 3;
+        const int gs = __shfl(gp, gi & 63, 64);
+        int ge = __shfl(gp, (gi + 1) & 63, 64);
+        if (gi + 1 >= 64) ge = b.n;
+        clip = gs < 0 || ge > b.n;
+        s_ = (gs < 0 ? 0 : gs) + (row & 7);
+        e_ = ge > b.n ? b.n : ge;
     };
     // stream + first-pass operands of a block; an empty / oversized block reads entry 0 of its range (clamped)
     auto issue = [&](const Blk &b, int (&c)[8], d2 (&v)[8], Ops &o) {
@@ -853,11 +886,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0
             const int i = lane + u * 64;
             v[u] = ntload(a.val + base + (i < nn ? i : nm1));
         }
-        const bool mine = rloc < b.nr;
-        const int64_t row = mine ? (int64_t)b.r0 + rloc : 0;
-        o.s = (int)(a.ia[row] - base);
-        o.e = (int)(a.ia[row + 1] - base);
-        if (!mine) o.s = o.e = 0;
+        if (OPS == 3) {
+            const int64_t ng = (a.nrows + 7) >> 3;
+            int64_t g = (int64_t)b.r0 + lane;
+            g = g < ng ? g : ng;
+            int64_t rel = a.ia[g] - base;
+            rel = rel < -4096 ? -4096 : rel > 4096 ? 4096 : rel;
+            o.s = (int)rel;
+            o.e = 0;
+        } else {
+            const bool mine = rloc < b.nr;
+            const int64_t row = mine ? (int64_t)b.r0 + rloc : 0;
+            o.s = (int)(a.ia[row] - base);
+            o.e = (int)(a.ia[row + 1] - base);
+            if (!mine) o.s = o.e = 0;
+        }
     };
     // epilogue operands of the CURRENT block's first pass: issued after its gathers and before the next block's stream (they
     // are not carried across a block as a second register set; the wait for the gathers still leaves them in flight)
@@ -870,8 +913,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0
             if (!need_y) o.yo = d2{0.0, 0.0};
         }
     };
-    auto finish_row = [&](int64_t row, d2 sum, d2 yo, d2 xi, d2 fr) {
-        if (OPS == 0) {
+    auto finish_row = [&](int64_t row, d2 sum, d2 yo, d2 xi, d2 fr, bool clip) {
+        if (OPS == 3) {
+            if (row < a.nrows) {
+                if (clip) {
+                    double *yp = reinterpret_cast<double *>(a.y + row);
+                    unsafeAtomicAdd(yp, sum.x);
+                    unsafeAtomicAdd(yp + 1, sum.y);
+                } else {
+                    a.y[row] = sum;
+                }
+            }
+        } else if (OPS == 0) {
             a.y[row] = sum;
         } else {
             sum += fr;
@@ -892,6 +945,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0
     issue(b0, cA, vA, oA);
     while (dyn ? dw.live(lb) : (lb < walk.per_xcd)) {
         const int dq2 = load_desc(lb + 2 * step);
+        unsigned int reply = 0;
+        bool asking = false;
+        if constexpr (dyn) {
+            asking = dw.asks(lb);
+            if (asking) reply = dw.ask(lane);        // in front of the gathers: answered by the time they are
+        }
         d2 xv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) xv[u] = a.xg[cA[u]];
@@ -906,13 +965,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0
 #pragma unroll
             for (int u = 0; u < 8; ++u) prod[lane + u * 64] = cmul(vA[u], xv[u]);
             wave_lds_fence();
-            for (int rbase = 0; rbase < b0.nr; rbase += RP) {
+            constexpr int RSTRIDE = OPS == 3 ? 8 : 1;                  // distance of a row's consecutive entries in the tile
+            const int nrows_blk = OPS == 3 ? 8 * b0.nr : b0.nr;
+            for (int rbase = 0; rbase < nrows_blk; rbase += RP) {
                 const int row = rbase + rloc;
                 int s_ = oA.s, e_ = oA.e;
+                bool clip = false;
                 d2 yo = oA.yo, xi = oA.xi, fr = oA.fr;
-                if (rbase > 0) {
+                if (OPS == 3) {
+                    group_range(b0, oA.s, row, s_, e_, clip);        // every lane takes part in the cross-lane moves
+                    if (row >= nrows_blk) s_ = e_ = 0;
+                } else if (rbase > 0) {
                     s_ = e_ = 0;
-                    if (row < b0.nr) {
+                    if (row < nrows_blk) {
                         s_ = (int)(a.ia[b0.r0 + row] - b0.p0);
                         e_ = (int)(a.ia[b0.r0 + row + 1] - b0.p0);
                         if (OPS == 2 && sub == 0) {
@@ -923,17 +988,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0
                     }
                 }
                 d2 sum = {0.0, 0.0};
-                for (int k = s_ + sub; k < e_; k += TPR) sum += prod[k];
+                for (int k = s_ + sub * RSTRIDE; k < e_; k += TPR * RSTRIDE) sum += prod[k];
 #pragma unroll
                 for (int off = TPR / 2; off > 0; off >>= 1) {
                     sum.x += __shfl_xor(sum.x, off, 64);
                     sum.y += __shfl_xor(sum.y, off, 64);
                 }
-                if (sub == 0 && row < b0.nr) finish_row((int64_t)b0.r0 + row, sum, yo, xi, fr);
+                if (sub == 0 && row < nrows_blk) finish_row(OPS == 3 ? (int64_t)b0.r0 * 8 + row : (int64_t)b0.r0 + row, sum, yo, xi, fr, clip);
             }
             wave_lds_fence();
         } else {
-            for (int r = 0; r < b0.nr; ++r) {     // a row longer than the tile: row at a time (correctness path)
+            for (int r = 0; r < (OPS == 3 ? 0 : b0.nr); ++r) {     // a row longer than the tile: row at a time (correctness path; sliced blocks never exceed the tile)
                 const int64_t row = (int64_t)b0.r0 + r;
                 const int64_t s_ = a.ia[row], e_ = a.ia[row + 1];
                 d2 sum = {0.0, 0.0};
@@ -947,7 +1012,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0
                         xi = a.xl[row];
                         fr = a.far[kt.tile(row)];
                     }
-                    finish_row(row, sum, yo, xi, fr);
+                    finish_row(row, sum, yo, xi, fr, false);
                 }
             }
         }
@@ -960,8 +1025,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS == 0
         oA.e = oB.e;
         b0 = b1;
         b1 = decode(dq2);
+        if constexpr (dyn) {
+            if (asking) dw.nxt = dw.take(reply);
+        }
         lb += step;
-        if constexpr (dyn) dw.advance(lb, lane);
+        if constexpr (dyn) dw.advance(lb);
     }
     if (a.partials != nullptr) {
 #pragma unroll
@@ -999,8 +1067,9 @@ static void launch_wave2_tpr(const SpmvArgs &a, int tpr, int grid, hipStream_t s
 
 int launch_spmv_wave2(const SpmvArgs &a, int tpr, int ops, int grid, hipStream_t s)
 {
-    if (ops == 0) launch_wave2_tpr<0>(a, tpr, grid, s);
-    else          launch_wave2_tpr<2>(a, tpr, grid, s);
+    if (ops == 0)      launch_wave2_tpr<0>(a, tpr, grid, s);
+    else if (ops == 3) launch_wave2_tpr<3>(a, tpr, grid, s);
+    else               launch_wave2_tpr<2>(a, tpr, grid, s);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }
@@ -1021,7 +1090,7 @@ static int occ_wave2(int tpr)
     }
     return occ;
 }
-int wave2_kernel_occupancy(int tpr, int ops) { return ops == 0 ? occ_wave2<0>(tpr) : occ_wave2<2>(tpr); }
+int wave2_kernel_occupancy(int tpr, int ops) { return ops == 0 ? occ_wave2<0>(tpr) : ops == 3 ? occ_wave2<3>(tpr) : occ_wave2<2>(tpr); }
 
 // ---- Kronecker split: tiled copy of x, structure check, count / fill of the two parts ----
 __global__ __launch_bounds__(kBlock) void k_kron_tile(const d2 *x, d2 *xt, int64_t n, KronTile t)
@@ -1095,6 +1164,113 @@ __global__ __launch_bounds__(kBlock) void k_kron_fill(const int64_t *ia, const i
         }
     }
 }
+// sliced far part: slots of a group (8 consecutive far rows) = 8 * (longest far row of the group)
+__global__ __launch_bounds__(kBlock) void k_kron_group_width(const int32_t *cnt_far, int64_t nrows, int64_t ngroups, int32_t *gw)
+{
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * blockDim.x) {
+        int mx = 0;
+        for (int j = 0; j < 8; ++j) {
+            const int64_t f = g * 8 + j;
+            const int c = f < nrows ? cnt_far[f] : 0;
+            mx = c > mx ? c : mx;
+        }
+        gw[g] = 8 * (mx > 0 ? mx : 1);       // an empty group keeps one (padding) slot per row: every row belongs to a block
+    }
+}
+int launch_kron_group_width(const int32_t *cnt_far, int64_t nrows, int64_t ngroups, int32_t *gw, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kron_group_width, dim3(2048), dim3(kBlock), 0, s, cnt_far, nrows, ngroups, gw);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// blocks of the sliced far part: block i = slots [512 i, 512 (i + 1)); r0 = the group that holds its first slot
+__global__ __launch_bounds__(kBlock) void k_build_slotdesc(const int64_t *gia, int64_t ngroups, int64_t slots, WaveDesc *wd, int64_t n_wb)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_wb + 2; i += (int64_t)gridDim.x * blockDim.x) {
+        WaveDesc d;
+        if (i >= n_wb) {
+            d.p0 = slots;
+            d.r0 = (int32_t)ngroups;
+            d.pad = 0;
+        } else {
+            const int64_t P = i * 512;
+            int64_t lo = 0, hi = ngroups;            // first group with gia[g] > P
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (gia[mid] > P) hi = mid;
+                else lo = mid + 1;
+            }
+            d.p0 = P;
+            d.r0 = (int32_t)(lo - 1);
+            d.pad = gia[lo - 1] < P ? 1 : 0;
+        }
+        wd[i] = d;
+    }
+}
+int launch_build_slotdesc(const int64_t *gia, int64_t ngroups, int64_t slots, WaveDesc *wd, int64_t n_wb, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_build_slotdesc, dim3(2048), dim3(kBlock), 0, s, gia, ngroups, slots, wd, n_wb);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// rows of the groups that a block boundary cuts: zero before the far pass adds both parts
+__global__ __launch_bounds__(kBlock) void k_zero_cut_groups(const WaveDesc *wd, int64_t n_wb, int64_t nrows, d2 *far)
+{
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_wb * 8; t += (int64_t)gridDim.x * blockDim.x) {
+        const WaveDesc d = wd[t >> 3];
+        const int64_t row = (int64_t)d.r0 * 8 + (t & 7);
+        if ((d.pad & 1) && row < nrows) far[row] = d2{0.0, 0.0};
+    }
+}
+int launch_zero_cut_groups(const WaveDesc *wd, int64_t n_wb, int64_t nrows, d2 *far, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_zero_cut_groups, dim3(2048), dim3(kBlock), 0, s, wd, n_wb, nrows, far);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// near entries as in k_kron_fill; far entries of far row f = 8g + j go to gia[g] + 8k + j (k-th far entry of the row), the
+// rest of the group's slots are padding: value 0, column = the row's own tiled index (always a valid element of the tiled x)
+__global__ __launch_bounds__(kBlock) void k_kron_fill_sliced(const int64_t *ia, const int32_t *ja, const d2 *val, int64_t nrows, KronTile t,
+                                                             const int64_t *ia_n, int32_t *ja_n, d2 *val_n, const int64_t *gia, int64_t ngroups,
+                                                             int32_t *ja_f, d2 *val_f)
+{
+    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < ngroups * 8; f += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = f >> 3, jj = f & 7;
+        const int64_t gb = gia[g], w = (gia[g + 1] - gb) >> 3;
+        int64_t k = 0;
+        if (f < nrows) {
+            const int64_t r = t.orig(f);
+            const int64_t maj = r / t.S;
+            int64_t pn = ia_n[r];
+            for (int64_t q = ia[r]; q < ia[r + 1]; ++q) {
+                const int32_t c = ja[q];
+                if ((c / t.S) != maj) {
+                    ja_f[gb + 8 * k + jj] = (int32_t)t.tile(c);
+                    val_f[gb + 8 * k + jj] = val[q];
+                    ++k;
+                } else {
+                    ja_n[pn] = c;
+                    val_n[pn++] = val[q];
+                }
+            }
+        }
+        for (; k < w; ++k) {
+            ja_f[gb + 8 * k + jj] = (int32_t)(f < nrows ? f : 0);
+            val_f[gb + 8 * k + jj] = d2{0.0, 0.0};
+        }
+    }
+}
+int launch_kron_fill_sliced(const int64_t *ia, const int32_t *ja, const d2 *val, int64_t nrows, const KronTile &t, const int64_t *ia_n,
+                            int32_t *ja_n, d2 *val_n, const int64_t *gia, int64_t ngroups, int32_t *ja_f, d2 *val_f, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kron_fill_sliced, dim3(4096), dim3(kBlock), 0, s, ia, ja, val, nrows, t, ia_n, ja_n, val_n, gia, ngroups, ja_f, val_f);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
 int launch_kron_fill(const int64_t *ia, const int32_t *ja, const d2 *val, int64_t nrows, const KronTile &t, const int64_t *ia_n, int32_t *ja_n,
                      d2 *val_n, const int64_t *ia_f, int32_t *ja_f, d2 *val_f, hipStream_t s)
 {

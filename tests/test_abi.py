@@ -40,9 +40,9 @@ def test_struct_layouts_match_header():
 #include <stddef.h>
 #include "qbhip.h"
 int main(void) {
-    printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(qbh_z), sizeof(qbh_lanczos_row), sizeof(qbh_opts), sizeof(qbh_stats),
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(qbh_z), sizeof(qbh_lanczos_row), sizeof(qbh_opts), sizeof(qbh_stats),
            sizeof(qbh_csr_info), sizeof(qbh_solver_info), offsetof(qbh_opts, kron_split), offsetof(qbh_opts, kron_minor),
-           offsetof(qbh_csr_info, kron_minor), offsetof(qbh_csr_info, kron_band));
+           offsetof(qbh_csr_info, kron_minor), offsetof(qbh_csr_info, kron_band), offsetof(qbh_csr_info, kron_sliced));
     return 0;
 }
 """
@@ -52,7 +52,7 @@ int main(void) {
         got = [int(t) for t in subprocess.check_output([os.path.join(tmp, "t")], text=True).split()]
     want = [C.sizeof(_lib.Z), C.sizeof(_lib.LanczosRow), C.sizeof(_lib.Opts), C.sizeof(_lib.Stats), C.sizeof(_lib.CsrInfo),
             C.sizeof(_lib.SolverInfo), _lib.Opts.kron_split.offset, _lib.Opts.kron_minor.offset, _lib.CsrInfo.kron_minor.offset,
-            _lib.CsrInfo.kron_band.offset]
+            _lib.CsrInfo.kron_band.offset, _lib.CsrInfo.kron_sliced.offset]
     assert got == want
 
 

@@ -17,8 +17,12 @@ def _rand(n, seed):
     return (rng.normal(size=n) + 1j * rng.normal(size=n)).astype(np.complex128)
 
 
+@pytest.mark.parametrize("sliced", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(4, 2, 4, 4), (4, 3, 6, 6), (4, 3, 5, 7), (4, 3, 7, 2), (3, 3, 4, 5)])
-def test_split_operator_equals_the_unsplit_one(shape):
+def test_split_operator_equals_the_unsplit_one(shape, sliced, monkeypatch):
+    # far part: 0 = row-major inside the bands, 1 = sliced in groups of 8 rows where that costs < 1/8 padding, 2 = sliced
+    # even where the minor size is not a multiple of 8 and the groups straddle bands (padding, same results)
+    monkeypatch.setenv("QBH_KRON_SLICED", str(sliced))
     lx, ly, nu, nd = shape
     n = lx * ly
     bonds = lattices.square(lx, ly)
@@ -27,6 +31,7 @@ def test_split_operator_equals_the_unsplit_one(shape):
     ik, ip = K.info(), P.info()
     assert ik.kron_minor == ik.ncols // int(round(ik.ncols / ik.kron_minor)) > 0 and ip.kron_minor == 0
     assert ik.kron_band in (2, 4, 8) and 0 < ik.kron_far_nnz < ik.nnz and ik.nnz == ip.nnz
+    assert ik.kron_sliced == (1 if sliced == 2 and ik.kron_band == 8 else ik.kron_sliced) and (sliced or not ik.kron_sliced)
     ia, ja, val = K.download()                                     # the handle still holds (and returns) the plain CSR
     O = qo.Csr(K.dim, ia, ja.astype(np.int64), val, False)
     x, y0 = _rand(K.dim, 1), _rand(K.dim, 2)
