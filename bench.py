@@ -611,7 +611,7 @@ def main():
     code_w = 0 if not coded else (1 if info.value_dict <= 256 else 2)
     tkey = "%s|%s|%s" % (args.workload, KERNEL_KEY[info.kernel], "dict" if coded else "plain") + ("|real" if real_used else "")
     if info.kron_minor:
-        tkey += "|kron"
+        tkey += "|kron_sliced" if info.kron_sliced else "|kron"
     traffic, tsrc = traffic_of(tkey + ("|reforder" if args.order == "reference" else "")) if world == 1 and not args.host_csr else (None, None)
     if coded or real_used:
         # the kernel moves its own format's bytes, not SURVEY 8(d)'s: the fraction is defined on those (cannot exceed 1)
@@ -645,7 +645,8 @@ def main():
                                          if not (coded or real_used) else "value codes %s, real fast path %s" % (coded, real_used),
                                          "value_dict": info.value_dict, "real_gather": real_used,
                                          "kron_split": ({"minor": int(info.kron_minor), "band": int(info.kron_band), "far_nnz": int(info.kron_far_nnz), "far_sliced": bool(info.kron_sliced),
-                                                         "launches_per_spmv": "k_kron_tile + k_spmv_wave2<.,0> (far) + k_spmv_wave2<.,2> (near)"}
+                                                         "launches_per_spmv": ("k_kron_tile + k_zero_cut_groups + k_spmv_wave2<.,3> (far, sliced) + k_spmv_wave2<.,2> (near)"
+                                                                               if info.kron_sliced else "k_kron_tile + k_spmv_wave2<.,0> (far) + k_spmv_wave2<.,2> (near)")}
                                                         if info.kron_minor else None),
                                          "operator_source": "host CSR in reference order through qbh_csr_create" if args.host_csr else
                                          "device generator, permuted on the device into the reference's Lin order and fermion convention "

@@ -1405,6 +1405,19 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         nr.swizzle = kron_swz;
         nr.wctr = A->d_wctr + 256;
         QBH_TRY(qbh::launch_spmv_wave2(nr, K.tpr_n, 2, K.grid_n, A->stream));
+#ifdef QBH_WAVE_TIMING
+        {   // debug build: where the wavefronts of the two passes spend their cycles (s_memtime ticks, 100 MHz)
+            unsigned long long h[3 * 128];
+            QBH_HIP(hipStreamSynchronize(A->stream));
+            QBH_HIP(hipMemcpy(h, A->d_wctr, sizeof(h), hipMemcpyDeviceToHost));
+            for (int pass = 1; pass <= 2; ++pass) {
+                const unsigned long long *d = h + (pass + 1) * 128 - 8;
+                const double nb = d[4] ? (double)d[4] : 1.0;
+                fprintf(stderr, "[wave timing] %s pass: blocks %llu, ticks per block: issue+column wait %.1f, gather wait %.1f, reduce %.1f, stream rest %.1f\n",
+                        pass == 1 ? "far" : "near", d[4], d[0] / nb, d[1] / nb, d[2] / nb, d[3] / nb);
+            }
+        }
+#endif
     } else if (wave) {
         a.wd = A->d_wd;
         a.n_wb = A->n_wb;

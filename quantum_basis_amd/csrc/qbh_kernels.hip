@@ -804,6 +804,11 @@ int launch_build_wavedesc(const int64_t *d_ia, int64_t nrows, int64_t window, Wa
 #ifndef QBH_NEAR_WAVES
 #define QBH_NEAR_WAVES 2
 #endif
+#ifdef QBH_NT_ROW_STORE
+#define QBH_ROW_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define QBH_ROW_STORE(p, v) (*(p) = (v))
+#endif
 template <int TPR, int OPS, bool DYN>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS != 2 ? 3 : QBH_NEAR_WAVES, OPS != 2 ? 3 : QBH_NEAR_WAVES))) void k_spmv_wave2(SpmvArgs a)
 {
@@ -836,6 +841,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS != 2
         int64_t p0;              // the 128-byte boundary below the block's first value (the stream is read from there: 8 lines per
                                  // 1 KB value load instead of 9); row offsets are taken relative to it
         int r0, nr, n;           // n = entries from p0 to the block's end; -1: a row longer than the tile (row-at-a-time path)
+        bool cont0, cont1;       // OPS 3: the first group began in the block before / the last group goes on in the block after
     };
     // OPS 3: a block is 512 consecutive SLOTS of the sliced stream whatever the groups are (descriptor: first slot, first
     // group that overlaps, pad = 1 when that group began in the previous block); a group cut by a block boundary gets its
@@ -850,7 +856,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS != 2
         const int64_t p1 = (int64_t)(((uint64_t)q5 << 32) | q4);
         b.r0 = __builtin_amdgcn_readlane(dq, 2);
         b.nr = __builtin_amdgcn_readlane(dq, 6) - b.r0;
-        if (OPS == 3) b.nr += __builtin_amdgcn_readlane(dq, 7) & 1;
+        b.cont0 = OPS == 3 && (__builtin_amdgcn_readlane(dq, 3) & 1);
+        b.cont1 = OPS == 3 && (__builtin_amdgcn_readlane(dq, 7) & 1);
+        if (b.cont1) b.nr += 1;
         b.n = (p1 - b.p0) <= NW ? (int)(p1 - b.p0) : -1;
         return b;
     };
@@ -913,26 +921,82 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS != 2
             if (!need_y) o.yo = d2{0.0, 0.0};
         }
     };
-    auto finish_row = [&](int64_t row, d2 sum, d2 yo, d2 xi, d2 fr, bool clip) {
+    // Finished rows of the ordered walk are not stored row by row: a wavefront's consecutive blocks hold consecutive rows, so
+    // the results wait in a wave-private LDS buffer and leave as full 1 KB stores when the run of rows ends (chunk change) or
+    // the buffer is full.  (tools/lab/region_probe: one 512-byte store per 8 KB block costs a stream 17 %, the same bytes in
+    // 1 KB stores every fourth block 4 %.)  OPS 3: a group cut between two blocks of the SAME run is summed in the buffer;
+    // only the groups cut at the ends of a run are added atomically.
+#ifndef QBH_BUF_MODE
+#define QBH_BUF_MODE 1                           // 0 never | 1 the sliced far pass | 2 every pass of the ordered walk
+#endif
+    constexpr bool BUF = DYN && (QBH_BUF_MODE == 2 || (QBH_BUF_MODE == 1 && OPS == 3));
+    constexpr int CAP = 256;
+    __shared__ d2 rbuf_s[BUF ? 4 * CAP : 1];
+    d2 *rbuf = rbuf_s + (BUF ? wv * CAP : 0);
+    int64_t buf_r0 = 0;
+    int buf_n = 0, buf_nb = 0;                   // rows buffered; rows buffered before the current block
+    bool at_first = false, at_last = false, merge_first = false, direct = !BUF;
+    auto emit = [&](int64_t row, d2 v, bool atomic) {
         if (OPS == 3) {
             if (row < a.nrows) {
-                if (clip) {
+                if (atomic) {
                     double *yp = reinterpret_cast<double *>(a.y + row);
-                    unsafeAtomicAdd(yp, sum.x);
-                    unsafeAtomicAdd(yp + 1, sum.y);
+                    unsafeAtomicAdd(yp, v.x);
+                    unsafeAtomicAdd(yp + 1, v.y);
                 } else {
-                    a.y[row] = sum;
+                    QBH_ROW_STORE(a.y + row, v);
                 }
             }
-        } else if (OPS == 0) {
-            a.y[row] = sum;
         } else {
+            QBH_ROW_STORE(a.y + row, v);
+        }
+    };
+    auto flush = [&]() {
+        if (BUF && buf_n > 0) {
+            wave_lds_fence();
+            for (int i = lane; i < buf_n; i += 64) emit(buf_r0 + i, rbuf[i], OPS == 3 && ((i < 8 && at_first) || (i >= buf_n - 8 && at_last)));
+            wave_lds_fence();
+            buf_n = 0;
+        }
+    };
+    // before the rows of a block: first row, row count, "first group continues the buffered one"
+    auto open_block = [&](int64_t first, int nrows_blk, bool c0, bool fits) {
+        if (BUF) {
+            if (buf_n > 0 && (!fits || first != buf_r0 + buf_n - (c0 ? 8 : 0) || first + nrows_blk - buf_r0 > CAP)) flush();
+            direct = !fits || nrows_blk > CAP;
+            if (!direct) {
+                if (buf_n == 0) {
+                    buf_r0 = first;
+                    at_first = c0;
+                    merge_first = false;
+                } else {
+                    merge_first = c0;
+                }
+                buf_nb = buf_n;
+            }
+        }
+    };
+    auto close_block = [&](int64_t first, int nrows_blk, bool c1) {
+        if (BUF && !direct) {
+            buf_n = (int)(first + nrows_blk - buf_r0);
+            at_last = c1;
+        }
+    };
+    auto finish_row = [&](int64_t row, d2 sum, d2 yo, d2 xi, d2 fr, bool clip) {
+        d2 v = sum;
+        if (OPS == 2) {
             sum += fr;
-            const d2 yn = a.alpha * sum + a.beta * yo + a.gamma * xi;
-            a.y[row] = yn;
-            acc[0] += xi.x * yn.x + xi.y * yn.y;
-            acc[1] += xi.x * yn.y - xi.y * yn.x;
-            acc[2] += yn.x * yn.x + yn.y * yn.y;
+            v = a.alpha * sum + a.beta * yo + a.gamma * xi;
+            acc[0] += xi.x * v.x + xi.y * v.y;
+            acc[1] += xi.x * v.y - xi.y * v.x;
+            acc[2] += v.x * v.x + v.y * v.y;
+        }
+        if (BUF && !direct) {
+            const int idx = (int)(row - buf_r0);
+            if (OPS == 3 && merge_first && idx < buf_nb) v += rbuf[idx];
+            rbuf[idx] = v;
+        } else {
+            emit(row, v, clip);
         }
     };
 
@@ -943,6 +1007,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS != 2
     d2 vA[8];
     Ops oA;
     issue(b0, cA, vA, oA);
+#ifdef QBH_WAVE_TIMING
+    unsigned long long tm[4] = {0, 0, 0, 0}, nblk = 0;
+#define QBH_TICK(i, t_from) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tm[i] += t_ - (t_from); t_from = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+    unsigned long long t_mark = __builtin_amdgcn_s_memtime();
+#else
+#define QBH_TICK(i, t_from) do { } while (0)
+#endif
     while (dyn ? dw.live(lb) : (lb < walk.per_xcd)) {
         const int dq2 = load_desc(lb + 2 * step);
         unsigned int reply = 0;
@@ -961,12 +1032,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS != 2
         Ops oB;
         issue(b1, cB, vB, oB);
         __builtin_amdgcn_sched_barrier(0);
+        QBH_TICK(0, t_mark);                   // top of the turn .. gathers and next stream issued (waits for this block's columns)
         if (b0.n >= 0) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) prod[lane + u * 64] = cmul(vA[u], xv[u]);
             wave_lds_fence();
+            QBH_TICK(1, t_mark);               // .. gathers arrived, products in LDS
             constexpr int RSTRIDE = OPS == 3 ? 8 : 1;                  // distance of a row's consecutive entries in the tile
             const int nrows_blk = OPS == 3 ? 8 * b0.nr : b0.nr;
+            const int64_t first_row = OPS == 3 ? (int64_t)b0.r0 * 8 : (int64_t)b0.r0;
+            open_block(first_row, nrows_blk, b0.cont0, true);
             for (int rbase = 0; rbase < nrows_blk; rbase += RP) {
                 const int row = rbase + rloc;
                 int s_ = oA.s, e_ = oA.e;
@@ -994,10 +1069,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS != 2
                     sum.x += __shfl_xor(sum.x, off, 64);
                     sum.y += __shfl_xor(sum.y, off, 64);
                 }
-                if (sub == 0 && row < nrows_blk) finish_row(OPS == 3 ? (int64_t)b0.r0 * 8 + row : (int64_t)b0.r0 + row, sum, yo, xi, fr, clip);
+                if (sub == 0 && row < nrows_blk) finish_row(first_row + row, sum, yo, xi, fr, clip);
             }
+            close_block(first_row, nrows_blk, b0.cont1);
+            QBH_TICK(2, t_mark);               // .. rows reduced and finished
             wave_lds_fence();
         } else {
+            open_block(0, 0, false, false);
             for (int r = 0; r < (OPS == 3 ? 0 : b0.nr); ++r) {     // a row longer than the tile: row at a time (correctness path; sliced blocks never exceed the tile)
                 const int64_t row = (int64_t)b0.r0 + r;
                 const int64_t s_ = a.ia[row], e_ = a.ia[row + 1];
@@ -1030,7 +1108,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS != 2
         }
         lb += step;
         if constexpr (dyn) dw.advance(lb);
+#ifdef QBH_WAVE_TIMING
+        // the copy of the next block's registers needs its VALUES: the wait for the rest of the stream lands here
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        QBH_TICK(3, t_mark);
+        ++nblk;
+#endif
     }
+#ifdef QBH_WAVE_TIMING
+    if (lane == 0) {
+        unsigned long long *dbg = a.wctr + 128 - 8;             // last 8 words of this pass's counter block
+        for (int i = 0; i < 4; ++i) atomicAdd(dbg + i, tm[i]);
+        atomicAdd(dbg + 4, nblk);
+    }
+#endif
+    flush();
     if (a.partials != nullptr) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc[c] = wave_sum(acc[c]);

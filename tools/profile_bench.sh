@@ -19,6 +19,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum T
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $grp -d /tmp/prof_$TAG/g$i -o p -- python3 $R/bench.py $ARGS > /tmp/prof_$TAG/g$i.log 2>&1
 done
-{ echo "# rocprofv3 --pmc passes (one counter group per run) of: python bench.py $ARGS"; echo "# mean per dispatch of the SpMV kernel; FETCH_SIZE/WRITE_SIZE are in KiB as reported (see DESIGN.md for the gfx950 x2 read correction)"; python3 $R/tools/pmc_summary.py /tmp/prof_$TAG; python3 $R/tools/pmc_summary.py /tmp/prof_$TAG "%mf_hubbard%"; python3 $R/tools/pmc_summary.py /tmp/prof_$TAG "%mf_heis%"; } > $OUT/${TAG}_pmc.txt
+{ echo "# rocprofv3 --pmc passes (one counter group per run) of: python bench.py $ARGS"; echo "# mean per dispatch of the SpMV kernel; FETCH_SIZE/WRITE_SIZE are in KiB as reported (see DESIGN.md for the gfx950 x2 read correction)"; python3 $R/tools/pmc_summary.py /tmp/prof_$TAG; python3 $R/tools/pmc_summary.py /tmp/prof_$TAG "%k_kron_tile%"; python3 $R/tools/pmc_summary.py /tmp/prof_$TAG "%k_zero_cut%"; python3 $R/tools/pmc_summary.py /tmp/prof_$TAG "%mf_hubbard%"; python3 $R/tools/pmc_summary.py /tmp/prof_$TAG "%mf_heis%"; } > $OUT/${TAG}_pmc.txt
 tail -3 $OUT/${TAG}_kernel_stats.txt
 cat $OUT/${TAG}_pmc.txt

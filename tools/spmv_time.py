@@ -16,7 +16,9 @@ def main():
     cfgs = sys.argv[2:] or [""]
     W = bench.workloads()[name]
     fmt = os.environ.get("SPMV_FORMAT", "complex128")
-    for cfg in cfgs:
+    rounds = int(os.environ.get("SPMV_ROUNDS", "1"))      # cycle through the configurations this many times: min / median per configuration
+    results = {}
+    for cfg in cfgs * rounds:
         saved = {}
         for kv in cfg.split():
             k, v = kv.split("=", 1)
@@ -36,6 +38,7 @@ def main():
         A.sync()
         s = A.stats()
         print("%-70s %8.3f ms/launch (%d launches)" % (cfg or "(default)", s.ms_spmv / max(1, s.n_spmv), s.n_spmv), flush=True)
+        results.setdefault(cfg, []).append(s.ms_spmv / max(1, s.n_spmv))
         v.free()
         A.destroy()
         for k, old in saved.items():
@@ -43,6 +46,10 @@ def main():
                 del os.environ[k]
             else:
                 os.environ[k] = old
+    if rounds > 1:
+        for cfg, r in results.items():
+            r = sorted(r)
+            print("%-70s min %8.3f  median %8.3f ms/launch over %d rounds" % (cfg or "(default)", r[0], r[len(r) // 2], len(r)), flush=True)
 
 
 if __name__ == "__main__":
