@@ -100,7 +100,11 @@ struct BlockWalk {
 // eighth of the wave blocks and ALL its wavefronts draw chunks of kDynChunk consecutive blocks from one counter, so the eighth
 // is consumed in order and the blocks in flight on an XCD are always neighbours.  blockIdx % 8 names the counter (the observed
 // dispatch order puts those workgroups on one XCD; if it did not, only the locality would suffer).
-constexpr int kDynChunk = 4;
+#ifndef QBH_DYN_CHUNK
+#define QBH_DYN_CHUNK 4
+#endif
+constexpr int kDynChunk = QBH_DYN_CHUNK;
+static_assert(kDynChunk >= 3, "the walk looks two turns ahead and learns the next chunk in the first turn of the current one");
 struct DynWalk {
     // cur: first block of the chunk the wavefront is in (turns n0 .. n0 + kDynChunk - 1); nxt: of the chunk after it.  The
     // counter is asked (ask) in the first turn of a chunk BEFORE that turn's gathers and read (take) after they have been
@@ -937,6 +941,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS != 2
     int buf_n = 0, buf_nb = 0;                   // rows buffered; rows buffered before the current block
     bool at_first = false, at_last = false, merge_first = false, direct = !BUF;
     auto emit = [&](int64_t row, d2 v, bool atomic) {
+#ifdef QBH_ABL_NO_FAR_STORE          // ablation builds only (wrong results): the far pass without its row stores
+        if (OPS == 3 || OPS == 0) {
+            if (v.x == 1.2345e300) a.y[row] = v;
+            return;
+        }
+#endif
         if (OPS == 3) {
             if (row < a.nrows) {
                 if (atomic) {
@@ -1025,6 +1035,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS != 2
         d2 xv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) xv[u] = a.xg[cA[u]];
+#ifdef QBH_ABL_NO_FAR_GATHER         // ablation builds only (wrong results): the far pass without its gathers
+        if (OPS == 3 || OPS == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = d2{(double)cA[u], 1.0};
+        }
+#endif
         issue_ops(b0, oA);
         __builtin_amdgcn_sched_barrier(0);      // the gathers go out BEFORE the next block's stream (in-order return)
         int cB[8];

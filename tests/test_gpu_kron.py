@@ -90,3 +90,39 @@ def test_split_is_skipped_where_it_does_not_apply():
     assert q.csr_mat.hubbard(n, 4, 4, bonds).info().kron_minor == 0                                   # coded values: row kernel
     assert q.csr_mat.hubbard(n, 4, 4, bonds, rows=(0, 2000), opts=q.make_opts(**PLAIN)).info().kron_minor == 0   # a row shard
     assert q.csr_mat.heisenberg(12, 6, lattices.chain(12), opts=q.make_opts(**PLAIN)).info().kron_minor == 0     # no product basis
+
+
+def test_headline_operator_split_and_sliced_equals_the_matrix_free_operator_at_full_size():
+    """BASELINE configs[2] (C3, dim 165,636,900, nnz 5.82e9) exactly as bench.py's headline applies it: complex128 CSR, Kronecker
+    split with the sliced far part.  The oracle cannot run at this size; the independent path is the matrix-free operator (no
+    stored matrix at all).  Lanczos form y <- alpha H x + beta y + gamma x with the fused reductions, complex x."""
+    import math
+    n_sites, nu, nd = 16, 8, 8
+    bonds = lattices.square(4, 4)
+    K = q.csr_mat.hubbard(n_sites, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_split=2, **PLAIN))
+    info = K.info()
+    S = math.comb(16, 8)
+    assert K.dim == S * S and info.kron_minor == S and info.kron_band == 8 and info.kron_sliced == 1
+    assert info.kernel == q._lib.KERNEL_WAVE and 0 < info.kron_far_nnz < info.nnz
+    M = q.csr_mat.hubbard(n_sites, nu, nd, bonds, t=1.0, U=1.1, matrix_free=True)
+    assert M.nnz == K.nnz
+    n = K.dim
+    v = K.vec(4)
+    K.randomize(v.at(0), 11)
+    K.randomize(v.at(n), 12)
+    K.axpy_norm(0.6j, v.at(n), v.at(0))                             # a genuinely complex x
+    K.randomize(v.at(n), 13)                                        # y_old
+    # same y_old for both operators
+    K.spmv(v.at(n), v.at(2 * n), 0.0, 0.0, 1.0)                     # slot 2 <- y_old  (alpha = beta = 0, gamma = 1: a copy)
+    K.spmv(v.at(n), v.at(3 * n), 0.0, 0.0, 1.0)                     # slot 3 <- y_old
+    alpha, beta, gamma = 0.7, -0.3, 0.25
+    xy_k, yy_k = K.spmv(v.at(0), v.at(2 * n), alpha, beta, gamma, want_red=True)
+    K.sync()
+    xy_m, yy_m = M.spmv(v.at(0), v.at(3 * n), alpha, beta, gamma, want_red=True)
+    M.sync()
+    hy = math.sqrt(yy_m)
+    assert abs(yy_k - yy_m) <= 1e-12 * yy_m and abs(xy_k - xy_m) <= 1e-12 * max(abs(xy_m), hy)
+    assert np.sqrt(K.axpy_norm(-1.0, v.at(2 * n), v.at(3 * n))) <= 1e-13 * hy
+    v.free()
+    M.destroy()
+    K.destroy()

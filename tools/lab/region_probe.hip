@@ -54,9 +54,17 @@ __global__ __launch_bounds__(256) void k_reg(const d2 *stream, const int *cols, 
         if (ST == 5 && (lane & 1) == 0) yold = outv[blk * 32 + (lane >> 1)];
 #pragma unroll
         for (int u = 0; u < NS; ++u) s[u] = __builtin_nontemporal_load(stream + base + u * 64 + lane);
-        if (COL) {
+        if (COL == 1) {
 #pragma unroll
             for (int u = 0; u < NS; ++u) c[u] = __builtin_nontemporal_load(cols + base + u * 64 + lane);
+        }
+        if (COL == 2) {                      // the same column bytes as NS / 4 16-byte loads per lane (block-transposed column storage)
+            typedef int i4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int u = 0; u < NS / 4; ++u) {
+                const i4 q = __builtin_nontemporal_load(reinterpret_cast<const i4 *>(cols + base + u * 256) + lane);
+                c[4 * u] = q.x; c[4 * u + 1] = q.y; c[4 * u + 2] = q.z; c[4 * u + 3] = q.w;
+            }
         }
 #pragma unroll
         for (int u = 0; u < NS; ++u) acc += s[u];
@@ -120,6 +128,9 @@ int main()
         run<8, 1, 0, 5>(stream, cols, outv, n, ctr, out, wgs);
         run<8, 1, 1, 2>(stream, cols, outv, n, ctr, out, wgs);
         run<8, 1, 1, 3>(stream, cols, outv, n, ctr, out, wgs);
+        run<8, 1, 2, 0>(stream, cols, outv, n, ctr, out, wgs);
+        run<8, 1, 2, 3>(stream, cols, outv, n, ctr, out, wgs);
+        run<8, 1, 2, 1>(stream, cols, outv, n, ctr, out, wgs);
         run<16, 1, 0, 0>(stream, cols, outv, n, ctr, out, wgs);
         run<16, 1, 0, 1>(stream, cols, outv, n, ctr, out, wgs);
     }
