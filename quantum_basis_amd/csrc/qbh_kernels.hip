@@ -1201,13 +1201,49 @@ static int occ_wave2(int tpr)
 int wave2_kernel_occupancy(int tpr, int ops) { return ops == 0 ? occ_wave2<0>(tpr) : ops == 3 ? occ_wave2<3>(tpr) : occ_wave2<2>(tpr); }
 
 // ---- Kronecker split: tiled copy of x, structure check, count / fill of the two parts ----
-__global__ __launch_bounds__(kBlock) void k_kron_tile(const d2 *x, d2 *xt, int64_t n, KronTile t)
+// Tiled copy of x for B = 8, through LDS: a workgroup moves 32 major indices x 8 bands; it reads 1 KB runs of x (64 minor indices
+// of one major index) and writes 4 KB runs of the tiled copy (32 major indices of one band) -- row stores in 128-byte pieces cost
+// several times their share of the bytes (tools/lab/region_probe).  The last, narrower band (S % 8 != 0) and other band widths
+// take the element-wise kernel.
+__global__ __launch_bounds__(kBlock) void k_kron_tile_edge(const d2 *x, d2 *xt, KronTile t, int64_t band0)
 {
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) xt[t.tile(r)] = x[r];
+    // elements of bands >= band0
+    const int64_t d0 = band0 * t.B, w = t.S - d0;
+    const int64_t cnt = t.NU * w;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t u = e / w, r = u * t.S + d0 + (e - u * w);
+        xt[t.tile(r)] = x[r];
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_kron_tile8(const d2 *x, d2 *xt, KronTile t, int64_t nfb)
+{
+    constexpr int TU = 32, TB = 8, LD = TB * 8 + 1;          // +1: the band-major read of the tile walks rows of the LDS array
+    __shared__ d2 tilebuf[TU * LD];
+    const int64_t tiles_u = (t.NU + TU - 1) / TU, tiles_b = (nfb + TB - 1) / TB;
+    for (int64_t w = blockIdx.x; w < tiles_u * tiles_b; w += gridDim.x) {
+        const int64_t tb = w / tiles_u, tu = w - tb * tiles_u;     // consecutive workgroups: the same bands, consecutive major indices
+        const int64_t u0 = tu * TU, b0 = tb * TB;
+        const int nu = (int)(t.NU - u0 < TU ? t.NU - u0 : TU), nb = (int)(nfb - b0 < TB ? nfb - b0 : TB);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TU * TB * 8 / kBlock; ++i) {
+            const int idx = threadIdx.x + i * kBlock, ul = idx >> 6, dl = idx & 63;
+            if (ul < nu && dl < nb * 8) tilebuf[ul * LD + dl] = __builtin_nontemporal_load(x + (u0 + ul) * t.S + b0 * 8 + dl);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TU * TB * 8 / kBlock; ++i) {
+            const int idx = threadIdx.x + i * kBlock, bl = idx >> 8, rest = idx & 255, ul = rest >> 3, j = rest & 7;
+            if (bl < nb && ul < nu) xt[(b0 + bl) * 8 * t.NU + (u0 + ul) * 8 + j] = tilebuf[ul * LD + bl * 8 + j];
+        }
+    }
 }
 int launch_kron_tile(const d2 *x, d2 *xt, int64_t n, const KronTile &t, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_kron_tile, dim3(2048), dim3(kBlock), 0, s, x, xt, n, t);
+    (void)n;
+    const int64_t nfb = t.B == 8 ? t.S / 8 : 0;                  // full bands through the LDS kernel
+    if (nfb > 0) hipLaunchKernelGGL(k_kron_tile8, dim3(4096), dim3(kBlock), 0, s, x, xt, t, nfb);
+    if (nfb * t.B < t.S) hipLaunchKernelGGL(k_kron_tile_edge, dim3(nfb > 0 ? 256 : 2048), dim3(kBlock), 0, s, x, xt, t, nfb);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }
