@@ -1368,7 +1368,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     // The two passes of a Kronecker split take the dynamic ordered walk per XCD (DynWalk: C3 far pass 86 -> 64 GB, near pass
     // 92 -> 68 GB, 31.7 -> 31.0 ms); the unsplit wave kernel keeps the static chunked walk (xcd_swizzle 2), under which all XCDs
     // stream from ONE region -- ordered eighths cost it 34 -> 43 ms on C3.  xcd_swizzle 3 / QBH_WAVE_SWIZZLE choose by name.
-    int wave_swz = A->opts.xcd_swizzle, kron_swz = 3;
+    int wave_swz = A->opts.xcd_swizzle, kron_swz = 3, wave_grid_used = A->wgrid;
     if (const char *e = getenv("QBH_WAVE_SWIZZLE")) wave_swz = kron_swz = atoi(e);
     if (wave && (kron ? kron_swz == 3 : wave_swz == 3)) {
         if (!A->d_wctr) wave_swz = kron_swz = 2;
@@ -1423,7 +1423,20 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         a.n_wb = A->n_wb;
         a.swizzle = wave_swz;
         a.wctr = A->d_wctr;
-        QBH_TRY(qbh::launch_spmv_wave(a, A->wtpr, A->wgrid, A->stream));
+        static const int pipe = getenv("QBH_WAVE_PIPELINED") ? atoi(getenv("QBH_WAVE_PIPELINED")) : 0;    // experiment: the pipelined kernel on an unsplit operator
+        if (pipe && A->wtpr <= 8) {
+            int ncu = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, A->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+            const int occ = std::max(1, qbh::wave2_kernel_occupancy(A->wtpr, 1));
+            int64_t g = std::min<int64_t>((int64_t)occ * ncu, ((((A->n_wb + 3) >> 2) + 7) / 8) * 8);
+            g = std::max<int64_t>(8, (g / 8) * 8);
+            g = std::min<int64_t>(g, A->wgrid);            // the partial-sum buffer is sized for the wave kernel's grid
+            wave_grid_used = (int)g;
+            QBH_TRY(qbh::launch_spmv_wave2(a, A->wtpr, 1, (int)g, A->stream));
+        } else {
+            QBH_TRY(qbh::launch_spmv_wave(a, A->wtpr, A->wgrid, A->stream));
+        }
     } else {
         QBH_TRY(qbh::launch_spmv(a, A->kernel, A->npb, A->tpr, A->grid, A->stream));
     }
@@ -1431,7 +1444,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         QBH_HIP(hipEventRecord(A->ev1, A->stream));
         A->ev_pending = true;
     }
-    int grid_last = kron ? A->kron.grid_n : wave ? A->wgrid : A->grid;
+    int grid_last = kron ? A->kron.grid_n : wave ? wave_grid_used : A->grid;
     if (A->has_rem) {
         if (async_gather) {
             if (A->comm.allgather_wait(A->comm.ctx) != 0) {

@@ -814,9 +814,10 @@ int launch_build_wavedesc(const int64_t *d_ia, int64_t nrows, int64_t window, Wa
 #define QBH_ROW_STORE(p, v) (*(p) = (v))
 #endif
 template <int TPR, int OPS, bool DYN>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS != 2 ? 3 : QBH_NEAR_WAVES, OPS != 2 ? 3 : QBH_NEAR_WAVES))) void k_spmv_wave2(SpmvArgs a)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 0 || OPS == 3) ? 3 : QBH_NEAR_WAVES, (OPS == 0 || OPS == 3) ? 3 : QBH_NEAR_WAVES))) void k_spmv_wave2(SpmvArgs a)
 {
     constexpr int NW = 512, RP = 64 / TPR;
+    constexpr bool EPI = OPS == 1 || OPS == 2, FAR = OPS == 2;      // OPS 1: the fused epilogue of an UNSPLIT operator (no far addend)
     __shared__ d2 prod_s[4 * NW];
     __shared__ double red[12];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -917,11 +918,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS != 2
     // epilogue operands of the CURRENT block's first pass: issued after its gathers and before the next block's stream (they
     // are not carried across a block as a second register set; the wait for the gathers still leaves them in flight)
     auto issue_ops = [&](const Blk &b, Ops &o) {
-        if (OPS == 2) {
+        if (EPI) {
             const int64_t row = rloc < b.nr ? (int64_t)b.r0 + rloc : 0;
             o.yo = a.y[row];
             o.xi = a.xl[row];
-            o.fr = a.far[kt.tile(row)];
+            o.fr = FAR ? a.far[kt.tile(row)] : d2{0.0, 0.0};
             if (!need_y) o.yo = d2{0.0, 0.0};
         }
     };
@@ -994,8 +995,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS != 2
     };
     auto finish_row = [&](int64_t row, d2 sum, d2 yo, d2 xi, d2 fr, bool clip) {
         d2 v = sum;
-        if (OPS == 2) {
-            sum += fr;
+        if (EPI) {
+            if (FAR) sum += fr;
             v = a.alpha * sum + a.beta * yo + a.gamma * xi;
             acc[0] += xi.x * v.x + xi.y * v.y;
             acc[1] += xi.x * v.y - xi.y * v.x;
@@ -1071,10 +1072,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS != 2
                     if (row < nrows_blk) {
                         s_ = (int)(a.ia[b0.r0 + row] - b0.p0);
                         e_ = (int)(a.ia[b0.r0 + row + 1] - b0.p0);
-                        if (OPS == 2 && sub == 0) {
+                        if (EPI && sub == 0) {
                             yo = need_y ? a.y[b0.r0 + row] : d2{0.0, 0.0};
                             xi = a.xl[b0.r0 + row];
-                            fr = a.far[kt.tile((int64_t)b0.r0 + row)];
+                            if (FAR) fr = a.far[kt.tile((int64_t)b0.r0 + row)];
                         }
                     }
                 }
@@ -1101,10 +1102,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OPS != 2
                 sum.y = wave_sum(sum.y);
                 if (lane == 0) {
                     d2 yo = {0.0, 0.0}, xi = {0.0, 0.0}, fr = {0.0, 0.0};
-                    if (OPS == 2) {
+                    if (EPI) {
                         if (need_y) yo = a.y[row];
                         xi = a.xl[row];
-                        fr = a.far[kt.tile(row)];
+                        if (FAR) fr = a.far[kt.tile(row)];
                     }
                     finish_row(row, sum, yo, xi, fr, false);
                 }
@@ -1177,6 +1178,7 @@ int launch_spmv_wave2(const SpmvArgs &a, int tpr, int ops, int grid, hipStream_t
 {
     if (ops == 0)      launch_wave2_tpr<0>(a, tpr, grid, s);
     else if (ops == 3) launch_wave2_tpr<3>(a, tpr, grid, s);
+    else if (ops == 1) launch_wave2_tpr<1>(a, tpr, grid, s);
     else               launch_wave2_tpr<2>(a, tpr, grid, s);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
@@ -1198,7 +1200,7 @@ static int occ_wave2(int tpr)
     }
     return occ;
 }
-int wave2_kernel_occupancy(int tpr, int ops) { return ops == 0 ? occ_wave2<0>(tpr) : ops == 3 ? occ_wave2<3>(tpr) : occ_wave2<2>(tpr); }
+int wave2_kernel_occupancy(int tpr, int ops) { return ops == 0 ? occ_wave2<0>(tpr) : ops == 3 ? occ_wave2<3>(tpr) : ops == 1 ? occ_wave2<1>(tpr) : occ_wave2<2>(tpr); }
 
 // ---- Kronecker split: tiled copy of x, structure check, count / fill of the two parts ----
 // Tiled copy of x for B = 8, through LDS: a workgroup moves 32 major indices x 8 bands; it reads 1 KB runs of x (64 minor indices
