@@ -808,13 +808,16 @@ int launch_build_wavedesc(const int64_t *d_ia, int64_t nrows, int64_t window, Wa
 #ifndef QBH_NEAR_WAVES
 #define QBH_NEAR_WAVES 2
 #endif
+#ifndef QBH_FAR_WAVES
+#define QBH_FAR_WAVES 3
+#endif
 #ifdef QBH_NT_ROW_STORE
 #define QBH_ROW_STORE(p, v) __builtin_nontemporal_store((v), (p))
 #else
 #define QBH_ROW_STORE(p, v) (*(p) = (v))
 #endif
 template <int TPR, int OPS, bool DYN>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 0 || OPS == 3) ? 3 : QBH_NEAR_WAVES, (OPS == 0 || OPS == 3) ? 3 : QBH_NEAR_WAVES))) void k_spmv_wave2(SpmvArgs a)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 0 || OPS == 3) ? QBH_FAR_WAVES : QBH_NEAR_WAVES, (OPS == 0 || OPS == 3) ? QBH_FAR_WAVES : QBH_NEAR_WAVES))) void k_spmv_wave2(SpmvArgs a)
 {
     constexpr int NW = 512, RP = 64 / TPR;
     constexpr bool EPI = OPS == 1 || OPS == 2, FAR = OPS == 2;      // OPS 1: the fused epilogue of an UNSPLIT operator (no far addend)

@@ -38,6 +38,11 @@ __global__ __launch_bounds__(256) void k_reg(const d2 *stream, const int *cols, 
             const size_t b = it * nwx + wx;
             if (b >= per) break;
             blk = xcd * per + b;
+        } else if (REG == 3 || REG == 4) {            // static, but a wavefront takes CH consecutive blocks (the kernels' chunks): 3: CH 4, 4: CH 16
+            constexpr size_t CH = REG == 3 ? 4 : 16;
+            const size_t b = (it / CH) * nwx * CH + wx * CH + it % CH;
+            if (b >= per) break;
+            blk = xcd * per + b;
         } else {
             if ((it & 3) == 0 && it > 0) {
                 if (lane == 0) chunk = atomicInc(ctr + xcd * 32, 0xFFFFFFFFu);
@@ -101,7 +106,7 @@ static void run(const d2 *stream, const int *cols, d2 *outv, size_t n_elems, uns
         if (ms < best) best = ms;
     }
     const double bytes = (double)n_blocks * NS * 64 * (16 + (COL ? 4 : 0)) + (ST ? (double)n_blocks * 512 * (ST == 5 ? 2 : 1) : 0);
-    const char *rn[] = {"one region, lock step", "own eighth per XCD, static", "own eighth per XCD, counter"};
+    const char *rn[] = {"one region, lock step", "own eighth per XCD, static", "own eighth per XCD, counter", "own eighth, 4 blocks per wave", "own eighth, 16 blocks per wave"};
     printf("  NS %2d %-28s cols %d stores %d wg/cu %d: %8.3f ms  %7.1f GB/s\n", NS, rn[REG], COL, ST, wgs, best, bytes / best / 1e6);
 }
 int main()
@@ -128,6 +133,10 @@ int main()
         run<8, 1, 0, 5>(stream, cols, outv, n, ctr, out, wgs);
         run<8, 1, 1, 2>(stream, cols, outv, n, ctr, out, wgs);
         run<8, 1, 1, 3>(stream, cols, outv, n, ctr, out, wgs);
+        run<8, 3, 0, 0>(stream, cols, outv, n, ctr, out, wgs);
+        run<8, 4, 0, 0>(stream, cols, outv, n, ctr, out, wgs);
+        run<8, 3, 1, 0>(stream, cols, outv, n, ctr, out, wgs);
+        run<8, 3, 1, 3>(stream, cols, outv, n, ctr, out, wgs);
         run<8, 1, 2, 0>(stream, cols, outv, n, ctr, out, wgs);
         run<8, 1, 2, 3>(stream, cols, outv, n, ctr, out, wgs);
         run<8, 1, 2, 1>(stream, cols, outv, n, ctr, out, wgs);
