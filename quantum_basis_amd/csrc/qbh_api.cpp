@@ -1280,6 +1280,12 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
             ms.beta = beta;
             ms.gamma = gamma;
             ms.partials = m.partials;
+            static const int sec_walk = getenv("QBH_SEC_WALK") ? atoi(getenv("QBH_SEC_WALK")) : 0;
+            if (sec_walk) {
+                if (!A->d_wctr) QBH_HIP(hipMalloc(&A->d_wctr, 3 * 128 * sizeof(unsigned long long)));
+                QBH_HIP(hipMemsetAsync(A->d_wctr, 0, 3 * 128 * sizeof(unsigned long long), A->stream));
+                ms.ctr = reinterpret_cast<unsigned int *>(A->d_wctr);
+            }
             QBH_TRY(qbh::launch_mf_sector(ms, A->stream, &mf_parts));
         } else if (A->kind == 2) {
             qbh::MfHeisArgs h{};

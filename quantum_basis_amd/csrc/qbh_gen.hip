@@ -2582,16 +2582,27 @@ constexpr int kSecMaxHops = 128;
 // y <- alpha MF(x) + beta y + gamma x for every row.  One work item = 1024 rows of one down block; an XCD takes a
 // contiguous run of items, so the workgroups that share an L2 sweep the same block -- and, hop by hop, the same target
 // blocks -- at the same time.
-template <bool REALX, int kSecUnroll>
+// ORD: the ordered walk of the wave kernels (qbh_kernels.hip, DynWalk) at workgroup granularity -- every XCD owns one contiguous
+// eighth of the items and its workgroups draw them one at a time from a counter, so they cannot drift apart over the ~1600 items
+// each of them processes (the static assignment keeps them on one block only while they stay in lock step).
+template <bool REALX, int kSecUnroll, bool ORD>
 __global__ __launch_bounds__(256) void k_mf_sector(MfSecArgs a)
 {
     const MfSec &T = *a.t;
     __shared__ MfSecHop sh[kSecMaxHops];
+    __shared__ int64_t s_item;
     const int64_t cu = T.cu;
     const int nslot = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
-    for (int64_t base = 0; base < a.n_items; base += gridDim.x) {
-        const int64_t it = base + (int64_t)xcd * nslot + slot;
+    const int64_t per = (a.n_items + 7) >> 3, xbase = xcd * per, xend = xbase + per < a.n_items ? xbase + per : a.n_items;
+    for (int64_t base = 0; ORD || base < a.n_items; base += gridDim.x) {     // ORD: until the XCD's counter runs out
+        int64_t it = base + (int64_t)xcd * nslot + slot;
         __syncthreads();
+        if (ORD) {
+            if (threadIdx.x == 0) s_item = xbase + (int64_t)atomicInc(a.ctr + xcd * 32, 0xFFFFFFFFu);
+            __syncthreads();
+            it = s_item;
+            if (it >= xend) break;
+        }
         if (it >= a.n_items) continue;
         const int64_t w = T.item[it];
         const MfSecBlock B = T.blk[w >> 20];
@@ -2728,7 +2739,7 @@ static int sector_launch_t(const MfSecArgs &a, hipStream_t s)
     static int occ = 0;
     if (occ == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mf_sector<REALX, UN>, 256, 0) != hipSuccess || n <= 0) n = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mf_sector<REALX, UN, false>, 256, 0) != hipSuccess || n <= 0) n = 4;
         occ = n;
     }
     int grid = 256 * occ;
@@ -2736,7 +2747,8 @@ static int sector_launch_t(const MfSecArgs &a, hipStream_t s)
         const int g = atoi(e);
         if (g >= 8) grid = (g / 8) * 8;
     }
-    hipLaunchKernelGGL((k_mf_sector<REALX, UN>), dim3(grid), dim3(256), 0, s, a);
+    if (a.ctr != nullptr) hipLaunchKernelGGL((k_mf_sector<REALX, UN, true>), dim3(grid), dim3(256), 0, s, a);
+    else                  hipLaunchKernelGGL((k_mf_sector<REALX, UN, false>), dim3(grid), dim3(256), 0, s, a);
     return QBH_OK;
 }
 

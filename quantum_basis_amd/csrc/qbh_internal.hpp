@@ -252,6 +252,7 @@ struct MfSecArgs {
     double *y_re;
     double alpha, beta, gamma;
     double *partials;            // [nparts * 3] or nullptr
+    unsigned int *ctr;           // ordered walk: 8 zeroed counters, 128 bytes apart (nullptr: static assignment)
 };
 // y <- alpha H x + beta y + gamma x in three launches (block tables, remainder rows, reductions); *nparts_out = partial sums
 int launch_mf_sector(const MfSecArgs &a, hipStream_t s, int *nparts_out);
