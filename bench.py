@@ -154,7 +154,7 @@ def reference_order_host_csr(name, w, q, stream):
     ia/ja, complex128 values, basis in the reference's Lin order j = Ja[i_a] + Jb[i_b] (src/model.cc:665-670,
     src/basis.cc:1144-1190).  Produced by the device generator + the device permutation qbh_csr_reference_order (checked entry
     by entry against the numpy re-derivation of the reference's pipeline in tests/test_gpu_reforder.py) and downloaded."""
-    o = q.make_opts(stream=stream.cuda_stream, value_dict=0, real_fast_path=0)
+    o = q.make_opts(stream=stream.cuda_stream, value_dict=0, real_fast_path=0, spmv_kernel=q._lib.KERNEL_ROWS, kron_split=0)
     G = build_operator(w, (0, -1), o)
     R = G.reference_order(*_reforder_args(w), opts=o)
     G.destroy()
@@ -568,7 +568,10 @@ def main():
         elif args.order == "reference":
             if world != 1 or args.matrix_free or value_dict != 0:
                 raise SystemExit("--order reference: one GPU, stored operator, --format complex128")
-            G = build_operator(W, (r0, r1), opts)
+            # the source of the permutation is never applied: row kernel geometry only, no second (split) copy, nothing timed
+            src_opts = q.make_opts(device=local_rank, stream=stream.cuda_stream, spmv_kernel=q._lib.KERNEL_ROWS, value_dict=0,
+                                   real_fast_path=0, kron_split=0)
+            G = build_operator(W, (r0, r1), src_opts)
             A = G.reference_order(*_reforder_args(W), opts=opts)
             G.destroy()
         else:

@@ -95,3 +95,42 @@ def test_reference_order_refuses_what_it_cannot_do():
     with pytest.raises(q._lib.QbhError):
         G.reference_order(0, 14, 0, 7)                                   # another basis
     G.destroy()
+
+
+def test_reference_order_at_headline_size_beside_its_source():
+    """C3 (dim 165,636,900, nnz 5.82e9) through the path of `bench.py --order reference`: the source operator is created for the
+    row kernel only (no split copy, nothing timed), 116 GB permuted on the device beside it.  The permuted operator is the same
+    operator in another basis: same nonzero count, Hermitian, and the ground-state energy of the matrix-free operator."""
+    from quantum_basis_amd import _lib
+    import ctypes as C
+    bonds = lattices.square(4, 4)
+    src = q.make_opts(spmv_kernel=_lib.KERNEL_ROWS, kron_split=0, **PLAIN)
+    G = q.csr_mat.hubbard(16, 8, 8, bonds, t=1.0, U=1.1, opts=src)
+    assert G.info().kron_minor == 0
+    R = G.reference_order(1, 16, 8, 8, opts=q.make_opts(**PLAIN))
+    nnz = G.nnz
+    G.destroy()
+    assert R.nnz == nnz and R.info().kron_minor == 0              # no product structure in the reference's order
+    n = R.dim
+    v = R.vec(4)
+    R.randomize(v.at(0), 21)
+    R.randomize(v.at(n), 22)
+    R.axpy_norm(0.5j, v.at(n), v.at(0))
+    R.randomize(v.at(n), 23)
+    R.spmv(v.at(0), v.at(2 * n))
+    R.spmv(v.at(n), v.at(3 * n))
+    lhs, rhs = R.dotc(v.at(0), v.at(3 * n)), R.dotc(v.at(2 * n), v.at(n))          # <x, H y> = <H x, y>
+    assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), 1.0)
+    v.free()
+    e_ref = q.locate_E0_lanczos(R, nev=1, ncv=0, maxit=1000).E0
+    R.destroy()
+    M = q.csr_mat.hubbard(16, 8, 8, bonds, t=1.0, U=1.1, matrix_free=True)
+    w = M.vec(1)
+    _lib.check(_lib.lib().qbh_vec_randomize_real(M.handle, w.ptr, C.c_uint32(1)), "qbh_vec_randomize_real")
+    maxit = 400
+    hess = np.zeros(2 * maxit)
+    m = q.lanczos_real(0, maxit - 1, maxit, M, w, hess)
+    e_mf = q.hess_eigen(hess, maxit, m, "sr")[0][0]
+    w.free()
+    M.destroy()
+    assert abs(e_ref - e_mf) <= 1e-10 * abs(e_mf)
