@@ -9,6 +9,7 @@
 #include <cstring>
 #include <initializer_list>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -164,8 +165,8 @@ int setup_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, int dict_mode, 
     // oversized-block path take the few long rows.
     int64_t window = (maxlen <= npb / 2) ? npb - (maxlen > 0 ? maxlen - 1 : 0) : npb / 2;
     int64_t n_blocks = std::max<int64_t>(1, (nnz + window - 1) / window);
-    QBH_HIP(hipMalloc(d_rb_o, (size_t)(n_blocks + 1) * sizeof(int32_t)));
-    QBH_HIP(hipMalloc(d_bp_o, (size_t)(n_blocks + 1) * sizeof(int64_t)));
+    QBH_HIP(qbh::dev_alloc(d_rb_o, (size_t)(n_blocks + 1) * sizeof(int32_t)));
+    QBH_HIP(qbh::dev_alloc(d_bp_o, (size_t)(n_blocks + 1) * sizeof(int64_t)));
     QBH_TRY(qbh::launch_build_rowblocks(d_ia, A->nrows, window, *d_rb_o, *d_bp_o, n_blocks, s));
     *npb_o = npb;
     *tpr_o = tpr;
@@ -249,9 +250,9 @@ int split_shard(qbh_csr *A)
         const int rc_ = (expr);                \
         if (rc_ != QBH_OK) return drop(rc_);   \
     } while (0)
-    SPLIT_HIP(hipMalloc(&cnt, (size_t)A->nrows * sizeof(int32_t)));
-    SPLIT_HIP(hipMalloc(&ia0, (size_t)(A->nrows + 1) * sizeof(int64_t)));
-    SPLIT_HIP(hipMalloc(&ia1, (size_t)(A->nrows + 1) * sizeof(int64_t)));
+    SPLIT_HIP(qbh::dev_alloc(&cnt, (size_t)A->nrows * sizeof(int32_t)));
+    SPLIT_HIP(qbh::dev_alloc(&ia0, (size_t)(A->nrows + 1) * sizeof(int64_t)));
+    SPLIT_HIP(qbh::dev_alloc(&ia1, (size_t)(A->nrows + 1) * sizeof(int64_t)));
     SPLIT_TRY(qbh::launch_split_count(A->d_ia, A->d_ja, A->nrows, lo, hi, cnt, s));
     SPLIT_TRY(qbh::exclusive_scan(cnt, A->nrows, ia0, s));
     (void)hipFree(cnt);
@@ -261,16 +262,16 @@ int split_shard(qbh_csr *A)
     const int64_t nnz1 = A->nnz - nnz0;
     if (nnz1 == 0) return drop(QBH_OK);        // nothing remote (block-diagonal shard): keep one part
     const bool coded = A->d_code != nullptr;
-    SPLIT_HIP(hipMalloc(&ja0, std::max<size_t>((size_t)nnz0, 1) * sizeof(int32_t)));
-    SPLIT_HIP(hipMalloc(&ja1, (size_t)nnz1 * sizeof(int32_t)));
+    SPLIT_HIP(qbh::dev_alloc(&ja0, std::max<size_t>((size_t)nnz0, 1) * sizeof(int32_t)));
+    SPLIT_HIP(qbh::dev_alloc(&ja1, (size_t)nnz1 * sizeof(int32_t)));
     if (coded) {
-        SPLIT_HIP(hipMalloc(&c0, (size_t)nnz0 * A->code_w + 16));
-        SPLIT_HIP(hipMalloc(&c1, (size_t)nnz1 * A->code_w + 16));
+        SPLIT_HIP(qbh::dev_alloc(&c0, (size_t)nnz0 * A->code_w + 16));
+        SPLIT_HIP(qbh::dev_alloc(&c1, (size_t)nnz1 * A->code_w + 16));
         SPLIT_HIP(hipMemsetAsync(c0 + (size_t)nnz0 * A->code_w, 0, 16, s));
         SPLIT_HIP(hipMemsetAsync(c1 + (size_t)nnz1 * A->code_w, 0, 16, s));
     } else {
-        SPLIT_HIP(hipMalloc(&v0, std::max<size_t>((size_t)nnz0, 1) * sizeof(d2)));
-        SPLIT_HIP(hipMalloc(&v1, (size_t)nnz1 * sizeof(d2)));
+        SPLIT_HIP(qbh::dev_alloc(&v0, std::max<size_t>((size_t)nnz0, 1) * sizeof(d2)));
+        SPLIT_HIP(qbh::dev_alloc(&v1, (size_t)nnz1 * sizeof(d2)));
     }
     SPLIT_TRY(qbh::launch_split_fill(A->d_ia, A->d_ja, A->d_val, A->d_code, A->nrows, lo, hi, ia0, ja0, v0, c0, ia1, ja1, v1, c1,
                                       A->code_w, s));
@@ -300,8 +301,55 @@ int split_shard(qbh_csr *A)
 
 
 // ---------------------------------------------------------------------------------- Kronecker split ----
+// The split is an acceleration structure beside the CSR: a second copy of the matrix.  It must never be the reason a later
+// allocation fails (Krylov bases, CG vectors, a second operator): live splits are registered, and dev_malloc releases them,
+// largest first, before it reports out of memory -- the operator then runs on its plain CSR (same results).
+std::mutex g_split_mu;
+std::vector<qbh_csr *> g_splits;
+void split_unregister(qbh_csr *A)
+{
+    std::lock_guard<std::mutex> lock(g_split_mu);
+    g_splits.erase(std::remove(g_splits.begin(), g_splits.end(), A), g_splits.end());
+}
+void split_register(qbh_csr *A)
+{
+    std::lock_guard<std::mutex> lock(g_split_mu);
+    if (std::find(g_splits.begin(), g_splits.end(), A) == g_splits.end()) g_splits.push_back(A);
+}
+void kron_release(qbh_csr *A);
+bool release_one_split()
+{
+    qbh_csr *pick = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_split_mu);
+        for (qbh_csr *A : g_splits)
+            if (!pick || A->nnz > pick->nnz) pick = A;
+    }
+    if (!pick) return false;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipSetDevice(pick->device);
+    (void)hipDeviceSynchronize();                     // nothing in flight may still read the split's arrays
+    kron_release(pick);
+    (void)hipSetDevice(dev);
+    return true;
+}
+}  // namespace
+namespace qbh {
+hipError_t device_alloc(void **p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    while (e == hipErrorOutOfMemory && release_one_split()) {
+        (void)hipGetLastError();
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+}  // namespace qbh
+namespace {
 void kron_release(qbh_csr *A)
 {
+    split_unregister(A);
     qbh_csr::KronSplit &K = A->kron;
     for (void *q : {(void *)K.ia_n, (void *)K.ia_f, (void *)K.ja_n, (void *)K.ja_f, (void *)K.val_n, (void *)K.val_f, (void *)K.wd_n,
                     (void *)K.wd_f, (void *)K.d_xt, (void *)K.d_far})
@@ -465,6 +513,7 @@ int kron_build(qbh_csr *A)
 #undef KRON_HIP
 #undef KRON_TRY
     K.active = true;
+    split_register(A);
     return QBH_OK;
 }
 
@@ -481,7 +530,7 @@ int setup_wave_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, qbh::WaveD
     // (7 slots of the tile are kept free: the kernel reads the stream from the 128-byte boundary below the block)
     const int64_t window = (maxlen <= 256) ? 505 - (maxlen > 0 ? maxlen - 1 : 0) : 249;
     const int64_t n_wb = std::max<int64_t>(1, (nnz + window - 1) / window);
-    QBH_HIP(hipMalloc(d_wd_o, (size_t)(n_wb + 2) * sizeof(qbh::WaveDesc)));
+    QBH_HIP(qbh::dev_alloc(d_wd_o, (size_t)(n_wb + 2) * sizeof(qbh::WaveDesc)));
     QBH_TRY(qbh::launch_build_wavedesc(d_ia, A->nrows, window, *d_wd_o, n_wb, s));
     const double avg = A->nrows > 0 ? (double)nnz / (double)A->nrows : 0.0;
     int tpr = avg <= 32 ? 2 : avg <= 64 ? 4 : avg <= 128 ? 8 : 16;      // rows per pass = 64 / tpr >= rows per block
@@ -545,7 +594,7 @@ int build_geometry(qbh_csr *A)
     const size_t nparts = (size_t)std::max(grid_max, qbh::kMaxRedBlocks);
     if (A->d_partials) (void)hipFree(A->d_partials);
     A->d_partials = nullptr;
-    QBH_HIP(hipMalloc(&A->d_partials, nparts * 16 * sizeof(double)));
+    QBH_HIP(qbh::dev_alloc(&A->d_partials, nparts * 16 * sizeof(double)));
     return QBH_OK;
 }
 
@@ -564,7 +613,7 @@ int autotune_kernel(qbh_csr *A)
     }
     hipStream_t s = A->stream;
     d2 *x = nullptr, *y = nullptr;
-    if (hipMalloc(&x, (size_t)A->ncols * sizeof(d2)) != hipSuccess || hipMalloc(&y, (size_t)A->nrows * sizeof(d2)) != hipSuccess) {
+    if (qbh::dev_alloc(&x, (size_t)A->ncols * sizeof(d2)) != hipSuccess || qbh::dev_alloc(&y, (size_t)A->nrows * sizeof(d2)) != hipSuccess) {
         (void)hipGetLastError();
         if (x) (void)hipFree(x);
         return QBH_OK;                     // no room for the trial vectors: keep the default choice
@@ -627,9 +676,9 @@ int finalize(qbh_csr *A)
 {
     hipStream_t s = A->stream;
     const qbh_opts &o = A->opts;
-    QBH_HIP(hipMalloc(&A->d_scal, 16 * sizeof(double)));
+    QBH_HIP(qbh::dev_alloc(&A->d_scal, 16 * sizeof(double)));
     QBH_HIP(hipHostMalloc(&A->h_scal, 16 * sizeof(double)));
-    QBH_HIP(hipMalloc(&A->d_wctr, 3 * 128 * sizeof(unsigned long long)));
+    QBH_HIP(qbh::dev_alloc(&A->d_wctr, 3 * 128 * sizeof(unsigned long long)));
     QBH_HIP(hipEventCreate(&A->ev0));
     QBH_HIP(hipEventCreate(&A->ev1));
     QBH_HIP(hipEventCreate(&A->ev2));
@@ -643,7 +692,7 @@ int finalize(qbh_csr *A)
     QBH_TRY(try_value_dict(A));
     const bool coded = A->d_code != nullptr;
     // is every stored value real?  (enables the 8-byte wire format of the x exchange)
-    QBH_HIP(hipMalloc(&A->d_flag, sizeof(int)));
+    QBH_HIP(qbh::dev_alloc(&A->d_flag, sizeof(int)));
     QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
     if (coded) {
         A->code_w = A->n_dict <= 256 ? 1 : 2;
@@ -654,7 +703,7 @@ int finalize(qbh_csr *A)
         for (int i = 0; i < A->n_dict; ++i) A->values_real = A->values_real && dict[(size_t)i].y == 0.0;
     } else if (A->d_val && A->nnz > 0) {
         double *tmp = nullptr;
-        QBH_HIP(hipMalloc(&tmp, (size_t)qbh::kMaxRedBlocks * sizeof(double)));
+        QBH_HIP(qbh::dev_alloc(&tmp, (size_t)qbh::kMaxRedBlocks * sizeof(double)));
         QBH_TRY(qbh::launch_imag_norm(A->d_val, A->nnz, tmp, s));
         std::vector<double> hp((size_t)qbh::blas_grid(A->nnz));
         QBH_HIP(hipMemcpyAsync(hp.data(), tmp, hp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -939,14 +988,14 @@ int qbh::adopt_mf_sector(qbh_csr **out, qbh::MfSec *host_tables, qbh::MfSec *dev
         qbh_csr_destroy(A);
         return code;
     };
-    if (hipMalloc(&A->d_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (qbh::dev_alloc(&A->d_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
     if (hipHostMalloc(&A->h_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
-    if (hipMalloc(&A->d_flag, sizeof(int)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (qbh::dev_alloc(&A->d_flag, sizeof(int)) != hipSuccess) return fail(QBH_ENOMEM);
     if (hipMemset(A->d_flag, 0, sizeof(int)) != hipSuccess) return fail(QBH_EHIP);
     if (hipEventCreate(&A->ev0) != hipSuccess || hipEventCreate(&A->ev1) != hipSuccess ||
         hipEventCreate(&A->ev2) != hipSuccess || hipEventCreate(&A->ev3) != hipSuccess)
         return fail(QBH_EHIP);
-    if (hipMalloc(&A->d_partials, (size_t)qbh::kMaxRedBlocks * 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (qbh::dev_alloc(&A->d_partials, (size_t)qbh::kMaxRedBlocks * 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
     A->stats = qbh_stats{};
     A->stats.ms_spmv_min = std::numeric_limits<double>::infinity();
     A->kind = 3;                // from here on the handle owns the tables (on any failure above the caller still does)
@@ -973,15 +1022,15 @@ int qbh::adopt_mf_hubbard(qbh_csr **out, const qbh::MfHubbard &t, int64_t nrows,
         qbh_csr_destroy(A);
         return code;
     };
-    if (hipMalloc(&A->d_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (qbh::dev_alloc(&A->d_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
     if (hipHostMalloc(&A->h_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
-    if (hipMalloc(&A->d_flag, sizeof(int)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (qbh::dev_alloc(&A->d_flag, sizeof(int)) != hipSuccess) return fail(QBH_ENOMEM);
     if (hipMemset(A->d_flag, 0, sizeof(int)) != hipSuccess) return fail(QBH_EHIP);
     if (hipEventCreate(&A->ev0) != hipSuccess || hipEventCreate(&A->ev1) != hipSuccess ||
         hipEventCreate(&A->ev2) != hipSuccess || hipEventCreate(&A->ev3) != hipSuccess)
         return fail(QBH_EHIP);
     const size_t nparts = (size_t)std::max(A->grid, qbh::kMaxRedBlocks);
-    if (hipMalloc(&A->d_partials, nparts * 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (qbh::dev_alloc(&A->d_partials, nparts * 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
     A->stats = qbh_stats{};
     A->stats.ms_spmv_min = std::numeric_limits<double>::infinity();
     A->kind = 1;                // from here on the handle owns the tables (on any failure above the caller still does)
@@ -1007,15 +1056,15 @@ int qbh::adopt_mf_heis(qbh_csr **out, const qbh::MfHeis &t, int64_t nrows, int64
         qbh_csr_destroy(A);
         return code;
     };
-    if (hipMalloc(&A->d_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (qbh::dev_alloc(&A->d_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
     if (hipHostMalloc(&A->h_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
-    if (hipMalloc(&A->d_flag, sizeof(int)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (qbh::dev_alloc(&A->d_flag, sizeof(int)) != hipSuccess) return fail(QBH_ENOMEM);
     if (hipMemset(A->d_flag, 0, sizeof(int)) != hipSuccess) return fail(QBH_EHIP);
     if (hipEventCreate(&A->ev0) != hipSuccess || hipEventCreate(&A->ev1) != hipSuccess ||
         hipEventCreate(&A->ev2) != hipSuccess || hipEventCreate(&A->ev3) != hipSuccess)
         return fail(QBH_EHIP);
     const size_t nparts = (size_t)std::max(A->grid, qbh::kMaxRedBlocks);
-    if (hipMalloc(&A->d_partials, nparts * 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
+    if (qbh::dev_alloc(&A->d_partials, nparts * 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
     A->stats = qbh_stats{};
     A->stats.ms_spmv_min = std::numeric_limits<double>::infinity();
     A->kind = 2;                // from here on the handle owns the tables (on any failure above the caller still does)
@@ -1282,7 +1331,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
             ms.partials = m.partials;
             static const int sec_walk = getenv("QBH_SEC_WALK") ? atoi(getenv("QBH_SEC_WALK")) : 0;
             if (sec_walk) {
-                if (!A->d_wctr) QBH_HIP(hipMalloc(&A->d_wctr, 3 * 128 * sizeof(unsigned long long)));
+                if (!A->d_wctr) QBH_HIP(qbh::dev_alloc(&A->d_wctr, 3 * 128 * sizeof(unsigned long long)));
                 QBH_HIP(hipMemsetAsync(A->d_wctr, 0, 3 * 128 * sizeof(unsigned long long), A->stream));
                 ms.ctr = reinterpret_cast<unsigned int *>(A->d_wctr);
             }
@@ -1536,7 +1585,7 @@ int enable_real_wire(qbh_csr *A, std::initializer_list<const d2 *> vecs)
         if (const char *e = getenv("QBH_NO_REAL_MODE")) {
             if (atoi(e)) A->real_mode = false;
         }
-        if (A->real_mode && !A->has_comm && !A->d_xr) QBH_HIP(hipMalloc(&A->d_xr, (size_t)A->ncols * sizeof(double)));
+        if (A->real_mode && !A->has_comm && !A->d_xr) QBH_HIP(qbh::dev_alloc(&A->d_xr, (size_t)A->ncols * sizeof(double)));
     }
     return QBH_OK;
 }
@@ -1625,7 +1674,7 @@ extern "C" int qbh_vec_alloc(qbh_z **d_out, int64_t n)
         qbh::set_error("no HIP device visible");
         return QBH_ENODEVICE;
     }
-    QBH_HIP(hipMalloc((void **)d_out, (size_t)n * sizeof(qbh_z)));
+    QBH_HIP(qbh::dev_alloc((void **)d_out, (size_t)n * sizeof(qbh_z)));
     return QBH_OK;
 }
 
@@ -1731,8 +1780,8 @@ int multmv_host(qbh_csr *A, const qbh_z *x_host, qbh_z *y_host, double beta)
     }
     Bind bind(A);
     const size_t bytes = (size_t)A->nrows * sizeof(d2);
-    if (!A->d_stage_x) QBH_HIP(hipMalloc(&A->d_stage_x, bytes));
-    if (!A->d_stage_y) QBH_HIP(hipMalloc(&A->d_stage_y, bytes));
+    if (!A->d_stage_x) QBH_HIP(qbh::dev_alloc(&A->d_stage_x, bytes));
+    if (!A->d_stage_y) QBH_HIP(qbh::dev_alloc(&A->d_stage_y, bytes));
     QBH_HIP(hipMemcpyAsync(A->d_stage_x, x_host, bytes, hipMemcpyHostToDevice, A->stream));
     if (beta != 0.0) QBH_HIP(hipMemcpyAsync(A->d_stage_y, y_host, bytes, hipMemcpyHostToDevice, A->stream));
     QBH_TRY(spmv_run(A, A->d_stage_x, A->d_stage_y, 1.0, beta, 0.0, nullptr));
@@ -1878,7 +1927,7 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
     {
         static const bool no_realvec = getenv("QBH_NO_REALVEC") != nullptr;      // A/B switch
         if (!rv_external && !A->has_comm && A->real_mode && A->kernel == QBH_KERNEL_ROWS && A->nrows == A->ncols && !no_realvec) {
-            if (hipMalloc(&rv, (size_t)(is_val1 ? 3 : 2) * (size_t)n * sizeof(double)) != hipSuccess) {
+            if (qbh::dev_alloc(&rv, (size_t)(is_val1 ? 3 : 2) * (size_t)n * sizeof(double)) != hipSuccess) {
                 (void)hipGetLastError();
                 rv = nullptr;                         // no room: stay on the complex vectors
             } else {
@@ -2123,7 +2172,7 @@ extern "C" int qbh_lanczos(const qbh_csr *A, int64_t k, int64_t np, int64_t maxi
     const int64_t nvec = val1 ? 3 : 2;
     const size_t bytes = (size_t)nvec * (size_t)A->nrows * sizeof(qbh_z);
     qbh_z *d_v = nullptr;
-    QBH_HIP(hipMalloc((void **)&d_v, bytes));
+    QBH_HIP(qbh::dev_alloc((void **)&d_v, bytes));
     int rc = QBH_OK;
     hipError_t e = hipMemcpy(d_v, v_host, bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = QBH_EHIP;
@@ -2183,7 +2232,7 @@ static int cg_core(qbh_csr *A, int64_t maxit, int64_t *m_io, double E0, double *
     {
         static const bool no_realvec = getenv("QBH_NO_REALVEC") != nullptr;
         if (!ext && !A->has_comm && A->real_mode && A->kernel == QBH_KERNEL_ROWS && A->nrows == A->ncols && !no_realvec) {
-            if (hipMalloc(&rv, (size_t)4 * (size_t)n * sizeof(double)) != hipSuccess) {
+            if (qbh::dev_alloc(&rv, (size_t)4 * (size_t)n * sizeof(double)) != hipSuccess) {
                 (void)hipGetLastError();
                 rv = nullptr;
             }
@@ -2325,7 +2374,7 @@ extern "C" int qbh_eigenvec_cg(const qbh_csr *A, int64_t maxit, int64_t *m, doub
     Bind bind(A);
     const size_t n = (size_t)A->nrows, bytes = n * sizeof(qbh_z);
     qbh_z *d = nullptr;
-    QBH_HIP(hipMalloc((void **)&d, 4 * bytes));
+    QBH_HIP(qbh::dev_alloc((void **)&d, 4 * bytes));
     int rc = QBH_OK;
     qbh_z *hv[4] = {v_host, r_host, p_host, pp_host};
     for (int i = 0; i < 3 && rc == QBH_OK; ++i)      // pp is scratch on entry
@@ -2394,7 +2443,7 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
     int64_t nc = n, ldr = 0;                  // complex length / leading dimension the BLAS-1 kernels see
     {
         d2 *v0 = nullptr;
-        QBH_HIP(hipMalloc(&v0, (size_t)n * sizeof(d2)));
+        QBH_HIP(qbh::dev_alloc(&v0, (size_t)n * sizeof(d2)));
         rc = qbh_vec_randomize(A, reinterpret_cast<qbh_z *>(v0), seed ? seed : 1u);
         if (rc == QBH_OK) rc = enable_real_wire(A, {v0});      // the random start vector is real
         static const bool no_realvec = getenv("QBH_NO_REALVEC") != nullptr;
@@ -2403,7 +2452,7 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
         if (all_real) {
             ldr = n + (n & 1);
             nc = ldr / 2;
-            e0 = hipMalloc(&V, (size_t)(m + 1) * (size_t)ldr * sizeof(double));
+            e0 = qbh::dev_alloc(&V, (size_t)(m + 1) * (size_t)ldr * sizeof(double));
             // every vector is written in full by the SpMV (beta = 0) before it is read; only the padding element
             // of an odd dimension has to be zero
             for (int j = 0; e0 == hipSuccess && (n & 1) && j <= m; ++j)
@@ -2411,7 +2460,7 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
             if (e0 == hipSuccess && rc == QBH_OK)
                 rc = qbh::launch_pack_real(v0, reinterpret_cast<double *>(V), n, A->d_flag, A->stream);
         } else {
-            e0 = hipMalloc(&V, (size_t)(m + 1) * (size_t)n * sizeof(d2));
+            e0 = qbh::dev_alloc(&V, (size_t)(m + 1) * (size_t)n * sizeof(d2));
             if (e0 == hipSuccess)
                 e0 = hipMemcpyAsync(V, v0, (size_t)n * sizeof(d2), hipMemcpyDeviceToDevice, A->stream);
         }
@@ -2423,7 +2472,7 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
             return e0 == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP;
         }
     }
-    hipError_t e = hipMalloc(&d_S, 64 * 64 * sizeof(double));
+    hipError_t e = qbh::dev_alloc(&d_S, 64 * 64 * sizeof(double));
     if (e != hipSuccess) {
         (void)hipFree(V);
         return QBH_ENOMEM;
@@ -2530,7 +2579,7 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
         *nconv_out = nconv;
         if (eigenvecs_host && all_real) {
             d2 *tmp = nullptr;
-            if (hipMalloc(&tmp, (size_t)n * sizeof(d2)) != hipSuccess) rc = QBH_ENOMEM;
+            if (qbh::dev_alloc(&tmp, (size_t)n * sizeof(d2)) != hipSuccess) rc = QBH_ENOMEM;
             for (int i = 0; rc == QBH_OK && i < (int)nev; ++i) {
                 rc = qbh::launch_unpack_real(rvec(i), tmp, n, A->stream);
                 if (rc == QBH_OK && hipMemcpyAsync(eigenvecs_host + (size_t)i * (size_t)n, tmp, (size_t)n * sizeof(d2),

@@ -256,10 +256,10 @@ struct Stager {
         cap = chunk;
         for (int b = 0; b < 2; ++b) {
             QBH_HIP(hipHostMalloc(&h_ja[b], (size_t)chunk * sizeof(int32_t)));
-            QBH_HIP(hipMalloc(&d_ja[b], (size_t)chunk * sizeof(int32_t)));
+            QBH_HIP(qbh::dev_alloc(&d_ja[b], (size_t)chunk * sizeof(int32_t)));
             if (with_val) {
                 QBH_HIP(hipHostMalloc(&h_val[b], (size_t)chunk * sizeof(d2)));
-                QBH_HIP(hipMalloc(&d_val[b], (size_t)chunk * sizeof(d2)));
+                QBH_HIP(qbh::dev_alloc(&d_val[b], (size_t)chunk * sizeof(d2)));
             }
             QBH_HIP(hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
         }
@@ -314,7 +314,7 @@ int build_shard_from_host(int64_t dim, int64_t nnz, int sym, const int64_t *ia, 
     } while (0)
 
     // the row pointers of the host rows involved (pageable -> device; 8 B per row, small next to the matrix)
-    QBH_B(hipMalloc(&d_ia, (size_t)n_ia * sizeof(int64_t)));
+    QBH_B(qbh::dev_alloc(&d_ia, (size_t)n_ia * sizeof(int64_t)));
     QBH_B(hipMemcpyAsync(d_ia, ia + row0, (size_t)n_ia * sizeof(int64_t), hipMemcpyHostToDevice, s));
     const int64_t *d_ia_own = d_ia + (r0 - row0);        // pointers of the shard's own rows
 
@@ -373,7 +373,7 @@ int build_shard_from_host(int64_t dim, int64_t nnz, int sym, const int64_t *ia, 
     };
 
     if (sym) {
-        QBH_B(hipMalloc(&d_low, (size_t)nloc * sizeof(int32_t)));
+        QBH_B(qbh::dev_alloc(&d_low, (size_t)nloc * sizeof(int32_t)));
         QBH_B(hipMemsetAsync(d_low, 0, (size_t)nloc * sizeof(int32_t), s));
         QBH_BT(stream_pass(false, [&](int b, int64_t g, int n, int64_t rlo, int64_t rhi) {
             hipLaunchKernelGGL(k_mirror_count, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, st.d_ja[b], g, n, d_ia, rlo, rhi,
@@ -381,19 +381,19 @@ int build_shard_from_host(int64_t dim, int64_t nnz, int sym, const int64_t *ia, 
         }));
     }
     mark("pass 1 (mirror count)");
-    QBH_B(hipMalloc(&d_cnt, (size_t)nloc * sizeof(int32_t)));
+    QBH_B(qbh::dev_alloc(&d_cnt, (size_t)nloc * sizeof(int32_t)));
     hipLaunchKernelGGL(k_row_total, dim3(blas_grid(nloc)), dim3(kBlock), 0, s, d_ia_own, d_low, nloc, d_cnt);
     QBH_B(hipGetLastError());
-    QBH_B(hipMalloc(&d_ia_f, (size_t)(nloc + 1) * sizeof(int64_t)));
+    QBH_B(qbh::dev_alloc(&d_ia_f, (size_t)(nloc + 1) * sizeof(int64_t)));
     QBH_BT(exclusive_scan(d_cnt, nloc, d_ia_f, s));
     int64_t nnz_f = 0;
     QBH_B(hipMemcpy(&nnz_f, d_ia_f + nloc, sizeof(int64_t), hipMemcpyDeviceToHost));
     (void)hipFree(d_cnt);
     d_cnt = nullptr;
-    QBH_B(hipMalloc(&d_ja_f, std::max<size_t>((size_t)nnz_f, 1) * sizeof(int32_t)));
-    QBH_B(hipMalloc(&d_val_f, std::max<size_t>((size_t)nnz_f, 1) * sizeof(d2)));
+    QBH_B(qbh::dev_alloc(&d_ja_f, std::max<size_t>((size_t)nnz_f, 1) * sizeof(int32_t)));
+    QBH_B(qbh::dev_alloc(&d_val_f, std::max<size_t>((size_t)nnz_f, 1) * sizeof(d2)));
     if (sym) {
-        QBH_B(hipMalloc(&d_cur, (size_t)nloc * sizeof(int32_t)));
+        QBH_B(qbh::dev_alloc(&d_cur, (size_t)nloc * sizeof(int32_t)));
         QBH_B(hipMemsetAsync(d_cur, 0, (size_t)nloc * sizeof(int32_t), s));
     }
     QBH_BT(stream_pass(true, [&](int b, int64_t g, int n, int64_t rlo, int64_t rhi) {
@@ -422,10 +422,10 @@ int build_shard_from_host(int64_t dim, int64_t nnz, int sym, const int64_t *ia, 
             int64_t *d_rows = nullptr, *d_off = nullptr;
             int32_t *tc = nullptr;
             d2 *tv = nullptr;
-            QBH_B(hipMalloc(&d_rows, rows.size() * sizeof(int64_t)));
-            QBH_B(hipMalloc(&d_off, rows.size() * sizeof(int64_t)));
-            QBH_B(hipMalloc(&tc, (size_t)tot * sizeof(int32_t)));
-            QBH_B(hipMalloc(&tv, (size_t)tot * sizeof(d2)));
+            QBH_B(qbh::dev_alloc(&d_rows, rows.size() * sizeof(int64_t)));
+            QBH_B(qbh::dev_alloc(&d_off, rows.size() * sizeof(int64_t)));
+            QBH_B(qbh::dev_alloc(&tc, (size_t)tot * sizeof(int32_t)));
+            QBH_B(qbh::dev_alloc(&tv, (size_t)tot * sizeof(d2)));
             QBH_B(hipMemcpy(d_rows, rows.data(), rows.size() * sizeof(int64_t), hipMemcpyHostToDevice));
             QBH_B(hipMemcpy(d_off, off.data(), rows.size() * sizeof(int64_t), hipMemcpyHostToDevice));
             hipLaunchKernelGGL(k_sort_lower_long, dim3((unsigned)std::min<size_t>(rows.size(), 4096)), dim3(kBlock), 0, s, d_ia_f, d_low,

@@ -308,10 +308,10 @@ extern "C" int qbh_comm_create_rccl(qbh_csr *A, const void *uid128, int rank, in
     QBH_C(hipEventCreate(&c->t0));
     QBH_C(hipEventCreate(&c->t1));
     c->owner = A;
-    QBH_C(hipMalloc(&c->d_xsend, (size_t)c->nblk * 2 * sizeof(double)));
-    QBH_C(hipMalloc(&c->d_xfull, full * 2 * sizeof(double)));
-    QBH_C(hipMalloc(&c->d_xfull_r, full * sizeof(double)));
-    QBH_C(hipMalloc(&c->d_scal, 16 * sizeof(double)));
+    QBH_C(qbh::dev_alloc(&c->d_xsend, (size_t)c->nblk * 2 * sizeof(double)));
+    QBH_C(qbh::dev_alloc(&c->d_xfull, full * 2 * sizeof(double)));
+    QBH_C(qbh::dev_alloc(&c->d_xfull_r, full * sizeof(double)));
+    QBH_C(qbh::dev_alloc(&c->d_scal, 16 * sizeof(double)));
     QBH_C(hipMemset(c->d_xsend, 0, (size_t)c->nblk * 2 * sizeof(double)));
     QBH_C(hipMemset(c->d_xfull, 0, full * 2 * sizeof(double)));
     QBH_C(hipMemset(c->d_scal, 0, 16 * sizeof(double)));

@@ -159,7 +159,7 @@ template <typename T>
 int upload(const std::vector<T> &h, T **d, std::vector<void *> &pool)
 {
     const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
-    QBH_HIP(hipMalloc((void **)d, bytes));
+    QBH_HIP(qbh::dev_alloc((void **)d, bytes));
     pool.push_back(*d);
     if (!h.empty()) QBH_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return QBH_OK;
@@ -366,9 +366,9 @@ extern "C" int qbh_gen_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, i
     int64_t *d_ia = nullptr;
     int32_t *d_ja = nullptr;
     d2 *d_val = nullptr;
-    hipError_t e = hipMalloc(&d_ia, (size_t)(nrows + 1) * sizeof(int64_t));
-    if (e == hipSuccess) e = hipMalloc(&d_ja, (size_t)nnz * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_val, (size_t)nnz * sizeof(d2));
+    hipError_t e = qbh::dev_alloc(&d_ia, (size_t)(nrows + 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = qbh::dev_alloc(&d_ja, (size_t)nnz * sizeof(int32_t));
+    if (e == hipSuccess) e = qbh::dev_alloc(&d_val, (size_t)nnz * sizeof(d2));
     if (e == hipSuccess) {
         const int64_t groups = nrows;
         int64_t grid = (groups * 32 + 255) / 256;
@@ -426,8 +426,8 @@ int upload_ell(const qbh::HopTableView &H, std::vector<double> &amp, int *width,
             val[(size_t)(q - H.ptr[i]) * N + i] = (uint8_t)code;
         }
     *width = w;
-    QBH_HIP(hipMalloc(d_tgt, tgt.size() * sizeof(uint32_t)));
-    QBH_HIP(hipMalloc(d_val, val.size()));
+    QBH_HIP(qbh::dev_alloc(d_tgt, tgt.size() * sizeof(uint32_t)));
+    QBH_HIP(qbh::dev_alloc(d_val, val.size()));
     QBH_HIP(hipMemcpy(*d_tgt, tgt.data(), tgt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     QBH_HIP(hipMemcpy(*d_val, val.data(), val.size(), hipMemcpyHostToDevice));
     return QBH_OK;
@@ -481,8 +481,8 @@ extern "C" int qbh_mf_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, in
             if (q) (void)hipFree(q);
     };
     auto build = [&]() -> int {
-    QBH_HIP(hipMalloc(&m.cfg_u, (size_t)Nu * sizeof(uint32_t)));
-    QBH_HIP(hipMalloc(&m.cfg_d, (size_t)Nd * sizeof(uint32_t)));
+    QBH_HIP(qbh::dev_alloc(&m.cfg_u, (size_t)Nu * sizeof(uint32_t)));
+    QBH_HIP(qbh::dev_alloc(&m.cfg_d, (size_t)Nd * sizeof(uint32_t)));
     QBH_HIP(hipMemcpy(m.cfg_u, hu.cfg.data(), (size_t)Nu * sizeof(uint32_t), hipMemcpyHostToDevice));
     QBH_HIP(hipMemcpy(m.cfg_d, hd.cfg.data(), (size_t)Nd * sizeof(uint32_t), hipMemcpyHostToDevice));
     HopTableView vu{Nu, hu.ptr.data(), hu.tgt.data(), hu.val.data()}, vd{Nd, hd.ptr.data(), hd.tgt.data(), hd.val.data()};
@@ -502,7 +502,7 @@ extern "C" int qbh_mf_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, in
                     if (amp[c] == hd.val[q]) code = (int)c;
                 pk[((size_t)(k / 4) * Nd + d) * 4 + (k & 3)] = (uint32_t)hd.tgt[q] | ((uint32_t)code << 24);
             }
-        QBH_HIP(hipMalloc(&m.pk_d, pk.size() * sizeof(uint32_t)));
+        QBH_HIP(qbh::dev_alloc(&m.pk_d, pk.size() * sizeof(uint32_t)));
         QBH_HIP(hipMemcpy(m.pk_d, pk.data(), pk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     return QBH_OK;
@@ -568,8 +568,8 @@ extern "C" int qbh_gen_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bo
     d2 *d_val = nullptr;
     int64_t nnz = 0;
     int rc = QBH_OK;
-    hipError_t e = hipMalloc(&d_cnt, (size_t)nrows * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_ia, (size_t)(nrows + 1) * sizeof(int64_t));
+    hipError_t e = qbh::dev_alloc(&d_cnt, (size_t)nrows * sizeof(int32_t));
+    if (e == hipSuccess) e = qbh::dev_alloc(&d_ia, (size_t)(nrows + 1) * sizeof(int64_t));
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_heis_count, dim3(blas_grid(nrows)), dim3(256), 0, 0, d_h, row_begin, row_end, d_cnt);
         e = hipGetLastError();
@@ -578,8 +578,8 @@ extern "C" int qbh_gen_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bo
     if (e == hipSuccess && rc == QBH_OK)
         e = hipMemcpy(&nnz, d_ia + nrows, sizeof(int64_t), hipMemcpyDeviceToHost);
     if (d_cnt) (void)hipFree(d_cnt);
-    if (e == hipSuccess && rc == QBH_OK) e = hipMalloc(&d_ja, (size_t)nnz * sizeof(int32_t));
-    if (e == hipSuccess && rc == QBH_OK) e = hipMalloc(&d_val, (size_t)nnz * sizeof(d2));
+    if (e == hipSuccess && rc == QBH_OK) e = qbh::dev_alloc(&d_ja, (size_t)nnz * sizeof(int32_t));
+    if (e == hipSuccess && rc == QBH_OK) e = qbh::dev_alloc(&d_val, (size_t)nnz * sizeof(d2));
     if (e == hipSuccess && rc == QBH_OK) {
         hipLaunchKernelGGL(k_heis_fill, dim3(blas_grid(nrows)), dim3(256), 0, 0, d_h, row_begin, row_end, d_ia, d_ja,
                            d_val);
@@ -1136,9 +1136,9 @@ static int gen_heisenberg_repr_impl(qbh_csr **out, int n_sites, int n_dn, int n_
         }                                                                                      \
     } while (0)
     // 1. which states are representatives; their stabiliser order and norm
-    QBH_R(hipMalloc(&d_code, (size_t)nstates));
-    QBH_R(hipMalloc(&d_cnt, (size_t)nstates * sizeof(int32_t)));
-    QBH_R(hipMalloc(&d_pos, (size_t)(nstates + 1) * sizeof(int64_t)));
+    QBH_R(qbh::dev_alloc(&d_code, (size_t)nstates));
+    QBH_R(qbh::dev_alloc(&d_cnt, (size_t)nstates * sizeof(int32_t)));
+    QBH_R(qbh::dev_alloc(&d_pos, (size_t)(nstates + 1) * sizeof(int64_t)));
     hipLaunchKernelGGL(k_repr_flag, dim3(blas_grid((nstates + 31) / 32)), dim3(256), 0, 0, d_R, d_tab, nstates, d_code, d_cnt);
     QBH_R(hipGetLastError());
     rc = exclusive_scan(d_cnt, nstates, d_pos, 0);
@@ -1152,8 +1152,8 @@ static int gen_heisenberg_repr_impl(qbh_csr **out, int n_sites, int n_dn, int n_
         cleanup(true);
         return QBH_EUNSUPP;
     }
-    QBH_R(hipMalloc(&d_reps, (size_t)dim * sizeof(uint64_t)));
-    QBH_R(hipMalloc(&d_info, (size_t)dim));
+    QBH_R(qbh::dev_alloc(&d_reps, (size_t)dim * sizeof(uint64_t)));
+    QBH_R(qbh::dev_alloc(&d_info, (size_t)dim));
     hipLaunchKernelGGL(k_repr_compact, dim3(blas_grid((nstates + 31) / 32)), dim3(256), 0, 0, d_R, nstates, d_code, d_pos, d_reps,
                        d_info);
     QBH_R(hipGetLastError());
@@ -1183,8 +1183,8 @@ static int gen_heisenberg_repr_impl(qbh_csr **out, int n_sites, int n_dn, int n_
             return rc;
         }
     }
-    QBH_R(hipMalloc(&d_cnt, (size_t)nloc * sizeof(int32_t)));
-    QBH_R(hipMalloc(&d_ia, (size_t)(nloc + 1) * sizeof(int64_t)));
+    QBH_R(qbh::dev_alloc(&d_cnt, (size_t)nloc * sizeof(int32_t)));
+    QBH_R(qbh::dev_alloc(&d_ia, (size_t)(nloc + 1) * sizeof(int64_t)));
     const int rgrid = (int)std::min<int64_t>((nloc + 127) / 128, 256 * 16);
     hipLaunchKernelGGL(k_repr_count, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_cnt, db.tab);
     QBH_R(hipGetLastError());
@@ -1195,7 +1195,7 @@ static int gen_heisenberg_repr_impl(qbh_csr **out, int n_sites, int n_dn, int n_
     }
     QBH_R(hipMemcpy(&nnz, d_ia + nloc, sizeof(int64_t), hipMemcpyDeviceToHost));
     (void)hipFree(d_cnt); d_cnt = nullptr;
-    QBH_R(hipMalloc(&d_ja, (size_t)nnz * sizeof(int32_t)));
+    QBH_R(qbh::dev_alloc(&d_ja, (size_t)nnz * sizeof(int32_t)));
     int n_dict = 0;
     if (want_dict) {
         rc = dict_build_finalize(&db, &d_dict, &n_dict, 0);
@@ -1207,7 +1207,7 @@ static int gen_heisenberg_repr_impl(qbh_csr **out, int n_sites, int n_dn, int n_
     if (n_dict > 0) {
         // few distinct values: emit 1- or 2-byte codes directly (5 or 6 B/nnz instead of 20)
         const int w = dict_code_width(n_dict);
-        QBH_R(hipMalloc(&d_code, (size_t)nnz * w + 16));
+        QBH_R(qbh::dev_alloc(&d_code, (size_t)nnz * w + 16));
         QBH_R(hipMemset(d_code + (size_t)nnz * w, 0, 16));
         if (w == 1)
             hipLaunchKernelGGL(k_repr_fill_coded<uint8_t>, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_ia,
@@ -1229,7 +1229,7 @@ static int gen_heisenberg_repr_impl(qbh_csr **out, int n_sites, int n_dn, int n_
     } else {
         if (d_dict) (void)hipFree(d_dict);
         d_dict = nullptr;
-        hipError_t e = hipMalloc(&d_val, (size_t)nnz * sizeof(d2));
+        hipError_t e = qbh::dev_alloc(&d_val, (size_t)nnz * sizeof(d2));
         if (e != hipSuccess) {
             set_error("qbh_gen_heisenberg_repr: %lld nonzeros with more than 65536 distinct values do not fit this GPU "
                       "uncoded (%.1f GB); shard the sector over more GPUs", (long long)nnz, 20e-9 * (double)nnz);
@@ -1313,9 +1313,9 @@ extern "C" int qbh_mopr_sz_repr_dev(int n_sites, int n_dn, int n_trans, const in
     hipError_t e = hipSuccess;
     int64_t dim = 0;
     if (rc == QBH_OK) {
-        e = hipMalloc(&d_code, (size_t)nstates);
-        if (e == hipSuccess) e = hipMalloc(&d_cnt, (size_t)nstates * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc(&d_pos, (size_t)(nstates + 1) * sizeof(int64_t));
+        e = qbh::dev_alloc(&d_code, (size_t)nstates);
+        if (e == hipSuccess) e = qbh::dev_alloc(&d_cnt, (size_t)nstates * sizeof(int32_t));
+        if (e == hipSuccess) e = qbh::dev_alloc(&d_pos, (size_t)(nstates + 1) * sizeof(int64_t));
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_repr_flag, dim3(blas_grid((nstates + 31) / 32)), dim3(256), 0, 0, d_R, d_tab, nstates, d_code, d_cnt);
             e = hipGetLastError();
@@ -1387,11 +1387,11 @@ int enumerate_sector(int n_sites, int n_dn, int n_trans, const int32_t *perms, c
     uint8_t *d_code = nullptr;
     int32_t *d_cnt = nullptr;
     int64_t *d_pos = nullptr;
-    QBH_HIP(hipMalloc(&d_code, (size_t)nstates));
+    QBH_HIP(qbh::dev_alloc(&d_code, (size_t)nstates));
     pool.push_back(d_code);
-    QBH_HIP(hipMalloc(&d_cnt, (size_t)nstates * sizeof(int32_t)));
+    QBH_HIP(qbh::dev_alloc(&d_cnt, (size_t)nstates * sizeof(int32_t)));
     pool.push_back(d_cnt);
-    QBH_HIP(hipMalloc(&d_pos, (size_t)(nstates + 1) * sizeof(int64_t)));
+    QBH_HIP(qbh::dev_alloc(&d_pos, (size_t)(nstates + 1) * sizeof(int64_t)));
     pool.push_back(d_pos);
     hipLaunchKernelGGL(k_repr_flag, dim3(blas_grid((nstates + 31) / 32)), dim3(256), 0, 0, *d_R_out, *d_tab_out, nstates, d_code, d_cnt);
     QBH_HIP(hipGetLastError());
@@ -1402,9 +1402,9 @@ int enumerate_sector(int n_sites, int n_dn, int n_trans, const int32_t *perms, c
         set_error("%s: empty sector", who);
         return QBH_EINVAL;
     }
-    QBH_HIP(hipMalloc(d_reps_out, (size_t)dim * sizeof(uint64_t)));
+    QBH_HIP(qbh::dev_alloc(d_reps_out, (size_t)dim * sizeof(uint64_t)));
     pool.push_back(*d_reps_out);
-    QBH_HIP(hipMalloc(d_info_out, (size_t)dim));
+    QBH_HIP(qbh::dev_alloc(d_info_out, (size_t)dim));
     pool.push_back(*d_info_out);
     hipLaunchKernelGGL(k_repr_compact, dim3(blas_grid((nstates + 31) / 32)), dim3(256), 0, 0, *d_R_out, nstates, d_code, d_pos, *d_reps_out,
                        *d_info_out);
@@ -2008,9 +2008,9 @@ static int gen_hubbard_repr_impl(qbh_csr **out, int n_sites, int n_up, int n_dn,
     // 1. which words are representatives (one code byte per word, counts per chunk of 4096 words)
     const int64_t nchunks = (nstates + kHubChunk - 1) / kHubChunk;
     const int egrid = (int)std::min<int64_t>(nchunks, 256 * 32);
-    QBH_R(hipMalloc(&d_code, (size_t)nstates));
-    QBH_R(hipMalloc(&d_cnt, (size_t)nchunks * sizeof(int32_t)));
-    QBH_R(hipMalloc(&d_pos, (size_t)(nchunks + 1) * sizeof(int64_t)));
+    QBH_R(qbh::dev_alloc(&d_code, (size_t)nstates));
+    QBH_R(qbh::dev_alloc(&d_cnt, (size_t)nchunks * sizeof(int32_t)));
+    QBH_R(qbh::dev_alloc(&d_pos, (size_t)(nchunks + 1) * sizeof(int64_t)));
     hipLaunchKernelGGL(k_hubrepr_flag, dim3(egrid), dim3(256), 0, 0, d_R, d_tab, nstates, d_code, d_cnt, nchunks);
     QBH_R(hipGetLastError());
     rc = exclusive_scan(d_cnt, nchunks, d_pos, 0);
@@ -2024,8 +2024,8 @@ static int gen_hubbard_repr_impl(qbh_csr **out, int n_sites, int n_up, int n_dn,
         cleanup(true);
         return QBH_EUNSUPP;
     }
-    QBH_R(hipMalloc(&d_reps, (size_t)dim * sizeof(uint64_t)));
-    QBH_R(hipMalloc(&d_info, (size_t)dim));
+    QBH_R(qbh::dev_alloc(&d_reps, (size_t)dim * sizeof(uint64_t)));
+    QBH_R(qbh::dev_alloc(&d_info, (size_t)dim));
     hipLaunchKernelGGL(k_hubrepr_compact, dim3(egrid), dim3(256), 0, 0, d_R, nstates, d_code, d_pos, nchunks, d_reps, d_info);
     QBH_R(hipGetLastError());
     QBH_R(hipDeviceSynchronize());
@@ -2054,8 +2054,8 @@ static int gen_hubbard_repr_impl(qbh_csr **out, int n_sites, int n_up, int n_dn,
             return rc;
         }
     }
-    QBH_R(hipMalloc(&d_cnt, (size_t)nloc * sizeof(int32_t)));
-    QBH_R(hipMalloc(&d_ia, (size_t)(nloc + 1) * sizeof(int64_t)));
+    QBH_R(qbh::dev_alloc(&d_cnt, (size_t)nloc * sizeof(int32_t)));
+    QBH_R(qbh::dev_alloc(&d_ia, (size_t)(nloc + 1) * sizeof(int64_t)));
     const int rgrid = (int)std::min<int64_t>((nloc + 127) / 128, 256 * 16);
     hipLaunchKernelGGL(k_hubrepr_count, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_cnt, db.tab);
     QBH_R(hipGetLastError());
@@ -2066,7 +2066,7 @@ static int gen_hubbard_repr_impl(qbh_csr **out, int n_sites, int n_up, int n_dn,
     }
     QBH_R(hipMemcpy(&nnz, d_ia + nloc, sizeof(int64_t), hipMemcpyDeviceToHost));
     (void)hipFree(d_cnt); d_cnt = nullptr;
-    QBH_R(hipMalloc(&d_ja, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t)));
+    QBH_R(qbh::dev_alloc(&d_ja, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t)));
     int n_dict = 0;
     if (want_dict) {
         rc = dict_build_finalize(&db, &d_dict, &n_dict, 0);
@@ -2079,7 +2079,7 @@ static int gen_hubbard_repr_impl(qbh_csr **out, int n_sites, int n_up, int n_dn,
         // few distinct values (hopping amplitude x sign x phase x sqrt of stabiliser ratios, the U ladder): 1- or 2-byte codes
         // are emitted directly and the 16 B/nnz value array never exists
         const int w = dict_code_width(n_dict);
-        QBH_R(hipMalloc(&d_code, (size_t)nnz * w + 16));
+        QBH_R(qbh::dev_alloc(&d_code, (size_t)nnz * w + 16));
         QBH_R(hipMemset(d_code + (size_t)nnz * w, 0, 16));
         if (w == 1)
             hipLaunchKernelGGL(k_hubrepr_fill_coded<uint8_t>, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_ia,
@@ -2101,7 +2101,7 @@ static int gen_hubbard_repr_impl(qbh_csr **out, int n_sites, int n_up, int n_dn,
     } else {
         if (d_dict) (void)hipFree(d_dict);
         d_dict = nullptr;
-        QBH_R(hipMalloc(&d_val, (size_t)std::max<int64_t>(nnz, 1) * sizeof(d2)));
+        QBH_R(qbh::dev_alloc(&d_val, (size_t)std::max<int64_t>(nnz, 1) * sizeof(d2)));
         hipLaunchKernelGGL(k_hubrepr_fill, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, r0, r1, d_ia, d_ja, d_val);
         QBH_R(hipGetLastError());
     }
@@ -2190,9 +2190,9 @@ int hubrepr_enumerate(const HubReprDev &R, const std::vector<uint64_t> &tab, std
     int64_t dim = 0;
     const int64_t nchunks = (nstates + kHubChunk - 1) / kHubChunk;
     const int egrid = (int)std::min<int64_t>(nchunks, 256 * 32);
-    hipError_t e = hipMalloc(&d_code, (size_t)nstates);
-    if (e == hipSuccess) e = hipMalloc(&d_cnt, (size_t)nchunks * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_pos, (size_t)(nchunks + 1) * sizeof(int64_t));
+    hipError_t e = qbh::dev_alloc(&d_code, (size_t)nstates);
+    if (e == hipSuccess) e = qbh::dev_alloc(&d_cnt, (size_t)nchunks * sizeof(int32_t));
+    if (e == hipSuccess) e = qbh::dev_alloc(&d_pos, (size_t)(nchunks + 1) * sizeof(int64_t));
     int rc = QBH_OK;
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_hubrepr_flag, dim3(egrid), dim3(256), 0, 0, d_R, d_tab, nstates, d_code, d_cnt, nchunks);
@@ -2204,8 +2204,8 @@ int hubrepr_enumerate(const HubReprDev &R, const std::vector<uint64_t> &tab, std
         set_error("%s: sector dimension %lld out of range", who, (long long)dim);
         rc = QBH_EUNSUPP;
     }
-    if (e == hipSuccess && rc == QBH_OK) e = hipMalloc(&d_reps, (size_t)dim * sizeof(uint64_t));
-    if (e == hipSuccess && rc == QBH_OK) e = hipMalloc(&d_info, (size_t)dim);
+    if (e == hipSuccess && rc == QBH_OK) e = qbh::dev_alloc(&d_reps, (size_t)dim * sizeof(uint64_t));
+    if (e == hipSuccess && rc == QBH_OK) e = qbh::dev_alloc(&d_info, (size_t)dim);
     if (e == hipSuccess && rc == QBH_OK) {
         hipLaunchKernelGGL(k_hubrepr_compact, dim3(egrid), dim3(256), 0, 0, d_R, nstates, d_code, d_pos, nchunks, d_reps, d_info);
         e = hipGetLastError();
@@ -3056,7 +3056,7 @@ extern "C" int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_d
     auto up = [&](auto **dst, const auto &h) {
         using T = typename std::remove_reference<decltype(h)>::type::value_type;
         if (e != hipSuccess || rc != QBH_OK) return;
-        e = hipMalloc((void **)dst, std::max<size_t>(h.size(), 1) * sizeof(T));
+        e = qbh::dev_alloc((void **)dst, std::max<size_t>(h.size(), 1) * sizeof(T));
         if (e == hipSuccess && !h.empty()) e = hipMemcpy(*dst, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
     };
     up(&ms->blk, blk);
@@ -3066,10 +3066,10 @@ extern "C" int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_d
     up(&ms->upell, upell);
     up(&ms->prank, prank);
     up(&d_flags, flags);
-    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&d_cnt, (size_t)dim * sizeof(int32_t));
-    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&d_flg, (size_t)dim * sizeof(int32_t));
-    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&d_ia, (size_t)(dim + 1) * sizeof(int64_t));
-    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&d_pos, (size_t)(dim + 1) * sizeof(int64_t));
+    if (rc == QBH_OK && e == hipSuccess) e = qbh::dev_alloc(&d_cnt, (size_t)dim * sizeof(int32_t));
+    if (rc == QBH_OK && e == hipSuccess) e = qbh::dev_alloc(&d_flg, (size_t)dim * sizeof(int32_t));
+    if (rc == QBH_OK && e == hipSuccess) e = qbh::dev_alloc(&d_ia, (size_t)(dim + 1) * sizeof(int64_t));
+    if (rc == QBH_OK && e == hipSuccess) e = qbh::dev_alloc(&d_pos, (size_t)(dim + 1) * sizeof(int64_t));
     const int rgrid = (int)std::min<int64_t>((dim + 127) / 128, 256 * 16);
     if (rc == QBH_OK && e == hipSuccess) {
         hipLaunchKernelGGL(k_secrem_count, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, ms->blk, n_blocks, d_flags, d_cnt);
@@ -3082,10 +3082,10 @@ extern "C" int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_d
     if (rc == QBH_OK && e == hipSuccess) e = hipMemcpy(&n_rrows, d_pos + dim, sizeof(int64_t), hipMemcpyDeviceToHost);
     if (d_cnt) (void)hipFree(d_cnt);
     if (d_flg) (void)hipFree(d_flg);
-    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&ms->rrow, (size_t)std::max<int64_t>(n_rrows, 1) * sizeof(int32_t));
-    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&ms->ria, (size_t)(n_rrows + 1) * sizeof(int64_t));
-    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&ms->rja, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t));
-    if (rc == QBH_OK && e == hipSuccess) e = hipMalloc(&ms->rval, (size_t)std::max<int64_t>(nnz, 1) * sizeof(d2));
+    if (rc == QBH_OK && e == hipSuccess) e = qbh::dev_alloc(&ms->rrow, (size_t)std::max<int64_t>(n_rrows, 1) * sizeof(int32_t));
+    if (rc == QBH_OK && e == hipSuccess) e = qbh::dev_alloc(&ms->ria, (size_t)(n_rrows + 1) * sizeof(int64_t));
+    if (rc == QBH_OK && e == hipSuccess) e = qbh::dev_alloc(&ms->rja, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t));
+    if (rc == QBH_OK && e == hipSuccess) e = qbh::dev_alloc(&ms->rval, (size_t)std::max<int64_t>(nnz, 1) * sizeof(d2));
     if (rc == QBH_OK && e == hipSuccess) {
         hipLaunchKernelGGL(k_secrem_fill, dim3(rgrid), dim3(128), 0, 0, d_R, d_tab, d_reps, d_info, dim, ms->blk, n_blocks, d_flags, d_ia, d_pos,
                            ms->rrow, ms->ria, ms->rja, ms->rval);
@@ -3136,7 +3136,7 @@ extern "C" int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_d
     if (all_real && nnz > 0) {
         double *tmp = nullptr;
         std::vector<double> hp((size_t)blas_grid(nnz));
-        if (hipMalloc(&tmp, (size_t)kMaxRedBlocks * sizeof(double)) == hipSuccess) {
+        if (qbh::dev_alloc(&tmp, (size_t)kMaxRedBlocks * sizeof(double)) == hipSuccess) {
             if (launch_imag_norm(ms->rval, nnz, tmp, 0) == QBH_OK &&
                 hipMemcpy(hp.data(), tmp, hp.size() * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) {
                 double sum = 0.0;
@@ -3161,7 +3161,7 @@ extern "C" int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_d
         }
     }
     MfSec *d_ms = nullptr;
-    if (hipMalloc(&d_ms, sizeof(MfSec)) != hipSuccess || hipMemcpy(d_ms, ms, sizeof(MfSec), hipMemcpyHostToDevice) != hipSuccess) {
+    if (qbh::dev_alloc(&d_ms, sizeof(MfSec)) != hipSuccess || hipMemcpy(d_ms, ms, sizeof(MfSec), hipMemcpyHostToDevice) != hipSuccess) {
         if (d_ms) (void)hipFree(d_ms);
         drop_all();
         set_error("%s: could not place the operator tables", who);

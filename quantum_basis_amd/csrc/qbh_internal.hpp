@@ -106,6 +106,15 @@ struct KronTile {
     }
 };
 
+// hipMalloc that releases live Kronecker splits (second copies of a matrix: acceleration structures, qbh_api.cpp) before it
+// reports out of memory.  Every allocation of the library except the splits' own goes through it.
+hipError_t device_alloc(void **p, size_t bytes);
+template <typename T>
+inline hipError_t dev_alloc(T **p, size_t bytes)
+{
+    return device_alloc(reinterpret_cast<void **>(p), bytes);
+}
+
 // launchers implemented in qbh_kernels.hip (all asynchronous on `s`)
 int launch_spmv(const SpmvArgs &a, int kernel, int npb, int tpr, int grid, hipStream_t s);
 int spmv_grid(int kernel, int64_t n_blocks, int64_t nrows, int tpr);

@@ -1798,10 +1798,10 @@ int dict_build_begin(DictBuild *b, int cap, hipStream_t s)
 {
     DictTab &T = b->tab;
     T.cap = cap < kDictMax ? cap : kDictMax;
-    QBH_HIP(hipMalloc(&T.fp, (size_t)kDictSlots * sizeof(unsigned long long)));
-    QBH_HIP(hipMalloc(&T.val, (size_t)kDictSlots * sizeof(d2)));
-    QBH_HIP(hipMalloc(&T.code, (size_t)kDictSlots * sizeof(uint32_t)));
-    QBH_HIP(hipMalloc(&T.flags, 4 * sizeof(int)));
+    QBH_HIP(qbh::dev_alloc(&T.fp, (size_t)kDictSlots * sizeof(unsigned long long)));
+    QBH_HIP(qbh::dev_alloc(&T.val, (size_t)kDictSlots * sizeof(d2)));
+    QBH_HIP(qbh::dev_alloc(&T.code, (size_t)kDictSlots * sizeof(uint32_t)));
+    QBH_HIP(qbh::dev_alloc(&T.flags, 4 * sizeof(int)));
     QBH_HIP(hipMemsetAsync(T.fp, 0, (size_t)kDictSlots * sizeof(unsigned long long), s));
     QBH_HIP(hipMemsetAsync(T.flags, 0, 4 * sizeof(int), s));
     return QBH_OK;
@@ -1850,7 +1850,7 @@ int dict_build_finalize(DictBuild *b, d2 **d_dict_out, int *n_out, hipStream_t s
         code[(size_t)ents[(size_t)c].slot] = (uint32_t)c;
     }
     d2 *d_dict = nullptr;
-    QBH_HIP(hipMalloc(&d_dict, n_alloc * sizeof(d2)));
+    QBH_HIP(qbh::dev_alloc(&d_dict, n_alloc * sizeof(d2)));
     hipError_t e1 = hipMemcpy(d_dict, dict.data(), n_alloc * sizeof(d2), hipMemcpyHostToDevice);
     hipError_t e2 = hipMemcpy(T.code, code.data(), code.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e1 != hipSuccess || e2 != hipSuccess) {
@@ -1900,7 +1900,7 @@ int build_value_dict(const d2 *d_val, int64_t nnz, int cap, uint8_t **d_code_out
         rc = dict_build_finalize(&b, &dict, &n, s);
         if (rc == QBH_OK && n > 0) {
             const int w = dict_code_width(n);
-            if (hipMalloc(&code, (size_t)nnz * w + 16) != hipSuccess) {
+            if (qbh::dev_alloc(&code, (size_t)nnz * w + 16) != hipSuccess) {
                 (void)hipGetLastError();
                 n = 0;                                   // no room for the codes: stay uncoded
             } else {
@@ -2516,7 +2516,7 @@ int exclusive_scan(const int32_t *d_cnt, int64_t n, int64_t *d_ia, hipStream_t s
 {
     const int64_t nchunks = (n + kScanChunk - 1) / kScanChunk;
     int64_t *d_chunk = nullptr;
-    QBH_HIP(hipMalloc(&d_chunk, (size_t)(nchunks + 1) * sizeof(int64_t)));
+    QBH_HIP(qbh::dev_alloc(&d_chunk, (size_t)(nchunks + 1) * sizeof(int64_t)));
     hipLaunchKernelGGL(k_scan_chunksum, dim3((unsigned)nchunks), dim3(256), 0, s, d_cnt, n, d_chunk);
     hipLaunchKernelGGL(k_scan_chunks_serial, dim3(1), dim3(64), 0, s, d_chunk, nchunks);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nchunks), dim3(256), 0, s, d_cnt, n, d_chunk, d_ia);

@@ -209,7 +209,7 @@ int upload_binom(Binom **d_out)
         fill_binom(host);
         filled = true;
     }
-    QBH_HIP(hipMalloc(d_out, sizeof(Binom)));
+    QBH_HIP(qbh::dev_alloc(d_out, sizeof(Binom)));
     QBH_HIP(hipMemcpy(*d_out, &host, sizeof(Binom), hipMemcpyHostToDevice));
     return QBH_OK;
 }
@@ -281,9 +281,9 @@ extern "C" int qbh_mopr_onebody_dev(int n_sites, int n_up, int n_dn, int n_terms
     int rc = upload_binom(&d_b);
     hipError_t e = hipSuccess;
     if (rc == QBH_OK) {
-        e = hipMalloc(&d_cu, cu.size() * 4);
-        if (e == hipSuccess) e = hipMalloc(&d_cd, cd.size() * 4);
-        if (e == hipSuccess) e = hipMalloc(&d_t, terms.size() * sizeof(OneBodyTerm));
+        e = qbh::dev_alloc(&d_cu, cu.size() * 4);
+        if (e == hipSuccess) e = qbh::dev_alloc(&d_cd, cd.size() * 4);
+        if (e == hipSuccess) e = qbh::dev_alloc(&d_t, terms.size() * sizeof(OneBodyTerm));
         if (e == hipSuccess) e = hipMemcpy(d_cu, cu.data(), cu.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(d_cd, cd.data(), cd.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(d_t, terms.data(), terms.size() * sizeof(OneBodyTerm), hipMemcpyHostToDevice);

@@ -192,20 +192,20 @@ extern "C" int qbh_csr_reference_order(qbh_csr **out, const qbh_csr *A, int kind
                 if (q) (void)hipFree(q);
         return code;
     };
-    RO_HIP(hipMalloc(&d_binom, hb.size() * 8));
+    RO_HIP(qbh::dev_alloc(&d_binom, hb.size() * 8));
     RO_HIP(hipMemcpy(d_binom, hb.data(), hb.size() * 8, hipMemcpyHostToDevice));
     a.binom = d_binom;
-    RO_HIP(hipMalloc(&k0, (size_t)dim * 8));
-    RO_HIP(hipMalloc(&k1, (size_t)dim * 8));
-    RO_HIP(hipMalloc(&v0, (size_t)dim * 4));
-    RO_HIP(hipMalloc(&v1, (size_t)dim * 4));
-    RO_HIP(hipMalloc(&sign, (size_t)dim));
+    RO_HIP(qbh::dev_alloc(&k0, (size_t)dim * 8));
+    RO_HIP(qbh::dev_alloc(&k1, (size_t)dim * 8));
+    RO_HIP(qbh::dev_alloc(&v0, (size_t)dim * 4));
+    RO_HIP(qbh::dev_alloc(&v1, (size_t)dim * 4));
+    RO_HIP(qbh::dev_alloc(&sign, (size_t)dim));
     hipLaunchKernelGGL(k_ref_keys, dim3(2048), dim3(256), 0, s, a, k0, v0, sign);
     RO_HIP(hipGetLastError());
     size_t tmp_bytes = 0;
     const int key_bits = (kind == 0 ? 1 : 2) * n_sites;
     RO_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0, k1, v0, v1, dim, 0, key_bits, s));
-    RO_HIP(hipMalloc(&tmp, tmp_bytes));
+    RO_HIP(qbh::dev_alloc(&tmp, tmp_bytes));
     RO_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k0, k1, v0, v1, dim, 0, key_bits, s));
     RO_HIP(hipStreamSynchronize(s));
     (void)hipFree(tmp);
@@ -216,17 +216,17 @@ extern "C" int qbh_csr_reference_order(qbh_csr **out, const qbh_csr *A, int kind
     k1 = nullptr;
     (void)hipFree(v0);
     v0 = nullptr;
-    RO_HIP(hipMalloc(&pos, (size_t)dim * 4));
-    RO_HIP(hipMalloc(&cnt, (size_t)dim * 4));
+    RO_HIP(qbh::dev_alloc(&pos, (size_t)dim * 4));
+    RO_HIP(qbh::dev_alloc(&cnt, (size_t)dim * 4));
     hipLaunchKernelGGL(k_ref_pos, dim3(2048), dim3(256), 0, s, v1, sign, dim, pos, A->d_ia, cnt);
     RO_HIP(hipGetLastError());
-    RO_HIP(hipMalloc(&ia_r, (size_t)(dim + 1) * 8));
+    RO_HIP(qbh::dev_alloc(&ia_r, (size_t)(dim + 1) * 8));
     {
         const int rc = exclusive_scan(cnt, dim, ia_r, s);
         if (rc != QBH_OK) return drop(rc);
     }
-    RO_HIP(hipMalloc(&ja_r, (size_t)std::max<int64_t>(nnz, 1) * 4));
-    RO_HIP(hipMalloc(&val_r, (size_t)std::max<int64_t>(nnz, 1) * 16));
+    RO_HIP(qbh::dev_alloc(&ja_r, (size_t)std::max<int64_t>(nnz, 1) * 4));
+    RO_HIP(qbh::dev_alloc(&val_r, (size_t)std::max<int64_t>(nnz, 1) * 16));
     hipLaunchKernelGGL(k_ref_fill, dim3(4096), dim3(256), 0, s, v1, pos, dim, A->d_ia, A->d_ja, A->d_val, ia_r, ja_r, val_r);
     RO_HIP(hipGetLastError());
     RO_HIP(hipStreamSynchronize(s));

@@ -128,3 +128,28 @@ def test_headline_operator_split_and_sliced_equals_the_matrix_free_operator_at_f
     v.free()
     M.destroy()
     K.destroy()
+
+
+def test_split_gives_its_memory_back_before_an_allocation_fails():
+    """The split is a second copy of the matrix.  At C3 size it leaves ~45 GB of the 288: a Krylov basis of 24 vectors (64 GB)
+    would not fit beside it.  Allocations that would fail release live splits first; the operator then runs on its plain CSR with
+    the same results."""
+    n_sites, nu, nd = 16, 8, 8
+    bonds = lattices.square(4, 4)
+    K = q.csr_mat.hubbard(n_sites, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_split=2, **PLAIN))
+    assert K.info().kron_minor > 0
+    n = K.dim
+    v = K.vec(3)
+    K.randomize(v.at(0), 31)
+    K.spmv(v.at(0), v.at(n))                                       # with the split
+    K.sync()
+    basis = [K.vec(1) for _ in range(24)]                           # 24 x 2.65 GB
+    assert K.info().kron_minor == 0                                 # the split was released, nothing failed
+    K.spmv(v.at(0), v.at(2 * n))                                    # plain CSR
+    K.sync()
+    hx = K.nrm2(v.at(n))
+    assert hx > 0 and np.sqrt(K.axpy_norm(-1.0, v.at(n), v.at(2 * n))) <= 1e-13 * hx
+    for b in basis:
+        b.free()
+    v.free()
+    K.destroy()
