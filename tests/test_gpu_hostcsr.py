@@ -151,3 +151,40 @@ def test_chunk_boundaries_of_the_staged_upload(monkeypatch):
         assert np.array_equal(cia, want[0][r0:r1 + 1] - lo) and np.array_equal(cja, want[1][lo:hi]) and np.array_equal(cval, want[2][lo:hi])
         B.destroy()
         C.destroy()
+
+
+def test_reference_ordered_host_csr_at_dim_1e7_through_qbh_csr_create():
+    """The same entry at dim 10,400,600 (Heisenberg chain L = 26, Sz = 0; 1.46e8 nonzeros in full storage): host arrays exactly
+    as the unchanged reference host code hands them over -- Hermitian-upper, int64 ia / ja, complex128, the reference's Lin order
+    (device generator + qbh_csr_reference_order + download: tests/test_gpu_reforder.py checks that pass entry by entry) -- through
+    qbh_csr_create, against the oracle's Hermitian-upper product on the SAME host arrays."""
+    from quantum_basis_amd import lattices
+    L = 26
+    src = q.make_opts(value_dict=0, real_fast_path=0, spmv_kernel=_lib.KERNEL_ROWS, kron_split=0)
+    G = q.csr_mat.heisenberg(L, L // 2, lattices.chain(L), J=1.0, opts=src)
+    R = G.reference_order(0, L, 0, L // 2, opts=src)
+    G.destroy()
+    d = R.dim
+    ia, ja, val = R.download()
+    R.destroy()
+    assert d == 10400600
+    rows = np.repeat(np.arange(d, dtype=np.int64), np.diff(ia))
+    keep = ja >= rows
+    uia = np.zeros(d + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows[keep], minlength=d), out=uia[1:])
+    uja, uval = ja[keep].astype(np.int64), val[keep]
+    nnz_full = len(ja)
+    del rows, keep, ia, ja, val
+    O = qo.Csr(d, uia, uja, uval, True)
+    x = qo.vec_randomize(d, 1) + 1j * qo.vec_randomize(d, 5)
+    want = O.multmv(x)
+    scale = np.abs(want).max()
+    for vd, rfp in ((0, 0), (1, 1)):
+        A = q.csr_mat(d, uia, uja, uval, sym=True, opts=q.make_opts(value_dict=vd, real_fast_path=rfp))
+        info = A.info()
+        assert info.nnz == nnz_full and info.create_bytes_in == len(uja) * 24 + (d + 1) * 8
+        assert info.create_bytes_in / (info.create_ms * 1e-3) > 1e9          # validation + upload + expansion: GB/s, not MB/s
+        y = np.empty_like(x)
+        A.MultMv(x, y)
+        assert np.abs(y - want).max() <= 1e-13 * scale
+        A.destroy()
