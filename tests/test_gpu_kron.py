@@ -153,3 +153,28 @@ def test_split_gives_its_memory_back_before_an_allocation_fails():
         b.free()
     v.free()
     K.destroy()
+
+
+def test_headline_lattice_at_U4_reproduces_the_published_ground_state_energy():
+    """An external pin at C3's size (dim 165,636,900): the 4x4 periodic Hubbard model at half filling and U = 4t is the standard
+    exact-diagonalisation benchmark, E0 = -13.6219 t, E0 / N = -0.8514 (Fano, Ortolani, Parola, PRB 42, 6877 (1990); Dagotto et
+    al., PRB 45, 10741 (1992)).  The matrix-free operator and the stored complex128 CSR applied through the Kronecker split with
+    the sliced far part (the headline path) must both give it, and agree with each other to rounding."""
+    import ctypes as C
+    from quantum_basis_amd import _lib
+    bonds = lattices.square(4, 4)
+    M = q.csr_mat.hubbard(16, 8, 8, bonds, t=1.0, U=4.0, matrix_free=True)
+    w = M.vec(1)
+    _lib.check(_lib.lib().qbh_vec_randomize_real(M.handle, w.ptr, C.c_uint32(1)), "qbh_vec_randomize_real")
+    maxit = 600
+    hess = np.zeros(2 * maxit)
+    m = q.lanczos_real(0, maxit - 1, maxit, M, w, hess)
+    e_mf = q.hess_eigen(hess, maxit, m, "sr")[0][0]
+    w.free()
+    M.destroy()
+    assert abs(e_mf - (-13.6219)) <= 1e-4 and abs(e_mf / 16 - (-0.8514)) <= 1e-4
+    K = q.csr_mat.hubbard(16, 8, 8, bonds, t=1.0, U=4.0, opts=q.make_opts(kron_split=2, **PLAIN))
+    assert K.info().kron_sliced == 1
+    e_k = q.locate_E0_lanczos(K, nev=1, ncv=0, maxit=1000).E0
+    K.destroy()
+    assert abs(e_k - e_mf) <= 1e-11 * abs(e_mf)
