@@ -517,6 +517,100 @@ int kron_build(qbh_csr *A)
     return QBH_OK;
 }
 
+// ---- the split for the library's default form of a real operator: dictionary-coded values, packed-double vectors ----
+void kronc_release(qbh_csr *A)
+{
+    qbh_csr::KronCoded &K = A->kronc;
+    for (CsrPart *P : {&K.near_p, &K.far_p})
+        for (void *q : {(void *)P->d_ia, (void *)P->d_ja, (void *)P->d_code, (void *)P->d_rb, (void *)P->d_bp})
+            if (q) (void)hipFree(q);
+    if (K.d_xt) (void)hipFree(K.d_xt);
+    K = qbh_csr::KronCoded{};
+}
+
+// Same decomposition as kron_build, for the row kernel: the near part keeps rows and columns, the far part has rows AND
+// columns in the tiled order of KronTile with B = 16 (one 128-byte line of doubles per major index and band); the far
+// launch gathers from the tiled copy of the packed x and accumulates onto the near launch's result at orig(row).
+// Opt-in (QBH_KRON_CODED=1) until it is timed at creation like the complex128 form.
+int kronc_build(qbh_csr *A)
+{
+    kronc_release(A);
+    const int want = getenv("QBH_KRON_CODED") ? atoi(getenv("QBH_KRON_CODED")) : 0;
+    if (!want || A->opts.kron_split == 0) return QBH_OK;
+    if (A->kernel != QBH_KERNEL_ROWS || A->d_code == nullptr || !A->values_real || A->kind != 0 || A->has_rem || A->nrows != A->ncols ||
+        A->row_offset != 0 || A->nnz <= 0)
+        return QBH_OK;
+    const int64_t S = A->opts.kron_minor;
+    if (S <= 1 || S >= A->nrows || A->nrows % S != 0) return QBH_OK;
+    const int64_t NU = A->nrows / S, n = A->nrows;
+    hipStream_t s = A->stream;
+    {
+        size_t free_b = 0, total_b = 0;
+        const size_t need = (size_t)A->nnz * (4 + A->code_w) + (size_t)n * (8 + 16 + 16) + ((size_t)2 << 30);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < need) return QBH_OK;
+    }
+    QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
+    QBH_TRY(qbh::launch_kron_check(A->d_ia, A->d_ja, n, S, A->d_flag, s));
+    int bad = 0;
+    QBH_HIP(hipMemcpyAsync(&bad, A->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    QBH_HIP(hipStreamSynchronize(s));
+    QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
+    if (bad) return QBH_OK;
+    qbh_csr::KronCoded &K = A->kronc;
+    int B = 16;
+    while (B > 2 && (double)NU * B * 8 > 2.5e6) B >>= 1;
+    K.t = qbh::KronTile{S, NU, B};
+    int32_t *cn = nullptr, *cf = nullptr;
+    auto fail = [&](int code) {
+        if (cn) (void)hipFree(cn);
+        if (cf) (void)hipFree(cf);
+        kronc_release(A);
+        return code;
+    };
+#define KC_HIP(call)                                                                  \
+    do {                                                                              \
+        hipError_t e_ = (call);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            (void)hipGetLastError();                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? QBH_OK : QBH_EHIP);               \
+        }                                                                             \
+    } while (0)
+#define KC_TRY(expr)                           \
+    do {                                       \
+        const int rc_ = (expr);                \
+        if (rc_ != QBH_OK) return fail(rc_);   \
+    } while (0)
+    KC_HIP(hipMalloc(&cn, (size_t)n * sizeof(int32_t)));
+    KC_HIP(hipMalloc(&cf, (size_t)n * sizeof(int32_t)));
+    KC_TRY(qbh::launch_kron_count(A->d_ia, A->d_ja, n, K.t, cn, cf, s));
+    KC_HIP(hipMalloc(&K.near_p.d_ia, (size_t)(n + 1) * sizeof(int64_t)));
+    KC_HIP(hipMalloc(&K.far_p.d_ia, (size_t)(n + 1) * sizeof(int64_t)));
+    KC_TRY(qbh::exclusive_scan(cn, n, K.near_p.d_ia, s));
+    KC_TRY(qbh::exclusive_scan(cf, n, K.far_p.d_ia, s));
+    (void)hipFree(cn);
+    cn = nullptr;
+    (void)hipFree(cf);
+    cf = nullptr;
+    KC_HIP(hipMemcpy(&K.near_p.nnz, K.near_p.d_ia + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+    KC_HIP(hipMemcpy(&K.far_p.nnz, K.far_p.d_ia + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (K.far_p.nnz == 0 || K.near_p.nnz + K.far_p.nnz != A->nnz) return fail(QBH_OK);
+    for (CsrPart *P : {&K.near_p, &K.far_p}) {
+        KC_HIP(hipMalloc(&P->d_ja, std::max<size_t>((size_t)P->nnz, 1) * sizeof(int32_t)));
+        KC_HIP(hipMalloc(&P->d_code, (size_t)P->nnz * A->code_w + 16));
+        KC_HIP(hipMemsetAsync(P->d_code + (size_t)P->nnz * A->code_w, 0, 16, s));
+    }
+    KC_TRY(qbh::launch_kron_fill_codes(A->d_ia, A->d_ja, A->d_code, A->code_w, n, K.t, K.near_p.d_ia, K.near_p.d_ja, K.near_p.d_code,
+                                       K.far_p.d_ia, K.far_p.d_ja, K.far_p.d_code, s));
+    KC_HIP(hipMalloc(&K.d_xt, (size_t)n * sizeof(double)));
+    for (CsrPart *P : {&K.near_p, &K.far_p})
+        KC_TRY(setup_geometry(A, P->d_ia, P->nnz, A->dict_mode, &P->npb, &P->tpr, &P->unroll, &P->window, &P->n_blocks, &P->d_rb, &P->d_bp, &P->grid));
+    KC_HIP(hipStreamSynchronize(s));
+#undef KC_HIP
+#undef KC_TRY
+    K.active = true;
+    return QBH_OK;
+}
+
 // wave-block geometry of one part for k_spmv_wave (uncoded complex128 values)
 int setup_wave_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, qbh::WaveDesc **d_wd_o, int64_t *n_wb_o, int *tpr_o, int *grid_o)
 {
@@ -591,6 +685,8 @@ int build_geometry(qbh_csr *A)
     }
     QBH_TRY(kron_build(A));
     if (A->kron.active) grid_max = std::max(grid_max, std::max(A->kron.grid_n, A->kron.grid_f));
+    QBH_TRY(kronc_build(A));
+    if (A->kronc.active) grid_max = std::max(grid_max, std::max(A->kronc.near_p.grid, A->kronc.far_p.grid));
     const size_t nparts = (size_t)std::max(grid_max, qbh::kMaxRedBlocks);
     if (A->d_partials) (void)hipFree(A->d_partials);
     A->d_partials = nullptr;
@@ -788,6 +884,7 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
     if (A->d_rb) (void)hipFree(A->d_rb);
     if (A->d_bp) (void)hipFree(A->d_bp);
     if (A->d_wd) (void)hipFree(A->d_wd);
+    kronc_release(A);
     if (A->rem.d_wd) (void)hipFree(A->rem.d_wd);
     kron_release(A);
     if (A->rem.d_ia) (void)hipFree(A->rem.d_ia);
@@ -1105,6 +1202,11 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->kron_far_nnz = A->kron.active ? A->kron.nnz_f : 0;
     info->kron_band = A->kron.active ? A->kron.t.B : 0;
     info->kron_sliced = A->kron.active && A->kron.sliced ? 1 : 0;
+    if (A->kronc.active) {                       // the coded form of the split (row kernel, packed-double vectors)
+        info->kron_minor = A->kronc.t.S;
+        info->kron_far_nnz = A->kronc.far_p.nnz;
+        info->kron_band = A->kronc.t.B;
+    }
     return QBH_OK;
 }
 
@@ -1429,7 +1531,41 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         if (!A->d_wctr) wave_swz = kron_swz = 2;
         else QBH_HIP(hipMemsetAsync(A->d_wctr, 0, 3 * 128 * sizeof(unsigned long long), A->stream));
     }
-    if (kron) {
+    const bool kronc = A->kronc.active && realm && a.xr != nullptr && a.y_re != nullptr && !A->has_comm && !A->has_rem && !(A->debug & 1);
+    if (kronc) {
+        // coded Kronecker split, all-real operation: tiled copy of the packed x, near launch (full epilogue), far launch
+        // (tiled rows and columns, accumulates at orig(row), fused reductions of the finished y)
+        const qbh_csr::KronCoded &K = A->kronc;
+        QBH_TRY(qbh::launch_kron_tile_re(a.xr, K.d_xt, A->nrows, K.t, A->stream));
+        qbh::SpmvArgs np = a;
+        np.ia = K.near_p.d_ia;
+        np.ja = K.near_p.d_ja;
+        np.code = K.near_p.d_code;
+        np.rb = K.near_p.d_rb;
+        np.bp = K.near_p.d_bp;
+        np.n_blocks = K.near_p.n_blocks;
+        np.unroll = K.near_p.unroll;
+        np.partials = nullptr;
+        QBH_TRY(qbh::launch_spmv(np, A->kernel, K.near_p.npb, K.near_p.tpr, K.near_p.grid, A->stream));
+        qbh::SpmvArgs fp = a;
+        fp.ia = K.far_p.d_ia;
+        fp.ja = K.far_p.d_ja;
+        fp.code = K.far_p.d_code;
+        fp.rb = K.far_p.d_rb;
+        fp.bp = K.far_p.d_bp;
+        fp.n_blocks = K.far_p.n_blocks;
+        fp.unroll = K.far_p.unroll;
+        fp.xr = K.d_xt;
+        fp.beta = 1.0;
+        fp.gamma = 0.0;
+        fp.partials = red ? A->d_partials : nullptr;
+        fp.swizzle = 1;                             // contiguous eighths of the bands per XCD
+        fp.rowmap = 1;
+        fp.kS = K.t.S;
+        fp.kNU = K.t.NU;
+        fp.kB = K.t.B;
+        QBH_TRY(qbh::launch_spmv(fp, A->kernel, K.far_p.npb, K.far_p.tpr, K.far_p.grid, A->stream));
+    } else if (kron) {
         // Kronecker split: tiled copy of x, far pass (plain row sums in tiled order), near pass with the fused epilogue
         const qbh_csr::KronSplit &K = A->kron;
         QBH_TRY(qbh::launch_kron_tile(xg, K.d_xt, A->nrows, K.t, A->stream));
@@ -1499,7 +1635,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         QBH_HIP(hipEventRecord(A->ev1, A->stream));
         A->ev_pending = true;
     }
-    int grid_last = kron ? A->kron.grid_n : wave ? wave_grid_used : A->grid;
+    int grid_last = kronc ? A->kronc.far_p.grid : kron ? A->kron.grid_n : wave ? wave_grid_used : A->grid;
     if (A->has_rem) {
         if (async_gather) {
             if (A->comm.allgather_wait(A->comm.ctx) != 0) {

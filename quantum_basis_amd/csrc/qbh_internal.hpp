@@ -81,6 +81,7 @@ struct SpmvArgs {
     const d2      *far;        // near pass: far-part row sums in tiled order (nullptr: none)
     int64_t        kS, kNU;    // minor size / major count of the product basis
     int            kB;         // band width of the tiling
+    int            rowmap;     // row kernel, coded Kronecker split: rows are in TILED order; y / x_local are addressed at orig(row)
 };
 
 // element (u, d) of the product basis <-> its position in the band-major ("tiled") order (band, u, d % B): the B minor
@@ -130,6 +131,10 @@ int launch_zero_cut_groups(const WaveDesc *wd, int64_t n_wb, int64_t nrows, d2 *
 int launch_kron_group_width(const int32_t *cnt_far, int64_t nrows, int64_t ngroups, int32_t *gw, hipStream_t s);
 int launch_kron_fill_sliced(const int64_t *ia, const int32_t *ja, const d2 *val, int64_t nrows, const KronTile &t, const int64_t *ia_n,
                             int32_t *ja_n, d2 *val_n, const int64_t *gia, int64_t ngroups, int32_t *ja_f, d2 *val_f, hipStream_t s);
+// the same split for dictionary-coded values (cw bytes per code) and the tiled copy of a packed-double x
+int launch_kron_fill_codes(const int64_t *ia, const int32_t *ja, const uint8_t *code, int cw, int64_t nrows, const KronTile &t, const int64_t *ia_n,
+                           int32_t *ja_n, uint8_t *code_n, const int64_t *ia_f, int32_t *ja_f, uint8_t *code_f, hipStream_t s);
+int launch_kron_tile_re(const double *x, double *xt, int64_t n, const KronTile &t, hipStream_t s);
 int launch_kron_fill(const int64_t *ia, const int32_t *ja, const d2 *val, int64_t nrows, const KronTile &t, const int64_t *ia_n, int32_t *ja_n,
                      d2 *val_n, const int64_t *ia_f, int32_t *ja_f, d2 *val_f, hipStream_t s);
 int wave_kernel_occupancy(int tpr);
@@ -363,6 +368,15 @@ struct qbh_csr {
     // Kronecker split of a product-basis operator H = T_major (x) 1 + 1 (x) T_minor + D (two-species Hubbard in the
     // generator's order): "far" = entries that change the major index (same minor index), stored band-major over the
     // minor index with TILED columns and applied first from a tiled copy of x; "near" = the rest in the original row order
+    // the split of a dictionary-coded REAL operator applied to packed-double vectors (the library's default form for real
+    // operators): two parts for the row kernel -- near (natural order) with the full epilogue, then far (rows and columns in
+    // tiled order, x = tiled copy) accumulating onto it at orig(row).  Band = 16 doubles = one 128-byte line.
+    struct KronCoded {
+        bool     active = false;
+        qbh::KronTile t{0, 0, 0};
+        CsrPart  near_p, far_p;
+        double  *d_xt = nullptr;
+    } kronc;
     struct KronSplit {
         bool     active = false;
         qbh::KronTile t{0, 0, 8};

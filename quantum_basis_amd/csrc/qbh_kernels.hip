@@ -155,12 +155,19 @@ struct DynWalk {
 // partial sums of <x,y> and |y|^2 (K3, K4 and the CG shift folded into K1).
 // yo / xi are the old y[row] and x_local[row], loaded by the caller (so that the loads can
 // be issued long before the row sum is ready).
+// rowmap (far part of a coded Kronecker split): the kernel's rows are in tiled order, the vectors are not
+__device__ __forceinline__ int64_t out_row(const SpmvArgs &a, int64_t row)
+{
+    return a.rowmap ? KronTile{a.kS, a.kNU, a.kB}.orig(row) : row;
+}
 __device__ __forceinline__ d2 load_y_old(const SpmvArgs &a, int64_t row)
 {
+    row = out_row(a, row);
     return a.y_re != nullptr ? d2{a.y_re[row], 0.0} : a.y[row];
 }
 __device__ __forceinline__ d2 load_x_local(const SpmvArgs &a, int64_t row)
 {
+    row = out_row(a, row);
     return a.y_re != nullptr ? d2{a.xl_re[row], 0.0} : a.xl[row];
 }
 
@@ -168,6 +175,7 @@ __device__ __forceinline__ void row_epilogue2(const SpmvArgs &a, int64_t row, d2
                                               double (&acc)[3])
 {
     d2 yn = a.alpha * sum + a.beta * yo + a.gamma * xi;
+    row = out_row(a, row);
     if (a.y_re != nullptr) a.y_re[row] = yn.x;
     else                   a.y[row] = yn;
     acc[0] += xi.x * yn.x + xi.y * yn.y;
@@ -1249,6 +1257,47 @@ int launch_kron_tile(const d2 *x, d2 *xt, int64_t n, const KronTile &t, hipStrea
     const int64_t nfb = t.B == 8 ? t.S / 8 : 0;                  // full bands through the LDS kernel
     if (nfb > 0) hipLaunchKernelGGL(k_kron_tile8, dim3(4096), dim3(kBlock), 0, s, x, xt, t, nfb);
     if (nfb * t.B < t.S) hipLaunchKernelGGL(k_kron_tile_edge, dim3(nfb > 0 ? 256 : 2048), dim3(kBlock), 0, s, x, xt, t, nfb);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// coded values: the same two parts with cw-byte codes instead of complex128 values
+__global__ __launch_bounds__(kBlock) void k_kron_fill_codes(const int64_t *ia, const int32_t *ja, const uint8_t *code, int cw, int64_t nrows, KronTile t,
+                                                            const int64_t *ia_n, int32_t *ja_n, uint8_t *code_n, const int64_t *ia_f, int32_t *ja_f,
+                                                            uint8_t *code_f)
+{
+    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < nrows; f += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t.orig(f);
+        const int64_t maj = r / t.S;
+        int64_t pn = ia_n[r], pf = ia_f[f];
+        for (int64_t k = ia[r]; k < ia[r + 1]; ++k) {
+            const int32_t c = ja[k];
+            if ((c / t.S) != maj) {
+                ja_f[pf] = (int32_t)t.tile(c);
+                for (int b = 0; b < cw; ++b) code_f[pf * cw + b] = code[k * cw + b];
+                ++pf;
+            } else {
+                ja_n[pn] = c;
+                for (int b = 0; b < cw; ++b) code_n[pn * cw + b] = code[k * cw + b];
+                ++pn;
+            }
+        }
+    }
+}
+int launch_kron_fill_codes(const int64_t *ia, const int32_t *ja, const uint8_t *code, int cw, int64_t nrows, const KronTile &t, const int64_t *ia_n,
+                           int32_t *ja_n, uint8_t *code_n, const int64_t *ia_f, int32_t *ja_f, uint8_t *code_f, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kron_fill_codes, dim3(4096), dim3(kBlock), 0, s, ia, ja, code, cw, nrows, t, ia_n, ja_n, code_n, ia_f, ja_f, code_f);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+__global__ __launch_bounds__(kBlock) void k_kron_tile_re(const double *x, double *xt, int64_t n, KronTile t)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) xt[t.tile(r)] = x[r];
+}
+int launch_kron_tile_re(const double *x, double *xt, int64_t n, const KronTile &t, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kron_tile_re, dim3(2048), dim3(kBlock), 0, s, x, xt, n, t);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }
