@@ -648,7 +648,9 @@ def main():
                                          if not (coded or real_used) else "value codes %s, real fast path %s" % (coded, real_used),
                                          "value_dict": info.value_dict, "real_gather": real_used,
                                          "kron_split": ({"minor": int(info.kron_minor), "band": int(info.kron_band), "far_nnz": int(info.kron_far_nnz), "far_sliced": bool(info.kron_sliced),
-                                                         "launches_per_spmv": ("k_kron_tile + k_zero_cut_groups + k_spmv_wave2<.,3> (far, sliced) + k_spmv_wave2<.,2> (near)"
+                                                         "launches_per_spmv": ("k_kron_tile_re + k_spmv_rows (near) + k_spmv_rows (far, tiled rows and columns; QBH_KRON_CODED=1)"
+                                                                               if info.value_dict else
+                                                                               "k_kron_tile + k_zero_cut_groups + k_spmv_wave2<.,3> (far, sliced) + k_spmv_wave2<.,2> (near)"
                                                                                if info.kron_sliced else "k_kron_tile + k_spmv_wave2<.,0> (far) + k_spmv_wave2<.,2> (near)")}
                                                         if info.kron_minor else None),
                                          "operator_source": "host CSR in reference order through qbh_csr_create" if args.host_csr else
