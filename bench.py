@@ -104,9 +104,26 @@ def traffic_of(key):
     (None, None) when that exact workload / kernel / value coding was never profiled.  NOT measured in this run."""
     try:
         e = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[key]
+        TRAFFIC_STAMP[key] = e.get("kernel_sources_sha16")
         return e["hbm_bytes"], e.get("source")
     except Exception:
         return None, None
+
+
+TRAFFIC_STAMP = {}
+
+
+def traffic_stamp(key):
+    """{'traffic_sources_sha16': hash of the kernel sources the PMC passes ran on, 'traffic_stale': True when the sources of this
+    run differ (or the entry predates the stamps): the quoted traffic is then a number about OTHER code}"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import src_hash
+        now = src_hash.kernel_sources_sha16()
+    except Exception:
+        now = None
+    was = TRAFFIC_STAMP.get(key)
+    return {"traffic_sources_sha16": was, "sources_sha16": now, "traffic_stale": (was is None or now is None or was != now)}
 
 
 def dim_of(w):
@@ -462,8 +479,15 @@ def main():
     if args.matrix_free:
         real_fp = 1                          # the matrix-free operators are real; their row-staged kernel is the real form
     dim = dim_of(W)
+    row_cuts = None
     if dim is None:
         r0, r1 = 0, -1                   # the generator shards by (rank, world) itself
+    elif world > 1 and W["kind"] == "hubbard" and not args.matrix_free and not args.host_csr and value_dict == 0:
+        # complex128 CSR of a product-basis operator: shards of WHOLE major (up-configuration) indices keep the Kronecker
+        # split in place and exchange the tiled copies of their blocks (dist.kron_row_cuts)
+        from math import comb
+        row_cuts = qdist.kron_row_cuts(dim, comb(W["n_sites"], W["n_dn"]), world)
+        r0, r1 = int(row_cuts[rank]), int(row_cuts[rank + 1])
     else:
         nblk, ranges = qdist.row_partition(dim, world)
         r0, r1 = ranges[rank]
@@ -589,7 +613,7 @@ def main():
                 # the library's own RCCL communicator (qbh_comm_create_rccl): no Python in the SpMV loop.  Every rank must
                 # end up on the same path, so the outcome is agreed on before anything is exchanged through it.
                 try:
-                    comm = qdist.NativeComm(dim, rank=rank, world=world).attach(A)
+                    comm = qdist.NativeComm(dim, rank=rank, world=world, cuts=row_cuts).attach(A)
                     ok = 1.0
                 except Exception as e:          # e.g. librccl not loadable: all ranks fall back together
                     comm, ok, native_err = None, 0.0, repr(e)
@@ -600,7 +624,7 @@ def main():
             if want_native:
                 exchange_kind = "native RCCL (qbh_comm_create_rccl)"
             else:
-                comm = qdist.ShardComm(dim, rank=rank, world=world, device=device, stream=stream).attach(A)  # noqa: F841
+                comm = qdist.ShardComm(dim, rank=rank, world=world, device=device, stream=stream, cuts=row_cuts).attach(A)  # noqa: F841
                 exchange_kind = "torch.distributed hooks (%s)" % backend + (" [native communicator failed: %s]" % native_err if native_err else "")
         nnz_total = int(allreduce_host([float(info.nnz)], dist.ReduceOp.SUM)[0])
         head = timed_lanczos(A, packed_real)
@@ -614,8 +638,9 @@ def main():
     code_w = 0 if not coded else (1 if info.value_dict <= 256 else 2)
     tkey = "%s|%s|%s" % (args.workload, KERNEL_KEY[info.kernel], "dict" if coded else "plain") + ("|real" if real_used else "")
     if info.kron_minor:
-        tkey += "|kron_sliced" if info.kron_sliced else "|kron"
-    traffic, tsrc = traffic_of(tkey + ("|reforder" if args.order == "reference" else "")) if world == 1 and not args.host_csr else (None, None)
+        tkey += ("|kron_sliced" if info.kron_sliced else "|kron") + ("|inplace" if info.kron_inplace else "")
+    tkey += "|reforder" if args.order == "reference" else ""
+    traffic, tsrc = traffic_of(tkey) if world == 1 and not args.host_csr else (None, None)
     if coded or real_used:
         # the kernel moves its own format's bytes, not SURVEY 8(d)'s: the fraction is defined on those (cannot exceed 1)
         vec_b = 8 if real_used else 16
@@ -629,7 +654,7 @@ def main():
         dtype = "f64 real (1-byte value codes, packed-double vectors; bit-identical to complex128)" if real_used else \
                 "complex128 vectors, %d-byte value codes" % code_w
     else:
-        roof = {"bound": "hbm", "kernel": ("k_spmv_wave2 (Kronecker split: tile + far + near launches)" if info.kron_minor else KERNEL_NAME[info.kernel]),
+        roof = {"bound": "hbm", "kernel": ("k_spmv_wave2 (Kronecker split in place: far + near launches)" if info.kron_minor else KERNEL_NAME[info.kernel]),
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_ratio": (round(traffic / bytes_launch, 3) if traffic else None), "traffic_source": tsrc,
                 "bytes_per_launch": bytes_launch, "ms_per_launch": round(ms_spmv, 4), "launches": head["n_spmv"],
@@ -650,8 +675,12 @@ def main():
                                          "kron_split": ({"minor": int(info.kron_minor), "band": int(info.kron_band), "far_nnz": int(info.kron_far_nnz), "far_sliced": bool(info.kron_sliced),
                                                          "launches_per_spmv": ("k_kron_tile_re + k_spmv_rows (near) + k_spmv_rows (far, tiled rows and columns; QBH_KRON_CODED=1)"
                                                                                if info.value_dict else
-                                                                               "k_kron_tile + k_zero_cut_groups + k_spmv_wave2<.,3> (far, sliced) + k_spmv_wave2<.,2> (near)"
-                                                                               if info.kron_sliced else "k_kron_tile + k_spmv_wave2<.,0> (far) + k_spmv_wave2<.,2> (near)")}
+                                                                               ("k_zero_cut_groups + k_spmv_wave2<.,3> (far, sliced) + k_spmv_wave2<.,2> (near); the tiled copy of x is written by the "
+                                                                                "pass that produces x (k_axpy_norm_tile8), k_kron_tile only in front of a driver's first step"
+                                                                                if world == 1 else
+                                                                                "tiled block -> all-gather || k_spmv_wave2<.,1> (near, own x) ; k_zero_cut_groups + k_spmv_wave2<.,3> (far, gathered tiled x) + k_kron_combine")
+                                                                               if info.kron_sliced else "k_kron_tile + k_spmv_wave2<.,0> (far) + k_spmv_wave2<.,2> (near)"),
+                                                         "in_place": bool(info.kron_inplace)}
                                                         if info.kron_minor else None),
                                          "operator_source": "host CSR in reference order through qbh_csr_create" if args.host_csr else
                                          "device generator, permuted on the device into the reference's Lin order and fermion convention "
@@ -659,6 +688,11 @@ def main():
                                          "build_s": round(t_gen, 3)},
         "roofline": roof, "e0": head["e0"], "lanczos_steps_to_converge": head["steps_e0"],
     }
+    if roof.get("traffic") is not None:
+        roof.update(traffic_stamp(tkey))
+        if roof["traffic_stale"]:
+            print("bench.py: WARNING roofline.traffic was measured on other kernel sources (%s, now %s): re-run tools/profile_bench.sh"
+                  % (roof["traffic_sources_sha16"], roof["sources_sha16"]), file=sys.stderr)
     if world > 1:
         # link bytes per GPU reported separately from the HBM bytes.  ms_per_gather is the event-timed duration of
         # the all-gather on RCCL's side stream (native communicator), max over ranks; it overlaps the locally-owned columns.
@@ -721,8 +755,6 @@ def main():
     if world == 1:
         A.destroy()          # the extra blocks below build their own operators: give the HBM back first (C4 substitute: 157 GB)
         torch.cuda.synchronize()
-        time.sleep(3.0)      # the driver returns > 200 GB (CSR + split copy) in the background; host-side calls of the next
-                             # block were seen to stall behind it (0.6 s per step at 11.7 ms per launch) when it started at once
     if world == 1 and not (coded or real_used) and not args.no_fast_path and not args.matrix_free and not args.host_csr and args.order != "reference":
         # the library's default path for this operator (lossless value codes; real operator + real vectors -> packed doubles):
         # same step definition, same K, its own roofline on its own format's bytes

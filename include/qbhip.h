@@ -67,6 +67,10 @@ const char *qbh_last_error(void);                   /* thread-local detail of th
                                   complex128 values only (coded operators use the row kernel)            */
 #define QBH_KERNEL_MATRIX_FREE 4 /* reported by qbh_csr_get_info for qbh_mf_hubbard operators   */
 
+/* qbh_opts.basis_kind */
+#define QBH_BASIS_NONE          0   /* an index is an index (default) */
+#define QBH_BASIS_REF_FERMION2  1   /* the reference's order of a two-species fermion basis (see qbh_opts.basis_kind) */
+
 typedef struct qbh_opts {
     int     device;          /* HIP ordinal; -1 = current device                                  */
     void   *stream;          /* hipStream_t to enqueue on; NULL = library-owned stream             */
@@ -82,17 +86,37 @@ typedef struct qbh_opts {
     int     real_fast_path;  /* 1 (default): a real operator applied to vectors with exactly zero imaginary
                                 parts gathers / exchanges 8-byte real parts (bit-identical results);
                                 0: always the complex128 arithmetic of the reference (north-star format)   */
-    int     kron_split;      /* 1 (default): an unsharded complex128 operator on a product basis (index = major * S + minor,
-                                every entry changes one of the two: the two-species Hubbard family in the generator's order)
-                                is also kept as H_near + H_far with the far part band-major over the minor index (same values,
-                                same 20 B per nonzero; verified on the device, skipped when HBM cannot hold the second copy);
-                                the split, the wave kernel and the row kernel are timed at creation and the fastest is kept
-                                (operators above 1e7 nonzeros; QBH_KERNEL_AUTO); 2: always when it applies; 0: never      */
+    int     kron_split;      /* 1 (default): a complex128 operator on a product basis (index = major * S + minor, every entry
+                                changes one of the two: the two-species Hubbard family in species-major order) is stored as
+                                H_near + H_far, the far part band-major over the minor index -- the handle's arrays are
+                                RE-ORDERED IN PLACE (same values, same int32 columns, same 20 B per nonzero; no second copy;
+                                qbh_csr_download merges the parts back).  The structure is verified on the device, the choice
+                                is structural (never timed).  Row shards made of whole major indices (row_offset and the
+                                row count multiples of S) split the same way.  2: the same (kept for older callers); 0: never */
     int64_t kron_minor;      /* S for an operator created from host / device arrays (0: unknown -> no split); the generators
-                                announce their own                                                            */
+                                announce their own; with basis_kind set it is derived from the hint                   */
+    int     deterministic;   /* 1: nothing about the operator is decided by a clock and nothing in an SpMV depends on the
+                                order in which wavefronts finish: no kernel timing at creation (QBH_KERNEL_AUTO keeps its
+                                default form), static walks instead of the per-XCD work counters.  Two runs on any two
+                                MI355X then give bit-identical vectors, a_j / b_j and step counts.  0 (default): see
+                                INTEGRATION.md section 4 for what is and is not reproducible                            */
+    int     basis_kind;      /* QBH_BASIS_*: what the row / column index of host arrays means.  QBH_BASIS_REF_FERMION2: the
+                                reference's own order for a two-species fermion model (mbasis_elem bit order, Lin tables of
+                                src/basis.cc:1144-1190, operators ordered by site, src/basis.cc:2650-2664) on n_sites sites
+                                with n_up + n_dn particles.  The library then keeps the operator INTERNALLY in species-major
+                                order (index = up * C(n_sites, n_dn) + down, so that the Kronecker split applies) and
+                                permutes / sign-flips vectors at the seams that copy them anyway (qbh_multmv/2, qbh_lanczos,
+                                qbh_eigenvec_cg, qbh_iram host vectors): callers see the reference's order throughout.  A hint
+                                that does not describe the matrix is detected (the permuted operator must have the product
+                                structure) and the operator is then kept exactly as given                              */
+    int     n_sites, n_up, n_dn;
 } qbh_opts;
 
 void qbh_opts_default(qbh_opts *o);
+/* Process-wide defaults: what qbh_opts_default() returns and what a NULL `opts` argument means from now on (NULL restores the
+ * built-in ones).  For a host whose constructor call cannot carry options -- the reference's csr_mat(lil_mat&) -- e.g. to name
+ * the basis of the matrices it is about to hand over (basis_kind, n_sites, n_up, n_dn). */
+void qbh_opts_set_default(const qbh_opts *o);
 
 /* ------------------------------------------------------------ operator --- */
 /* Replaces csr_mat<T>::csr_mat(lil_mat<T>&) + create_handle (src/sparse.cc:202-260).
@@ -148,8 +172,19 @@ typedef struct qbh_csr_info {
     int64_t kron_far_nnz;                    /* nonzeros of the far part (band-major)                               */
     int     kron_band;                       /* band width of the tiling                                            */
     int     kron_sliced;                     /* 1: far part interleaved inside groups of 8 rows (one x line per 8 lanes) */
+    int     kron_inplace;                    /* 1: the arrays hold [near | far] instead of a CSR (no second copy)           */
+    int     tuned;                           /* -1: the SpMV form was not timed at creation; 0 / 1: it was, the row / wave kernel won */
+    double  tune_ms_rows, tune_ms_wave;      /* the two times of that comparison (0 when not timed)                         */
+    int     basis_internal;                  /* QBH_BASIS_*: != 0 when the operator is held in another order than the caller's */
+    int     pad_;
 } qbh_csr_info;
 int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info);
+
+/* What qbh_opts.basis_kind says at creation, for an operator that already exists (a plain unsharded complex128 CSR: created
+ * with value_dict = 0, kron_split = 0): the operator is re-ordered internally (needs room for a second copy of the matrix
+ * while it runs) and split when the order described has the product structure; returns QBH_OK and changes nothing when the
+ * hint does not describe the matrix (qbh_csr_info.basis_internal tells).  Device vectors made before the call are in the old order. */
+int qbh_csr_set_basis(qbh_csr *A, int basis_kind, int n_sites, int n_up, int n_dn);
 
 /* Level-1 seam, host vectors.  Replace csr_mat<T>::MultMv (y = H x, src/sparse.cc:291-297)
  * and csr_mat<T>::MultMv2 (y += H x, src/sparse.cc:262-289).  x and y are host pointers of

@@ -14,6 +14,7 @@ if os.environ.get("QBHIP_LIBRARY"):      # e.g. a host-AddressSanitizer build of
 
 QBH_OK = 0
 KERNEL_AUTO, KERNEL_STREAM, KERNEL_VECTOR, KERNEL_ROWS, KERNEL_MATRIX_FREE, KERNEL_WAVE = 0, 1, 2, 3, 4, 5
+BASIS_NONE, BASIS_REF_FERMION2 = 0, 1
 
 
 class QbhError(RuntimeError):
@@ -32,7 +33,8 @@ class Opts(C.Structure):
     _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("spmv_kernel", C.c_int),
                 ("nnz_per_block", C.c_int), ("xcd_swizzle", C.c_int), ("value_dict", C.c_int),
                 ("profile", C.c_int), ("check_hermitian", C.c_int), ("real_fast_path", C.c_int),
-                ("kron_split", C.c_int), ("kron_minor", C.c_int64)]
+                ("kron_split", C.c_int), ("kron_minor", C.c_int64), ("deterministic", C.c_int), ("basis_kind", C.c_int),
+                ("n_sites", C.c_int), ("n_up", C.c_int), ("n_dn", C.c_int)]
 
 
 class CsrInfo(C.Structure):
@@ -40,7 +42,9 @@ class CsrInfo(C.Structure):
                 ("nnz", C.c_int64), ("n_blocks", C.c_int64), ("bytes_matrix", C.c_int64),
                 ("bytes_algorithmic", C.c_int64), ("kernel", C.c_int), ("value_dict", C.c_int),
                 ("device", C.c_int), ("stream", C.c_void_p), ("create_ms", C.c_double),
-                ("create_bytes_in", C.c_int64), ("kron_minor", C.c_int64), ("kron_far_nnz", C.c_int64), ("kron_band", C.c_int), ("kron_sliced", C.c_int)]
+                ("create_bytes_in", C.c_int64), ("kron_minor", C.c_int64), ("kron_far_nnz", C.c_int64), ("kron_band", C.c_int), ("kron_sliced", C.c_int),
+                ("kron_inplace", C.c_int), ("tuned", C.c_int), ("tune_ms_rows", C.c_double), ("tune_ms_wave", C.c_double),
+                ("basis_internal", C.c_int), ("pad_", C.c_int)]
 
 
 class LanczosRow(C.Structure):
@@ -77,7 +81,7 @@ class Stats(C.Structure):
 
 # every symbol include/qbhip.h declares (tests check that the .so exports all of them)
 EXPORTS = [
-    "qbh_version", "qbh_device_count", "qbh_strerror", "qbh_last_error", "qbh_opts_default",
+    "qbh_version", "qbh_device_count", "qbh_strerror", "qbh_last_error", "qbh_opts_default", "qbh_opts_set_default",
     "qbh_csr_create", "qbh_csr_create_rows", "qbh_balanced_row_cuts", "qbh_csr_create_device", "qbh_csr_destroy", "qbh_csr_get_info",
     "qbh_multmv", "qbh_multmv2",
     "qbh_vec_alloc", "qbh_vec_free", "qbh_vec_upload", "qbh_vec_download", "qbh_vec_zero",
@@ -87,7 +91,7 @@ EXPORTS = [
     "qbh_mopr_spin_dev", "qbh_mopr_onebody_dev", "qbh_mopr_sz_repr_dev", "qbh_mopr_flip_repr_dev",
     "qbh_crc32", "qbh_vec_disk_write", "qbh_vec_disk_read", "qbh_ckpt_lanczos_update", "qbh_ckpt_lanczos_init", "qbh_lanczos_ckpt",
     "qbh_csr_set_comm", "qbh_rccl_unique_id", "qbh_comm_create_rccl", "qbh_comm_destroy", "qbh_get_stats", "qbh_sync",
-    "qbh_gen_hubbard", "qbh_mf_hubbard", "qbh_gen_heisenberg", "qbh_mf_heisenberg", "qbh_gen_heisenberg_repr", "qbh_gen_hubbard_repr", "qbh_gen_heisenberg_repr_cuts", "qbh_gen_hubbard_repr_cuts", "qbh_mf_hubbard_repr", "qbh_mopr_diag_hubrepr_dev", "qbh_mopr_c_hubrepr_dev", "qbh_csr_download", "qbh_csr_reference_order",
+    "qbh_gen_hubbard", "qbh_mf_hubbard", "qbh_gen_heisenberg", "qbh_mf_heisenberg", "qbh_gen_heisenberg_repr", "qbh_gen_hubbard_repr", "qbh_gen_heisenberg_repr_cuts", "qbh_gen_hubbard_repr_cuts", "qbh_mf_hubbard_repr", "qbh_mopr_diag_hubrepr_dev", "qbh_mopr_c_hubrepr_dev", "qbh_csr_download", "qbh_csr_reference_order", "qbh_csr_set_basis",
 ]
 
 _lib = None
@@ -119,6 +123,7 @@ def lib():
     L.qbh_last_error.restype = C.c_char_p
     L.qbh_csr_destroy.restype = None
     L.qbh_opts_default.restype = None
+    L.qbh_opts_set_default.restype = None
     vp, i64, dbl = C.c_void_p, C.c_int64, C.c_double
     L.qbh_csr_create.argtypes = [C.POINTER(vp), i64, i64, C.c_int, vp, vp, vp, C.POINTER(Opts)]
     L.qbh_csr_create_rows.argtypes = [C.POINTER(vp), i64, i64, C.c_int, vp, vp, vp, i64, i64, C.POINTER(Opts)]

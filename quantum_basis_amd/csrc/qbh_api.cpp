@@ -61,9 +61,31 @@ extern "C" int qbh_device_count(void)
     return n;
 }
 
+namespace {
+std::mutex g_defaults_mu;
+bool g_have_defaults = false;
+qbh_opts g_defaults;
+}  // namespace
+
+// process-wide defaults: what qbh_opts_default returns and what a NULL `opts` argument means from now on (NULL: back to the
+// built-in ones).  For a host whose constructor call cannot carry options (the reference's csr_mat(lil_mat&))
+extern "C" void qbh_opts_set_default(const qbh_opts *o)
+{
+    std::lock_guard<std::mutex> lock(g_defaults_mu);
+    g_have_defaults = o != nullptr;
+    if (o) g_defaults = *o;
+}
+
 extern "C" void qbh_opts_default(qbh_opts *o)
 {
     if (!o) return;
+    {
+        std::lock_guard<std::mutex> lock(g_defaults_mu);
+        if (g_have_defaults) {
+            *o = g_defaults;
+            return;
+        }
+    }
     o->device = -1;
     o->stream = nullptr;
     o->spmv_kernel = QBH_KERNEL_AUTO;
@@ -75,6 +97,9 @@ extern "C" void qbh_opts_default(qbh_opts *o)
     o->real_fast_path = 1;
     o->kron_split = 1;
     o->kron_minor = 0;
+    o->deterministic = 0;
+    o->basis_kind = QBH_BASIS_NONE;
+    o->n_sites = o->n_up = o->n_dn = 0;
 }
 
 // ------------------------------------------------------------ operator ---------
@@ -301,60 +326,91 @@ int split_shard(qbh_csr *A)
 
 
 // ---------------------------------------------------------------------------------- Kronecker split ----
-// The split is an acceleration structure beside the CSR: a second copy of the matrix.  It must never be the reason a later
-// allocation fails (Krylov bases, CG vectors, a second operator): live splits are registered, and dev_malloc releases them,
-// largest first, before it reports out of memory -- the operator then runs on its plain CSR (same results).
-std::mutex g_split_mu;
-std::vector<qbh_csr *> g_splits;
-void split_unregister(qbh_csr *A)
-{
-    std::lock_guard<std::mutex> lock(g_split_mu);
-    g_splits.erase(std::remove(g_splits.begin(), g_splits.end(), A), g_splits.end());
-}
-void split_register(qbh_csr *A)
-{
-    std::lock_guard<std::mutex> lock(g_split_mu);
-    if (std::find(g_splits.begin(), g_splits.end(), A) == g_splits.end()) g_splits.push_back(A);
-}
-void kron_release(qbh_csr *A);
-bool release_one_split()
-{
-    qbh_csr *pick = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(g_split_mu);
-        for (qbh_csr *A : g_splits)
-            if (!pick || A->nnz > pick->nnz) pick = A;
-    }
-    if (!pick) return false;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipSetDevice(pick->device);
-    (void)hipDeviceSynchronize();                     // nothing in flight may still read the split's arrays
-    kron_release(pick);
-    (void)hipSetDevice(dev);
-    return true;
-}
 }  // namespace
 namespace qbh {
-hipError_t device_alloc(void **p, size_t bytes)
-{
-    hipError_t e = hipMalloc(p, bytes);
-    while (e == hipErrorOutOfMemory && release_one_split()) {
-        (void)hipGetLastError();
-        e = hipMalloc(p, bytes);
-    }
-    return e;
-}
+hipError_t device_alloc(void **p, size_t bytes) { return hipMalloc(p, bytes); }
 }  // namespace qbh
 namespace {
-void kron_release(qbh_csr *A)
+// everything of the split except the matrix arrays themselves (those are the handle's own d_ja / d_val, re-ordered in place)
+void kron_free_aux(qbh_csr *A)
 {
-    split_unregister(A);
     qbh_csr::KronSplit &K = A->kron;
-    for (void *q : {(void *)K.ia_n, (void *)K.ia_f, (void *)K.ja_n, (void *)K.ja_f, (void *)K.val_n, (void *)K.val_f, (void *)K.wd_n,
-                    (void *)K.wd_f, (void *)K.d_xt, (void *)K.d_far})
+    for (void *q : {(void *)K.ia_n, (void *)K.ia_f, (void *)K.wd_n, (void *)K.wd_f, (void *)K.d_xt, (void *)K.d_far})
         if (q) (void)hipFree(q);
+    if (K.own_far) {
+        if (K.ja_f) (void)hipFree(K.ja_f);
+        if (K.val_f) (void)hipFree(K.val_f);
+    }
     K = qbh_csr::KronSplit{};
+}
+
+qbh::KronParts kron_parts(const qbh_csr *A)
+{
+    const qbh_csr::KronSplit &K = A->kron;
+    qbh::KronParts p{};
+    p.ia = A->d_ia;
+    p.ia_n = K.ia_n;
+    p.fp = K.ia_f;
+    p.ja_n = K.ja_n;
+    p.ja_f = K.ja_f;
+    p.val_n = K.val_n;
+    p.val_f = K.val_f;
+    p.t = K.t;
+    p.U0 = K.U0;
+    p.cols = K.cols;
+    p.sliced = K.sliced ? 1 : 0;
+    p.nfar_rows = K.sliced ? K.n_groups * 8 : A->nrows;
+    return p;
+}
+
+qbh::KronCols kron_cols_one(int64_t S, int64_t NUg, int B)
+{
+    qbh::KronCols c{};
+    c.S = S;
+    c.B = B;
+    c.nr = 1;
+    c.cu[0] = 0;
+    c.cu[1] = NUg;
+    return c;
+}
+
+// wave-block geometry of the two parts (pipelined kernel); callable again after the parts moved
+int kron_geometry(qbh_csr *A)
+{
+    qbh_csr::KronSplit &K = A->kron;
+    hipStream_t s = A->stream;
+    const int64_t n = A->nrows;
+    for (int part = 0; part < 2; ++part) {
+        const bool sl = part && K.sliced;                    // sliced far part: blocks of 512 slots, ia_f = group pointers
+        const int64_t *ia = part ? K.ia_f : K.ia_n;
+        const int64_t nnz = part ? K.far_slots : K.nnz_n;
+        const int64_t nr = sl ? K.n_groups : n;
+        QBH_TRY(qbh::launch_max_rowlen(ia, nr, (int64_t *)A->d_scal, s));
+        int64_t maxlen = 0;
+        QBH_HIP(hipMemcpyAsync(&maxlen, A->d_scal, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        QBH_HIP(hipStreamSynchronize(s));
+        const int64_t window = sl ? 512 : (maxlen <= 256) ? 505 - (maxlen > 0 ? maxlen - 1 : 0) : 249;
+        const int64_t n_wb = std::max<int64_t>(1, (nnz + window - 1) / window);
+        qbh::WaveDesc *&wd = part ? K.wd_f : K.wd_n;
+        if (wd) (void)hipFree(wd);
+        wd = nullptr;
+        QBH_HIP(hipMalloc(&wd, (size_t)(n_wb + 2) * sizeof(qbh::WaveDesc)));
+        if (sl) QBH_TRY(qbh::launch_build_slotdesc(ia, nr, nnz, wd, n_wb, s));
+        else    QBH_TRY(qbh::launch_build_wavedesc(ia, nr, window, wd, n_wb, s));
+        const double avg = (double)(part ? K.nnz_f : K.nnz_n) / (double)n;
+        const int tpr = avg <= 32 ? 2 : avg <= 64 ? 4 : 8;
+        int ncu = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, A->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        const int occ = std::max(1, qbh::wave2_kernel_occupancy(tpr, part ? (sl ? 3 : 0) : 2));
+        int64_t g = std::min<int64_t>((int64_t)occ * ncu, ((((n_wb + 3) >> 2) + 7) / 8) * 8);
+        g = std::max<int64_t>(8, (g / 8) * 8);
+        (part ? K.nwb_f : K.nwb_n) = n_wb;
+        (part ? K.tpr_f : K.tpr_n) = tpr;
+        (part ? K.grid_f : K.grid_n) = (int)g;
+    }
+    QBH_HIP(hipStreamSynchronize(s));
+    return QBH_OK;
 }
 
 // H = H_near + H_far for an operator on a product basis (index = major * S + minor) whose entries change either the
@@ -362,29 +418,29 @@ void kron_release(qbh_csr *A)
 // same minor index).  The far part is what makes a row-major sweep re-read x: every major index pulls in the x rows of
 // all its neighbours (C3: 17 x 2.65 GB per SpMV).  Stored band-major over the minor index -- rows and columns in the
 // tiled order of KronTile -- a band of 8 minor indices needs ONE 128-byte line per major index, and 8 consecutive far
-// rows share every line they gather.  Per SpMV: x -> tiled copy, far pass (row sums, tiled order), near pass (+ far
-// result, fused epilogue).  Same values, same columns, same 20 B per nonzero: an acceleration structure beside the CSR
-// the handle keeps for qbh_csr_download / qbh_csr_set_comm; skipped when HBM cannot hold both.
+// rows share every line they gather.  Per SpMV: x -> tiled copy (or written by the pass that produced x), far pass (row sums,
+// tiled order), near pass (+ far result, fused epilogue).
+// Round 4: the split REPLACES the CSR -- the handle's own d_ja / d_val are re-ordered in place into [near | far] (same
+// values, same columns, same 20 B per nonzero; peak during the conversion = the CSR + one copy of the far part), row shards
+// made of whole major indices split the same way, and qbh_csr_download / kron_restore merge the parts back.  The choice is
+// STRUCTURAL (verified on the device, never assumed, never timed): results do not depend on the box.
 int kron_build(qbh_csr *A)
 {
-    kron_release(A);
-    if (!A->use_wave || A->kind != 0 || A->has_rem || A->nrows != A->ncols || A->row_offset != 0 || A->nnz <= 0) return QBH_OK;
-    if (A->opts.kron_split == 0) return QBH_OK;
+    if (A->kron.active) return QBH_OK;
+    if (!A->use_wave || A->kind != 0 || A->has_rem || A->nnz <= 0 || !A->own_arrays || !A->d_val || A->kron_off) return QBH_OK;
+    if (A->opts.kron_split == 0 || (A->debug & 1)) return QBH_OK;
+    if (A->opts.real_fast_path && A->values_real) return QBH_OK;      // the real-gather form of the row kernel needs the CSR
     if (const char *e = getenv("QBH_NO_KRON")) {
         if (atoi(e)) return QBH_OK;
     }
     const int64_t S = A->opts.kron_minor;
-    if (S <= 1 || S >= A->nrows || A->nrows % S != 0) return QBH_OK;
-    const int64_t NU = A->nrows / S;
+    if (S <= 1 || S >= A->ncols || A->ncols % S != 0 || A->nrows % S != 0 || A->row_offset % S != 0) return QBH_OK;
+    const int64_t NU = A->nrows / S, NUg = A->ncols / S, U0 = A->row_offset / S;
+    const int64_t n = A->nrows;
     hipStream_t s = A->stream;
-    {   // second copy of the matrix + two vectors + descriptors
-        size_t free_b = 0, total_b = 0;
-        const size_t need = (size_t)A->nnz * 20 + (size_t)A->nrows * (16 + 16 + 16 + 8) + ((size_t)2 << 30);
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < need) return QBH_OK;
-    }
     // the structure is verified, never assumed: one entry that changes both indices and the operator stays unsplit
     QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
-    QBH_TRY(qbh::launch_kron_check(A->d_ia, A->d_ja, A->nrows, S, A->d_flag, s));
+    QBH_TRY(qbh::launch_kron_check2(A->d_ia, A->d_ja, n, S, U0, A->d_flag, s));
     int bad = 0;
     QBH_HIP(hipMemcpyAsync(&bad, A->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
     QBH_HIP(hipStreamSynchronize(s));
@@ -392,17 +448,33 @@ int kron_build(qbh_csr *A)
     if (bad) return QBH_OK;
     qbh_csr::KronSplit &K = A->kron;
     int B = 8;                                       // one 128-byte line of complex128 per (band, major index)
-    while (B > 2 && (double)NU * B * 16 > 2.5e6) B >>= 1;              // keep a band of x inside an XCD's L2
+    while (B > 2 && (double)NUg * B * 16 > 2.5e6) B >>= 1;             // keep a band of x inside an XCD's L2
     if (const char *e = getenv("QBH_KRON_BAND")) {
         const int b = atoi(e);
         if (b == 2 || b == 4 || b == 8 || b == 16) B = b;
     }
     K.t = qbh::KronTile{S, NU, B};
-    int32_t *cn = nullptr, *cf = nullptr;
+    K.U0 = U0;
+    K.NUg = NUg;
+    K.cols = kron_cols_one(S, NUg, B);
+    int32_t *cn = nullptr, *cf = nullptr, *tmp_c = nullptr;
+    d2 *tmp_v = nullptr;
+    void *chunk = nullptr;
+    int32_t *d_rb = nullptr;
+    int64_t *d_bp = nullptr;
+    bool destructive = false;                        // the CSR is being re-ordered: a failure from here on is an error
     auto fail = [&](int code) {
-        if (cn) (void)hipFree(cn);
-        if (cf) (void)hipFree(cf);
-        kron_release(A);
+        for (void *q : {(void *)cn, (void *)cf, (void *)tmp_c, (void *)tmp_v, chunk, (void *)d_rb, (void *)d_bp})
+            if (q) (void)hipFree(q);
+        K.own_far = false;                           // tmp_c / tmp_v freed above
+        K.ja_f = nullptr;
+        K.val_f = nullptr;
+        kron_free_aux(A);
+        if (destructive && code == QBH_OK) code = QBH_EHIP;
+        if (destructive) {
+            qbh::set_error("Kronecker split: the in-place conversion failed half way; the operator is unusable");
+            A->broken = true;
+        }
         return code;
     };
 #define KRON_HIP(call)                                                                                   \
@@ -418,10 +490,9 @@ int kron_build(qbh_csr *A)
         const int rc_ = (expr);                \
         if (rc_ != QBH_OK) return fail(rc_);   \
     } while (0)
-    const int64_t n = A->nrows;
     KRON_HIP(hipMalloc(&cn, (size_t)n * sizeof(int32_t)));
     KRON_HIP(hipMalloc(&cf, (size_t)n * sizeof(int32_t)));
-    KRON_TRY(qbh::launch_kron_count(A->d_ia, A->d_ja, n, K.t, cn, cf, s));
+    KRON_TRY(qbh::launch_kron_count2(A->d_ia, A->d_ja, n, K.t, U0, cn, cf, s));
     KRON_HIP(hipMalloc(&K.ia_n, (size_t)(n + 1) * sizeof(int64_t)));
     KRON_HIP(hipMalloc(&K.ia_f, (size_t)(n + 1) * sizeof(int64_t)));
     KRON_TRY(qbh::exclusive_scan(cn, n, K.ia_n, s));
@@ -431,10 +502,12 @@ int kron_build(qbh_csr *A)
     if (K.nnz_f == 0 || K.nnz_n + K.nnz_f != A->nnz) return fail(QBH_OK);       // nothing far: the split buys nothing
     // Sliced far part: the 8 far rows of a (band, major index) pair hold the SAME major-index moves in the same order, so
     // interleaving them entry by entry makes every 8 consecutive stream elements one 128-byte line of the tiled x.  Groups
-    // are padded to their longest row (none for a product operator: only at ragged band edges); kept while the padding
-    // stays under 1/8 of the far entries and a group fits the wave tile.
+    // are padded to their longest row (none for a product operator); kept while the padding stays under 1/8 of the far
+    // entries and a group fits the wave tile.
     K.sliced = false;
-    K.n_groups = (n + 7) / 8;
+    // groups of 8 far rows cover the FULL bands only (with B = 8 each group is one (band, major index) pair); the rows of the
+    // narrow last band hold no far entries, are never written by the far pass and keep the zero d_far was created with
+    K.n_groups = B == 8 ? (S / 8) * NU : (n + 7) / 8;
     K.far_slots = K.nnz_f;
     int want_sliced = 1;                             // QBH_KRON_SLICED: 0 never, 1 when the padding is small, 2 whenever a group fits
     if (const char *e = getenv("QBH_KRON_SLICED")) want_sliced = atoi(e);
@@ -469,51 +542,108 @@ int kron_build(qbh_csr *A)
     cn = nullptr;
     (void)hipFree(cf);
     cf = nullptr;
-    KRON_HIP(hipMalloc(&K.ja_n, std::max<size_t>((size_t)K.nnz_n, 1) * sizeof(int32_t)));
-    KRON_HIP(hipMalloc(&K.ja_f, (size_t)K.far_slots * sizeof(int32_t)));
-    KRON_HIP(hipMalloc(&K.val_n, std::max<size_t>((size_t)K.nnz_n, 1) * sizeof(d2)));
-    KRON_HIP(hipMalloc(&K.val_f, (size_t)K.far_slots * sizeof(d2)));
-    if (K.sliced)
-        KRON_TRY(qbh::launch_kron_fill_sliced(A->d_ia, A->d_ja, A->d_val, n, K.t, K.ia_n, K.ja_n, K.val_n, K.ia_f, K.n_groups, K.ja_f, K.val_f, s));
-    else
-        KRON_TRY(qbh::launch_kron_fill(A->d_ia, A->d_ja, A->d_val, n, K.t, K.ia_n, K.ja_n, K.val_n, K.ia_f, K.ja_f, K.val_f, s));
-    KRON_HIP(hipMalloc(&K.d_xt, (size_t)n * sizeof(d2)));
-    KRON_HIP(hipMalloc(&K.d_far, (size_t)n * sizeof(d2)));
-    // wave-block geometry of the two parts (pipelined kernel)
-    for (int part = 0; part < 2; ++part) {
-        const bool sl = part && K.sliced;                    // sliced far part: blocks of whole groups, ia_f = group pointers
-        const int64_t *ia = part ? K.ia_f : K.ia_n;
-        const int64_t nnz = part ? K.far_slots : K.nnz_n;
-        const int64_t nr = sl ? K.n_groups : n;
-        KRON_TRY(qbh::launch_max_rowlen(ia, nr, (int64_t *)A->d_scal, s));
-        int64_t maxlen = 0;
-        KRON_HIP(hipMemcpyAsync(&maxlen, A->d_scal, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        KRON_HIP(hipStreamSynchronize(s));
-        // sliced: blocks are 512 consecutive slots of the stream, whatever the groups (cut groups are added atomically)
-        const int64_t window = sl ? 512 : (maxlen <= 256) ? 505 - (maxlen > 0 ? maxlen - 1 : 0) : 249;
-        const int64_t n_wb = std::max<int64_t>(1, (nnz + window - 1) / window);
-        qbh::WaveDesc *wd = nullptr;
-        KRON_HIP(hipMalloc(&wd, (size_t)(n_wb + 2) * sizeof(qbh::WaveDesc)));
-        (part ? K.wd_f : K.wd_n) = wd;
-        if (sl) KRON_TRY(qbh::launch_build_slotdesc(ia, nr, nnz, wd, n_wb, s));
-        else    KRON_TRY(qbh::launch_build_wavedesc(ia, nr, window, wd, n_wb, s));
-        const double avg = (double)(part ? K.nnz_f : K.nnz_n) / (double)n;
-        const int tpr = avg <= 32 ? 2 : avg <= 64 ? 4 : 8;
-        int ncu = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, A->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-        const int occ = std::max(1, qbh::wave2_kernel_occupancy(tpr, part ? (sl ? 3 : 0) : 2));
-        int64_t g = std::min<int64_t>((int64_t)occ * ncu, ((((n_wb + 3) >> 2) + 7) / 8) * 8);
-        g = std::max<int64_t>(8, (g / 8) * 8);
-        (part ? K.nwb_f : K.nwb_n) = n_wb;
-        (part ? K.tpr_f : K.tpr_n) = tpr;
-        (part ? K.grid_f : K.grid_n) = (int)g;
-    }
+    // ---- everything the conversion needs is allocated BEFORE the CSR is touched ----
+    KRON_TRY(qbh::launch_max_rowlen(A->d_ia, n, (int64_t *)A->d_scal, s));
+    int64_t maxlen = 0;
+    KRON_HIP(hipMemcpyAsync(&maxlen, A->d_scal, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     KRON_HIP(hipStreamSynchronize(s));
+    const int64_t cw = std::max<int64_t>((int64_t)1 << 26, 4 * maxlen);             // nonzeros per compaction step
+    const int64_t n_chunks = (A->nnz + cw - 1) / cw;
+    KRON_HIP(hipMalloc(&tmp_v, (size_t)K.far_slots * sizeof(d2)));
+    KRON_HIP(hipMalloc(&tmp_c, (size_t)K.far_slots * sizeof(int32_t)));
+    KRON_HIP(hipMalloc(&chunk, (size_t)(cw + maxlen) * sizeof(d2)));
+    KRON_HIP(hipMalloc(&d_rb, (size_t)(n_chunks + 1) * sizeof(int32_t)));
+    KRON_HIP(hipMalloc(&d_bp, (size_t)(n_chunks + 1) * sizeof(int64_t)));
+    KRON_HIP(hipMalloc(&K.d_far, (size_t)n * sizeof(d2)));
+    KRON_HIP(hipMemsetAsync(K.d_far, 0, (size_t)n * sizeof(d2), s));
+    KRON_TRY(qbh::launch_build_rowblocks(A->d_ia, n, cw, d_rb, d_bp, n_chunks, s));
+    std::vector<int32_t> rb((size_t)n_chunks + 1);
+    KRON_HIP(hipMemcpyAsync(rb.data(), d_rb, rb.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    KRON_HIP(hipStreamSynchronize(s));
+    std::vector<int64_t> nb((size_t)n_chunks + 1);            // near entries in front of each step's first row
+    for (int64_t c = 0; c <= n_chunks; ++c) KRON_HIP(hipMemcpyAsync(&nb[(size_t)c], K.ia_n + rb[(size_t)c], sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    KRON_HIP(hipStreamSynchronize(s));
+    // far part out of the intact CSR (values, then columns in the tiled order of the gathered x)
+    KRON_TRY(qbh::launch_kron_far_fill(false, K.sliced, A->d_ia, A->d_ja, A->d_val, n, K.t, U0, K.cols, K.ia_f, K.n_groups, nullptr, tmp_v, s));
+    KRON_TRY(qbh::launch_kron_far_fill(true, K.sliced, A->d_ia, A->d_ja, A->d_val, n, K.t, U0, K.cols, K.ia_f, K.n_groups, tmp_c, nullptr, s));
+    KRON_HIP(hipStreamSynchronize(s));
+    // near part compacted towards the front of the arrays, step by step through the staging buffer (a step's destination
+    // never reaches the source of a later step: near entries in front of a row <= all entries in front of it); the values
+    // first -- their classification reads the columns
+    destructive = true;
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        const int64_t r0 = rb[(size_t)c], r1 = rb[(size_t)c + 1], cnt = nb[(size_t)c + 1] - nb[(size_t)c];
+        if (r1 <= r0 || cnt <= 0) continue;
+        KRON_TRY(qbh::launch_kron_near_gather_vals(A->d_ia, A->d_ja, A->d_val, r0, r1, K.t, U0, K.ia_n, (d2 *)chunk, s));
+        KRON_HIP(hipMemcpyAsync(A->d_val + nb[(size_t)c], chunk, (size_t)cnt * sizeof(d2), hipMemcpyDeviceToDevice, s));
+    }
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        const int64_t r0 = rb[(size_t)c], r1 = rb[(size_t)c + 1], cnt = nb[(size_t)c + 1] - nb[(size_t)c];
+        if (r1 <= r0 || cnt <= 0) continue;
+        KRON_TRY(qbh::launch_kron_near_gather_cols(A->d_ia, A->d_ja, r0, r1, K.t, U0, K.ia_n, (int32_t *)chunk, s));
+        KRON_HIP(hipMemcpyAsync(A->d_ja + nb[(size_t)c], chunk, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    }
+    K.ja_n = A->d_ja;
+    K.val_n = A->d_val;
+    if (K.nnz_n + K.far_slots <= A->nnz) {           // no padding: the far part takes the space the far entries left
+        KRON_HIP(hipMemcpyAsync(A->d_val + K.nnz_n, tmp_v, (size_t)K.far_slots * sizeof(d2), hipMemcpyDeviceToDevice, s));
+        KRON_HIP(hipMemcpyAsync(A->d_ja + K.nnz_n, tmp_c, (size_t)K.far_slots * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        KRON_HIP(hipStreamSynchronize(s));
+        (void)hipFree(tmp_v);
+        (void)hipFree(tmp_c);
+        K.ja_f = A->d_ja + K.nnz_n;
+        K.val_f = A->d_val + K.nnz_n;
+        K.own_far = false;
+    } else {                                         // padded groups: the far part keeps its own (larger) arrays
+        K.ja_f = tmp_c;
+        K.val_f = tmp_v;
+        K.own_far = true;
+    }
+    tmp_v = nullptr;
+    tmp_c = nullptr;
+    KRON_HIP(hipStreamSynchronize(s));
+    (void)hipFree(chunk);
+    chunk = nullptr;
+    (void)hipFree(d_rb);
+    d_rb = nullptr;
+    (void)hipFree(d_bp);
+    d_bp = nullptr;
+    K.inplace = true;
+    KRON_TRY(kron_geometry(A));
 #undef KRON_HIP
 #undef KRON_TRY
     K.active = true;
-    split_register(A);
+    return QBH_OK;
+}
+
+// the CSR back out of the two parts (new arrays, merged row by row: the original rows, bit for bit); the handle is unsplit
+// afterwards and stays so.  Needs room for a second copy of the matrix while it runs.
+int kron_restore(qbh_csr *A)
+{
+    if (!A->kron.active) return QBH_OK;
+    hipStream_t s = A->stream;
+    QBH_HIP(hipStreamSynchronize(s));
+    int32_t *nja = nullptr;
+    d2 *nval = nullptr;
+    if (hipMalloc(&nja, (size_t)A->nnz * sizeof(int32_t)) != hipSuccess || hipMalloc(&nval, (size_t)A->nnz * sizeof(d2)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (nja) (void)hipFree(nja);
+        qbh::set_error("Kronecker split: no room to merge the parts back into a CSR (%.1f GB needed beside the operator)", A->nnz * 20e-9);
+        return QBH_ENOMEM;
+    }
+    int rc = qbh::launch_kron_merge_rows(kron_parts(A), 0, A->nrows, nja, nval, 0, s);
+    if (rc == QBH_OK && hipStreamSynchronize(s) != hipSuccess) rc = QBH_EHIP;
+    if (rc != QBH_OK) {
+        (void)hipFree(nja);
+        (void)hipFree(nval);
+        return rc;
+    }
+    (void)hipFree(A->d_ja);
+    (void)hipFree(A->d_val);
+    A->d_ja = nja;
+    A->d_val = nval;
+    kron_free_aux(A);
+    A->kron_off = true;
     return QBH_OK;
 }
 
@@ -659,34 +789,41 @@ int build_geometry(qbh_csr *A)
     A->rem.d_bp = nullptr;
     A->d_wd = nullptr;
     A->rem.d_wd = nullptr;
-    QBH_TRY(setup_geometry(A, A->d_ia, A->nnz, A->dict_mode, &A->npb, &A->tpr, &A->unroll, &A->window, &A->n_blocks, &A->d_rb,
-                           &A->d_bp, &A->grid));
-    int grid_max = A->grid;
-    if (A->has_rem) {
-        CsrPart &R = A->rem;
-        QBH_TRY(setup_geometry(A, R.d_ia, R.nnz, A->dict_mode, &R.npb, &R.tpr, &R.unroll, &R.window, &R.n_blocks, &R.d_rb, &R.d_bp,
-                               &R.grid));
-        grid_max = std::max(grid_max, R.grid);
-    }
     // complex128 values (no dictionary): the wave kernel, unless the row kernel was asked for by name
     A->use_wave = A->kernel == QBH_KERNEL_ROWS && A->dict_mode == 0 && A->d_val != nullptr && A->opts.spmv_kernel != QBH_KERNEL_ROWS;
     if (A->tuned == 0) A->use_wave = false;            // timed at creation (autotune_kernel): the row kernel won
     if (const char *e = getenv("QBH_NO_WAVE")) {
         if (atoi(e)) A->use_wave = false;
     }
-    if (A->use_wave) {
-        QBH_TRY(setup_wave_geometry(A, A->d_ia, A->nnz, &A->d_wd, &A->n_wb, &A->wtpr, &A->wgrid));
-        grid_max = std::max(grid_max, A->wgrid);
+    // an operator on a product basis is re-ordered in place into its two parts: it has no CSR geometry afterwards
+    QBH_TRY(kron_build(A));
+    int grid_max = 0;
+    if (A->kron.active) {
+        grid_max = std::max(A->kron.grid_n, A->kron.grid_f);
+        A->grid = A->wgrid = grid_max;
+        A->n_blocks = A->n_wb = 0;
+    } else {
+        QBH_TRY(setup_geometry(A, A->d_ia, A->nnz, A->dict_mode, &A->npb, &A->tpr, &A->unroll, &A->window, &A->n_blocks, &A->d_rb,
+                               &A->d_bp, &A->grid));
+        grid_max = A->grid;
         if (A->has_rem) {
             CsrPart &R = A->rem;
-            QBH_TRY(setup_wave_geometry(A, R.d_ia, R.nnz, &R.d_wd, &R.n_wb, &R.wtpr, &R.wgrid));
-            grid_max = std::max(grid_max, R.wgrid);
+            QBH_TRY(setup_geometry(A, R.d_ia, R.nnz, A->dict_mode, &R.npb, &R.tpr, &R.unroll, &R.window, &R.n_blocks, &R.d_rb, &R.d_bp,
+                                   &R.grid));
+            grid_max = std::max(grid_max, R.grid);
         }
+        if (A->use_wave) {
+            QBH_TRY(setup_wave_geometry(A, A->d_ia, A->nnz, &A->d_wd, &A->n_wb, &A->wtpr, &A->wgrid));
+            grid_max = std::max(grid_max, A->wgrid);
+            if (A->has_rem) {
+                CsrPart &R = A->rem;
+                QBH_TRY(setup_wave_geometry(A, R.d_ia, R.nnz, &R.d_wd, &R.n_wb, &R.wtpr, &R.wgrid));
+                grid_max = std::max(grid_max, R.wgrid);
+            }
+        }
+        QBH_TRY(kronc_build(A));
+        if (A->kronc.active) grid_max = std::max(grid_max, std::max(A->kronc.near_p.grid, A->kronc.far_p.grid));
     }
-    QBH_TRY(kron_build(A));
-    if (A->kron.active) grid_max = std::max(grid_max, std::max(A->kron.grid_n, A->kron.grid_f));
-    QBH_TRY(kronc_build(A));
-    if (A->kronc.active) grid_max = std::max(grid_max, std::max(A->kronc.near_p.grid, A->kronc.far_p.grid));
     const size_t nparts = (size_t)std::max(grid_max, qbh::kMaxRedBlocks);
     if (A->d_partials) (void)hipFree(A->d_partials);
     A->d_partials = nullptr;
@@ -696,14 +833,16 @@ int build_geometry(qbh_csr *A)
 
 int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double gamma, double *red);
 
-// QBH_KERNEL_AUTO on complex128 values: the wave kernel wins where the gathers hit the caches (1-D and Kronecker-structured
-// operators), the row kernel where they miss (momentum sectors: its lanes-to-rows gathers and larger blocks cost fewer line
-// fetches), the Kronecker split where it applies and fits -- so the three forms are TIMED on the operator itself, two launches
-// each, and the fastest one is kept (the structures of the others are released).  Below 1e7 nonzeros nothing is timed (the wave
-// kernel is kept: results stay bit-reproducible from run to run for every operator a CPU can check).
+// QBH_KERNEL_AUTO on complex128 values of an operator WITHOUT a product structure: the wave kernel wins where the gathers hit
+// the caches (1-D operators, kagome), the row kernel where they miss (momentum sectors: its lanes-to-rows gathers and larger
+// blocks cost fewer line fetches) -- so the two are TIMED on the operator itself and the faster one is kept.  Not timed (the
+// choice is then the same on every box and results are bit-reproducible from run to run): operators below 1e7 nonzeros, row
+// shards, a Kronecker split (structural), qbh_opts.deterministic, QBH_NO_AUTOTUNE=1.  qbh_csr_info.tuned / tune_ms_* report
+// what happened.
 int autotune_kernel(qbh_csr *A)
 {
     if (A->opts.spmv_kernel != QBH_KERNEL_AUTO || !A->use_wave || A->kind != 0 || A->has_rem || A->has_comm || A->nnz < 10000000) return QBH_OK;
+    if (A->kron.active || A->opts.deterministic || A->nrows != A->ncols) return QBH_OK;
     if (const char *e = getenv("QBH_NO_AUTOTUNE")) {
         if (atoi(e)) return QBH_OK;
     }
@@ -724,21 +863,13 @@ int autotune_kernel(qbh_csr *A)
     if (qbh::launch_fill_const(y, A->nrows, 0.25, s) != QBH_OK) return done(QBH_OK);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return done(QBH_OK);
-    const bool have_kron = A->kron.active;
     const int saved_profile = A->opts.profile;
     A->opts.profile = 0;
-    if (have_kron && A->opts.kron_split == 2) {                         // asked for by name: nothing to decide
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        A->opts.profile = saved_profile;
-        return done(QBH_OK);
-    }
     // one warm launch, then the FASTEST of three timed launches per form (clock ramps and page faults only ever add time);
     // the wave kernel is the default and is given up only for a form that is at least 3 % faster
-    double t_mode[3] = {1e300, 1e300, 1e300};
-    for (int mode = 0; mode < (have_kron ? 3 : 2); ++mode) {          // 0 row kernel | 1 wave kernel | 2 Kronecker split
+    double t_mode[2] = {1e300, 1e300};
+    for (int mode = 0; mode < 2; ++mode) {                              // 0 row kernel | 1 wave kernel
         A->use_wave = mode != 0;
-        A->kron.active = mode == 2;
         double red[3];
         bool ok = spmv_run(A, x, y, 0.5, -0.25, 0.0, red) == QBH_OK;                                   // warm
         for (int r = 0; r < 3 && ok; ++r) {
@@ -750,17 +881,16 @@ int autotune_kernel(qbh_csr *A)
     }
     int best_mode = 1;
     if (getenv("QBH_TUNE_TRACE"))
-        fprintf(stderr, "qbhip autotune: dim %lld nnz %lld: row kernel %.3f ms, wave kernel %.3f ms, Kronecker split %s\n", (long long)A->nrows,
-                (long long)A->nnz, t_mode[0], t_mode[1], have_kron ? (std::to_string(t_mode[2]) + " ms").c_str() : "n/a");
+        fprintf(stderr, "qbhip autotune: dim %lld nnz %lld: row kernel %.3f ms, wave kernel %.3f ms\n", (long long)A->nrows,
+                (long long)A->nnz, t_mode[0], t_mode[1]);
     if (t_mode[0] < 0.97 * t_mode[best_mode]) best_mode = 0;
-    if (have_kron && t_mode[2] < 0.97 * t_mode[best_mode]) best_mode = 2;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     A->opts.profile = saved_profile;
     A->use_wave = best_mode != 0;
     A->tuned = best_mode != 0 ? 1 : 0;
-    A->kron.active = have_kron;
-    if (best_mode != 2) kron_release(A);
+    A->tune_ms[0] = t_mode[0];
+    A->tune_ms[1] = t_mode[1];
     A->stats = qbh_stats{};
     A->stats.ms_spmv_min = std::numeric_limits<double>::infinity();
     A->xr_of = nullptr;
@@ -784,12 +914,18 @@ int finalize(qbh_csr *A)
     A->kernel = (o.spmv_kernel == QBH_KERNEL_VECTOR) ? QBH_KERNEL_VECTOR
               : (o.spmv_kernel == QBH_KERNEL_STREAM) ? QBH_KERNEL_STREAM : QBH_KERNEL_ROWS;
 
+    QBH_HIP(qbh::dev_alloc(&A->d_flag, sizeof(int)));
+    QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
+    // the caller told us what its index means (qbh_opts.basis_kind): hold the operator in the order the kernels like, keep
+    // the map for the vector seams; a hint that does not describe the matrix changes nothing
+    if (o.basis_kind != QBH_BASIS_NONE && A->basis.kind == 0) {
+        bool applied = false;
+        QBH_TRY(qbh::basis_to_internal(A, o.basis_kind, o.n_sites, o.n_up, o.n_dn, &applied));
+    }
     // value dictionary first: it decides how much LDS a row block needs
     QBH_TRY(try_value_dict(A));
     const bool coded = A->d_code != nullptr;
     // is every stored value real?  (enables the 8-byte wire format of the x exchange)
-    QBH_HIP(qbh::dev_alloc(&A->d_flag, sizeof(int)));
-    QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
     if (coded) {
         A->code_w = A->n_dict <= 256 ? 1 : 2;
         A->dict_mode = A->n_dict <= 256 ? 1 : A->n_dict <= qbh::kDictLds ? 2 : 3;
@@ -886,7 +1022,7 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
     if (A->d_wd) (void)hipFree(A->d_wd);
     kronc_release(A);
     if (A->rem.d_wd) (void)hipFree(A->rem.d_wd);
-    kron_release(A);
+    kron_free_aux(A);
     if (A->rem.d_ia) (void)hipFree(A->rem.d_ia);
     if (A->rem.d_ja) (void)hipFree(A->rem.d_ja);
     if (A->rem.d_val) (void)hipFree(A->rem.d_val);
@@ -895,6 +1031,8 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
     if (A->rem.d_bp) (void)hipFree(A->rem.d_bp);
     qbh::release_native_comm(A);
     if (A->d_flag) (void)hipFree(A->d_flag);
+    if (A->basis.d_map) (void)hipFree(A->basis.d_map);
+    if (A->basis.d_stage) (void)hipFree(A->basis.d_stage);
     if (A->d_xr) (void)hipFree(A->d_xr);
     if (A->kind == 1) {
         (void)hipFree(A->mf.cfg_u);
@@ -1202,6 +1340,18 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->kron_far_nnz = A->kron.active ? A->kron.nnz_f : 0;
     info->kron_band = A->kron.active ? A->kron.t.B : 0;
     info->kron_sliced = A->kron.active && A->kron.sliced ? 1 : 0;
+    info->kron_inplace = A->kron.active && A->kron.inplace ? 1 : 0;
+    if (A->kron.active) {
+        const qbh_csr::KronSplit &K = A->kron;
+        info->n_blocks = K.nwb_n + K.nwb_f;
+        info->bytes_matrix = (A->nrows + 1) * 16 + ((K.sliced ? K.n_groups : A->nrows) + 1) * 8 +
+                             (K.own_far ? nnz + K.far_slots : nnz) * 20 + (K.nwb_n + K.nwb_f + 4) * 16;
+    }
+    info->tuned = A->tuned;
+    info->tune_ms_rows = A->tune_ms[0];
+    info->tune_ms_wave = A->tune_ms[1];
+    info->basis_internal = A->basis.kind;
+    info->pad_ = 0;
     if (A->kronc.active) {                       // the coded form of the split (row kernel, packed-double vectors)
         info->kron_minor = A->kronc.t.S;
         info->kron_far_nnz = A->kronc.far_p.nnz;
@@ -1210,11 +1360,45 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     return QBH_OK;
 }
 
+// Declare what the index of an EXISTING operator means (the same thing qbh_opts.basis_kind says at creation): the operator is
+// re-ordered internally, its geometry rebuilt; device vectors made before the call are in the old order.
+extern "C" int qbh_csr_set_basis(qbh_csr *A, int basis_kind, int n_sites, int n_up, int n_dn)
+{
+    if (!A) return QBH_EINVAL;
+    if (A->has_comm || A->has_rem || A->kron.active || A->kronc.active || A->d_code || A->basis.kind != 0 || A->kind != 0) {
+        qbh::set_error("qbh_csr_set_basis: needs a plain, unsharded complex128 CSR (value_dict = 0, kron_split = 0 at creation) without a communicator");
+        return QBH_EUNSUPP;
+    }
+    Bind bind(A);
+    QBH_HIP(hipStreamSynchronize(A->stream));
+    bool applied = false;
+    QBH_TRY(qbh::basis_to_internal(A, basis_kind, n_sites, n_up, n_dn, &applied));
+    if (!applied) return QBH_OK;
+    A->opts.basis_kind = basis_kind;
+    A->opts.n_sites = n_sites;
+    A->opts.n_up = n_up;
+    A->opts.n_dn = n_dn;
+    if (A->opts.kron_split == 0) A->opts.kron_split = 1;
+    A->tuned = -1;
+    QBH_TRY(build_geometry(A));
+    QBH_HIP(hipStreamSynchronize(A->stream));
+    return QBH_OK;
+}
+
 extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
 {
     if (!A) return QBH_EINVAL;
     if (!comm || comm->nranks < 1) {          // NULL detaches; a 1-rank communicator is valid (hooks still run)
         A->has_comm = false;
+        if (A->kron.active && A->kron.comm_tiled) {       // far columns back to the tiled order of the whole vector
+            Bind bind(A);
+            const qbh::KronCols one = kron_cols_one(A->kron.t.S, A->kron.NUg, A->kron.t.B);
+            QBH_TRY(qbh::launch_kron_remap_cols(A->kron.ja_f, A->kron.far_slots, A->kron.cols, one, A->stream));
+            QBH_HIP(hipStreamSynchronize(A->stream));
+            A->kron.cols = one;
+            A->kron.comm_tiled = false;
+            A->kron.xt_of = nullptr;
+        }
         return QBH_OK;
     }
     if (A->kind == 3) {
@@ -1248,16 +1432,64 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
         A->comm_cuts.clear();
         A->comm_full = comm->nblk * (int64_t)comm->nranks;
     }
-    if (A->kind == 0 && !A->has_rem && A->nrows < A->ncols) {      // first communicator on a stored row shard: split it now
-        // the split comes FIRST and the communicator is committed only when it succeeded: a failure (out of memory)
-        // leaves the operator exactly as it was, unattached, with its single-part geometry
+    if (A->kind == 0) {
+        // A shard split in place (kron_build) exchanges the TILED copy of its block -- which only works when every rank does:
+        // cuts at whole major indices and every operator split.  The ranks agree through the communicator's own all-reduce
+        // (every rank of a stored operator makes this call, split or not); without agreement a split shard is merged back
+        // into its CSR and takes the generic path below.
+        Bind bind(A);
+        qbh_csr::KronSplit &K = A->kron;
+        const int64_t S = K.active ? K.t.S : 1;
+        bool mine = K.active && comm->nranks <= qbh::kKronMaxRanks;
+        if (mine) {
+            if (comm->row_cuts) {
+                for (int q = 0; q <= comm->nranks; ++q) mine = mine && comm->row_cuts[q] % S == 0;
+            } else {
+                mine = comm->nblk % S == 0;
+            }
+        }
+        double agree = mine ? 1.0 : 0.0;
+        if (comm->nranks > 1) {
+            QBH_HIP(hipMemcpyAsync(comm->d_scal, &agree, sizeof(double), hipMemcpyHostToDevice, A->stream));
+            if (comm->allreduce_sum(comm->ctx, 0, 1) != 0) {
+                qbh::set_error("qbh_csr_set_comm: allreduce_sum hook failed");
+                return QBH_ECOMM;
+            }
+            QBH_HIP(hipMemcpyAsync(&agree, comm->d_scal, sizeof(double), hipMemcpyDeviceToHost, A->stream));
+            QBH_HIP(hipStreamSynchronize(A->stream));
+            agree = agree == (double)comm->nranks ? 1.0 : 0.0;
+        }
+        if (K.active && agree == 1.0) {
+            qbh::KronCols to{};
+            to.S = S;
+            to.B = K.t.B;
+            to.nr = comm->nranks;
+            for (int q = 0; q <= comm->nranks; ++q) {
+                const int64_t cut = comm->row_cuts ? comm->row_cuts[q] : std::min<int64_t>((int64_t)q * comm->nblk, A->ncols);
+                to.cu[q] = cut / S;
+            }
+            QBH_TRY(qbh::launch_kron_remap_cols(K.ja_f, K.far_slots, K.cols, to, A->stream));
+            QBH_HIP(hipStreamSynchronize(A->stream));
+            K.cols = to;
+            K.comm_tiled = true;
+            K.xt_of = nullptr;
+        } else if (K.active) {
+            QBH_TRY(kron_restore(A));
+            QBH_TRY(build_geometry(A));
+        }
+    }
+    if (A->kind == 0 && !A->kron.active && !A->has_rem && A->nrows < A->ncols) {      // first communicator on a stored row shard: split it now
+        // the split comes FIRST and the communicator is committed only when it succeeded: a failure of the split itself (out
+        // of memory) leaves the operator exactly as it was, unattached, with its single-part geometry; a failure AFTER it
+        // (geometry of the two parts) leaves a handle that refuses every further SpMV
         Bind bind(A);
         QBH_HIP(hipStreamSynchronize(A->stream));
         QBH_TRY(split_shard(A));
         if (A->has_rem) {
             const int rc = build_geometry(A);
-            if (rc != QBH_OK) {
+            if (rc != QBH_OK) {                     // the shard IS split but has no geometry: nothing can run on it any more
                 A->has_comm = false;
+                A->broken = true;
                 return rc;
             }
         }
@@ -1345,8 +1577,195 @@ void harvest_events(qbh_csr *A)
 // A split shard runs two launches: the locally-owned columns (which only need this rank's block of x
 // and therefore overlap with the all-gather), then the remote columns, accumulating into y; the fused
 // reductions are produced by the last launch, on the final y.
+// does the next complex SpMV of this handle take the passes of the Kronecker split?  (An operator split in place has no
+// other form: spmv_run refuses whatever would need its CSR.)
+inline bool kron_path(const qbh_csr *A)
+{
+    return A->use_wave && A->kron.active && !(A->debug & 1) && A->ovr_yr == nullptr && !(A->real_mode && A->kernel == QBH_KERNEL_ROWS) &&
+           (!A->has_comm || A->kron.comm_tiled);
+}
+// where the pass that writes the next SpMV's x also writes its tiled copy (nullptr: the SpMV makes the copy itself): the
+// handle's own buffer, or -- under a communicator -- the send buffer of the exchange (the rank's block travels tiled)
+inline d2 *tiled_target(const qbh_csr *A)
+{
+    static const bool no_fold = getenv("QBH_NO_TILE_FOLD") != nullptr;      // A/B switch
+    if (no_fold || !A->kron.fold || !kron_path(A) || A->kron.t.B != 8 || A->kron.t.S < 8) return nullptr;
+    if (A->has_comm) return A->real_wire ? nullptr : reinterpret_cast<d2 *>(A->comm.d_xsend);
+    return (A->nrows == A->ncols && A->kron.xt_cap >= A->nrows) ? A->kron.d_xt : nullptr;
+}
+// Only a driver knows that nothing else writes its vectors between the pass that produces x and the SpMV that reads it
+// (a caller of the building-block entry points may scale or overwrite a vector in between): the drivers hold this guard.
+struct FoldGuard {
+    qbh_csr *A;
+    explicit FoldGuard(qbh_csr *a) : A(a)
+    {
+        A->kron.xt_of = nullptr;
+        A->kron.fold = true;
+    }
+    ~FoldGuard()
+    {
+        A->kron.xt_of = nullptr;
+        A->kron.fold = false;
+    }
+};
+
+// The SpMV of an operator split in place (kron_build).  One GPU (or a shard driven with the full-length x): tiled copy of x
+// unless the pass that produced x wrote it, far pass (row sums in tiled order), near pass (+ far result, fused epilogue and
+// reductions).  Under a communicator every rank sends the TILED copy of its own block; the near pass needs only the rank's own
+// x and runs while the all-gather is in flight (epilogue without the far addend), then the far pass reads the gathered blocks
+// and a light third pass adds its result and produces the reductions on the finished y.
+int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double gamma, double *red)
+{
+    qbh_csr::KronSplit &K = A->kron;
+    if (!kron_path(A)) {
+        qbh::set_error("this operator is stored split in place (qbh_opts.kron_split): the requested form of the SpMV (%s) needs its CSR",
+                       A->has_comm ? "a communicator whose ranks do not all exchange tiled blocks" : (A->debug & 1) ? "QBH_DEBUG column mask"
+                                                                                                             : "packed-real vectors");
+        return QBH_EUNSUPP;
+    }
+    hipStream_t s = A->stream;
+    const bool prof = A->opts.profile != 0;
+    const bool comm = A->has_comm;
+    int kron_swz = A->opts.deterministic ? 2 : 3;           // dynamic ordered walk per XCD unless the caller wants static walks
+    if (const char *e = getenv("QBH_WAVE_SWIZZLE")) kron_swz = atoi(e);
+    if (kron_swz == 3) {
+        if (!A->d_wctr) kron_swz = 2;
+        else QBH_HIP(hipMemsetAsync(A->d_wctr, 0, 3 * 128 * sizeof(unsigned long long), s));
+    }
+    const d2 *xl = comm ? x : x + A->row_offset;            // the rank's own block of x
+    const d2 *xt = nullptr;                                  // what the far pass gathers from
+    bool async_gather = false;
+    if (comm) {
+        d2 *send = reinterpret_cast<d2 *>(A->comm.d_xsend);
+        if (K.xt_of != (const void *)x) QBH_TRY(qbh::launch_kron_tile(x, send, A->nrows, K.t, s));
+        K.xt_of = nullptr;
+        async_gather = A->comm.allgather_begin && A->comm.allgather_wait;
+        const int hrc = async_gather ? A->comm.allgather_begin(A->comm.ctx, 0) : A->comm.allgather_x(A->comm.ctx, 0);
+        if (hrc != 0) {
+            qbh::set_error("allgather hook failed");
+            return QBH_ECOMM;
+        }
+        A->stats.n_gather++;
+        xt = reinterpret_cast<const d2 *>(A->comm.d_xfull);
+    } else {
+        if (K.xt_cap < A->ncols) {                           // first use: the tiled copy of the full-length x
+            if (K.d_xt) (void)hipFree(K.d_xt);
+            K.d_xt = nullptr;
+            K.xt_cap = 0;
+            QBH_HIP(qbh::dev_alloc(&K.d_xt, (size_t)A->ncols * sizeof(d2)));
+            K.xt_cap = A->ncols;
+            K.xt_of = nullptr;
+        }
+        if (prof) {
+            harvest_events(A);
+            QBH_HIP(hipEventRecord(A->ev0, s));
+        }
+        if (K.xt_of != (const void *)x) QBH_TRY(qbh::launch_kron_tile(x, K.d_xt, A->ncols, qbh::KronTile{K.t.S, K.NUg, K.t.B}, s));
+        K.xt_of = nullptr;
+        xt = K.d_xt;
+    }
+    qbh::SpmvArgs f{};                                       // far pass
+    f.ia = K.ia_f;
+    f.ja = K.ja_f;
+    f.val = K.val_f;
+    f.wd = K.wd_f;
+    f.n_wb = K.nwb_f;
+    f.nrows = K.sliced ? K.n_groups * 8 : A->nrows;          // sliced: whole groups of the full bands
+    f.xg = xt;
+    f.xl = xl;
+    f.y = K.d_far;
+    f.alpha = 1.0;
+    f.colmask = -1;
+    f.chunk_mult = A->chunk_mult;
+    f.swizzle = kron_swz == 3 ? 3 : 1;      // one contiguous eighth of the bands per XCD: a band of x stays in that XCD's L2
+    f.wctr = A->d_wctr ? A->d_wctr + 128 : nullptr;
+    qbh::SpmvArgs nr{};                                      // near pass
+    nr.ia = K.ia_n;
+    nr.ja = K.ja_n;
+    nr.val = K.val_n;
+    nr.wd = K.wd_n;
+    nr.n_wb = K.nwb_n;
+    nr.nrows = A->nrows;
+    nr.xg = xl - A->row_offset;                              // near columns are global indices of locally-owned elements
+    nr.xl = xl;
+    nr.y = y;
+    nr.alpha = alpha;
+    nr.beta = beta;
+    nr.gamma = gamma;
+    nr.colmask = -1;
+    nr.chunk_mult = A->chunk_mult;
+    nr.kS = K.t.S;
+    nr.kNU = K.t.NU;
+    nr.kB = K.t.B;
+    nr.swizzle = kron_swz;
+    nr.wctr = A->d_wctr ? A->d_wctr + 256 : nullptr;
+    int nparts = K.grid_n;
+    if (!comm) {
+        if (K.sliced) QBH_TRY(qbh::launch_zero_cut_groups(K.wd_f, K.nwb_f, f.nrows, K.d_far, s));
+        QBH_TRY(qbh::launch_spmv_wave2(f, K.tpr_f, K.sliced ? 3 : 0, K.grid_f, s));
+        nr.far = K.d_far;
+        nr.partials = red ? A->d_partials : nullptr;
+        QBH_TRY(qbh::launch_spmv_wave2(nr, K.tpr_n, 2, K.grid_n, s));
+#ifdef QBH_WAVE_TIMING
+        {   // debug build: where the wavefronts of the two passes spend their cycles (s_memtime ticks, 100 MHz)
+            unsigned long long h[3 * 128];
+            QBH_HIP(hipStreamSynchronize(s));
+            QBH_HIP(hipMemcpy(h, A->d_wctr, sizeof(h), hipMemcpyDeviceToHost));
+            for (int pass = 1; pass <= 2; ++pass) {
+                const unsigned long long *d = h + (pass + 1) * 128 - 8;
+                const double nb = d[4] ? (double)d[4] : 1.0;
+                fprintf(stderr, "[wave timing] %s pass: blocks %llu, ticks per block: issue+column wait %.1f, gather wait %.1f, reduce %.1f, stream rest %.1f\n",
+                        pass == 1 ? "far" : "near", d[4], d[0] / nb, d[1] / nb, d[2] / nb, d[3] / nb);
+            }
+        }
+#endif
+        if (prof) {
+            QBH_HIP(hipEventRecord(A->ev1, s));
+            A->ev_pending = true;
+        }
+    } else {
+        if (prof) {
+            harvest_events(A);
+            QBH_HIP(hipEventRecord(A->ev0, s));
+        }
+        nr.far = nullptr;
+        nr.partials = nullptr;
+        QBH_TRY(qbh::launch_spmv_wave2(nr, K.tpr_n, 1, K.grid_n, s));        // y = alpha H_near x + beta y + gamma x
+        if (prof) {
+            QBH_HIP(hipEventRecord(A->ev1, s));
+            A->ev_pending = true;
+        }
+        if (async_gather && A->comm.allgather_wait(A->comm.ctx) != 0) {
+            qbh::set_error("allgather_wait hook failed");
+            return QBH_ECOMM;
+        }
+        if (prof) QBH_HIP(hipEventRecord(A->ev2, s));
+        if (K.sliced) QBH_TRY(qbh::launch_zero_cut_groups(K.wd_f, K.nwb_f, f.nrows, K.d_far, s));
+        QBH_TRY(qbh::launch_spmv_wave2(f, K.tpr_f, K.sliced ? 3 : 0, K.grid_f, s));
+        QBH_TRY(qbh::launch_kron_combine(K.d_far, K.t, xl, y, A->nrows, alpha, red ? A->d_partials : nullptr, &nparts, s));
+        if (prof) {
+            QBH_HIP(hipEventRecord(A->ev3, s));
+            A->ev_pending2 = true;
+        }
+    }
+    A->xr_of = nullptr;
+    A->stats.n_spmv++;
+    if (red && A->defer_red) {
+        QBH_TRY(qbh::launch_reduce_partials(A->d_partials, nparts, 3, A->d_scal, s));
+    } else if (red) {
+        QBH_TRY(finish_reduction(A, nparts, 3, red));
+        if (prof) harvest_events(A);
+    }
+    return QBH_OK;
+}
+
 int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double gamma, double *red)
 {
+    if (A->broken) {
+        qbh::set_error("the operator was left inconsistent by an earlier failed call (qbh_csr_set_comm / creation): destroy it");
+        return QBH_EINVAL;
+    }
+    if (A->kron.active) return spmv_kron(A, x, y, alpha, beta, gamma, red);
     const d2 *xg, *xl;
     bool async_gather = false;
     const bool packed = A->has_comm && A->real_wire;
@@ -1521,14 +1940,13 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     }
     // complex128 values, complex vectors: the wave kernel; the real gather / all-real forms stay on the row kernel
     const bool wave = A->use_wave && a.xr == nullptr && a.y_re == nullptr;
-    const bool kron = wave && A->kron.active && !A->has_comm && !A->has_rem && !(A->debug & 1);
     // The two passes of a Kronecker split take the dynamic ordered walk per XCD (DynWalk: C3 far pass 86 -> 64 GB, near pass
     // 92 -> 68 GB, 31.7 -> 31.0 ms); the unsplit wave kernel keeps the static chunked walk (xcd_swizzle 2), under which all XCDs
     // stream from ONE region -- ordered eighths cost it 34 -> 43 ms on C3.  xcd_swizzle 3 / QBH_WAVE_SWIZZLE choose by name.
-    int wave_swz = A->opts.xcd_swizzle, kron_swz = 3, wave_grid_used = A->wgrid;
-    if (const char *e = getenv("QBH_WAVE_SWIZZLE")) wave_swz = kron_swz = atoi(e);
-    if (wave && (kron ? kron_swz == 3 : wave_swz == 3)) {
-        if (!A->d_wctr) wave_swz = kron_swz = 2;
+    int wave_swz = A->opts.xcd_swizzle, wave_grid_used = A->wgrid;
+    if (const char *e = getenv("QBH_WAVE_SWIZZLE")) wave_swz = atoi(e);
+    if (wave && wave_swz == 3) {
+        if (!A->d_wctr || A->opts.deterministic) wave_swz = 2;
         else QBH_HIP(hipMemsetAsync(A->d_wctr, 0, 3 * 128 * sizeof(unsigned long long), A->stream));
     }
     const bool kronc = A->kronc.active && realm && a.xr != nullptr && a.y_re != nullptr && !A->has_comm && !A->has_rem && !(A->debug & 1);
@@ -1565,50 +1983,6 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         fp.kNU = K.t.NU;
         fp.kB = K.t.B;
         QBH_TRY(qbh::launch_spmv(fp, A->kernel, K.far_p.npb, K.far_p.tpr, K.far_p.grid, A->stream));
-    } else if (kron) {
-        // Kronecker split: tiled copy of x, far pass (plain row sums in tiled order), near pass with the fused epilogue
-        const qbh_csr::KronSplit &K = A->kron;
-        QBH_TRY(qbh::launch_kron_tile(xg, K.d_xt, A->nrows, K.t, A->stream));
-        qbh::SpmvArgs f = a;
-        f.ia = K.ia_f;
-        f.ja = K.ja_f;
-        f.val = K.val_f;
-        f.wd = K.wd_f;
-        f.n_wb = K.nwb_f;
-        f.xg = K.d_xt;
-        f.y = K.d_far;
-        f.partials = nullptr;
-        f.swizzle = kron_swz == 3 ? 3 : 1;      // one contiguous eighth of the bands per XCD: a band of x stays in that XCD's L2
-        f.wctr = A->d_wctr + 128;
-        f.nrows = A->nrows;                       // sliced: the last group may reach past the last far row
-        if (K.sliced) QBH_TRY(qbh::launch_zero_cut_groups(K.wd_f, K.nwb_f, A->nrows, K.d_far, A->stream));
-        QBH_TRY(qbh::launch_spmv_wave2(f, K.tpr_f, K.sliced ? 3 : 0, K.grid_f, A->stream));
-        qbh::SpmvArgs nr = a;
-        nr.ia = K.ia_n;
-        nr.ja = K.ja_n;
-        nr.val = K.val_n;
-        nr.wd = K.wd_n;
-        nr.n_wb = K.nwb_n;
-        nr.far = K.d_far;
-        nr.kS = K.t.S;
-        nr.kNU = K.t.NU;
-        nr.kB = K.t.B;
-        nr.swizzle = kron_swz;
-        nr.wctr = A->d_wctr + 256;
-        QBH_TRY(qbh::launch_spmv_wave2(nr, K.tpr_n, 2, K.grid_n, A->stream));
-#ifdef QBH_WAVE_TIMING
-        {   // debug build: where the wavefronts of the two passes spend their cycles (s_memtime ticks, 100 MHz)
-            unsigned long long h[3 * 128];
-            QBH_HIP(hipStreamSynchronize(A->stream));
-            QBH_HIP(hipMemcpy(h, A->d_wctr, sizeof(h), hipMemcpyDeviceToHost));
-            for (int pass = 1; pass <= 2; ++pass) {
-                const unsigned long long *d = h + (pass + 1) * 128 - 8;
-                const double nb = d[4] ? (double)d[4] : 1.0;
-                fprintf(stderr, "[wave timing] %s pass: blocks %llu, ticks per block: issue+column wait %.1f, gather wait %.1f, reduce %.1f, stream rest %.1f\n",
-                        pass == 1 ? "far" : "near", d[4], d[0] / nb, d[1] / nb, d[2] / nb, d[3] / nb);
-            }
-        }
-#endif
     } else if (wave) {
         a.wd = A->d_wd;
         a.n_wb = A->n_wb;
@@ -1635,7 +2009,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         QBH_HIP(hipEventRecord(A->ev1, A->stream));
         A->ev_pending = true;
     }
-    int grid_last = kronc ? A->kronc.far_p.grid : kron ? A->kron.grid_n : wave ? wave_grid_used : A->grid;
+    int grid_last = kronc ? A->kronc.far_p.grid : wave ? wave_grid_used : A->grid;
     if (A->has_rem) {
         if (async_gather) {
             if (A->comm.allgather_wait(A->comm.ctx) != 0) {
@@ -1770,8 +2144,15 @@ inline double *packed_target(qbh_csr *A)
 int axpy_norm_run(qbh_csr *A, d2 alpha, const d2 *x, d2 *y, double *nrm2sq)
 {
     double *yr = packed_target(A);          // y is the next SpMV's x in every driver: emit its packed copy here
+    if (d2 *yt = tiled_target(A)) {         // ... or, for a Kronecker split, its tiled copy
+        QBH_TRY(qbh::launch_axpy_norm_tile(alpha, nullptr, x, y, yt, A->nrows, A->kron.t, A->d_partials, A->stream));
+        A->kron.xt_of = y;
+        A->xr_of = nullptr;
+        return finish_reduction(A, qbh::blas_grid(A->nrows), 1, nrm2sq);
+    }
     QBH_TRY(qbh::launch_axpy_norm(alpha, nullptr, x, y, A->nrows, A->d_partials, yr, A->d_flag, A->stream));
     A->xr_of = yr ? y : nullptr;
+    A->kron.xt_of = nullptr;
     return finish_reduction(A, qbh::blas_grid(A->nrows), 1, nrm2sq);
 }
 
@@ -1780,8 +2161,15 @@ int axpy_norm_run(qbh_csr *A, d2 alpha, const d2 *x, d2 *y, double *nrm2sq)
 int axpy_norm_deferred(qbh_csr *A, double scale, const d2 *x, d2 *y, double *dot_out, double *nrm2sq)
 {
     double *yr = packed_target(A);
-    QBH_TRY(qbh::launch_axpy_norm(d2{scale, 0.0}, A->d_scal, x, y, A->nrows, A->d_partials, yr, A->d_flag, A->stream));
-    A->xr_of = yr ? y : nullptr;
+    if (d2 *yt = tiled_target(A)) {
+        QBH_TRY(qbh::launch_axpy_norm_tile(d2{scale, 0.0}, A->d_scal, x, y, yt, A->nrows, A->kron.t, A->d_partials, A->stream));
+        A->kron.xt_of = y;
+        A->xr_of = nullptr;
+    } else {
+        QBH_TRY(qbh::launch_axpy_norm(d2{scale, 0.0}, A->d_scal, x, y, A->nrows, A->d_partials, yr, A->d_flag, A->stream));
+        A->xr_of = yr ? y : nullptr;
+        A->kron.xt_of = nullptr;
+    }
     QBH_TRY(qbh::launch_reduce_partials(A->d_partials, qbh::blas_grid(A->nrows), 1, A->d_scal + 4, A->stream));
     QBH_HIP(hipMemcpyAsync(A->h_scal, A->d_scal, 5 * sizeof(double), hipMemcpyDeviceToHost, A->stream));
     QBH_HIP(hipStreamSynchronize(A->stream));
@@ -1820,22 +2208,66 @@ extern "C" int qbh_vec_free(qbh_z *d)
     return QBH_OK;
 }
 
+namespace {
+// Host <-> device copies of vectors.  An operator held in another order than the caller's (qbh_opts.basis_kind) keeps its
+// device vectors in the INTERNAL order: these two seams -- every host vector passes one of them -- translate, so callers see
+// their own order throughout.  n must then be a whole number of vectors.
+int vec_h2d(qbh_csr *A, d2 *d_dst, const void *h_src, int64_t n)
+{
+    if (A->basis.kind == 0) {
+        QBH_HIP(hipMemcpyAsync(d_dst, h_src, (size_t)n * sizeof(d2), hipMemcpyHostToDevice, A->stream));
+        QBH_HIP(hipStreamSynchronize(A->stream));
+        return QBH_OK;
+    }
+    const int64_t dim = A->nrows;
+    if (n % dim != 0) {
+        qbh::set_error("vector copy of %lld elements: an operator with a basis map moves whole vectors (%lld elements)", (long long)n, (long long)dim);
+        return QBH_EINVAL;
+    }
+    if (!A->basis.d_stage) QBH_HIP(qbh::dev_alloc(&A->basis.d_stage, (size_t)dim * sizeof(d2)));
+    for (int64_t j = 0; j < n / dim; ++j) {
+        QBH_HIP(hipMemcpyAsync(A->basis.d_stage, (const char *)h_src + (size_t)j * (size_t)dim * sizeof(d2), (size_t)dim * sizeof(d2),
+                               hipMemcpyHostToDevice, A->stream));
+        QBH_TRY(qbh::launch_basis_scatter(A->basis.d_map, A->basis.d_stage, d_dst + (size_t)j * (size_t)dim, dim, A->stream));
+        QBH_HIP(hipStreamSynchronize(A->stream));
+    }
+    return QBH_OK;
+}
+int vec_d2h(qbh_csr *A, void *h_dst, const d2 *d_src, int64_t n)
+{
+    if (A->basis.kind == 0) {
+        QBH_HIP(hipMemcpyAsync(h_dst, d_src, (size_t)n * sizeof(d2), hipMemcpyDeviceToHost, A->stream));
+        QBH_HIP(hipStreamSynchronize(A->stream));
+        return QBH_OK;
+    }
+    const int64_t dim = A->nrows;
+    if (n % dim != 0) {
+        qbh::set_error("vector copy of %lld elements: an operator with a basis map moves whole vectors (%lld elements)", (long long)n, (long long)dim);
+        return QBH_EINVAL;
+    }
+    if (!A->basis.d_stage) QBH_HIP(qbh::dev_alloc(&A->basis.d_stage, (size_t)dim * sizeof(d2)));
+    for (int64_t j = 0; j < n / dim; ++j) {
+        QBH_TRY(qbh::launch_basis_gather(A->basis.d_map, d_src + (size_t)j * (size_t)dim, A->basis.d_stage, dim, A->stream));
+        QBH_HIP(hipMemcpyAsync((char *)h_dst + (size_t)j * (size_t)dim * sizeof(d2), A->basis.d_stage, (size_t)dim * sizeof(d2),
+                               hipMemcpyDeviceToHost, A->stream));
+        QBH_HIP(hipStreamSynchronize(A->stream));
+    }
+    return QBH_OK;
+}
+}  // namespace
+
 extern "C" int qbh_vec_upload(const qbh_csr *A, qbh_z *d_dst, const qbh_z *h_src, int64_t n)
 {
     if (!A || !d_dst || !h_src || n < 0) return QBH_EINVAL;
     Bind bind(A);
-    QBH_HIP(hipMemcpyAsync(d_dst, h_src, (size_t)n * sizeof(qbh_z), hipMemcpyHostToDevice, A->stream));
-    QBH_HIP(hipStreamSynchronize(A->stream));
-    return QBH_OK;
+    return vec_h2d(const_cast<qbh_csr *>(A), reinterpret_cast<d2 *>(d_dst), h_src, n);
 }
 
 extern "C" int qbh_vec_download(const qbh_csr *A, qbh_z *h_dst, const qbh_z *d_src, int64_t n)
 {
     if (!A || !h_dst || !d_src || n < 0) return QBH_EINVAL;
     Bind bind(A);
-    QBH_HIP(hipMemcpyAsync(h_dst, d_src, (size_t)n * sizeof(qbh_z), hipMemcpyDeviceToHost, A->stream));
-    QBH_HIP(hipStreamSynchronize(A->stream));
-    return QBH_OK;
+    return vec_d2h(const_cast<qbh_csr *>(A), h_dst, reinterpret_cast<const d2 *>(d_src), n);
 }
 
 extern "C" int qbh_vec_zero(const qbh_csr *A, qbh_z *d, int64_t n)
@@ -1856,9 +2288,15 @@ extern "C" int qbh_vec_randomize(const qbh_csr *Ac, qbh_z *d_x, uint32_t seed)
         return qbh::launch_fill_const(x, A->nrows, std::sqrt(1.0 / (double)A->ncols), A->stream);
     }
     const int64_t nruns = (A->nrows + 15) / 16;
-    QBH_TRY(qbh::launch_randomize(x, nullptr, A->nrows, A->has_comm ? A->row_offset : 0, seed, A->d_partials, A->stream));
+    d2 *xr = x;                                  // the Lehmer stream is indexed by the CALLER's element number
+    if (A->basis.kind != 0) {
+        if (!A->basis.d_stage) QBH_HIP(qbh::dev_alloc(&A->basis.d_stage, (size_t)A->nrows * sizeof(d2)));
+        xr = A->basis.d_stage;
+    }
+    QBH_TRY(qbh::launch_randomize(xr, nullptr, A->nrows, A->has_comm ? A->row_offset : 0, seed, A->d_partials, A->stream));
     double sq = 0.0;
     QBH_TRY(finish_reduction(A, qbh::blas_grid(nruns), 1, &sq));
+    if (xr != x) QBH_TRY(qbh::launch_basis_scatter(A->basis.d_map, xr, x, A->nrows, A->stream));
     return qbh::launch_scal(1.0 / std::sqrt(sq), x, A->nrows, A->stream);
 }
 
@@ -1918,6 +2356,12 @@ int multmv_host(qbh_csr *A, const qbh_z *x_host, qbh_z *y_host, double beta)
     const size_t bytes = (size_t)A->nrows * sizeof(d2);
     if (!A->d_stage_x) QBH_HIP(qbh::dev_alloc(&A->d_stage_x, bytes));
     if (!A->d_stage_y) QBH_HIP(qbh::dev_alloc(&A->d_stage_y, bytes));
+    if (A->basis.kind != 0) {                     // the caller's order at the seam, the internal one in HBM
+        QBH_TRY(vec_h2d(A, A->d_stage_x, x_host, A->nrows));
+        if (beta != 0.0) QBH_TRY(vec_h2d(A, A->d_stage_y, y_host, A->nrows));
+        QBH_TRY(spmv_run(A, A->d_stage_x, A->d_stage_y, 1.0, beta, 0.0, nullptr));
+        return vec_d2h(A, y_host, A->d_stage_y, A->nrows);
+    }
     QBH_HIP(hipMemcpyAsync(A->d_stage_x, x_host, bytes, hipMemcpyHostToDevice, A->stream));
     if (beta != 0.0) QBH_HIP(hipMemcpyAsync(A->d_stage_y, y_host, bytes, hipMemcpyHostToDevice, A->stream));
     QBH_TRY(spmv_run(A, A->d_stage_x, A->d_stage_y, 1.0, beta, 0.0, nullptr));
@@ -2016,7 +2460,7 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
 
     double nrm = 0.0;
     if (ext_rv) {
-        if (is_val1 || A->has_comm || !A->values_real || A->kernel != QBH_KERNEL_ROWS || A->nrows != A->ncols) {
+        if (is_val1 || A->has_comm || !A->values_real || A->kernel != QBH_KERNEL_ROWS || A->nrows != A->ncols || A->kron.active) {
             qbh::set_error("qbh_lanczos_real: needs a real operator on one GPU (row kernel / matrix-free), purpose sr_val0 or dnmcs");
             return QBH_EINVAL;
         }
@@ -2033,6 +2477,7 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
     }
 
     WireGuard wire_guard{A};
+    FoldGuard fold_guard{A};
     if (ext_rv) {
         A->real_wire = false;
         A->real_mode = true;                               // no packed side buffer is needed: the vectors are the packed form
@@ -2149,6 +2594,7 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
                 QBH_TRY(qbh::launch_scal(sc[j], v + (size_t)j * (size_t)n, n, A->stream));
                 sc[j] = 1.0;
                 A->xr_of = nullptr;
+                A->kron.xt_of = nullptr;
             }
         return QBH_OK;
     };
@@ -2310,14 +2756,10 @@ extern "C" int qbh_lanczos(const qbh_csr *A, int64_t k, int64_t np, int64_t maxi
     qbh_z *d_v = nullptr;
     QBH_HIP(qbh::dev_alloc((void **)&d_v, bytes));
     int rc = QBH_OK;
-    hipError_t e = hipMemcpy(d_v, v_host, bytes, hipMemcpyHostToDevice);
-    if (e != hipSuccess) rc = QBH_EHIP;
+    rc = vec_h2d(const_cast<qbh_csr *>(A), reinterpret_cast<d2 *>(d_v), v_host, nvec * A->nrows);
     if (rc == QBH_OK) rc = qbh_lanczos_dev(A, k, np, maxit, m, d_v, hessenberg, purpose, info);
-    if (rc == QBH_OK) {
-        // on exit the last two Lanczos vectors are returned (src/qbasis.h:1056-1058); phi0 is read-only
-        e = hipMemcpy(v_host, d_v, (size_t)2 * (size_t)A->nrows * sizeof(qbh_z), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = QBH_EHIP;
-    }
+    // on exit the last two Lanczos vectors are returned (src/qbasis.h:1056-1058); phi0 is read-only
+    if (rc == QBH_OK) rc = vec_d2h(const_cast<qbh_csr *>(A), v_host, reinterpret_cast<const d2 *>(d_v), 2 * A->nrows);
     (void)hipFree(d_v);
     return rc;
 }
@@ -2344,8 +2786,9 @@ static int cg_core(qbh_csr *A, int64_t maxit, int64_t *m_io, double E0, double *
     const int64_t spmv0 = A->stats.n_spmv;
     const double ms_spmv0 = A->stats.ms_spmv;
     WireGuard wire_guard{A};
+    FoldGuard fold_guard{A};
     if (ext) {
-        if (A->has_comm || !A->values_real || A->kernel != QBH_KERNEL_ROWS || A->nrows != A->ncols) {
+        if (A->has_comm || !A->values_real || A->kernel != QBH_KERNEL_ROWS || A->nrows != A->ncols || A->kron.active) {
             qbh::set_error("qbh_eigenvec_cg_real: needs a real operator on one GPU (row kernel / matrix-free)");
             return QBH_EINVAL;
         }
@@ -2467,7 +2910,14 @@ static int cg_core(qbh_csr *A, int64_t maxit, int64_t *m_io, double E0, double *
             const double beta = std::sqrt(sq) / accu;                                        // :326
             {
                 double *pr = packed_target(A);      // p is the next SpMV's x: emit its packed real copy in the same pass
-                QBH_TRY(qbh::launch_xpby(r, beta * beta, p, n, pr, A->d_flag, A->stream));   // :327-328
+                if (d2 *pt = tiled_target(A)) {     // ... or its tiled copy (Kronecker split)
+                    QBH_TRY(qbh::launch_xpby_tile(r, beta * beta, p, pt, n, A->kron.t, A->stream));
+                    A->kron.xt_of = p;
+                    pr = nullptr;
+                } else {
+                    QBH_TRY(qbh::launch_xpby(r, beta * beta, p, n, pr, A->d_flag, A->stream));   // :327-328
+                    A->kron.xt_of = nullptr;
+                }
                 A->xr_of = pr ? p : nullptr;
             }
             accu *= beta;
@@ -2513,11 +2963,11 @@ extern "C" int qbh_eigenvec_cg(const qbh_csr *A, int64_t maxit, int64_t *m, doub
     QBH_HIP(qbh::dev_alloc((void **)&d, 4 * bytes));
     int rc = QBH_OK;
     qbh_z *hv[4] = {v_host, r_host, p_host, pp_host};
+    qbh_csr *Am = const_cast<qbh_csr *>(A);
     for (int i = 0; i < 3 && rc == QBH_OK; ++i)      // pp is scratch on entry
-        if (hipMemcpy(d + i * n, hv[i], bytes, hipMemcpyHostToDevice) != hipSuccess) rc = QBH_EHIP;
+        rc = vec_h2d(Am, reinterpret_cast<d2 *>(d + i * n), hv[i], (int64_t)n);
     if (rc == QBH_OK) rc = qbh_eigenvec_cg_dev(A, maxit, m, E0, accu, d, d + n, d + 2 * n, d + 3 * n, info);
-    for (int i = 0; i < 4 && rc == QBH_OK; ++i)
-        if (hipMemcpy(hv[i], d + i * n, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = QBH_EHIP;
+    for (int i = 0; i < 4 && rc == QBH_OK; ++i) rc = vec_d2h(Am, hv[i], reinterpret_cast<const d2 *>(d + i * n), (int64_t)n);
     (void)hipFree(d);
     return rc;
 }
@@ -2718,15 +3168,11 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
             if (qbh::dev_alloc(&tmp, (size_t)n * sizeof(d2)) != hipSuccess) rc = QBH_ENOMEM;
             for (int i = 0; rc == QBH_OK && i < (int)nev; ++i) {
                 rc = qbh::launch_unpack_real(rvec(i), tmp, n, A->stream);
-                if (rc == QBH_OK && hipMemcpyAsync(eigenvecs_host + (size_t)i * (size_t)n, tmp, (size_t)n * sizeof(d2),
-                                                   hipMemcpyDeviceToHost, A->stream) != hipSuccess)
-                    rc = QBH_EHIP;
-                if (rc == QBH_OK && hipStreamSynchronize(A->stream) != hipSuccess) rc = QBH_EHIP;
+                if (rc == QBH_OK) rc = vec_d2h(A, eigenvecs_host + (size_t)i * (size_t)n, tmp, n);
             }
             if (tmp) (void)hipFree(tmp);
         } else if (eigenvecs_host) {
-            e = hipMemcpyAsync(eigenvecs_host, V, (size_t)nev * (size_t)n * sizeof(d2), hipMemcpyDeviceToHost, A->stream);
-            if (e != hipSuccess) rc = QBH_EHIP;
+            for (int i = 0; rc == QBH_OK && i < (int)nev; ++i) rc = vec_d2h(A, eigenvecs_host + (size_t)i * (size_t)n, vec(i), n);
         }
         e = hipStreamSynchronize(A->stream);
         if (e != hipSuccess) rc = QBH_EHIP;
@@ -2784,8 +3230,37 @@ extern "C" int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1, int64_
         qbh::set_error("qbh_csr_download: the operator is matrix-free (no stored CSR)");
         return QBH_EUNSUPP;
     }
+    if (A->basis.kind != 0) {
+        qbh::set_error("qbh_csr_download: the operator is held in another basis order than the caller's (qbh_opts.basis_kind); "
+                       "its rows are not the caller's rows");
+        return QBH_EUNSUPP;
+    }
     Bind bind(A);
     QBH_HIP(hipStreamSynchronize(A->stream));
+    if (A->kron.active) {                    // split in place: the rows are merged back on the device (columns ascending)
+        std::vector<int64_t> hia((size_t)(r1 - r0 + 1));
+        QBH_HIP(hipMemcpy(hia.data(), A->d_ia + r0, hia.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+        const int64_t p0 = hia.front(), cnt = hia.back() - hia.front();
+        if (ia)
+            for (size_t i = 0; i < hia.size(); ++i) ia[i] = hia[i] - p0;
+        if (cnt == 0 || (!ja && !val)) return QBH_OK;
+        int32_t *tj = nullptr;
+        d2 *tv = nullptr;
+        QBH_HIP(qbh::dev_alloc(&tj, (size_t)cnt * sizeof(int32_t)));
+        hipError_t he = qbh::dev_alloc(&tv, (size_t)cnt * sizeof(d2));
+        int rc = he == hipSuccess ? qbh::launch_kron_merge_rows(kron_parts(A), r0, r1, tj, tv, p0, A->stream) : QBH_ENOMEM;
+        if (rc == QBH_OK && ja) he = hipMemcpyAsync(ja, tj, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost, A->stream);
+        if (rc == QBH_OK && he == hipSuccess && val) he = hipMemcpyAsync(val, tv, (size_t)cnt * sizeof(d2), hipMemcpyDeviceToHost, A->stream);
+        if (rc == QBH_OK && he == hipSuccess) he = hipStreamSynchronize(A->stream);
+        (void)hipFree(tj);
+        if (tv) (void)hipFree(tv);
+        if (rc == QBH_OK && he != hipSuccess) {
+            qbh::set_error("qbh_csr_download: %s", hipGetErrorString(he));
+            (void)hipGetLastError();
+            rc = QBH_EHIP;
+        }
+        return rc;
+    }
     std::vector<int64_t> ia0, ia1;
     std::vector<int32_t> ja0, ja1;
     std::vector<d2> v0, v1;

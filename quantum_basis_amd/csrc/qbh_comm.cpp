@@ -159,8 +159,10 @@ int enqueue_gather(qbh_native_comm *c, int packed)
         }
         if ((r = c->api->GroupEnd()) != ncclSuccess) return fail(c, "ncclGroupEnd", r);
         if (mine > 0 && hipMemcpyAsync(recv + (size_t)c->cuts[(size_t)c->rank] * w, c->d_xsend, mine * w * sizeof(double),
-                                       hipMemcpyDeviceToDevice, c->side) != hipSuccess)
+                                       hipMemcpyDeviceToDevice, c->side) != hipSuccess) {
+            qbh::set_error("qbh_comm: device copy of the rank's own block failed: %s", hipGetErrorString(hipGetLastError()));
             return 1;
+        }
     }
     if (timed) {
         if (hipEventRecord(c->t1, c->side) != hipSuccess) return 1;

@@ -392,7 +392,7 @@ extern "C" int qbh_gen_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, i
     qbh_opts o2;
     if (opts) o2 = *opts;
     else qbh_opts_default(&o2);
-    if (o2.kron_minor == 0 && nrows == dim) o2.kron_minor = Nd;
+    if (o2.kron_minor == 0) o2.kron_minor = Nd;        // index = up * Nd + down; kron_build checks that a shard is made of whole up blocks
     return qbh_csr_create_device(out, nrows, dim, row_begin, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, &o2);
 }
 

@@ -107,6 +107,55 @@ struct KronTile {
     }
 };
 
+// Column order of the far part = order of the gathered x it reads: rank q (major indices [cu[q], cu[q+1])) contributes the
+// tiled copy (KronTile{S, cu[q+1] - cu[q], B}) of its own block, blocks in rank order.  One rank (cu = {0, NU}): the tiled
+// order of the whole vector.
+constexpr int kKronMaxRanks = 16;
+struct KronCols {
+    int64_t S;
+    int     B, nr;
+    int64_t cu[kKronMaxRanks + 1];
+    __host__ __device__ int64_t tile(int64_t c) const
+    {
+        const int64_t u = c / S;
+        int q = 0;
+        while (q + 1 < nr && u >= cu[q + 1]) ++q;
+        return cu[q] * S + KronTile{S, cu[q + 1] - cu[q], B}.tile(c - cu[q] * S);
+    }
+    __host__ __device__ int64_t orig(int64_t i) const
+    {
+        int q = 0;
+        while (q + 1 < nr && i >= cu[q + 1] * S) ++q;
+        return cu[q] * S + KronTile{S, cu[q + 1] - cu[q], B}.orig(i - cu[q] * S);
+    }
+};
+// the two parts of an operator split in place (kernel argument of the merge)
+struct KronParts {
+    const int64_t *ia, *ia_n, *fp;      // CSR row pointers; near row pointers; far row pointers (or group pointers when sliced)
+    const int32_t *ja_n, *ja_f;
+    const d2      *val_n, *val_f;
+    KronTile       t;                   // tiled order of the LOCAL rows
+    int64_t        U0;                  // first major index of the shard
+    KronCols       cols;
+    int            sliced;
+    int64_t        nfar_rows;           // far rows that exist in the far structure (sliced: the rows of the full bands)
+};
+int basis_to_internal(qbh_csr *A, int kind, int n_sites, int n_up, int n_dn, bool *applied);      // qbh_reorder.hip
+int launch_basis_scatter(const uint32_t *map, const d2 *in, d2 *out, int64_t n, hipStream_t s);
+int launch_basis_gather(const uint32_t *map, const d2 *in, d2 *out, int64_t n, hipStream_t s);
+int launch_kron_check2(const int64_t *ia, const int32_t *ja, int64_t nrows, int64_t S, int64_t U0, int *d_flag, hipStream_t s);
+int launch_kron_count2(const int64_t *ia, const int32_t *ja, int64_t nrows, const KronTile &t, int64_t U0, int32_t *cnt_near, int32_t *cnt_far,
+                       hipStream_t s);
+int launch_kron_far_fill(bool col, bool sliced, const int64_t *ia, const int32_t *ja, const d2 *val, int64_t nrows, const KronTile &t, int64_t U0,
+                         const KronCols &cols, const int64_t *fp, int64_t ngroups, int32_t *out_c, d2 *out_v, hipStream_t s);
+int launch_kron_near_gather_cols(const int64_t *ia, const int32_t *ja, int64_t r0, int64_t r1, const KronTile &t, int64_t U0, const int64_t *ia_n,
+                                 int32_t *tmp, hipStream_t s);
+int launch_kron_near_gather_vals(const int64_t *ia, const int32_t *ja, const d2 *val, int64_t r0, int64_t r1, const KronTile &t, int64_t U0,
+                                 const int64_t *ia_n, d2 *tmp, hipStream_t s);
+int launch_kron_merge_rows(const KronParts &p, int64_t r0, int64_t r1, int32_t *out_ja, d2 *out_val, int64_t out_base, hipStream_t s);
+int launch_kron_remap_cols(int32_t *ja_f, int64_t n, const KronCols &from, const KronCols &to, hipStream_t s);
+int launch_kron_combine(const d2 *far, const KronTile &t, const d2 *xl, d2 *y, int64_t n, double alpha, double *partials, int *nparts, hipStream_t s);
+
 // hipMalloc that releases live Kronecker splits (second copies of a matrix: acceleration structures, qbh_api.cpp) before it
 // reports out of memory.  Every allocation of the library except the splits' own goes through it.
 hipError_t device_alloc(void **p, size_t bytes);
@@ -146,6 +195,10 @@ int launch_reduce_partials(const double *partials, int nparts, int ncomp, double
 int launch_dotc(const d2 *x, const d2 *y, int64_t n, double *partials, hipStream_t s);
 int launch_axpy_norm(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, int64_t n, double *partials, double *yr, int *flag,
                      hipStream_t s);
+// the same passes writing the TILED copy of the updated y as well (Kronecker split, band 8: the next SpMV's far-pass gather source)
+int launch_axpy_norm_tile(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, d2 *yt, int64_t n, const KronTile &t, double *partials,
+                          hipStream_t s);
+int launch_xpby_tile(const d2 *x, double b, d2 *y, d2 *yt, int64_t n, const KronTile &t, hipStream_t s);
 int launch_nrm2sq(const d2 *x, int64_t n, double *partials, hipStream_t s);
 int launch_scal(double a, d2 *x, int64_t n, hipStream_t s);
 int launch_axpy_norm_re(double alpha, const double *alpha_dev, const double *x, double *y, int64_t n, double *partials, hipStream_t s);
@@ -379,7 +432,12 @@ struct qbh_csr {
     } kronc;
     struct KronSplit {
         bool     active = false;
-        qbh::KronTile t{0, 0, 8};
+        bool     inplace = false;       // the handle's d_ja / d_val hold [near | far]: there is no CSR beside the split
+        bool     own_far = false;       // padded far groups: ja_f / val_f are allocations of their own
+        qbh::KronTile t{0, 0, 8};       // tiled order of the LOCAL rows (NU = major indices of this shard)
+        int64_t  U0 = 0, NUg = 0;       // first major index of the shard, major indices of the whole operator
+        qbh::KronCols cols{};           // order of the gathered x the far columns index (one rank: KronTile{S, NUg, B})
+        bool     comm_tiled = false;    // a communicator is attached and every rank exchanges the tiled copy of its block
         int64_t  nnz_n = 0, nnz_f = 0;
         bool     sliced = false;        // far part interleaved inside groups of 8 rows (ia_f = group pointers, n_groups + 1 entries)
         int64_t  n_groups = 0, far_slots = 0;   // far_slots = entries stored in the far arrays (nnz_f + padding)
@@ -389,12 +447,18 @@ struct qbh_csr {
         qbh::WaveDesc *wd_n = nullptr, *wd_f = nullptr;
         int64_t  nwb_n = 0, nwb_f = 0;
         int      tpr_n = 2, tpr_f = 2, grid_n = 0, grid_f = 0;
-        qbh::d2 *d_xt = nullptr, *d_far = nullptr;      // tiled copy of x, far-part row sums (tiled order)
+        qbh::d2 *d_xt = nullptr, *d_far = nullptr;      // tiled copy of x (xt_cap elements, made on first use), far-part row sums (tiled order)
+        int64_t  xt_cap = 0;
+        const void *xt_of = nullptr;    // the vector whose tiled copy d_xt holds (written by the pass that produced it); consumed by one SpMV
+        bool     fold = false;          // set by a driver for the duration of a solve: its BLAS-1 passes write the tiled copy of the next x
     } kron;
     // wave kernel geometry (uncoded complex128 values; QBH_KERNEL_WAVE)
     bool     use_wave = false;
+    bool     broken = false;         // a failed call left the arrays inconsistent: every SpMV is refused
+    bool     kron_off = false;       // the split was merged back into a CSR (kron_restore): stay unsplit
     unsigned long long *d_wctr = nullptr;   // [3 * 128] work counters of the dynamic walk (main / far / near launch)
     int      tuned = -1;             // kernel timed best at creation: -1 not timed, 0 row kernel, 1 wave kernel (kept across rebuilds)
+    double   tune_ms[2] = {0.0, 0.0}; // the two times (row kernel, wave kernel) when it was
     qbh::WaveDesc *d_wd = nullptr;
     int64_t  n_wb = 0;
     int      wtpr = 2, wgrid = 0;
@@ -427,6 +491,13 @@ struct qbh_csr {
     double  *d_xr = nullptr;        // [ncols] packed Re(x) when there is no communicator
     const void *xr_of = nullptr;    // the vector whose real parts the packed buffer currently holds
     int     *d_flag = nullptr;      // raised by k_pack_real on a non-zero imaginary part
+
+    // the caller's basis when it is not the order the operator is held in (qbh_opts.basis_kind)
+    struct BasisMap {
+        int       kind = 0;              // QBH_BASIS_*; 0: the operator is held in the caller's order
+        uint32_t *d_map = nullptr;       // [nrows] caller index r -> internal index | sign << 31
+        qbh::d2  *d_stage = nullptr;     // [nrows] staging of one vector in the caller's order
+    } basis;
 
     // communicator
     bool     has_comm = false;

@@ -1045,8 +1045,36 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
             if (asking) reply = dw.ask(lane);        // in front of the gathers: answered by the time they are
         }
         d2 xv[8];
+#if defined(QBH_ABL_NEAR_LDS)            // ablation builds only (wrong results): near gathers served from a wave-private LDS window
+        if (OPS == 2) {
+            constexpr int WN = 640;
+            __shared__ d2 win_s[4 * WN];
+            d2 *win = win_s + wv * WN;
+            const int wbase = b0.r0 - 264;
+#if QBH_ABL_NEAR_LDS == 2
+            if (asking) {                 // first turn of a chunk: the window of x around the chunk's rows (synchronously: pessimistic)
+                for (int k = 0; k < WN / 64; ++k) {
+                    int64_t r = (int64_t)wbase + lane + 64 * k;
+                    r = r < 0 ? 0 : r >= a.nrows ? a.nrows - 1 : r;
+                    win[lane + 64 * k] = a.xg[r];
+                }
+                wave_lds_fence();
+            }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) xv[u] = a.xg[cA[u]];
+            for (int u = 0; u < 8; ++u) {
+                const unsigned rel = (unsigned)(cA[u] - wbase);
+                xv[u] = rel < (unsigned)WN ? win[rel] : a.xg[cA[u]];
+            }
+#else
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = win[(unsigned)(cA[u] - wbase) % WN];
+#endif
+        } else
+#endif
+        {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = a.xg[cA[u]];
+        }
 #ifdef QBH_ABL_NO_FAR_GATHER         // ablation builds only (wrong results): the far pass without its gathers
         if (OPS == 3 || OPS == 0) {
 #pragma unroll
@@ -2067,6 +2095,91 @@ int launch_axpy_norm(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, int6
                      hipStream_t s)
 {
     hipLaunchKernelGGL(k_axpy_norm, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, alpha_dev, x, y, n, partials, yr, flag);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// The same update for an operator with a Kronecker split (band 8): y is the next SpMV's x in every driver, and the far pass
+// gathers from its TILED copy (KronTile) -- written here, by the pass that produces y, instead of by a k_kron_tile launch
+// in front of the SpMV (one read of y and one launch less per step).  Work item = 32 major indices x 8 bands through LDS as in
+// k_kron_tile8: 1 KB runs of x / y in, 1 KB runs of y and 4 KB runs of the tiled copy out; the narrow last band (S % 8 != 0)
+// element-wise.  MODE 0: y += alpha x (alpha_dev as in k_axpy_norm), partial |y|^2.  MODE 1: y = x + alpha.x * y (k_xpby), no sum.
+// Static assignment of the items to workgroups: the partial sums are run-to-run reproducible.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_axpy_norm_tile8(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, d2 *yt, KronTile t,
+                                                            int64_t nfb, double *partials)
+{
+    constexpr int TU = 32, TB = 8, LD = TB * 8 + 1;
+    __shared__ d2 tilebuf[TU * LD];
+    __shared__ double red[4];
+    double acc[1] = {0.0};
+    if (MODE == 0 && alpha_dev != nullptr) alpha = d2{alpha.x * alpha_dev[0], 0.0};
+    auto upd = [&](d2 xv, d2 yv) -> d2 {
+        if (MODE == 0) {
+            const d2 v = yv + cmul(alpha, xv);
+            acc[0] += v.x * v.x + v.y * v.y;
+            return v;
+        }
+        return xv + alpha.x * yv;
+    };
+    const int64_t tiles_u = (t.NU + TU - 1) / TU, tiles_b = (nfb + TB - 1) / TB;
+    for (int64_t w = blockIdx.x; w < tiles_u * tiles_b; w += gridDim.x) {
+        const int64_t tb = w / tiles_u, tu = w - tb * tiles_u;
+        const int64_t u0 = tu * TU, b0 = tb * TB;
+        const int nu = (int)(t.NU - u0 < TU ? t.NU - u0 : TU), nb = (int)(nfb - b0 < TB ? nfb - b0 : TB);
+        d2 xv[TU * TB * 8 / kBlock], yv[TU * TB * 8 / kBlock];
+#pragma unroll
+        for (int i = 0; i < TU * TB * 8 / kBlock; ++i) {
+            const int idx = threadIdx.x + i * kBlock, ul = idx >> 6, dl = idx & 63;
+            const bool in = ul < nu && dl < nb * 8;
+            const int64_t r = in ? (u0 + ul) * t.S + b0 * 8 + dl : 0;
+            xv[i] = __builtin_nontemporal_load(x + r);
+            yv[i] = __builtin_nontemporal_load(y + r);
+        }
+        __syncthreads();                               // the previous item's tile has been read
+#pragma unroll
+        for (int i = 0; i < TU * TB * 8 / kBlock; ++i) {
+            const int idx = threadIdx.x + i * kBlock, ul = idx >> 6, dl = idx & 63;
+            if (ul < nu && dl < nb * 8) {
+                const d2 v = upd(xv[i], yv[i]);
+                y[(u0 + ul) * t.S + b0 * 8 + dl] = v;
+                tilebuf[ul * LD + dl] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TU * TB * 8 / kBlock; ++i) {
+            const int idx = threadIdx.x + i * kBlock, bl = idx >> 8, rest = idx & 255, ul = rest >> 3, j = rest & 7;
+            if (bl < nb && ul < nu) yt[(b0 + bl) * 8 * t.NU + (u0 + ul) * 8 + j] = tilebuf[ul * LD + bl * 8 + j];
+        }
+    }
+    const int64_t d0 = nfb * 8, we = t.S - d0;             // the narrow last band
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < t.NU * we; e += (int64_t)gridDim.x * kBlock) {
+        const int64_t u = e / we, r = u * t.S + d0 + (e - u * we);
+        const d2 v = upd(x[r], y[r]);
+        y[r] = v;
+        yt[t.tile(r)] = v;
+    }
+    if (MODE == 0) {
+        block_sum<1>(acc, red);
+        if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+    }
+}
+
+// grid = blas_grid(n): the partial sums are reduced by the same second stage as k_axpy_norm's
+int launch_axpy_norm_tile(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, d2 *yt, int64_t n, const KronTile &t, double *partials,
+                          hipStream_t s)
+{
+    if (t.B != 8 || t.S < 8) return QBH_EINVAL;
+    hipLaunchKernelGGL(k_axpy_norm_tile8<0>, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, alpha_dev, x, y, yt, t, t.S / 8, partials);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+int launch_xpby_tile(const d2 *x, double b, d2 *y, d2 *yt, int64_t n, const KronTile &t, hipStream_t s)
+{
+    if (t.B != 8 || t.S < 8) return QBH_EINVAL;
+    hipLaunchKernelGGL(k_axpy_norm_tile8<1>, dim3(blas_grid(n)), dim3(kBlock), 0, s, d2{b, 0.0}, (const double *)nullptr, x, y, yt, t, t.S / 8,
+                       (double *)nullptr);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }

@@ -135,7 +135,50 @@ __global__ __launch_bounds__(256) void k_ref_fill(const int32_t *order, const ui
     }
 }
 
+// inverse direction (qbh_opts.basis_kind): reference row r holds generator index g = order[r]
+__global__ __launch_bounds__(256) void k_inv_maps(const int32_t *order, const uint8_t *sign, int64_t dim, int32_t *inv_order, uint32_t *map,
+                                                  const int64_t *ia_ref, int32_t *cnt_new)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < dim; r += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t g = order[r];
+        inv_order[g] = (int32_t)r;
+        map[r] = (uint32_t)g | ((uint32_t)sign[g] << 31);
+        cnt_new[g] = (int32_t)(ia_ref[r + 1] - ia_ref[r]);
+    }
+}
+
+// vectors between the caller's order (index r) and the internal one (map[r] = internal index | sign << 31)
+__global__ __launch_bounds__(256) void k_basis_scatter(const uint32_t *map, const d2 *in, d2 *out, int64_t n)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t m = map[r];
+        const d2 v = in[r];
+        out[m & 0x7FFFFFFFu] = (m >> 31) ? -v : v;
+    }
+}
+__global__ __launch_bounds__(256) void k_basis_gather(const uint32_t *map, const d2 *in, d2 *out, int64_t n)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t m = map[r];
+        const d2 v = in[m & 0x7FFFFFFFu];
+        out[r] = (m >> 31) ? -v : v;
+    }
+}
+
 }  // namespace
+
+int launch_basis_scatter(const uint32_t *map, const d2 *in, d2 *out, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_basis_scatter, dim3(blas_grid(n)), dim3(256), 0, s, map, in, out, n);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+int launch_basis_gather(const uint32_t *map, const d2 *in, d2 *out, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_basis_gather, dim3(blas_grid(n)), dim3(256), 0, s, map, in, out, n);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
 
 }  // namespace qbh
 
@@ -156,10 +199,28 @@ extern "C" int qbh_csr_reference_order(qbh_csr **out, const qbh_csr *A, int kind
         set_error("qbh_csr_reference_order: invalid argument");
         return QBH_EINVAL;
     }
-    if (A->kind != 0 || A->d_val == nullptr || A->has_rem || A->nrows != A->ncols || A->row_offset != 0) {
-        set_error("qbh_csr_reference_order: needs an unsharded stored operator with complex128 values (create it with value_dict = 0)");
+    if (A->kind != 0 || A->d_val == nullptr || A->has_rem || A->nrows != A->ncols || A->row_offset != 0 || A->kron.active) {
+        set_error("qbh_csr_reference_order: needs an unsharded stored CSR with complex128 values (create it with value_dict = 0, kron_split = 0)");
         return QBH_EUNSUPP;
     }
+    // everything below (scratch, kernels on A->stream, the new handle) lives on A's device, whatever the caller's current one is
+    struct DevGuard {
+        int prev = -1;
+        explicit DevGuard(int dev)
+        {
+            if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+            (void)hipSetDevice(dev);
+        }
+        ~DevGuard()
+        {
+            if (prev >= 0) (void)hipSetDevice(prev);
+        }
+    } dev_guard(A->device);
+    qbh_opts opts_here;
+    if (opts) opts_here = *opts;
+    else qbh_opts_default(&opts_here);
+    opts_here.device = A->device;
+    opts = &opts_here;
     RefOrderArgs a{};
     a.kind = kind;
     a.n_sites = n_sites;
@@ -233,4 +294,107 @@ extern "C" int qbh_csr_reference_order(qbh_csr **out, const qbh_csr *A, int kind
     (void)drop(QBH_OK);                       // scratch only; the three result arrays go to the new handle
     const int rc = qbh_csr_create_device(out, dim, dim, 0, nnz, ia_r, ja_r, reinterpret_cast<qbh_z *>(val_r), 1, opts);
     return rc;
+}
+
+
+// qbh_opts.basis_kind = QBH_BASIS_REF_FERMION2: the plain CSR of A is in the reference's order of a two-species fermion basis
+// (rows sorted by (sub_b, sub_a), operators ordered by site: what model::generate_Ham_sparse_full hands over,
+// src/model.cc:649-679, src/basis.cc:1144-1190).  Re-express it in species-major order -- H_int = D P^T H_ref P D, index =
+// up * C(n_sites, n_dn) + down, all up operators before all down operators -- so that the Kronecker split applies, and keep the
+// map for the vector seams.  The hint is CHECKED: the permuted operator must have the product structure, else everything is
+// left as given (*applied = false).  Needs room for a second copy of the matrix while it runs.
+int qbh::basis_to_internal(qbh_csr *A, int kind, int n_sites, int n_up, int n_dn, bool *applied)
+{
+    using namespace qbh;
+    *applied = false;
+    if (kind != QBH_BASIS_REF_FERMION2 || n_sites < 2 || n_sites > 31 || n_up < 0 || n_up > n_sites || n_dn < 0 || n_dn > n_sites) return QBH_OK;
+    if (A->kind != 0 || !A->d_val || A->d_code || !A->own_arrays || A->has_rem || A->has_comm || A->kron.active || A->nrows != A->ncols ||
+        A->row_offset != 0 || A->basis.kind != 0)
+        return QBH_OK;
+    RefOrderArgs a{};
+    a.kind = 1;
+    a.n_sites = n_sites;
+    a.n_up = n_up;
+    a.n_dn = n_dn;
+    std::vector<uint64_t> hb(33 * 33, 0);
+    for (int p = 0; p <= 32; ++p)
+        for (int k = 0; k <= 32; ++k) hb[(size_t)p * 33 + k] = (k == 0) ? 1 : (p == 0 ? 0 : hb[(size_t)(p - 1) * 33 + k - 1] + hb[(size_t)(p - 1) * 33 + k]);
+    a.n_minor = (int64_t)hb[(size_t)n_sites * 33 + n_dn];
+    a.dim = (int64_t)hb[(size_t)n_sites * 33 + n_up] * a.n_minor;
+    if (a.dim != A->nrows || a.n_minor < 2 || a.n_minor >= a.dim) return QBH_OK;          // not the basis described: kept as given
+    const int64_t dim = a.dim, nnz = A->nnz;
+    hipStream_t s = A->stream;
+    uint64_t *k0 = nullptr, *k1 = nullptr, *d_binom = nullptr;
+    int32_t *v0 = nullptr, *v1 = nullptr, *cnt = nullptr, *ja_n = nullptr, *inv_order = nullptr;
+    uint8_t *sign = nullptr;
+    uint32_t *map = nullptr;
+    void *tmp = nullptr;
+    int64_t *ia_n = nullptr;
+    d2 *val_n = nullptr;
+    auto drop = [&](int code) {                // scratch and (unless adopted) results; out of memory = "kept as given", not an error
+        for (void *q : {(void *)k0, (void *)k1, (void *)v0, (void *)v1, (void *)cnt, (void *)sign, tmp, (void *)d_binom, (void *)inv_order, (void *)map,
+                        (void *)ia_n, (void *)ja_n, (void *)val_n})
+            if (q) (void)hipFree(q);
+        return code == QBH_ENOMEM ? QBH_OK : code;
+    };
+    RO_HIP(qbh::dev_alloc(&d_binom, hb.size() * 8));
+    RO_HIP(hipMemcpy(d_binom, hb.data(), hb.size() * 8, hipMemcpyHostToDevice));
+    a.binom = d_binom;
+    RO_HIP(qbh::dev_alloc(&k0, (size_t)dim * 8));
+    RO_HIP(qbh::dev_alloc(&k1, (size_t)dim * 8));
+    RO_HIP(qbh::dev_alloc(&v0, (size_t)dim * 4));
+    RO_HIP(qbh::dev_alloc(&v1, (size_t)dim * 4));
+    RO_HIP(qbh::dev_alloc(&sign, (size_t)dim));
+    hipLaunchKernelGGL(k_ref_keys, dim3(2048), dim3(256), 0, s, a, k0, v0, sign);
+    RO_HIP(hipGetLastError());
+    size_t tmp_bytes = 0;
+    RO_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0, k1, v0, v1, dim, 0, 2 * n_sites, s));
+    RO_HIP(qbh::dev_alloc(&tmp, tmp_bytes));
+    RO_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k0, k1, v0, v1, dim, 0, 2 * n_sites, s));
+    RO_HIP(hipStreamSynchronize(s));
+    for (void **q : {(void **)&tmp, (void **)&k0, (void **)&k1, (void **)&v0}) {
+        (void)hipFree(*q);
+        *q = nullptr;
+    }
+    RO_HIP(qbh::dev_alloc(&inv_order, (size_t)dim * 4));
+    RO_HIP(qbh::dev_alloc(&map, (size_t)dim * 4));
+    RO_HIP(qbh::dev_alloc(&cnt, (size_t)dim * 4));
+    hipLaunchKernelGGL(k_inv_maps, dim3(2048), dim3(256), 0, s, v1, sign, dim, inv_order, map, A->d_ia, cnt);
+    RO_HIP(hipGetLastError());
+    RO_HIP(qbh::dev_alloc(&ia_n, (size_t)(dim + 1) * 8));
+    {
+        const int rc = exclusive_scan(cnt, dim, ia_n, s);
+        if (rc != QBH_OK) return drop(rc);
+    }
+    RO_HIP(qbh::dev_alloc(&ja_n, (size_t)std::max<int64_t>(nnz, 1) * 4));
+    RO_HIP(qbh::dev_alloc(&val_n, (size_t)std::max<int64_t>(nnz, 1) * 16));
+    // row g of the internal operator = reference row inv_order[g]; column c_ref -> map[c_ref] (index | sign)
+    hipLaunchKernelGGL(k_ref_fill, dim3(4096), dim3(256), 0, s, inv_order, map, dim, A->d_ia, A->d_ja, A->d_val, ia_n, ja_n, val_n);
+    RO_HIP(hipGetLastError());
+    // the hint is checked, not trusted: in the order it describes every entry keeps the up or the down configuration
+    RO_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
+    {
+        const int rc = launch_kron_check2(ia_n, ja_n, dim, a.n_minor, 0, A->d_flag, s);
+        if (rc != QBH_OK) return drop(rc);
+    }
+    int bad = 0;
+    RO_HIP(hipMemcpyAsync(&bad, A->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    RO_HIP(hipStreamSynchronize(s));
+    RO_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
+    if (bad) return drop(QBH_OK);
+    (void)hipFree(A->d_ia);
+    (void)hipFree(A->d_ja);
+    (void)hipFree(A->d_val);
+    A->d_ia = ia_n;
+    A->d_ja = ja_n;
+    A->d_val = val_n;
+    ia_n = nullptr;
+    ja_n = nullptr;
+    val_n = nullptr;
+    A->basis.kind = kind;
+    A->basis.d_map = map;
+    map = nullptr;
+    A->opts.kron_minor = a.n_minor;
+    *applied = true;
+    return drop(QBH_OK);
 }

@@ -250,7 +250,19 @@ def rebalance_cuts(cuts, cost):
     want = cum[-1] * np.arange(1, world) / world
     new = np.interp(want, cum, cuts.astype(np.float64))        # piecewise-linear inverse of the cumulative cost
     out = np.concatenate([[cuts[0]], np.round(new).astype(np.int64), [cuts[-1]]])
-    for q in range(1, world + 1):                              # strictly increasing
-        out[q] = max(out[q], out[q - 1] + 1)
-    out[-1] = cuts[-1]
+    for q in range(1, world):                                  # strictly increasing, every shard keeps at least one row:
+        out[q] = max(out[q], out[q - 1] + 1)                   # ... pushed up from the left
+    for q in range(world - 1, 0, -1):
+        out[q] = min(out[q], out[q + 1] - 1)                   # ... and held back from the right (the last cut stays at dim)
+    assert np.all(np.diff(out) > 0), "fewer rows than shards"
     return out
+
+
+def kron_row_cuts(dim, minor, world):
+    """Row cuts at WHOLE MAJOR INDICES of a product basis (index = major * minor + minor_index) for `world` row shards, as
+    even as the major count allows: what a shard of an operator with a Kronecker split (qbh_opts.kron_split) needs to keep its
+    two-part form and to exchange the tiled copy of its block under a communicator (cuts not at multiples of `minor` fall back to
+    the plain CSR shard)."""
+    assert minor > 0 and dim % minor == 0 and dim // minor >= world
+    nu = dim // minor
+    return np.asarray([(q * nu) // world * minor for q in range(world + 1)], dtype=np.int64)

@@ -37,7 +37,8 @@ def _cvec(a, name):
 
 
 def make_opts(device=-1, stream=None, spmv_kernel=_lib.KERNEL_AUTO, nnz_per_block=0, xcd_swizzle=2,
-              value_dict=1, profile=0, check_hermitian=1, real_fast_path=1, kron_split=1, kron_minor=0):
+              value_dict=1, profile=0, check_hermitian=1, real_fast_path=1, kron_split=1, kron_minor=0, deterministic=0,
+              basis_kind=0, n_sites=0, n_up=0, n_dn=0):
     o = _lib.Opts()
     lib().qbh_opts_default(C.byref(o))
     o.device = device
@@ -51,6 +52,9 @@ def make_opts(device=-1, stream=None, spmv_kernel=_lib.KERNEL_AUTO, nnz_per_bloc
     o.real_fast_path = real_fast_path
     o.kron_split = kron_split
     o.kron_minor = kron_minor
+    o.deterministic = deterministic
+    o.basis_kind = basis_kind
+    o.n_sites, o.n_up, o.n_dn = n_sites, n_up, n_dn
     return o
 
 
@@ -352,6 +356,13 @@ class csr_mat:
         check(lib().qbh_csr_reference_order(C.byref(h), self.handle, int(kind), int(n_sites), int(n_up), int(n_dn), C.byref(o)),
               "qbh_csr_reference_order")
         return csr_mat(self.dim, None, None, None, _handle=h)
+
+    def set_basis(self, basis_kind, n_sites, n_up, n_dn):
+        """Tell an existing plain CSR what its index means (qbh_csr_set_basis; _lib.BASIS_REF_FERMION2 = the reference's order of a
+        two-species fermion basis): it is then held species-major internally (Kronecker split), vectors are translated at
+        upload / download / randomize.  Returns True when the hint described the matrix."""
+        check(lib().qbh_csr_set_basis(self.handle, int(basis_kind), int(n_sites), int(n_up), int(n_dn)), "qbh_csr_set_basis")
+        return self.info().basis_internal != 0
 
     def download(self, r0=0, r1=None, values=True):
         """Copy rows [r0, r1) of the device CSR back (tests / CPU-baseline sample)."""

@@ -115,6 +115,40 @@ def gpu_sharded_solver(rank, world, port, backend, out_dir, matrix_free=False, s
     dist.destroy_process_group()
 
 
+def gpu_sharded_kron(rank, world, port, backend, out_dir, mixed=False):
+    """Row shards of WHOLE MAJOR INDICES of a product-basis operator (complex128 CSR, Hubbard 4x3: dim 853,776, S = 924): every
+    shard is split in place, the ranks exchange the TILED copies of their blocks, the near pass runs while the gather is in
+    flight.  mixed: rank 1 creates its shard unsplit -- the ranks then agree on the plain exchange and rank 0 merges its parts
+    back into a CSR (kron_restore)."""
+    import torch
+    dist = _init(rank, world, port, backend)
+    torch.cuda.set_device(0)
+    import quantum_basis_amd as q
+    from quantum_basis_amd import dist as qdist, lattices
+
+    L, ne, bonds, dim, S = 12, 6, lattices.square(4, 3), 853776, 924
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        split = 0 if (mixed and rank == 1) else 1
+        opts = q.make_opts(device=0, stream=stream.cuda_stream, value_dict=0, real_fast_path=0, kron_split=split)
+        cuts = qdist.kron_row_cuts(dim, S, world)
+        r0, r1 = int(cuts[rank]), int(cuts[rank + 1])
+        A = q.csr_mat.hubbard(L, ne, ne, bonds, rows=(r0, r1), opts=opts)
+        assert A.info().kron_minor == (S if split else 0)
+        comm = qdist.ShardComm(dim, rank=rank, world=world, device=torch.device("cuda", 0), stream=stream, cuts=cuts).attach(A)
+        assert A.info().kron_minor == (0 if mixed else S)          # agreed by all ranks, or merged back
+        res = q.locate_E0_lanczos(A, nev=1, ncv=1, maxit=400)
+        assert not comm.errors, comm.errors
+        x = q.vec_randomize(A, seed=1)
+        np.save(os.path.join(out_dir, "x_%d.npy" % rank), x)
+        np.save(os.path.join(out_dir, "vec_%d.npy" % rank), res.eigenvecs)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "res.npy"), np.array([res.E0, res.steps["E0"], res.steps["V0"]]))
+            np.save(os.path.join(out_dir, "hess.npy"), res.hessenberg_E0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def gpu_sharded_complex(rank, world, port, backend, out_dir):
     """A genuinely complex Hermitian operator (translation-symmetric sector, helpers.case('chain16_k3')) row-sharded
     from host arrays through qbh_csr_create_device: the exchange must stay complex (16 B per element)."""

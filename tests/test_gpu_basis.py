@@ -1,0 +1,113 @@
+"""qbh_opts.basis_kind = QBH_BASIS_REF_FERMION2: host arrays in the REFERENCE's own order (Lin order of src/basis.cc:1144-1190,
+operators ordered by site, Hermitian-upper int64 CSR exactly as model::generate_Ham_sparse_full hands over, src/model.cc:649-679)
+are held species-major inside the library so that the Kronecker split applies; vectors are permuted / sign-flipped at the seams.
+Callers must see the reference's order throughout: every result is compared with the oracle ON THE SAME HOST ARRAYS, with the
+internal permutation active."""
+import math
+
+import numpy as np
+import pytest
+
+import quantum_basis_amd as q
+from quantum_basis_amd import _lib
+from oracle import qb_oracle as qo
+
+import refham
+
+pytestmark = pytest.mark.gpu
+PLAIN = dict(value_dict=0, real_fast_path=0)
+
+
+def _rand(n, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.normal(size=n) + 1j * rng.normal(size=n)).astype(np.complex128)
+
+
+def _hint(n, nu, nd, **kw):
+    return q.make_opts(basis_kind=_lib.BASIS_REF_FERMION2, n_sites=n, n_up=nu, n_dn=nd, **kw)
+
+
+@pytest.mark.parametrize("ly,nu,nd", [(2, 4, 4), (2, 3, 5), (3, 6, 6)])
+def test_reference_ordered_host_arrays_run_on_the_split_with_the_hint(ly, nu, nd):
+    n = 4 * ly
+    dim, ia, ja, val, sym = refham.hubbard_csr(4, ly, nu, nd, t=1.0, U=1.1)
+    O = qo.Csr(dim, ia, ja, val, sym)
+    A = q.csr_mat(dim, ia, ja, val, sym=True, opts=_hint(n, nu, nd, **PLAIN))
+    info = A.info()
+    assert info.basis_internal == _lib.BASIS_REF_FERMION2 and info.kron_minor == math.comb(n, nd) and info.kron_inplace == 1
+    # MultMv / MultMv2 (src/sparse.cc:262-297) through the host seam, caller's order in and out
+    x, y0 = _rand(dim, 1), _rand(dim, 2)
+    want = O.multmv(x)
+    y = np.empty(dim, dtype=np.complex128)
+    A.MultMv(x, y)
+    assert np.abs(y - want).max() <= 2e-13 * np.abs(want).max()
+    y = y0.copy()
+    A.MultMv2(x, y)
+    assert np.abs(y - (y0 + want)).max() <= 2e-13 * np.abs(want).max()
+    # lanczos (src/lanczos.cc:134-266) from the reference's start vector: a_j, b_j and the step count of the oracle
+    maxit = 1000
+    v = np.zeros(2 * dim, dtype=np.complex128)
+    v[:dim] = qo.vec_randomize(dim, 1)
+    vo = v.copy()
+    hess, hess_o = np.zeros(2 * maxit), np.zeros(2 * maxit)
+    m = q.lanczos(0, maxit - 1, maxit, dim, A, v, hess, "sr_val0")
+    mo, _, _ = qo.lanczos(0, maxit - 1, maxit, O, vo, hess_o, "sr_val0")
+    assert abs(m - mo) <= 1
+    assert np.allclose(hess[maxit:maxit + 20], hess_o[maxit:maxit + 20], rtol=1e-9) and np.allclose(hess[1:21], hess_o[1:21], rtol=1e-9)
+    for j in (0, 1):                                                  # the two vectors handed back are the oracle's, in the caller's order
+        assert abs(abs(np.vdot(v[j * dim:(j + 1) * dim], vo[j * dim:(j + 1) * dim])) - 1.0) < 1e-6
+    # the device start vector is the same Lehmer stream in the CALLER's element order
+    assert np.allclose(q.vec_randomize(A, seed=1), qo.vec_randomize(dim, 1), rtol=1e-13, atol=0)
+    # locate_E0_lanczos: E0 and the eigenvector, in the caller's order
+    r = q.locate_E0_lanczos(A, nev=1, ncv=1, maxit=1000)
+    ro = qo.locate_E0_lanczos(O, nev=1, ncv=1, maxit=1000)
+    assert abs(r.E0 - ro["E0"]) <= 1e-11 * abs(ro["E0"])
+    assert abs(abs(np.vdot(r.eigenvecs, ro["eigenvecs"])) - 1.0) < 1e-8
+    assert np.abs(O.multmv(r.eigenvecs) - r.E0 * r.eigenvecs).max() < 1e-7
+    with pytest.raises(q.QbhError):                                   # its rows are not the caller's rows
+        A.download()
+    A.destroy()
+
+
+def test_a_hint_that_does_not_describe_the_matrix_changes_nothing():
+    """8 sites, 3 up + 5 down.  (5, 3) has the same dimension and the same minor size but sorts the wrong particles into the
+    major index: the permuted operator has no product structure, which the device check sees; (4, 4) has another dimension.
+    Both leave the operator exactly as given -- unpermuted, unsplit, correct."""
+    n, nu, nd = 8, 3, 5
+    dim, ia, ja, val, sym = refham.hubbard_csr(4, 2, nu, nd, t=1.0, U=1.1)
+    O = qo.Csr(dim, ia, ja, val, sym)
+    x = _rand(dim, 4)
+    want = O.multmv(x)
+    for hint in [(n, 5, 3), (n, 4, 4), (10, 3, 5)]:
+        A = q.csr_mat(dim, ia, ja, val, sym=True, opts=_hint(*hint, **PLAIN))
+        info = A.info()
+        assert info.basis_internal == 0 and info.kron_minor == 0, hint
+        y = np.empty(dim, dtype=np.complex128)
+        A.MultMv(x, y)
+        assert np.abs(y - want).max() <= 2e-13 * np.abs(want).max()
+        fia, fja, fval = A.download()                                  # still the caller's rows (both triangles)
+        assert fia[-1] == 2 * ia[-1] - dim
+        A.destroy()
+
+
+def test_set_basis_on_an_existing_operator():
+    """qbh_csr_set_basis: the same declaration for an operator that already exists (bench.py --order reference uses it on the
+    device-permuted C3).  Hubbard 4x3 in the reference's order, made on the device."""
+    from quantum_basis_amd import lattices
+    n, nu, nd = 12, 6, 6
+    G = q.csr_mat.hubbard(n, nu, nd, lattices.square(4, 3), t=1.0, U=1.1, opts=q.make_opts(kron_split=0, **PLAIN))
+    R = G.reference_order(1, n, nu, nd, opts=q.make_opts(kron_split=0, **PLAIN))
+    e_ref = q.locate_E0_lanczos(R).E0
+    assert R.info().kron_minor == 0
+    assert R.set_basis(_lib.BASIS_REF_FERMION2, n, nu, nd)
+    info = R.info()
+    assert info.kron_minor == math.comb(n, nd) and info.kron_inplace == 1 and info.basis_internal == 1
+    r = q.locate_E0_lanczos(R)
+    assert abs(r.E0 - e_ref) <= 1e-11 * abs(e_ref)
+    # the eigenvector comes back in the reference's order: it is the generator's eigenvector permuted and sign-flipped
+    g = q.locate_E0_lanczos(G)
+    dim, ia, ja, val, sym = refham.hubbard_csr(4, 3, nu, nd, t=1.0, U=1.1)
+    assert np.abs(qo.Csr(dim, ia, ja, val, sym).multmv(r.eigenvecs) - r.E0 * r.eigenvecs).max() < 1e-7
+    assert abs(g.E0 - r.E0) <= 1e-11 * abs(r.E0)
+    G.destroy()
+    R.destroy()

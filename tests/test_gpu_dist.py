@@ -52,6 +52,29 @@ def test_sharded_solver_matches_single_gpu(world, backend, mf):
     assert abs(np.linalg.norm(vec) - 1.0) < 1e-12
 
 
+@pytest.mark.parametrize("world,backend,mixed", [(2, "gloo", False), (3, "gloo", False), (1, "nccl", False), (2, "gloo", True)])
+def test_sharded_kron_split_matches_single_gpu(world, backend, mixed):
+    """SURVEY 8e for the headline form: shards of whole major indices keep the Kronecker split, exchange tiled blocks, overlap
+    the near pass with the gather; E0, a_j / b_j, step counts and the eigenvector equal the one-rank run."""
+    import torch.multiprocessing as mp
+    import dist_worker
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(dist_worker.gpu_sharded_kron, args=(world, _free_port(), backend, tmp, mixed), nprocs=world, join=True)
+        res = np.load(tmp + "/res.npy")
+        hess = np.load(tmp + "/hess.npy")
+        x = np.concatenate([np.load(tmp + "/x_%d.npy" % r) for r in range(world)])
+        vec = np.concatenate([np.load(tmp + "/vec_%d.npy" % r) for r in range(world)])
+    A = q.csr_mat.hubbard(12, 6, 6, lattices.square(4, 3), opts=q.make_opts(value_dict=0, real_fast_path=0))
+    assert A.info().kron_inplace == 1
+    ref = q.locate_E0_lanczos(A, nev=1, ncv=1, maxit=400)
+    assert abs(res[0] - ref.E0) <= 1e-11 * abs(ref.E0)
+    assert abs(res[1] - ref.steps["E0"]) <= 1 and abs(res[2] - ref.steps["V0"]) <= 2
+    maxit = 400
+    assert np.allclose(hess[maxit:maxit + 20], ref.hessenberg_E0[maxit:maxit + 20], rtol=1e-9)
+    assert np.allclose(x, qo.vec_randomize(853776, 1), rtol=1e-13, atol=0)
+    assert abs(abs(np.vdot(vec, ref.eigenvecs)) - 1.0) < 1e-8 and abs(np.linalg.norm(vec) - 1.0) < 1e-12
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_complex_operator_from_host_arrays(world):
     import torch.multiprocessing as mp

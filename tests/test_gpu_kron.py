@@ -1,6 +1,7 @@
 """The Kronecker split of a product-basis operator (qbh_opts.kron_split): H = H_near + H_far with the far part stored
-band-major over the minor index and applied from a tiled copy of x.  Same values, same 20 B per nonzero; every result must
-equal the unsplit operator's (and the oracle's) up to summation order."""
+band-major over the minor index and applied from a tiled copy of x.  Same values, same 20 B per nonzero, re-ordered IN PLACE
+(no CSR beside it: qbh_csr_download merges the parts back); every result must equal the unsplit operator's (and the oracle's)
+up to summation order."""
 import numpy as np
 import pytest
 
@@ -33,8 +34,15 @@ def test_split_operator_equals_the_unsplit_one(shape, sliced, monkeypatch):
     ik, ip = K.info(), P.info()
     assert ik.kron_minor == ik.ncols // int(round(ik.ncols / ik.kron_minor)) > 0 and ip.kron_minor == 0
     assert ik.kron_band in (2, 4, 8) and 0 < ik.kron_far_nnz < ik.nnz and ik.nnz == ip.nnz
-    assert ik.kron_sliced == (1 if sliced == 2 and ik.kron_band == 8 else ik.kron_sliced) and (sliced or not ik.kron_sliced)
-    ia, ja, val = K.download()                                     # the handle still holds (and returns) the plain CSR
+    # rows of the narrow last band (S % 8 != 0) keep their far entries in the near part: a product operator never pads
+    assert ik.kron_sliced == (1 if sliced and ik.kron_band == 8 else 0) and ik.kron_inplace == 1
+    assert ik.bytes_matrix <= ip.bytes_matrix + 64 * ik.nrows + 65536           # no second copy of the matrix
+    ia, ja, val = K.download()                                     # the parts merged back on the device ...
+    pia, pja, pval = P.download()
+    assert np.array_equal(ia, pia) and np.array_equal(ja, pja) and np.array_equal(val.view(np.float64), pval.view(np.float64))   # ... bit for bit
+    r0, r1 = K.dim // 3, K.dim // 3 + 17                           # a row range that starts inside a band group
+    sia, sja, sval = K.download(r0, r1)
+    assert np.array_equal(sia, ia[r0:r1 + 1] - ia[r0]) and np.array_equal(sja, ja[ia[r0]:ia[r1]]) and np.array_equal(sval, val[ia[r0]:ia[r1]])
     O = qo.Csr(K.dim, ia, ja.astype(np.int64), val, False)
     x, y0 = _rand(K.dim, 1), _rand(K.dim, 2)
     want = O.multmv(x)
@@ -90,8 +98,60 @@ def test_split_is_skipped_where_it_does_not_apply():
     n = 8
     bonds = lattices.square(4, 2)
     assert q.csr_mat.hubbard(n, 4, 4, bonds).info().kron_minor == 0                                   # coded values: row kernel
-    assert q.csr_mat.hubbard(n, 4, 4, bonds, rows=(0, 2000), opts=q.make_opts(**PLAIN)).info().kron_minor == 0   # a row shard
+    assert q.csr_mat.hubbard(n, 4, 4, bonds, rows=(0, 2000), opts=q.make_opts(**PLAIN)).info().kron_minor == 0   # a row shard that cuts a major index
+    assert q.csr_mat.hubbard(n, 4, 4, bonds, opts=q.make_opts(value_dict=0)).info().kron_minor == 0             # real fast path wanted: the row kernel's real gather needs the CSR
     assert q.csr_mat.heisenberg(12, 6, lattices.chain(12), opts=q.make_opts(**PLAIN)).info().kron_minor == 0     # no product basis
+
+
+@pytest.mark.parametrize("shape,majors", [((4, 2, 4, 4), (20, 50)), ((4, 3, 6, 6), (300, 620)), ((4, 3, 5, 7), (0, 100)), ((3, 3, 4, 5), (100, 126))])
+def test_row_shard_of_whole_major_indices_is_split_in_place(shape, majors):
+    """a row shard made of whole major indices keeps the two-part form (near columns all locally owned; far columns in
+    the tiled order of the FULL x).  Driven with the full-length x and no communicator it must give the oracle's rows; downloaded
+    it must be the rows of the unsplit operator, bit for bit."""
+    lx, ly, nu, nd = shape
+    n = lx * ly
+    bonds = lattices.square(lx, ly)
+    P = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_split=0, **PLAIN))
+    ia, ja, val = P.download()
+    dim = P.dim
+    P.destroy()
+    import math
+    S = math.comb(n, nd)
+    r0, r1 = majors[0] * S, majors[1] * S
+    Sh = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1, rows=(r0, r1), opts=q.make_opts(**PLAIN))
+    info = Sh.info()
+    assert info.kron_minor == S and info.kron_inplace == 1 and info.nrows == r1 - r0 and info.ncols == dim
+    sia, sja, sval = Sh.download()
+    assert np.array_equal(sia, ia[r0:r1 + 1] - ia[r0]) and np.array_equal(sja, ja[ia[r0]:ia[r1]]) and np.array_equal(sval, val[ia[r0]:ia[r1]])
+    O = qo.Csr(dim, ia, ja.astype(np.int64), val, False)
+    x, y0 = _rand(dim, 5), _rand(r1 - r0, 6)
+    want = O.multmv(x)[r0:r1]
+    xv, yv = q.engine.DeviceVec(Sh, dim), Sh.vec()
+    xv.upload(x)
+    for alpha, beta, gamma in [(1.0, 0.0, 0.0), (0.7, -0.3, 0.25)]:
+        yv.upload(y0)
+        xy, yy = Sh.spmv(xv.ptr, yv.ptr, alpha, beta, gamma, want_red=True)
+        ref = alpha * want + beta * y0 + gamma * x[r0:r1]
+        assert np.abs(yv.download() - ref).max() <= 2e-13 * max(np.abs(want).max(), 1.0)
+        assert abs(xy - np.vdot(x[r0:r1], ref)) <= 1e-11 * max(abs(np.vdot(x[r0:r1], ref)), 1.0)
+        assert abs(yy - np.vdot(ref, ref).real) <= 1e-11 * np.vdot(ref, ref).real
+    xv.free()
+    yv.free()
+    Sh.destroy()
+
+
+def test_deterministic_option_gives_bit_identical_lanczos_coefficients():
+    """qbh_opts.deterministic: static walks, nothing timed at creation -- two solves give the same hessenberg array bit for bit
+    and the same step count (the stop rule of src/lanczos.cc:228-245 consumes exactly these scalars).  Hubbard 4x3, split."""
+    bonds = lattices.square(4, 3)
+    out = []
+    for _ in range(2):
+        K = q.csr_mat.hubbard(12, 6, 6, bonds, t=1.0, U=1.1, opts=q.make_opts(deterministic=1, **PLAIN))
+        assert K.info().kron_inplace == 1 and K.info().tuned == -1
+        r = q.locate_E0_lanczos(K, nev=1, ncv=0, maxit=400)
+        out.append((r.hessenberg_E0.copy(), r.steps["E0"], r.E0))
+        K.destroy()
+    assert out[0][1] == out[1][1] and np.array_equal(out[0][0], out[1][0]) and out[0][2] == out[1][2]
 
 
 def test_headline_operator_split_and_sliced_equals_the_matrix_free_operator_at_full_size():
@@ -130,28 +190,43 @@ def test_headline_operator_split_and_sliced_equals_the_matrix_free_operator_at_f
     K.destroy()
 
 
-def test_split_gives_its_memory_back_before_an_allocation_fails():
-    """The split is a second copy of the matrix.  At C3 size it leaves ~45 GB of the 288: a Krylov basis of 24 vectors (64 GB)
-    would not fit beside it.  Allocations that would fail release live splits first; the operator then runs on its plain CSR with
-    the same results."""
+def test_split_replaces_the_csr_no_second_copy_at_headline_size():
+    """Round 3 kept the split BESIDE the CSR (C3: ~232 of 288 GB, released under memory pressure).  It now replaces it: the
+    operator holds nnz * 20 B + row pointers + two vectors (~125 GB at C3), a 24-vector Krylov basis (64 GB) fits beside it and
+    the split stays.  The merged-back rows equal the generator's own (a second, unsplit operator made from the same rows)."""
+    import torch
     n_sites, nu, nd = 16, 8, 8
     bonds = lattices.square(4, 4)
-    K = q.csr_mat.hubbard(n_sites, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_split=2, **PLAIN))
-    assert K.info().kron_minor > 0
+    free0 = torch.cuda.mem_get_info()[0]
+    K = q.csr_mat.hubbard(n_sites, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_split=1, **PLAIN))
+    info = K.info()
+    assert info.kron_minor > 0 and info.kron_inplace == 1 and info.kron_sliced == 1
     n = K.dim
     v = K.vec(3)
     K.randomize(v.at(0), 31)
-    K.spmv(v.at(0), v.at(n))                                       # with the split
+    K.spmv(v.at(0), v.at(n))
     K.sync()
+    used = free0 - torch.cuda.mem_get_info()[0]
+    # matrix (20 B per nonzero, once) + ia, ia_n (16 B per row) + tiled x, far sums (32) + the 3 vectors (48) + descriptors and slack:
+    # ~125 GB for the operator itself (round 3: ~232 GB)
+    assert used <= info.nnz * 20 + 104 * n + (2 << 30), used
     basis = [K.vec(1) for _ in range(24)]                           # 24 x 2.65 GB
-    assert K.info().kron_minor == 0                                 # the split was released, nothing failed
-    K.spmv(v.at(0), v.at(2 * n))                                    # plain CSR
+    assert K.info().kron_minor > 0
+    K.spmv(v.at(0), v.at(2 * n))
     K.sync()
     hx = K.nrm2(v.at(n))
-    assert hx > 0 and np.sqrt(K.axpy_norm(-1.0, v.at(n), v.at(2 * n))) <= 1e-13 * hx
+    assert hx > 0 and np.sqrt(K.axpy_norm(-1.0, v.at(n), v.at(2 * n))) == 0.0     # same launches, same walk-independent sums
     for b in basis:
         b.free()
     v.free()
+    # rows of a middle major index, merged back, against an unsplit shard of the same rows
+    S = info.kron_minor
+    r0 = 6001 * S
+    P = q.csr_mat.hubbard(n_sites, nu, nd, bonds, t=1.0, U=1.1, rows=(r0, r0 + S), opts=q.make_opts(kron_split=0, **PLAIN))
+    pia, pja, pval = P.download(0, S)
+    kia, kja, kval = K.download(r0, r0 + S)
+    assert np.array_equal(kia, pia) and np.array_equal(kja, pja) and np.array_equal(kval.view(np.float64), pval.view(np.float64))
+    P.destroy()
     K.destroy()
 
 

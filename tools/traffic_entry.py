@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""HBM traffic of ONE SpMV from rocprofv3 --pmc passes (sqlite rocpd output under <root>/g*/): every kernel that is dispatched
+(about) once per SpMV -- the far / near passes of a Kronecker split, k_zero_cut_groups, k_kron_tile when it is not folded into
+the producer, k_kron_combine, or the single launch of an unsplit operator -- mean counter value per dispatch, summed.
+Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE / WRITE_SIZE are KiB, and on gfx950
+FETCH_SIZE counts wide coalesced reads at half their size: read bytes = 2 * FETCH_SIZE * 1024 (cross-checked with
+TCC_EA0_RDREQ_128B * 128 where that pass exists).  Writes the entry bench.py reads from profiles/traffic.json, stamped with
+the hash of the kernel sources it was measured on (tools/src_hash.py): bench.py reports when the sources have changed since.
+usage: traffic_entry.py <prof_root> <traffic key> <source label> <out.json>"""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import src_hash  # noqa: E402
+
+SPMV_LIKE = ("k_spmv_", "k_zero_cut_groups", "k_kron_tile", "k_kron_combine", "k_mf_")
+
+
+def main():
+    root, key, label, out = sys.argv[1:5]
+    per = {}                      # kernel -> counter -> (n, mean)
+    for db_path in sorted(glob.glob(root + "/g*/*results.db")):
+        db = sqlite3.connect(db_path)
+        q = "select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name"
+        for k, c, n, v in db.execute(q):
+            name = k.split("(")[0]
+            if any(t in name for t in SPMV_LIKE):
+                per.setdefault(name, {})[c] = (n, v)
+    if not per:
+        raise SystemExit("no SpMV kernels in " + root)
+    nmax = max(max(n for n, _ in cs.values()) for cs in per.values())
+    kernels, read, write, rd128 = {}, 0.0, 0.0, 0.0
+    for name, cs in sorted(per.items()):
+        n = max(n for n, _ in cs.values())
+        if n < 0.9 * nmax or "FETCH_SIZE" not in cs:
+            continue              # not a per-SpMV launch (e.g. the tile copy in front of a driver's first step)
+        r = 2.0 * cs["FETCH_SIZE"][1] * 1024.0
+        w = cs.get("WRITE_SIZE", (0, 0.0))[1] * 1024.0
+        kernels[name.replace("void ", "").replace("qbh::", "")] = {"dispatches": n, "read_bytes": r, "write_bytes": w,
+                                                                       "TCC_EA0_RDREQ_128B_x128": cs.get("TCC_EA0_RDREQ_128B_sum", (0, 0.0))[1] * 128.0}
+        read += r
+        write += w
+        rd128 += cs.get("TCC_EA0_RDREQ_128B_sum", (0, 0.0))[1] * 128.0
+    entry = {key: {"kernel": " + ".join(kernels), "read_bytes": read, "write_bytes": write, "hbm_bytes": read + write,
+                   "check_TCC_EA0_RDREQ_128B_x128": rd128, "per_kernel": kernels, "source": label,
+                   "kernel_sources_sha16": src_hash.kernel_sources_sha16()}}
+    json.dump(entry, open(out, "w"), indent=1)
+    print(json.dumps(entry, indent=1))
+
+
+if __name__ == "__main__":
+    main()
