@@ -424,6 +424,9 @@ def main():
     ap.add_argument("--order", default="generator", choices=["generator", "reference"],
                     help="reference: permute the generated operator ON THE DEVICE into the reference's Lin order and fermion convention "
                          "(qbh_csr_reference_order; src/basis.cc:1144-1190) before timing -- the order the unchanged host code hands over")
+    ap.add_argument("--no-basis-hint", action="store_true",
+                    help="with --order reference / --host-csr: do NOT tell the library what the reference-ordered index means (qbh_opts.basis_kind); "
+                         "default is to name the basis, so the operator is held species-major internally and the Kronecker split applies")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed run to convergence (E0)")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)
@@ -577,18 +580,22 @@ def main():
                            nnz_per_block=args.npb, xcd_swizzle=args.swizzle,
                            value_dict=value_dict, real_fast_path=real_fp, profile=1)
         t_gen = time.time()
+        hint = (not args.no_basis_hint) and W["kind"] == "hubbard" and world == 1 and value_dict == 0
         if args.host_csr:
             hd, hia, hja, hval = reference_order_host_csr(args.workload, W, q, stream)
             t_host = time.time() - t_gen
             assert hd == dim
             t_gen = time.time()
+            if hint:            # what the unchanged host code would say once (qbh_opts_set_default)
+                opts.basis_kind, opts.n_sites, opts.n_up, opts.n_dn = q._lib.BASIS_REF_FERMION2, W["n_sites"], W["n_up"], W["n_dn"]
             A = q.csr_mat(dim, hia, hja, hval, sym=True, opts=opts, rows=None if world == 1 else (r0, r1))
             ci = A.info()
             create = {"create_s": round(ci.create_ms * 1e-3, 4), "input_bytes": int(ci.create_bytes_in),
                       "create_GBps_of_input": round(ci.create_bytes_in / ci.create_ms / 1e6, 2),
                       "host_arrays_s (device generator + device permutation + download, not the product)": round(t_host, 2),
                       "entry": "qbh_csr_create" if world == 1 else "qbh_csr_create_rows", "storage": "Hermitian-upper, int64 ia/ja, complex128",
-                      "order": "reference Lin order (src/model.cc:665-670)", "nnz_upper": int(hia[-1])}
+                      "order": "reference Lin order (src/model.cc:665-670)", "nnz_upper": int(hia[-1]),
+                      "basis_hint": ("qbh_opts.basis_kind = QBH_BASIS_REF_FERMION2" if hint else None), "basis_hint_accepted": bool(ci.basis_internal)}
         elif args.order == "reference":
             if world != 1 or args.matrix_free or value_dict != 0:
                 raise SystemExit("--order reference: one GPU, stored operator, --format complex128")
@@ -596,8 +603,17 @@ def main():
             src_opts = q.make_opts(device=local_rank, stream=stream.cuda_stream, spmv_kernel=q._lib.KERNEL_ROWS, value_dict=0,
                                    real_fast_path=0, kron_split=0)
             G = build_operator(W, (r0, r1), src_opts)
+            if hint:
+                opts.kron_split = 0          # created as a plain CSR in the reference's order; the basis is declared once the source is gone
             A = G.reference_order(*_reforder_args(W), opts=opts)
             G.destroy()
+            if hint:
+                torch.cuda.synchronize()
+                t_b = time.time()
+                named = A.set_basis(q._lib.BASIS_REF_FERMION2, W["n_sites"], W["n_up"], W["n_dn"])
+                torch.cuda.synchronize()
+                create = {"basis_hint": "qbh_csr_set_basis(QBH_BASIS_REF_FERMION2, %d, %d, %d)" % (W["n_sites"], W["n_up"], W["n_dn"]),
+                          "basis_hint_accepted": bool(named), "set_basis_s": round(time.time() - t_b, 3)}
         else:
             A = build_operator(W, (r0, r1), opts, matrix_free=args.matrix_free, shard=(rank, world))
         torch.cuda.synchronize()
@@ -682,6 +698,7 @@ def main():
                                                                                if info.kron_sliced else "k_kron_tile + k_spmv_wave2<.,0> (far) + k_spmv_wave2<.,2> (near)"),
                                                          "in_place": bool(info.kron_inplace)}
                                                         if info.kron_minor else None),
+                                         "basis_internal": ("species-major (index = up * C(n, n_dn) + down), vectors translated at the seams" if info.basis_internal else None),
                                          "operator_source": "host CSR in reference order through qbh_csr_create" if args.host_csr else
                                          "device generator, permuted on the device into the reference's Lin order and fermion convention "
                                          "(qbh_csr_reference_order)" if args.order == "reference" else "device generator",

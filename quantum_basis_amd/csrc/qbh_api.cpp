@@ -1660,7 +1660,13 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
             harvest_events(A);
             QBH_HIP(hipEventRecord(A->ev0, s));
         }
-        if (K.xt_of != (const void *)x) QBH_TRY(qbh::launch_kron_tile(x, K.d_xt, A->ncols, qbh::KronTile{K.t.S, K.NUg, K.t.B}, s));
+        // QBH_KRON_REUSE_TILE=1 (measurement only, tools/shard_time.py): the caller promises that x has not changed since the
+        // previous SpMV of this handle -- what is timed is then the far + near passes of a shard without the tiled copy of the
+        // FULL x, which a rank of a multi-GPU run never makes (it tiles its own block and receives the others)
+        static const bool reuse_tile = getenv("QBH_KRON_REUSE_TILE") != nullptr;
+        if (K.xt_of != (const void *)x && !(reuse_tile && K.xt_last == (const void *)x))
+            QBH_TRY(qbh::launch_kron_tile(x, K.d_xt, A->ncols, qbh::KronTile{K.t.S, K.NUg, K.t.B}, s));
+        K.xt_last = x;
         K.xt_of = nullptr;
         xt = K.d_xt;
     }

@@ -449,6 +449,7 @@ struct qbh_csr {
         int      tpr_n = 2, tpr_f = 2, grid_n = 0, grid_f = 0;
         qbh::d2 *d_xt = nullptr, *d_far = nullptr;      // tiled copy of x (xt_cap elements, made on first use), far-part row sums (tiled order)
         int64_t  xt_cap = 0;
+        const void *xt_last = nullptr;  // measurement switch QBH_KRON_REUSE_TILE: the x of the previous SpMV
         const void *xt_of = nullptr;    // the vector whose tiled copy d_xt holds (written by the pass that produced it); consumed by one SpMV
         bool     fold = false;          // set by a driver for the duration of a solve: its BLAS-1 passes write the tiled copy of the next x
     } kron;
