@@ -579,6 +579,8 @@ def main():
         opts = q.make_opts(device=local_rank, stream=stream.cuda_stream, spmv_kernel=args.kernel,
                            nnz_per_block=args.npb, xcd_swizzle=args.swizzle,
                            value_dict=value_dict, real_fast_path=real_fp, profile=1)
+        if args.site_cut and W["kind"] == "heisenberg" and world == 1 and value_dict == 0:
+            opts.basis_kind, opts.n_sites, opts.n_up, opts.n_dn = q._lib.BASIS_SPIN_SECTOR, W["n_sites"], args.site_cut, W["n_dn"]
         t_gen = time.time()
         hint = (not args.no_basis_hint) and W["kind"] == "hubbard" and world == 1 and value_dict == 0
         if args.host_csr:
@@ -654,7 +656,7 @@ def main():
     code_w = 0 if not coded else (1 if info.value_dict <= 256 else 2)
     tkey = "%s|%s|%s" % (args.workload, KERNEL_KEY[info.kernel], "dict" if coded else "plain") + ("|real" if real_used else "")
     if info.kron_minor:
-        tkey += ("|kron_sliced" if info.kron_sliced else "|kron") + ("|inplace" if info.kron_inplace else "")
+        tkey += ("|kron_sliced" if info.kron_sliced else "|kron") + ("|inplace" if info.kron_inplace else "") + ("|cut%d" % args.site_cut if info.kron_classes > 1 else "")
     tkey += "|reforder" if args.order == "reference" else ""
     traffic, tsrc = traffic_of(tkey) if world == 1 and not args.host_csr else (None, None)
     if coded or real_used:
@@ -698,7 +700,9 @@ def main():
                                                                                if info.kron_sliced else "k_kron_tile + k_spmv_wave2<.,0> (far) + k_spmv_wave2<.,2> (near)"),
                                                          "in_place": bool(info.kron_inplace)}
                                                         if info.kron_minor else None),
-                                         "basis_internal": ("species-major (index = up * C(n, n_dn) + down), vectors translated at the seams" if info.basis_internal else None),
+                                         "basis_internal": ({1: "species-major (index = up * C(n, n_dn) + down), vectors translated at the seams",
+                                                             2: "class-major cut sector (%d low sites, %d classes, cross part %d nonzeros), vectors translated at the seams"
+                                                                % (args.site_cut, info.kron_classes, info.kron_cross_nnz)}.get(info.basis_internal)),
                                          "operator_source": "host CSR in reference order through qbh_csr_create" if args.host_csr else
                                          "device generator, permuted on the device into the reference's Lin order and fermion convention "
                                          "(qbh_csr_reference_order)" if args.order == "reference" else "device generator",

@@ -70,6 +70,11 @@ const char *qbh_last_error(void);                   /* thread-local detail of th
 /* qbh_opts.basis_kind */
 #define QBH_BASIS_NONE          0   /* an index is an index (default) */
 #define QBH_BASIS_REF_FERMION2  1   /* the reference's order of a two-species fermion basis (see qbh_opts.basis_kind) */
+#define QBH_BASIS_SPIN_SECTOR   2   /* spin-1/2 (one species), n_dn particles on n_sites sites, index = rank of the bit pattern in ascending
+                                       order (qbh_gen_heisenberg; n_up unused): the sites are cut into a low and a high half
+                                       (qbh_opts.n_up = number of low sites, 0 = n_sites / 2) and the operator is held class-major
+                                       internally -- class = particle number of the high half -- so that bonds inside a half get the
+                                       Kronecker treatment and only the bonds across the cut stay unstructured (kagome-30: 17-21 %) */
 
 typedef struct qbh_opts {
     int     device;          /* HIP ordinal; -1 = current device                                  */
@@ -176,7 +181,8 @@ typedef struct qbh_csr_info {
     int     tuned;                           /* -1: the SpMV form was not timed at creation; 0 / 1: it was, the row / wave kernel won */
     double  tune_ms_rows, tune_ms_wave;      /* the two times of that comparison (0 when not timed)                         */
     int     basis_internal;                  /* QBH_BASIS_*: != 0 when the operator is held in another order than the caller's */
-    int     pad_;
+    int     kron_classes;                    /* classes of the product structure: 1 two-species operators, > 1 a cut single-species sector */
+    int64_t kron_cross_nnz;                  /* nonzeros of the third (unstructured) part                                       */
 } qbh_csr_info;
 int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info);
 

@@ -14,7 +14,7 @@ if os.environ.get("QBHIP_LIBRARY"):      # e.g. a host-AddressSanitizer build of
 
 QBH_OK = 0
 KERNEL_AUTO, KERNEL_STREAM, KERNEL_VECTOR, KERNEL_ROWS, KERNEL_MATRIX_FREE, KERNEL_WAVE = 0, 1, 2, 3, 4, 5
-BASIS_NONE, BASIS_REF_FERMION2 = 0, 1
+BASIS_NONE, BASIS_REF_FERMION2, BASIS_SPIN_SECTOR = 0, 1, 2
 
 
 class QbhError(RuntimeError):
@@ -44,7 +44,7 @@ class CsrInfo(C.Structure):
                 ("device", C.c_int), ("stream", C.c_void_p), ("create_ms", C.c_double),
                 ("create_bytes_in", C.c_int64), ("kron_minor", C.c_int64), ("kron_far_nnz", C.c_int64), ("kron_band", C.c_int), ("kron_sliced", C.c_int),
                 ("kron_inplace", C.c_int), ("tuned", C.c_int), ("tune_ms_rows", C.c_double), ("tune_ms_wave", C.c_double),
-                ("basis_internal", C.c_int), ("pad_", C.c_int)]
+                ("basis_internal", C.c_int), ("kron_classes", C.c_int), ("kron_cross_nnz", C.c_int64)]
 
 
 class LanczosRow(C.Structure):

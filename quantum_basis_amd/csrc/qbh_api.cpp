@@ -335,7 +335,8 @@ namespace {
 void kron_free_aux(qbh_csr *A)
 {
     qbh_csr::KronSplit &K = A->kron;
-    for (void *q : {(void *)K.ia_n, (void *)K.ia_f, (void *)K.wd_n, (void *)K.wd_f, (void *)K.d_xt, (void *)K.d_far})
+    for (void *q : {(void *)K.ia_n, (void *)K.ia_f, (void *)K.wd_n, (void *)K.wd_f, (void *)K.d_xt, (void *)K.d_far, (void *)K.ia_x, (void *)K.xrow,
+                    (void *)K.wd_x, (void *)K.d_cls})
         if (q) (void)hipFree(q);
     if (K.own_far) {
         if (K.ja_f) (void)hipFree(K.ja_f);
@@ -355,11 +356,12 @@ qbh::KronParts kron_parts(const qbh_csr *A)
     p.ja_f = K.ja_f;
     p.val_n = K.val_n;
     p.val_f = K.val_f;
-    p.t = K.t;
-    p.U0 = K.U0;
-    p.cols = K.cols;
-    p.sliced = K.sliced ? 1 : 0;
-    p.nfar_rows = K.sliced ? K.n_groups * 8 : A->nrows;
+    p.ia_x = K.ia_x;
+    p.xrow = K.xrow;
+    p.n_xrows = K.n_xrows;
+    p.ja_x = K.ja_x;
+    p.val_x = K.val_x;
+    p.map = K.map;
     return p;
 }
 
@@ -374,97 +376,136 @@ qbh::KronCols kron_cols_one(int64_t S, int64_t NUg, int B)
     return c;
 }
 
-// wave-block geometry of the two parts (pipelined kernel); callable again after the parts moved
-int kron_geometry(qbh_csr *A)
+int wave_geometry_for(qbh_csr *A, const int64_t *ia, int64_t nr, int64_t nnz, double avg, bool slots, int ops, qbh::WaveDesc **wd_io, int64_t *nwb_o,
+                      int *tpr_o, int *grid_o)
 {
-    qbh_csr::KronSplit &K = A->kron;
     hipStream_t s = A->stream;
-    const int64_t n = A->nrows;
-    for (int part = 0; part < 2; ++part) {
-        const bool sl = part && K.sliced;                    // sliced far part: blocks of 512 slots, ia_f = group pointers
-        const int64_t *ia = part ? K.ia_f : K.ia_n;
-        const int64_t nnz = part ? K.far_slots : K.nnz_n;
-        const int64_t nr = sl ? K.n_groups : n;
-        QBH_TRY(qbh::launch_max_rowlen(ia, nr, (int64_t *)A->d_scal, s));
-        int64_t maxlen = 0;
-        QBH_HIP(hipMemcpyAsync(&maxlen, A->d_scal, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        QBH_HIP(hipStreamSynchronize(s));
-        const int64_t window = sl ? 512 : (maxlen <= 256) ? 505 - (maxlen > 0 ? maxlen - 1 : 0) : 249;
-        const int64_t n_wb = std::max<int64_t>(1, (nnz + window - 1) / window);
-        qbh::WaveDesc *&wd = part ? K.wd_f : K.wd_n;
-        if (wd) (void)hipFree(wd);
-        wd = nullptr;
-        QBH_HIP(hipMalloc(&wd, (size_t)(n_wb + 2) * sizeof(qbh::WaveDesc)));
-        if (sl) QBH_TRY(qbh::launch_build_slotdesc(ia, nr, nnz, wd, n_wb, s));
-        else    QBH_TRY(qbh::launch_build_wavedesc(ia, nr, window, wd, n_wb, s));
-        const double avg = (double)(part ? K.nnz_f : K.nnz_n) / (double)n;
-        const int tpr = avg <= 32 ? 2 : avg <= 64 ? 4 : 8;
-        int ncu = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, A->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-        const int occ = std::max(1, qbh::wave2_kernel_occupancy(tpr, part ? (sl ? 3 : 0) : 2));
-        int64_t g = std::min<int64_t>((int64_t)occ * ncu, ((((n_wb + 3) >> 2) + 7) / 8) * 8);
-        g = std::max<int64_t>(8, (g / 8) * 8);
-        (part ? K.nwb_f : K.nwb_n) = n_wb;
-        (part ? K.tpr_f : K.tpr_n) = tpr;
-        (part ? K.grid_f : K.grid_n) = (int)g;
-    }
+    QBH_TRY(qbh::launch_max_rowlen(ia, nr, (int64_t *)A->d_scal, s));
+    int64_t maxlen = 0;
+    QBH_HIP(hipMemcpyAsync(&maxlen, A->d_scal, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     QBH_HIP(hipStreamSynchronize(s));
+    const int64_t window = slots ? 512 : (maxlen <= 256) ? 505 - (maxlen > 0 ? maxlen - 1 : 0) : 249;
+    const int64_t n_wb = std::max<int64_t>(1, (nnz + window - 1) / window);
+    if (*wd_io) (void)hipFree(*wd_io);
+    *wd_io = nullptr;
+    QBH_HIP(hipMalloc(wd_io, (size_t)(n_wb + 2) * sizeof(qbh::WaveDesc)));
+    if (slots) QBH_TRY(qbh::launch_build_slotdesc(ia, nr, nnz, *wd_io, n_wb, s));
+    else       QBH_TRY(qbh::launch_build_wavedesc(ia, nr, window, *wd_io, n_wb, s));
+    const int tpr = avg <= 32 ? 2 : avg <= 64 ? 4 : 8;
+    int ncu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, A->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    const int occ = std::max(1, ops >= 0 ? qbh::wave2_kernel_occupancy(tpr, ops) : qbh::wave_kernel_occupancy(tpr));
+    int64_t g = std::min<int64_t>((int64_t)occ * ncu, ((((n_wb + 3) >> 2) + 7) / 8) * 8);
+    g = std::max<int64_t>(8, (g / 8) * 8);
+    *nwb_o = n_wb;
+    *tpr_o = tpr;
+    *grid_o = (int)g;
     return QBH_OK;
 }
 
-// H = H_near + H_far for an operator on a product basis (index = major * S + minor) whose entries change either the
-// minor index (near: inside the row's own block of S columns, an L2-sized window of x) or the major index alone (far:
-// same minor index).  The far part is what makes a row-major sweep re-read x: every major index pulls in the x rows of
-// all its neighbours (C3: 17 x 2.65 GB per SpMV).  Stored band-major over the minor index -- rows and columns in the
-// tiled order of KronTile -- a band of 8 minor indices needs ONE 128-byte line per major index, and 8 consecutive far
-// rows share every line they gather.  Per SpMV: x -> tiled copy (or written by the pass that produced x), far pass (row sums,
-// tiled order), near pass (+ far result, fused epilogue).
-// Round 4: the split REPLACES the CSR -- the handle's own d_ja / d_val are re-ordered in place into [near | far] (same
-// values, same columns, same 20 B per nonzero; peak during the conversion = the CSR + one copy of the far part), row shards
-// made of whole major indices split the same way, and qbh_csr_download / kron_restore merge the parts back.  The choice is
-// STRUCTURAL (verified on the device, never assumed, never timed): results do not depend on the box.
+// wave-block geometry of the parts (pipelined kernel; the dense cross part of a several-class operator: the plain wave kernel)
+int kron_geometry(qbh_csr *A)
+{
+    qbh_csr::KronSplit &K = A->kron;
+    const int64_t n = A->nrows;
+    QBH_TRY(wave_geometry_for(A, K.ia_n, n, K.nnz_n, (double)K.nnz_n / (double)n, false, K.map.nc > 1 ? 4 : 2, &K.wd_n, &K.nwb_n, &K.tpr_n, &K.grid_n));
+    QBH_TRY(wave_geometry_for(A, K.ia_f, K.sliced ? K.n_groups : K.map.nfar_rows(), K.far_slots, (double)K.nnz_f / (double)n, K.sliced, K.sliced ? 3 : 0,
+                              &K.wd_f, &K.nwb_f, &K.tpr_f, &K.grid_f));
+    if (K.map.nc > 1) {
+        std::vector<qbh::KronCls> hc((size_t)K.map.nc + 1);
+        for (int c = 0; c <= K.map.nc; ++c)
+            hc[(size_t)c] = qbh::KronCls{K.map.rbase[c], c < K.map.nc ? K.map.S[c] : 1, c < K.map.nc ? K.map.NU[c] : 0, K.map.fbase[c]};
+        if (!K.d_cls) QBH_HIP(hipMalloc(&K.d_cls, hc.size() * sizeof(qbh::KronCls)));
+        QBH_HIP(hipMemcpy(K.d_cls, hc.data(), hc.size() * sizeof(qbh::KronCls), hipMemcpyHostToDevice));
+        QBH_TRY(qbh::launch_kron_desc_classes(K.wd_n, K.nwb_n, K.d_cls, K.map.nc, A->stream));
+        if (K.nnz_x > 0)
+            QBH_TRY(wave_geometry_for(A, K.ia_x, n, K.nnz_x, (double)K.nnz_x / (double)n, false, -1, &K.wd_x, &K.nwb_x, &K.tpr_x, &K.grid_x));
+    }
+    QBH_HIP(hipStreamSynchronize(A->stream));
+    return QBH_OK;
+}
+
+// H = H_near + H_far (+ H_cross) for an operator whose rows have a product structure (KronMap): index = major * S + minor with
+// every entry changing either the minor index (near: inside the row's own block of S columns, an L2-sized window of x) or the
+// major index alone (far: same minor index).  The far part is what makes a row-major sweep re-read x: every major index pulls in
+// the x rows of all its neighbours (C3: 17 x 2.65 GB per SpMV).  Stored band-major over the minor index -- rows and columns in
+// the tiled order of KronTile -- a band of 8 minor indices needs ONE 128-byte line per major index, and 8 consecutive far rows
+// share every line they gather.  Per SpMV: x -> tiled copy (or written by the pass that produced x), far pass (row sums, tiled
+// order), near pass (+ far result, fused epilogue).
+// Round 4: the split REPLACES the CSR -- the handle's own d_ja / d_val are re-ordered in place into [near | far | cross] (same
+// values, same columns, same 20 B per nonzero; peak during the conversion = the CSR + one copy of the far and cross parts), row
+// shards made of whole major indices split the same way, and qbh_csr_download / kron_restore merge the parts back.  The choice
+// is STRUCTURAL (verified on the device, never assumed, never timed): results do not depend on the box.  kron_split = 1 leaves
+// operators below 1e8 nonzeros alone (three launches cost more than they save there); 2 splits whatever has the structure.
 int kron_build(qbh_csr *A)
 {
     if (A->kron.active) return QBH_OK;
     if (!A->use_wave || A->kind != 0 || A->has_rem || A->nnz <= 0 || !A->own_arrays || !A->d_val || A->kron_off) return QBH_OK;
     if (A->opts.kron_split == 0 || (A->debug & 1)) return QBH_OK;
+    if (A->opts.kron_split == 1 && A->nnz < 100000000) return QBH_OK;
     if (A->opts.real_fast_path && A->values_real) return QBH_OK;      // the real-gather form of the row kernel needs the CSR
     if (const char *e = getenv("QBH_NO_KRON")) {
         if (atoi(e)) return QBH_OK;
     }
-    const int64_t S = A->opts.kron_minor;
-    if (S <= 1 || S >= A->ncols || A->ncols % S != 0 || A->nrows % S != 0 || A->row_offset % S != 0) return QBH_OK;
-    const int64_t NU = A->nrows / S, NUg = A->ncols / S, U0 = A->row_offset / S;
     const int64_t n = A->nrows;
     hipStream_t s = A->stream;
-    // the structure is verified, never assumed: one entry that changes both indices and the operator stays unsplit
-    QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
-    QBH_TRY(qbh::launch_kron_check2(A->d_ia, A->d_ja, n, S, U0, A->d_flag, s));
-    int bad = 0;
-    QBH_HIP(hipMemcpyAsync(&bad, A->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
-    QBH_HIP(hipStreamSynchronize(s));
-    QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
-    if (bad) return QBH_OK;
     qbh_csr::KronSplit &K = A->kron;
-    int B = 8;                                       // one 128-byte line of complex128 per (band, major index)
-    while (B > 2 && (double)NUg * B * 16 > 2.5e6) B >>= 1;             // keep a band of x inside an XCD's L2
-    if (const char *e = getenv("QBH_KRON_BAND")) {
-        const int b = atoi(e);
-        if (b == 2 || b == 4 || b == 8 || b == 16) B = b;
+    const bool multi = A->basis.kind == QBH_BASIS_SPIN_SECTOR && A->basis.classes.nc > 1;
+    if (multi) {
+        if (A->nrows != A->ncols || A->row_offset != 0) return QBH_OK;
+        K.map = A->basis.classes;
+        K.map.sliced = 1;
+        K.t = qbh::KronTile{K.map.S[0], K.map.NU[0], 8};
+        K.U0 = 0;
+        K.NUg = 0;
+        K.cols = kron_cols_one(1, n, 8);
+    } else {
+        const int64_t S = A->opts.kron_minor;
+        if (S <= 1 || S >= A->ncols || A->ncols % S != 0 || A->nrows % S != 0 || A->row_offset % S != 0) return QBH_OK;
+        const int64_t NU = A->nrows / S, NUg = A->ncols / S, U0 = A->row_offset / S;
+        // the structure is verified, never assumed: one entry that changes both indices and the operator stays unsplit
+        QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
+        QBH_TRY(qbh::launch_kron_check2(A->d_ia, A->d_ja, n, S, U0, A->d_flag, s));
+        int bad = 0;
+        QBH_HIP(hipMemcpyAsync(&bad, A->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+        QBH_HIP(hipStreamSynchronize(s));
+        QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
+        if (bad) return QBH_OK;
+        int B = 8;                                       // one 128-byte line of complex128 per (band, major index)
+        while (B > 2 && (double)NUg * B * 16 > 2.5e6) B >>= 1;             // keep a band of x inside an XCD's L2
+        if (const char *e = getenv("QBH_KRON_BAND")) {
+            const int b = atoi(e);
+            if (b == 2 || b == 4 || b == 8 || b == 16) B = b;
+        }
+        K.t = qbh::KronTile{S, NU, B};
+        K.U0 = U0;
+        K.NUg = NUg;
+        K.cols = kron_cols_one(S, NUg, B);
+        qbh::KronMap m{};
+        m.nc = 1;
+        m.B = B;
+        m.U0 = U0;
+        m.rbase[0] = 0;
+        m.rbase[1] = n;
+        m.S[0] = S;
+        m.NU[0] = NU;
+        m.fbase[0] = 0;
+        m.fbase[1] = (S / B) * B * NU;
+        m.cols = K.cols;
+        int want_sliced = 1;                             // QBH_KRON_SLICED: 0 never, 1 when the padding is small, 2 whenever a group fits
+        if (const char *e = getenv("QBH_KRON_SLICED")) want_sliced = atoi(e);
+        m.sliced = (want_sliced && B == 8 && S >= 8) ? 1 : 0;
+        K.map = m;
     }
-    K.t = qbh::KronTile{S, NU, B};
-    K.U0 = U0;
-    K.NUg = NUg;
-    K.cols = kron_cols_one(S, NUg, B);
-    int32_t *cn = nullptr, *cf = nullptr, *tmp_c = nullptr;
-    d2 *tmp_v = nullptr;
+    int32_t *cn = nullptr, *cf = nullptr, *cx = nullptr, *tmp_c = nullptr, *tmpx_c = nullptr;
+    d2 *tmp_v = nullptr, *tmpx_v = nullptr;
     void *chunk = nullptr;
     int32_t *d_rb = nullptr;
     int64_t *d_bp = nullptr;
     bool destructive = false;                        // the CSR is being re-ordered: a failure from here on is an error
     auto fail = [&](int code) {
-        for (void *q : {(void *)cn, (void *)cf, (void *)tmp_c, (void *)tmp_v, chunk, (void *)d_rb, (void *)d_bp})
+        for (void *q : {(void *)cn, (void *)cf, (void *)cx, (void *)tmp_c, (void *)tmp_v, (void *)tmpx_c, (void *)tmpx_v, chunk, (void *)d_rb, (void *)d_bp})
             if (q) (void)hipFree(q);
         K.own_far = false;                           // tmp_c / tmp_v freed above
         K.ja_f = nullptr;
@@ -490,35 +531,34 @@ int kron_build(qbh_csr *A)
         const int rc_ = (expr);                \
         if (rc_ != QBH_OK) return fail(rc_);   \
     } while (0)
+    // ---- how many entries of every row go where ----
+    int64_t nfr = K.map.nfar_rows();
     KRON_HIP(hipMalloc(&cn, (size_t)n * sizeof(int32_t)));
-    KRON_HIP(hipMalloc(&cf, (size_t)n * sizeof(int32_t)));
-    KRON_TRY(qbh::launch_kron_count2(A->d_ia, A->d_ja, n, K.t, U0, cn, cf, s));
+    KRON_HIP(hipMalloc(&cf, (size_t)std::max<int64_t>(nfr, n) * sizeof(int32_t)));
+    KRON_HIP(hipMalloc(&cx, (size_t)n * sizeof(int32_t)));
+    KRON_HIP(hipMemsetAsync(cf, 0, (size_t)std::max<int64_t>(nfr, n) * sizeof(int32_t), s));
+    KRON_TRY(qbh::launch_kron_count3(A->d_ia, A->d_ja, n, K.map, cn, cf, cx, s));
     KRON_HIP(hipMalloc(&K.ia_n, (size_t)(n + 1) * sizeof(int64_t)));
-    KRON_HIP(hipMalloc(&K.ia_f, (size_t)(n + 1) * sizeof(int64_t)));
     KRON_TRY(qbh::exclusive_scan(cn, n, K.ia_n, s));
-    KRON_TRY(qbh::exclusive_scan(cf, n, K.ia_f, s));
     KRON_HIP(hipMemcpy(&K.nnz_n, K.ia_n + n, sizeof(int64_t), hipMemcpyDeviceToHost));
-    KRON_HIP(hipMemcpy(&K.nnz_f, K.ia_f + n, sizeof(int64_t), hipMemcpyDeviceToHost));
-    if (K.nnz_f == 0 || K.nnz_n + K.nnz_f != A->nnz) return fail(QBH_OK);       // nothing far: the split buys nothing
-    // Sliced far part: the 8 far rows of a (band, major index) pair hold the SAME major-index moves in the same order, so
-    // interleaving them entry by entry makes every 8 consecutive stream elements one 128-byte line of the tiled x.  Groups
-    // are padded to their longest row (none for a product operator); kept while the padding stays under 1/8 of the far
-    // entries and a group fits the wave tile.
+    // far part: sliced (groups of 8 far rows, entries interleaved: every 8 consecutive stream elements are one 128-byte line of
+    // the tiled x; groups padded to their longest row -- none for a product operator) while the padding stays under 1/8 of the
+    // far entries and a group fits the wave tile; else plain rows in tiled order
     K.sliced = false;
-    // groups of 8 far rows cover the FULL bands only (with B = 8 each group is one (band, major index) pair); the rows of the
-    // narrow last band hold no far entries, are never written by the far pass and keep the zero d_far was created with
-    K.n_groups = B == 8 ? (S / 8) * NU : (n + 7) / 8;
-    K.far_slots = K.nnz_f;
-    int want_sliced = 1;                             // QBH_KRON_SLICED: 0 never, 1 when the padding is small, 2 whenever a group fits
-    if (const char *e = getenv("QBH_KRON_SLICED")) want_sliced = atoi(e);
-    if (want_sliced && B == 8) {
+    K.n_groups = nfr / 8;
+    if (K.map.sliced) {
         int32_t *gw = nullptr;
         int64_t *gia = nullptr;
-        KRON_HIP(hipMalloc(&gw, (size_t)K.n_groups * sizeof(int32_t)));
-        int rc = qbh::launch_kron_group_width(cf, n, K.n_groups, gw, s);
+        KRON_HIP(hipMalloc(&gw, (size_t)std::max<int64_t>(K.n_groups, 1) * sizeof(int32_t)));
+        int rc = qbh::launch_kron_group_width(cf, nfr, K.n_groups, gw, s);
         hipError_t he = rc == QBH_OK ? hipMalloc(&gia, (size_t)(K.n_groups + 1) * sizeof(int64_t)) : hipSuccess;
         if (rc == QBH_OK && he == hipSuccess) rc = qbh::exclusive_scan(gw, K.n_groups, gia, s);
-        int64_t slots = 0, maxgw = 0;
+        int64_t slots = 0, maxgw = 0, far_true = 0;
+        int64_t *tmp_scan = nullptr;
+        if (rc == QBH_OK && he == hipSuccess) he = hipMalloc(&tmp_scan, (size_t)(nfr + 1) * sizeof(int64_t));
+        if (rc == QBH_OK && he == hipSuccess) rc = qbh::exclusive_scan(cf, nfr, tmp_scan, s);
+        if (rc == QBH_OK && he == hipSuccess) he = hipMemcpy(&far_true, tmp_scan + nfr, sizeof(int64_t), hipMemcpyDeviceToHost);
+        if (tmp_scan) (void)hipFree(tmp_scan);
         if (rc == QBH_OK && he == hipSuccess) he = hipMemcpy(&slots, gia + K.n_groups, sizeof(int64_t), hipMemcpyDeviceToHost);
         if (rc == QBH_OK && he == hipSuccess) rc = qbh::launch_max_rowlen(gia, K.n_groups, (int64_t *)A->d_scal, s);
         if (rc == QBH_OK && he == hipSuccess) he = hipMemcpyAsync(&maxgw, A->d_scal, sizeof(int64_t), hipMemcpyDeviceToHost, s);
@@ -529,19 +569,67 @@ int kron_build(qbh_csr *A)
             (void)hipGetLastError();
             return fail(rc != QBH_OK ? rc : he == hipErrorOutOfMemory ? QBH_OK : QBH_EHIP);
         }
-        if ((want_sliced == 2 || slots - K.nnz_f <= K.nnz_f / 8) && maxgw <= 504 && slots < ((int64_t)1 << 40)) {
-            (void)hipFree(K.ia_f);
+        int want_sliced = 1;
+        if (const char *e = getenv("QBH_KRON_SLICED")) want_sliced = atoi(e);
+        K.nnz_f = far_true;
+        if ((want_sliced == 2 || multi || slots - far_true <= far_true / 8) && maxgw <= 504 && slots < ((int64_t)1 << 40) && K.n_groups > 0) {
             K.ia_f = gia;
             K.sliced = true;
             K.far_slots = slots;
         } else {
             (void)hipFree(gia);
+            if (multi) return fail(QBH_OK);           // several classes need the compact far rows of the sliced form
+            K.map.sliced = 0;                         // plain rows in tiled order: every row has a far row id again
+            K.map.fbase[1] = n;
+            nfr = n;
+            KRON_HIP(hipMemsetAsync(cf, 0, (size_t)n * sizeof(int32_t), s));
+            KRON_TRY(qbh::launch_kron_count3(A->d_ia, A->d_ja, n, K.map, cn, cf, cx, s));
         }
     }
-    (void)hipFree(cn);
-    cn = nullptr;
-    (void)hipFree(cf);
-    cf = nullptr;
+    if (!K.sliced) {
+        KRON_HIP(hipMalloc(&K.ia_f, (size_t)(nfr + 1) * sizeof(int64_t)));
+        KRON_TRY(qbh::exclusive_scan(cf, nfr, K.ia_f, s));
+        KRON_HIP(hipMemcpy(&K.nnz_f, K.ia_f + nfr, sizeof(int64_t), hipMemcpyDeviceToHost));
+        K.far_slots = K.nnz_f;
+        K.n_groups = (nfr + 7) / 8;
+    }
+    // cross part: a compact list of the few rows that have one (one class), or row pointers over all rows (several classes)
+    K.n_xrows = 0;
+    if (multi) {
+        KRON_HIP(hipMalloc(&K.ia_x, (size_t)(n + 1) * sizeof(int64_t)));
+        KRON_TRY(qbh::exclusive_scan(cx, n, K.ia_x, s));
+        KRON_HIP(hipMemcpy(&K.nnz_x, K.ia_x + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+        K.n_xrows = K.nnz_x > 0 ? n : 0;
+    } else {
+        int32_t *fl = nullptr, *cc = nullptr;
+        int64_t *pos = nullptr;
+        KRON_HIP(hipMalloc(&fl, (size_t)n * sizeof(int32_t)));
+        hipError_t he = hipMalloc(&pos, (size_t)(n + 1) * sizeof(int64_t));
+        int rc = he == hipSuccess ? qbh::launch_kron_flags(cx, n, fl, s) : QBH_OK;
+        if (rc == QBH_OK && he == hipSuccess) rc = qbh::exclusive_scan(fl, n, pos, s);
+        if (rc == QBH_OK && he == hipSuccess) he = hipMemcpy(&K.n_xrows, pos + n, sizeof(int64_t), hipMemcpyDeviceToHost);
+        if (rc == QBH_OK && he == hipSuccess && K.n_xrows > 0) {
+            he = hipMalloc(&K.xrow, (size_t)K.n_xrows * sizeof(int32_t));
+            if (he == hipSuccess) he = hipMalloc(&cc, (size_t)K.n_xrows * sizeof(int32_t));
+            if (he == hipSuccess) he = hipMalloc(&K.ia_x, (size_t)(K.n_xrows + 1) * sizeof(int64_t));
+            if (he == hipSuccess) rc = qbh::launch_kron_xrows(cx, n, pos, K.xrow, cc, s);
+            if (rc == QBH_OK && he == hipSuccess) rc = qbh::exclusive_scan(cc, K.n_xrows, K.ia_x, s);
+            if (rc == QBH_OK && he == hipSuccess) he = hipMemcpy(&K.nnz_x, K.ia_x + K.n_xrows, sizeof(int64_t), hipMemcpyDeviceToHost);
+        }
+        (void)hipFree(fl);
+        if (pos) (void)hipFree(pos);
+        if (cc) (void)hipFree(cc);
+        if (rc != QBH_OK || he != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(rc != QBH_OK ? rc : he == hipErrorOutOfMemory ? QBH_OK : QBH_EHIP);
+        }
+    }
+    for (int32_t **q : {&cn, &cf, &cx}) {
+        (void)hipFree(*q);
+        *q = nullptr;
+    }
+    if (K.nnz_f == 0 || K.nnz_n + K.nnz_f + K.nnz_x != A->nnz) return fail(QBH_OK);       // nothing far: the split buys nothing
+    if (multi && (double)K.nnz_x > 0.4 * (double)A->nnz) return fail(QBH_OK);               // mostly unstructured: not worth three passes
     // ---- everything the conversion needs is allocated BEFORE the CSR is touched ----
     KRON_TRY(qbh::launch_max_rowlen(A->d_ia, n, (int64_t *)A->d_scal, s));
     int64_t maxlen = 0;
@@ -551,11 +639,16 @@ int kron_build(qbh_csr *A)
     const int64_t n_chunks = (A->nnz + cw - 1) / cw;
     KRON_HIP(hipMalloc(&tmp_v, (size_t)K.far_slots * sizeof(d2)));
     KRON_HIP(hipMalloc(&tmp_c, (size_t)K.far_slots * sizeof(int32_t)));
+    if (K.nnz_x > 0) {
+        KRON_HIP(hipMalloc(&tmpx_v, (size_t)K.nnz_x * sizeof(d2)));
+        KRON_HIP(hipMalloc(&tmpx_c, (size_t)K.nnz_x * sizeof(int32_t)));
+    }
     KRON_HIP(hipMalloc(&chunk, (size_t)(cw + maxlen) * sizeof(d2)));
     KRON_HIP(hipMalloc(&d_rb, (size_t)(n_chunks + 1) * sizeof(int32_t)));
     KRON_HIP(hipMalloc(&d_bp, (size_t)(n_chunks + 1) * sizeof(int64_t)));
-    KRON_HIP(hipMalloc(&K.d_far, (size_t)n * sizeof(d2)));
-    KRON_HIP(hipMemsetAsync(K.d_far, 0, (size_t)n * sizeof(d2), s));
+    const int64_t far_len = multi ? K.map.nfar_rows() + 8 : n;          // one class: the slots of the narrow-band rows take the cross sums
+    KRON_HIP(hipMalloc(&K.d_far, (size_t)far_len * sizeof(d2)));
+    KRON_HIP(hipMemsetAsync(K.d_far, 0, (size_t)far_len * sizeof(d2), s));
     KRON_TRY(qbh::launch_build_rowblocks(A->d_ia, n, cw, d_rb, d_bp, n_chunks, s));
     std::vector<int32_t> rb((size_t)n_chunks + 1);
     KRON_HIP(hipMemcpyAsync(rb.data(), d_rb, rb.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -563,9 +656,14 @@ int kron_build(qbh_csr *A)
     std::vector<int64_t> nb((size_t)n_chunks + 1);            // near entries in front of each step's first row
     for (int64_t c = 0; c <= n_chunks; ++c) KRON_HIP(hipMemcpyAsync(&nb[(size_t)c], K.ia_n + rb[(size_t)c], sizeof(int64_t), hipMemcpyDeviceToHost, s));
     KRON_HIP(hipStreamSynchronize(s));
-    // far part out of the intact CSR (values, then columns in the tiled order of the gathered x)
-    KRON_TRY(qbh::launch_kron_far_fill(false, K.sliced, A->d_ia, A->d_ja, A->d_val, n, K.t, U0, K.cols, K.ia_f, K.n_groups, nullptr, tmp_v, s));
-    KRON_TRY(qbh::launch_kron_far_fill(true, K.sliced, A->d_ia, A->d_ja, A->d_val, n, K.t, U0, K.cols, K.ia_f, K.n_groups, tmp_c, nullptr, s));
+    // far and cross parts out of the intact CSR (values, then columns in the tiled order of the gathered x)
+    KRON_TRY(qbh::launch_kron_far_fill(false, A->d_ia, A->d_ja, A->d_val, K.map, K.ia_f, K.n_groups, nullptr, tmp_v, s));
+    KRON_TRY(qbh::launch_kron_far_fill(true, A->d_ia, A->d_ja, A->d_val, K.map, K.ia_f, K.n_groups, tmp_c, nullptr, s));
+    if (K.nnz_x > 0) {
+        const int64_t nx = multi ? n : K.n_xrows;
+        KRON_TRY(qbh::launch_kron_part_gather_vals(2, A->d_ia, A->d_ja, A->d_val, 0, nx, K.map, K.ia_x, K.xrow, tmpx_v, s));
+        KRON_TRY(qbh::launch_kron_part_gather_cols(2, A->d_ia, A->d_ja, 0, nx, K.map, K.ia_x, K.xrow, tmpx_c, s));
+    }
     KRON_HIP(hipStreamSynchronize(s));
     // near part compacted towards the front of the arrays, step by step through the staging buffer (a step's destination
     // never reaches the source of a later step: near entries in front of a row <= all entries in front of it); the values
@@ -574,26 +672,28 @@ int kron_build(qbh_csr *A)
     for (int64_t c = 0; c < n_chunks; ++c) {
         const int64_t r0 = rb[(size_t)c], r1 = rb[(size_t)c + 1], cnt = nb[(size_t)c + 1] - nb[(size_t)c];
         if (r1 <= r0 || cnt <= 0) continue;
-        KRON_TRY(qbh::launch_kron_near_gather_vals(A->d_ia, A->d_ja, A->d_val, r0, r1, K.t, U0, K.ia_n, (d2 *)chunk, s));
+        KRON_TRY(qbh::launch_kron_part_gather_vals(0, A->d_ia, A->d_ja, A->d_val, r0, r1, K.map, K.ia_n, nullptr, (d2 *)chunk, s));
         KRON_HIP(hipMemcpyAsync(A->d_val + nb[(size_t)c], chunk, (size_t)cnt * sizeof(d2), hipMemcpyDeviceToDevice, s));
     }
     for (int64_t c = 0; c < n_chunks; ++c) {
         const int64_t r0 = rb[(size_t)c], r1 = rb[(size_t)c + 1], cnt = nb[(size_t)c + 1] - nb[(size_t)c];
         if (r1 <= r0 || cnt <= 0) continue;
-        KRON_TRY(qbh::launch_kron_near_gather_cols(A->d_ia, A->d_ja, r0, r1, K.t, U0, K.ia_n, (int32_t *)chunk, s));
+        KRON_TRY(qbh::launch_kron_part_gather_cols(0, A->d_ia, A->d_ja, r0, r1, K.map, K.ia_n, nullptr, (int32_t *)chunk, s));
         KRON_HIP(hipMemcpyAsync(A->d_ja + nb[(size_t)c], chunk, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     }
     K.ja_n = A->d_ja;
     K.val_n = A->d_val;
-    if (K.nnz_n + K.far_slots <= A->nnz) {           // no padding: the far part takes the space the far entries left
-        KRON_HIP(hipMemcpyAsync(A->d_val + K.nnz_n, tmp_v, (size_t)K.far_slots * sizeof(d2), hipMemcpyDeviceToDevice, s));
-        KRON_HIP(hipMemcpyAsync(A->d_ja + K.nnz_n, tmp_c, (size_t)K.far_slots * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    int64_t tail = K.nnz_n;
+    if (K.nnz_n + K.far_slots + K.nnz_x <= A->nnz) {    // no padding: the far part takes the space the far entries left
+        KRON_HIP(hipMemcpyAsync(A->d_val + tail, tmp_v, (size_t)K.far_slots * sizeof(d2), hipMemcpyDeviceToDevice, s));
+        KRON_HIP(hipMemcpyAsync(A->d_ja + tail, tmp_c, (size_t)K.far_slots * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
         KRON_HIP(hipStreamSynchronize(s));
         (void)hipFree(tmp_v);
         (void)hipFree(tmp_c);
-        K.ja_f = A->d_ja + K.nnz_n;
-        K.val_f = A->d_val + K.nnz_n;
+        K.ja_f = A->d_ja + tail;
+        K.val_f = A->d_val + tail;
         K.own_far = false;
+        tail += K.far_slots;
     } else {                                         // padded groups: the far part keeps its own (larger) arrays
         K.ja_f = tmp_c;
         K.val_f = tmp_v;
@@ -601,13 +701,22 @@ int kron_build(qbh_csr *A)
     }
     tmp_v = nullptr;
     tmp_c = nullptr;
+    if (K.nnz_x > 0) {                               // the cross part behind it (it always fits: its entries came out of these arrays)
+        KRON_HIP(hipMemcpyAsync(A->d_val + tail, tmpx_v, (size_t)K.nnz_x * sizeof(d2), hipMemcpyDeviceToDevice, s));
+        KRON_HIP(hipMemcpyAsync(A->d_ja + tail, tmpx_c, (size_t)K.nnz_x * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        KRON_HIP(hipStreamSynchronize(s));
+        K.ja_x = A->d_ja + tail;
+        K.val_x = A->d_val + tail;
+        (void)hipFree(tmpx_v);
+        (void)hipFree(tmpx_c);
+        tmpx_v = nullptr;
+        tmpx_c = nullptr;
+    }
     KRON_HIP(hipStreamSynchronize(s));
-    (void)hipFree(chunk);
-    chunk = nullptr;
-    (void)hipFree(d_rb);
-    d_rb = nullptr;
-    (void)hipFree(d_bp);
-    d_bp = nullptr;
+    for (void **q : {&chunk, (void **)&d_rb, (void **)&d_bp}) {
+        (void)hipFree(*q);
+        *q = nullptr;
+    }
     K.inplace = true;
     KRON_TRY(kron_geometry(A));
 #undef KRON_HIP
@@ -616,7 +725,7 @@ int kron_build(qbh_csr *A)
     return QBH_OK;
 }
 
-// the CSR back out of the two parts (new arrays, merged row by row: the original rows, bit for bit); the handle is unsplit
+// the CSR back out of the parts (new arrays, merged row by row: the original rows, bit for bit); the handle is unsplit
 // afterwards and stays so.  Needs room for a second copy of the matrix while it runs.
 int kron_restore(qbh_csr *A)
 {
@@ -1341,17 +1450,21 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->kron_band = A->kron.active ? A->kron.t.B : 0;
     info->kron_sliced = A->kron.active && A->kron.sliced ? 1 : 0;
     info->kron_inplace = A->kron.active && A->kron.inplace ? 1 : 0;
+    info->kron_classes = 0;
+    info->kron_cross_nnz = 0;
     if (A->kron.active) {
         const qbh_csr::KronSplit &K = A->kron;
-        info->n_blocks = K.nwb_n + K.nwb_f;
-        info->bytes_matrix = (A->nrows + 1) * 16 + ((K.sliced ? K.n_groups : A->nrows) + 1) * 8 +
-                             (K.own_far ? nnz + K.far_slots : nnz) * 20 + (K.nwb_n + K.nwb_f + 4) * 16;
+        info->n_blocks = K.nwb_n + K.nwb_f + K.nwb_x;
+        info->bytes_matrix = (A->nrows + 1) * 16 + ((K.sliced ? K.n_groups : A->nrows) + 1) * 8 + (K.n_xrows + 1) * (K.xrow ? 12 : 8) +
+                             (K.own_far ? nnz + K.far_slots : nnz) * 20 + (K.nwb_n + K.nwb_f + K.nwb_x + 6) * 16;
+        info->kron_classes = K.map.nc;
+        info->kron_cross_nnz = K.nnz_x;
+        for (int c = 0; c < K.map.nc; ++c) info->kron_minor = std::max<int64_t>(info->kron_minor, K.map.S[c]);      // several classes: the largest block
     }
     info->tuned = A->tuned;
     info->tune_ms_rows = A->tune_ms[0];
     info->tune_ms_wave = A->tune_ms[1];
     info->basis_internal = A->basis.kind;
-    info->pad_ = 0;
     if (A->kronc.active) {                       // the coded form of the split (row kernel, packed-double vectors)
         info->kron_minor = A->kronc.t.S;
         info->kron_far_nnz = A->kronc.far_p.nnz;
@@ -1394,8 +1507,10 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
             Bind bind(A);
             const qbh::KronCols one = kron_cols_one(A->kron.t.S, A->kron.NUg, A->kron.t.B);
             QBH_TRY(qbh::launch_kron_remap_cols(A->kron.ja_f, A->kron.far_slots, A->kron.cols, one, A->stream));
+            QBH_TRY(qbh::launch_kron_remap_cols(A->kron.ja_x, A->kron.nnz_x, A->kron.cols, one, A->stream));
             QBH_HIP(hipStreamSynchronize(A->stream));
             A->kron.cols = one;
+            A->kron.map.cols = one;
             A->kron.comm_tiled = false;
             A->kron.xt_of = nullptr;
         }
@@ -1440,7 +1555,7 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
         Bind bind(A);
         qbh_csr::KronSplit &K = A->kron;
         const int64_t S = K.active ? K.t.S : 1;
-        bool mine = K.active && comm->nranks <= qbh::kKronMaxRanks;
+        bool mine = K.active && K.map.nc == 1 && comm->nranks <= qbh::kKronMaxRanks;
         if (mine) {
             if (comm->row_cuts) {
                 for (int q = 0; q <= comm->nranks; ++q) mine = mine && comm->row_cuts[q] % S == 0;
@@ -1469,8 +1584,10 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
                 to.cu[q] = cut / S;
             }
             QBH_TRY(qbh::launch_kron_remap_cols(K.ja_f, K.far_slots, K.cols, to, A->stream));
+            QBH_TRY(qbh::launch_kron_remap_cols(K.ja_x, K.nnz_x, K.cols, to, A->stream));
             QBH_HIP(hipStreamSynchronize(A->stream));
             K.cols = to;
+            K.map.cols = to;
             K.comm_tiled = true;
             K.xt_of = nullptr;
         } else if (K.active) {
@@ -1589,7 +1706,7 @@ inline bool kron_path(const qbh_csr *A)
 inline d2 *tiled_target(const qbh_csr *A)
 {
     static const bool no_fold = getenv("QBH_NO_TILE_FOLD") != nullptr;      // A/B switch
-    if (no_fold || !A->kron.fold || !kron_path(A) || A->kron.t.B != 8 || A->kron.t.S < 8) return nullptr;
+    if (no_fold || !A->kron.fold || !kron_path(A) || A->kron.map.nc != 1 || A->kron.t.B != 8 || A->kron.t.S < 8) return nullptr;
     if (A->has_comm) return A->real_wire ? nullptr : reinterpret_cast<d2 *>(A->comm.d_xsend);
     return (A->nrows == A->ncols && A->kron.xt_cap >= A->nrows) ? A->kron.d_xt : nullptr;
 }
@@ -1664,8 +1781,15 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
         // previous SpMV of this handle -- what is timed is then the far + near passes of a shard without the tiled copy of the
         // FULL x, which a rank of a multi-GPU run never makes (it tiles its own block and receives the others)
         static const bool reuse_tile = getenv("QBH_KRON_REUSE_TILE") != nullptr;
-        if (K.xt_of != (const void *)x && !(reuse_tile && K.xt_last == (const void *)x))
-            QBH_TRY(qbh::launch_kron_tile(x, K.d_xt, A->ncols, qbh::KronTile{K.t.S, K.NUg, K.t.B}, s));
+        if (K.xt_of != (const void *)x && !(reuse_tile && K.xt_last == (const void *)x)) {
+            if (K.map.nc == 1) {
+                QBH_TRY(qbh::launch_kron_tile(x, K.d_xt, A->ncols, qbh::KronTile{K.t.S, K.NUg, K.t.B}, s));
+            } else {                         // every class is a product basis of its own: tiled class by class
+                for (int c = 0; c < K.map.nc; ++c)
+                    QBH_TRY(qbh::launch_kron_tile(x + K.map.rbase[c], K.d_xt + K.map.rbase[c], K.map.rbase[c + 1] - K.map.rbase[c],
+                                                  qbh::KronTile{K.map.S[c], K.map.NU[c], K.map.B}, s));
+            }
+        }
         K.xt_last = x;
         K.xt_of = nullptr;
         xt = K.d_xt;
@@ -1676,7 +1800,7 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
     f.val = K.val_f;
     f.wd = K.wd_f;
     f.n_wb = K.nwb_f;
-    f.nrows = K.sliced ? K.n_groups * 8 : A->nrows;          // sliced: whole groups of the full bands
+    f.nrows = K.map.nfar_rows();                             // sliced: whole groups of the full bands
     f.xg = xt;
     f.xl = xl;
     f.y = K.d_far;
@@ -1710,8 +1834,38 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
         if (K.sliced) QBH_TRY(qbh::launch_zero_cut_groups(K.wd_f, K.nwb_f, f.nrows, K.d_far, s));
         QBH_TRY(qbh::launch_spmv_wave2(f, K.tpr_f, K.sliced ? 3 : 0, K.grid_f, s));
         nr.far = K.d_far;
-        nr.partials = red ? A->d_partials : nullptr;
-        QBH_TRY(qbh::launch_spmv_wave2(nr, K.tpr_n, 2, K.grid_n, s));
+        if (K.map.nc == 1) {
+            // the far entries of the rows that do not fill a band: their sums go into those rows' slots of the far buffer
+            QBH_TRY(qbh::launch_kron_cross_rows(K.ia_x, K.xrow, K.n_xrows, K.ja_x, K.val_x, xt, K.t, K.d_far, s));
+            nr.partials = red ? A->d_partials : nullptr;
+            QBH_TRY(qbh::launch_spmv_wave2(nr, K.tpr_n, 2, K.grid_n, s));
+        } else {
+            nr.kcls = K.d_cls;
+            nr.partials = (red && K.nnz_x == 0) ? A->d_partials : nullptr;
+            QBH_TRY(qbh::launch_spmv_wave2(nr, K.tpr_n, 4, K.grid_n, s));
+            if (K.nnz_x > 0) {               // third pass: the unstructured part, accumulating onto y; reductions on the finished y
+                qbh::SpmvArgs cr{};
+                cr.ia = K.ia_x;
+                cr.ja = K.ja_x;
+                cr.val = K.val_x;
+                cr.wd = K.wd_x;
+                cr.n_wb = K.nwb_x;
+                cr.nrows = A->nrows;
+                cr.xg = xt;                  // columns are stored in the tiled order of x
+                cr.xl = xl;
+                cr.y = y;
+                cr.alpha = alpha;
+                cr.beta = 1.0;
+                cr.gamma = 0.0;
+                cr.colmask = -1;
+                cr.chunk_mult = A->chunk_mult;
+                cr.swizzle = (A->opts.xcd_swizzle == 3 && !A->opts.deterministic && A->d_wctr) ? 3 : (A->opts.xcd_swizzle == 3 ? 2 : A->opts.xcd_swizzle);
+                cr.wctr = A->d_wctr;
+                cr.partials = red ? A->d_partials : nullptr;
+                QBH_TRY(qbh::launch_spmv_wave(cr, K.tpr_x, K.grid_x, s));
+                nparts = K.grid_x;
+            }
+        }
 #ifdef QBH_WAVE_TIMING
         {   // debug build: where the wavefronts of the two passes spend their cycles (s_memtime ticks, 100 MHz)
             unsigned long long h[3 * 128];
@@ -1748,6 +1902,7 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
         if (prof) QBH_HIP(hipEventRecord(A->ev2, s));
         if (K.sliced) QBH_TRY(qbh::launch_zero_cut_groups(K.wd_f, K.nwb_f, f.nrows, K.d_far, s));
         QBH_TRY(qbh::launch_spmv_wave2(f, K.tpr_f, K.sliced ? 3 : 0, K.grid_f, s));
+        QBH_TRY(qbh::launch_kron_cross_rows(K.ia_x, K.xrow, K.n_xrows, K.ja_x, K.val_x, xt, K.t, K.d_far, s));
         QBH_TRY(qbh::launch_kron_combine(K.d_far, K.t, xl, y, A->nrows, alpha, red ? A->d_partials : nullptr, &nparts, s));
         if (prof) {
             QBH_HIP(hipEventRecord(A->ev3, s));

@@ -82,6 +82,7 @@ struct SpmvArgs {
     int64_t        kS, kNU;    // minor size / major count of the product basis
     int            kB;         // band width of the tiling
     int            rowmap;     // row kernel, coded Kronecker split: rows are in TILED order; y / x_local are addressed at orig(row)
+    const struct KronCls *kcls; // near pass of an operator with several classes (OPS 4): class table, nc + 1 entries
 };
 
 // element (u, d) of the product basis <-> its position in the band-major ("tiled") order (band, u, d % B): the B minor
@@ -129,32 +130,112 @@ struct KronCols {
         return cu[q] * S + KronTile{S, cu[q + 1] - cu[q], B}.orig(i - cu[q] * S);
     }
 };
-// the two parts of an operator split in place (kernel argument of the merge)
+// Product structure of the rows of an operator split in place (qbh_kron.hip).
+// One class (nc == 1): index = major * S + minor over the whole (local) row range -- the two-species operators; a row shard
+// starts at major index U0 and its far columns follow `cols` (rank-major tiled order of the gathered x).
+// Several classes (a single-species sector whose sites are cut into a low and a high half, rows in class-major order,
+// unsharded): class c holds NU[c] blocks of S[c] rows from row rbase[c] on.
+// An entry is NEAR when it stays inside the row's block, FAR when it stays inside the class and keeps the position inside the
+// block, CROSS otherwise (and for the far entries of the rows of a narrow last band, S % B != 0: the far part consists of whole
+// groups of B rows with one major index each -- no padding for a product operator, whatever S is).
+constexpr int kKronMaxClasses = 24;
+struct KronCls {                        // what the near pass needs of one class (device table, nc + 1 entries; the last is a sentinel)
+    int64_t rbase, S, NU, fbase;
+};
+struct KronMap {
+    int      nc, B, sliced;
+    int64_t  U0;
+    int64_t  rbase[kKronMaxClasses + 1], S[kKronMaxClasses], NU[kKronMaxClasses];
+    int64_t  fbase[kKronMaxClasses + 1];        // sliced: far rows of class c are numbered fbase[c] + tiled index (full bands only)
+    KronCols cols;
+    __host__ __device__ int cls(int64_t r) const
+    {
+        int c = 0;
+        while (c + 1 < nc && r >= rbase[c + 1]) ++c;
+        return c;
+    }
+    __host__ __device__ bool edge(int c, int64_t d) const { return d >= (S[c] / B) * B; }
+    // 0 near, 1 far, 2 cross; r = local row, col = global column
+    __host__ __device__ int kind(int64_t r, int64_t col) const
+    {
+        const int c = cls(r);
+        const int64_t local = r - rbase[c], u = local / S[c], d = local - u * S[c];
+        if (nc == 1) {
+            const int64_t cm = col / S[0];
+            if (cm == U0 + u) return 0;
+            if (col - cm * S[0] == d) return edge(0, d) ? 2 : 1;
+            return 2;
+        }
+        const int64_t lo = rbase[c] + u * S[c];
+        if (col >= lo && col < lo + S[c]) return 0;
+        if (col >= rbase[c] && col < rbase[c + 1] && (col - rbase[c]) % S[c] == d) return edge(c, d) ? 2 : 1;
+        return 2;
+    }
+    // position of (global) column col in the tiled x the far and cross parts gather from, and back
+    __host__ __device__ int64_t xcol(int64_t col) const
+    {
+        if (nc == 1) return cols.tile(col);
+        const int c = cls(col);
+        return rbase[c] + KronTile{S[c], NU[c], B}.tile(col - rbase[c]);
+    }
+    __host__ __device__ int64_t xcol_orig(int64_t i) const
+    {
+        if (nc == 1) return cols.orig(i);
+        const int c = cls(i);
+        return rbase[c] + KronTile{S[c], NU[c], B}.orig(i - rbase[c]);
+    }
+    // far row id of local row r (-1: a row of a narrow last band when sliced), and back
+    __host__ __device__ int64_t frow(int64_t r) const
+    {
+        const int c = cls(r);
+        const int64_t local = r - rbase[c];
+        if (sliced && edge(c, local % S[c])) return -1;
+        return (sliced ? fbase[c] : rbase[c]) + KronTile{S[c], NU[c], B}.tile(local);
+    }
+    __host__ __device__ int64_t frow_orig(int64_t f) const
+    {
+        int c = 0;
+        if (sliced) while (c + 1 < nc && f >= fbase[c + 1]) ++c;
+        else c = cls(f);
+        return rbase[c] + KronTile{S[c], NU[c], B}.orig(f - (sliced ? fbase[c] : rbase[c]));
+    }
+    __host__ __device__ int64_t nfar_rows() const { return sliced ? fbase[nc] : rbase[nc]; }
+};
+// the three parts of an operator split in place (kernel argument of the merge)
 struct KronParts {
     const int64_t *ia, *ia_n, *fp;      // CSR row pointers; near row pointers; far row pointers (or group pointers when sliced)
     const int32_t *ja_n, *ja_f;
     const d2      *val_n, *val_f;
-    KronTile       t;                   // tiled order of the LOCAL rows
-    int64_t        U0;                  // first major index of the shard
-    KronCols       cols;
-    int            sliced;
-    int64_t        nfar_rows;           // far rows that exist in the far structure (sliced: the rows of the full bands)
+    const int64_t *ia_x;                // cross part: row pointers over xrow (compact row list) or over all rows (xrow == nullptr)
+    const int32_t *xrow;
+    int64_t        n_xrows;
+    const int32_t *ja_x;                // columns in the tiled order of x (KronMap::xcol)
+    const d2      *val_x;
+    KronMap        map;
 };
-int basis_to_internal(qbh_csr *A, int kind, int n_sites, int n_up, int n_dn, bool *applied);      // qbh_reorder.hip
-int launch_basis_scatter(const uint32_t *map, const d2 *in, d2 *out, int64_t n, hipStream_t s);
-int launch_basis_gather(const uint32_t *map, const d2 *in, d2 *out, int64_t n, hipStream_t s);
-int launch_kron_check2(const int64_t *ia, const int32_t *ja, int64_t nrows, int64_t S, int64_t U0, int *d_flag, hipStream_t s);
-int launch_kron_count2(const int64_t *ia, const int32_t *ja, int64_t nrows, const KronTile &t, int64_t U0, int32_t *cnt_near, int32_t *cnt_far,
-                       hipStream_t s);
-int launch_kron_far_fill(bool col, bool sliced, const int64_t *ia, const int32_t *ja, const d2 *val, int64_t nrows, const KronTile &t, int64_t U0,
-                         const KronCols &cols, const int64_t *fp, int64_t ngroups, int32_t *out_c, d2 *out_v, hipStream_t s);
-int launch_kron_near_gather_cols(const int64_t *ia, const int32_t *ja, int64_t r0, int64_t r1, const KronTile &t, int64_t U0, const int64_t *ia_n,
-                                 int32_t *tmp, hipStream_t s);
-int launch_kron_near_gather_vals(const int64_t *ia, const int32_t *ja, const d2 *val, int64_t r0, int64_t r1, const KronTile &t, int64_t U0,
-                                 const int64_t *ia_n, d2 *tmp, hipStream_t s);
+int launch_kron_count3(const int64_t *ia, const int32_t *ja, int64_t nrows, const KronMap &map, int32_t *cnt_near, int32_t *cnt_far,
+                       int32_t *cnt_x, hipStream_t s);
+int launch_kron_far_fill(bool col, const int64_t *ia, const int32_t *ja, const d2 *val, const KronMap &map, const int64_t *fp, int64_t ngroups,
+                         int32_t *out_c, d2 *out_v, hipStream_t s);
+// part 0 (near, natural columns) or 2 (cross, tiled columns) of rows [r0, r1) packed behind one another into tmp
+int launch_kron_part_gather_cols(int part, const int64_t *ia, const int32_t *ja, int64_t r0, int64_t r1, const KronMap &map, const int64_t *iap,
+                                 const int32_t *rowidx, int32_t *tmp, hipStream_t s);
+int launch_kron_part_gather_vals(int part, const int64_t *ia, const int32_t *ja, const d2 *val, int64_t r0, int64_t r1, const KronMap &map,
+                                 const int64_t *iap, const int32_t *rowidx, d2 *tmp, hipStream_t s);
+int launch_kron_xrows(const int32_t *cnt_x, int64_t nrows, const int64_t *pos, int32_t *xrow, int32_t *cnt_compact, hipStream_t s);
+int launch_kron_flags(const int32_t *cnt, int64_t n, int32_t *flag01, hipStream_t s);
 int launch_kron_merge_rows(const KronParts &p, int64_t r0, int64_t r1, int32_t *out_ja, d2 *out_val, int64_t out_base, hipStream_t s);
 int launch_kron_remap_cols(int32_t *ja_f, int64_t n, const KronCols &from, const KronCols &to, hipStream_t s);
 int launch_kron_combine(const d2 *far, const KronTile &t, const d2 *xl, d2 *y, int64_t n, double alpha, double *partials, int *nparts, hipStream_t s);
+// sparse cross part (nc == 1: the far entries of the rows of the narrow last band): row sums into the far buffer's slots of those rows
+int launch_kron_cross_rows(const int64_t *ia_x, const int32_t *xrow, int64_t n_xrows, const int32_t *ja_x, const d2 *val_x, const d2 *xt,
+                           const KronTile &t, d2 *far, hipStream_t s);
+int launch_kron_desc_classes(WaveDesc *wd, int64_t n_wb, const KronCls *cls, int nc, hipStream_t s);
+int launch_kron_check2(const int64_t *ia, const int32_t *ja, int64_t nrows, int64_t S, int64_t U0, int *d_flag, hipStream_t s);
+// qbh_opts.basis_kind (qbh_reorder.hip): re-express the plain CSR of A in the library's internal order, keep the vector map
+int basis_to_internal(qbh_csr *A, int kind, int n_sites, int n_up, int n_dn, bool *applied);
+int launch_basis_scatter(const uint32_t *map, const d2 *in, d2 *out, int64_t n, hipStream_t s);
+int launch_basis_gather(const uint32_t *map, const d2 *in, d2 *out, int64_t n, hipStream_t s);
 
 // hipMalloc that releases live Kronecker splits (second copies of a matrix: acceleration structures, qbh_api.cpp) before it
 // reports out of memory.  Every allocation of the library except the splits' own goes through it.
@@ -432,13 +513,14 @@ struct qbh_csr {
     } kronc;
     struct KronSplit {
         bool     active = false;
-        bool     inplace = false;       // the handle's d_ja / d_val hold [near | far]: there is no CSR beside the split
+        bool     inplace = false;       // the handle's d_ja / d_val hold [near | far | cross]: there is no CSR beside the split
         bool     own_far = false;       // padded far groups: ja_f / val_f are allocations of their own
-        qbh::KronTile t{0, 0, 8};       // tiled order of the LOCAL rows (NU = major indices of this shard)
-        int64_t  U0 = 0, NUg = 0;       // first major index of the shard, major indices of the whole operator
-        qbh::KronCols cols{};           // order of the gathered x the far columns index (one rank: KronTile{S, NUg, B})
+        qbh::KronMap map{};             // product structure of the rows: one class (two-species) or several (cut single-species sector)
+        qbh::KronTile t{0, 0, 8};       // one class: tiled order of the LOCAL rows (NU = major indices of this shard)
+        int64_t  U0 = 0, NUg = 0;       // one class: first major index of the shard, major indices of the whole operator
+        qbh::KronCols cols{};           // one class: order of the gathered x the far / cross columns index (one rank: KronTile{S, NUg, B})
         bool     comm_tiled = false;    // a communicator is attached and every rank exchanges the tiled copy of its block
-        int64_t  nnz_n = 0, nnz_f = 0;
+        int64_t  nnz_n = 0, nnz_f = 0, nnz_x = 0;
         bool     sliced = false;        // far part interleaved inside groups of 8 rows (ia_f = group pointers, n_groups + 1 entries)
         int64_t  n_groups = 0, far_slots = 0;   // far_slots = entries stored in the far arrays (nnz_f + padding)
         int64_t *ia_n = nullptr, *ia_f = nullptr;
@@ -447,7 +529,17 @@ struct qbh_csr {
         qbh::WaveDesc *wd_n = nullptr, *wd_f = nullptr;
         int64_t  nwb_n = 0, nwb_f = 0;
         int      tpr_n = 2, tpr_f = 2, grid_n = 0, grid_f = 0;
-        qbh::d2 *d_xt = nullptr, *d_far = nullptr;      // tiled copy of x (xt_cap elements, made on first use), far-part row sums (tiled order)
+        // cross part.  One class: the far entries of the rows of the narrow last band, compact row list (xrow), applied by
+        // k_kron_cross_rows into the far buffer.  Several classes: row pointers over ALL rows, applied by k_spmv_wave as a third pass.
+        int64_t *ia_x = nullptr;
+        int32_t *xrow = nullptr, *ja_x = nullptr;
+        qbh::d2 *val_x = nullptr;
+        int64_t  n_xrows = 0;
+        qbh::WaveDesc *wd_x = nullptr;
+        int64_t  nwb_x = 0;
+        int      tpr_x = 2, grid_x = 0;
+        qbh::KronCls *d_cls = nullptr;  // several classes: device table for the near pass
+        qbh::d2 *d_xt = nullptr, *d_far = nullptr;      // tiled copy of x (xt_cap elements, made on first use), far-part row sums
         int64_t  xt_cap = 0;
         const void *xt_last = nullptr;  // measurement switch QBH_KRON_REUSE_TILE: the x of the previous SpMV
         const void *xt_of = nullptr;    // the vector whose tiled copy d_xt holds (written by the pass that produced it); consumed by one SpMV
@@ -496,6 +588,7 @@ struct qbh_csr {
     // the caller's basis when it is not the order the operator is held in (qbh_opts.basis_kind)
     struct BasisMap {
         int       kind = 0;              // QBH_BASIS_*; 0: the operator is held in the caller's order
+        qbh::KronMap classes{};          // QBH_BASIS_SPIN_SECTOR: the class table of the internal (class-major) order
         uint32_t *d_map = nullptr;       // [nrows] caller index r -> internal index | sign << 31
         qbh::d2  *d_stage = nullptr;     // [nrows] staging of one vector in the caller's order
     } basis;

@@ -828,7 +828,9 @@ template <int TPR, int OPS, bool DYN>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 0 || OPS == 3) ? QBH_FAR_WAVES : QBH_NEAR_WAVES, (OPS == 0 || OPS == 3) ? QBH_FAR_WAVES : QBH_NEAR_WAVES))) void k_spmv_wave2(SpmvArgs a)
 {
     constexpr int NW = 512, RP = 64 / TPR;
-    constexpr bool EPI = OPS == 1 || OPS == 2, FAR = OPS == 2;      // OPS 1: the fused epilogue of an UNSPLIT operator (no far addend)
+    constexpr bool EPI = OPS == 1 || OPS == 2 || OPS == 4, FAR = OPS == 2 || OPS == 4;      // OPS 1: the fused epilogue WITHOUT a far addend
+    constexpr bool MULTI = OPS == 4;             // OPS 4 = OPS 2 for an operator with several classes (KronMap): the far result of a row sits at its
+                                                 // compact far row id, looked up through the class table a.kcls; the block's descriptor names its class
     __shared__ d2 prod_s[4 * NW];
     __shared__ double red[12];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -858,6 +860,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
                                  // 1 KB value load instead of 9); row offsets are taken relative to it
         int r0, nr, n;           // n = entries from p0 to the block's end; -1: a row longer than the tile (row-at-a-time path)
         bool cont0, cont1;       // OPS 3: the first group began in the block before / the last group goes on in the block after
+        int cls;                 // OPS 4: class of the block's first row
+    };
+    // far result of one row (OPS 2 / 4)
+    auto far_at = [&](int64_t row, int c0) -> d2 {
+        if constexpr (MULTI) {
+            int c = c0;
+            while (row >= a.kcls[c + 1].rbase) ++c;                 // a block rarely straddles two classes
+            const KronCls k = a.kcls[c];
+            const int64_t local = row - k.rbase, u = local / k.S, d = local - u * k.S;
+            if (d >= ((k.S >> 3) << 3)) return d2{0.0, 0.0};         // a row of the class's narrow last band: no far part
+            return a.far[k.fbase + (d >> 3) * 8 * k.NU + u * 8 + (d & 7)];
+        } else {
+            return a.far[kt.tile(row)];
+        }
     };
     // OPS 3: a block is 512 consecutive SLOTS of the sliced stream whatever the groups are (descriptor: first slot, first
     // group that overlaps, pad = 1 when that group began in the previous block); a group cut by a block boundary gets its
@@ -872,6 +888,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
         const int64_t p1 = (int64_t)(((uint64_t)q5 << 32) | q4);
         b.r0 = __builtin_amdgcn_readlane(dq, 2);
         b.nr = __builtin_amdgcn_readlane(dq, 6) - b.r0;
+        b.cls = MULTI ? __builtin_amdgcn_readlane(dq, 3) : 0;
         b.cont0 = OPS == 3 && (__builtin_amdgcn_readlane(dq, 3) & 1);
         b.cont1 = OPS == 3 && (__builtin_amdgcn_readlane(dq, 7) & 1);
         if (b.cont1) b.nr += 1;
@@ -933,7 +950,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
             const int64_t row = rloc < b.nr ? (int64_t)b.r0 + rloc : 0;
             o.yo = a.y[row];
             o.xi = a.xl[row];
-            o.fr = FAR ? a.far[kt.tile(row)] : d2{0.0, 0.0};
+            o.fr = FAR ? far_at(row, b.cls) : d2{0.0, 0.0};
             if (!need_y) o.yo = d2{0.0, 0.0};
         }
     };
@@ -1114,7 +1131,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
                         if (EPI && sub == 0) {
                             yo = need_y ? a.y[b0.r0 + row] : d2{0.0, 0.0};
                             xi = a.xl[b0.r0 + row];
-                            if (FAR) fr = a.far[kt.tile((int64_t)b0.r0 + row)];
+                            if (FAR) fr = far_at((int64_t)b0.r0 + row, b0.cls);
                         }
                     }
                 }
@@ -1144,7 +1161,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
                     if (EPI) {
                         if (need_y) yo = a.y[row];
                         xi = a.xl[row];
-                        if (FAR) fr = a.far[kt.tile(row)];
+                        if (FAR) fr = far_at(row, b0.cls);
                     }
                     finish_row(row, sum, yo, xi, fr, false);
                 }
@@ -1218,6 +1235,7 @@ int launch_spmv_wave2(const SpmvArgs &a, int tpr, int ops, int grid, hipStream_t
     if (ops == 0)      launch_wave2_tpr<0>(a, tpr, grid, s);
     else if (ops == 3) launch_wave2_tpr<3>(a, tpr, grid, s);
     else if (ops == 1) launch_wave2_tpr<1>(a, tpr, grid, s);
+    else if (ops == 4) launch_wave2_tpr<4>(a, tpr, grid, s);
     else               launch_wave2_tpr<2>(a, tpr, grid, s);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
@@ -1239,7 +1257,10 @@ static int occ_wave2(int tpr)
     }
     return occ;
 }
-int wave2_kernel_occupancy(int tpr, int ops) { return ops == 0 ? occ_wave2<0>(tpr) : ops == 3 ? occ_wave2<3>(tpr) : ops == 1 ? occ_wave2<1>(tpr) : occ_wave2<2>(tpr); }
+int wave2_kernel_occupancy(int tpr, int ops)
+{
+    return ops == 0 ? occ_wave2<0>(tpr) : ops == 3 ? occ_wave2<3>(tpr) : ops == 1 ? occ_wave2<1>(tpr) : ops == 4 ? occ_wave2<4>(tpr) : occ_wave2<2>(tpr);
+}
 
 // ---- Kronecker split: tiled copy of x, structure check, count / fill of the two parts ----
 // Tiled copy of x for B = 8, through LDS: a workgroup moves 32 major indices x 8 bands; it reads 1 KB runs of x (64 minor indices

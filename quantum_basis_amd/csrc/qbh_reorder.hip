@@ -147,6 +147,41 @@ __global__ __launch_bounds__(256) void k_inv_maps(const int32_t *order, const ui
     }
 }
 
+// QBH_BASIS_SPIN_SECTOR: caller index r = rank of the n_sites-bit pattern with n_dn bits set; internal index = class-major
+// (class = bits set among the high sites): rbase[c] + rank(high part) * S[c] + rank(low part)
+struct SpinCut {
+    int n_sites, n_dn, h, p_min, nc;
+    int64_t rbase[kKronMaxClasses + 1], S[kKronMaxClasses];
+    const uint64_t *binom;             // [33 * 33]
+};
+__device__ __forceinline__ int64_t colex_rank(uint32_t bits, const uint64_t *binom)
+{
+    int64_t r = 0;
+    int j = 0;
+    while (bits) {
+        const int p = __ffs(bits) - 1;
+        bits &= bits - 1;
+        ++j;
+        r += (int64_t)binom[p * 33 + j];
+    }
+    return r;
+}
+__global__ __launch_bounds__(256) void k_spin_sector_map(SpinCut a, int64_t dim, int32_t *inv_order, uint32_t *map, const int64_t *ia_ref, int32_t *cnt_new)
+{
+    RefOrderArgs ua{};
+    ua.n_sites = a.n_sites;
+    ua.binom = a.binom;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < dim; r += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t pat = colex_unrank(ua, r, a.n_dn);
+        const uint32_t lp = pat & ((1u << a.h) - 1u), hp = pat >> a.h;
+        const int c = __popc(hp) - a.p_min;
+        const int64_t g = a.rbase[c] + colex_rank(hp, a.binom) * a.S[c] + colex_rank(lp, a.binom);
+        inv_order[g] = (int32_t)r;
+        map[r] = (uint32_t)g;
+        cnt_new[g] = (int32_t)(ia_ref[r + 1] - ia_ref[r]);
+    }
+}
+
 // vectors between the caller's order (index r) and the internal one (map[r] = internal index | sign << 31)
 __global__ __launch_bounds__(256) void k_basis_scatter(const uint32_t *map, const d2 *in, d2 *out, int64_t n)
 {
@@ -307,7 +342,9 @@ int qbh::basis_to_internal(qbh_csr *A, int kind, int n_sites, int n_up, int n_dn
 {
     using namespace qbh;
     *applied = false;
-    if (kind != QBH_BASIS_REF_FERMION2 || n_sites < 2 || n_sites > 31 || n_up < 0 || n_up > n_sites || n_dn < 0 || n_dn > n_sites) return QBH_OK;
+    if ((kind != QBH_BASIS_REF_FERMION2 && kind != QBH_BASIS_SPIN_SECTOR) || n_sites < 2 || n_sites > 31 || n_up < 0 || n_up > n_sites || n_dn < 0 ||
+        n_dn > n_sites)
+        return QBH_OK;
     if (A->kind != 0 || !A->d_val || A->d_code || !A->own_arrays || A->has_rem || A->has_comm || A->kron.active || A->nrows != A->ncols ||
         A->row_offset != 0 || A->basis.kind != 0)
         return QBH_OK;
@@ -321,7 +358,34 @@ int qbh::basis_to_internal(qbh_csr *A, int kind, int n_sites, int n_up, int n_dn
         for (int k = 0; k <= 32; ++k) hb[(size_t)p * 33 + k] = (k == 0) ? 1 : (p == 0 ? 0 : hb[(size_t)(p - 1) * 33 + k - 1] + hb[(size_t)(p - 1) * 33 + k]);
     a.n_minor = (int64_t)hb[(size_t)n_sites * 33 + n_dn];
     a.dim = (int64_t)hb[(size_t)n_sites * 33 + n_up] * a.n_minor;
-    if (a.dim != A->nrows || a.n_minor < 2 || a.n_minor >= a.dim) return QBH_OK;          // not the basis described: kept as given
+    SpinCut sc{};
+    KronMap classes{};
+    if (kind == QBH_BASIS_SPIN_SECTOR) {
+        // n_up carries the number of LOW sites of the cut (0: half of them); class = particles among the high sites
+        a.dim = a.n_minor;
+        const int h = n_up > 0 ? n_up : n_sites / 2;
+        const int p_min = std::max(0, n_dn - h), p_max = std::min(n_sites - h, n_dn);
+        if (h < 3 || h > n_sites - 1 || n_sites - h > 24 || p_max - p_min + 1 > kKronMaxClasses || p_max <= p_min) return QBH_OK;
+        sc.n_sites = n_sites;
+        sc.n_dn = n_dn;
+        sc.h = h;
+        sc.p_min = p_min;
+        sc.nc = p_max - p_min + 1;
+        classes.nc = sc.nc;
+        classes.B = 8;
+        classes.sliced = 1;
+        classes.U0 = 0;
+        for (int c = 0; c < sc.nc; ++c) {
+            const int p = p_min + c;
+            classes.S[c] = sc.S[c] = (int64_t)hb[(size_t)h * 33 + (n_dn - p)];
+            classes.NU[c] = (int64_t)hb[(size_t)(n_sites - h) * 33 + p];
+            classes.rbase[c + 1] = sc.rbase[c + 1] = sc.rbase[c] + classes.S[c] * classes.NU[c];
+            classes.fbase[c + 1] = classes.fbase[c] + (classes.S[c] / 8) * 8 * classes.NU[c];
+            if ((double)classes.NU[c] * 128.0 > 2.5e6) return QBH_OK;          // a band of the class's x must fit an XCD's L2
+        }
+        if (sc.rbase[sc.nc] != a.dim) return QBH_OK;
+    }
+    if (a.dim != A->nrows || (kind == QBH_BASIS_REF_FERMION2 && (a.n_minor < 2 || a.n_minor >= a.dim))) return QBH_OK;   // not the basis described: kept as given
     const int64_t dim = a.dim, nnz = A->nnz;
     hipStream_t s = A->stream;
     uint64_t *k0 = nullptr, *k1 = nullptr, *d_binom = nullptr;
@@ -340,27 +404,33 @@ int qbh::basis_to_internal(qbh_csr *A, int kind, int n_sites, int n_up, int n_dn
     RO_HIP(qbh::dev_alloc(&d_binom, hb.size() * 8));
     RO_HIP(hipMemcpy(d_binom, hb.data(), hb.size() * 8, hipMemcpyHostToDevice));
     a.binom = d_binom;
-    RO_HIP(qbh::dev_alloc(&k0, (size_t)dim * 8));
-    RO_HIP(qbh::dev_alloc(&k1, (size_t)dim * 8));
-    RO_HIP(qbh::dev_alloc(&v0, (size_t)dim * 4));
-    RO_HIP(qbh::dev_alloc(&v1, (size_t)dim * 4));
-    RO_HIP(qbh::dev_alloc(&sign, (size_t)dim));
-    hipLaunchKernelGGL(k_ref_keys, dim3(2048), dim3(256), 0, s, a, k0, v0, sign);
-    RO_HIP(hipGetLastError());
-    size_t tmp_bytes = 0;
-    RO_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0, k1, v0, v1, dim, 0, 2 * n_sites, s));
-    RO_HIP(qbh::dev_alloc(&tmp, tmp_bytes));
-    RO_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k0, k1, v0, v1, dim, 0, 2 * n_sites, s));
-    RO_HIP(hipStreamSynchronize(s));
-    for (void **q : {(void **)&tmp, (void **)&k0, (void **)&k1, (void **)&v0}) {
-        (void)hipFree(*q);
-        *q = nullptr;
-    }
     RO_HIP(qbh::dev_alloc(&inv_order, (size_t)dim * 4));
     RO_HIP(qbh::dev_alloc(&map, (size_t)dim * 4));
     RO_HIP(qbh::dev_alloc(&cnt, (size_t)dim * 4));
-    hipLaunchKernelGGL(k_inv_maps, dim3(2048), dim3(256), 0, s, v1, sign, dim, inv_order, map, A->d_ia, cnt);
-    RO_HIP(hipGetLastError());
+    if (kind == QBH_BASIS_REF_FERMION2) {
+        RO_HIP(qbh::dev_alloc(&k0, (size_t)dim * 8));
+        RO_HIP(qbh::dev_alloc(&k1, (size_t)dim * 8));
+        RO_HIP(qbh::dev_alloc(&v0, (size_t)dim * 4));
+        RO_HIP(qbh::dev_alloc(&v1, (size_t)dim * 4));
+        RO_HIP(qbh::dev_alloc(&sign, (size_t)dim));
+        hipLaunchKernelGGL(k_ref_keys, dim3(2048), dim3(256), 0, s, a, k0, v0, sign);
+        RO_HIP(hipGetLastError());
+        size_t tmp_bytes = 0;
+        RO_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0, k1, v0, v1, dim, 0, 2 * n_sites, s));
+        RO_HIP(qbh::dev_alloc(&tmp, tmp_bytes));
+        RO_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k0, k1, v0, v1, dim, 0, 2 * n_sites, s));
+        RO_HIP(hipStreamSynchronize(s));
+        for (void **q : {(void **)&tmp, (void **)&k0, (void **)&k1, (void **)&v0}) {
+            (void)hipFree(*q);
+            *q = nullptr;
+        }
+        hipLaunchKernelGGL(k_inv_maps, dim3(2048), dim3(256), 0, s, v1, sign, dim, inv_order, map, A->d_ia, cnt);
+        RO_HIP(hipGetLastError());
+    } else {
+        sc.binom = d_binom;
+        hipLaunchKernelGGL(k_spin_sector_map, dim3(2048), dim3(256), 0, s, sc, dim, inv_order, map, A->d_ia, cnt);
+        RO_HIP(hipGetLastError());
+    }
     RO_HIP(qbh::dev_alloc(&ia_n, (size_t)(dim + 1) * 8));
     {
         const int rc = exclusive_scan(cnt, dim, ia_n, s);
@@ -371,17 +441,24 @@ int qbh::basis_to_internal(qbh_csr *A, int kind, int n_sites, int n_up, int n_dn
     // row g of the internal operator = reference row inv_order[g]; column c_ref -> map[c_ref] (index | sign)
     hipLaunchKernelGGL(k_ref_fill, dim3(4096), dim3(256), 0, s, inv_order, map, dim, A->d_ia, A->d_ja, A->d_val, ia_n, ja_n, val_n);
     RO_HIP(hipGetLastError());
-    // the hint is checked, not trusted: in the order it describes every entry keeps the up or the down configuration
-    RO_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
-    {
-        const int rc = launch_kron_check2(ia_n, ja_n, dim, a.n_minor, 0, A->d_flag, s);
-        if (rc != QBH_OK) return drop(rc);
+    if (kind == QBH_BASIS_REF_FERMION2) {
+        // the hint is checked, not trusted: in the order it describes every entry keeps the up or the down configuration
+        RO_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
+        {
+            const int rc = launch_kron_check2(ia_n, ja_n, dim, a.n_minor, 0, A->d_flag, s);
+            if (rc != QBH_OK) return drop(rc);
+        }
+        int bad = 0;
+        RO_HIP(hipMemcpyAsync(&bad, A->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+        RO_HIP(hipStreamSynchronize(s));
+        RO_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
+        if (bad) return drop(QBH_OK);
+    } else {
+        // nothing to check: whatever the matrix is, entries that keep neither the block nor the position inside it go to the third
+        // (unstructured) part of the split, and kron_build gives the split up when that part is most of the operator
+        RO_HIP(hipStreamSynchronize(s));
+        A->basis.classes = classes;
     }
-    int bad = 0;
-    RO_HIP(hipMemcpyAsync(&bad, A->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
-    RO_HIP(hipStreamSynchronize(s));
-    RO_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
-    if (bad) return drop(QBH_OK);
     (void)hipFree(A->d_ia);
     (void)hipFree(A->d_ja);
     (void)hipFree(A->d_val);
@@ -394,7 +471,7 @@ int qbh::basis_to_internal(qbh_csr *A, int kind, int n_sites, int n_up, int n_dn
     A->basis.kind = kind;
     A->basis.d_map = map;
     map = nullptr;
-    A->opts.kron_minor = a.n_minor;
+    if (kind == QBH_BASIS_REF_FERMION2) A->opts.kron_minor = a.n_minor;
     *applied = true;
     return drop(QBH_OK);
 }

@@ -129,7 +129,7 @@ def gpu_sharded_kron(rank, world, port, backend, out_dir, mixed=False):
     L, ne, bonds, dim, S = 12, 6, lattices.square(4, 3), 853776, 924
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        split = 0 if (mixed and rank == 1) else 1
+        split = 0 if (mixed and rank == 1) else 2              # 2: split whatever has the structure (1 leaves small operators alone)
         opts = q.make_opts(device=0, stream=stream.cuda_stream, value_dict=0, real_fast_path=0, kron_split=split)
         cuts = qdist.kron_row_cuts(dim, S, world)
         r0, r1 = int(cuts[rank]), int(cuts[rank + 1])

@@ -64,7 +64,7 @@ def test_sharded_kron_split_matches_single_gpu(world, backend, mixed):
         hess = np.load(tmp + "/hess.npy")
         x = np.concatenate([np.load(tmp + "/x_%d.npy" % r) for r in range(world)])
         vec = np.concatenate([np.load(tmp + "/vec_%d.npy" % r) for r in range(world)])
-    A = q.csr_mat.hubbard(12, 6, 6, lattices.square(4, 3), opts=q.make_opts(value_dict=0, real_fast_path=0))
+    A = q.csr_mat.hubbard(12, 6, 6, lattices.square(4, 3), opts=q.make_opts(value_dict=0, real_fast_path=0, kron_split=2))
     assert A.info().kron_inplace == 1
     ref = q.locate_E0_lanczos(A, nev=1, ncv=1, maxit=400)
     assert abs(res[0] - ref.E0) <= 1e-11 * abs(ref.E0)

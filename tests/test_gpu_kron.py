@@ -118,7 +118,7 @@ def test_row_shard_of_whole_major_indices_is_split_in_place(shape, majors):
     import math
     S = math.comb(n, nd)
     r0, r1 = majors[0] * S, majors[1] * S
-    Sh = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1, rows=(r0, r1), opts=q.make_opts(**PLAIN))
+    Sh = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1, rows=(r0, r1), opts=q.make_opts(kron_split=2, **PLAIN))
     info = Sh.info()
     assert info.kron_minor == S and info.kron_inplace == 1 and info.nrows == r1 - r0 and info.ncols == dim
     sia, sja, sval = Sh.download()
@@ -146,7 +146,7 @@ def test_deterministic_option_gives_bit_identical_lanczos_coefficients():
     bonds = lattices.square(4, 3)
     out = []
     for _ in range(2):
-        K = q.csr_mat.hubbard(12, 6, 6, bonds, t=1.0, U=1.1, opts=q.make_opts(deterministic=1, **PLAIN))
+        K = q.csr_mat.hubbard(12, 6, 6, bonds, t=1.0, U=1.1, opts=q.make_opts(deterministic=1, kron_split=2, **PLAIN))
         assert K.info().kron_inplace == 1 and K.info().tuned == -1
         r = q.locate_E0_lanczos(K, nev=1, ncv=0, maxit=400)
         out.append((r.hessenberg_E0.copy(), r.steps["E0"], r.E0))

@@ -1,0 +1,87 @@
+"""The Kronecker split of a SINGLE-SPECIES sector (qbh_opts.basis_kind = QBH_BASIS_SPIN_SECTOR): the sites are cut into a low and
+a high half, the operator is held class-major internally (class = particles among the high sites), bonds inside the low half
+are the near part, bonds inside the high half the far part (band-major per class), bonds across the cut a third, unstructured
+part.  Callers keep the generator's order (vectors are translated at upload / download / randomize); every result must equal the
+unsplit operator's and the oracle's."""
+import numpy as np
+import pytest
+
+import quantum_basis_amd as q
+from quantum_basis_amd import _lib, lattices
+from oracle import qb_oracle as qo
+
+pytestmark = pytest.mark.gpu
+PLAIN = dict(value_dict=0, real_fast_path=0)
+
+
+def _rand(n, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.normal(size=n) + 1j * rng.normal(size=n)).astype(np.complex128)
+
+
+CASES = {
+    "chain16": (16, 8, lattices.chain(16)),
+    "kagome12": (12, 6, lattices.kagome(2, 2)),
+    "triangular16": (16, 8, lattices.triangular(4, 4)),
+    "chain18_n7": (18, 7, lattices.chain(18)),
+    "kagome18": (18, 9, lattices.kagome(3, 2)),
+}
+
+
+@pytest.mark.parametrize("name,h", [("chain16", 8), ("chain16", 10), ("kagome12", 6), ("triangular16", 8), ("chain18_n7", 9), ("kagome18", 9), ("kagome18", 11)])
+def test_cut_sector_equals_the_unsplit_operator(name, h):
+    n, k, bonds = CASES[name]
+    P = q.csr_mat.heisenberg(n, k, bonds, J=1.0, opts=q.make_opts(kron_split=0, **PLAIN))
+    ia, ja, val = P.download()
+    dim = P.dim
+    O = qo.Csr(dim, ia, ja.astype(np.int64), val, False)
+    K = q.csr_mat.heisenberg(n, k, bonds, J=1.0, opts=q.make_opts(kron_split=2, basis_kind=_lib.BASIS_SPIN_SECTOR, n_sites=n, n_up=h, n_dn=k, **PLAIN))
+    info = K.info()
+    assert info.basis_internal == _lib.BASIS_SPIN_SECTOR and info.nnz == ia[-1]
+    crossing = np.mean([(a < h) != (b < h) for a, b in bonds])          # share of the bonds across the cut
+    if crossing < 0.3:
+        assert info.kron_classes > 1 and info.kron_inplace == 1 and info.kron_sliced == 1
+        assert 0 < info.kron_far_nnz < info.nnz and 0 < info.kron_cross_nnz < 0.4 * info.nnz
+    elif crossing > 0.5:
+        assert info.kron_classes == 0           # mostly unstructured: permuted, not split -- and still right (below)
+    x, y0 = _rand(dim, 1), _rand(dim, 2)
+    want = O.multmv(x)
+    scale = np.abs(want).max()
+    v = K.vec(2)
+    for alpha, beta, gamma in [(1.0, 0.0, 0.0), (0.7, -0.3, 0.25), (-1.0, 1.0, 1.5)]:
+        v.upload(x, 0)
+        v.upload(y0, dim)
+        xy, yy = K.spmv(v.at(0), v.at(dim), alpha, beta, gamma, want_red=True)
+        ref = alpha * want + beta * y0 + gamma * x
+        assert np.abs(v.download(dim, dim) - ref).max() <= 2e-13 * max(scale, 1.0)
+        assert abs(xy - np.vdot(x, ref)) <= 1e-11 * max(abs(np.vdot(x, ref)), 1.0)
+        assert abs(yy - np.vdot(ref, ref).real) <= 1e-11 * np.vdot(ref, ref).real
+    v.free()
+    y = np.empty(dim, dtype=np.complex128)
+    K.MultMv(x, y)
+    assert np.abs(y - want).max() <= 2e-13 * scale
+    # start vector, Lanczos + CG through the three passes: the unsplit operator's answers, in the caller's order
+    assert np.allclose(q.vec_randomize(K, seed=1), qo.vec_randomize(dim, 1), rtol=1e-13, atol=0)
+    rk, rp = q.locate_E0_lanczos(K), q.locate_E0_lanczos(P)
+    assert abs(rk.E0 - rp.E0) <= 1e-11 * abs(rp.E0) and abs(rk.steps["E0"] - rp.steps["E0"]) <= 1
+    assert np.abs(O.multmv(rk.eigenvecs) - rk.E0 * rk.eigenvecs).max() < 1e-7
+    K.destroy()
+    P.destroy()
+
+
+def test_a_useless_cut_leaves_the_operator_unsplit_but_correct():
+    """A cut with most bonds across it (every second site low on a chain: all bonds cross): the third part would be most of the
+    operator, so no split is made -- the operator is still permuted, and still right."""
+    n, k = 16, 8
+    bonds = [(i, (i + 8) % 16) for i in range(16)]              # every bond joins the low half to the high half
+    P = q.csr_mat.heisenberg(n, k, bonds, J=1.0, opts=q.make_opts(kron_split=0, **PLAIN))
+    ia, ja, val = P.download()
+    O = qo.Csr(P.dim, ia, ja.astype(np.int64), val, False)
+    K = q.csr_mat.heisenberg(n, k, bonds, J=1.0, opts=q.make_opts(kron_split=2, basis_kind=_lib.BASIS_SPIN_SECTOR, n_sites=n, n_up=8, n_dn=k, **PLAIN))
+    assert K.info().kron_classes == 0 and K.info().kron_minor == 0
+    x = _rand(P.dim, 3)
+    y = np.empty(P.dim, dtype=np.complex128)
+    K.MultMv(x, y)
+    assert np.abs(y - O.multmv(x)).max() <= 2e-13 * np.abs(y).max()
+    K.destroy()
+    P.destroy()
