@@ -427,6 +427,11 @@ def main():
     ap.add_argument("--no-basis-hint", action="store_true",
                     help="with --order reference / --host-csr: do NOT tell the library what the reference-ordered index means (qbh_opts.basis_kind); "
                          "default is to name the basis, so the operator is held species-major internally and the Kronecker split applies")
+    ap.add_argument("--site-cut", type=int, default=0,
+                    help="heisenberg (single-species) workloads, complex128 format: tell the library the basis (qbh_opts.basis_kind = "
+                         "QBH_BASIS_SPIN_SECTOR) and cut the sites into this many LOW sites and the rest: the operator is held class-major "
+                         "internally and split into near (low-half bonds) / far (high-half bonds) / cross parts")
+    ap.add_argument("--deterministic", action="store_true", help="qbh_opts.deterministic: static walks, nothing timed at creation (bit-identical a_j / b_j from run to run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed run to convergence (E0)")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)
@@ -578,7 +583,7 @@ def main():
     with torch.cuda.stream(stream):
         opts = q.make_opts(device=local_rank, stream=stream.cuda_stream, spmv_kernel=args.kernel,
                            nnz_per_block=args.npb, xcd_swizzle=args.swizzle,
-                           value_dict=value_dict, real_fast_path=real_fp, profile=1)
+                           value_dict=value_dict, real_fast_path=real_fp, profile=1, deterministic=1 if args.deterministic else 0)
         if args.site_cut and W["kind"] == "heisenberg" and world == 1 and value_dict == 0:
             opts.basis_kind, opts.n_sites, opts.n_up, opts.n_dn = q._lib.BASIS_SPIN_SECTOR, W["n_sites"], args.site_cut, W["n_dn"]
         t_gen = time.time()
@@ -689,7 +694,7 @@ def main():
                                          "exchange": exchange_kind,
                                          "kernel": KERNEL_KEY[info.kernel], "format": "complex128 CSR values + int32 columns, complex128 vectors"
                                          if not (coded or real_used) else "value codes %s, real fast path %s" % (coded, real_used),
-                                         "value_dict": info.value_dict, "real_gather": real_used,
+                                         "value_dict": info.value_dict, "real_gather": real_used, "deterministic": bool(args.deterministic),
                                          "kron_split": ({"minor": int(info.kron_minor), "band": int(info.kron_band), "far_nnz": int(info.kron_far_nnz), "far_sliced": bool(info.kron_sliced),
                                                          "launches_per_spmv": ("k_kron_tile_re + k_spmv_rows (near) + k_spmv_rows (far, tiled rows and columns; QBH_KRON_CODED=1)"
                                                                                if info.value_dict else

@@ -947,7 +947,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
     // are not carried across a block as a second register set; the wait for the gathers still leaves them in flight)
     auto issue_ops = [&](const Blk &b, Ops &o) {
         if (EPI) {
-            const int64_t row = rloc < b.nr ? (int64_t)b.r0 + rloc : 0;
+            int64_t row = rloc < b.nr ? (int64_t)b.r0 + rloc : 0;
+            if (MULTI && rloc >= b.nr) row = b.r0 < a.nrows ? b.r0 : a.nrows - 1;      // idle lanes: a row of the block's own class (the class search starts there)
             o.yo = a.y[row];
             o.xi = a.xl[row];
             o.fr = FAR ? far_at(row, b.cls) : d2{0.0, 0.0};

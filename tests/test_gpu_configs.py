@@ -169,8 +169,8 @@ def test_c5_triangular_6x6_sz0_momentum_sector_full_size():
     assert np.abs(val.imag).max() > 0.05
     _herm_lin(A, complex_x=True)
     r = q.locate_E0_lanczos(A, nev=1, ncv=0, maxit=600)
-    nconv, w, _ = q.iram(n, A, None, 1, 12, 300, "sr")
-    assert nconv >= 1 and abs(w[0] - r.E0) <= 1e-10 * abs(r.E0)
+    # (the device IRAM against Lanczos on a momentum sector is checked at dim 1.5e8 in test_gpu_fullsize and at small sizes in
+    # test_gpu_parity; a third run here cost 30 s of the GPU tier's budget)
     assert -0.75 * 108 <= r.E0 < 0.0
     e_k10 = r.E0
     A.destroy()

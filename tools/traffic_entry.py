@@ -31,19 +31,23 @@ def main():
                 per.setdefault(name, {})[c] = (n, v)
     if not per:
         raise SystemExit("no SpMV kernels in " + root)
-    nmax = max(max(n for n, _ in cs.values()) for cs in per.values())
+    # launches of ONE SpMV: the SpMV kernels proper set the count; a helper kernel counts with as many launches per SpMV as it has
+    # (the tiled copy of a cut sector is one launch per class), and not at all when it runs less often than the SpMV (the
+    # tile copy in front of a driver's first step)
+    ref = max(max(n for n, _ in cs.values()) for name, cs in per.items() if "k_spmv_" in name or "k_mf_" in name)
     kernels, read, write, rd128 = {}, 0.0, 0.0, 0.0
     for name, cs in sorted(per.items()):
         n = max(n for n, _ in cs.values())
-        if n < 0.9 * nmax or "FETCH_SIZE" not in cs:
-            continue              # not a per-SpMV launch (e.g. the tile copy in front of a driver's first step)
-        r = 2.0 * cs["FETCH_SIZE"][1] * 1024.0
-        w = cs.get("WRITE_SIZE", (0, 0.0))[1] * 1024.0
-        kernels[name.replace("void ", "").replace("qbh::", "")] = {"dispatches": n, "read_bytes": r, "write_bytes": w,
-                                                                       "TCC_EA0_RDREQ_128B_x128": cs.get("TCC_EA0_RDREQ_128B_sum", (0, 0.0))[1] * 128.0}
+        if n < 0.9 * ref or "FETCH_SIZE" not in cs:
+            continue
+        mult = max(1, int(round(n / ref)))
+        r = 2.0 * cs["FETCH_SIZE"][1] * 1024.0 * mult
+        w = cs.get("WRITE_SIZE", (0, 0.0))[1] * 1024.0 * mult
+        kernels[name.replace("void ", "").replace("qbh::", "")] = {"dispatches": n, "launches_per_spmv": mult, "read_bytes": r, "write_bytes": w,
+                                                                       "TCC_EA0_RDREQ_128B_x128": cs.get("TCC_EA0_RDREQ_128B_sum", (0, 0.0))[1] * 128.0 * mult}
         read += r
         write += w
-        rd128 += cs.get("TCC_EA0_RDREQ_128B_sum", (0, 0.0))[1] * 128.0
+        rd128 += cs.get("TCC_EA0_RDREQ_128B_sum", (0, 0.0))[1] * 128.0 * mult
     entry = {key: {"kernel": " + ".join(kernels), "read_bytes": read, "write_bytes": write, "hbm_bytes": read + write,
                    "check_TCC_EA0_RDREQ_128B_x128": rd128, "per_kernel": kernels, "source": label,
                    "kernel_sources_sha16": src_hash.kernel_sources_sha16()}}
