@@ -342,6 +342,10 @@ void kron_free_aux(qbh_csr *A)
         if (K.ja_f) (void)hipFree(K.ja_f);
         if (K.val_f) (void)hipFree(K.val_f);
     }
+    if (K.own_x) {
+        if (K.ja_x) (void)hipFree(K.ja_x);
+        if (K.val_x) (void)hipFree(K.val_x);
+    }
     K = qbh_csr::KronSplit{};
 }
 
@@ -377,7 +381,7 @@ qbh::KronCols kron_cols_one(int64_t S, int64_t NUg, int B)
 }
 
 int wave_geometry_for(qbh_csr *A, const int64_t *ia, int64_t nr, int64_t nnz, double avg, bool slots, int ops, qbh::WaveDesc **wd_io, int64_t *nwb_o,
-                      int *tpr_o, int *grid_o)
+                      int *tpr_o, int *grid_o, int64_t shift = 0)
 {
     hipStream_t s = A->stream;
     QBH_TRY(qbh::launch_max_rowlen(ia, nr, (int64_t *)A->d_scal, s));
@@ -385,11 +389,11 @@ int wave_geometry_for(qbh_csr *A, const int64_t *ia, int64_t nr, int64_t nnz, do
     QBH_HIP(hipMemcpyAsync(&maxlen, A->d_scal, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     QBH_HIP(hipStreamSynchronize(s));
     const int64_t window = slots ? 512 : (maxlen <= 256) ? 505 - (maxlen > 0 ? maxlen - 1 : 0) : 249;
-    const int64_t n_wb = std::max<int64_t>(1, (nnz + window - 1) / window);
+    const int64_t n_wb = std::max<int64_t>(1, (nnz + (slots ? shift : 0) + window - 1) / window);
     if (*wd_io) (void)hipFree(*wd_io);
     *wd_io = nullptr;
     QBH_HIP(hipMalloc(wd_io, (size_t)(n_wb + 2) * sizeof(qbh::WaveDesc)));
-    if (slots) QBH_TRY(qbh::launch_build_slotdesc(ia, nr, nnz, *wd_io, n_wb, s));
+    if (slots) QBH_TRY(qbh::launch_build_slotdesc(ia, nr, nnz, *wd_io, n_wb, shift, s));
     else       QBH_TRY(qbh::launch_build_wavedesc(ia, nr, window, *wd_io, n_wb, s));
     const int tpr = avg <= 32 ? 2 : avg <= 64 ? 4 : 8;
     int ncu = 256;
@@ -510,6 +514,10 @@ int kron_build(qbh_csr *A)
         K.own_far = false;                           // tmp_c / tmp_v freed above
         K.ja_f = nullptr;
         K.val_f = nullptr;
+        if (K.own_x && (tmpx_c == nullptr)) {        // already adopted: freed by kron_free_aux
+        } else {
+            K.own_x = false;
+        }
         kron_free_aux(A);
         if (destructive && code == QBH_OK) code = QBH_EHIP;
         if (destructive) {
@@ -684,7 +692,13 @@ int kron_build(qbh_csr *A)
     K.ja_n = A->d_ja;
     K.val_n = A->d_val;
     int64_t tail = K.nnz_n;
-    if (K.nnz_n + K.far_slots + K.nnz_x <= A->nnz) {    // no padding: the far part takes the space the far entries left
+    // The blocks of the far stream are exact runs of 512 slots: they should start on 128-byte boundaries of BOTH arrays (8 lines
+    // per 1 KB value load instead of 9, 2 per 256-byte column load instead of 3), i.e. the far part should begin a multiple of 32
+    // entries behind the arrays' (aligned) base.  One class: the small cross part keeps the scratch arrays it was gathered into,
+    // which leaves its entries' worth of slack behind the near part for that.
+    const bool own_x = !multi && K.nnz_x >= 32 && getenv("QBH_NO_FAR_ALIGN") == nullptr;
+    if (own_x && ((K.nnz_n + 31) / 32) * 32 + K.far_slots <= A->nnz) tail = ((K.nnz_n + 31) / 32) * 32;
+    if (tail + K.far_slots + (own_x ? 0 : K.nnz_x) <= A->nnz) {    // no padding: the far part takes the space the far entries left
         KRON_HIP(hipMemcpyAsync(A->d_val + tail, tmp_v, (size_t)K.far_slots * sizeof(d2), hipMemcpyDeviceToDevice, s));
         KRON_HIP(hipMemcpyAsync(A->d_ja + tail, tmp_c, (size_t)K.far_slots * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
         KRON_HIP(hipStreamSynchronize(s));
@@ -701,7 +715,13 @@ int kron_build(qbh_csr *A)
     }
     tmp_v = nullptr;
     tmp_c = nullptr;
-    if (K.nnz_x > 0) {                               // the cross part behind it (it always fits: its entries came out of these arrays)
+    if (K.nnz_x > 0 && own_x) {                      // the cross part stays where it was gathered (a few MB)
+        K.ja_x = tmpx_c;
+        K.val_x = tmpx_v;
+        K.own_x = true;
+        tmpx_c = nullptr;
+        tmpx_v = nullptr;
+    } else if (K.nnz_x > 0) {                        // the cross part behind it (it always fits: its entries came out of these arrays)
         KRON_HIP(hipMemcpyAsync(A->d_val + tail, tmpx_v, (size_t)K.nnz_x * sizeof(d2), hipMemcpyDeviceToDevice, s));
         KRON_HIP(hipMemcpyAsync(A->d_ja + tail, tmpx_c, (size_t)K.nnz_x * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
         KRON_HIP(hipStreamSynchronize(s));
@@ -719,6 +739,10 @@ int kron_build(qbh_csr *A)
     }
     K.inplace = true;
     KRON_TRY(kron_geometry(A));
+    if (getenv("QBH_PRINT_PTRS"))
+        fprintf(stderr, "qbhip kron arrays: ia %p ja %p val %p | ia_n %p fp %p | ja_f %p val_f %p | wd_n %p wd_f %p | far %p | nnz_n %lld far_slots %lld\n", (void *)A->d_ia,
+                (void *)A->d_ja, (void *)A->d_val, (void *)K.ia_n, (void *)K.ia_f, (void *)K.ja_f, (void *)K.val_f, (void *)K.wd_n, (void *)K.wd_f, (void *)K.d_far,
+                (long long)K.nnz_n, (long long)K.far_slots);
 #undef KRON_HIP
 #undef KRON_TRY
     K.active = true;
@@ -1771,6 +1795,7 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
             K.xt_cap = 0;
             QBH_HIP(qbh::dev_alloc(&K.d_xt, (size_t)A->ncols * sizeof(d2)));
             K.xt_cap = A->ncols;
+            if (getenv("QBH_PRINT_PTRS")) fprintf(stderr, "qbhip kron xt %p x %p y %p\n", (void *)K.d_xt, (const void *)x, (void *)y);
             K.xt_of = nullptr;
         }
         if (prof) {

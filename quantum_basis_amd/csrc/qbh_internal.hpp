@@ -256,7 +256,7 @@ int wave2_kernel_occupancy(int tpr, int ops);
 int launch_kron_tile(const d2 *x, d2 *xt, int64_t n, const KronTile &t, hipStream_t s);
 int launch_kron_check(const int64_t *ia, const int32_t *ja, int64_t nrows, int64_t S, int *d_flag, hipStream_t s);
 int launch_kron_count(const int64_t *ia, const int32_t *ja, int64_t nrows, const KronTile &t, int32_t *cnt_near, int32_t *cnt_far, hipStream_t s);
-int launch_build_slotdesc(const int64_t *gia, int64_t ngroups, int64_t slots, WaveDesc *wd, int64_t n_wb, hipStream_t s);
+int launch_build_slotdesc(const int64_t *gia, int64_t ngroups, int64_t slots, WaveDesc *wd, int64_t n_wb, int64_t shift, hipStream_t s);
 int launch_zero_cut_groups(const WaveDesc *wd, int64_t n_wb, int64_t nrows, d2 *far, hipStream_t s);
 int launch_kron_group_width(const int32_t *cnt_far, int64_t nrows, int64_t ngroups, int32_t *gw, hipStream_t s);
 int launch_kron_fill_sliced(const int64_t *ia, const int32_t *ja, const d2 *val, int64_t nrows, const KronTile &t, const int64_t *ia_n,
@@ -515,6 +515,7 @@ struct qbh_csr {
         bool     active = false;
         bool     inplace = false;       // the handle's d_ja / d_val hold [near | far | cross]: there is no CSR beside the split
         bool     own_far = false;       // padded far groups: ja_f / val_f are allocations of their own
+        bool     own_x = false;         // one class: the small cross part lives in its own arrays (its room aligns the far part)
         qbh::KronMap map{};             // product structure of the rows: one class (two-species) or several (cut single-species sector)
         qbh::KronTile t{0, 0, 8};       // one class: tiled order of the LOCAL rows (NU = major indices of this shard)
         int64_t  U0 = 0, NUg = 0;       // one class: first major index of the shard, major indices of the whole operator

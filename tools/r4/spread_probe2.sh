@@ -1,0 +1,5 @@
+#!/bin/bash
+R=/root/repo
+cd $R
+export QBH_NO_AUTOTUNE=1 SPMV_REPS=10 QBH_PRINT_PTRS=1
+python3 tools/spmv_time.py hubbard_4x4_half "" "" "" "" "" "" 2>&1 | grep -E "ms/launch|qbhip kron"
