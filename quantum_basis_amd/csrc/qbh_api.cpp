@@ -460,6 +460,9 @@ int kron_build(qbh_csr *A)
         if (A->nrows != A->ncols || A->row_offset != 0) return QBH_OK;
         K.map = A->basis.classes;
         K.map.sliced = 1;
+        // QBH_CROSS_IN_NEAR=0: the entries across the cut as a third pass of their own (k_spmv_wave, tiled columns); default: they
+        // stay in the near part -- natural columns, gathers that miss -- which saves the third pass's reading of the vectors
+        K.map.cross_near = (getenv("QBH_CROSS_IN_NEAR") && atoi(getenv("QBH_CROSS_IN_NEAR")) == 0) ? 0 : 1;
         K.t = qbh::KronTile{K.map.S[0], K.map.NU[0], 8};
         K.U0 = 0;
         K.NUg = 0;
@@ -638,6 +641,7 @@ int kron_build(qbh_csr *A)
     }
     if (K.nnz_f == 0 || K.nnz_n + K.nnz_f + K.nnz_x != A->nnz) return fail(QBH_OK);       // nothing far: the split buys nothing
     if (multi && (double)K.nnz_x > 0.4 * (double)A->nnz) return fail(QBH_OK);               // mostly unstructured: not worth three passes
+    if (multi && K.map.cross_near && (double)K.nnz_f < 0.15 * (double)A->nnz) return fail(QBH_OK);     // ... nor two, when hardly anything is far
     // ---- everything the conversion needs is allocated BEFORE the CSR is touched ----
     KRON_TRY(qbh::launch_max_rowlen(A->d_ia, n, (int64_t *)A->d_scal, s));
     int64_t maxlen = 0;

@@ -144,6 +144,7 @@ struct KronCls {                        // what the near pass needs of one class
 };
 struct KronMap {
     int      nc, B, sliced;
+    int      cross_near;                // several classes: the unstructured entries stay in the near part (two passes instead of three)
     int64_t  U0;
     int64_t  rbase[kKronMaxClasses + 1], S[kKronMaxClasses], NU[kKronMaxClasses];
     int64_t  fbase[kKronMaxClasses + 1];        // sliced: far rows of class c are numbered fbase[c] + tiled index (full bands only)
@@ -168,8 +169,8 @@ struct KronMap {
         }
         const int64_t lo = rbase[c] + u * S[c];
         if (col >= lo && col < lo + S[c]) return 0;
-        if (col >= rbase[c] && col < rbase[c + 1] && (col - rbase[c]) % S[c] == d) return edge(c, d) ? 2 : 1;
-        return 2;
+        if (col >= rbase[c] && col < rbase[c + 1] && (col - rbase[c]) % S[c] == d && !edge(c, d)) return 1;
+        return cross_near ? 0 : 2;
     }
     // position of (global) column col in the tiled x the far and cross parts gather from, and back
     __host__ __device__ int64_t xcol(int64_t col) const

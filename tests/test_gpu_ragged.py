@@ -28,8 +28,11 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("cross_in_near", [1, 0])
 @pytest.mark.parametrize("name,h", [("chain16", 8), ("chain16", 10), ("kagome12", 6), ("triangular16", 8), ("chain18_n7", 9), ("kagome18", 9), ("kagome18", 11)])
-def test_cut_sector_equals_the_unsplit_operator(name, h):
+def test_cut_sector_equals_the_unsplit_operator(name, h, cross_in_near, monkeypatch):
+    # the entries across the cut: inside the near part (default: two passes) or a third pass of their own
+    monkeypatch.setenv("QBH_CROSS_IN_NEAR", str(cross_in_near))
     n, k, bonds = CASES[name]
     P = q.csr_mat.heisenberg(n, k, bonds, J=1.0, opts=q.make_opts(kron_split=0, **PLAIN))
     ia, ja, val = P.download()
@@ -41,7 +44,7 @@ def test_cut_sector_equals_the_unsplit_operator(name, h):
     crossing = np.mean([(a < h) != (b < h) for a, b in bonds])          # share of the bonds across the cut
     if crossing < 0.3:
         assert info.kron_classes > 1 and info.kron_inplace == 1 and info.kron_sliced == 1
-        assert 0 < info.kron_far_nnz < info.nnz and 0 < info.kron_cross_nnz < 0.4 * info.nnz
+        assert 0 < info.kron_far_nnz < info.nnz and (info.kron_cross_nnz == 0 if cross_in_near else 0 < info.kron_cross_nnz < 0.4 * info.nnz)
     elif crossing > 0.5:
         assert info.kron_classes == 0           # mostly unstructured: permuted, not split -- and still right (below)
     x, y0 = _rand(dim, 1), _rand(dim, 2)
