@@ -1776,6 +1776,15 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
     if (kron_swz == 3) {
         if (!A->d_wctr) kron_swz = 2;
         else QBH_HIP(hipMemsetAsync(A->d_wctr, 0, 3 * 128 * sizeof(unsigned long long), s));
+#ifdef QBH_XCD_TIMING
+        if (A->d_wctr) {                                     // slot 2 of every XCD collects a minimum
+            unsigned long long h[3 * 128] = {0};
+            for (int p = 0; p < 3; ++p)
+                for (int k = 0; k < 8; ++k) h[p * 128 + k * 16 + 2] = ~0ull;
+            QBH_HIP(hipMemcpyAsync(A->d_wctr, h, sizeof(h), hipMemcpyHostToDevice, s));
+            QBH_HIP(hipStreamSynchronize(s));
+        }
+#endif
     }
     const d2 *xl = comm ? x : x + A->row_offset;            // the rank's own block of x
     const d2 *xt = nullptr;                                  // what the far pass gathers from
@@ -1895,6 +1904,24 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
                 nparts = K.grid_x;
             }
         }
+#ifdef QBH_XCD_TIMING
+        {   // debug build: last and first wavefront of every XCD to run out of blocks, relative to the earliest of the pass (100 MHz ticks -> us)
+            unsigned long long h[3 * 128];
+            QBH_HIP(hipStreamSynchronize(s));
+            QBH_HIP(hipMemcpy(h, A->d_wctr, sizeof(h), hipMemcpyDeviceToHost));
+            for (int pass = 1; pass <= 2; ++pass) {
+                const unsigned long long *d = h + pass * 128;
+                unsigned long long lo = ~0ull, hi = 0;
+                for (int k = 0; k < 8; ++k) {
+                    lo = std::min(lo, d[k * 16 + 2]);
+                    hi = std::max(hi, d[k * 16 + 1]);
+                }
+                fprintf(stderr, "[xcd timing] %s pass: last wavefront of each XCD done at (us before the pass ends):", pass == 1 ? "far" : "near");
+                for (int k = 0; k < 8; ++k) fprintf(stderr, " %.0f", (double)(hi - d[k * 16 + 1]) * 0.01);
+                fprintf(stderr, " | first wavefront anywhere idle %.0f us before the end\n", (double)(hi - lo) * 0.01);
+            }
+        }
+#endif
 #ifdef QBH_WAVE_TIMING
         {   // debug build: where the wavefronts of the two passes spend their cycles (s_memtime ticks, 100 MHz)
             unsigned long long h[3 * 128];

@@ -120,10 +120,12 @@ struct DynWalk {
         return c;
     }
     __device__ int64_t take(unsigned int c) const { return xbase + (int64_t)__builtin_amdgcn_readfirstlane(c) * kDynChunk; }
-    __device__ void init(int64_t n_blocks, unsigned long long *counters, int lane)
+    // region: whose eighth of the blocks (0..7); a wavefront starts on its own XCD's and, when that is exhausted, joins the
+    // queues of the others one after the other (k_spmv_wave2's hop loop): the XCDs do not run at the same speed
+    __device__ void init(int64_t n_blocks, unsigned long long *counters, int lane, int region = -1)
     {
         n_wb = n_blocks;
-        const int xcd = blockIdx.x & 7;
+        const int xcd = region < 0 ? (int)(blockIdx.x & 7) : region;
         const int64_t per = (n_blocks + 7) >> 3;
         xbase = xcd * per;
         xend = xbase + per < n_blocks ? xbase + per : n_blocks;
@@ -843,7 +845,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
     BlockWalk walk((a.n_wb + 3) >> 2, a.swizzle, a.chunk_mult);
     constexpr bool dyn = DYN;
     DynWalk dw;
-    if constexpr (dyn) dw.init(a.n_wb, a.wctr, lane);
     auto load_desc = [&](int64_t lb) -> int {
         int64_t w = a.n_wb;
         if (dyn) {
@@ -1041,6 +1042,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
         }
     };
 
+    // Ordered dynamic walk: the XCDs do not run at the same speed (measured with QBH_XCD_TIMING on C3: three of the eight finish
+    // their eighth of the near pass 1.5-1.9 ms before the pass ends, one its eighth of the far pass 1.3 ms early), so a wavefront
+    // whose own XCD's region is exhausted joins the queue of the next XCD's region, and so on round the ring.  The hop is OUTSIDE
+    // the pipelined loop (a pipeline drain and refill per hop, at most 7 per wavefront): the loop itself has no new branch.
+    constexpr int NHOP =
+#ifdef QBH_NO_XCD_STEAL
+        1;
+#else
+        dyn ? 8 : 1;
+#endif
+#ifdef QBH_WAVE_TIMING
+    unsigned long long tm[4] = {0, 0, 0, 0}, nblk = 0;
+#endif
+    for (int hop = 0; hop < NHOP; ++hop) {
+    if constexpr (dyn) dw.init(a.n_wb, a.wctr, lane, (int)((blockIdx.x + hop) & 7));
     int64_t lb = dyn ? 0 : walk.slot;
     int dq0 = load_desc(lb), dq1 = load_desc(lb + step);
     Blk b0 = decode(dq0), b1 = decode(dq1);
@@ -1049,7 +1065,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
     Ops oA;
     issue(b0, cA, vA, oA);
 #ifdef QBH_WAVE_TIMING
-    unsigned long long tm[4] = {0, 0, 0, 0}, nblk = 0;
 #define QBH_TICK(i, t_from) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tm[i] += t_ - (t_from); t_from = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
     unsigned long long t_mark = __builtin_amdgcn_s_memtime();
 #else
@@ -1190,6 +1205,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
         ++nblk;
 #endif
     }
+    flush();
+    }       // hop
+#ifdef QBH_XCD_TIMING            // debug build: when does each XCD run out of blocks?  (s_memtime ticks; slots 1 / 2 behind every XCD's counter)
+    if (dyn && lane == 0) {
+        const unsigned long long t_end = wall_clock64();       // the device-wide constant-rate counter (s_memtime is per XCD)
+        atomicMax(a.wctr + (blockIdx.x & 7) * 16 + 1, t_end);
+        atomicMin(a.wctr + (blockIdx.x & 7) * 16 + 2, t_end);
+    }
+#endif
 #ifdef QBH_WAVE_TIMING
     if (lane == 0) {
         unsigned long long *dbg = a.wctr + 128 - 8;             // last 8 words of this pass's counter block
@@ -1197,7 +1221,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
         atomicAdd(dbg + 4, nblk);
     }
 #endif
-    flush();
     if (a.partials != nullptr) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc[c] = wave_sum(acc[c]);
