@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QBH_VERSION 300
+#define QBH_VERSION 400
 
 /* error codes */
 #define QBH_OK          0

@@ -40,6 +40,27 @@ inline void check(int rc, const char *where)
     throw std::runtime_error(msg);
 }
 
+// Tell the library once what the row index of the matrices the host is about to hand over means: the reference's own order of
+// a two-species fermion basis (Lin tables, src/basis.cc:1144-1190; operators ordered by site).  csr_mat's constructor passes no
+// options, so this sets the process-wide defaults (qbh_opts_set_default): operators created afterwards are held species-major
+// inside the library (Kronecker split), callers keep seeing the reference's order.  A hint that does not describe a matrix
+// changes nothing for that matrix.  n_sites = 0 restores the built-in defaults.
+inline void declare_reference_fermion_basis(int n_sites, int n_up, int n_dn)
+{
+    if (n_sites <= 0) {
+        qbh_opts_set_default(nullptr);
+        return;
+    }
+    qbh_opts o;
+    qbh_opts_set_default(nullptr);
+    qbh_opts_default(&o);
+    o.basis_kind = QBH_BASIS_REF_FERMION2;
+    o.n_sites = n_sites;
+    o.n_up = n_up;
+    o.n_dn = n_dn;
+    qbh_opts_set_default(&o);
+}
+
 class csr_mat;
 inline void vec_randomize(const csr_mat &mat, cplx *x, const uint32_t &seed);
 

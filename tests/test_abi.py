@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert sorted(_lib.EXPORTS) == declared
-    assert L.qbh_version() == 300
+    assert L.qbh_version() == 400
 
 
 def test_struct_layouts_match_header():
@@ -54,6 +54,25 @@ int main(void) {
             C.sizeof(_lib.SolverInfo), _lib.Opts.kron_split.offset, _lib.Opts.kron_minor.offset, _lib.CsrInfo.kron_minor.offset,
             _lib.CsrInfo.kron_band.offset, _lib.CsrInfo.kron_sliced.offset]
     assert got == want
+
+
+def test_process_wide_default_options_for_a_host_whose_constructor_carries_none():
+    """qbh_opts_set_default: what a NULL `opts` means for the reference's csr_mat(lil_mat&): the host
+    names its basis once, qbh_opts_default hands it back, NULL restores the built-in defaults."""
+    L = _lib.lib()
+    o = _lib.Opts()
+    L.qbh_opts_default(C.byref(o))
+    assert (o.basis_kind, o.deterministic, o.kron_split, o.value_dict, o.real_fast_path) == (0, 0, 1, 1, 1)
+    o.basis_kind, o.n_sites, o.n_up, o.n_dn = _lib.BASIS_REF_FERMION2, 16, 8, 8
+    L.qbh_opts_set_default(C.byref(o))
+    try:
+        o2 = _lib.Opts()
+        L.qbh_opts_default(C.byref(o2))
+        assert (o2.basis_kind, o2.n_sites, o2.n_up, o2.n_dn, o2.kron_split) == (_lib.BASIS_REF_FERMION2, 16, 8, 8, 1)
+    finally:
+        L.qbh_opts_set_default(None)
+    L.qbh_opts_default(C.byref(o))
+    assert (o.basis_kind, o.n_sites) == (0, 0)
 
 
 def test_strerror_and_no_device_is_loud():

@@ -35,6 +35,29 @@ def test_row_partition_covers_and_pads():
         assert sum(b - a for a, b in ranges) == ncols
 
 
+def test_kron_row_cuts_are_whole_major_indices_and_even():
+    """cuts of a product basis (index = major * S + minor) for shards that keep the Kronecker split: multiples of S, covering,
+    as even as the major count allows (C3: 12870 majors over 8 ranks)"""
+    for dim, S, world in [(4900, 70, 1), (4900, 70, 2), (4900, 70, 3), (853776, 924, 5), (165636900, 12870, 8), (165636900, 12870, 7)]:
+        cuts = qdist.kron_row_cuts(dim, S, world)
+        assert cuts[0] == 0 and cuts[-1] == dim and len(cuts) == world + 1 and np.all(cuts % S == 0)
+        sizes = np.diff(cuts) // S
+        assert sizes.min() >= 1 and sizes.max() - sizes.min() <= 1
+        nblk, ranges = qdist.partition_from_cuts(cuts)
+        assert nblk == sizes.max() * S and ranges[-1][1] == dim
+
+
+def test_rebalance_cuts_keeps_every_shard_non_empty():
+    """the strictly-increasing fix-up must hold from BOTH sides: a cost profile that piles everything into the last shard used
+    to push interior cuts past dim (advisor, round 3)"""
+    cuts = qdist.rebalance_cuts([0, 2, 4, 6, 8], [1e-9, 1e-9, 1e-9, 1.0])
+    assert cuts[0] == 0 and cuts[-1] == 8 and np.all(np.diff(cuts) > 0)
+    cuts = qdist.rebalance_cuts([0, 100, 200, 300], [3.0, 1.0, 1.0])
+    assert cuts[0] == 0 and cuts[-1] == 300 and np.all(np.diff(cuts) > 0) and cuts[1] < 100
+    with pytest.raises(AssertionError):
+        qdist.rebalance_cuts([0, 1, 2, 3], [1.0, 1.0])          # wrong shape is refused loudly
+
+
 @pytest.mark.parametrize("world,ragged", [(2, False), (3, False), (2, True), (3, True)])
 def test_sharded_lanczos_with_gloo_hooks(world, ragged):
     import torch.multiprocessing as mp

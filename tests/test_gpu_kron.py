@@ -94,6 +94,40 @@ def test_split_from_host_arrays_needs_the_hint_and_is_verified():
         A.destroy()
 
 
+@pytest.mark.parametrize("drop_mod,expect_sliced", [(29, 1), (3, 0)])
+def test_ragged_far_rows_pad_their_groups_or_fall_back_to_plain_rows(drop_mod, expect_sliced):
+    """An operator that keeps the product structure but whose far rows differ INSIDE a group of 8 (here: the up-hops of the minor
+    indices divisible by drop_mod removed -- a correlated hopping): the sliced far part pads such groups (value 0, the row's own
+    tiled column) and then needs arrays of its own; with more than 1/8 padding the far part stays in plain tiled rows.  Both
+    must apply and download exactly like the CSR they came from."""
+    n, nu, nd = 8, 4, 4
+    G = q.csr_mat.hubbard(n, nu, nd, lattices.square(4, 2), opts=q.make_opts(kron_split=0, **PLAIN))
+    ia, ja, val = G.download()
+    dim, S = G.dim, 70
+    G.destroy()
+    rows = np.repeat(np.arange(dim), np.diff(ia))
+    far = (rows // S) != (ja // S)
+    keep = ~(far & ((rows % S) % drop_mod == 0))                   # depends on the minor index only: stays Hermitian
+    nia = np.zeros(dim + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows[keep], minlength=dim), out=nia[1:])
+    nja, nval = ja[keep].astype(np.int64), val[keep]
+    O = qo.Csr(dim, nia, nja, nval, False)
+    A = q.csr_mat(dim, nia, nja, nval, sym=False, opts=q.make_opts(kron_minor=S, kron_split=2, **PLAIN))
+    info = A.info()
+    assert info.kron_minor == S and info.kron_inplace == 1 and info.kron_sliced == expect_sliced
+    x = _rand(dim, 9)
+    y = np.empty(dim, dtype=np.complex128)
+    A.MultMv(x, y)
+    want = O.multmv(x)
+    assert np.abs(y - want).max() <= 2e-13 * np.abs(want).max()
+    dia, dja, dval = A.download()
+    assert np.array_equal(dia, nia) and np.array_equal(dja, nja) and np.array_equal(dval, nval)
+    e = q.locate_E0_lanczos(A).E0
+    eo = qo.locate_E0_lanczos(O, nev=1, ncv=1, maxit=600)["E0"]
+    assert abs(e - eo) <= 1e-10 * abs(eo)
+    A.destroy()
+
+
 def test_split_is_skipped_where_it_does_not_apply():
     n = 8
     bonds = lattices.square(4, 2)
