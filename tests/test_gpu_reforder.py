@@ -122,6 +122,23 @@ def test_reference_order_at_headline_size_beside_its_source():
     lhs, rhs = R.dotc(v.at(0), v.at(3 * n)), R.dotc(v.at(2 * n), v.at(n))          # <x, H y> = <H x, y>
     assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), 1.0)
     v.free()
+
+    def first_steps():
+        vv = R.vec(2)
+        R.randomize(vv.at(0), 1)                                   # the Lehmer stream in the CALLER's element order, whatever the internal one
+        hess = np.zeros(2 * 64)
+        m = q.lanczos(0, 12, 64, n, R, None, hess, "dnmcs", device_v=vv)
+        vv.free()
+        assert m == 12
+        return hess[64:76].copy(), hess[1:13].copy()
+    a_plain, b_plain = first_steps()
+    # ... and the same reference-ordered operator once its basis is NAMED (qbh_csr_set_basis, what bench.py --order reference does):
+    # held species-major internally, split in place -- the recurrence must not notice (a_j, b_j of the first 12 steps)
+    assert R.set_basis(_lib.BASIS_REF_FERMION2, 16, 8, 8)
+    info = R.info()
+    assert info.basis_internal == _lib.BASIS_REF_FERMION2 and info.kron_minor == 12870 and info.kron_inplace == 1 and info.kron_sliced == 1
+    a_split, b_split = first_steps()
+    assert np.allclose(a_split, a_plain, rtol=1e-10, atol=1e-10) and np.allclose(b_split, b_plain, rtol=1e-10, atol=1e-10)
     e_ref = q.locate_E0_lanczos(R, nev=1, ncv=0, maxit=1000).E0
     R.destroy()
     M = q.csr_mat.hubbard(16, 8, 8, bonds, t=1.0, U=1.1, matrix_free=True)
