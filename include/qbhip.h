@@ -97,7 +97,8 @@ typedef struct qbh_opts {
                                 RE-ORDERED IN PLACE (same values, same int32 columns, same 20 B per nonzero; no second copy;
                                 qbh_csr_download merges the parts back).  The structure is verified on the device, the choice
                                 is structural (never timed).  Row shards made of whole major indices (row_offset and the
-                                row count multiples of S) split the same way.  2: the same (kept for older callers); 0: never */
+                                row count multiples of S) split the same way.  1 leaves operators below 1e8 nonzeros alone
+                                (three launches cost more than they save there); 2: whatever has the structure; 0: never */
     int64_t kron_minor;      /* S for an operator created from host / device arrays (0: unknown -> no split); the generators
                                 announce their own; with basis_kind set it is derived from the hint                   */
     int     deterministic;   /* 1: nothing about the operator is decided by a clock and nothing in an SpMV depends on the
