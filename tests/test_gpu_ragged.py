@@ -88,3 +88,34 @@ def test_a_useless_cut_leaves_the_operator_unsplit_but_correct():
     assert np.abs(y - O.multmv(x)).max() <= 2e-13 * np.abs(y).max()
     K.destroy()
     P.destroy()
+
+
+@pytest.mark.parametrize("cross_in_near", [1, 0])
+def test_cut_sector_under_a_communicator_is_merged_back_and_stays_right(cross_in_near, monkeypatch):
+    """Only the one-class split has an exchange format of its own: a cut sector that gets a communicator (here the native
+    one-rank RCCL communicator) is merged back into a CSR -- near, far and cross parts, row by row (kron_restore) -- and keeps
+    its internal order and its vector translation."""
+    from quantum_basis_amd import dist as qdist
+    monkeypatch.setenv("QBH_CROSS_IN_NEAR", str(cross_in_near))
+    n, k, bonds = CASES["kagome18"]
+    P = q.csr_mat.heisenberg(n, k, bonds, J=1.0, opts=q.make_opts(kron_split=0, **PLAIN))
+    ia, ja, val = P.download()
+    dim = P.dim
+    O = qo.Csr(dim, ia, ja.astype(np.int64), val, False)
+    K = q.csr_mat.heisenberg(n, k, bonds, J=1.0, opts=q.make_opts(kron_split=2, basis_kind=_lib.BASIS_SPIN_SECTOR, n_sites=n, n_up=9, n_dn=k, **PLAIN))
+    assert K.info().kron_classes > 1
+    x = _rand(dim, 5)
+    want = O.multmv(x)
+    qdist.NativeComm(dim, rank=0, world=1).attach(K)
+    info = K.info()
+    assert info.kron_classes == 0 and info.kron_minor == 0 and info.basis_internal == _lib.BASIS_SPIN_SECTOR
+    v = K.vec(2)
+    v.upload(x, 0)
+    K.spmv(v.at(0), v.at(dim))
+    assert np.abs(v.download(dim, dim) - want).max() <= 2e-13 * np.abs(want).max()
+    v.free()
+    rk, rp = q.locate_E0_lanczos(K), q.locate_E0_lanczos(P)
+    assert abs(rk.E0 - rp.E0) <= 1e-11 * abs(rp.E0)
+    assert np.abs(O.multmv(rk.eigenvecs) - rk.E0 * rk.eigenvecs).max() < 1e-7
+    K.destroy()
+    P.destroy()
