@@ -394,6 +394,14 @@ typedef struct qbh_comm {
      * elements indexed by GLOBAL column and the gather hook places rank q's block at offset row_cuts[q].  The array is
      * copied by qbh_csr_set_comm. */
     const int64_t *row_cuts;
+    /* optional (NULL = not provided): the gather in PARTS.  A shard whose operator is split (qbh_opts.kron_split) sweeps the
+     * gathered x band range by band range, and in the tiled block every rank sends a band range is a contiguous piece:
+     * allgather_part_begin(ctx, part, nparts, off_len) enqueues, for every rank q, the exchange of the complex128 elements
+     * [off_len[2q], off_len[2q] + off_len[2q+1]) of rank q's block (counted from the start of that block in d_xsend / d_xfull);
+     * the parts are begun in ascending order right after one another.  allgather_part_wait(ctx, part) orders the operator's
+     * stream after the completion of that part; the far pass of the band range runs while the later parts are on the wire. */
+    int    (*allgather_part_begin)(void *ctx, int part, int nparts, const int64_t *off_len);
+    int    (*allgather_part_wait)(void *ctx, int part);
 } qbh_comm;
 int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm);
 

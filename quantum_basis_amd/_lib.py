@@ -66,12 +66,17 @@ ALLWAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
 
 
+PART_BEGIN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64))
+PART_WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+
+
 class Comm(C.Structure):
     _fields_ = [("rank", C.c_int), ("nranks", C.c_int), ("nblk", C.c_int64),
                 ("d_xsend", C.c_void_p), ("d_xfull", C.c_void_p), ("d_scal", C.c_void_p),
                 ("d_xfull_r", C.c_void_p),
                 ("ctx", C.c_void_p), ("allgather_x", ALLGATHER_FN), ("allreduce_sum", ALLREDUCE_FN),
-                ("allgather_begin", ALLGATHER_FN), ("allgather_wait", ALLWAIT_FN), ("row_cuts", C.c_void_p)]
+                ("allgather_begin", ALLGATHER_FN), ("allgather_wait", ALLWAIT_FN), ("row_cuts", C.c_void_p),
+                ("allgather_part_begin", PART_BEGIN_FN), ("allgather_part_wait", PART_WAIT_FN)]      # optional: the gather in parts
 
 
 class Stats(C.Structure):

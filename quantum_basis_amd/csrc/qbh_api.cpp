@@ -1041,7 +1041,7 @@ int finalize(qbh_csr *A)
     const qbh_opts &o = A->opts;
     QBH_HIP(qbh::dev_alloc(&A->d_scal, 16 * sizeof(double)));
     QBH_HIP(hipHostMalloc(&A->h_scal, 16 * sizeof(double)));
-    QBH_HIP(qbh::dev_alloc(&A->d_wctr, 3 * 128 * sizeof(unsigned long long)));
+    QBH_HIP(qbh::dev_alloc(&A->d_wctr, qbh::kWctrRegions * 128 * sizeof(unsigned long long)));
     QBH_HIP(hipEventCreate(&A->ev0));
     QBH_HIP(hipEventCreate(&A->ev1));
     QBH_HIP(hipEventCreate(&A->ev2));
@@ -1526,6 +1526,44 @@ extern "C" int qbh_csr_set_basis(qbh_csr *A, int basis_kind, int n_sites, int n_
     return QBH_OK;
 }
 
+// The gather in parts (qbh_comm::allgather_part_begin): the far pass sweeps the gathered x band range by band range, a band
+// range is one contiguous piece of every rank's tiled block, so the far pass of the first range can run while the later ranges
+// are still on the links -- the step then costs max(wire, near + far) instead of max(wire, near) + far.  Default: 4 parts when
+// there are ranks to receive from (QBH_GATHER_PARTS overrides; 1 = the single gather), none when the communicator has no
+// part hooks (the Python ShardComm) or the far part is not sliced.
+int kron_gather_parts(qbh_csr *A, const qbh_comm *comm)
+{
+    qbh_csr::KronSplit &K = A->kron;
+    K.n_parts = 1;
+    K.part_off_len.clear();
+    if (!K.sliced || !comm->allgather_part_begin || !comm->allgather_part_wait || !A->d_wctr || K.nwb_f <= 0) return QBH_OK;
+    int64_t want = comm->nranks > 1 ? 4 : 1;
+    if (const char *e = getenv("QBH_GATHER_PARTS")) want = atoi(e);
+    const int64_t nfb = K.t.S / K.t.B;                       // full bands (the far pass covers exactly these)
+    want = std::max<int64_t>(1, std::min<int64_t>({want, 8, nfb}));
+    if (want == 1) return QBH_OK;
+    int64_t band[9];
+    for (int64_t k = 0; k <= want; ++k) band[k] = k * nfb / want;
+    K.part_blk[0] = 0;
+    for (int64_t k = 1; k < want; ++k) {                     // first slot of the range's first group -> the block that holds it
+        int64_t slot = 0;
+        QBH_HIP(hipMemcpy(&slot, K.ia_f + band[k] * K.t.NU, sizeof(int64_t), hipMemcpyDeviceToHost));
+        K.part_blk[k] = std::min<int64_t>(slot / 512, K.nwb_f);
+    }
+    K.part_blk[want] = K.nwb_f;
+    K.part_off_len.assign((size_t)want * 2 * (size_t)comm->nranks, 0);
+    for (int64_t k = 0; k < want; ++k)
+        for (int q = 0; q < comm->nranks; ++q) {
+            const int64_t nu = K.cols.cu[q + 1] - K.cols.cu[q];
+            const int64_t off = band[k] * K.t.B * nu;
+            const int64_t end = k == want - 1 ? nu * K.t.S : band[k + 1] * K.t.B * nu;
+            K.part_off_len[((size_t)k * (size_t)comm->nranks + (size_t)q) * 2] = off;
+            K.part_off_len[((size_t)k * (size_t)comm->nranks + (size_t)q) * 2 + 1] = end - off;
+        }
+    K.n_parts = (int)want;
+    return QBH_OK;
+}
+
 extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
 {
     if (!A) return QBH_EINVAL;
@@ -1540,6 +1578,7 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
             A->kron.cols = one;
             A->kron.map.cols = one;
             A->kron.comm_tiled = false;
+            A->kron.n_parts = 1;
             A->kron.xt_of = nullptr;
         }
         return QBH_OK;
@@ -1618,6 +1657,7 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
             K.map.cols = to;
             K.comm_tiled = true;
             K.xt_of = nullptr;
+            QBH_TRY(kron_gather_parts(A, comm));
         } else if (K.active) {
             QBH_TRY(kron_restore(A));
             QBH_TRY(build_geometry(A));
@@ -1775,7 +1815,7 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
     if (const char *e = getenv("QBH_WAVE_SWIZZLE")) kron_swz = atoi(e);
     if (kron_swz == 3) {
         if (!A->d_wctr) kron_swz = 2;
-        else QBH_HIP(hipMemsetAsync(A->d_wctr, 0, 3 * 128 * sizeof(unsigned long long), s));
+        else QBH_HIP(hipMemsetAsync(A->d_wctr, 0, (size_t)(comm && K.n_parts > 1 ? qbh::kWctrRegions : 3) * 128 * sizeof(unsigned long long), s));
 #ifdef QBH_XCD_TIMING
         if (A->d_wctr) {                                     // slot 2 of every XCD collects a minimum
             unsigned long long h[3 * 128] = {0};
@@ -1794,7 +1834,13 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
         if (K.xt_of != (const void *)x) QBH_TRY(qbh::launch_kron_tile(x, send, A->nrows, K.t, s));
         K.xt_of = nullptr;
         async_gather = A->comm.allgather_begin && A->comm.allgather_wait;
-        const int hrc = async_gather ? A->comm.allgather_begin(A->comm.ctx, 0) : A->comm.allgather_x(A->comm.ctx, 0);
+        int hrc = 0;
+        if (K.n_parts > 1) {                                 // band ranges one after another: the far pass follows them (below)
+            for (int k = 0; k < K.n_parts && hrc == 0; ++k)
+                hrc = A->comm.allgather_part_begin(A->comm.ctx, k, K.n_parts, K.part_off_len.data() + (size_t)k * 2 * (size_t)A->comm.nranks);
+        } else {
+            hrc = async_gather ? A->comm.allgather_begin(A->comm.ctx, 0) : A->comm.allgather_x(A->comm.ctx, 0);
+        }
         if (hrc != 0) {
             qbh::set_error("allgather hook failed");
             return QBH_ECOMM;
@@ -1951,13 +1997,31 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
             QBH_HIP(hipEventRecord(A->ev1, s));
             A->ev_pending = true;
         }
-        if (async_gather && A->comm.allgather_wait(A->comm.ctx) != 0) {
-            qbh::set_error("allgather_wait hook failed");
-            return QBH_ECOMM;
+        if (K.n_parts > 1) {
+            // every band range of the far part as soon as its piece of the gathered x is there; a block that straddles a range
+            // boundary belongs to the later range (the pieces complete in order), its cut groups add up through the atomics
+            QBH_TRY(qbh::launch_zero_cut_groups(K.wd_f, K.nwb_f, f.nrows, K.d_far, s));
+            for (int k = 0; k < K.n_parts; ++k) {
+                if (A->comm.allgather_part_wait(A->comm.ctx, k) != 0) {
+                    qbh::set_error("allgather_part_wait hook failed");
+                    return QBH_ECOMM;
+                }
+                if (prof && k == 0) QBH_HIP(hipEventRecord(A->ev2, s));
+                qbh::SpmvArgs fk = f;
+                fk.wd = K.wd_f + K.part_blk[k];
+                fk.n_wb = K.part_blk[k + 1] - K.part_blk[k];
+                fk.wctr = A->d_wctr ? A->d_wctr + (3 + k) * 128 : nullptr;
+                if (fk.n_wb > 0) QBH_TRY(qbh::launch_spmv_wave2(fk, K.tpr_f, 3, (int)std::min<int64_t>(K.grid_f, std::max<int64_t>(fk.n_wb, 8)), s));
+            }
+        } else {
+            if (async_gather && A->comm.allgather_wait(A->comm.ctx) != 0) {
+                qbh::set_error("allgather_wait hook failed");
+                return QBH_ECOMM;
+            }
+            if (prof) QBH_HIP(hipEventRecord(A->ev2, s));
+            if (K.sliced) QBH_TRY(qbh::launch_zero_cut_groups(K.wd_f, K.nwb_f, f.nrows, K.d_far, s));
+            QBH_TRY(qbh::launch_spmv_wave2(f, K.tpr_f, K.sliced ? 3 : 0, K.grid_f, s));
         }
-        if (prof) QBH_HIP(hipEventRecord(A->ev2, s));
-        if (K.sliced) QBH_TRY(qbh::launch_zero_cut_groups(K.wd_f, K.nwb_f, f.nrows, K.d_far, s));
-        QBH_TRY(qbh::launch_spmv_wave2(f, K.tpr_f, K.sliced ? 3 : 0, K.grid_f, s));
         QBH_TRY(qbh::launch_kron_cross_rows(K.ia_x, K.xrow, K.n_xrows, K.ja_x, K.val_x, xt, K.t, K.d_far, s));
         QBH_TRY(qbh::launch_kron_combine(K.d_far, K.t, xl, y, A->nrows, alpha, red ? A->d_partials : nullptr, &nparts, s));
         if (prof) {
@@ -2069,7 +2133,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
             ms.partials = m.partials;
             static const int sec_walk = getenv("QBH_SEC_WALK") ? atoi(getenv("QBH_SEC_WALK")) : 0;
             if (sec_walk) {
-                if (!A->d_wctr) QBH_HIP(qbh::dev_alloc(&A->d_wctr, 3 * 128 * sizeof(unsigned long long)));
+                if (!A->d_wctr) QBH_HIP(qbh::dev_alloc(&A->d_wctr, qbh::kWctrRegions * 128 * sizeof(unsigned long long)));
                 QBH_HIP(hipMemsetAsync(A->d_wctr, 0, 3 * 128 * sizeof(unsigned long long), A->stream));
                 ms.ctr = reinterpret_cast<unsigned int *>(A->d_wctr);
             }

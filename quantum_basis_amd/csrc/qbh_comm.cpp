@@ -95,6 +95,7 @@ struct qbh_native_comm {
     hipStream_t op = nullptr;         // the operator's stream
     hipStream_t side = nullptr;       // RCCL's stream
     hipEvent_t  ready = nullptr, done = nullptr;
+    hipEvent_t  part_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // the gather in parts
     double     *d_xsend = nullptr, *d_xfull = nullptr, *d_xfull_r = nullptr, *d_scal = nullptr;
     bool        in_flight = false;
     char        err[256] = "";
@@ -189,6 +190,65 @@ int hook_gather(void *ctx, int packed)
     return hook_wait(ctx);
 }
 
+// The gather in parts (qbh_comm::allgather_part_begin): part `part` of `nparts` = elements [off, off + len) of every rank's
+// block, one send + one receive per peer in a single group (each xGMI link carries one piece per direction), the own piece a
+// device copy; all on the side stream, in the order of the calls.  An event per part lets the operator's stream wait for one.
+int hook_part_begin(void *ctx, int part, int nparts, const int64_t *off_len)
+{
+    auto *c = static_cast<qbh_native_comm *>(ctx);
+    if (part < 0 || part >= 8 || nparts > 8) return 1;
+    const bool timed = c->owner && c->owner->opts.profile != 0;
+    if (part == 0) {
+        harvest_gather_time(c);
+        if (hipEventRecord(c->ready, c->op) != hipSuccess || hipStreamWaitEvent(c->side, c->ready, 0) != hipSuccess) return 1;
+        if (timed && hipEventRecord(c->t0, c->side) != hipSuccess) return 1;
+    }
+    if (!c->part_done[part] && hipEventCreateWithFlags(&c->part_done[part], hipEventDisableTiming) != hipSuccess) return 1;
+    auto base = [&](int q) { return c->ragged ? c->cuts[(size_t)q] : (int64_t)q * c->nblk; };
+    ncclResult_t r;
+    const int64_t my_off = off_len[2 * c->rank], my_len = off_len[2 * c->rank + 1];
+    if (c->nranks > 1) {
+        if ((r = c->api->GroupStart()) != ncclSuccess) return fail(c, "ncclGroupStart", r);
+        for (int q = 0; q < c->nranks; ++q) {
+            if (q == c->rank) continue;
+            const int64_t off = off_len[2 * q], len = off_len[2 * q + 1];
+            if (len > 0) {
+                r = c->api->Recv(c->d_xfull + (size_t)(base(q) + off) * 2, (size_t)len * 2, ncclDouble, q, c->comm, c->side);
+                if (r != ncclSuccess) {
+                    (void)c->api->GroupEnd();
+                    return fail(c, "ncclRecv", r);
+                }
+            }
+            if (my_len > 0) {
+                r = c->api->Send(c->d_xsend + (size_t)my_off * 2, (size_t)my_len * 2, ncclDouble, q, c->comm, c->side);
+                if (r != ncclSuccess) {
+                    (void)c->api->GroupEnd();
+                    return fail(c, "ncclSend", r);
+                }
+            }
+        }
+        if ((r = c->api->GroupEnd()) != ncclSuccess) return fail(c, "ncclGroupEnd", r);
+    }
+    if (my_len > 0 && hipMemcpyAsync(c->d_xfull + (size_t)(base(c->rank) + my_off) * 2, c->d_xsend + (size_t)my_off * 2, (size_t)my_len * 2 * sizeof(double),
+                                     hipMemcpyDeviceToDevice, c->side) != hipSuccess) {
+        qbh::set_error("qbh_comm: device copy of the rank's own piece failed: %s", hipGetErrorString(hipGetLastError()));
+        return 1;
+    }
+    if (hipEventRecord(c->part_done[part], c->side) != hipSuccess) return 1;
+    if (part == nparts - 1 && timed) {
+        if (hipEventRecord(c->t1, c->side) != hipSuccess) return 1;
+        c->timing_pending = true;
+    }
+    return 0;
+}
+
+int hook_part_wait(void *ctx, int part)
+{
+    auto *c = static_cast<qbh_native_comm *>(ctx);
+    if (part < 0 || part >= 8 || !c->part_done[part]) return 1;
+    return hipStreamWaitEvent(c->op, c->part_done[part], 0) == hipSuccess ? 0 : 1;
+}
+
 int hook_allreduce(void *ctx, int off, int n)
 {
     auto *c = static_cast<qbh_native_comm *>(ctx);
@@ -210,6 +270,8 @@ void destroy_native(qbh_native_comm *c)
     if (c->d_scal) (void)hipFree(c->d_scal);
     if (c->ready) (void)hipEventDestroy(c->ready);
     if (c->done) (void)hipEventDestroy(c->done);
+    for (hipEvent_t e : c->part_done)
+        if (e) (void)hipEventDestroy(e);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -339,6 +401,8 @@ extern "C" int qbh_comm_create_rccl(qbh_csr *A, const void *uid128, int rank, in
     h.allreduce_sum = hook_allreduce;
     h.allgather_begin = hook_begin;
     h.allgather_wait = hook_wait;
+    h.allgather_part_begin = hook_part_begin;
+    h.allgather_part_wait = hook_part_wait;
     h.row_cuts = c->ragged ? c->cuts.data() : nullptr;
     rc = qbh_csr_set_comm(A, &h);
     if (rc != QBH_OK) return bail(rc);

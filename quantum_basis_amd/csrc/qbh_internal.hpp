@@ -40,6 +40,8 @@ void set_error(const char *fmt, ...);
 
 // descriptor of one wave block of k_spmv_wave: the whole rows [r0, r0(next)) holding the nonzeros [p0, p0(next));
 // entry n_wb is a sentinel {nnz, nrows}
+constexpr int kWctrRegions = 3 + 8;
+
 struct WaveDesc {
     int64_t p0;
     int32_t r0;
@@ -546,12 +548,18 @@ struct qbh_csr {
         const void *xt_last = nullptr;  // measurement switch QBH_KRON_REUSE_TILE: the x of the previous SpMV
         const void *xt_of = nullptr;    // the vector whose tiled copy d_xt holds (written by the pass that produced it); consumed by one SpMV
         bool     fold = false;          // set by a driver for the duration of a solve: its BLAS-1 passes write the tiled copy of the next x
+        // the gather in parts (comm_tiled, sliced far part, a communicator with allgather_part_begin): part k = bands
+        // [k nfb / n_parts, (k + 1) nfb / n_parts) of every rank's tiled block (the last part takes the narrow edge band along);
+        // the far pass of part k = blocks [part_blk[k], part_blk[k + 1]) and starts when that part has arrived
+        int      n_parts = 1;
+        int64_t  part_blk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        std::vector<int64_t> part_off_len;      // [n_parts][2 * nranks]: offset, length (elements) inside each rank's block
     } kron;
     // wave kernel geometry (uncoded complex128 values; QBH_KERNEL_WAVE)
     bool     use_wave = false;
     bool     broken = false;         // a failed call left the arrays inconsistent: every SpMV is refused
     bool     kron_off = false;       // the split was merged back into a CSR (kron_restore): stay unsplit
-    unsigned long long *d_wctr = nullptr;   // [3 * 128] work counters of the dynamic walk (main / far / near launch)
+    unsigned long long *d_wctr = nullptr;   // [kWctrRegions * 128] work counters of the dynamic walk (main / far / near launch, far launches of a gather in parts)
     int      tuned = -1;             // kernel timed best at creation: -1 not timed, 0 row kernel, 1 wave kernel (kept across rebuilds)
     double   tune_ms[2] = {0.0, 0.0}; // the two times (row kernel, wave kernel) when it was
     qbh::WaveDesc *d_wd = nullptr;

@@ -73,10 +73,12 @@ class ShardComm:
     """Owns the exchange buffers (torch tensors in HBM) and the hook callbacks.  cuts: global row cuts of a ragged
     (nnz-balanced) partition, or None for uniform blocks."""
 
-    def __init__(self, ncols, rank=None, world=None, device=None, stream=None, group=None, cuts=None):
+    def __init__(self, ncols, rank=None, world=None, device=None, stream=None, group=None, cuts=None, parts=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
+        self.parts = parts           # offer the gather in parts (qbh_comm.allgather_part_begin) to a split shard
+        self.n_parts_begun = 0
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
@@ -107,6 +109,8 @@ class ShardComm:
         self._ar = _lib.ALLREDUCE_FN(self._allreduce)
         self._ag_begin = _lib.ALLGATHER_FN(self._allgather_begin)
         self._ag_wait = _lib.ALLWAIT_FN(self._allgather_wait)
+        self._pt_begin = _lib.PART_BEGIN_FN(self._part_begin)
+        self._pt_wait = _lib.PART_WAIT_FN(self._part_wait)
         self._work = None
         self.n_async = 0             # exchanges started through the begin/wait pair
         self.overlap = True          # hand the begin/wait pair to the library (local columns overlap the gather)
@@ -181,6 +185,36 @@ class ShardComm:
             self.errors.append(traceback.format_exc())
             return 1
 
+    def _part_begin(self, _ctx, part, nparts, off_len):
+        """One part of the gather in parts: elements [off, off + len) of every rank's block, one broadcast per rank, on the
+        operator's stream (no overlap on this rig: what it exercises is the library's part geometry across real ranks)."""
+        try:
+            with self._ctx():
+                for q, (a, _b) in enumerate(self.ranges):
+                    off, ln = int(off_len[2 * q]), int(off_len[2 * q + 1])
+                    if ln <= 0:
+                        continue
+                    base = a if self.cuts is not None else q * self.nblk
+                    dst = self.xfull[2 * (base + off):2 * (base + off + ln)]
+                    if q == self.rank:
+                        dst.copy_(self.xsend[2 * off:2 * (off + ln)])
+                    src = q if self.group is None else self.dist.get_global_rank(self.group, q)
+                    if self.direct:
+                        self.dist.broadcast(dst, src=src, group=self.group)
+                    else:
+                        self.torch.cuda.current_stream().synchronize()
+                        h = dst.cpu()
+                        self.dist.broadcast(h, src=src, group=self.group)
+                        dst.copy_(h)
+            self.n_parts_begun += 1
+            return 0
+        except Exception:
+            self.errors.append(traceback.format_exc())
+            return 1
+
+    def _part_wait(self, _ctx, part):
+        return 0                     # everything above ran on (or was ordered with) the operator's stream
+
     def _allreduce(self, _ctx, off, n):
         try:
             with self._ctx():
@@ -230,6 +264,9 @@ class ShardComm:
         if self.overlap:
             c.allgather_begin = self._ag_begin
             c.allgather_wait = self._ag_wait
+        if self.parts:
+            c.allgather_part_begin = self._pt_begin
+            c.allgather_part_wait = self._pt_wait
         self._struct = c
         check(lib().qbh_csr_set_comm(mat.handle, C.byref(c)), "qbh_csr_set_comm")
         mat._comm = self          # keep the callbacks and buffers alive as long as the operator

@@ -115,12 +115,15 @@ def gpu_sharded_solver(rank, world, port, backend, out_dir, matrix_free=False, s
     dist.destroy_process_group()
 
 
-def gpu_sharded_kron(rank, world, port, backend, out_dir, mixed=False):
+def gpu_sharded_kron(rank, world, port, backend, out_dir, mixed=False, parts=0, native=False):
     """Row shards of WHOLE MAJOR INDICES of a product-basis operator (complex128 CSR, Hubbard 4x3: dim 853,776, S = 924): every
     shard is split in place, the ranks exchange the TILED copies of their blocks, the near pass runs while the gather is in
     flight.  mixed: rank 1 creates its shard unsplit -- the ranks then agree on the plain exchange and rank 0 merges its parts
-    back into a CSR (kron_restore)."""
+    back into a CSR (kron_restore).  parts: the gather in that many band ranges (qbh_comm.allgather_part_begin), the far pass of
+    a range following its piece; native: the library's own RCCL communicator (one rank: every piece is the rank's own)."""
     import torch
+    if parts:
+        os.environ["QBH_GATHER_PARTS"] = str(parts)
     dist = _init(rank, world, port, backend)
     torch.cuda.set_device(0)
     import quantum_basis_amd as q
@@ -135,16 +138,24 @@ def gpu_sharded_kron(rank, world, port, backend, out_dir, mixed=False):
         r0, r1 = int(cuts[rank]), int(cuts[rank + 1])
         A = q.csr_mat.hubbard(L, ne, ne, bonds, rows=(r0, r1), opts=opts)
         assert A.info().kron_minor == (S if split else 0)
-        comm = qdist.ShardComm(dim, rank=rank, world=world, device=torch.device("cuda", 0), stream=stream, cuts=cuts).attach(A)
+        if native:
+            comm = qdist.NativeComm(dim, rank=rank, world=world, cuts=cuts if world > 1 else None).attach(A)
+        else:
+            comm = qdist.ShardComm(dim, rank=rank, world=world, device=torch.device("cuda", 0), stream=stream, cuts=cuts, parts=bool(parts)).attach(A)
         assert A.info().kron_minor == (0 if mixed else S)          # agreed by all ranks, or merged back
         res = q.locate_E0_lanczos(A, nev=1, ncv=1, maxit=400)
-        assert not comm.errors, comm.errors
+        if not native:
+            assert not comm.errors, comm.errors
+            assert (comm.n_parts_begun > 0) == bool(parts), comm.n_parts_begun
         x = q.vec_randomize(A, seed=1)
         np.save(os.path.join(out_dir, "x_%d.npy" % rank), x)
         np.save(os.path.join(out_dir, "vec_%d.npy" % rank), res.eigenvecs)
         if rank == 0:
             np.save(os.path.join(out_dir, "res.npy"), np.array([res.E0, res.steps["E0"], res.steps["V0"]]))
             np.save(os.path.join(out_dir, "hess.npy"), res.hessenberg_E0)
+        if native:
+            comm.detach(A)
+            A.destroy()
     dist.barrier()
     dist.destroy_process_group()
 

@@ -52,14 +52,17 @@ def test_sharded_solver_matches_single_gpu(world, backend, mf):
     assert abs(np.linalg.norm(vec) - 1.0) < 1e-12
 
 
-@pytest.mark.parametrize("world,backend,mixed", [(2, "gloo", False), (3, "gloo", False), (1, "nccl", False), (2, "gloo", True)])
-def test_sharded_kron_split_matches_single_gpu(world, backend, mixed):
+@pytest.mark.parametrize("world,backend,mixed,parts,native", [(2, "gloo", False, 0, False), (3, "gloo", False, 0, False), (1, "nccl", False, 0, False),
+                                                              (2, "gloo", True, 0, False), (2, "gloo", False, 4, False), (3, "gloo", False, 7, False),
+                                                              (1, "nccl", False, 0, True), (1, "nccl", False, 4, True)])
+def test_sharded_kron_split_matches_single_gpu(world, backend, mixed, parts, native):
     """SURVEY 8e for the headline form: shards of whole major indices keep the Kronecker split, exchange tiled blocks, overlap
-    the near pass with the gather; E0, a_j / b_j, step counts and the eigenvector equal the one-rank run."""
+    the near pass with the gather; E0, a_j / b_j, step counts and the eigenvector equal the one-rank run.  parts: the gather in
+    band ranges with the far pass following range by range (what the native RCCL communicator does by default for N > 1)."""
     import torch.multiprocessing as mp
     import dist_worker
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(dist_worker.gpu_sharded_kron, args=(world, _free_port(), backend, tmp, mixed), nprocs=world, join=True)
+        mp.spawn(dist_worker.gpu_sharded_kron, args=(world, _free_port(), backend, tmp, mixed, parts, native), nprocs=world, join=True)
         res = np.load(tmp + "/res.npy")
         hess = np.load(tmp + "/hess.npy")
         x = np.concatenate([np.load(tmp + "/x_%d.npy" % r) for r in range(world)])
