@@ -726,6 +726,9 @@ def main():
         out["exchange"] = {"bytes_received_per_gpu_per_spmv": int(elem * dim * (world - 1) / world), "element_bytes": elem,
                            "ms_per_gather": round(head["ms_gather"], 4) if head["ms_gather"] > 0 else None,
                            "gathers": head["n_gather"],
+                           # > 1: the tiled blocks travel as that many band ranges and the far pass follows range by range; the
+                           # per-rank ms_spmv then contains whatever the far pass waited for the later ranges
+                           "gather_parts": int(A.info().gather_parts),
                            "allreduce": "<= 3 doubles per reduction point"}
         # per rank: SpMV kernel ms (both parts of a split shard), gather ms on the side stream, how much of the gather the
         # locally-owned columns hide, and the rank's own roofline on ITS algorithmic bytes (local nnz, rows, the whole x)
@@ -795,7 +798,9 @@ def main():
                 f_cw = 0 if not f_coded else (1 if fi.value_dict <= 256 else 2)
                 vec_b = 8 if f_real else 16
                 fbytes = fi.nnz * (4 + (f_cw if f_coded else 16)) + (fi.nrows + 1) * 8 + fi.nrows * 2 * vec_b
-                ftr, fsrc = traffic_of("%s|%s|%s" % (args.workload, KERNEL_KEY[fi.kernel], "dict" if f_coded else "plain") + ("|real" if f_real else ""))
+                f_kronc = bool(fi.kron_minor > 0 and fi.kron_sliced and f_coded and f_real)      # the sliced coded split (qbh_kronc.hip)
+                ftr, fsrc = traffic_of("%s|%s|%s" % (args.workload, KERNEL_KEY[fi.kernel], "dict" if f_coded else "plain") + ("|real" if f_real else "")
+                                       + ("|kronc" if f_kronc else ""))
                 out["fast_path"] = {
                     "value": round(fp["steps"] / fp["elapsed"], 4), "unit": "lanczos_iters/s", "steps": fp["steps"],
                     "ms_per_step": round(1e3 * fp["elapsed"] / fp["steps"], 4),
@@ -803,7 +808,10 @@ def main():
                              else "complex128 vectors, %d-byte value codes" % f_cw,
                     "value_dict": fi.value_dict, "real_gather": f_real, "e0": fp["e0"],
                     "e0_rel_diff_vs_complex128": (abs(fp["e0"] - head["e0"]) / abs(head["e0"])) if (fp["e0"] is not None and head["e0"]) else None,
-                    "roofline": {"bound": "hbm", "kernel": KERNEL_NAME[fi.kernel], "achieved": round(fbytes / fp["ms_spmv"] / 1e6, 2),
+                    "kron_split": ({"minor": int(fi.kron_minor), "band": int(fi.kron_band), "form": "both parts sliced in groups of 16 rows, near x block in LDS",
+                                    "stored_far_entries": int(fi.kron_far_nnz)} if f_kronc else None),
+                    "roofline": {"bound": "hbm", "kernel": "k_kronc_far + k_kronc_near + k_kron_tile_re" if f_kronc else KERNEL_NAME[fi.kernel],
+                                 "achieved": round(fbytes / fp["ms_spmv"] / 1e6, 2),
                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(fbytes / fp["ms_spmv"] / 1e6 / HBM_PEAK_GBPS, 4),
                                  "traffic": ftr, "traffic_source": fsrc, "bytes_per_launch": fbytes,
                                  "ms_per_launch": round(fp["ms_spmv"], 4), "launches": fp["n_spmv"],

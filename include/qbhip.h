@@ -184,6 +184,7 @@ typedef struct qbh_csr_info {
     int     basis_internal;                  /* QBH_BASIS_*: != 0 when the operator is held in another order than the caller's */
     int     kron_classes;                    /* classes of the product structure: 1 two-species operators, > 1 a cut single-species sector */
     int64_t kron_cross_nnz;                  /* nonzeros of the third (unstructured) part                                       */
+    int     gather_parts;                    /* communicator attached: band ranges the gather of x travels in (1 = one gather)   */
 } qbh_csr_info;
 int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info);
 

@@ -44,7 +44,7 @@ class CsrInfo(C.Structure):
                 ("device", C.c_int), ("stream", C.c_void_p), ("create_ms", C.c_double),
                 ("create_bytes_in", C.c_int64), ("kron_minor", C.c_int64), ("kron_far_nnz", C.c_int64), ("kron_band", C.c_int), ("kron_sliced", C.c_int),
                 ("kron_inplace", C.c_int), ("tuned", C.c_int), ("tune_ms_rows", C.c_double), ("tune_ms_wave", C.c_double),
-                ("basis_internal", C.c_int), ("kron_classes", C.c_int), ("kron_cross_nnz", C.c_int64)]
+                ("basis_internal", C.c_int), ("kron_classes", C.c_int), ("kron_cross_nnz", C.c_int64), ("gather_parts", C.c_int)]
 
 
 class LanczosRow(C.Structure):

@@ -792,18 +792,108 @@ void kronc_release(qbh_csr *A)
         for (void *q : {(void *)P->d_ia, (void *)P->d_ja, (void *)P->d_code, (void *)P->d_rb, (void *)P->d_bp})
             if (q) (void)hipFree(q);
     if (K.d_xt) (void)hipFree(K.d_xt);
+    for (void *q : {(void *)K.sl.gia_n, (void *)K.sl.gia_f, (void *)K.sl.ja_n, (void *)K.sl.ja_f, (void *)K.sl.code_n, (void *)K.sl.code_f, (void *)K.sl.d_far, (void *)K.sl.d_dictr})
+        if (q) (void)hipFree(q);
     K = qbh_csr::KronCoded{};
+}
+
+// The sliced form of the coded split (qbh_kronc.hip): both parts in groups of 16 rows, near columns relative to the major
+// index's block (its x block lives in LDS during the near pass), far columns in the tiled order.  Needs 1-byte codes with a free
+// code for the padding, the block of x (S doubles) inside one workgroup's LDS, and room for a second copy of the coded operator.
+int kronc_build_sliced(qbh_csr *A, int64_t S, int64_t NU)
+{
+    const int64_t n = A->nrows;
+    hipStream_t s = A->stream;
+    if (A->dict_mode != 1 || A->code_w != 1 || A->n_dict > 255 || NU > 65535 || S > 20 * 1024 || qbh::kronc_near_lds_bytes(S) > (size_t)159 * 1024) return QBH_OK;
+    qbh_csr::KronCoded &K = A->kronc;
+    qbh::KroncSliced &L = K.sl;
+    const int nb = (int)((S + 15) / 16);
+    const int64_t G = (int64_t)nb * NU;
+    int32_t *wn = nullptr, *wf = nullptr;
+    auto fail = [&](int code) {
+        if (wn) (void)hipFree(wn);
+        if (wf) (void)hipFree(wf);
+        kronc_release(A);
+        return code;
+    };
+#define KS_HIP(call)                                                                  \
+    do {                                                                              \
+        hipError_t e_ = (call);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            (void)hipGetLastError();                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? QBH_OK : QBH_EHIP);               \
+        }                                                                             \
+    } while (0)
+#define KS_TRY(expr)                           \
+    do {                                       \
+        const int rc_ = (expr);                \
+        if (rc_ != QBH_OK) return fail(rc_);   \
+    } while (0)
+    KS_HIP(hipMalloc(&wn, (size_t)G * sizeof(int32_t)));
+    KS_HIP(hipMalloc(&wf, (size_t)G * sizeof(int32_t)));
+    KS_TRY(qbh::launch_kronc_widths(A->d_ia, A->d_ja, S, NU, nb, wn, wf, s));
+    KS_HIP(hipMalloc(&L.gia_n, (size_t)(G + 1) * sizeof(int64_t)));
+    KS_HIP(hipMalloc(&L.gia_f, (size_t)(G + 1) * sizeof(int64_t)));
+    KS_TRY(qbh::exclusive_scan(wn, G, L.gia_n, s));
+    KS_TRY(qbh::exclusive_scan(wf, G, L.gia_f, s));
+    (void)hipFree(wn);
+    wn = nullptr;
+    (void)hipFree(wf);
+    wf = nullptr;
+    KS_HIP(hipMemcpy(&L.slots_n, L.gia_n + G, sizeof(int64_t), hipMemcpyDeviceToHost));
+    KS_HIP(hipMemcpy(&L.slots_f, L.gia_f + G, sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (L.slots_f == 0 || L.slots_n + L.slots_f > 2 * A->nnz + 64 * G) return fail(QBH_OK);          // nothing far, or rows too ragged to pad
+    {
+        size_t free_b = 0, total_b = 0;
+        const size_t need = (size_t)L.slots_n * 3 + (size_t)L.slots_f * 3 + (size_t)G * 16 * 8 + (size_t)n * 8 + ((size_t)1 << 30);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < need) return fail(QBH_OK);
+    }
+    constexpr size_t kPad = 1024;            // the passes read up to 8 x 64 slots past a group's end without clamping (qbh_kronc.hip)
+    KS_HIP(hipMalloc(&L.ja_n, ((size_t)L.slots_n + kPad) * sizeof(uint16_t)));
+    KS_HIP(hipMalloc(&L.code_n, (size_t)L.slots_n + kPad));
+    KS_HIP(hipMalloc(&L.ja_f, ((size_t)L.slots_f + kPad) * sizeof(uint16_t)));
+    KS_HIP(hipMalloc(&L.code_f, (size_t)L.slots_f + kPad));
+    KS_HIP(hipMemsetAsync(L.ja_n + L.slots_n, 0, kPad * sizeof(uint16_t), s));
+    KS_HIP(hipMemsetAsync(L.code_n + L.slots_n, 0, kPad, s));
+    KS_HIP(hipMemsetAsync(L.ja_f + L.slots_f, 0, kPad * sizeof(uint16_t), s));
+    KS_HIP(hipMemsetAsync(L.code_f + L.slots_f, 0, kPad, s));
+    KS_HIP(hipMalloc(&L.d_far, (size_t)G * 16 * sizeof(double)));
+    {
+        std::vector<qbh::d2> hd((size_t)A->n_dict);
+        std::vector<double> hr(256, 0.0);
+        KS_HIP(hipMemcpy(hd.data(), A->d_dict, hd.size() * sizeof(qbh::d2), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < hd.size(); ++i) hr[i] = hd[i].x;
+        KS_HIP(hipMalloc(&L.d_dictr, 256 * sizeof(double)));
+        KS_HIP(hipMemcpy(L.d_dictr, hr.data(), 256 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    KS_HIP(hipMalloc(&K.d_xt, (size_t)n * sizeof(double)));
+    KS_TRY(qbh::launch_kronc_fill(A->d_ia, A->d_ja, A->d_code, S, NU, nb, A->n_dict, L.gia_n, L.ja_n, L.code_n, L.gia_f, L.ja_f, L.code_f, s));
+    if (!A->d_wctr) KS_HIP(qbh::dev_alloc(&A->d_wctr, qbh::kWctrRegions * 128 * sizeof(unsigned long long)));
+    KS_HIP(hipStreamSynchronize(s));
+#undef KS_HIP
+#undef KS_TRY
+    L.S = S;
+    L.NU = NU;
+    L.nb = nb;
+    L.active = true;
+    K.t = qbh::KronTile{S, NU, 16};
+    K.active = true;
+    return QBH_OK;
 }
 
 // Same decomposition as kron_build, for the row kernel: the near part keeps rows and columns, the far part has rows AND
 // columns in the tiled order of KronTile with B = 16 (one 128-byte line of doubles per major index and band); the far
 // launch gathers from the tiled copy of the packed x and accumulates onto the near launch's result at orig(row).
-// Opt-in (QBH_KRON_CODED=1) until it is timed at creation like the complex128 form.
+// Measured slower than the unsplit operator; QBH_KRON_CODED=1 builds it for comparison.
 int kronc_build(qbh_csr *A)
 {
     kronc_release(A);
-    const int want = getenv("QBH_KRON_CODED") ? atoi(getenv("QBH_KRON_CODED")) : 0;
-    if (!want || A->opts.kron_split == 0) return QBH_OK;
+    // kron_split as for the complex128 form: 1 splits operators of 1e8 nonzeros and more, 2 whatever has the structure -- into the
+    // sliced form (kronc_build_sliced) when its preconditions hold, else not at all.  QBH_KRON_CODED = 0 / 1 / 2 overrides
+    // (1: the earlier form for the row kernel, measured slower than the unsplit operator; kept for comparison).
+    int want = (A->opts.kron_split == 2 || (A->opts.kron_split == 1 && A->nnz >= 100000000)) ? 2 : 0;
+    if (const char *e = getenv("QBH_KRON_CODED")) want = atoi(e);
+    if (!want || A->opts.kron_split == 0 || !A->opts.real_fast_path) return QBH_OK;       // only the all-real operation runs it
     if (A->kernel != QBH_KERNEL_ROWS || A->d_code == nullptr || !A->values_real || A->kind != 0 || A->has_rem || A->nrows != A->ncols ||
         A->row_offset != 0 || A->nnz <= 0)
         return QBH_OK;
@@ -823,6 +913,7 @@ int kronc_build(qbh_csr *A)
     QBH_HIP(hipStreamSynchronize(s));
     QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
     if (bad) return QBH_OK;
+    if (want == 2) return kronc_build_sliced(A, S, NU);
     qbh_csr::KronCoded &K = A->kronc;
     int B = 16;
     while (B > 2 && (double)NU * B * 8 > 2.5e6) B >>= 1;
@@ -1480,6 +1571,7 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->kron_inplace = A->kron.active && A->kron.inplace ? 1 : 0;
     info->kron_classes = 0;
     info->kron_cross_nnz = 0;
+    info->gather_parts = A->has_comm ? ((A->kron.active && A->kron.comm_tiled) ? A->kron.n_parts : 1) : 0;
     if (A->kron.active) {
         const qbh_csr::KronSplit &K = A->kron;
         info->n_blocks = K.nwb_n + K.nwb_f + K.nwb_x;
@@ -1495,7 +1587,8 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->basis_internal = A->basis.kind;
     if (A->kronc.active) {                       // the coded form of the split (row kernel, packed-double vectors)
         info->kron_minor = A->kronc.t.S;
-        info->kron_far_nnz = A->kronc.far_p.nnz;
+        info->kron_far_nnz = A->kronc.sl.active ? A->kronc.sl.slots_f : A->kronc.far_p.nnz;      // sliced: stored far entries (padding included)
+        info->kron_sliced = A->kronc.sl.active ? 1 : 0;
         info->kron_band = A->kronc.t.B;
     }
     return QBH_OK;
@@ -2231,11 +2324,17 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         else QBH_HIP(hipMemsetAsync(A->d_wctr, 0, 3 * 128 * sizeof(unsigned long long), A->stream));
     }
     const bool kronc = A->kronc.active && realm && a.xr != nullptr && a.y_re != nullptr && !A->has_comm && !A->has_rem && !(A->debug & 1);
+    int kronc_parts = 0;
     if (kronc) {
         // coded Kronecker split, all-real operation: tiled copy of the packed x, near launch (full epilogue), far launch
         // (tiled rows and columns, accumulates at orig(row), fused reductions of the finished y)
         const qbh_csr::KronCoded &K = A->kronc;
         QBH_TRY(qbh::launch_kron_tile_re(a.xr, K.d_xt, A->nrows, K.t, A->stream));
+        if (K.sl.active) {
+            // sliced form: far pass (row sums in group order), near pass from the LDS-resident block of x with the whole epilogue
+            QBH_TRY(qbh::launch_kronc(K.sl, A->d_dict, A->n_dict, K.d_xt, a.xr, a.y_re, a.alpha, a.beta, a.gamma, red ? A->d_partials : nullptr,
+                                      A->opts.deterministic ? nullptr : reinterpret_cast<unsigned int *>(A->d_wctr), &kronc_parts, A->stream));
+        } else {
         qbh::SpmvArgs np = a;
         np.ia = K.near_p.d_ia;
         np.ja = K.near_p.d_ja;
@@ -2264,6 +2363,8 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         fp.kNU = K.t.NU;
         fp.kB = K.t.B;
         QBH_TRY(qbh::launch_spmv(fp, A->kernel, K.far_p.npb, K.far_p.tpr, K.far_p.grid, A->stream));
+        kronc_parts = K.far_p.grid;
+        }
     } else if (wave) {
         a.wd = A->d_wd;
         a.n_wb = A->n_wb;
@@ -2290,7 +2391,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         QBH_HIP(hipEventRecord(A->ev1, A->stream));
         A->ev_pending = true;
     }
-    int grid_last = kronc ? A->kronc.far_p.grid : wave ? wave_grid_used : A->grid;
+    int grid_last = kronc ? kronc_parts : wave ? wave_grid_used : A->grid;
     if (A->has_rem) {
         if (async_gather) {
             if (A->comm.allgather_wait(A->comm.ctx) != 0) {

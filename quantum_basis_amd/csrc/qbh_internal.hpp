@@ -298,6 +298,26 @@ int launch_randomize(d2 *x, double *xr, int64_t n, int64_t global_offset, uint32
 int launch_fill_const(d2 *x, int64_t n, double re, hipStream_t s);
 int launch_max_rowlen(const int64_t *d_ia, int64_t nrows, int64_t *d_out, hipStream_t s);
 int blas_grid(int64_t n);
+
+// sliced form of the coded Kronecker split (qbh_kronc.hip): groups of 16 rows, entry k of row j at gia[g] + 16 k + j
+struct KroncSliced {
+    bool      active = false;
+    int64_t   S = 0, NU = 0;
+    int       nb = 0;                   // bands of 16 minor indices (the last may be narrower)
+    int64_t   slots_n = 0, slots_f = 0; // stored entries (nonzeros + padding)
+    int64_t  *gia_n = nullptr, *gia_f = nullptr;      // [nb * NU + 1] group pointers: near groups (maj, b), far groups (b, maj)
+    uint16_t *ja_n = nullptr;           // near columns relative to the major index's block
+    uint16_t *ja_f = nullptr;           // far columns: the target major index (gathered from the tiled x, KronTile{S, NU, 16})
+    uint8_t  *code_n = nullptr, *code_f = nullptr;
+    double   *d_far = nullptr;          // [nb * NU * 16] far row sums in far-group order
+    double   *d_dictr = nullptr;        // [256] real parts of the value dictionary, zero from entry n_dict on (the padding code)
+};
+int launch_kronc_widths(const int64_t *ia, const int32_t *ja, int64_t S, int64_t NU, int nb, int32_t *wn, int32_t *wf, hipStream_t s);
+int launch_kronc_fill(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t S, int64_t NU, int nb, int zcode, const int64_t *gia_n,
+                      uint16_t *ja_n, uint8_t *code_n, const int64_t *gia_f, uint16_t *ja_f, uint8_t *code_f, hipStream_t s);
+size_t kronc_near_lds_bytes(int64_t S);
+int launch_kronc(const KroncSliced &K, const d2 *dict, int n_dict, const double *xt, const double *x, double *y, double alpha, double beta,
+                 double gamma, double *partials, unsigned int *ctr, int *nparts_out, hipStream_t s);
 int launch_pack_real(const d2 *x, double *out, int64_t n, int *flag, hipStream_t s);
 int launch_unpack_real(const double *in, d2 *out, int64_t n, hipStream_t s);
 int launch_imag_norm(const d2 *x, int64_t n, double *partials, hipStream_t s);
@@ -513,6 +533,7 @@ struct qbh_csr {
         qbh::KronTile t{0, 0, 0};
         CsrPart  near_p, far_p;
         double  *d_xt = nullptr;
+        qbh::KroncSliced sl;            // the sliced form (both parts; near gathers from LDS): near_p / far_p are then empty
     } kronc;
     struct KronSplit {
         bool     active = false;

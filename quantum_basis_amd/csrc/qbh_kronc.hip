@@ -1,0 +1,418 @@
+// The Kronecker split for the library's DEFAULT form of a real operator: dictionary-coded values (1 byte per nonzero) applied
+// to packed-double vectors (qbh_opts.real_fast_path).  Same decomposition as qbh_kron.hip -- index = major * S + minor, every
+// entry changes the minor index (near) or the major index alone (far) -- but both parts are stored SLICED: groups of 16 rows
+// (one band of 16 minor indices of one major index), entry k of row j of a group at slot gia[g] + 16 k + j, short rows padded
+// with a code whose value is zero.  A wavefront reads 64 consecutive slots per instruction (4 entries of each of the 16 rows):
+// column and code streams are perfectly coalesced without row pointers or staging, and
+//   * far part (gathers from the band-major "tiled" copy of x, KronTile{S, NU, 16}; a far entry keeps the minor index, so its
+//     column is stored as the target major index alone, 2 bytes): the 16 rows of a group gather ONE 128-byte line of the
+//     tiled x per entry -- 4 lines per wave instruction instead of up to 64 separate requests;
+//   * near part (columns relative to the major index's own block, 2 bytes each): the whole block of x -- S doubles, 103 KB at
+//     C3 -- is loaded into LDS once per major index and every gather is an LDS read.
+// Far pass first (row sums into a buffer in group order), then the near pass with the fused epilogue
+// y = alpha (near + far) + beta y + gamma x and the reductions <x, y>, |y|^2 of the finished y.
+// The row kernel this replaces is bound by the RATE of 8-byte gathers through the L1 (420-490 G/s); here no
+// gather is an L1 request of its own.  Reference operation: csr_mat<T>::MultMv2 (src/sparse.cc:262-289) on a real operator.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+
+#include "qbh_internal.hpp"
+
+namespace qbh {
+namespace {
+
+constexpr int kGB = 16;                      // rows per group = doubles per 128-byte line
+
+// widths (entries per row, padded) of the near group (maj, b) and of the far group (b, maj): one thread per group
+__global__ __launch_bounds__(256) void k_kronc_widths(const int64_t *ia, const int32_t *ja, int64_t S, int64_t NU, int nb, int32_t *wn, int32_t *wf)
+{
+    const int64_t G = (int64_t)nb * NU;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < G; g += (int64_t)gridDim.x * 256) {
+        const int64_t maj = g / nb, b = g - maj * nb;
+        const int64_t d0 = b * kGB, wb = S - d0 < kGB ? S - d0 : kGB;
+        int mn = 0, mf = 0;
+        for (int64_t j = 0; j < wb; ++j) {
+            const int64_t r = maj * S + d0 + j;
+            int cn = 0, cf = 0;
+            for (int64_t q = ia[r]; q < ia[r + 1]; ++q) {
+                if (ja[q] / S == maj) ++cn;
+                else ++cf;
+            }
+            mn = cn > mn ? cn : mn;
+            mf = cf > mf ? cf : mf;
+        }
+        wn[g] = mn * kGB;
+        wf[b * NU + maj] = mf * kGB;
+    }
+}
+
+// one thread per (near group, lane j): scatters the row's entries into the two sliced parts and pads both to the group widths
+__global__ __launch_bounds__(256) void k_kronc_fill(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t S, int64_t NU, int nb,
+                                                    uint8_t zcode, const int64_t *gia_n, uint16_t *ja_n, uint8_t *code_n,
+                                                    const int64_t *gia_f, uint16_t *ja_f, uint8_t *code_f)
+{
+    const int64_t G = (int64_t)nb * NU;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < G * kGB; i += (int64_t)gridDim.x * 256) {
+        const int64_t g = i >> 4, j = i & 15;
+        const int64_t maj = g / nb, b = g - maj * nb;
+        const int64_t d0 = b * kGB, wb = S - d0 < kGB ? S - d0 : kGB;
+        const int64_t gf = b * NU + maj;
+        const int64_t bn = gia_n[g], wn = (gia_n[g + 1] - bn) >> 4;
+        const int64_t bf = gia_f[gf], wf = (gia_f[gf + 1] - bf) >> 4;
+        int64_t kn = 0, kf = 0;
+        const int64_t r0 = maj * S + d0;           // first row of the group: a valid element for the padding columns
+        if (j < wb) {
+            const int64_t r = r0 + j;
+            for (int64_t q = ia[r]; q < ia[r + 1]; ++q) {
+                const int64_t c = ja[q];
+                if (c / S == maj) {
+                    ja_n[bn + kn * kGB + j] = (uint16_t)(c - maj * S);
+                    code_n[bn + kn * kGB + j] = code[q];
+                    ++kn;
+                } else {
+                    ja_f[bf + kf * kGB + j] = (uint16_t)(c / S);          // the minor index is the row's own
+                    code_f[bf + kf * kGB + j] = code[q];
+                    ++kf;
+                }
+            }
+        }
+        const int64_t own = j < wb ? j : 0;
+        for (; kn < wn; ++kn) {
+            ja_n[bn + kn * kGB + j] = (uint16_t)(d0 + own);
+            code_n[bn + kn * kGB + j] = zcode;
+        }
+        for (; kf < wf; ++kf) {
+            ja_f[bf + kf * kGB + j] = (uint16_t)maj;
+            code_f[bf + kf * kGB + j] = zcode;
+        }
+    }
+}
+
+// ---- the two passes ----------------------------------------------------------------------------------------------------------
+// One wavefront works on NG groups at a time: all their column / code loads (UN instructions of 64 slots per group, clamped to
+// the group) are in flight before the first gather.  lane = 16 ks + j: row j of the group, entries ks, ks + 4, ...
+// NT: non-temporal stream loads.  A group starts on a 32-byte (columns) / 16-byte (codes) boundary, so consecutive instructions
+// share the line they straddle: with plain loads the L1 keeps it (far pass: 3.25e8 -> 2.74e8 requests at the L2, 4.8 -> 4.3 ms),
+// the near pass -- short of LDS and VALU cycles, not of requests -- is faster with the stream kept out of the L1 (4.3 vs 5.1 ms)
+template <int NG, int UN, typename ColT, bool NT>
+struct GroupStream {
+    ColT    c[NG][UN];
+    uint8_t cb[NG][UN];
+    int     w[NG];
+    // slot of entry k = 4 u + ks of row j: base + 16 k + j = base + 64 u + lane.  Instruction u is issued when the group has
+    // entries 4 u .. (a wave-uniform test, so no index is clamped); its lanes past the group's end read slots of the next group
+    // (valid columns; the arrays end in zeroed padding) and are masked out of the sum
+    __device__ __forceinline__ void load(int gi, const ColT *ja, const uint8_t *code, int64_t base, int64_t end, int lane)
+    {
+        const int wg = (int)((end - base) >> 4);
+        w[gi] = wg;
+        const ColT *jp = ja + base + lane;
+        const uint8_t *cp = code + base + lane;
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (4 * u < wg) c[gi][u] = NT ? __builtin_nontemporal_load(jp + 64 * u) : jp[64 * u];
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (4 * u < wg) cb[gi][u] = NT ? __builtin_nontemporal_load(cp + 64 * u) : cp[64 * u];
+    }
+};
+
+__device__ __forceinline__ double quad_sum(double v)        // sum over the four sub-slices ks of a row: lanes 0..15 hold the row sums
+{
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+struct KroncArgs {
+    const int64_t *gia_n, *gia_f;
+    const uint16_t *ja_n;
+    const uint16_t *ja_f;       // far columns: the target MAJOR index (the element is (that major index, the row's minor index))
+    const uint8_t *code_n, *code_f;
+    const d2 *dict;
+    const double *dictr;        // the dictionary's real parts, 256 doubles, entry n_dict = 0 (the padding code)
+    int n_dict;
+    int64_t S, NU;
+    int nb;
+    const double *xt, *x;
+    double *far, *y;
+    double alpha, beta, gamma;
+    double *partials;
+    unsigned int *ctr;
+    int chunk;                  // far pass: groups per wavefront turn (<= 32)
+    int abl;                    // ablation bits (QBH_KRONC_ABL, wrong results by design): 1 no dictionary lookups, 2 no gathers, 4 no row sums
+};
+
+template <int NG, int UN>
+__global__ __launch_bounds__(256) void k_kronc_far(KroncArgs a)
+{
+    __shared__ double dict_s[256];
+    dict_s[threadIdx.x] = (int)threadIdx.x < a.n_dict ? a.dict[threadIdx.x].x : 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t G = (int64_t)a.nb * a.NU;
+    // every XCD sweeps one contiguous eighth of the groups (band-major: a band of the tiled x stays in that XCD's L2), its
+    // wavefronts take chunks of a.chunk groups round robin -- small enough that what the XCD's ~900 wavefronts work on at any
+    // time lies inside ONE band (NU groups): chunks of 32 spread them over three bands, 4.8 MB of x against a 4 MB L2
+    const int xcd = blockIdx.x & 7, nwx = (int)(gridDim.x >> 3) * 4, wx = (int)(blockIdx.x >> 3) * 4 + wv;
+    const int64_t per = (G + 7) >> 3, xb = xcd * per, xe = xb + per < G ? xb + per : G;
+    const int CH = a.chunk;
+    for (int64_t g0 = xb + (int64_t)wx * CH; g0 < xe; g0 += (int64_t)nwx * CH) {
+        const int ng = (int)(xe - g0 < CH ? xe - g0 : CH);
+        const int64_t gp = a.gia_f[g0 + (lane <= ng ? lane : ng)];
+        GroupStream<NG, UN, uint16_t, false> cur;
+        int64_t base[NG];
+        auto fetch = [&](GroupStream<NG, UN, uint16_t, false> &st, int64_t (&bs)[NG], int i0) {
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                const int i = i0 + gi < ng ? i0 + gi : ng - 1;
+                bs[gi] = __shfl(gp, i, 64);
+                st.load(gi, a.ja_f, a.code_f, bs[gi], __shfl(gp, i + 1, 64), lane);
+            }
+        };
+        fetch(cur, base, 0);
+        for (int i0 = 0; i0 < ng; i0 += NG) {
+            double xv[NG][UN];
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                // element (major u', minor 16 b + j) of the tiled x: band base + u' * (width of the band) + j
+                const int64_t g = g0 + (i0 + gi < ng ? i0 + gi : ng - 1);
+                const int64_t b = g / a.NU;
+                const int wB = (int)(a.S - b * kGB < kGB ? a.S - b * kGB : kGB);
+                const double *xb_ = a.xt + b * kGB * a.NU + (lane & 15);
+#pragma unroll
+                for (int u = 0; u < UN; ++u) xv[gi][u] = (4 * u < cur.w[gi] && !(a.abl & 2)) ? xb_[(int)cur.c[gi][u] * wB] : (double)cur.c[gi][u];
+            }
+            // the next groups' streams go out behind the gathers, in front of the arithmetic that waits for them
+            GroupStream<NG, UN, uint16_t, false> nxt;
+            int64_t nbase[NG];
+            fetch(nxt, nbase, i0 + NG < ng ? i0 + NG : i0);
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                double acc = 0.0;
+#pragma unroll
+                for (int u = 0; u < UN; ++u)
+                    if (4 * u < cur.w[gi]) {
+                        const double v = ((a.abl & 1) ? (double)cur.cb[gi][u] : dict_s[cur.cb[gi][u]]) * xv[gi][u];
+                        if (4 * u + (lane >> 4) < cur.w[gi]) acc += v;
+                    }
+                if (cur.w[gi] > 4 * UN) {                                            // rows longer than 4 UN entries
+                    const int64_t g = g0 + i0 + gi;
+                    const int64_t b = g / a.NU;
+                    const int wB = (int)(a.S - b * kGB < kGB ? a.S - b * kGB : kGB);
+                    const double *xb_ = a.xt + b * kGB * a.NU + (lane & 15);
+                    for (int k = 4 * UN + (lane >> 4); k < cur.w[gi]; k += 4) {
+                        const int64_t s = base[gi] + (int64_t)k * kGB + (lane & 15);
+                        acc += dict_s[a.code_f[s]] * xb_[(int)a.ja_f[s] * wB];
+                    }
+                }
+                if (!(a.abl & 4)) acc = quad_sum(acc);
+                if (lane < kGB && i0 + gi < ng) a.far[(g0 + i0 + gi) * kGB + lane] = acc;
+            }
+            cur = nxt;
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) base[gi] = nbase[gi];
+        }
+    }
+}
+
+// One workgroup of 16 wavefronts per major index at a time (drawn from a counter): x[maj * S .. + S) into LDS, then wavefront w
+// takes the groups b = w, w + 16, ... of that major index, NG at a time, the streams of the next NG in flight meanwhile.  The
+// value dictionary is read through the L1 (2 KB, always resident): the LDS pipe is what this pass is short of.
+template <int NG, int UN>
+__global__ __launch_bounds__(1024) void k_kronc_near(KroncArgs a)
+{
+    extern __shared__ double lds[];                 // [S] window of x, [256] dictionary, [48] scratch, s_maj
+    double *win = lds;
+    double *dict = lds + a.S;                       // a small dictionary sits in one row of banks: its lookups do not conflict
+    double *red = dict + 256;
+    int *s_maj = reinterpret_cast<int *>(red + 48);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 256) dict[tid] = a.dictr[tid];
+    double acc3[2] = {0.0, 0.0};                    // <x, y>, |y|^2
+    const int nb = a.nb;
+    unsigned int turn = 0;
+    for (;;) {
+        __syncthreads();                            // the previous window is no longer read
+        if (tid == 0) *s_maj = a.ctr ? (int)atomicAdd(a.ctr, 1u) : (int)(blockIdx.x + turn * gridDim.x);      // no counter: static turns
+        ++turn;
+        __syncthreads();
+        const int64_t maj = *s_maj;
+        if (maj >= a.NU) break;
+        const double *xb = a.x + maj * a.S;
+        for (int64_t o = 0; o < a.S; o += 8 * 1024) {          // eight loads per thread in flight at a time
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = o + tid + 1024 * u < a.S ? xb[o + tid + 1024 * u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (o + tid + 1024 * u < a.S) win[o + tid + 1024 * u] = v[u];
+        }
+        __syncthreads();
+        const int64_t gbase = maj * nb;
+        for (int r0 = 0; r0 < nb; r0 += 16 * 32) {       // rounds of 32 groups per wavefront
+            // group pointers of this wavefront's groups in the round: lane l <-> group b = r0 + wv + 16 l
+            const int bl = r0 + wv + 16 * (lane & 31);
+            const int64_t gq = gbase + (bl < nb ? bl : nb - 1);
+            const int64_t p0 = a.gia_n[gq], p1 = a.gia_n[gq + 1];
+            const int ng = r0 + wv < nb ? ((nb - 1 - r0 - wv) / 16 + 1 < 32 ? (nb - 1 - r0 - wv) / 16 + 1 : 32) : 0;
+            struct Pass {
+                GroupStream<NG, UN, uint16_t, true> st;
+                double yo[NG], fr[NG];
+            };
+            auto fetch = [&](Pass &P, int i0) {
+#pragma unroll
+                for (int gi = 0; gi < NG; ++gi) {
+                    const int i = i0 + gi < ng ? i0 + gi : (ng > 0 ? ng - 1 : 0);
+                    P.st.load(gi, a.ja_n, a.code_n, __shfl(p0, i, 64), __shfl(p1, i, 64), lane);
+                    const int b = r0 + wv + 16 * i;
+                    const int64_t d = (int64_t)b * kGB + (lane & 15);
+                    const bool rowok = lane < kGB && d < a.S && i0 + gi < ng;
+                    P.yo[gi] = (rowok && a.beta != 0.0) ? a.y[maj * a.S + d] : 0.0;
+                    P.fr[gi] = rowok ? a.far[((int64_t)b * a.NU + maj) * kGB + lane] : 0.0;
+                }
+            };
+            Pass cur;
+            if (ng > 0) fetch(cur, 0);
+            for (int i0 = 0; i0 < ng; i0 += NG) {
+                Pass nxt;
+                fetch(nxt, i0 + NG < ng ? i0 + NG : i0);
+#pragma unroll
+                for (int gi = 0; gi < NG; ++gi) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int u = 0; u < UN; ++u)
+                        if (4 * u < cur.st.w[gi]) {
+                            const double v = ((a.abl & 1) ? (double)cur.st.cb[gi][u] : dict[cur.st.cb[gi][u]]) *
+                                             ((a.abl & 2) ? (double)cur.st.c[gi][u] : win[cur.st.c[gi][u]]);
+                            if (4 * u + (lane >> 4) < cur.st.w[gi]) acc += v;
+                        }
+                    const int64_t gb = cur.st.w[gi] > 4 * UN ? __shfl(p0, i0 + gi, 64) : 0;          // outside the divergent loop
+                    for (int k = 4 * UN + (lane >> 4); k < cur.st.w[gi]; k += 4) {
+                        const int64_t s = gb + (int64_t)k * kGB + (lane & 15);
+                        acc += dict[a.code_n[s]] * win[a.ja_n[s]];
+                    }
+                    if (!(a.abl & 4)) acc = quad_sum(acc);
+                    const int b = r0 + wv + 16 * (i0 + gi);
+                    const int64_t d = (int64_t)b * kGB + (lane & 15);
+                    if (lane < kGB && d < a.S && i0 + gi < ng) {
+                        const double xi = win[d];
+                        const double yn = a.alpha * (acc + cur.fr[gi]) + a.beta * cur.yo[gi] + a.gamma * xi;
+                        a.y[maj * a.S + d] = yn;
+                        acc3[0] += xi * yn;
+                        acc3[1] += yn * yn;
+                    }
+                }
+                cur = nxt;
+            }
+        }
+    }
+    if (a.partials != nullptr) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            double v = acc3[c];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) red[c * 16 + wv] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double s0 = 0.0, s1 = 0.0;
+            for (int w = 0; w < 16; ++w) {
+                s0 += red[w];
+                s1 += red[16 + w];
+            }
+            a.partials[(size_t)blockIdx.x * 3 + 0] = s0;
+            a.partials[(size_t)blockIdx.x * 3 + 1] = 0.0;
+            a.partials[(size_t)blockIdx.x * 3 + 2] = s1;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_kronc_widths(const int64_t *ia, const int32_t *ja, int64_t S, int64_t NU, int nb, int32_t *wn, int32_t *wf, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kronc_widths, dim3(4096), dim3(256), 0, s, ia, ja, S, NU, nb, wn, wf);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+int launch_kronc_fill(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t S, int64_t NU, int nb, int zcode, const int64_t *gia_n,
+                      uint16_t *ja_n, uint8_t *code_n, const int64_t *gia_f, uint16_t *ja_f, uint8_t *code_f, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kronc_fill, dim3(8192), dim3(256), 0, s, ia, ja, code, S, NU, nb, (uint8_t)zcode, gia_n, ja_n, code_n, gia_f, ja_f, code_f);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+size_t kronc_near_lds_bytes(int64_t S) { return (size_t)(S + 256 + 48 + 2) * sizeof(double); }
+
+// y <- alpha H x + beta y + gamma x on packed-double vectors; partials (or nullptr): 3 per workgroup of the near launch,
+// *nparts_out workgroups.  ctr: one unsigned counter (the near launch's draw of major indices), or nullptr for static turns
+// (qbh_opts.deterministic: the partial sums of the reductions are then formed in the same order in every run).
+int launch_kronc(const KroncSliced &K, const d2 *dict, int n_dict, const double *xt, const double *x, double *y, double alpha, double beta,
+                 double gamma, double *partials, unsigned int *ctr, int *nparts_out, hipStream_t s)
+{
+    KroncArgs a{};
+    a.gia_n = K.gia_n;
+    a.gia_f = K.gia_f;
+    a.ja_n = K.ja_n;
+    a.ja_f = K.ja_f;
+    a.code_n = K.code_n;
+    a.code_f = K.code_f;
+    a.dict = dict;
+    a.dictr = K.d_dictr;
+    a.n_dict = n_dict;
+    a.S = K.S;
+    a.NU = K.NU;
+    a.nb = K.nb;
+    a.xt = xt;
+    a.x = x;
+    a.far = K.d_far;
+    a.y = y;
+    a.alpha = alpha;
+    a.beta = beta;
+    a.gamma = gamma;
+    a.partials = partials;
+    a.ctr = ctr;
+    // tuning switches (measurement only): groups a wavefront has in flight per pass
+    static const int far_ng = getenv("QBH_KRONC_FAR_NG") ? atoi(getenv("QBH_KRONC_FAR_NG")) : 1;
+    static const int near_ng = getenv("QBH_KRONC_NEAR_NG") ? atoi(getenv("QBH_KRONC_NEAR_NG")) : 2;
+    auto far_k = far_ng == 1 ? k_kronc_far<1, 6> : far_ng == 3 ? k_kronc_far<3, 6> : k_kronc_far<2, 6>;
+    auto near_k = near_ng == 1 ? k_kronc_near<1, 6> : near_ng == 3 ? k_kronc_near<3, 6> : k_kronc_near<2, 6>;
+    static int far_occ = 0;
+    static size_t attr_done = 0;
+    if (far_occ == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, far_k, 256, 0) != hipSuccess || n <= 0) n = 4;
+        far_occ = n > 8 ? 8 : n;
+    }
+    const size_t lds = kronc_near_lds_bytes(K.S);
+    if (attr_done < lds) {
+        QBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(near_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = lds;
+    }
+    {
+        static const int far_chunk = getenv("QBH_KRONC_FAR_CHUNK") ? atoi(getenv("QBH_KRONC_FAR_CHUNK")) : 0;
+        // the wavefronts of one XCD (32 CUs x far_occ workgroups x 4) together stay inside about half a band
+        int64_t c = far_chunk > 0 ? far_chunk : K.NU / (2 * (int64_t)32 * far_occ * 4);
+        a.chunk = (int)(c < 1 ? 1 : c > 32 ? 32 : c);
+    }
+    {
+        static const int abl = getenv("QBH_KRONC_ABL") ? atoi(getenv("QBH_KRONC_ABL")) : 0;
+        a.abl = abl;
+    }
+    if (ctr) QBH_HIP(hipMemsetAsync(ctr, 0, sizeof(unsigned int), s));
+    hipLaunchKernelGGL(far_k, dim3(256 * far_occ), dim3(256), 0, s, a);
+    QBH_HIP(hipGetLastError());
+    const int grid_n = (int)(K.NU < 256 ? K.NU : 256);
+    hipLaunchKernelGGL(near_k, dim3(grid_n), dim3(1024), lds, s, a);
+    QBH_HIP(hipGetLastError());
+    if (nparts_out) *nparts_out = grid_n;
+    return QBH_OK;
+}
+
+}  // namespace qbh

@@ -143,6 +143,7 @@ def gpu_sharded_kron(rank, world, port, backend, out_dir, mixed=False, parts=0, 
         else:
             comm = qdist.ShardComm(dim, rank=rank, world=world, device=torch.device("cuda", 0), stream=stream, cuts=cuts, parts=bool(parts)).attach(A)
         assert A.info().kron_minor == (0 if mixed else S)          # agreed by all ranks, or merged back
+        assert A.info().gather_parts == (parts if parts else 1)
         res = q.locate_E0_lanczos(A, nev=1, ncv=1, maxit=400)
         if not native:
             assert not comm.errors, comm.errors
