@@ -668,7 +668,9 @@ def main():
         # the kernel moves its own format's bytes, not SURVEY 8(d)'s: the fraction is defined on those (cannot exceed 1)
         vec_b = 8 if real_used else 16
         fmt_bytes = info.nnz * (4 + (code_w if coded else 16)) + (info.nrows + 1) * 8 + info.nrows * 2 * vec_b
-        roof = {"bound": "hbm", "kernel": KERNEL_NAME[info.kernel], "achieved": round(fmt_bytes / ms_spmv / 1e6, 2), "peak": HBM_PEAK_GBPS,
+        kronc = bool(info.kron_minor and info.kron_sliced and coded and real_used)      # the sliced coded split (qbh_kronc.hip)
+        roof = {"bound": "hbm", "kernel": "k_kronc_far + k_kronc_near + k_kron_tile_re" if kronc else KERNEL_NAME[info.kernel],
+                "achieved": round(fmt_bytes / ms_spmv / 1e6, 2), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(fmt_bytes / ms_spmv / 1e6 / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "traffic_ratio": (round(traffic / fmt_bytes, 3) if traffic else None), "traffic_source": tsrc,
                 "bytes_per_launch": fmt_bytes, "ms_per_launch": round(ms_spmv, 4), "launches": head["n_spmv"],
@@ -696,7 +698,9 @@ def main():
                                          if not (coded or real_used) else "value codes %s, real fast path %s" % (coded, real_used),
                                          "value_dict": info.value_dict, "real_gather": real_used, "deterministic": bool(args.deterministic),
                                          "kron_split": ({"minor": int(info.kron_minor), "band": int(info.kron_band), "far_nnz": int(info.kron_far_nnz), "far_sliced": bool(info.kron_sliced),
-                                                         "launches_per_spmv": ("k_kron_tile_re + k_spmv_rows (near) + k_spmv_rows (far, tiled rows and columns; QBH_KRON_CODED=1)"
+                                                         "launches_per_spmv": ("k_kron_tile_re + k_kronc_far (sliced, whole lines of the tiled x) + k_kronc_near (sliced, x block in LDS, epilogue)"
+                                                                               if (info.value_dict and info.kron_sliced) else
+                                                                               "k_kron_tile_re + k_spmv_rows (near) + k_spmv_rows (far, tiled rows and columns; QBH_KRON_CODED=1)"
                                                                                if info.value_dict else
                                                                                ("k_zero_cut_groups + k_spmv_wave2<.,3> (far, sliced) + k_spmv_wave2<.,2> (near); the tiled copy of x is written by the "
                                                                                 "pass that produces x (k_axpy_norm_tile8), k_kron_tile only in front of a driver's first step"
@@ -800,7 +804,7 @@ def main():
                 fbytes = fi.nnz * (4 + (f_cw if f_coded else 16)) + (fi.nrows + 1) * 8 + fi.nrows * 2 * vec_b
                 f_kronc = bool(fi.kron_minor > 0 and fi.kron_sliced and f_coded and f_real)      # the sliced coded split (qbh_kronc.hip)
                 ftr, fsrc = traffic_of("%s|%s|%s" % (args.workload, KERNEL_KEY[fi.kernel], "dict" if f_coded else "plain") + ("|real" if f_real else "")
-                                       + ("|kronc" if f_kronc else ""))
+                                       + ("|kron_sliced" if f_kronc else ""))
                 out["fast_path"] = {
                     "value": round(fp["steps"] / fp["elapsed"], 4), "unit": "lanczos_iters/s", "steps": fp["steps"],
                     "ms_per_step": round(1e3 * fp["elapsed"] / fp["steps"], 4),

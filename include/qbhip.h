@@ -98,7 +98,13 @@ typedef struct qbh_opts {
                                 qbh_csr_download merges the parts back).  The structure is verified on the device, the choice
                                 is structural (never timed).  Row shards made of whole major indices (row_offset and the
                                 row count multiples of S) split the same way.  1 leaves operators below 1e8 nonzeros alone
-                                (three launches cost more than they save there); 2: whatever has the structure; 0: never */
+                                (three launches cost more than they save there); 2: whatever has the structure; 0: never.
+                                The library's DEFAULT format (value_dict + real_fast_path: 1-byte value codes applied to
+                                packed-double vectors) follows the same rule with a split of its own: a second, re-ordered
+                                copy of the coded operator (3 B per nonzero beside the 5 B per nonzero of the coded CSR, which
+                                stays for complex vectors, shards and qbh_csr_download) whose near pass gathers from the block
+                                of x held in LDS -- taken when S doubles fit one workgroup's LDS (S <= 20480) and the major
+                                count fits 16 bits; used by the all-real solves only (qbh_csr_info.kron_minor / kron_sliced) */
     int64_t kron_minor;      /* S for an operator created from host / device arrays (0: unknown -> no split); the generators
                                 announce their own; with basis_kind set it is derived from the hint                   */
     int     deterministic;   /* 1: nothing about the operator is decided by a clock and nothing in an SpMV depends on the

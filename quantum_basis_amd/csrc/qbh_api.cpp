@@ -2333,7 +2333,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         if (K.sl.active) {
             // sliced form: far pass (row sums in group order), near pass from the LDS-resident block of x with the whole epilogue
             QBH_TRY(qbh::launch_kronc(K.sl, A->d_dict, A->n_dict, K.d_xt, a.xr, a.y_re, a.alpha, a.beta, a.gamma, red ? A->d_partials : nullptr,
-                                      A->opts.deterministic ? nullptr : reinterpret_cast<unsigned int *>(A->d_wctr), &kronc_parts, A->stream));
+                                      reinterpret_cast<unsigned int *>(A->d_wctr), A->opts.deterministic != 0, &kronc_parts, A->stream));
         } else {
         qbh::SpmvArgs np = a;
         np.ia = K.near_p.d_ia;

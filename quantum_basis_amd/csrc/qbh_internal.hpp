@@ -317,7 +317,7 @@ int launch_kronc_fill(const int64_t *ia, const int32_t *ja, const uint8_t *code,
                       uint16_t *ja_n, uint8_t *code_n, const int64_t *gia_f, uint16_t *ja_f, uint8_t *code_f, hipStream_t s);
 size_t kronc_near_lds_bytes(int64_t S);
 int launch_kronc(const KroncSliced &K, const d2 *dict, int n_dict, const double *xt, const double *x, double *y, double alpha, double beta,
-                 double gamma, double *partials, unsigned int *ctr, int *nparts_out, hipStream_t s);
+                 double gamma, double *partials, unsigned int *ctr, bool static_near, int *nparts_out, hipStream_t s);
 int launch_pack_real(const d2 *x, double *out, int64_t n, int *flag, hipStream_t s);
 int launch_unpack_real(const double *in, d2 *out, int64_t n, hipStream_t s);
 int launch_imag_norm(const d2 *x, int64_t n, double *partials, hipStream_t s);

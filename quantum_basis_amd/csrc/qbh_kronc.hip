@@ -1,9 +1,11 @@
 // The Kronecker split for the library's DEFAULT form of a real operator: dictionary-coded values (1 byte per nonzero) applied
 // to packed-double vectors (qbh_opts.real_fast_path).  Same decomposition as qbh_kron.hip -- index = major * S + minor, every
 // entry changes the minor index (near) or the major index alone (far) -- but both parts are stored SLICED: groups of 16 rows
-// (one band of 16 minor indices of one major index), entry k of row j of a group at slot gia[g] + 16 k + j, short rows padded
-// with a code whose value is zero.  A wavefront reads 64 consecutive slots per instruction (4 entries of each of the 16 rows):
-// column and code streams are perfectly coalesced without row pointers or staging, and
+// (one band of 16 minor indices of one major index), widths padded to a multiple of 4 entries with a code whose value is zero.
+// Inside a group the order is LANE-MAJOR: lane = 16 (k % 4) + j of a wavefront owns entries k, k + 4, ... of row j, and its
+// nu = width / 4 columns (2 bytes each) and codes (1 byte each) are contiguous -- ONE 16-byte column load and ONE 8-byte code load
+// per lane bring a whole group (up to 32 entries per row), 6 registers per group instead of 12, so a wavefront keeps several
+// groups in flight.  The streams stay dense (a group's columns are 64 nu consecutive 2-byte words) and need no row pointers:
 //   * far part (gathers from the band-major "tiled" copy of x, KronTile{S, NU, 16}; a far entry keeps the minor index, so its
 //     column is stored as the target major index alone, 2 bytes): the 16 rows of a group gather ONE 128-byte line of the
 //     tiled x per entry -- 4 lines per wave instruction instead of up to 64 separate requests;
@@ -43,8 +45,10 @@ __global__ __launch_bounds__(256) void k_kronc_widths(const int64_t *ia, const i
             mn = cn > mn ? cn : mn;
             mf = cf > mf ? cf : mf;
         }
-        wn[g] = mn * kGB;
-        wf[b * NU + maj] = mf * kGB;
+        // widths in multiples of 4 entries: a group is then a whole number of 64-slot wave instructions -- no lane of a pass ever
+        // reads another group's slots (nothing to mask), column loads are whole aligned 128-byte lines
+        wn[g] = ((mn + 3) & ~3) * kGB;
+        wf[b * NU + maj] = ((mf + 3) & ~3) * kGB;
     }
 }
 
@@ -62,61 +66,66 @@ __global__ __launch_bounds__(256) void k_kronc_fill(const int64_t *ia, const int
         const int64_t bn = gia_n[g], wn = (gia_n[g + 1] - bn) >> 4;
         const int64_t bf = gia_f[gf], wf = (gia_f[gf + 1] - bf) >> 4;
         int64_t kn = 0, kf = 0;
-        const int64_t r0 = maj * S + d0;           // first row of the group: a valid element for the padding columns
+        // entry k of row j of a group of width w: lane 16 (k % 4) + j, its (k / 4)-th word
+        auto pos = [&](int64_t k, int64_t w) { return (16 * (k & 3) + j) * (w >> 2) + (k >> 2); };
+        const int64_t r0 = maj * S + d0;           // first row of the group
         if (j < wb) {
             const int64_t r = r0 + j;
             for (int64_t q = ia[r]; q < ia[r + 1]; ++q) {
                 const int64_t c = ja[q];
                 if (c / S == maj) {
-                    ja_n[bn + kn * kGB + j] = (uint16_t)(c - maj * S);
-                    code_n[bn + kn * kGB + j] = code[q];
+                    ja_n[bn + pos(kn, wn)] = (uint16_t)(c - maj * S);
+                    code_n[bn + pos(kn, wn)] = code[q];
                     ++kn;
                 } else {
-                    ja_f[bf + kf * kGB + j] = (uint16_t)(c / S);          // the minor index is the row's own
-                    code_f[bf + kf * kGB + j] = code[q];
+                    ja_f[bf + pos(kf, wf)] = (uint16_t)(c / S);          // the minor index is the row's own
+                    code_f[bf + pos(kf, wf)] = code[q];
                     ++kf;
                 }
             }
         }
         const int64_t own = j < wb ? j : 0;
         for (; kn < wn; ++kn) {
-            ja_n[bn + kn * kGB + j] = (uint16_t)(d0 + own);
-            code_n[bn + kn * kGB + j] = zcode;
+            ja_n[bn + pos(kn, wn)] = (uint16_t)(d0 + own);
+            code_n[bn + pos(kn, wn)] = zcode;
         }
         for (; kf < wf; ++kf) {
-            ja_f[bf + kf * kGB + j] = (uint16_t)maj;
-            code_f[bf + kf * kGB + j] = zcode;
+            ja_f[bf + pos(kf, wf)] = (uint16_t)maj;
+            code_f[bf + pos(kf, wf)] = zcode;
         }
     }
 }
 
-// ---- the two passes ----------------------------------------------------------------------------------------------------------
-// One wavefront works on NG groups at a time: all their column / code loads (UN instructions of 64 slots per group, clamped to
-// the group) are in flight before the first gather.  lane = 16 ks + j: row j of the group, entries ks, ks + 4, ...
-// NT: non-temporal stream loads.  A group starts on a 32-byte (columns) / 16-byte (codes) boundary, so consecutive instructions
-// share the line they straddle: with plain loads the L1 keeps it (far pass: 3.25e8 -> 2.74e8 requests at the L2, 4.8 -> 4.3 ms),
-// the near pass -- short of LDS and VALU cycles, not of requests -- is faster with the stream kept out of the L1 (4.3 vs 5.1 ms)
-template <int NG, int UN, typename ColT, bool NT>
+}  // namespace
+
+// ---- the two passes (named in namespace qbh: the profiling tools select kernels by name) ---------------------------------------
+// One wavefront works on NG groups at a time; a group's columns and codes of one lane are two loads (unaligned: the lane's words
+// start at lane * nu).  NT: non-temporal loads -- the near pass keeps its stream out of the L1, the far pass does not (its
+// neighbouring lanes' words share lines).
+template <int NG, bool NT>
 struct GroupStream {
-    ColT    c[NG][UN];
-    uint8_t cb[NG][UN];
-    int     w[NG];
-    // slot of entry k = 4 u + ks of row j: base + 16 k + j = base + 64 u + lane.  Instruction u is issued when the group has
-    // entries 4 u .. (a wave-uniform test, so no index is clamped); its lanes past the group's end read slots of the next group
-    // (valid columns; the arrays end in zeroed padding) and are masked out of the sum
-    __device__ __forceinline__ void load(int gi, const ColT *ja, const uint8_t *code, int64_t base, int64_t end, int lane)
+    uint32_t c[NG][4];          // 8 columns (2 bytes each): entries k = 4 u + ks, u = 0..7
+    uint32_t cb[NG][2];         // 8 codes
+    int      nu[NG];            // entries per lane = width / 4
+    __device__ __forceinline__ void load(int gi, const uint16_t *ja, const uint8_t *code, int64_t base, int64_t end, int lane)
     {
-        const int wg = (int)((end - base) >> 4);
-        w[gi] = wg;
-        const ColT *jp = ja + base + lane;
-        const uint8_t *cp = code + base + lane;
-#pragma unroll
-        for (int u = 0; u < UN; ++u)
-            if (4 * u < wg) c[gi][u] = NT ? __builtin_nontemporal_load(jp + 64 * u) : jp[64 * u];
-#pragma unroll
-        for (int u = 0; u < UN; ++u)
-            if (4 * u < wg) cb[gi][u] = NT ? __builtin_nontemporal_load(cp + 64 * u) : cp[64 * u];
+        const int n = (int)((end - base) >> 6);
+        nu[gi] = n;
+        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+        const v4 *jp = reinterpret_cast<const v4 *>(ja + base + (int64_t)lane * n);
+        const v2 *cp = reinterpret_cast<const v2 *>(code + base + (int64_t)lane * n);
+        const v4 cw = NT ? __builtin_nontemporal_load(jp) : *jp;
+        const v2 cd = NT ? __builtin_nontemporal_load(cp) : *cp;
+        c[gi][0] = cw.x;
+        c[gi][1] = cw.y;
+        c[gi][2] = cw.z;
+        c[gi][3] = cw.w;
+        cb[gi][0] = cd.x;
+        cb[gi][1] = cd.y;
     }
+    __device__ __forceinline__ int col(int gi, int u) const { return (int)((c[gi][u >> 1] >> (16 * (u & 1))) & 0xFFFFu); }
+    __device__ __forceinline__ int cod(int gi, int u) const { return (int)((cb[gi][u >> 2] >> (8 * (u & 3))) & 0xFFu); }
 };
 
 __device__ __forceinline__ double quad_sum(double v)        // sum over the four sub-slices ks of a row: lanes 0..15 hold the row sums
@@ -141,30 +150,43 @@ struct KroncArgs {
     double alpha, beta, gamma;
     double *partials;
     unsigned int *ctr;
+    unsigned int *fctr;         // far pass: one chunk counter per XCD, 128 bytes apart
     int chunk;                  // far pass: groups per wavefront turn (<= 32)
     int abl;                    // ablation bits (QBH_KRONC_ABL, wrong results by design): 1 no dictionary lookups, 2 no gathers, 4 no row sums
 };
 
-template <int NG, int UN>
+template <int NG, int UN, bool NT>
 __global__ __launch_bounds__(256) void k_kronc_far(KroncArgs a)
 {
+    static_assert(UN == 8, "a lane's loads cover 8 entries");
     __shared__ double dict_s[256];
     dict_s[threadIdx.x] = (int)threadIdx.x < a.n_dict ? a.dict[threadIdx.x].x : 0.0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t G = (int64_t)a.nb * a.NU;
-    // every XCD sweeps one contiguous eighth of the groups (band-major: a band of the tiled x stays in that XCD's L2), its
-    // wavefronts take chunks of a.chunk groups round robin -- small enough that what the XCD's ~900 wavefronts work on at any
-    // time lies inside ONE band (NU groups): chunks of 32 spread them over three bands, 4.8 MB of x against a 4 MB L2
-    const int xcd = blockIdx.x & 7, nwx = (int)(gridDim.x >> 3) * 4, wx = (int)(blockIdx.x >> 3) * 4 + wv;
+    // every XCD sweeps one contiguous eighth of the groups (band-major: a band of the tiled x, 1.6 MB at C3, stays in that XCD's
+    // L2) and its wavefronts DRAW chunks of a.chunk groups from the XCD's counter, the next one while the current is processed:
+    // with a static round robin the wavefronts drift bands apart over a pass (a few per cent of speed difference over ~1400
+    // chunks each) and 42 % of the gather lines missed the L2
+    const int xcd = blockIdx.x & 7;
     const int64_t per = (G + 7) >> 3, xb = xcd * per, xe = xb + per < G ? xb + per : G;
     const int CH = a.chunk;
-    for (int64_t g0 = xb + (int64_t)wx * CH; g0 < xe; g0 += (int64_t)nwx * CH) {
+    unsigned int *fc = a.fctr + xcd * 32;
+    auto draw = [&]() {
+        unsigned int v = 0;
+        if (lane == 0) v = atomicAdd(fc, 1u);
+        return (int64_t)__builtin_amdgcn_readfirstlane(v);
+    };
+    (void)wv;
+    for (int64_t cidx = draw(); xb + cidx * CH < xe;) {
+        const int64_t cnext = draw();
+        const int64_t g0 = xb + cidx * CH;
+        cidx = cnext;
         const int ng = (int)(xe - g0 < CH ? xe - g0 : CH);
         const int64_t gp = a.gia_f[g0 + (lane <= ng ? lane : ng)];
-        GroupStream<NG, UN, uint16_t, false> cur;
+        GroupStream<NG, NT> cur;
         int64_t base[NG];
-        auto fetch = [&](GroupStream<NG, UN, uint16_t, false> &st, int64_t (&bs)[NG], int i0) {
+        auto fetch = [&](GroupStream<NG, NT> &st, int64_t (&bs)[NG], int i0) {
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi) {
                 const int i = i0 + gi < ng ? i0 + gi : ng - 1;
@@ -175,18 +197,20 @@ __global__ __launch_bounds__(256) void k_kronc_far(KroncArgs a)
         fetch(cur, base, 0);
         for (int i0 = 0; i0 < ng; i0 += NG) {
             double xv[NG][UN];
+            const double *xband[NG];
+            int wBs[NG];
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi) {
                 // element (major u', minor 16 b + j) of the tiled x: band base + u' * (width of the band) + j
                 const int64_t g = g0 + (i0 + gi < ng ? i0 + gi : ng - 1);
                 const int64_t b = g / a.NU;
-                const int wB = (int)(a.S - b * kGB < kGB ? a.S - b * kGB : kGB);
-                const double *xb_ = a.xt + b * kGB * a.NU + (lane & 15);
+                wBs[gi] = (int)(a.S - b * kGB < kGB ? a.S - b * kGB : kGB);
+                xband[gi] = a.xt + b * kGB * a.NU + (lane & 15);
 #pragma unroll
-                for (int u = 0; u < UN; ++u) xv[gi][u] = (4 * u < cur.w[gi] && !(a.abl & 2)) ? xb_[(int)cur.c[gi][u] * wB] : (double)cur.c[gi][u];
+                for (int u = 0; u < UN; ++u) xv[gi][u] = (u < cur.nu[gi] && !(a.abl & 2)) ? xband[gi][cur.col(gi, u) * wBs[gi]] : 0.0;
             }
             // the next groups' streams go out behind the gathers, in front of the arithmetic that waits for them
-            GroupStream<NG, UN, uint16_t, false> nxt;
+            GroupStream<NG, NT> nxt;
             int64_t nbase[NG];
             fetch(nxt, nbase, i0 + NG < ng ? i0 + NG : i0);
 #pragma unroll
@@ -194,19 +218,11 @@ __global__ __launch_bounds__(256) void k_kronc_far(KroncArgs a)
                 double acc = 0.0;
 #pragma unroll
                 for (int u = 0; u < UN; ++u)
-                    if (4 * u < cur.w[gi]) {
-                        const double v = ((a.abl & 1) ? (double)cur.cb[gi][u] : dict_s[cur.cb[gi][u]]) * xv[gi][u];
-                        if (4 * u + (lane >> 4) < cur.w[gi]) acc += v;
-                    }
-                if (cur.w[gi] > 4 * UN) {                                            // rows longer than 4 UN entries
-                    const int64_t g = g0 + i0 + gi;
-                    const int64_t b = g / a.NU;
-                    const int wB = (int)(a.S - b * kGB < kGB ? a.S - b * kGB : kGB);
-                    const double *xb_ = a.xt + b * kGB * a.NU + (lane & 15);
-                    for (int k = 4 * UN + (lane >> 4); k < cur.w[gi]; k += 4) {
-                        const int64_t s = base[gi] + (int64_t)k * kGB + (lane & 15);
-                        acc += dict_s[a.code_f[s]] * xb_[(int)a.ja_f[s] * wB];
-                    }
+                    if (u < cur.nu[gi]) acc += ((a.abl & 1) ? 1.0 : dict_s[cur.cod(gi, u)]) * xv[gi][u];
+                if (cur.nu[gi] > UN) {                                               // rows longer than 32 entries: the lane's further words
+                    const uint16_t *jp = a.ja_f + base[gi] + (int64_t)lane * cur.nu[gi];
+                    const uint8_t *cp = a.code_f + base[gi] + (int64_t)lane * cur.nu[gi];
+                    for (int u = UN; u < cur.nu[gi]; ++u) acc += dict_s[cp[u]] * xband[gi][(int)jp[u] * wBs[gi]];
                 }
                 if (!(a.abl & 4)) acc = quad_sum(acc);
                 if (lane < kGB && i0 + gi < ng) a.far[(g0 + i0 + gi) * kGB + lane] = acc;
@@ -224,6 +240,7 @@ __global__ __launch_bounds__(256) void k_kronc_far(KroncArgs a)
 template <int NG, int UN>
 __global__ __launch_bounds__(1024) void k_kronc_near(KroncArgs a)
 {
+    static_assert(UN == 8, "a lane's loads cover 8 entries");
     extern __shared__ double lds[];                 // [S] window of x, [256] dictionary, [48] scratch, s_maj
     double *win = lds;
     double *dict = lds + a.S;                       // a small dictionary sits in one row of banks: its lookups do not conflict
@@ -259,7 +276,7 @@ __global__ __launch_bounds__(1024) void k_kronc_near(KroncArgs a)
             const int64_t p0 = a.gia_n[gq], p1 = a.gia_n[gq + 1];
             const int ng = r0 + wv < nb ? ((nb - 1 - r0 - wv) / 16 + 1 < 32 ? (nb - 1 - r0 - wv) / 16 + 1 : 32) : 0;
             struct Pass {
-                GroupStream<NG, UN, uint16_t, true> st;
+                GroupStream<NG, true> st;
                 double yo[NG], fr[NG];
             };
             auto fetch = [&](Pass &P, int i0) {
@@ -284,15 +301,11 @@ __global__ __launch_bounds__(1024) void k_kronc_near(KroncArgs a)
                     double acc = 0.0;
 #pragma unroll
                     for (int u = 0; u < UN; ++u)
-                        if (4 * u < cur.st.w[gi]) {
-                            const double v = ((a.abl & 1) ? (double)cur.st.cb[gi][u] : dict[cur.st.cb[gi][u]]) *
-                                             ((a.abl & 2) ? (double)cur.st.c[gi][u] : win[cur.st.c[gi][u]]);
-                            if (4 * u + (lane >> 4) < cur.st.w[gi]) acc += v;
-                        }
-                    const int64_t gb = cur.st.w[gi] > 4 * UN ? __shfl(p0, i0 + gi, 64) : 0;          // outside the divergent loop
-                    for (int k = 4 * UN + (lane >> 4); k < cur.st.w[gi]; k += 4) {
-                        const int64_t s = gb + (int64_t)k * kGB + (lane & 15);
-                        acc += dict[a.code_n[s]] * win[a.ja_n[s]];
+                        if (u < cur.st.nu[gi])
+                            acc += ((a.abl & 1) ? 1.0 : dict[cur.st.cod(gi, u)]) * ((a.abl & 2) ? 1.0 : win[cur.st.col(gi, u)]);
+                    if (cur.st.nu[gi] > UN) {                                        // rows longer than 32 entries
+                        const int64_t gb = __shfl(p0, i0 + gi, 64) + (int64_t)lane * cur.st.nu[gi];
+                        for (int u = UN; u < cur.st.nu[gi]; ++u) acc += dict[a.code_n[gb + u]] * win[a.ja_n[gb + u]];
                     }
                     if (!(a.abl & 4)) acc = quad_sum(acc);
                     const int b = r0 + wv + 16 * (i0 + gi);
@@ -331,8 +344,6 @@ __global__ __launch_bounds__(1024) void k_kronc_near(KroncArgs a)
     }
 }
 
-}  // namespace
-
 int launch_kronc_widths(const int64_t *ia, const int32_t *ja, int64_t S, int64_t NU, int nb, int32_t *wn, int32_t *wf, hipStream_t s)
 {
     hipLaunchKernelGGL(k_kronc_widths, dim3(4096), dim3(256), 0, s, ia, ja, S, NU, nb, wn, wf);
@@ -351,10 +362,11 @@ int launch_kronc_fill(const int64_t *ia, const int32_t *ja, const uint8_t *code,
 size_t kronc_near_lds_bytes(int64_t S) { return (size_t)(S + 256 + 48 + 2) * sizeof(double); }
 
 // y <- alpha H x + beta y + gamma x on packed-double vectors; partials (or nullptr): 3 per workgroup of the near launch,
-// *nparts_out workgroups.  ctr: one unsigned counter (the near launch's draw of major indices), or nullptr for static turns
-// (qbh_opts.deterministic: the partial sums of the reductions are then formed in the same order in every run).
+// *nparts_out workgroups.  ctr: 9 x 32 unsigned counters (the near launch's draw of major indices, the far launch's chunk counter
+// per XCD); static_near (qbh_opts.deterministic): static turns in the near pass -- the partial sums of the reductions are then
+// formed in the same order in every run.
 int launch_kronc(const KroncSliced &K, const d2 *dict, int n_dict, const double *xt, const double *x, double *y, double alpha, double beta,
-                 double gamma, double *partials, unsigned int *ctr, int *nparts_out, hipStream_t s)
+                 double gamma, double *partials, unsigned int *ctr, bool static_near, int *nparts_out, hipStream_t s)
 {
     KroncArgs a{};
     a.gia_n = K.gia_n;
@@ -377,12 +389,15 @@ int launch_kronc(const KroncSliced &K, const d2 *dict, int n_dict, const double 
     a.beta = beta;
     a.gamma = gamma;
     a.partials = partials;
-    a.ctr = ctr;
+    a.ctr = static_near ? nullptr : ctr;      // near pass: draw of major indices (static turns: reductions in a fixed order)
+    a.fctr = ctr + 32;                        // far pass: chunk counters (its results do not depend on who computes a group)
     // tuning switches (measurement only): groups a wavefront has in flight per pass
     static const int far_ng = getenv("QBH_KRONC_FAR_NG") ? atoi(getenv("QBH_KRONC_FAR_NG")) : 1;
     static const int near_ng = getenv("QBH_KRONC_NEAR_NG") ? atoi(getenv("QBH_KRONC_NEAR_NG")) : 2;
-    auto far_k = far_ng == 1 ? k_kronc_far<1, 6> : far_ng == 3 ? k_kronc_far<3, 6> : k_kronc_far<2, 6>;
-    auto near_k = near_ng == 1 ? k_kronc_near<1, 6> : near_ng == 3 ? k_kronc_near<3, 6> : k_kronc_near<2, 6>;
+    static const int far_nt = getenv("QBH_KRONC_FAR_NT") ? atoi(getenv("QBH_KRONC_FAR_NT")) : 0;
+    auto far_k = far_nt ? (far_ng == 1 ? k_kronc_far<1, 8, true> : k_kronc_far<2, 8, true>)
+                        : (far_ng == 1 ? k_kronc_far<1, 8, false> : far_ng == 3 ? k_kronc_far<3, 8, false> : k_kronc_far<2, 8, false>);
+    auto near_k = near_ng == 1 ? k_kronc_near<1, 8> : near_ng == 2 ? k_kronc_near<2, 8> : near_ng == 3 ? k_kronc_near<3, 8> : k_kronc_near<4, 8>;
     static int far_occ = 0;
     static size_t attr_done = 0;
     if (far_occ == 0) {
@@ -397,15 +412,15 @@ int launch_kronc(const KroncSliced &K, const d2 *dict, int n_dict, const double 
     }
     {
         static const int far_chunk = getenv("QBH_KRONC_FAR_CHUNK") ? atoi(getenv("QBH_KRONC_FAR_CHUNK")) : 0;
-        // the wavefronts of one XCD (32 CUs x far_occ workgroups x 4) together stay inside about half a band
-        int64_t c = far_chunk > 0 ? far_chunk : K.NU / (2 * (int64_t)32 * far_occ * 4);
+        // the wavefronts of one XCD (32 CUs x far_occ workgroups x 4) together stay inside about one band
+        int64_t c = far_chunk > 0 ? far_chunk : K.NU / ((int64_t)32 * far_occ * 4);
         a.chunk = (int)(c < 1 ? 1 : c > 32 ? 32 : c);
     }
     {
         static const int abl = getenv("QBH_KRONC_ABL") ? atoi(getenv("QBH_KRONC_ABL")) : 0;
         a.abl = abl;
     }
-    if (ctr) QBH_HIP(hipMemsetAsync(ctr, 0, sizeof(unsigned int), s));
+    QBH_HIP(hipMemsetAsync(ctr, 0, 9 * 32 * sizeof(unsigned int), s));
     hipLaunchKernelGGL(far_k, dim3(256 * far_occ), dim3(256), 0, s, a);
     QBH_HIP(hipGetLastError());
     const int grid_n = (int)(K.NU < 256 ? K.NU : 256);

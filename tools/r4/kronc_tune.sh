@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 cd $R
 timeout 600 python -m pytest tests/test_gpu_kron.py -x -q -m gpu -k "coded_real_form" 2>&1 | tail -30
 cd /tmp && export TMPDIR=/tmp
-for cfg in "2 2" "1 1" "1 2"; do
+for cfg in "2 3" "1 2" "3 4" "4 3" "2 1"; do
   set -- $cfg
   export QBH_KRON_CODED=2 QBH_KRONC_FAR_NG=$1 QBH_KRONC_NEAR_NG=$2
   rm -rf /tmp/kp; mkdir -p /tmp/kp

@@ -16,7 +16,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import src_hash  # noqa: E402
 
-SPMV_LIKE = ("k_spmv_", "k_zero_cut_groups", "k_kron_tile", "k_kron_combine", "k_mf_")
+SPMV_LIKE = ("k_spmv_", "k_zero_cut_groups", "k_kron_tile", "k_kron_combine", "k_mf_", "k_kronc_far", "k_kronc_near")
 
 
 def main():
@@ -34,7 +34,7 @@ def main():
     # launches of ONE SpMV: the SpMV kernels proper set the count; a helper kernel counts with as many launches per SpMV as it has
     # (the tiled copy of a cut sector is one launch per class), and not at all when it runs less often than the SpMV (the
     # tile copy in front of a driver's first step)
-    ref = max(max(n for n, _ in cs.values()) for name, cs in per.items() if "k_spmv_" in name or "k_mf_" in name)
+    ref = max(max(n for n, _ in cs.values()) for name, cs in per.items() if "k_spmv_" in name or "k_mf_" in name or "k_kronc_near" in name)
     kernels, read, write, rd128 = {}, 0.0, 0.0, 0.0
     for name, cs in sorted(per.items()):
         n = max(n for n, _ in cs.values())
