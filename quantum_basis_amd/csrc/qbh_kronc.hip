@@ -152,7 +152,7 @@ struct KroncArgs {
     unsigned int *ctr;
     unsigned int *fctr;         // far pass: one chunk counter per XCD, 128 bytes apart
     int chunk;                  // far pass: groups per wavefront turn (<= 32)
-    int abl;                    // ablation bits (QBH_KRONC_ABL, wrong results by design): 1 no dictionary lookups, 2 no gathers, 4 no row sums
+    int abl;                    // ablation bits (QBH_KRONC_ABL, wrong results by design): 1 no dictionary lookups, 2 no gathers, 4 no row sums, 8 near: no block load, 16 near: no epilogue
 };
 
 template <int NG, int UN, bool NT>
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(1024) void k_kronc_near(KroncArgs a)
         const int64_t maj = *s_maj;
         if (maj >= a.NU) break;
         const double *xb = a.x + maj * a.S;
-        for (int64_t o = 0; o < a.S; o += 8 * 1024) {          // eight loads per thread in flight at a time
+        for (int64_t o = 0; o < a.S && !(a.abl & 8); o += 8 * 1024) {          // eight loads per thread in flight at a time
             double v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = o + tid + 1024 * u < a.S ? xb[o + tid + 1024 * u] : 0.0;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(1024) void k_kronc_near(KroncArgs a)
                     P.st.load(gi, a.ja_n, a.code_n, __shfl(p0, i, 64), __shfl(p1, i, 64), lane);
                     const int b = r0 + wv + 16 * i;
                     const int64_t d = (int64_t)b * kGB + (lane & 15);
-                    const bool rowok = lane < kGB && d < a.S && i0 + gi < ng;
+                    const bool rowok = lane < kGB && d < a.S && i0 + gi < ng && !(a.abl & 16);
                     P.yo[gi] = (rowok && a.beta != 0.0) ? a.y[maj * a.S + d] : 0.0;
                     P.fr[gi] = rowok ? a.far[((int64_t)b * a.NU + maj) * kGB + lane] : 0.0;
                 }
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(1024) void k_kronc_near(KroncArgs a)
                     if (!(a.abl & 4)) acc = quad_sum(acc);
                     const int b = r0 + wv + 16 * (i0 + gi);
                     const int64_t d = (int64_t)b * kGB + (lane & 15);
-                    if (lane < kGB && d < a.S && i0 + gi < ng) {
+                    if (lane < kGB && d < a.S && i0 + gi < ng && !(a.abl & 16)) {
                         const double xi = win[d];
                         const double yn = a.alpha * (acc + cur.fr[gi]) + a.beta * cur.yo[gi] + a.gamma * xi;
                         a.y[maj * a.S + d] = yn;
