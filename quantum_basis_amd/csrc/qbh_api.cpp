@@ -1873,17 +1873,26 @@ inline d2 *tiled_target(const qbh_csr *A)
 }
 // Only a driver knows that nothing else writes its vectors between the pass that produces x and the SpMV that reads it
 // (a caller of the building-block entry points may scale or overwrite a vector in between): the drivers hold this guard.
+// the coded split's tiled x (packed doubles): written by the all-real Lanczos step's axpy when the operator runs that form
+inline double *kronc_tiled_target(const qbh_csr *A)
+{
+    static const bool off = getenv("QBH_NO_TILE_FOLD") != nullptr;
+    return (A->kronc.active && A->kronc.sl.active && !A->has_comm && !A->has_rem && !off) ? A->kronc.d_xt : nullptr;
+}
+
 struct FoldGuard {
     qbh_csr *A;
     explicit FoldGuard(qbh_csr *a) : A(a)
     {
         A->kron.xt_of = nullptr;
+        A->kronc.xt_of = nullptr;
         A->kron.fold = true;
     }
     ~FoldGuard()
     {
         A->kron.xt_of = nullptr;
         A->kron.fold = false;
+        A->kronc.xt_of = nullptr;
     }
 };
 
@@ -2328,8 +2337,9 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     if (kronc) {
         // coded Kronecker split, all-real operation: tiled copy of the packed x, near launch (full epilogue), far launch
         // (tiled rows and columns, accumulates at orig(row), fused reductions of the finished y)
-        const qbh_csr::KronCoded &K = A->kronc;
-        QBH_TRY(qbh::launch_kron_tile_re(a.xr, K.d_xt, A->nrows, K.t, A->stream));
+        qbh_csr::KronCoded &K = A->kronc;
+        if (K.xt_of != (const void *)a.xr) QBH_TRY(qbh::launch_kron_tile_re(a.xr, K.d_xt, A->nrows, K.t, A->stream));
+        K.xt_of = nullptr;                           // an alias is good for one SpMV
         if (K.sl.active) {
             // sliced form: far pass (row sums in group order), near pass from the LDS-resident block of x with the whole epilogue
             QBH_TRY(qbh::launch_kronc(K.sl, A->d_dict, A->n_dict, K.d_xt, a.xr, a.y_re, a.alpha, a.beta, a.gamma, red ? A->d_partials : nullptr,
@@ -2923,7 +2933,11 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
             A->ovr_xr = nullptr;
             A->ovr_yr = nullptr;
             QBH_TRY(rc1);
-            QBH_TRY(qbh::launch_axpy_norm_re(-sc[sx] * sc[sx], A->d_scal, rpt(mcur - 1), rpt(mcur), n, A->d_partials, A->stream));
+            // the result is the next SpMV's x: a coded Kronecker split gets its tiled copy written here (as tiled_target does for
+            // the complex128 form)
+            double *yt = kronc_tiled_target(A);
+            QBH_TRY(qbh::launch_axpy_norm_re(-sc[sx] * sc[sx], A->d_scal, rpt(mcur - 1), rpt(mcur), n, A->d_partials, A->stream, yt, A->kronc.t));
+            A->kronc.xt_of = yt ? (const void *)rpt(mcur) : nullptr;
             QBH_TRY(qbh::launch_reduce_partials(A->d_partials, qbh::blas_grid(n), 1, A->d_scal + 4, A->stream));
             QBH_HIP(hipMemcpyAsync(A->h_scal, A->d_scal, 5 * sizeof(double), hipMemcpyDeviceToHost, A->stream));
             QBH_HIP(hipStreamSynchronize(A->stream));
@@ -2956,6 +2970,7 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
         return QBH_OK;
     };
     auto normalise_slots = [&]() -> int {
+        A->kronc.xt_of = nullptr;                          // whatever happens to the slots below, no tiled copy describes them
         if (rv != nullptr && rv_external) {                // the caller's vectors are the packed doubles themselves
             for (int j = 0; j < 2; ++j)
                 if (sc[j] != 1.0) {
@@ -3024,7 +3039,9 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
             if (rc != QBH_OK) break;
             if (sc[sy] * std::hypot(t[0], t[1]) > prec) {
                 if (rv != nullptr) {
-                    rc = qbh::launch_axpy_norm_re(-t[0], nullptr, rv + 2 * (size_t)n, rpt(m), n, A->d_partials, A->stream);
+                    double *yt = kronc_tiled_target(A);
+                    rc = qbh::launch_axpy_norm_re(-t[0], nullptr, rv + 2 * (size_t)n, rpt(m), n, A->d_partials, A->stream, yt, A->kronc.t);
+                    A->kronc.xt_of = yt ? (const void *)rpt(m) : nullptr;
                     if (rc == QBH_OK) rc = finish_reduction(A, qbh::blas_grid(n), 1, &sq);
                 } else {
                     rc = axpy_norm_run(A, d2{-t[0], -t[1]}, phi, vpt(m), &sq);   // u_m -= <phi0,u_m> phi0

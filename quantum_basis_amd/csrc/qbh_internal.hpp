@@ -285,7 +285,8 @@ int launch_axpy_norm_tile(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y,
 int launch_xpby_tile(const d2 *x, double b, d2 *y, d2 *yt, int64_t n, const KronTile &t, hipStream_t s);
 int launch_nrm2sq(const d2 *x, int64_t n, double *partials, hipStream_t s);
 int launch_scal(double a, d2 *x, int64_t n, hipStream_t s);
-int launch_axpy_norm_re(double alpha, const double *alpha_dev, const double *x, double *y, int64_t n, double *partials, hipStream_t s);
+int launch_axpy_norm_re(double alpha, const double *alpha_dev, const double *x, double *y, int64_t n, double *partials, hipStream_t s,
+                        double *yt = nullptr, const KronTile &t = KronTile{1, 1, 1});
 int launch_cg_update_re(double alpha, const double *p, const double *pp, double *v, double *r, int64_t n, double *partials, hipStream_t s);
 int launch_xpby_re(const double *x, double b, double *y, int64_t n, hipStream_t s);
 int launch_dot_re(const double *x, const double *y, int64_t n, double *partials, hipStream_t s);
@@ -534,6 +535,7 @@ struct qbh_csr {
         CsrPart  near_p, far_p;
         double  *d_xt = nullptr;
         qbh::KroncSliced sl;            // the sliced form (both parts; near gathers from LDS): near_p / far_p are then empty
+        const void *xt_of = nullptr;    // the packed vector whose tiled copy d_xt holds (written by the pass that produced it); consumed by one SpMV
     } kronc;
     struct KronSplit {
         bool     active = false;

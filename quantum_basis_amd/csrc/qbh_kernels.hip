@@ -2268,8 +2268,10 @@ int launch_scal(double a, d2 *x, int64_t n, hipStream_t s)
 
 // y = x + b*y   (CG direction update p = r + beta^2 p, src/lanczos.cc:327-328)
 // all-real Lanczos: y += alpha * x on vectors stored as doubles, partial |y|^2 (alpha_dev as in k_axpy_norm)
+// yt != nullptr: the result also in the tiled order t (16 consecutive minor indices = one aligned 128-byte line): the next SpMV of
+// a coded Kronecker split (qbh_kronc.hip) gathers its far part from it and needs no k_kron_tile_re
 __global__ __launch_bounds__(kBlock) void k_axpy_norm_re(double alpha, const double *alpha_dev, const double *x, double *y,
-                                                         int64_t n, double *partials)
+                                                         int64_t n, double *partials, double *yt, KronTile t)
 {
     __shared__ double red[4];
     double acc[1] = {0.0};
@@ -2278,15 +2280,17 @@ __global__ __launch_bounds__(kBlock) void k_axpy_norm_re(double alpha, const dou
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const double v = y[i] + alpha * x[i];
         y[i] = v;
+        if (yt != nullptr) yt[t.tile(i)] = v;
         acc[0] += v * v;
     }
     block_sum<1>(acc, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
 }
 
-int launch_axpy_norm_re(double alpha, const double *alpha_dev, const double *x, double *y, int64_t n, double *partials, hipStream_t s)
+int launch_axpy_norm_re(double alpha, const double *alpha_dev, const double *x, double *y, int64_t n, double *partials, hipStream_t s, double *yt,
+                        const KronTile &t)
 {
-    hipLaunchKernelGGL(k_axpy_norm_re, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, alpha_dev, x, y, n, partials);
+    hipLaunchKernelGGL(k_axpy_norm_re, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, alpha_dev, x, y, n, partials, yt, t);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }
