@@ -2280,7 +2280,15 @@ __global__ __launch_bounds__(kBlock) void k_axpy_norm_re(double alpha, const dou
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const double v = y[i] + alpha * x[i];
         y[i] = v;
-        if (yt != nullptr) yt[t.tile(i)] = v;
+        if (yt != nullptr) {
+            if (n < 2147483647LL && t.B == 16) {          // 32-bit index arithmetic (the 64-bit divisions of tile() cost more than the store)
+                const uint32_t S32 = (uint32_t)t.S, u = (uint32_t)i / S32, d = (uint32_t)i - u * S32, b = d >> 4;
+                const uint32_t wB = S32 - (b << 4) < 16u ? S32 - (b << 4) : 16u;
+                yt[(int64_t)b * 16 * t.NU + (int64_t)(u * wB + (d & 15u))] = v;
+            } else {
+                yt[t.tile(i)] = v;
+            }
+        }
         acc[0] += v * v;
     }
     block_sum<1>(acc, red);

@@ -235,12 +235,11 @@ __global__ __launch_bounds__(256) void k_kronc_far(KroncArgs a)
 }
 
 // One workgroup of 16 wavefronts per major index at a time (drawn from a counter): x[maj * S .. + S) into LDS, then wavefront w
-// takes the groups b = w, w + 16, ... of that major index, NG at a time, the streams of the next NG in flight meanwhile.  The
-// value dictionary is read through the L1 (2 KB, always resident): the LDS pipe is what this pass is short of.
+// takes a run of consecutive bands of that major index, four groups at a time, the streams of the next four in flight meanwhile.
 template <int NG, int UN>
 __global__ __launch_bounds__(1024) void k_kronc_near(KroncArgs a)
 {
-    static_assert(UN == 8, "a lane's loads cover 8 entries");
+    static_assert(UN == 8 && NG == 4, "a lane's loads cover 8 entries; a pass is four groups (lane >> 4 picks one in the epilogue)");
     extern __shared__ double lds[];                 // [S] window of x, [256] dictionary, [48] scratch, s_maj
     double *win = lds;
     double *dict = lds + a.S;                       // a small dictionary sits in one row of banks: its lookups do not conflict
@@ -269,33 +268,38 @@ __global__ __launch_bounds__(1024) void k_kronc_near(KroncArgs a)
         }
         __syncthreads();
         const int64_t gbase = maj * nb;
-        for (int r0 = 0; r0 < nb; r0 += 16 * 32) {       // rounds of 32 groups per wavefront
-            // group pointers of this wavefront's groups in the round: lane l <-> group b = r0 + wv + 16 l
-            const int bl = r0 + wv + 16 * (lane & 31);
-            const int64_t gq = gbase + (bl < nb ? bl : nb - 1);
-            const int64_t p0 = a.gia_n[gq], p1 = a.gia_n[gq + 1];
-            const int ng = r0 + wv < nb ? ((nb - 1 - r0 - wv) / 16 + 1 < 32 ? (nb - 1 - r0 - wv) / 16 + 1 : 32) : 0;
+        // wavefront wv takes the consecutive bands [wv q, (wv + 1) q), four at a time: after the row sums every lane holds the
+        // sum of ITS row j for each of the four groups, so lane l = 16 gi + j takes group gi's -- 64 consecutive rows of y per
+        // wave instruction (one 512-byte read of the old y, one 512-byte store) instead of four 128-byte pieces that each
+        // straddle a line (S * 8 bytes is not a multiple of 128)
+        const int q = (((nb + 15) >> 4) + 3) & ~3;
+        for (int r0 = 0; r0 < q; r0 += 60) {             // rounds of up to 60 bands: their pointers sit in one register per lane
+            const int bw0 = wv * q + r0;
+            const int nround = q - r0 < 60 ? q - r0 : 60;
+            const int ng = nb - bw0 < 0 ? 0 : nb - bw0 < nround ? nb - bw0 : nround;
+            const int64_t gp = a.gia_n[gbase + (bw0 + lane < nb ? bw0 + lane : nb)];
             struct Pass {
                 GroupStream<NG, true> st;
-                double yo[NG], fr[NG];
+                double yo, fr;
             };
             auto fetch = [&](Pass &P, int i0) {
 #pragma unroll
                 for (int gi = 0; gi < NG; ++gi) {
                     const int i = i0 + gi < ng ? i0 + gi : (ng > 0 ? ng - 1 : 0);
-                    P.st.load(gi, a.ja_n, a.code_n, __shfl(p0, i, 64), __shfl(p1, i, 64), lane);
-                    const int b = r0 + wv + 16 * i;
-                    const int64_t d = (int64_t)b * kGB + (lane & 15);
-                    const bool rowok = lane < kGB && d < a.S && i0 + gi < ng && !(a.abl & 16);
-                    P.yo[gi] = (rowok && a.beta != 0.0) ? a.y[maj * a.S + d] : 0.0;
-                    P.fr[gi] = rowok ? a.far[((int64_t)b * a.NU + maj) * kGB + lane] : 0.0;
+                    P.st.load(gi, a.ja_n, a.code_n, __shfl(gp, i, 64), __shfl(gp, i + 1, 64), lane);
                 }
+                const int b = bw0 + i0 + (lane >> 4);
+                const int64_t d = (int64_t)b * kGB + (lane & 15);
+                const bool rowok = i0 + (lane >> 4) < ng && d < a.S && !(a.abl & 16);
+                P.yo = (rowok && a.beta != 0.0) ? a.y[maj * a.S + d] : 0.0;
+                P.fr = rowok ? a.far[((int64_t)b * a.NU + maj) * kGB + (lane & 15)] : 0.0;
             };
             Pass cur;
             if (ng > 0) fetch(cur, 0);
             for (int i0 = 0; i0 < ng; i0 += NG) {
                 Pass nxt;
                 fetch(nxt, i0 + NG < ng ? i0 + NG : i0);
+                double mine = 0.0;                       // the row sum this lane finishes: group lane >> 4 of the pass
 #pragma unroll
                 for (int gi = 0; gi < NG; ++gi) {
                     double acc = 0.0;
@@ -304,19 +308,20 @@ __global__ __launch_bounds__(1024) void k_kronc_near(KroncArgs a)
                         if (u < cur.st.nu[gi])
                             acc += ((a.abl & 1) ? 1.0 : dict[cur.st.cod(gi, u)]) * ((a.abl & 2) ? 1.0 : win[cur.st.col(gi, u)]);
                     if (cur.st.nu[gi] > UN) {                                        // rows longer than 32 entries
-                        const int64_t gb = __shfl(p0, i0 + gi, 64) + (int64_t)lane * cur.st.nu[gi];
+                        const int64_t gb = __shfl(gp, i0 + gi < ng ? i0 + gi : ng - 1, 64) + (int64_t)lane * cur.st.nu[gi];
                         for (int u = UN; u < cur.st.nu[gi]; ++u) acc += dict[a.code_n[gb + u]] * win[a.ja_n[gb + u]];
                     }
                     if (!(a.abl & 4)) acc = quad_sum(acc);
-                    const int b = r0 + wv + 16 * (i0 + gi);
-                    const int64_t d = (int64_t)b * kGB + (lane & 15);
-                    if (lane < kGB && d < a.S && i0 + gi < ng && !(a.abl & 16)) {
-                        const double xi = win[d];
-                        const double yn = a.alpha * (acc + cur.fr[gi]) + a.beta * cur.yo[gi] + a.gamma * xi;
-                        a.y[maj * a.S + d] = yn;
-                        acc3[0] += xi * yn;
-                        acc3[1] += yn * yn;
-                    }
+                    if ((lane >> 4) == gi) mine = acc;
+                }
+                const int b = bw0 + i0 + (lane >> 4);
+                const int64_t d = (int64_t)b * kGB + (lane & 15);
+                if (i0 + (lane >> 4) < ng && d < a.S && !(a.abl & 16)) {
+                    const double xi = win[d];
+                    const double yn = a.alpha * (mine + cur.fr) + a.beta * cur.yo + a.gamma * xi;
+                    a.y[maj * a.S + d] = yn;
+                    acc3[0] += xi * yn;
+                    acc3[1] += yn * yn;
                 }
                 cur = nxt;
             }
@@ -393,11 +398,10 @@ int launch_kronc(const KroncSliced &K, const d2 *dict, int n_dict, const double 
     a.fctr = ctr + 32;                        // far pass: chunk counters (its results do not depend on who computes a group)
     // tuning switches (measurement only): groups a wavefront has in flight per pass
     static const int far_ng = getenv("QBH_KRONC_FAR_NG") ? atoi(getenv("QBH_KRONC_FAR_NG")) : 1;
-    static const int near_ng = getenv("QBH_KRONC_NEAR_NG") ? atoi(getenv("QBH_KRONC_NEAR_NG")) : 2;
     static const int far_nt = getenv("QBH_KRONC_FAR_NT") ? atoi(getenv("QBH_KRONC_FAR_NT")) : 0;
     auto far_k = far_nt ? (far_ng == 1 ? k_kronc_far<1, 8, true> : k_kronc_far<2, 8, true>)
                         : (far_ng == 1 ? k_kronc_far<1, 8, false> : far_ng == 3 ? k_kronc_far<3, 8, false> : k_kronc_far<2, 8, false>);
-    auto near_k = near_ng == 1 ? k_kronc_near<1, 8> : near_ng == 2 ? k_kronc_near<2, 8> : near_ng == 3 ? k_kronc_near<3, 8> : k_kronc_near<4, 8>;
+    auto near_k = k_kronc_near<4, 8>;
     static int far_occ = 0;
     static size_t attr_done = 0;
     if (far_occ == 0) {
