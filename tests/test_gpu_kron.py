@@ -188,6 +188,28 @@ def test_deterministic_option_gives_bit_identical_lanczos_coefficients():
     assert out[0][1] == out[1][1] and np.array_equal(out[0][0], out[1][0]) and out[0][2] == out[1][2]
 
 
+def test_deterministic_option_on_the_coded_split_of_the_default_format():
+    """the same promise for the library's default format (value codes, packed-double vectors) through its sliced split
+    (qbh_kronc.hip): the near pass takes major indices in static turns instead of drawing them from a counter, so the partial sums
+    of the fused reductions are formed in the same order -- bit-identical hessenberg arrays and step counts; without the option the
+    results agree to rounding only.  Hubbard 4x3 on the triangular lattice (36 bonds), kron_split = 2."""
+    bonds = lattices.triangular(4, 3)
+    out = []
+    for _ in range(2):
+        K = q.csr_mat.hubbard(12, 6, 6, bonds, t=1.0, U=1.1, opts=q.make_opts(deterministic=1, kron_split=2))
+        ik = K.info()
+        assert ik.value_dict > 0 and ik.kron_minor == 924 and ik.kron_sliced == 1 and ik.kron_band == 16 and ik.kron_inplace == 0
+        r = q.locate_E0_lanczos(K, nev=1, ncv=0, maxit=400)
+        assert K.stats().n_spmv_real > 0
+        out.append((r.hessenberg_E0.copy(), r.steps["E0"], r.E0))
+        K.destroy()
+    assert out[0][1] == out[1][1] and np.array_equal(out[0][0], out[1][0]) and out[0][2] == out[1][2]
+    P = q.csr_mat.hubbard(12, 6, 6, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_split=0))
+    rp = q.locate_E0_lanczos(P, nev=1, ncv=0, maxit=400)
+    P.destroy()
+    assert abs(rp.E0 - out[0][2]) <= 1e-12 * abs(rp.E0) and abs(rp.steps["E0"] - out[0][1]) <= 1
+
+
 def test_headline_operator_split_and_sliced_equals_the_matrix_free_operator_at_full_size():
     """BASELINE configs[2] (C3, dim 165,636,900, nnz 5.82e9) exactly as bench.py's headline applies it: complex128 CSR, Kronecker
     split with the sliced far part.  The oracle cannot run at this size; the independent path is the matrix-free operator (no
