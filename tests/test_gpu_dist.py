@@ -53,8 +53,7 @@ def test_sharded_solver_matches_single_gpu(world, backend, mf):
 
 
 @pytest.mark.parametrize("world,backend,mixed,parts,native", [(2, "gloo", False, 0, False), (3, "gloo", False, 0, False), (1, "nccl", False, 0, False),
-                                                              (2, "gloo", True, 0, False), (2, "gloo", False, 4, False), (3, "gloo", False, 7, False),
-                                                              (1, "nccl", False, 0, True), (1, "nccl", False, 4, True)])
+                                                              (2, "gloo", True, 0, False), (3, "gloo", False, 7, False), (1, "nccl", False, 4, True)])
 def test_sharded_kron_split_matches_single_gpu(world, backend, mixed, parts, native):
     """SURVEY 8e for the headline form: shards of whole major indices keep the Kronecker split, exchange tiled blocks, overlap
     the near pass with the gather; E0, a_j / b_j, step counts and the eigenvector equal the one-rank run.  parts: the gather in
