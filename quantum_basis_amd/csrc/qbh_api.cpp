@@ -792,7 +792,7 @@ void kronc_release(qbh_csr *A)
         for (void *q : {(void *)P->d_ia, (void *)P->d_ja, (void *)P->d_code, (void *)P->d_rb, (void *)P->d_bp})
             if (q) (void)hipFree(q);
     if (K.d_xt) (void)hipFree(K.d_xt);
-    for (void *q : {(void *)K.sl.gia_n, (void *)K.sl.gia_f, (void *)K.sl.ja_n, (void *)K.sl.ja_f, (void *)K.sl.code_n, (void *)K.sl.code_f, (void *)K.sl.d_far, (void *)K.sl.d_dictr})
+    for (void *q : {(void *)K.sl.gia_n, (void *)K.sl.gia_f, (void *)K.sl.ja_n, (void *)K.sl.ja_f, (void *)K.sl.code_n, (void *)K.sl.code_f, (void *)K.sl.d_far, (void *)K.sl.d_dictr, (void *)K.sl.tf_ptr})
         if (q) (void)hipFree(q);
     K = qbh_csr::KronCoded{};
 }
@@ -829,19 +829,42 @@ int kronc_build_sliced(qbh_csr *A, int64_t S, int64_t NU)
         const int rc_ = (expr);                \
         if (rc_ != QBH_OK) return fail(rc_);   \
     } while (0)
+    // Is the far part T (x) 1 (the far entries of a row do not depend on its minor index: two-species models)?  Then it is kept as
+    // T alone -- NU short rows, always in the L2 -- and the far pass has no stream.  QBH_KRONC_FAR_UNI=0: keep the general form.
+    {
+        int nonuni = 0;
+        const char *e = getenv("QBH_KRONC_FAR_UNI");
+        if (e && atoi(e) == 0) {
+            nonuni = 1;
+        } else {
+            KS_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
+            KS_TRY(qbh::launch_kronc_far_uniform(A->d_ia, A->d_ja, A->d_code, S, n, A->d_flag, s));
+            KS_HIP(hipMemcpyAsync(&nonuni, A->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+            KS_HIP(hipStreamSynchronize(s));
+            KS_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
+        }
+        L.far_uni = nonuni == 0;
+    }
     KS_HIP(hipMalloc(&wn, (size_t)G * sizeof(int32_t)));
     KS_HIP(hipMalloc(&wf, (size_t)G * sizeof(int32_t)));
     KS_TRY(qbh::launch_kronc_widths(A->d_ia, A->d_ja, S, NU, nb, wn, wf, s));
     KS_HIP(hipMalloc(&L.gia_n, (size_t)(G + 1) * sizeof(int64_t)));
-    KS_HIP(hipMalloc(&L.gia_f, (size_t)(G + 1) * sizeof(int64_t)));
     KS_TRY(qbh::exclusive_scan(wn, G, L.gia_n, s));
-    KS_TRY(qbh::exclusive_scan(wf, G, L.gia_f, s));
+    if (L.far_uni) {
+        KS_TRY(qbh::launch_kronc_t_widths(A->d_ia, A->d_ja, S, NU, wf, s));
+        KS_HIP(hipMalloc(&L.tf_ptr, (size_t)(NU + 1) * sizeof(int64_t)));
+        KS_TRY(qbh::exclusive_scan(wf, NU, L.tf_ptr, s));
+        KS_HIP(hipMemcpy(&L.slots_f, L.tf_ptr + NU, sizeof(int64_t), hipMemcpyDeviceToHost));
+    } else {
+        KS_HIP(hipMalloc(&L.gia_f, (size_t)(G + 1) * sizeof(int64_t)));
+        KS_TRY(qbh::exclusive_scan(wf, G, L.gia_f, s));
+        KS_HIP(hipMemcpy(&L.slots_f, L.gia_f + G, sizeof(int64_t), hipMemcpyDeviceToHost));
+    }
     (void)hipFree(wn);
     wn = nullptr;
     (void)hipFree(wf);
     wf = nullptr;
     KS_HIP(hipMemcpy(&L.slots_n, L.gia_n + G, sizeof(int64_t), hipMemcpyDeviceToHost));
-    KS_HIP(hipMemcpy(&L.slots_f, L.gia_f + G, sizeof(int64_t), hipMemcpyDeviceToHost));
     if (L.slots_f == 0 || L.slots_n + L.slots_f > 2 * A->nnz + 64 * G) return fail(QBH_OK);          // nothing far, or rows too ragged to pad
     {
         size_t free_b = 0, total_b = 0;
@@ -868,6 +891,7 @@ int kronc_build_sliced(qbh_csr *A, int64_t S, int64_t NU)
     }
     KS_HIP(hipMalloc(&K.d_xt, (size_t)n * sizeof(double)));
     KS_TRY(qbh::launch_kronc_fill(A->d_ia, A->d_ja, A->d_code, S, NU, nb, A->n_dict, L.gia_n, L.ja_n, L.code_n, L.gia_f, L.ja_f, L.code_f, s));
+    if (L.far_uni) KS_TRY(qbh::launch_kronc_t_fill(A->d_ia, A->d_ja, A->d_code, S, NU, A->n_dict, L.tf_ptr, L.ja_f, L.code_f, s));
     if (!A->d_wctr) KS_HIP(qbh::dev_alloc(&A->d_wctr, qbh::kWctrRegions * 128 * sizeof(unsigned long long)));
     KS_HIP(hipStreamSynchronize(s));
 #undef KS_HIP

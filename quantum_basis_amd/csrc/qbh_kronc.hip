@@ -52,7 +52,58 @@ __global__ __launch_bounds__(256) void k_kronc_widths(const int64_t *ia, const i
     }
 }
 
+// Is the far part T (x) 1 -- the far entries (target major index, code) of row (u, d) the same for every minor index d?  (Two-species
+// models in species-major order: a hop of the major species does not see the minor one.)  One thread per row compares with row (u, 0).
+__global__ __launch_bounds__(256) void k_kronc_far_uniform(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t S, int64_t n, int *flag)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+        const int64_t u = r / S;
+        if (r == u * S) continue;
+        int64_t q = ia[r], q0 = ia[u * S];
+        const int64_t e = ia[r + 1], e0 = ia[u * S + 1];
+        bool bad = false;
+        for (;;) {
+            while (q < e && ja[q] / S == u) ++q;
+            while (q0 < e0 && ja[q0] / S == u) ++q0;
+            if (q >= e || q0 >= e0) break;
+            bad = bad || ja[q] / S != ja[q0] / S || code[q] != code[q0];
+            ++q;
+            ++q0;
+        }
+        if (bad || q < e || q0 < e0) *flag = 1;
+    }
+}
+
+// T of a uniform far part: widths (padded to a multiple of 4) and entries of row (u, 0), lane-major over ks = k % 4
+__global__ __launch_bounds__(256) void k_kronc_t_widths(const int64_t *ia, const int32_t *ja, int64_t S, int64_t NU, int32_t *wt)
+{
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < NU; u += (int64_t)gridDim.x * 256) {
+        int cf = 0;
+        for (int64_t q = ia[u * S]; q < ia[u * S + 1]; ++q) cf += ja[q] / S != u ? 1 : 0;
+        wt[u] = (cf + 3) & ~3;
+    }
+}
+__global__ __launch_bounds__(256) void k_kronc_t_fill(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t S, int64_t NU, uint8_t zcode,
+                                                      const int64_t *tp, uint16_t *tcol, uint8_t *tcode)
+{
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < NU; u += (int64_t)gridDim.x * 256) {
+        const int64_t base = tp[u], w = tp[u + 1] - base, nu = w >> 2;
+        int64_t k = 0;
+        for (int64_t q = ia[u * S]; q < ia[u * S + 1]; ++q) {
+            if (ja[q] / S == u) continue;
+            tcol[base + (k & 3) * nu + (k >> 2)] = (uint16_t)(ja[q] / S);
+            tcode[base + (k & 3) * nu + (k >> 2)] = code[q];
+            ++k;
+        }
+        for (; k < w; ++k) {
+            tcol[base + (k & 3) * nu + (k >> 2)] = (uint16_t)u;
+            tcode[base + (k & 3) * nu + (k >> 2)] = zcode;
+        }
+    }
+}
+
 // one thread per (near group, lane j): scatters the row's entries into the two sliced parts and pads both to the group widths
+// (gia_f == nullptr: the far part is kept as T, see above -- only the near part is written)
 __global__ __launch_bounds__(256) void k_kronc_fill(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t S, int64_t NU, int nb,
                                                     uint8_t zcode, const int64_t *gia_n, uint16_t *ja_n, uint8_t *code_n,
                                                     const int64_t *gia_f, uint16_t *ja_f, uint8_t *code_f)
@@ -64,7 +115,7 @@ __global__ __launch_bounds__(256) void k_kronc_fill(const int64_t *ia, const int
         const int64_t d0 = b * kGB, wb = S - d0 < kGB ? S - d0 : kGB;
         const int64_t gf = b * NU + maj;
         const int64_t bn = gia_n[g], wn = (gia_n[g + 1] - bn) >> 4;
-        const int64_t bf = gia_f[gf], wf = (gia_f[gf + 1] - bf) >> 4;
+        const int64_t bf = gia_f ? gia_f[gf] : 0, wf = gia_f ? (gia_f[gf + 1] - bf) >> 4 : 0;
         int64_t kn = 0, kf = 0;
         // entry k of row j of a group of width w: lane 16 (k % 4) + j, its (k / 4)-th word
         auto pos = [&](int64_t k, int64_t w) { return (16 * (k & 3) + j) * (w >> 2) + (k >> 2); };
@@ -77,7 +128,7 @@ __global__ __launch_bounds__(256) void k_kronc_fill(const int64_t *ia, const int
                     ja_n[bn + pos(kn, wn)] = (uint16_t)(c - maj * S);
                     code_n[bn + pos(kn, wn)] = code[q];
                     ++kn;
-                } else {
+                } else if (gia_f) {
                     ja_f[bf + pos(kf, wf)] = (uint16_t)(c / S);          // the minor index is the row's own
                     code_f[bf + pos(kf, wf)] = code[q];
                     ++kf;
@@ -107,14 +158,16 @@ struct GroupStream {
     uint32_t c[NG][4];          // 8 columns (2 bytes each): entries k = 4 u + ks, u = 0..7
     uint32_t cb[NG][2];         // 8 codes
     int      nu[NG];            // entries per lane = width / 4
-    __device__ __forceinline__ void load(int gi, const uint16_t *ja, const uint8_t *code, int64_t base, int64_t end, int lane)
+    // own: the index of the lane's words inside the group -- the lane itself, or lane >> 4 for a far part kept as T (the 16 rows
+    // of a group share their entries: sh = 2, a group is 4 nu words)
+    __device__ __forceinline__ void load(int gi, const uint16_t *ja, const uint8_t *code, int64_t base, int64_t end, int own, int sh = 6)
     {
-        const int n = (int)((end - base) >> 6);
+        const int n = (int)((end - base) >> sh);
         nu[gi] = n;
         typedef uint32_t v4 __attribute__((ext_vector_type(4)));
         typedef uint32_t v2 __attribute__((ext_vector_type(2)));
-        const v4 *jp = reinterpret_cast<const v4 *>(ja + base + (int64_t)lane * n);
-        const v2 *cp = reinterpret_cast<const v2 *>(code + base + (int64_t)lane * n);
+        const v4 *jp = reinterpret_cast<const v4 *>(ja + base + (int64_t)own * n);
+        const v2 *cp = reinterpret_cast<const v2 *>(code + base + (int64_t)own * n);
         const v4 cw = NT ? __builtin_nontemporal_load(jp) : *jp;
         const v2 cd = NT ? __builtin_nontemporal_load(cp) : *cp;
         c[gi][0] = cw.x;
@@ -138,6 +191,7 @@ __device__ __forceinline__ double quad_sum(double v)        // sum over the four
 struct KroncArgs {
     const int64_t *gia_n, *gia_f;
     const uint16_t *ja_n;
+    const int64_t *tf_ptr;      // far part kept as T (uniform over the minor index): entries of major index u at [tf_ptr[u], tf_ptr[u + 1]) of ja_f / code_f
     const uint16_t *ja_f;       // far columns: the target MAJOR index (the element is (that major index, the row's minor index))
     const uint8_t *code_n, *code_f;
     const d2 *dict;
@@ -155,7 +209,8 @@ struct KroncArgs {
     int abl;                    // ablation bits (QBH_KRONC_ABL, wrong results by design): 1 no dictionary lookups, 2 no gathers, 4 no row sums, 8 near: no block load, 16 near: no epilogue
 };
 
-template <int NG, int UN, bool NT>
+// UNI: the far part is T (x) 1 -- a group (b, maj) reads the entries of major index maj from T (0.7 MB at C3: always in the L2)
+template <int NG, int UN, bool NT, bool UNI>
 __global__ __launch_bounds__(256) void k_kronc_far(KroncArgs a)
 {
     static_assert(UN == 8, "a lane's loads cover 8 entries");
@@ -183,7 +238,15 @@ __global__ __launch_bounds__(256) void k_kronc_far(KroncArgs a)
         const int64_t g0 = xb + cidx * CH;
         cidx = cnext;
         const int ng = (int)(xe - g0 < CH ? xe - g0 : CH);
-        const int64_t gp = a.gia_f[g0 + (lane <= ng ? lane : ng)];
+        int64_t gp, ge = 0;
+        if (UNI) {
+            const int64_t g = g0 + (lane < ng ? lane : ng - 1);
+            const int64_t mj = g - (g / a.NU) * a.NU;
+            gp = a.tf_ptr[mj];
+            ge = a.tf_ptr[mj + 1];
+        } else {
+            gp = a.gia_f[g0 + (lane <= ng ? lane : ng)];
+        }
         GroupStream<NG, NT> cur;
         int64_t base[NG];
         auto fetch = [&](GroupStream<NG, NT> &st, int64_t (&bs)[NG], int i0) {
@@ -191,7 +254,8 @@ __global__ __launch_bounds__(256) void k_kronc_far(KroncArgs a)
             for (int gi = 0; gi < NG; ++gi) {
                 const int i = i0 + gi < ng ? i0 + gi : ng - 1;
                 bs[gi] = __shfl(gp, i, 64);
-                st.load(gi, a.ja_f, a.code_f, bs[gi], __shfl(gp, i + 1, 64), lane);
+                if (UNI) st.load(gi, a.ja_f, a.code_f, bs[gi], __shfl(ge, i, 64), lane >> 4, 2);
+                else     st.load(gi, a.ja_f, a.code_f, bs[gi], __shfl(gp, i + 1, 64), lane);
             }
         };
         fetch(cur, base, 0);
@@ -220,8 +284,8 @@ __global__ __launch_bounds__(256) void k_kronc_far(KroncArgs a)
                 for (int u = 0; u < UN; ++u)
                     if (u < cur.nu[gi]) acc += ((a.abl & 1) ? 1.0 : dict_s[cur.cod(gi, u)]) * xv[gi][u];
                 if (cur.nu[gi] > UN) {                                               // rows longer than 32 entries: the lane's further words
-                    const uint16_t *jp = a.ja_f + base[gi] + (int64_t)lane * cur.nu[gi];
-                    const uint8_t *cp = a.code_f + base[gi] + (int64_t)lane * cur.nu[gi];
+                    const uint16_t *jp = a.ja_f + base[gi] + (int64_t)(UNI ? lane >> 4 : lane) * cur.nu[gi];
+                    const uint8_t *cp = a.code_f + base[gi] + (int64_t)(UNI ? lane >> 4 : lane) * cur.nu[gi];
                     for (int u = UN; u < cur.nu[gi]; ++u) acc += dict_s[cp[u]] * xband[gi][(int)jp[u] * wBs[gi]];
                 }
                 if (!(a.abl & 4)) acc = quad_sum(acc);
@@ -349,6 +413,26 @@ __global__ __launch_bounds__(1024) void k_kronc_near(KroncArgs a)
     }
 }
 
+int launch_kronc_far_uniform(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t S, int64_t n, int *d_flag, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kronc_far_uniform, dim3(8192), dim3(256), 0, s, ia, ja, code, S, n, d_flag);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+int launch_kronc_t_widths(const int64_t *ia, const int32_t *ja, int64_t S, int64_t NU, int32_t *wt, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kronc_t_widths, dim3(256), dim3(256), 0, s, ia, ja, S, NU, wt);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+int launch_kronc_t_fill(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t S, int64_t NU, int zcode, const int64_t *tp, uint16_t *tcol,
+                        uint8_t *tcode, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kronc_t_fill, dim3(256), dim3(256), 0, s, ia, ja, code, S, NU, (uint8_t)zcode, tp, tcol, tcode);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
 int launch_kronc_widths(const int64_t *ia, const int32_t *ja, int64_t S, int64_t NU, int nb, int32_t *wn, int32_t *wf, hipStream_t s)
 {
     hipLaunchKernelGGL(k_kronc_widths, dim3(4096), dim3(256), 0, s, ia, ja, S, NU, nb, wn, wf);
@@ -376,6 +460,7 @@ int launch_kronc(const KroncSliced &K, const d2 *dict, int n_dict, const double 
     KroncArgs a{};
     a.gia_n = K.gia_n;
     a.gia_f = K.gia_f;
+    a.tf_ptr = K.tf_ptr;
     a.ja_n = K.ja_n;
     a.ja_f = K.ja_f;
     a.code_n = K.code_n;
@@ -399,8 +484,9 @@ int launch_kronc(const KroncSliced &K, const d2 *dict, int n_dict, const double 
     // tuning switches (measurement only): groups a wavefront has in flight per pass
     static const int far_ng = getenv("QBH_KRONC_FAR_NG") ? atoi(getenv("QBH_KRONC_FAR_NG")) : 1;
     static const int far_nt = getenv("QBH_KRONC_FAR_NT") ? atoi(getenv("QBH_KRONC_FAR_NT")) : 0;
-    auto far_k = far_nt ? (far_ng == 1 ? k_kronc_far<1, 8, true> : k_kronc_far<2, 8, true>)
-                        : (far_ng == 1 ? k_kronc_far<1, 8, false> : far_ng == 3 ? k_kronc_far<3, 8, false> : k_kronc_far<2, 8, false>);
+    auto far_k = K.far_uni ? (far_ng == 1 ? k_kronc_far<1, 8, false, true> : k_kronc_far<2, 8, false, true>)
+                 : far_nt  ? (far_ng == 1 ? k_kronc_far<1, 8, true, false> : k_kronc_far<2, 8, true, false>)
+                           : (far_ng == 1 ? k_kronc_far<1, 8, false, false> : far_ng == 3 ? k_kronc_far<3, 8, false, false> : k_kronc_far<2, 8, false, false>);
     auto near_k = k_kronc_near<4, 8>;
     static int far_occ = 0;
     static size_t attr_done = 0;

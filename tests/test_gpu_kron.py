@@ -311,14 +311,14 @@ def test_headline_lattice_at_U4_reproduces_the_published_ground_state_energy():
     assert abs(e_k - e_mf) <= 1e-11 * abs(e_mf)
 
 
-@pytest.mark.parametrize("form", ["1", "2"])
+@pytest.mark.parametrize("form", ["1", "2", "2g"])
 @pytest.mark.parametrize("shape", [(4, 2, 4, 4), (4, 3, 6, 6), (4, 3, 5, 7), (4, 4, 2, 2), (4, 3, 6, 6, "tri"), (4, 4, 1, 7, "tri")])
 def test_coded_real_form_of_the_split(shape, form, monkeypatch):
     """The library's default form of a real operator (dictionary-coded values, packed-double Lanczos vectors) through the split
     for the row kernel (QBH_KRON_CODED=1: near launch in natural order, far launch with tiled rows and columns accumulating at
     orig(row); QBH_KRON_CODED=2: both parts sliced in groups of 16 rows, far pass gathering whole lines of the tiled x, near pass
-    gathering from the block of x held in LDS -- qbh_kronc.hip): same E0, same step count, same eigenvector as the unsplit coded
-    operator and as the oracle's operator."""
+    gathering from the block of x held in LDS -- qbh_kronc.hip; "2g": with the far part in its general form, not recognised as
+    T (x) 1): same E0, same step count, same eigenvector as the unsplit coded operator and as the oracle's operator."""
     lx, ly, nu, nd = shape[:4]
     n = lx * ly
     # triangular: 3 n bonds -- rows of more than 32 entries per part (what a lane's two loads cover: the scalar tail runs); 4x4
@@ -326,11 +326,15 @@ def test_coded_real_form_of_the_split(shape, form, monkeypatch):
     bonds = lattices.triangular(lx, ly) if len(shape) > 4 else lattices.square(lx, ly)
     P = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_split=0))      # the default format (coded + real fast path), unsplit
     assert P.info().kron_minor == 0 and P.info().value_dict > 0
-    monkeypatch.setenv("QBH_KRON_CODED", form)
+    monkeypatch.setenv("QBH_KRON_CODED", form[0])
+    if form == "2g":                 # the general form of the far part (a Hubbard far part is T (x) 1 and would be kept as T alone)
+        monkeypatch.setenv("QBH_KRONC_FAR_UNI", "0")
     K = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1)
     ik = K.info()
     assert ik.kron_minor > 0 and ik.kron_band in (2, 4, 8, 16) and 0 < ik.kron_far_nnz < ik.nnz and ik.value_dict > 0
-    assert ik.kron_sliced == (1 if form == "2" else 0) and (form == "1" or ik.kron_band == 16)
+    assert ik.kron_sliced == (0 if form == "1" else 1) and (form == "1" or ik.kron_band == 16)
+    if form == "2":                  # T alone: one short row per major index instead of one per row
+        assert ik.kron_far_nnz <= 40 * int(round(ik.nrows / ik.kron_minor))
     rk, rp = q.locate_E0_lanczos(K), q.locate_E0_lanczos(P)
     assert abs(rk.E0 - rp.E0) <= 1e-12 * abs(rp.E0) and abs(rk.steps["E0"] - rp.steps["E0"]) <= 1
     assert abs(abs(np.vdot(rk.eigenvecs, rp.eigenvecs)) - 1.0) < 1e-8
