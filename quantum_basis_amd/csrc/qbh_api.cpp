@@ -792,7 +792,7 @@ void kronc_release(qbh_csr *A)
         for (void *q : {(void *)P->d_ia, (void *)P->d_ja, (void *)P->d_code, (void *)P->d_rb, (void *)P->d_bp})
             if (q) (void)hipFree(q);
     if (K.d_xt) (void)hipFree(K.d_xt);
-    for (void *q : {(void *)K.sl.gia_n, (void *)K.sl.gia_f, (void *)K.sl.ja_n, (void *)K.sl.ja_f, (void *)K.sl.code_n, (void *)K.sl.code_f, (void *)K.sl.d_far, (void *)K.sl.d_dictr, (void *)K.sl.tf_ptr})
+    for (void *q : {(void *)K.sl.gia_n, (void *)K.sl.gia_f, (void *)K.sl.ja_n, (void *)K.sl.ja_f, (void *)K.sl.code_n, (void *)K.sl.code_f, (void *)K.sl.d_far, (void *)K.sl.d_dictr, (void *)K.sl.tf_ptr, (void *)K.sl.dcode})
         if (q) (void)hipFree(q);
     K = qbh_csr::KronCoded{};
 }
@@ -845,11 +845,29 @@ int kronc_build_sliced(qbh_csr *A, int64_t S, int64_t NU)
         }
         L.far_uni = nonuni == 0;
     }
+    // ... and is the near part 1 (x) T' + D (off-diagonal near entries independent of the major index)?  Then T' is kept once -- nb
+    // groups, in the L2 -- beside one diagonal code per row, and the near pass has no stream either.  QBH_KRONC_NEAR_UNI=0: general form.
+    {
+        int nonuni = 0;
+        const char *e = getenv("QBH_KRONC_NEAR_UNI");
+        if (e && atoi(e) == 0) {
+            nonuni = 1;
+        } else {
+            KS_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
+            KS_TRY(qbh::launch_kronc_near_uniform(A->d_ia, A->d_ja, A->d_code, S, n, A->d_flag, s));
+            KS_HIP(hipMemcpyAsync(&nonuni, A->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+            KS_HIP(hipStreamSynchronize(s));
+            KS_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
+        }
+        L.near_uni = nonuni == 0;
+    }
     KS_HIP(hipMalloc(&wn, (size_t)G * sizeof(int32_t)));
     KS_HIP(hipMalloc(&wf, (size_t)G * sizeof(int32_t)));
     KS_TRY(qbh::launch_kronc_widths(A->d_ia, A->d_ja, S, NU, nb, wn, wf, s));
-    KS_HIP(hipMalloc(&L.gia_n, (size_t)(G + 1) * sizeof(int64_t)));
-    KS_TRY(qbh::exclusive_scan(wn, G, L.gia_n, s));
+    const int64_t Gn = L.near_uni ? nb : G;                  // near groups stored
+    if (L.near_uni) KS_TRY(qbh::launch_kronc_s_widths(A->d_ia, A->d_ja, S, nb, wn, s));
+    KS_HIP(hipMalloc(&L.gia_n, (size_t)(Gn + 1) * sizeof(int64_t)));
+    KS_TRY(qbh::exclusive_scan(wn, Gn, L.gia_n, s));
     if (L.far_uni) {
         KS_TRY(qbh::launch_kronc_t_widths(A->d_ia, A->d_ja, S, NU, wf, s));
         KS_HIP(hipMalloc(&L.tf_ptr, (size_t)(NU + 1) * sizeof(int64_t)));
@@ -864,7 +882,7 @@ int kronc_build_sliced(qbh_csr *A, int64_t S, int64_t NU)
     wn = nullptr;
     (void)hipFree(wf);
     wf = nullptr;
-    KS_HIP(hipMemcpy(&L.slots_n, L.gia_n + G, sizeof(int64_t), hipMemcpyDeviceToHost));
+    KS_HIP(hipMemcpy(&L.slots_n, L.gia_n + Gn, sizeof(int64_t), hipMemcpyDeviceToHost));
     if (L.slots_f == 0 || L.slots_n + L.slots_f > 2 * A->nnz + 64 * G) return fail(QBH_OK);          // nothing far, or rows too ragged to pad
     {
         size_t free_b = 0, total_b = 0;
@@ -890,7 +908,14 @@ int kronc_build_sliced(qbh_csr *A, int64_t S, int64_t NU)
         KS_HIP(hipMemcpy(L.d_dictr, hr.data(), 256 * sizeof(double), hipMemcpyHostToDevice));
     }
     KS_HIP(hipMalloc(&K.d_xt, (size_t)n * sizeof(double)));
-    KS_TRY(qbh::launch_kronc_fill(A->d_ia, A->d_ja, A->d_code, S, NU, nb, A->n_dict, L.gia_n, L.ja_n, L.code_n, L.gia_f, L.ja_f, L.code_f, s));
+    if (!(L.near_uni && L.far_uni))
+        KS_TRY(qbh::launch_kronc_fill(A->d_ia, A->d_ja, A->d_code, S, NU, nb, A->n_dict, L.near_uni ? nullptr : L.gia_n, L.ja_n, L.code_n, L.gia_f, L.ja_f,
+                                      L.code_f, s));
+    if (L.near_uni) {
+        KS_TRY(qbh::launch_kronc_s_fill(A->d_ia, A->d_ja, A->d_code, S, nb, A->n_dict, L.gia_n, L.ja_n, L.code_n, s));
+        KS_HIP(hipMalloc(&L.dcode, (size_t)n));
+        KS_TRY(qbh::launch_kronc_dcode(A->d_ia, A->d_ja, A->d_code, n, A->n_dict, L.dcode, s));
+    }
     if (L.far_uni) KS_TRY(qbh::launch_kronc_t_fill(A->d_ia, A->d_ja, A->d_code, S, NU, A->n_dict, L.tf_ptr, L.ja_f, L.code_f, s));
     if (!A->d_wctr) KS_HIP(qbh::dev_alloc(&A->d_wctr, qbh::kWctrRegions * 128 * sizeof(unsigned long long)));
     KS_HIP(hipStreamSynchronize(s));

@@ -309,12 +309,19 @@ struct KroncSliced {
     int64_t  *gia_n = nullptr, *gia_f = nullptr;      // [nb * NU + 1] group pointers: near groups (maj, b), far groups (b, maj)
     uint16_t *ja_n = nullptr;           // near columns relative to the major index's block
     uint16_t *ja_f = nullptr;           // far columns: the target major index (gathered from the tiled x, KronTile{S, NU, 16})
+    bool      near_uni = false;         // the near part is 1 (x) T' + D: gia_n / ja_n / code_n hold the nb groups of T' (shared by all major indices), dcode the diagonal codes
+    uint8_t  *dcode = nullptr;
     bool      far_uni = false;          // the far part is T (x) 1: ja_f / code_f hold T (entries of major index u at tf_ptr[u] ..), no far groups
     int64_t  *tf_ptr = nullptr;
     uint8_t  *code_n = nullptr, *code_f = nullptr;
     double   *d_far = nullptr;          // [nb * NU * 16] far row sums in far-group order
     double   *d_dictr = nullptr;        // [256] real parts of the value dictionary, zero from entry n_dict on (the padding code)
 };
+int launch_kronc_near_uniform(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t S, int64_t n, int *d_flag, hipStream_t s);
+int launch_kronc_s_widths(const int64_t *ia, const int32_t *ja, int64_t S, int nb, int32_t *ws, hipStream_t s);
+int launch_kronc_s_fill(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t S, int nb, int zcode, const int64_t *gs, uint16_t *scol,
+                        uint8_t *scode, hipStream_t s);
+int launch_kronc_dcode(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t n, int zcode, uint8_t *dcode, hipStream_t s);
 int launch_kronc_far_uniform(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t S, int64_t n, int *d_flag, hipStream_t s);
 int launch_kronc_t_widths(const int64_t *ia, const int32_t *ja, int64_t S, int64_t NU, int32_t *wt, hipStream_t s);
 int launch_kronc_t_fill(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t S, int64_t NU, int zcode, const int64_t *tp, uint16_t *tcol,

@@ -102,8 +102,77 @@ __global__ __launch_bounds__(256) void k_kronc_t_fill(const int64_t *ia, const i
     }
 }
 
+// Is the near part 1 (x) T' + D -- the off-diagonal near entries (column relative to the block, code) of row (u, d) the same for
+// every major index u, only the diagonal entry differing?  (Two-species models: a hop of the minor species does not see the
+// major one; the diagonal, U times the double occupancy, sees both.)  One thread per row compares with row (0, d).
+__global__ __launch_bounds__(256) void k_kronc_near_uniform(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t S, int64_t n, int *flag)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+        const int64_t u = r / S, d = r - u * S;
+        if (u == 0) continue;
+        int64_t q = ia[r], q0 = ia[d];
+        const int64_t e = ia[r + 1], e0 = ia[d + 1];
+        bool bad = false;
+        for (;;) {
+            while (q < e && (ja[q] / S != u || ja[q] == r)) ++q;
+            while (q0 < e0 && (ja[q0] / S != 0 || ja[q0] == d)) ++q0;
+            if (q >= e || q0 >= e0) break;
+            bad = bad || ja[q] - u * S != ja[q0] || code[q] != code[q0];
+            ++q;
+            ++q0;
+        }
+        if (bad || q < e || q0 < e0) *flag = 1;
+    }
+}
+
+// the shared near pattern T' (rows (0, d) without their diagonal): group widths, entries (lane-major as below), and the code of
+// every row's diagonal entry (the padding code where a row has none)
+__global__ __launch_bounds__(256) void k_kronc_s_widths(const int64_t *ia, const int32_t *ja, int64_t S, int nb, int32_t *ws)
+{
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < nb; b += (int64_t)gridDim.x * 256) {
+        const int64_t d0 = b * kGB, wb = S - d0 < kGB ? S - d0 : kGB;
+        int m = 0;
+        for (int64_t j = 0; j < wb; ++j) {
+            int c = 0;
+            for (int64_t q = ia[d0 + j]; q < ia[d0 + j + 1]; ++q) c += (ja[q] / S == 0 && ja[q] != d0 + j) ? 1 : 0;
+            m = c > m ? c : m;
+        }
+        ws[b] = ((m + 3) & ~3) * kGB;
+    }
+}
+__global__ __launch_bounds__(256) void k_kronc_s_fill(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t S, int nb, uint8_t zcode,
+                                                      const int64_t *gs, uint16_t *scol, uint8_t *scode)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)nb * kGB; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i >> 4, j = i & 15, d0 = b * kGB, wb = S - d0 < kGB ? S - d0 : kGB;
+        const int64_t base = gs[b], w = (gs[b + 1] - base) >> 4;
+        auto pos = [&](int64_t k) { return (16 * (k & 3) + j) * (w >> 2) + (k >> 2); };
+        int64_t k = 0;
+        if (j < wb)
+            for (int64_t q = ia[d0 + j]; q < ia[d0 + j + 1]; ++q) {
+                if (ja[q] / S != 0 || ja[q] == d0 + j) continue;
+                scol[base + pos(k)] = (uint16_t)ja[q];
+                scode[base + pos(k)] = code[q];
+                ++k;
+            }
+        for (; k < w; ++k) {
+            scol[base + pos(k)] = (uint16_t)(d0 + (j < wb ? j : 0));
+            scode[base + pos(k)] = zcode;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_kronc_dcode(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t n, uint8_t zcode, uint8_t *dcode)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+        uint8_t c = zcode;
+        for (int64_t q = ia[r]; q < ia[r + 1]; ++q)
+            if (ja[q] == r) c = code[q];
+        dcode[r] = c;
+    }
+}
+
 // one thread per (near group, lane j): scatters the row's entries into the two sliced parts and pads both to the group widths
-// (gia_f == nullptr: the far part is kept as T, see above -- only the near part is written)
+// (gia_f == nullptr: the far part is kept as T, see above; gia_n == nullptr: the near part as T' and the diagonal codes)
 __global__ __launch_bounds__(256) void k_kronc_fill(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t S, int64_t NU, int nb,
                                                     uint8_t zcode, const int64_t *gia_n, uint16_t *ja_n, uint8_t *code_n,
                                                     const int64_t *gia_f, uint16_t *ja_f, uint8_t *code_f)
@@ -114,7 +183,7 @@ __global__ __launch_bounds__(256) void k_kronc_fill(const int64_t *ia, const int
         const int64_t maj = g / nb, b = g - maj * nb;
         const int64_t d0 = b * kGB, wb = S - d0 < kGB ? S - d0 : kGB;
         const int64_t gf = b * NU + maj;
-        const int64_t bn = gia_n[g], wn = (gia_n[g + 1] - bn) >> 4;
+        const int64_t bn = gia_n ? gia_n[g] : 0, wn = gia_n ? (gia_n[g + 1] - bn) >> 4 : 0;
         const int64_t bf = gia_f ? gia_f[gf] : 0, wf = gia_f ? (gia_f[gf + 1] - bf) >> 4 : 0;
         int64_t kn = 0, kf = 0;
         // entry k of row j of a group of width w: lane 16 (k % 4) + j, its (k / 4)-th word
@@ -125,6 +194,7 @@ __global__ __launch_bounds__(256) void k_kronc_fill(const int64_t *ia, const int
             for (int64_t q = ia[r]; q < ia[r + 1]; ++q) {
                 const int64_t c = ja[q];
                 if (c / S == maj) {
+                    if (!gia_n) continue;
                     ja_n[bn + pos(kn, wn)] = (uint16_t)(c - maj * S);
                     code_n[bn + pos(kn, wn)] = code[q];
                     ++kn;
@@ -191,6 +261,7 @@ __device__ __forceinline__ double quad_sum(double v)        // sum over the four
 struct KroncArgs {
     const int64_t *gia_n, *gia_f;
     const uint16_t *ja_n;
+    const uint8_t *dcode;       // near part kept as T' (the same groups for every major index) + the code of every row's diagonal entry; else nullptr
     const int64_t *tf_ptr;      // far part kept as T (uniform over the minor index): entries of major index u at [tf_ptr[u], tf_ptr[u + 1]) of ja_f / code_f
     const uint16_t *ja_f;       // far columns: the target MAJOR index (the element is (that major index, the row's minor index))
     const uint8_t *code_n, *code_f;
@@ -300,7 +371,8 @@ __global__ __launch_bounds__(256) void k_kronc_far(KroncArgs a)
 
 // One workgroup of 16 wavefronts per major index at a time (drawn from a counter): x[maj * S .. + S) into LDS, then wavefront w
 // takes a run of consecutive bands of that major index, four groups at a time, the streams of the next four in flight meanwhile.
-template <int NG, int UN>
+// NT: non-temporal stream loads (general form: the stream is read once); the T' form wants its groups kept in the caches
+template <int NG, int UN, bool NT>
 __global__ __launch_bounds__(1024) void k_kronc_near(KroncArgs a)
 {
     static_assert(UN == 8 && NG == 4, "a lane's loads cover 8 entries; a pass is four groups (lane >> 4 picks one in the epilogue)");
@@ -341,10 +413,13 @@ __global__ __launch_bounds__(1024) void k_kronc_near(KroncArgs a)
             const int bw0 = wv * q + r0;
             const int nround = q - r0 < 60 ? q - r0 : 60;
             const int ng = nb - bw0 < 0 ? 0 : nb - bw0 < nround ? nb - bw0 : nround;
-            const int64_t gp = a.gia_n[gbase + (bw0 + lane < nb ? bw0 + lane : nb)];
+            // T' form (a.dcode): every major index reads the same nb groups -- no stream from HBM, the pattern lives in the L2
+            // (ablation bit 32 does the same to an operator in the general form: what the pass costs without its stream)
+            const int64_t gp = a.gia_n[((a.abl & 32) || a.dcode ? 0 : gbase) + (bw0 + lane < nb ? bw0 + lane : nb)];
             struct Pass {
-                GroupStream<NG, true> st;
+                GroupStream<NG, NT> st;
                 double yo, fr;
+                int dc;
             };
             auto fetch = [&](Pass &P, int i0) {
 #pragma unroll
@@ -357,6 +432,7 @@ __global__ __launch_bounds__(1024) void k_kronc_near(KroncArgs a)
                 const bool rowok = i0 + (lane >> 4) < ng && d < a.S && !(a.abl & 16);
                 P.yo = (rowok && a.beta != 0.0) ? a.y[maj * a.S + d] : 0.0;
                 P.fr = rowok ? a.far[((int64_t)b * a.NU + maj) * kGB + (lane & 15)] : 0.0;
+                P.dc = (rowok && a.dcode) ? a.dcode[maj * a.S + d] : a.n_dict;          // n_dict = the padding code (value 0)
             };
             Pass cur;
             if (ng > 0) fetch(cur, 0);
@@ -382,6 +458,7 @@ __global__ __launch_bounds__(1024) void k_kronc_near(KroncArgs a)
                 const int64_t d = (int64_t)b * kGB + (lane & 15);
                 if (i0 + (lane >> 4) < ng && d < a.S && !(a.abl & 16)) {
                     const double xi = win[d];
+                    if (a.dcode) mine += dict[cur.dc] * xi;          // the diagonal entry, kept apart from T'
                     const double yn = a.alpha * (mine + cur.fr) + a.beta * cur.yo + a.gamma * xi;
                     a.y[maj * a.S + d] = yn;
                     acc3[0] += xi * yn;
@@ -413,6 +490,31 @@ __global__ __launch_bounds__(1024) void k_kronc_near(KroncArgs a)
     }
 }
 
+int launch_kronc_near_uniform(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t S, int64_t n, int *d_flag, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kronc_near_uniform, dim3(8192), dim3(256), 0, s, ia, ja, code, S, n, d_flag);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+int launch_kronc_s_widths(const int64_t *ia, const int32_t *ja, int64_t S, int nb, int32_t *ws, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kronc_s_widths, dim3(64), dim3(256), 0, s, ia, ja, S, nb, ws);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+int launch_kronc_s_fill(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t S, int nb, int zcode, const int64_t *gs, uint16_t *scol,
+                        uint8_t *scode, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kronc_s_fill, dim3(256), dim3(256), 0, s, ia, ja, code, S, nb, (uint8_t)zcode, gs, scol, scode);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+int launch_kronc_dcode(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t n, int zcode, uint8_t *dcode, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kronc_dcode, dim3(8192), dim3(256), 0, s, ia, ja, code, n, (uint8_t)zcode, dcode);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
 int launch_kronc_far_uniform(const int64_t *ia, const int32_t *ja, const uint8_t *code, int64_t S, int64_t n, int *d_flag, hipStream_t s)
 {
     hipLaunchKernelGGL(k_kronc_far_uniform, dim3(8192), dim3(256), 0, s, ia, ja, code, S, n, d_flag);
@@ -461,6 +563,7 @@ int launch_kronc(const KroncSliced &K, const d2 *dict, int n_dict, const double 
     a.gia_n = K.gia_n;
     a.gia_f = K.gia_f;
     a.tf_ptr = K.tf_ptr;
+    a.dcode = K.near_uni ? K.dcode : nullptr;
     a.ja_n = K.ja_n;
     a.ja_f = K.ja_f;
     a.code_n = K.code_n;
@@ -487,7 +590,7 @@ int launch_kronc(const KroncSliced &K, const d2 *dict, int n_dict, const double 
     auto far_k = K.far_uni ? (far_ng == 1 ? k_kronc_far<1, 8, false, true> : k_kronc_far<2, 8, false, true>)
                  : far_nt  ? (far_ng == 1 ? k_kronc_far<1, 8, true, false> : k_kronc_far<2, 8, true, false>)
                            : (far_ng == 1 ? k_kronc_far<1, 8, false, false> : far_ng == 3 ? k_kronc_far<3, 8, false, false> : k_kronc_far<2, 8, false, false>);
-    auto near_k = k_kronc_near<4, 8>;
+    auto near_k = K.near_uni ? k_kronc_near<4, 8, false> : k_kronc_near<4, 8, true>;
     static int far_occ = 0;
     static size_t attr_done = 0;
     if (far_occ == 0) {

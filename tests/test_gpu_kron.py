@@ -327,8 +327,9 @@ def test_coded_real_form_of_the_split(shape, form, monkeypatch):
     P = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_split=0))      # the default format (coded + real fast path), unsplit
     assert P.info().kron_minor == 0 and P.info().value_dict > 0
     monkeypatch.setenv("QBH_KRON_CODED", form[0])
-    if form == "2g":                 # the general form of the far part (a Hubbard far part is T (x) 1 and would be kept as T alone)
+    if form == "2g":                 # the general form of both parts (a Hubbard operator is T (x) 1 + 1 (x) T' + D and would be kept as T, T', D)
         monkeypatch.setenv("QBH_KRONC_FAR_UNI", "0")
+        monkeypatch.setenv("QBH_KRONC_NEAR_UNI", "0")
     K = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1)
     ik = K.info()
     assert ik.kron_minor > 0 and ik.kron_band in (2, 4, 8, 16) and 0 < ik.kron_far_nnz < ik.nnz and ik.value_dict > 0

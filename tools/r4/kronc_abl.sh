@@ -4,7 +4,7 @@ mkdir -p gpurun_out/r4kronc
 O=$GRAFT_REPO_ROOT/gpurun_out/r4kronc
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-for abl in 0 8 16 24 31; do
+for abl in 0 32; do
   export QBH_KRON_CODED=2 QBH_KRONC_ABL=$abl
   rm -rf /tmp/kp; mkdir -p /tmp/kp
   timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kp -o k -- python3 $R/bench.py --format fast --steps 10 --warmup 2 --no-converge --no-cpu-baseline --no-matrix-free > /tmp/kp/log 2>&1
