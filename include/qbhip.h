@@ -104,7 +104,10 @@ typedef struct qbh_opts {
                                 copy of the coded operator (3 B per nonzero beside the 5 B per nonzero of the coded CSR, which
                                 stays for complex vectors, shards and qbh_csr_download) whose near pass gathers from the block
                                 of x held in LDS -- taken when S doubles fit one workgroup's LDS (S <= 20480) and the major
-                                count fits 16 bits; used by the all-real solves only (qbh_csr_info.kron_minor / kron_sliced) */
+                                count fits 16 bits; used by the all-real solves only (qbh_csr_info.kron_minor / kron_sliced).
+                                Where the far entries of a row do not depend on its minor index and the near ones, the diagonal
+                                apart, not on its major index (H = T (x) 1 + 1 (x) T' + D: the two-species models), that is
+                                recognised on the device and the parts are kept once (T, T', one diagonal code per row)        */
     int64_t kron_minor;      /* S for an operator created from host / device arrays (0: unknown -> no split); the generators
                                 announce their own; with basis_kind set it is derived from the hint                   */
     int     deterministic;   /* 1: nothing about the operator is decided by a clock and nothing in an SpMV depends on the
