@@ -14,7 +14,10 @@
 // Far pass first (row sums into a buffer in group order), then the near pass with the fused epilogue
 // y = alpha (near + far) + beta y + gamma x and the reductions <x, y>, |y|^2 of the finished y.
 // The row kernel this replaces is bound by the RATE of 8-byte gathers through the L1 (420-490 G/s); here no
-// gather is an L1 request of its own.  Reference operation: csr_mat<T>::MultMv2 (src/sparse.cc:262-289) on a real operator.
+// gather is an L1 request of its own.  Two recognitions, each verified entry by entry on the device: a far part whose entries do not
+// depend on the row's minor index (T (x) 1) is kept as T alone, a near part whose off-diagonal entries do not depend on the row's
+// major index (1 (x) T' + D) as T' and one diagonal code per row -- the two-species models are both, and their passes then stream
+// nothing but vectors.  Reference operation: csr_mat<T>::MultMv2 (src/sparse.cc:262-289) on a real operator.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -592,7 +595,8 @@ int launch_kronc(const KroncSliced &K, const d2 *dict, int n_dict, const double 
                            : (far_ng == 1 ? k_kronc_far<1, 8, false, false> : far_ng == 3 ? k_kronc_far<3, 8, false, false> : k_kronc_far<2, 8, false, false>);
     auto near_k = K.near_uni ? k_kronc_near<4, 8, false> : k_kronc_near<4, 8, true>;
     static int far_occ = 0;
-    static size_t attr_done = 0;
+    static size_t attr_done_k[2] = {0, 0};          // per instance of the near kernel
+    size_t &attr_done = attr_done_k[K.near_uni ? 1 : 0];
     if (far_occ == 0) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, far_k, 256, 0) != hipSuccess || n <= 0) n = 4;
