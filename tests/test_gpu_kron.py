@@ -210,6 +210,47 @@ def test_deterministic_option_on_the_coded_split_of_the_default_format():
     assert abs(rp.E0 - out[0][2]) <= 1e-12 * abs(rp.E0) and abs(rp.steps["E0"] - out[0][1]) <= 1
 
 
+@pytest.mark.parametrize("variant", ["kronecker_sum", "far_sees_minor", "near_sees_major", "both"])
+def test_coded_split_recognises_only_what_is_there(variant):
+    """The recognitions of the coded split (far part T (x) 1, near part 1 (x) T' + D) are decided by the ENTRIES, not by the model:
+    the Hubbard 4x2 operator from host arrays in the default format (value codes, real fast path) -- as it is, with the far
+    entries of the minor indices divisible by 3 negated (still Hermitian: a far entry keeps the minor index; the far part is
+    no longer T (x) 1), with the off-diagonal near entries of every fifth major index negated (the near part is no longer
+    1 (x) T' + D), and with both.  Each must give the lowest eigenvalue of ITS matrix (scipy eigsh on the same arrays) and its
+    eigenvector; qbh_csr_info shows which far form was taken."""
+    n, nu, nd = 8, 4, 4
+    G = q.csr_mat.hubbard(n, nu, nd, lattices.square(4, 2), t=1.0, U=1.3, opts=q.make_opts(kron_split=0, **PLAIN))
+    ia, ja, val = G.download()
+    dim, S = G.dim, 70
+    G.destroy()
+    rows = np.repeat(np.arange(dim), np.diff(ia))
+    val = val.copy()
+    far = (rows // S) != (ja // S)
+    near_off = (~far) & (rows != ja)
+    if variant in ("far_sees_minor", "both"):
+        val[far & ((rows % S) % 3 == 0)] *= -1.0
+    if variant in ("near_sees_major", "both"):
+        val[near_off & ((rows // S) % 5 == 0)] *= -1.0
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    M = sp.csr_matrix((val.real, ja, ia), shape=(dim, dim))
+    assert abs(M - M.T).max() == 0.0
+    w, v = spl.eigsh(M, k=1, which="SA", tol=1e-13)                 # (a dense eigh of 4900 x 4900 costs 7 s per variant)
+    A = q.csr_mat(dim, ia, ja.astype(np.int64), val, sym=False, opts=q.make_opts(kron_minor=S, kron_split=2))
+    info = A.info()
+    assert info.value_dict > 0 and info.kron_minor == S and info.kron_sliced == 1 and info.kron_band == 16
+    nnz_far = int(far.sum())
+    if variant in ("kronecker_sum", "near_sees_major"):
+        assert info.kron_far_nnz <= 70 * 16                        # T alone: at most 16 entries for each of the 70 major indices
+    else:
+        assert info.kron_far_nnz >= nnz_far                        # every far entry stored (plus padding)
+    r = q.locate_E0_lanczos(A, nev=1, ncv=1, maxit=600)
+    assert A.stats().n_spmv_real > 0
+    assert abs(r.E0 - w[0]) <= 1e-11 * abs(w[0])
+    assert abs(abs(np.vdot(r.eigenvecs, v[:, 0])) - 1.0) < 1e-7
+    A.destroy()
+
+
 def test_headline_operator_split_and_sliced_equals_the_matrix_free_operator_at_full_size():
     """BASELINE configs[2] (C3, dim 165,636,900, nnz 5.82e9) exactly as bench.py's headline applies it: complex128 CSR, Kronecker
     split with the sliced far part.  The oracle cannot run at this size; the independent path is the matrix-free operator (no
