@@ -431,6 +431,7 @@ def main():
                     help="heisenberg (single-species) workloads, complex128 format: tell the library the basis (qbh_opts.basis_kind = "
                          "QBH_BASIS_SPIN_SECTOR) and cut the sites into this many LOW sites and the rest: the operator is held class-major "
                          "internally and split into near (low-half bonds) / far (high-half bonds) / cross parts")
+    ap.add_argument("--cols16", type=int, default=1, help="qbh_opts.kron_cols16: 1 (library default) the parts of a split operator keep 2-byte columns, 0 int32 columns")
     ap.add_argument("--deterministic", action="store_true", help="qbh_opts.deterministic: static walks, nothing timed at creation (bit-identical a_j / b_j from run to run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed run to convergence (E0)")
@@ -583,7 +584,8 @@ def main():
     with torch.cuda.stream(stream):
         opts = q.make_opts(device=local_rank, stream=stream.cuda_stream, spmv_kernel=args.kernel,
                            nnz_per_block=args.npb, xcd_swizzle=args.swizzle,
-                           value_dict=value_dict, real_fast_path=real_fp, profile=1, deterministic=1 if args.deterministic else 0)
+                           value_dict=value_dict, real_fast_path=real_fp, profile=1, deterministic=1 if args.deterministic else 0,
+                           kron_cols16=args.cols16)
         if args.site_cut and W["kind"] == "heisenberg" and world == 1 and value_dict == 0:
             opts.basis_kind, opts.n_sites, opts.n_up, opts.n_dn = q._lib.BASIS_SPIN_SECTOR, W["n_sites"], args.site_cut, W["n_dn"]
         t_gen = time.time()
@@ -698,6 +700,8 @@ def main():
                                          if not (coded or real_used) else "value codes %s, real fast path %s" % (coded, real_used),
                                          "value_dict": info.value_dict, "real_gather": real_used, "deterministic": bool(args.deterministic),
                                          "kron_split": ({"minor": int(info.kron_minor), "band": int(info.kron_band), "far_nnz": int(info.kron_far_nnz), "far_sliced": bool(info.kron_sliced),
+                                                         "columns": {0: "int32", 1: "near part 2-byte, far part int32", 2: "near part int32, far part 2-byte",
+                                                                     3: "2-byte in both parts (relative to the wave block's base; qbh_csr_download re-derives int32)"}[int(info.kron_cols16)],
                                                          "launches_per_spmv": ("k_kron_tile_re + k_kronc_far (sliced, whole lines of the tiled x) + k_kronc_near (sliced, x block in LDS, epilogue)"
                                                                                if (info.value_dict and info.kron_sliced) else
                                                                                "k_kron_tile_re + k_spmv_rows (near) + k_spmv_rows (far, tiled rows and columns; QBH_KRON_CODED=1)"

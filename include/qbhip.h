@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QBH_VERSION 400
+#define QBH_VERSION 500
 
 /* error codes */
 #define QBH_OK          0
@@ -125,6 +125,11 @@ typedef struct qbh_opts {
                                 that does not describe the matrix is detected (the permuted operator must have the product
                                 structure) and the operator is then kept exactly as given                              */
     int     n_sites, n_up, n_dn;
+    int     kron_cols16;     /* 1 (default): the parts of a split two-species operator keep 2-byte columns where they fit -- near:
+                                relative to the major index of the wave block's first row (S <= 32768); far (whole operator, sliced):
+                                the target major index (major count <= 32768); 16 instead of 20 B of stream per nonzero, the same
+                                values in the same order: results are bit-identical to the int32 form.  qbh_csr_download re-derives
+                                the int32 columns.  0: int32 columns (SURVEY 8(d)'s format to the byte)                     */
 } qbh_opts;
 
 void qbh_opts_default(qbh_opts *o);
@@ -194,6 +199,7 @@ typedef struct qbh_csr_info {
     int     kron_classes;                    /* classes of the product structure: 1 two-species operators, > 1 a cut single-species sector */
     int64_t kron_cross_nnz;                  /* nonzeros of the third (unstructured) part                                       */
     int     gather_parts;                    /* communicator attached: band ranges the gather of x travels in (1 = one gather)   */
+    int     kron_cols16;                     /* bit 0: the near part holds 2-byte columns, bit 1: the far part (qbh_opts.kron_cols16)   */
 } qbh_csr_info;
 int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info);
 

@@ -34,7 +34,7 @@ class Opts(C.Structure):
                 ("nnz_per_block", C.c_int), ("xcd_swizzle", C.c_int), ("value_dict", C.c_int),
                 ("profile", C.c_int), ("check_hermitian", C.c_int), ("real_fast_path", C.c_int),
                 ("kron_split", C.c_int), ("kron_minor", C.c_int64), ("deterministic", C.c_int), ("basis_kind", C.c_int),
-                ("n_sites", C.c_int), ("n_up", C.c_int), ("n_dn", C.c_int)]
+                ("n_sites", C.c_int), ("n_up", C.c_int), ("n_dn", C.c_int), ("kron_cols16", C.c_int)]
 
 
 class CsrInfo(C.Structure):
@@ -44,7 +44,8 @@ class CsrInfo(C.Structure):
                 ("device", C.c_int), ("stream", C.c_void_p), ("create_ms", C.c_double),
                 ("create_bytes_in", C.c_int64), ("kron_minor", C.c_int64), ("kron_far_nnz", C.c_int64), ("kron_band", C.c_int), ("kron_sliced", C.c_int),
                 ("kron_inplace", C.c_int), ("tuned", C.c_int), ("tune_ms_rows", C.c_double), ("tune_ms_wave", C.c_double),
-                ("basis_internal", C.c_int), ("kron_classes", C.c_int), ("kron_cross_nnz", C.c_int64), ("gather_parts", C.c_int)]
+                ("basis_internal", C.c_int), ("kron_classes", C.c_int), ("kron_cross_nnz", C.c_int64), ("gather_parts", C.c_int),
+                ("kron_cols16", C.c_int)]
 
 
 class LanczosRow(C.Structure):

@@ -96,6 +96,7 @@ extern "C" void qbh_opts_default(qbh_opts *o)
     o->check_hermitian = 1;
     o->real_fast_path = 1;
     o->kron_split = 1;
+    o->kron_cols16 = 1;
     o->kron_minor = 0;
     o->deterministic = 0;
     o->basis_kind = QBH_BASIS_NONE;
@@ -336,7 +337,7 @@ void kron_free_aux(qbh_csr *A)
 {
     qbh_csr::KronSplit &K = A->kron;
     for (void *q : {(void *)K.ia_n, (void *)K.ia_f, (void *)K.wd_n, (void *)K.wd_f, (void *)K.d_xt, (void *)K.d_far, (void *)K.ia_x, (void *)K.xrow,
-                    (void *)K.wd_x, (void *)K.d_cls})
+                    (void *)K.wd_x, (void *)K.d_cls, (void *)K.c16_n, (void *)K.c16_f})
         if (q) (void)hipFree(q);
     if (K.own_far) {
         if (K.ja_f) (void)hipFree(K.ja_f);
@@ -358,6 +359,8 @@ qbh::KronParts kron_parts(const qbh_csr *A)
     p.fp = K.ia_f;
     p.ja_n = K.ja_n;
     p.ja_f = K.ja_f;
+    p.c16_n = K.c16_n;
+    p.c16_f = K.c16_f;
     p.val_n = K.val_n;
     p.val_f = K.val_f;
     p.ia_x = K.ia_x;
@@ -426,7 +429,65 @@ int kron_geometry(qbh_csr *A)
         if (K.nnz_x > 0)
             QBH_TRY(wave_geometry_for(A, K.ia_x, n, K.nnz_x, (double)K.nnz_x / (double)n, false, -1, &K.wd_x, &K.nwb_x, &K.tpr_x, &K.grid_x));
     }
+    // 2-byte columns are relative to a base the block's descriptor names: fresh descriptors get it again
+    if (K.c16_n) QBH_TRY(qbh::launch_kron_desc_c16(K.wd_n, K.nwb_n, K.t.S, false, false, A->stream));
+    if (K.c16_f) QBH_TRY(qbh::launch_kron_desc_c16(K.wd_f, K.nwb_f, K.t.NU, true, false, A->stream));
     QBH_HIP(hipStreamSynchronize(A->stream));
+    return QBH_OK;
+}
+
+// 2-byte columns for the parts of a one-class split (qbh_opts.kron_cols16).  The two passes are bound by the rate of line
+// requests, not by bytes: the column stream is 16 of a block's ~150 lines as int32 and 8 as uint16.
+//   near part: column - (first column of the shard + pad * S), pad = major index of the block's first row (a block of whole rows
+//              with <= 512 entries reaches into the next major index at most: values < 2 S);
+//   far part (sliced, whole operator): target major index + (band - band of the block's first group) * NU; the element of the
+//              tiled x is band0 * 8 NU + 8 * value + slot % 8.
+// Each part is converted when every value fits 16 bits (checked on the device) and then lives in an allocation of its own; when
+// both are and nothing else sits in the int32 array it is released (C3: 23.3 GB -> 11.6 GB of columns).  qbh_csr_download /
+// kron_restore re-derive the int32 columns (k_kron_merge_rows): value mod S inside the row's block, value mod NU as the major index.
+int kron_short_cols(qbh_csr *A)
+{
+    qbh_csr::KronSplit &K = A->kron;
+    if (!A->opts.kron_cols16 || K.map.nc != 1 || !K.inplace || K.c16_n || K.c16_f) return QBH_OK;
+    hipStream_t s = A->stream;
+    const int64_t S = K.t.S, NU = K.t.NU;
+    auto convert = [&](bool far, uint16_t **out) -> int {
+        const int64_t cnt = far ? K.far_slots : K.nnz_n;
+        uint16_t *c = nullptr;
+        if (hipMalloc(&c, (size_t)(cnt + 64) * sizeof(uint16_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            return QBH_OK;                               // no room: the part keeps its int32 columns
+        }
+        int bad = 0;
+        int rc = qbh::launch_kron_desc_c16(far ? K.wd_f : K.wd_n, far ? K.nwb_f : K.nwb_n, far ? NU : S, far, false, s);
+        hipError_t he = hipMemsetAsync(A->d_flag, 0, sizeof(int), s);
+        if (rc == QBH_OK && he == hipSuccess) he = hipMemsetAsync(c + cnt, 0, 64 * sizeof(uint16_t), s);
+        if (rc == QBH_OK && he == hipSuccess)
+            rc = far ? qbh::launch_kron_c16_far(K.wd_f, K.ja_f, K.far_slots, NU, c, A->d_flag, s)
+                     : qbh::launch_kron_c16_near(K.wd_n, K.nwb_n, K.ja_n, S, A->row_offset, c, A->d_flag, s);
+        if (rc == QBH_OK && he == hipSuccess) he = hipMemcpyAsync(&bad, A->d_flag, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (rc == QBH_OK && he == hipSuccess) he = hipStreamSynchronize(s);
+        if (rc == QBH_OK && he == hipSuccess) he = hipMemsetAsync(A->d_flag, 0, sizeof(int), s);
+        if (rc != QBH_OK || he != hipSuccess || bad) {  // does not fit (or failed): back to the plain descriptors
+            (void)hipGetLastError();
+            (void)hipFree(c);
+            const int rc2 = qbh::launch_kron_desc_c16(far ? K.wd_f : K.wd_n, far ? K.nwb_f : K.nwb_n, far ? NU : S, far, true, s);
+            if (hipStreamSynchronize(s) != hipSuccess || rc2 != QBH_OK) return QBH_EHIP;
+            return rc != QBH_OK ? rc : he != hipSuccess ? QBH_EHIP : QBH_OK;
+        }
+        *out = c;
+        return QBH_OK;
+    };
+    if (K.nnz_n > 0 && 2 * S <= 65536) QBH_TRY(convert(false, &K.c16_n));
+    // far: the sliced layout over the tiled order of the WHOLE vector (a shard under a communicator gathers rank-major blocks)
+    if (K.sliced && !K.own_far && K.t.B == 8 && A->nrows == A->ncols && A->row_offset == 0 && 2 * NU <= 65536 && K.far_slots > 0)
+        QBH_TRY(convert(true, &K.c16_f));
+    if (K.c16_n && K.c16_f && A->own_arrays && (K.nnz_x == 0 || K.own_x)) {      // nothing is left in the int32 array
+        (void)hipFree(A->d_ja);
+        A->d_ja = nullptr;
+    }
+    if (K.c16_n) K.ja_n = nullptr;
+    if (K.c16_f) K.ja_f = nullptr;
     return QBH_OK;
 }
 
@@ -743,6 +804,7 @@ int kron_build(qbh_csr *A)
     }
     K.inplace = true;
     KRON_TRY(kron_geometry(A));
+    KRON_TRY(kron_short_cols(A));
     if (getenv("QBH_PRINT_PTRS"))
         fprintf(stderr, "qbhip kron arrays: ia %p ja %p val %p | ia_n %p fp %p | ja_f %p val_f %p | wd_n %p wd_f %p | far %p | nnz_n %lld far_slots %lld\n", (void *)A->d_ia,
                 (void *)A->d_ja, (void *)A->d_val, (void *)K.ia_n, (void *)K.ia_f, (void *)K.ja_f, (void *)K.val_f, (void *)K.wd_n, (void *)K.wd_f, (void *)K.d_far,
@@ -775,7 +837,7 @@ int kron_restore(qbh_csr *A)
         (void)hipFree(nval);
         return rc;
     }
-    (void)hipFree(A->d_ja);
+    if (A->d_ja) (void)hipFree(A->d_ja);
     (void)hipFree(A->d_val);
     A->d_ja = nja;
     A->d_val = nval;
@@ -1619,6 +1681,7 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->kron_sliced = A->kron.active && A->kron.sliced ? 1 : 0;
     info->kron_inplace = A->kron.active && A->kron.inplace ? 1 : 0;
     info->kron_classes = 0;
+    info->kron_cols16 = 0;
     info->kron_cross_nnz = 0;
     info->gather_parts = A->has_comm ? ((A->kron.active && A->kron.comm_tiled) ? A->kron.n_parts : 1) : 0;
     if (A->kron.active) {
@@ -1626,6 +1689,9 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
         info->n_blocks = K.nwb_n + K.nwb_f + K.nwb_x;
         info->bytes_matrix = (A->nrows + 1) * 16 + ((K.sliced ? K.n_groups : A->nrows) + 1) * 8 + (K.n_xrows + 1) * (K.xrow ? 12 : 8) +
                              (K.own_far ? nnz + K.far_slots : nnz) * 20 + (K.nwb_n + K.nwb_f + K.nwb_x + 6) * 16;
+        // columns as they are held: the int32 array while anything lives in it, 2 bytes per entry of a converted part
+        info->bytes_matrix += (A->d_ja ? 0 : -4 * nnz) + 2 * (K.c16_n ? K.nnz_n : 0) + 2 * (K.c16_f ? K.far_slots : 0) + ((!A->d_ja && K.own_x) ? 4 * K.nnz_x : 0);
+        info->kron_cols16 = (K.c16_n ? 1 : 0) | (K.c16_f ? 2 : 0);
         info->kron_classes = K.map.nc;
         info->kron_cross_nnz = K.nnz_x;
         for (int c = 0; c < K.map.nc; ++c) info->kron_minor = std::max<int64_t>(info->kron_minor, K.map.S[c]);      // several classes: the largest block
@@ -1714,7 +1780,7 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
         if (A->kron.active && A->kron.comm_tiled) {       // far columns back to the tiled order of the whole vector
             Bind bind(A);
             const qbh::KronCols one = kron_cols_one(A->kron.t.S, A->kron.NUg, A->kron.t.B);
-            QBH_TRY(qbh::launch_kron_remap_cols(A->kron.ja_f, A->kron.far_slots, A->kron.cols, one, A->stream));
+            if (A->kron.ja_f) QBH_TRY(qbh::launch_kron_remap_cols(A->kron.ja_f, A->kron.far_slots, A->kron.cols, one, A->stream));
             QBH_TRY(qbh::launch_kron_remap_cols(A->kron.ja_x, A->kron.nnz_x, A->kron.cols, one, A->stream));
             QBH_HIP(hipStreamSynchronize(A->stream));
             A->kron.cols = one;
@@ -1764,7 +1830,7 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
         Bind bind(A);
         qbh_csr::KronSplit &K = A->kron;
         const int64_t S = K.active ? K.t.S : 1;
-        bool mine = K.active && K.map.nc == 1 && comm->nranks <= qbh::kKronMaxRanks;
+        bool mine = K.active && K.map.nc == 1 && comm->nranks <= qbh::kKronMaxRanks && !(K.c16_f && comm->nranks > 1);
         if (mine) {
             if (comm->row_cuts) {
                 for (int q = 0; q <= comm->nranks; ++q) mine = mine && comm->row_cuts[q] % S == 0;
@@ -1792,7 +1858,7 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
                 const int64_t cut = comm->row_cuts ? comm->row_cuts[q] : std::min<int64_t>((int64_t)q * comm->nblk, A->ncols);
                 to.cu[q] = cut / S;
             }
-            QBH_TRY(qbh::launch_kron_remap_cols(K.ja_f, K.far_slots, K.cols, to, A->stream));
+            if (K.ja_f) QBH_TRY(qbh::launch_kron_remap_cols(K.ja_f, K.far_slots, K.cols, to, A->stream));      // 2-byte far columns: one rank, nothing moves
             QBH_TRY(qbh::launch_kron_remap_cols(K.ja_x, K.nnz_x, K.cols, to, A->stream));
             QBH_HIP(hipStreamSynchronize(A->stream));
             K.cols = to;
@@ -2032,6 +2098,10 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
     qbh::SpmvArgs f{};                                       // far pass
     f.ia = K.ia_f;
     f.ja = K.ja_f;
+    f.ja16 = K.c16_f;
+    f.kS = K.t.S;
+    f.kNU = K.NUg;
+    f.kB = K.t.B;
     f.val = K.val_f;
     f.wd = K.wd_f;
     f.n_wb = K.nwb_f;
@@ -2047,11 +2117,12 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
     qbh::SpmvArgs nr{};                                      // near pass
     nr.ia = K.ia_n;
     nr.ja = K.ja_n;
+    nr.ja16 = K.c16_n;
     nr.val = K.val_n;
     nr.wd = K.wd_n;
     nr.n_wb = K.nwb_n;
     nr.nrows = A->nrows;
-    nr.xg = xl - A->row_offset;                              // near columns are global indices of locally-owned elements
+    nr.xg = K.c16_n ? xl : xl - A->row_offset;               // near columns are global indices of locally-owned elements (2-byte: relative to the shard)
     nr.xl = xl;
     nr.y = y;
     nr.alpha = alpha;

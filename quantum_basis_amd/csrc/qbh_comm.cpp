@@ -46,13 +46,26 @@ std::string g_rccl_error;          // why the loader failed (written once, under
 
 void load_rccl(RcclApi &api)
 {
-    // a copy that is already mapped (e.g. the one torch bundles) is reused: same soname
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (api.handle) break;
-        const char *e = dlerror();          // dlerror() clears the message: read it exactly once per failure
-        g_rccl_error = e ? e : "no such library";
+    // QBH_RCCL_LIB names the library outright -- test rigs put tests/stub_rccl/librccl_stub.so there to run N ranks on one
+    // GPU, which real RCCL refuses; it is loaded RTLD_LOCAL so that its nccl* symbols never shadow a real librccl in the process
+    if (const char *path = getenv("QBH_RCCL_LIB")) {
+        if (*path) {
+            api.handle = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+            if (!api.handle) {
+                const char *e = dlerror();
+                g_rccl_error = std::string("QBH_RCCL_LIB=") + path + ": " + (e ? e : "cannot be loaded");
+                return;
+            }
+        }
     }
+    // a copy that is already mapped (e.g. the one torch bundles) is reused: same soname
+    if (!api.handle)
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (api.handle) break;
+            const char *e = dlerror();          // dlerror() clears the message: read it exactly once per failure
+            g_rccl_error = e ? e : "no such library";
+        }
     if (!api.handle) return;
 #define QBH_SYM(field, sym)                                                   \
     api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, sym)); \

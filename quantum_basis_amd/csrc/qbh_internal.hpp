@@ -85,6 +85,10 @@ struct SpmvArgs {
     int            kB;         // band width of the tiling
     int            rowmap;     // row kernel, coded Kronecker split: rows are in TILED order; y / x_local are addressed at orig(row)
     const struct KronCls *kcls; // near pass of an operator with several classes (OPS 4): class table, nc + 1 entries
+    // 2-byte columns of a part of the Kronecker split (k_spmv_wave2<.., C16 = true>; ja is then unused): relative to a base the
+    // block's descriptor names (WaveDesc::pad) -- near part: column - pad * kS (pad = major index of the block's first row);
+    // sliced far part: target major index + (band - (pad >> 1)) * kNU, the x element is (pad >> 1) * 8 kNU + 8 * that + lane % 8
+    const uint16_t *ja16;
 };
 
 // element (u, d) of the product basis <-> its position in the band-major ("tiled") order (band, u, d % B): the B minor
@@ -208,6 +212,7 @@ struct KronMap {
 struct KronParts {
     const int64_t *ia, *ia_n, *fp;      // CSR row pointers; near row pointers; far row pointers (or group pointers when sliced)
     const int32_t *ja_n, *ja_f;
+    const uint16_t *c16_n, *c16_f;      // 2-byte forms of the near / far columns (nullptr: the int32 arrays hold them); see SpmvArgs::ja16
     const d2      *val_n, *val_f;
     const int64_t *ia_x;                // cross part: row pointers over xrow (compact row list) or over all rows (xrow == nullptr)
     const int32_t *xrow;
@@ -234,6 +239,13 @@ int launch_kron_combine(const d2 *far, const KronTile &t, const d2 *xl, d2 *y, i
 int launch_kron_cross_rows(const int64_t *ia_x, const int32_t *xrow, int64_t n_xrows, const int32_t *ja_x, const d2 *val_x, const d2 *xt,
                            const KronTile &t, d2 *far, hipStream_t s);
 int launch_kron_desc_classes(WaveDesc *wd, int64_t n_wb, const KronCls *cls, int nc, hipStream_t s);
+// 2-byte columns: the base every block's columns are relative to goes into its descriptor (far = false: pad = r0 / div, the major
+// index of the block's first row; far = true: pad = cut flag | band of the block's first group << 1), undo restores the plain form
+int launch_kron_desc_c16(WaveDesc *wd, int64_t n_wb, int64_t div, bool far, bool undo, hipStream_t s);
+// near columns of every block relative to its base / far columns as target major index relative to the block's band; *flag is
+// raised when a value does not fit 16 bits (or a far column is not what the sliced layout promises)
+int launch_kron_c16_near(const WaveDesc *wd, int64_t n_wb, const int32_t *ja, int64_t S, int64_t col0, uint16_t *out, int *flag, hipStream_t s);
+int launch_kron_c16_far(const WaveDesc *wd, const int32_t *ja, int64_t slots, int64_t NU, uint16_t *out, int *flag, hipStream_t s);
 int launch_kron_check2(const int64_t *ia, const int32_t *ja, int64_t nrows, int64_t S, int64_t U0, int *d_flag, hipStream_t s);
 // qbh_opts.basis_kind (qbh_reorder.hip): re-express the plain CSR of A in the library's internal order, keep the vector map
 int basis_to_internal(qbh_csr *A, int kind, int n_sites, int n_up, int n_dn, bool *applied);
@@ -565,6 +577,7 @@ struct qbh_csr {
         int64_t  n_groups = 0, far_slots = 0;   // far_slots = entries stored in the far arrays (nnz_f + padding)
         int64_t *ia_n = nullptr, *ia_f = nullptr;
         int32_t *ja_n = nullptr, *ja_f = nullptr;
+        uint16_t *c16_n = nullptr, *c16_f = nullptr;    // 2-byte columns (qbh_opts.kron_cols16): allocations of their own; the int32 form of that part is gone
         qbh::d2 *val_n = nullptr, *val_f = nullptr;
         qbh::WaveDesc *wd_n = nullptr, *wd_f = nullptr;
         int64_t  nwb_n = 0, nwb_f = 0;

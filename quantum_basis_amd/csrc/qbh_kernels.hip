@@ -826,9 +826,12 @@ int launch_build_wavedesc(const int64_t *d_ia, int64_t nrows, int64_t window, Wa
 #else
 #define QBH_ROW_STORE(p, v) (*(p) = (v))
 #endif
-template <int TPR, int OPS, bool DYN>
+// C16: the part's columns are 2 bytes each (a.ja16), relative to a base named by the block's descriptor (SpmvArgs::ja16): 8 lines
+// of column stream per block instead of 16 -- the passes are bound by line requests, not bytes
+template <int TPR, int OPS, bool DYN, bool C16 = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 0 || OPS == 3) ? QBH_FAR_WAVES : QBH_NEAR_WAVES, (OPS == 0 || OPS == 3) ? QBH_FAR_WAVES : QBH_NEAR_WAVES))) void k_spmv_wave2(SpmvArgs a)
 {
+    static_assert(!C16 || OPS == 1 || OPS == 2 || OPS == 3, "2-byte columns: the one-class near passes and the sliced far pass");
     constexpr int NW = 512, RP = 64 / TPR;
     constexpr bool EPI = OPS == 1 || OPS == 2 || OPS == 4, FAR = OPS == 2 || OPS == 4;      // OPS 1: the fused epilogue WITHOUT a far addend
     constexpr bool MULTI = OPS == 4;             // OPS 4 = OPS 2 for an operator with several classes (KronMap): the far result of a row sits at its
@@ -862,6 +865,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
         int r0, nr, n;           // n = entries from p0 to the block's end; -1: a row longer than the tile (row-at-a-time path)
         bool cont0, cont1;       // OPS 3: the first group began in the block before / the last group goes on in the block after
         int cls;                 // OPS 4: class of the block's first row
+        int64_t xb;              // C16: element of the gather source that column value 0 of this block names
     };
     // far result of one row (OPS 2 / 4)
     auto far_at = [&](int64_t row, int c0) -> d2 {
@@ -891,6 +895,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
         b.r0 = __builtin_amdgcn_readlane(dq, 2);
         b.nr = __builtin_amdgcn_readlane(dq, 6) - b.r0;
         b.cls = MULTI ? __builtin_amdgcn_readlane(dq, 3) : 0;
+        b.xb = 0;
+        if constexpr (C16) {
+            const int64_t pad = (uint32_t)__builtin_amdgcn_readlane(dq, 3);
+            b.xb = OPS == 3 ? (pad >> 1) * 8 * a.kNU : pad * a.kS;
+        }
         b.cont0 = OPS == 3 && (__builtin_amdgcn_readlane(dq, 3) & 1);
         b.cont1 = OPS == 3 && (__builtin_amdgcn_readlane(dq, 7) & 1);
         if (b.cont1) b.nr += 1;
@@ -922,7 +931,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = lane + u * 64;
-            c[u] = ntload(a.ja + base + (i < nn ? i : nm1)) & a.colmask;
+            if constexpr (C16) c[u] = ntload(a.ja16 + base + (i < nn ? i : nm1));
+            else               c[u] = ntload(a.ja + base + (i < nn ? i : nm1)) & a.colmask;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -1105,7 +1115,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
 #endif
         } else
 #endif
-        {
+        if constexpr (C16) {
+            // sliced far part: slot i of a block belongs to far row 8 g + i % 8 (groups and blocks start at multiples of 8 slots)
+            const d2 *xq = a.xg + b0.xb + (OPS == 3 ? (lane & 7) : 0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = xq[OPS == 3 ? (cA[u] << 3) : cA[u]];
+        } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) xv[u] = a.xg[cA[u]];
         }
@@ -1170,7 +1185,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
                 const int64_t row = (int64_t)b0.r0 + r;
                 const int64_t s_ = a.ia[row], e_ = a.ia[row + 1];
                 d2 sum = {0.0, 0.0};
-                for (int64_t k = s_ + lane; k < e_; k += 64) sum += cmul(a.val[k], a.xg[a.ja[k] & a.colmask]);
+                for (int64_t k = s_ + lane; k < e_; k += 64) sum += cmul(a.val[k], C16 ? a.xg[b0.xb + a.ja16[k]] : a.xg[a.ja[k] & a.colmask]);
                 sum.x = wave_sum(sum.x);
                 sum.y = wave_sum(sum.y);
                 if (lane == 0) {
@@ -1237,27 +1252,36 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
     }
 }
 
-template <int OPS>
+template <int OPS, bool C16 = false>
 static void launch_wave2_tpr(const SpmvArgs &a, int tpr, int grid, hipStream_t s)
 {
     if (a.swizzle == 3) {
         switch (tpr) {
-        case 2:  hipLaunchKernelGGL((k_spmv_wave2<2, OPS, true>),  dim3(grid), dim3(kBlock), 0, s, a); break;
-        case 4:  hipLaunchKernelGGL((k_spmv_wave2<4, OPS, true>),  dim3(grid), dim3(kBlock), 0, s, a); break;
-        default: hipLaunchKernelGGL((k_spmv_wave2<8, OPS, true>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 2:  hipLaunchKernelGGL((k_spmv_wave2<2, OPS, true, C16>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 4:  hipLaunchKernelGGL((k_spmv_wave2<4, OPS, true, C16>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_spmv_wave2<8, OPS, true, C16>),  dim3(grid), dim3(kBlock), 0, s, a); break;
         }
     } else {
         switch (tpr) {
-        case 2:  hipLaunchKernelGGL((k_spmv_wave2<2, OPS, false>),  dim3(grid), dim3(kBlock), 0, s, a); break;
-        case 4:  hipLaunchKernelGGL((k_spmv_wave2<4, OPS, false>),  dim3(grid), dim3(kBlock), 0, s, a); break;
-        default: hipLaunchKernelGGL((k_spmv_wave2<8, OPS, false>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 2:  hipLaunchKernelGGL((k_spmv_wave2<2, OPS, false, C16>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 4:  hipLaunchKernelGGL((k_spmv_wave2<4, OPS, false, C16>),  dim3(grid), dim3(kBlock), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_spmv_wave2<8, OPS, false, C16>),  dim3(grid), dim3(kBlock), 0, s, a); break;
         }
     }
 }
 
 int launch_spmv_wave2(const SpmvArgs &a, int tpr, int ops, int grid, hipStream_t s)
 {
-    if (ops == 0)      launch_wave2_tpr<0>(a, tpr, grid, s);
+    if (a.ja16 != nullptr) {                 // 2-byte columns: the one-class near passes and the sliced far pass
+        if (ops == 3)      launch_wave2_tpr<3, true>(a, tpr, grid, s);
+        else if (ops == 1) launch_wave2_tpr<1, true>(a, tpr, grid, s);
+        else if (ops == 2) launch_wave2_tpr<2, true>(a, tpr, grid, s);
+        else {
+            set_error("launch_spmv_wave2: 2-byte columns with pass form %d", ops);
+            return QBH_EINVAL;
+        }
+    }
+    else if (ops == 0) launch_wave2_tpr<0>(a, tpr, grid, s);
     else if (ops == 3) launch_wave2_tpr<3>(a, tpr, grid, s);
     else if (ops == 1) launch_wave2_tpr<1>(a, tpr, grid, s);
     else if (ops == 4) launch_wave2_tpr<4>(a, tpr, grid, s);

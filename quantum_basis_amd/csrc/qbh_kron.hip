@@ -152,6 +152,9 @@ __global__ __launch_bounds__(kBlock) void k_kron_merge_rows(KronParts p, int64_t
             }
         }
         const int32_t own = (int32_t)m.xcol((m.nc == 1 ? m.U0 * m.S[0] : 0) + r);
+        // 2-byte columns (one class): a near column is congruent to the stored value mod S and lies in the row's own block; a far
+        // column keeps the row's minor index, its major index is the stored value mod NUg (padding: the row's own major index)
+        const int64_t S0 = m.S[0], NUg = m.cols.cu[m.cols.nr], rmaj = m.U0 + r / S0, rmin = r % S0;
         // cross list
         int64_t px = 0, ex = 0;
         if (p.n_xrows > 0) {
@@ -174,10 +177,16 @@ __global__ __launch_bounds__(kBlock) void k_kron_merge_rows(KronParts p, int64_t
         int64_t o = p.ia[r] - out_base;
         const int64_t oe = p.ia[r + 1] - out_base;
         while (o < oe) {
-            int64_t cn = pn < en ? (int64_t)p.ja_n[pn] : -1, cf = -1, cx = px < ex ? m.xcol_orig(p.ja_x[px]) : -1;
+            int64_t cn = -1, cf = -1, cx = px < ex ? m.xcol_orig(p.ja_x[px]) : -1;
+            if (pn < en) cn = p.c16_n ? rmaj * S0 + (int64_t)p.c16_n[pn] % S0 : (int64_t)p.ja_n[pn];
             if (k < fw) {
-                const int32_t ct = p.ja_f[fb + fs * k];
-                if (ct != own) cf = m.xcol_orig(ct);
+                if (p.c16_f) {
+                    const int64_t um = (int64_t)p.c16_f[fb + fs * k] % NUg;
+                    if (um != rmaj) cf = um * S0 + rmin;
+                } else {
+                    const int32_t ct = p.ja_f[fb + fs * k];
+                    if (ct != own) cf = m.xcol_orig(ct);
+                }
             }
             int which = -1;
             int64_t best = -1;
@@ -257,7 +266,68 @@ __global__ __launch_bounds__(kBlock) void k_kron_desc_classes(WaveDesc *wd, int6
     }
 }
 
+// ---- 2-byte columns (qbh_opts.kron_cols16) ----
+__global__ __launch_bounds__(kBlock) void k_kron_desc_c16(WaveDesc *wd, int64_t n_wb, int64_t div, int far, int undo)
+{
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_wb + 2; w += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t cut = far ? (wd[w].pad & 1) : 0;
+        const int64_t base = (undo || w >= n_wb) ? 0 : (int64_t)wd[w].r0 / div;        // the sentinels name element 0
+        wd[w].pad = far ? (int32_t)(base << 1) | cut : (int32_t)base;
+    }
+}
+
+// one wavefront per near block: entries [p0, p0(next)) relative to the block's base
+__global__ __launch_bounds__(kBlock) void k_kron_c16_near(const WaveDesc *wd, int64_t n_wb, const int32_t *ja, int64_t S, int64_t col0, uint16_t *out, int *flag)
+{
+    const int lane = threadIdx.x & 63;
+    bool bad = false;
+    for (int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n_wb; w += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        const int64_t p0 = wd[w].p0, p1 = wd[w + 1].p0, base = col0 + (int64_t)wd[w].pad * S;     // col0 = the shard's first (global) column
+        for (int64_t k = p0 + lane; k < p1; k += 64) {
+            const int64_t c = (int64_t)ja[k] - base;
+            bad = bad || c < 0 || c > 65535;
+            out[k] = (uint16_t)c;
+        }
+    }
+    if (bad) *flag = 1;
+}
+
+// far slot i (block i / 512): tiled column band * 8 NU + u' * 8 + j, j = i % 8 by construction
+__global__ __launch_bounds__(kBlock) void k_kron_c16_far(const WaveDesc *wd, const int32_t *ja, int64_t slots, int64_t NU, uint16_t *out, int *flag)
+{
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t band0 = wd[i >> 9].pad >> 1;
+        const int64_t col = ja[i], b = col / (8 * NU), rem = col - b * 8 * NU;
+        const int64_t c = (rem >> 3) + (b - band0) * NU;
+        bad = bad || (rem & 7) != (i & 7) || c < 0 || c > 65535 || wd[i >> 9].p0 != ((i >> 9) << 9);
+        out[i] = (uint16_t)c;
+    }
+    if (bad) *flag = 1;
+}
+
 }  // namespace
+
+int launch_kron_desc_c16(WaveDesc *wd, int64_t n_wb, int64_t div, bool far, bool undo, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kron_desc_c16, dim3(1024), dim3(kBlock), 0, s, wd, n_wb, div, far ? 1 : 0, undo ? 1 : 0);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+int launch_kron_c16_near(const WaveDesc *wd, int64_t n_wb, const int32_t *ja, int64_t S, int64_t col0, uint16_t *out, int *flag, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kron_c16_near, dim3(4096), dim3(kBlock), 0, s, wd, n_wb, ja, S, col0, out, flag);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+int launch_kron_c16_far(const WaveDesc *wd, const int32_t *ja, int64_t slots, int64_t NU, uint16_t *out, int *flag, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kron_c16_far, dim3(4096), dim3(kBlock), 0, s, wd, ja, slots, NU, out, flag);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
 
 int launch_kron_check2(const int64_t *ia, const int32_t *ja, int64_t nrows, int64_t S, int64_t U0, int *d_flag, hipStream_t s)
 {

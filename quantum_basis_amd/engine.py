@@ -38,7 +38,8 @@ def _cvec(a, name):
 
 def make_opts(device=-1, stream=None, spmv_kernel=_lib.KERNEL_AUTO, nnz_per_block=0, xcd_swizzle=2,
               value_dict=1, profile=0, check_hermitian=1, real_fast_path=1, kron_split=1, kron_minor=0, deterministic=0,
-              basis_kind=0, n_sites=0, n_up=0, n_dn=0):
+              basis_kind=0, n_sites=0, n_up=0, n_dn=0, **more):
+    """qbh_opts with the library's defaults; `more` names any further field of the struct (include/qbhip.h), e.g. kron_cols16=0."""
     o = _lib.Opts()
     lib().qbh_opts_default(C.byref(o))
     o.device = device
@@ -55,6 +56,11 @@ def make_opts(device=-1, stream=None, spmv_kernel=_lib.KERNEL_AUTO, nnz_per_bloc
     o.deterministic = deterministic
     o.basis_kind = basis_kind
     o.n_sites, o.n_up, o.n_dn = n_sites, n_up, n_dn
+    known = {f[0] for f in _lib.Opts._fields_}
+    for k, v in more.items():
+        if k not in known:
+            raise TypeError("make_opts: qbh_opts has no field %r" % k)
+        setattr(o, k, v)
     return o
 
 

@@ -74,6 +74,68 @@ def test_split_operator_equals_the_unsplit_one(shape, sliced, monkeypatch):
     P.destroy()
 
 
+@pytest.mark.parametrize("deterministic", [1, 0])
+@pytest.mark.parametrize("shape", [(4, 3, 6, 6), (4, 3, 5, 7), (4, 4, 2, 2), (4, 2, 4, 4)])
+def test_two_byte_columns_are_the_same_operator_bit_for_bit(shape, deterministic):
+    """qbh_opts.kron_cols16: the parts of the split keep 2-byte columns relative to a base named by the block descriptor.  Same
+    values in the same order through the same passes, so y, the fused reductions and the Lanczos coefficients must equal the
+    int32 form's BIT FOR BIT (the atomics of the sliced far pass add two addends: order-independent), and qbh_csr_download must
+    re-derive the int32 columns exactly."""
+    lx, ly, nu, nd = shape
+    n = lx * ly
+    bonds = lattices.square(lx, ly)
+    mk = lambda c16: q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1,
+                                       opts=q.make_opts(kron_split=2, deterministic=deterministic, kron_cols16=c16, **PLAIN))
+    K16, K32 = mk(1), mk(0)
+    i16, i32 = K16.info(), K32.info()
+    assert i32.kron_cols16 == 0 and i16.kron_sliced == i32.kron_sliced
+    assert i16.kron_cols16 == (3 if i16.kron_sliced else 1)            # the far part only in its sliced layout
+    assert i16.bytes_matrix < i32.bytes_matrix
+    a, b = K16.download(), K32.download()
+    for u, v in zip(a, b):
+        assert np.array_equal(u.view(np.float64) if u.dtype == np.complex128 else u, v.view(np.float64) if v.dtype == np.complex128 else v)
+    r0, r1 = K16.dim // 3, K16.dim // 3 + 29
+    for u, v in zip(K16.download(r0, r1), K32.download(r0, r1)):
+        assert np.array_equal(u, v)
+    x, y0 = _rand(K16.dim, 4), _rand(K16.dim, 5)
+    for alpha, beta, gamma in [(1.0, 0.0, 0.0), (0.7, -0.3, 0.25)]:
+        out = []
+        for A in (K16, K32):
+            v = A.vec(2)
+            v.upload(x, 0)
+            v.upload(y0, A.dim)
+            red = A.spmv(v.at(0), v.at(A.dim), alpha, beta, gamma, want_red=True)
+            out.append((v.download(A.dim, A.dim), red))
+            v.free()
+        assert np.array_equal(out[0][0].view(np.float64), out[1][0].view(np.float64))
+        if deterministic:
+            assert out[0][1] == out[1][1]
+    if deterministic:
+        h = []
+        for A in (K16, K32):
+            r = q.locate_E0_lanczos(A, nev=1, ncv=0, maxit=300)
+            h.append(r)
+        assert h[0].E0 == h[1].E0 and h[0].steps == h[1].steps
+    K16.destroy()
+    K32.destroy()
+
+
+def test_two_byte_columns_survive_a_one_rank_communicator_and_a_restore():
+    """A whole operator in 2-byte columns under a 1-rank communicator (hooks run, nothing moves) and merged back into a CSR
+    (kron_restore through a communicator that cannot exchange tiled blocks is covered in test_gpu_dist)."""
+    n, nu, nd = 12, 6, 6
+    bonds = lattices.square(4, 3)
+    K = q.csr_mat.hubbard(n, nu, nd, bonds, opts=q.make_opts(kron_split=2, **PLAIN))
+    assert K.info().kron_cols16 == 3
+    x = _rand(K.dim, 11)
+    y = np.empty(K.dim, dtype=np.complex128)
+    K.MultMv(x, y)
+    ia, ja, val = K.download()
+    want = qo.Csr(K.dim, ia, ja.astype(np.int64), val, False).multmv(x)
+    assert np.abs(y - want).max() <= 2e-13 * np.abs(want).max()
+    K.destroy()
+
+
 def test_split_from_host_arrays_needs_the_hint_and_is_verified():
     """An operator created from host arrays is split only when the caller names the minor size -- and only when EVERY entry
     keeps the major or the minor index: a wrong hint leaves the operator unsplit (checked on the device), never wrong."""
