@@ -15,10 +15,14 @@ What the blocks of the JSON line are measured on:
   value / roofline   THE NORTH-STAR FORMAT (default --format complex128): CSR with complex128 values (16 B) + int32
                      columns, complex128 vectors, complex arithmetic -- the format SURVEY 8(d)'s algorithmic bytes
                      (nnz*20 + rows*40) describe, semantics of csr_mat::MultMv2 (src/sparse.cc:262-289).
-                     roofline.frac = algorithmic bytes / kernel time / 8 TB/s and cannot exceed 1.
+                     At N = 1 the headline is the MEDIAN of --processes fresh child processes (each builds its own operator
+                     and times W + exactly K steps); min / median / max are printed in "processes".
   fast_path          the library's default for a real operator (lossless, bit-identical results): 1-byte value codes,
-                     vectors and gathers as packed doubles.  Its roofline block is defined on ITS OWN format bytes
-                     (nnz*(4+code bytes) + rows*24), so that fraction cannot exceed 1 either.
+                     vectors and gathers as packed doubles.  Its roofline fraction is defined on the bytes the form that
+                     runs must MOVE (coded_format_roofline): the sliced coded split of a recognised Kronecker sum streams
+                     almost no matrix, so bytes of a CSR it does not read are reported as *_equivalent_GBps, never as frac.
+  locate_E0          the user call locate_E0_lanczos(nev=1, ncv=1) = Lanczos + CG eigenvector (src/model.cc:1123-1316,
+                     src/lanczos.cc:281-341), timed end to end, with the CG step's own bytes and fraction.
   matrix_free_*      SURVEY 8f-1, no stored matrix (not the CSR path).
   cpu_baseline       the oracle port and the reference's own MKL SpMV on the host cores (reported, not a target).
 
@@ -124,6 +128,41 @@ def traffic_stamp(key):
         now = None
     was = TRAFFIC_STAMP.get(key)
     return {"traffic_sources_sha16": was, "sources_sha16": now, "traffic_stale": (was is None or now is None or was != now)}
+
+
+def coded_format_roofline(info, ms_spmv, code_w, coded, real_used, traffic, tsrc, launches, survey_bytes, kernel_name):
+    """Roofline block of an operator held in the library's DEFAULT format (value codes and / or packed-double vectors).
+    The fraction is defined on the bytes the form that RUNS has to move, so it cannot exceed 1:
+      * plain coded CSR: nnz * (4 + code bytes) + row pointers + x once + y once;
+      * the sliced coded split with the recognised T (x) 1 + 1 (x) T' + D structure (qbh_kronc.hip) streams almost no matrix:
+        x, old y, new y (3 vector passes), the tiled copy of x written and read (2), the far row sums written and read (2), one
+        diagonal code per row, and the stored T / T' entries (3 B each) -- C3: ~9.5 GB, not the 33 GB of the coded CSR.
+    What a CSR of the operator would have moved (the format's bytes, SURVEY 8(d)'s bytes) over the same time is given as
+    *_equivalent_GBps: a speed-up figure, NOT a fraction of any roofline."""
+    vec_b = 8 if real_used else 16
+    fmt_bytes = info.nnz * (4 + (code_w if coded else 16)) + (info.nrows + 1) * 8 + info.nrows * 2 * vec_b
+    kronc = bool(info.kron_minor and info.kron_sliced and coded and real_used)      # the sliced coded split (qbh_kronc.hip)
+    uniform = kronc and info.kron_far_nnz * 8 < info.nnz                             # T kept once: far entries stored << nnz
+    if uniform:
+        moved = info.nrows * (7 * vec_b + 1) + int(info.kron_far_nnz) * 3
+        definition = ("recognised form T (x) 1 + 1 (x) T' + D: rows * (7 * %d + 1) [x, old y, new y, tiled x written + read, far sums "
+                      "written + read, diagonal code] + stored T entries * 3" % vec_b)
+    elif kronc:
+        moved = info.nnz * 3 + info.nrows * 7 * vec_b
+        definition = "sliced coded split, general form: nnz * (2 + 1) + rows * 7 * %d" % vec_b
+    else:
+        moved = fmt_bytes
+        definition = "this format's bytes: nnz*(4 + %d) + (rows+1)*8 + rows*%d" % (code_w if coded else 16, 2 * vec_b)
+    return {"bound": "hbm", "kernel": "k_kronc_far + k_kronc_near (tiled x written by the producer pass)" if kronc else kernel_name,
+            "achieved": round(moved / ms_spmv / 1e6, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(moved / ms_spmv / 1e6 / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "traffic_ratio": (round(traffic / moved, 3) if traffic else None), "traffic_source": tsrc,
+            "bytes_per_launch": int(moved), "ms_per_launch": round(ms_spmv, 4), "launches": launches, "bytes_definition": definition,
+            "format_bytes_per_launch": int(fmt_bytes), "format_equivalent_GBps": round(fmt_bytes / ms_spmv / 1e6, 2),
+            "survey_8d_bytes_per_launch": int(survey_bytes), "survey_8d_equivalent_GBps": round(survey_bytes / ms_spmv / 1e6, 2),
+            "note": "frac is on the bytes the running form must move; the *_equivalent_GBps figures divide bytes the kernel does NOT move "
+                    "by its time -- speed-ups over a CSR sweep, not roofline fractions"
+                    + ("; the two passes are bound by L2 line requests and LDS gathers, not by HBM bandwidth (DESIGN 4.1g)" if kronc else "")}
 
 
 def dim_of(w):
@@ -368,6 +407,23 @@ def cpu_midsize_full_run(W, q, stream):
                    cpu_lanczos_steps=int(m_cpu), cpu_s=round(t_cpu, 3), cpu_iters_per_s=round(m_cpu / t_cpu, 3),
                    cpu_threads=qo.num_threads(), e0_gpu=e0_gpu, e0_cpu=e0_cpu,
                    e0_rel_err_vs_cpu=abs(e0_gpu - e0_cpu) / abs(e0_cpu))
+        # the user call end to end on both sides: locate_E0_lanczos(nev = 1, ncv = 1) = Lanczos + CG eigenvector
+        try:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rg = q.locate_E0_lanczos(G, nev=1, ncv=1, maxit=maxit)
+            torch.cuda.synchronize()
+            tg_ = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            rc_ = qo.locate_E0_lanczos(O, nev=1, ncv=1, maxit=maxit)
+            tc_ = time.perf_counter() - t0
+            res["locate_E0"] = {"workload": name, "gpu_s": round(tg_, 4), "cpu_s": round(tc_, 3), "cpu_threads": qo.num_threads(), "cpu_kind": "port (oracle, Hermitian-upper storage)",
+                                "gpu_steps": {k_: int(v_) for k_, v_ in rg.steps.items() if k_ in ("E0", "V0")},
+                                "cpu_steps": {k_: int(v_) for k_, v_ in rc_.get("steps", {}).items() if k_ in ("E0", "V0")},
+                                "e0_rel_diff": abs(rg.E0 - rc_["E0"]) / abs(rc_["E0"]),
+                                "eigenvector_overlap": float(abs(np.vdot(rg.eigenvecs, rc_["eigenvecs"])))}
+        except Exception as e:
+            res["locate_E0"] = {"error": repr(e)}
         b_spmv = int(fia[-1]) * 20 + (d + 1) * 8 + d * 32
         x = qo.first_touch(qo.vec_randomize(d, 2))
         try:
@@ -401,6 +457,48 @@ def cpu_midsize_full_run(W, q, stream):
             res["iram"] = {"error": repr(e)}
         G.destroy()
     return res
+
+
+def locate_e0_block(A, q, torch, b_spmv, maxit=1000):
+    """The call a user of the reference makes: model::locate_E0_lanczos(nev = 1, ncv = 1) (src/model.cc:1123-1316) = Lanczos to
+    convergence ("sr_val0", src/lanczos.cc:134-266) + the CG eigenvector (src/lanczos.cc:281-341), every vector resident in HBM.
+    Timed stage by stage with the start vectors of the reference (seed 1).  A CG step is one SpMV in the form
+    pp = (H - E0) p with <p, pp> fused into its epilogue, k_cg_update (v += a p, r -= a pp, |r|^2: 4 reads + 2 writes) and
+    k_xpby (p = r + b p: 2 reads + 1 write, + the tiled copy of p for the split operator's next SpMV)."""
+    dim = A.dim
+    v = A.vec(4)
+    hess = np.zeros(2 * maxit)
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        A.randomize(v.at(0), 1)
+        m = q.lanczos(0, maxit - 1, maxit, dim, A, None, hess, "sr_val0", device_v=v)
+        e0 = float(q.hess_eigen(hess, maxit, m, "sr")[0][0])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        A.randomize(v.at(2 * dim), 1)
+        A.stats(reset=True)
+        mcg, accu = q.eigenvec_CG(dim, maxit, 0, A, e0, v.at(2 * dim), v.at(0), v.at(dim), v.at(3 * dim), device=True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        st = A.stats()
+        # the eigenvector's residual, one more SpMV: |H v - E0 v|
+        red = A.spmv(v.at(2 * dim), v.at(0), 1.0, 0.0, -e0, want_red=True)
+        resid = float(np.sqrt(max(red[1], 0.0)))
+    finally:
+        v.free()
+    ms_cg = 1e3 * (t2 - t1) / max(mcg, 1)
+    b_alg = b_spmv + 144 * dim            # SURVEY a8: 1 SpMV + nine 16-byte-per-element vector passes
+    b_fused = b_spmv + 160 * dim          # what the three fused launches move: + the tiled copy of the new p
+    return {"call": "locate_E0_lanczos(nev=1, ncv=1): Lanczos to convergence + CG eigenvector (src/model.cc:1123-1316, src/lanczos.cc:281-341)",
+            "seconds_total": round(t2 - t0, 4), "lanczos_s": round(t1 - t0, 4), "lanczos_steps": int(m), "lanczos_ms_per_step": round(1e3 * (t1 - t0) / max(m, 1), 4),
+            "cg_s": round(t2 - t1, 4), "cg_steps": int(mcg), "cg_ms_per_step": round(ms_cg, 4), "cg_accuracy": float(accu),
+            "cg_spmv_ms_per_launch": round(st.ms_spmv / max(st.n_spmv, 1), 4),
+            "cg_bytes_per_step_algorithmic": int(b_alg), "cg_bytes_per_step_fused_kernels": int(b_fused),
+            "cg_roofline": {"bound": "hbm", "achieved": round(b_alg / ms_cg / 1e6, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": round(b_alg / ms_cg / 1e6 / HBM_PEAK_GBPS, 4),
+                            "bytes_definition": "B_spmv + 144 * dim per CG step (SURVEY a8: 1 SpMV + 9 BLAS-1 passes of 16 B per element), over the WALL time of a step"},
+            "e0": e0, "eigenvector_residual_norm": resid}
 
 
 # ------------------------------------------------------------------------------------------------- main ----
@@ -443,7 +541,17 @@ def main():
     ap.add_argument("--converge", action="store_true", help="run to convergence also for the dim > 1e9 packed-real workloads")
     ap.add_argument("--no-fast-path", action="store_true", help="skip the extra measurement of the coded / real fast path")
     ap.add_argument("--no-plain", action="store_true", help="(kept for older command lines; the uncoded kernel is the headline now)")
+    ap.add_argument("--processes", type=int, default=3,
+                    help="N = 1 only: the headline (W warm-up + exactly K timed steps on a freshly created operator) is measured in this many "
+                         "FRESH child processes, started one after the other before this process touches the GPU; the line reports min / "
+                         "median / max and the headline value / roofline.frac are the MEDIAN process's (physical placement differs from "
+                         "process to process: DESIGN 5.0c).  1: this process only")
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-locate", action="store_true", help="skip the timing of the user call locate_E0_lanczos(nev=1, ncv=1) = Lanczos + CG eigenvector")
     args = ap.parse_args()
+    if args.child:
+        args.no_cpu_baseline = args.no_fast_path = args.no_matrix_free = args.no_converge = args.no_locate = True
+        args.processes = 1
     if args.format is None:                  # workloads whose complex128 CSR cannot be stored name their own default
         args.format = workloads()[args.workload].get("format", "complex128")
     fmt_fast = args.format == "fast"
@@ -462,6 +570,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
         args.gpus = world
+    children = []
+    if world == 1 and args.processes > 1 and not args.child and not args.host_csr and not args.packed_real and not workloads()[args.workload].get("packed_real"):
+        # fresh processes FIRST: this process has made no GPU call yet (torch.cuda.device_count() does not initialise the GPU
+        # on this image), so each child sees the device as the driver's own process would
+        import subprocess
+        argv = [a for a in sys.argv[1:]]
+        for i in range(args.processes):
+            pr = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv + ["--child"], capture_output=True, text=True)
+            line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+            if pr.returncode != 0 or not line:
+                raise SystemExit("bench.py: child process %d failed (rc %d)\n%s\n%s" % (i, pr.returncode, pr.stdout[-2000:], pr.stderr[-4000:]))
+            children.append(json.loads(line[-1]))
     _lib.require_gpu()                      # no CPU fallback: fail loudly
     # QBH_DIST_BACKEND=gloo lets several ranks share one GPU on a single-GPU test rig (RCCL refuses that)
     backend = os.environ.get("QBH_DIST_BACKEND", "nccl")
@@ -612,17 +732,30 @@ def main():
             src_opts = q.make_opts(device=local_rank, stream=stream.cuda_stream, spmv_kernel=q._lib.KERNEL_ROWS, value_dict=0,
                                    real_fast_path=0, kron_split=0)
             G = build_operator(W, (r0, r1), src_opts)
-            if hint:
-                opts.kron_split = 0          # created as a plain CSR in the reference's order; the basis is declared once the source is gone
+            # created as a plain CSR in the reference's order (three copies of a 116 GB matrix do not fit: the source of the
+            # permutation must go first); then EITHER the caller names the basis OR -- --no-basis-hint, what the unchanged host
+            # code can say: nothing -- the library's own search runs (qbh_opts.basis_detect; the same code qbh_csr_create runs)
+            detect = W["kind"] == "hubbard" and value_dict == 0 and not hint
+            if hint or detect:
+                opts.kron_split = 0
+                opts.basis_detect = 0
             A = G.reference_order(*_reforder_args(W), opts=opts)
             G.destroy()
-            if hint:
+            if hint or detect:
                 torch.cuda.synchronize()
                 t_b = time.time()
-                named = A.set_basis(q._lib.BASIS_REF_FERMION2, W["n_sites"], W["n_up"], W["n_dn"])
+                if hint:
+                    named = A.set_basis(q._lib.BASIS_REF_FERMION2, W["n_sites"], W["n_up"], W["n_dn"])
+                else:
+                    named = A.set_basis(q._lib.BASIS_DETECT, 0, 0, 0)
                 torch.cuda.synchronize()
-                create = {"basis_hint": "qbh_csr_set_basis(QBH_BASIS_REF_FERMION2, %d, %d, %d)" % (W["n_sites"], W["n_up"], W["n_dn"]),
-                          "basis_hint_accepted": bool(named), "set_basis_s": round(time.time() - t_b, 3)}
+                bi = A.info()
+                create = {"basis_hint": ("qbh_csr_set_basis(QBH_BASIS_REF_FERMION2, %d, %d, %d)" % (W["n_sites"], W["n_up"], W["n_dn"])) if hint else
+                          "none: the library searched the two-species bases of this dimension by itself (qbh_opts.basis_detect)",
+                          "basis_hint_accepted": bool(named), "basis_detected": bool(bi.basis_detected),
+                          "basis_found": [int(bi.basis_n_sites), int(bi.basis_n_up), int(bi.basis_n_dn)] if named else None,
+                          "detect_ms (candidates tried through the one-pass pre-check, incl. the permutation of the one that verified)": round(bi.basis_detect_ms, 1),
+                          "set_basis_s": round(time.time() - t_b, 3)}
         else:
             A = build_operator(W, (r0, r1), opts, matrix_free=args.matrix_free, shard=(rank, world))
         torch.cuda.synchronize()
@@ -632,7 +765,9 @@ def main():
             dim = int(info.ncols)
         exchange_kind = None
         if world > 1:
-            want_native = backend == "nccl" and not os.environ.get("QBH_PY_HOOKS")
+            # QBH_RCCL_LIB (the test-only librccl stub, tests/stub_rccl/) puts the library's own communicator under ranks that
+            # share one GPU: torch's rendezvous then runs over gloo, the exchange still through qbh_comm_create_rccl
+            want_native = (backend == "nccl" or bool(os.environ.get("QBH_RCCL_LIB"))) and not os.environ.get("QBH_PY_HOOKS")
             native_err = None
             if want_native:
                 # the library's own RCCL communicator (qbh_comm_create_rccl): no Python in the SpMV loop.  Every rank must
@@ -667,17 +802,7 @@ def main():
     tkey += "|reforder" if args.order == "reference" else ""
     traffic, tsrc = traffic_of(tkey) if world == 1 and not args.host_csr else (None, None)
     if coded or real_used:
-        # the kernel moves its own format's bytes, not SURVEY 8(d)'s: the fraction is defined on those (cannot exceed 1)
-        vec_b = 8 if real_used else 16
-        fmt_bytes = info.nnz * (4 + (code_w if coded else 16)) + (info.nrows + 1) * 8 + info.nrows * 2 * vec_b
-        kronc = bool(info.kron_minor and info.kron_sliced and coded and real_used)      # the sliced coded split (qbh_kronc.hip)
-        roof = {"bound": "hbm", "kernel": "k_kronc_far + k_kronc_near + k_kron_tile_re" if kronc else KERNEL_NAME[info.kernel],
-                "achieved": round(fmt_bytes / ms_spmv / 1e6, 2), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(fmt_bytes / ms_spmv / 1e6 / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "traffic_ratio": (round(traffic / fmt_bytes, 3) if traffic else None), "traffic_source": tsrc,
-                "bytes_per_launch": fmt_bytes, "ms_per_launch": round(ms_spmv, 4), "launches": head["n_spmv"],
-                "bytes_definition": "this format's bytes: nnz*(4 + %d) + (rows+1)*8 + rows*%d" % (code_w if coded else 16, 2 * vec_b),
-                "survey_8d_bytes_per_launch": bytes_launch, "survey_8d_equivalent_GBps": round(achieved, 2)}
+        roof = coded_format_roofline(info, ms_spmv, code_w, coded, real_used, traffic, tsrc, head["n_spmv"], bytes_launch, KERNEL_NAME[info.kernel])
         dtype = "f64 real (1-byte value codes, packed-double vectors; bit-identical to complex128)" if real_used else \
                 "complex128 vectors, %d-byte value codes" % code_w
     else:
@@ -727,6 +852,26 @@ def main():
         if roof["traffic_stale"]:
             print("bench.py: WARNING roofline.traffic was measured on other kernel sources (%s, now %s): re-run tools/profile_bench.sh"
                   % (roof["traffic_sources_sha16"], roof["sources_sha16"]), file=sys.stderr)
+    if children:
+        # The headline is the MEDIAN of the fresh processes (each: its own operator, W warm-up + exactly K timed steps); the
+        # spread is printed beside it.  What this process measured afterwards on its own operator is listed, not used.
+        runs = sorted(children, key=lambda c: c["roofline"]["ms_per_launch"])
+        med = runs[len(runs) // 2]
+        mine = {"ms_per_launch": roof["ms_per_launch"], "frac": roof["frac"], "value": out["value"], "ms_per_step": out["ms_per_step"]}
+        out["processes"] = {
+            "n": len(runs),
+            "what": "fresh child processes run one after the other BEFORE this process made any GPU call; each builds its own operator "
+                    "and times W warm-up + exactly K Lanczos steps; headline value / ms_per_step / roofline = the median process",
+            "ms_per_launch": [c["roofline"]["ms_per_launch"] for c in runs], "frac": [c["roofline"]["frac"] for c in runs],
+            "value": [c["value"] for c in runs], "ms_per_step": [c["ms_per_step"] for c in runs],
+            "frac_min": runs[-1]["roofline"]["frac"], "frac_median": med["roofline"]["frac"], "frac_max": runs[0]["roofline"]["frac"],
+            "this_process_after_the_children": mine}
+        for k in ("value", "steps", "ms_per_step"):
+            out[k] = med[k]
+        for k in ("achieved", "frac", "ms_per_launch", "launches", "traffic_ratio"):
+            if k in med["roofline"]:
+                roof[k] = med["roofline"][k]
+        roof["frac_min"], roof["frac_max"] = runs[-1]["roofline"]["frac"], runs[0]["roofline"]["frac"]
     if world > 1:
         # link bytes per GPU reported separately from the HBM bytes.  ms_per_gather is the event-timed duration of
         # the all-gather on RCCL's side stream (native communicator), max over ranks; it overlaps the locally-owned columns.
@@ -788,6 +933,15 @@ def main():
                 out["e0_rel_err_vs_cpu"] = mid["e0_rel_err_vs_cpu"]
         except Exception as e:      # the baseline is reported, never required
             out["cpu_baseline"] = {"value": None, "unit": "lanczos_iters/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    if rank == 0 and world == 1 and not args.no_locate and not args.matrix_free and not packed_real and not (coded or real_used):
+        try:
+            with torch.cuda.stream(stream):
+                out["locate_E0"] = locate_e0_block(A, q, torch, bytes_launch)
+                mid = out.get("cpu_baseline", {}).get("midsize", {})
+                if "locate_E0" in mid:          # the same call on the mid-size operator, GPU beside the CPU oracle
+                    out["locate_E0"]["midsize"] = mid["locate_E0"]
+        except Exception as e:
+            out["locate_E0"] = {"error": repr(e)}
     n = A.dim
     if world == 1:
         A.destroy()          # the extra blocks below build their own operators: give the HBM back first (C4 substitute: 157 GB)
@@ -804,11 +958,13 @@ def main():
                 f_coded = bool(fi.value_dict)
                 f_real = fp["n_real"] > 0
                 f_cw = 0 if not f_coded else (1 if fi.value_dict <= 256 else 2)
-                vec_b = 8 if f_real else 16
-                fbytes = fi.nnz * (4 + (f_cw if f_coded else 16)) + (fi.nrows + 1) * 8 + fi.nrows * 2 * vec_b
                 f_kronc = bool(fi.kron_minor > 0 and fi.kron_sliced and f_coded and f_real)      # the sliced coded split (qbh_kronc.hip)
-                ftr, fsrc = traffic_of("%s|%s|%s" % (args.workload, KERNEL_KEY[fi.kernel], "dict" if f_coded else "plain") + ("|real" if f_real else "")
-                                       + ("|kron_sliced" if f_kronc else ""))
+                fkey = "%s|%s|%s" % (args.workload, KERNEL_KEY[fi.kernel], "dict" if f_coded else "plain") + ("|real" if f_real else "") + ("|kron_sliced" if f_kronc else "")
+                ftr, fsrc = traffic_of(fkey)
+                froof = coded_format_roofline(fi, fp["ms_spmv"], f_cw, f_coded, f_real, ftr, fsrc, fp["n_spmv"],
+                                              fi.nnz * 20 + (fi.nrows + 1) * 8 + fi.nrows * 32, KERNEL_NAME[fi.kernel])
+                if ftr is not None:
+                    froof.update(traffic_stamp(fkey))
                 out["fast_path"] = {
                     "value": round(fp["steps"] / fp["elapsed"], 4), "unit": "lanczos_iters/s", "steps": fp["steps"],
                     "ms_per_step": round(1e3 * fp["elapsed"] / fp["steps"], 4),
@@ -818,12 +974,7 @@ def main():
                     "e0_rel_diff_vs_complex128": (abs(fp["e0"] - head["e0"]) / abs(head["e0"])) if (fp["e0"] is not None and head["e0"]) else None,
                     "kron_split": ({"minor": int(fi.kron_minor), "band": int(fi.kron_band), "form": "both parts sliced in groups of 16 rows, near x block in LDS",
                                     "stored_far_entries": int(fi.kron_far_nnz)} if f_kronc else None),
-                    "roofline": {"bound": "hbm", "kernel": "k_kronc_far + k_kronc_near + k_kron_tile_re" if f_kronc else KERNEL_NAME[fi.kernel],
-                                 "achieved": round(fbytes / fp["ms_spmv"] / 1e6, 2),
-                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(fbytes / fp["ms_spmv"] / 1e6 / HBM_PEAK_GBPS, 4),
-                                 "traffic": ftr, "traffic_source": fsrc, "bytes_per_launch": fbytes,
-                                 "ms_per_launch": round(fp["ms_spmv"], 4), "launches": fp["n_spmv"],
-                                 "bytes_definition": "this format's bytes: nnz*(4 + %d) + (rows+1)*8 + rows*%d" % (f_cw if f_coded else 16, 2 * vec_b)},
+                    "roofline": froof,
                     "note": "lossless: values are dictionary-coded, and a real operator applied to real vectors gathers 8-byte real parts"}
                 F.destroy()
         except Exception as e:

@@ -70,6 +70,7 @@ const char *qbh_last_error(void);                   /* thread-local detail of th
 /* qbh_opts.basis_kind */
 #define QBH_BASIS_NONE          0   /* an index is an index (default) */
 #define QBH_BASIS_REF_FERMION2  1   /* the reference's order of a two-species fermion basis (see qbh_opts.basis_kind) */
+#define QBH_BASIS_DETECT       -1   /* qbh_csr_set_basis only: run the search of qbh_opts.basis_detect on an existing operator */
 #define QBH_BASIS_SPIN_SECTOR   2   /* spin-1/2 (one species), n_dn particles on n_sites sites, index = rank of the bit pattern in ascending
                                        order (qbh_gen_heisenberg; n_up unused): the sites are cut into a low and a high half
                                        (qbh_opts.n_up = number of low sites, 0 = n_sites / 2) and the operator is held class-major
@@ -130,6 +131,40 @@ typedef struct qbh_opts {
                                 the target major index (major count <= 32768); 16 instead of 20 B of stream per nonzero, the same
                                 values in the same order: results are bit-identical to the int32 form.  qbh_csr_download re-derives
                                 the int32 columns.  0: int32 columns (SURVEY 8(d)'s format to the byte)                     */
+    /* ---- which FORM of an equivalent computation runs (summation order may differ between forms; every form is tested
+     * against the oracle).  These were environment switches up to ABI 400; the library reads no environment variable that
+     * changes a result any more (QBH_DEBUG holds measurement / tracing knobs only, QBH_HOST_THREADS the host thread count,
+     * QBH_RCCL_LIB the communication library).  qbh_opts_default() sets the values in brackets. ---- */
+    int     kron_sliced;     /* [1] far part of the split interleaved in groups of 8 rows where that costs < 1/8 padding; 0: plain
+                                rows in tiled order; 2: sliced whenever a group fits the wave tile (padding accepted)          */
+    int     kron_band;       /* [0] band width of the tiling: 0 = one 128-byte line per major index, narrower while a band of x
+                                exceeds an XCD's L2; 2 / 4 / 8 / 16 force it                                                  */
+    int     kron_cross_in_near; /* [1] cut single-species sector (QBH_BASIS_SPIN_SECTOR): the entries across the cut stay in the
+                                near part (two passes); 0: a third pass of their own                                       */
+    int     kron_coded;      /* [-1] split of the DEFAULT (coded, real) format: -1 follows kron_split; 0 never; 1 the two-part row
+                                kernel form (measured slower, kept for comparison); 2 the sliced form (qbh_kronc.hip)        */
+    int     kron_uniform;    /* [3] sliced coded split: bit 0 recognise a far part T (x) 1, bit 1 a near part 1 (x) T' + D and keep
+                                T / T' once; 0: every group stored                                                         */
+    int     gather_parts;    /* [0] band ranges the gather of x travels in under a communicator with part hooks: 0 = 4 when
+                                there are peers, else 1; 1..8 force it.  EVERY rank must pass the same value                  */
+    int     wave_walk;       /* [-1] walk of the wave kernels over their blocks: -1 = the ordered per-XCD work counters (static
+                                chunked walk when deterministic); 0 interleaved, 1 contiguous eighths, 2 chunked, 3 counters   */
+    int     tile_fold;       /* [1] inside the solvers the pass that produces the next x also writes its tiled copy; 0: every
+                                SpMV makes the copy itself (what a caller of qbh_spmv_dev always gets)                       */
+    int     autotune;        /* [1] operators without product structure above 1e7 nonzeros: row kernel vs wave kernel timed at
+                                creation (never when deterministic); 0: the wave kernel                                    */
+    int     shard_split;     /* [1] a plain row shard under a communicator is split into locally-owned and remote columns so
+                                that the local part overlaps the all-gather; 0: one launch after the gather                  */
+    int     real_forms;      /* [7] with real_fast_path, for real operators and vectors: bit 0 only real parts travel in the
+                                all-gather, bit 1 the row kernel gathers 8-byte real parts, bit 2 the solvers keep their
+                                vectors as packed doubles                                                                  */
+    int     basis_detect;    /* [1] arrays that arrive without basis_kind and without kron_minor (the reference's
+                                csr_mat(lil_mat&) carries no options), whole operator, large enough for the split
+                                (kron_split = 1: >= 1e8 nonzeros; 2: any): every (n_sites, n_up, n_dn) with C(n_sites, n_up) *
+                                C(n_sites, n_dn) = dim is tried as QBH_BASIS_REF_FERMION2 -- one pass over the columns per
+                                candidate, BEFORE anything is permuted -- and the first under which the operator has the
+                                product structure is taken (qbh_csr_info.basis_internal / basis_detected / basis_n_*).  A
+                                matrix of a colliding dimension without the structure stays exactly as given.  0: never     */
 } qbh_opts;
 
 void qbh_opts_default(qbh_opts *o);
@@ -200,6 +235,9 @@ typedef struct qbh_csr_info {
     int64_t kron_cross_nnz;                  /* nonzeros of the third (unstructured) part                                       */
     int     gather_parts;                    /* communicator attached: band ranges the gather of x travels in (1 = one gather)   */
     int     kron_cols16;                     /* bit 0: the near part holds 2-byte columns, bit 1: the far part (qbh_opts.kron_cols16)   */
+    int     basis_detected;                  /* 1: basis_internal was found by the library itself (qbh_opts.basis_detect)               */
+    int     basis_n_sites, basis_n_up, basis_n_dn;   /* the basis named by the caller or found (0 when basis_internal == 0)          */
+    double  basis_detect_ms;                 /* wall ms the search took (inside create_ms for host arrays), whatever it found          */
 } qbh_csr_info;
 int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info);
 

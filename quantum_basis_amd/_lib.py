@@ -15,6 +15,7 @@ if os.environ.get("QBHIP_LIBRARY"):      # e.g. a host-AddressSanitizer build of
 QBH_OK = 0
 KERNEL_AUTO, KERNEL_STREAM, KERNEL_VECTOR, KERNEL_ROWS, KERNEL_MATRIX_FREE, KERNEL_WAVE = 0, 1, 2, 3, 4, 5
 BASIS_NONE, BASIS_REF_FERMION2, BASIS_SPIN_SECTOR = 0, 1, 2
+BASIS_DETECT = -1         # qbh_csr_set_basis only: the library's own search (qbh_opts.basis_detect)
 
 
 class QbhError(RuntimeError):
@@ -34,7 +35,10 @@ class Opts(C.Structure):
                 ("nnz_per_block", C.c_int), ("xcd_swizzle", C.c_int), ("value_dict", C.c_int),
                 ("profile", C.c_int), ("check_hermitian", C.c_int), ("real_fast_path", C.c_int),
                 ("kron_split", C.c_int), ("kron_minor", C.c_int64), ("deterministic", C.c_int), ("basis_kind", C.c_int),
-                ("n_sites", C.c_int), ("n_up", C.c_int), ("n_dn", C.c_int), ("kron_cols16", C.c_int)]
+                ("n_sites", C.c_int), ("n_up", C.c_int), ("n_dn", C.c_int), ("kron_cols16", C.c_int),
+                ("kron_sliced", C.c_int), ("kron_band", C.c_int), ("kron_cross_in_near", C.c_int), ("kron_coded", C.c_int),
+                ("kron_uniform", C.c_int), ("gather_parts", C.c_int), ("wave_walk", C.c_int), ("tile_fold", C.c_int),
+                ("autotune", C.c_int), ("shard_split", C.c_int), ("real_forms", C.c_int), ("basis_detect", C.c_int)]
 
 
 class CsrInfo(C.Structure):
@@ -45,7 +49,8 @@ class CsrInfo(C.Structure):
                 ("create_bytes_in", C.c_int64), ("kron_minor", C.c_int64), ("kron_far_nnz", C.c_int64), ("kron_band", C.c_int), ("kron_sliced", C.c_int),
                 ("kron_inplace", C.c_int), ("tuned", C.c_int), ("tune_ms_rows", C.c_double), ("tune_ms_wave", C.c_double),
                 ("basis_internal", C.c_int), ("kron_classes", C.c_int), ("kron_cross_nnz", C.c_int64), ("gather_parts", C.c_int),
-                ("kron_cols16", C.c_int)]
+                ("kron_cols16", C.c_int), ("basis_detected", C.c_int), ("basis_n_sites", C.c_int), ("basis_n_up", C.c_int),
+                ("basis_n_dn", C.c_int), ("basis_detect_ms", C.c_double)]
 
 
 class LanczosRow(C.Structure):

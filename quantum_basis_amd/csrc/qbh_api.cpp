@@ -28,6 +28,64 @@ void set_error(const char *fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// QBH_DEBUG="key=value,key=value" (bare integer: flags); parsed again only when the variable's text has changed (a test
+// harness may set it between two creations)
+static void parse_debug(const char *e, DebugSw &d)
+{
+    d = DebugSw{};
+    if (!e || !*e) return;
+    struct Key { const char *name; int *i; long long *ll; };
+    const Key keys[] = {{"flags", &d.flags, nullptr}, {"colmask", &d.colmask, nullptr}, {"tpr", &d.tpr, nullptr}, {"unroll", &d.unroll, nullptr},
+                        {"grid", &d.grid, nullptr}, {"wave_tpr", &d.wave_tpr, nullptr}, {"chunk_mult", &d.chunk_mult, nullptr},
+                        {"trace_create", &d.trace_create, nullptr}, {"trace_tune", &d.trace_tune, nullptr}, {"trace_dict", &d.trace_dict, nullptr},
+                        {"print_ptrs", &d.print_ptrs, nullptr}, {"sec_walk", &d.sec_walk, nullptr}, {"sec_grid", &d.sec_grid, nullptr},
+                        {"sec_unroll", &d.sec_unroll, nullptr}, {"wave_pipelined", &d.wave_pipelined, nullptr}, {"create_chunk", nullptr, &d.create_chunk},
+                        {"force_ragged", &d.force_ragged, nullptr}, {"mf_row", &d.mf_row, nullptr}, {"mf_chunk", &d.mf_chunk, nullptr},
+                        {"mf_window", &d.mf_window, nullptr}, {"kronc_abl", &d.kronc_abl, nullptr}, {"kronc_far_chunk", &d.kronc_far_chunk, nullptr},
+                        {"kronc_far_ng", &d.kronc_far_ng, nullptr}, {"kronc_far_nt", &d.kronc_far_nt, nullptr}, {"no_far_align", &d.no_far_align, nullptr},
+                        {"no_defer", &d.no_defer, nullptr}};
+    const std::string all(e);
+    size_t pos = 0;
+    while (pos <= all.size()) {
+        size_t end = all.find(',', pos);
+        if (end == std::string::npos) end = all.size();
+        const std::string item = all.substr(pos, end - pos);
+        pos = end + 1;
+        if (item.empty()) continue;
+        const size_t eq = item.find('=');
+        if (eq == std::string::npos) {
+            if (item.find_first_not_of("0123456789") == std::string::npos) d.flags = atoi(item.c_str());
+            else fprintf(stderr, "qbhip: QBH_DEBUG: '%s' is not key=value\n", item.c_str());
+            continue;
+        }
+        const std::string k = item.substr(0, eq), v = item.substr(eq + 1);
+        bool known = false;
+        for (const Key &key : keys)
+            if (k == key.name) {
+                if (key.i) *key.i = atoi(v.c_str());
+                else *key.ll = atoll(v.c_str());
+                known = true;
+            }
+        if (!known) fprintf(stderr, "qbhip: QBH_DEBUG: unknown key '%s'\n", k.c_str());
+    }
+}
+
+const DebugSw &debug_sw()
+{
+    static std::mutex mu;
+    static std::string seen = "\x01";           // never equal to a real value: the first call parses
+    static DebugSw sw[2];                        // the previous one stays valid for a caller that still holds a reference to it
+    static int cur = 0;
+    const char *e = getenv("QBH_DEBUG");
+    std::lock_guard<std::mutex> lock(mu);
+    if (seen != (e ? e : "")) {
+        seen = e ? e : "";
+        cur ^= 1;
+        parse_debug(e, sw[cur]);
+    }
+    return sw[cur];
+}
 }  // namespace qbh
 
 extern "C" const char *qbh_last_error(void) { return qbh::g_err; }
@@ -73,7 +131,11 @@ extern "C" void qbh_opts_set_default(const qbh_opts *o)
 {
     std::lock_guard<std::mutex> lock(g_defaults_mu);
     g_have_defaults = o != nullptr;
-    if (o) g_defaults = *o;
+    if (o) {
+        g_defaults = *o;
+        g_defaults.device = -1;          // a default names no device and no stream: those belong to one call
+        g_defaults.stream = nullptr;
+    }
 }
 
 extern "C" void qbh_opts_default(qbh_opts *o)
@@ -86,6 +148,13 @@ extern "C" void qbh_opts_default(qbh_opts *o)
             return;
         }
     }
+    qbh::opts_builtin(o);
+}
+
+// the built-in defaults, whatever qbh_opts_set_default says: what a NULL `opts` means for operators the library generates or
+// adopts itself (a host's hint about the basis of ITS arrays must not reach them)
+void qbh::opts_builtin(qbh_opts *o)
+{
     o->device = -1;
     o->stream = nullptr;
     o->spmv_kernel = QBH_KERNEL_AUTO;
@@ -97,6 +166,18 @@ extern "C" void qbh_opts_default(qbh_opts *o)
     o->real_fast_path = 1;
     o->kron_split = 1;
     o->kron_cols16 = 1;
+    o->kron_sliced = 1;
+    o->kron_band = 0;
+    o->kron_cross_in_near = 1;
+    o->kron_coded = -1;
+    o->kron_uniform = 3;
+    o->gather_parts = 0;
+    o->wave_walk = -1;
+    o->tile_fold = 1;
+    o->autotune = 1;
+    o->shard_split = 1;
+    o->real_forms = 7;
+    o->basis_detect = 1;
     o->kron_minor = 0;
     o->deterministic = 0;
     o->basis_kind = QBH_BASIS_NONE;
@@ -184,8 +265,8 @@ int setup_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, int dict_mode, 
         qbh::set_error("nnz_per_block must be 1024, 2048 or 4096 (8192: row kernel with value dictionary only)");
         return QBH_EINVAL;
     }
-    if (const char *e = getenv("QBH_TPR")) tpr = atoi(e);            // tuning experiments
-    if (const char *e = getenv("QBH_UNROLL")) unroll = atoi(e);
+    if (qbh::debug_sw().tpr) tpr = qbh::debug_sw().tpr;              // tuning experiments
+    if (qbh::debug_sw().unroll) unroll = qbh::debug_sw().unroll;
     // a block holds the rows that START inside its window, so it can exceed the window by
     // one row; keep window + maxlen - 1 <= npb when rows are short, otherwise let the
     // oversized-block path take the few long rows.
@@ -227,10 +308,7 @@ int setup_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, int dict_mode, 
             *grid_o = (int)std::max<int64_t>(8, (g / 8) * 8);
         }
     }
-    if (const char *e = getenv("QBH_GRID")) {                        // tuning experiments
-        const int g = atoi(e);
-        if (g >= 8) *grid_o = (g / 8) * 8;
-    }
+    if (qbh::debug_sw().grid >= 8) *grid_o = (qbh::debug_sw().grid / 8) * 8;      // tuning experiments
     return QBH_OK;
 }
 
@@ -239,9 +317,7 @@ int setup_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, int dict_mode, 
 int split_shard(qbh_csr *A)
 {
     if (A->nrows == A->ncols || A->nnz == 0) return QBH_OK;
-    if (const char *e = getenv("QBH_NO_SPLIT")) {
-        if (atoi(e)) return QBH_OK;
-    }
+    if (!A->opts.shard_split) return QBH_OK;
     hipStream_t s = A->stream;
     {   // the split holds a second copy of the shard until the original is released: skip it (one launch per SpMV, no
         // overlap with the gather) rather than fail when HBM cannot hold both.  The decision is per rank (ranks whose
@@ -508,11 +584,9 @@ int kron_build(qbh_csr *A)
     if (A->kron.active) return QBH_OK;
     if (!A->use_wave || A->kind != 0 || A->has_rem || A->nnz <= 0 || !A->own_arrays || !A->d_val || A->kron_off) return QBH_OK;
     if (A->opts.kron_split == 0 || (A->debug & 1)) return QBH_OK;
-    if (A->opts.kron_split == 1 && A->nnz < 100000000) return QBH_OK;
+    // the threshold is on the WHOLE operator (a shard's share scaled up): uneven shards must not decide differently
+    if (A->opts.kron_split == 1 && (double)A->nnz * ((double)A->ncols / (double)A->nrows) < 1e8) return QBH_OK;
     if (A->opts.real_fast_path && A->values_real) return QBH_OK;      // the real-gather form of the row kernel needs the CSR
-    if (const char *e = getenv("QBH_NO_KRON")) {
-        if (atoi(e)) return QBH_OK;
-    }
     const int64_t n = A->nrows;
     hipStream_t s = A->stream;
     qbh_csr::KronSplit &K = A->kron;
@@ -521,9 +595,9 @@ int kron_build(qbh_csr *A)
         if (A->nrows != A->ncols || A->row_offset != 0) return QBH_OK;
         K.map = A->basis.classes;
         K.map.sliced = 1;
-        // QBH_CROSS_IN_NEAR=0: the entries across the cut as a third pass of their own (k_spmv_wave, tiled columns); default: they
-        // stay in the near part -- natural columns, gathers that miss -- which saves the third pass's reading of the vectors
-        K.map.cross_near = (getenv("QBH_CROSS_IN_NEAR") && atoi(getenv("QBH_CROSS_IN_NEAR")) == 0) ? 0 : 1;
+        // qbh_opts.kron_cross_in_near = 0: the entries across the cut as a third pass of their own (k_spmv_wave, tiled columns);
+        // default: they stay in the near part -- natural columns, gathers that miss -- which saves the third pass's reading of the vectors
+        K.map.cross_near = A->opts.kron_cross_in_near ? 1 : 0;
         K.t = qbh::KronTile{K.map.S[0], K.map.NU[0], 8};
         K.U0 = 0;
         K.NUg = 0;
@@ -542,8 +616,8 @@ int kron_build(qbh_csr *A)
         if (bad) return QBH_OK;
         int B = 8;                                       // one 128-byte line of complex128 per (band, major index)
         while (B > 2 && (double)NUg * B * 16 > 2.5e6) B >>= 1;             // keep a band of x inside an XCD's L2
-        if (const char *e = getenv("QBH_KRON_BAND")) {
-            const int b = atoi(e);
+        {
+            const int b = A->opts.kron_band;
             if (b == 2 || b == 4 || b == 8 || b == 16) B = b;
         }
         K.t = qbh::KronTile{S, NU, B};
@@ -561,8 +635,7 @@ int kron_build(qbh_csr *A)
         m.fbase[0] = 0;
         m.fbase[1] = (S / B) * B * NU;
         m.cols = K.cols;
-        int want_sliced = 1;                             // QBH_KRON_SLICED: 0 never, 1 when the padding is small, 2 whenever a group fits
-        if (const char *e = getenv("QBH_KRON_SLICED")) want_sliced = atoi(e);
+        const int want_sliced = A->opts.kron_sliced;     // 0 never, 1 when the padding is small, 2 whenever a group fits
         m.sliced = (want_sliced && B == 8 && S >= 8) ? 1 : 0;
         K.map = m;
     }
@@ -641,8 +714,7 @@ int kron_build(qbh_csr *A)
             (void)hipGetLastError();
             return fail(rc != QBH_OK ? rc : he == hipErrorOutOfMemory ? QBH_OK : QBH_EHIP);
         }
-        int want_sliced = 1;
-        if (const char *e = getenv("QBH_KRON_SLICED")) want_sliced = atoi(e);
+        const int want_sliced = A->opts.kron_sliced;
         K.nnz_f = far_true;
         if ((want_sliced == 2 || multi || slots - far_true <= far_true / 8) && maxgw <= 504 && slots < ((int64_t)1 << 40) && K.n_groups > 0) {
             K.ia_f = gia;
@@ -761,7 +833,7 @@ int kron_build(qbh_csr *A)
     // per 1 KB value load instead of 9, 2 per 256-byte column load instead of 3), i.e. the far part should begin a multiple of 32
     // entries behind the arrays' (aligned) base.  One class: the small cross part keeps the scratch arrays it was gathered into,
     // which leaves its entries' worth of slack behind the near part for that.
-    const bool own_x = !multi && K.nnz_x >= 32 && getenv("QBH_NO_FAR_ALIGN") == nullptr;
+    const bool own_x = !multi && K.nnz_x >= 32 && !qbh::debug_sw().no_far_align;
     if (own_x && ((K.nnz_n + 31) / 32) * 32 + K.far_slots <= A->nnz) tail = ((K.nnz_n + 31) / 32) * 32;
     if (tail + K.far_slots + (own_x ? 0 : K.nnz_x) <= A->nnz) {    // no padding: the far part takes the space the far entries left
         KRON_HIP(hipMemcpyAsync(A->d_val + tail, tmp_v, (size_t)K.far_slots * sizeof(d2), hipMemcpyDeviceToDevice, s));
@@ -805,7 +877,7 @@ int kron_build(qbh_csr *A)
     K.inplace = true;
     KRON_TRY(kron_geometry(A));
     KRON_TRY(kron_short_cols(A));
-    if (getenv("QBH_PRINT_PTRS"))
+    if (qbh::debug_sw().print_ptrs)
         fprintf(stderr, "qbhip kron arrays: ia %p ja %p val %p | ia_n %p fp %p | ja_f %p val_f %p | wd_n %p wd_f %p | far %p | nnz_n %lld far_slots %lld\n", (void *)A->d_ia,
                 (void *)A->d_ja, (void *)A->d_val, (void *)K.ia_n, (void *)K.ia_f, (void *)K.ja_f, (void *)K.val_f, (void *)K.wd_n, (void *)K.wd_f, (void *)K.d_far,
                 (long long)K.nnz_n, (long long)K.far_slots);
@@ -895,8 +967,7 @@ int kronc_build_sliced(qbh_csr *A, int64_t S, int64_t NU)
     // T alone -- NU short rows, always in the L2 -- and the far pass has no stream.  QBH_KRONC_FAR_UNI=0: keep the general form.
     {
         int nonuni = 0;
-        const char *e = getenv("QBH_KRONC_FAR_UNI");
-        if (e && atoi(e) == 0) {
+        if (!(A->opts.kron_uniform & 1)) {
             nonuni = 1;
         } else {
             KS_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
@@ -911,8 +982,7 @@ int kronc_build_sliced(qbh_csr *A, int64_t S, int64_t NU)
     // groups, in the L2 -- beside one diagonal code per row, and the near pass has no stream either.  QBH_KRONC_NEAR_UNI=0: general form.
     {
         int nonuni = 0;
-        const char *e = getenv("QBH_KRONC_NEAR_UNI");
-        if (e && atoi(e) == 0) {
+        if (!(A->opts.kron_uniform & 2)) {
             nonuni = 1;
         } else {
             KS_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
@@ -969,7 +1039,10 @@ int kronc_build_sliced(qbh_csr *A, int64_t S, int64_t NU)
         KS_HIP(hipMalloc(&L.d_dictr, 256 * sizeof(double)));
         KS_HIP(hipMemcpy(L.d_dictr, hr.data(), 256 * sizeof(double), hipMemcpyHostToDevice));
     }
-    KS_HIP(hipMalloc(&K.d_xt, (size_t)n * sizeof(double)));
+    // 16 doubles of zeroed slack: the far pass gathers whole 16-wide lines even in the narrow last band (S % 16 != 0), whose
+    // last line would otherwise end past the allocation
+    KS_HIP(hipMalloc(&K.d_xt, (size_t)(n + 16) * sizeof(double)));
+    KS_HIP(hipMemsetAsync(K.d_xt + n, 0, 16 * sizeof(double), s));
     if (!(L.near_uni && L.far_uni))
         KS_TRY(qbh::launch_kronc_fill(A->d_ia, A->d_ja, A->d_code, S, NU, nb, A->n_dict, L.near_uni ? nullptr : L.gia_n, L.ja_n, L.code_n, L.gia_f, L.ja_f,
                                       L.code_f, s));
@@ -1003,7 +1076,7 @@ int kronc_build(qbh_csr *A)
     // sliced form (kronc_build_sliced) when its preconditions hold, else not at all.  QBH_KRON_CODED = 0 / 1 / 2 overrides
     // (1: the earlier form for the row kernel, measured slower than the unsplit operator; kept for comparison).
     int want = (A->opts.kron_split == 2 || (A->opts.kron_split == 1 && A->nnz >= 100000000)) ? 2 : 0;
-    if (const char *e = getenv("QBH_KRON_CODED")) want = atoi(e);
+    if (A->opts.kron_coded >= 0) want = A->opts.kron_coded;
     if (!want || A->opts.kron_split == 0 || !A->opts.real_fast_path) return QBH_OK;       // only the all-real operation runs it
     if (A->kernel != QBH_KERNEL_ROWS || A->d_code == nullptr || !A->values_real || A->kind != 0 || A->has_rem || A->nrows != A->ncols ||
         A->row_offset != 0 || A->nnz <= 0)
@@ -1097,8 +1170,8 @@ int setup_wave_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, qbh::WaveD
     QBH_TRY(qbh::launch_build_wavedesc(d_ia, A->nrows, window, *d_wd_o, n_wb, s));
     const double avg = A->nrows > 0 ? (double)nnz / (double)A->nrows : 0.0;
     int tpr = avg <= 32 ? 2 : avg <= 64 ? 4 : avg <= 128 ? 8 : 16;      // rows per pass = 64 / tpr >= rows per block
-    if (const char *e = getenv("QBH_WAVE_TPR")) {
-        const int t = atoi(e);
+    {
+        const int t = qbh::debug_sw().wave_tpr;
         if (t == 2 || t == 4 || t == 8 || t == 16) tpr = t;
     }
     int ncu = 256;
@@ -1107,10 +1180,7 @@ int setup_wave_geometry(qbh_csr *A, const int64_t *d_ia, int64_t nnz, qbh::WaveD
     const int occ = std::max(1, qbh::wave_kernel_occupancy(tpr));
     int64_t g = std::min<int64_t>((int64_t)occ * ncu, ((((n_wb + 3) >> 2) + 7) / 8) * 8);
     g = std::max<int64_t>(8, (g / 8) * 8);
-    if (const char *e = getenv("QBH_GRID")) {
-        const int gg = atoi(e);
-        if (gg >= 8) g = (gg / 8) * 8;
-    }
+    if (qbh::debug_sw().grid >= 8) g = (qbh::debug_sw().grid / 8) * 8;
     *n_wb_o = n_wb;
     *tpr_o = tpr;
     *grid_o = (int)g;
@@ -1131,9 +1201,6 @@ int build_geometry(qbh_csr *A)
     // complex128 values (no dictionary): the wave kernel, unless the row kernel was asked for by name
     A->use_wave = A->kernel == QBH_KERNEL_ROWS && A->dict_mode == 0 && A->d_val != nullptr && A->opts.spmv_kernel != QBH_KERNEL_ROWS;
     if (A->tuned == 0) A->use_wave = false;            // timed at creation (autotune_kernel): the row kernel won
-    if (const char *e = getenv("QBH_NO_WAVE")) {
-        if (atoi(e)) A->use_wave = false;
-    }
     // an operator on a product basis is re-ordered in place into its two parts: it has no CSR geometry afterwards
     QBH_TRY(kron_build(A));
     int grid_max = 0;
@@ -1182,9 +1249,7 @@ int autotune_kernel(qbh_csr *A)
 {
     if (A->opts.spmv_kernel != QBH_KERNEL_AUTO || !A->use_wave || A->kind != 0 || A->has_rem || A->has_comm || A->nnz < 10000000) return QBH_OK;
     if (A->kron.active || A->opts.deterministic || A->nrows != A->ncols) return QBH_OK;
-    if (const char *e = getenv("QBH_NO_AUTOTUNE")) {
-        if (atoi(e)) return QBH_OK;
-    }
+    if (!A->opts.autotune) return QBH_OK;
     hipStream_t s = A->stream;
     d2 *x = nullptr, *y = nullptr;
     if (qbh::dev_alloc(&x, (size_t)A->ncols * sizeof(d2)) != hipSuccess || qbh::dev_alloc(&y, (size_t)A->nrows * sizeof(d2)) != hipSuccess) {
@@ -1219,7 +1284,7 @@ int autotune_kernel(qbh_csr *A)
         }
     }
     int best_mode = 1;
-    if (getenv("QBH_TUNE_TRACE"))
+    if (qbh::debug_sw().trace_tune)
         fprintf(stderr, "qbhip autotune: dim %lld nnz %lld: row kernel %.3f ms, wave kernel %.3f ms\n", (long long)A->nrows,
                 (long long)A->nnz, t_mode[0], t_mode[1]);
     if (t_mode[0] < 0.97 * t_mode[best_mode]) best_mode = 0;
@@ -1260,6 +1325,13 @@ int finalize(qbh_csr *A)
     if (o.basis_kind != QBH_BASIS_NONE && A->basis.kind == 0) {
         bool applied = false;
         QBH_TRY(qbh::basis_to_internal(A, o.basis_kind, o.n_sites, o.n_up, o.n_dn, &applied));
+    } else if (o.basis_kind == QBH_BASIS_NONE && o.basis_detect && o.kron_minor == 0 && o.kron_split != 0 && A->basis.kind == 0 &&
+               (o.kron_split == 2 || A->nnz >= 100000000)) {
+        // nobody said what the index means (the reference's constructor cannot): look for a two-species basis of this dimension
+        bool applied = false;
+        const double t_d = now_ms();
+        QBH_TRY(qbh::basis_detect(A, &applied));
+        A->detect_ms = now_ms() - t_d;
     }
     // value dictionary first: it decides how much LDS a row block needs
     QBH_TRY(try_value_dict(A));
@@ -1295,17 +1367,18 @@ int finalize(qbh_csr *A)
     return QBH_OK;
 }
 
-int new_handle(qbh_csr **out, const qbh_opts *opts)
+int new_handle(qbh_csr **out, const qbh_opts *opts, bool host_arrays = false)
 {
     int dev = 0;
     QBH_TRY(require_device(opts, &dev));
     qbh_csr *A = new (std::nothrow) qbh_csr();
     if (!A) return QBH_ENOMEM;
     if (opts) A->opts = *opts;
-    else qbh_opts_default(&A->opts);
+    else if (host_arrays) qbh_opts_default(&A->opts);      // process-wide defaults: the host-array entry points they are documented for
+    else qbh::opts_builtin(&A->opts);
     A->device = dev;
-    if (const char *dbg = getenv("QBH_DEBUG")) A->debug = atoi(dbg);   // timing experiments only
-    if (const char *e = getenv("QBH_CHUNK_MULT")) A->chunk_mult = std::max(1, atoi(e));
+    A->debug = qbh::debug_sw().flags;                                   // timing experiments only
+    if (qbh::debug_sw().chunk_mult > 0) A->chunk_mult = qbh::debug_sw().chunk_mult;
     if (A->opts.stream) {
         A->stream = (hipStream_t)A->opts.stream;
         A->own_stream = false;
@@ -1429,14 +1502,17 @@ static int create_from_host(qbh_csr **out, int64_t dim, int64_t nnz, int sym_upp
         return QBH_EINVAL;
     }
     const double t0 = now_ms();
-    const bool trace = getenv("QBH_CREATE_TRACE") != nullptr;
+    const bool trace = qbh::debug_sw().trace_create != 0;
     QBH_TRY(qbh::validate_host_csr(dim, nnz, sym_upper, ia, ja));
     if (trace) fprintf(stderr, "[qbh_csr_create] %-22s %8.2f ms\n", "host validation", now_ms() - t0);
     const d2 *hv = reinterpret_cast<const d2 *>(val);
-    if (!sym_upper && (!opts || opts->check_hermitian)) QBH_TRY(qbh::check_hermitian_host(dim, ia, ja, hv));
+    qbh_opts eff;                             // NULL means the process-wide defaults here
+    if (opts) eff = *opts;
+    else qbh_opts_default(&eff);
+    if (!sym_upper && eff.check_hermitian) QBH_TRY(qbh::check_hermitian_host(dim, ia, ja, hv));
 
     qbh_csr *A = nullptr;
-    QBH_TRY(new_handle(&A, opts));
+    QBH_TRY(new_handle(&A, opts, true));
     A->nrows = r1 - r0;
     A->ncols = dim;
     A->row_offset = r0;
@@ -1700,6 +1776,11 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->tune_ms_rows = A->tune_ms[0];
     info->tune_ms_wave = A->tune_ms[1];
     info->basis_internal = A->basis.kind;
+    info->basis_detected = A->basis.detected ? 1 : 0;
+    info->basis_n_sites = A->basis.kind ? A->basis.n_sites : 0;
+    info->basis_n_up = A->basis.kind ? A->basis.n_up : 0;
+    info->basis_n_dn = A->basis.kind ? A->basis.n_dn : 0;
+    info->basis_detect_ms = A->detect_ms;
     if (A->kronc.active) {                       // the coded form of the split (row kernel, packed-double vectors)
         info->kron_minor = A->kronc.t.S;
         info->kron_far_nnz = A->kronc.sl.active ? A->kronc.sl.slots_f : A->kronc.far_p.nnz;      // sliced: stored far entries (padding included)
@@ -1721,12 +1802,18 @@ extern "C" int qbh_csr_set_basis(qbh_csr *A, int basis_kind, int n_sites, int n_
     Bind bind(A);
     QBH_HIP(hipStreamSynchronize(A->stream));
     bool applied = false;
-    QBH_TRY(qbh::basis_to_internal(A, basis_kind, n_sites, n_up, n_dn, &applied));
+    if (basis_kind == QBH_BASIS_DETECT) {
+        const double t_d = now_ms();
+        QBH_TRY(qbh::basis_detect(A, &applied));
+        A->detect_ms = now_ms() - t_d;
+    } else {
+        QBH_TRY(qbh::basis_to_internal(A, basis_kind, n_sites, n_up, n_dn, &applied));
+    }
     if (!applied) return QBH_OK;
-    A->opts.basis_kind = basis_kind;
-    A->opts.n_sites = n_sites;
-    A->opts.n_up = n_up;
-    A->opts.n_dn = n_dn;
+    A->opts.basis_kind = A->basis.kind;
+    A->opts.n_sites = A->basis.n_sites;
+    A->opts.n_up = A->basis.n_up;
+    A->opts.n_dn = A->basis.n_dn;
     if (A->opts.kron_split == 0) A->opts.kron_split = 1;
     A->tuned = -1;
     QBH_TRY(build_geometry(A));
@@ -1739,17 +1826,25 @@ extern "C" int qbh_csr_set_basis(qbh_csr *A, int basis_kind, int n_sites, int n_
 // are still on the links -- the step then costs max(wire, near + far) instead of max(wire, near) + far.  Default: 4 parts when
 // there are ranks to receive from (QBH_GATHER_PARTS overrides; 1 = the single gather), none when the communicator has no
 // part hooks (the Python ShardComm) or the far part is not sliced.
-int kron_gather_parts(qbh_csr *A, const qbh_comm *comm)
+// what THIS rank could do (1 = the single gather); the ranks then take the smallest proposal (qbh_csr_set_comm): a rank that
+// issued one whole-block group while its peers issue four part groups would hang the exchange
+int kron_parts_wanted(const qbh_csr *A, const qbh_comm *comm)
+{
+    const qbh_csr::KronSplit &K = A->kron;
+    if (!K.active || !K.sliced || !comm->allgather_part_begin || !comm->allgather_part_wait || !A->d_wctr || K.nwb_f <= 0) return 1;
+    int64_t want = comm->nranks > 1 ? 4 : 1;
+    if (A->opts.gather_parts > 0) want = A->opts.gather_parts;
+    const int64_t nfb = K.t.S / K.t.B;                       // full bands (the far pass covers exactly these)
+    return (int)std::max<int64_t>(1, std::min<int64_t>({want, 8, nfb}));
+}
+
+int kron_gather_parts(qbh_csr *A, const qbh_comm *comm, int64_t want)
 {
     qbh_csr::KronSplit &K = A->kron;
     K.n_parts = 1;
     K.part_off_len.clear();
-    if (!K.sliced || !comm->allgather_part_begin || !comm->allgather_part_wait || !A->d_wctr || K.nwb_f <= 0) return QBH_OK;
-    int64_t want = comm->nranks > 1 ? 4 : 1;
-    if (const char *e = getenv("QBH_GATHER_PARTS")) want = atoi(e);
-    const int64_t nfb = K.t.S / K.t.B;                       // full bands (the far pass covers exactly these)
-    want = std::max<int64_t>(1, std::min<int64_t>({want, 8, nfb}));
-    if (want == 1) return QBH_OK;
+    const int64_t nfb = K.t.S / K.t.B;
+    if (want <= 1 || kron_parts_wanted(A, comm) < want) return QBH_OK;
     int64_t band[9];
     for (int64_t k = 0; k <= want; ++k) band[k] = k * nfb / want;
     K.part_blk[0] = 0;
@@ -1797,10 +1892,17 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
     }
     if (!comm->d_xsend || !comm->d_xfull || !comm->d_scal || !comm->allgather_x || !comm->allreduce_sum ||
         comm->rank < 0 || comm->rank >= comm->nranks || comm->nblk < A->nrows) {
+        // without buffers and hooks there is nothing to tell the peers with: the one failure that stays local
         qbh::set_error("qbh_csr_set_comm: incomplete communicator (rank %d/%d nblk %lld nrows %lld)", comm->rank, comm->nranks,
                        (long long)comm->nblk, (long long)A->nrows);
         return QBH_EINVAL;
     }
+    // This call is COLLECTIVE for nranks > 1: every rank's local verdict travels through the communicator's own all-reduce
+    // before anything is decided, so that no rank returns early while its peers wait in a collective, and the form of the
+    // exchange (tiled blocks or plain, how many parts) is the same everywhere by construction.
+    int local_err = QBH_OK;
+    std::vector<int64_t> cuts_new;
+    int64_t full_new = 0;
     if (comm->row_cuts) {
         const int64_t *c = comm->row_cuts;
         bool ok = c[0] == 0 && c[comm->nranks] == A->ncols && c[comm->rank] == A->row_offset &&
@@ -1809,47 +1911,67 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
         if (!ok) {
             qbh::set_error("qbh_csr_set_comm: row_cuts do not describe this shard (rank %d/%d rows [%lld, %lld))", comm->rank,
                            comm->nranks, (long long)A->row_offset, (long long)(A->row_offset + A->nrows));
-            return QBH_EINVAL;
+            local_err = QBH_EINVAL;
+        } else {
+            cuts_new.assign(c, c + comm->nranks + 1);
+            full_new = A->ncols;
         }
-        A->comm_cuts.assign(c, c + comm->nranks + 1);
-        A->comm_full = A->ncols;
     } else {
         if (comm->nblk * comm->rank != A->row_offset || comm->nblk * comm->nranks < A->ncols) {
             qbh::set_error("qbh_csr_set_comm: inconsistent communicator (rank %d/%d nblk %lld row_offset %lld)",
                            comm->rank, comm->nranks, (long long)comm->nblk, (long long)A->row_offset);
-            return QBH_EINVAL;
+            local_err = QBH_EINVAL;
         }
-        A->comm_cuts.clear();
-        A->comm_full = comm->nblk * (int64_t)comm->nranks;
+        full_new = comm->nblk * (int64_t)comm->nranks;
     }
+    Bind bind(A);
+    // sums of indicators over the ranks: [0] failures, [1] ranks that can exchange tiled blocks, [2 + k] ranks proposing k + 1 parts
+    auto agree = [&](double (&v)[12]) -> int {
+        if (comm->nranks == 1) return QBH_OK;
+        QBH_HIP(hipMemcpyAsync(comm->d_scal, v, sizeof(v), hipMemcpyHostToDevice, A->stream));
+        if (comm->allreduce_sum(comm->ctx, 0, 12) != 0) {
+            qbh::set_error("qbh_csr_set_comm: allreduce_sum hook failed");
+            return QBH_ECOMM;
+        }
+        QBH_HIP(hipMemcpyAsync(v, comm->d_scal, sizeof(v), hipMemcpyDeviceToHost, A->stream));
+        QBH_HIP(hipStreamSynchronize(A->stream));
+        return QBH_OK;
+    };
+    qbh_csr::KronSplit &K = A->kron;
+    const int64_t S = K.active ? K.t.S : 1;
+    bool mine = local_err == QBH_OK && A->kind == 0 && K.active && K.map.nc == 1 && comm->nranks <= qbh::kKronMaxRanks && !(K.c16_f && comm->nranks > 1);
+    if (mine) {
+        if (comm->row_cuts) {
+            for (int q = 0; q <= comm->nranks; ++q) mine = mine && comm->row_cuts[q] % S == 0;
+        } else {
+            mine = comm->nblk % S == 0;
+        }
+    }
+    const int my_parts = mine ? kron_parts_wanted(A, comm) : 1;
+    double v[12] = {0};
+    v[0] = local_err != QBH_OK ? 1.0 : 0.0;
+    v[1] = mine ? 1.0 : 0.0;
+    v[2 + (my_parts - 1)] = 1.0;
+    QBH_TRY(agree(v));
+    if (v[0] > 0.0) {
+        if (local_err == QBH_OK) qbh::set_error("qbh_csr_set_comm: a peer rank rejected the communicator (its qbh_last_error says why)");
+        return local_err != QBH_OK ? local_err : QBH_ECOMM;
+    }
+    A->comm_cuts = cuts_new;
+    A->comm_full = full_new;
+    const bool all_tiled = v[1] == (double)comm->nranks;
+    int parts = 1;
+    for (int k = 0; k < 8; ++k)
+        if (v[2 + k] > 0.0) {
+            parts = k + 1;                       // the smallest proposal
+            break;
+        }
     if (A->kind == 0) {
         // A shard split in place (kron_build) exchanges the TILED copy of its block -- which only works when every rank does:
-        // cuts at whole major indices and every operator split.  The ranks agree through the communicator's own all-reduce
-        // (every rank of a stored operator makes this call, split or not); without agreement a split shard is merged back
-        // into its CSR and takes the generic path below.
-        Bind bind(A);
-        qbh_csr::KronSplit &K = A->kron;
-        const int64_t S = K.active ? K.t.S : 1;
-        bool mine = K.active && K.map.nc == 1 && comm->nranks <= qbh::kKronMaxRanks && !(K.c16_f && comm->nranks > 1);
-        if (mine) {
-            if (comm->row_cuts) {
-                for (int q = 0; q <= comm->nranks; ++q) mine = mine && comm->row_cuts[q] % S == 0;
-            } else {
-                mine = comm->nblk % S == 0;
-            }
-        }
-        double agree = mine ? 1.0 : 0.0;
-        if (comm->nranks > 1) {
-            QBH_HIP(hipMemcpyAsync(comm->d_scal, &agree, sizeof(double), hipMemcpyHostToDevice, A->stream));
-            if (comm->allreduce_sum(comm->ctx, 0, 1) != 0) {
-                qbh::set_error("qbh_csr_set_comm: allreduce_sum hook failed");
-                return QBH_ECOMM;
-            }
-            QBH_HIP(hipMemcpyAsync(&agree, comm->d_scal, sizeof(double), hipMemcpyDeviceToHost, A->stream));
-            QBH_HIP(hipStreamSynchronize(A->stream));
-            agree = agree == (double)comm->nranks ? 1.0 : 0.0;
-        }
-        if (K.active && agree == 1.0) {
+        // cuts at whole major indices and every operator split.  Without agreement a split shard is merged back into its CSR
+        // and takes the generic path below; whether that worked is agreed on once more (a rank out of memory there must not
+        // leave its peers attached and waiting in their first gather).
+        if (K.active && all_tiled) {
             qbh::KronCols to{};
             to.S = S;
             to.B = K.t.B;
@@ -1865,10 +1987,20 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
             K.map.cols = to;
             K.comm_tiled = true;
             K.xt_of = nullptr;
-            QBH_TRY(kron_gather_parts(A, comm));
-        } else if (K.active) {
-            QBH_TRY(kron_restore(A));
-            QBH_TRY(build_geometry(A));
+            QBH_TRY(kron_gather_parts(A, comm, parts));
+        } else if (!all_tiled) {
+            int rrc = QBH_OK;
+            if (K.active) {
+                rrc = kron_restore(A);
+                if (rrc == QBH_OK) rrc = build_geometry(A);
+            }
+            double w[12] = {0};
+            w[0] = rrc != QBH_OK ? 1.0 : 0.0;
+            const int arc = agree(w);
+            if (rrc != QBH_OK || arc != QBH_OK || w[0] > 0.0) {
+                if (rrc == QBH_OK && arc == QBH_OK) qbh::set_error("qbh_csr_set_comm: a peer rank could not merge its split operator back into a CSR");
+                return rrc != QBH_OK ? rrc : arc != QBH_OK ? arc : QBH_ECOMM;
+            }
         }
     }
     if (A->kind == 0 && !A->kron.active && !A->has_rem && A->nrows < A->ncols) {      // first communicator on a stored row shard: split it now
@@ -1981,8 +2113,7 @@ inline bool kron_path(const qbh_csr *A)
 // handle's own buffer, or -- under a communicator -- the send buffer of the exchange (the rank's block travels tiled)
 inline d2 *tiled_target(const qbh_csr *A)
 {
-    static const bool no_fold = getenv("QBH_NO_TILE_FOLD") != nullptr;      // A/B switch
-    if (no_fold || !A->kron.fold || !kron_path(A) || A->kron.map.nc != 1 || A->kron.t.B != 8 || A->kron.t.S < 8) return nullptr;
+    if (!A->opts.tile_fold || !A->kron.fold || !kron_path(A) || A->kron.map.nc != 1 || A->kron.t.B != 8 || A->kron.t.S < 8) return nullptr;
     if (A->has_comm) return A->real_wire ? nullptr : reinterpret_cast<d2 *>(A->comm.d_xsend);
     return (A->nrows == A->ncols && A->kron.xt_cap >= A->nrows) ? A->kron.d_xt : nullptr;
 }
@@ -1991,8 +2122,7 @@ inline d2 *tiled_target(const qbh_csr *A)
 // the coded split's tiled x (packed doubles): written by the all-real Lanczos step's axpy when the operator runs that form
 inline double *kronc_tiled_target(const qbh_csr *A)
 {
-    static const bool off = getenv("QBH_NO_TILE_FOLD") != nullptr;
-    return (A->kronc.active && A->kronc.sl.active && !A->has_comm && !A->has_rem && !off) ? A->kronc.d_xt : nullptr;
+    return (A->kronc.active && A->kronc.sl.active && !A->has_comm && !A->has_rem && A->opts.tile_fold) ? A->kronc.d_xt : nullptr;
 }
 
 struct FoldGuard {
@@ -2029,7 +2159,7 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
     const bool prof = A->opts.profile != 0;
     const bool comm = A->has_comm;
     int kron_swz = A->opts.deterministic ? 2 : 3;           // dynamic ordered walk per XCD unless the caller wants static walks
-    if (const char *e = getenv("QBH_WAVE_SWIZZLE")) kron_swz = atoi(e);
+    if (A->opts.wave_walk >= 0) kron_swz = A->opts.wave_walk;
     if (kron_swz == 3) {
         if (!A->d_wctr) kron_swz = 2;
         else QBH_HIP(hipMemsetAsync(A->d_wctr, 0, (size_t)(comm && K.n_parts > 1 ? qbh::kWctrRegions : 3) * 128 * sizeof(unsigned long long), s));
@@ -2071,18 +2201,14 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
             K.xt_cap = 0;
             QBH_HIP(qbh::dev_alloc(&K.d_xt, (size_t)A->ncols * sizeof(d2)));
             K.xt_cap = A->ncols;
-            if (getenv("QBH_PRINT_PTRS")) fprintf(stderr, "qbhip kron xt %p x %p y %p\n", (void *)K.d_xt, (const void *)x, (void *)y);
+            if (qbh::debug_sw().print_ptrs) fprintf(stderr, "qbhip kron xt %p x %p y %p\n", (void *)K.d_xt, (const void *)x, (void *)y);
             K.xt_of = nullptr;
         }
         if (prof) {
             harvest_events(A);
             QBH_HIP(hipEventRecord(A->ev0, s));
         }
-        // QBH_KRON_REUSE_TILE=1 (measurement only, tools/shard_time.py): the caller promises that x has not changed since the
-        // previous SpMV of this handle -- what is timed is then the far + near passes of a shard without the tiled copy of the
-        // FULL x, which a rank of a multi-GPU run never makes (it tiles its own block and receives the others)
-        static const bool reuse_tile = getenv("QBH_KRON_REUSE_TILE") != nullptr;
-        if (K.xt_of != (const void *)x && !(reuse_tile && K.xt_last == (const void *)x)) {
+        if (K.xt_of != (const void *)x) {
             if (K.map.nc == 1) {
                 QBH_TRY(qbh::launch_kron_tile(x, K.d_xt, A->ncols, qbh::KronTile{K.t.S, K.NUg, K.t.B}, s));
             } else {                         // every class is a product basis of its own: tiled class by class
@@ -2091,7 +2217,6 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
                                                   qbh::KronTile{K.map.S[c], K.map.NU[c], K.map.B}, s));
             }
         }
-        K.xt_last = x;
         K.xt_of = nullptr;
         xt = K.d_xt;
     }
@@ -2353,7 +2478,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
             ms.beta = beta;
             ms.gamma = gamma;
             ms.partials = m.partials;
-            static const int sec_walk = getenv("QBH_SEC_WALK") ? atoi(getenv("QBH_SEC_WALK")) : 0;
+            const int sec_walk = qbh::debug_sw().sec_walk;
             if (sec_walk) {
                 if (!A->d_wctr) QBH_HIP(qbh::dev_alloc(&A->d_wctr, qbh::kWctrRegions * 128 * sizeof(unsigned long long)));
                 QBH_HIP(hipMemsetAsync(A->d_wctr, 0, 3 * 128 * sizeof(unsigned long long), A->stream));
@@ -2426,7 +2551,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     a.unroll = A->unroll;
     a.colmask = (A->debug & 1) ? 1023 : -1;
     if (A->debug & 1) {
-        if (const char *e = getenv("QBH_COLMASK")) a.colmask = atoi(e);      // gather-window experiments (results wrong by design)
+        if (qbh::debug_sw().colmask) a.colmask = qbh::debug_sw().colmask;    // gather-window experiments (results wrong by design)
     }
     const bool prof = A->opts.profile != 0;
     if (async_gather && !A->has_rem) {          // nothing to overlap with: the single part needs the gathered x
@@ -2447,7 +2572,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     // 92 -> 68 GB, 31.7 -> 31.0 ms); the unsplit wave kernel keeps the static chunked walk (xcd_swizzle 2), under which all XCDs
     // stream from ONE region -- ordered eighths cost it 34 -> 43 ms on C3.  xcd_swizzle 3 / QBH_WAVE_SWIZZLE choose by name.
     int wave_swz = A->opts.xcd_swizzle, wave_grid_used = A->wgrid;
-    if (const char *e = getenv("QBH_WAVE_SWIZZLE")) wave_swz = atoi(e);
+    if (A->opts.wave_walk >= 0) wave_swz = A->opts.wave_walk;
     if (wave && wave_swz == 3) {
         if (!A->d_wctr || A->opts.deterministic) wave_swz = 2;
         else QBH_HIP(hipMemsetAsync(A->d_wctr, 0, 3 * 128 * sizeof(unsigned long long), A->stream));
@@ -2500,7 +2625,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         a.n_wb = A->n_wb;
         a.swizzle = wave_swz;
         a.wctr = A->d_wctr;
-        static const int pipe = getenv("QBH_WAVE_PIPELINED") ? atoi(getenv("QBH_WAVE_PIPELINED")) : 0;    // experiment: the pipelined kernel on an unsplit operator
+        const int pipe = qbh::debug_sw().wave_pipelined;    // experiment: the pipelined kernel on an unsplit operator
         if (pipe && A->wtpr <= 8) {
             int ncu = 256;
             hipDeviceProp_t prop;
@@ -2581,9 +2706,7 @@ int enable_real_wire(qbh_csr *A, std::initializer_list<const d2 *> vecs)
     A->xr_of = nullptr;
     if (A->has_comm && !A->comm.d_xfull_r) return QBH_OK;
     if (!A->opts.real_fast_path) return QBH_OK;
-    if (const char *e = getenv("QBH_NO_REAL_WIRE")) {
-        if (atoi(e)) return QBH_OK;
-    }
+    if (!(A->opts.real_forms & 1)) return QBH_OK;
     double total = A->values_real ? 0.0 : 1.0;
     // every rank must take the same decision: sum the per-vector |Im|^2 (and the operator flag) over ranks
     for (const d2 *v : vecs) {
@@ -2604,9 +2727,7 @@ int enable_real_wire(qbh_csr *A, std::initializer_list<const d2 *> vecs)
         A->real_wire = A->has_comm;
         // the row kernel can then gather 8-byte real parts (bit-identical result, half the x traffic)
         A->real_mode = A->kernel == QBH_KERNEL_ROWS;
-        if (const char *e = getenv("QBH_NO_REAL_MODE")) {
-            if (atoi(e)) A->real_mode = false;
-        }
+        if (!(A->opts.real_forms & 2)) A->real_mode = false;
         if (A->real_mode && !A->has_comm && !A->d_xr) QBH_HIP(qbh::dev_alloc(&A->d_xr, (size_t)A->ncols * sizeof(double)));
     }
     return QBH_OK;
@@ -3018,7 +3139,7 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
     } rv_guard{&rv, &rv_external};
     if (rv_external) rv = ext_rv;
     {
-        static const bool no_realvec = getenv("QBH_NO_REALVEC") != nullptr;      // A/B switch
+        const bool no_realvec = !(A->opts.real_forms & 4);
         if (!rv_external && !A->has_comm && A->real_mode && A->kernel == QBH_KERNEL_ROWS && A->nrows == A->ncols && !no_realvec) {
             if (qbh::dev_alloc(&rv, (size_t)(is_val1 ? 3 : 2) * (size_t)n * sizeof(double)) != hipSuccess) {
                 (void)hipGetLastError();
@@ -3067,7 +3188,7 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
             sc[sy] = 1.0 / b[mcur];
             return QBH_OK;
         }
-        static const bool no_defer = getenv("QBH_NO_DEFER") != nullptr;       // A/B switch
+        const bool no_defer = qbh::debug_sw().no_defer != 0;                   // A/B switch
         if (!A->has_comm && !no_defer) {
             // one GPU: <u, w> stays on the device and feeds the axpy directly; one host synchronisation per step
             A->defer_red = true;
@@ -3328,7 +3449,7 @@ static int cg_core(qbh_csr *A, int64_t maxit, int64_t *m_io, double E0, double *
         ~RvGuard() { if (*p) (void)hipFree(*p); }
     } rv_guard{&rv};
     {
-        static const bool no_realvec = getenv("QBH_NO_REALVEC") != nullptr;
+        const bool no_realvec = !(A->opts.real_forms & 4);
         if (!ext && !A->has_comm && A->real_mode && A->kernel == QBH_KERNEL_ROWS && A->nrows == A->ncols && !no_realvec) {
             if (qbh::dev_alloc(&rv, (size_t)4 * (size_t)n * sizeof(double)) != hipSuccess) {
                 (void)hipGetLastError();
@@ -3551,7 +3672,7 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
         QBH_HIP(qbh::dev_alloc(&v0, (size_t)n * sizeof(d2)));
         rc = qbh_vec_randomize(A, reinterpret_cast<qbh_z *>(v0), seed ? seed : 1u);
         if (rc == QBH_OK) rc = enable_real_wire(A, {v0});      // the random start vector is real
-        static const bool no_realvec = getenv("QBH_NO_REALVEC") != nullptr;
+        const bool no_realvec = !(A->opts.real_forms & 4);
         all_real = rc == QBH_OK && !A->has_comm && A->real_mode && A->kernel == QBH_KERNEL_ROWS && A->nrows == A->ncols && !no_realvec;
         hipError_t e0 = hipSuccess;
         if (all_real) {

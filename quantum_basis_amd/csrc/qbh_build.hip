@@ -321,9 +321,9 @@ int build_shard_from_host(int64_t dim, int64_t nnz, int sym, const int64_t *ia, 
     // staging chunk: 4 M nonzeros for large matrices; small ones use ~1/8 of their range so that pinning the staging
     // buffers (the fixed cost of a small create) stays cheap and the upload still pipelines
     int64_t chunk = std::min<int64_t>(4 << 20, std::max<int64_t>(256 << 10, (g_end - g_begin + 7) / 8));
-    if (const char *e = getenv("QBH_CREATE_CHUNK")) chunk = std::max<int64_t>(1024, atoll(e));
+    if (debug_sw().create_chunk > 0) chunk = std::max<int64_t>(1024, debug_sw().create_chunk);
     chunk = std::min<int64_t>(chunk, std::max<int64_t>(g_end - g_begin, 1));
-    const bool trace = getenv("QBH_CREATE_TRACE") != nullptr;
+    const bool trace = debug_sw().trace_create != 0;
     double t_mark = wall_ms();
     auto mark = [&](const char *what) {
         if (!trace) return;

@@ -354,9 +354,7 @@ extern "C" int qbh_comm_create_rccl(qbh_csr *A, const void *uid128, int rank, in
         c->cuts[(size_t)q] = row_cuts ? row_cuts[q] : u;
         if (c->cuts[(size_t)q] != u) c->ragged = true;
     }
-    if (const char *e = getenv("QBH_COMM_FORCE_RAGGED")) {      // test rigs: take the ragged (grouped broadcast) path even for uniform cuts
-        if (atoi(e)) c->ragged = true;
-    }
+    if (qbh::debug_sw().force_ragged) c->ragged = true;         // test rigs: the send/recv all-gather-v even for uniform cuts
     c->nblk = uni;
     for (int q = 0; q < nranks; ++q) c->nblk = std::max(c->nblk, c->cuts[(size_t)q + 1] - c->cuts[(size_t)q]);
     int rc = QBH_OK;

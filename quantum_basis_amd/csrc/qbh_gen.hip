@@ -391,7 +391,9 @@ extern "C" int qbh_gen_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, i
     // (up configuration) x (down configuration): announce the minor size for the Kronecker split (qbh_opts.kron_split)
     qbh_opts o2;
     if (opts) o2 = *opts;
-    else qbh_opts_default(&o2);
+    else opts_builtin(&o2);
+    o2.basis_detect = 0;
+    if (o2.basis_kind == QBH_BASIS_REF_FERMION2) o2.basis_kind = QBH_BASIS_NONE;      // the generator's order is species-major already: a host's hint about ITS arrays does not describe it
     if (o2.kron_minor == 0) o2.kron_minor = Nd;        // index = up * Nd + down; kron_build checks that a shard is made of whole up blocks
     return qbh_csr_create_device(out, nrows, dim, row_begin, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, &o2);
 }
@@ -596,7 +598,9 @@ extern "C" int qbh_gen_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bo
         return rc != QBH_OK ? rc : (e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP);
     }
     // ownership passes with the call: on failure the arrays have already been released
-    return qbh_csr_create_device(out, nrows, dim, row_begin, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, opts);
+    qbh_opts og;                                       // generated rows are in the generator's own order: nothing to look for
+    opts_generated(opts, &og);
+    return qbh_csr_create_device(out, nrows, dim, row_begin, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, &og);
 }
 
 // ---------------------------------------------- matrix-free Heisenberg operator --
@@ -1244,7 +1248,11 @@ static int gen_heisenberg_repr_impl(qbh_csr **out, int n_sites, int n_dn, int n_
     cleanup(false);
     if (dim_out) *dim_out = dim;
     if (d_code) rc = adopt_coded_csr(out, nloc, dim, r0, nnz, d_ia, d_ja, d_code, d_dict, n_dict, opts);
-    else rc = qbh_csr_create_device(out, nloc, dim, r0, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, opts);
+    else {
+        qbh_opts og;
+        opts_generated(opts, &og);
+        rc = qbh_csr_create_device(out, nloc, dim, r0, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, &og);
+    }
     return rc;                  // ownership passed with the call: on failure the arrays have already been released
 }
 
@@ -2110,7 +2118,9 @@ static int gen_hubbard_repr_impl(qbh_csr **out, int n_sites, int n_up, int n_dn,
     cleanup(false);
     if (dim_out) *dim_out = dim;
     if (d_code) return adopt_coded_csr(out, nloc, dim, r0, nnz, d_ia, d_ja, d_code, d_dict, n_dict, opts);
-    return qbh_csr_create_device(out, nloc, dim, r0, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, opts);
+    qbh_opts og;
+    opts_generated(opts, &og);
+    return qbh_csr_create_device(out, nloc, dim, r0, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, &og);
 }
 
 // ------------------------- diagonal one-body operators between Hubbard momentum sectors --
@@ -2743,10 +2753,7 @@ static int sector_launch_t(const MfSecArgs &a, hipStream_t s)
         occ = n;
     }
     int grid = 256 * occ;
-    if (const char *e = getenv("QBH_SEC_GRID")) {
-        const int g = atoi(e);
-        if (g >= 8) grid = (g / 8) * 8;
-    }
+    if (debug_sw().sec_grid >= 8) grid = (debug_sw().sec_grid / 8) * 8;
     if (a.ctr != nullptr) hipLaunchKernelGGL((k_mf_sector<REALX, UN, true>), dim3(grid), dim3(256), 0, s, a);
     else                  hipLaunchKernelGGL((k_mf_sector<REALX, UN, false>), dim3(grid), dim3(256), 0, s, a);
     return QBH_OK;
@@ -2757,7 +2764,7 @@ int launch_mf_sector(const MfSecArgs &a, hipStream_t s, int *nparts_out)
     static int un = 0;
     if (un == 0) {
         un = 8;
-        if (const char *e = getenv("QBH_SEC_UNROLL")) un = atoi(e);          // tuning experiments: 4, 8, 16
+        if (debug_sw().sec_unroll) un = debug_sw().sec_unroll;              // tuning experiments: 4, 8, 16
     }
     if (a.xr != nullptr) {
         if (un == 4)       sector_launch_t<true, 4>(a, s);

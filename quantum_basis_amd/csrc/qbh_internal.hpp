@@ -21,6 +21,33 @@ constexpr int kRowCap = 1024;        // row offsets staged in LDS per row block
 
 void set_error(const char *fmt, ...);
 
+// Measurement, tuning and tracing knobs, read ONCE from the single environment variable QBH_DEBUG ("key=value,key=value";
+// a bare integer n means flags=n).  None of them selects a form of the computation a caller could rely on -- those are fields
+// of qbh_opts (include/qbhip.h).  0 / -1 = the library's own choice.
+struct DebugSw {
+    int flags = 0;            // bit 0: mask the gather columns so that they stay in cache (results wrong by design)
+    int colmask = 0;          // the mask for flags & 1 (0: 1023)
+    int tpr = 0, unroll = 0, grid = 0, wave_tpr = 0, chunk_mult = 0;      // launch-geometry overrides
+    int trace_create = 0, trace_tune = 0, trace_dict = 0, print_ptrs = 0;
+    int sec_walk = 0, sec_grid = 0, sec_unroll = 0;                       // matrix-free sector kernel
+    int wave_pipelined = 0;   // the pipelined wave kernel on an unsplit operator
+    long long create_chunk = 0;                                           // staging chunk of qbh_csr_create (nonzeros)
+    int force_ragged = 0;     // native communicator: the send/recv all-gather-v even for uniform cuts
+    int mf_row = -1, mf_chunk = 0, mf_window = 0;                         // matrix-free Hubbard kernel
+    int kronc_abl = 0, kronc_far_chunk = 0, kronc_far_ng = 0, kronc_far_nt = 0;
+    int no_far_align = 0;     // in-place split: the far part directly behind the near part (unaligned)
+    int no_defer = 0;         // Lanczos: read <u, w> back every step instead of keeping it on the device
+};
+const DebugSw &debug_sw();
+void opts_builtin(qbh_opts *o);          // the built-in defaults, whatever qbh_opts_set_default says
+inline void opts_generated(const qbh_opts *opts, qbh_opts *out)      // options of an operator the library generates itself
+{
+    if (opts) *out = *opts;
+    else opts_builtin(out);
+    out->basis_detect = 0;                 // its rows are in the generator's own order: no basis to look for
+    if (out->basis_kind == QBH_BASIS_REF_FERMION2) out->basis_kind = QBH_BASIS_NONE;      // a host's hint about ITS arrays does not describe them
+}
+
 #define QBH_HIP(call)                                                                      \
     do {                                                                                   \
         hipError_t _e = (call);                                                            \
@@ -249,6 +276,7 @@ int launch_kron_c16_far(const WaveDesc *wd, const int32_t *ja, int64_t slots, in
 int launch_kron_check2(const int64_t *ia, const int32_t *ja, int64_t nrows, int64_t S, int64_t U0, int *d_flag, hipStream_t s);
 // qbh_opts.basis_kind (qbh_reorder.hip): re-express the plain CSR of A in the library's internal order, keep the vector map
 int basis_to_internal(qbh_csr *A, int kind, int n_sites, int n_up, int n_dn, bool *applied);
+int basis_detect(qbh_csr *A, bool *applied);     // qbh_opts.basis_detect: try every two-species basis of the operator's dimension
 int launch_basis_scatter(const uint32_t *map, const d2 *in, d2 *out, int64_t n, hipStream_t s);
 int launch_basis_gather(const uint32_t *map, const d2 *in, d2 *out, int64_t n, hipStream_t s);
 
@@ -594,7 +622,6 @@ struct qbh_csr {
         qbh::KronCls *d_cls = nullptr;  // several classes: device table for the near pass
         qbh::d2 *d_xt = nullptr, *d_far = nullptr;      // tiled copy of x (xt_cap elements, made on first use), far-part row sums
         int64_t  xt_cap = 0;
-        const void *xt_last = nullptr;  // measurement switch QBH_KRON_REUSE_TILE: the x of the previous SpMV
         const void *xt_of = nullptr;    // the vector whose tiled copy d_xt holds (written by the pass that produced it); consumed by one SpMV
         bool     fold = false;          // set by a driver for the duration of a solve: its BLAS-1 passes write the tiled copy of the next x
         // the gather in parts (comm_tiled, sliced far part, a communicator with allgather_part_begin): part k = bands
@@ -647,6 +674,8 @@ struct qbh_csr {
     // the caller's basis when it is not the order the operator is held in (qbh_opts.basis_kind)
     struct BasisMap {
         int       kind = 0;              // QBH_BASIS_*; 0: the operator is held in the caller's order
+        int       n_sites = 0, n_up = 0, n_dn = 0;       // the basis described (or found)
+        bool      detected = false;      // found by the library itself (qbh_opts.basis_detect), not named by the caller
         qbh::KronMap classes{};          // QBH_BASIS_SPIN_SECTOR: the class table of the internal (class-major) order
         uint32_t *d_map = nullptr;       // [nrows] caller index r -> internal index | sign << 31
         qbh::d2  *d_stage = nullptr;     // [nrows] staging of one vector in the caller's order
@@ -660,7 +689,7 @@ struct qbh_csr {
     struct qbh_native_comm *native = nullptr; // RCCL communicator owned by the handle (qbh_comm_create_rccl)
 
     // creation from host arrays: wall ms of the whole qbh_csr_create call / of the upload + expansion, host bytes read
-    double    create_ms = 0.0, create_ms_upload = 0.0;
+    double    create_ms = 0.0, create_ms_upload = 0.0, detect_ms = 0.0;
     int64_t   create_bytes_in = 0;
 
     // stats

@@ -1965,7 +1965,7 @@ int dict_build_finalize(DictBuild *b, d2 **d_dict_out, int *n_out, hipStream_t s
     int h[4] = {0, 0, 0, 0};
     QBH_HIP(hipMemcpyAsync(h, T.flags, sizeof(h), hipMemcpyDeviceToHost, s));
     QBH_HIP(hipStreamSynchronize(s));
-    if (getenv("QBH_DEBUG_DICT")) fprintf(stderr, "dict: overflow %d claimed %d cap %d\n", h[0], h[1], T.cap);
+    if (debug_sw().trace_dict) fprintf(stderr, "dict: overflow %d claimed %d cap %d\n", h[0], h[1], T.cap);
     if (h[0] || h[1] <= 0 || h[1] > T.cap) return QBH_OK;
     std::vector<unsigned long long> fp((size_t)kDictSlots);
     std::vector<d2> val((size_t)kDictSlots);
@@ -1990,7 +1990,7 @@ int dict_build_finalize(DictBuild *b, d2 **d_dict_out, int *n_out, hipStream_t s
     std::sort(ents.begin(), ents.end(), [](const Ent &x, const Ent &y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
     // two different values with one fingerprint would share a slot: the count would not add up
     const int n = (int)ents.size();
-    if (getenv("QBH_DEBUG_DICT")) fprintf(stderr, "dict: %d entries\n", n);
+    if (debug_sw().trace_dict) fprintf(stderr, "dict: %d entries\n", n);
     if (n != h[1] || n > T.cap) return QBH_OK;
     const size_t n_alloc = (size_t)std::max(n, kDictLds);
     std::vector<d2> dict(n_alloc, d2{0.0, 0.0});
@@ -3266,9 +3266,7 @@ int launch_mf_heis(const MfHeisArgs &a, hipStream_t s, int *nparts_out)
 bool mf_row_kernel_ok(const MfArgs &a)
 {
     if (a.xr == nullptr || a.t.pk_d == nullptr) return false;
-    if (const char *e = getenv("QBH_MF_ROW")) {
-        if (!atoi(e)) return false;
-    }
+    if (debug_sw().mf_row == 0) return false;
     return a.t.Nd >= 256 && a.t.Nd < (1 << 24) && a.t.wu <= kMfMaxUp && (a.t.wd % 8) == 0;
 }
 
@@ -3299,8 +3297,8 @@ int launch_mf_hubbard(const MfArgs &a, int grid, hipStream_t s, int *nparts_out)
             return QBH_OK;
         }
         int chunk = 8192, wcap = 18432;                // 144 KB window around an 8192-element chunk (measured: 2048..8192 within 5 %; bound by the up-row reads)
-        if (const char *e = getenv("QBH_MF_CHUNK")) chunk = std::max(1024, atoi(e));
-        if (const char *e = getenv("QBH_MF_WINDOW")) wcap = std::max(chunk, std::min(18432, atoi(e)));
+        if (debug_sw().mf_chunk) chunk = std::max(1024, debug_sw().mf_chunk);
+        if (debug_sw().mf_window) wcap = std::max(chunk, std::min(18432, debug_sw().mf_window));
         const size_t lds = (size_t)wcap * sizeof(double);
         QBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_hubbard_row<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

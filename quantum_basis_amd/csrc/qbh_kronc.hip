@@ -23,6 +23,8 @@
 #include <cstdint>
 #include <cstdlib>
 
+#include <mutex>
+
 #include "qbh_internal.hpp"
 
 namespace qbh {
@@ -588,34 +590,45 @@ int launch_kronc(const KroncSliced &K, const d2 *dict, int n_dict, const double 
     a.ctr = static_near ? nullptr : ctr;      // near pass: draw of major indices (static turns: reductions in a fixed order)
     a.fctr = ctr + 32;                        // far pass: chunk counters (its results do not depend on who computes a group)
     // tuning switches (measurement only): groups a wavefront has in flight per pass
-    static const int far_ng = getenv("QBH_KRONC_FAR_NG") ? atoi(getenv("QBH_KRONC_FAR_NG")) : 1;
-    static const int far_nt = getenv("QBH_KRONC_FAR_NT") ? atoi(getenv("QBH_KRONC_FAR_NT")) : 0;
+    const int far_ng = debug_sw().kronc_far_ng ? debug_sw().kronc_far_ng : 1;
+    const int far_nt = debug_sw().kronc_far_nt;
     auto far_k = K.far_uni ? (far_ng == 1 ? k_kronc_far<1, 8, false, true> : k_kronc_far<2, 8, false, true>)
                  : far_nt  ? (far_ng == 1 ? k_kronc_far<1, 8, true, false> : k_kronc_far<2, 8, true, false>)
                            : (far_ng == 1 ? k_kronc_far<1, 8, false, false> : far_ng == 3 ? k_kronc_far<3, 8, false, false> : k_kronc_far<2, 8, false, false>);
     auto near_k = K.near_uni ? k_kronc_near<4, 8, false> : k_kronc_near<4, 8, true>;
-    static int far_occ = 0;
-    static size_t attr_done_k[2] = {0, 0};          // per instance of the near kernel
-    size_t &attr_done = attr_done_k[K.near_uni ? 1 : 0];
-    if (far_occ == 0) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, far_k, 256, 0) != hipSuccess || n <= 0) n = 4;
-        far_occ = n > 8 ? 8 : n;
-    }
+    // hipFuncSetAttribute applies per DEVICE: the bookkeeping is per device as well (a process may drive several GPUs), under a
+    // lock (two host threads with one operator each)
+    constexpr int kMaxDev = 16;
+    static std::mutex mu;
+    static int far_occ_dev[kMaxDev] = {0};
+    static size_t attr_done_dev[kMaxDev][2] = {{0, 0}};          // per instance of the near kernel
+    int dev = 0;
+    QBH_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDev) dev = kMaxDev - 1;             // beyond the table: set the attribute every time (below)
     const size_t lds = kronc_near_lds_bytes(K.S);
-    if (attr_done < lds) {
-        QBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(near_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = lds;
+    int far_occ = 0;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (far_occ_dev[dev] == 0 || dev == kMaxDev - 1) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, far_k, 256, 0) != hipSuccess || n <= 0) n = 4;
+            far_occ_dev[dev] = n > 8 ? 8 : n;
+        }
+        far_occ = far_occ_dev[dev];
+        size_t &attr_done = attr_done_dev[dev][K.near_uni ? 1 : 0];
+        if (attr_done < lds || dev == kMaxDev - 1) {
+            QBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(near_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_done = lds;
+        }
     }
     {
-        static const int far_chunk = getenv("QBH_KRONC_FAR_CHUNK") ? atoi(getenv("QBH_KRONC_FAR_CHUNK")) : 0;
+        const int far_chunk = debug_sw().kronc_far_chunk;
         // the wavefronts of one XCD (32 CUs x far_occ workgroups x 4) together stay inside about one band
         int64_t c = far_chunk > 0 ? far_chunk : K.NU / ((int64_t)32 * far_occ * 4);
         a.chunk = (int)(c < 1 ? 1 : c > 32 ? 32 : c);
     }
     {
-        static const int abl = getenv("QBH_KRONC_ABL") ? atoi(getenv("QBH_KRONC_ABL")) : 0;
-        a.abl = abl;
+        a.abl = debug_sw().kronc_abl;
     }
     QBH_HIP(hipMemsetAsync(ctr, 0, 9 * 32 * sizeof(unsigned int), s));
     hipLaunchKernelGGL(far_k, dim3(256 * far_occ), dim3(256), 0, s, a);

@@ -147,6 +147,29 @@ __global__ __launch_bounds__(256) void k_inv_maps(const int32_t *order, const ui
     }
 }
 
+// Does the order a hint describes give the operator the product structure?  Asked of the ORIGINAL arrays through the map --
+// one pass over the columns with a 4-byte gather each -- BEFORE the operator is permuted (a full second copy): a wrong hint, or a
+// candidate of the library's own search (qbh_opts.basis_detect), costs milliseconds instead of a permutation.  A wavefront per
+// 64 rows, lanes striding the row: coalesced column reads.
+__global__ __launch_bounds__(256) void k_ref_precheck(const uint32_t *map, int64_t dim, const int64_t *ia, const int32_t *ja, int64_t S, int *flag)
+{
+    const int lane = threadIdx.x & 63;
+    bool bad = false;
+    for (int64_t r0 = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64; r0 < dim; r0 += (((int64_t)gridDim.x * blockDim.x) >> 6) * 64) {
+        if (*reinterpret_cast<volatile int *>(flag)) return;               // somebody found a counter-example already
+        const int64_t r1 = r0 + 64 < dim ? r0 + 64 : dim;
+        for (int64_t r = r0; r < r1; ++r) {
+            const int64_t g = map[r] & 0x7FFFFFFFu, gm = g / S, gd = g - gm * S;
+            for (int64_t k = ia[r] + lane; k < ia[r + 1]; k += 64) {
+                const int64_t c = map[ja[k]] & 0x7FFFFFFFu, cm = c / S;
+                bad = bad || (cm != gm && c - cm * S != gd);
+            }
+        }
+        if (bad) break;
+    }
+    if (bad) *flag = 1;
+}
+
 // QBH_BASIS_SPIN_SECTOR: caller index r = rank of the n_sites-bit pattern with n_dn bits set; internal index = class-major
 // (class = bits set among the high sites): rbase[c] + rank(high part) * S[c] + rank(low part)
 struct SpinCut {
@@ -253,7 +276,7 @@ extern "C" int qbh_csr_reference_order(qbh_csr **out, const qbh_csr *A, int kind
     } dev_guard(A->device);
     qbh_opts opts_here;
     if (opts) opts_here = *opts;
-    else qbh_opts_default(&opts_here);
+    else qbh::opts_builtin(&opts_here);
     opts_here.device = A->device;
     opts = &opts_here;
     RefOrderArgs a{};
@@ -426,6 +449,15 @@ int qbh::basis_to_internal(qbh_csr *A, int kind, int n_sites, int n_up, int n_dn
         }
         hipLaunchKernelGGL(k_inv_maps, dim3(2048), dim3(256), 0, s, v1, sign, dim, inv_order, map, A->d_ia, cnt);
         RO_HIP(hipGetLastError());
+        // the hint is checked, not trusted -- and checked BEFORE the operator is permuted
+        RO_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_ref_precheck, dim3(4096), dim3(256), 0, s, map, dim, A->d_ia, A->d_ja, a.n_minor, A->d_flag);
+        RO_HIP(hipGetLastError());
+        int bad = 0;
+        RO_HIP(hipMemcpyAsync(&bad, A->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+        RO_HIP(hipStreamSynchronize(s));
+        RO_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), s));
+        if (bad) return drop(QBH_OK);
     } else {
         sc.binom = d_binom;
         hipLaunchKernelGGL(k_spin_sector_map, dim3(2048), dim3(256), 0, s, sc, dim, inv_order, map, A->d_ia, cnt);
@@ -472,6 +504,44 @@ int qbh::basis_to_internal(qbh_csr *A, int kind, int n_sites, int n_up, int n_dn
     A->basis.d_map = map;
     map = nullptr;
     if (kind == QBH_BASIS_REF_FERMION2) A->opts.kron_minor = a.n_minor;
+    A->basis.n_sites = n_sites;
+    A->basis.n_up = n_up;
+    A->basis.n_dn = n_dn;
     *applied = true;
     return drop(QBH_OK);
+}
+
+// qbh_opts.basis_detect: host arrays arrive without a word about their basis (the reference's csr_mat(lil_mat&) carries no
+// options, src/sparse.cc:202-260; its matrices are in Lin order, src/basis.cc:1144-1190).  Every (n_sites, n_up, n_dn) with
+// C(n_sites, n_up) * C(n_sites, n_dn) = dim is tried as QBH_BASIS_REF_FERMION2 through the pre-check above; the first under
+// which the operator has the product structure is taken.  Being right about the physics is not required: ANY order with the
+// product structure is a valid internal order (vectors are translated with the same map), a matrix of a colliding dimension
+// without it stays as given.
+int qbh::basis_detect(qbh_csr *A, bool *applied)
+{
+    *applied = false;
+    if (A->kind != 0 || !A->d_val || A->d_code || !A->own_arrays || A->has_rem || A->has_comm || A->kron.active || A->nrows != A->ncols ||
+        A->row_offset != 0 || A->basis.kind != 0)
+        return QBH_OK;
+    const int64_t dim = A->nrows;
+    std::vector<uint64_t> hb(33 * 33, 0);
+    for (int p = 0; p <= 32; ++p)
+        for (int k = 0; k <= 32; ++k) hb[(size_t)p * 33 + k] = (k == 0) ? 1 : (p == 0 ? 0 : hb[(size_t)(p - 1) * 33 + k - 1] + hb[(size_t)(p - 1) * 33 + k]);
+    int tried = 0;
+    for (int n = 2; n <= 31 && tried < 24; ++n)
+        for (int nu = 1; nu < n && tried < 24; ++nu) {
+            const uint64_t cu = hb[(size_t)n * 33 + nu];
+            if (cu < 2 || (uint64_t)dim % cu != 0) continue;
+            const uint64_t want = (uint64_t)dim / cu;
+            for (int nd = 1; nd < n && tried < 24; ++nd) {
+                if (hb[(size_t)n * 33 + nd] != want || want < 2) continue;
+                ++tried;
+                QBH_TRY(qbh::basis_to_internal(A, QBH_BASIS_REF_FERMION2, n, nu, nd, applied));
+                if (*applied) {
+                    A->basis.detected = true;
+                    return QBH_OK;
+                }
+            }
+        }
+    return QBH_OK;
 }

@@ -2,8 +2,13 @@
 // the SAME host CSR (the unchanged model::generate_Ham_sparse_full output), takes its nnz-balanced row block
 // (qbh_balanced_row_cuts), builds only that block on its GPU (qbh_csr_create_rows) and joins the native RCCL
 // communicator (qbh_comm_create_rccl); then the unchanged solver call: lanczos("sr_val0") + hess_eigen, eigenvec_CG.
-// usage: sharded_main csr.bin rank nranks uid_file [uniform]   (rank 0 writes the ncclUniqueId to uid_file, the others wait;
-//        "uniform": equal row blocks -> ncclAllGather instead of the send/recv all-gather-v of nnz-balanced cuts)
+// usage: sharded_main csr.bin rank nranks uid_file [uniform] [key=value ...]   (rank 0 writes the ncclUniqueId to uid_file, the
+//        others wait; "uniform": equal row blocks -> ncclAllGather instead of the send/recv all-gather-v of nnz-balanced cuts)
+//        kron=S      the index is major * S + minor (qbh_opts.kron_minor, kron_split = 2): row blocks of whole major indices, every
+//                    shard split in place, the ranks exchange the tiled copies of their blocks
+//        parts=K     qbh_opts.gather_parts;  unsplit=R  rank R keeps its shard unsplit (the ranks must fall back together)
+//        plain=1     complex128 values and vectors (value_dict = 0, real_fast_path = 0)
+//        dump=PREFIX rank r writes PREFIX.r.bin: m, mcg, E0, a_j / b_j (2 m doubles), its slice of the eigenvector
 #include <chrono>
 #include <complex>
 #include <cstdio>
@@ -52,8 +57,25 @@ int main(int argc, char **argv)
         }
     }
     std::vector<int64_t> cuts(nranks + 1);
-    const bool uniform = argc > 5 && std::string(argv[5]) == "uniform" && dim % nranks == 0;
-    if (uniform) {
+    bool uniform = false;
+    int64_t kron = 0;
+    int parts = 0, unsplit = -1, plain = 0;
+    std::string dump;
+    for (int i = 5; i < argc; ++i) {
+        const std::string a(argv[i]);
+        if (a == "uniform") uniform = dim % nranks == 0;
+        else if (a.rfind("kron=", 0) == 0) kron = std::atoll(a.c_str() + 5);
+        else if (a.rfind("parts=", 0) == 0) parts = std::atoi(a.c_str() + 6);
+        else if (a.rfind("unsplit=", 0) == 0) unsplit = std::atoi(a.c_str() + 8);
+        else if (a.rfind("plain=", 0) == 0) plain = std::atoi(a.c_str() + 6);
+        else if (a.rfind("dump=", 0) == 0) dump = a.substr(5);
+        else return 2;
+    }
+    if (kron > 0) {                                  // whole major indices per rank, as even as they come
+        const int64_t nu = dim / kron;
+        for (int q = 0; q <= nranks; ++q) cuts[q] = (nu * q / nranks) * kron;
+        uniform = uniform && nu % nranks == 0;
+    } else if (uniform) {
         for (int q = 0; q <= nranks; ++q) cuts[q] = dim / nranks * q;
     } else {
         must(qbh_balanced_row_cuts(dim, nnz, (int)sym, ia.data(), ja.data(), nranks, cuts.data()), "qbh_balanced_row_cuts");
@@ -61,6 +83,12 @@ int main(int argc, char **argv)
     qbh_opts opts;
     qbh_opts_default(&opts);
     opts.device = rank % (qbh_device_count() > 0 ? qbh_device_count() : 1);          // one process per GPU
+    if (plain) opts.value_dict = 0, opts.real_fast_path = 0;
+    if (kron > 0) {
+        opts.kron_minor = kron;
+        opts.kron_split = rank == unsplit ? 0 : 2;
+    }
+    opts.gather_parts = parts;
     qbh_csr *A = nullptr;
     must(qbh_csr_create_rows(&A, dim, nnz, (int)sym, ia.data(), ja.data(), reinterpret_cast<const qbh_z *>(val.data()), cuts[rank],
                              cuts[rank + 1], &opts), "qbh_csr_create_rows");
@@ -80,8 +108,21 @@ int main(int argc, char **argv)
     must(qbh_eigenvec_cg_dev(A, maxit, &mcg, E0, &accu, d_v + 2 * n, d_v, d_v + n, d_v + 3 * n, nullptr), "qbh_eigenvec_cg_dev");
     double nrm = 0.0;
     must(qbh_nrm2_dev(A, d_v + 2 * n, &nrm), "qbh_nrm2_dev");                         // global norm of the eigenvector
-    std::printf("OK %d %d %lld %lld %lld %.17g %lld %.3e %.15g\n", rank, nranks, (long long)cuts[rank], (long long)cuts[rank + 1],
-                (long long)m, E0, (long long)mcg, accu, nrm);
+    qbh_csr_info inf;
+    must(qbh_csr_get_info(A, &inf), "qbh_csr_get_info");
+    if (!dump.empty()) {
+        std::vector<cplx> vec(n);
+        must(qbh_vec_download(A, reinterpret_cast<qbh_z *>(vec.data()), d_v + 2 * n, n), "qbh_vec_download");
+        std::ofstream o(dump + "." + std::to_string(rank) + ".bin", std::ios::binary);
+        const int64_t head[2] = {m, mcg};
+        o.write((const char *)head, 16);
+        o.write((const char *)&E0, 8);
+        o.write((const char *)(hess.data() + maxit), 8 * m);       // a_j
+        o.write((const char *)hess.data(), 8 * m);                 // b_j
+        o.write((const char *)vec.data(), 16 * n);
+    }
+    std::printf("OK %d %d %lld %lld %lld %.17g %lld %.3e %.15g kron %lld parts %d cols16 %d\n", rank, nranks, (long long)cuts[rank],
+                (long long)cuts[rank + 1], (long long)m, E0, (long long)mcg, accu, nrm, (long long)inf.kron_minor, inf.gather_parts, inf.kron_cols16);
     qbh_vec_free(d_v);
     must(qbh_comm_destroy(A), "qbh_comm_destroy");
     qbh_csr_destroy(A);

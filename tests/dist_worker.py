@@ -122,8 +122,6 @@ def gpu_sharded_kron(rank, world, port, backend, out_dir, mixed=False, parts=0, 
     back into a CSR (kron_restore).  parts: the gather in that many band ranges (qbh_comm.allgather_part_begin), the far pass of
     a range following its piece; native: the library's own RCCL communicator (one rank: every piece is the rank's own)."""
     import torch
-    if parts:
-        os.environ["QBH_GATHER_PARTS"] = str(parts)
     dist = _init(rank, world, port, backend)
     torch.cuda.set_device(0)
     import quantum_basis_amd as q
@@ -133,7 +131,7 @@ def gpu_sharded_kron(rank, world, port, backend, out_dir, mixed=False, parts=0, 
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         split = 0 if (mixed and rank == 1) else 2              # 2: split whatever has the structure (1 leaves small operators alone)
-        opts = q.make_opts(device=0, stream=stream.cuda_stream, value_dict=0, real_fast_path=0, kron_split=split)
+        opts = q.make_opts(device=0, stream=stream.cuda_stream, value_dict=0, real_fast_path=0, kron_split=split, gather_parts=parts)
         cuts = qdist.kron_row_cuts(dim, S, world)
         r0, r1 = int(cuts[rank]), int(cuts[rank + 1])
         A = q.csr_mat.hubbard(L, ne, ne, bonds, rows=(r0, r1), opts=opts)

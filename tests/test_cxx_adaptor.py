@@ -77,12 +77,12 @@ def test_sharded_host_program_compiles_and_links():
 @pytest.mark.parametrize("force_ragged", [0, 1])
 def test_sharded_cxx_host_rank_over_native_rccl(force_ragged):
     """A C++ host process as one rank of the row-sharded run: qbh_balanced_row_cuts -> qbh_csr_create_rows ->
-    qbh_comm_create_rccl (1 rank on this one-GPU box; QBH_COMM_FORCE_RAGGED=1 takes the grouped-broadcast gather of
+    qbh_comm_create_rccl (1 rank on this one-GPU box; QBH_DEBUG=force_ragged=1 takes the send/recv all-gather-v of
     ragged partitions) -> qbh_lanczos_dev / qbh_eigenvec_cg_dev.  No Python anywhere in the SpMV loop."""
     with tempfile.TemporaryDirectory() as tmp:
         exe = _build(tmp, "sharded_main")
         path, O, x = _dump(tmp, "hubbard_4x2")
-        env = dict(os.environ, QBH_COMM_FORCE_RAGGED=str(force_ragged))
+        env = dict(os.environ, QBH_DEBUG="force_ragged=%d" % force_ragged)
         p = subprocess.run([exe, path, "0", "1", os.path.join(tmp, "uid.bin")], capture_output=True, text=True, env=env)
         assert p.returncode == 0, p.stdout + p.stderr
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("OK ")]      # RCCL prints a version banner first

@@ -27,14 +27,21 @@ def _hint(n, nu, nd, **kw):
     return q.make_opts(basis_kind=_lib.BASIS_REF_FERMION2, n_sites=n, n_up=nu, n_dn=nd, **kw)
 
 
+@pytest.mark.parametrize("hinted", [1, 0])
 @pytest.mark.parametrize("ly,nu,nd", [(2, 4, 4), (2, 3, 5), (3, 6, 6)])
-def test_reference_ordered_host_arrays_run_on_the_split_with_the_hint(ly, nu, nd):
+def test_reference_ordered_host_arrays_run_on_the_split_with_the_hint_and_without(ly, nu, nd, hinted):
+    """hinted = 0: NOTHING is said about the basis -- what the reference's csr_mat(lil_mat&) (src/sparse.cc:202-260) can say.  The
+    library looks for a two-species basis of this dimension by itself (qbh_opts.basis_detect; kron_split = 2 lifts the 1e8-nonzero
+    threshold for the test), finds one under which the operator has the product structure and runs the same split path."""
     n = 4 * ly
     dim, ia, ja, val, _ = refham.hubbard_csr(4, ly, nu, nd, t=1.0, U=1.1)          # Hermitian-upper, reference order
     O = qo.Csr(dim, ia, ja, val, True)
-    A = q.csr_mat(dim, ia, ja, val, sym=True, opts=_hint(n, nu, nd, kron_split=2, **PLAIN))
+    A = q.csr_mat(dim, ia, ja, val, sym=True, opts=_hint(n, nu, nd, kron_split=2, **PLAIN) if hinted else q.make_opts(kron_split=2, **PLAIN))
     info = A.info()
     assert info.basis_internal == _lib.BASIS_REF_FERMION2 and info.kron_minor == math.comb(n, nd) and info.kron_inplace == 1
+    assert info.basis_detected == (0 if hinted else 1) and info.basis_n_sites == n
+    assert math.comb(n, info.basis_n_up) * math.comb(n, info.basis_n_dn) == dim
+    assert (info.basis_detect_ms > 0.0) == (not hinted) and info.basis_detect_ms < info.create_ms + 1e-9
     # MultMv / MultMv2 (src/sparse.cc:262-297) through the host seam, caller's order in and out
     x, y0 = _rand(dim, 1), _rand(dim, 2)
     want = O.multmv(x)
@@ -90,6 +97,48 @@ def test_a_hint_that_does_not_describe_the_matrix_changes_nothing():
         A.destroy()
 
 
+def test_a_matrix_of_a_colliding_dimension_without_the_structure_stays_as_given():
+    """dim 4900 = C(8, 4)^2 -- but a random Hermitian band matrix: the search tries (8, 4, 4), the pre-check finds an entry that
+    changes both indices after a handful of rows, nothing is permuted (the arrays download exactly as they went in) and the
+    operator is right.  So is a Hubbard matrix whose caller turned the search off."""
+    dim = 4900
+    rng = np.random.default_rng(7)
+    import scipy.sparse as sp
+    B = sp.random(dim, dim, density=2e-3, random_state=rng, format="csr", dtype=np.float64)
+    H = (B + B.T + sp.diags(rng.normal(size=dim))).tocsr().astype(np.complex128)
+    H.sort_indices()
+    ia, ja, val = H.indptr.astype(np.int64), H.indices.astype(np.int64), H.data
+    A = q.csr_mat(dim, ia, ja, val, sym=False, opts=q.make_opts(kron_split=2, **PLAIN))
+    info = A.info()
+    assert info.basis_internal == 0 and info.basis_detected == 0 and info.kron_minor == 0 and info.basis_detect_ms > 0.0
+    fia, fja, fval = A.download()
+    assert np.array_equal(fia, ia) and np.array_equal(fja, ja) and np.array_equal(fval, val)
+    x = _rand(dim, 8)
+    y = np.empty(dim, dtype=np.complex128)
+    A.MultMv(x, y)
+    want = H @ x
+    assert np.abs(y - want).max() <= 2e-13 * np.abs(want).max()
+    A.destroy()
+    d2_, ia2, ja2, val2, _ = refham.hubbard_csr(4, 2, 4, 4, t=1.0, U=1.1)
+    A = q.csr_mat(d2_, ia2, ja2, val2, sym=True, opts=q.make_opts(kron_split=2, basis_detect=0, **PLAIN))
+    assert A.info().basis_internal == 0 and A.info().basis_detect_ms == 0.0
+    A.destroy()
+
+
+def test_default_format_finds_the_basis_too():
+    """The options the unchanged host code really passes: none (value codes + real fast path on).  The search runs before the
+    value dictionary is built; the coded split then applies to the permuted operator."""
+    n, nu, nd = 12, 6, 6
+    dim, ia, ja, val, _ = refham.hubbard_csr(4, 3, nu, nd, t=1.0, U=1.1)
+    A = q.csr_mat(dim, ia, ja, val, sym=True, opts=q.make_opts(kron_split=2))
+    info = A.info()
+    assert info.basis_detected == 1 and info.basis_internal == _lib.BASIS_REF_FERMION2 and info.value_dict > 0 and info.kron_minor == math.comb(n, nd)
+    r = q.locate_E0_lanczos(A, nev=1, ncv=1, maxit=1000)
+    ro = qo.locate_E0_lanczos(qo.Csr(dim, ia, ja, val, True), nev=1, ncv=1, maxit=1000)
+    assert abs(r.E0 - ro["E0"]) <= 1e-11 * abs(ro["E0"]) and abs(abs(np.vdot(r.eigenvecs, ro["eigenvecs"])) - 1.0) < 1e-8
+    A.destroy()
+
+
 def test_set_basis_on_an_existing_operator():
     """qbh_csr_set_basis: the same declaration for an operator that already exists (bench.py --order reference uses it on the
     device-permuted C3).  Hubbard 4x3 in the reference's order, made on the device."""
@@ -99,6 +148,12 @@ def test_set_basis_on_an_existing_operator():
     R = G.reference_order(1, n, nu, nd, opts=q.make_opts(kron_split=0, **PLAIN))
     e_ref = q.locate_E0_lanczos(R).E0
     assert R.info().kron_minor == 0
+    R2 = G.reference_order(1, n, nu, nd, opts=q.make_opts(kron_split=0, **PLAIN))
+    assert R2.set_basis(_lib.BASIS_DETECT, 0, 0, 0)                        # the library's own search on an existing operator
+    i2 = R2.info()
+    assert i2.basis_internal == 1 and i2.basis_detected == 1 and (i2.basis_n_sites, i2.basis_n_up, i2.basis_n_dn) == (n, nu, nd)
+    assert abs(q.locate_E0_lanczos(R2).E0 - e_ref) <= 1e-11 * abs(e_ref)
+    R2.destroy()
     assert R.set_basis(_lib.BASIS_REF_FERMION2, n, nu, nd)                 # (kron_split 0 -> 1 by the call; 4x3 is below the size 1 splits)
     info = R.info()
     assert info.basis_internal == 1 and info.kron_minor in (0, math.comb(n, nd))

@@ -140,7 +140,7 @@ def test_chunk_boundaries_of_the_staged_upload(monkeypatch):
     want = A.download()
     A.destroy()
     for chunk in ("1000", "1024", "77777"):
-        monkeypatch.setenv("QBH_CREATE_CHUNK", chunk)
+        monkeypatch.setenv("QBH_DEBUG", "create_chunk=" + chunk)        # a measurement knob, not a form: the debug list
         B = q.csr_mat(d, ia, ja, val, sym=sym, opts=q.make_opts(value_dict=0))
         got = B.download()
         assert all(np.array_equal(a, b) for a, b in zip(want, got)), chunk

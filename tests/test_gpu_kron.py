@@ -22,14 +22,13 @@ def _rand(n, seed):
 # the last two shapes have 4 / 8 far entries per row: 128 / 64 rows per 512-slot block, so a run of four blocks overflows the
 # wave's row buffer (mid-run flush, groups cut at the flush added atomically)
 @pytest.mark.parametrize("shape", [(4, 2, 4, 4), (4, 3, 6, 6), (4, 3, 5, 7), (4, 3, 7, 2), (3, 3, 4, 5), (4, 4, 1, 3), (4, 4, 2, 2)])
-def test_split_operator_equals_the_unsplit_one(shape, sliced, monkeypatch):
+def test_split_operator_equals_the_unsplit_one(shape, sliced):
     # far part: 0 = row-major inside the bands, 1 = sliced in groups of 8 rows where that costs < 1/8 padding, 2 = sliced
     # even where the minor size is not a multiple of 8 and the groups straddle bands (padding, same results)
-    monkeypatch.setenv("QBH_KRON_SLICED", str(sliced))
     lx, ly, nu, nd = shape
     n = lx * ly
     bonds = lattices.square(lx, ly)
-    K = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_split=2, **PLAIN))     # 2: no timing, always split
+    K = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_split=2, kron_sliced=sliced, **PLAIN))     # kron_split 2: always split
     P = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_split=0, **PLAIN))
     ik, ip = K.info(), P.info()
     assert ik.kron_minor == ik.ncols // int(round(ik.ncols / ik.kron_minor)) > 0 and ip.kron_minor == 0
@@ -416,10 +415,10 @@ def test_headline_lattice_at_U4_reproduces_the_published_ground_state_energy():
 
 @pytest.mark.parametrize("form", ["1", "2", "2g"])
 @pytest.mark.parametrize("shape", [(4, 2, 4, 4), (4, 3, 6, 6), (4, 3, 5, 7), (4, 4, 2, 2), (4, 3, 6, 6, "tri"), (4, 4, 1, 7, "tri")])
-def test_coded_real_form_of_the_split(shape, form, monkeypatch):
+def test_coded_real_form_of_the_split(shape, form):
     """The library's default form of a real operator (dictionary-coded values, packed-double Lanczos vectors) through the split
-    for the row kernel (QBH_KRON_CODED=1: near launch in natural order, far launch with tiled rows and columns accumulating at
-    orig(row); QBH_KRON_CODED=2: both parts sliced in groups of 16 rows, far pass gathering whole lines of the tiled x, near pass
+    for the row kernel (qbh_opts.kron_coded = 1: near launch in natural order, far launch with tiled rows and columns accumulating at
+    orig(row); kron_coded = 2: both parts sliced in groups of 16 rows, far pass gathering whole lines of the tiled x, near pass
     gathering from the block of x held in LDS -- qbh_kronc.hip; "2g": with the far part in its general form, not recognised as
     T (x) 1): same E0, same step count, same eigenvector as the unsplit coded operator and as the oracle's operator."""
     lx, ly, nu, nd = shape[:4]
@@ -429,11 +428,8 @@ def test_coded_real_form_of_the_split(shape, form, monkeypatch):
     bonds = lattices.triangular(lx, ly) if len(shape) > 4 else lattices.square(lx, ly)
     P = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_split=0))      # the default format (coded + real fast path), unsplit
     assert P.info().kron_minor == 0 and P.info().value_dict > 0
-    monkeypatch.setenv("QBH_KRON_CODED", form[0])
-    if form == "2g":                 # the general form of both parts (a Hubbard operator is T (x) 1 + 1 (x) T' + D and would be kept as T, T', D)
-        monkeypatch.setenv("QBH_KRONC_FAR_UNI", "0")
-        monkeypatch.setenv("QBH_KRONC_NEAR_UNI", "0")
-    K = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1)
+    # "2g": the general form of both parts (a Hubbard operator is T (x) 1 + 1 (x) T' + D and would be kept as T, T', D)
+    K = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_coded=int(form[0]), kron_uniform=0 if form == "2g" else 3))
     ik = K.info()
     assert ik.kron_minor > 0 and ik.kron_band in (2, 4, 8, 16) and 0 < ik.kron_far_nnz < ik.nnz and ik.value_dict > 0
     assert ik.kron_sliced == (0 if form == "1" else 1) and (form == "1" or ik.kron_band == 16)

@@ -1,0 +1,151 @@
+"""SURVEY 8(e) through the library's NATIVE communicator with N > 1 ranks before a multi-GPU node ever runs it: N C++ host
+processes (tests/cxx/sharded_main.cpp) share this box's one GPU and exchange through tests/stub_rccl/librccl_stub.so -- a
+test-only stand-in for librccl (real RCCL refuses two ranks on one device) selected with QBH_RCCL_LIB -- so that
+qbh_comm_create_rccl, the collective qbh_csr_set_comm, ncclAllGather for uniform blocks, the grouped ncclSend / ncclRecv
+all-gather-v for ragged ones, the gather in band ranges with its per-part events, the tiled exchange of split shards, the fall
+back when one rank cannot split, and the all-reduce of the Lanczos / CG scalars all execute with real peers.  The stub FAILS
+where real RCCL would hang (a receive no send matches, element counts that differ).  Every rank must report the one-rank
+E0, a_j / b_j, step counts and its slice of the one-rank eigenvector.  (The matvec served: src/sparse.cc:262-289.)"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import quantum_basis_amd as q
+from quantum_basis_amd import lattices
+from test_cxx_adaptor import ROOT, _build
+from test_rccl_stub import STUB, _stub
+
+pytestmark = pytest.mark.gpu
+S_MINOR = 70            # Hubbard 4x2, 4 + 4 electrons in the generator's species-major order: index = up * 70 + down, dim 4900
+
+
+@pytest.fixture(scope="module")
+def rig():
+    _stub()             # builds the stub when the .so is not there
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = _build(tmp, "sharded_main")
+        G = q.csr_mat.hubbard(8, 4, 4, lattices.square(4, 2), t=1.0, U=1.1, opts=q.make_opts(kron_split=0, value_dict=0, real_fast_path=0))
+        ia, ja, val = G.download()
+        dim = G.dim
+        G.destroy()
+        path = os.path.join(tmp, "csr.bin")
+        with open(path, "wb") as f:
+            np.array([dim, len(ja), 0], dtype=np.int64).tofile(f)
+            ia.astype(np.int64).tofile(f), ja.astype(np.int64).tofile(f), val.tofile(f)
+        yield {"tmp": tmp, "exe": exe, "csr": path, "dim": dim, "ref": {}}
+
+
+def _run(rig, nranks, args, tag):
+    uid = os.path.join(rig["tmp"], "uid_%s.bin" % tag)
+    dump = os.path.join(rig["tmp"], "dump_%s" % tag)
+    env = dict(os.environ, QBH_RCCL_LIB=STUB, TMPDIR=rig["tmp"], HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([rig["exe"], rig["csr"], str(r), str(nranks), uid] + args + ["dump=" + dump], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True, env=env) for r in range(nranks)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for p2 in procs:
+                p2.kill()
+            raise
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    res = []
+    for r in range(nranks):
+        line = [ln for ln in outs[r].splitlines() if ln.startswith("OK ")]
+        assert len(line) == 1, outs[r]
+        tok = line[0].split()
+        raw = np.fromfile("%s.%d.bin" % (dump, r), dtype=np.uint8)
+        m, mcg = np.frombuffer(raw[:16].tobytes(), dtype=np.int64)
+        e0 = np.frombuffer(raw[16:24].tobytes(), dtype=np.float64)[0]
+        ab = np.frombuffer(raw[24:24 + 16 * m].tobytes(), dtype=np.float64)
+        vec = np.frombuffer(raw[24 + 16 * m:].tobytes(), dtype=np.complex128)
+        res.append({"r0": int(tok[3]), "r1": int(tok[4]), "m": int(m), "mcg": int(mcg), "E0": float(e0), "a": ab[:m], "b": ab[m:], "vec": vec,
+                    "accu": float(tok[8]), "nrm": float(tok[9]), "kron": int(tok[11]), "parts": int(tok[13]), "cols16": int(tok[15])})
+    return res
+
+
+def _reference(rig, plain):
+    """the ONE-rank answer of the same program (same format), also through the stub"""
+    key = "plain" if plain else "default"
+    if key not in rig["ref"]:
+        rig["ref"][key] = _run(rig, 1, ["plain=1"] if plain else [], "ref_" + key)[0]
+    return rig["ref"][key]
+
+
+def _check(rig, res, ref, nranks):
+    assert res[0]["r0"] == 0 and res[-1]["r1"] == rig["dim"] and all(res[i]["r1"] == res[i + 1]["r0"] for i in range(nranks - 1))
+    assert abs(ref["E0"] + 14.076058658879278) < 1e-9
+    full = np.concatenate([r["vec"] for r in res])
+    for r in res:
+        assert abs(r["E0"] - ref["E0"]) <= 1e-12 * abs(ref["E0"])
+        assert abs(r["m"] - ref["m"]) <= 1 and abs(r["mcg"] - ref["mcg"]) <= 2
+        k = min(r["m"], ref["m"], 40)                                 # beyond ~40 steps rounding differences are amplified by the recurrence
+        assert np.allclose(r["a"][:k], ref["a"][:k], rtol=0, atol=1e-9) and np.allclose(r["b"][:k], ref["b"][:k], rtol=0, atol=1e-9)
+        assert r["accu"] < 2e-12 and abs(r["nrm"] - 1.0) < 1e-10
+        assert all(np.array_equal(r["a"], res[0]["a"]) for r in res)  # the scalars are all-reduced: every rank holds the same bits
+    assert abs(abs(np.vdot(full, ref["vec"])) - 1.0) < 1e-8           # the slices ARE the one-rank eigenvector
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 4])
+@pytest.mark.parametrize("parts", [1, 4, 7])
+def test_split_shards_exchange_tiled_blocks_over_the_native_communicator(rig, nranks, parts):
+    """complex128 shards of whole major indices, each split in place (2-byte near columns, int32 far columns), the TILED block
+    of every rank on the wire, in 1 / 4 / 7 band ranges; 2 ranks: uniform blocks, 3 and 4 ranks: ragged (70 major indices)."""
+    res = _run(rig, nranks, ["plain=1", "kron=%d" % S_MINOR, "parts=%d" % parts] + (["uniform"] if nranks == 2 else []), "kron_%d_%d" % (nranks, parts))
+    assert all(r["kron"] == S_MINOR and r["parts"] == parts and r["cols16"] == 1 for r in res), res
+    _check(rig, res, _reference(rig, True), nranks)
+
+
+@pytest.mark.parametrize("nranks,unsplit", [(2, 1), (3, 0)])
+def test_one_unsplit_rank_makes_every_rank_fall_back_together(rig, nranks, unsplit):
+    """One rank keeps its shard unsplit: the collective qbh_csr_set_comm must end with EVERY rank on the plain exchange (the
+    split ones merged back into a CSR), not with mismatched message sizes."""
+    res = _run(rig, nranks, ["plain=1", "kron=%d" % S_MINOR, "parts=4", "unsplit=%d" % unsplit], "mixed_%d" % nranks)
+    assert all(r["kron"] == 0 and r["parts"] == 1 for r in res), res
+    _check(rig, res, _reference(rig, True), nranks)
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 4])
+@pytest.mark.parametrize("cuts", ["uniform", "ragged"])
+@pytest.mark.parametrize("plain", [0, 1])
+def test_plain_shards_over_the_native_communicator(rig, nranks, cuts, plain):
+    """Unsplit row shards (locally-owned / remote column split): the library's default format -- coded values, REAL wire format,
+    8 bytes per element through d_xfull_r -- and the complex128 format; ncclAllGather for uniform blocks (4900 / 3 is not whole:
+    falls to the ragged path by itself) and the grouped send / receive all-gather-v for nnz-balanced cuts."""
+    if cuts == "uniform" and rig["dim"] % nranks:
+        pytest.skip("4900 rows do not divide by %d" % nranks)
+    res = _run(rig, nranks, (["plain=1"] if plain else []) + (["uniform"] if cuts == "uniform" else []), "plain_%d_%s_%d" % (nranks, cuts, plain))
+    _check(rig, res, _reference(rig, bool(plain)), nranks)
+
+
+def test_bench_two_ranks_on_one_gpu_through_the_native_communicator(rig):
+    """bench.py --gpus 2 as the driver launches it, two ranks sharing the GPU (gloo for torch's own rendezvous, the library's
+    exchange through qbh_comm_create_rccl on the stub): the N > 1 line's schema -- per_rank timing, ms_gather, hidden fraction --
+    is populated and E0 equals the one-rank value."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, QBH_RCCL_LIB=STUB, QBH_DIST_BACKEND="gloo", TMPDIR=rig["tmp"], HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "5", "--warmup", "2", "--workload", "hubbard_4x3_half", "--no-cpu-baseline", "--no-matrix-free", "--no-fast-path"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert one.returncode == 0, one.stdout + one.stderr
+    ref = json.loads([ln for ln in one.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True,
+                          env=env, cwd=ROOT, timeout=900)
+    assert many.returncode == 0, many.stdout + many.stderr
+    got = json.loads([ln for ln in many.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert got["n_gpus"] == 2 and "native RCCL" in got["config"]["exchange"], got["config"]
+    assert abs(got["e0"] - ref["e0"]) <= 1e-10 * abs(ref["e0"])
+    pr = got["per_rank"]
+    assert len(pr) == 2 and all(set(("rank", "rows", "nnz", "ms_spmv", "ms_gather", "gather_hidden_frac", "roofline_frac")) <= set(p) for p in pr), pr
+    assert all(p["ms_spmv"] > 0 and p["rows"] > 0 for p in pr) and sum(p["rows"] for p in pr) == got["config"]["dim"], pr

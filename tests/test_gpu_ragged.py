@@ -30,15 +30,14 @@ CASES = {
 
 @pytest.mark.parametrize("cross_in_near", [1, 0])
 @pytest.mark.parametrize("name,h", [("chain16", 8), ("chain16", 10), ("kagome12", 6), ("triangular16", 8), ("chain18_n7", 9), ("kagome18", 9), ("kagome18", 11)])
-def test_cut_sector_equals_the_unsplit_operator(name, h, cross_in_near, monkeypatch):
+def test_cut_sector_equals_the_unsplit_operator(name, h, cross_in_near):
     # the entries across the cut: inside the near part (default: two passes) or a third pass of their own
-    monkeypatch.setenv("QBH_CROSS_IN_NEAR", str(cross_in_near))
     n, k, bonds = CASES[name]
     P = q.csr_mat.heisenberg(n, k, bonds, J=1.0, opts=q.make_opts(kron_split=0, **PLAIN))
     ia, ja, val = P.download()
     dim = P.dim
     O = qo.Csr(dim, ia, ja.astype(np.int64), val, False)
-    K = q.csr_mat.heisenberg(n, k, bonds, J=1.0, opts=q.make_opts(kron_split=2, basis_kind=_lib.BASIS_SPIN_SECTOR, n_sites=n, n_up=h, n_dn=k, **PLAIN))
+    K = q.csr_mat.heisenberg(n, k, bonds, J=1.0, opts=q.make_opts(kron_split=2, basis_kind=_lib.BASIS_SPIN_SECTOR, n_sites=n, n_up=h, n_dn=k, kron_cross_in_near=cross_in_near, **PLAIN))
     info = K.info()
     assert info.basis_internal == _lib.BASIS_SPIN_SECTOR and info.nnz == ia[-1]
     crossing = np.mean([(a < h) != (b < h) for a, b in bonds])          # share of the bonds across the cut
@@ -91,18 +90,17 @@ def test_a_useless_cut_leaves_the_operator_unsplit_but_correct():
 
 
 @pytest.mark.parametrize("cross_in_near", [1, 0])
-def test_cut_sector_under_a_communicator_is_merged_back_and_stays_right(cross_in_near, monkeypatch):
+def test_cut_sector_under_a_communicator_is_merged_back_and_stays_right(cross_in_near):
     """Only the one-class split has an exchange format of its own: a cut sector that gets a communicator (here the native
     one-rank RCCL communicator) is merged back into a CSR -- near, far and cross parts, row by row (kron_restore) -- and keeps
     its internal order and its vector translation."""
     from quantum_basis_amd import dist as qdist
-    monkeypatch.setenv("QBH_CROSS_IN_NEAR", str(cross_in_near))
     n, k, bonds = CASES["kagome18"]
     P = q.csr_mat.heisenberg(n, k, bonds, J=1.0, opts=q.make_opts(kron_split=0, **PLAIN))
     ia, ja, val = P.download()
     dim = P.dim
     O = qo.Csr(dim, ia, ja.astype(np.int64), val, False)
-    K = q.csr_mat.heisenberg(n, k, bonds, J=1.0, opts=q.make_opts(kron_split=2, basis_kind=_lib.BASIS_SPIN_SECTOR, n_sites=n, n_up=9, n_dn=k, **PLAIN))
+    K = q.csr_mat.heisenberg(n, k, bonds, J=1.0, opts=q.make_opts(kron_split=2, basis_kind=_lib.BASIS_SPIN_SECTOR, n_sites=n, n_up=9, n_dn=k, kron_cross_in_near=cross_in_near, **PLAIN))
     assert K.info().kron_classes > 1
     x = _rand(dim, 5)
     want = O.multmv(x)
