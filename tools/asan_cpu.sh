@@ -7,8 +7,8 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $R/tools/asan_build
 cd $R/quantum_basis_amd/csrc
 /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -fsanitize=address -fno-omit-frame-pointer -I../../include -I. \
-    -shared -o $R/tools/asan_build/libqbhip_asan.so -x hip qbh_kernels.hip qbh_gen.hip qbh_build.hip qbh_mopr.hip qbh_api.cpp \
-    qbh_comm.cpp qbh_ckpt.cpp qbh_hess.cpp -ldl
+    -shared -o $R/tools/asan_build/libqbhip_asan.so -x hip qbh_kernels.hip qbh_kron.hip qbh_kronc.hip qbh_gen.hip qbh_build.hip qbh_mopr.hip qbh_reorder.hip \
+    qbh_api.cpp qbh_split.cpp qbh_commattach.cpp qbh_spmv.cpp qbh_solvers.cpp qbh_comm.cpp qbh_ckpt.cpp qbh_hess.cpp -ldl
 cd $R
 ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 \
 LD_PRELOAD=$(find /opt/rocm/lib/llvm -name "libclang_rt.asan-x86_64.so" | head -1) \
