@@ -843,7 +843,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
     const int sub = lane % TPR, rloc = lane / TPR;
     double acc[3] = {0.0, 0.0, 0.0};
     const bool need_y = a.beta != 0.0;
-    const KronTile kt{a.kS, a.kNU, a.kB};
 
     BlockWalk walk((a.n_wb + 3) >> 2, a.swizzle, a.chunk_mult);
     constexpr bool dyn = DYN;
@@ -868,16 +867,22 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
         int64_t xb;              // C16: element of the gather source that column value 0 of this block names
     };
     // far result of one row (OPS 2 / 4)
+    // (rows and minor sizes are below 2^31 -- int32 columns -- so the index arithmetic of a row's far slot is 32-bit: a 64-bit
+    // division by a run-time divisor is ~100 instructions on the critical path of every block's epilogue operands)
+    const uint32_t kS32 = (uint32_t)a.kS, kB32 = (uint32_t)a.kB;
+    const int kLB = 31 - __builtin_clz(kB32 | 1u);                   // band widths are powers of two
     auto far_at = [&](int64_t row, int c0) -> d2 {
         if constexpr (MULTI) {
             int c = c0;
             while (row >= a.kcls[c + 1].rbase) ++c;                 // a block rarely straddles two classes
             const KronCls k = a.kcls[c];
-            const int64_t local = row - k.rbase, u = local / k.S, d = local - u * k.S;
-            if (d >= ((k.S >> 3) << 3)) return d2{0.0, 0.0};         // a row of the class's narrow last band: no far part
-            return a.far[k.fbase + (d >> 3) * 8 * k.NU + u * 8 + (d & 7)];
+            const uint32_t local = (uint32_t)(row - k.rbase), S32 = (uint32_t)k.S, u = local / S32, d = local - u * S32;
+            if (d >= ((S32 >> 3) << 3)) return d2{0.0, 0.0};         // a row of the class's narrow last band: no far part
+            return a.far[k.fbase + (int64_t)(d >> 3) * 8 * k.NU + (int64_t)u * 8 + (d & 7)];
         } else {
-            return a.far[kt.tile(row)];
+            const uint32_t r = (uint32_t)row, u = r / kS32, d = r - u * kS32;
+            const uint32_t b = d >> kLB, j = d & (kB32 - 1u), rem = kS32 - (b << kLB), wB = rem < kB32 ? rem : kB32;
+            return a.far[(int64_t)b * (a.kNU << kLB) + (int64_t)u * wB + j];
         }
     };
     // OPS 3: a block is 512 consecutive SLOTS of the sliced stream whatever the groups are (descriptor: first slot, first

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Time the bare SpMV launch (y = alpha*H*x + beta*y + gamma*x, the Lanczos form) of one benchmark operator under several
-environment settings (measurement tool: kernel experiments read their switches from the environment when the operator
-is created).  Usage: python tools/spmv_time.py hubbard_4x4_half "QBH_DMA=1024" "QBH_DMA=1024 QBH_GRID=512" ...
+configurations.  A configuration is a string of key=value tokens: a lower-case key is a field of qbh_opts (kron_cols16=0,
+deterministic=1, wave_walk=2 ...; site_cut=18 names the QBH_BASIS_SPIN_SECTOR cut of a Heisenberg workload), an upper-case key
+an environment variable (QBH_DEBUG=grid=512,no_far_align=1: the library re-reads the debug list when its text changes).
+Usage: python tools/spmv_time.py hubbard_4x4_half "" "kron_cols16=0" "QBH_DEBUG=no_far_align=1" ...
 An empty string is the default configuration.  Prints ms per launch from the library's own HIP events."""
 import os
 import sys
@@ -20,11 +22,17 @@ def main():
     results = {}
     for cfg in cfgs * rounds:
         saved = {}
+        kw = {}
         for kv in cfg.split():
             k, v = kv.split("=", 1)
-            saved[k] = os.environ.get(k)
-            os.environ[k] = v
-        opts = q.make_opts(profile=1, value_dict=0 if fmt == "complex128" else 1, real_fast_path=0 if fmt == "complex128" else 1)
+            if k.isupper():
+                saved[k] = os.environ.get(k)
+                os.environ[k] = v
+            elif k == "site_cut":
+                kw.update(basis_kind=q._lib.BASIS_SPIN_SECTOR, n_sites=W["n_sites"], n_up=int(v), n_dn=W["n_dn"])
+            else:
+                kw[k] = int(v)
+        opts = q.make_opts(profile=1, value_dict=0 if fmt == "complex128" else 1, real_fast_path=0 if fmt == "complex128" else 1, **kw)
         A = bench.build_operator(W, (0, bench.dim_of(W)), opts)
         v = A.vec(2)
         A.randomize(v.at(0), 1)
