@@ -799,6 +799,7 @@ def main():
     tkey = "%s|%s|%s" % (args.workload, KERNEL_KEY[info.kernel], "dict" if coded else "plain") + ("|real" if real_used else "")
     if info.kron_minor:
         tkey += ("|kron_sliced" if info.kron_sliced else "|kron") + ("|inplace" if info.kron_inplace else "") + ("|cut%d" % args.site_cut if info.kron_classes > 1 else "")
+        tkey += "|c16" if info.kron_cols16 == 3 else ""           # 2-byte columns in both parts: another stream, another traffic entry
     tkey += "|reforder" if args.order == "reference" else ""
     traffic, tsrc = traffic_of(tkey) if world == 1 and not args.host_csr else (None, None)
     if coded or real_used:

@@ -363,6 +363,22 @@ int qbh_mopr_spin_dev(int n_sites, int n_dn_old, int kind, const qbh_z *coef /* 
                       qbh_z *d_vec_new, void *stream);
 int qbh_mopr_onebody_dev(int n_sites, int n_up, int n_dn, int n_terms, const int32_t *a, const int32_t *b, const int32_t *spin,
                          const qbh_z *w, const qbh_z *d_vec_old, qbh_z *d_vec_new, void *stream);
+/* The GENERAL form of moprXvec_full (src/model.cc:1468-1538): any mopr of the two families, written as a sum of ordered products
+ * of elementary site operators,  A = sum_t coef[t] * O_{t,0} O_{t,1} ... O_{t,len_t-1}  (O_{t,0} the LEFTMOST factor; factors of
+ * term t are entries term_ptr[t] .. term_ptr[t+1]-1 of op_kind / op_site / op_species; term_ptr[0] = 0).
+ *   family 0, spin-1/2 sector with n_a_old down spins (basis of qbh_gen_heisenberg; n_b_old and op_species unused, may be 0 / NULL):
+ *       op_kind 0 = S^z_s, 1 = S^+_s (down -> up), 2 = S^-_s (up -> down)
+ *   family 1, two-species fermions with n_a_old up and n_b_old down particles (basis of qbh_gen_hubbard), species 0 = up, 1 = down:
+ *       op_kind 0 = n_{s,sp}, 1 = c^dag_{s,sp}, 2 = c_{s,sp}; basis states are prod_{o ascending} c^dag_o |0> over the orbitals
+ *       o = s + species * n_sites (all up operators left of all down operators), c^dag_o |w> = (-1)^{occupied orbitals below o} |w + o>
+ * Any local 2 x 2 matrix of the reference's opr<T> is a combination of {1, S^z, S^+, S^-} resp. {1, n, c^dag, c}, so every
+ * opr_prod / mopr over these site types is such a list.  Every product must change the particle numbers by the same amount (one
+ * target sector: sec_new of the reference); *dim_new_out (may be NULL) = its dimension, d_vec_new must hold that many elements.
+ * Every target row gathers its contributions (the adjoint factors run over the row's own pattern): no atomics, deterministic.
+ * <= 4096 factors in all. */
+int qbh_mopr_terms_dev(int family, int n_sites, int n_a_old, int n_b_old, int n_terms, const int32_t *term_ptr, const int32_t *op_kind,
+                       const int32_t *op_site, const int32_t *op_species, const qbh_z *coef, const qbh_z *d_vec_old, qbh_z *d_vec_new,
+                       int64_t *dim_new_out, void *stream);
 /* Counterpart of model<T>::moprXvec_repr (src/model.cc:1715-1846) for S^z_q = sum_s coef[s] S^z_s between two momentum
  * sectors of the same n_dn (basis of qbh_gen_heisenberg_repr: all representatives, ascending; perms as there).  coef must
  * transform like a character, coef[g(s)] = eta(g) coef[s] (e.g. exp(i q.r_s)/sqrt(N)), and chars_new are the characters

@@ -7,5 +7,5 @@ the host-side mirror of the reference's operator/solver interface plus the ctype
 from . import _lib  # noqa: F401
 from .engine import (csr_mat, DeviceVec, lanczos, lanczos_real, eigenvec_CG, eigenvec_CG_real, hess_eigen, iram, iram_arpack, vec_randomize,  # noqa: F401
                      locate_E0_lanczos, locate_E0_iram, measure_full_dynamic, write_lanczos_log, make_opts, lanczos_precision, sparse_precision,
-                     balanced_row_cuts, moprXvec_spin, moprXvec_onebody, moprXvec_sz_repr, moprXvec_flip_repr, moprXvec_diag_hubrepr, moprXvec_c_hubrepr, measure_full_dynamic_dev,
+                     balanced_row_cuts, moprXvec_spin, moprXvec_onebody, moprXvec_terms, moprXvec_sz_repr, moprXvec_flip_repr, moprXvec_diag_hubrepr, moprXvec_c_hubrepr, measure_full_dynamic_dev,
                      measure_full_static_spin_dev, measure_repr_static_hubbard, energy_scale)

@@ -99,7 +99,7 @@ EXPORTS = [
     "qbh_vec_randomize",
     "qbh_spmv_dev", "qbh_dotc_dev", "qbh_axpy_norm_dev", "qbh_scal_dev", "qbh_nrm2_dev",
     "qbh_lanczos", "qbh_lanczos_dev", "qbh_lanczos_real_dev", "qbh_vec_randomize_real", "qbh_eigenvec_cg_real_dev", "qbh_eigenvec_cg", "qbh_eigenvec_cg_dev", "qbh_hess_eigen", "qbh_iram",
-    "qbh_mopr_spin_dev", "qbh_mopr_onebody_dev", "qbh_mopr_sz_repr_dev", "qbh_mopr_flip_repr_dev",
+    "qbh_mopr_spin_dev", "qbh_mopr_onebody_dev", "qbh_mopr_terms_dev", "qbh_mopr_sz_repr_dev", "qbh_mopr_flip_repr_dev",
     "qbh_crc32", "qbh_vec_disk_write", "qbh_vec_disk_read", "qbh_ckpt_lanczos_update", "qbh_ckpt_lanczos_init", "qbh_lanczos_ckpt",
     "qbh_csr_set_comm", "qbh_rccl_unique_id", "qbh_comm_create_rccl", "qbh_comm_destroy", "qbh_get_stats", "qbh_sync",
     "qbh_gen_hubbard", "qbh_mf_hubbard", "qbh_gen_heisenberg", "qbh_mf_heisenberg", "qbh_gen_heisenberg_repr", "qbh_gen_hubbard_repr", "qbh_gen_heisenberg_repr_cuts", "qbh_gen_hubbard_repr_cuts", "qbh_mf_hubbard_repr", "qbh_mopr_diag_hubrepr_dev", "qbh_mopr_c_hubrepr_dev", "qbh_csr_download", "qbh_csr_reference_order", "qbh_csr_set_basis",
@@ -172,6 +172,7 @@ def lib():
     L.qbh_mopr_sz_repr_dev.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.POINTER(i64)]
     L.qbh_mopr_flip_repr_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(i64)]
     L.qbh_mopr_onebody_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    L.qbh_mopr_terms_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i64), vp]
     L.qbh_crc32.argtypes = [C.c_uint32, vp, i64]
     L.qbh_crc32.restype = C.c_uint32
     L.qbh_vec_disk_write.argtypes = [C.c_char_p, i64, C.c_int, vp]

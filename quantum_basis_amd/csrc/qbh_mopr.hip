@@ -141,6 +141,19 @@ __device__ __forceinline__ uint64_t rank_of(const uint64_t *B, uint32_t c)
     return r;
 }
 
+__device__ __forceinline__ uint64_t rank_of64(const uint64_t *B, uint64_t c)
+{
+    uint64_t r = 0;
+    int t = 0;
+    while (c) {
+        const int p = __ffsll((long long)c) - 1;
+        ++t;
+        r += bin(B, p, t);
+        c &= c - 1;
+    }
+    return r;
+}
+
 __global__ __launch_bounds__(256) void k_mopr_onebody(int64_t Nu, int64_t Nd, const uint32_t *cfg_u, const uint32_t *cfg_d, int n_terms,
                                                       const OneBodyTerm *terms, const Binom *Bd, const d2 *x_old, d2 *y_new)
 {
@@ -172,6 +185,80 @@ __global__ __launch_bounds__(256) void k_mopr_onebody(int64_t Nu, int64_t Nd, co
             const d2 x = x_old[j];
             acc.x += sign * (t.wr * x.x - t.wi * x.y);
             acc.y += sign * (t.wr * x.y + t.wi * x.x);
+        }
+        y_new[row] = acc;
+    }
+}
+
+// ---- the general form: A = sum_t coef_t O_{t,0} O_{t,1} ... (ordered products of elementary site operators) ----
+// Every product maps a basis state to at most one basis state, so the TARGET row finds its source by running the adjoint
+// factors over its own pattern, leftmost factor first: (O_0 O_1 ... O_{L-1})^+ |i> = O_{L-1}^+ ... O_1^+ O_0^+ |i> = amp |j>, and
+// <i| O_0 ... O_{L-1} |j> = amp (all elementary matrix elements are real).  No atomics, deterministic.
+// family 0, spin-1/2 (bit = 1: down):  kind 0 S^z, 1 S^+ (down -> up), 2 S^- (up -> down)
+// family 1, two-species fermions, orbital o = site + species * n_sites in the word u | d << n_sites, |w> = prod_{o ascending}
+//           c+_o |0> (all up operators left of all down operators, as qbh_gen_hubbard / qbh_mopr_c_hubrepr_dev):
+//           kind 0 n_o, 1 c+_o, 2 c_o; c+_o |w> = (-1)^{occupied orbitals below o} |w + o>
+struct TermOp { int8_t kind; int8_t orb; };
+constexpr int kMaxTermOps = 4096;
+
+template <int FAMILY>
+__global__ __launch_bounds__(256) void k_mopr_terms(int n_sites, int na_new, int nb_new, int na_old, int nb_old, int64_t nd_new, int64_t nd_old,
+                                                    const uint32_t *cfg_u, const uint32_t *cfg_d, int n_terms, const int32_t *term_ptr,
+                                                    const TermOp *ops, const d2 *coef, const Binom *Bd, const d2 *x_old, d2 *y_new, int64_t dim_new)
+{
+    __shared__ uint64_t B[(kMaxSites + 1) * (kMaxPart + 1)];
+    for (int i = threadIdx.x; i < (kMaxSites + 1) * (kMaxPart + 1); i += 256) B[i] = Bd->c[i];
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < dim_new; row += stride) {
+        uint64_t w0;
+        if (FAMILY == 0) {
+            w0 = unrank(B, n_sites, na_new, (uint64_t)row);
+        } else {
+            const int64_t u = row / nd_new, d = row - u * nd_new;
+            w0 = (uint64_t)cfg_u[u] | ((uint64_t)cfg_d[d] << n_sites);
+        }
+        d2 acc = {0.0, 0.0};
+        for (int t = 0; t < n_terms; ++t) {
+            uint64_t w = w0;
+            double amp = 1.0;
+            for (int k = term_ptr[t]; k < term_ptr[t + 1] && amp != 0.0; ++k) {
+                const TermOp op = ops[k];
+                const uint64_t bit = 1ULL << op.orb;
+                const bool set = (w & bit) != 0;
+                if (FAMILY == 0) {
+                    if (op.kind == 0) amp *= set ? -0.5 : 0.5;
+                    else if (op.kind == 1) {                 // (S^+)^+ = S^-: the target has the spin UP here, the source had it down
+                        if (set) amp = 0.0;
+                        else w |= bit;
+                    } else {                                 // (S^-)^+ = S^+
+                        if (!set) amp = 0.0;
+                        else w &= ~bit;
+                    }
+                } else {
+                    if (op.kind == 0) {
+                        if (!set) amp = 0.0;
+                    } else {
+                        const bool want_set = op.kind == 1;  // (c+_o)^+ = c_o needs the orbital occupied in the target
+                        if (set != want_set) amp = 0.0;
+                        else {
+                            if (__popcll(w & (bit - 1ULL)) & 1) amp = -amp;
+                            w ^= bit;
+                        }
+                    }
+                }
+            }
+            if (amp == 0.0) continue;
+            int64_t j;
+            if (FAMILY == 0) {
+                j = (int64_t)rank_of64(B, w);
+            } else {
+                const uint32_t uj = (uint32_t)(w & ((1ULL << n_sites) - 1ULL)), dj = (uint32_t)(w >> n_sites);
+                j = (int64_t)rank_of(B, uj) * nd_old + (int64_t)rank_of(B, dj);
+            }
+            const d2 x = x_old[j], c = coef[t];
+            acc.x += amp * (c.x * x.x - c.y * x.y);
+            acc.y += amp * (c.x * x.y + c.y * x.x);
         }
         y_new[row] = acc;
     }
@@ -301,6 +388,115 @@ extern "C" int qbh_mopr_onebody_dev(int n_sites, int n_up, int n_dn, int n_terms
     if (rc != QBH_OK) return rc;
     if (e != hipSuccess) {
         set_error("qbh_mopr_onebody_dev: %s", hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP;
+    }
+    return QBH_OK;
+}
+
+
+extern "C" int qbh_mopr_terms_dev(int family, int n_sites, int n_a_old, int n_b_old, int n_terms, const int32_t *term_ptr, const int32_t *op_kind,
+                                  const int32_t *op_site, const int32_t *op_species, const qbh_z *coef, const qbh_z *d_vec_old, qbh_z *d_vec_new,
+                                  int64_t *dim_new_out, void *stream)
+{
+    using namespace qbh;
+    if ((family != 0 && family != 1) || !term_ptr || !op_kind || !op_site || !coef || !d_vec_old || !d_vec_new || n_terms <= 0 || n_sites <= 0 ||
+        n_sites > (family == 0 ? kMaxSites : 31) || n_a_old < 0 || n_a_old > n_sites || n_b_old < 0 || n_b_old > n_sites || term_ptr[0] != 0 ||
+        (family == 1 && !op_species)) {
+        set_error("qbh_mopr_terms_dev: invalid argument");
+        return QBH_EINVAL;
+    }
+    const int n_ops = term_ptr[n_terms];
+    if (n_ops <= 0 || n_ops > kMaxTermOps) {
+        set_error("qbh_mopr_terms_dev: %d elementary factors (1 .. %d allowed)", n_ops, kMaxTermOps);
+        return QBH_EINVAL;
+    }
+    // every product must change the particle numbers by the same amount: vec_new lives in ONE sector (src/model.cc:1468-1471)
+    std::vector<TermOp> ops((size_t)n_ops);
+    int da = 0, db = 0;
+    for (int t = 0; t < n_terms; ++t) {
+        if (term_ptr[t + 1] < term_ptr[t]) {
+            set_error("qbh_mopr_terms_dev: term_ptr is not ascending");
+            return QBH_EINVAL;
+        }
+        int ta = 0, tb = 0;
+        for (int k = term_ptr[t]; k < term_ptr[t + 1]; ++k) {
+            const int sp = family == 1 ? op_species[k] : 0;
+            if (op_kind[k] < 0 || op_kind[k] > 2 || op_site[k] < 0 || op_site[k] >= n_sites || sp < 0 || sp > 1) {
+                set_error("qbh_mopr_terms_dev: factor %d of term %d out of range", k - term_ptr[t], t);
+                return QBH_EINVAL;
+            }
+            ops[(size_t)k] = TermOp{(int8_t)op_kind[k], (int8_t)(op_site[k] + sp * n_sites)};
+            // family 0: S^+ removes a down spin, S^- adds one; family 1: c+ adds a particle of its species, c removes one
+            const int delta = op_kind[k] == 0 ? 0 : family == 0 ? (op_kind[k] == 1 ? -1 : 1) : (op_kind[k] == 1 ? 1 : -1);
+            (sp ? tb : ta) += delta;
+        }
+        if (t == 0) da = ta, db = tb;
+        else if (ta != da || tb != db) {
+            set_error("qbh_mopr_terms_dev: term %d changes the particle numbers by (%d, %d), term 0 by (%d, %d): one target sector only", t, ta, tb,
+                      da, db);
+            return QBH_EINVAL;
+        }
+    }
+    const int na_new = n_a_old + da, nb_new = family == 1 ? n_b_old + db : 0;
+    if (na_new < 0 || na_new > n_sites || nb_new < 0 || nb_new > n_sites || na_new > kMaxPart - 1 || n_a_old > kMaxPart - 1 ||
+        (family == 1 && (nb_new > kMaxPart - 1 || n_b_old > kMaxPart - 1))) {
+        set_error("qbh_mopr_terms_dev: the target sector (%d, %d) does not exist", na_new, nb_new);
+        return QBH_EINVAL;
+    }
+    if (qbh_device_count() <= 0) {
+        set_error("no HIP device visible");
+        return QBH_ENODEVICE;
+    }
+    std::vector<uint32_t> cu, cd;
+    int64_t dim_new = 0, nd_new = 1, nd_old = 1;
+    if (family == 1) {
+        enumerate(n_sites, na_new, cu);
+        enumerate(n_sites, nb_new, cd);
+        nd_new = (int64_t)cd.size();
+        nd_old = (int64_t)binom_host(n_sites, n_b_old);
+        dim_new = (int64_t)cu.size() * nd_new;
+    } else {
+        dim_new = (int64_t)binom_host(n_sites, na_new);
+    }
+    if (dim_new_out) *dim_new_out = dim_new;
+    uint32_t *d_cu = nullptr, *d_cd = nullptr;
+    int32_t *d_ptr = nullptr;
+    TermOp *d_ops = nullptr;
+    d2 *d_coef = nullptr;
+    Binom *d_b = nullptr;
+    int rc = upload_binom(&d_b);
+    hipError_t e = hipSuccess;
+    if (rc == QBH_OK) {
+        if (family == 1) {
+            e = qbh::dev_alloc(&d_cu, cu.size() * 4);
+            if (e == hipSuccess) e = qbh::dev_alloc(&d_cd, cd.size() * 4);
+            if (e == hipSuccess) e = hipMemcpy(d_cu, cu.data(), cu.size() * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(d_cd, cd.data(), cd.size() * 4, hipMemcpyHostToDevice);
+        }
+        if (e == hipSuccess) e = qbh::dev_alloc(&d_ptr, (size_t)(n_terms + 1) * 4);
+        if (e == hipSuccess) e = qbh::dev_alloc(&d_ops, ops.size() * sizeof(TermOp));
+        if (e == hipSuccess) e = qbh::dev_alloc(&d_coef, (size_t)n_terms * sizeof(d2));
+        if (e == hipSuccess) e = hipMemcpy(d_ptr, term_ptr, (size_t)(n_terms + 1) * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_ops, ops.data(), ops.size() * sizeof(TermOp), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_coef, coef, (size_t)n_terms * sizeof(d2), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipStream_t s = (hipStream_t)stream;
+            const dim3 g(blas_grid(dim_new)), b(256);
+            if (family == 0)
+                hipLaunchKernelGGL((k_mopr_terms<0>), g, b, 0, s, n_sites, na_new, 0, n_a_old, 0, (int64_t)1, (int64_t)1, d_cu, d_cd, n_terms, d_ptr, d_ops,
+                                   d_coef, d_b, reinterpret_cast<const d2 *>(d_vec_old), reinterpret_cast<d2 *>(d_vec_new), dim_new);
+            else
+                hipLaunchKernelGGL((k_mopr_terms<1>), g, b, 0, s, n_sites, na_new, nb_new, n_a_old, n_b_old, nd_new, nd_old, d_cu, d_cd, n_terms, d_ptr,
+                                   d_ops, d_coef, d_b, reinterpret_cast<const d2 *>(d_vec_old), reinterpret_cast<d2 *>(d_vec_new), dim_new);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+        }
+    }
+    for (void *p : {(void *)d_cu, (void *)d_cd, (void *)d_ptr, (void *)d_ops, (void *)d_coef, (void *)d_b})
+        if (p) (void)hipFree(p);
+    if (rc != QBH_OK) return rc;
+    if (e != hipSuccess) {
+        set_error("qbh_mopr_terms_dev: %s", hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? QBH_ENOMEM : QBH_EHIP;
     }
     return QBH_OK;

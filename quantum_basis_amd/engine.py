@@ -653,6 +653,35 @@ def moprXvec_onebody(n_sites, n_up, n_dn, terms, d_vec_old, d_vec_new, stream=No
           "qbh_mopr_onebody_dev")
 
 
+SPIN_OPS = {"Sz": 0, "S+": 1, "S-": 2}
+FERMION_OPS = {"n": 0, "c+": 1, "c": 2}
+
+
+def moprXvec_terms(family, n_sites, n_a_old, n_b_old, terms, d_vec_old, d_vec_new, stream=None):
+    """The general moprXvec_full (src/model.cc:1468-1538; qbh_mopr_terms_dev): A = sum_t coef_t * (ordered product of elementary
+    site operators), applied on the device in the generators' basis order.  terms: iterable of (coef, factors), the factors from
+    LEFT to right; family "spin": factors ("Sz" | "S+" | "S-", site) on a sector with n_a_old down spins; family "fermion":
+    factors ("n" | "c+" | "c", site, species) with species 0 = up, 1 = down on the (n_a_old, n_b_old) sector.  Returns the
+    dimension of the target sector (every product must change the particle numbers by the same amount)."""
+    fam = {"spin": 0, "fermion": 1}[family]
+    names = SPIN_OPS if fam == 0 else FERMION_OPS
+    terms = list(terms)
+    ptr, kind, site, spec, coef = [0], [], [], [], []
+    for c, factors in terms:
+        coef.append(complex(c))
+        for f in factors:
+            kind.append(names[f[0]])
+            site.append(int(f[1]))
+            spec.append(int(f[2]) if fam == 1 else 0)
+        ptr.append(len(kind))
+    ptr, kind, site, spec = (np.asarray(a, dtype=np.int32) for a in (ptr, kind, site, spec))
+    coef = np.asarray(coef, dtype=np.complex128)
+    dim_new = C.c_int64(0)
+    check(lib().qbh_mopr_terms_dev(fam, n_sites, n_a_old, n_b_old, len(terms), _p(ptr), _p(kind), _p(site), _p(spec), _p(coef), d_vec_old, d_vec_new,
+                                   C.byref(dim_new), stream), "qbh_mopr_terms_dev")
+    return dim_new.value
+
+
 def moprXvec_sz_repr(n_sites, n_dn, perms, chars_new, coef, d_vec_old, d_vec_new):
     """moprXvec_repr (src/model.cc:1715-1846) for S^z_q between momentum sectors of qbh_gen_heisenberg_repr; returns the
     number of representatives."""

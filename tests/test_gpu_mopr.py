@@ -322,3 +322,114 @@ def test_measure_full_static_reproduces_the_references_asserted_correlators():
         q.measure_full_static_spin_dev(A, L, n_dn, v.ptr, [(-1, at(1))])
     v.free()
     A.destroy()
+
+
+# ---- the general term list (qbh_mopr_terms_dev): any mopr as a sum of ordered products of elementary site operators ----
+def _dense_spin_ops(n):
+    """S^z_s, S^+_s, S^-_s on the 2^n product space; state index = bit pattern, bit s = 1: site s is DOWN"""
+    sz, sp = np.diag([0.5, -0.5]), np.array([[0.0, 1.0], [0.0, 0.0]])           # local index 0 = up, 1 = down; S^+ |down> = |up>
+    ops = {}
+    for s in range(n):
+        for name, m in (("Sz", sz), ("S+", sp), ("S-", sp.T)):
+            full = np.array([[1.0]])
+            for k in reversed(range(n)):                                          # site n-1 is the most significant bit
+                full = np.kron(full, m if k == s else np.eye(2))
+            ops[(name, s)] = full
+    return ops
+
+
+def _dense_fermion_ops(n_orb):
+    """c+_o, c_o, n_o by Jordan-Wigner on 2^n_orb states; |w> = prod_{o ascending} c+_o |0>, so c+_o |w> = (-1)^{occupied below o} |w + o>"""
+    dim = 1 << n_orb
+    ops = {}
+    for o in range(n_orb):
+        cd = np.zeros((dim, dim))
+        for w in range(dim):
+            if not (w >> o) & 1:
+                cd[w | (1 << o), w] = -1.0 if bin(w & ((1 << o) - 1)).count("1") & 1 else 1.0
+        ops[("c+", o)], ops[("c", o)], ops[("n", o)] = cd, cd.T.copy(), cd @ cd.T
+    return ops
+
+
+@pytest.mark.parametrize("delta", [0, 1, -1])
+def test_general_term_list_on_a_spin_sector_matches_dense_operators(delta):
+    n, nd = 9, 4
+    rng = np.random.default_rng(11 + delta)
+    ops = _dense_spin_ops(n)
+    tail = {0: [], 1: [("S-", 6)], -1: [("S+", 2)]}[delta]                          # S^- adds a down spin, S^+ removes one
+    terms = [(0.7 + 0.2j, [("S+", 2), ("S-", 5), ("Sz", 1)] + tail), (-1.3j, [("S-", 0), ("S+", 7)] + tail), (0.4, [("Sz", 3), ("Sz", 3)] + tail),
+             (1.1, tail + [("Sz", 8)]), (0.25 - 0.5j, [("S+", 4), ("S-", 4), ("S-", 1), ("S+", 0)] + tail)]
+    dense = sum(c * np.linalg.multi_dot([ops[f] for f in fs] + [np.eye(1 << n)]) for c, fs in terms)
+    old, new = _patterns(n, nd), _patterns(n, nd + delta)
+    x = (rng.normal(size=len(old)) + 1j * rng.normal(size=len(old))).astype(np.complex128)
+    want = (dense[np.ix_(new, old)] @ x)
+    A = q.csr_mat.heisenberg(n, nd, lattices.chain(n))
+    vx, vy = q.DeviceVec(A, len(old)), q.DeviceVec(A, len(new))
+    vx.upload(x)
+    dim_new = q.moprXvec_terms("spin", n, nd, 0, terms, vx.ptr, vy.ptr)
+    assert dim_new == len(new)
+    got = vy.download()
+    assert np.abs(got - want).max() <= 1e-13 * max(np.abs(want).max(), 1.0)
+    # the special-purpose entry point is one instance of the general one
+    if delta:
+        coef = np.exp(2j * np.pi * np.arange(n) / n)
+        q.moprXvec_spin(n, nd, -delta, coef, vx.ptr, vy.ptr)
+        a = vy.download()
+        q.moprXvec_terms("spin", n, nd, 0, [(coef[s], [("S-" if delta > 0 else "S+", s)]) for s in range(n)], vx.ptr, vy.ptr)
+        assert np.abs(vy.download() - a).max() <= 1e-13
+    vx.free(), vy.free()
+    A.destroy()
+
+
+@pytest.mark.parametrize("case", ["number_conserving", "spin_flip", "remove_up", "add_pair"])
+def test_general_term_list_on_two_species_fermions_matches_jordan_wigner(case):
+    """Fermion signs against an independent Jordan-Wigner construction on the 2^(2 n_sites) Fock space: the convention is the
+    generators' (all up operators left of all down operators, sites ascending inside a species)."""
+    n, nu, nd = 5, 2, 3
+    ops = _dense_fermion_ops(2 * n)
+    F = lambda name, s, sp: (name, s + sp * n)                                       # dense orbital index
+    if case == "number_conserving":
+        terms = [(0.8, [("c+", 1, 0), ("c", 3, 0)]), (-0.6j, [("c+", 4, 1), ("c", 0, 1)]), (1.5, [("n", 2, 0), ("n", 2, 1)]),
+                 (0.3 + 0.1j, [("c+", 0, 0), ("c+", 1, 1), ("c", 3, 1), ("c", 2, 0)]), (2.0, [("c", 1, 0), ("c+", 1, 0)])]
+        dnu, dnd = 0, 0
+    elif case == "spin_flip":                   # S^+_s = c+_{s,up} c_{s,down} and a hop that flips the spin: (n_up, n_dn) -> (n_up + 1, n_dn - 1)
+        terms = [(1.0, [("c+", s, 0), ("c", s, 1)]) for s in range(n)] + [(0.5j, [("c+", 0, 0), ("c", 4, 1), ("n", 2, 1)])]
+        dnu, dnd = 1, -1
+    elif case == "remove_up":                   # the photo-emission operator c_{q,up}
+        terms = [(np.exp(2j * np.pi * s / n), [("c", s, 0)]) for s in range(n)]
+        dnu, dnd = -1, 0
+    else:                                       # a pair creation c+_{s,up} c+_{s,down}
+        terms = [(1.0 + 0.5 * s, [("c+", s, 0), ("c+", s, 1)]) for s in range(n)]
+        dnu, dnd = 1, 1
+    dense = sum(c * np.linalg.multi_dot([ops[F(*f)] for f in fs] + [np.eye(1 << (2 * n))]) for c, fs in terms)
+    pu, pd_ = _patterns(n, nu), _patterns(n, nd)
+    pu2, pd2 = _patterns(n, nu + dnu), _patterns(n, nd + dnd)
+    old = np.array([int(u) | (int(d) << n) for u in pu for d in pd_])                # index = rank(up) * C(n, n_dn) + rank(down)
+    new = np.array([int(u) | (int(d) << n) for u in pu2 for d in pd2])
+    rng = np.random.default_rng(3)
+    x = (rng.normal(size=len(old)) + 1j * rng.normal(size=len(old))).astype(np.complex128)
+    want = dense[np.ix_(new, old)] @ x
+    A = q.csr_mat.hubbard(n, nu, nd, lattices.chain(n))
+    vx, vy = q.DeviceVec(A, len(old)), q.DeviceVec(A, len(new))
+    vx.upload(x)
+    assert q.moprXvec_terms("fermion", n, nu, nd, terms, vx.ptr, vy.ptr) == len(new)
+    assert np.abs(vy.download() - want).max() <= 1e-13 * max(np.abs(want).max(), 1.0)
+    if case == "number_conserving":             # ... and agrees with the one-body entry point on its own ground
+        one = [(1, 3, 0, 0.8), (4, 0, 1, -0.6j), (2, 2, 1, 0.25)]
+        q.moprXvec_onebody(n, nu, nd, one, vx.ptr, vy.ptr)
+        a = vy.download()
+        q.moprXvec_terms("fermion", n, nu, nd, [(w, [("c+", a_, sp), ("c", b_, sp)] if a_ != b_ else [("n", a_, sp)]) for a_, b_, sp, w in one], vx.ptr, vy.ptr)
+        assert np.abs(vy.download() - a).max() <= 1e-13
+    vx.free(), vy.free()
+    A.destroy()
+
+
+def test_general_term_list_refuses_terms_that_leave_different_sectors():
+    from quantum_basis_amd import _lib
+    A = q.csr_mat.hubbard(4, 2, 2, lattices.chain(4))
+    v = q.DeviceVec(A, 2 * A.dim)
+    with pytest.raises(_lib.QbhError) as e:
+        q.moprXvec_terms("fermion", 4, 2, 2, [(1.0, [("c", 0, 0)]), (1.0, [("c", 0, 1)])], v.at(0), v.at(A.dim))
+    assert e.value.code == -1
+    v.free()
+    A.destroy()

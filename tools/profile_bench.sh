@@ -4,13 +4,14 @@
 # traffic entry stamped with the hash of the kernel sources (tools/traffic_entry.py).
 # usage: tools/profile_bench.sh <tag> <traffic key> [bench args...]   -> gpurun_out/<tag>_*.{txt,json}
 set -u
-R=/root/repo
+R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; KEY=$2; shift; shift
 export TMPDIR=/tmp
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp
-ARGS="--steps 20 --warmup 3 --no-converge --no-cpu-baseline --no-fast-path --no-matrix-free $*"
+# --processes 1: under rocprofv3 a process must not start children (the profiler has initialised the GPU before main() runs)
+ARGS="--steps 20 --warmup 3 --no-converge --no-cpu-baseline --no-fast-path --no-matrix-free --no-locate --processes 1 $*"
 rm -rf /tmp/prof_$TAG; mkdir -p /tmp/prof_$TAG
 python3 $R/bench.py $ARGS 2>/dev/null | grep '"metric"' > $OUT/${TAG}_bench_line.json
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG/stats -o s -- python3 $R/bench.py $ARGS > /tmp/prof_$TAG/stats.log 2>&1

@@ -3,8 +3,10 @@
 major indices (dist.kron_row_cuts), split in place like the unsharded operator -- driven with the full-length x and no
 communicator.  What a rank of a P-GPU run executes per SpMV is the near pass on its own block + the far pass on the gathered
 tiled x (+ the light combine pass); here the far pass reads a tiled copy of the full x made on this GPU (k_kron_tile over the
-WHOLE vector, 5.3 GB at C3 -- a P-rank run tiles only its own block and receives the rest), so the tile launch is timed
-excluded with QBH_KRON_REUSE_TILE=1 (x does not change between the timed launches).  usage: QBH_KRON_REUSE_TILE=1 python tools/shard_time.py [workload] [P ...]"""
+WHOLE vector, 5.3 GB at C3 -- a P-rank run tiles only its own block and receives the rest).  Up to round 4 a product switch
+(QBH_KRON_REUSE_TILE) let this tool skip that copy; the switch is gone from the library (a caller's promise about x is not a
+product feature), so the timing INCLUDES the copy and the record carries its cost estimate beside it: dim * 32 B at the
+5.3 TB/s k_kron_tile8 was measured at (profiles/r4_lab/fold_per_kernel.txt: 1.0 ms at C3).  usage: python tools/shard_time.py [workload] [P ...]"""
 import json
 import os
 import sys
@@ -51,8 +53,10 @@ def main():
             ms = st.ms_spmv / max(1, st.n_spmv)
             b_alg = info.nnz * 20 + (info.nrows + 1) * 8 + dim * 16 + info.nrows * 16
             rec = {"workload": name, "P": P, "rank": rank, "rows": int(info.nrows), "nnz": int(info.nnz), "kron_minor": int(info.kron_minor),
-                   "ms_spmv": round(ms, 3), "tile_of_full_x_in_the_timing": not bool(os.environ.get("QBH_KRON_REUSE_TILE")),
-                   "algorithmic_bytes": int(b_alg), "frac": round(b_alg / (ms * 1e-3) / 8e12, 4)}
+                   "ms_spmv": round(ms, 3), "tile_of_full_x_in_the_timing": True, "tile_of_full_x_ms_estimate": round(dim * 32 / 5.3e9, 3),
+                   "ms_spmv_minus_tile_estimate": round(ms - dim * 32 / 5.3e9, 3),
+                   "algorithmic_bytes": int(b_alg), "frac": round(b_alg / (ms * 1e-3) / 8e12, 4),
+                   "frac_minus_tile_estimate": round(b_alg / ((ms - dim * 32 / 5.3e9) * 1e-3) / 8e12, 4)}
             print(json.dumps(rec), flush=True)
             out.append(rec)
             xv.free()
