@@ -143,8 +143,10 @@ typedef struct qbh_opts {
                                 near part (two passes); 0: a third pass of their own                                       */
     int     kron_coded;      /* [-1] split of the DEFAULT (coded, real) format: -1 follows kron_split; 0 never; 1 the two-part row
                                 kernel form (measured slower, kept for comparison); 2 the sliced form (qbh_kronc.hip)        */
-    int     kron_uniform;    /* [3] sliced coded split: bit 0 recognise a far part T (x) 1, bit 1 a near part 1 (x) T' + D and keep
-                                T / T' once; 0: every group stored                                                         */
+    int     kron_uniform;    /* [7] sliced coded split: bit 0 recognise a far part T (x) 1, bit 1 a near part 1 (x) T' + D and keep
+                                T / T' once; bit 2: when BOTH are recognised apply the operator with the row-staged table kernel
+                                (T, T' as hop tables, one diagonal code per row: no tiled copy, no far sums) instead of the two
+                                sliced passes (qbh_csr_info.kron_table_kernel); 0: every group stored                       */
     int     gather_parts;    /* [0] band ranges the gather of x travels in under a communicator with part hooks: 0 = 4 when
                                 there are peers, else 1; 1..8 force it.  EVERY rank must pass the same value                  */
     int     wave_walk;       /* [-1] walk of the wave kernels over their blocks: -1 = the ordered per-XCD work counters (static
@@ -238,6 +240,7 @@ typedef struct qbh_csr_info {
     int     basis_detected;                  /* 1: basis_internal was found by the library itself (qbh_opts.basis_detect)               */
     int     basis_n_sites, basis_n_up, basis_n_dn;   /* the basis named by the caller or found (0 when basis_internal == 0)          */
     double  basis_detect_ms;                 /* wall ms the search took (inside create_ms for host arrays), whatever it found          */
+    int     kron_table_kernel;               /* 1: the coded split was recognised as T (x) 1 + 1 (x) T' + D and the all-real SpMV runs the table kernel */
 } qbh_csr_info;
 int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info);
 

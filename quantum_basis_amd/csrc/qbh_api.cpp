@@ -172,7 +172,7 @@ void qbh::opts_builtin(qbh_opts *o)
     o->kron_band = 0;
     o->kron_cross_in_near = 1;
     o->kron_coded = -1;
-    o->kron_uniform = 3;
+    o->kron_uniform = 7;
     o->gather_parts = 0;
     o->wave_walk = -1;
     o->tile_fold = 1;
@@ -1023,6 +1023,7 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->basis_n_up = A->basis.kind ? A->basis.n_up : 0;
     info->basis_n_dn = A->basis.kind ? A->basis.n_dn : 0;
     info->basis_detect_ms = A->detect_ms;
+    info->kron_table_kernel = (A->kronc.active && A->kronc.table_route) ? 1 : 0;
     if (A->kronc.active) {                       // the coded form of the split (row kernel, packed-double vectors)
         info->kron_minor = A->kronc.t.S;
         info->kron_far_nnz = A->kronc.sl.active ? A->kronc.sl.slots_f : A->kronc.far_p.nnz;      // sliced: stored far entries (padding included)

@@ -43,6 +43,7 @@ int kron_build(qbh_csr *A);
 int kron_restore(qbh_csr *A);
 void kronc_release(qbh_csr *A);
 int kronc_build_sliced(qbh_csr *A, int64_t S, int64_t NU);
+int kronc_table_route(qbh_csr *A);
 int kronc_build(qbh_csr *A);
 // ---- qbh_commattach.cpp ----
 int kron_parts_wanted(const qbh_csr *A, const qbh_comm *comm);
@@ -104,7 +105,7 @@ inline d2 *tiled_target(const qbh_csr *A)
 // the coded split's tiled x (packed doubles): written by the all-real Lanczos step's axpy when the operator runs that form
 inline double *kronc_tiled_target(const qbh_csr *A)
 {
-    return (A->kronc.active && A->kronc.sl.active && !A->has_comm && !A->has_rem && A->opts.tile_fold) ? A->kronc.d_xt : nullptr;
+    return (A->kronc.active && A->kronc.sl.active && !A->kronc.table_route && !A->has_comm && !A->has_rem && A->opts.tile_fold) ? A->kronc.d_xt : nullptr;
 }
 
 struct FoldGuard {

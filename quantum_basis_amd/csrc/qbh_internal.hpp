@@ -492,6 +492,10 @@ struct MfArgs {
     double alpha, beta, gamma;
     double *partials;
     double *y_re;                // all-real operation: y stored as doubles (x_local = xr)
+    // the diagonal as one value code per row + the real parts of the value dictionary (an operator RECOGNISED as T (x) 1 + 1 (x) T' + D,
+    // qbh_split.cpp kronc_table_route) instead of U * double occupancy from the two configuration lists (t.cfg_u / t.cfg_d unused then)
+    const uint8_t *dcode = nullptr;
+    const double  *ddict = nullptr;
 };
 int launch_mf_hubbard(const MfArgs &a, int grid, hipStream_t s, int *nparts_out);
 
@@ -588,6 +592,10 @@ struct qbh_csr {
         CsrPart  near_p, far_p;
         double  *d_xt = nullptr;
         qbh::KroncSliced sl;            // the sliced form (both parts; near gathers from LDS): near_p / far_p are then empty
+        // both parts recognised (T (x) 1 + 1 (x) T' + D): T and T' once more as the hop tables of the row-staged table kernel
+        // (k_mf_hubbard_row), which then applies the operator instead of the two sliced passes (qbh_opts.kron_uniform bit 2)
+        bool     table_route = false;
+        qbh::MfHubbard tables;
         const void *xt_of = nullptr;    // the packed vector whose tiled copy d_xt holds (written by the pass that produced it); consumed by one SpMV
     } kronc;
     struct KronSplit {

@@ -2959,6 +2959,7 @@ __global__ __launch_bounds__(kMfRowBlock) void k_mf_hubbard_row(MfArgs a, int ch
 {
     extern __shared__ double xs[];                 // [Nd] or [wcap]
     __shared__ double amp_s[16];
+    __shared__ double dd_s[256];                   // a.dcode: the value dictionary's real parts (the diagonal is dd_s[dcode[row]])
     __shared__ long long up_off[kMfMaxUp + 8];
     __shared__ double up_amp[kMfMaxUp + 8];
     __shared__ int up_n;
@@ -2968,6 +2969,7 @@ __global__ __launch_bounds__(kMfRowBlock) void k_mf_hubbard_row(MfArgs a, int ch
     const int64_t Nd = t.Nd;
     double acc[3] = {0.0, 0.0, 0.0};
     if (tid < 16) amp_s[tid] = t.amp[tid];
+    if (a.dcode != nullptr && tid < 256) dd_s[tid] = a.ddict[tid];
     const int64_t u_first = a.row_begin / Nd, u_last = (a.row_begin + a.nrows - 1) / Nd;
     const bool need_y = a.beta != 0.0;
     const uint4 *pk = reinterpret_cast<const uint4 *>(t.pk_d);
@@ -3016,11 +3018,11 @@ __global__ __launch_bounds__(kMfRowBlock) void k_mf_hubbard_row(MfArgs a, int ch
         int64_t d_hi = (a.row_begin + a.nrows - u * Nd) < Nd ? (a.row_begin + a.nrows - u * Nd) : Nd;
         if (d_lo < c_lo) d_lo = c_lo;
         if (d_hi > c_hi) d_hi = c_hi;
-        const uint32_t cu = t.cfg_u[u];
+        const uint32_t cu = a.dcode != nullptr ? 0u : t.cfg_u[u];
         const int nu = up_n;
         for (int64_t d = d_lo + tid; d < d_hi; d += kMfRowBlock) {
             const double xd = xs[d - w_lo];
-            double sum = t.U * (double)__popc(cu & t.cfg_d[d]) * xd;
+            double sum = (a.dcode != nullptr ? dd_s[a.dcode[u * Nd + d]] : t.U * (double)__popc(cu & t.cfg_d[d])) * xd;
             // up-species hops first (global, longest latency): 8 coalesced row loads in flight
             for (int j0 = 0; j0 < nu; j0 += 8) {
                 double xv[8];

@@ -507,6 +507,24 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         // coded Kronecker split, all-real operation: tiled copy of the packed x, near launch (full epilogue), far launch
         // (tiled rows and columns, accumulates at orig(row), fused reductions of the finished y)
         qbh_csr::KronCoded &K = A->kronc;
+        if (K.sl.active && K.table_route) {
+            // T (x) 1 + 1 (x) T' + D recognised: the row-staged table kernel applies it from T, T' and one diagonal code per row --
+            // no tiled copy, no far sums: x read (+ its neighbour rows through the caches), old y read, y written
+            qbh::MfArgs m{};
+            m.t = K.tables;
+            m.row_begin = 0;
+            m.nrows = A->nrows;
+            m.xr = a.xr;
+            m.y_re = a.y_re;
+            m.alpha = a.alpha;
+            m.beta = a.beta;
+            m.gamma = a.gamma;
+            m.partials = red ? A->d_partials : nullptr;
+            m.dcode = K.sl.dcode;
+            m.ddict = K.sl.d_dictr;
+            K.xt_of = nullptr;
+            QBH_TRY(qbh::launch_mf_hubbard(m, 0, A->stream, &kronc_parts));
+        } else {
         if (K.xt_of != (const void *)a.xr) QBH_TRY(qbh::launch_kron_tile_re(a.xr, K.d_xt, A->nrows, K.t, A->stream));
         K.xt_of = nullptr;                           // an alias is good for one SpMV
         if (K.sl.active) {
@@ -543,6 +561,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         fp.kB = K.t.B;
         QBH_TRY(qbh::launch_spmv(fp, A->kernel, K.far_p.npb, K.far_p.tpr, K.far_p.grid, A->stream));
         kronc_parts = K.far_p.grid;
+        }
         }
     } else if (wave) {
         a.wd = A->d_wd;

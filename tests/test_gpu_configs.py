@@ -115,6 +115,23 @@ def test_c4_substitute_hubbard_4x5_n5_full_size():
     M.destroy()
 
 
+def test_c4_substitute_in_the_north_star_format_split_in_place():
+    """The same operator as complex128 CSR (157 GB: 7.83e9 x 20 B), split in place with 2-byte columns (S = C(20, 5) = 15504): the
+    form bench.py --workload hubbard_4x5_n5 times.  y = Hx against the matrix-free operator at full size, E0 against its Lanczos."""
+    bonds = lattices.square(4, 5)
+    A = q.csr_mat.hubbard(20, 5, 5, bonds, t=1.0, U=1.1, opts=q.make_opts(value_dict=0, real_fast_path=0))
+    info = A.info()
+    assert info.kron_minor == math.comb(20, 5) and info.kron_inplace == 1 and info.kron_sliced == 1 and info.kron_cols16 == 3
+    assert info.value_dict == 0 and info.bytes_matrix < info.nnz * 16.5 + 64 * info.nrows        # 16 B of values + 2 B of columns per nonzero
+    M = q.csr_mat.hubbard(20, 5, 5, bonds, t=1.0, U=1.1, matrix_free=True)
+    _same_y(A, M)
+    r = q.locate_E0_lanczos(A, nev=1, ncv=0, maxit=800)
+    e_mf, m_mf = _packed_lanczos_e0(M, 800)
+    assert abs(r.E0 - e_mf) <= 1e-12 * abs(e_mf) and abs(r.steps["E0"] - m_mf) <= 1
+    A.destroy()
+    M.destroy()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

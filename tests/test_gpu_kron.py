@@ -2,6 +2,8 @@
 band-major over the minor index and applied from a tiled copy of x.  Same values, same 20 B per nonzero, re-ordered IN PLACE
 (no CSR beside it: qbh_csr_download merges the parts back); every result must equal the unsplit operator's (and the oracle's)
 up to summation order."""
+import math
+
 import numpy as np
 import pytest
 
@@ -413,7 +415,7 @@ def test_headline_lattice_at_U4_reproduces_the_published_ground_state_energy():
     assert abs(e_k - e_mf) <= 1e-11 * abs(e_mf)
 
 
-@pytest.mark.parametrize("form", ["1", "2", "2g"])
+@pytest.mark.parametrize("form", ["1", "2", "2g", "2t"])
 @pytest.mark.parametrize("shape", [(4, 2, 4, 4), (4, 3, 6, 6), (4, 3, 5, 7), (4, 4, 2, 2), (4, 3, 6, 6, "tri"), (4, 4, 1, 7, "tri")])
 def test_coded_real_form_of_the_split(shape, form):
     """The library's default form of a real operator (dictionary-coded values, packed-double Lanczos vectors) through the split
@@ -429,11 +431,13 @@ def test_coded_real_form_of_the_split(shape, form):
     P = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_split=0))      # the default format (coded + real fast path), unsplit
     assert P.info().kron_minor == 0 and P.info().value_dict > 0
     # "2g": the general form of both parts (a Hubbard operator is T (x) 1 + 1 (x) T' + D and would be kept as T, T', D)
-    K = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_coded=int(form[0]), kron_uniform=0 if form == "2g" else 3))
+    # "2t" (the default): both parts recognised -> the row-staged table kernel applies T, T' and the diagonal codes (minor size >= 256)
+    K = q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_coded=int(form[0]), kron_uniform={"2g": 0, "2t": 7}.get(form, 3)))
+    assert K.info().kron_table_kernel == (1 if form == "2t" and math.comb(n, nd) >= 256 else 0)
     ik = K.info()
     assert ik.kron_minor > 0 and ik.kron_band in (2, 4, 8, 16) and 0 < ik.kron_far_nnz < ik.nnz and ik.value_dict > 0
     assert ik.kron_sliced == (0 if form == "1" else 1) and (form == "1" or ik.kron_band == 16)
-    if form == "2":                  # T alone: one short row per major index instead of one per row
+    if form in ("2", "2t"):          # T alone: one short row per major index instead of one per row
         assert ik.kron_far_nnz <= 40 * int(round(ik.nrows / ik.kron_minor))
     rk, rp = q.locate_E0_lanczos(K), q.locate_E0_lanczos(P)
     assert abs(rk.E0 - rp.E0) <= 1e-12 * abs(rp.E0) and abs(rk.steps["E0"] - rp.steps["E0"]) <= 1
