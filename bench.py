@@ -143,7 +143,13 @@ def coded_format_roofline(info, ms_spmv, code_w, coded, real_used, traffic, tsrc
     fmt_bytes = info.nnz * (4 + (code_w if coded else 16)) + (info.nrows + 1) * 8 + info.nrows * 2 * vec_b
     kronc = bool(info.kron_minor and info.kron_sliced and coded and real_used)      # the sliced coded split (qbh_kronc.hip)
     uniform = kronc and info.kron_far_nnz * 8 < info.nnz                             # T kept once: far entries stored << nnz
-    if uniform:
+    table = bool(getattr(info, "kron_table_kernel", 0)) and real_used
+    if table:
+        moved = info.nrows * (3 * vec_b + 1) + int(info.kron_far_nnz) * 3
+        definition = ("recognised form T (x) 1 + 1 (x) T' + D applied by the row-staged table kernel: rows * (3 * %d + 1) [x, old y, new y, "
+                      "diagonal code] + the T / T' tables; the ~17 neighbour rows of every up-configuration are re-read through the L2 / "
+                      "Infinity Cache, not from HBM" % vec_b)
+    elif uniform:
         moved = info.nrows * (7 * vec_b + 1) + int(info.kron_far_nnz) * 3
         definition = ("recognised form T (x) 1 + 1 (x) T' + D: rows * (7 * %d + 1) [x, old y, new y, tiled x written + read, far sums "
                       "written + read, diagonal code] + stored T entries * 3" % vec_b)
@@ -153,7 +159,8 @@ def coded_format_roofline(info, ms_spmv, code_w, coded, real_used, traffic, tsrc
     else:
         moved = fmt_bytes
         definition = "this format's bytes: nnz*(4 + %d) + (rows+1)*8 + rows*%d" % (code_w if coded else 16, 2 * vec_b)
-    return {"bound": "hbm", "kernel": "k_kronc_far + k_kronc_near (tiled x written by the producer pass)" if kronc else kernel_name,
+    return {"bound": "hbm", "kernel": "k_mf_hubbard_row on T, T' and one diagonal code per row (kronc_table_route)" if table else
+            "k_kronc_far + k_kronc_near (tiled x written by the producer pass)" if kronc else kernel_name,
             "achieved": round(moved / ms_spmv / 1e6, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(moved / ms_spmv / 1e6 / HBM_PEAK_GBPS, 4), "traffic": traffic,
             "traffic_ratio": (round(traffic / moved, 3) if traffic else None), "traffic_source": tsrc,
@@ -162,7 +169,9 @@ def coded_format_roofline(info, ms_spmv, code_w, coded, real_used, traffic, tsrc
             "survey_8d_bytes_per_launch": int(survey_bytes), "survey_8d_equivalent_GBps": round(survey_bytes / ms_spmv / 1e6, 2),
             "note": "frac is on the bytes the running form must move; the *_equivalent_GBps figures divide bytes the kernel does NOT move "
                     "by its time -- speed-ups over a CSR sweep, not roofline fractions"
-                    + ("; the two passes are bound by L2 line requests and LDS gathers, not by HBM bandwidth (DESIGN 4.1g)" if kronc else "")}
+                    + ("; the table kernel is bound by the L2-served neighbour-row reads and the LDS gathers of the staged row, not by HBM "
+                       "bandwidth (DESIGN 4.6)" if table else
+                       "; the two passes are bound by L2 line requests and LDS gathers, not by HBM bandwidth (DESIGN 4.1g)" if kronc else "")}
 
 
 def dim_of(w):
@@ -800,6 +809,7 @@ def main():
     if info.kron_minor:
         tkey += ("|kron_sliced" if info.kron_sliced else "|kron") + ("|inplace" if info.kron_inplace else "") + ("|cut%d" % args.site_cut if info.kron_classes > 1 else "")
         tkey += "|c16" if info.kron_cols16 == 3 else ""           # 2-byte columns in both parts: another stream, another traffic entry
+        tkey += "|table" if info.kron_table_kernel else ""        # the table route moves other bytes than the sliced passes
     tkey += "|reforder" if args.order == "reference" else ""
     traffic, tsrc = traffic_of(tkey) if world == 1 and not args.host_csr else (None, None)
     if coded or real_used:
@@ -960,7 +970,8 @@ def main():
                 f_real = fp["n_real"] > 0
                 f_cw = 0 if not f_coded else (1 if fi.value_dict <= 256 else 2)
                 f_kronc = bool(fi.kron_minor > 0 and fi.kron_sliced and f_coded and f_real)      # the sliced coded split (qbh_kronc.hip)
-                fkey = "%s|%s|%s" % (args.workload, KERNEL_KEY[fi.kernel], "dict" if f_coded else "plain") + ("|real" if f_real else "") + ("|kron_sliced" if f_kronc else "")
+                fkey = "%s|%s|%s" % (args.workload, KERNEL_KEY[fi.kernel], "dict" if f_coded else "plain") + ("|real" if f_real else "") + ("|kron_sliced" if f_kronc else "") + \
+                       ("|table" if fi.kron_table_kernel else "")
                 ftr, fsrc = traffic_of(fkey)
                 froof = coded_format_roofline(fi, fp["ms_spmv"], f_cw, f_coded, f_real, ftr, fsrc, fp["n_spmv"],
                                               fi.nnz * 20 + (fi.nrows + 1) * 8 + fi.nrows * 32, KERNEL_NAME[fi.kernel])
@@ -973,7 +984,9 @@ def main():
                              else "complex128 vectors, %d-byte value codes" % f_cw,
                     "value_dict": fi.value_dict, "real_gather": f_real, "e0": fp["e0"],
                     "e0_rel_diff_vs_complex128": (abs(fp["e0"] - head["e0"]) / abs(head["e0"])) if (fp["e0"] is not None and head["e0"]) else None,
-                    "kron_split": ({"minor": int(fi.kron_minor), "band": int(fi.kron_band), "form": "both parts sliced in groups of 16 rows, near x block in LDS",
+                    "kron_split": ({"minor": int(fi.kron_minor), "band": int(fi.kron_band),
+                                    "form": "recognised as T (x) 1 + 1 (x) T' + D: applied by the row-staged table kernel (qbh_csr_info.kron_table_kernel)"
+                                    if fi.kron_table_kernel else "both parts sliced in groups of 16 rows, near x block in LDS",
                                     "stored_far_entries": int(fi.kron_far_nnz)} if f_kronc else None),
                     "roofline": froof,
                     "note": "lossless: values are dictionary-coded, and a real operator applied to real vectors gathers 8-byte real parts"}
