@@ -121,6 +121,31 @@ def test_two_byte_columns_are_the_same_operator_bit_for_bit(shape, deterministic
     K32.destroy()
 
 
+def test_two_byte_columns_are_taken_part_by_part_where_they_fit():
+    """18 sites, 1 up + 9 down electrons: S = C(18, 9) = 48620 -- a near column relative to the block's first row can reach
+    2 S > 65535, so the near part keeps int32 columns; the major count 18 fits easily, so the far part is converted
+    (qbh_csr_info.kron_cols16 == 2).  Mixed forms must apply and download like the all-int32 operator."""
+    n, nu, nd = 18, 1, 9
+    bonds = lattices.chain(n)
+    mk = lambda c16: q.csr_mat.hubbard(n, nu, nd, bonds, t=1.0, U=1.1, opts=q.make_opts(kron_split=2, deterministic=1, kron_cols16=c16, **PLAIN))
+    K16, K32 = mk(1), mk(0)
+    assert K16.info().kron_minor == math.comb(18, 9) and K16.info().kron_sliced == 1
+    assert K16.info().kron_cols16 == 2 and K32.info().kron_cols16 == 0
+    for u, v in zip(K16.download(), K32.download()):
+        assert np.array_equal(u, v)
+    x = _rand(K16.dim, 21)
+    out = []
+    for A in (K16, K32):
+        v = A.vec(2)
+        v.upload(x, 0)
+        red = A.spmv(v.at(0), v.at(A.dim), 1.0, 0.0, 0.0, want_red=True)
+        out.append((v.download(A.dim, A.dim), red))
+        v.free()
+    assert np.array_equal(out[0][0].view(np.float64), out[1][0].view(np.float64)) and out[0][1] == out[1][1]
+    K16.destroy()
+    K32.destroy()
+
+
 def test_two_byte_columns_survive_a_one_rank_communicator_and_a_restore():
     """A whole operator in 2-byte columns under a 1-rank communicator (hooks run, nothing moves) and merged back into a CSR
     (kron_restore through a communicator that cannot exchange tiled blocks is covered in test_gpu_dist)."""
