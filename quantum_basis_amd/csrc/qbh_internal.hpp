@@ -116,6 +116,9 @@ struct SpmvArgs {
     // block's descriptor names (WaveDesc::pad) -- near part: column - pad * kS (pad = major index of the block's first row);
     // sliced far part: target major index + (band - (pad >> 1)) * kNU, the x element is (pad >> 1) * 8 kNU + 8 * that + lane % 8
     const uint16_t *ja16;
+    // k_spmv_wave2 under the dynamic walk, passes with the fused epilogue: one slot of three sums per chunk of blocks
+    // (wave2_chunk_slots(n_wb) slots; never nullptr for those launches), added up in a fixed order by launch_reduce_chunks
+    double *chunk_red;
 };
 
 // element (u, d) of the product basis <-> its position in the band-major ("tiled") order (band, u, d % B): the B minor
@@ -296,6 +299,8 @@ int rows_kernel_occupancy(int npb, int tpr, int un, int dict_mode);
 int launch_spmv_wave(const SpmvArgs &a, int tpr, int grid, hipStream_t s);
 int launch_spmv_wave2(const SpmvArgs &a, int tpr, int ops, int grid, hipStream_t s);   // pipelined; ops 0 plain store, 2 epilogue + far addend
 int wave2_kernel_occupancy(int tpr, int ops);
+int64_t wave2_chunk_slots(int64_t n_wb);
+int launch_reduce_chunks(const double *slots, int64_t n_slots, double *partials, int *nparts_out, hipStream_t s);
 int launch_kron_tile(const d2 *x, d2 *xt, int64_t n, const KronTile &t, hipStream_t s);
 int launch_kron_check(const int64_t *ia, const int32_t *ja, int64_t nrows, int64_t S, int *d_flag, hipStream_t s);
 int launch_kron_count(const int64_t *ia, const int32_t *ja, int64_t nrows, const KronTile &t, int32_t *cnt_near, int32_t *cnt_far, hipStream_t s);
@@ -628,6 +633,8 @@ struct qbh_csr {
         int64_t  nwb_x = 0;
         int      tpr_x = 2, grid_x = 0;
         qbh::KronCls *d_cls = nullptr;  // several classes: device table for the near pass
+        double  *d_chunk_red = nullptr; // near pass under the dynamic walk: three sums per chunk of blocks (reproducible reductions)
+        int64_t  n_chunk_slots = 0;
         qbh::d2 *d_xt = nullptr, *d_far = nullptr;      // tiled copy of x (xt_cap elements, made on first use), far-part row sums
         int64_t  xt_cap = 0;
         const void *xt_of = nullptr;    // the vector whose tiled copy d_xt holds (written by the pass that produced it); consumed by one SpMV

@@ -112,6 +112,7 @@ struct DynWalk {
     // behind it.  (An atomic add would be rewritten by the compiler into a wave reduction that reads the reply at once;
     // the wrapping increment is left alone, and the counter counts chunks.)
     int64_t xbase, xend, n_wb, cur, nxt, n0;
+    int region;
     unsigned int *ctr;
     __device__ unsigned int ask(int lane) const
     {
@@ -126,6 +127,7 @@ struct DynWalk {
     {
         n_wb = n_blocks;
         const int xcd = region < 0 ? (int)(blockIdx.x & 7) : region;
+        this->region = xcd;
         const int64_t per = (n_blocks + 7) >> 3;
         xbase = xcd * per;
         xend = xbase + per < n_blocks ? xbase + per : n_blocks;
@@ -135,6 +137,12 @@ struct DynWalk {
         n0 = 0;
     }
     __device__ bool asks(int64_t n) const { return n == n0; }        // the turn that draws the next chunk
+    // number of the CURRENT chunk among all chunks of the launch (8 regions x chunks per region): where its reduction partials go
+    __device__ int64_t chunk_slot() const
+    {
+        const int64_t per = (n_wb + 7) >> 3, cpx = (per + kDynChunk - 1) / kDynChunk;
+        return (int64_t)region * cpx + (cur - xbase) / kDynChunk;
+    }
     __device__ int64_t at(int64_t n) const { return (n < n0 + kDynChunk ? cur : nxt) + n % kDynChunk; }
     // wave block of this wavefront's n-th turn (n = the current turn .. two turns ahead); n_wb = the sentinel (past the end)
     __device__ int64_t block(int64_t n) const
@@ -834,6 +842,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
     static_assert(!C16 || OPS == 1 || OPS == 2 || OPS == 3, "2-byte columns: the one-class near passes and the sliced far pass");
     constexpr int NW = 512, RP = 64 / TPR;
     constexpr bool EPI = OPS == 1 || OPS == 2 || OPS == 4, FAR = OPS == 2 || OPS == 4;      // OPS 1: the fused epilogue WITHOUT a far addend
+    // The fused reductions under the ordered dynamic walk: which wavefront takes which chunk depends on the run, so per-wavefront
+    // partial sums would make <x, y> and |y|^2 differ in the last bits from run to run.  Every CHUNK (kDynChunk consecutive blocks,
+    // always taken whole by one wavefront, rows in order) has a slot of its own instead: its three sums are stored when the
+    // wavefront moves on and k_reduce_chunks adds the slots in a fixed order -- bit-reproducible a_j / b_j at the dynamic walk's speed.
+    constexpr bool CHUNKRED = DYN && (OPS == 1 || OPS == 2 || OPS == 4);
     constexpr bool MULTI = OPS == 4;             // OPS 4 = OPS 2 for an operator with several classes (KronMap): the far result of a row sits at its
                                                  // compact far row id, looked up through the class table a.kcls; the block's descriptor names its class
     __shared__ d2 prod_s[4 * NW];
@@ -1070,6 +1083,22 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
 #ifdef QBH_WAVE_TIMING
     unsigned long long tm[4] = {0, 0, 0, 0}, nblk = 0;
 #endif
+    int64_t red_slot = -1;                       // CHUNKRED: slot of the chunk whose rows acc[] is collecting
+    auto red_flush = [&]() {
+        if constexpr (CHUNKRED) {
+            if (red_slot >= 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] = wave_sum(acc[c]);
+                if (lane == 0) {
+                    double *slot = a.chunk_red + red_slot * 3;
+                    slot[0] = acc[0];
+                    slot[1] = acc[1];
+                    slot[2] = acc[2];
+                }
+                acc[0] = acc[1] = acc[2] = 0.0;
+            }
+        }
+    };
     for (int hop = 0; hop < NHOP; ++hop) {
     if constexpr (dyn) dw.init(a.n_wb, a.wctr, lane, (int)((blockIdx.x + hop) & 7));
     int64_t lb = dyn ? 0 : walk.slot;
@@ -1091,7 +1120,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
         bool asking = false;
         if constexpr (dyn) {
             asking = dw.asks(lb);
-            if (asking) reply = dw.ask(lane);        // in front of the gathers: answered by the time they are
+            if (asking) {
+                if constexpr (CHUNKRED) {            // first turn of a chunk: the sums of the chunk before go to its slot
+                    red_flush();
+                    red_slot = dw.chunk_slot();
+                }
+                reply = dw.ask(lane);                // in front of the gathers: answered by the time they are
+            }
         }
         d2 xv[8];
 #if defined(QBH_ABL_NEAR_LDS)            // ablation builds only (wrong results): near gathers served from a wave-private LDS window
@@ -1226,6 +1261,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
 #endif
     }
     flush();
+    red_flush();
+    red_slot = -1;
     }       // hop
 #ifdef QBH_XCD_TIMING            // debug build: when does each XCD run out of blocks?  (s_memtime ticks; slots 1 / 2 behind every XCD's counter)
     if (dyn && lane == 0) {
@@ -1241,7 +1278,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
         atomicAdd(dbg + 4, nblk);
     }
 #endif
-    if (a.partials != nullptr) {
+    if (!CHUNKRED && a.partials != nullptr) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc[c] = wave_sum(acc[c]);
         if (lane == 0) {
@@ -1255,6 +1292,40 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
                 a.partials[(size_t)blockIdx.x * 3 + c] = (red[c * 4 + 0] + red[c * 4 + 1]) + (red[c * 4 + 2] + red[c * 4 + 3]);
         }
     }
+}
+
+// slots of the chunk partials -> 256 x 3 partial sums in a fixed order (block b: slots [b * per, (b + 1) * per), lanes striding,
+// fixed tree): what finish_reduction / k_reduce_partials then add up.  34 MB at C3, once per SpMV: ~10 us.
+__global__ __launch_bounds__(256) void k_reduce_chunks(const double *slots, int64_t n_slots, double *partials)
+{
+    __shared__ double sm[12];
+    const int64_t per = (n_slots + gridDim.x - 1) / gridDim.x, s0 = (int64_t)blockIdx.x * per, s1 = s0 + per < n_slots ? s0 + per : n_slots;
+    double v[3] = {0.0, 0.0, 0.0};
+    for (int64_t i = s0 + threadIdx.x; i < s1; i += 256) {
+        v[0] += slots[i * 3 + 0];
+        v[1] += slots[i * 3 + 1];
+        v[2] += slots[i * 3 + 2];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = wave_sum(v[c]);
+    if ((threadIdx.x & 63) == 0)
+        for (int c = 0; c < 3; ++c) sm[c * 4 + (threadIdx.x >> 6)] = v[c];
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int c = 0; c < 3; ++c) partials[(size_t)blockIdx.x * 3 + c] = (sm[c * 4 + 0] + sm[c * 4 + 1]) + (sm[c * 4 + 2] + sm[c * 4 + 3]);
+}
+int launch_reduce_chunks(const double *slots, int64_t n_slots, double *partials, int *nparts_out, hipStream_t s)
+{
+    const int g = 256;
+    hipLaunchKernelGGL(k_reduce_chunks, dim3(g), dim3(256), 0, s, slots, n_slots, partials);
+    QBH_HIP(hipGetLastError());
+    if (nparts_out) *nparts_out = g;
+    return QBH_OK;
+}
+int64_t wave2_chunk_slots(int64_t n_wb)
+{
+    const int64_t per = (n_wb + 7) >> 3;
+    return 8 * ((per + kDynChunk - 1) / kDynChunk);
 }
 
 template <int OPS, bool C16 = false>
@@ -1277,6 +1348,10 @@ static void launch_wave2_tpr(const SpmvArgs &a, int tpr, int grid, hipStream_t s
 
 int launch_spmv_wave2(const SpmvArgs &a, int tpr, int ops, int grid, hipStream_t s)
 {
+    if (a.swizzle == 3 && (ops == 1 || ops == 2 || ops == 4) && a.chunk_red == nullptr) {
+        set_error("launch_spmv_wave2: the dynamic walk of an epilogue pass needs its chunk-partial slots");
+        return QBH_EINVAL;
+    }
     if (a.ja16 != nullptr) {                 // 2-byte columns: the one-class near passes and the sliced far pass
         if (ops == 3)      launch_wave2_tpr<3, true>(a, tpr, grid, s);
         else if (ops == 1) launch_wave2_tpr<1, true>(a, tpr, grid, s);

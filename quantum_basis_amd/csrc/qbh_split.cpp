@@ -24,7 +24,7 @@ void kron_free_aux(qbh_csr *A)
 {
     qbh_csr::KronSplit &K = A->kron;
     for (void *q : {(void *)K.ia_n, (void *)K.ia_f, (void *)K.wd_n, (void *)K.wd_f, (void *)K.d_xt, (void *)K.d_far, (void *)K.ia_x, (void *)K.xrow,
-                    (void *)K.wd_x, (void *)K.d_cls, (void *)K.c16_n, (void *)K.c16_f})
+                    (void *)K.wd_x, (void *)K.d_cls, (void *)K.c16_n, (void *)K.c16_f, (void *)K.d_chunk_red})
         if (q) (void)hipFree(q);
     if (K.own_far) {
         if (K.ja_f) (void)hipFree(K.ja_f);
@@ -116,6 +116,12 @@ int kron_geometry(qbh_csr *A)
         if (K.nnz_x > 0)
             QBH_TRY(wave_geometry_for(A, K.ia_x, n, K.nnz_x, (double)K.nnz_x / (double)n, false, -1, &K.wd_x, &K.nwb_x, &K.tpr_x, &K.grid_x));
     }
+    // slots of the near pass's chunk partials (zeroed once: every real chunk overwrites its slot in every launch)
+    if (K.d_chunk_red) (void)hipFree(K.d_chunk_red);
+    K.d_chunk_red = nullptr;
+    K.n_chunk_slots = qbh::wave2_chunk_slots(K.nwb_n);
+    QBH_HIP(hipMalloc(&K.d_chunk_red, (size_t)K.n_chunk_slots * 3 * sizeof(double)));
+    QBH_HIP(hipMemsetAsync(K.d_chunk_red, 0, (size_t)K.n_chunk_slots * 3 * sizeof(double), A->stream));
     // 2-byte columns are relative to a base the block's descriptor names: fresh descriptors get it again
     if (K.c16_n) QBH_TRY(qbh::launch_kron_desc_c16(K.wd_n, K.nwb_n, K.t.S, false, false, A->stream));
     if (K.c16_f) QBH_TRY(qbh::launch_kron_desc_c16(K.wd_f, K.nwb_f, K.t.NU, true, false, A->stream));

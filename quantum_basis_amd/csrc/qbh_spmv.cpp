@@ -82,7 +82,10 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
     hipStream_t s = A->stream;
     const bool prof = A->opts.profile != 0;
     const bool comm = A->has_comm;
-    int kron_swz = A->opts.deterministic ? 2 : 3;           // dynamic ordered walk per XCD unless the caller wants static walks
+    // the dynamic ordered walk per XCD -- also for a caller who wants bit-reproducible results: y does not depend on which wavefront
+    // computes a row, and the fused reductions are collected per CHUNK of blocks and added in a fixed order (k_spmv_wave2's
+    // CHUNKRED, k_reduce_chunks) since round 5; qbh_opts.wave_walk = 2 still names the static walk
+    int kron_swz = 3;
     if (A->opts.wave_walk >= 0) kron_swz = A->opts.wave_walk;
     if (kron_swz == 3) {
         if (!A->d_wctr) kron_swz = 2;
@@ -184,6 +187,12 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
     nr.kB = K.t.B;
     nr.swizzle = kron_swz;
     nr.wctr = A->d_wctr ? A->d_wctr + 256 : nullptr;
+    nr.chunk_red = K.d_chunk_red;                            // dynamic walk: the near pass's reduction partials, one slot per chunk
+    const bool chunk_red = kron_swz == 3 && K.d_chunk_red != nullptr;
+    if (kron_swz == 3 && !K.d_chunk_red) {
+        qbh::set_error("Kronecker split: the chunk partials of the near pass were not allocated");
+        return QBH_EHIP;
+    }
     int nparts = K.grid_n;
     if (!comm) {
         if (K.sliced) QBH_TRY(qbh::launch_zero_cut_groups(K.wd_f, K.nwb_f, f.nrows, K.d_far, s));
@@ -194,10 +203,12 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
             QBH_TRY(qbh::launch_kron_cross_rows(K.ia_x, K.xrow, K.n_xrows, K.ja_x, K.val_x, xt, K.t, K.d_far, s));
             nr.partials = red ? A->d_partials : nullptr;
             QBH_TRY(qbh::launch_spmv_wave2(nr, K.tpr_n, 2, K.grid_n, s));
+            if (red && chunk_red) QBH_TRY(qbh::launch_reduce_chunks(K.d_chunk_red, K.n_chunk_slots, A->d_partials, &nparts, s));
         } else {
             nr.kcls = K.d_cls;
             nr.partials = (red && K.nnz_x == 0) ? A->d_partials : nullptr;
             QBH_TRY(qbh::launch_spmv_wave2(nr, K.tpr_n, 4, K.grid_n, s));
+            if (red && K.nnz_x == 0 && chunk_red) QBH_TRY(qbh::launch_reduce_chunks(K.d_chunk_red, K.n_chunk_slots, A->d_partials, &nparts, s));
             if (K.nnz_x > 0) {               // third pass: the unstructured part, accumulating onto y; reductions on the finished y
                 qbh::SpmvArgs cr{};
                 cr.ia = K.ia_x;
@@ -578,6 +589,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
             g = std::max<int64_t>(8, (g / 8) * 8);
             g = std::min<int64_t>(g, A->wgrid);            // the partial-sum buffer is sized for the wave kernel's grid
             wave_grid_used = (int)g;
+            if (a.swizzle == 3) a.swizzle = 2;             // the experiment has no chunk-partial slots: static walk, per-workgroup partials
             QBH_TRY(qbh::launch_spmv_wave2(a, A->wtpr, 1, (int)g, A->stream));
         } else {
             QBH_TRY(qbh::launch_spmv_wave(a, A->wtpr, A->wgrid, A->stream));

@@ -43,6 +43,8 @@ int main(void) {
     printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(qbh_z), sizeof(qbh_lanczos_row), sizeof(qbh_opts), sizeof(qbh_stats),
            sizeof(qbh_csr_info), sizeof(qbh_solver_info), offsetof(qbh_opts, kron_split), offsetof(qbh_opts, kron_minor),
            offsetof(qbh_csr_info, kron_minor), offsetof(qbh_csr_info, kron_band), offsetof(qbh_csr_info, kron_sliced));
+    printf("%zu %zu %zu %zu %zu\n", offsetof(qbh_opts, kron_cols16), offsetof(qbh_opts, gather_parts), offsetof(qbh_opts, basis_detect),
+           offsetof(qbh_csr_info, kron_cols16), offsetof(qbh_csr_info, kron_table_kernel));
     return 0;
 }
 """
@@ -52,7 +54,9 @@ int main(void) {
         got = [int(t) for t in subprocess.check_output([os.path.join(tmp, "t")], text=True).split()]
     want = [C.sizeof(_lib.Z), C.sizeof(_lib.LanczosRow), C.sizeof(_lib.Opts), C.sizeof(_lib.Stats), C.sizeof(_lib.CsrInfo),
             C.sizeof(_lib.SolverInfo), _lib.Opts.kron_split.offset, _lib.Opts.kron_minor.offset, _lib.CsrInfo.kron_minor.offset,
-            _lib.CsrInfo.kron_band.offset, _lib.CsrInfo.kron_sliced.offset]
+            _lib.CsrInfo.kron_band.offset, _lib.CsrInfo.kron_sliced.offset,
+            _lib.Opts.kron_cols16.offset, _lib.Opts.gather_parts.offset, _lib.Opts.basis_detect.offset, _lib.CsrInfo.kron_cols16.offset,
+            _lib.CsrInfo.kron_table_kernel.offset]
     assert got == want
 
 
@@ -63,12 +67,17 @@ def test_process_wide_default_options_for_a_host_whose_constructor_carries_none(
     o = _lib.Opts()
     L.qbh_opts_default(C.byref(o))
     assert (o.basis_kind, o.deterministic, o.kron_split, o.value_dict, o.real_fast_path) == (0, 0, 1, 1, 1)
+    # the form switches that were environment variables up to ABI 400: their documented defaults
+    assert (o.kron_cols16, o.kron_sliced, o.kron_band, o.kron_cross_in_near, o.kron_coded, o.kron_uniform, o.gather_parts, o.wave_walk, o.tile_fold,
+            o.autotune, o.shard_split, o.real_forms, o.basis_detect) == (1, 1, 0, 1, -1, 7, 0, -1, 1, 1, 1, 7, 1)
     o.basis_kind, o.n_sites, o.n_up, o.n_dn = _lib.BASIS_REF_FERMION2, 16, 8, 8
+    o.device, o.stream = 3, 0x1234                       # a default names no device and no stream: not kept
     L.qbh_opts_set_default(C.byref(o))
     try:
         o2 = _lib.Opts()
         L.qbh_opts_default(C.byref(o2))
         assert (o2.basis_kind, o2.n_sites, o2.n_up, o2.n_dn, o2.kron_split) == (_lib.BASIS_REF_FERMION2, 16, 8, 8, 1)
+        assert o2.device == -1 and not o2.stream
     finally:
         L.qbh_opts_set_default(None)
     L.qbh_opts_default(C.byref(o))
@@ -152,3 +161,20 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "qb_oracle" not in text and "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_no_environment_variable_selects_a_form():
+    """Switch hygiene (round 5): the library reads exactly three environment variables -- QBH_DEBUG (one key=value list of
+    measurement / tracing knobs), QBH_HOST_THREADS, QBH_RCCL_LIB -- and tests never steer it through the environment of a form."""
+    import glob
+    import re
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "quantum_basis_amd", "csrc", "*.*")):
+        names |= set(re.findall(r'getenv\("([A-Z_0-9]+)"\)', open(f).read()))
+    assert names == {"QBH_DEBUG", "QBH_HOST_THREADS", "QBH_RCCL_LIB"}, names
+    allowed = {"QBH_DEBUG", "QBH_RCCL_LIB", "QBH_DIST_BACKEND", "QBH_HOST_THREADS", "QBH_PY_HOOKS", "QBH_WORKLOAD", "QBH_OK"}
+    for f in glob.glob(os.path.join(ROOT, "tests", "*.py")):
+        if os.path.basename(f) == "test_abi.py":
+            continue
+        used = set(re.findall(r'(?:setenv|environ)[^\n]*?"(QBH_[A-Z_0-9]+)"', open(f).read()))
+        assert used <= allowed, (f, used - allowed)
