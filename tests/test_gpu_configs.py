@@ -122,7 +122,8 @@ def test_c4_substitute_in_the_north_star_format_split_in_place():
     A = q.csr_mat.hubbard(20, 5, 5, bonds, t=1.0, U=1.1, opts=q.make_opts(value_dict=0, real_fast_path=0))
     info = A.info()
     assert info.kron_minor == math.comb(20, 5) and info.kron_inplace == 1 and info.kron_sliced == 1 and info.kron_cols16 == 3
-    assert info.value_dict == 0 and info.bytes_matrix < info.nnz * 16.5 + 64 * info.nrows        # 16 B of values + 2 B of columns per nonzero
+    # 16 B of values + 2 B of columns per nonzero (+ row / group pointers and descriptors): 18 B, not the 20 B of the int32 form
+    assert info.value_dict == 0 and info.nnz * 18 <= info.bytes_matrix < info.nnz * 18 + 64 * info.nrows
     M = q.csr_mat.hubbard(20, 5, 5, bonds, t=1.0, U=1.1, matrix_free=True)
     _same_y(A, M)
     r = q.locate_E0_lanczos(A, nev=1, ncv=0, maxit=800)
