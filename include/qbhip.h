@@ -95,7 +95,7 @@ typedef struct qbh_opts {
     int     kron_split;      /* 1 (default): a complex128 operator on a product basis (index = major * S + minor, every entry
                                 changes one of the two: the two-species Hubbard family in species-major order) is stored as
                                 H_near + H_far, the far part band-major over the minor index -- the handle's arrays are
-                                RE-ORDERED IN PLACE (same values, same int32 columns, same 20 B per nonzero; no second copy;
+                                RE-ORDERED IN PLACE (same values in the same order, columns as int32 or -- kron_cols16 -- 2 bytes each; no second copy;
                                 qbh_csr_download merges the parts back).  The structure is verified on the device, the choice
                                 is structural (never timed).  Row shards made of whole major indices (row_offset and the
                                 row count multiples of S) split the same way.  1 leaves operators below 1e8 nonzeros alone
