@@ -147,8 +147,7 @@ def coded_format_roofline(info, ms_spmv, code_w, coded, real_used, traffic, tsrc
     if table:
         moved = info.nrows * (3 * vec_b + 1) + int(info.kron_far_nnz) * 3
         definition = ("recognised form T (x) 1 + 1 (x) T' + D applied by the row-staged table kernel: rows * (3 * %d + 1) [x, old y, new y, "
-                      "diagonal code] + the T / T' tables; the ~17 neighbour rows of every up-configuration are re-read through the L2 / "
-                      "Infinity Cache, not from HBM" % vec_b)
+                      "diagonal code] + the T / T' tables: the COMPULSORY bytes; the kernel re-reads neighbour rows on top (traffic)" % vec_b)
     elif uniform:
         moved = info.nrows * (7 * vec_b + 1) + int(info.kron_far_nnz) * 3
         definition = ("recognised form T (x) 1 + 1 (x) T' + D: rows * (7 * %d + 1) [x, old y, new y, tiled x written + read, far sums "
@@ -169,8 +168,9 @@ def coded_format_roofline(info, ms_spmv, code_w, coded, real_used, traffic, tsrc
             "survey_8d_bytes_per_launch": int(survey_bytes), "survey_8d_equivalent_GBps": round(survey_bytes / ms_spmv / 1e6, 2),
             "note": "frac is on the bytes the running form must move; the *_equivalent_GBps figures divide bytes the kernel does NOT move "
                     "by its time -- speed-ups over a CSR sweep, not roofline fractions"
-                    + ("; the table kernel is bound by the L2-served neighbour-row reads and the LDS gathers of the staged row, not by HBM "
-                       "bandwidth (DESIGN 4.6)" if table else
+                    + ("; the table kernel re-reads the ~17 neighbour rows of every up-configuration from HBM (traffic_ratio says how often): on "
+                       "its ACTUAL traffic it runs close to the fabric ceiling (C3: 31.8 GB in 4.7 ms = 6.8 TB/s), so its lever is reuse of those "
+                       "rows, not a faster pass (DESIGN 5.0d item 5)" if table else
                        "; the two passes are bound by L2 line requests and LDS gathers, not by HBM bandwidth (DESIGN 4.1g)" if kronc else "")}
 
 
