@@ -2258,11 +2258,21 @@ int launch_axpy_norm(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, int6
 // k_kron_tile8: 1 KB runs of x / y in, 1 KB runs of y and 4 KB runs of the tiled copy out; the narrow last band (S % 8 != 0)
 // element-wise.  MODE 0: y += alpha x (alpha_dev as in k_axpy_norm), partial |y|^2.  MODE 1: y = x + alpha.x * y (k_xpby), no sum.
 // Static assignment of the items to workgroups: the partial sums are run-to-run reproducible.
+// item = TU major indices x TB bands: reads runs of TB * 128 bytes of x and y (TB * 8 minor indices of one major index), writes
+// the updated y in natural order (the same runs) AND through LDS in tiled order (runs of TU * 128 bytes: TU major indices of one
+// band).  TU * TB = 256 keeps the tile at 33 KB.  QBH_TILE_TU / QBH_TILE_TB: build-time tuning (round 4: 32 x 8; round 5, measured through whole bench lines: 8 x 32 saves 0.15-0.25 ms of the 2.2 ms pass).
+#ifndef QBH_TILE_TU
+#define QBH_TILE_TU 8
+#endif
+#ifndef QBH_TILE_TB
+#define QBH_TILE_TB 32
+#endif
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_axpy_norm_tile8(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, d2 *yt, KronTile t,
                                                             int64_t nfb, double *partials)
 {
-    constexpr int TU = 32, TB = 8, LD = TB * 8 + 1;
+    constexpr int TU = QBH_TILE_TU, TB = QBH_TILE_TB, RW = TB * 8, LD = RW + 1;      // RW: elements of one major index in the item
+    static_assert(TU * TB == 256 && (TU & (TU - 1)) == 0 && (TB & (TB - 1)) == 0, "TU x TB = 256, powers of two");
     __shared__ d2 tilebuf[TU * LD];
     __shared__ double red[4];
     double acc[1] = {0.0};
@@ -2283,7 +2293,7 @@ __global__ __launch_bounds__(kBlock) void k_axpy_norm_tile8(d2 alpha, const doub
         d2 xv[TU * TB * 8 / kBlock], yv[TU * TB * 8 / kBlock];
 #pragma unroll
         for (int i = 0; i < TU * TB * 8 / kBlock; ++i) {
-            const int idx = threadIdx.x + i * kBlock, ul = idx >> 6, dl = idx & 63;
+            const int idx = threadIdx.x + i * kBlock, ul = idx / RW, dl = idx % RW;
             const bool in = ul < nu && dl < nb * 8;
             const int64_t r = in ? (u0 + ul) * t.S + b0 * 8 + dl : 0;
             xv[i] = __builtin_nontemporal_load(x + r);
@@ -2292,7 +2302,7 @@ __global__ __launch_bounds__(kBlock) void k_axpy_norm_tile8(d2 alpha, const doub
         __syncthreads();                               // the previous item's tile has been read
 #pragma unroll
         for (int i = 0; i < TU * TB * 8 / kBlock; ++i) {
-            const int idx = threadIdx.x + i * kBlock, ul = idx >> 6, dl = idx & 63;
+            const int idx = threadIdx.x + i * kBlock, ul = idx / RW, dl = idx % RW;
             if (ul < nu && dl < nb * 8) {
                 const d2 v = upd(xv[i], yv[i]);
                 y[(u0 + ul) * t.S + b0 * 8 + dl] = v;
@@ -2302,7 +2312,7 @@ __global__ __launch_bounds__(kBlock) void k_axpy_norm_tile8(d2 alpha, const doub
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < TU * TB * 8 / kBlock; ++i) {
-            const int idx = threadIdx.x + i * kBlock, bl = idx >> 8, rest = idx & 255, ul = rest >> 3, j = rest & 7;
+            const int idx = threadIdx.x + i * kBlock, bl = idx / (TU * 8), rest = idx % (TU * 8), ul = rest >> 3, j = rest & 7;
             if (bl < nb && ul < nu) yt[(b0 + bl) * 8 * t.NU + (u0 + ul) * 8 + j] = tilebuf[ul * LD + bl * 8 + j];
         }
     }

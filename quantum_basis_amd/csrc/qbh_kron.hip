@@ -3,7 +3,8 @@
 // A stored operator whose rows have a product structure (KronMap, qbh_internal.hpp) is re-ordered inside its own arrays:
 //   [ near entries, rows in natural order | far entries, rows band-major inside their class, interleaved in groups of 8 rows |
 //     cross entries, row-major ]
-// Same values, same int32 columns, same 20 B per nonzero as the CSR it replaces; the CSR is NOT kept beside
+// Same values in the same order as the CSR it replaces; columns as int32 (20 B per nonzero) or -- round 5,
+// qbh_opts.kron_cols16 -- 2 bytes each relative to a base the wave block's descriptor names (18 B); the CSR is NOT kept beside
 // it -- qbh_csr_download and kron_restore merge the parts back row by row (columns ascending: the original row, bit for bit).
 //
 // One class: the two-species (Hubbard) operators in species-major order, src/model.cc:619-685 -- index = up * S + down; near =

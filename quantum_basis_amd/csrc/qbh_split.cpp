@@ -192,7 +192,7 @@ int kron_short_cols(qbh_csr *A)
 // share every line they gather.  Per SpMV: x -> tiled copy (or written by the pass that produced x), far pass (row sums, tiled
 // order), near pass (+ far result, fused epilogue).
 // Round 4: the split REPLACES the CSR -- the handle's own d_ja / d_val are re-ordered in place into [near | far | cross] (same
-// values, same columns, same 20 B per nonzero; peak during the conversion = the CSR + one copy of the far and cross parts), row
+// values, same columns -- 2 bytes each afterwards where they fit, kron_short_cols; peak during the conversion = the CSR + one copy of the far and cross parts), row
 // shards made of whole major indices split the same way, and qbh_csr_download / kron_restore merge the parts back.  The choice
 // is STRUCTURAL (verified on the device, never assumed, never timed): results do not depend on the box.  kron_split = 1 leaves
 // operators below 1e8 nonzeros alone (three launches cost more than they save there); 2 splits whatever has the structure.

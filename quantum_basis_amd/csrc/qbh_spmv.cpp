@@ -518,7 +518,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         // coded Kronecker split, all-real operation: tiled copy of the packed x, near launch (full epilogue), far launch
         // (tiled rows and columns, accumulates at orig(row), fused reductions of the finished y)
         qbh_csr::KronCoded &K = A->kronc;
-        if (K.sl.active && K.table_route) {
+        if (K.sl.active && K.table_route && qbh::debug_sw().mf_row != 0) {      // (mf_row=0: the debug switch that turns the row-staged kernel off)
             // T (x) 1 + 1 (x) T' + D recognised: the row-staged table kernel applies it from T, T' and one diagonal code per row --
             // no tiled copy, no far sums: x read (+ its neighbour rows through the caches), old y read, y written
             qbh::MfArgs m{};
