@@ -900,6 +900,9 @@ def main():
                            # > 1: the tiled blocks travel as that many band ranges and the far pass follows range by range; the
                            # per-rank ms_spmv then contains whatever the far pass waited for the later ranges
                            "gather_parts": int(A.info().gather_parts),
+                           # what the ranks agreed on when the communicator was attached (qbh_csr_set_comm is collective): split shards
+                           # exchanging the tiled copies of their blocks, or the plain blocks of unsplit shards
+                           "tiled_blocks_of_split_shards": bool(A.info().kron_minor),
                            "allreduce": "<= 3 doubles per reduction point"}
         # per rank: SpMV kernel ms (both parts of a split shard), gather ms on the side stream, how much of the gather the
         # locally-owned columns hide, and the rank's own roofline on ITS algorithmic bytes (local nnz, rows, the whole x)

@@ -883,7 +883,7 @@ int qbh::adopt_mf_sector(qbh_csr **out, qbh::MfSec *host_tables, qbh::MfSec *dev
     if (qbh::dev_alloc(&A->d_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
     if (hipHostMalloc(&A->h_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
     if (qbh::dev_alloc(&A->d_flag, sizeof(int)) != hipSuccess) return fail(QBH_ENOMEM);
-    if (hipMemset(A->d_flag, 0, sizeof(int)) != hipSuccess) return fail(QBH_EHIP);
+    if (hipMemsetAsync(A->d_flag, 0, sizeof(int), A->stream) != hipSuccess) return fail(QBH_EHIP);      // on the handle's stream: the null stream is not ordered with it
     if (hipEventCreate(&A->ev0) != hipSuccess || hipEventCreate(&A->ev1) != hipSuccess ||
         hipEventCreate(&A->ev2) != hipSuccess || hipEventCreate(&A->ev3) != hipSuccess)
         return fail(QBH_EHIP);
@@ -917,7 +917,7 @@ int qbh::adopt_mf_hubbard(qbh_csr **out, const qbh::MfHubbard &t, int64_t nrows,
     if (qbh::dev_alloc(&A->d_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
     if (hipHostMalloc(&A->h_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
     if (qbh::dev_alloc(&A->d_flag, sizeof(int)) != hipSuccess) return fail(QBH_ENOMEM);
-    if (hipMemset(A->d_flag, 0, sizeof(int)) != hipSuccess) return fail(QBH_EHIP);
+    if (hipMemsetAsync(A->d_flag, 0, sizeof(int), A->stream) != hipSuccess) return fail(QBH_EHIP);      // on the handle's stream: the null stream is not ordered with it
     if (hipEventCreate(&A->ev0) != hipSuccess || hipEventCreate(&A->ev1) != hipSuccess ||
         hipEventCreate(&A->ev2) != hipSuccess || hipEventCreate(&A->ev3) != hipSuccess)
         return fail(QBH_EHIP);
@@ -951,7 +951,7 @@ int qbh::adopt_mf_heis(qbh_csr **out, const qbh::MfHeis &t, int64_t nrows, int64
     if (qbh::dev_alloc(&A->d_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
     if (hipHostMalloc(&A->h_scal, 16 * sizeof(double)) != hipSuccess) return fail(QBH_ENOMEM);
     if (qbh::dev_alloc(&A->d_flag, sizeof(int)) != hipSuccess) return fail(QBH_ENOMEM);
-    if (hipMemset(A->d_flag, 0, sizeof(int)) != hipSuccess) return fail(QBH_EHIP);
+    if (hipMemsetAsync(A->d_flag, 0, sizeof(int), A->stream) != hipSuccess) return fail(QBH_EHIP);      // on the handle's stream: the null stream is not ordered with it
     if (hipEventCreate(&A->ev0) != hipSuccess || hipEventCreate(&A->ev1) != hipSuccess ||
         hipEventCreate(&A->ev2) != hipSuccess || hipEventCreate(&A->ev3) != hipSuccess)
         return fail(QBH_EHIP);

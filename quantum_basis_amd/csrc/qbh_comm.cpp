@@ -387,9 +387,15 @@ extern "C" int qbh_comm_create_rccl(qbh_csr *A, const void *uid128, int rank, in
     QBH_C(qbh::dev_alloc(&c->d_xfull, full * 2 * sizeof(double)));
     QBH_C(qbh::dev_alloc(&c->d_xfull_r, full * sizeof(double)));
     QBH_C(qbh::dev_alloc(&c->d_scal, 16 * sizeof(double)));
-    QBH_C(hipMemset(c->d_xsend, 0, (size_t)c->nblk * 2 * sizeof(double)));
-    QBH_C(hipMemset(c->d_xfull, 0, full * 2 * sizeof(double)));
-    QBH_C(hipMemset(c->d_scal, 0, 16 * sizeof(double)));
+    // On the OPERATOR's stream, and waited for: hipMemset runs on the null stream and may return before it has executed, and a host's
+    // stream (torch creates non-blocking ones) is not ordered with the null stream -- the zeroing could land AFTER the first data the
+    // operator's stream puts into these buffers.  Found by the first 2-rank run through the librccl stand-in (round 5): the agreement
+    // all-reduce of qbh_csr_set_comm lost one rank's contribution now and then, and both ranks fell back to the plain exchange.
+    QBH_C(hipMemsetAsync(c->d_xsend, 0, (size_t)c->nblk * 2 * sizeof(double), c->op));
+    QBH_C(hipMemsetAsync(c->d_xfull, 0, full * 2 * sizeof(double), c->op));
+    QBH_C(hipMemsetAsync(c->d_xfull_r, 0, full * sizeof(double), c->op));
+    QBH_C(hipMemsetAsync(c->d_scal, 0, 16 * sizeof(double), c->op));
+    QBH_C(hipStreamSynchronize(c->op));
 #undef QBH_C
     ncclUniqueId id;
     std::memcpy(&id, uid128, sizeof(id));

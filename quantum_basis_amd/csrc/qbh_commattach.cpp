@@ -160,6 +160,9 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
     A->comm_cuts = cuts_new;
     A->comm_full = full_new;
     const bool all_tiled = v[1] == (double)comm->nranks;
+    if (qbh::debug_sw().trace_create)
+        fprintf(stderr, "[qbh_csr_set_comm] rank %d/%d: split %d, can exchange tiled %d (S %lld, cuts %s), proposes %d parts; agreed: failures %.0f, tiled %.0f of %d\n",
+                comm->rank, comm->nranks, (int)K.active, (int)mine, (long long)S, comm->row_cuts ? "given" : "uniform", my_parts, v[0], v[1], comm->nranks);
     int parts = 1;
     for (int k = 0; k < 8; ++k)
         if (v[2 + k] > 0.0) {

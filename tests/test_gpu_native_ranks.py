@@ -149,3 +149,26 @@ def test_bench_two_ranks_on_one_gpu_through_the_native_communicator(rig):
     pr = got["per_rank"]
     assert len(pr) == 2 and all(set(("rank", "rows", "nnz", "ms_spmv", "ms_gather", "gather_hidden_frac", "roofline_frac")) <= set(p) for p in pr), pr
     assert all(p["ms_spmv"] > 0 and p["rows"] > 0 for p in pr) and sum(p["rows"] for p in pr) == got["config"]["dim"], pr
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_python_hosts_keep_their_split_shards_under_the_native_communicator(rig, nranks):
+    """The Python route of bench.py (quantum_basis_amd.dist.NativeComm on a torch stream, torch's own rendezvous over gloo):
+    split shards must STAY split after the collective attach, with the default 4 gather parts, and give the one-rank E0.
+    (Round 5's first C3 run through the stand-in fell back to the plain exchange now and then: qbh_comm_create_rccl zeroed its
+    buffers with hipMemset on the null stream, which is not ordered with a non-blocking host stream -- the zeroing could land
+    after the agreement's own data.  tools/r5/parts_probe.py is the probe that showed it.)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, QBH_RCCL_LIB=STUB, TMPDIR=rig["tmp"], HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tools", "r5", "parts_probe.py"), "hubbard_4x3_half", "0", "2"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    after = [ln for ln in p.stdout.splitlines() if " after :" in ln]
+    e0 = [float(ln.split()[3]) for ln in p.stdout.splitlines() if " E0 " in ln]
+    assert len(after) == nranks and all("kron_minor 924 gather_parts 4" in ln for ln in after), p.stdout
+    assert len(e0) == nranks and all(abs(e + 16.879382788684) < 1e-9 for e in e0), p.stdout
