@@ -878,6 +878,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
         bool cont0, cont1;       // OPS 3: the first group began in the block before / the last group goes on in the block after
         int cls;                 // OPS 4: class of the block's first row
         int64_t xb;              // C16: element of the gather source that column value 0 of this block names
+        int lead;                // entries between p0 and the block's first entry (they belong to the block before: loaded, never used)
     };
     // far result of one row (OPS 2 / 4)
     // (rows and minor sizes are below 2^31 -- int32 columns -- so the index arithmetic of a row's far slot is 32-bit: a 64-bit
@@ -909,6 +910,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
         const int64_t pfirst = (int64_t)(((uint64_t)q1 << 32) | q0);
         // OPS 3: blocks are exact runs of slots, cut so that they start on 128-byte boundaries of the arrays (k_build_slotdesc's shift)
         b.p0 = OPS == 3 ? pfirst : pfirst - (pfirst & 7);
+        b.lead = OPS == 3 ? 0 : (int)(pfirst & 7);
         const int64_t p1 = (int64_t)(((uint64_t)q5 << 32) | q4);
         b.r0 = __builtin_amdgcn_readlane(dq, 2);
         b.nr = __builtin_amdgcn_readlane(dq, 6) - b.r0;
@@ -951,6 +953,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
             const int i = lane + u * 64;
             if constexpr (C16) c[u] = ntload(a.ja16 + base + (i < nn ? i : nm1));
             else               c[u] = ntload(a.ja + base + (i < nn ? i : nm1)) & a.colmask;
+        }
+        // The up to 7 entries in front of the block's first one are the tail of the block BEFORE: their 2-byte columns are relative
+        // to THAT block's base, and decoded with this block's they can point up to two major indices ahead -- past the end of x
+        // for the last blocks of an operator or shard (found by the 4-rank C3 rehearsal, round 5: a memory access fault on the ranks
+        // whose vectors ended at an allocation boundary).  Their products are never used: gather element 0 of the block's base.
+        if constexpr (C16 && OPS != 3) {
+            if (b.n > 0 && lane < b.lead) c[0] = 0;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {

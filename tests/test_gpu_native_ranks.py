@@ -168,7 +168,33 @@ def test_python_hosts_keep_their_split_shards_under_the_native_communicator(rig,
                         "--master-port", str(port), os.path.join(ROOT, "tools", "r5", "parts_probe.py"), "hubbard_4x3_half", "0", "2"],
                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
-    after = [ln for ln in p.stdout.splitlines() if " after :" in ln]
-    e0 = [float(ln.split()[3]) for ln in p.stdout.splitlines() if " E0 " in ln]
+    import re
+    after = re.findall(r"rank \d+ after : kron_minor \d+ gather_parts \d+", p.stdout)
+    e0 = [float(t) for t in re.findall(r"rank \d+ E0 (-?[0-9.]+) steps", p.stdout)]      # (the ranks' lines can run into one another)
     assert len(after) == nranks and all("kron_minor 924 gather_parts 4" in ln for ln in after), p.stdout
     assert len(e0) == nranks and all(abs(e + 16.879382788684) < 1e-9 for e in e0), p.stdout
+
+
+def test_headline_operator_on_four_ranks_through_the_native_communicator(rig):
+    """C3 itself (dim 165,636,900) as four ragged row shards of whole major indices on this one GPU, each split in place with 2-byte
+    near columns, the tiled blocks exchanged through qbh_comm_create_rccl in 4 gather parts: the first Lanczos coefficients must be
+    the one-rank values on every rank.  This is the run that found two bugs no small test had seen (round 5): buffers zeroed on the
+    null stream, and the 2-byte columns of the up-to-7 entries a near block loads in front of its first one being decoded with the
+    wrong base -- a read past the end of x on the ranks whose vectors ended at an allocation boundary."""
+    import re
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, QBH_RCCL_LIB=STUB, TMPDIR=rig["tmp"], HSA_ENABLE_IPC_MODE_LEGACY="0", PROBE_MAXIT="6")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tools", "r5", "parts_probe.py"), "hubbard_4x4_half", "0", "1"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    after = re.findall(r"rank \d+ after : kron_minor (\d+) gather_parts (\d+)", p.stdout)
+    ran = re.findall(r"rank \d+ ran (\d+) steps, a0 (-?[0-9.]+) b1 (-?[0-9.]+)", p.stdout)
+    assert len(after) == 4 and all(a == ("12870", "4") for a in after), p.stdout
+    assert len(ran) == 4 and all(r[0] == "5" for r in ran), p.stdout
+    # the one-rank coefficients of the same start vector (seed 1): tests/test_gpu_kron.py pins them through E0; here to 1e-9
+    assert all(abs(float(r[1]) - 4.399209342849) < 1e-9 and abs(float(r[2]) - 5.951874544884) < 1e-9 for r in ran), ran
