@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QBH_VERSION 500
+#define QBH_VERSION 501
 
 /* error codes */
 #define QBH_OK          0
@@ -76,6 +76,8 @@ const char *qbh_last_error(void);                   /* thread-local detail of th
                                        (qbh_opts.n_up = number of low sites, 0 = n_sites / 2) and the operator is held class-major
                                        internally -- class = particle number of the high half -- so that bonds inside a half get the
                                        Kronecker treatment and only the bonds across the cut stay unstructured (kagome-30: 17-21 %) */
+#define QBH_BASIS_SECTOR_ORBIT  3   /* reported by qbh_csr_info.basis_internal only: a matrix-free momentum-sector operator whose rows
+                                       are held orbit by orbit of the up patterns (qbh_opts.sector_orbit); not a value of basis_kind */
 
 typedef struct qbh_opts {
     int     device;          /* HIP ordinal; -1 = current device                                  */
@@ -167,6 +169,13 @@ typedef struct qbh_opts {
                                 candidate, BEFORE anything is permuted -- and the first under which the operator has the
                                 product structure is taken (qbh_csr_info.basis_internal / basis_detected / basis_n_*).  A
                                 matrix of a colliding dimension without the structure stays exactly as given.  0: never     */
+    int     sector_orbit;    /* [1] qbh_mf_hubbard_repr: the rows of a down block (one per up pattern) are held ORBIT BY ORBIT of
+                                the translation group, so that a translated pattern lies inside the same 8 x n_trans bytes:
+                                every down hop of a block then reads its target block front to back once, instead of
+                                gathering through a per-translation rank table.  The handle keeps its device vectors in that
+                                order (qbh_csr_info.basis_internal = QBH_BASIS_SECTOR_ORBIT; host vectors are translated at the
+                                seams as for basis_kind, device vectors by qbh_vec_to_internal / _from_internal).  0: rows in
+                                ascending pattern order, the form of ABI <= 500                                            */
 } qbh_opts;
 
 void qbh_opts_default(qbh_opts *o);
@@ -264,6 +273,11 @@ int qbh_vec_free(qbh_z *d);
 int qbh_vec_upload(const qbh_csr *A, qbh_z *d_dst, const qbh_z *h_src, int64_t n);
 int qbh_vec_download(const qbh_csr *A, qbh_z *h_dst, const qbh_z *d_src, int64_t n);
 int qbh_vec_zero(const qbh_csr *A, qbh_z *d, int64_t n);
+/* Device vectors of an operator that is held in another order than the caller's (qbh_csr_info.basis_internal != 0) are in the
+ * INTERNAL order.  These two copy one vector of A's row count between the orders on the device (d_dst != d_src); for an
+ * operator held in the caller's order they are plain copies. */
+int qbh_vec_to_internal(const qbh_csr *A, qbh_z *d_dst_internal, const qbh_z *d_src_caller);
+int qbh_vec_from_internal(const qbh_csr *A, qbh_z *d_dst_caller, const qbh_z *d_src_internal);
 /* Replaces vec_randomize (src/miscellaneous.cc:371-386): element j (GLOBAL index
  * row_offset + j) gets minstd_rand0 draw number j+1 of `seed`, times 1/2147483647, minus
  * 0.5, imaginary part 0; then the vector is scaled by 1/||x|| (global norm under a

@@ -15,6 +15,7 @@ if os.environ.get("QBHIP_LIBRARY"):      # e.g. a host-AddressSanitizer build of
 QBH_OK = 0
 KERNEL_AUTO, KERNEL_STREAM, KERNEL_VECTOR, KERNEL_ROWS, KERNEL_MATRIX_FREE, KERNEL_WAVE = 0, 1, 2, 3, 4, 5
 BASIS_NONE, BASIS_REF_FERMION2, BASIS_SPIN_SECTOR = 0, 1, 2
+BASIS_SECTOR_ORBIT = 3    # qbh_csr_info.basis_internal of a matrix-free sector operator held orbit by orbit (qbh_opts.sector_orbit)
 BASIS_DETECT = -1         # qbh_csr_set_basis only: the library's own search (qbh_opts.basis_detect)
 
 
@@ -38,7 +39,8 @@ class Opts(C.Structure):
                 ("n_sites", C.c_int), ("n_up", C.c_int), ("n_dn", C.c_int), ("kron_cols16", C.c_int),
                 ("kron_sliced", C.c_int), ("kron_band", C.c_int), ("kron_cross_in_near", C.c_int), ("kron_coded", C.c_int),
                 ("kron_uniform", C.c_int), ("gather_parts", C.c_int), ("wave_walk", C.c_int), ("tile_fold", C.c_int),
-                ("autotune", C.c_int), ("shard_split", C.c_int), ("real_forms", C.c_int), ("basis_detect", C.c_int)]
+                ("autotune", C.c_int), ("shard_split", C.c_int), ("real_forms", C.c_int), ("basis_detect", C.c_int),
+                ("sector_orbit", C.c_int)]
 
 
 class CsrInfo(C.Structure):
@@ -95,7 +97,7 @@ EXPORTS = [
     "qbh_version", "qbh_device_count", "qbh_strerror", "qbh_last_error", "qbh_opts_default", "qbh_opts_set_default",
     "qbh_csr_create", "qbh_csr_create_rows", "qbh_balanced_row_cuts", "qbh_csr_create_device", "qbh_csr_destroy", "qbh_csr_get_info",
     "qbh_multmv", "qbh_multmv2",
-    "qbh_vec_alloc", "qbh_vec_free", "qbh_vec_upload", "qbh_vec_download", "qbh_vec_zero",
+    "qbh_vec_alloc", "qbh_vec_free", "qbh_vec_upload", "qbh_vec_download", "qbh_vec_zero", "qbh_vec_to_internal", "qbh_vec_from_internal",
     "qbh_vec_randomize",
     "qbh_spmv_dev", "qbh_dotc_dev", "qbh_axpy_norm_dev", "qbh_scal_dev", "qbh_nrm2_dev",
     "qbh_lanczos", "qbh_lanczos_dev", "qbh_lanczos_real_dev", "qbh_vec_randomize_real", "qbh_eigenvec_cg_real_dev", "qbh_eigenvec_cg", "qbh_eigenvec_cg_dev", "qbh_hess_eigen", "qbh_iram",
@@ -150,6 +152,8 @@ def lib():
     L.qbh_vec_upload.argtypes = [vp, vp, vp, i64]
     L.qbh_vec_download.argtypes = [vp, vp, vp, i64]
     L.qbh_vec_zero.argtypes = [vp, vp, i64]
+    L.qbh_vec_to_internal.argtypes = [vp, vp, vp]
+    L.qbh_vec_from_internal.argtypes = [vp, vp, vp]
     L.qbh_vec_randomize.argtypes = [vp, vp, C.c_uint32]
     L.qbh_spmv_dev.argtypes = [vp, vp, vp, dbl, dbl, dbl, vp]
     L.qbh_dotc_dev.argtypes = [vp, vp, vp, vp]

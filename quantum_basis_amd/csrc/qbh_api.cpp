@@ -41,7 +41,7 @@ static void parse_debug(const char *e, DebugSw &d)
     const Key keys[] = {{"flags", &d.flags, nullptr}, {"colmask", &d.colmask, nullptr}, {"tpr", &d.tpr, nullptr}, {"unroll", &d.unroll, nullptr},
                         {"grid", &d.grid, nullptr}, {"wave_tpr", &d.wave_tpr, nullptr}, {"chunk_mult", &d.chunk_mult, nullptr},
                         {"trace_create", &d.trace_create, nullptr}, {"trace_tune", &d.trace_tune, nullptr}, {"trace_dict", &d.trace_dict, nullptr},
-                        {"print_ptrs", &d.print_ptrs, nullptr}, {"sec_walk", &d.sec_walk, nullptr}, {"sec_grid", &d.sec_grid, nullptr},
+                        {"print_ptrs", &d.print_ptrs, nullptr}, {"sec_walk", &d.sec_walk, nullptr}, {"sec_grid", &d.sec_grid, nullptr}, {"sec_nt", &d.sec_nt, nullptr}, {"sec_tile", &d.sec_tile, nullptr},
                         {"sec_unroll", &d.sec_unroll, nullptr}, {"wave_pipelined", &d.wave_pipelined, nullptr}, {"create_chunk", nullptr, &d.create_chunk},
                         {"force_ragged", &d.force_ragged, nullptr}, {"mf_row", &d.mf_row, nullptr}, {"mf_chunk", &d.mf_chunk, nullptr},
                         {"mf_window", &d.mf_window, nullptr}, {"kronc_abl", &d.kronc_abl, nullptr}, {"kronc_far_chunk", &d.kronc_far_chunk, nullptr},
@@ -180,6 +180,7 @@ void qbh::opts_builtin(qbh_opts *o)
     o->shard_split = 1;
     o->real_forms = 7;
     o->basis_detect = 1;
+    o->sector_orbit = 1;
     o->kron_minor = 0;
     o->deterministic = 0;
     o->basis_kind = QBH_BASIS_NONE;
@@ -699,7 +700,8 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
     }
     if (A->mfsec) {
         for (void *q : {(void *)A->mfsec->blk, (void *)A->mfsec->hop, (void *)A->mfsec->item, (void *)A->mfsec->ucfg,
-                        (void *)A->mfsec->upell, (void *)A->mfsec->prank, (void *)A->mfsec->rrow, (void *)A->mfsec->ria,
+                        (void *)A->mfsec->upell, (void *)A->mfsec->prank, (void *)A->mfsec->oid, (void *)A->mfsec->oek, (void *)A->mfsec->tpar,
+                        (void *)A->mfsec->usgn, (void *)A->mfsec->utab, (void *)A->mfsec->uext, (void *)A->mfsec->rrow, (void *)A->mfsec->ria,
                         (void *)A->mfsec->rja, (void *)A->mfsec->rval, (void *)A->d_mfsec})
             if (q) (void)hipFree(q);
         delete A->mfsec;
@@ -984,8 +986,8 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
                               3 * (int64_t)A->mfh.n_bonds) * 8;
     if (A->kind == 3 && A->mfsec) {
         const qbh::MfSec &m = *A->mfsec;
-        info->bytes_matrix = m.n_blocks * (int64_t)sizeof(qbh::MfSecBlock) + m.n_items * 8 + m.cu * 4 * (1 + m.w_up + m.n_trans) +
-                             m.n_rrows * 12 + m.rnnz * 20;
+        info->bytes_matrix = m.n_blocks * (int64_t)sizeof(qbh::MfSecBlock) + m.n_items * 8 + m.n_rrows * 12 + m.rnnz * 20 +
+                             (m.orbit ? m.cu * 26 + m.n_orb * m.w_orb * 6 : m.cu * 4 * (1 + m.w_up + m.n_trans));
     }
     info->kernel = A->kind != 0 ? QBH_KERNEL_MATRIX_FREE : A->use_wave ? QBH_KERNEL_WAVE : A->kernel;
     info->value_dict = A->d_code ? A->n_dict : 0;
@@ -1175,6 +1177,28 @@ extern "C" int qbh_vec_zero(const qbh_csr *A, qbh_z *d, int64_t n)
     Bind bind(A);
     QBH_HIP(hipMemsetAsync(d, 0, (size_t)n * sizeof(qbh_z), A->stream));
     return QBH_OK;
+}
+
+extern "C" int qbh_vec_to_internal(const qbh_csr *A, qbh_z *d_dst, const qbh_z *d_src)
+{
+    if (!A || !d_dst || !d_src || d_dst == d_src) return QBH_EINVAL;
+    Bind bind(A);
+    if (A->basis.kind == 0) {
+        QBH_HIP(hipMemcpyAsync(d_dst, d_src, (size_t)A->nrows * sizeof(qbh_z), hipMemcpyDeviceToDevice, A->stream));
+        return QBH_OK;
+    }
+    return qbh::launch_basis_scatter(A->basis.d_map, reinterpret_cast<const d2 *>(d_src), reinterpret_cast<d2 *>(d_dst), A->nrows, A->stream);
+}
+
+extern "C" int qbh_vec_from_internal(const qbh_csr *A, qbh_z *d_dst, const qbh_z *d_src)
+{
+    if (!A || !d_dst || !d_src || d_dst == d_src) return QBH_EINVAL;
+    Bind bind(A);
+    if (A->basis.kind == 0) {
+        QBH_HIP(hipMemcpyAsync(d_dst, d_src, (size_t)A->nrows * sizeof(qbh_z), hipMemcpyDeviceToDevice, A->stream));
+        return QBH_OK;
+    }
+    return qbh::launch_basis_gather(A->basis.d_map, reinterpret_cast<const d2 *>(d_src), reinterpret_cast<d2 *>(d_dst), A->nrows, A->stream);
 }
 
 extern "C" int qbh_vec_randomize(const qbh_csr *Ac, qbh_z *d_x, uint32_t seed)

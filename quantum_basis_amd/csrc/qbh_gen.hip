@@ -2474,7 +2474,7 @@ extern "C" int qbh_mopr_c_hubrepr_dev(int n_sites, int n_up_old, int n_dn_old, i
 namespace qbh {
 namespace {
 
-constexpr int kSecTile = 1024;
+constexpr int kSecTile = 1024;     // rows of one work item unless the debug knob sec_tile says otherwise (MfSec::tile)
 
 // row i of the remainder: full row for a stabilised block, otherwise only the flagged down hops (bit t of flags[blk])
 __device__ int hubrepr_row_rem(const HubReprDev &R, const uint64_t *tab, const uint64_t *reps, const uint8_t *info, int64_t dim,
@@ -2587,6 +2587,42 @@ __global__ __launch_bounds__(128) void k_secrem_fill(const HubReprDev *Rp, const
     }
 }
 
+// ---- orbit order (MfSec): indices of the ascending order -> positions
+__device__ __forceinline__ int64_t sec_orbit_index(const MfSecBlock *blk, int64_t n_blocks, const uint32_t *opos, int64_t i)
+{
+    int64_t lo = 0, hi = n_blocks - 1;                 // last block with row0 <= i
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (blk[mid].row0 <= i) lo = mid;
+        else hi = mid - 1;
+    }
+    const MfSecBlock B = blk[lo];
+    return B.regular ? B.row0 + (int64_t)opos[i - B.row0] : i;
+}
+__global__ __launch_bounds__(256) void k_sec_orbit_remap(const MfSecBlock *blk, int64_t n_blocks, const uint32_t *opos, int32_t *rrow,
+                                                         int64_t n_rrows, int32_t *rja, int64_t rnnz)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n_rrows; q += stride)
+        rrow[q] = (int32_t)sec_orbit_index(blk, n_blocks, opos, rrow[q]);
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < rnnz; q += stride)
+        rja[q] = (int32_t)sec_orbit_index(blk, n_blocks, opos, rja[q]);
+}
+__global__ __launch_bounds__(256) void k_sec_orbit_map(const MfSecBlock *blk, const int64_t *item, int64_t n_items, const uint32_t *opos,
+                                                       uint32_t *map, int tile_rows)
+{
+    for (int64_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const int64_t w = item[it];
+        const MfSecBlock B = blk[w >> 20];
+        const int tile = (int)(w & 0xFFFFF);
+        for (int j = 0; j < tile_rows / 256; ++j) {
+            const int r = tile * tile_rows + j * 256 + (int)threadIdx.x;
+            if (r >= B.nrows) break;
+            map[B.row0 + r] = (uint32_t)(B.row0 + (B.regular ? (int64_t)opos[r] : (int64_t)r));
+        }
+    }
+}
+
 constexpr int kSecMaxHops = 128;
 
 // y <- alpha MF(x) + beta y + gamma x for every row.  One work item = 1024 rows of one down block; an XCD takes a
@@ -2620,8 +2656,8 @@ __global__ __launch_bounds__(256) void k_mf_sector(MfSecArgs a)
         if (B.regular)
             for (int h = threadIdx.x; h < B.nhop; h += 256) sh[h] = T.hop[B.hop0 + h];
         __syncthreads();
-        for (int j = 0; j < kSecTile / 256; ++j) {
-            const int r = tile * kSecTile + j * 256 + (int)threadIdx.x;
+        for (int j = 0; j < T.tile / 256; ++j) {
+            const int r = tile * T.tile + j * 256 + (int)threadIdx.x;
             if (r >= B.nrows) break;
             const int64_t row = B.row0 + r;
             d2 sum = {0.0, 0.0};
@@ -2695,6 +2731,143 @@ __global__ __launch_bounds__(256) void k_mf_sector(MfSecArgs a)
     }
 }
 
+// The same product with the rows of a regular block in ORBIT ORDER (MfSec): no per-row rank tables.  A down hop reads the target
+// block at the positions of the tile itself, permuted inside runs of <= n_trans rows (coalesced; every block is read front to
+// back once per hop that lands in it, whatever the L2 holds); an up hop reads a run of the block's own x named by the ORBIT's
+// slot table.  Per row and block 26 bytes of tables (pattern, orbit, element | kind, two sign masks) instead of
+// 4 (w_up + nhop) = 170; the group tables (composition, position inside an orbit per stabiliser kind) sit in LDS.
+// NT: the streams that are read once -- the row tables, the target blocks of the down hops, old y -- are loaded non-temporally so
+// that they do not push the block's own x (read ~ w_up times by the up hops) out of the L2.  ORD: items drawn from per-XCD counters.
+template <typename V>
+__device__ __forceinline__ V sec_ld(const V *p, bool nt)
+{
+    return nt ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool REALX, int kSecUnroll, bool NT, bool ORD>
+__global__ __launch_bounds__(256) void k_mf_sector_orb(MfSecArgs a)
+{
+    const MfSec &T = *a.t;
+    __shared__ MfSecHop sh[kSecMaxHops];
+    __shared__ int64_t s_item;
+    __shared__ uint8_t s_comp[64 * 64];
+    __shared__ uint8_t s_kidx[16 * 64];
+    __shared__ double s_dict[256];
+    for (int i = threadIdx.x; i < 64 * 64 / 4; i += 256) reinterpret_cast<uint32_t *>(s_comp)[i] = reinterpret_cast<const uint32_t *>(T.comp)[i];
+    for (int i = threadIdx.x; i < 16 * 64 / 4; i += 256) reinterpret_cast<uint32_t *>(s_kidx)[i] = reinterpret_cast<const uint32_t *>(T.kidx)[i];
+    s_dict[threadIdx.x] = T.updict[threadIdx.x];
+    const int64_t n_orb = T.n_orb;
+    const int W = T.w_orb;
+    const int nslot = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
+    const int64_t per = (a.n_items + 7) >> 3, xbase = xcd * per, xend = xbase + per < a.n_items ? xbase + per : a.n_items;
+    for (int64_t base = 0; ORD || base < a.n_items; base += gridDim.x) {
+        int64_t it = base + (int64_t)xcd * nslot + slot;
+        __syncthreads();
+        if (ORD) {
+            if (threadIdx.x == 0) s_item = xbase + (int64_t)atomicInc(a.ctr + xcd * 32, 0xFFFFFFFFu);
+            __syncthreads();
+            it = s_item;
+            if (it >= xend) break;
+        }
+        if (it >= a.n_items) continue;
+        const int64_t w = T.item[it];
+        const MfSecBlock B = T.blk[w >> 20];
+        const int tile = (int)(w & 0xFFFFF);
+        if (B.regular)
+            for (int h = threadIdx.x; h < B.nhop; h += 256) sh[h] = T.hop[B.hop0 + h];
+        __syncthreads();
+        for (int j = 0; j < T.tile / 256; ++j) {
+            const int p = tile * T.tile + j * 256 + (int)threadIdx.x;
+            if (p >= B.nrows) break;
+            const int64_t row = B.row0 + p;
+            d2 sum = {0.0, 0.0};
+            if (B.regular) {
+                const uint32_t u = sec_ld(T.ucfg + p, NT), d = B.d, o = sec_ld(T.oid + p, NT), ek = sec_ld(T.oek + p, NT);
+                const uint64_t tp = sec_ld(T.tpar + p, NT), us = sec_ld(T.usgn + p, NT);
+                const int e = (int)(ek & 63u), kind = (int)(ek >> 6);
+                const uint8_t *kx = s_kidx + kind * 64;
+                const int64_t pb = B.row0 + p - (int)kx[e];              // the orbit's first member in this block
+                double dr = T.U * (double)__popc(u & d);
+                for (int q = 0; q < T.n_pairs; ++q) {
+                    const int iu = (u >> T.pi[q]) & 1, id = (d >> T.pi[q]) & 1, ju = (u >> T.pj[q]) & 1, jd = (d >> T.pj[q]) & 1;
+                    dr += T.pv[q][0] * (iu & ju) + T.pv[q][1] * (iu & jd) + T.pv[q][2] * (id & ju) + T.pv[q][3] * (id & jd);
+                }
+                if (T.has_number_terms) {
+                    for (uint32_t m = u; m; m &= m - 1) dr += T.nup[__ffs(m) - 1];
+                    for (uint32_t m = d; m; m &= m - 1) dr += T.ndn[__ffs(m) - 1];
+                }
+                if (REALX) sum.x = dr * a.xr[row];
+                else       sum = dr * a.xg[row];
+                const uint8_t *ce = s_comp + e * 64;                      // comp[e][s]
+                for (int k0 = 0; k0 < W; k0 += kSecUnroll) {              // up hops: runs of the block's own x
+                    uint32_t en[kSecUnroll], ex[kSecUnroll];
+#pragma unroll
+                    for (int q = 0; q < kSecUnroll; ++q) en[q] = k0 + q < W ? T.utab[(size_t)(k0 + q) * (size_t)n_orb + o] : 0u;
+#pragma unroll
+                    for (int q = 0; q < kSecUnroll; ++q)                   // rare: another amplitude than the first, a stabilised target orbit
+                        ex[q] = (en[q] & (1u << 30)) ? (uint32_t)T.uext[(size_t)(k0 + q) * (size_t)n_orb + o] : 0u;
+                    int64_t ix[kSecUnroll];
+#pragma unroll
+                    for (int q = 0; q < kSecUnroll; ++q)
+                        ix[q] = B.row0 + (int64_t)(en[q] & 0xFFFFFFu) + (int)s_kidx[(int)(ex[q] >> 8) * 64 + (int)ce[(int)((en[q] >> 24) & 63u)]];
+                    if (REALX) {
+                        double xv[kSecUnroll];
+#pragma unroll
+                        for (int q = 0; q < kSecUnroll; ++q) xv[q] = (en[q] >> 31) ? a.xr[ix[q]] : 0.0;
+#pragma unroll
+                        for (int q = 0; q < kSecUnroll; ++q) {
+                            const double am = s_dict[(int)(ex[q] & 255u)];
+                            sum.x += (((us >> (k0 + q)) & 1ULL) ? -am : am) * xv[q];
+                        }
+                    } else {
+                        d2 xv[kSecUnroll];
+#pragma unroll
+                        for (int q = 0; q < kSecUnroll; ++q) xv[q] = (en[q] >> 31) ? a.xg[ix[q]] : d2{0.0, 0.0};
+#pragma unroll
+                        for (int q = 0; q < kSecUnroll; ++q) {
+                            const double am = s_dict[(int)(ex[q] & 255u)];
+                            sum += (((us >> (k0 + q)) & 1ULL) ? -am : am) * xv[q];
+                        }
+                    }
+                    if (!(en[kSecUnroll - 1] >> 31)) break;
+                }
+                for (int h0 = 0; h0 < B.nhop; h0 += kSecUnroll) {          // down hops into regular blocks: the same positions there
+                    int64_t ix[kSecUnroll];
+#pragma unroll
+                    for (int q = 0; q < kSecUnroll; ++q) {
+                        const int hh = h0 + q < B.nhop ? h0 + q : 0;
+                        ix[q] = sh[hh].off - B.row0 + pb + (int)kx[(int)s_comp[sh[hh].g * 64 + e]];
+                    }
+                    if (REALX) {
+                        double xv[kSecUnroll];
+#pragma unroll
+                        for (int q = 0; q < kSecUnroll; ++q) xv[q] = h0 + q < B.nhop ? sec_ld(a.xr + ix[q], NT) : 0.0;
+#pragma unroll
+                        for (int q = 0; q < kSecUnroll; ++q)
+                            if (h0 + q < B.nhop) sum.x += (((tp >> sh[h0 + q].g) & 1ULL) ? -sh[h0 + q].cr : sh[h0 + q].cr) * xv[q];
+                    } else {
+                        d2 xv[kSecUnroll];
+#pragma unroll
+                        for (int q = 0; q < kSecUnroll; ++q) xv[q] = h0 + q < B.nhop ? sec_ld(a.xg + ix[q], NT) : d2{0.0, 0.0};
+#pragma unroll
+                        for (int q = 0; q < kSecUnroll; ++q)
+                            if (h0 + q < B.nhop) {
+                                const double sg = ((tp >> sh[h0 + q].g) & 1ULL) ? -1.0 : 1.0;
+                                const double cr = sg * sh[h0 + q].cr, ci = sg * sh[h0 + q].ci;
+                                sum += d2{cr * xv[q].x - ci * xv[q].y, cr * xv[q].y + ci * xv[q].x};
+                            }
+                    }
+                }
+            }
+            d2 yo = {0.0, 0.0}, xi = {0.0, 0.0};
+            if (a.beta != 0.0) yo = a.y_re ? d2{sec_ld(a.y_re + row, NT), 0.0} : sec_ld(a.y + row, NT);
+            if (a.gamma != 0.0) xi = a.y_re ? d2{a.xl_re[row], 0.0} : a.xl[row];
+            const d2 yn = a.alpha * sum + a.beta * yo + a.gamma * xi;
+            if (a.y_re) a.y_re[row] = yn.x;
+            else        a.y[row] = yn;
+        }
+    }
+}
+
 // the stored remainder: one lane per row that has entries
 template <bool REALX>
 __global__ __launch_bounds__(256) void k_sec_remainder(MfSecArgs a)
@@ -2743,6 +2916,28 @@ __global__ __launch_bounds__(256) void k_sec_reduce(MfSecArgs a)
 }  // namespace
 
 template <bool REALX, int UN>
+static int sector_orbit_launch_t(const MfSecArgs &a, hipStream_t s)
+{
+    static int occ = 0;
+    if (occ == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mf_sector_orb<REALX, UN, true, false>, 256, 0) != hipSuccess || n <= 0) n = 4;
+        occ = n;
+    }
+    int grid = 256 * occ;
+    if (debug_sw().sec_grid >= 8) grid = (debug_sw().sec_grid / 8) * 8;
+    const bool nt = debug_sw().sec_nt != 0;
+    if (a.ctr != nullptr) {
+        if (nt) hipLaunchKernelGGL((k_mf_sector_orb<REALX, UN, true, true>), dim3(grid), dim3(256), 0, s, a);
+        else    hipLaunchKernelGGL((k_mf_sector_orb<REALX, UN, false, true>), dim3(grid), dim3(256), 0, s, a);
+    } else {
+        if (nt) hipLaunchKernelGGL((k_mf_sector_orb<REALX, UN, true, false>), dim3(grid), dim3(256), 0, s, a);
+        else    hipLaunchKernelGGL((k_mf_sector_orb<REALX, UN, false, false>), dim3(grid), dim3(256), 0, s, a);
+    }
+    return QBH_OK;
+}
+
+template <bool REALX, int UN>
 static int sector_launch_t(const MfSecArgs &a, hipStream_t s)
 {
     // persistent grid: exactly the resident workgroups (a multiple of 8), so that the XCD-contiguous item order holds
@@ -2766,7 +2961,15 @@ int launch_mf_sector(const MfSecArgs &a, hipStream_t s, int *nparts_out)
         un = 8;
         if (debug_sw().sec_unroll) un = debug_sw().sec_unroll;              // tuning experiments: 4, 8, 16
     }
-    if (a.xr != nullptr) {
+    if (a.orbit) {
+        if (a.xr != nullptr) {
+            if (un == 4) sector_orbit_launch_t<true, 4>(a, s);
+            else         sector_orbit_launch_t<true, 8>(a, s);
+        } else {
+            if (un == 4) sector_orbit_launch_t<false, 4>(a, s);
+            else         sector_orbit_launch_t<false, 8>(a, s);
+        }
+    } else if (a.xr != nullptr) {
         if (un == 4)       sector_launch_t<true, 4>(a, s);
         else if (un == 16) sector_launch_t<true, 16>(a, s);
         else               sector_launch_t<true, 8>(a, s);
@@ -2937,6 +3140,192 @@ extern "C" int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_d
             }
             upell[k * (size_t)cu + (size_t)r] = ((uint32_t)code << 24) | uprow[(size_t)r][k].first;
         }
+    // ---- the orbit order of the up patterns (MfSec, qbh_opts.sector_orbit): built and CHECKED here, position by position and
+    // translation by translation / slot by slot, against the rank tables above; anything that does not hold (translations that
+    // are not a group, up amplitudes that are not translation invariant, too many stabiliser kinds or slots) keeps the
+    // ascending order and the rank tables
+    int sec_tile = kSecTile;
+    if (debug_sw().sec_tile == 256 || debug_sw().sec_tile == 512 || debug_sw().sec_tile == 2048) sec_tile = debug_sw().sec_tile;
+    const bool want_orbit = opts ? opts->sector_orbit != 0 : true;
+    bool orbit = want_orbit && n_trans <= 64;
+    std::vector<uint32_t> opos, oid, ucfg_o;        // old rank -> position; orbit of a position; pattern at a position
+    std::vector<uint16_t> oek;
+    std::vector<uint64_t> tpar, usgn;
+    std::vector<uint32_t> utab;                     // base' | s << 24 | ext << 30 | valid << 31
+    std::vector<uint16_t> uext;                     // code | kind' << 8 of the slots whose ext bit is set
+    std::vector<uint8_t> gcomp((size_t)64 * 64, 0), kidx((size_t)16 * 64, 0);
+    int w_orb = 0, n_kinds = 0;
+    int64_t n_orb = 0;
+    std::vector<double> odict;
+    if (orbit) {
+        for (int a = 0; a < n_trans && orbit; ++a)          // comp[a][b]: "b, then a"
+            for (int b = 0; b < n_trans && orbit; ++b) {
+                int c = -1;
+                for (int q = 0; q < n_trans && c < 0; ++q) {
+                    bool same = true;
+                    for (int st = 0; st < n_sites && same; ++st)
+                        same = perms[(size_t)q * n_sites + st] == perms[(size_t)a * n_sites + perms[(size_t)b * n_sites + st]];
+                    if (same) c = q;
+                }
+                if (c < 0) orbit = false;
+                else gcomp[(size_t)a * 64 + b] = (uint8_t)c;
+            }
+        for (int a = 0; a < n_trans && orbit; ++a)          // distinct elements
+            for (int b = a + 1; b < n_trans && orbit; ++b) {
+                bool same = true;
+                for (int st = 0; st < n_sites && same; ++st) same = perms[(size_t)a * n_sites + st] == perms[(size_t)b * n_sites + st];
+                if (same) orbit = false;
+            }
+    }
+    if (orbit) {
+        std::vector<int32_t> orb_of((size_t)cu, -1);
+        std::vector<uint8_t> elem((size_t)cu, 0), kind_of_orb;
+        std::vector<uint32_t> base_of_orb, rep_of_orb;
+        std::vector<uint64_t> kind_mask;                  // stabiliser (bit a: image(a, u0) = u0) of every kind
+        opos.assign((size_t)cu, 0);
+        uint32_t nextpos = 0;
+        for (int64_t r = 0; r < cu && orbit; ++r) {
+            if (orb_of[(size_t)r] >= 0) continue;
+            const int32_t o = (int32_t)base_of_orb.size();
+            uint64_t stab = 0;
+            uint8_t idx_here[64];
+            int nm = 0;
+            for (int a = 0; a < n_trans; ++a) {
+                const int64_t rk = (int64_t)(prank[(size_t)a * cu + r] & 0x7FFFFFFFu);
+                if (rk == r) stab |= 1ULL << a;
+                if (orb_of[(size_t)rk] < 0) {
+                    orb_of[(size_t)rk] = o;
+                    elem[(size_t)rk] = (uint8_t)a;
+                    opos[(size_t)rk] = nextpos + (uint32_t)nm;
+                    ++nm;
+                }
+                idx_here[a] = (uint8_t)(opos[(size_t)rk] - nextpos);
+            }
+            int kd = -1;
+            for (size_t q = 0; q < kind_mask.size(); ++q)
+                if (kind_mask[q] == stab) kd = (int)q;
+            if (kd < 0) {
+                if (kind_mask.empty() && __builtin_popcountll(stab) != 1) {     // kind 0 is the trivial stabiliser: reserve it
+                    uint64_t triv = 0;
+                    for (int a = 0; a < n_trans; ++a) {
+                        bool ident = true;
+                        for (int st = 0; st < n_sites && ident; ++st) ident = perms[(size_t)a * n_sites + st] == st;
+                        if (ident) triv |= 1ULL << a;
+                    }
+                    if (__builtin_popcountll(triv) != 1) { orbit = false; break; }
+                    kind_mask.push_back(triv);
+                    for (int a = 0; a < n_trans; ++a) kidx[(size_t)a] = (uint8_t)a;
+                }
+                if (kind_mask.size() >= 16) { orbit = false; break; }
+                kd = (int)kind_mask.size();
+                kind_mask.push_back(stab);
+                for (int a = 0; a < n_trans; ++a) kidx[(size_t)kd * 64 + a] = idx_here[a];
+            } else {
+                for (int a = 0; a < n_trans; ++a)
+                    if (kidx[(size_t)kd * 64 + a] != idx_here[a]) orbit = false;
+            }
+            kind_of_orb.push_back((uint8_t)kd);
+            base_of_orb.push_back(nextpos);
+            rep_of_orb.push_back((uint32_t)r);
+            nextpos += (uint32_t)nm;
+        }
+        if (orbit && !kind_mask.empty() && __builtin_popcountll(kind_mask[0]) == 1) {
+            for (int a = 0; a < n_trans; ++a)
+                if (kidx[(size_t)a] != (uint8_t)a) orbit = false;     // kind 0: position inside the orbit = the group element
+        } else if (orbit && !kind_mask.empty()) {
+            orbit = false;                                 // no orbit with a trivial stabiliser came first and none was reserved
+        }
+        n_orb = (int64_t)base_of_orb.size();
+        n_kinds = (int)kind_mask.size();
+        if (orbit) {
+            ucfg_o.assign((size_t)cu, 0);
+            oid.assign((size_t)cu, 0);
+            oek.assign((size_t)cu, 0);
+            tpar.assign((size_t)cu, 0);
+            usgn.assign((size_t)cu, 0);
+            for (int64_t r = 0; r < cu; ++r) {
+                const uint32_t pp = opos[(size_t)r];
+                const int32_t o = orb_of[(size_t)r];
+                ucfg_o[pp] = ucfg[(size_t)r];
+                oid[pp] = (uint32_t)o;
+                oek[pp] = (uint16_t)(elem[(size_t)r] | (kind_of_orb[(size_t)o] << 6));
+                uint64_t tp = 0;
+                for (int g = 0; g < n_trans; ++g) tp |= (uint64_t)(prank[(size_t)g * cu + r] >> 31) << g;
+                tpar[pp] = tp;
+            }
+            // down hops: the translated pattern sits at  p - kidx[kind][e] + kidx[kind][comp[g][e]]
+            for (int64_t r = 0; r < cu && orbit; ++r) {
+                const uint32_t pp = opos[(size_t)r];
+                const int e = oek[pp] & 63, kd = oek[pp] >> 6;
+                for (int g = 0; g < n_trans; ++g) {
+                    const uint32_t want = opos[(size_t)(prank[(size_t)g * cu + r] & 0x7FFFFFFFu)];
+                    const uint32_t got = pp - kidx[(size_t)kd * 64 + e] + kidx[(size_t)kd * 64 + gcomp[(size_t)g * 64 + e]];
+                    if (want != got) { orbit = false; break; }
+                }
+            }
+        }
+        // up hops: the slots of an orbit are the allowed terms of its smallest member, in term order
+        if (orbit) {
+            std::vector<std::vector<uint64_t>> slots((size_t)n_orb);
+            std::vector<std::vector<int>> slot_term((size_t)n_orb);
+            for (int64_t o = 0; o < n_orb && orbit; ++o) {
+                const uint32_t u0 = ucfg[(size_t)rep_of_orb[(size_t)o]];
+                for (int t = 0; t < R.n_terms; ++t) {
+                    const int ti = R.ti[t], tj = R.tj[t];
+                    if (ti == tj || R.aup[t][0] * R.aup[t][0] < 1e-28) continue;
+                    if (!((u0 >> ti) & 1u) || ((u0 >> tj) & 1u)) continue;
+                    const uint32_t v = u0 ^ (1u << ti) ^ (1u << tj);
+                    const int64_t rv = (int64_t)(std::lower_bound(ucfg.begin(), ucfg.end(), v) - ucfg.begin());
+                    const int32_t o2 = orb_of[(size_t)rv];
+                    size_t code = std::find(odict.begin(), odict.end(), R.aup[t][0]) - odict.begin();
+                    if (code == odict.size()) {
+                        if (odict.size() >= 255) { orbit = false; break; }
+                        odict.push_back(R.aup[t][0]);
+                    }
+                    slots[(size_t)o].push_back((uint64_t)base_of_orb[(size_t)o2] | ((uint64_t)elem[(size_t)rv] << 24) | ((uint64_t)code << 32) |
+                                               ((uint64_t)kind_of_orb[(size_t)o2] << 40) | (1ULL << 63));
+                    slot_term[(size_t)o].push_back(t);
+                }
+                w_orb = std::max(w_orb, (int)slots[(size_t)o].size());
+            }
+            if (w_orb > 64) orbit = false;
+            if (orbit) {
+                utab.assign((size_t)std::max(w_orb, 1) * (size_t)n_orb, 0u);
+                uext.assign((size_t)std::max(w_orb, 1) * (size_t)n_orb, 0);
+                for (int64_t o = 0; o < n_orb; ++o)
+                    for (size_t k = 0; k < slots[(size_t)o].size(); ++k) {
+                        const uint64_t en = slots[(size_t)o][k];
+                        const uint32_t code = (uint32_t)((en >> 32) & 255u), kd2 = (uint32_t)((en >> 40) & 63u);
+                        const bool ext = code != 0 || kd2 != 0;
+                        utab[k * (size_t)n_orb + (size_t)o] = (uint32_t)(en & 0x3FFFFFFFu) | (ext ? 1u << 30 : 0u) | (1u << 31);
+                        uext[k * (size_t)n_orb + (size_t)o] = (uint16_t)(code | (kd2 << 8));
+                    }
+            }
+            // every member: the image of slot k is an allowed term of the same amplitude, lands where the table says, and the
+            // member has no other hop
+            for (int64_t r = 0; r < cu && orbit; ++r) {
+                const uint32_t pp = opos[(size_t)r], u = ucfg[(size_t)r];
+                const int32_t o = orb_of[(size_t)r];
+                const int e = oek[pp] & 63;
+                uint64_t sg = 0;
+                if (slots[(size_t)o].size() != uprow[(size_t)r].size()) { orbit = false; break; }
+                for (size_t k = 0; k < slots[(size_t)o].size() && orbit; ++k) {
+                    const int t = slot_term[(size_t)o][k];
+                    const int i2 = perms[(size_t)e * n_sites + R.ti[t]], j2 = perms[(size_t)e * n_sites + R.tj[t]];
+                    const auto f = tmap.find({i2, j2});
+                    if (f == tmap.end() || f->second[0] != R.aup[t][0] || !((u >> i2) & 1u) || ((u >> j2) & 1u)) { orbit = false; break; }
+                    const uint32_t v = u ^ (1u << i2) ^ (1u << j2);
+                    const int64_t rv = (int64_t)(std::lower_bound(ucfg.begin(), ucfg.end(), v) - ucfg.begin());
+                    const uint64_t ent = slots[(size_t)o][k];
+                    const uint32_t got = (uint32_t)(ent & 0xFFFFFFu) +
+                                         kidx[(size_t)((ent >> 40) & 63) * 64 + gcomp[(size_t)e * 64 + (size_t)((ent >> 24) & 63)]];
+                    if (opos[(size_t)rv] != got) { orbit = false; break; }
+                    if (between_par(u, i2, j2)) sg |= 1ULL << k;
+                }
+                usgn[pp] = sg;
+            }
+        }
+    }
     // canonical down patterns, their stabilisers, the rows of every block
     struct HostBlock { uint32_t d; std::vector<int> stab; int64_t nrows, row0; };
     std::vector<HostBlock> hb;
@@ -2998,7 +3387,7 @@ extern "C" int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_d
         B.regular = b.stab.empty() ? 1 : 0;
         B.hop0 = (int32_t)hops.size();
         B.nhop = 0;
-        for (int64_t tl = 0; tl * kSecTile < b.nrows; ++tl) items.push_back((bi << 20) | tl);
+        for (int64_t tl = 0; tl * sec_tile < b.nrows; ++tl) items.push_back((bi << 20) | tl);
         if (!B.regular) continue;
         std::map<std::pair<int64_t, int>, std::pair<double, double>> acc;     // (target row0, g) -> coefficient
         for (int t = 0; t < R.n_terms; ++t) {
@@ -3047,7 +3436,8 @@ extern "C" int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_d
     int64_t dim_dev = 0;
     MfSec *ms = new MfSec();
     auto drop_tables = [&]() {
-        for (void *q : {(void *)ms->blk, (void *)ms->hop, (void *)ms->item, (void *)ms->ucfg, (void *)ms->upell, (void *)ms->prank})
+        for (void *q : {(void *)ms->blk, (void *)ms->hop, (void *)ms->item, (void *)ms->ucfg, (void *)ms->upell, (void *)ms->prank,
+                        (void *)ms->oid, (void *)ms->oek, (void *)ms->tpar, (void *)ms->usgn, (void *)ms->utab, (void *)ms->uext})
             if (q) (void)hipFree(q);
         delete ms;
     };
@@ -3069,9 +3459,21 @@ extern "C" int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_d
     up(&ms->blk, blk);
     up(&ms->hop, hops);
     up(&ms->item, items);
-    up(&ms->ucfg, ucfg);
-    up(&ms->upell, upell);
-    up(&ms->prank, prank);
+    uint32_t *d_opos = nullptr;                      // old rank -> position: for the remainder's indices and the vector map
+    if (orbit) {
+        up(&ms->ucfg, ucfg_o);
+        up(&ms->oid, oid);
+        up(&ms->oek, oek);
+        up(&ms->tpar, tpar);
+        up(&ms->usgn, usgn);
+        up(&ms->utab, utab);
+        up(&ms->uext, uext);
+        up(&d_opos, opos);
+    } else {
+        up(&ms->ucfg, ucfg);
+        up(&ms->upell, upell);
+        up(&ms->prank, prank);
+    }
     up(&d_flags, flags);
     if (rc == QBH_OK && e == hipSuccess) e = qbh::dev_alloc(&d_cnt, (size_t)dim * sizeof(int32_t));
     if (rc == QBH_OK && e == hipSuccess) e = qbh::dev_alloc(&d_flg, (size_t)dim * sizeof(int32_t));
@@ -3098,12 +3500,25 @@ extern "C" int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_d
                            ms->rrow, ms->ria, ms->rja, ms->rval);
         e = hipGetLastError();
     }
+    uint32_t *d_vmap = nullptr;                      // caller's row -> internal row (the handle's basis map)
+    if (rc == QBH_OK && e == hipSuccess && orbit) {
+        // the remainder was generated with the rows and columns of the ascending order: move both to the positions
+        hipLaunchKernelGGL(k_sec_orbit_remap, dim3(blas_grid(std::max<int64_t>(nnz, n_rrows))), dim3(256), 0, 0, ms->blk, n_blocks, d_opos,
+                           ms->rrow, n_rrows, ms->rja, nnz);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = qbh::dev_alloc(&d_vmap, (size_t)dim * sizeof(uint32_t));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_sec_orbit_map, dim3((unsigned)std::min<int64_t>((int64_t)items.size(), 1 << 20)), dim3(256), 0, 0, ms->blk,
+                               ms->item, (int64_t)items.size(), d_opos, d_vmap, sec_tile);
+            e = hipGetLastError();
+        }
+    }
     if (rc == QBH_OK && e == hipSuccess) e = hipDeviceSynchronize();
     free_pool(pool);
-    for (void *q : {(void *)d_reps, (void *)d_info, (void *)d_flags, (void *)d_ia, (void *)d_pos})
+    for (void *q : {(void *)d_reps, (void *)d_info, (void *)d_flags, (void *)d_ia, (void *)d_pos, (void *)d_opos})
         if (q) (void)hipFree(q);
     auto drop_all = [&]() {
-        for (void *q : {(void *)ms->rrow, (void *)ms->ria, (void *)ms->rja, (void *)ms->rval})
+        for (void *q : {(void *)ms->rrow, (void *)ms->ria, (void *)ms->rja, (void *)ms->rval, (void *)d_vmap})
             if (q) (void)hipFree(q);
         drop_tables();
     };
@@ -3124,10 +3539,20 @@ extern "C" int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_d
     ms->cu = cu;
     ms->n_blocks = n_blocks;
     ms->n_items = (int64_t)items.size();
+    ms->tile = sec_tile;
     ms->U = U;
     ms->n_rrows = n_rrows;
     ms->rnnz = nnz;
     for (size_t c = 0; c < updict.size(); ++c) ms->updict[c] = updict[c];
+    if (orbit) {
+        ms->orbit = 1;
+        ms->w_orb = w_orb;
+        ms->n_kinds = n_kinds;
+        ms->n_orb = n_orb;
+        for (size_t c = 0; c < 256; ++c) ms->updict[c] = c < odict.size() ? odict[c] : 0.0;
+        std::copy(gcomp.begin(), gcomp.end(), ms->comp);
+        std::copy(kidx.begin(), kidx.end(), ms->kidx);
+    }
     for (int t = 0; t < R.n_terms; ++t)
         if (R.ti[t] == R.tj[t]) {
             ms->nup[(int)R.ti[t]] += R.aup[t][0];
@@ -3181,6 +3606,10 @@ extern "C" int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_d
         (void)hipFree(d_ms);
         drop_all();
         return rc;
+    }
+    if (orbit) {                                     // device vectors of this handle are in the orbit order; the seams translate
+        (*out)->basis.kind = QBH_BASIS_SECTOR_ORBIT;
+        (*out)->basis.d_map = d_vmap;
     }
     if (dim_out) *dim_out = dim;
     return QBH_OK;

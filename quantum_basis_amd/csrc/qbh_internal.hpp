@@ -29,7 +29,7 @@ struct DebugSw {
     int colmask = 0;          // the mask for flags & 1 (0: 1023)
     int tpr = 0, unroll = 0, grid = 0, wave_tpr = 0, chunk_mult = 0;      // launch-geometry overrides
     int trace_create = 0, trace_tune = 0, trace_dict = 0, print_ptrs = 0;
-    int sec_walk = 0, sec_grid = 0, sec_unroll = 0;                       // matrix-free sector kernel
+    int sec_walk = -1, sec_grid = 0, sec_unroll = 0, sec_nt = -1, sec_tile = 0;   // matrix-free sector kernel
     int wave_pipelined = 0;   // the pipelined wave kernel on an unsplit operator
     long long create_chunk = 0;                                           // staging chunk of qbh_csr_create (nonzeros)
     int force_ragged = 0;     // native communicator: the send/recv all-gather-v even for uniform cuts
@@ -282,6 +282,7 @@ int basis_to_internal(qbh_csr *A, int kind, int n_sites, int n_up, int n_dn, boo
 int basis_detect(qbh_csr *A, bool *applied);     // qbh_opts.basis_detect: try every two-species basis of the operator's dimension
 int launch_basis_scatter(const uint32_t *map, const d2 *in, d2 *out, int64_t n, hipStream_t s);
 int launch_basis_gather(const uint32_t *map, const d2 *in, d2 *out, int64_t n, hipStream_t s);
+int launch_basis_scatter_re(const uint32_t *map, const double *in, double *out, int64_t n, hipStream_t s);
 
 // hipMalloc that releases live Kronecker splits (second copies of a matrix: acceleration structures, qbh_api.cpp) before it
 // reports out of memory.  Every allocation of the library except the splits' own goes through it.
@@ -448,7 +449,7 @@ struct MfSecHop {
     double  cr, ci;              // amplitude * hop sign * sign(g, down part) * conj(chi(g))
 };
 struct MfSec {
-    int      n_sites = 0, n_up = 0, n_dn = 0, n_trans = 0, w_up = 0, n_pairs = 0;
+    int      n_sites = 0, n_up = 0, n_dn = 0, n_trans = 0, w_up = 0, n_pairs = 0, tile = 1024;
     int64_t  dim = 0, cu = 0, n_blocks = 0, n_items = 0;
     double   U = 0.0;
     MfSecBlock *blk = nullptr;   // [n_blocks], ascending down pattern
@@ -458,6 +459,26 @@ struct MfSec {
     uint32_t   *upell = nullptr; // [w_up][cu]: code << 24 | target rank, 0xFFFFFFFF = none
     uint32_t   *prank = nullptr; // [n_trans][cu]: parity << 31 | rank of the translated up pattern
     double      updict[256] = {0};
+    // ORBIT ORDER of the rows of a regular block (qbh_opts.sector_orbit): position p holds the up pattern image(e, u0) of an
+    // orbit {image(g, u0)} of the translation group, the orbits one after the other (ascending smallest member u0), their
+    // members in ascending order of the first group element e that produces them.  A translated pattern is then a member of
+    // the SAME orbit -- a down hop reads its target block at the same positions, permuted inside runs of <= n_trans rows --
+    // and the up hops of a member are the images of the hops of u0, so their table is per orbit, not per row:
+    //   down hop (block B', translation g):  x[B'.row0 + p - kidx[kind][e] + kidx[kind][comp[g][e]]] * sign(bit g of tpar[p])
+    //   up hop, slot k of the orbit (target orbit at base', kind', group element s with hop_k(u0) = image(s, u0')):
+    //                                        x[B.row0 + base' + kidx[kind'][comp[e][s]]] * updict[code] * sign(bit k of usgn[p])
+    // comp[a][b] = the group element "b, then a"; kidx[kind][a] = position of image(a, u0) inside an orbit whose stabiliser
+    // is of that kind (kind 0: trivial stabiliser, kidx = identity).
+    int         orbit = 0, w_orb = 0, n_kinds = 0;
+    int64_t     n_orb = 0;
+    uint32_t   *oid = nullptr;   // [cu] orbit of position p
+    uint16_t   *oek = nullptr;   // [cu] e | kind << 6
+    uint64_t   *tpar = nullptr;  // [cu] bit g: parity of translation g on the up pattern at p
+    uint64_t   *usgn = nullptr;  // [cu] bit k: fermion sign of up-hop slot k for the pattern at p
+    uint32_t   *utab = nullptr;  // [w_orb][n_orb]: base' | s << 24 | ext << 30 | valid << 31
+    uint16_t   *uext = nullptr;  // [w_orb][n_orb]: code | kind' << 8, read only where ext is set (else code 0, kind' 0)
+    uint8_t     comp[64 * 64] = {0};
+    uint8_t     kidx[16 * 64] = {0};
     double      nup[32] = {0}, ndn[32] = {0};          // number-operator terms per site
     int8_t      pi[128] = {0}, pj[128] = {0};
     double      pv[128][4] = {{0}};
@@ -483,6 +504,7 @@ struct MfSecArgs {
     double alpha, beta, gamma;
     double *partials;            // [nparts * 3] or nullptr
     unsigned int *ctr;           // ordered walk: 8 zeroed counters, 128 bytes apart (nullptr: static assignment)
+    int orbit;                   // the tables are in orbit order (MfSec::orbit): k_mf_sector_orb
 };
 // y <- alpha H x + beta y + gamma x in three launches (block tables, remainder rows, reductions); *nparts_out = partial sums
 int launch_mf_sector(const MfSecArgs &a, hipStream_t s, int *nparts_out);

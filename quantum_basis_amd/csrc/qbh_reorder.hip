@@ -223,8 +223,23 @@ __global__ __launch_bounds__(256) void k_basis_gather(const uint32_t *map, const
     }
 }
 
+__global__ __launch_bounds__(256) void k_basis_scatter_re(const uint32_t *map, const double *in, double *out, int64_t n)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t m = map[r];
+        const double v = in[r];
+        out[m & 0x7FFFFFFFu] = (m >> 31) ? -v : v;
+    }
+}
+
 }  // namespace
 
+int launch_basis_scatter_re(const uint32_t *map, const double *in, double *out, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_basis_scatter_re, dim3(blas_grid(n)), dim3(256), 0, s, map, in, out, n);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
 int launch_basis_scatter(const uint32_t *map, const d2 *in, d2 *out, int64_t n, hipStream_t s)
 {
     hipLaunchKernelGGL(k_basis_scatter, dim3(blas_grid(n)), dim3(256), 0, s, map, in, out, n);

@@ -384,9 +384,15 @@ extern "C" int qbh_vec_randomize_real(const qbh_csr *Ac, double *d_x, uint32_t s
     if (!A || !d_x || seed == 0) return QBH_EINVAL;
     Bind bind(A);
     const int64_t nruns = (A->nrows + 15) / 16;
-    QBH_TRY(qbh::launch_randomize(nullptr, d_x, A->nrows, A->has_comm ? A->row_offset : 0, seed, A->d_partials, A->stream));
+    double *xr = d_x;                            // the Lehmer stream is indexed by the CALLER's element number (as qbh_vec_randomize)
+    if (A->basis.kind != 0) {
+        if (!A->basis.d_stage) QBH_HIP(qbh::dev_alloc(&A->basis.d_stage, (size_t)A->nrows * sizeof(d2)));
+        xr = reinterpret_cast<double *>(A->basis.d_stage);
+    }
+    QBH_TRY(qbh::launch_randomize(nullptr, xr, A->nrows, A->has_comm ? A->row_offset : 0, seed, A->d_partials, A->stream));
     double sq = 0.0;
     QBH_TRY(finish_reduction(A, qbh::blas_grid(nruns), 1, &sq));
+    if (xr != d_x) QBH_TRY(qbh::launch_basis_scatter_re(A->basis.d_map, xr, d_x, A->nrows, A->stream));
     return qbh::launch_scal_re(1.0 / std::sqrt(sq), d_x, A->nrows, A->stream);
 }
 

@@ -413,7 +413,10 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
             ms.beta = beta;
             ms.gamma = gamma;
             ms.partials = m.partials;
-            const int sec_walk = qbh::debug_sw().sec_walk;
+            ms.orbit = A->mfsec->orbit;
+            // items drawn from per-XCD counters: the orbit-order kernel by default (its workgroups finish far apart under a
+            // static assignment: 87 -> 61 ms on 4x5 with 8+8), the rank-table kernel only on request (it got slower: 223 -> 233 ms)
+            const int sec_walk = qbh::debug_sw().sec_walk < 0 ? (ms.orbit ? 1 : 0) : qbh::debug_sw().sec_walk;
             if (sec_walk) {
                 if (!A->d_wctr) QBH_HIP(qbh::dev_alloc(&A->d_wctr, qbh::kWctrRegions * 128 * sizeof(unsigned long long)));
                 QBH_HIP(hipMemsetAsync(A->d_wctr, 0, 3 * 128 * sizeof(unsigned long long), A->stream));

@@ -345,6 +345,14 @@ class csr_mat:
     def randomize(self, d_x, seed):
         check(lib().qbh_vec_randomize(self.handle, d_x, C.c_uint32(seed)), "qbh_vec_randomize")
 
+    def to_internal(self, d_dst, d_src):
+        """d_dst (this operator's internal order) <- d_src (the caller's order): device vectors of an operator with
+        info().basis_internal != 0 are in the internal order (qbh_vec_to_internal); a plain copy otherwise."""
+        check(lib().qbh_vec_to_internal(self.handle, d_dst, d_src), "qbh_vec_to_internal")
+
+    def from_internal(self, d_dst, d_src):
+        check(lib().qbh_vec_from_internal(self.handle, d_dst, d_src), "qbh_vec_from_internal")
+
     def sync(self):
         check(lib().qbh_sync(self.handle), "qbh_sync")
 

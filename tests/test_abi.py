@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert sorted(_lib.EXPORTS) == declared
-    assert L.qbh_version() == 500
+    assert L.qbh_version() == 501
 
 
 def test_struct_layouts_match_header():
@@ -45,6 +45,7 @@ int main(void) {
            offsetof(qbh_csr_info, kron_minor), offsetof(qbh_csr_info, kron_band), offsetof(qbh_csr_info, kron_sliced));
     printf("%zu %zu %zu %zu %zu\n", offsetof(qbh_opts, kron_cols16), offsetof(qbh_opts, gather_parts), offsetof(qbh_opts, basis_detect),
            offsetof(qbh_csr_info, kron_cols16), offsetof(qbh_csr_info, kron_table_kernel));
+    printf("%zu\n", offsetof(qbh_opts, sector_orbit));
     return 0;
 }
 """
@@ -56,7 +57,7 @@ int main(void) {
             C.sizeof(_lib.SolverInfo), _lib.Opts.kron_split.offset, _lib.Opts.kron_minor.offset, _lib.CsrInfo.kron_minor.offset,
             _lib.CsrInfo.kron_band.offset, _lib.CsrInfo.kron_sliced.offset,
             _lib.Opts.kron_cols16.offset, _lib.Opts.gather_parts.offset, _lib.Opts.basis_detect.offset, _lib.CsrInfo.kron_cols16.offset,
-            _lib.CsrInfo.kron_table_kernel.offset]
+            _lib.CsrInfo.kron_table_kernel.offset, _lib.Opts.sector_orbit.offset]
     assert got == want
 
 
@@ -69,7 +70,7 @@ def test_process_wide_default_options_for_a_host_whose_constructor_carries_none(
     assert (o.basis_kind, o.deterministic, o.kron_split, o.value_dict, o.real_fast_path) == (0, 0, 1, 1, 1)
     # the form switches that were environment variables up to ABI 400: their documented defaults
     assert (o.kron_cols16, o.kron_sliced, o.kron_band, o.kron_cross_in_near, o.kron_coded, o.kron_uniform, o.gather_parts, o.wave_walk, o.tile_fold,
-            o.autotune, o.shard_split, o.real_forms, o.basis_detect) == (1, 1, 0, 1, -1, 7, 0, -1, 1, 1, 1, 7, 1)
+            o.autotune, o.shard_split, o.real_forms, o.basis_detect, o.sector_orbit) == (1, 1, 0, 1, -1, 7, 0, -1, 1, 1, 1, 7, 1, 1)
     o.basis_kind, o.n_sites, o.n_up, o.n_dn = _lib.BASIS_REF_FERMION2, 16, 8, 8
     o.device, o.stream = 3, 0x1234                       # a default names no device and no stream: not kept
     L.qbh_opts_set_default(C.byref(o))

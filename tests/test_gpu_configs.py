@@ -222,17 +222,22 @@ def test_c4_as_written_half_filling_sector_full_size():
     S = q.csr_mat.hubbard_repr(n, nu, nu, bonds, perms, chars, t=1.0, U=1.1, shard=(0, 4))
     i = S.info()
     assert i.ncols == dim and i.row_offset == 0 and i.nrows == 426685540
-    v = M.vec(2)
+    assert M.info().basis_internal == _lib.BASIS_SECTOR_ORBIT                    # rows orbit by orbit of the up patterns
+    v, c = M.vec(2), M.vec(1)
     M.randomize(v.at(0), 11)
     M.spmv(v.at(0), v.at(dim))
     M.sync()
     ys = S.vec()
-    S.spmv(v.at(0), ys.ptr)                      # unsharded convention: x is the full-length vector
+    M.from_internal(c.ptr, v.at(0))              # the stored shard has the caller's (ascending) order
+    S.spmv(c.ptr, ys.ptr)                        # unsharded convention: x is the full-length vector
     S.sync()
     hy = S.nrm2(ys.ptr)
     assert hy > 0.0
-    assert np.sqrt(S.axpy_norm(-1.0, ys.ptr, v.at(dim))) <= 1e-13 * hy          # rows [0, nrows) of the matrix-free result
+    M.from_internal(c.ptr, v.at(dim))
+    M.sync()
+    assert np.sqrt(S.axpy_norm(-1.0, ys.ptr, c.ptr)) <= 1e-13 * hy               # rows [0, nrows) of the matrix-free result
     ys.free()
+    c.free()
     v.free()
     S.destroy()
     e0, m = _packed_lanczos_e0(M, maxit=600)

@@ -782,28 +782,46 @@ def test_matrix_free_sector_operator_equals_the_stored_one(Lx, Ly, nu, nd):
     for k in itertools.product(range(Lx), range(Ly)):
         chars = lattices.characters(shifts, k, (Lx, Ly))
         A = q.csr_mat.hubbard_repr(n, nu, nd, bonds, perms, chars, t=1.0, U=1.3, pairs=pairs)
+        # the two row orders of the matrix-free form: orbit by orbit of the up patterns (default; device vectors in that order,
+        # host vectors translated at the seams) and ascending (the rank-table kernel)
         M = q.csr_mat.hubbard_repr_mf(n, nu, nd, bonds, perms, chars, t=1.0, U=1.3, pairs=pairs)
+        M0 = q.csr_mat.hubbard_repr_mf(n, nu, nd, bonds, perms, chars, t=1.0, U=1.3, pairs=pairs, opts=q.make_opts(sector_orbit=0))
         dim = A.info().ncols
-        assert M.info().ncols == dim
+        assert M.info().ncols == dim and M0.info().ncols == dim
+        assert M.info().basis_internal == q._lib.BASIS_SECTOR_ORBIT and M0.info().basis_internal == 0
         x = rng.standard_normal(dim) + 1j * rng.standard_normal(dim)
         y0 = rng.standard_normal(dim) + 1j * rng.standard_normal(dim)
         out = []
-        for op in (A, M):
+        for op in (A, M, M0):
             v = op.vec(2)
             v.upload(x, 0)
             v.upload(y0, dim)
             red = op.spmv(v.at(0), v.at(dim), 0.7, -0.4, 0.25, want_red=True)
             out.append((v.download(dim, dim), red))
             v.free()
-        ref, got = out
+        ref = out[0]
         scale = np.abs(ref[0]).max()
-        assert np.abs(got[0] - ref[0]).max() < 1e-12 * scale, (k, np.abs(got[0] - ref[0]).max())
-        assert abs(got[1][0] - ref[1][0]) < 1e-10 * abs(ref[1][0]) and abs(got[1][1] - ref[1][1]) < 1e-10 * ref[1][1]
+        for got in out[1:]:
+            assert np.abs(got[0] - ref[0]).max() < 1e-12 * scale, (k, np.abs(got[0] - ref[0]).max())
+            assert abs(got[1][0] - ref[1][0]) < 1e-10 * abs(ref[1][0]) and abs(got[1][1] - ref[1][1]) < 1e-10 * ref[1][1]
+        # device vectors: the caller's order <-> the operator's own
+        v, w = A.vec(2), M.vec(2)
+        v.upload(x, 0)
+        M.to_internal(w.at(0), v.at(0))
+        M.spmv(w.at(0), w.at(dim))
+        M.from_internal(v.at(dim), w.at(dim))
+        M.sync()                                            # every handle has its own stream
+        A.spmv(v.at(0), v.at(dim), 1.0, -1.0, 0.0)          # H x - (H x through the matrix-free form)
+        assert A.nrm2(v.at(dim)) < 1e-12 * scale * np.sqrt(dim)
+        v.free()
+        w.free()
         if dim > 40:
-            e_a, e_m = _lanczos_e0(A, dim), _lanczos_e0(M, dim)
+            e_a, e_m, e_0 = _lanczos_e0(A, dim), _lanczos_e0(M, dim), _lanczos_e0(M0, dim)
             assert abs(e_a - e_m) < 1e-10 * max(1.0, abs(e_a)), (k, e_a, e_m)
+            assert abs(e_a - e_0) < 1e-10 * max(1.0, abs(e_a)), (k, e_a, e_0)
         A.destroy()
         M.destroy()
+        M0.destroy()
 
 
 def test_matrix_free_sector_operator_at_scale():
@@ -820,15 +838,23 @@ def test_matrix_free_sector_operator_at_scale():
         M = q.csr_mat.hubbard_repr_mf(n, 6, 6, bonds, perms, chars)
         dim = A.info().ncols
         assert M.info().ncols == dim == 75117600
-        v = A.vec(3)
+        assert M.info().basis_internal == q._lib.BASIS_SECTOR_ORBIT
+        v, w = A.vec(3), M.vec(2)
         A.randomize(v.at(0), 9)
         A.spmv(v.at(0), v.at(dim))
         A.sync()
-        M.spmv(v.at(0), v.at(2 * dim))
+        M.to_internal(w.at(0), v.at(0))                     # M keeps its device vectors orbit by orbit
+        M.spmv(w.at(0), w.at(dim))
+        M.from_internal(v.at(2 * dim), w.at(dim))
         M.sync()
         hx = A.nrm2(v.at(dim))
         assert np.sqrt(A.axpy_norm(-1.0, v.at(dim), v.at(2 * dim))) <= 1e-12 * hx
+        M.randomize(w.at(0), 9)                             # the same stream by the caller's element number
+        M.from_internal(w.at(dim), w.at(0))
+        M.sync()
+        assert np.sqrt(A.axpy_norm(-1.0, v.at(0), w.at(dim))) <= 1e-14
         v.free()
+        w.free()
         e_a = _lanczos_e0(A, dim, maxit=600)
         A.destroy()
         if real:
