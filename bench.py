@@ -935,7 +935,9 @@ def main():
         mf_key = "%s|matrix_free|plain" % args.workload + ("|real" if vb == 8 else "")
         mtr, msrc = traffic_of(mf_key) if world == 1 else (None, None)
         out["config"]["kernel"] = "matrix_free"
-        out["roofline"] = {"bound": "hbm", "kernel": {"hubbard": "k_mf_hubbard", "hubbard_repr_mf": "k_mf_sector"}.get(W["kind"], "k_mf_heis"),
+        out["roofline"] = {"bound": "hbm", "kernel": {"hubbard": "k_mf_hubbard",
+                                                        "hubbard_repr_mf": "k_mf_sector_orb + k_sec_remainder + k_sec_reduce (rows orbit by orbit)"
+                                                        if int(info.basis_internal) == 3 else "k_mf_sector + k_sec_remainder + k_sec_reduce"}.get(W["kind"], "k_mf_heis"),
                            "achieved": round(vec_bytes / ms_spmv / 1e6, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": round(vec_bytes / ms_spmv / 1e6 / HBM_PEAK_GBPS, 4), "traffic": mtr,
                            "traffic_ratio": (round(mtr / vec_bytes, 2) if mtr else None), "traffic_source": msrc,

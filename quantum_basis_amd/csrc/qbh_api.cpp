@@ -41,7 +41,7 @@ static void parse_debug(const char *e, DebugSw &d)
     const Key keys[] = {{"flags", &d.flags, nullptr}, {"colmask", &d.colmask, nullptr}, {"tpr", &d.tpr, nullptr}, {"unroll", &d.unroll, nullptr},
                         {"grid", &d.grid, nullptr}, {"wave_tpr", &d.wave_tpr, nullptr}, {"chunk_mult", &d.chunk_mult, nullptr},
                         {"trace_create", &d.trace_create, nullptr}, {"trace_tune", &d.trace_tune, nullptr}, {"trace_dict", &d.trace_dict, nullptr},
-                        {"print_ptrs", &d.print_ptrs, nullptr}, {"sec_walk", &d.sec_walk, nullptr}, {"sec_grid", &d.sec_grid, nullptr}, {"sec_nt", &d.sec_nt, nullptr}, {"sec_tile", &d.sec_tile, nullptr},
+                        {"print_ptrs", &d.print_ptrs, nullptr}, {"sec_walk", &d.sec_walk, nullptr}, {"sec_grid", &d.sec_grid, nullptr}, {"sec_tile", &d.sec_tile, nullptr},
                         {"sec_unroll", &d.sec_unroll, nullptr}, {"wave_pipelined", &d.wave_pipelined, nullptr}, {"create_chunk", nullptr, &d.create_chunk},
                         {"force_ragged", &d.force_ragged, nullptr}, {"mf_row", &d.mf_row, nullptr}, {"mf_chunk", &d.mf_chunk, nullptr},
                         {"mf_window", &d.mf_window, nullptr}, {"kronc_abl", &d.kronc_abl, nullptr}, {"kronc_far_chunk", &d.kronc_far_chunk, nullptr},

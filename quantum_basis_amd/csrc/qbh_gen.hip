@@ -2736,27 +2736,38 @@ __global__ __launch_bounds__(256) void k_mf_sector(MfSecArgs a)
 // back once per hop that lands in it, whatever the L2 holds); an up hop reads a run of the block's own x named by the ORBIT's
 // slot table.  Per row and block 26 bytes of tables (pattern, orbit, element | kind, two sign masks) instead of
 // 4 (w_up + nhop) = 170; the group tables (composition, position inside an orbit per stabiliser kind) sit in LDS.
-// NT: the streams that are read once -- the row tables, the target blocks of the down hops, old y -- are loaded non-temporally so
-// that they do not push the block's own x (read ~ w_up times by the up hops) out of the L2.  ORD: items drawn from per-XCD counters.
-template <typename V>
-__device__ __forceinline__ V sec_ld(const V *p, bool nt)
+// ORD: items drawn from per-XCD counters (the default: under the static assignment the workgroups finish far apart, 87 -> 61 ms on
+// 4x5 with 8+8).  Loading the streams that are read once (row tables, target blocks, old y) non-temporally was measured and changes
+// neither the L2 misses nor the time; smaller items keep more of the block's own x in the L2 (tile 256: -17 % misses) but pay more
+// in per-item work than that saves (profiles/r5_lab/sector_orbit_order_timings.txt).
+// a value every lane holds (read from LDS or through a lane-held index) moved to scalar registers, so that what is derived from
+// it -- block descriptors, base addresses -- is scalar work and the gathers take the form  uniform base + 32-bit lane offset
+__device__ __forceinline__ int sec_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t sec_uni(int64_t v)
 {
-    return nt ? __builtin_nontemporal_load(p) : *p;
+    return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v));
 }
-template <bool REALX, int kSecUnroll, bool NT, bool ORD>
+template <typename V>
+__device__ __forceinline__ V sec_at(const V *base, uint32_t i)               // base uniform, i < 2^32 / sizeof(V)
+{
+    return *reinterpret_cast<const V *>(reinterpret_cast<const char *>(base) + (size_t)(uint32_t)(i * (uint32_t)sizeof(V)));
+}
+template <bool REALX, int kSecUnroll, bool ORD>
 __global__ __launch_bounds__(256) void k_mf_sector_orb(MfSecArgs a)
 {
     const MfSec &T = *a.t;
     __shared__ MfSecHop sh[kSecMaxHops];
     __shared__ int64_t s_item;
-    __shared__ uint8_t s_comp[64 * 64];
+    __shared__ uint8_t s_comp[64 * 64];     // [a][b]: the down hops read [g][e] -- g the same in every lane, e running with the lane
+    __shared__ uint8_t s_compT[64 * 64];    // [b][a]: the up hops read comp[e][s] as [s][e] -- e * 64 would put all lanes into two banks
     __shared__ uint8_t s_kidx[16 * 64];
     __shared__ double s_dict[256];
     for (int i = threadIdx.x; i < 64 * 64 / 4; i += 256) reinterpret_cast<uint32_t *>(s_comp)[i] = reinterpret_cast<const uint32_t *>(T.comp)[i];
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) s_compT[(i & 63) * 64 + (i >> 6)] = T.comp[i];
     for (int i = threadIdx.x; i < 16 * 64 / 4; i += 256) reinterpret_cast<uint32_t *>(s_kidx)[i] = reinterpret_cast<const uint32_t *>(T.kidx)[i];
     s_dict[threadIdx.x] = T.updict[threadIdx.x];
-    const int64_t n_orb = T.n_orb;
-    const int W = T.w_orb;
+    const int64_t n_orb = a.n_orb;
+    const int W = a.w_orb;
     const int nslot = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
     const int64_t per = (a.n_items + 7) >> 3, xbase = xcd * per, xend = xbase + per < a.n_items ? xbase + per : a.n_items;
     for (int64_t base = 0; ORD || base < a.n_items; base += gridDim.x) {
@@ -2765,7 +2776,7 @@ __global__ __launch_bounds__(256) void k_mf_sector_orb(MfSecArgs a)
         if (ORD) {
             if (threadIdx.x == 0) s_item = xbase + (int64_t)atomicInc(a.ctr + xcd * 32, 0xFFFFFFFFu);
             __syncthreads();
-            it = s_item;
+            it = sec_uni(s_item);
             if (it >= xend) break;
         }
         if (it >= a.n_items) continue;
@@ -2775,17 +2786,21 @@ __global__ __launch_bounds__(256) void k_mf_sector_orb(MfSecArgs a)
         if (B.regular)
             for (int h = threadIdx.x; h < B.nhop; h += 256) sh[h] = T.hop[B.hop0 + h];
         __syncthreads();
-        for (int j = 0; j < T.tile / 256; ++j) {
-            const int p = tile * T.tile + j * 256 + (int)threadIdx.x;
+        const double *xrb = REALX ? a.xr + B.row0 : nullptr;              // the block's own x
+        const d2 *xgb = REALX ? nullptr : a.xg + B.row0;
+        for (int j = 0; j < a.tile / 256; ++j) {
+            const int tb = tile * a.tile + j * 256;                       // the same in every lane
+            const uint32_t ln = threadIdx.x;
+            const int p = tb + (int)ln;
             if (p >= B.nrows) break;
             const int64_t row = B.row0 + p;
             d2 sum = {0.0, 0.0};
             if (B.regular) {
-                const uint32_t u = sec_ld(T.ucfg + p, NT), d = B.d, o = sec_ld(T.oid + p, NT), ek = sec_ld(T.oek + p, NT);
-                const uint64_t tp = sec_ld(T.tpar + p, NT), us = sec_ld(T.usgn + p, NT);
+                const uint32_t u = sec_at(a.ucfg + tb, ln), d = B.d, o = sec_at(a.oid + tb, ln), ek = sec_at(a.oek + tb, ln);
+                const uint64_t tp = sec_at(a.tpar + tb, ln), us = sec_at(a.usgn + tb, ln);
                 const int e = (int)(ek & 63u), kind = (int)(ek >> 6);
                 const uint8_t *kx = s_kidx + kind * 64;
-                const int64_t pb = B.row0 + p - (int)kx[e];              // the orbit's first member in this block
+                const uint32_t pb = (uint32_t)(p - (int)kx[e]);           // the orbit's first member inside a block
                 double dr = T.U * (double)__popc(u & d);
                 for (int q = 0; q < T.n_pairs; ++q) {
                     const int iu = (u >> T.pi[q]) & 1, id = (d >> T.pi[q]) & 1, ju = (u >> T.pj[q]) & 1, jd = (d >> T.pj[q]) & 1;
@@ -2795,24 +2810,24 @@ __global__ __launch_bounds__(256) void k_mf_sector_orb(MfSecArgs a)
                     for (uint32_t m = u; m; m &= m - 1) dr += T.nup[__ffs(m) - 1];
                     for (uint32_t m = d; m; m &= m - 1) dr += T.ndn[__ffs(m) - 1];
                 }
-                if (REALX) sum.x = dr * a.xr[row];
-                else       sum = dr * a.xg[row];
-                const uint8_t *ce = s_comp + e * 64;                      // comp[e][s]
+                if (REALX) sum.x = dr * sec_at(xrb + tb, ln);
+                else       sum = dr * sec_at(xgb + tb, ln);
+                const uint8_t *ce = s_compT + e;                          // comp[e][s] at ce[s * 64]
                 for (int k0 = 0; k0 < W; k0 += kSecUnroll) {              // up hops: runs of the block's own x
                     uint32_t en[kSecUnroll], ex[kSecUnroll];
 #pragma unroll
-                    for (int q = 0; q < kSecUnroll; ++q) en[q] = k0 + q < W ? T.utab[(size_t)(k0 + q) * (size_t)n_orb + o] : 0u;
+                    for (int q = 0; q < kSecUnroll; ++q) en[q] = k0 + q < W ? sec_at(a.utab + (size_t)(k0 + q) * (size_t)n_orb, o) : 0u;
 #pragma unroll
                     for (int q = 0; q < kSecUnroll; ++q)                   // rare: another amplitude than the first, a stabilised target orbit
-                        ex[q] = (en[q] & (1u << 30)) ? (uint32_t)T.uext[(size_t)(k0 + q) * (size_t)n_orb + o] : 0u;
-                    int64_t ix[kSecUnroll];
+                        ex[q] = (en[q] & (1u << 30)) ? (uint32_t)sec_at(a.uext + (size_t)(k0 + q) * (size_t)n_orb, o) : 0u;
+                    uint32_t ix[kSecUnroll];
 #pragma unroll
                     for (int q = 0; q < kSecUnroll; ++q)
-                        ix[q] = B.row0 + (int64_t)(en[q] & 0xFFFFFFu) + (int)s_kidx[(int)(ex[q] >> 8) * 64 + (int)ce[(int)((en[q] >> 24) & 63u)]];
+                        ix[q] = (en[q] & 0xFFFFFFu) + (uint32_t)s_kidx[(int)(ex[q] >> 8) * 64 + (int)ce[(int)((en[q] >> 18) & (63u << 6))]];
                     if (REALX) {
                         double xv[kSecUnroll];
 #pragma unroll
-                        for (int q = 0; q < kSecUnroll; ++q) xv[q] = (en[q] >> 31) ? a.xr[ix[q]] : 0.0;
+                        for (int q = 0; q < kSecUnroll; ++q) xv[q] = (en[q] >> 31) ? sec_at(xrb, ix[q]) : 0.0;
 #pragma unroll
                         for (int q = 0; q < kSecUnroll; ++q) {
                             const double am = s_dict[(int)(ex[q] & 255u)];
@@ -2821,7 +2836,7 @@ __global__ __launch_bounds__(256) void k_mf_sector_orb(MfSecArgs a)
                     } else {
                         d2 xv[kSecUnroll];
 #pragma unroll
-                        for (int q = 0; q < kSecUnroll; ++q) xv[q] = (en[q] >> 31) ? a.xg[ix[q]] : d2{0.0, 0.0};
+                        for (int q = 0; q < kSecUnroll; ++q) xv[q] = (en[q] >> 31) ? sec_at(xgb, ix[q]) : d2{0.0, 0.0};
 #pragma unroll
                         for (int q = 0; q < kSecUnroll; ++q) {
                             const double am = s_dict[(int)(ex[q] & 255u)];
@@ -2831,27 +2846,31 @@ __global__ __launch_bounds__(256) void k_mf_sector_orb(MfSecArgs a)
                     if (!(en[kSecUnroll - 1] >> 31)) break;
                 }
                 for (int h0 = 0; h0 < B.nhop; h0 += kSecUnroll) {          // down hops into regular blocks: the same positions there
-                    int64_t ix[kSecUnroll];
+                    uint32_t ix[kSecUnroll];
+                    int64_t off[kSecUnroll];
+                    int gg[kSecUnroll];
 #pragma unroll
                     for (int q = 0; q < kSecUnroll; ++q) {
                         const int hh = h0 + q < B.nhop ? h0 + q : 0;
-                        ix[q] = sh[hh].off - B.row0 + pb + (int)kx[(int)s_comp[sh[hh].g * 64 + e]];
+                        off[q] = sec_uni(sh[hh].off);
+                        gg[q] = sec_uni(sh[hh].g);
+                        ix[q] = pb + (uint32_t)kx[(int)s_comp[gg[q] * 64 + e]];
                     }
                     if (REALX) {
                         double xv[kSecUnroll];
 #pragma unroll
-                        for (int q = 0; q < kSecUnroll; ++q) xv[q] = h0 + q < B.nhop ? sec_ld(a.xr + ix[q], NT) : 0.0;
+                        for (int q = 0; q < kSecUnroll; ++q) xv[q] = h0 + q < B.nhop ? sec_at(a.xr + off[q], ix[q]) : 0.0;
 #pragma unroll
                         for (int q = 0; q < kSecUnroll; ++q)
-                            if (h0 + q < B.nhop) sum.x += (((tp >> sh[h0 + q].g) & 1ULL) ? -sh[h0 + q].cr : sh[h0 + q].cr) * xv[q];
+                            if (h0 + q < B.nhop) sum.x += (((tp >> gg[q]) & 1ULL) ? -sh[h0 + q].cr : sh[h0 + q].cr) * xv[q];
                     } else {
                         d2 xv[kSecUnroll];
 #pragma unroll
-                        for (int q = 0; q < kSecUnroll; ++q) xv[q] = h0 + q < B.nhop ? sec_ld(a.xg + ix[q], NT) : d2{0.0, 0.0};
+                        for (int q = 0; q < kSecUnroll; ++q) xv[q] = h0 + q < B.nhop ? sec_at(a.xg + off[q], ix[q]) : d2{0.0, 0.0};
 #pragma unroll
                         for (int q = 0; q < kSecUnroll; ++q)
                             if (h0 + q < B.nhop) {
-                                const double sg = ((tp >> sh[h0 + q].g) & 1ULL) ? -1.0 : 1.0;
+                                const double sg = ((tp >> gg[q]) & 1ULL) ? -1.0 : 1.0;
                                 const double cr = sg * sh[h0 + q].cr, ci = sg * sh[h0 + q].ci;
                                 sum += d2{cr * xv[q].x - ci * xv[q].y, cr * xv[q].y + ci * xv[q].x};
                             }
@@ -2859,8 +2878,8 @@ __global__ __launch_bounds__(256) void k_mf_sector_orb(MfSecArgs a)
                 }
             }
             d2 yo = {0.0, 0.0}, xi = {0.0, 0.0};
-            if (a.beta != 0.0) yo = a.y_re ? d2{sec_ld(a.y_re + row, NT), 0.0} : sec_ld(a.y + row, NT);
-            if (a.gamma != 0.0) xi = a.y_re ? d2{a.xl_re[row], 0.0} : a.xl[row];
+            if (a.beta != 0.0) yo = a.y_re ? d2{sec_at(a.y_re + B.row0 + tb, ln), 0.0} : sec_at(a.y + B.row0 + tb, ln);
+            if (a.gamma != 0.0) xi = a.y_re ? d2{sec_at(a.xl_re + B.row0 + tb, ln), 0.0} : sec_at(a.xl + B.row0 + tb, ln);
             const d2 yn = a.alpha * sum + a.beta * yo + a.gamma * xi;
             if (a.y_re) a.y_re[row] = yn.x;
             else        a.y[row] = yn;
@@ -2921,19 +2940,13 @@ static int sector_orbit_launch_t(const MfSecArgs &a, hipStream_t s)
     static int occ = 0;
     if (occ == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mf_sector_orb<REALX, UN, true, false>, 256, 0) != hipSuccess || n <= 0) n = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mf_sector_orb<REALX, UN, true>, 256, 0) != hipSuccess || n <= 0) n = 4;
         occ = n;
     }
     int grid = 256 * occ;
     if (debug_sw().sec_grid >= 8) grid = (debug_sw().sec_grid / 8) * 8;
-    const bool nt = debug_sw().sec_nt != 0;
-    if (a.ctr != nullptr) {
-        if (nt) hipLaunchKernelGGL((k_mf_sector_orb<REALX, UN, true, true>), dim3(grid), dim3(256), 0, s, a);
-        else    hipLaunchKernelGGL((k_mf_sector_orb<REALX, UN, false, true>), dim3(grid), dim3(256), 0, s, a);
-    } else {
-        if (nt) hipLaunchKernelGGL((k_mf_sector_orb<REALX, UN, true, false>), dim3(grid), dim3(256), 0, s, a);
-        else    hipLaunchKernelGGL((k_mf_sector_orb<REALX, UN, false, false>), dim3(grid), dim3(256), 0, s, a);
-    }
+    if (a.ctr != nullptr) hipLaunchKernelGGL((k_mf_sector_orb<REALX, UN, true>), dim3(grid), dim3(256), 0, s, a);
+    else                  hipLaunchKernelGGL((k_mf_sector_orb<REALX, UN, false>), dim3(grid), dim3(256), 0, s, a);
     return QBH_OK;
 }
 

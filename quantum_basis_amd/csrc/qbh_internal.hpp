@@ -29,7 +29,7 @@ struct DebugSw {
     int colmask = 0;          // the mask for flags & 1 (0: 1023)
     int tpr = 0, unroll = 0, grid = 0, wave_tpr = 0, chunk_mult = 0;      // launch-geometry overrides
     int trace_create = 0, trace_tune = 0, trace_dict = 0, print_ptrs = 0;
-    int sec_walk = -1, sec_grid = 0, sec_unroll = 0, sec_nt = -1, sec_tile = 0;   // matrix-free sector kernel
+    int sec_walk = -1, sec_grid = 0, sec_unroll = 0, sec_tile = 0;        // matrix-free sector kernel
     int wave_pipelined = 0;   // the pipelined wave kernel on an unsplit operator
     long long create_chunk = 0;                                           // staging chunk of qbh_csr_create (nonzeros)
     int force_ragged = 0;     // native communicator: the send/recv all-gather-v even for uniform cuts
@@ -505,6 +505,12 @@ struct MfSecArgs {
     double *partials;            // [nparts * 3] or nullptr
     unsigned int *ctr;           // ordered walk: 8 zeroed counters, 128 bytes apart (nullptr: static assignment)
     int orbit;                   // the tables are in orbit order (MfSec::orbit): k_mf_sector_orb
+    // the orbit-order tables once more as kernel arguments: pointers read out of *t are generic (flat loads), these are global
+    const uint32_t *ucfg, *oid, *utab;
+    const uint16_t *oek, *uext;
+    const uint64_t *tpar, *usgn;
+    int64_t n_orb;
+    int w_orb, tile;
 };
 // y <- alpha H x + beta y + gamma x in three launches (block tables, remainder rows, reductions); *nparts_out = partial sums
 int launch_mf_sector(const MfSecArgs &a, hipStream_t s, int *nparts_out);

@@ -414,6 +414,16 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
             ms.gamma = gamma;
             ms.partials = m.partials;
             ms.orbit = A->mfsec->orbit;
+            ms.ucfg = A->mfsec->ucfg;
+            ms.oid = A->mfsec->oid;
+            ms.utab = A->mfsec->utab;
+            ms.oek = A->mfsec->oek;
+            ms.uext = A->mfsec->uext;
+            ms.tpar = A->mfsec->tpar;
+            ms.usgn = A->mfsec->usgn;
+            ms.n_orb = A->mfsec->n_orb;
+            ms.w_orb = A->mfsec->w_orb;
+            ms.tile = A->mfsec->tile;
             // items drawn from per-XCD counters: the orbit-order kernel by default (its workgroups finish far apart under a
             // static assignment: 87 -> 61 ms on 4x5 with 8+8), the rank-table kernel only on request (it got slower: 223 -> 233 ms)
             const int sec_walk = qbh::debug_sw().sec_walk < 0 ? (ms.orbit ? 1 : 0) : qbh::debug_sw().sec_walk;

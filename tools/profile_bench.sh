@@ -24,7 +24,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum T
   i=$((i+1))
   timeout 900 rocprofv3 --pmc $grp -d /tmp/prof_$TAG/g$i -o p -- python3 $R/bench.py $ARGS > /tmp/prof_$TAG/g$i.log 2>&1
 done
-{ echo "# rocprofv3 --pmc passes (one counter group per run) of: python bench.py $ARGS"; echo "# mean per dispatch; FETCH_SIZE/WRITE_SIZE are in KiB as reported (see DESIGN.md for the gfx950 x2 read correction)"; for pat in "%spmv%" "%k_kronc%" "%k_kron_tile%" "%k_zero_cut%" "%k_kron_combine%" "%k_axpy_norm%" "%mf_hubbard%" "%mf_heis%"; do python3 $R/tools/pmc_summary.py /tmp/prof_$TAG "$pat"; done; } > $OUT/${TAG}_pmc.txt
+{ echo "# rocprofv3 --pmc passes (one counter group per run) of: python bench.py $ARGS"; echo "# mean per dispatch; FETCH_SIZE/WRITE_SIZE are in KiB as reported (see DESIGN.md for the gfx950 x2 read correction)"; for pat in "%spmv%" "%k_kronc%" "%k_kron_tile%" "%k_zero_cut%" "%k_kron_combine%" "%k_axpy_norm%" "%mf_hubbard%" "%mf_heis%" "%k_mf_sector%" "%k_sec_re%"; do python3 $R/tools/pmc_summary.py /tmp/prof_$TAG "$pat"; done; } > $OUT/${TAG}_pmc.txt
 python3 $R/tools/traffic_entry.py /tmp/prof_$TAG "$KEY" "profiles/${TAG}_pmc.txt" $OUT/${TAG}_traffic_entry.json > /dev/null
 head -12 $OUT/${TAG}_kernel_stats.txt; tail -3 $OUT/${TAG}_kernel_stats.txt | cut -c1-400
 cat $OUT/${TAG}_traffic_entry.json | head -40

@@ -16,7 +16,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import src_hash  # noqa: E402
 
-SPMV_LIKE = ("k_spmv_", "k_zero_cut_groups", "k_kron_tile", "k_kron_combine", "k_mf_", "k_kronc_far", "k_kronc_near")
+SPMV_LIKE = ("k_spmv_", "k_zero_cut_groups", "k_kron_tile", "k_kron_combine", "k_mf_", "k_kronc_far", "k_kronc_near", "k_sec_remainder", "k_sec_reduce")
 
 
 def main():
