@@ -229,6 +229,7 @@ def test_c4_as_written_half_filling_sector_full_size():
     M.sync()
     ys = S.vec()
     M.from_internal(c.ptr, v.at(0))              # the stored shard has the caller's (ascending) order
+    M.sync()                                     # every handle works on its own stream
     S.spmv(c.ptr, ys.ptr)                        # unsharded convention: x is the full-length vector
     S.sync()
     hy = S.nrm2(ys.ptr)

@@ -13,7 +13,7 @@ def main():
         q = ("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
              "where kernel_name like ? group by kernel_name, counter_name")
         for k, c, n, v in db.execute(q, (like,)):
-            print("%-44s %-36s n=%-3d mean=%.6g" % (k.split("(")[0][-44:], c, n, v))
+            print("%-44s %-36s n=%-3d mean=%.6g" % (k.replace("(anonymous namespace)::", "").split("(")[0][-44:], c, n, v))
 
 
 if __name__ == "__main__":

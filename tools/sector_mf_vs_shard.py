@@ -32,10 +32,14 @@ def main():
     assert i.ncols == dim
     print("sector k=%s dim %d; matrix-free operator built in %.1f s; stored shard rows [%d, %d), nnz %d, built in %.1f s" %
           (k, dim, t1 - t0, i.row_offset, i.row_offset + i.nrows, i.nnz, t2 - t1), flush=True)
-    v = M.vec(2)                                           # x and y of the matrix-free operator (full length)
-    M.randomize(v.at(0), 11)
-    M.spmv(v.at(0), v.at(dim))
+    w = M.vec(2)                                           # x and y of the matrix-free operator, in ITS row order (orbit by orbit)
+    M.randomize(w.at(0), 11)
+    M.spmv(w.at(0), w.at(dim))
+    v = q.engine.DeviceVec(S, 2 * dim)                     # the same two vectors in the caller's order, owned by the stored shard's handle
+    M.from_internal(v.at(0), w.at(0))
+    M.from_internal(v.at(dim), w.at(dim))
     M.sync()
+    w.free()
     ys = S.vec()
     S.spmv(v.at(0), ys.ptr)                                # unsharded convention: x is the full vector
     S.sync()

@@ -26,7 +26,7 @@ def main():
         db = sqlite3.connect(db_path)
         q = "select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name"
         for k, c, n, v in db.execute(q):
-            name = k.split("(")[0]
+            name = k.replace("(anonymous namespace)::", "").split("(")[0]
             if any(t in name for t in SPMV_LIKE):
                 per.setdefault(name, {})[c] = (n, v)
     if not per:
