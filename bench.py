@@ -468,6 +468,30 @@ def cpu_midsize_full_run(W, q, stream):
     return res
 
 
+def bare_spmv_block(A, b_spmv, reps=10):
+    """qbh_spmv_dev on a vector the library did not produce -- what an ARPACK reverse-communication caller gets (src/lanczos.cc:393-495):
+    no pass of a driver has written the tiled copy of x, so the SpMV of a split operator makes it itself (k_kron_tile8) inside
+    the timed launch.  The headline's ms_per_launch is the SpMV inside qbh_lanczos_dev, where the producer pass writes that copy."""
+    v = A.vec(2)
+    try:
+        A.randomize(v.at(0), 5)
+        for _ in range(2):
+            A.spmv(v.at(0), v.at(A.dim))
+        A.sync()
+        A.stats(reset=True)
+        for _ in range(reps):
+            A.spmv(v.at(0), v.at(A.dim))
+        A.sync()
+        st = A.stats()
+        ms = st.ms_spmv / max(1, st.n_spmv)
+        return {"call": "qbh_spmv_dev(x, y) on a fresh x (y = H x, no reductions)", "launches": int(st.n_spmv), "ms_per_launch": round(ms, 4),
+                "frac": round(b_spmv / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "bytes_per_launch": int(b_spmv),
+                "note": "includes the tiled copy of x the split operator needs (one more pass over x: read 16 B, write 16 B per element), "
+                        "which inside the solvers is written by the pass that produces x"}
+    finally:
+        v.free()
+
+
 def locate_e0_block(A, q, torch, b_spmv, maxit=1000):
     """The call a user of the reference makes: model::locate_E0_lanczos(nev = 1, ncv = 1) (src/model.cc:1123-1316) = Lanczos to
     convergence ("sr_val0", src/lanczos.cc:134-266) + the CG eigenvector (src/lanczos.cc:281-341), every vector resident in HBM.
@@ -854,7 +878,9 @@ def main():
                                                         if info.kron_minor else None),
                                          "basis_internal": ({1: "species-major (index = up * C(n, n_dn) + down), vectors translated at the seams",
                                                              2: "class-major cut sector (%d low sites, %d classes, cross part %d nonzeros), vectors translated at the seams"
-                                                                % (args.site_cut, info.kron_classes, info.kron_cross_nnz)}.get(info.basis_internal)),
+                                                                % (args.site_cut, info.kron_classes, info.kron_cross_nnz),
+                                                             3: "the rows of every down block orbit by orbit of the up patterns (qbh_opts.sector_orbit); vectors translated at the seams"}
+                                                            .get(info.basis_internal)),
                                          "operator_source": "host CSR in reference order through qbh_csr_create" if args.host_csr else
                                          "device generator, permuted on the device into the reference's Lin order and fermion convention "
                                          "(qbh_csr_reference_order)" if args.order == "reference" else "device generator",
@@ -957,6 +983,11 @@ def main():
         except Exception as e:      # the baseline is reported, never required
             out["cpu_baseline"] = {"value": None, "unit": "lanczos_iters/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     if rank == 0 and world == 1 and not args.no_locate and not args.matrix_free and not packed_real and not (coded or real_used):
+        try:
+            with torch.cuda.stream(stream):
+                out["bare_spmv"] = bare_spmv_block(A, bytes_launch)
+        except Exception as e:
+            out["bare_spmv"] = {"failed": repr(e)}
         try:
             with torch.cuda.stream(stream):
                 out["locate_E0"] = locate_e0_block(A, q, torch, bytes_launch)
