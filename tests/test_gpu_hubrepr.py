@@ -824,6 +824,35 @@ def test_matrix_free_sector_operator_equals_the_stored_one(Lx, Ly, nu, nd):
         M0.destroy()
 
 
+def test_matrix_free_sector_operator_with_a_non_abelian_group():
+    """The orbit order rests on the group's composition table (position of g(e(u0)) inside the orbit of u0): a ring of 6 sites with
+    its DIHEDRAL group (6 rotations + 6 reflections, g1 g2 != g2 g1) in its two one-dimensional representations with real
+    characters -- the library must take the orbit form (its own position-by-position check at build passes) and reproduce the
+    stored sector operator."""
+    L, nu, nd = 6, 3, 2
+    bonds = lattices.chain(L)
+    rot = [[(s + t) % L for s in range(L)] for t in range(L)]
+    ref = [[(t - s) % L for s in range(L)] for t in range(L)]
+    perms = rot + ref
+    rng = np.random.default_rng(5)
+    for chars in ([1.0 + 0j] * (2 * L), [1.0 + 0j] * L + [-1.0 + 0j] * L):
+        A = q.csr_mat.hubbard_repr(L, nu, nd, bonds, perms, chars, t=1.0, U=1.3)
+        M = q.csr_mat.hubbard_repr_mf(L, nu, nd, bonds, perms, chars, t=1.0, U=1.3)
+        dim = A.info().ncols
+        assert dim > 0 and M.info().ncols == dim and M.info().basis_internal == q._lib.BASIS_SECTOR_ORBIT
+        x = rng.standard_normal(dim) + 1j * rng.standard_normal(dim)
+        out = []
+        for op in (A, M):
+            v = op.vec(2)
+            v.upload(x, 0)
+            op.spmv(v.at(0), v.at(dim))
+            out.append(v.download(dim, dim))
+            v.free()
+        assert np.abs(out[1] - out[0]).max() < 1e-12 * np.abs(out[0]).max()
+        A.destroy()
+        M.destroy()
+
+
 def test_matrix_free_sector_operator_at_scale():
     """4x5 with 6+6 electrons, k = (0,0) (75,117,600 representatives): the matrix-free sector operator (0.3 GB) against the
     stored one (14 GB) -- the same y on a random vector, the same ground-state energy through the packed-double Lanczos
