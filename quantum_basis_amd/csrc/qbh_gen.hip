@@ -16,6 +16,7 @@
 #include <array>
 #include <cmath>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <string>
 #include <type_traits>
@@ -2948,13 +2949,13 @@ __global__ __launch_bounds__(256) void k_sec_reduce(MfSecArgs a)
 template <bool REALX, int UN>
 static int sector_orbit_launch_t(const MfSecArgs &a, hipStream_t s)
 {
-    static int occ = 0;
-    if (occ == 0) {
+    static std::atomic<int> occ{0};            // the same value on every device of one model; a race writes it twice
+    if (occ.load() == 0) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mf_sector_orb<REALX, UN, true>, 256, 0) != hipSuccess || n <= 0) n = 4;
-        occ = n;
+        occ.store(n);
     }
-    int grid = 256 * occ;
+    int grid = 256 * occ.load();
     if (debug_sw().sec_grid >= 8) grid = (debug_sw().sec_grid / 8) * 8;
     if (a.ctr != nullptr) hipLaunchKernelGGL((k_mf_sector_orb<REALX, UN, true>), dim3(grid), dim3(256), 0, s, a);
     else                  hipLaunchKernelGGL((k_mf_sector_orb<REALX, UN, false>), dim3(grid), dim3(256), 0, s, a);
@@ -2965,13 +2966,13 @@ template <bool REALX, int UN>
 static int sector_launch_t(const MfSecArgs &a, hipStream_t s)
 {
     // persistent grid: exactly the resident workgroups (a multiple of 8), so that the XCD-contiguous item order holds
-    static int occ = 0;
-    if (occ == 0) {
+    static std::atomic<int> occ{0};            // the same value on every device of one model; a race writes it twice
+    if (occ.load() == 0) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mf_sector<REALX, UN, false>, 256, 0) != hipSuccess || n <= 0) n = 4;
-        occ = n;
+        occ.store(n);
     }
-    int grid = 256 * occ;
+    int grid = 256 * occ.load();
     if (debug_sw().sec_grid >= 8) grid = (debug_sw().sec_grid / 8) * 8;
     if (a.ctr != nullptr) hipLaunchKernelGGL((k_mf_sector<REALX, UN, true>), dim3(grid), dim3(256), 0, s, a);
     else                  hipLaunchKernelGGL((k_mf_sector<REALX, UN, false>), dim3(grid), dim3(256), 0, s, a);
