@@ -295,7 +295,9 @@ inline void vec_randomize(const csr_mat &mat, cplx *x, const uint32_t &seed)
 // examples/trans_symmetric/latt_square/square_Fermi_Hubbard.cc (see qbh_gen_hubbard_repr in qbhip.h).  bonds: (i, j) pairs,
 // each giving -t (c+_i c_j + h.c.) for both species; perms[g * n_sites + s] = image of site s under translation g
 // (lattice::translation_plan), chars[g] = exp(-i k.t_g).
-// matrix_free = true: the same operator without the matrix (qbh_mf_hubbard_repr: block tables + a small stored remainder).
+// matrix_free = true: the same operator without the matrix (qbh_mf_hubbard_repr: block tables + a small stored remainder).  Its
+// host vectors are the sector's vectors as for the stored form; its DEVICE vectors are kept in the handle's own row order
+// (qbh_opts.sector_orbit; qbh_vec_to_internal / qbh_vec_from_internal convert, qbh_csr_info.basis_internal tells).
 inline csr_mat hubbard_sector(int n_sites, int n_up, int n_dn, const std::vector<std::pair<int, int>> &bonds, double t, double U,
                               const std::vector<int32_t> &perms, const std::vector<cplx> &chars, const qbh_opts *opts = nullptr,
                               bool matrix_free = false)
