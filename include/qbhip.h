@@ -603,8 +603,16 @@ int qbh_gen_hubbard_repr_cuts(qbh_csr **out, int n_sites, int n_up, int n_dn, in
  * up-species and number-operator amplitudes).  Representatives are ordered by the down pattern first: in a down block whose
  * pattern is trivially stabilised every up pattern is a representative, the up hops are the full-basis up-hop table applied
  * inside the block and each down hop is (target block, translation, coefficient); only the rows in or next to stabilised
- * blocks (< 1 %) are stored as CSR.  4x5 at half filling: ~40 MB of tables + ~1 GB instead of 364 GB.  The handle works with
- * every solver entry point; qbh_csr_download and qbh_csr_set_comm refuse it. */
+ * blocks (< 1 %) are stored as CSR.  4x5 at half filling: ~40 MB of tables + ~3.4 GB instead of 364 GB.  The handle works with
+ * every solver entry point; qbh_csr_download and qbh_csr_set_comm refuse it.
+ * Row order ON THE DEVICE (qbh_opts.sector_orbit, default 1): inside a block the up patterns are held orbit by orbit of the
+ * translation group -- a translated pattern then lies within n_trans rows of the same position in the target block, so a down
+ * hop reads its target block once, front to back, and the up hops go through a per-ORBIT table.  Host vectors keep the order
+ * of the representatives (every host seam translates); device vectors are in the handle's order
+ * (qbh_csr_info.basis_internal = QBH_BASIS_SECTOR_ORBIT; qbh_vec_to_internal / qbh_vec_from_internal convert; vectors made by
+ * qbh_vec_randomize(_real) hold the same stream as in the other order).  The construction is verified entry by entry at build;
+ * translations that are not a group, up amplitudes that are not invariant under them, or more than 64 translations keep the
+ * ascending order (basis_internal = 0). */
 int qbh_mf_hubbard_repr(qbh_csr **out, int n_sites, int n_up, int n_dn, int n_terms, const int32_t *term_sites,
                         const qbh_z *amp_up, const qbh_z *amp_dn, double U, int n_pairs, const int32_t *pair_sites,
                         const double *pair_v, int n_trans, const int32_t *perms, const double *chars, double fake_pos,
