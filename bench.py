@@ -564,6 +564,7 @@ def main():
                          "internally and split into near (low-half bonds) / far (high-half bonds) / cross parts")
     ap.add_argument("--cols16", type=int, default=1, help="qbh_opts.kron_cols16: 1 (library default) the parts of a split operator keep 2-byte columns, 0 int32 columns")
     ap.add_argument("--deterministic", action="store_true", help="qbh_opts.deterministic: static walks, nothing timed at creation (bit-identical a_j / b_j from run to run)")
+    ap.add_argument("--no-pipeline", action="store_true", help="qbh_opts.lanczos_pipeline = 0: one host synchronisation per Lanczos step (the loop of ABI <= 501), for A/B runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed run to convergence (E0)")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)
@@ -741,7 +742,7 @@ def main():
         opts = q.make_opts(device=local_rank, stream=stream.cuda_stream, spmv_kernel=args.kernel,
                            nnz_per_block=args.npb, xcd_swizzle=args.swizzle,
                            value_dict=value_dict, real_fast_path=real_fp, profile=1, deterministic=1 if args.deterministic else 0,
-                           kron_cols16=args.cols16)
+                           kron_cols16=args.cols16, lanczos_pipeline=0 if args.no_pipeline else 1)
         if args.site_cut and W["kind"] == "heisenberg" and world == 1 and value_dict == 0:
             opts.basis_kind, opts.n_sites, opts.n_up, opts.n_dn = q._lib.BASIS_SPIN_SECTOR, W["n_sites"], args.site_cut, W["n_dn"]
         t_gen = time.time()

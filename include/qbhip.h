@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QBH_VERSION 501
+#define QBH_VERSION 600
 
 /* error codes */
 #define QBH_OK          0
@@ -176,6 +176,12 @@ typedef struct qbh_opts {
                                 order (qbh_csr_info.basis_internal = QBH_BASIS_SECTOR_ORBIT; host vectors are translated at the
                                 seams as for basis_kind, device vectors by qbh_vec_to_internal / _from_internal).  0: rows in
                                 ascending pattern order, the form of ABI <= 500                                            */
+    int     lanczos_pipeline; /* [1] qbh_lanczos(_dev), one GPU, complex vectors, purpose sr_val0 / dnmcs: the three-term step
+                                keeps a_{m-1}, b_m and 1/b_m on the device and step m + 1 is enqueued BEFORE step m's two scalars
+                                have been read back; the Ritz test (src/lanczos.cc:229-245) runs one step behind, and on
+                                convergence or breakdown the one speculative step is discarded (it wrote to a third vector the
+                                handle keeps), so m, a[], b[], the two vectors returned and the stop step are exactly those of
+                                the unpipelined loop.  0: one host synchronisation per step (the form of ABI <= 501)       */
 } qbh_opts;
 
 void qbh_opts_default(qbh_opts *o);
@@ -516,6 +522,9 @@ int qbh_get_stats(const qbh_csr *A, qbh_stats *s, int reset);
 /* Block until everything enqueued on the operator's stream has finished (device building blocks
  * without a reduction are asynchronous; needed before another operator/stream touches the vectors). */
 int qbh_sync(const qbh_csr *A);
+/* Change one of the options that do not touch the stored form of the operator, after creation (everything else in qbh_opts is
+ * fixed when the handle is made): "lanczos_pipeline", "profile", "tile_fold".  QBH_EINVAL for any other name. */
+int qbh_csr_set_option(qbh_csr *A, const char *name, int value);
 
 /* ------------------------------------------------ synthetic operators ---- */
 /* Measurement harness: device-side assembly of the benchmark Hamiltonians directly into

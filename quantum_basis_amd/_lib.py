@@ -40,7 +40,7 @@ class Opts(C.Structure):
                 ("kron_sliced", C.c_int), ("kron_band", C.c_int), ("kron_cross_in_near", C.c_int), ("kron_coded", C.c_int),
                 ("kron_uniform", C.c_int), ("gather_parts", C.c_int), ("wave_walk", C.c_int), ("tile_fold", C.c_int),
                 ("autotune", C.c_int), ("shard_split", C.c_int), ("real_forms", C.c_int), ("basis_detect", C.c_int),
-                ("sector_orbit", C.c_int)]
+                ("sector_orbit", C.c_int), ("lanczos_pipeline", C.c_int)]
 
 
 class CsrInfo(C.Structure):
@@ -103,7 +103,7 @@ EXPORTS = [
     "qbh_lanczos", "qbh_lanczos_dev", "qbh_lanczos_real_dev", "qbh_vec_randomize_real", "qbh_eigenvec_cg_real_dev", "qbh_eigenvec_cg", "qbh_eigenvec_cg_dev", "qbh_hess_eigen", "qbh_iram",
     "qbh_mopr_spin_dev", "qbh_mopr_onebody_dev", "qbh_mopr_terms_dev", "qbh_mopr_sz_repr_dev", "qbh_mopr_flip_repr_dev",
     "qbh_crc32", "qbh_vec_disk_write", "qbh_vec_disk_read", "qbh_ckpt_lanczos_update", "qbh_ckpt_lanczos_init", "qbh_lanczos_ckpt",
-    "qbh_csr_set_comm", "qbh_rccl_unique_id", "qbh_comm_create_rccl", "qbh_comm_destroy", "qbh_get_stats", "qbh_sync",
+    "qbh_csr_set_comm", "qbh_rccl_unique_id", "qbh_comm_create_rccl", "qbh_comm_destroy", "qbh_get_stats", "qbh_sync", "qbh_csr_set_option",
     "qbh_gen_hubbard", "qbh_mf_hubbard", "qbh_gen_heisenberg", "qbh_mf_heisenberg", "qbh_gen_heisenberg_repr", "qbh_gen_hubbard_repr", "qbh_gen_heisenberg_repr_cuts", "qbh_gen_hubbard_repr_cuts", "qbh_mf_hubbard_repr", "qbh_mopr_diag_hubrepr_dev", "qbh_mopr_c_hubrepr_dev", "qbh_csr_download", "qbh_csr_reference_order", "qbh_csr_set_basis",
 ]
 
@@ -191,6 +191,7 @@ def lib():
     L.qbh_comm_destroy.argtypes = [vp]
     L.qbh_get_stats.argtypes = [vp, C.POINTER(Stats), C.c_int]
     L.qbh_sync.argtypes = [vp]
+    L.qbh_csr_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.qbh_gen_hubbard.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, vp, dbl, dbl,
                                   i64, i64, C.POINTER(Opts)]
     L.qbh_mf_hubbard.argtypes = L.qbh_gen_hubbard.argtypes

@@ -46,7 +46,7 @@ static void parse_debug(const char *e, DebugSw &d)
                         {"force_ragged", &d.force_ragged, nullptr}, {"mf_row", &d.mf_row, nullptr}, {"mf_chunk", &d.mf_chunk, nullptr},
                         {"mf_window", &d.mf_window, nullptr}, {"kronc_abl", &d.kronc_abl, nullptr}, {"kronc_far_chunk", &d.kronc_far_chunk, nullptr},
                         {"kronc_far_ng", &d.kronc_far_ng, nullptr}, {"kronc_far_nt", &d.kronc_far_nt, nullptr}, {"no_far_align", &d.no_far_align, nullptr},
-                        {"no_defer", &d.no_defer, nullptr}};
+                        {"no_defer", &d.no_defer, nullptr}, {"pipe_nospec", &d.pipe_nospec, nullptr}, {"host_delay_us", &d.host_delay_us, nullptr}};
     const std::string all(e);
     size_t pos = 0;
     while (pos <= all.size()) {
@@ -181,6 +181,7 @@ void qbh::opts_builtin(qbh_opts *o)
     o->real_forms = 7;
     o->basis_detect = 1;
     o->sector_orbit = 1;
+    o->lanczos_pipeline = 1;
     o->kron_minor = 0;
     o->deterministic = 0;
     o->basis_kind = QBH_BASIS_NONE;
@@ -716,6 +717,14 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
     }
     if (A->ev2) (void)hipEventDestroy(A->ev2);
     if (A->ev3) (void)hipEventDestroy(A->ev3);
+    for (auto &o : A->ev_old)
+        for (hipEvent_t e : o.e)
+            if (e) (void)hipEventDestroy(e);
+    if (A->lz.d_buf) (void)hipFree(A->lz.d_buf);
+    if (A->lz.d_state) (void)hipFree(A->lz.d_state);
+    if (A->lz.h_log) (void)hipHostFree(A->lz.h_log);
+    for (hipEvent_t e : A->lz.ev)
+        if (e) (void)hipEventDestroy(e);
     if (A->d_partials) (void)hipFree(A->d_partials);
     if (A->d_scal) (void)hipFree(A->d_scal);
     if (A->d_wctr) (void)hipFree(A->d_wctr);
@@ -1071,6 +1080,24 @@ extern "C" int qbh_sync(const qbh_csr *A)
     if (!A) return QBH_EINVAL;
     Bind bind(A);
     QBH_HIP(hipStreamSynchronize(A->stream));
+    return QBH_OK;
+}
+
+extern "C" int qbh_csr_set_option(qbh_csr *A, const char *name, int value)
+{
+    if (!A || !name) return QBH_EINVAL;
+    const std::string nm(name);
+    if (nm == "lanczos_pipeline") A->opts.lanczos_pipeline = value;
+    else if (nm == "profile") {
+        Bind bind(A);
+        harvest_events(A);                  // nothing stays pending across the change
+        A->opts.profile = value;
+    }
+    else if (nm == "tile_fold") A->opts.tile_fold = value;
+    else {
+        qbh::set_error("qbh_csr_set_option: '%s' is not an option that can change after creation", name);
+        return QBH_EINVAL;
+    }
     return QBH_OK;
 }
 

@@ -37,6 +37,8 @@ struct DebugSw {
     int kronc_abl = 0, kronc_far_chunk = 0, kronc_far_ng = 0, kronc_far_nt = 0;
     int no_far_align = 0;     // in-place split: the far part directly behind the near part (unaligned)
     int no_defer = 0;         // Lanczos: read <u, w> back every step instead of keeping it on the device
+    int host_delay_us = 0;    // Lanczos: the host spins this long after every read-back of a step's scalars (models a slow / descheduled host)
+    int pipe_nospec = 0;      // pipelined Lanczos loop: 1 = never enqueue a step before the one before it has been read back (debugging)
 };
 const DebugSw &debug_sw();
 void opts_builtin(qbh_opts *o);          // the built-in defaults, whatever qbh_opts_set_default says
@@ -119,7 +121,21 @@ struct SpmvArgs {
     // k_spmv_wave2 under the dynamic walk, passes with the fused epilogue: one slot of three sums per chunk of blocks
     // (wave2_chunk_slots(n_wb) slots; never nullptr for those launches), added up in a fixed order by launch_reduce_chunks
     double *chunk_red;
+    // pipelined three-term step (lanczos_core, round 6): the beta term reads yin (nullptr = y: in place); with coef_mode != 0 the
+    // coefficients come from device memory, left there by the step before (k_lanczos_tail) -- 1: alpha = coef[0], beta = coef[1];
+    // 2: alpha = coef[0] only (a later pass accumulating onto y with its own beta)
+    const d2      *yin;
+    const double  *coef;
+    int            coef_mode;
 };
+// first statement of every kernel that takes SpmvArgs: the coefficients a previous kernel of the stream left on the device
+__device__ __forceinline__ void spmv_args_resolve(SpmvArgs &a)
+{
+    if (a.coef_mode != 0) {
+        a.alpha = a.coef[0];
+        if (a.coef_mode == 1) a.beta = a.coef[1];
+    }
+}
 
 // element (u, d) of the product basis <-> its position in the band-major ("tiled") order (band, u, d % B): the B minor
 // indices of one band are contiguous for every major index, so 8 consecutive far rows gather one 128-byte line per entry
@@ -324,13 +340,18 @@ int launch_build_rowblocks(const int64_t *d_ia, int64_t nrows, int64_t window, i
 int launch_reduce_partials(const double *partials, int nparts, int ncomp, double *out, hipStream_t s);
 int launch_dotc(const d2 *x, const d2 *y, int64_t n, double *partials, hipStream_t s);
 int launch_axpy_norm(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, int64_t n, double *partials, double *yr, int *flag,
-                     hipStream_t s);
+                     hipStream_t s, const double *scale_dev = nullptr);
 // the same passes writing the TILED copy of the updated y as well (Kronecker split, band 8: the next SpMV's far-pass gather source)
 int launch_axpy_norm_tile(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, d2 *yt, int64_t n, const KronTile &t, double *partials,
-                          hipStream_t s);
+                          hipStream_t s, const double *scale_dev = nullptr);
+// tail of a pipelined Lanczos step: |w'|^2 from the axpy's partial sums, a = sc_x * <u, w>, b = sqrt(|w'|^2), the next step's
+// coefficients into state[0..3], {<u,w>, |w'|^2, a, b} into log_slot (host-visible)
+int launch_lanczos_tail(const double *partials, int nparts, const double *dot, double *state, double *log_slot, double sc_x_host, int use_host,
+                        hipStream_t s);
 int launch_xpby_tile(const d2 *x, double b, d2 *y, d2 *yt, int64_t n, const KronTile &t, hipStream_t s);
 int launch_nrm2sq(const d2 *x, int64_t n, double *partials, hipStream_t s);
 int launch_scal(double a, d2 *x, int64_t n, hipStream_t s);
+int launch_scal_to(double a, const d2 *x, d2 *y, int64_t n, hipStream_t s);
 int launch_axpy_norm_re(double alpha, const double *alpha_dev, const double *x, double *y, int64_t n, double *partials, hipStream_t s,
                         double *yt = nullptr, const KronTile &t = KronTile{1, 1, 1});
 int launch_cg_update_re(double alpha, const double *p, const double *pp, double *v, double *r, int64_t n, double *partials, hipStream_t s);
@@ -742,4 +763,27 @@ struct qbh_csr {
     const double *ovr_xr = nullptr;  // all-real operation requested by a driver for the next spmv_run: x and ...
     double       *ovr_yr = nullptr;  // ... y as packed doubles (the complex pointer arguments are ignored)
     bool      defer_red = false;     // spmv_run leaves its three reduced scalars in d_scal[0..2] (no copy, no sync)
+
+    // Pipelined three-term recurrence (lanczos_core, round 6): step m + 1 is enqueued before step m's scalars have been read
+    // back.  ovr_yin / ovr_coef apply to the next spmv_run only (SpmvArgs::yin / coef).
+    const qbh::d2 *ovr_yin = nullptr;
+    const double  *ovr_coef = nullptr;
+    struct LzPipe {
+        qbh::d2 *d_buf = nullptr;    // third vector: a step writes v_m where v_{m-3} was, so a discarded speculative step destroys nothing
+        int64_t  cap = 0;            // its capacity in elements
+        double  *d_state = nullptr;  // [8] alpha, beta, axpy scale of the NEXT step, scale of the newest vector (k_lanczos_tail)
+        double  *h_log = nullptr;    // pinned, device-visible: kLzRing slots of 4 doubles {<u,w>, |w'|^2, a, b}, written by the tail kernel itself
+        double  *d_log = nullptr;    // the device address of h_log
+        hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};    // one per slot: its tail kernel has finished
+    } lz;
+    // SpMV timing events of the steps still in flight behind the current set ev0..ev3 (profile = 1 under a pipelined driver)
+    struct EvSet {
+        hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool p = false, p2 = false, drop = false;
+    };
+    EvSet ev_old[3];
+    int   n_ev_old = 0;
+    bool  ev_keep = false;           // set by a pipelined driver: next_event_set() queues the current set instead of waiting for it
+    bool  ev_drop = false;           // the current set times a discarded speculative SpMV: not counted
 };
+constexpr int kLzRing = 8;

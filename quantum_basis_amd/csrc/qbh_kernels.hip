@@ -173,7 +173,7 @@ __device__ __forceinline__ int64_t out_row(const SpmvArgs &a, int64_t row)
 __device__ __forceinline__ d2 load_y_old(const SpmvArgs &a, int64_t row)
 {
     row = out_row(a, row);
-    return a.y_re != nullptr ? d2{a.y_re[row], 0.0} : a.y[row];
+    return a.y_re != nullptr ? d2{a.y_re[row], 0.0} : a.yin[row];
 }
 __device__ __forceinline__ d2 load_x_local(const SpmvArgs &a, int64_t row)
 {
@@ -212,6 +212,7 @@ __device__ __forceinline__ void row_epilogue(const SpmvArgs &a, int64_t row, d2 
 template <int NPB, int TPR, bool DICT>
 __global__ __launch_bounds__(kBlock) void k_spmv_stream(SpmvArgs a)
 {
+    spmv_args_resolve(a);
     __shared__ d2 prod[NPB];
     __shared__ int rowoff[kRowCap + 1];
     __shared__ double red[12];
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(SpmvArgs a)
 template <int NPB, int P, int UN, int DICT, bool REALX>
 __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
 {
+    spmv_args_resolve(a);
     constexpr int R = kBlock / P;            // rows per pass
     constexpr int U = NPB / kBlock;          // staged cols per lane
     constexpr int CPW = DICT >= 2 ? 4 : 8;   // codes per 8-byte word
@@ -604,6 +606,7 @@ __device__ __forceinline__ void wave_lds_fence()
 template <int TPR, bool DYN>
 __global__ __launch_bounds__(kBlock) void k_spmv_wave(SpmvArgs a)
 {
+    spmv_args_resolve(a);
     constexpr int U = 8, NW = 64 * U, RP = 64 / TPR;
     __shared__ d2 prod_s[4 * NW];
     __shared__ double red[12];
@@ -663,7 +666,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_wave(SpmvArgs a)
                 s0 = (int)(a.ia[r0 + rloc] - base);
                 e0 = (int)(a.ia[r0 + rloc + 1] - base);
                 if (sub == 0) {
-                    if (need_y) yo = a.y[r0 + rloc];
+                    if (need_y) yo = a.yin[r0 + rloc];
                     if (need_x) xi = a.xl[r0 + rloc];
                 }
             }
@@ -738,8 +741,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv_wave(SpmvArgs a)
     }
 }
 
-int launch_spmv_wave(const SpmvArgs &a, int tpr, int grid, hipStream_t s)
+int launch_spmv_wave(const SpmvArgs &a_in, int tpr, int grid, hipStream_t s)
 {
+    SpmvArgs a = a_in;
+    if (a.yin == nullptr) a.yin = a.y;           // the beta term reads y itself unless a driver names another vector
     if (a.swizzle == 3) {
         switch (tpr) {
         case 2:  hipLaunchKernelGGL((k_spmv_wave<2, true>),  dim3(grid), dim3(kBlock), 0, s, a); break;
@@ -839,6 +844,7 @@ int launch_build_wavedesc(const int64_t *d_ia, int64_t nrows, int64_t window, Wa
 template <int TPR, int OPS, bool DYN, bool C16 = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 0 || OPS == 3) ? QBH_FAR_WAVES : QBH_NEAR_WAVES, (OPS == 0 || OPS == 3) ? QBH_FAR_WAVES : QBH_NEAR_WAVES))) void k_spmv_wave2(SpmvArgs a)
 {
+    spmv_args_resolve(a);
     static_assert(!C16 || OPS == 1 || OPS == 2 || OPS == 3, "2-byte columns: the one-class near passes and the sliced far pass");
     constexpr int NW = 512, RP = 64 / TPR;
     constexpr bool EPI = OPS == 1 || OPS == 2 || OPS == 4, FAR = OPS == 2 || OPS == 4;      // OPS 1: the fused epilogue WITHOUT a far addend
@@ -988,7 +994,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
         if (EPI) {
             int64_t row = rloc < b.nr ? (int64_t)b.r0 + rloc : 0;
             if (MULTI && rloc >= b.nr) row = b.r0 < a.nrows ? b.r0 : a.nrows - 1;      // idle lanes: a row of the block's own class (the class search starts there)
-            o.yo = a.y[row];
+            o.yo = a.yin[row];
             o.xi = a.xl[row];
             o.fr = FAR ? far_at(row, b.cls) : d2{0.0, 0.0};
             if (!need_y) o.yo = d2{0.0, 0.0};
@@ -1210,7 +1216,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
                         s_ = (int)(a.ia[b0.r0 + row] - b0.p0);
                         e_ = (int)(a.ia[b0.r0 + row + 1] - b0.p0);
                         if (EPI && sub == 0) {
-                            yo = need_y ? a.y[b0.r0 + row] : d2{0.0, 0.0};
+                            yo = need_y ? a.yin[b0.r0 + row] : d2{0.0, 0.0};
                             xi = a.xl[b0.r0 + row];
                             if (FAR) fr = far_at((int64_t)b0.r0 + row, b0.cls);
                         }
@@ -1240,7 +1246,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
                 if (lane == 0) {
                     d2 yo = {0.0, 0.0}, xi = {0.0, 0.0}, fr = {0.0, 0.0};
                     if (EPI) {
-                        if (need_y) yo = a.y[row];
+                        if (need_y) yo = a.yin[row];
                         xi = a.xl[row];
                         if (FAR) fr = far_at(row, b0.cls);
                     }
@@ -1355,8 +1361,10 @@ static void launch_wave2_tpr(const SpmvArgs &a, int tpr, int grid, hipStream_t s
     }
 }
 
-int launch_spmv_wave2(const SpmvArgs &a, int tpr, int ops, int grid, hipStream_t s)
+int launch_spmv_wave2(const SpmvArgs &a_in, int tpr, int ops, int grid, hipStream_t s)
 {
+    SpmvArgs a = a_in;
+    if (a.yin == nullptr) a.yin = a.y;           // the beta term reads y itself unless a driver names another vector
     if (a.swizzle == 3 && (ops == 1 || ops == 2 || ops == 4) && a.chunk_red == nullptr) {
         set_error("launch_spmv_wave2: the dynamic walk of an epilogue pass needs its chunk-partial slots");
         return QBH_EINVAL;
@@ -1679,6 +1687,7 @@ int launch_kron_fill(const int64_t *ia, const int32_t *ja, const d2 *val, int64_
 template <int G, int UN, bool DICT>
 __global__ __launch_bounds__(kBlock) void k_spmv_vector(SpmvArgs a)
 {
+    spmv_args_resolve(a);
     __shared__ double red[12];
     __shared__ d2 dict_s[DICT ? 256 : 1];
     const int tid = threadIdx.x;
@@ -1929,8 +1938,10 @@ static int launch_spmv_t(const SpmvArgs &a, int kernel, int npb, int tpr, int gr
     }
 }
 
-int launch_spmv(const SpmvArgs &a, int kernel, int npb, int tpr, int grid, hipStream_t s)
+int launch_spmv(const SpmvArgs &a_in, int kernel, int npb, int tpr, int grid, hipStream_t s)
 {
+    SpmvArgs a = a_in;
+    if (a.yin == nullptr) a.yin = a.y;           // the beta term reads y itself unless a driver names another vector
     int rc;
     if (kernel == QBH_KERNEL_ROWS) {
         switch (a.code == nullptr ? 0 : a.dict_mode) {
@@ -2202,6 +2213,48 @@ int launch_reduce_partials(const double *partials, int nparts, int ncomp, double
     return QBH_OK;
 }
 
+// Tail of a pipelined Lanczos step (lanczos_core): the second stage of the axpy's |w'|^2 (the same summation order as
+// k_reduce_partials, so b_m is the number the unpipelined step returns), then the scalars of src/lanczos.cc:200-214 in the
+// arithmetic the host used to do -- a = sc_x * <u, w>, b = sqrt(|w'|^2), sc_new = 1 / b -- and the NEXT step's coefficients
+// (alpha = sc_new, beta = -b * sc_x, axpy scale = -sc_new^2) left in state[] for the kernels of step m + 1, which the host has
+// already enqueued.  The four numbers of this step go to a pinned host slot directly: no copy engine in the stream.
+__global__ __launch_bounds__(1024) void k_lanczos_tail(const double *partials, int nparts, const double *dot, double *state, double *log_slot,
+                                                       double sc_x_host, int use_host)
+{
+    __shared__ double sm[16];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 1024) v += partials[i];
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sq = 0.0;
+        for (int w = 0; w < 16; ++w) sq += sm[w];
+        const double sc_x = use_host ? sc_x_host : state[3];
+        const double d = dot[0];
+        const double a = sc_x * d;
+        const double b = sqrt(sq);
+        const double sc_new = 1.0 / b;
+        state[0] = sc_new;
+        state[1] = -b * sc_x;
+        state[2] = -sc_new * sc_new;
+        state[3] = sc_new;
+        log_slot[0] = d;
+        log_slot[1] = sq;
+        log_slot[2] = a;
+        log_slot[3] = b;
+        __threadfence_system();
+    }
+}
+int launch_lanczos_tail(const double *partials, int nparts, const double *dot, double *state, double *log_slot, double sc_x_host, int use_host,
+                        hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lanczos_tail, dim3(1), dim3(1024), 0, s, partials, nparts, dot, state, log_slot, sc_x_host, use_host);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
 __global__ __launch_bounds__(kBlock) void k_dotc(const d2 *x, const d2 *y, int64_t n, double *partials)
 {
     __shared__ double red[8];
@@ -2231,12 +2284,14 @@ int launch_dotc(const d2 *x, const d2 *y, int64_t n, double *partials, hipStream
 // path, produced here instead of by a separate k_pack_real pass; flag as in k_pack_real.
 // alpha_dev != nullptr: the coefficient is alpha.x * alpha_dev[0] (a scalar a previous kernel of the same stream left
 // on the device -- the Lanczos step then needs one host synchronisation instead of two)
+// scale_dev != nullptr (pipelined Lanczos step): alpha.x itself is read from the device as well
 __global__ __launch_bounds__(kBlock) void k_axpy_norm(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, int64_t n,
-                                                      double *partials, double *yr, int *flag)
+                                                      double *partials, double *yr, int *flag, const double *scale_dev)
 {
     __shared__ double red[4];
     double acc[1] = {0.0};
     bool bad = false;
+    if (scale_dev != nullptr) alpha.x = scale_dev[0];
     if (alpha_dev != nullptr) alpha = d2{alpha.x * alpha_dev[0], 0.0};
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
@@ -2254,9 +2309,9 @@ __global__ __launch_bounds__(kBlock) void k_axpy_norm(d2 alpha, const double *al
 }
 
 int launch_axpy_norm(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, int64_t n, double *partials, double *yr, int *flag,
-                     hipStream_t s)
+                     hipStream_t s, const double *scale_dev)
 {
-    hipLaunchKernelGGL(k_axpy_norm, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, alpha_dev, x, y, n, partials, yr, flag);
+    hipLaunchKernelGGL(k_axpy_norm, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, alpha_dev, x, y, n, partials, yr, flag, scale_dev);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }
@@ -2278,13 +2333,14 @@ int launch_axpy_norm(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, int6
 #endif
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_axpy_norm_tile8(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, d2 *yt, KronTile t,
-                                                            int64_t nfb, double *partials)
+                                                            int64_t nfb, double *partials, const double *scale_dev)
 {
     constexpr int TU = QBH_TILE_TU, TB = QBH_TILE_TB, RW = TB * 8, LD = RW + 1;      // RW: elements of one major index in the item
     static_assert(TU * TB == 256 && (TU & (TU - 1)) == 0 && (TB & (TB - 1)) == 0, "TU x TB = 256, powers of two");
     __shared__ d2 tilebuf[TU * LD];
     __shared__ double red[4];
     double acc[1] = {0.0};
+    if (MODE == 0 && scale_dev != nullptr) alpha.x = scale_dev[0];
     if (MODE == 0 && alpha_dev != nullptr) alpha = d2{alpha.x * alpha_dev[0], 0.0};
     auto upd = [&](d2 xv, d2 yv) -> d2 {
         if (MODE == 0) {
@@ -2340,10 +2396,10 @@ __global__ __launch_bounds__(kBlock) void k_axpy_norm_tile8(d2 alpha, const doub
 
 // grid = blas_grid(n): the partial sums are reduced by the same second stage as k_axpy_norm's
 int launch_axpy_norm_tile(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, d2 *yt, int64_t n, const KronTile &t, double *partials,
-                          hipStream_t s)
+                          hipStream_t s, const double *scale_dev)
 {
     if (t.B != 8 || t.S < 8) return QBH_EINVAL;
-    hipLaunchKernelGGL(k_axpy_norm_tile8<0>, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, alpha_dev, x, y, yt, t, t.S / 8, partials);
+    hipLaunchKernelGGL(k_axpy_norm_tile8<0>, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, alpha_dev, x, y, yt, t, t.S / 8, partials, scale_dev);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }
@@ -2351,7 +2407,7 @@ int launch_xpby_tile(const d2 *x, double b, d2 *y, d2 *yt, int64_t n, const Kron
 {
     if (t.B != 8 || t.S < 8) return QBH_EINVAL;
     hipLaunchKernelGGL(k_axpy_norm_tile8<1>, dim3(blas_grid(n)), dim3(kBlock), 0, s, d2{b, 0.0}, (const double *)nullptr, x, y, yt, t, t.S / 8,
-                       (double *)nullptr);
+                       (double *)nullptr, (const double *)nullptr);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }
@@ -2380,6 +2436,19 @@ __global__ __launch_bounds__(kBlock) void k_scal(double a, d2 *x, int64_t n)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) x[i] = a * x[i];
+}
+
+// y = a * x (out of place: the exit of the pipelined Lanczos driver moves a vector into the caller's slot and normalises it in one pass)
+__global__ __launch_bounds__(kBlock) void k_scal_to(double a, const d2 *x, d2 *y, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) y[i] = a * x[i];
+}
+int launch_scal_to(double a, const d2 *x, d2 *y, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_scal_to, dim3(blas_grid(n)), dim3(kBlock), 0, s, a, x, y, n);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
 }
 
 int launch_scal(double a, d2 *x, int64_t n, hipStream_t s)

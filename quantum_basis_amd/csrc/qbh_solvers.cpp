@@ -52,6 +52,14 @@ extern "C" int qbh_hess_eigen(const double *hessenberg, int64_t maxit, int64_t m
 // ----------------------------------------------------------------- Lanczos ------
 // ext_rv != nullptr: the caller's vectors ARE packed doubles (two slots of nrows doubles; qbh_lanczos_real_dev) -- the
 // all-real path runs in place, nothing complex is ever allocated.  Otherwise d_v holds the reference's complex slots.
+static void host_delay()
+{
+    const int us = qbh::debug_sw().host_delay_us;
+    if (us <= 0) return;
+    const double t0 = now_ms();
+    while ((now_ms() - t0) * 1e3 < us) { }
+}
+
 static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_t *m_out, qbh_z *d_v, double *ext_rv,
                         double *hess, const char *purpose, qbh_solver_info *info)
 {
@@ -202,6 +210,7 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
             QBH_TRY(rc1);
             double dot = 0.0;
             QBH_TRY(axpy_norm_deferred(A, -sc[sx] * sc[sx], vpt(mcur - 1), vpt(mcur), &dot, &sq));
+            host_delay();
             a[mcur - 1] = sc[sx] * dot;
             b[mcur] = std::sqrt(sq);
             sc[sy] = 1.0 / b[mcur];
@@ -257,15 +266,187 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
             return QBH_OK;
         }
     }
+    std::vector<double> w((size_t)mm + 8), zl((size_t)mm + 8), ws((size_t)mm + 8);     // ws always holds four Ritz values
+    int rc = QBH_OK;
+    // the convergence test of src/lanczos.cc:228-247 after step m: 1 = converged (stop), 0 = go on, -1 = error (rc set)
+    auto ritz_test = [&]() -> int {
+        // the four lowest Ritz values and the last component of the lowest Ritz vector: all the test below
+        // uses of hess_eigen's full decomposition (src/lanczos.cc:229-231), in O(m) instead of O(m^2..m^3)
+        double zl0 = 0.0;
+        const int nsm = (int)std::min<int64_t>(4, m);
+        for (int q = 0; q < 4; ++q) ws[(size_t)q] = 0.0;
+        rc = qbh::tridiag_lowest(m, a, b + 1, nsm, ws.data(), &zl0);
+        if (rc == QBH_ENOCONV) {           // overflow guard of the twisted factorisation: fall back to QL
+            rc = qbh::tridiag_eigen_lastrow(m, a, b + 1, w.data(), zl.data());
+            if (rc != QBH_OK) return -1;
+            int64_t imin = 0;
+            for (int64_t j = 1; j < m; ++j)
+                if (w[j] < w[imin]) imin = j;
+            std::copy(w.begin(), w.begin() + m, ws.begin());
+            std::partial_sort(ws.begin(), ws.begin() + nsm, ws.begin() + m);
+            zl0 = zl[(size_t)imin];
+        }
+        if (rc != QBH_OK) return -1;
+        const double ritz0 = ws[0], ritz1 = m > 1 ? ws[1] : 0.0;
+        if (m > 3) {
+            accuracy = std::fabs(b[m] * zl0);
+            const double accu_E0 = std::fabs((ritz0 - theta0_prev) / ritz0);
+            const double accu_E1 = std::fabs((ritz1 - theta1_prev) / ritz1);
+            if (info && info->log && info->log_len < info->log_cap) {
+                qbh_lanczos_row &r = info->log[info->log_len];
+                r.k = m;
+                for (int q = 0; q < 4; ++q) r.ritz[q] = ws[q];
+                r.a_km1 = a[m - 1];
+                r.b_k = b[m];
+                r.accuracy = accuracy;
+                r.accu_E0 = accu_E0;
+                r.accu_E1 = accu_E1;
+            }
+            if (info) info->log_len++;
+            if (accu_E0 < prec) cnt_accuE0++;
+            else cnt_accuE0 = 0;
+            if (cnt_accuE0 > 15 && accuracy < prec) return 1;   // :240
+        }
+        theta0_prev = ritz0;
+        theta1_prev = ritz1;
+        return 0;
+    };
+
+    // ---- the pipelined loop (qbh_opts.lanczos_pipeline): one GPU, complex vectors, no phi0 re-orthogonalisation ----
+    // Step j turns v_{j-1} (and v_{j-2}) into u_j in three launches that never need the host: the SpMV reads alpha_j = 1/b_{j-1}
+    // and beta_j = -b_{j-1}/b_{j-2} from device memory, the axpy its scale -1/b_{j-1}^2 likewise, and k_lanczos_tail turns the two
+    // reduced sums into a_{j-1}, b_j and the coefficients of step j + 1.  The host enqueues step j + 1 BEFORE it waits for step j's
+    // two numbers, so the Ritz test, the log row and every host-side latency run under the next SpMV.  u_j is written where
+    // v_{j-3} was (three buffers in rotation: the caller's two slots and one the handle keeps): a speculative step that the test
+    // then rules out -- convergence at :240, breakdown at :216 -- has destroyed nothing and is simply not counted.
+    const bool no_defer_sw = qbh::debug_sw().no_defer != 0;
+    bool pipe = A->opts.lanczos_pipeline != 0 && !A->has_comm && !is_val1 && rv == nullptr && !no_defer_sw && A->kind == 0 &&
+                A->nrows == A->ncols && !A->has_rem && (A->kron.active ? kron_path(A) : true);
+    if (pipe) {
+        qbh_csr::LzPipe &P = A->lz;
+        if (P.cap < n) {
+            if (P.d_buf) (void)hipFree(P.d_buf);
+            P.d_buf = nullptr;
+            P.cap = 0;
+            if (qbh::dev_alloc(&P.d_buf, (size_t)n * sizeof(d2)) != hipSuccess) {
+                (void)hipGetLastError();
+                P.d_buf = nullptr;
+                pipe = false;                              // no room for the third vector: the unpipelined loop
+            } else {
+                P.cap = n;
+            }
+        }
+        if (pipe && !P.d_state) {
+            QBH_HIP(qbh::dev_alloc(&P.d_state, 8 * sizeof(double)));
+            QBH_HIP(hipHostMalloc(&P.h_log, (size_t)kLzRing * 4 * sizeof(double), hipHostMallocMapped));
+            QBH_HIP(hipHostGetDevicePointer((void **)&P.d_log, P.h_log, 0));
+            for (hipEvent_t &e : P.ev) QBH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+    }
+    if (pipe) {
+        qbh_csr::LzPipe &P = A->lz;
+        struct KeepGuard {
+            qbh_csr *A;
+            ~KeepGuard() { A->ev_keep = false; A->ovr_yin = nullptr; A->ovr_coef = nullptr; A->defer_red = false; }
+        } keep_guard{A};
+        A->ev_keep = true;
+        d2 *B[3] = {v, v + (size_t)n, P.d_buf};
+        const int64_t k_in = k;
+        const int c0 = (int)(k_in % 2);
+        const int cyc[3] = {1 - c0, c0, 2};                // where v_{k-1}, v_k and u_{k+1} live; period 3 from there
+        auto buf = [&](int64_t j) { return B[cyc[(j - (k_in - 1)) % 3]]; };
+        int64_t enq = k_in;                                // last step enqueued
+        auto enqueue = [&](int64_t j) -> int {
+            const bool first = j == k_in + 1;              // its coefficients are the host's: sc = 1 for both vectors handed in
+            d2 *x = buf(j - 1), *y = buf(j);
+            A->defer_red = true;
+            A->ovr_yin = buf(j - 2);
+            A->ovr_coef = first ? nullptr : P.d_state;
+            const int rc1 = spmv_run(A, x, y, 1.0, -b[k_in], 0.0, red);     // (alpha, beta ignored when the device names them)
+            A->defer_red = false;
+            A->ovr_yin = nullptr;
+            A->ovr_coef = nullptr;
+            QBH_TRY(rc1);
+            const double *scale_dev = first ? nullptr : P.d_state + 2;
+            double *yr = packed_target(A);
+            if (d2 *yt = tiled_target(A)) {
+                QBH_TRY(qbh::launch_axpy_norm_tile(d2{-1.0, 0.0}, A->d_scal, x, y, yt, n, A->kron.t, A->d_partials, A->stream, scale_dev));
+                A->kron.xt_of = y;
+                A->xr_of = nullptr;
+            } else {
+                QBH_TRY(qbh::launch_axpy_norm(d2{-1.0, 0.0}, A->d_scal, x, y, n, A->d_partials, yr, A->d_flag, A->stream, scale_dev));
+                A->xr_of = yr ? y : nullptr;
+                A->kron.xt_of = nullptr;
+            }
+            const int slot = (int)(j % kLzRing);
+            QBH_TRY(qbh::launch_lanczos_tail(A->d_partials, qbh::blas_grid(n), A->d_scal, P.d_state, P.d_log + 4 * slot, 1.0, first ? 1 : 0, A->stream));
+            QBH_HIP(hipEventRecord(P.ev[slot], A->stream));
+            enq = j;
+            return QBH_OK;
+        };
+        // a_{j-1}, b_j of step j; with `speculate` the step after it goes out first
+        auto accept = [&](int64_t j, bool speculate) -> int {
+            if (speculate && enq == j && !qbh::debug_sw().pipe_nospec) QBH_TRY(enqueue(j + 1));
+            const int slot = (int)(j % kLzRing);
+            QBH_HIP(hipEventSynchronize(P.ev[slot]));
+            host_delay();
+            const volatile double *L = P.h_log + 4 * slot;
+            a[j - 1] = L[2];
+            b[j] = L[3];
+            return QBH_OK;
+        };
+        if (k == 0) {                                      // :167-191 -- the bootstrap step is never tested, the do-while always follows
+            b[0] = 0.0;
+            QBH_TRY(enqueue(1));
+            QBH_TRY(accept(1, true));
+            m = ++k;
+            --np;
+        }
+        do {                                               // :193
+            m++;
+            if (enq < m) rc = enqueue(m);
+            if (rc == QBH_OK) rc = accept(m, m < mm);
+            if (rc != QBH_OK) break;
+            if (std::fabs(b[m]) < prec) break;             // :216
+            if (is_val && ritz_test() != 0) break;         // :228-247
+        } while (m < mm);
+        if (enq > m) {                                     // the speculative step: not a step of this run
+            A->stats.n_spmv--;
+            A->ev_drop = true;
+            A->kron.xt_of = nullptr;
+            A->xr_of = nullptr;
+        }
+        if (rc == QBH_OK) {
+            // v_m and v_{m-1} = u / b into the caller's slots m % 2 and (m - 1) % 2 (src/qbasis.h:1056-1058): the normalisation
+            // pass the unpipelined loop makes on exit, out of place where the rotation left a vector in another buffer
+            auto scale_of = [&](int64_t j) { return j > k_in ? 1.0 / b[j] : 1.0; };
+            struct Mv { d2 *src, *dst; double sc; } mv[2] = {{buf(m), B[m % 2], scale_of(m)}, {buf(m - 1), B[(m - 1) % 2], scale_of(m - 1)}};
+            auto move = [&](const Mv &q) -> int {
+                if (q.src == q.dst) return q.sc != 1.0 ? qbh::launch_scal(q.sc, q.dst, n, A->stream) : QBH_OK;
+                return qbh::launch_scal_to(q.sc, q.src, q.dst, n, A->stream);
+            };
+            if (mv[0].dst == mv[1].src && mv[1].dst == mv[0].src) {        // exchanged: through the free buffer
+                d2 *spare = B[2];                          // both sources are the caller's slots, so the handle's buffer is the free one
+                rc = qbh::launch_scal_to(mv[0].sc, mv[0].src, spare, n, A->stream);
+                if (rc == QBH_OK) rc = move(mv[1]);
+                if (rc == QBH_OK) rc = qbh::launch_scal_to(1.0, spare, mv[0].dst, n, A->stream);
+            } else if (mv[0].dst == mv[1].src) {
+                rc = move(mv[1]);
+                if (rc == QBH_OK) rc = move(mv[0]);
+            } else {
+                rc = move(mv[0]);
+                if (rc == QBH_OK) rc = move(mv[1]);
+            }
+            A->kron.xt_of = nullptr;
+            A->xr_of = nullptr;
+        }
+    } else {
     if (k == 0) {                                          // :167-191
         b[0] = 0.0;
         QBH_TRY(step(1, 0.0));
         m = ++k;
         --np;
     }
-
-    std::vector<double> w((size_t)mm + 8), zl((size_t)mm + 8), ws((size_t)mm + 8);     // ws always holds four Ritz values
-    int rc = QBH_OK;
     do {                                                   // :193
         m++;
         rc = step(m, b[m - 1]);
@@ -299,47 +480,11 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
         }
 
         if (is_val) {                                      // :228-247
-            // the four lowest Ritz values and the last component of the lowest Ritz vector: all the test below
-            // uses of hess_eigen's full decomposition (src/lanczos.cc:229-231), in O(m) instead of O(m^2..m^3)
-            double zl0 = 0.0;
-            const int nsm = (int)std::min<int64_t>(4, m);
-            for (int q = 0; q < 4; ++q) ws[(size_t)q] = 0.0;
-            rc = qbh::tridiag_lowest(m, a, b + 1, nsm, ws.data(), &zl0);
-            if (rc == QBH_ENOCONV) {           // overflow guard of the twisted factorisation: fall back to QL
-                rc = qbh::tridiag_eigen_lastrow(m, a, b + 1, w.data(), zl.data());
-                if (rc != QBH_OK) break;
-                int64_t imin = 0;
-                for (int64_t j = 1; j < m; ++j)
-                    if (w[j] < w[imin]) imin = j;
-                std::copy(w.begin(), w.begin() + m, ws.begin());
-                std::partial_sort(ws.begin(), ws.begin() + nsm, ws.begin() + m);
-                zl0 = zl[(size_t)imin];
-            }
-            if (rc != QBH_OK) break;
-            const double ritz0 = ws[0], ritz1 = m > 1 ? ws[1] : 0.0;
-            if (m > 3) {
-                accuracy = std::fabs(b[m] * zl0);
-                const double accu_E0 = std::fabs((ritz0 - theta0_prev) / ritz0);
-                const double accu_E1 = std::fabs((ritz1 - theta1_prev) / ritz1);
-                if (info && info->log && info->log_len < info->log_cap) {
-                    qbh_lanczos_row &r = info->log[info->log_len];
-                    r.k = m;
-                    for (int q = 0; q < 4; ++q) r.ritz[q] = ws[q];
-                    r.a_km1 = a[m - 1];
-                    r.b_k = b[m];
-                    r.accuracy = accuracy;
-                    r.accu_E0 = accu_E0;
-                    r.accu_E1 = accu_E1;
-                }
-                if (info) info->log_len++;
-                if (accu_E0 < prec) cnt_accuE0++;
-                else cnt_accuE0 = 0;
-                if (cnt_accuE0 > 15 && accuracy < prec) break;   // :240
-            }
-            theta0_prev = ritz0;
-            theta1_prev = ritz1;
+            const int t = ritz_test();
+            if (t != 0) break;
         }
     } while (m < mm);
+    }
     if (rc == QBH_OK) rc = finish_real_wire(A);
     if (rc == QBH_OK) rc = normalise_slots();
     if (rc == QBH_OK) {

@@ -39,28 +39,74 @@ int finish_reduction(qbh_csr *A, int nparts, int ncomp, double *host_out)
     return QBH_OK;
 }
 
-void harvest_events(qbh_csr *A)
+static void harvest_set(qbh_csr *A, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, bool p, bool p2, bool drop)
 {
     float ms = 0.f, total = 0.f;
     bool any = false;
-    if (A->ev_pending) {
-        if (hipEventSynchronize(A->ev1) == hipSuccess && hipEventElapsedTime(&ms, A->ev0, A->ev1) == hipSuccess) {
-            total += ms;
-            any = true;
-        }
-        A->ev_pending = false;
+    if (p && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+        total += ms;
+        any = true;
     }
-    if (A->ev_pending2) {
-        if (hipEventSynchronize(A->ev3) == hipSuccess && hipEventElapsedTime(&ms, A->ev2, A->ev3) == hipSuccess) {
-            total += ms;
-            any = true;
-        }
-        A->ev_pending2 = false;
+    if (p2 && hipEventSynchronize(e3) == hipSuccess && hipEventElapsedTime(&ms, e2, e3) == hipSuccess) {
+        total += ms;
+        any = true;
     }
-    if (any) {
+    if (any && !drop) {
         A->stats.ms_spmv += total;
         if (total < A->stats.ms_spmv_min) A->stats.ms_spmv_min = total;
     }
+}
+
+// everything that is pending: the sets queued behind the current one (oldest first), then the current one
+void harvest_events(qbh_csr *A)
+{
+    for (int i = 0; i < A->n_ev_old; ++i) {
+        qbh_csr::EvSet &o = A->ev_old[i];
+        harvest_set(A, o.e[0], o.e[1], o.e[2], o.e[3], o.p, o.p2, o.drop);
+        o.p = o.p2 = o.drop = false;
+    }
+    // the queued sets keep their events (reused by next_event_set); they are simply no longer pending
+    harvest_set(A, A->ev0, A->ev1, A->ev2, A->ev3, A->ev_pending, A->ev_pending2, A->ev_drop);
+    A->ev_pending = A->ev_pending2 = A->ev_drop = false;
+}
+
+// In front of an SpMV's first timing event.  Ordinarily: wait for the previous SpMV's events (as ever).  Under a pipelined driver
+// (ev_keep) the previous SpMV may not even have started: its set is queued and a free one becomes current; only a set three
+// SpMVs old is ever waited for.
+int next_event_set(qbh_csr *A)
+{
+    if (!A->ev_keep) {
+        harvest_events(A);
+        return QBH_OK;
+    }
+    if (!A->ev_pending && !A->ev_pending2) return QBH_OK;            // the current set is free
+    constexpr int NQ = (int)(sizeof(A->ev_old) / sizeof(A->ev_old[0]));
+    // a slot whose set is no longer pending (or was never created) takes the current events; its own become current
+    int slot = -1;
+    for (int i = 0; i < NQ && slot < 0; ++i)
+        if (!A->ev_old[i].p && !A->ev_old[i].p2) slot = i;
+    if (slot < 0) {                                                   // all in flight: the oldest is three SpMVs old
+        qbh_csr::EvSet &o = A->ev_old[0];
+        harvest_set(A, o.e[0], o.e[1], o.e[2], o.e[3], o.p, o.p2, o.drop);
+        o.p = o.p2 = o.drop = false;
+        qbh_csr::EvSet first = A->ev_old[0];
+        for (int i = 0; i + 1 < NQ; ++i) A->ev_old[i] = A->ev_old[i + 1];
+        A->ev_old[NQ - 1] = first;
+        slot = NQ - 1;
+    }
+    qbh_csr::EvSet &q = A->ev_old[slot];
+    for (int k = 0; k < 4; ++k)
+        if (!q.e[k]) QBH_HIP(hipEventCreate(&q.e[k]));
+    std::swap(q.e[0], A->ev0);
+    std::swap(q.e[1], A->ev1);
+    std::swap(q.e[2], A->ev2);
+    std::swap(q.e[3], A->ev3);
+    q.p = A->ev_pending;
+    q.p2 = A->ev_pending2;
+    q.drop = A->ev_drop;
+    A->ev_pending = A->ev_pending2 = A->ev_drop = false;
+    if (slot + 1 > A->n_ev_old) A->n_ev_old = slot + 1;
+    return QBH_OK;
 }
 
 
@@ -132,7 +178,7 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
             K.xt_of = nullptr;
         }
         if (prof) {
-            harvest_events(A);
+            QBH_TRY(next_event_set(A));
             QBH_HIP(hipEventRecord(A->ev0, s));
         }
         if (K.xt_of != (const void *)x) {
@@ -188,6 +234,13 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
     nr.swizzle = kron_swz;
     nr.wctr = A->d_wctr ? A->d_wctr + 256 : nullptr;
     nr.chunk_red = K.d_chunk_red;                            // dynamic walk: the near pass's reduction partials, one slot per chunk
+    if ((A->ovr_yin || A->ovr_coef) && comm) {
+        qbh::set_error("internal: the pipelined three-term step is a one-GPU form");
+        return QBH_EUNSUPP;
+    }
+    nr.yin = A->ovr_yin;                                     // pipelined three-term step (lanczos_core): out of place, coefficients on the device
+    nr.coef = A->ovr_coef;
+    nr.coef_mode = A->ovr_coef ? 1 : 0;
     const bool chunk_red = kron_swz == 3 && K.d_chunk_red != nullptr;
     if (kron_swz == 3 && !K.d_chunk_red) {
         qbh::set_error("Kronecker split: the chunk partials of the near pass were not allocated");
@@ -223,6 +276,8 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
                 cr.alpha = alpha;
                 cr.beta = 1.0;
                 cr.gamma = 0.0;
+                cr.coef = A->ovr_coef;
+                cr.coef_mode = A->ovr_coef ? 2 : 0;
                 cr.colmask = -1;
                 cr.chunk_mult = A->chunk_mult;
                 cr.swizzle = (A->opts.xcd_swizzle == 3 && !A->opts.deterministic && A->d_wctr) ? 3 : (A->opts.xcd_swizzle == 3 ? 2 : A->opts.xcd_swizzle);
@@ -269,7 +324,7 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
         }
     } else {
         if (prof) {
-            harvest_events(A);
+            QBH_TRY(next_event_set(A));
             QBH_HIP(hipEventRecord(A->ev0, s));
         }
         nr.far = nullptr;
@@ -329,6 +384,10 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         return QBH_EINVAL;
     }
     if (A->kron.active) return spmv_kron(A, x, y, alpha, beta, gamma, red);
+    if ((A->ovr_yin || A->ovr_coef) && (A->has_comm || A->kind != 0 || A->ovr_yr != nullptr || A->real_mode)) {
+        qbh::set_error("internal: the pipelined three-term step needs a stored complex operator on one GPU");
+        return QBH_EUNSUPP;
+    }
     const d2 *xg, *xl;
     bool async_gather = false;
     const bool packed = A->has_comm && A->real_wire;
@@ -389,7 +448,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         m.partials = red ? A->d_partials : nullptr;
         const bool profm = A->opts.profile != 0;
         if (profm) {
-            harvest_events(A);
+            QBH_TRY(next_event_set(A));
             QBH_HIP(hipEventRecord(A->ev0, A->stream));
         }
         int mf_parts = A->grid;
@@ -493,6 +552,9 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     a.alpha = alpha;
     a.beta = beta;
     a.gamma = gamma;
+    a.yin = A->ovr_yin;
+    a.coef = A->ovr_coef;
+    a.coef_mode = A->ovr_coef ? 1 : 0;
     a.partials = (red && !A->has_rem) ? A->d_partials : nullptr;
     a.swizzle = A->opts.xcd_swizzle;
     a.chunk_mult = A->chunk_mult;
@@ -511,7 +573,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         async_gather = false;
     }
     if (prof) {
-        harvest_events(A);
+        QBH_TRY(next_event_set(A));
         QBH_HIP(hipEventRecord(A->ev0, A->stream));
     }
     // complex128 values, complex vectors: the wave kernel; the real gather / all-real forms stay on the row kernel
@@ -635,6 +697,8 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         if (realm) a.xr = A->has_comm ? A->comm.d_xfull_r : xr_nocomm;
         a.beta = 1.0;                       // accumulate onto the local part's result
         a.gamma = 0.0;
+        a.yin = nullptr;
+        a.coef_mode = A->ovr_coef ? 2 : 0;
         a.partials = red ? A->d_partials : nullptr;
         a.unroll = R.unroll;
         if (prof) QBH_HIP(hipEventRecord(A->ev2, A->stream));

@@ -356,6 +356,10 @@ class csr_mat:
     def sync(self):
         check(lib().qbh_sync(self.handle), "qbh_sync")
 
+    def set_option(self, name, value):
+        """qbh_csr_set_option: lanczos_pipeline / profile / tile_fold on an existing operator."""
+        check(lib().qbh_csr_set_option(self.handle, name.encode(), int(value)), "qbh_csr_set_option")
+
     def stats(self, reset=False):
         s = _lib.Stats()
         check(lib().qbh_get_stats(self.handle, C.byref(s), int(reset)), "qbh_get_stats")
