@@ -592,6 +592,22 @@ def main():
     value_dict = args.value_dict if args.value_dict is not None else (1 if fmt_fast else 0)
     real_fp = args.real_fast_path if args.real_fast_path is not None else (1 if fmt_fast else 0)
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N rank processes ourselves -- FRESH processes, from a parent
+        # that has made no GPU call (never re-exec a process that has touched the GPU) -- relay rank 0's line and their exit code
+        import socket
+        import subprocess
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        pr = subprocess.run(cmd, env=env)
+        raise SystemExit(pr.returncode)
+
     import torch
     import torch.distributed as dist
     import quantum_basis_amd as q
@@ -601,10 +617,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
         args.gpus = world
     children, child_failures = [], []
+    if args.processes > 1 and ("rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROFILER_") or k.startswith("ROCPROF_") for k in os.environ)):
+        # under rocprofv3 this process has already been GPU-initialised by the profiler's preload and its children would inherit
+        # the preload: one process, so that kernel statistics and PMC means describe exactly one run
+        print("bench.py: profiler preload detected: --processes 1", file=sys.stderr)
+        args.processes = 1
     if world == 1 and args.processes > 1 and not args.child and not args.host_csr and not args.packed_real and not workloads()[args.workload].get("packed_real"):
         # fresh processes FIRST: this process has made no GPU call yet (torch.cuda.device_count() does not initialise the GPU
         # on this image), so each child sees the device as the driver's own process would
@@ -902,7 +921,7 @@ def main():
         med = runs[len(runs) // 2]
         mine = {"ms_per_launch": roof["ms_per_launch"], "frac": roof["frac"], "value": out["value"], "ms_per_step": out["ms_per_step"]}
         out["processes"] = {
-            "n": len(runs),
+            "n": len(runs), "requested": args.processes, "incomplete": len(runs) < args.processes,
             "what": "fresh child processes run one after the other BEFORE this process made any GPU call; each builds its own operator "
                     "and times W warm-up + exactly K Lanczos steps; headline value / ms_per_step / roofline = the median process",
             "ms_per_launch": [c["roofline"]["ms_per_launch"] for c in runs], "frac": [c["roofline"]["frac"] for c in runs],

@@ -151,6 +151,23 @@ def test_bench_two_ranks_on_one_gpu_through_the_native_communicator(rig):
     assert all(p["ms_spmv"] > 0 and p["rows"] > 0 for p in pr) and sum(p["rows"] for p in pr) == got["config"]["dim"], pr
 
 
+def test_bench_starts_its_own_ranks_when_no_launcher_did(rig):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the way the driver runs N = 1): the parent starts the rank processes itself
+    before it touches the GPU, relays rank 0's line and the ranks' exit code; --gpus 1 is unchanged."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(QBH_RCCL_LIB=STUB, QBH_DIST_BACKEND="gloo", TMPDIR=rig["tmp"], HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "4", "--warmup", "2", "--workload", "hubbard_4x3_half", "--no-cpu-baseline", "--no-matrix-free", "--no-fast-path", "--processes", "1"]
+    many = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert many.returncode == 0, many.stdout + many.stderr
+    lines = [ln for ln in many.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, many.stdout                                    # ONE JSON line, rank 0's
+    got = json.loads(lines[0])
+    assert got["n_gpus"] == 2 and got["steps"] == 4 and len(got["per_rank"]) == 2 and "native RCCL" in got["config"]["exchange"], got
+    assert abs(got["e0"] + 16.879382788684) < 1e-9
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "hubbard_4x3_half", "--packed-real"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert bad.returncode != 0                                             # the ranks' failure is the parent's exit code
+
+
 @pytest.mark.parametrize("nranks", [2, 3])
 def test_python_hosts_keep_their_split_shards_under_the_native_communicator(rig, nranks):
     """The Python route of bench.py (quantum_basis_amd.dist.NativeComm on a torch stream, torch's own rendezvous over gloo):

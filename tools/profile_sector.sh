@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp
-ARGS="--workload $WL --steps 10 --warmup 3"
+ARGS="--workload $WL --steps 10 --warmup 3 --processes 1 --no-locate"
 rm -rf /tmp/prof_$TAG; mkdir -p /tmp/prof_$TAG
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG/stats -o s -- python3 $R/bench.py $ARGS > /tmp/prof_$TAG/stats.log 2>&1
 python3 $R/tools/stats_summary.py /tmp/prof_$TAG/stats "python bench.py $ARGS" > $OUT/${TAG}_kernel_stats.txt
