@@ -892,7 +892,7 @@ def main():
                                                                                ("k_zero_cut_groups + k_spmv_wave2<.,3> (far, sliced) + k_spmv_wave2<.,2> (near); the tiled copy of x is written by the "
                                                                                 "pass that produces x (k_axpy_norm_tile8), k_kron_tile only in front of a driver's first step"
                                                                                 if world == 1 else
-                                                                                "tiled block -> all-gather || k_spmv_wave2<.,1> (near, own x) ; k_zero_cut_groups + k_spmv_wave2<.,3> (far, gathered tiled x) + k_kron_combine")
+                                                                                "tiled block (8-byte real parts when the solve is real: qbh_opts.real_wire) -> all-gather in parts || k_spmv_wave2<.,1> (near, own x) ; per part: k_kron_place (gathered blocks -> tiled order of the whole x) + k_spmv_wave2<.,3> (far, the one-GPU kernel, 2-byte columns) ; k_kron_combine")
                                                                                if info.kron_sliced else "k_kron_tile + k_spmv_wave2<.,0> (far) + k_spmv_wave2<.,2> (near)"),
                                                          "in_place": bool(info.kron_inplace)}
                                                         if info.kron_minor else None),
@@ -939,7 +939,7 @@ def main():
     if world > 1:
         # link bytes per GPU reported separately from the HBM bytes.  ms_per_gather is the event-timed duration of
         # the all-gather on RCCL's side stream (native communicator), max over ranks; it overlaps the locally-owned columns.
-        elem = 8 if real_used else 16
+        elem = int(A.info().wire_element_bytes) or (8 if real_used else 16)      # what the last gather carried (qbh_csr_info.wire_element_bytes)
         out["exchange"] = {"bytes_received_per_gpu_per_spmv": int(elem * dim * (world - 1) / world), "element_bytes": elem,
                            "ms_per_gather": round(head["ms_gather"], 4) if head["ms_gather"] > 0 else None,
                            "gathers": head["n_gather"],

@@ -182,6 +182,12 @@ typedef struct qbh_opts {
                                 convergence or breakdown the one speculative step is discarded (it wrote to a third vector the
                                 handle keeps), so m, a[], b[], the two vectors returned and the stop step are exactly those of
                                 the unpipelined loop.  0: one host synchronisation per step (the form of ABI <= 501)       */
+    int     real_wire;       /* [1] row shards of an operator split in place (kron_split) under a communicator: when the operator's
+                                values and the vectors of a solve are exactly real (the all-reduced sum of |Im|^2 of the start
+                                vectors is 0), the tiled blocks travel as 8-byte real parts (qbh_comm.d_xfull_r) and are expanded
+                                when they are moved to their place in the tiled x -- half the bytes on the links, the same
+                                numbers in the SpMV.  Independent of real_fast_path (which selects the real FORMS of the unsplit
+                                kernels).  0: 16-byte elements                                                             */
 } qbh_opts;
 
 void qbh_opts_default(qbh_opts *o);
@@ -256,6 +262,8 @@ typedef struct qbh_csr_info {
     int     basis_n_sites, basis_n_up, basis_n_dn;   /* the basis named by the caller or found (0 when basis_internal == 0)          */
     double  basis_detect_ms;                 /* wall ms the search took (inside create_ms for host arrays), whatever it found          */
     int     kron_table_kernel;               /* 1: the coded split was recognised as T (x) 1 + 1 (x) T' + D and the all-real SpMV runs the table kernel */
+    int     wire_element_bytes;              /* communicator attached: bytes per element of x the LAST gather put on the links -- 16 (complex128) or 8
+                                                (real parts only: qbh_opts.real_wire on split shards, the real fast path on plain ones); 0 before the first */
 } qbh_csr_info;
 int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info);
 
@@ -495,6 +503,11 @@ typedef struct qbh_comm {
      * stream after the completion of that part; the far pass of the band range runs while the later parts are on the wire. */
     int    (*allgather_part_begin)(void *ctx, int part, int nparts, const int64_t *off_len);
     int    (*allgather_part_wait)(void *ctx, int part);
+    /* optional (NULL = not provided; ABI 600): the gather in parts with the wire format named -- packed = 1: the pieces are
+     * DOUBLES [off_len[2q], + off_len[2q+1]) of rank q's block, from d_xsend viewed as double[] into d_xfull_r (qbh_opts.real_wire);
+     * packed = 0: exactly allgather_part_begin.  Without it a real solve on split shards gathers in one piece (allgather_begin
+     * with packed = 1). */
+    int    (*allgather_part_begin_w)(void *ctx, int part, int nparts, const int64_t *off_len, int packed);
 } qbh_comm;
 int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm);
 

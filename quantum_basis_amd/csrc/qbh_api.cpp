@@ -182,6 +182,7 @@ void qbh::opts_builtin(qbh_opts *o)
     o->basis_detect = 1;
     o->sector_orbit = 1;
     o->lanczos_pipeline = 1;
+    o->real_wire = 1;
     o->kron_minor = 0;
     o->deterministic = 0;
     o->basis_kind = QBH_BASIS_NONE;
@@ -1012,6 +1013,7 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->kron_classes = 0;
     info->kron_cols16 = 0;
     info->kron_cross_nnz = 0;
+    info->wire_element_bytes = A->has_comm ? A->wire_bytes_last : 0;
     info->gather_parts = A->has_comm ? ((A->kron.active && A->kron.comm_tiled) ? A->kron.n_parts : 1) : 0;
     if (A->kron.active) {
         const qbh_csr::KronSplit &K = A->kron;

@@ -97,9 +97,12 @@ inline bool kron_path(const qbh_csr *A)
 inline d2 *tiled_target(const qbh_csr *A)
 {
     if (!A->opts.tile_fold || !A->kron.fold || !kron_path(A) || A->kron.map.nc != 1 || A->kron.t.B != 8 || A->kron.t.S < 8) return nullptr;
-    if (A->has_comm) return A->real_wire ? nullptr : reinterpret_cast<d2 *>(A->comm.d_xsend);
+    if (A->has_comm) return reinterpret_cast<d2 *>(A->comm.d_xsend);      // (as packed real parts under the real wire: tiled_real)
     return (A->nrows == A->ncols && A->kron.xt_cap >= A->nrows) ? A->kron.d_xt : nullptr;
 }
+
+// does the tiled copy of a split shard's block travel as packed real parts (qbh_opts.real_wire, enabled per solve)?
+inline int tiled_real(const qbh_csr *A) { return (A->has_comm && A->real_wire && A->kron.active && A->kron.comm_tiled) ? 1 : 0; }
 
 // Only a driver knows that nothing else writes its vectors between the pass that produces x and the SpMV that reads it
 // (a caller of the building-block entry points may scale or overwrite a vector in between): the drivers hold this guard.

@@ -206,9 +206,11 @@ int hook_gather(void *ctx, int packed)
 // The gather in parts (qbh_comm::allgather_part_begin): part `part` of `nparts` = elements [off, off + len) of every rank's
 // block, one send + one receive per peer in a single group (each xGMI link carries one piece per direction), the own piece a
 // device copy; all on the side stream, in the order of the calls.  An event per part lets the operator's stream wait for one.
-int hook_part_begin(void *ctx, int part, int nparts, const int64_t *off_len)
+int hook_part_begin_w(void *ctx, int part, int nparts, const int64_t *off_len, int packed)
 {
     auto *c = static_cast<qbh_native_comm *>(ctx);
+    const size_t w = packed ? 1 : 2;                               // doubles per element on the wire
+    double *recv = packed ? c->d_xfull_r : c->d_xfull;
     if (part < 0 || part >= 8 || nparts > 8) return 1;
     const bool timed = c->owner && c->owner->opts.profile != 0;
     if (part == 0) {
@@ -226,14 +228,14 @@ int hook_part_begin(void *ctx, int part, int nparts, const int64_t *off_len)
             if (q == c->rank) continue;
             const int64_t off = off_len[2 * q], len = off_len[2 * q + 1];
             if (len > 0) {
-                r = c->api->Recv(c->d_xfull + (size_t)(base(q) + off) * 2, (size_t)len * 2, ncclDouble, q, c->comm, c->side);
+                r = c->api->Recv(recv + (size_t)(base(q) + off) * w, (size_t)len * w, ncclDouble, q, c->comm, c->side);
                 if (r != ncclSuccess) {
                     (void)c->api->GroupEnd();
                     return fail(c, "ncclRecv", r);
                 }
             }
             if (my_len > 0) {
-                r = c->api->Send(c->d_xsend + (size_t)my_off * 2, (size_t)my_len * 2, ncclDouble, q, c->comm, c->side);
+                r = c->api->Send(c->d_xsend + (size_t)my_off * w, (size_t)my_len * w, ncclDouble, q, c->comm, c->side);
                 if (r != ncclSuccess) {
                     (void)c->api->GroupEnd();
                     return fail(c, "ncclSend", r);
@@ -242,7 +244,7 @@ int hook_part_begin(void *ctx, int part, int nparts, const int64_t *off_len)
         }
         if ((r = c->api->GroupEnd()) != ncclSuccess) return fail(c, "ncclGroupEnd", r);
     }
-    if (my_len > 0 && hipMemcpyAsync(c->d_xfull + (size_t)(base(c->rank) + my_off) * 2, c->d_xsend + (size_t)my_off * 2, (size_t)my_len * 2 * sizeof(double),
+    if (my_len > 0 && hipMemcpyAsync(recv + (size_t)(base(c->rank) + my_off) * w, c->d_xsend + (size_t)my_off * w, (size_t)my_len * w * sizeof(double),
                                      hipMemcpyDeviceToDevice, c->side) != hipSuccess) {
         qbh::set_error("qbh_comm: device copy of the rank's own piece failed: %s", hipGetErrorString(hipGetLastError()));
         return 1;
@@ -254,6 +256,8 @@ int hook_part_begin(void *ctx, int part, int nparts, const int64_t *off_len)
     }
     return 0;
 }
+
+int hook_part_begin(void *ctx, int part, int nparts, const int64_t *off_len) { return hook_part_begin_w(ctx, part, nparts, off_len, 0); }
 
 int hook_part_wait(void *ctx, int part)
 {
@@ -420,6 +424,7 @@ extern "C" int qbh_comm_create_rccl(qbh_csr *A, const void *uid128, int rank, in
     h.allgather_wait = hook_wait;
     h.allgather_part_begin = hook_part_begin;
     h.allgather_part_wait = hook_part_wait;
+    h.allgather_part_begin_w = hook_part_begin_w;
     h.row_cuts = c->ragged ? c->cuts.data() : nullptr;
     rc = qbh_csr_set_comm(A, &h);
     if (rc != QBH_OK) return bail(rc);

@@ -55,7 +55,7 @@ int kron_gather_parts(qbh_csr *A, const qbh_comm *comm, int64_t want)
     K.part_off_len.assign((size_t)want * 2 * (size_t)comm->nranks, 0);
     for (int64_t k = 0; k < want; ++k)
         for (int q = 0; q < comm->nranks; ++q) {
-            const int64_t nu = K.cols.cu[q + 1] - K.cols.cu[q];
+            const int64_t nu = K.rank_cu[q + 1] - K.rank_cu[q];
             const int64_t off = band[k] * K.t.B * nu;
             const int64_t end = k == want - 1 ? nu * K.t.S : band[k + 1] * K.t.B * nu;
             K.part_off_len[((size_t)k * (size_t)comm->nranks + (size_t)q) * 2] = off;
@@ -72,15 +72,9 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
     if (!A) return QBH_EINVAL;
     if (!comm || comm->nranks < 1) {          // NULL detaches; a 1-rank communicator is valid (hooks still run)
         A->has_comm = false;
-        if (A->kron.active && A->kron.comm_tiled) {       // far columns back to the tiled order of the whole vector
-            Bind bind(A);
-            const qbh::KronCols one = kron_cols_one(A->kron.t.S, A->kron.NUg, A->kron.t.B);
-            if (A->kron.ja_f) QBH_TRY(qbh::launch_kron_remap_cols(A->kron.ja_f, A->kron.far_slots, A->kron.cols, one, A->stream));
-            QBH_TRY(qbh::launch_kron_remap_cols(A->kron.ja_x, A->kron.nnz_x, A->kron.cols, one, A->stream));
-            QBH_HIP(hipStreamSynchronize(A->stream));
-            A->kron.cols = one;
-            A->kron.map.cols = one;
+        if (A->kron.active && A->kron.comm_tiled) {       // (the far columns never left the tiled order of the whole vector)
             A->kron.comm_tiled = false;
+            A->kron.n_ranks = 1;
             A->kron.n_parts = 1;
             A->kron.xt_of = nullptr;
         }
@@ -139,7 +133,7 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
     };
     qbh_csr::KronSplit &K = A->kron;
     const int64_t S = K.active ? K.t.S : 1;
-    bool mine = local_err == QBH_OK && A->kind == 0 && K.active && K.map.nc == 1 && comm->nranks <= qbh::kKronMaxRanks && !(K.c16_f && comm->nranks > 1);
+    bool mine = local_err == QBH_OK && A->kind == 0 && K.active && K.map.nc == 1 && comm->nranks <= qbh::kKronMaxRanks;
     if (mine) {
         if (comm->row_cuts) {
             for (int q = 0; q <= comm->nranks; ++q) mine = mine && comm->row_cuts[q] % S == 0;
@@ -175,22 +169,30 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
         // and takes the generic path below; whether that worked is agreed on once more (a rank out of memory there must not
         // leave its peers attached and waiting in their first gather).
         if (K.active && all_tiled) {
-            qbh::KronCols to{};
-            to.S = S;
-            to.B = K.t.B;
-            to.nr = comm->nranks;
+            // Every rank sends the tiled copy of its own block; the far (and cross) columns of every shard keep indexing the tiled
+            // order of the WHOLE vector -- 2 bytes each, relative to the block's band, exactly the one-GPU operator's -- and the
+            // gathered blocks are moved to their place in the handle's tiled x (k_kron_place) piece by piece as they arrive.
+            // Nothing of the operator changes when a communicator comes or goes.
+            K.n_ranks = comm->nranks;
             for (int q = 0; q <= comm->nranks; ++q) {
                 const int64_t cut = comm->row_cuts ? comm->row_cuts[q] : std::min<int64_t>((int64_t)q * comm->nblk, A->ncols);
-                to.cu[q] = cut / S;
+                K.rank_cu[q] = cut / S;
             }
-            if (K.ja_f) QBH_TRY(qbh::launch_kron_remap_cols(K.ja_f, K.far_slots, K.cols, to, A->stream));      // 2-byte far columns: one rank, nothing moves
-            QBH_TRY(qbh::launch_kron_remap_cols(K.ja_x, K.nnz_x, K.cols, to, A->stream));
-            QBH_HIP(hipStreamSynchronize(A->stream));
-            K.cols = to;
-            K.map.cols = to;
             K.comm_tiled = true;
             K.xt_of = nullptr;
-            QBH_TRY(kron_gather_parts(A, comm, parts));
+            // the rest of this branch can fail on one rank only (a copy inside kron_gather_parts): agreed on once more, so that
+            // no rank is left attached and waiting in its first gather while a peer has returned an error
+            int prc = kron_gather_parts(A, comm, parts);
+            double w[12] = {0};
+            w[0] = prc != QBH_OK ? 1.0 : 0.0;
+            const int arc = agree(w);
+            if (prc != QBH_OK || arc != QBH_OK || w[0] > 0.0) {
+                K.comm_tiled = false;
+                K.n_ranks = 1;
+                K.n_parts = 1;
+                if (prc == QBH_OK && arc == QBH_OK) qbh::set_error("qbh_csr_set_comm: a peer rank could not set up the gather in parts");
+                return prc != QBH_OK ? prc : arc != QBH_OK ? arc : QBH_ECOMM;
+            }
         } else if (!all_tiled) {
             int rrc = QBH_OK;
             if (K.active) {

@@ -318,7 +318,7 @@ int launch_spmv_wave2(const SpmvArgs &a, int tpr, int ops, int grid, hipStream_t
 int wave2_kernel_occupancy(int tpr, int ops);
 int64_t wave2_chunk_slots(int64_t n_wb);
 int launch_reduce_chunks(const double *slots, int64_t n_slots, double *partials, int *nparts_out, hipStream_t s);
-int launch_kron_tile(const d2 *x, d2 *xt, int64_t n, const KronTile &t, hipStream_t s);
+int launch_kron_tile(const d2 *x, d2 *xt, int64_t n, const KronTile &t, hipStream_t s, int xt_real = 0, int *flag = nullptr);
 int launch_kron_check(const int64_t *ia, const int32_t *ja, int64_t nrows, int64_t S, int *d_flag, hipStream_t s);
 int launch_kron_count(const int64_t *ia, const int32_t *ja, int64_t nrows, const KronTile &t, int32_t *cnt_near, int32_t *cnt_far, hipStream_t s);
 int launch_build_slotdesc(const int64_t *gia, int64_t ngroups, int64_t slots, WaveDesc *wd, int64_t n_wb, int64_t shift, hipStream_t s);
@@ -343,12 +343,24 @@ int launch_axpy_norm(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, int6
                      hipStream_t s, const double *scale_dev = nullptr);
 // the same passes writing the TILED copy of the updated y as well (Kronecker split, band 8: the next SpMV's far-pass gather source)
 int launch_axpy_norm_tile(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, d2 *yt, int64_t n, const KronTile &t, double *partials,
-                          hipStream_t s, const double *scale_dev = nullptr);
+                          hipStream_t s, const double *scale_dev = nullptr, int yt_real = 0, int *flag = nullptr);
+// the tiled blocks of the ranks, as gathered (rank after rank; complex or packed real parts), moved into the tiled order of the
+// whole vector the far part of every shard indexes: elements [off[q], off[q] + len[q]) of rank q's block
+struct KronPlace {
+    const d2 *src;                   // d_xfull (or, real != 0, d_xfull_r viewed as doubles)
+    d2       *dst;                   // the handle's tiled x (ncols elements)
+    int       real, nr, B;
+    int64_t   S, NUg, nfb;           // minor size, major indices of the whole operator, full bands
+    int64_t   cu[kKronMaxRanks + 1]; // major-index cuts of the ranks
+    int64_t   base[kKronMaxRanks];   // first element of rank q's block in src
+    int64_t   off[kKronMaxRanks], len[kKronMaxRanks];
+};
+int launch_kron_place(const KronPlace &a, hipStream_t s);
 // tail of a pipelined Lanczos step: |w'|^2 from the axpy's partial sums, a = sc_x * <u, w>, b = sqrt(|w'|^2), the next step's
 // coefficients into state[0..3], {<u,w>, |w'|^2, a, b} into log_slot (host-visible)
 int launch_lanczos_tail(const double *partials, int nparts, const double *dot, double *state, double *log_slot, double sc_x_host, int use_host,
                         hipStream_t s);
-int launch_xpby_tile(const d2 *x, double b, d2 *y, d2 *yt, int64_t n, const KronTile &t, hipStream_t s);
+int launch_xpby_tile(const d2 *x, double b, d2 *y, d2 *yt, int64_t n, const KronTile &t, hipStream_t s, int yt_real = 0, int *flag = nullptr);
 int launch_nrm2sq(const d2 *x, int64_t n, double *partials, hipStream_t s);
 int launch_scal(double a, d2 *x, int64_t n, hipStream_t s);
 int launch_scal_to(double a, const d2 *x, d2 *y, int64_t n, hipStream_t s);
@@ -662,6 +674,8 @@ struct qbh_csr {
         int64_t  U0 = 0, NUg = 0;       // one class: first major index of the shard, major indices of the whole operator
         qbh::KronCols cols{};           // one class: order of the gathered x the far / cross columns index (one rank: KronTile{S, NUg, B})
         bool     comm_tiled = false;    // a communicator is attached and every rank exchanges the tiled copy of its block
+        int      n_ranks = 1;           // ... of that communicator, and the major-index cuts of its ranks: the gathered blocks are moved
+        int64_t  rank_cu[qbh::kKronMaxRanks + 1] = {0};     // (k_kron_place) into the tiled order of the WHOLE vector, which `cols` keeps describing
         int64_t  nnz_n = 0, nnz_f = 0, nnz_x = 0;
         bool     sliced = false;        // far part interleaved inside groups of 8 rows (ia_f = group pointers, n_groups + 1 entries)
         int64_t  n_groups = 0, far_slots = 0;   // far_slots = entries stored in the far arrays (nnz_f + padding)
@@ -750,6 +764,7 @@ struct qbh_csr {
     qbh_comm comm{};
     std::vector<int64_t> comm_cuts;          // copy of comm.row_cuts (ragged partition) or empty
     int64_t  comm_full = 0;                  // elements of d_xfull: nranks * nblk (uniform) or ncols (ragged)
+    int      wire_bytes_last = 0;            // bytes per element the last gather carried (qbh_csr_info.wire_element_bytes)
     struct qbh_native_comm *native = nullptr; // RCCL communicator owned by the handle (qbh_comm_create_rccl)
 
     // creation from host arrays: wall ms of the whole qbh_csr_create call / of the upload + expansion, host bytes read

@@ -1413,21 +1413,32 @@ int wave2_kernel_occupancy(int tpr, int ops)
 // of one major index) and writes 4 KB runs of the tiled copy (32 major indices of one band) -- row stores in 128-byte pieces cost
 // several times their share of the bytes (tools/lab/region_probe).  The last, narrower band (S % 8 != 0) and other band widths
 // take the element-wise kernel.
-__global__ __launch_bounds__(kBlock) void k_kron_tile_edge(const d2 *x, d2 *xt, KronTile t, int64_t band0)
+// xt_real (real wire of a split shard, qbh_opts.real_wire): the tiled copy is written as packed REAL PARTS (8 bytes per element);
+// a non-zero imaginary part raises *flag (finish_real_wire turns that into a loud error)
+__global__ __launch_bounds__(kBlock) void k_kron_tile_edge(const d2 *x, d2 *xt, KronTile t, int64_t band0, int xt_real, int *flag)
 {
     // elements of bands >= band0
     const int64_t d0 = band0 * t.B, w = t.S - d0;
     const int64_t cnt = t.NU * w;
+    bool bad = false;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t u = e / w, r = u * t.S + d0 + (e - u * w);
-        xt[t.tile(r)] = x[r];
+        const d2 v = x[r];
+        if (xt_real) {
+            reinterpret_cast<double *>(xt)[t.tile(r)] = v.x;
+            bad |= v.y != 0.0;
+        } else {
+            xt[t.tile(r)] = v;
+        }
     }
+    if (bad) *flag = 1;
 }
-__global__ __launch_bounds__(kBlock) void k_kron_tile8(const d2 *x, d2 *xt, KronTile t, int64_t nfb)
+__global__ __launch_bounds__(kBlock) void k_kron_tile8(const d2 *x, d2 *xt, KronTile t, int64_t nfb, int xt_real, int *flag)
 {
     constexpr int TU = 32, TB = 8, LD = TB * 8 + 1;          // +1: the band-major read of the tile walks rows of the LDS array
     __shared__ d2 tilebuf[TU * LD];
     const int64_t tiles_u = (t.NU + TU - 1) / TU, tiles_b = (nfb + TB - 1) / TB;
+    bool bad = false;
     for (int64_t w = blockIdx.x; w < tiles_u * tiles_b; w += gridDim.x) {
         const int64_t tb = w / tiles_u, tu = w - tb * tiles_u;     // consecutive workgroups: the same bands, consecutive major indices
         const int64_t u0 = tu * TU, b0 = tb * TB;
@@ -1442,16 +1453,60 @@ __global__ __launch_bounds__(kBlock) void k_kron_tile8(const d2 *x, d2 *xt, Kron
 #pragma unroll
         for (int i = 0; i < TU * TB * 8 / kBlock; ++i) {
             const int idx = threadIdx.x + i * kBlock, bl = idx >> 8, rest = idx & 255, ul = rest >> 3, j = rest & 7;
-            if (bl < nb && ul < nu) xt[(b0 + bl) * 8 * t.NU + (u0 + ul) * 8 + j] = tilebuf[ul * LD + bl * 8 + j];
+            if (bl < nb && ul < nu) {
+                const d2 v = tilebuf[ul * LD + bl * 8 + j];
+                const int64_t o = (b0 + bl) * 8 * t.NU + (u0 + ul) * 8 + j;
+                if (xt_real) {
+                    reinterpret_cast<double *>(xt)[o] = v.x;
+                    bad |= v.y != 0.0;
+                } else {
+                    xt[o] = v;
+                }
+            }
         }
     }
+    if (bad) *flag = 1;
 }
-int launch_kron_tile(const d2 *x, d2 *xt, int64_t n, const KronTile &t, hipStream_t s)
+int launch_kron_tile(const d2 *x, d2 *xt, int64_t n, const KronTile &t, hipStream_t s, int xt_real, int *flag)
 {
     (void)n;
+    if (xt_real && !flag) return QBH_EINVAL;
     const int64_t nfb = t.B == 8 ? t.S / 8 : 0;                  // full bands through the LDS kernel
-    if (nfb > 0) hipLaunchKernelGGL(k_kron_tile8, dim3(4096), dim3(kBlock), 0, s, x, xt, t, nfb);
-    if (nfb * t.B < t.S) hipLaunchKernelGGL(k_kron_tile_edge, dim3(nfb > 0 ? 256 : 2048), dim3(kBlock), 0, s, x, xt, t, nfb);
+    if (nfb > 0) hipLaunchKernelGGL(k_kron_tile8, dim3(4096), dim3(kBlock), 0, s, x, xt, t, nfb, xt_real, flag);
+    if (nfb * t.B < t.S) hipLaunchKernelGGL(k_kron_tile_edge, dim3(nfb > 0 ? 256 : 2048), dim3(kBlock), 0, s, x, xt, t, nfb, xt_real, flag);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// Under a communicator the tiled blocks of the ranks arrive rank after rank (d_xfull, or d_xfull_r as packed real parts); the far
+// part of EVERY shard indexes the tiled order of the WHOLE vector (KronTile{S, NUg, B}) -- the same 2-byte columns as the
+// one-GPU operator, relative to the block's band -- so the pieces are moved to their place: band b of rank q's block (NU_q
+// consecutive major indices, one contiguous run) becomes the run behind major index cu[q] of band b.  One launch per gather
+// part, blockIdx.y = source rank; real wire: the 8-byte elements are expanded on the way (zero imaginary part).
+__global__ __launch_bounds__(kBlock) void k_kron_place(KronPlace a)
+{
+    const int q = blockIdx.y;
+    const int64_t nuq = a.cu[q + 1] - a.cu[q], full = a.nfb * a.B * nuq, wE = a.S - a.nfb * a.B;     // elements of rank q's full bands; width of the edge band
+    const int64_t e0 = a.off[q], e1 = e0 + a.len[q];
+    const double *sr = reinterpret_cast<const double *>(a.src);
+    for (int64_t e = e0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; e < e1; e += (int64_t)gridDim.x * kBlock) {
+        int64_t o;
+        if (e < full) {
+            const int64_t b = e / (a.B * nuq), r = e - b * a.B * nuq;
+            o = b * a.B * a.NUg + a.cu[q] * a.B + r;
+        } else {
+            o = a.nfb * a.B * a.NUg + a.cu[q] * wE + (e - full);
+        }
+        a.dst[o] = a.real ? d2{sr[a.base[q] + e], 0.0} : a.src[a.base[q] + e];
+    }
+}
+int launch_kron_place(const KronPlace &a, hipStream_t s)
+{
+    int64_t longest = 0;
+    for (int q = 0; q < a.nr; ++q) longest = a.len[q] > longest ? a.len[q] : longest;
+    if (longest <= 0 || a.nr <= 0) return QBH_OK;
+    const int64_t gx = std::min<int64_t>(2048, (longest + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_kron_place, dim3((unsigned)gx, (unsigned)a.nr), dim3(kBlock), 0, s, a);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }
@@ -2333,8 +2388,9 @@ int launch_axpy_norm(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, int6
 #endif
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_axpy_norm_tile8(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, d2 *yt, KronTile t,
-                                                            int64_t nfb, double *partials, const double *scale_dev)
+                                                            int64_t nfb, double *partials, const double *scale_dev, int yt_real, int *flag)
 {
+    bool bad = false;           // yt_real (real wire of a split shard): the tiled copy as packed real parts, *flag on a non-zero imaginary part
     constexpr int TU = QBH_TILE_TU, TB = QBH_TILE_TB, RW = TB * 8, LD = RW + 1;      // RW: elements of one major index in the item
     static_assert(TU * TB == 256 && (TU & (TU - 1)) == 0 && (TB & (TB - 1)) == 0, "TU x TB = 256, powers of two");
     __shared__ d2 tilebuf[TU * LD];
@@ -2378,7 +2434,16 @@ __global__ __launch_bounds__(kBlock) void k_axpy_norm_tile8(d2 alpha, const doub
 #pragma unroll
         for (int i = 0; i < TU * TB * 8 / kBlock; ++i) {
             const int idx = threadIdx.x + i * kBlock, bl = idx / (TU * 8), rest = idx % (TU * 8), ul = rest >> 3, j = rest & 7;
-            if (bl < nb && ul < nu) yt[(b0 + bl) * 8 * t.NU + (u0 + ul) * 8 + j] = tilebuf[ul * LD + bl * 8 + j];
+            if (bl < nb && ul < nu) {
+                const d2 v = tilebuf[ul * LD + bl * 8 + j];
+                const int64_t o = (b0 + bl) * 8 * t.NU + (u0 + ul) * 8 + j;
+                if (yt_real) {
+                    reinterpret_cast<double *>(yt)[o] = v.x;
+                    bad |= v.y != 0.0;
+                } else {
+                    yt[o] = v;
+                }
+            }
         }
     }
     const int64_t d0 = nfb * 8, we = t.S - d0;             // the narrow last band
@@ -2386,8 +2451,14 @@ __global__ __launch_bounds__(kBlock) void k_axpy_norm_tile8(d2 alpha, const doub
         const int64_t u = e / we, r = u * t.S + d0 + (e - u * we);
         const d2 v = upd(x[r], y[r]);
         y[r] = v;
-        yt[t.tile(r)] = v;
+        if (yt_real) {
+            reinterpret_cast<double *>(yt)[t.tile(r)] = v.x;
+            bad |= v.y != 0.0;
+        } else {
+            yt[t.tile(r)] = v;
+        }
     }
+    if (bad) *flag = 1;
     if (MODE == 0) {
         block_sum<1>(acc, red);
         if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
@@ -2396,18 +2467,18 @@ __global__ __launch_bounds__(kBlock) void k_axpy_norm_tile8(d2 alpha, const doub
 
 // grid = blas_grid(n): the partial sums are reduced by the same second stage as k_axpy_norm's
 int launch_axpy_norm_tile(d2 alpha, const double *alpha_dev, const d2 *x, d2 *y, d2 *yt, int64_t n, const KronTile &t, double *partials,
-                          hipStream_t s, const double *scale_dev)
+                          hipStream_t s, const double *scale_dev, int yt_real, int *flag)
 {
-    if (t.B != 8 || t.S < 8) return QBH_EINVAL;
-    hipLaunchKernelGGL(k_axpy_norm_tile8<0>, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, alpha_dev, x, y, yt, t, t.S / 8, partials, scale_dev);
+    if (t.B != 8 || t.S < 8 || (yt_real && !flag)) return QBH_EINVAL;
+    hipLaunchKernelGGL(k_axpy_norm_tile8<0>, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, alpha_dev, x, y, yt, t, t.S / 8, partials, scale_dev, yt_real, flag);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }
-int launch_xpby_tile(const d2 *x, double b, d2 *y, d2 *yt, int64_t n, const KronTile &t, hipStream_t s)
+int launch_xpby_tile(const d2 *x, double b, d2 *y, d2 *yt, int64_t n, const KronTile &t, hipStream_t s, int yt_real, int *flag)
 {
-    if (t.B != 8 || t.S < 8) return QBH_EINVAL;
+    if (t.B != 8 || t.S < 8 || (yt_real && !flag)) return QBH_EINVAL;
     hipLaunchKernelGGL(k_axpy_norm_tile8<1>, dim3(blas_grid(n)), dim3(kBlock), 0, s, d2{b, 0.0}, (const double *)nullptr, x, y, yt, t, t.S / 8,
-                       (double *)nullptr, (const double *)nullptr);
+                       (double *)nullptr, (const double *)nullptr, yt_real, flag);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }

@@ -370,7 +370,7 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
             const double *scale_dev = first ? nullptr : P.d_state + 2;
             double *yr = packed_target(A);
             if (d2 *yt = tiled_target(A)) {
-                QBH_TRY(qbh::launch_axpy_norm_tile(d2{-1.0, 0.0}, A->d_scal, x, y, yt, n, A->kron.t, A->d_partials, A->stream, scale_dev));
+                QBH_TRY(qbh::launch_axpy_norm_tile(d2{-1.0, 0.0}, A->d_scal, x, y, yt, n, A->kron.t, A->d_partials, A->stream, scale_dev, tiled_real(A), A->d_flag));
                 A->kron.xt_of = y;
                 A->xr_of = nullptr;
             } else {
@@ -707,7 +707,7 @@ static int cg_core(qbh_csr *A, int64_t maxit, int64_t *m_io, double E0, double *
             {
                 double *pr = packed_target(A);      // p is the next SpMV's x: emit its packed real copy in the same pass
                 if (d2 *pt = tiled_target(A)) {     // ... or its tiled copy (Kronecker split)
-                    QBH_TRY(qbh::launch_xpby_tile(r, beta * beta, p, pt, n, A->kron.t, A->stream));
+                    QBH_TRY(qbh::launch_xpby_tile(r, beta * beta, p, pt, n, A->kron.t, A->stream, tiled_real(A), A->d_flag));
                     A->kron.xt_of = p;
                     pr = nullptr;
                 } else {

@@ -133,8 +133,8 @@ int kron_geometry(qbh_csr *A)
 // requests, not by bytes: the column stream is 16 of a block's ~150 lines as int32 and 8 as uint16.
 //   near part: column - (first column of the shard + pad * S), pad = major index of the block's first row (a block of whole rows
 //              with <= 512 entries reaches into the next major index at most: values < 2 S);
-//   far part (sliced, whole operator): target major index + (band - band of the block's first group) * NU; the element of the
-//              tiled x is band0 * 8 NU + 8 * value + slot % 8.
+//   far part (sliced): target major index + (band - band of the block's first group) * NUg (NUg = major indices of the WHOLE
+//              operator, also for a row shard); the element of the tiled x is band0 * 8 NUg + 8 * value + slot % 8.
 // Each part is converted when every value fits 16 bits (checked on the device) and then lives in an allocation of its own; when
 // both are and nothing else sits in the int32 array it is released (C3: 23.3 GB -> 11.6 GB of columns).  qbh_csr_download /
 // kron_restore re-derive the int32 columns (k_kron_merge_rows): value mod S inside the row's block, value mod NU as the major index.
@@ -156,7 +156,7 @@ int kron_short_cols(qbh_csr *A)
         hipError_t he = hipMemsetAsync(A->d_flag, 0, sizeof(int), s);
         if (rc == QBH_OK && he == hipSuccess) he = hipMemsetAsync(c + cnt, 0, 64 * sizeof(uint16_t), s);
         if (rc == QBH_OK && he == hipSuccess)
-            rc = far ? qbh::launch_kron_c16_far(K.wd_f, K.ja_f, K.far_slots, NU, c, A->d_flag, s)
+            rc = far ? qbh::launch_kron_c16_far(K.wd_f, K.ja_f, K.far_slots, K.NUg, c, A->d_flag, s)
                      : qbh::launch_kron_c16_near(K.wd_n, K.nwb_n, K.ja_n, S, A->row_offset, c, A->d_flag, s);
         if (rc == QBH_OK && he == hipSuccess) he = hipMemcpyAsync(&bad, A->d_flag, sizeof(int), hipMemcpyDeviceToHost, s);
         if (rc == QBH_OK && he == hipSuccess) he = hipStreamSynchronize(s);
@@ -172,8 +172,10 @@ int kron_short_cols(qbh_csr *A)
         return QBH_OK;
     };
     if (K.nnz_n > 0 && 2 * S <= 65536) QBH_TRY(convert(false, &K.c16_n));
-    // far: the sliced layout over the tiled order of the WHOLE vector (a shard under a communicator gathers rank-major blocks)
-    if (K.sliced && !K.own_far && K.t.B == 8 && A->nrows == A->ncols && A->row_offset == 0 && 2 * NU <= 65536 && K.far_slots > 0)
+    // far: the sliced layout over the tiled order of the WHOLE vector -- also for a row shard: value = target major index (of the
+    // whole operator) + (band - band of the block's first group) * NUg; under a communicator the gathered blocks are moved into that
+    // order (k_kron_place), the columns never change
+    if (K.sliced && !K.own_far && K.t.B == 8 && 2 * K.NUg <= 65536 && K.far_slots > 0)
         QBH_TRY(convert(true, &K.c16_f));
     if (K.c16_n && K.c16_f && A->own_arrays && (K.nnz_x == 0 || K.own_x)) {      // nothing is left in the int32 array
         (void)hipFree(A->d_ja);

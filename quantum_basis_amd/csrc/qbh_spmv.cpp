@@ -147,36 +147,43 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
 #endif
     }
     const d2 *xl = comm ? x : x + A->row_offset;            // the rank's own block of x
-    const d2 *xt = nullptr;                                  // what the far pass gathers from
+    const d2 *xt = nullptr;                                  // what the far pass gathers from: the tiled copy of the WHOLE x
     bool async_gather = false;
+    if (K.xt_cap < A->ncols) {                               // first use: the tiled copy of the full-length x
+        if (K.d_xt) (void)hipFree(K.d_xt);
+        K.d_xt = nullptr;
+        K.xt_cap = 0;
+        QBH_HIP(qbh::dev_alloc(&K.d_xt, (size_t)A->ncols * sizeof(d2)));
+        K.xt_cap = A->ncols;
+        if (qbh::debug_sw().print_ptrs) fprintf(stderr, "qbhip kron xt %p x %p y %p\n", (void *)K.d_xt, (const void *)x, (void *)y);
+        K.xt_of = nullptr;
+    }
+    // under a communicator: the wire format of this solve (8-byte real parts when the drivers agreed on it), and whether the
+    // gather travels in parts (with real parts only through the hook that names the format)
+    const int realw = tiled_real(A);
+    const int np_used = (comm && K.n_parts > 1 && (!realw || A->comm.allgather_part_begin_w)) ? K.n_parts : 1;
     if (comm) {
         d2 *send = reinterpret_cast<d2 *>(A->comm.d_xsend);
-        if (K.xt_of != (const void *)x) QBH_TRY(qbh::launch_kron_tile(x, send, A->nrows, K.t, s));
+        if (K.xt_of != (const void *)x) QBH_TRY(qbh::launch_kron_tile(x, send, A->nrows, K.t, s, realw, A->d_flag));
         K.xt_of = nullptr;
         async_gather = A->comm.allgather_begin && A->comm.allgather_wait;
         int hrc = 0;
-        if (K.n_parts > 1) {                                 // band ranges one after another: the far pass follows them (below)
-            for (int k = 0; k < K.n_parts && hrc == 0; ++k)
-                hrc = A->comm.allgather_part_begin(A->comm.ctx, k, K.n_parts, K.part_off_len.data() + (size_t)k * 2 * (size_t)A->comm.nranks);
+        if (np_used > 1) {                                   // band ranges one after another: the far pass follows them (below)
+            for (int k = 0; k < np_used && hrc == 0; ++k) {
+                const int64_t *ol = K.part_off_len.data() + (size_t)k * 2 * (size_t)A->comm.nranks;
+                hrc = realw ? A->comm.allgather_part_begin_w(A->comm.ctx, k, np_used, ol, 1) : A->comm.allgather_part_begin(A->comm.ctx, k, np_used, ol);
+            }
         } else {
-            hrc = async_gather ? A->comm.allgather_begin(A->comm.ctx, 0) : A->comm.allgather_x(A->comm.ctx, 0);
+            hrc = async_gather ? A->comm.allgather_begin(A->comm.ctx, realw) : A->comm.allgather_x(A->comm.ctx, realw);
         }
         if (hrc != 0) {
             qbh::set_error("allgather hook failed");
             return QBH_ECOMM;
         }
         A->stats.n_gather++;
-        xt = reinterpret_cast<const d2 *>(A->comm.d_xfull);
+        A->wire_bytes_last = realw ? 8 : 16;
+        xt = K.d_xt;
     } else {
-        if (K.xt_cap < A->ncols) {                           // first use: the tiled copy of the full-length x
-            if (K.d_xt) (void)hipFree(K.d_xt);
-            K.d_xt = nullptr;
-            K.xt_cap = 0;
-            QBH_HIP(qbh::dev_alloc(&K.d_xt, (size_t)A->ncols * sizeof(d2)));
-            K.xt_cap = A->ncols;
-            if (qbh::debug_sw().print_ptrs) fprintf(stderr, "qbhip kron xt %p x %p y %p\n", (void *)K.d_xt, (const void *)x, (void *)y);
-            K.xt_of = nullptr;
-        }
         if (prof) {
             QBH_TRY(next_event_set(A));
             QBH_HIP(hipEventRecord(A->ev0, s));
@@ -193,6 +200,30 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
         K.xt_of = nullptr;
         xt = K.d_xt;
     }
+    // the pieces of the gathered blocks -> their place in the tiled x (part k of np_used, or everything)
+    auto place = [&](int k) -> int {
+        qbh::KronPlace pa{};
+        pa.real = realw;
+        pa.src = realw ? reinterpret_cast<const d2 *>(A->comm.d_xfull_r) : reinterpret_cast<const d2 *>(A->comm.d_xfull);
+        pa.dst = K.d_xt;
+        pa.nr = A->comm.nranks;
+        pa.B = K.t.B;
+        pa.S = K.t.S;
+        pa.NUg = K.NUg;
+        pa.nfb = K.t.S / K.t.B;
+        for (int q = 0; q <= pa.nr; ++q) pa.cu[q] = K.rank_cu[q];
+        for (int q = 0; q < pa.nr; ++q) {
+            pa.base[q] = A->comm.row_cuts ? A->comm.row_cuts[q] : (int64_t)q * A->comm.nblk;
+            if (np_used > 1) {
+                pa.off[q] = K.part_off_len[((size_t)k * (size_t)pa.nr + (size_t)q) * 2];
+                pa.len[q] = K.part_off_len[((size_t)k * (size_t)pa.nr + (size_t)q) * 2 + 1];
+            } else {
+                pa.off[q] = 0;
+                pa.len[q] = (K.rank_cu[q + 1] - K.rank_cu[q]) * K.t.S;
+            }
+        }
+        return qbh::launch_kron_place(pa, s);
+    };
     qbh::SpmvArgs f{};                                       // far pass
     f.ia = K.ia_f;
     f.ja = K.ja_f;
@@ -334,16 +365,18 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
             QBH_HIP(hipEventRecord(A->ev1, s));
             A->ev_pending = true;
         }
-        if (K.n_parts > 1) {
-            // every band range of the far part as soon as its piece of the gathered x is there; a block that straddles a range
-            // boundary belongs to the later range (the pieces complete in order), its cut groups add up through the atomics
+        if (np_used > 1) {
+            // every band range of the far part as soon as its piece of the gathered x is there and has been moved to its place; a
+            // block that straddles a range boundary belongs to the later range (the pieces complete in order), its cut groups add
+            // up through the atomics
             QBH_TRY(qbh::launch_zero_cut_groups(K.wd_f, K.nwb_f, f.nrows, K.d_far, s));
-            for (int k = 0; k < K.n_parts; ++k) {
+            for (int k = 0; k < np_used; ++k) {
                 if (A->comm.allgather_part_wait(A->comm.ctx, k) != 0) {
                     qbh::set_error("allgather_part_wait hook failed");
                     return QBH_ECOMM;
                 }
                 if (prof && k == 0) QBH_HIP(hipEventRecord(A->ev2, s));
+                QBH_TRY(place(k));
                 qbh::SpmvArgs fk = f;
                 fk.wd = K.wd_f + K.part_blk[k];
                 fk.n_wb = K.part_blk[k + 1] - K.part_blk[k];
@@ -356,6 +389,7 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
                 return QBH_ECOMM;
             }
             if (prof) QBH_HIP(hipEventRecord(A->ev2, s));
+            QBH_TRY(place(0));
             if (K.sliced) QBH_TRY(qbh::launch_zero_cut_groups(K.wd_f, K.nwb_f, f.nrows, K.d_far, s));
             QBH_TRY(qbh::launch_spmv_wave2(f, K.tpr_f, K.sliced ? 3 : 0, K.grid_f, s));
         }
@@ -411,6 +445,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         }
         if (!async_gather && packed && !realm) QBH_TRY(expand_packed());
         A->stats.n_gather++;
+        A->wire_bytes_last = packed ? 8 : 16;
         xg = reinterpret_cast<const d2 *>(A->comm.d_xfull);
         xl = x;
     } else if (A->ovr_yr != nullptr) {           // all-real operation on packed vectors (driver-internal)
@@ -737,8 +772,15 @@ int enable_real_wire(qbh_csr *A, std::initializer_list<const d2 *> vecs)
     A->real_mode = false;
     A->xr_of = nullptr;
     if (A->has_comm && !A->comm.d_xfull_r) return QBH_OK;
-    if (!A->opts.real_fast_path) return QBH_OK;
-    if (!(A->opts.real_forms & 1)) return QBH_OK;
+    // split shards exchanging tiled blocks: qbh_opts.real_wire alone decides (their kernels have no real forms to select);
+    // everything else: the real fast path and its forms
+    const bool tiled = A->has_comm && A->kron.active && A->kron.comm_tiled;
+    if (tiled) {
+        if (!A->opts.real_wire) return QBH_OK;
+    } else {
+        if (!A->opts.real_fast_path) return QBH_OK;
+        if (!(A->opts.real_forms & 1)) return QBH_OK;
+    }
     double total = A->values_real ? 0.0 : 1.0;
     // every rank must take the same decision: sum the per-vector |Im|^2 (and the operator flag) over ranks
     for (const d2 *v : vecs) {
@@ -758,7 +800,7 @@ int enable_real_wire(qbh_csr *A, std::initializer_list<const d2 *> vecs)
         QBH_HIP(hipMemsetAsync(A->d_flag, 0, sizeof(int), A->stream));
         A->real_wire = A->has_comm;
         // the row kernel can then gather 8-byte real parts (bit-identical result, half the x traffic)
-        A->real_mode = A->kernel == QBH_KERNEL_ROWS;
+        A->real_mode = A->kernel == QBH_KERNEL_ROWS && !tiled;
         if (!(A->opts.real_forms & 2)) A->real_mode = false;
         if (A->real_mode && !A->has_comm && !A->d_xr) QBH_HIP(qbh::dev_alloc(&A->d_xr, (size_t)A->ncols * sizeof(double)));
     }
@@ -799,7 +841,7 @@ int axpy_norm_run(qbh_csr *A, d2 alpha, const d2 *x, d2 *y, double *nrm2sq)
 {
     double *yr = packed_target(A);          // y is the next SpMV's x in every driver: emit its packed copy here
     if (d2 *yt = tiled_target(A)) {         // ... or, for a Kronecker split, its tiled copy
-        QBH_TRY(qbh::launch_axpy_norm_tile(alpha, nullptr, x, y, yt, A->nrows, A->kron.t, A->d_partials, A->stream));
+        QBH_TRY(qbh::launch_axpy_norm_tile(alpha, nullptr, x, y, yt, A->nrows, A->kron.t, A->d_partials, A->stream, nullptr, tiled_real(A), A->d_flag));
         A->kron.xt_of = y;
         A->xr_of = nullptr;
         return finish_reduction(A, qbh::blas_grid(A->nrows), 1, nrm2sq);
@@ -816,7 +858,7 @@ int axpy_norm_deferred(qbh_csr *A, double scale, const d2 *x, d2 *y, double *dot
 {
     double *yr = packed_target(A);
     if (d2 *yt = tiled_target(A)) {
-        QBH_TRY(qbh::launch_axpy_norm_tile(d2{scale, 0.0}, A->d_scal, x, y, yt, A->nrows, A->kron.t, A->d_partials, A->stream));
+        QBH_TRY(qbh::launch_axpy_norm_tile(d2{scale, 0.0}, A->d_scal, x, y, yt, A->nrows, A->kron.t, A->d_partials, A->stream, nullptr, tiled_real(A), A->d_flag));
         A->kron.xt_of = y;
         A->xr_of = nullptr;
     } else {

@@ -111,6 +111,7 @@ class ShardComm:
         self._ag_wait = _lib.ALLWAIT_FN(self._allgather_wait)
         self._pt_begin = _lib.PART_BEGIN_FN(self._part_begin)
         self._pt_wait = _lib.PART_WAIT_FN(self._part_wait)
+        self._pt_begin_w = _lib.PART_BEGIN_W_FN(self._part_begin_w)
         self._work = None
         self.n_async = 0             # exchanges started through the begin/wait pair
         self.overlap = True          # hand the begin/wait pair to the library (local columns overlap the gather)
@@ -186,18 +187,27 @@ class ShardComm:
             return 1
 
     def _part_begin(self, _ctx, part, nparts, off_len):
+        return self._part_begin_w(_ctx, part, nparts, off_len, 0)
+
+    def _part_begin_w(self, _ctx, part, nparts, off_len, packed):
         """One part of the gather in parts: elements [off, off + len) of every rank's block, one broadcast per rank, on the
-        operator's stream (no overlap on this rig: what it exercises is the library's part geometry across real ranks)."""
+        operator's stream (no overlap on this rig: what it exercises is the library's part geometry across real ranks).
+        packed: the elements are doubles (real parts only, qbh_opts.real_wire), from xsend[:nblk] into xfull_r."""
         try:
+            if packed:
+                self.n_packed += 1
+                w, full, send = 1, self.xfull_r, self.xsend
+            else:
+                w, full, send = 2, self.xfull, self.xsend
             with self._ctx():
                 for q, (a, _b) in enumerate(self.ranges):
                     off, ln = int(off_len[2 * q]), int(off_len[2 * q + 1])
                     if ln <= 0:
                         continue
                     base = a if self.cuts is not None else q * self.nblk
-                    dst = self.xfull[2 * (base + off):2 * (base + off + ln)]
+                    dst = full[w * (base + off):w * (base + off + ln)]
                     if q == self.rank:
-                        dst.copy_(self.xsend[2 * off:2 * (off + ln)])
+                        dst.copy_(send[w * off:w * (off + ln)])
                     src = q if self.group is None else self.dist.get_global_rank(self.group, q)
                     if self.direct:
                         self.dist.broadcast(dst, src=src, group=self.group)
@@ -267,6 +277,7 @@ class ShardComm:
         if self.parts:
             c.allgather_part_begin = self._pt_begin
             c.allgather_part_wait = self._pt_wait
+            c.allgather_part_begin_w = self._pt_begin_w
         self._struct = c
         check(lib().qbh_csr_set_comm(mat.handle, C.byref(c)), "qbh_csr_set_comm")
         mat._comm = self          # keep the callbacks and buffers alive as long as the operator

@@ -8,6 +8,7 @@
 //                    shard split in place, the ranks exchange the tiled copies of their blocks
 //        parts=K     qbh_opts.gather_parts;  unsplit=R  rank R keeps its shard unsplit (the ranks must fall back together)
 //        plain=1     complex128 values and vectors (value_dict = 0, real_fast_path = 0)
+//        realwire=0  qbh_opts.real_wire = 0 (split shards: 16-byte elements on the links even for a real solve)
 //        dump=PREFIX rank r writes PREFIX.r.bin: m, mcg, E0, a_j / b_j (2 m doubles), its slice of the eigenvector
 #include <chrono>
 #include <complex>
@@ -59,7 +60,7 @@ int main(int argc, char **argv)
     std::vector<int64_t> cuts(nranks + 1);
     bool uniform = false;
     int64_t kron = 0;
-    int parts = 0, unsplit = -1, plain = 0;
+    int parts = 0, unsplit = -1, plain = 0, realwire = 1;
     std::string dump;
     for (int i = 5; i < argc; ++i) {
         const std::string a(argv[i]);
@@ -68,6 +69,7 @@ int main(int argc, char **argv)
         else if (a.rfind("parts=", 0) == 0) parts = std::atoi(a.c_str() + 6);
         else if (a.rfind("unsplit=", 0) == 0) unsplit = std::atoi(a.c_str() + 8);
         else if (a.rfind("plain=", 0) == 0) plain = std::atoi(a.c_str() + 6);
+        else if (a.rfind("realwire=", 0) == 0) realwire = std::atoi(a.c_str() + 9);
         else if (a.rfind("dump=", 0) == 0) dump = a.substr(5);
         else return 2;
     }
@@ -89,6 +91,7 @@ int main(int argc, char **argv)
         opts.kron_split = rank == unsplit ? 0 : 2;
     }
     opts.gather_parts = parts;
+    opts.real_wire = realwire;
     qbh_csr *A = nullptr;
     must(qbh_csr_create_rows(&A, dim, nnz, (int)sym, ia.data(), ja.data(), reinterpret_cast<const qbh_z *>(val.data()), cuts[rank],
                              cuts[rank + 1], &opts), "qbh_csr_create_rows");
@@ -121,8 +124,9 @@ int main(int argc, char **argv)
         o.write((const char *)hess.data(), 8 * m);                 // b_j
         o.write((const char *)vec.data(), 16 * n);
     }
-    std::printf("OK %d %d %lld %lld %lld %.17g %lld %.3e %.15g kron %lld parts %d cols16 %d\n", rank, nranks, (long long)cuts[rank],
-                (long long)cuts[rank + 1], (long long)m, E0, (long long)mcg, accu, nrm, (long long)inf.kron_minor, inf.gather_parts, inf.kron_cols16);
+    std::printf("OK %d %d %lld %lld %lld %.17g %lld %.3e %.15g kron %lld parts %d cols16 %d wire %d\n", rank, nranks, (long long)cuts[rank],
+                (long long)cuts[rank + 1], (long long)m, E0, (long long)mcg, accu, nrm, (long long)inf.kron_minor, inf.gather_parts, inf.kron_cols16,
+                inf.wire_element_bytes);
     qbh_vec_free(d_v);
     must(qbh_comm_destroy(A), "qbh_comm_destroy");
     qbh_csr_destroy(A);

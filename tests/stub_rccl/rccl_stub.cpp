@@ -8,6 +8,14 @@
 // to work enqueued afterwards; point-to-point calls inside ncclGroupStart / ncclGroupEnd are matched per (source,
 // destination) pair in the order they were posted; element counts of a matched send / receive must agree (real RCCL hangs
 // or corrupts -- the stub FAILS, which is what a test wants); collectives must be called by all ranks in the same order.
+// SOLO mode (QBH_STUB_SOLO=<GB/s per link>): ONE rank process of an N-rank job runs alone and its peers are MODELLED -- nothing
+// synchronises the device: a group of receives is a host function on the stream that holds it for (longest message) / link rate
+// + QBH_STUB_LATENCY_US (default 20; every peer has a link of its own) -- the receive buffers keep what they held (zeros: the
+// peers' blocks of x are zero, every number stays finite, the results mean nothing; QBH_STUB_SOLO_COPY=1 fills them with the
+// rank's own block by hipMemcpyAsync, which on this rig is an SDMA copy at ~80 GB/s and dominates the model) -- and an
+// all-reduce returns nranks times the rank's own contribution (so the collective agreements of qbh_csr_set_comm come out as
+// they would with real peers) after the latency.  A rehearsal of the TIMING path -- events, side stream, what the near pass
+// hides of the gather -- on one GPU.
 // Mechanics: every call synchronises its stream, stages device memory through files mapped by all ranks (under $TMPDIR --
 // a container's /dev/shm is often 64 MB) and meets the other ranks at a sense-reversing barrier in a mapped control block.
 #include <fcntl.h>
@@ -69,6 +77,10 @@ struct Box {
 }  // namespace
 
 struct ncclComm {
+    bool solo = false, solo_copy = false;
+    double link_gbps = 50.0, latency_us = 20.0;
+    double *h_red = nullptr;                 // pinned staging of the solo all-reduce (a ring of 64 slots of 16 doubles)
+    long long red_slot = 0;
     int rank = 0, nranks = 1;
     std::string base;
     Ctl *ctl = nullptr;
@@ -181,10 +193,54 @@ const char *peer_box(ncclComm *c, int q)
     return c->box[q].map;
 }
 
+// ---- solo mode ----
+struct Hold {
+    double us;
+};
+void hold_stream(void *p)
+{
+    Hold *h = static_cast<Hold *>(p);
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < h->us) { }
+    delete h;
+}
+ncclResult_t solo_hold(hipStream_t s, double us)
+{
+    if (us <= 0.0) return ncclSuccess;
+    if (hipLaunchHostFunc(s, hold_stream, new Hold{us}) != hipSuccess) return fail("hipLaunchHostFunc failed (solo mode)");
+    return ncclSuccess;
+}
+ncclResult_t solo_exchange(ncclComm *c, std::vector<Pending> &ops)
+{
+    const void *src = nullptr;
+    size_t src_bytes = 0, longest = 0;
+    hipStream_t s = nullptr;
+    for (const Pending &p : ops) {
+        s = p.stream;
+        if (p.send && p.bytes > src_bytes) {
+            src = p.src;
+            src_bytes = p.bytes;
+        }
+    }
+    for (const Pending &p : ops) {
+        if (p.send || p.bytes == 0) continue;
+        longest = std::max(longest, p.bytes);
+        // QBH_STUB_SOLO_COPY: as many bytes as the peer would have delivered, from the rank's own block (repeated when the peer's block is longer)
+        for (size_t done = 0; c->solo_copy && done < p.bytes && src_bytes > 0;) {
+            const size_t n = std::min(src_bytes, p.bytes - done);
+            if (hipMemcpyAsync(static_cast<char *>(p.dst) + done, src, n, hipMemcpyDeviceToDevice, p.stream) != hipSuccess) return fail("hipMemcpyAsync failed (solo mode)");
+            done += n;
+        }
+    }
+    ++c->n_calls;
+    return solo_hold(s, c->latency_us + (double)longest / (c->link_gbps * 1e3));
+}
+
 // one exchange round: the posted sends go into the outbox, everybody meets, the posted receives are served from the peers'
 // outboxes (k-th receive from q <- k-th message of q addressed to this rank), everybody meets again
 ncclResult_t exchange(ncclComm *c, std::vector<Pending> &ops)
 {
+    if (c->solo) return solo_exchange(c, ops);
     std::vector<hipStream_t> streams;
     for (const Pending &p : ops) {
         bool seen = false;
@@ -291,6 +347,20 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
     c->rank = rank;
     c->nranks = nranks;
     c->base = std::string(id.internal, strnlen(id.internal, sizeof(id.internal)));
+    if (const char *solo = getenv("QBH_STUB_SOLO")) {
+        if (*solo && atof(solo) > 0.0) {
+            c->solo = true;
+            c->link_gbps = atof(solo);
+            if (const char *lat = getenv("QBH_STUB_LATENCY_US")) c->latency_us = atof(lat);
+            if (const char *cp = getenv("QBH_STUB_SOLO_COPY")) c->solo_copy = atoi(cp) != 0;
+            if (hipHostMalloc(&c->h_red, 64 * 16 * sizeof(double)) != hipSuccess) {
+                delete c;
+                return fail("hipHostMalloc failed (solo mode)");
+            }
+            *out = c;
+            return ncclSuccess;
+        }
+    }
     const std::string ctl_path = c->base + ".ctl";
     const int fd = open(ctl_path.c_str(), O_RDWR | O_CREAT, 0600);
     if (fd < 0 || ftruncate(fd, sizeof(Ctl)) != 0) {
@@ -324,6 +394,11 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
 ncclResult_t ncclCommDestroy(ncclComm_t c)
 {
     if (!c) return ncclSuccess;
+    if (c->solo) {
+        if (c->h_red) (void)hipHostFree(c->h_red);
+        delete c;
+        return ncclSuccess;
+    }
     for (int q = 0; q < kMaxRanks; ++q) {
         if (c->box[q].map) munmap(c->box[q].map, (size_t)c->box[q].mapped);
         if (c->box[q].fd >= 0) close(c->box[q].fd);
@@ -393,6 +468,10 @@ ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataT
     const ncclResult_t r = exchange(c, ops);
     if (r != ncclSuccess) return r;
     char *own = static_cast<char *>(recv) + (size_t)c->rank * bytes;
+    if (c->solo) {
+        if (own != send && bytes > 0 && hipMemcpyAsync(own, send, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail("ncclAllGather: own block copy failed");
+        return ncclSuccess;
+    }
     if (own != send && bytes > 0 && copy(own, send, bytes, hipMemcpyDeviceToDevice) != hipSuccess) return fail("ncclAllGather: own block copy failed");
     return ncclSuccess;
 }
@@ -402,6 +481,23 @@ ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataT
     if (!c) return fail("ncclAllReduce: no communicator");
     if (t != ncclFloat64 || op != ncclSum) return fail("this stub reduces doubles with ncclSum only");
     if (g_group_depth > 0) return fail("collectives inside a group are not supported by this stub");
+    if (c->solo) {                           // nranks times the rank's own contribution stands for the sum; all in stream order
+        if (count > 16) return fail("solo all-reduce of more than 16 doubles");
+        double *slot = c->h_red + (c->red_slot++ % 64) * 16;
+        if (count > 0 && hipMemcpyAsync(slot, send, count * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return fail("hipMemcpyAsync failed (solo mode)");
+        struct Scale { double *p; size_t n; double f, us; };
+        auto fn = [](void *u) {
+            Scale *q = static_cast<Scale *>(u);
+            for (size_t i = 0; i < q->n; ++i) q->p[i] *= q->f;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < q->us) { }
+            delete q;
+        };
+        if (hipLaunchHostFunc(s, fn, new Scale{slot, count, (double)c->nranks, c->latency_us}) != hipSuccess) return fail("hipLaunchHostFunc failed (solo mode)");
+        if (count > 0 && hipMemcpyAsync(recv, slot, count * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) return fail("hipMemcpyAsync failed (solo mode)");
+        ++c->n_calls;
+        return ncclSuccess;
+    }
     if (sync(s) != hipSuccess) return fail("hipStreamSynchronize failed");
     const size_t bytes = count * sizeof(double);
     char *mine = own_box(c, (long long)bytes);

@@ -67,7 +67,7 @@ def _run(rig, nranks, args, tag):
         ab = np.frombuffer(raw[24:24 + 16 * m].tobytes(), dtype=np.float64)
         vec = np.frombuffer(raw[24 + 16 * m:].tobytes(), dtype=np.complex128)
         res.append({"r0": int(tok[3]), "r1": int(tok[4]), "m": int(m), "mcg": int(mcg), "E0": float(e0), "a": ab[:m], "b": ab[m:], "vec": vec,
-                    "accu": float(tok[8]), "nrm": float(tok[9]), "kron": int(tok[11]), "parts": int(tok[13]), "cols16": int(tok[15])})
+                    "accu": float(tok[8]), "nrm": float(tok[9]), "kron": int(tok[11]), "parts": int(tok[13]), "cols16": int(tok[15]), "wire": int(tok[17])})
     return res
 
 
@@ -95,11 +95,15 @@ def _check(rig, res, ref, nranks):
 
 @pytest.mark.parametrize("nranks", [2, 3, 4])
 @pytest.mark.parametrize("parts", [1, 4, 7])
-def test_split_shards_exchange_tiled_blocks_over_the_native_communicator(rig, nranks, parts):
-    """complex128 shards of whole major indices, each split in place (2-byte near columns, int32 far columns), the TILED block
-    of every rank on the wire, in 1 / 4 / 7 band ranges; 2 ranks: uniform blocks, 3 and 4 ranks: ragged (70 major indices)."""
-    res = _run(rig, nranks, ["plain=1", "kron=%d" % S_MINOR, "parts=%d" % parts] + (["uniform"] if nranks == 2 else []), "kron_%d_%d" % (nranks, parts))
-    assert all(r["kron"] == S_MINOR and r["parts"] == parts and r["cols16"] == 1 for r in res), res
+@pytest.mark.parametrize("realwire", [1, 0])
+def test_split_shards_exchange_tiled_blocks_over_the_native_communicator(rig, nranks, parts, realwire):
+    """complex128 shards of whole major indices, each split in place with 2-byte columns in BOTH parts (the one-GPU kernel: the far
+    columns index the tiled order of the whole vector, the gathered blocks are moved there piece by piece), the TILED block of
+    every rank on the wire -- as 8-byte real parts (qbh_opts.real_wire: real operator, real Lanczos / CG vectors) or as complex128
+    elements -- in 1 / 4 / 7 band ranges; 2 ranks: uniform blocks, 3 and 4 ranks: ragged (70 major indices)."""
+    res = _run(rig, nranks, ["plain=1", "kron=%d" % S_MINOR, "parts=%d" % parts, "realwire=%d" % realwire] + (["uniform"] if nranks == 2 else []),
+               "kron_%d_%d_%d" % (nranks, parts, realwire))
+    assert all(r["kron"] == S_MINOR and r["parts"] == parts and r["cols16"] == 3 and r["wire"] == (8 if realwire else 16) for r in res), res
     _check(rig, res, _reference(rig, True), nranks)
 
 
