@@ -454,6 +454,21 @@ int qbh_ckpt_lanczos_init(const char *dir, int64_t *k_out, int64_t maxit, int64_
 int qbh_lanczos_ckpt(const qbh_csr *A, int64_t maxit, int64_t *m, qbh_z *v_host, double *hessenberg,
                      const char *purpose, int64_t every, int64_t max_steps, const char *dir, int *converged,
                      qbh_solver_info *info);
+/* The CG half of the protocol (src/ckpt.cc:344-517; ckpt_CG_init / ckpt_CG_update / ckpt_CG_clean as eigenvec_CG calls them,
+ * src/lanczos.cc:286,312,333): files CG_V<m>.dat, CG_R<m>.dat, CG_P<m>.dat in vec_disk_write format and the two markers
+ * CG_updt.Qckpt1 / CG_updt.Qckpt2.  qbh_eigenvec_cg_ckpt is eigenvec_CG with enable_ckpt = true: resumes from `dir` when it
+ * holds a step (otherwise starts from v with m = 0), commits a checkpoint every `every` steps and at the end, stops after
+ * max_steps new steps when max_steps > 0; info->cg_resid[j] receives the residual of every step j made by this call (the rows
+ * of log_CG.txt, src/lanczos.cc:308-311,334-337).
+ * Row shards: qbh_lanczos_ckpt and qbh_eigenvec_cg_ckpt are COLLECTIVE under a communicator -- every rank checkpoints its slice
+ * in dir/shard<r>of<P>/ with the same file names; the ranks meet between writing the new step and removing the old one, and
+ * before a resume, so that all of them continue from the same step (<= 16 ranks). */
+int qbh_ckpt_cg_update(const char *dir, int64_t m, int64_t dim, const qbh_z *v, const qbh_z *r, const qbh_z *p);
+int qbh_ckpt_cg_init(const char *dir, int64_t *m_out, int64_t maxit, int64_t dim, qbh_z *v, qbh_z *r, qbh_z *p);
+int qbh_ckpt_cg_clean(const char *dir);
+int qbh_eigenvec_cg_ckpt(const qbh_csr *A, int64_t maxit, int64_t *m, double E0, double *accu, qbh_z *v_host, qbh_z *r_host,
+                         qbh_z *p_host, qbh_z *pp_host, int64_t every, int64_t max_steps, const char *dir, int *converged,
+                         qbh_solver_info *info);
 
 /* Replaces hess_eigen (src/lanczos.cc:355-390), host only: eigen-decomposition of the
  * m x m tridiagonal held in hessenberg (ld = maxit), sorted by order ("sr","lr","sm","lm");

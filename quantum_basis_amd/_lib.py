@@ -105,6 +105,7 @@ EXPORTS = [
     "qbh_lanczos", "qbh_lanczos_dev", "qbh_lanczos_real_dev", "qbh_vec_randomize_real", "qbh_eigenvec_cg_real_dev", "qbh_eigenvec_cg", "qbh_eigenvec_cg_dev", "qbh_hess_eigen", "qbh_iram",
     "qbh_mopr_spin_dev", "qbh_mopr_onebody_dev", "qbh_mopr_terms_dev", "qbh_mopr_sz_repr_dev", "qbh_mopr_flip_repr_dev",
     "qbh_crc32", "qbh_vec_disk_write", "qbh_vec_disk_read", "qbh_ckpt_lanczos_update", "qbh_ckpt_lanczos_init", "qbh_lanczos_ckpt",
+    "qbh_ckpt_cg_update", "qbh_ckpt_cg_init", "qbh_ckpt_cg_clean", "qbh_eigenvec_cg_ckpt",
     "qbh_csr_set_comm", "qbh_rccl_unique_id", "qbh_comm_create_rccl", "qbh_comm_destroy", "qbh_get_stats", "qbh_sync", "qbh_csr_set_option",
     "qbh_gen_hubbard", "qbh_mf_hubbard", "qbh_gen_heisenberg", "qbh_mf_heisenberg", "qbh_gen_heisenberg_repr", "qbh_gen_hubbard_repr", "qbh_gen_heisenberg_repr_cuts", "qbh_gen_hubbard_repr_cuts", "qbh_mf_hubbard_repr", "qbh_mopr_diag_hubrepr_dev", "qbh_mopr_c_hubrepr_dev", "qbh_csr_download", "qbh_csr_reference_order", "qbh_csr_set_basis",
 ]
@@ -188,6 +189,11 @@ def lib():
                                         C.POINTER(dbl), vp, vp, C.c_char_p]
     L.qbh_lanczos_ckpt.argtypes = [vp, i64, C.POINTER(i64), vp, vp, C.c_char_p, i64, i64, C.c_char_p, C.POINTER(C.c_int),
                                    C.POINTER(SolverInfo)]
+    L.qbh_ckpt_cg_update.argtypes = [C.c_char_p, i64, i64, vp, vp, vp]
+    L.qbh_ckpt_cg_init.argtypes = [C.c_char_p, C.POINTER(i64), i64, i64, vp, vp, vp]
+    L.qbh_ckpt_cg_clean.argtypes = [C.c_char_p]
+    L.qbh_eigenvec_cg_ckpt.argtypes = [vp, i64, C.POINTER(i64), dbl, C.POINTER(dbl), vp, vp, vp, vp, i64, i64, C.c_char_p, C.POINTER(C.c_int),
+                                       C.POINTER(SolverInfo)]
     L.qbh_rccl_unique_id.argtypes = [vp]
     L.qbh_comm_create_rccl.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     L.qbh_comm_destroy.argtypes = [vp]

@@ -319,3 +319,28 @@ def native_lanczos_checkpointed(mat, maxit, purpose="sr_val0", every=50, directo
     check(lib().qbh_lanczos_ckpt(mat.handle, maxit, C.byref(m), v.ctypes.data_as(C.c_void_p), hess.ctypes.data_as(C.c_void_p),
                                  purpose.encode(), every, max_steps, directory.encode(), C.byref(conv), C.byref(info)), "qbh_lanczos_ckpt")
     return m.value, hess, v[:2 * dim].copy(), bool(conv.value)
+
+
+def native_cg_checkpointed(mat, maxit, E0, v0, every=20, directory=CKPT_DIR, max_steps=0):
+    """qbh_eigenvec_cg_ckpt: eigenvec_CG with enable_ckpt = true (src/lanczos.cc:281-341, src/ckpt.cc:344-517) inside the library.
+    Returns (m, accu, v, converged, resid) -- resid[j] = the residual of step j for the steps made by THIS call (log_CG.txt rows)."""
+    import ctypes as C
+    from ._lib import SolverInfo, check, lib
+    dim = mat.dim
+    vs = [np.ascontiguousarray(v0, dtype=np.complex128).copy()] + [np.zeros(dim, dtype=np.complex128) for _ in range(3)]
+    m, conv, accu = C.c_int64(0), C.c_int(0), C.c_double(0.0)
+    info = SolverInfo()
+    resid = np.zeros(maxit + 2)
+    info.cg_resid = resid.ctypes.data_as(C.POINTER(C.c_double))
+    os.makedirs(directory, exist_ok=True)
+    check(lib().qbh_eigenvec_cg_ckpt(mat.handle, maxit, C.byref(m), float(np.real(E0)), C.byref(accu), *[x.ctypes.data_as(C.c_void_p) for x in vs],
+                                     every, max_steps, directory.encode(), C.byref(conv), C.byref(info)), "qbh_eigenvec_cg_ckpt")
+    return m.value, accu.value, vs[0], bool(conv.value), resid
+
+
+def append_log_cg(resid, m_from, m_to, filename="log_CG.txt"):
+    """The rows eigenvec_CG appends to log_CG.txt (src/lanczos.cc:308-311,334-337: setprecision(10), two columns of width 20),
+    read by the reference's python/lanczos_plotCG.py."""
+    with open(filename, "a") as f:
+        for j in range(m_from + 1, m_to + 1):
+            f.write("%20d%20.10g\n" % (j, resid[j]))

@@ -135,17 +135,13 @@ extern "C" int qbh_vec_disk_read(const char *filename, int64_t n, int elem_size,
 }
 
 // ckpt_lanczos_update, "val" purposes (src/ckpt.cc:178-297).  v: host vectors in the reference's slots (v[j] at
-// (j%2)*dim, phi0 at 2*dim for sr_val1).
-extern "C" int qbh_ckpt_lanczos_update(const char *dir, int64_t m, int64_t maxit, int64_t dim, int cnt_accuE0, double accuracy,
-                                       double theta0_prev, double theta1_prev, const qbh_z *v, const double *hessenberg,
-                                       const char *purpose)
+// (j%2)*dim, phi0 at 2*dim for sr_val1).  In two phases so that the ranks of a row-sharded run can meet between them
+// (qbh_lanczos_ckpt): WRITE leaves the first marker and the complete new data beside the old; COMMIT leaves the second marker,
+// removes the old data and the markers.  Until every rank has finished WRITE no rank starts COMMIT, so a crash anywhere leaves
+// either the old step readable on every rank or the new step complete on every rank.
+static int lanczos_update_write(const std::string &d, int64_t m, int64_t maxit, int64_t dim, int cnt_accuE0, double accuracy, double theta0_prev,
+                                double theta1_prev, const qbh_z *v, const double *hessenberg, const std::string &pur)
 {
-    if (!dir || !v || !hessenberg || !purpose || m < 0 || m >= maxit || dim <= 0) return QBH_EINVAL;
-    const std::string d(dir), pur(purpose);
-    if (pur.find("val") == std::string::npos) {
-        qbh::set_error("qbh_ckpt_lanczos_update: only the \"val\" purposes are checkpointed (got %s)", purpose);
-        return QBH_EUNSUPP;
-    }
     std::error_code ec;
     if (fs::exists(d, ec) && !fs::is_directory(d, ec)) fs::remove_all(d, ec);
     fs::create_directories(d, ec);
@@ -177,6 +173,12 @@ extern "C" int qbh_ckpt_lanczos_update(const char *dir, int64_t m, int64_t maxit
         std::memcpy(buf + 20, &theta1_prev, 8);
         if (!write_pod(P(d, "lczs_mlns.dat.new"), buf, sizeof(buf))) return QBH_EINVAL;
     }
+    return QBH_OK;
+}
+static int lanczos_update_commit(const std::string &d, int64_t m, const std::string &pur)
+{
+    std::error_code ec;
+    const bool val0 = pur.find("val0") != std::string::npos;
     if (!write_pod(P(d, "lczs_updt.Qckpt2"), &m, sizeof(int64_t))) return QBH_EINVAL;   // before / after this point: old / new data
     rm(P(d, "HessenbergA.dat"));
     rm(P(d, "HessenbergB.dat"));
@@ -192,6 +194,19 @@ extern "C" int qbh_ckpt_lanczos_update(const char *dir, int64_t m, int64_t maxit
     rm(P(d, "lczs_updt.Qckpt1"));
     rm(P(d, "lczs_updt.Qckpt2"));
     return QBH_OK;
+}
+extern "C" int qbh_ckpt_lanczos_update(const char *dir, int64_t m, int64_t maxit, int64_t dim, int cnt_accuE0, double accuracy,
+                                       double theta0_prev, double theta1_prev, const qbh_z *v, const double *hessenberg,
+                                       const char *purpose)
+{
+    if (!dir || !v || !hessenberg || !purpose || m < 0 || m >= maxit || dim <= 0) return QBH_EINVAL;
+    const std::string d(dir), pur(purpose);
+    if (pur.find("val") == std::string::npos) {
+        qbh::set_error("qbh_ckpt_lanczos_update: only the \"val\" purposes are checkpointed (got %s)", purpose);
+        return QBH_EUNSUPP;
+    }
+    QBH_TRY(lanczos_update_write(d, m, maxit, dim, cnt_accuE0, accuracy, theta0_prev, theta1_prev, v, hessenberg, pur));
+    return lanczos_update_commit(d, m, pur);
 }
 
 // ckpt_lanczos_init, "val" purposes (src/ckpt.cc:23-176): finishes or rewinds an interrupted update, finds the last
@@ -284,31 +299,158 @@ extern "C" int qbh_ckpt_lanczos_init(const char *dir, int64_t *k_out, int64_t ma
     return QBH_OK;
 }
 
+// ---- row shards: every rank keeps a reference-format checkpoint of ITS slice in dir/shard<r>of<P>/ ----
+// The ranks meet (through the communicator's own all-reduce) between the two phases of an update and before a resume, so that
+// they always continue from the same step: <= 16 ranks (one slot of qbh_comm.d_scal per rank).
+namespace {
+
+std::string shard_dir(const qbh_csr *A, const char *dir)
+{
+    if (!A->has_comm || A->comm.nranks <= 1) return std::string(dir);
+    return P(dir, "shard" + std::to_string(A->comm.rank) + "of" + std::to_string(A->comm.nranks));
+}
+
+// every rank's number, on every rank
+int rank_gather(qbh_csr *A, double mine, std::vector<double> &all)
+{
+    const int np = A->has_comm ? A->comm.nranks : 1;
+    all.assign((size_t)np, mine);
+    if (np <= 1) return QBH_OK;
+    if (np > 16) {
+        qbh::set_error("checkpoints of row shards: at most 16 ranks");
+        return QBH_EUNSUPP;
+    }
+    double v[16] = {0};
+    v[A->comm.rank] = mine;
+    QBH_HIP(hipMemcpyAsync(A->comm.d_scal, v, sizeof(v), hipMemcpyHostToDevice, A->stream));
+    if (A->comm.allreduce_sum(A->comm.ctx, 0, 16) != 0) {
+        qbh::set_error("allreduce_sum hook failed (checkpoint agreement)");
+        return QBH_ECOMM;
+    }
+    QBH_HIP(hipMemcpyAsync(v, A->comm.d_scal, sizeof(v), hipMemcpyDeviceToHost, A->stream));
+    QBH_HIP(hipStreamSynchronize(A->stream));
+    for (int q = 0; q < np; ++q) all[(size_t)q] = v[q];
+    return QBH_OK;
+}
+
+// the rank's verdict on a phase, agreed: QBH_OK only when every rank succeeded
+int agree_ok(qbh_csr *A, int my_rc, const char *what)
+{
+    std::vector<double> all;
+    QBH_TRY(rank_gather(A, my_rc == QBH_OK ? 0.0 : 1.0, all));
+    for (double f : all)
+        if (f != 0.0) {
+            if (my_rc == QBH_OK) qbh::set_error("%s failed on a peer rank", what);
+            return my_rc != QBH_OK ? my_rc : QBH_ECOMM;
+        }
+    return QBH_OK;
+}
+
+bool file_is(const std::string &f, int64_t n, int elem)
+{
+    std::error_code ec;
+    return fs::exists(f, ec) && fs::file_size(f, ec) == (uint64_t)(sizeof(int64_t) + (uint64_t)n * (uint64_t)elem + sizeof(uint32_t));
+}
+
+// Before a resume on shards: a rank whose update was interrupted AFTER its new data was complete may finish it only when every
+// rank is at that step (pending-and-complete, or already committed); otherwise everybody falls back to the step before.
+// pending_marker: lczs_updt.Qckpt1 / CG_updt.Qckpt1; complete(m): the rank's new files for step m are all there (sizes);
+// committed(): the step the directory holds without markers (-1: none).
+template <typename Complete, typename Committed>
+int settle_pending(qbh_csr *A, const std::string &d, const char *mk1_name, const char *mk2_name, Complete complete, Committed committed)
+{
+    if (!A->has_comm || A->comm.nranks <= 1) return QBH_OK;
+    std::error_code ec;
+    const std::string mk1 = P(d, mk1_name), mk2 = P(d, mk2_name);
+    int64_t cand = -1;
+    double state = 0.0;                              // 0 no pending update, 1 pending and complete, -1 pending and incomplete
+    if (fs::exists(mk1, ec) && fs::file_size(mk1, ec) == sizeof(int64_t)) {
+        std::ifstream f(mk1, std::ios::in | std::ios::binary);
+        f.read(reinterpret_cast<char *>(&cand), sizeof(int64_t));
+        state = (fs::exists(mk2, ec) || complete(cand)) ? 1.0 : -1.0;
+    } else {
+        cand = committed();
+    }
+    std::vector<double> st, cs;
+    QBH_TRY(rank_gather(A, state, st));
+    QBH_TRY(rank_gather(A, (double)cand, cs));
+    bool all_there = true;
+    double top = -1.0;
+    for (size_t q = 0; q < st.size(); ++q) {
+        all_there = all_there && st[q] >= 0.0;
+        top = std::max(top, cs[q]);
+    }
+    for (size_t q = 0; q < st.size(); ++q) all_there = all_there && cs[q] == top;
+    if (state == 1.0 && !fs::exists(mk2, ec)) {
+        if (all_there) {
+            if (!write_pod(mk2, &cand, sizeof(int64_t))) return QBH_EINVAL;      // the init below finishes the clean-up
+        }
+        // else: the marker stays alone and the init below rewinds, as on every other rank
+    } else if (state == 1.0 && fs::exists(mk2, ec) && !all_there) {
+        qbh::set_error("checkpoint of row shards: this rank committed step %lld but a peer does not hold it", (long long)cand);
+        return QBH_EINVAL;
+    }
+    return QBH_OK;
+}
+
+}  // namespace
+
 // lanczos(0, maxit - 1, ...) of the reference with enable_ckpt = true: resume from `dir` if it holds a usable step,
 // otherwise start from v (v[0] normalised, phi0 at 2*dim for sr_val1); a checkpoint is committed every `every` steps
 // and at the end.  max_steps > 0 stops after that many new steps (an "interrupted" run for tests and time-sliced
 // jobs).  *converged reports whether the stop rule fired.  v and hessenberg are host arrays as in qbh_lanczos.
-extern "C" int qbh_lanczos_ckpt(const qbh_csr *A, int64_t maxit, int64_t *m_out, qbh_z *v_host, double *hessenberg,
+// A row shard under a communicator (collective call): every rank checkpoints its slice in dir/shard<r>of<P>/ with the same
+// file names and protocol, and the ranks agree between the phases (above).
+extern "C" int qbh_lanczos_ckpt(const qbh_csr *Ac, int64_t maxit, int64_t *m_out, qbh_z *v_host, double *hessenberg,
                                 const char *purpose, int64_t every, int64_t max_steps, const char *dir, int *converged,
                                 qbh_solver_info *info_out)
 {
+    qbh_csr *A = const_cast<qbh_csr *>(Ac);
     if (!A || !m_out || !v_host || !hessenberg || !purpose || !dir || maxit < 3 || every < 1) return QBH_EINVAL;
     const std::string pur(purpose);
     const int nvec = pur.find("val1") != std::string::npos ? 3 : 2;
-    qbh_csr_info ci;
-    QBH_TRY(qbh_csr_get_info(A, &ci));
-    const int64_t n = ci.nrows;
-    if (ci.nrows != ci.ncols) {       // every rank would write the same file names into `dir` with its shard-local length
-        qbh::set_error("qbh_lanczos_ckpt: row-sharded operators are not supported (checkpoint files hold whole vectors)");
+    const int64_t n = A->nrows;
+    if (A->nrows != A->ncols && !A->has_comm) {
+        qbh::set_error("qbh_lanczos_ckpt: a row shard needs its communicator (every rank checkpoints its own slice)");
         return QBH_EUNSUPP;
     }
+    const std::string d = shard_dir(A, dir);
+    const bool val0 = pur.find("val0") != std::string::npos;
+    {
+        std::error_code ec;
+        fs::create_directories(d, ec);
+    }
+    QBH_TRY(settle_pending(
+        A, d, "lczs_updt.Qckpt1", "lczs_updt.Qckpt2",
+        [&](int64_t m) {
+            return m > 0 && file_is(P(d, "HessenbergA.dat.new"), m, 8) && file_is(P(d, "HessenbergB.dat.new"), m + 1, 8) &&
+                   file_is(P(d, "lanczosV" + std::to_string(m - 1) + ".dat"), n, 16) && file_is(P(d, "lanczosV" + std::to_string(m) + ".dat"), n, 16) &&
+                   fs::exists(P(d, "lczs_mlns.dat.new")) && (val0 || file_is(P(d, "lanczosY0.dat.new"), n, 16));
+        },
+        [&]() -> int64_t {
+            const std::vector<int64_t> ks = lanczos_vec_indices(d);
+            if (ks.empty()) return -1;
+            int64_t m = ks[0];
+            for (size_t i = 1; i < ks.size() && ks[i] == m + 1; ++i) m = ks[i];
+            return m;
+        }));
     int cnt = 0;
     double accuracy = 0.0, t0 = 0.0, t1 = 0.0;
     int64_t k = 0;
-    QBH_TRY(qbh_ckpt_lanczos_init(dir, &k, maxit, n, &cnt, &accuracy, &t0, &t1, v_host, hessenberg, purpose));
+    QBH_TRY(qbh_ckpt_lanczos_init(d.c_str(), &k, maxit, n, &cnt, &accuracy, &t0, &t1, v_host, hessenberg, purpose));
+    {   // every rank from the same step, or every rank from scratch
+        std::vector<double> ks;
+        QBH_TRY(rank_gather(A, (double)k, ks));
+        for (double q : ks)
+            if (q != (double)k) k = 0;
+        std::vector<double> k2;
+        QBH_TRY(rank_gather(A, (double)k, k2));
+        for (double q : k2)
+            if (q == 0.0) k = 0;
+    }
     if (k == 0) {                                  // from scratch: nothing of an earlier run may survive
         std::error_code ec;
-        for (auto &e : fs::directory_iterator(dir, ec)) {
+        for (auto &e : fs::directory_iterator(d, ec)) {
             const std::string nm = e.path().filename().string();
             if (nm.compare(0, 8, "lanczosV") == 0 || nm.compare(0, 8, "lanczosY") == 0 || nm.compare(0, 10, "Hessenberg") == 0 ||
                 nm.compare(0, 5, "lczs_") == 0)
@@ -346,8 +488,11 @@ extern "C" int qbh_lanczos_ckpt(const qbh_csr *A, int64_t maxit, int64_t *m_out,
         m = m_new;
         rc = qbh_vec_download(A, v_host, d_v, (int64_t)nvec * n);
         if (rc != QBH_OK) break;
-        rc = qbh_ckpt_lanczos_update(dir, m, maxit, n, (int)info.cnt_accuE0, info.accuracy, info.theta0_prev, info.theta1_prev, v_host,
-                                     hessenberg, purpose);
+        // phase 1 on every rank, the ranks meet, phase 2 on every rank (one rank: the two phases back to back)
+        rc = lanczos_update_write(d, m, maxit, n, (int)info.cnt_accuE0, info.accuracy, info.theta0_prev, info.theta1_prev, v_host, hessenberg, pur);
+        rc = agree_ok(A, rc, "writing the checkpoint");
+        if (rc != QBH_OK) break;
+        rc = lanczos_update_commit(d, m, pur);
         if (early || (info.cnt_accuE0 > 15 && info.accuracy < QBH_LANCZOS_PRECISION)) {
             conv = true;
             break;
@@ -363,5 +508,202 @@ extern "C" int qbh_lanczos_ckpt(const qbh_csr *A, int64_t maxit, int64_t *m_out,
         info_out->log_cap = log_cap;
         info_out->log_len = log_total;
     }
+    return QBH_OK;
+}
+
+// ------------------------------------------------------------------- CG checkpoints (src/ckpt.cc:344-517) ----
+// Files CG_V<m>.dat, CG_R<m>.dat, CG_P<m>.dat (vec_disk_write format) and the two markers CG_updt.Qckpt1 / .Qckpt2: the first is
+// written before the new vectors, the second after them ("before / after this point, have to use old / new data"), then the
+// vectors of the step before and both markers go.
+namespace {
+
+std::vector<int64_t> cg_indices(const std::string &dir)
+{
+    std::vector<int64_t> ks;
+    std::error_code ec;
+    for (auto &e : fs::directory_iterator(dir, ec)) {
+        const std::string n = e.path().filename().string();
+        if (n.size() > 8 && n.compare(0, 4, "CG_V") == 0 && n.compare(n.size() - 4, 4, ".dat") == 0) {
+            const std::string mid = n.substr(4, n.size() - 8);
+            if (!mid.empty() && mid.find_first_not_of("0123456789") == std::string::npos) ks.push_back(std::stoll(mid));
+        }
+    }
+    std::sort(ks.begin(), ks.end());
+    return ks;
+}
+std::string cgf(const std::string &d, char which, int64_t m) { return P(d, std::string("CG_") + which + std::to_string(m) + ".dat"); }
+
+int cg_update_write(const std::string &d, int64_t m, int64_t dim, const qbh_z *v, const qbh_z *r, const qbh_z *p)
+{
+    std::error_code ec;
+    if (fs::exists(d, ec) && !fs::is_directory(d, ec)) fs::remove_all(d, ec);
+    fs::create_directories(d, ec);
+    rm(P(d, "CG_updt.Qckpt1"));
+    rm(P(d, "CG_updt.Qckpt2"));
+    if (!write_pod(P(d, "CG_updt.Qckpt1"), &m, sizeof(int64_t))) return QBH_EINVAL;
+    QBH_TRY(qbh_vec_disk_write(cgf(d, 'V', m).c_str(), dim, 16, v));
+    QBH_TRY(qbh_vec_disk_write(cgf(d, 'R', m).c_str(), dim, 16, r));
+    QBH_TRY(qbh_vec_disk_write(cgf(d, 'P', m).c_str(), dim, 16, p));
+    return QBH_OK;
+}
+int cg_update_commit(const std::string &d, int64_t m)
+{
+    if (!write_pod(P(d, "CG_updt.Qckpt2"), &m, sizeof(int64_t))) return QBH_EINVAL;     // src/ckpt.cc:467: fs::copy of the first marker
+    for (int64_t k : cg_indices(d))                        // the reference removes step m - 1; updates `every` steps apart: whatever is older
+        if (k != m)
+            for (char w : {'V', 'R', 'P'}) rm(cgf(d, w, k));
+    rm(P(d, "CG_updt.Qckpt1"));
+    rm(P(d, "CG_updt.Qckpt2"));
+    return QBH_OK;
+}
+
+}  // namespace
+
+extern "C" int qbh_ckpt_cg_update(const char *dir, int64_t m, int64_t dim, const qbh_z *v, const qbh_z *r, const qbh_z *p)
+{
+    if (!dir || !v || !r || !p || m < 0 || dim <= 0) return QBH_EINVAL;
+    QBH_TRY(cg_update_write(dir, m, dim, v, r, p));
+    return cg_update_commit(dir, m);
+}
+
+// ckpt_CG_init (src/ckpt.cc:344-433): finishes or rewinds an interrupted update, finds the step on disk and loads v, r, p.
+// *m_out = 0: nothing usable.
+extern "C" int qbh_ckpt_cg_init(const char *dir, int64_t *m_out, int64_t maxit, int64_t dim, qbh_z *v, qbh_z *r, qbh_z *p)
+{
+    if (!dir || !m_out || !v || !r || !p || dim <= 0) return QBH_EINVAL;
+    *m_out = 0;
+    const std::string d(dir);
+    std::error_code ec;
+    if (!fs::is_directory(d, ec)) return QBH_OK;
+    const std::string mk1 = P(d, "CG_updt.Qckpt1"), mk2 = P(d, "CG_updt.Qckpt2");
+    if (fs::exists(mk1, ec) && fs::file_size(mk1, ec) == sizeof(int64_t)) {
+        int64_t k = 0;
+        {
+            std::ifstream f(mk1, std::ios::in | std::ios::binary);
+            f.read(reinterpret_cast<char *>(&k), sizeof(int64_t));
+        }
+        if (fs::exists(mk2, ec)) {                         // :382-392 new data complete: the older vectors go
+            for (int64_t kk : cg_indices(d))
+                if (kk != k)
+                    for (char w : {'V', 'R', 'P'}) rm(cgf(d, w, kk));
+        } else {                                           // :393-405 torn update: its files go, the step before stays
+            for (char w : {'V', 'R', 'P'}) rm(cgf(d, w, k));
+        }
+        rm(mk1);
+        rm(mk2);
+    } else {
+        rm(mk1);
+        rm(mk2);
+    }
+    const std::vector<int64_t> ks = cg_indices(d);         // :410-413: the first step present (after the clean-up: the only one)
+    if (ks.empty()) return QBH_OK;
+    const int64_t m = ks.back();
+    if (m <= 0 || m >= maxit) return QBH_OK;
+    std::vector<qbh_z> tv((size_t)dim), tr((size_t)dim), tp((size_t)dim);
+    // where the reference asserts on an unreadable file, nothing is loaded and the caller starts from scratch
+    if (qbh_vec_disk_read(cgf(d, 'V', m).c_str(), dim, 16, tv.data()) != 0) return QBH_OK;
+    if (qbh_vec_disk_read(cgf(d, 'R', m).c_str(), dim, 16, tr.data()) != 0) return QBH_OK;
+    if (qbh_vec_disk_read(cgf(d, 'P', m).c_str(), dim, 16, tp.data()) != 0) return QBH_OK;
+    std::memcpy(v, tv.data(), (size_t)dim * 16);
+    std::memcpy(r, tr.data(), (size_t)dim * 16);
+    std::memcpy(p, tp.data(), (size_t)dim * 16);
+    *m_out = m;
+    return QBH_OK;
+}
+
+// ckpt_CG_clean (src/ckpt.cc:480-517)
+extern "C" int qbh_ckpt_cg_clean(const char *dir)
+{
+    if (!dir) return QBH_EINVAL;
+    const std::string d(dir);
+    for (int64_t k : cg_indices(d))
+        for (char w : {'V', 'R', 'P'}) rm(cgf(d, w, k));
+    return QBH_OK;
+}
+
+// eigenvec_CG of the reference with enable_ckpt = true (src/lanczos.cc:281-341): resume from `dir` when it holds a step,
+// otherwise start from v (m = 0); a checkpoint every `every` CG steps and at the end; max_steps > 0 stops after that many new
+// steps.  *converged: the loop ended by its own rule (residual below lanczos_precision with |v| = 1).  The residual history
+// (log_CG.txt, src/lanczos.cc:308-311,334-337) is returned in info->cg_resid[1..m] for the steps made by THIS call.
+// Row shards (collective): dir/shard<r>of<P>/ as for qbh_lanczos_ckpt.
+extern "C" int qbh_eigenvec_cg_ckpt(const qbh_csr *Ac, int64_t maxit, int64_t *m_out, double E0, double *accu_out, qbh_z *v_host, qbh_z *r_host,
+                                    qbh_z *p_host, qbh_z *pp_host, int64_t every, int64_t max_steps, const char *dir, int *converged,
+                                    qbh_solver_info *info_out)
+{
+    qbh_csr *A = const_cast<qbh_csr *>(Ac);
+    if (!A || !m_out || !accu_out || !v_host || !r_host || !p_host || !pp_host || !dir || maxit < 2 || every < 1) return QBH_EINVAL;
+    if (A->nrows != A->ncols && !A->has_comm) {
+        qbh::set_error("qbh_eigenvec_cg_ckpt: a row shard needs its communicator");
+        return QBH_EUNSUPP;
+    }
+    const int64_t n = A->nrows;
+    const std::string d = shard_dir(A, dir);
+    {
+        std::error_code ec;
+        fs::create_directories(d, ec);
+    }
+    QBH_TRY(settle_pending(
+        A, d, "CG_updt.Qckpt1", "CG_updt.Qckpt2",
+        [&](int64_t m) { return file_is(cgf(d, 'V', m), n, 16) && file_is(cgf(d, 'R', m), n, 16) && file_is(cgf(d, 'P', m), n, 16); },
+        [&]() -> int64_t {
+            const std::vector<int64_t> ks = cg_indices(d);
+            return ks.empty() ? -1 : ks.back();
+        }));
+    int64_t m = 0;
+    QBH_TRY(qbh_ckpt_cg_init(d.c_str(), &m, maxit, n, v_host, r_host, p_host));
+    {
+        std::vector<double> ms;
+        QBH_TRY(rank_gather(A, (double)m, ms));
+        for (double q : ms)
+            if (q != (double)m) m = 0;
+        std::vector<double> m2;
+        QBH_TRY(rank_gather(A, (double)m, m2));
+        for (double q : m2)
+            if (q == 0.0) m = 0;
+    }
+    if (m == 0) QBH_TRY(qbh_ckpt_cg_clean(d.c_str()));
+    qbh_z *dv = nullptr;
+    QBH_TRY(qbh_vec_alloc(&dv, 4 * n));
+    qbh_z *hv[4] = {v_host, r_host, p_host, pp_host};
+    int rc = QBH_OK;
+    for (int i = 0; i < 3 && rc == QBH_OK; ++i) rc = qbh_vec_upload(A, dv + (size_t)i * (size_t)n, hv[i], n);
+    double accu = 0.0;
+    int64_t done = 0;
+    bool conv = false;
+    std::vector<double> resid((size_t)maxit + 2, 0.0);
+    while (rc == QBH_OK && m < maxit) {
+        int64_t stop = std::min<int64_t>(m + every, maxit);
+        if (max_steps > 0) stop = std::min<int64_t>(stop, m + (max_steps - done));
+        if (stop <= m) break;
+        qbh_solver_info ci{};
+        ci.cg_resid = resid.data();
+        int64_t m_new = m;
+        rc = qbh_eigenvec_cg_dev(A, stop, &m_new, E0, &accu, dv, dv + n, dv + 2 * n, dv + 3 * n, &ci);
+        if (rc != QBH_OK) break;
+        if (info_out && info_out->cg_resid)
+            for (int64_t j = m + 1; j <= m_new; ++j) info_out->cg_resid[j] = resid[(size_t)j];
+        if (info_out) info_out->n_matvec += ci.n_matvec;
+        const bool ended = m_new < stop || (m_new == m);        // the loop left by its own rule
+        done += m_new - m;
+        m = m_new;
+        for (int i = 0; i < 3 && rc == QBH_OK; ++i) rc = qbh_vec_download(A, hv[i], dv + (size_t)i * (size_t)n, n);
+        if (rc != QBH_OK) break;
+        if (m > 0) {
+            rc = cg_update_write(d, m, n, v_host, r_host, p_host);
+            rc = agree_ok(A, rc, "writing the CG checkpoint");
+            if (rc != QBH_OK) break;
+            rc = cg_update_commit(d, m);
+        }
+        if (ended) {
+            conv = true;
+            break;
+        }
+    }
+    if (rc == QBH_OK) rc = qbh_vec_download(A, pp_host, dv + 3 * (size_t)n, n);
+    (void)qbh_vec_free(dv);
+    if (rc != QBH_OK) return rc;
+    *m_out = m;
+    *accu_out = accu;
+    if (converged) *converged = conv ? 1 : 0;
     return QBH_OK;
 }

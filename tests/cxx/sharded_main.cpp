@@ -9,6 +9,8 @@
 //        parts=K     qbh_opts.gather_parts;  unsplit=R  rank R keeps its shard unsplit (the ranks must fall back together)
 //        plain=1     complex128 values and vectors (value_dict = 0, real_fast_path = 0)
 //        realwire=0  qbh_opts.real_wire = 0 (split shards: 16-byte elements on the links even for a real solve)
+//        ckpt=DIR every=K maxsteps=N   the Lanczos run through qbh_lanczos_ckpt (collective: every rank checkpoints its slice in
+//                    DIR/shard<r>of<P>/), stopped after N new steps when N > 0; then only the Lanczos part is dumped
 //        dump=PREFIX rank r writes PREFIX.r.bin: m, mcg, E0, a_j / b_j (2 m doubles), its slice of the eigenvector
 #include <chrono>
 #include <complex>
@@ -61,7 +63,8 @@ int main(int argc, char **argv)
     bool uniform = false;
     int64_t kron = 0;
     int parts = 0, unsplit = -1, plain = 0, realwire = 1;
-    std::string dump;
+    std::string dump, ckdir;
+    long long every = 10, maxsteps = 0;
     for (int i = 5; i < argc; ++i) {
         const std::string a(argv[i]);
         if (a == "uniform") uniform = dim % nranks == 0;
@@ -70,6 +73,9 @@ int main(int argc, char **argv)
         else if (a.rfind("unsplit=", 0) == 0) unsplit = std::atoi(a.c_str() + 8);
         else if (a.rfind("plain=", 0) == 0) plain = std::atoi(a.c_str() + 6);
         else if (a.rfind("realwire=", 0) == 0) realwire = std::atoi(a.c_str() + 9);
+        else if (a.rfind("ckpt=", 0) == 0) ckdir = a.substr(5);
+        else if (a.rfind("every=", 0) == 0) every = std::atoll(a.c_str() + 6);
+        else if (a.rfind("maxsteps=", 0) == 0) maxsteps = std::atoll(a.c_str() + 9);
         else if (a.rfind("dump=", 0) == 0) dump = a.substr(5);
         else return 2;
     }
@@ -102,6 +108,33 @@ int main(int argc, char **argv)
     must(qbh_vec_randomize(A, d_v, 1), "qbh_vec_randomize");                         // this rank's slice of the global start vector
     std::vector<double> hess(2 * maxit, 0.0), ritz(maxit), s((size_t)maxit * maxit);
     int64_t m = 0;
+    if (!ckdir.empty()) {
+        // the checkpointed run (host vectors, as lanczos() of the reference with enable_ckpt): interrupted after maxsteps, or to the end
+        std::vector<cplx> hv(2 * n);
+        must(qbh_vec_download(A, reinterpret_cast<qbh_z *>(hv.data()), d_v, 2 * n), "qbh_vec_download");
+        int conv = 0;
+        must(qbh_lanczos_ckpt(A, maxit, &m, reinterpret_cast<qbh_z *>(hv.data()), hess.data(), "sr_val0", every, maxsteps, ckdir.c_str(), &conv, nullptr),
+             "qbh_lanczos_ckpt");
+        double E0c = 0.0;
+        if (m > 2) {
+            must(qbh_hess_eigen(hess.data(), maxit, m, "sr", ritz.data(), s.data()), "qbh_hess_eigen");
+            E0c = ritz[0];
+        }
+        if (!dump.empty()) {
+            std::ofstream o(dump + "." + std::to_string(rank) + ".bin", std::ios::binary);
+            const int64_t head[2] = {m, (int64_t)conv};
+            o.write((const char *)head, 16);
+            o.write((const char *)&E0c, 8);
+            o.write((const char *)(hess.data() + maxit), 8 * m);
+            o.write((const char *)hess.data(), 8 * m);
+        }
+        std::printf("OK %d %d %lld %lld %lld %.17g %d 0 1 kron 0 parts 0 cols16 0 wire 0\n", rank, nranks, (long long)cuts[rank], (long long)cuts[rank + 1],
+                    (long long)m, E0c, conv);
+        qbh_vec_free(d_v);
+        must(qbh_comm_destroy(A), "qbh_comm_destroy");
+        qbh_csr_destroy(A);
+        return 0;
+    }
     must(qbh_lanczos_dev(A, 0, maxit - 1, maxit, &m, d_v, hess.data(), "sr_val0", nullptr), "qbh_lanczos_dev");
     must(qbh_hess_eigen(hess.data(), maxit, m, "sr", ritz.data(), s.data()), "qbh_hess_eigen");
     const double E0 = ritz[0];

@@ -291,3 +291,100 @@ def test_interrupted_run_resumes_to_the_same_answer(tmp_path):
     assert abs(m0 - m2) <= 1
     assert np.allclose(h0[maxit:maxit + 40], hess2[maxit:maxit + 40], rtol=1e-9)
     assert abs(np.linalg.norm(v_pair[:d]) - 1.0) < 1e-12
+
+
+# ---- the CG half of the protocol (src/ckpt.cc:344-517) -------------------------------------------------------------
+def _cg_native(d, m, dim, seed):
+    import ctypes as C
+    from quantum_basis_amd._lib import check, lib
+    rng = np.random.default_rng(seed)
+    vs = [(rng.normal(size=dim) + 1j * rng.normal(size=dim)).astype(np.complex128) for _ in range(3)]
+    check(lib().qbh_ckpt_cg_update(d.encode(), m, dim, *[x.ctypes.data_as(C.c_void_p) for x in vs]), "qbh_ckpt_cg_update")
+    return vs
+
+
+def _cg_init(d, maxit, dim):
+    import ctypes as C
+    from quantum_basis_amd._lib import check, lib
+    m = C.c_int64(-1)
+    vs = [np.zeros(dim, dtype=np.complex128) for _ in range(3)]
+    check(lib().qbh_ckpt_cg_init(d.encode(), C.byref(m), maxit, dim, *[x.ctypes.data_as(C.c_void_p) for x in vs]), "qbh_ckpt_cg_init")
+    return m.value, vs
+
+
+def test_cg_checkpoint_files_and_markers_are_the_references(tmp_path):
+    """ckpt_CG_update / ckpt_CG_init / ckpt_CG_clean: CG_V<m>.dat, CG_R<m>.dat, CG_P<m>.dat in vec_disk_write format, the step
+    before removed after the second marker, both markers gone at the end (src/ckpt.cc:438-478)."""
+    d = str(tmp_path / "out_Qckpt")
+    dim, maxit = 37, 100
+    assert _cg_init(d, maxit, dim)[0] == 0                                   # no directory: start from scratch
+    v5 = _cg_native(d, 5, dim, 1)
+    assert sorted(os.listdir(d)) == ["CG_P5.dat", "CG_R5.dat", "CG_V5.dat"]
+    raw = open(os.path.join(d, "CG_R5.dat"), "rb").read()                    # int64 n | payload | CRC-32 (src/miscellaneous.cc:439-469)
+    assert struct.unpack("<q", raw[:8])[0] == dim and raw[8:-4] == v5[1].tobytes() and struct.unpack("<I", raw[-4:])[0] == zlib.crc32(raw[:-4]) & 0xFFFFFFFF
+    v6 = _cg_native(d, 6, dim, 2)
+    assert sorted(os.listdir(d)) == ["CG_P6.dat", "CG_R6.dat", "CG_V6.dat"]  # :470-475
+    m, got = _cg_init(d, maxit, dim)
+    assert m == 6 and all(np.array_equal(a, b) for a, b in zip(got, v6))
+    # the Python mirror's reader accepts the files (one format)
+    assert np.array_equal(ckpt.vec_disk_read(os.path.join(d, "CG_V6.dat"), dim, np.complex128), v6[0])
+    # torn update, first marker only (:393-405): the new step's files go, the step before is what is loaded
+    open(os.path.join(d, "CG_updt.Qckpt1"), "wb").write(struct.pack("<q", 7))
+    ckpt.vec_disk_write(os.path.join(d, "CG_V7.dat"), v5[0])
+    ckpt.vec_disk_write(os.path.join(d, "CG_R7.dat"), v5[1])                 # (P7 never written)
+    m, got = _cg_init(d, maxit, dim)
+    assert m == 6 and np.array_equal(got[2], v6[2]) and sorted(os.listdir(d)) == ["CG_P6.dat", "CG_R6.dat", "CG_V6.dat"]
+    # interrupted after the second marker (:382-392): the new data is complete, the old step goes
+    for w, x in zip("VRP", v5):
+        ckpt.vec_disk_write(os.path.join(d, "CG_%s7.dat" % w), x)
+    open(os.path.join(d, "CG_updt.Qckpt1"), "wb").write(struct.pack("<q", 7))
+    open(os.path.join(d, "CG_updt.Qckpt2"), "wb").write(struct.pack("<q", 7))
+    m, got = _cg_init(d, maxit, dim)
+    assert m == 7 and np.array_equal(got[0], v5[0]) and sorted(os.listdir(d)) == ["CG_P7.dat", "CG_R7.dat", "CG_V7.dat"]
+    # a corrupted vector: nothing is loaded (the reference asserts)
+    raw = bytearray(open(os.path.join(d, "CG_P7.dat"), "rb").read())
+    raw[40] ^= 1
+    open(os.path.join(d, "CG_P7.dat"), "wb").write(bytes(raw))
+    assert _cg_init(d, maxit, dim)[0] == 0
+    from quantum_basis_amd._lib import check, lib
+    check(lib().qbh_ckpt_cg_clean(d.encode()), "qbh_ckpt_cg_clean")          # :480-517
+    assert os.listdir(d) == []
+
+
+@pytest.mark.gpu
+def test_cg_eigenvector_run_interrupted_and_resumed(tmp_path):
+    """qbh_eigenvec_cg_ckpt (eigenvec_CG with enable_ckpt, src/lanczos.cc:281-341): stopped after 25 steps, the files on disk are the
+    reference's, a NEW operator resumes from them and ends where the uninterrupted run ends; the residuals of log_CG.txt are
+    returned for the steps each call made."""
+    import helpers
+    import quantum_basis_amd as q
+    d, ia, ja, val, sym = helpers.case("hubbard_4x2")
+    g = helpers.probe()["hubbard_4x2"]
+    maxit = 1000
+    A = q.csr_mat(d, ia, ja, val, sym)
+    E0 = q.locate_E0_lanczos(A, nev=1, ncv=0, maxit=maxit).E0 if False else g["E0"]
+    v0 = q.vec_randomize(A, seed=1)
+    # uninterrupted device run (no checkpoints)
+    vs = [v0.copy()] + [np.zeros(d, dtype=np.complex128) for _ in range(3)]
+    m_ref, accu_ref = q.eigenvec_CG(d, maxit, 0, A, E0, *vs)
+    res_ref = list(q.eigenvec_CG.last["resid"])
+    ck = str(tmp_path / "out_Qckpt")
+    m1, accu1, _, conv1, resid1 = ckpt.native_cg_checkpointed(A, maxit, E0, v0, every=10, directory=ck, max_steps=25)
+    assert m1 == 25 and not conv1
+    assert sorted(os.listdir(ck)) == ["CG_P25.dat", "CG_R25.dat", "CG_V25.dat"]
+    assert np.allclose(resid1[1:26], res_ref[:25], rtol=1e-6)
+    A.destroy()
+    B = q.csr_mat(d, ia, ja, val, sym)
+    m2, accu2, v, conv2, resid2 = ckpt.native_cg_checkpointed(B, maxit, E0, np.zeros(d), every=40, directory=ck)      # v0 ignored: resumed
+    assert conv2 and abs(m2 - m_ref) <= 3 and accu2 < 2e-12
+    assert resid2[25] == 0.0 and resid2[26] > 0.0                             # only the steps of this call
+    assert abs(np.linalg.norm(v) - 1.0) < 1e-10 and abs(abs(np.vdot(v, vs[0])) - 1.0) < 1e-9       # the same eigenvector
+    y = np.empty(d, dtype=np.complex128)
+    B.MultMv(v, y)
+    assert np.linalg.norm(y - E0 * v) < 1e-9
+    log = str(tmp_path / "log_CG.txt")
+    ckpt.append_log_cg(resid1, 0, m1, log)
+    ckpt.append_log_cg(resid2, m1, m2, log)
+    rows = [ln.split() for ln in open(log)]
+    assert [int(r[0]) for r in rows] == list(range(1, m2 + 1)) and all(len(ln) == 41 for ln in open(log))      # setw(20) x 2 + newline
+    B.destroy()

@@ -155,6 +155,44 @@ def test_bench_two_ranks_on_one_gpu_through_the_native_communicator(rig):
     assert all(p["ms_spmv"] > 0 and p["rows"] > 0 for p in pr) and sum(p["rows"] for p in pr) == got["config"]["dim"], pr
 
 
+@pytest.mark.parametrize("kron", [0, 1])
+def test_sharded_lanczos_run_interrupted_and_resumed_from_rank_checkpoints(rig, kron):
+    """qbh_lanczos_ckpt on row shards (collective): two ranks, stopped after 20 steps -- every rank's slice sits in
+    <dir>/shard<r>of2/ under the reference's own file names (src/ckpt.cc:178-297) with shard-local lengths -- then two NEW
+    processes resume from the files and converge to the one-rank E0; the first 20 coefficients come from disk.  Then a torn
+    update on ONE rank (first marker, new data complete, no second marker -- the crash window between the ranks' commits):
+    the ranks settle on the new step together.  Plain shards and split shards (tiled exchange, real wire)."""
+    import shutil
+    import struct
+    ck = os.path.join(rig["tmp"], "ck_shards_%d" % kron)
+    shutil.rmtree(ck, ignore_errors=True)
+    extra = ["plain=1"] + (["kron=%d" % S_MINOR, "uniform"] if kron else [])
+    ref = _reference(rig, True)
+    r1 = _run(rig, 2, extra + ["ckpt=" + ck, "every=7", "maxsteps=20"], "ck1_%d" % kron)
+    assert all(r["m"] == 20 and r["mcg"] == 0 for r in r1)                               # (mcg slot: converged flag)
+    for r, res in enumerate(r1):
+        d = os.path.join(ck, "shard%dof2" % r)
+        assert sorted(os.listdir(d)) == ["HessenbergA.dat", "HessenbergB.dat", "lanczosV19.dat", "lanczosV20.dat", "lczs_mlns.dat"]
+        n = res["r1"] - res["r0"]
+        assert os.path.getsize(os.path.join(d, "lanczosV20.dat")) == 8 + 16 * n + 4      # the rank's slice, vec_disk_write format
+        assert struct.unpack("<q", open(os.path.join(d, "lanczosV20.dat"), "rb").read(8))[0] == n
+        assert os.path.getsize(os.path.join(d, "HessenbergA.dat")) == 8 + 8 * 20 + 4
+    assert np.array_equal(r1[0]["a"], r1[1]["a"])
+    # the crash window: rank 1 is put back into "new data written, second marker missing" for a step-21 update while rank 0 holds 21 committed
+    r21 = _run(rig, 2, extra + ["ckpt=" + ck, "every=1", "maxsteps=1"], "ck21_%d" % kron)
+    assert all(r["m"] == 21 for r in r21)
+    d1 = os.path.join(ck, "shard1of2")
+    for nm in ("HessenbergA.dat", "HessenbergB.dat", "lczs_mlns.dat"):
+        os.rename(os.path.join(d1, nm), os.path.join(d1, nm + ".new"))
+    open(os.path.join(d1, "lczs_updt.Qckpt1"), "wb").write(struct.pack("<q", 21))
+    r2 = _run(rig, 2, extra + ["ckpt=" + ck, "every=50"], "ck2_%d" % kron)
+    assert all(r["mcg"] == 1 for r in r2)                                                  # converged
+    for r in r2:
+        assert abs(r["m"] - ref["m"]) <= 1 and abs(r["E0"] - ref["E0"]) <= 1e-11 * abs(ref["E0"])
+        assert np.array_equal(r["a"][:20], r1[0]["a"][:20]) and np.array_equal(r["b"][:20], r1[0]["b"][:20])      # from disk, bit for bit
+        assert np.array_equal(r["a"][:21], r21[0]["a"][:21])
+
+
 def test_bench_starts_its_own_ranks_when_no_launcher_did(rig):
     """`python bench.py --gpus 2` with WORLD_SIZE unset (the way the driver runs N = 1): the parent starts the rank processes itself
     before it touches the GPU, relays rank 0's line and the ranks' exit code; --gpus 1 is unchanged."""
