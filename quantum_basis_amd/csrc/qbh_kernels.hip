@@ -1016,12 +1016,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
     int buf_n = 0, buf_nb = 0;                   // rows buffered; rows buffered before the current block
     bool at_first = false, at_last = false, merge_first = false, direct = !BUF;
     auto emit = [&](int64_t row, d2 v, bool atomic) {
-#ifdef QBH_ABL_NO_FAR_STORE          // ablation builds only (wrong results): the far pass without its row stores
-        if (OPS == 3 || OPS == 0) {
-            if (v.x == 1.2345e300) a.y[row] = v;
-            return;
-        }
-#endif
         if (OPS == 3) {
             if (row < a.nrows) {
                 if (atomic) {
@@ -1144,32 +1138,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
             }
         }
         d2 xv[8];
-#if defined(QBH_ABL_NEAR_LDS)            // ablation builds only (wrong results): near gathers served from a wave-private LDS window
-        if (OPS == 2) {
-            constexpr int WN = 640;
-            __shared__ d2 win_s[4 * WN];
-            d2 *win = win_s + wv * WN;
-            const int wbase = b0.r0 - 264;
-#if QBH_ABL_NEAR_LDS == 2
-            if (asking) {                 // first turn of a chunk: the window of x around the chunk's rows (synchronously: pessimistic)
-                for (int k = 0; k < WN / 64; ++k) {
-                    int64_t r = (int64_t)wbase + lane + 64 * k;
-                    r = r < 0 ? 0 : r >= a.nrows ? a.nrows - 1 : r;
-                    win[lane + 64 * k] = a.xg[r];
-                }
-                wave_lds_fence();
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const unsigned rel = (unsigned)(cA[u] - wbase);
-                xv[u] = rel < (unsigned)WN ? win[rel] : a.xg[cA[u]];
-            }
-#else
-#pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = win[(unsigned)(cA[u] - wbase) % WN];
-#endif
-        } else
-#endif
         if constexpr (C16) {
             // sliced far part: slot i of a block belongs to far row 8 g + i % 8 (groups and blocks start at multiples of 8 slots)
             const d2 *xq = a.xg + b0.xb + (OPS == 3 ? (lane & 7) : 0);
@@ -1179,12 +1147,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 
 #pragma unroll
             for (int u = 0; u < 8; ++u) xv[u] = a.xg[cA[u]];
         }
-#ifdef QBH_ABL_NO_FAR_GATHER         // ablation builds only (wrong results): the far pass without its gathers
-        if (OPS == 3 || OPS == 0) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = d2{(double)cA[u], 1.0};
-        }
-#endif
         issue_ops(b0, oA);
         __builtin_amdgcn_sched_barrier(0);      // the gathers go out BEFORE the next block's stream (in-order return)
         int cB[8];

@@ -749,7 +749,7 @@ def moprXvec_flip_repr(n_sites, n_dn_old, kind, perms, chars_old, chars_new, coe
     return d0.value, d1.value
 
 
-def measure_repr_static_hubbard(n_sites, n_up, n_dn, perms, chars, d_psi, one_body=(), two_body=(), spin_exchange=(), opts=None):
+def measure_repr_static_hubbard(n_sites, n_up, n_dn, perms, chars, d_psi, one_body=(), two_body=(), spin_exchange=(), opts=None, source=None):
     """model::measure_repr_static (src/model.cc:1860-1891) for the two-species fermion family in a momentum sector:
     <psi| O_t |psi> with O_t = (1/N) sum_R T(R) O T(-R), the translation average of
         O = sum (a_up c+_{i,up} c_{j,up} + a_dn c+_{i,dn} c_{j,dn})                        one_body  = [(i, j, a_up, a_dn), ...]
@@ -761,7 +761,17 @@ def measure_repr_static_hubbard(n_sites, n_up, n_dn, perms, chars, d_psi, one_bo
     on top of the last one <S_i . S_j>.  The reference transforms the operator with every translation plan and applies the
     averaged mopr through moprXvec_repr; here the averaged operator is assembled as a sector operator on the device
     (qbh_gen_hubbard_repr: same rows, same representatives as the Hamiltonian of the sector) and applied once.
-    d_psi: device vector of the sector (e.g. the eigenvector of locate_E0_lanczos on the sector operator)."""
+    d_psi: device vector of the sector IN THE ORDER OF THE GENERATORS (ascending representatives) -- the order of a stored
+    hubbard_repr operator's device vectors and of every host vector.  A device vector of a handle that keeps another order
+    internally (info().basis_internal != 0: the matrix-free sector operator with qbh_opts.sector_orbit, an operator whose basis
+    was named or detected) must be passed together with that handle as `source`: it is translated first (qbh_vec_from_internal).
+    Without `source` a handle-ordered vector would give a silently wrong number, so name the handle whenever there is one."""
+    conv = None
+    if source is not None and source.info().basis_internal != 0:
+        conv = source.vec(1)
+        source.from_internal(conv.ptr, d_psi)
+        source.sync()
+        d_psi = conv.ptr
     perms = np.asarray(perms, dtype=np.int64)
     w = 1.0 / len(perms)
     terms, pairs, exch = [], [], []
@@ -776,6 +786,8 @@ def measure_repr_static_hubbard(n_sites, n_up, n_dn, perms, chars, d_psi, one_bo
     val = Ot.dotc(d_psi, y.ptr)
     y.free()
     Ot.destroy()
+    if conv is not None:
+        conv.free()
     return val
 
 

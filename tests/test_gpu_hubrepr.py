@@ -959,5 +959,28 @@ def test_two_body_diagonal_observables_in_a_sector_against_the_full_basis():
     # the reference's own asserted one-body correlator through the same entry point (square_Fermi_Hubbard.cc:182)
     hop = q.measure_repr_static_hubbard(n, nu, nd, perms, chars, psi.ptr, one_body=[(1, 5, 1.0, 0.0)])
     assert abs(hop - 0.3957690742) < 1e-8
+    # The same measurement on the eigenvector of the MATRIX-FREE sector operator, which keeps its device vectors orbit by orbit
+    # (qbh_opts.sector_orbit, qbh_csr_info.basis_internal != 0): a handle-ordered device vector must be named with its handle
+    # (`source`), and then gives the same numbers; handed over bare it is a different vector (nothing used to check).
+    M = q.csr_mat.hubbard_repr_mf(n, nu, nd, bonds, perms, chars, t=1.0, U=1.1)
+    assert M.info().basis_internal != 0
+    maxit = 400
+    vm = M.vec(2)
+    M.randomize(vm.at(0), 1)
+    hess = np.zeros(2 * maxit)
+    mm = q.lanczos(0, maxit - 1, maxit, dim, M, None, hess, "sr_val0", device_v=vm)
+    e0m = q.hess_eigen(hess, maxit, mm, "sr")[0][0]
+    assert abs(e0m - w_full[0]) < 1e-9
+    cg = M.vec(4)
+    M.randomize(cg.at(0), 1)
+    q.eigenvec_CG(dim, maxit, 0, M, e0m, cg.at(0), cg.at(dim), cg.at(2 * dim), cg.at(3 * dim), device=True)
+    docc_m = q.measure_repr_static_hubbard(n, nu, nd, perms, chars, cg.at(0), two_body=[(2, 2, 0.0, 1.0, 0.0, 0.0)], source=M)
+    hop_m = q.measure_repr_static_hubbard(n, nu, nd, perms, chars, cg.at(0), one_body=[(1, 5, 1.0, 0.0)], source=M)
+    assert abs(docc_m - docc_full) < 1e-8 and abs(hop_m - 0.3957690742) < 1e-8
+    hop_bare = q.measure_repr_static_hubbard(n, nu, nd, perms, chars, cg.at(0), one_body=[(1, 5, 1.0, 0.0)])
+    assert abs(hop_bare - 0.3957690742) > 1e-4                      # the orbit-ordered vector is NOT the generator-ordered one
+    vm.free()
+    cg.free()
+    M.destroy()
     psi.free()
     A.destroy()
