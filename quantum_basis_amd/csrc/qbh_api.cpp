@@ -622,7 +622,8 @@ int new_handle(qbh_csr **out, const qbh_opts *opts, bool host_arrays)
     else if (host_arrays) qbh_opts_default(&A->opts);      // process-wide defaults: the host-array entry points they are documented for
     else qbh::opts_builtin(&A->opts);
     A->device = dev;
-    A->debug = qbh::debug_sw().flags;                                   // timing experiments only
+    A->dbg = qbh::debug_sw();                 // snapshot: the hot paths (every SpMV, every Lanczos step) read the handle's copy, never the environment
+    A->debug = A->dbg.flags;                                            // timing experiments only
     if (qbh::debug_sw().chunk_mult > 0) A->chunk_mult = qbh::debug_sw().chunk_mult;
     if (A->opts.stream) {
         A->stream = (hipStream_t)A->opts.stream;

@@ -52,6 +52,7 @@ int kron_gather_parts(qbh_csr *A, const qbh_comm *comm, int64_t want);
 int finish_reduction(qbh_csr *A, int nparts, int ncomp, double *host_out);
 void harvest_events(qbh_csr *A);
 int next_event_set(qbh_csr *A);
+int deferred_reduction(qbh_csr *A, int nparts);
 int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double gamma, double *red);
 int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double gamma, double *red);
 int enable_real_wire(qbh_csr *A, std::initializer_list<const d2 *> vecs);

@@ -21,7 +21,9 @@ constexpr int kRowCap = 1024;        // row offsets staged in LDS per row block
 
 void set_error(const char *fmt, ...);
 
-// Measurement, tuning and tracing knobs, read ONCE from the single environment variable QBH_DEBUG ("key=value,key=value";
+// Measurement, tuning and tracing knobs from the single environment variable QBH_DEBUG, read when an operator is CREATED (the handle
+// keeps a snapshot, qbh_csr::dbg: nothing on a hot path touches the environment, and a change of the variable in the middle of a
+// solve changes nothing) ("key=value,key=value";
 // a bare integer n means flags=n).  None of them selects a form of the computation a caller could rely on -- those are fields
 // of qbh_opts (include/qbhip.h).  0 / -1 = the library's own choice.
 struct DebugSw {
@@ -280,7 +282,7 @@ int launch_kron_xrows(const int32_t *cnt_x, int64_t nrows, const int64_t *pos, i
 int launch_kron_flags(const int32_t *cnt, int64_t n, int32_t *flag01, hipStream_t s);
 int launch_kron_merge_rows(const KronParts &p, int64_t r0, int64_t r1, int32_t *out_ja, d2 *out_val, int64_t out_base, hipStream_t s);
 int launch_kron_remap_cols(int32_t *ja_f, int64_t n, const KronCols &from, const KronCols &to, hipStream_t s);
-int launch_kron_combine(const d2 *far, const KronTile &t, const d2 *xl, d2 *y, int64_t n, double alpha, double *partials, int *nparts, hipStream_t s);
+int launch_kron_combine(const d2 *far, const KronTile &t, const d2 *xl, d2 *y, int64_t n, double alpha, double *partials, int *nparts, hipStream_t s, const double *coef = nullptr);
 // sparse cross part (nc == 1: the far entries of the rows of the narrow last band): row sums into the far buffer's slots of those rows
 int launch_kron_cross_rows(const int64_t *ia_x, const int32_t *xrow, int64_t n_xrows, const int32_t *ja_x, const d2 *val_x, const d2 *xt,
                            const KronTile &t, d2 *far, hipStream_t s);
@@ -359,7 +361,7 @@ int launch_kron_place(const KronPlace &a, hipStream_t s);
 // tail of a pipelined Lanczos step: |w'|^2 from the axpy's partial sums, a = sc_x * <u, w>, b = sqrt(|w'|^2), the next step's
 // coefficients into state[0..3], {<u,w>, |w'|^2, a, b} into log_slot (host-visible)
 int launch_lanczos_tail(const double *partials, int nparts, const double *dot, double *state, double *log_slot, double sc_x_host, int use_host,
-                        hipStream_t s);
+                        hipStream_t s, const double *sq_ready = nullptr);
 int launch_xpby_tile(const d2 *x, double b, d2 *y, d2 *yt, int64_t n, const KronTile &t, hipStream_t s, int yt_real = 0, int *flag = nullptr);
 int launch_nrm2sq(const d2 *x, int64_t n, double *partials, hipStream_t s);
 int launch_scal(double a, d2 *x, int64_t n, hipStream_t s);
@@ -775,6 +777,7 @@ struct qbh_csr {
     qbh_stats stats{};
     bool      ev_pending = false;
     int       debug = 0;
+    qbh::DebugSw dbg;                // QBH_DEBUG as it was when the handle was made (new_handle): set the variable before creating the operator
     const double *ovr_xr = nullptr;  // all-real operation requested by a driver for the next spmv_run: x and ...
     double       *ovr_yr = nullptr;  // ... y as packed doubles (the complex pointer arguments are ignored)
     bool      defer_red = false;     // spmv_run leaves its three reduced scalars in d_scal[0..2] (no copy, no sync)

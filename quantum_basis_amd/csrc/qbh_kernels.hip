@@ -2235,12 +2235,14 @@ int launch_reduce_partials(const double *partials, int nparts, int ncomp, double
 // arithmetic the host used to do -- a = sc_x * <u, w>, b = sqrt(|w'|^2), sc_new = 1 / b -- and the NEXT step's coefficients
 // (alpha = sc_new, beta = -b * sc_x, axpy scale = -sc_new^2) left in state[] for the kernels of step m + 1, which the host has
 // already enqueued.  The four numbers of this step go to a pinned host slot directly: no copy engine in the stream.
+// sq_ready != nullptr (under a communicator): |w'|^2 has been reduced and all-reduced already (partials unused).
 __global__ __launch_bounds__(1024) void k_lanczos_tail(const double *partials, int nparts, const double *dot, double *state, double *log_slot,
-                                                       double sc_x_host, int use_host)
+                                                       double sc_x_host, int use_host, const double *sq_ready)
 {
     __shared__ double sm[16];
     double v = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += 1024) v += partials[i];
+    if (sq_ready == nullptr)
+        for (int i = threadIdx.x; i < nparts; i += 1024) v += partials[i];
     v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
@@ -2248,6 +2250,7 @@ __global__ __launch_bounds__(1024) void k_lanczos_tail(const double *partials, i
     if (threadIdx.x == 0) {
         double sq = 0.0;
         for (int w = 0; w < 16; ++w) sq += sm[w];
+        if (sq_ready != nullptr) sq = sq_ready[0];
         const double sc_x = use_host ? sc_x_host : state[3];
         const double d = dot[0];
         const double a = sc_x * d;
@@ -2265,9 +2268,9 @@ __global__ __launch_bounds__(1024) void k_lanczos_tail(const double *partials, i
     }
 }
 int launch_lanczos_tail(const double *partials, int nparts, const double *dot, double *state, double *log_slot, double sc_x_host, int use_host,
-                        hipStream_t s)
+                        hipStream_t s, const double *sq_ready)
 {
-    hipLaunchKernelGGL(k_lanczos_tail, dim3(1), dim3(1024), 0, s, partials, nparts, dot, state, log_slot, sc_x_host, use_host);
+    hipLaunchKernelGGL(k_lanczos_tail, dim3(1), dim3(1024), 0, s, partials, nparts, dot, state, log_slot, sc_x_host, use_host, sq_ready);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }

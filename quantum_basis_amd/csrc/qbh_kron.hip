@@ -213,10 +213,12 @@ __global__ __launch_bounds__(kBlock) void k_kron_remap_cols(int32_t *ja_f, int64
 
 // y += alpha * far[tile(row)] and the fused reductions <x, y>, |y|^2 of the finished y: closes an SpMV whose near pass ran first
 // (under a communicator: it only needs the rank's own block of x and overlaps the all-gather)
-__global__ __launch_bounds__(kBlock) void k_kron_combine(const d2 *far, KronTile t, const d2 *xl, d2 *y, int64_t n, double alpha, double *partials)
+// coef != nullptr (pipelined three-term step): alpha is read from the device, as the near pass read it
+__global__ __launch_bounds__(kBlock) void k_kron_combine(const d2 *far, KronTile t, const d2 *xl, d2 *y, int64_t n, double alpha, double *partials, const double *coef)
 {
     __shared__ double red[12];
     double acc[3] = {0.0, 0.0, 0.0};
+    if (coef != nullptr) alpha = coef[0];
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
         const d2 v = y[r] + alpha * far[t.tile(r)];
         y[r] = v;
@@ -404,10 +406,11 @@ int launch_kron_remap_cols(int32_t *ja_f, int64_t n, const KronCols &from, const
     return QBH_OK;
 }
 
-int launch_kron_combine(const d2 *far, const KronTile &t, const d2 *xl, d2 *y, int64_t n, double alpha, double *partials, int *nparts, hipStream_t s)
+int launch_kron_combine(const d2 *far, const KronTile &t, const d2 *xl, d2 *y, int64_t n, double alpha, double *partials, int *nparts, hipStream_t s,
+                        const double *coef)
 {
     const int g = blas_grid(n);
-    hipLaunchKernelGGL(k_kron_combine, dim3(g), dim3(kBlock), 0, s, far, t, xl, y, n, alpha, partials);
+    hipLaunchKernelGGL(k_kron_combine, dim3(g), dim3(kBlock), 0, s, far, t, xl, y, n, alpha, partials, coef);
     QBH_HIP(hipGetLastError());
     if (nparts) *nparts = g;
     return QBH_OK;

@@ -52,9 +52,9 @@ extern "C" int qbh_hess_eigen(const double *hessenberg, int64_t maxit, int64_t m
 // ----------------------------------------------------------------- Lanczos ------
 // ext_rv != nullptr: the caller's vectors ARE packed doubles (two slots of nrows doubles; qbh_lanczos_real_dev) -- the
 // all-real path runs in place, nothing complex is ever allocated.  Otherwise d_v holds the reference's complex slots.
-static void host_delay()
+static void host_delay(const qbh_csr *A)
 {
-    const int us = qbh::debug_sw().host_delay_us;
+    const int us = A->dbg.host_delay_us;
     if (us <= 0) return;
     const double t0 = now_ms();
     while ((now_ms() - t0) * 1e3 < us) { }
@@ -201,7 +201,7 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
             sc[sy] = 1.0 / b[mcur];
             return QBH_OK;
         }
-        const bool no_defer = qbh::debug_sw().no_defer != 0;                   // A/B switch
+        const bool no_defer = A->dbg.no_defer != 0;                   // A/B switch
         if (!A->has_comm && !no_defer) {
             // one GPU: <u, w> stays on the device and feeds the axpy directly; one host synchronisation per step
             A->defer_red = true;
@@ -210,7 +210,7 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
             QBH_TRY(rc1);
             double dot = 0.0;
             QBH_TRY(axpy_norm_deferred(A, -sc[sx] * sc[sx], vpt(mcur - 1), vpt(mcur), &dot, &sq));
-            host_delay();
+            host_delay(A);
             a[mcur - 1] = sc[sx] * dot;
             b[mcur] = std::sqrt(sq);
             sc[sy] = 1.0 / b[mcur];
@@ -219,7 +219,9 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
         QBH_TRY(spmv_run(A, vpt(mcur - 1), vpt(mcur), sc[sx], -bprev * sc[sy], 0.0, red));
         a[mcur - 1] = sc[sx] * red[0];
         // w -= a v_{m-1} ; b = |w|                                                         K5+K6
-        QBH_TRY(axpy_norm_run(A, d2{-a[mcur - 1] * sc[sx], 0.0}, vpt(mcur - 1), vpt(mcur), &sq));
+        // (the coefficient in the association every form of the step uses: (-sc^2) * <u, w> -- the deferred and the pipelined loops
+        // multiply on the device in this order, so a_j, b_j do not depend on which loop ran)
+        QBH_TRY(axpy_norm_run(A, d2{(-sc[sx] * sc[sx]) * red[0], 0.0}, vpt(mcur - 1), vpt(mcur), &sq));
         b[mcur] = std::sqrt(sq);
         sc[sy] = 1.0 / b[mcur];
         return QBH_OK;
@@ -319,9 +321,10 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
     // two numbers, so the Ritz test, the log row and every host-side latency run under the next SpMV.  u_j is written where
     // v_{j-3} was (three buffers in rotation: the caller's two slots and one the handle keeps): a speculative step that the test
     // then rules out -- convergence at :240, breakdown at :216 -- has destroyed nothing and is simply not counted.
-    const bool no_defer_sw = qbh::debug_sw().no_defer != 0;
-    bool pipe = A->opts.lanczos_pipeline != 0 && !A->has_comm && !is_val1 && rv == nullptr && !no_defer_sw && A->kind == 0 &&
-                A->nrows == A->ncols && !A->has_rem && (A->kron.active ? kron_path(A) : true);
+    const bool no_defer_sw = A->dbg.no_defer != 0;
+    // (under a communicator the two sums of a step are all-reduced in stream order between the same launches: still no host)
+    bool pipe = A->opts.lanczos_pipeline != 0 && !is_val1 && rv == nullptr && !no_defer_sw && A->kind == 0 &&
+                (A->has_comm || (A->nrows == A->ncols && !A->has_rem)) && (A->kron.active ? kron_path(A) : true);
     if (pipe) {
         qbh_csr::LzPipe &P = A->lz;
         if (P.cap < n) {
@@ -368,17 +371,26 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
             A->ovr_coef = nullptr;
             QBH_TRY(rc1);
             const double *scale_dev = first ? nullptr : P.d_state + 2;
+            double *ds = scal_buf(A);                      // <u, w> of this step (summed over the ranks), left there by the deferred SpMV
             double *yr = packed_target(A);
             if (d2 *yt = tiled_target(A)) {
-                QBH_TRY(qbh::launch_axpy_norm_tile(d2{-1.0, 0.0}, A->d_scal, x, y, yt, n, A->kron.t, A->d_partials, A->stream, scale_dev, tiled_real(A), A->d_flag));
+                QBH_TRY(qbh::launch_axpy_norm_tile(d2{-1.0, 0.0}, ds, x, y, yt, n, A->kron.t, A->d_partials, A->stream, scale_dev, tiled_real(A), A->d_flag));
                 A->kron.xt_of = y;
                 A->xr_of = nullptr;
             } else {
-                QBH_TRY(qbh::launch_axpy_norm(d2{-1.0, 0.0}, A->d_scal, x, y, n, A->d_partials, yr, A->d_flag, A->stream, scale_dev));
+                QBH_TRY(qbh::launch_axpy_norm(d2{-1.0, 0.0}, ds, x, y, n, A->d_partials, yr, A->d_flag, A->stream, scale_dev));
                 A->xr_of = yr ? y : nullptr;
                 A->kron.xt_of = nullptr;
             }
             const int slot = (int)(j % kLzRing);
+            if (A->has_comm) {                             // |w'|^2: local sum, sum over the ranks, then the scalars -- all in stream order
+                QBH_TRY(qbh::launch_reduce_partials(A->d_partials, qbh::blas_grid(n), 1, ds + 4, A->stream));
+                if (A->comm.allreduce_sum(A->comm.ctx, 4, 1) != 0) {
+                    qbh::set_error("allreduce_sum hook failed");
+                    return QBH_ECOMM;
+                }
+                QBH_TRY(qbh::launch_lanczos_tail(A->d_partials, 0, ds, P.d_state, P.d_log + 4 * slot, 1.0, first ? 1 : 0, A->stream, ds + 4));
+            } else
             QBH_TRY(qbh::launch_lanczos_tail(A->d_partials, qbh::blas_grid(n), A->d_scal, P.d_state, P.d_log + 4 * slot, 1.0, first ? 1 : 0, A->stream));
             QBH_HIP(hipEventRecord(P.ev[slot], A->stream));
             enq = j;
@@ -386,10 +398,10 @@ static int lanczos_core(qbh_csr *A, int64_t k, int64_t np, int64_t maxit, int64_
         };
         // a_{j-1}, b_j of step j; with `speculate` the step after it goes out first
         auto accept = [&](int64_t j, bool speculate) -> int {
-            if (speculate && enq == j && !qbh::debug_sw().pipe_nospec) QBH_TRY(enqueue(j + 1));
+            if (speculate && enq == j && !A->dbg.pipe_nospec) QBH_TRY(enqueue(j + 1));
             const int slot = (int)(j % kLzRing);
             QBH_HIP(hipEventSynchronize(P.ev[slot]));
-            host_delay();
+            host_delay(A);
             const volatile double *L = P.h_log + 4 * slot;
             a[j - 1] = L[2];
             b[j] = L[3];

@@ -58,6 +58,19 @@ static void harvest_set(qbh_csr *A, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2,
 }
 
 // everything that is pending: the sets queued behind the current one (oldest first), then the current one
+// defer_red: the three fused sums stay on the device -- in the scalar buffer the communicator's all-reduce works on, summed
+// over the ranks in stream order (no copy, no synchronisation)
+int deferred_reduction(qbh_csr *A, int nparts)
+{
+    double *ds = scal_buf(A);
+    QBH_TRY(qbh::launch_reduce_partials(A->d_partials, nparts, 3, ds, A->stream));
+    if (A->has_comm && A->comm.allreduce_sum(A->comm.ctx, 0, 3) != 0) {
+        qbh::set_error("allreduce_sum hook failed");
+        return QBH_ECOMM;
+    }
+    return QBH_OK;
+}
+
 void harvest_events(qbh_csr *A)
 {
     for (int i = 0; i < A->n_ev_old; ++i) {
@@ -155,7 +168,7 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
         K.xt_cap = 0;
         QBH_HIP(qbh::dev_alloc(&K.d_xt, (size_t)A->ncols * sizeof(d2)));
         K.xt_cap = A->ncols;
-        if (qbh::debug_sw().print_ptrs) fprintf(stderr, "qbhip kron xt %p x %p y %p\n", (void *)K.d_xt, (const void *)x, (void *)y);
+        if (A->dbg.print_ptrs) fprintf(stderr, "qbhip kron xt %p x %p y %p\n", (void *)K.d_xt, (const void *)x, (void *)y);
         K.xt_of = nullptr;
     }
     // under a communicator: the wire format of this solve (8-byte real parts when the drivers agreed on it), and whether the
@@ -265,10 +278,6 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
     nr.swizzle = kron_swz;
     nr.wctr = A->d_wctr ? A->d_wctr + 256 : nullptr;
     nr.chunk_red = K.d_chunk_red;                            // dynamic walk: the near pass's reduction partials, one slot per chunk
-    if ((A->ovr_yin || A->ovr_coef) && comm) {
-        qbh::set_error("internal: the pipelined three-term step is a one-GPU form");
-        return QBH_EUNSUPP;
-    }
     nr.yin = A->ovr_yin;                                     // pipelined three-term step (lanczos_core): out of place, coefficients on the device
     nr.coef = A->ovr_coef;
     nr.coef_mode = A->ovr_coef ? 1 : 0;
@@ -394,7 +403,7 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
             QBH_TRY(qbh::launch_spmv_wave2(f, K.tpr_f, K.sliced ? 3 : 0, K.grid_f, s));
         }
         QBH_TRY(qbh::launch_kron_cross_rows(K.ia_x, K.xrow, K.n_xrows, K.ja_x, K.val_x, xt, K.t, K.d_far, s));
-        QBH_TRY(qbh::launch_kron_combine(K.d_far, K.t, xl, y, A->nrows, alpha, red ? A->d_partials : nullptr, &nparts, s));
+        QBH_TRY(qbh::launch_kron_combine(K.d_far, K.t, xl, y, A->nrows, alpha, red ? A->d_partials : nullptr, &nparts, s, A->ovr_coef));
         if (prof) {
             QBH_HIP(hipEventRecord(A->ev3, s));
             A->ev_pending2 = true;
@@ -403,7 +412,7 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
     A->xr_of = nullptr;
     A->stats.n_spmv++;
     if (red && A->defer_red) {
-        QBH_TRY(qbh::launch_reduce_partials(A->d_partials, nparts, 3, A->d_scal, s));
+        QBH_TRY(deferred_reduction(A, nparts));
     } else if (red) {
         QBH_TRY(finish_reduction(A, nparts, 3, red));
         if (prof) harvest_events(A);
@@ -418,8 +427,8 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         return QBH_EINVAL;
     }
     if (A->kron.active) return spmv_kron(A, x, y, alpha, beta, gamma, red);
-    if ((A->ovr_yin || A->ovr_coef) && (A->has_comm || A->kind != 0 || A->ovr_yr != nullptr || A->real_mode)) {
-        qbh::set_error("internal: the pipelined three-term step needs a stored complex operator on one GPU");
+    if ((A->ovr_yin || A->ovr_coef) && (A->kind != 0 || A->ovr_yr != nullptr)) {
+        qbh::set_error("internal: the pipelined three-term step needs a stored operator and complex vectors");
         return QBH_EUNSUPP;
     }
     const d2 *xg, *xl;
@@ -520,7 +529,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
             ms.tile = A->mfsec->tile;
             // items drawn from per-XCD counters: the orbit-order kernel by default (its workgroups finish far apart under a
             // static assignment: 87 -> 61 ms on 4x5 with 8+8), the rank-table kernel only on request (it got slower: 223 -> 233 ms)
-            const int sec_walk = qbh::debug_sw().sec_walk < 0 ? (ms.orbit ? 1 : 0) : qbh::debug_sw().sec_walk;
+            const int sec_walk = A->dbg.sec_walk < 0 ? (ms.orbit ? 1 : 0) : A->dbg.sec_walk;
             if (sec_walk) {
                 if (!A->d_wctr) QBH_HIP(qbh::dev_alloc(&A->d_wctr, qbh::kWctrRegions * 128 * sizeof(unsigned long long)));
                 QBH_HIP(hipMemsetAsync(A->d_wctr, 0, 3 * 128 * sizeof(unsigned long long), A->stream));
@@ -553,7 +562,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         A->stats.n_spmv++;
         if (realm) A->stats.n_spmv_real++;
         if (red && A->defer_red) {
-            QBH_TRY(qbh::launch_reduce_partials(A->d_partials, mf_parts, 3, A->d_scal, A->stream));
+            QBH_TRY(deferred_reduction(A, mf_parts));
         } else if (red) {
             QBH_TRY(finish_reduction(A, mf_parts, 3, red));
             if (profm) harvest_events(A);
@@ -596,7 +605,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     a.unroll = A->unroll;
     a.colmask = (A->debug & 1) ? 1023 : -1;
     if (A->debug & 1) {
-        if (qbh::debug_sw().colmask) a.colmask = qbh::debug_sw().colmask;    // gather-window experiments (results wrong by design)
+        if (A->dbg.colmask) a.colmask = A->dbg.colmask;    // gather-window experiments (results wrong by design)
     }
     const bool prof = A->opts.profile != 0;
     if (async_gather && !A->has_rem) {          // nothing to overlap with: the single part needs the gathered x
@@ -628,7 +637,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         // coded Kronecker split, all-real operation: tiled copy of the packed x, near launch (full epilogue), far launch
         // (tiled rows and columns, accumulates at orig(row), fused reductions of the finished y)
         qbh_csr::KronCoded &K = A->kronc;
-        if (K.sl.active && K.table_route && qbh::debug_sw().mf_row != 0) {      // (mf_row=0: the debug switch that turns the row-staged kernel off)
+        if (K.sl.active && K.table_route && A->dbg.mf_row != 0) {      // (mf_row=0: the debug switch that turns the row-staged kernel off)
             // T (x) 1 + 1 (x) T' + D recognised: the row-staged table kernel applies it from T, T' and one diagonal code per row --
             // no tiled copy, no far sums: x read (+ its neighbour rows through the caches), old y read, y written
             qbh::MfArgs m{};
@@ -689,7 +698,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         a.n_wb = A->n_wb;
         a.swizzle = wave_swz;
         a.wctr = A->d_wctr;
-        const int pipe = qbh::debug_sw().wave_pipelined;    // experiment: the pipelined kernel on an unsplit operator
+        const int pipe = A->dbg.wave_pipelined;    // experiment: the pipelined kernel on an unsplit operator
         if (pipe && A->wtpr <= 8) {
             int ncu = 256;
             hipDeviceProp_t prop;
@@ -756,7 +765,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     A->stats.n_spmv++;
     if (realm) A->stats.n_spmv_real++;
     if (red && A->defer_red) {
-        QBH_TRY(qbh::launch_reduce_partials(A->d_partials, grid_last, 3, A->d_scal, A->stream));
+        QBH_TRY(deferred_reduction(A, grid_last));
     } else if (red) {
         QBH_TRY(finish_reduction(A, grid_last, 3, red));
         if (prof) harvest_events(A);

@@ -8,6 +8,7 @@
 //                    shard split in place, the ranks exchange the tiled copies of their blocks
 //        parts=K     qbh_opts.gather_parts;  unsplit=R  rank R keeps its shard unsplit (the ranks must fall back together)
 //        plain=1     complex128 values and vectors (value_dict = 0, real_fast_path = 0)
+//        pipeline=0  qbh_opts.lanczos_pipeline = 0 (one host synchronisation per Lanczos step)
 //        realwire=0  qbh_opts.real_wire = 0 (split shards: 16-byte elements on the links even for a real solve)
 //        ckpt=DIR every=K maxsteps=N   the Lanczos run through qbh_lanczos_ckpt (collective: every rank checkpoints its slice in
 //                    DIR/shard<r>of<P>/), stopped after N new steps when N > 0; then only the Lanczos part is dumped
@@ -62,7 +63,7 @@ int main(int argc, char **argv)
     std::vector<int64_t> cuts(nranks + 1);
     bool uniform = false;
     int64_t kron = 0;
-    int parts = 0, unsplit = -1, plain = 0, realwire = 1;
+    int parts = 0, unsplit = -1, plain = 0, realwire = 1, pipeline = 1;
     std::string dump, ckdir;
     long long every = 10, maxsteps = 0;
     for (int i = 5; i < argc; ++i) {
@@ -73,6 +74,7 @@ int main(int argc, char **argv)
         else if (a.rfind("unsplit=", 0) == 0) unsplit = std::atoi(a.c_str() + 8);
         else if (a.rfind("plain=", 0) == 0) plain = std::atoi(a.c_str() + 6);
         else if (a.rfind("realwire=", 0) == 0) realwire = std::atoi(a.c_str() + 9);
+        else if (a.rfind("pipeline=", 0) == 0) pipeline = std::atoi(a.c_str() + 9);
         else if (a.rfind("ckpt=", 0) == 0) ckdir = a.substr(5);
         else if (a.rfind("every=", 0) == 0) every = std::atoll(a.c_str() + 6);
         else if (a.rfind("maxsteps=", 0) == 0) maxsteps = std::atoll(a.c_str() + 9);
@@ -98,6 +100,7 @@ int main(int argc, char **argv)
     }
     opts.gather_parts = parts;
     opts.real_wire = realwire;
+    opts.lanczos_pipeline = pipeline;
     qbh_csr *A = nullptr;
     must(qbh_csr_create_rows(&A, dim, nnz, (int)sym, ia.data(), ja.data(), reinterpret_cast<const qbh_z *>(val.data()), cuts[rank],
                              cuts[rank + 1], &opts), "qbh_csr_create_rows");

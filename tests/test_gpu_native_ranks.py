@@ -156,6 +156,20 @@ def test_bench_two_ranks_on_one_gpu_through_the_native_communicator(rig):
 
 
 @pytest.mark.parametrize("kron", [0, 1])
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_pipelined_lanczos_loop_under_a_communicator_is_the_unpipelined_one(rig, nranks, kron):
+    """qbh_opts.lanczos_pipeline under a communicator: <u, w> and |w'|^2 are all-reduced in stream order between the same launches
+    and step m + 1 goes out before step m has been read back; m, a_j, b_j on every rank are bit for bit those of the loop that
+    synchronises with the host twice per step (the stand-in sums in rank order, as every deterministic all-reduce does)."""
+    extra = ["plain=1"] + (["kron=%d" % S_MINOR, "parts=4"] if kron else [])
+    p1 = _run(rig, nranks, extra + ["pipeline=1"], "pl1_%d_%d" % (nranks, kron))
+    p0 = _run(rig, nranks, extra + ["pipeline=0"], "pl0_%d_%d" % (nranks, kron))
+    for a, b in zip(p1, p0):
+        assert a["m"] == b["m"] and np.array_equal(a["a"], b["a"]) and np.array_equal(a["b"], b["b"]) and a["E0"] == b["E0"]
+    _check(rig, p1, _reference(rig, True), nranks)
+
+
+@pytest.mark.parametrize("kron", [0, 1])
 def test_sharded_lanczos_run_interrupted_and_resumed_from_rank_checkpoints(rig, kron):
     """qbh_lanczos_ckpt on row shards (collective): two ranks, stopped after 20 steps -- every rank's slice sits in
     <dir>/shard<r>of2/ under the reference's own file names (src/ckpt.cc:178-297) with shard-local lengths -- then two NEW
