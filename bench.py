@@ -559,9 +559,9 @@ def main():
                     help="with --order reference / --host-csr: do NOT tell the library what the reference-ordered index means (qbh_opts.basis_kind); "
                          "default is to name the basis, so the operator is held species-major internally and the Kronecker split applies")
     ap.add_argument("--site-cut", type=int, default=0,
-                    help="heisenberg (single-species) workloads, complex128 format: tell the library the basis (qbh_opts.basis_kind = "
-                         "QBH_BASIS_SPIN_SECTOR) and cut the sites into this many LOW sites and the rest: the operator is held class-major "
-                         "internally and split into near (low-half bonds) / far (high-half bonds) / cross parts")
+                    help="heisenberg (single-species) workloads, complex128 format (qbh_opts.sector_cut): the sites are cut into this many LOW "
+                         "sites and the rest, the operator is held class-major internally and split into near (low-half bonds) / far (high-half "
+                         "bonds) / cross parts; 0 (default) = the library picks the cut, -1 = never (rows in ascending pattern order)")
     ap.add_argument("--cols16", type=int, default=1, help="qbh_opts.kron_cols16: 1 (library default) the parts of a split operator keep 2-byte columns, 0 int32 columns")
     ap.add_argument("--deterministic", action="store_true", help="qbh_opts.deterministic: static walks, nothing timed at creation (bit-identical a_j / b_j from run to run)")
     ap.add_argument("--no-pipeline", action="store_true", help="qbh_opts.lanczos_pipeline = 0: one host synchronisation per Lanczos step (the loop of ABI <= 501), for A/B runs")
@@ -762,8 +762,7 @@ def main():
                            nnz_per_block=args.npb, xcd_swizzle=args.swizzle,
                            value_dict=value_dict, real_fast_path=real_fp, profile=1, deterministic=1 if args.deterministic else 0,
                            kron_cols16=args.cols16, lanczos_pipeline=0 if args.no_pipeline else 1)
-        if args.site_cut and W["kind"] == "heisenberg" and world == 1 and value_dict == 0:
-            opts.basis_kind, opts.n_sites, opts.n_up, opts.n_dn = q._lib.BASIS_SPIN_SECTOR, W["n_sites"], args.site_cut, W["n_dn"]
+        opts.sector_cut = args.site_cut if world == 1 else -1          # qbh_opts.sector_cut: 0 = the library picks the cut of a heisenberg sector, -1 never
         t_gen = time.time()
         hint = (not args.no_basis_hint) and W["kind"] == "hubbard" and world == 1 and value_dict == 0
         if args.host_csr:
@@ -854,7 +853,7 @@ def main():
     code_w = 0 if not coded else (1 if info.value_dict <= 256 else 2)
     tkey = "%s|%s|%s" % (args.workload, KERNEL_KEY[info.kernel], "dict" if coded else "plain") + ("|real" if real_used else "")
     if info.kron_minor:
-        tkey += ("|kron_sliced" if info.kron_sliced else "|kron") + ("|inplace" if info.kron_inplace else "") + ("|cut%d" % args.site_cut if info.kron_classes > 1 else "")
+        tkey += ("|kron_sliced" if info.kron_sliced else "|kron") + ("|inplace" if info.kron_inplace else "") + ("|cut%d" % int(info.basis_n_up) if info.kron_classes > 1 else "")
         tkey += "|c16" if info.kron_cols16 == 3 else ""           # 2-byte columns in both parts: another stream, another traffic entry
         tkey += "|table" if info.kron_table_kernel else ""        # the table route moves other bytes than the sliced passes
     tkey += "|reforder" if args.order == "reference" else ""
@@ -898,7 +897,7 @@ def main():
                                                         if info.kron_minor else None),
                                          "basis_internal": ({1: "species-major (index = up * C(n, n_dn) + down), vectors translated at the seams",
                                                              2: "class-major cut sector (%d low sites, %d classes, cross part %d nonzeros), vectors translated at the seams"
-                                                                % (args.site_cut, info.kron_classes, info.kron_cross_nnz),
+                                                                % (int(info.basis_n_up), info.kron_classes, info.kron_cross_nnz),
                                                              3: "the rows of every down block orbit by orbit of the up patterns (qbh_opts.sector_orbit); vectors translated at the seams"}
                                                             .get(info.basis_internal)),
                                          "operator_source": "host CSR in reference order through qbh_csr_create" if args.host_csr else

@@ -188,6 +188,16 @@ typedef struct qbh_opts {
                                 when they are moved to their place in the tiled x -- half the bytes on the links, the same
                                 numbers in the SpMV.  Independent of real_fast_path (which selects the real FORMS of the unsplit
                                 kernels).  0: 16-byte elements                                                             */
+    int     sector_cut;      /* [0] qbh_gen_heisenberg, whole operator, complex128 values (value_dict = 0, real_fast_path = 0), large enough
+                                for the split (kron_split = 1: >= 1e8 nonzeros; 2: any) and no basis_kind named: the sites are cut into
+                                h LOW sites and the rest, the operator is held class-major (class = particles among the high sites) and
+                                split into near (bonds inside the low sites) / far (inside the high sites) / cross parts -- the form
+                                of QBH_BASIS_SPIN_SECTOR (qbh_csr_info.basis_internal = 2; host vectors are translated at the seams,
+                                device vectors by qbh_vec_to_internal / _from_internal).  0: the library picks h -- the feasible cut
+                                (both parts at least max(4, n_sites / 4) sites, every class's band of x inside an XCD's L2, every
+                                near window inside it too) with the fewest bonds
+                                across it, the one nearest n_sites / 2 among equals; nothing feasible: the operator stays as generated.
+                                > 0: that h.  -1: never (the rows stay in ascending pattern order, the form of ABI <= 501)      */
 } qbh_opts;
 
 void qbh_opts_default(qbh_opts *o);

@@ -183,6 +183,7 @@ void qbh::opts_builtin(qbh_opts *o)
     o->sector_orbit = 1;
     o->lanczos_pipeline = 1;
     o->real_wire = 1;
+    o->sector_cut = 0;
     o->kron_minor = 0;
     o->deterministic = 0;
     o->basis_kind = QBH_BASIS_NONE;

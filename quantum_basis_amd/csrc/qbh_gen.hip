@@ -601,6 +601,41 @@ extern "C" int qbh_gen_heisenberg(qbh_csr **out, int n_sites, int n_dn, int n_bo
     // ownership passes with the call: on failure the arrays have already been released
     qbh_opts og;                                       // generated rows are in the generator's own order: nothing to look for
     opts_generated(opts, &og);
+    // qbh_opts.sector_cut: a whole complex128 operator large enough for the split is held as a CUT sector (class-major, near / far /
+    // cross parts) unless the caller named a basis or said -1.  The cut: h low sites such that every class fits the kernels' windows
+    // (the limits basis_to_internal checks) with the fewest bonds across it -- those entries are the ones that stay unstructured.
+    if (og.basis_kind == QBH_BASIS_NONE && og.sector_cut >= 0 && row_begin == 0 && row_end == dim && og.value_dict == 0 && og.real_fast_path == 0 &&
+        og.kron_split != 0 && (og.kron_split == 2 || nnz >= 100000000) && n_sites <= 31) {
+        int h = og.sector_cut;
+        if (h == 0) {
+            int best = -1, best_cross = 1 << 30;
+            const int part_min = std::max(4, n_sites / 4);           // both parts of a cut hold a quarter of the sites at least
+            for (int c = part_min; c <= n_sites - part_min; ++c) {
+                if (n_sites - c > 24) continue;
+                const int p_min = std::max(0, n_dn - c), p_max = std::min(n_sites - c, n_dn);
+                if (p_max <= p_min || p_max - p_min + 1 > kKronMaxClasses) continue;
+                bool ok = true;
+                for (int p = p_min; p <= p_max && ok; ++p) {
+                    ok = (double)binom_u64(n_sites - c, p) * 128.0 <= 2.5e6          // a band of the class's x inside an XCD's L2
+                         && (double)binom_u64(c, n_dn - p) * 16.0 <= 4.0e6;         // ... and the window of x a block of the class gathers its near entries from
+                }
+                if (!ok) continue;
+                int cross = 0;
+                for (const auto &bw : bmap) cross += (bw.first.first < c) != (bw.first.second < c) ? 1 : 0;
+                if (cross < best_cross || (cross == best_cross && std::abs(2 * c - n_sites) < std::abs(2 * best - n_sites))) {
+                    best = c;
+                    best_cross = cross;
+                }
+            }
+            h = best;
+        }
+        if (h > 0) {
+            og.basis_kind = QBH_BASIS_SPIN_SECTOR;
+            og.n_sites = n_sites;
+            og.n_up = h;
+            og.n_dn = n_dn;
+        }
+    }
     return qbh_csr_create_device(out, nrows, dim, row_begin, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, &og);
 }
 

@@ -799,6 +799,14 @@ def measure_full_static_spin_dev(mat, n_sites, n_dn, d_phi, ops):
     import math
     cur_n, src, bufs = n_dn, d_phi, []
     try:
+        if mat.info().basis_internal != 0:
+            # the handle keeps its device vectors in another order than the generators' (a cut sector, a named / detected basis):
+            # the mopr helpers work in the generators' order, so phi is translated first (qbh_vec_from_internal)
+            conv = mat.vec(1)
+            bufs.append(conv)
+            mat.from_internal(conv.ptr, d_phi)
+            mat.sync()
+            d_phi = src = conv.ptr
         for kind, coef in reversed(list(ops)):
             new_n = cur_n - kind
             dst = DeviceVec(mat, math.comb(n_sites, new_n))
@@ -821,7 +829,17 @@ def measure_full_dynamic_dev(mat_new, apply_mopr, maxit):
     dim = mat_new.dim
     v = mat_new.vec(2)
     try:
-        apply_mopr(v.at(0))
+        if mat_new.info().basis_internal != 0:          # apply_mopr writes in the generators' order: translated into the handle's
+            tmp = mat_new.vec(1)
+            try:
+                apply_mopr(tmp.ptr)
+                mat_new.sync()
+                mat_new.to_internal(v.at(0), tmp.ptr)
+                mat_new.sync()
+            finally:
+                tmp.free()
+        else:
+            apply_mopr(v.at(0))
         norm = mat_new.nrm2(v.at(0))                               # sqrt(<phi| Aq^+ Aq |phi>)
         hessenberg = np.zeros(2 * maxit)
         if abs(norm) < lanczos_precision:

@@ -117,3 +117,54 @@ def test_cut_sector_under_a_communicator_is_merged_back_and_stays_right(cross_in
     assert np.abs(O.multmv(rk.eigenvecs) - rk.E0 * rk.eigenvecs).max() < 1e-7
     K.destroy()
     P.destroy()
+
+
+def _auto_cut(n, k, bonds):
+    """the rule of qbh_opts.sector_cut = 0 (qbh_gen_heisenberg): feasible cut with the fewest bonds across it, nearest n / 2 among equals"""
+    import math
+    best, best_cross = -1, 1 << 30
+    part_min = max(4, n // 4)
+    for c in range(part_min, n - part_min + 1):
+        if n - c > 24:
+            continue
+        p_min, p_max = max(0, k - c), min(n - c, k)
+        if p_max <= p_min or p_max - p_min + 1 > 24:
+            continue
+        if any(math.comb(n - c, p) * 128.0 > 2.5e6 or math.comb(c, k - p) * 16.0 > 4.0e6 for p in range(p_min, p_max + 1)):
+            continue
+        cross = sum((min(a, b) < c) != (max(a, b) < c) for a, b in bonds)
+        if cross < best_cross or (cross == best_cross and abs(2 * c - n) < abs(2 * best - n)):
+            best, best_cross = c, cross
+    return best
+
+
+@pytest.mark.parametrize("name", ["kagome18", "chain18_n7", "triangular16"])
+def test_the_generator_picks_the_cut_by_itself(name):
+    """qbh_opts.sector_cut = 0 (default): a whole complex128 Heisenberg sector large enough for the split (kron_split = 2 here: any size;
+    1: from 1e8 nonzeros, where kagome-30 picks h = 18) is held as a cut sector without the caller naming a basis; -1 keeps the rows in
+    ascending pattern order; > 0 names the cut.  Host vectors are the caller's in every case (translated at the seams)."""
+    n, k, bonds = CASES[name]
+    bl = [tuple(b) for b in np.asarray(bonds).reshape(-1, 2)]
+    P = q.csr_mat.heisenberg(n, k, bonds, J=1.0, opts=q.make_opts(kron_split=2, sector_cut=-1, **PLAIN))
+    assert P.info().basis_internal == 0
+    K = q.csr_mat.heisenberg(n, k, bonds, J=1.0, opts=q.make_opts(kron_split=2, **PLAIN))
+    ik = K.info()
+    h = _auto_cut(n, k, bl)
+    assert h > 0 and ik.basis_internal == _lib.BASIS_SPIN_SECTOR and ik.basis_n_up == h and ik.basis_n_sites == n and ik.basis_n_dn == k
+    E = q.csr_mat.heisenberg(n, k, bonds, J=1.0, opts=q.make_opts(kron_split=2, sector_cut=h - 1, **PLAIN))
+    assert E.info().basis_n_up == h - 1
+    x = _rand(P.dim, 3)
+    ys = []
+    for A in (P, K, E):
+        y = np.empty(P.dim, dtype=np.complex128)
+        A.MultMv(x, y)
+        ys.append(y)
+    scale = np.abs(ys[0]).max()
+    assert np.abs(ys[1] - ys[0]).max() <= 2e-13 * scale and np.abs(ys[2] - ys[0]).max() <= 2e-13 * scale
+    rk, rp = q.locate_E0_lanczos(K), q.locate_E0_lanczos(P)
+    assert abs(rk.E0 - rp.E0) <= 1e-11 * abs(rp.E0) and abs(abs(np.vdot(rk.eigenvecs, rp.eigenvecs)) - 1.0) < 1e-8
+    # the default format (coded values, real fast path) is not touched by the option
+    D = q.csr_mat.heisenberg(n, k, bonds, J=1.0, opts=q.make_opts(kron_split=2))
+    assert D.info().basis_internal == 0
+    for A in (P, K, E, D):
+        A.destroy()
