@@ -170,8 +170,8 @@ def coded_format_roofline(info, ms_spmv, code_w, coded, real_used, traffic, tsrc
                     "by its time -- speed-ups over a CSR sweep, not roofline fractions"
                     + ("; the table kernel re-reads the ~17 neighbour rows of every up-configuration from HBM (traffic_ratio says how often): on "
                        "its ACTUAL traffic it runs close to the fabric ceiling (C3: 31.8 GB in 4.7 ms = 6.8 TB/s), so its lever is reuse of those "
-                       "rows, not a faster pass (DESIGN 5.0d item 5)" if table else
-                       "; the two passes are bound by L2 line requests and LDS gathers, not by HBM bandwidth (DESIGN 4.1g)" if kronc else "")}
+                       "rows, not a faster pass (DESIGN-history 5.0d item 5)" if table else
+                       "; the two passes are bound by L2 line requests and LDS gathers, not by HBM bandwidth (DESIGN-history 4.1g)" if kronc else "")}
 
 
 def dim_of(w):
@@ -579,7 +579,7 @@ def main():
                     help="N = 1 only: the headline (W warm-up + exactly K timed steps on a freshly created operator) is measured in this many "
                          "FRESH child processes, started one after the other before this process touches the GPU; the line reports min / "
                          "median / max and the headline value / roofline.frac are the MEDIAN process's (physical placement differs from "
-                         "process to process: DESIGN 5.0c).  1: this process only")
+                         "process to process: DESIGN-history 5.0c).  1: this process only")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-locate", action="store_true", help="skip the timing of the user call locate_E0_lanczos(nev=1, ncv=1) = Lanczos + CG eigenvector")
     args = ap.parse_args()

@@ -593,7 +593,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rows(SpmvArgs a)
 // flight together; the products go to a wave-private 8 KB LDS tile and TPR lanes per row sum them, shuffle-reduce
 // and run the fused epilogue.  Against the workgroup-granular kernels above this keeps 16 independent load / gather
 // / reduce pipelines per CU instead of 3 lock-stepped ones, which is what the cache-friendly operators were limited
-// by: chain L = 26 goes from 1.06 to 0.72 ms.  Descriptors (first row / first nonzero of the
+// by (DESIGN-history 5.0 item 4): chain L = 26 goes from 1.06 to 0.72 ms.  Descriptors (first row / first nonzero of the
 // block and of the next one) are fetched one block ahead.
 // Complex128 values, complex vectors only: the coded / real-gather formats stay on k_spmv_rows.
 __device__ __forceinline__ void wave_lds_fence()
@@ -827,7 +827,7 @@ int launch_build_wavedesc(const int64_t *d_ia, int64_t nrows, int64_t window, Wa
 //        the same entry number: every gather instruction reads full 128-byte lines of the tiled x.  ia holds the group
 //        pointers, the descriptor's row fields count groups.
 // OPS 2: fused epilogue, the far result of the row added first (read at the row's tiled index)
-// wavefronts per SIMD of the near pass: 2 = 204 VGPRs, no spill; 3 = 168 VGPRs with 17 spilled (measured: see DESIGN 4.1c)
+// wavefronts per SIMD of the near pass: 2 = 204 VGPRs, no spill; 3 = 168 VGPRs with 17 spilled (measured: see DESIGN-history 4.1c)
 #ifndef QBH_NEAR_WAVES
 #define QBH_NEAR_WAVES 2
 #endif
@@ -840,7 +840,7 @@ int launch_build_wavedesc(const int64_t *d_ia, int64_t nrows, int64_t window, Wa
 #define QBH_ROW_STORE(p, v) (*(p) = (v))
 #endif
 // C16: the part's columns are 2 bytes each (a.ja16), relative to a base named by the block's descriptor (SpmvArgs::ja16): 8 lines
-// of column stream per block instead of 16 -- the passes are bound by line requests, not bytes
+// of column stream per block instead of 16 -- the passes are bound by line requests, not bytes (DESIGN-history 5.0b)
 template <int TPR, int OPS, bool DYN, bool C16 = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((OPS == 0 || OPS == 3) ? QBH_FAR_WAVES : QBH_NEAR_WAVES, (OPS == 0 || OPS == 3) ? QBH_FAR_WAVES : QBH_NEAR_WAVES))) void k_spmv_wave2(SpmvArgs a)
 {

@@ -13,7 +13,7 @@
 //     C3 -- is loaded into LDS once per major index and every gather is an LDS read.
 // Far pass first (row sums into a buffer in group order), then the near pass with the fused epilogue
 // y = alpha (near + far) + beta y + gamma x and the reductions <x, y>, |y|^2 of the finished y.
-// The row kernel this replaces is bound by the RATE of 8-byte gathers through the L1 (420-490 G/s); here no
+// The row kernel this replaces is bound by the RATE of 8-byte gathers through the L1 (DESIGN-history 5.0b item 10: 420-490 G/s); here no
 // gather is an L1 request of its own.  Two recognitions, each verified entry by entry on the device: a far part whose entries do not
 // depend on the row's minor index (T (x) 1) is kept as T alone, a near part whose off-diagonal entries do not depend on the row's
 // major index (1 (x) T' + D) as T' and one diagonal code per row -- the two-species models are both, and their passes then stream

@@ -130,7 +130,7 @@ int kron_geometry(qbh_csr *A)
 }
 
 // 2-byte columns for the parts of a one-class split (qbh_opts.kron_cols16).  The two passes are bound by the rate of line
-// requests, not by bytes: the column stream is 16 of a block's ~150 lines as int32 and 8 as uint16.
+// requests, not by bytes (DESIGN-history 5.0b): the column stream is 16 of a block's ~150 lines as int32 and 8 as uint16.
 //   near part: column - (first column of the shard + pad * S), pad = major index of the block's first row (a block of whole rows
 //              with <= 512 entries reaches into the next major index at most: values < 2 S);
 //   far part (sliced): target major index + (band - band of the block's first group) * NUg (NUg = major indices of the WHOLE
@@ -688,10 +688,10 @@ int kronc_build_sliced(qbh_csr *A, int64_t S, int64_t NU)
 }
 
 // An operator RECOGNISED as T (x) 1 + 1 (x) T' + D needs no stored matrix at all: T and T' are the two hop tables of the
-// row-staged table kernel (k_mf_hubbard_row, DESIGN 4.6: one workgroup holds the row X[u][:] in LDS, T' gathers from LDS, T is
+// row-staged table kernel (k_mf_hubbard_row, DESIGN-history 4.6: one workgroup holds the row X[u][:] in LDS, T' gathers from LDS, T is
 // ~17 coalesced row AXPYs), D one value code per row.  That kernel reads x once more than it must and writes y once -- three
 // vector passes against the seven of the sliced split (tiled copy written + read, far sums written + read) -- and is the faster
-// of the two wherever both apply (C3: 4.65 against 6.9 ms per SpMV).  The tables are decoded on the host from the
+// of the two wherever both apply (C3: 4.65 against 6.9 ms per SpMV, DESIGN-history 5.0d).  The tables are decoded on the host from the
 // sliced structures (lane-major layouts of k_kronc_t_fill / k_kronc_s_fill) -- a few hundred KB -- and re-packed as ELL / packed
 // words.  Not taken when the amplitudes do not fit the kernel's 15 codes, the rows its widths, or S its 24-bit targets.
 int kronc_table_route(qbh_csr *A)
@@ -795,7 +795,7 @@ int kronc_table_route(qbh_csr *A)
 // Same decomposition as kron_build, for the row kernel: the near part keeps rows and columns, the far part has rows AND
 // columns in the tiled order of KronTile with B = 16 (one 128-byte line of doubles per major index and band); the far
 // launch gathers from the tiled copy of the packed x and accumulates onto the near launch's result at orig(row).
-// Measured slower than the unsplit operator; QBH_KRON_CODED=1 builds it for comparison.
+// Measured slower than the unsplit operator (DESIGN-history 5.0b item 10); QBH_KRON_CODED=1 builds it for comparison.
 int kronc_build(qbh_csr *A)
 {
     kronc_release(A);
