@@ -274,6 +274,8 @@ typedef struct qbh_csr_info {
     int     kron_table_kernel;               /* 1: the coded split was recognised as T (x) 1 + 1 (x) T' + D and the all-real SpMV runs the table kernel */
     int     wire_element_bytes;              /* communicator attached: bytes per element of x the LAST gather put on the links -- 16 (complex128) or 8
                                                 (real parts only: qbh_opts.real_wire on split shards, the real fast path on plain ones); 0 before the first */
+    double  gather_needed_frac;              /* split shard under a communicator: the share of its peers' major indices that its far / cross entries read
+                                                (only those are moved into the tiled x; a sparse exchange would carry this share of the all-gather); else 1 */
 } qbh_csr_info;
 int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info);
 

@@ -52,7 +52,7 @@ class CsrInfo(C.Structure):
                 ("kron_inplace", C.c_int), ("tuned", C.c_int), ("tune_ms_rows", C.c_double), ("tune_ms_wave", C.c_double),
                 ("basis_internal", C.c_int), ("kron_classes", C.c_int), ("kron_cross_nnz", C.c_int64), ("gather_parts", C.c_int),
                 ("kron_cols16", C.c_int), ("basis_detected", C.c_int), ("basis_n_sites", C.c_int), ("basis_n_up", C.c_int),
-                ("basis_n_dn", C.c_int), ("basis_detect_ms", C.c_double), ("kron_table_kernel", C.c_int), ("wire_element_bytes", C.c_int)]
+                ("basis_n_dn", C.c_int), ("basis_detect_ms", C.c_double), ("kron_table_kernel", C.c_int), ("wire_element_bytes", C.c_int), ("gather_needed_frac", C.c_double)]
 
 
 class LanczosRow(C.Structure):

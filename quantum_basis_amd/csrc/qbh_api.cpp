@@ -1016,6 +1016,7 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->kron_cols16 = 0;
     info->kron_cross_nnz = 0;
     info->wire_element_bytes = A->has_comm ? A->wire_bytes_last : 0;
+    info->gather_needed_frac = (A->has_comm && A->kron.active && A->kron.comm_tiled) ? A->kron.need_frac : 1.0;
     info->gather_parts = A->has_comm ? ((A->kron.active && A->kron.comm_tiled) ? A->kron.n_parts : 1) : 0;
     if (A->kron.active) {
         const qbh_csr::KronSplit &K = A->kron;

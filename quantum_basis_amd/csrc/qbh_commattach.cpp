@@ -46,6 +46,7 @@ int kron_gather_parts(qbh_csr *A, const qbh_comm *comm, int64_t want)
     int64_t band[9];
     for (int64_t k = 0; k <= want; ++k) band[k] = k * nfb / want;
     K.part_blk[0] = 0;
+    for (int64_t k = 0; k <= want; ++k) K.part_band[k] = band[k];
     for (int64_t k = 1; k < want; ++k) {                     // first slot of the range's first group -> the block that holds it
         int64_t slot = 0;
         QBH_HIP(hipMemcpy(&slot, K.ia_f + band[k] * K.t.NU, sizeof(int64_t), hipMemcpyDeviceToHost));
@@ -65,6 +66,51 @@ int kron_gather_parts(qbh_csr *A, const qbh_comm *comm, int64_t want)
     return QBH_OK;
 }
 
+// Which major indices of its peers does this shard read?  The far part of a shard gathers, for each of its own major indices,
+// the hop targets of that up configuration: a subset of the gathered x (C3, 8 ranks in the generator's order: 42-68 %,
+// tools/needed_columns.py).  Only those are moved into the tiled x (k_kron_place with a list): the rest of every block
+// arrives and is never touched.  need_frac = what a sparse exchange would still have to carry.
+int kron_needed_majors(qbh_csr *A, int nranks)
+{
+    qbh_csr::KronSplit &K = A->kron;
+    if (K.d_need) (void)hipFree(K.d_need);
+    K.d_need = nullptr;
+    K.need_frac = 1.0;
+    const int64_t NUg = K.NUg;
+    uint8_t *d_bits = nullptr;
+    QBH_HIP(qbh::dev_alloc(&d_bits, (size_t)NUg));
+    std::vector<uint8_t> bits((size_t)NUg, 0);
+    int rc = QBH_OK;
+    hipError_t e = hipMemsetAsync(d_bits, 0, (size_t)NUg, A->stream);
+    if (e == hipSuccess) rc = qbh::launch_kron_need(K.c16_f, K.c16_f ? nullptr : K.ja_f, K.far_slots, K.ja_x, K.nnz_x, K.t.S, NUg, K.t.B, d_bits, A->stream);
+    if (e == hipSuccess && rc == QBH_OK) e = hipMemcpyAsync(bits.data(), d_bits, (size_t)NUg, hipMemcpyDeviceToHost, A->stream);
+    if (e == hipSuccess && rc == QBH_OK) e = hipStreamSynchronize(A->stream);
+    (void)hipFree(d_bits);
+    if (rc != QBH_OK) return rc;
+    if (e != hipSuccess) {
+        qbh::set_error("kron_needed_majors: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return QBH_EHIP;
+    }
+    std::vector<int32_t> list;
+    int64_t peers_all = 0, peers_need = 0;
+    K.need_lo[0] = 0;
+    for (int q = 0; q < nranks; ++q) {
+        for (int64_t u = K.rank_cu[q]; u < K.rank_cu[q + 1]; ++u)
+            if (bits[(size_t)u]) list.push_back((int32_t)(u - K.rank_cu[q]));
+        K.need_lo[q + 1] = (int64_t)list.size();
+        if (K.rank_cu[q] != K.U0) {
+            peers_all += K.rank_cu[q + 1] - K.rank_cu[q];
+            peers_need += K.need_lo[q + 1] - K.need_lo[q];
+        }
+    }
+    if (peers_all > 0) K.need_frac = (double)peers_need / (double)peers_all;
+    if (list.empty()) list.push_back(0);
+    QBH_HIP(qbh::dev_alloc(&K.d_need, list.size() * sizeof(int32_t)));
+    QBH_HIP(hipMemcpy(K.d_need, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return QBH_OK;
+}
+
 }  // namespace qbhapi
 
 extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
@@ -77,6 +123,8 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
             A->kron.n_ranks = 1;
             A->kron.n_parts = 1;
             A->kron.xt_of = nullptr;
+            if (A->kron.d_need) (void)hipFree(A->kron.d_need);
+            A->kron.d_need = nullptr;
         }
         return QBH_OK;
     }
@@ -183,6 +231,7 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
             // the rest of this branch can fail on one rank only (a copy inside kron_gather_parts): agreed on once more, so that
             // no rank is left attached and waiting in its first gather while a peer has returned an error
             int prc = kron_gather_parts(A, comm, parts);
+            if (prc == QBH_OK) prc = kron_needed_majors(A, comm->nranks);
             double w[12] = {0};
             w[0] = prc != QBH_OK ? 1.0 : 0.0;
             const int arc = agree(w);

@@ -356,8 +356,17 @@ struct KronPlace {
     int64_t   cu[kKronMaxRanks + 1]; // major-index cuts of the ranks
     int64_t   base[kKronMaxRanks];   // first element of rank q's block in src
     int64_t   off[kKronMaxRanks], len[kKronMaxRanks];
+    // only the major indices this shard's far / cross entries read (k_kron_need): list[lo[q] .. lo[q + 1]) = the needed LOCAL major
+    // indices of rank q, ascending; band0 .. band1 = the bands of this piece (band1 == nfb + 1: the narrow edge band as well).
+    // list == nullptr: everything (the element ranges off / len above)
+    const int32_t *list;
+    int64_t   lo[kKronMaxRanks + 1];
+    int64_t   band0, band1;
 };
 int launch_kron_place(const KronPlace &a, hipStream_t s);
+// need[u] = 1 for every major index u of the WHOLE operator that a far (2-byte or int32 columns) or cross entry of this shard reads
+int launch_kron_need(const uint16_t *c16_f, const int32_t *ja_f, int64_t far_slots, const int32_t *ja_x, int64_t nnz_x, int64_t S, int64_t NUg, int B,
+                     uint8_t *need, hipStream_t s);
 // tail of a pipelined Lanczos step: |w'|^2 from the axpy's partial sums, a = sc_x * <u, w>, b = sqrt(|w'|^2), the next step's
 // coefficients into state[0..3], {<u,w>, |w'|^2, a, b} into log_slot (host-visible)
 int launch_lanczos_tail(const double *partials, int nparts, const double *dot, double *state, double *log_slot, double sc_x_host, int use_host,
@@ -678,6 +687,9 @@ struct qbh_csr {
         bool     comm_tiled = false;    // a communicator is attached and every rank exchanges the tiled copy of its block
         int      n_ranks = 1;           // ... of that communicator, and the major-index cuts of its ranks: the gathered blocks are moved
         int64_t  rank_cu[qbh::kKronMaxRanks + 1] = {0};     // (k_kron_place) into the tiled order of the WHOLE vector, which `cols` keeps describing
+        int32_t *d_need = nullptr;      // the needed local major indices of every rank, rank after rank (k_kron_need at attach): only those are moved
+        int64_t  need_lo[qbh::kKronMaxRanks + 1] = {0};
+        double   need_frac = 1.0;       // needed / all major indices of the peers (what a sparse exchange would have to carry)
         int64_t  nnz_n = 0, nnz_f = 0, nnz_x = 0;
         bool     sliced = false;        // far part interleaved inside groups of 8 rows (ia_f = group pointers, n_groups + 1 entries)
         int64_t  n_groups = 0, far_slots = 0;   // far_slots = entries stored in the far arrays (nnz_f + padding)
@@ -709,6 +721,7 @@ struct qbh_csr {
         // the far pass of part k = blocks [part_blk[k], part_blk[k + 1]) and starts when that part has arrived
         int      n_parts = 1;
         int64_t  part_blk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int64_t  part_band[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};    // first band of every part (part_band[n_parts] = number of full bands)
         std::vector<int64_t> part_off_len;      // [n_parts][2 * nranks]: offset, length (elements) inside each rank's block
     } kron;
     // wave kernel geometry (uncoded complex128 values; QBH_KERNEL_WAVE)

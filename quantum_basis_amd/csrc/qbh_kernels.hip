@@ -1449,8 +1449,29 @@ __global__ __launch_bounds__(kBlock) void k_kron_place(KronPlace a)
 {
     const int q = blockIdx.y;
     const int64_t nuq = a.cu[q + 1] - a.cu[q], full = a.nfb * a.B * nuq, wE = a.S - a.nfb * a.B;     // elements of rank q's full bands; width of the edge band
-    const int64_t e0 = a.off[q], e1 = e0 + a.len[q];
     const double *sr = reinterpret_cast<const double *>(a.src);
+    if (a.list != nullptr) {
+        // needed major indices only: work item = (band, listed major), B elements each (one 128-byte line of complex128)
+        const int64_t nl = a.lo[q + 1] - a.lo[q];
+        const int32_t *lst = a.list + a.lo[q];
+        const int64_t nb = a.band1 - a.band0;
+        for (int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x; w < nb * nl * a.B; w += (int64_t)gridDim.x * kBlock) {
+            const int64_t j = w % a.B, t = w / a.B, i = t % nl, b = a.band0 + t / nl;
+            const int64_t ul = lst[i];
+            int64_t e, o;
+            if (b < a.nfb) {
+                e = b * a.B * nuq + ul * a.B + j;
+                o = b * a.B * a.NUg + (a.cu[q] + ul) * a.B + j;
+            } else {                                         // the narrow edge band: wE elements per major index
+                if (j >= wE) continue;
+                e = full + ul * wE + j;
+                o = a.nfb * a.B * a.NUg + (a.cu[q] + ul) * wE + j;
+            }
+            a.dst[o] = a.real ? d2{sr[a.base[q] + e], 0.0} : a.src[a.base[q] + e];
+        }
+        return;
+    }
+    const int64_t e0 = a.off[q], e1 = e0 + a.len[q];
     for (int64_t e = e0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; e < e1; e += (int64_t)gridDim.x * kBlock) {
         int64_t o;
         if (e < full) {
@@ -1465,10 +1486,43 @@ __global__ __launch_bounds__(kBlock) void k_kron_place(KronPlace a)
 int launch_kron_place(const KronPlace &a, hipStream_t s)
 {
     int64_t longest = 0;
-    for (int q = 0; q < a.nr; ++q) longest = a.len[q] > longest ? a.len[q] : longest;
+    for (int q = 0; q < a.nr; ++q) {
+        const int64_t n = a.list ? (a.band1 - a.band0) * (a.lo[q + 1] - a.lo[q]) * a.B : a.len[q];
+        longest = n > longest ? n : longest;
+    }
     if (longest <= 0 || a.nr <= 0) return QBH_OK;
     const int64_t gx = std::min<int64_t>(2048, (longest + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_kron_place, dim3((unsigned)gx, (unsigned)a.nr), dim3(kBlock), 0, s, a);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// which major indices of the whole operator does this shard read through its far and cross parts?  (Columns are positions in the
+// tiled order of the whole vector: full band b, major u, j -> b B NUg + u B + j; edge band -> nfb B NUg + u wE + j.)
+__global__ __launch_bounds__(kBlock) void k_kron_need(const uint16_t *c16_f, const int32_t *ja_f, int64_t far_slots, const int32_t *ja_x, int64_t nnz_x,
+                                                      int64_t S, int64_t NUg, int B, uint8_t *need)
+{
+    const int64_t nfb = S / B, fullx = nfb * B * NUg, wE = S - nfb * B;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < far_slots; i += stride) {
+        int64_t u;
+        if (c16_f != nullptr) u = (int64_t)c16_f[i] % NUg;
+        else {
+            const int64_t c = ja_f[i];
+            u = c < fullx ? (c % (B * NUg)) / B : (c - fullx) / (wE > 0 ? wE : 1);
+        }
+        if (u >= 0 && u < NUg) need[u] = 1;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz_x; i += stride) {
+        const int64_t c = ja_x[i];
+        const int64_t u = c < fullx ? (c % (B * NUg)) / B : (c - fullx) / (wE > 0 ? wE : 1);
+        if (u >= 0 && u < NUg) need[u] = 1;
+    }
+}
+int launch_kron_need(const uint16_t *c16_f, const int32_t *ja_f, int64_t far_slots, const int32_t *ja_x, int64_t nnz_x, int64_t S, int64_t NUg, int B,
+                     uint8_t *need, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kron_need, dim3(2048), dim3(kBlock), 0, s, c16_f, ja_f, far_slots, ja_x, nnz_x, S, NUg, B, need);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }

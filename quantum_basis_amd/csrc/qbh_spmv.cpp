@@ -225,6 +225,11 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
         pa.NUg = K.NUg;
         pa.nfb = K.t.S / K.t.B;
         for (int q = 0; q <= pa.nr; ++q) pa.cu[q] = K.rank_cu[q];
+        pa.list = K.d_need;                                  // only the major indices this shard reads
+        for (int q = 0; q <= pa.nr; ++q) pa.lo[q] = K.need_lo[q];
+        const int64_t edge = (K.t.S % K.t.B) ? 1 : 0;         // the narrow last band travels with the last piece
+        pa.band0 = np_used > 1 ? K.part_band[k] : 0;
+        pa.band1 = np_used > 1 ? (k == np_used - 1 ? pa.nfb + edge : K.part_band[k + 1]) : pa.nfb + edge;
         for (int q = 0; q < pa.nr; ++q) {
             pa.base[q] = A->comm.row_cuts ? A->comm.row_cuts[q] : (int64_t)q * A->comm.nblk;
             if (np_used > 1) {

@@ -131,7 +131,7 @@ int main(int argc, char **argv)
             o.write((const char *)(hess.data() + maxit), 8 * m);
             o.write((const char *)hess.data(), 8 * m);
         }
-        std::printf("OK %d %d %lld %lld %lld %.17g %d 0 1 kron 0 parts 0 cols16 0 wire 0\n", rank, nranks, (long long)cuts[rank], (long long)cuts[rank + 1],
+        std::printf("OK %d %d %lld %lld %lld %.17g %d 0 1 kron 0 parts 0 cols16 0 wire 0 need 1\n", rank, nranks, (long long)cuts[rank], (long long)cuts[rank + 1],
                     (long long)m, E0c, conv);
         qbh_vec_free(d_v);
         must(qbh_comm_destroy(A), "qbh_comm_destroy");
@@ -160,9 +160,9 @@ int main(int argc, char **argv)
         o.write((const char *)hess.data(), 8 * m);                 // b_j
         o.write((const char *)vec.data(), 16 * n);
     }
-    std::printf("OK %d %d %lld %lld %lld %.17g %lld %.3e %.15g kron %lld parts %d cols16 %d wire %d\n", rank, nranks, (long long)cuts[rank],
+    std::printf("OK %d %d %lld %lld %lld %.17g %lld %.3e %.15g kron %lld parts %d cols16 %d wire %d need %.4f\n", rank, nranks, (long long)cuts[rank],
                 (long long)cuts[rank + 1], (long long)m, E0, (long long)mcg, accu, nrm, (long long)inf.kron_minor, inf.gather_parts, inf.kron_cols16,
-                inf.wire_element_bytes);
+                inf.wire_element_bytes, inf.gather_needed_frac);
     qbh_vec_free(d_v);
     must(qbh_comm_destroy(A), "qbh_comm_destroy");
     qbh_csr_destroy(A);

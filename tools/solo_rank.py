@@ -74,7 +74,7 @@ def main():
     print(json.dumps({
         "tool": "tools/solo_rank.py", "workload": name, "ranks": P, "rank": rank, "rows": int(info.nrows), "nnz": int(info.nnz), "steps": int(nst),
         "columns": {0: "int32", 1: "near 2-byte, far int32", 2: "near int32, far 2-byte", 3: "2-byte in both parts"}[int(inf.kron_cols16)],
-        "gather_parts": int(inf.gather_parts), "element_bytes": elem, "lanczos_pipeline": pipeline,
+        "gather_parts": int(inf.gather_parts), "element_bytes": elem, "gather_needed_frac": round(float(inf.gather_needed_frac), 4), "lanczos_pipeline": pipeline,
         "link_model": {"GBps_per_link": rate, "latency_us": float(os.environ.get("QBH_STUB_LATENCY_US", 20)),
                        "modelled_ms_per_gather (longest block / link rate + latency per part)": round(block_bytes / rate / 1e6 + 0.02 * max(int(inf.gather_parts), 1), 3)},
         "ms_per_step": round(ms_step, 4), "ms_spmv_kernels (near + far + place + combine, event-timed on the operator's stream; the far pass's wait for its pieces is inside)": round(ms_spmv, 4),
