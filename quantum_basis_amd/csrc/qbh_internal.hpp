@@ -384,7 +384,7 @@ int launch_nrm2sq_re(const double *x, int64_t n, double *partials, hipStream_t s
 int launch_scal_re(double a, double *x, int64_t n, hipStream_t s);
 int launch_xpby(const d2 *x, double b, d2 *y, int64_t n, double *yr, int *flag, hipStream_t s);            // y = x + b*y
 int launch_cg_update(d2 alpha, const d2 *p, const d2 *pp, d2 *v, d2 *r, int64_t n, double *partials,
-                     hipStream_t s);                                               // v+=a p; r-=a pp; |r|^2
+                     hipStream_t s, const double *delta_dev = nullptr, double accu2 = 0.0);                                               // v+=a p; r-=a pp; |r|^2
 int launch_randomize(d2 *x, double *xr, int64_t n, int64_t global_offset, uint32_t seed, double *partials, hipStream_t s);
 int launch_fill_const(d2 *x, int64_t n, double re, hipStream_t s);
 int launch_max_rowlen(const int64_t *d_ia, int64_t nrows, int64_t *d_out, hipStream_t s);

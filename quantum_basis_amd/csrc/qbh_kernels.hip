@@ -2609,11 +2609,18 @@ int launch_xpby(const d2 *x, double b, d2 *y, int64_t n, double *yr, int *flag, 
 }
 
 // v += alpha*p ; r -= alpha*pp ; partial |r|^2   (src/lanczos.cc:324-326 in one pass)
+// delta_dev != nullptr: alpha = accu2 / delta with delta = <p, pp> left on the device by the SpMV that produced pp (no host
+// round-trip between the SpMV and this pass); the arithmetic of the host expression, operation by operation (no contraction)
 __global__ __launch_bounds__(kBlock) void k_cg_update(d2 alpha, const d2 *p, const d2 *pp, d2 *v, d2 *r,
-                                                      int64_t n, double *partials)
+                                                      int64_t n, double *partials, const double *delta_dev, double accu2)
 {
     __shared__ double red[4];
     double acc[1] = {0.0};
+    if (delta_dev != nullptr) {
+        const double re = delta_dev[0], im = delta_dev[1];
+        const double den = __dadd_rn(__dmul_rn(re, re), __dmul_rn(im, im));
+        alpha = d2{__ddiv_rn(__dmul_rn(accu2, re), den), -__ddiv_rn(__dmul_rn(accu2, im), den)};
+    }
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         v[i] = v[i] + cmul(alpha, p[i]);
@@ -2626,9 +2633,9 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(d2 alpha, const d2 *p, con
 }
 
 int launch_cg_update(d2 alpha, const d2 *p, const d2 *pp, d2 *v, d2 *r, int64_t n, double *partials,
-                     hipStream_t s)
+                     hipStream_t s, const double *delta_dev, double accu2)
 {
-    hipLaunchKernelGGL(k_cg_update, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, p, pp, v, r, n, partials);
+    hipLaunchKernelGGL(k_cg_update, dim3(blas_grid(n)), dim3(kBlock), 0, s, alpha, p, pp, v, r, n, partials, delta_dev, accu2);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }

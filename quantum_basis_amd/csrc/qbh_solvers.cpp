@@ -710,10 +710,21 @@ static int cg_core(qbh_csr *A, int64_t maxit, int64_t *m_io, double E0, double *
             }
         } else {
             // pp = (H - E0) p with the reference's (machine_prec - E0) shift, delta = <p,pp>  :319-323
-            QBH_TRY(spmv_run(A, p, pp, 1.0, 0.0, machine_prec - E0, red));
-            const double den = red[0] * red[0] + red[1] * red[1];
-            const d2 alpha = {accu * accu * red[0] / den, -accu * accu * red[1] / den};
-            QBH_TRY(qbh::launch_cg_update(alpha, p, pp, v, r, n, A->d_partials, A->stream));   // :324-325
+            if (A->opts.lanczos_pipeline != 0 && !A->dbg.no_defer) {
+                // delta stays on the device (summed over the ranks in stream order) and the update pass forms alpha itself: one host
+                // synchronisation per CG step instead of two.  (The stop test of :293 cannot run a step behind without out-of-place
+                // copies of v, r, p: the remaining one stays.)
+                A->defer_red = true;
+                const int rc1 = spmv_run(A, p, pp, 1.0, 0.0, machine_prec - E0, red);
+                A->defer_red = false;
+                QBH_TRY(rc1);
+                QBH_TRY(qbh::launch_cg_update(d2{0.0, 0.0}, p, pp, v, r, n, A->d_partials, A->stream, scal_buf(A), accu * accu));   // :324-325
+            } else {
+                QBH_TRY(spmv_run(A, p, pp, 1.0, 0.0, machine_prec - E0, red));
+                const double den = red[0] * red[0] + red[1] * red[1];
+                const d2 alpha = {accu * accu * red[0] / den, -accu * accu * red[1] / den};
+                QBH_TRY(qbh::launch_cg_update(alpha, p, pp, v, r, n, A->d_partials, A->stream));   // :324-325
+            }
             QBH_TRY(finish_reduction(A, qbh::blas_grid(n), 1, &sq));
             const double beta = std::sqrt(sq) / accu;                                        // :326
             {

@@ -184,3 +184,31 @@ def test_profile_events_under_the_pipeline_count_every_step_once():
     assert A.stats().n_spmv == 10
     v.free()
     A.destroy()
+
+
+@pytest.mark.parametrize("name", ["kron_sliced_4x3", "rows_complex_chain16_k3", "wave_unsplit_4x3"])
+def test_cg_with_the_dot_product_left_on_the_device_is_the_same_cg(name):
+    """eigenvec_CG (src/lanczos.cc:319-331): delta = <p, pp> stays on the device and the update pass forms alpha = gamma^2 / delta
+    itself (one host synchronisation per step instead of two) -- in the host expression's arithmetic, operation by operation: the
+    residual history, the step count and the vectors are bit for bit those of the loop that reads delta back."""
+    A = MAKERS[name](1)
+    dim, maxit = A.dim, 1000
+    x0 = qo.vec_randomize(dim, 1)
+    hess = np.zeros(2 * maxit)
+    v = np.zeros(2 * dim, dtype=np.complex128)
+    v[:dim] = x0
+    m = q.lanczos(0, maxit - 1, maxit, dim, A, v, hess, "sr_val0")
+    e0 = q.hess_eigen(hess, maxit, m, "sr")[0][0]
+    outs = []
+    for pipe in (1, 0):
+        A.set_option("lanczos_pipeline", pipe)
+        vs = [x0.copy()] + [np.zeros(dim, dtype=np.complex128) for _ in range(3)]
+        mcg, accu = q.eigenvec_CG(dim, maxit, 0, A, e0, *vs)
+        outs.append((mcg, accu, list(q.eigenvec_CG.last["resid"]), vs))
+    (m1, a1, r1, v1), (m0, a0, r0, v0) = outs
+    assert m1 == m0 and 5 < m1 < maxit and a1 == a0 and r1 == r0
+    assert all(np.array_equal(x.view(np.float64), y.view(np.float64)) for x, y in zip(v1, v0))
+    y = np.empty(dim, dtype=np.complex128)
+    A.MultMv(v1[0], y)
+    assert np.linalg.norm(y - e0 * v1[0]) < 1e-8
+    A.destroy()
