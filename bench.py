@@ -939,7 +939,11 @@ def main():
         # link bytes per GPU reported separately from the HBM bytes.  ms_per_gather is the event-timed duration of
         # the all-gather on RCCL's side stream (native communicator), max over ranks; it overlaps the locally-owned columns.
         elem = int(A.info().wire_element_bytes) or (8 if real_used else 16)      # what the last gather carried (qbh_csr_info.wire_element_bytes)
-        out["exchange"] = {"bytes_received_per_gpu_per_spmv": int(elem * dim * (world - 1) / world), "element_bytes": elem,
+        sparse_x, need_frac = bool(A.info().gather_sparse), float(A.info().gather_needed_frac)
+        out["exchange"] = {"bytes_received_per_gpu_per_spmv": int(elem * dim * (world - 1) / world * (need_frac if sparse_x else 1.0)), "element_bytes": elem,
+                           # personalised exchange (qbh_opts.sparse_gather): every rank sends each peer only the major indices that peer's far / cross
+                           # entries read; needed_frac_rank0 = that share of the all-gather for THIS rank (it differs from rank to rank)
+                           "personalised": sparse_x, "needed_frac_rank0": round(need_frac, 4),
                            "ms_per_gather": round(head["ms_gather"], 4) if head["ms_gather"] > 0 else None,
                            "gathers": head["n_gather"],
                            # > 1: the tiled blocks travel as that many band ranges and the far pass follows range by range; the

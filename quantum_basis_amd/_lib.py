@@ -40,7 +40,7 @@ class Opts(C.Structure):
                 ("kron_sliced", C.c_int), ("kron_band", C.c_int), ("kron_cross_in_near", C.c_int), ("kron_coded", C.c_int),
                 ("kron_uniform", C.c_int), ("gather_parts", C.c_int), ("wave_walk", C.c_int), ("tile_fold", C.c_int),
                 ("autotune", C.c_int), ("shard_split", C.c_int), ("real_forms", C.c_int), ("basis_detect", C.c_int),
-                ("sector_orbit", C.c_int), ("lanczos_pipeline", C.c_int), ("real_wire", C.c_int), ("sector_cut", C.c_int)]
+                ("sector_orbit", C.c_int), ("lanczos_pipeline", C.c_int), ("real_wire", C.c_int), ("sparse_gather", C.c_int), ("sector_cut", C.c_int)]
 
 
 class CsrInfo(C.Structure):
@@ -52,7 +52,7 @@ class CsrInfo(C.Structure):
                 ("kron_inplace", C.c_int), ("tuned", C.c_int), ("tune_ms_rows", C.c_double), ("tune_ms_wave", C.c_double),
                 ("basis_internal", C.c_int), ("kron_classes", C.c_int), ("kron_cross_nnz", C.c_int64), ("gather_parts", C.c_int),
                 ("kron_cols16", C.c_int), ("basis_detected", C.c_int), ("basis_n_sites", C.c_int), ("basis_n_up", C.c_int),
-                ("basis_n_dn", C.c_int), ("basis_detect_ms", C.c_double), ("kron_table_kernel", C.c_int), ("wire_element_bytes", C.c_int), ("gather_needed_frac", C.c_double)]
+                ("basis_n_dn", C.c_int), ("basis_detect_ms", C.c_double), ("kron_table_kernel", C.c_int), ("wire_element_bytes", C.c_int), ("gather_sparse", C.c_int), ("gather_needed_frac", C.c_double)]
 
 
 class LanczosRow(C.Structure):
@@ -86,7 +86,7 @@ class Comm(C.Structure):
                 ("ctx", C.c_void_p), ("allgather_x", ALLGATHER_FN), ("allreduce_sum", ALLREDUCE_FN),
                 ("allgather_begin", ALLGATHER_FN), ("allgather_wait", ALLWAIT_FN), ("row_cuts", C.c_void_p),
                 ("allgather_part_begin", PART_BEGIN_FN), ("allgather_part_wait", PART_WAIT_FN),      # optional: the gather in parts
-                ("allgather_part_begin_w", PART_BEGIN_W_FN)]                                            # ... with the wire format named (ABI 600)
+                ("allgather_part_begin_w", PART_BEGIN_W_FN), ("exchange_v", C.c_void_p)]                               # (exchange_v: native communicator only)                                            # ... with the wire format named (ABI 600)
 
 
 class Stats(C.Structure):

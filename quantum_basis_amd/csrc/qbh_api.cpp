@@ -184,6 +184,7 @@ void qbh::opts_builtin(qbh_opts *o)
     o->lanczos_pipeline = 1;
     o->real_wire = 1;
     o->sector_cut = 0;
+    o->sparse_gather = 1;
     o->kron_minor = 0;
     o->deterministic = 0;
     o->basis_kind = QBH_BASIS_NONE;
@@ -1016,6 +1017,7 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->kron_cols16 = 0;
     info->kron_cross_nnz = 0;
     info->wire_element_bytes = A->has_comm ? A->wire_bytes_last : 0;
+    info->gather_sparse = (A->has_comm && A->kron.active && A->kron.comm_tiled && A->kron.sparse) ? 1 : 0;
     info->gather_needed_frac = (A->has_comm && A->kron.active && A->kron.comm_tiled) ? A->kron.need_frac : 1.0;
     info->gather_parts = A->has_comm ? ((A->kron.active && A->kron.comm_tiled) ? A->kron.n_parts : 1) : 0;
     if (A->kron.active) {

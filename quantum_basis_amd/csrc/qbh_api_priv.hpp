@@ -48,7 +48,8 @@ int kronc_build(qbh_csr *A);
 // ---- qbh_commattach.cpp ----
 int kron_parts_wanted(const qbh_csr *A, const qbh_comm *comm);
 int kron_gather_parts(qbh_csr *A, const qbh_comm *comm, int64_t want);
-int kron_needed_majors(qbh_csr *A, int nranks);
+int kron_needed_majors(qbh_csr *A, int nranks, std::vector<uint8_t> *bits_out);
+int kron_sparse_setup(qbh_csr *A, const qbh_comm *comm, const std::vector<uint8_t> &bits);
 // ---- qbh_spmv.cpp ----
 int finish_reduction(qbh_csr *A, int nparts, int ncomp, double *host_out);
 void harvest_events(qbh_csr *A);

@@ -259,6 +259,55 @@ int hook_part_begin_w(void *ctx, int part, int nparts, const int64_t *off_len, i
 
 int hook_part_begin(void *ctx, int part, int nparts, const int64_t *off_len) { return hook_part_begin_w(ctx, part, nparts, off_len, 0); }
 
+// The personalised exchange in parts (qbh_comm::exchange_v): one send + one receive per peer in a single group, each with its
+// own offset and length in the library's packed buffers; zero lengths are skipped (both sides know them: the lists were agreed
+// at attach time).  Same stream, events and timing as the gather in parts.
+int hook_exchange_v(void *ctx, int part, int nparts, const int64_t *send_off_len, const int64_t *recv_off_len, int elem_doubles, const void *d_send,
+                    void *d_recv)
+{
+    auto *c = static_cast<qbh_native_comm *>(ctx);
+    if (part < 0 || part >= 8 || nparts > 8 || (elem_doubles != 1 && elem_doubles != 2)) return 1;
+    const bool timed = c->owner && c->owner->opts.profile != 0;
+    if (part == 0) {
+        harvest_gather_time(c);
+        if (hipEventRecord(c->ready, c->op) != hipSuccess || hipStreamWaitEvent(c->side, c->ready, 0) != hipSuccess) return 1;
+        if (timed && hipEventRecord(c->t0, c->side) != hipSuccess) return 1;
+    }
+    if (!c->part_done[part] && hipEventCreateWithFlags(&c->part_done[part], hipEventDisableTiming) != hipSuccess) return 1;
+    const size_t w = (size_t)elem_doubles;
+    const double *sb = static_cast<const double *>(d_send);
+    double *rb = static_cast<double *>(d_recv);
+    ncclResult_t r;
+    if (c->nranks > 1) {
+        if ((r = c->api->GroupStart()) != ncclSuccess) return fail(c, "ncclGroupStart", r);
+        for (int q = 0; q < c->nranks; ++q) {
+            if (q == c->rank) continue;
+            const int64_t roff = recv_off_len[2 * q], rlen = recv_off_len[2 * q + 1], soff = send_off_len[2 * q], slen = send_off_len[2 * q + 1];
+            if (rlen > 0) {
+                r = c->api->Recv(rb + (size_t)roff * w, (size_t)rlen * w, ncclDouble, q, c->comm, c->side);
+                if (r != ncclSuccess) {
+                    (void)c->api->GroupEnd();
+                    return fail(c, "ncclRecv", r);
+                }
+            }
+            if (slen > 0) {
+                r = c->api->Send(sb + (size_t)soff * w, (size_t)slen * w, ncclDouble, q, c->comm, c->side);
+                if (r != ncclSuccess) {
+                    (void)c->api->GroupEnd();
+                    return fail(c, "ncclSend", r);
+                }
+            }
+        }
+        if ((r = c->api->GroupEnd()) != ncclSuccess) return fail(c, "ncclGroupEnd", r);
+    }
+    if (hipEventRecord(c->part_done[part], c->side) != hipSuccess) return 1;
+    if (part == nparts - 1 && timed) {
+        if (hipEventRecord(c->t1, c->side) != hipSuccess) return 1;
+        c->timing_pending = true;
+    }
+    return 0;
+}
+
 int hook_part_wait(void *ctx, int part)
 {
     auto *c = static_cast<qbh_native_comm *>(ctx);
@@ -425,6 +474,7 @@ extern "C" int qbh_comm_create_rccl(qbh_csr *A, const void *uid128, int rank, in
     h.allgather_part_begin = hook_part_begin;
     h.allgather_part_wait = hook_part_wait;
     h.allgather_part_begin_w = hook_part_begin_w;
+    h.exchange_v = hook_exchange_v;
     h.row_cuts = c->ragged ? c->cuts.data() : nullptr;
     rc = qbh_csr_set_comm(A, &h);
     if (rc != QBH_OK) return bail(rc);

@@ -70,7 +70,7 @@ int kron_gather_parts(qbh_csr *A, const qbh_comm *comm, int64_t want)
 // the hop targets of that up configuration: a subset of the gathered x (C3, 8 ranks in the generator's order: 42-68 %,
 // tools/needed_columns.py).  Only those are moved into the tiled x (k_kron_place with a list): the rest of every block
 // arrives and is never touched.  need_frac = what a sparse exchange would still have to carry.
-int kron_needed_majors(qbh_csr *A, int nranks)
+int kron_needed_majors(qbh_csr *A, int nranks, std::vector<uint8_t> *bits_out)
 {
     qbh_csr::KronSplit &K = A->kron;
     if (K.d_need) (void)hipFree(K.d_need);
@@ -108,6 +108,56 @@ int kron_needed_majors(qbh_csr *A, int nranks)
     if (list.empty()) list.push_back(0);
     QBH_HIP(qbh::dev_alloc(&K.d_need, list.size() * sizeof(int32_t)));
     QBH_HIP(hipMemcpy(K.d_need, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (bits_out) bits_out->swap(bits);
+    return QBH_OK;
+}
+
+// Personalised exchange (qbh_opts.sparse_gather): every rank tells every other which major indices it reads -- the need bitmaps
+// travel ONCE through the communicator's own all-gather (in front of the rank's send block) -- and keeps, per destination, the
+// list of its own major indices that destination reads.  Collective (every rank of a communicator that agreed on it calls it).
+int kron_sparse_setup(qbh_csr *A, const qbh_comm *comm, const std::vector<uint8_t> &bits)
+{
+    qbh_csr::KronSplit &K = A->kron;
+    const int np = comm->nranks;
+    const int64_t NUg = K.NUg, S = K.t.S, NUq = K.t.NU;
+    if ((int64_t)bits.size() != NUg || NUg > comm->nblk * (int64_t)sizeof(qbh::d2)) return QBH_EINVAL;
+    auto base = [&](int q) { return comm->row_cuts ? comm->row_cuts[q] : (int64_t)q * comm->nblk; };
+    QBH_HIP(hipMemcpyAsync(comm->d_xsend, bits.data(), (size_t)NUg, hipMemcpyHostToDevice, A->stream));
+    QBH_HIP(hipStreamSynchronize(A->stream));
+    if (comm->allgather_x(comm->ctx, 0) != 0) {
+        qbh::set_error("qbh_csr_set_comm: allgather hook failed (need bitmaps)");
+        return QBH_ECOMM;
+    }
+    std::vector<int32_t> list;
+    std::vector<uint8_t> theirs((size_t)NUg);
+    K.send_lo[0] = 0;
+    for (int p = 0; p < np; ++p) {
+        if (p != comm->rank) {
+            QBH_HIP(hipMemcpyAsync(theirs.data(), reinterpret_cast<const char *>(comm->d_xfull) + (size_t)base(p) * sizeof(qbh::d2), (size_t)NUg,
+                                   hipMemcpyDeviceToHost, A->stream));
+            QBH_HIP(hipStreamSynchronize(A->stream));
+            for (int64_t ul = 0; ul < NUq; ++ul)
+                if (theirs[(size_t)(K.U0 + ul)]) list.push_back((int32_t)ul);
+        }
+        K.send_lo[p + 1] = (int64_t)list.size();
+    }
+    // what this rank receives: its own need list, peers only (kron_needed_majors)
+    int64_t recv_majors = 0;
+    for (int q = 0; q < np; ++q)
+        if (q != comm->rank) recv_majors += K.need_lo[q + 1] - K.need_lo[q];
+    const int64_t send_elems = std::max<int64_t>(1, (int64_t)list.size() * S), recv_elems = std::max<int64_t>(1, recv_majors * S);
+    if (list.empty()) list.push_back(0);
+    for (void **q : {(void **)&K.d_send_list, (void **)&K.d_vsend, (void **)&K.d_vrecv}) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+    QBH_HIP(qbh::dev_alloc(&K.d_send_list, list.size() * sizeof(int32_t)));
+    QBH_HIP(hipMemcpy(K.d_send_list, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    QBH_HIP(qbh::dev_alloc(&K.d_vsend, (size_t)send_elems * sizeof(qbh::d2)));
+    QBH_HIP(qbh::dev_alloc(&K.d_vrecv, (size_t)recv_elems * sizeof(qbh::d2)));
+    K.vsend_cap = send_elems;
+    K.vrecv_cap = recv_elems;
+    K.sparse = true;
     return QBH_OK;
 }
 
@@ -125,6 +175,11 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
             A->kron.xt_of = nullptr;
             if (A->kron.d_need) (void)hipFree(A->kron.d_need);
             A->kron.d_need = nullptr;
+            for (void **q : {(void **)&A->kron.d_send_list, (void **)&A->kron.d_vsend, (void **)&A->kron.d_vrecv}) {
+                if (*q) (void)hipFree(*q);
+                *q = nullptr;
+            }
+            A->kron.sparse = false;
         }
         return QBH_OK;
     }
@@ -194,6 +249,7 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
     v[0] = local_err != QBH_OK ? 1.0 : 0.0;
     v[1] = mine ? 1.0 : 0.0;
     v[2 + (my_parts - 1)] = 1.0;
+    v[10] = (mine && A->opts.sparse_gather != 0 && comm->exchange_v != nullptr && comm->allgather_part_wait != nullptr) ? 1.0 : 0.0;
     QBH_TRY(agree(v));
     if (v[0] > 0.0) {
         if (local_err == QBH_OK) qbh::set_error("qbh_csr_set_comm: a peer rank rejected the communicator (its qbh_last_error says why)");
@@ -231,12 +287,23 @@ extern "C" int qbh_csr_set_comm(qbh_csr *A, const qbh_comm *comm)
             // the rest of this branch can fail on one rank only (a copy inside kron_gather_parts): agreed on once more, so that
             // no rank is left attached and waiting in its first gather while a peer has returned an error
             int prc = kron_gather_parts(A, comm, parts);
-            if (prc == QBH_OK) prc = kron_needed_majors(A, comm->nranks);
+            std::vector<uint8_t> bits;
+            if (prc == QBH_OK) prc = kron_needed_majors(A, comm->nranks, &bits);
+            K.sparse = false;
+            const bool all_sparse = comm->nranks > 1 && v[10] == (double)comm->nranks;
+            if (all_sparse) {
+                // the bitmap exchange is a collective of its own: every rank enters it, a rank whose preparation failed with a
+                // bitmap of zeros (its verdict travels in the agreement below)
+                if (prc != QBH_OK) bits.assign((size_t)K.NUg, 0);
+                const int src = kron_sparse_setup(A, comm, bits);
+                if (prc == QBH_OK) prc = src;
+            }
             double w[12] = {0};
             w[0] = prc != QBH_OK ? 1.0 : 0.0;
             const int arc = agree(w);
             if (prc != QBH_OK || arc != QBH_OK || w[0] > 0.0) {
                 K.comm_tiled = false;
+                K.sparse = false;
                 K.n_ranks = 1;
                 K.n_parts = 1;
                 if (prc == QBH_OK && arc == QBH_OK) qbh::set_error("qbh_csr_set_comm: a peer rank could not set up the gather in parts");

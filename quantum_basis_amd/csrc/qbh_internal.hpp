@@ -362,8 +362,24 @@ struct KronPlace {
     const int32_t *list;
     int64_t   lo[kKronMaxRanks + 1];
     int64_t   band0, band1;
+    // compact != 0 (personalised exchange): rank q's piece in src holds ONLY the listed major indices, band-major
+    // (band b, i-th listed major, j) at base[q] + b B m_q + i B + j with m_q = lo[q + 1] - lo[q] -- what k_kron_pack wrote on rank q
+    int       compact;
+    int       skip;                  // compact: this rank's range of the list is not in src (the own rank: placed from its tiled block); -1: none
 };
 int launch_kron_place(const KronPlace &a, hipStream_t s);
+// personalised exchange, sender: the listed major indices of the rank's own tiled block, packed per destination
+// (dest p: [b][i][j] at base[p], i over list[lo[p] .. lo[p + 1])); real != 0: 8-byte elements
+struct KronPack {
+    const d2 *src;                   // the tiled copy of the own block (d_xsend; complex or, real != 0, packed real parts)
+    d2       *dst;                   // d_vsend
+    int       real, nr, B;
+    int64_t   S, NUq, nfb;           // minor size, major indices of THIS rank, full bands
+    const int32_t *list;
+    int64_t   lo[kKronMaxRanks + 1];
+    int64_t   base[kKronMaxRanks];
+};
+int launch_kron_pack(const KronPack &a, hipStream_t s);
 // need[u] = 1 for every major index u of the WHOLE operator that a far (2-byte or int32 columns) or cross entry of this shard reads
 int launch_kron_need(const uint16_t *c16_f, const int32_t *ja_f, int64_t far_slots, const int32_t *ja_x, int64_t nnz_x, int64_t S, int64_t NUg, int B,
                      uint8_t *need, hipStream_t s);
@@ -690,6 +706,12 @@ struct qbh_csr {
         int32_t *d_need = nullptr;      // the needed local major indices of every rank, rank after rank (k_kron_need at attach): only those are moved
         int64_t  need_lo[qbh::kKronMaxRanks + 1] = {0};
         double   need_frac = 1.0;       // needed / all major indices of the peers (what a sparse exchange would have to carry)
+        // personalised exchange (qbh_opts.sparse_gather + qbh_comm.exchange_v): what every peer reads of THIS rank's major indices
+        bool     sparse = false;
+        int32_t *d_send_list = nullptr; // local major indices per destination, destination after destination
+        int64_t  send_lo[qbh::kKronMaxRanks + 1] = {0};
+        qbh::d2 *d_vsend = nullptr, *d_vrecv = nullptr;      // packed pieces out / in (complex128 capacity)
+        int64_t  vsend_cap = 0, vrecv_cap = 0;
         int64_t  nnz_n = 0, nnz_f = 0, nnz_x = 0;
         bool     sliced = false;        // far part interleaved inside groups of 8 rows (ia_f = group pointers, n_groups + 1 entries)
         int64_t  n_groups = 0, far_slots = 0;   // far_slots = entries stored in the far arrays (nnz_f + padding)

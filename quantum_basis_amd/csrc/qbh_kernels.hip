@@ -1452,6 +1452,7 @@ __global__ __launch_bounds__(kBlock) void k_kron_place(KronPlace a)
     const double *sr = reinterpret_cast<const double *>(a.src);
     if (a.list != nullptr) {
         // needed major indices only: work item = (band, listed major), B elements each (one 128-byte line of complex128)
+        if (a.compact && q == a.skip) return;
         const int64_t nl = a.lo[q + 1] - a.lo[q];
         const int32_t *lst = a.list + a.lo[q];
         const int64_t nb = a.band1 - a.band0;
@@ -1459,12 +1460,13 @@ __global__ __launch_bounds__(kBlock) void k_kron_place(KronPlace a)
             const int64_t j = w % a.B, t = w / a.B, i = t % nl, b = a.band0 + t / nl;
             const int64_t ul = lst[i];
             int64_t e, o;
+            const int64_t um = a.compact ? i : ul, nm = a.compact ? nl : nuq;      // position and count of the major indices in the source piece
             if (b < a.nfb) {
-                e = b * a.B * nuq + ul * a.B + j;
+                e = b * a.B * nm + um * a.B + j;
                 o = b * a.B * a.NUg + (a.cu[q] + ul) * a.B + j;
             } else {                                         // the narrow edge band: wE elements per major index
                 if (j >= wE) continue;
-                e = full + ul * wE + j;
+                e = a.nfb * a.B * nm + um * wE + j;
                 o = a.nfb * a.B * a.NUg + (a.cu[q] + ul) * wE + j;
             }
             a.dst[o] = a.real ? d2{sr[a.base[q] + e], 0.0} : a.src[a.base[q] + e];
@@ -1487,12 +1489,48 @@ int launch_kron_place(const KronPlace &a, hipStream_t s)
 {
     int64_t longest = 0;
     for (int q = 0; q < a.nr; ++q) {
-        const int64_t n = a.list ? (a.band1 - a.band0) * (a.lo[q + 1] - a.lo[q]) * a.B : a.len[q];
+        const int64_t n = a.list ? ((a.compact && q == a.skip) ? 0 : (a.band1 - a.band0) * (a.lo[q + 1] - a.lo[q]) * a.B) : a.len[q];
         longest = n > longest ? n : longest;
     }
     if (longest <= 0 || a.nr <= 0) return QBH_OK;
     const int64_t gx = std::min<int64_t>(2048, (longest + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_kron_place, dim3((unsigned)gx, (unsigned)a.nr), dim3(kBlock), 0, s, a);
+    QBH_HIP(hipGetLastError());
+    return QBH_OK;
+}
+
+// personalised exchange, sender side: for destination p (blockIdx.y) the listed major indices of the own tiled block, band-major
+__global__ __launch_bounds__(kBlock) void k_kron_pack(KronPack a)
+{
+    const int p = blockIdx.y;
+    const int64_t nl = a.lo[p + 1] - a.lo[p], wE = a.S - a.nfb * a.B, nb = a.nfb + (wE > 0 ? 1 : 0);
+    const int32_t *lst = a.list + a.lo[p];
+    const double *sr = reinterpret_cast<const double *>(a.src);
+    double *dr = reinterpret_cast<double *>(a.dst);
+    for (int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x; w < nb * nl * a.B; w += (int64_t)gridDim.x * kBlock) {
+        const int64_t j = w % a.B, t = w / a.B, i = t % nl, b = t / nl;
+        const int64_t ul = lst[i];
+        int64_t e, o;
+        if (b < a.nfb) {
+            e = b * a.B * a.NUq + ul * a.B + j;
+            o = b * a.B * nl + i * a.B + j;
+        } else {
+            if (j >= wE) continue;
+            e = a.nfb * a.B * a.NUq + ul * wE + j;
+            o = a.nfb * a.B * nl + i * wE + j;
+        }
+        if (a.real) dr[a.base[p] + o] = sr[e];
+        else        a.dst[a.base[p] + o] = a.src[e];
+    }
+}
+int launch_kron_pack(const KronPack &a, hipStream_t s)
+{
+    int64_t longest = 0;
+    const int64_t nb = a.nfb + ((a.S - a.nfb * a.B) > 0 ? 1 : 0);
+    for (int p = 0; p < a.nr; ++p) longest = std::max<int64_t>(longest, nb * (a.lo[p + 1] - a.lo[p]) * a.B);
+    if (longest <= 0 || a.nr <= 0) return QBH_OK;
+    const int64_t gx = std::min<int64_t>(2048, (longest + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_kron_pack, dim3((unsigned)gx, (unsigned)a.nr), dim3(kBlock), 0, s, a);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }

@@ -24,7 +24,7 @@ void kron_free_aux(qbh_csr *A)
 {
     qbh_csr::KronSplit &K = A->kron;
     for (void *q : {(void *)K.ia_n, (void *)K.ia_f, (void *)K.wd_n, (void *)K.wd_f, (void *)K.d_xt, (void *)K.d_far, (void *)K.ia_x, (void *)K.xrow,
-                    (void *)K.wd_x, (void *)K.d_cls, (void *)K.c16_n, (void *)K.c16_f, (void *)K.d_chunk_red, (void *)K.d_need})
+                    (void *)K.wd_x, (void *)K.d_cls, (void *)K.c16_n, (void *)K.c16_f, (void *)K.d_chunk_red, (void *)K.d_need, (void *)K.d_send_list, (void *)K.d_vsend, (void *)K.d_vrecv})
         if (q) (void)hipFree(q);
     if (K.own_far) {
         if (K.ja_f) (void)hipFree(K.ja_f);

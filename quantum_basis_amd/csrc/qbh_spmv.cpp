@@ -148,7 +148,7 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
     if (A->opts.wave_walk >= 0) kron_swz = A->opts.wave_walk;
     if (kron_swz == 3) {
         if (!A->d_wctr) kron_swz = 2;
-        else QBH_HIP(hipMemsetAsync(A->d_wctr, 0, (size_t)(comm && K.n_parts > 1 ? qbh::kWctrRegions : 3) * 128 * sizeof(unsigned long long), s));
+        else QBH_HIP(hipMemsetAsync(A->d_wctr, 0, (size_t)(comm && (K.n_parts > 1 || K.sparse) ? qbh::kWctrRegions : 3) * 128 * sizeof(unsigned long long), s));
 #ifdef QBH_XCD_TIMING
         if (A->d_wctr) {                                     // slot 2 of every XCD collects a minimum
             unsigned long long h[3 * 128] = {0};
@@ -174,14 +174,77 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
     // under a communicator: the wire format of this solve (8-byte real parts when the drivers agreed on it), and whether the
     // gather travels in parts (with real parts only through the hook that names the format)
     const int realw = tiled_real(A);
-    const int np_used = (comm && K.n_parts > 1 && (!realw || A->comm.allgather_part_begin_w)) ? K.n_parts : 1;
+    const bool sparse = comm && K.sparse && A->comm.exchange_v != nullptr;      // personalised exchange: only what each peer reads travels
+    const int np_used = sparse ? std::max(1, K.n_parts) : (comm && K.n_parts > 1 && (!realw || A->comm.allgather_part_begin_w)) ? K.n_parts : 1;
+    const int64_t nfb_all = K.t.S / K.t.B, w_edge = K.t.S - nfb_all * K.t.B;
+    // part k of the exchange = bands [pb0, pb1) of every piece, the last part takes the narrow edge band along
+    auto part_bands = [&](int k, int64_t &pb0, int64_t &pb1, bool &with_edge) {
+        pb0 = np_used > 1 ? K.part_band[k] : 0;
+        pb1 = np_used > 1 ? K.part_band[k + 1] : nfb_all;
+        with_edge = k == np_used - 1 && w_edge > 0;
+    };
     if (comm) {
         d2 *send = reinterpret_cast<d2 *>(A->comm.d_xsend);
         if (K.xt_of != (const void *)x) QBH_TRY(qbh::launch_kron_tile(x, send, A->nrows, K.t, s, realw, A->d_flag));
         K.xt_of = nullptr;
         async_gather = A->comm.allgather_begin && A->comm.allgather_wait;
         int hrc = 0;
-        if (np_used > 1) {                                   // band ranges one after another: the far pass follows them (below)
+        if (sparse) {
+            const int npk = A->comm.nranks, me = A->comm.rank;
+            // (1) the rank's own needed major indices straight from its tiled block into the tiled x
+            {
+                qbh::KronPlace po{};
+                po.real = realw;
+                po.src = send;
+                po.dst = K.d_xt;
+                po.nr = npk;
+                po.B = K.t.B;
+                po.S = K.t.S;
+                po.NUg = K.NUg;
+                po.nfb = nfb_all;
+                for (int q = 0; q <= npk; ++q) po.cu[q] = K.rank_cu[q];
+                po.list = K.d_need;
+                for (int q = 0; q <= npk; ++q) po.lo[q] = q <= me ? K.need_lo[me] : K.need_lo[me + 1];     // only the own rank has entries
+                po.band0 = 0;
+                po.band1 = nfb_all + (w_edge > 0 ? 1 : 0);
+                QBH_TRY(qbh::launch_kron_place(po, s));
+            }
+            // (2) per destination: the major indices it reads, packed band-major
+            qbh::KronPack pk{};
+            pk.src = send;
+            pk.dst = K.d_vsend;
+            pk.real = realw;
+            pk.nr = npk;
+            pk.B = K.t.B;
+            pk.S = K.t.S;
+            pk.NUq = K.t.NU;
+            pk.nfb = nfb_all;
+            pk.list = K.d_send_list;
+            for (int q = 0; q <= npk; ++q) pk.lo[q] = K.send_lo[q];
+            for (int q = 0; q < npk; ++q) pk.base[q] = K.send_lo[q] * K.t.S;
+            QBH_TRY(qbh::launch_kron_pack(pk, s));
+            // (3) the pieces, band range after band range
+            std::vector<int64_t> so((size_t)2 * npk), ro((size_t)2 * npk);
+            int64_t rbase = 0;
+            std::vector<int64_t> rb((size_t)npk, 0);
+            for (int q = 0; q < npk; ++q) {
+                rb[(size_t)q] = rbase;
+                if (q != me) rbase += (K.need_lo[q + 1] - K.need_lo[q]) * K.t.S;
+            }
+            for (int k = 0; k < np_used && hrc == 0; ++k) {
+                int64_t pb0, pb1;
+                bool with_edge;
+                part_bands(k, pb0, pb1, with_edge);
+                for (int q = 0; q < npk; ++q) {
+                    const int64_t ns = q == me ? 0 : K.send_lo[q + 1] - K.send_lo[q], nr_ = q == me ? 0 : K.need_lo[q + 1] - K.need_lo[q];
+                    so[(size_t)2 * q] = K.send_lo[q] * K.t.S + pb0 * K.t.B * ns;
+                    so[(size_t)2 * q + 1] = (pb1 - pb0) * K.t.B * ns + (with_edge ? ns * w_edge : 0);
+                    ro[(size_t)2 * q] = rb[(size_t)q] + pb0 * K.t.B * nr_;
+                    ro[(size_t)2 * q + 1] = (pb1 - pb0) * K.t.B * nr_ + (with_edge ? nr_ * w_edge : 0);
+                }
+                hrc = A->comm.exchange_v(A->comm.ctx, k, np_used, so.data(), ro.data(), realw ? 1 : 2, K.d_vsend, K.d_vrecv);
+            }
+        } else if (np_used > 1) {                            // band ranges one after another: the far pass follows them (below)
             for (int k = 0; k < np_used && hrc == 0; ++k) {
                 const int64_t *ol = K.part_off_len.data() + (size_t)k * 2 * (size_t)A->comm.nranks;
                 hrc = realw ? A->comm.allgather_part_begin_w(A->comm.ctx, k, np_used, ol, 1) : A->comm.allgather_part_begin(A->comm.ctx, k, np_used, ol);
@@ -217,6 +280,33 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
     auto place = [&](int k) -> int {
         qbh::KronPlace pa{};
         pa.real = realw;
+        if (sparse) {                                        // the peers' packed pieces: only the listed major indices, compact
+            const int npk = A->comm.nranks, me = A->comm.rank;
+            pa.src = K.d_vrecv;
+            pa.dst = K.d_xt;
+            pa.nr = npk;
+            pa.B = K.t.B;
+            pa.S = K.t.S;
+            pa.NUg = K.NUg;
+            pa.nfb = nfb_all;
+            pa.compact = 1;
+            pa.list = K.d_need;
+            for (int q = 0; q <= npk; ++q) pa.cu[q] = K.rank_cu[q];
+            // the list keeps the own rank's entries in the middle: the peers' ranges are named one by one, the own range is empty
+            int64_t rbase = 0;
+            for (int q = 0; q < npk; ++q) {
+                pa.base[q] = rbase;
+                if (q != me) rbase += (K.need_lo[q + 1] - K.need_lo[q]) * K.t.S;
+            }
+            for (int q = 0; q <= npk; ++q) pa.lo[q] = K.need_lo[q];
+            pa.skip = me;
+            int64_t pb0, pb1;
+            bool with_edge;
+            part_bands(k, pb0, pb1, with_edge);
+            pa.band0 = pb0;
+            pa.band1 = pb1 + (with_edge ? 1 : 0);
+            return qbh::launch_kron_place(pa, s);
+        }
         pa.src = realw ? reinterpret_cast<const d2 *>(A->comm.d_xfull_r) : reinterpret_cast<const d2 *>(A->comm.d_xfull);
         pa.dst = K.d_xt;
         pa.nr = A->comm.nranks;
@@ -379,7 +469,7 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
             QBH_HIP(hipEventRecord(A->ev1, s));
             A->ev_pending = true;
         }
-        if (np_used > 1) {
+        if (np_used > 1 || sparse) {
             // every band range of the far part as soon as its piece of the gathered x is there and has been moved to its place; a
             // block that straddles a range boundary belongs to the later range (the pieces complete in order), its cut groups add
             // up through the atomics
@@ -392,8 +482,8 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
                 if (prof && k == 0) QBH_HIP(hipEventRecord(A->ev2, s));
                 QBH_TRY(place(k));
                 qbh::SpmvArgs fk = f;
-                fk.wd = K.wd_f + K.part_blk[k];
-                fk.n_wb = K.part_blk[k + 1] - K.part_blk[k];
+                fk.wd = K.wd_f + (np_used > 1 ? K.part_blk[k] : 0);
+                fk.n_wb = np_used > 1 ? K.part_blk[k + 1] - K.part_blk[k] : K.nwb_f;
                 fk.wctr = A->d_wctr ? A->d_wctr + (3 + k) * 128 : nullptr;
                 if (fk.n_wb > 0) QBH_TRY(qbh::launch_spmv_wave2(fk, K.tpr_f, 3, (int)std::min<int64_t>(K.grid_f, std::max<int64_t>(fk.n_wb, 8)), s));
             }

@@ -9,6 +9,7 @@
 //        parts=K     qbh_opts.gather_parts;  unsplit=R  rank R keeps its shard unsplit (the ranks must fall back together)
 //        plain=1     complex128 values and vectors (value_dict = 0, real_fast_path = 0)
 //        pipeline=0  qbh_opts.lanczos_pipeline = 0 (one host synchronisation per Lanczos step)
+//        sparse=0    qbh_opts.sparse_gather = 0 (every rank's whole block travels to everybody)
 //        realwire=0  qbh_opts.real_wire = 0 (split shards: 16-byte elements on the links even for a real solve)
 //        ckpt=DIR every=K maxsteps=N   the Lanczos run through qbh_lanczos_ckpt (collective: every rank checkpoints its slice in
 //                    DIR/shard<r>of<P>/), stopped after N new steps when N > 0; then only the Lanczos part is dumped
@@ -63,7 +64,7 @@ int main(int argc, char **argv)
     std::vector<int64_t> cuts(nranks + 1);
     bool uniform = false;
     int64_t kron = 0;
-    int parts = 0, unsplit = -1, plain = 0, realwire = 1, pipeline = 1;
+    int parts = 0, unsplit = -1, plain = 0, realwire = 1, pipeline = 1, sparse = 1;
     std::string dump, ckdir;
     long long every = 10, maxsteps = 0;
     for (int i = 5; i < argc; ++i) {
@@ -75,6 +76,7 @@ int main(int argc, char **argv)
         else if (a.rfind("plain=", 0) == 0) plain = std::atoi(a.c_str() + 6);
         else if (a.rfind("realwire=", 0) == 0) realwire = std::atoi(a.c_str() + 9);
         else if (a.rfind("pipeline=", 0) == 0) pipeline = std::atoi(a.c_str() + 9);
+        else if (a.rfind("sparse=", 0) == 0) sparse = std::atoi(a.c_str() + 7);
         else if (a.rfind("ckpt=", 0) == 0) ckdir = a.substr(5);
         else if (a.rfind("every=", 0) == 0) every = std::atoll(a.c_str() + 6);
         else if (a.rfind("maxsteps=", 0) == 0) maxsteps = std::atoll(a.c_str() + 9);
@@ -101,6 +103,7 @@ int main(int argc, char **argv)
     opts.gather_parts = parts;
     opts.real_wire = realwire;
     opts.lanczos_pipeline = pipeline;
+    opts.sparse_gather = sparse;
     qbh_csr *A = nullptr;
     must(qbh_csr_create_rows(&A, dim, nnz, (int)sym, ia.data(), ja.data(), reinterpret_cast<const qbh_z *>(val.data()), cuts[rank],
                              cuts[rank + 1], &opts), "qbh_csr_create_rows");
@@ -131,7 +134,7 @@ int main(int argc, char **argv)
             o.write((const char *)(hess.data() + maxit), 8 * m);
             o.write((const char *)hess.data(), 8 * m);
         }
-        std::printf("OK %d %d %lld %lld %lld %.17g %d 0 1 kron 0 parts 0 cols16 0 wire 0 need 1\n", rank, nranks, (long long)cuts[rank], (long long)cuts[rank + 1],
+        std::printf("OK %d %d %lld %lld %lld %.17g %d 0 1 kron 0 parts 0 cols16 0 wire 0 need 1 sparse 0\n", rank, nranks, (long long)cuts[rank], (long long)cuts[rank + 1],
                     (long long)m, E0c, conv);
         qbh_vec_free(d_v);
         must(qbh_comm_destroy(A), "qbh_comm_destroy");
@@ -160,9 +163,9 @@ int main(int argc, char **argv)
         o.write((const char *)hess.data(), 8 * m);                 // b_j
         o.write((const char *)vec.data(), 16 * n);
     }
-    std::printf("OK %d %d %lld %lld %lld %.17g %lld %.3e %.15g kron %lld parts %d cols16 %d wire %d need %.4f\n", rank, nranks, (long long)cuts[rank],
+    std::printf("OK %d %d %lld %lld %lld %.17g %lld %.3e %.15g kron %lld parts %d cols16 %d wire %d need %.4f sparse %d\n", rank, nranks, (long long)cuts[rank],
                 (long long)cuts[rank + 1], (long long)m, E0, (long long)mcg, accu, nrm, (long long)inf.kron_minor, inf.gather_parts, inf.kron_cols16,
-                inf.wire_element_bytes, inf.gather_needed_frac);
+                inf.wire_element_bytes, inf.gather_needed_frac, inf.gather_sparse);
     qbh_vec_free(d_v);
     must(qbh_comm_destroy(A), "qbh_comm_destroy");
     qbh_csr_destroy(A);

@@ -67,7 +67,7 @@ def _run(rig, nranks, args, tag):
         ab = np.frombuffer(raw[24:24 + 16 * m].tobytes(), dtype=np.float64)
         vec = np.frombuffer(raw[24 + 16 * m:].tobytes(), dtype=np.complex128)
         res.append({"r0": int(tok[3]), "r1": int(tok[4]), "m": int(m), "mcg": int(mcg), "E0": float(e0), "a": ab[:m], "b": ab[m:], "vec": vec,
-                    "accu": float(tok[8]), "nrm": float(tok[9]), "kron": int(tok[11]), "parts": int(tok[13]), "cols16": int(tok[15]), "wire": int(tok[17]), "need": float(tok[19])})
+                    "accu": float(tok[8]), "nrm": float(tok[9]), "kron": int(tok[11]), "parts": int(tok[13]), "cols16": int(tok[15]), "wire": int(tok[17]), "need": float(tok[19]), "sparse": int(tok[21])})
     return res
 
 
@@ -95,18 +95,21 @@ def _check(rig, res, ref, nranks):
 
 @pytest.mark.parametrize("nranks", [2, 3, 4])
 @pytest.mark.parametrize("parts", [1, 4, 7])
-@pytest.mark.parametrize("realwire", [1, 0])
-def test_split_shards_exchange_tiled_blocks_over_the_native_communicator(rig, nranks, parts, realwire):
+@pytest.mark.parametrize("realwire,sparse", [(1, 1), (0, 1), (1, 0), (0, 0)])
+def test_split_shards_exchange_tiled_blocks_over_the_native_communicator(rig, nranks, parts, realwire, sparse):
     """complex128 shards of whole major indices, each split in place with 2-byte columns in BOTH parts (the one-GPU kernel: the far
     columns index the tiled order of the whole vector, the gathered blocks are moved there piece by piece), the TILED block of
     every rank on the wire -- as 8-byte real parts (qbh_opts.real_wire: real operator, real Lanczos / CG vectors) or as complex128
-    elements -- in 1 / 4 / 7 band ranges; 2 ranks: uniform blocks, 3 and 4 ranks: ragged (70 major indices)."""
-    res = _run(rig, nranks, ["plain=1", "kron=%d" % S_MINOR, "parts=%d" % parts, "realwire=%d" % realwire] + (["uniform"] if nranks == 2 else []),
-               "kron_%d_%d_%d" % (nranks, parts, realwire))
+    elements, whole (all-gather) or only what each peer reads (qbh_opts.sparse_gather: the personalised exchange) -- in 1 / 4 / 7 band ranges; 2 ranks: uniform blocks, 3 and 4 ranks: ragged (70 major indices)."""
+    res = _run(rig, nranks, ["plain=1", "kron=%d" % S_MINOR, "parts=%d" % parts, "realwire=%d" % realwire, "sparse=%d" % sparse] + (["uniform"] if nranks == 2 else []),
+               "kron_%d_%d_%d_%d" % (nranks, parts, realwire, sparse))
     assert all(r["kron"] == S_MINOR and r["parts"] == parts and r["cols16"] == 3 and r["wire"] == (8 if realwire else 16) for r in res), res
     # only the major indices a shard's far / cross entries read are moved into its tiled x: on the 4 x 2 lattice every up configuration
     # hops into every rank's range, so the share stays high here (C3 with 8 ranks: 0.42-0.68, tools/needed_columns.py)
     assert all(0.3 < r["need"] <= 1.0 for r in res), [r["need"] for r in res]
+    # sparse = 1: the exchange is personalised -- every rank sends each peer only the major indices that peer reads (packed per
+    # destination, same band ranges), the receiver moves them to their place; sparse = 0: whole blocks to everybody
+    assert all(r["sparse"] == sparse for r in res), res
     _check(rig, res, _reference(rig, True), nranks)
 
 
