@@ -565,6 +565,7 @@ def main():
     ap.add_argument("--cols16", type=int, default=1, help="qbh_opts.kron_cols16: 1 (library default) the parts of a split operator keep 2-byte columns, 0 int32 columns")
     ap.add_argument("--deterministic", action="store_true", help="qbh_opts.deterministic: static walks, nothing timed at creation (bit-identical a_j / b_j from run to run)")
     ap.add_argument("--no-pipeline", action="store_true", help="qbh_opts.lanczos_pipeline = 0: one host synchronisation per Lanczos step (the loop of ABI <= 501), for A/B runs")
+    ap.add_argument("--no-partition", action="store_true", help="N > 1, hubbard workloads: keep the up configurations in ascending pattern order (qbh_opts.major_partition = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed run to convergence (E0)")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)
@@ -762,6 +763,10 @@ def main():
                            nnz_per_block=args.npb, xcd_swizzle=args.swizzle,
                            value_dict=value_dict, real_fast_path=real_fp, profile=1, deterministic=1 if args.deterministic else 0,
                            kron_cols16=args.cols16, lanczos_pipeline=0 if args.no_pipeline else 1)
+        if world > 1 and W["kind"] == "hubbard" and not args.matrix_free and not args.host_csr and value_dict == 0 and not args.no_partition:
+            # the up configurations in the order of a recursive bisection of the hop graph into `world` parts: every rank's far part then reads
+            # far fewer of its peers' major indices, which is what the personalised exchange carries (qbh_opts.major_partition)
+            opts.major_partition = world
         opts.sector_cut = args.site_cut if world == 1 else -1          # qbh_opts.sector_cut: 0 = the library picks the cut of a heisenberg sector, -1 never
         t_gen = time.time()
         hint = (not args.no_basis_hint) and W["kind"] == "hubbard" and world == 1 and value_dict == 0
@@ -943,7 +948,7 @@ def main():
         out["exchange"] = {"bytes_received_per_gpu_per_spmv": int(elem * dim * (world - 1) / world * (need_frac if sparse_x else 1.0)), "element_bytes": elem,
                            # personalised exchange (qbh_opts.sparse_gather): every rank sends each peer only the major indices that peer's far / cross
                            # entries read; needed_frac_rank0 = that share of the all-gather for THIS rank (it differs from rank to rank)
-                           "personalised": sparse_x, "needed_frac_rank0": round(need_frac, 4),
+                           "personalised": sparse_x, "needed_frac_rank0": round(need_frac, 4), "major_partition": int(A.info().major_partition),
                            "ms_per_gather": round(head["ms_gather"], 4) if head["ms_gather"] > 0 else None,
                            "gathers": head["n_gather"],
                            # > 1: the tiled blocks travel as that many band ranges and the far pass follows range by range; the

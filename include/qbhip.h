@@ -193,6 +193,16 @@ typedef struct qbh_opts {
                                 peer only those (packed per destination, in the same band ranges as the gather in parts); the
                                 receiver moves them to their place in its tiled x.  C3, 8 ranks, generator's order: 42-68 % of the
                                 all-gather's bytes.  0: every rank's whole block travels to everybody                           */
+    int     major_partition; /* [0] qbh_gen_hubbard: P > 1 orders the up configurations (the MAJOR index of the product basis) so that P
+                                consecutive blocks of them -- the row shards of dist.kron_row_cuts / (q * NU) / P -- are the parts of
+                                a recursive spectral bisection of the up-hop graph instead of ranges of ascending bit patterns: a
+                                rank's far part then reads far fewer of its peers' major indices (C3, 8 ranks: 0.30 instead of
+                                0.42-0.68 of the all-gather; 4 ranks 0.45 instead of 0.93; tools/needed_columns.py), which is what the
+                                personalised exchange carries.  Eigenvalues do not depend on the order; vectors of such an operator
+                                are in ITS order (qbh_csr_info.major_partition, qbh_csr_major_order gives the map), except that
+                                qbh_vec_randomize still draws element (u, d) from position (generator's u) * S + d of the stream, so
+                                the start vector is the same physical vector for every P.  Deterministic (every rank computes the
+                                same order from the same tables).  0: ascending bit patterns                                    */
     int     sector_cut;      /* [0] qbh_gen_heisenberg, whole operator, complex128 values (value_dict = 0, real_fast_path = 0), large enough
                                 for the split (kron_split = 1: >= 1e8 nonzeros; 2: any) and no basis_kind named: the sites are cut into
                                 h LOW sites and the rest, the operator is held class-major (class = particles among the high sites) and
@@ -279,6 +289,7 @@ typedef struct qbh_csr_info {
     int     kron_table_kernel;               /* 1: the coded split was recognised as T (x) 1 + 1 (x) T' + D and the all-real SpMV runs the table kernel */
     int     wire_element_bytes;              /* communicator attached: bytes per element of x the LAST gather put on the links -- 16 (complex128) or 8
                                                 (real parts only: qbh_opts.real_wire on split shards, the real fast path on plain ones); 0 before the first */
+    int     major_partition;                 /* > 1: the major indices are in the partition order of qbh_opts.major_partition (that many parts) */
     int     gather_sparse;                   /* 1: the exchange is personalised (qbh_opts.sparse_gather): only the needed major indices travel */
     double  gather_needed_frac;              /* split shard under a communicator: the share of its peers' major indices that its far / cross entries read
                                                 (only those are moved into the tiled x; a sparse exchange would carry this share of the all-gather); else 1 */
@@ -579,6 +590,10 @@ int qbh_sync(const qbh_csr *A);
 /* Change one of the options that do not touch the stored form of the operator, after creation (everything else in qbh_opts is
  * fixed when the handle is made): "lanczos_pipeline", "profile", "tile_fold".  QBH_EINVAL for any other name. */
 int qbh_csr_set_option(qbh_csr *A, const char *name, int value);
+/* qbh_opts.major_partition: generator_major[i] = the major index the generator's ascending order gives the up configuration that
+ * this operator holds at major index i (n_major entries, the same on every rank).  QBH_EUNSUPP for an operator in the generator's
+ * own order. */
+int qbh_csr_major_order(const qbh_csr *A, int32_t *generator_major, int64_t n_major);
 
 /* ------------------------------------------------ synthetic operators ---- */
 /* Measurement harness: device-side assembly of the benchmark Hamiltonians directly into

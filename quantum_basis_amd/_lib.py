@@ -40,7 +40,7 @@ class Opts(C.Structure):
                 ("kron_sliced", C.c_int), ("kron_band", C.c_int), ("kron_cross_in_near", C.c_int), ("kron_coded", C.c_int),
                 ("kron_uniform", C.c_int), ("gather_parts", C.c_int), ("wave_walk", C.c_int), ("tile_fold", C.c_int),
                 ("autotune", C.c_int), ("shard_split", C.c_int), ("real_forms", C.c_int), ("basis_detect", C.c_int),
-                ("sector_orbit", C.c_int), ("lanczos_pipeline", C.c_int), ("real_wire", C.c_int), ("sparse_gather", C.c_int), ("sector_cut", C.c_int)]
+                ("sector_orbit", C.c_int), ("lanczos_pipeline", C.c_int), ("real_wire", C.c_int), ("sparse_gather", C.c_int), ("major_partition", C.c_int), ("sector_cut", C.c_int)]
 
 
 class CsrInfo(C.Structure):
@@ -52,7 +52,7 @@ class CsrInfo(C.Structure):
                 ("kron_inplace", C.c_int), ("tuned", C.c_int), ("tune_ms_rows", C.c_double), ("tune_ms_wave", C.c_double),
                 ("basis_internal", C.c_int), ("kron_classes", C.c_int), ("kron_cross_nnz", C.c_int64), ("gather_parts", C.c_int),
                 ("kron_cols16", C.c_int), ("basis_detected", C.c_int), ("basis_n_sites", C.c_int), ("basis_n_up", C.c_int),
-                ("basis_n_dn", C.c_int), ("basis_detect_ms", C.c_double), ("kron_table_kernel", C.c_int), ("wire_element_bytes", C.c_int), ("gather_sparse", C.c_int), ("gather_needed_frac", C.c_double)]
+                ("basis_n_dn", C.c_int), ("basis_detect_ms", C.c_double), ("kron_table_kernel", C.c_int), ("wire_element_bytes", C.c_int), ("major_partition", C.c_int), ("gather_sparse", C.c_int), ("gather_needed_frac", C.c_double)]
 
 
 class LanczosRow(C.Structure):
@@ -106,7 +106,7 @@ EXPORTS = [
     "qbh_mopr_spin_dev", "qbh_mopr_onebody_dev", "qbh_mopr_terms_dev", "qbh_mopr_sz_repr_dev", "qbh_mopr_flip_repr_dev",
     "qbh_crc32", "qbh_vec_disk_write", "qbh_vec_disk_read", "qbh_ckpt_lanczos_update", "qbh_ckpt_lanczos_init", "qbh_lanczos_ckpt",
     "qbh_ckpt_cg_update", "qbh_ckpt_cg_init", "qbh_ckpt_cg_clean", "qbh_eigenvec_cg_ckpt",
-    "qbh_csr_set_comm", "qbh_rccl_unique_id", "qbh_comm_create_rccl", "qbh_comm_destroy", "qbh_get_stats", "qbh_sync", "qbh_csr_set_option",
+    "qbh_csr_set_comm", "qbh_rccl_unique_id", "qbh_comm_create_rccl", "qbh_comm_destroy", "qbh_get_stats", "qbh_sync", "qbh_csr_set_option", "qbh_csr_major_order",
     "qbh_gen_hubbard", "qbh_mf_hubbard", "qbh_gen_heisenberg", "qbh_mf_heisenberg", "qbh_gen_heisenberg_repr", "qbh_gen_hubbard_repr", "qbh_gen_heisenberg_repr_cuts", "qbh_gen_hubbard_repr_cuts", "qbh_mf_hubbard_repr", "qbh_mopr_diag_hubrepr_dev", "qbh_mopr_c_hubrepr_dev", "qbh_csr_download", "qbh_csr_reference_order", "qbh_csr_set_basis",
 ]
 
@@ -200,6 +200,7 @@ def lib():
     L.qbh_get_stats.argtypes = [vp, C.POINTER(Stats), C.c_int]
     L.qbh_sync.argtypes = [vp]
     L.qbh_csr_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.qbh_csr_major_order.argtypes = [vp, vp, i64]
     L.qbh_gen_hubbard.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, vp, dbl, dbl,
                                   i64, i64, C.POINTER(Opts)]
     L.qbh_mf_hubbard.argtypes = L.qbh_gen_hubbard.argtypes

@@ -185,6 +185,7 @@ void qbh::opts_builtin(qbh_opts *o)
     o->real_wire = 1;
     o->sector_cut = 0;
     o->sparse_gather = 1;
+    o->major_partition = 0;
     o->kron_minor = 0;
     o->deterministic = 0;
     o->basis_kind = QBH_BASIS_NONE;
@@ -724,6 +725,7 @@ extern "C" void qbh_csr_destroy(qbh_csr *A)
     for (auto &o : A->ev_old)
         for (hipEvent_t e : o.e)
             if (e) (void)hipEventDestroy(e);
+    if (A->d_major_inv) (void)hipFree(A->d_major_inv);
     if (A->lz.d_buf) (void)hipFree(A->lz.d_buf);
     if (A->lz.d_state) (void)hipFree(A->lz.d_state);
     if (A->lz.h_log) (void)hipHostFree(A->lz.h_log);
@@ -1017,6 +1019,7 @@ extern "C" int qbh_csr_get_info(const qbh_csr *A, qbh_csr_info *info)
     info->kron_cols16 = 0;
     info->kron_cross_nnz = 0;
     info->wire_element_bytes = A->has_comm ? A->wire_bytes_last : 0;
+    info->major_partition = A->d_major_inv ? A->major_parts : 0;
     info->gather_sparse = (A->has_comm && A->kron.active && A->kron.comm_tiled && A->kron.sparse) ? 1 : 0;
     info->gather_needed_frac = (A->has_comm && A->kron.active && A->kron.comm_tiled) ? A->kron.need_frac : 1.0;
     info->gather_parts = A->has_comm ? ((A->kron.active && A->kron.comm_tiled) ? A->kron.n_parts : 1) : 0;
@@ -1105,6 +1108,19 @@ extern "C" int qbh_csr_set_option(qbh_csr *A, const char *name, int value)
         qbh::set_error("qbh_csr_set_option: '%s' is not an option that can change after creation", name);
         return QBH_EINVAL;
     }
+    return QBH_OK;
+}
+
+extern "C" int qbh_csr_major_order(const qbh_csr *A, int32_t *generator_major, int64_t n_major)
+{
+    if (!A || !generator_major) return QBH_EINVAL;
+    if (!A->d_major_inv) {
+        qbh::set_error("qbh_csr_major_order: the operator is in the generator's own order");
+        return QBH_EUNSUPP;
+    }
+    if (n_major != A->major_n) return QBH_EINVAL;
+    Bind bind(A);
+    QBH_HIP(hipMemcpy(generator_major, A->d_major_inv, (size_t)n_major * sizeof(int32_t), hipMemcpyDeviceToHost));
     return QBH_OK;
 }
 
@@ -1250,6 +1266,9 @@ extern "C" int qbh_vec_randomize(const qbh_csr *Ac, qbh_z *d_x, uint32_t seed)
         if (!A->basis.d_stage) QBH_HIP(qbh::dev_alloc(&A->basis.d_stage, (size_t)A->nrows * sizeof(d2)));
         xr = A->basis.d_stage;
     }
+    if (A->d_major_inv)      // partition order of the major indices: element (u, d) is drawn at position (generator's u) * S + d of the stream
+        QBH_TRY(qbh::launch_randomize(xr, nullptr, A->nrows, 0, seed, A->d_partials, A->stream, A->d_major_inv + A->row_offset / A->major_S, A->major_S));
+    else
     QBH_TRY(qbh::launch_randomize(xr, nullptr, A->nrows, A->has_comm ? A->row_offset : 0, seed, A->d_partials, A->stream));
     double sq = 0.0;
     QBH_TRY(finish_reduction(A, qbh::blas_grid(nruns), 1, &sq));

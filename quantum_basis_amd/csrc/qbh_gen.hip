@@ -94,6 +94,105 @@ void build_hops(int L, int n, const std::map<std::pair<int, int>, double> &bonds
     }
 }
 
+// Recursive spectral bisection of the hop graph of one species into `parts` parts of sizes (q + 1) N / parts - q N / parts (the
+// major-index ranges of dist.kron_row_cuts): at every level the Fiedler vector of the sub-graph by power iteration on c I - L
+// with the constant vector projected out (600 sweeps; plain double arithmetic in a fixed order: every rank computes the same
+// numbers), nodes sorted by it and cut at the size the left ranks own.  Inside a part the nodes keep their ascending order.
+// inv[new index] = old index.
+void partition_majors(const HopTable &H, int parts, std::vector<int32_t> &inv)
+{
+    const int64_t N = (int64_t)H.cfg.size();
+    std::vector<int64_t> cu((size_t)parts + 1);
+    for (int q = 0; q <= parts; ++q) cu[(size_t)q] = (int64_t)q * N / parts;
+    std::vector<int32_t> order((size_t)N), pos((size_t)N, -1);
+    for (int64_t i = 0; i < N; ++i) order[(size_t)i] = (int32_t)i;
+    struct Job { int64_t lo, hi; int q0, q1; };
+    std::vector<Job> stack{{0, N, 0, parts}};
+    std::vector<double> f, g;
+    while (!stack.empty()) {
+        const Job j = stack.back();
+        stack.pop_back();
+        if (j.q1 - j.q0 <= 1) {
+            std::sort(order.begin() + j.lo, order.begin() + j.hi);        // ascending patterns inside a part
+            continue;
+        }
+        const int64_t n = j.hi - j.lo;
+        for (int64_t i = 0; i < n; ++i) pos[(size_t)order[(size_t)(j.lo + i)]] = (int32_t)i;
+        f.assign((size_t)n, 0.0);
+        g.assign((size_t)n, 0.0);
+        uint64_t lcg = 88172645463325252ULL;
+        double cmax = 1.0;
+        for (int64_t i = 0; i < n; ++i) {
+            lcg = lcg * 6364136223846793005ULL + 1442695040888963407ULL;
+            f[(size_t)i] = (double)(lcg >> 11) / 9007199254740992.0 - 0.5;
+            const int32_t u = order[(size_t)(j.lo + i)];
+            cmax = std::max(cmax, 2.0 * (double)(H.ptr[u + 1] - H.ptr[u]));
+        }
+        for (int sweep = 0; sweep < 600; ++sweep) {
+            double mean = 0.0;
+            for (int64_t i = 0; i < n; ++i) mean += f[(size_t)i];
+            mean /= (double)n;
+            double nrm = 0.0;
+            for (int64_t i = 0; i < n; ++i) {
+                const int32_t u = order[(size_t)(j.lo + i)];
+                double deg = 0.0, sum = 0.0;
+                for (int32_t e = H.ptr[u]; e < H.ptr[u + 1]; ++e) {
+                    const int32_t p = pos[(size_t)H.tgt[(size_t)e]];
+                    if (p >= 0 && H.tgt[(size_t)e] != u) {
+                        deg += 1.0;
+                        sum += f[(size_t)p] - mean;
+                    }
+                }
+                const double v = (cmax - deg) * (f[(size_t)i] - mean) + sum;       // (c I - L)(f - mean)
+                g[(size_t)i] = v;
+                nrm += v * v;
+            }
+            nrm = std::sqrt(nrm);
+            if (!(nrm > 0.0)) break;
+            for (int64_t i = 0; i < n; ++i) f[(size_t)i] = g[(size_t)i] / nrm;
+        }
+        for (int64_t i = 0; i < n; ++i) pos[(size_t)order[(size_t)(j.lo + i)]] = -1;
+        std::vector<std::pair<double, int32_t>> key((size_t)n);
+        for (int64_t i = 0; i < n; ++i) key[(size_t)i] = {f[(size_t)i], order[(size_t)(j.lo + i)]};
+        std::sort(key.begin(), key.end());
+        for (int64_t i = 0; i < n; ++i) order[(size_t)(j.lo + i)] = key[(size_t)i].second;
+        const int qm = j.q0 + (j.q1 - j.q0) / 2;
+        const int64_t mid = j.lo + (cu[(size_t)qm] - cu[(size_t)j.q0]);
+        stack.push_back({j.lo, mid, j.q0, qm});
+        stack.push_back({mid, j.hi, qm, j.q1});
+    }
+    inv = order;
+}
+
+// the hop table with its configurations re-labelled: new index i holds old configuration inv[i]; every list sorted by new target
+void permute_hops(HopTable &H, const std::vector<int32_t> &inv)
+{
+    const size_t N = H.cfg.size();
+    std::vector<int32_t> fwd(N);
+    for (size_t i = 0; i < N; ++i) fwd[(size_t)inv[i]] = (int32_t)i;
+    HopTable P;
+    P.cfg.resize(N);
+    P.ptr.assign(N + 1, 0);
+    P.nlo.assign(N, 0);
+    P.tgt.reserve(H.tgt.size());
+    P.val.reserve(H.val.size());
+    std::vector<std::pair<int32_t, double>> row;
+    for (size_t i = 0; i < N; ++i) {
+        const int32_t o = inv[i];
+        P.cfg[i] = H.cfg[(size_t)o];
+        row.clear();
+        for (int32_t e = H.ptr[o]; e < H.ptr[o + 1]; ++e) row.emplace_back(fwd[(size_t)H.tgt[(size_t)e]], H.val[(size_t)e]);
+        std::sort(row.begin(), row.end());
+        for (const auto &e : row) {
+            P.tgt.push_back(e.first);
+            P.val.push_back(e.second);
+            if (e.first < (int32_t)i) P.nlo[i]++;
+        }
+        P.ptr[i + 1] = (int32_t)P.tgt.size();
+    }
+    H = std::move(P);
+}
+
 struct HubDev {
     const uint32_t *cfg_u, *cfg_d;
     const int32_t *ptr_u, *tgt_u, *nlo_u, *ptr_d, *tgt_d, *nlo_d;
@@ -332,6 +431,13 @@ extern "C" int qbh_gen_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, i
         set_error("qbh_gen_hubbard: bad row range");
         return QBH_EINVAL;
     }
+    // qbh_opts.major_partition: the up configurations in the order of a recursive spectral bisection into that many parts
+    std::vector<int32_t> major_inv;                    // [new major index] -> the generator's (ascending pattern) index
+    const int n_parts = (opts && opts->major_partition > 1 && (int64_t)opts->major_partition <= Nu) ? opts->major_partition : 0;
+    if (n_parts > 1) {
+        partition_majors(hu, n_parts, major_inv);
+        permute_hops(hu, major_inv);
+    }
     std::vector<int64_t> pre_d((size_t)Nd + 1, 0), base_u((size_t)Nu + 1, 0);
     for (int64_t d = 0; d < Nd; ++d) pre_d[d + 1] = pre_d[d] + (hd.ptr[d + 1] - hd.ptr[d]);
     for (int64_t u = 0; u < Nu; ++u)
@@ -396,7 +502,22 @@ extern "C" int qbh_gen_hubbard(qbh_csr **out, int n_sites, int n_up, int n_dn, i
     o2.basis_detect = 0;
     if (o2.basis_kind == QBH_BASIS_REF_FERMION2) o2.basis_kind = QBH_BASIS_NONE;      // the generator's order is species-major already: a host's hint about ITS arrays does not describe it
     if (o2.kron_minor == 0) o2.kron_minor = Nd;        // index = up * Nd + down; kron_build checks that a shard is made of whole up blocks
-    return qbh_csr_create_device(out, nrows, dim, row_begin, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, &o2);
+    const int crc = qbh_csr_create_device(out, nrows, dim, row_begin, nnz, d_ia, d_ja, reinterpret_cast<qbh_z *>(d_val), 1, &o2);
+    if (crc == QBH_OK && n_parts > 1) {               // the map stays with the handle: qbh_vec_randomize, qbh_csr_major_order
+        qbh_csr *A = *out;
+        if (qbh::dev_alloc(&A->d_major_inv, (size_t)Nu * sizeof(int32_t)) != hipSuccess ||
+            hipMemcpy(A->d_major_inv, major_inv.data(), (size_t)Nu * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            qbh_csr_destroy(A);
+            *out = nullptr;
+            set_error("qbh_gen_hubbard: no room for the major-index map");
+            return QBH_ENOMEM;
+        }
+        A->major_n = Nu;
+        A->major_S = Nd;
+        A->major_parts = n_parts;
+    }
+    return crc;
 }
 
 namespace {

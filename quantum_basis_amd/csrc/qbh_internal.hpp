@@ -401,7 +401,7 @@ int launch_scal_re(double a, double *x, int64_t n, hipStream_t s);
 int launch_xpby(const d2 *x, double b, d2 *y, int64_t n, double *yr, int *flag, hipStream_t s);            // y = x + b*y
 int launch_cg_update(d2 alpha, const d2 *p, const d2 *pp, d2 *v, d2 *r, int64_t n, double *partials,
                      hipStream_t s, const double *delta_dev = nullptr, double accu2 = 0.0);                                               // v+=a p; r-=a pp; |r|^2
-int launch_randomize(d2 *x, double *xr, int64_t n, int64_t global_offset, uint32_t seed, double *partials, hipStream_t s);
+int launch_randomize(d2 *x, double *xr, int64_t n, int64_t global_offset, uint32_t seed, double *partials, hipStream_t s, const int32_t *major_inv = nullptr, int64_t S = 0);
 int launch_fill_const(d2 *x, int64_t n, double re, hipStream_t s);
 int launch_max_rowlen(const int64_t *d_ia, int64_t nrows, int64_t *d_out, hipStream_t s);
 int blas_grid(int64_t n);
@@ -801,6 +801,10 @@ struct qbh_csr {
     qbh_comm comm{};
     std::vector<int64_t> comm_cuts;          // copy of comm.row_cuts (ragged partition) or empty
     int64_t  comm_full = 0;                  // elements of d_xfull: nranks * nblk (uniform) or ncols (ragged)
+    // qbh_opts.major_partition (qbh_gen_hubbard): the generator's major index of every major index of this operator, [major_n]
+    int32_t *d_major_inv = nullptr;
+    int64_t  major_n = 0, major_S = 0;
+    int      major_parts = 0;
     int      wire_bytes_last = 0;            // bytes per element the last gather carried (qbh_csr_info.wire_element_bytes)
     struct qbh_native_comm *native = nullptr; // RCCL communicator owned by the handle (qbh_comm_create_rccl)
 

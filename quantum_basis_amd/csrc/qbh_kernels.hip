@@ -2779,8 +2779,10 @@ __device__ __forceinline__ uint64_t lehmer_pow(uint64_t e)
 }
 
 // xr != nullptr: the vector is stored as packed doubles (qbh_vec_randomize_real), same stream of numbers
+// major_inv != nullptr (qbh_opts.major_partition): local element j = (local major j / S, minor j % S) is drawn at position
+// major_inv[j / S] * S + j % S of the stream -- the same physical vector whatever order the major indices are held in
 __global__ __launch_bounds__(kBlock) void k_randomize(d2 *x, double *xr, int64_t n, int64_t global_offset, uint32_t seed,
-                                                      double *partials)
+                                                      double *partials, const int32_t *major_inv, int64_t S)
 {
 #pragma clang fp contract(off)
     __shared__ double red[4];
@@ -2792,9 +2794,11 @@ __global__ __launch_bounds__(kBlock) void k_randomize(d2 *x, double *xr, int64_t
     if (s0 == 0) s0 = 1;
     for (int64_t run = (int64_t)blockIdx.x * kBlock + threadIdx.x; run < nruns; run += stride) {
         const int64_t j0 = run * kRandRun;
-        uint64_t state = (s0 * lehmer_pow((uint64_t)(global_offset + j0))) % M;   // state before draw j0+1
+        auto pos = [&](int64_t j) -> uint64_t { return major_inv ? (uint64_t)((int64_t)major_inv[j / S] * S + j % S) : (uint64_t)(global_offset + j); };
+        uint64_t state = (s0 * lehmer_pow(pos(j0))) % M;   // state before the draw of element j0
         const int64_t j1 = (j0 + kRandRun < n) ? j0 + kRandRun : n;
         for (int64_t j = j0; j < j1; ++j) {
+            if (major_inv != nullptr && j > j0 && j % S == 0) state = (s0 * lehmer_pow(pos(j))) % M;      // a new major index: another stretch of the stream
             state = (state * 16807ULL) % M;
             const double t = (double)state * (1.0 / 2147483647.0);
             d2 v;
@@ -2809,11 +2813,12 @@ __global__ __launch_bounds__(kBlock) void k_randomize(d2 *x, double *xr, int64_t
     if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
 }
 
-int launch_randomize(d2 *x, double *xr, int64_t n, int64_t global_offset, uint32_t seed, double *partials, hipStream_t s)
+int launch_randomize(d2 *x, double *xr, int64_t n, int64_t global_offset, uint32_t seed, double *partials, hipStream_t s, const int32_t *major_inv,
+                     int64_t S)
 {
     const int64_t nruns = (n + kRandRun - 1) / kRandRun;
     hipLaunchKernelGGL(k_randomize, dim3(blas_grid(nruns)), dim3(kBlock), 0, s, x, xr, n, global_offset, seed,
-                       partials);
+                       partials, major_inv, S);
     QBH_HIP(hipGetLastError());
     return QBH_OK;
 }

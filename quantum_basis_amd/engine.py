@@ -356,6 +356,16 @@ class csr_mat:
     def sync(self):
         check(lib().qbh_sync(self.handle), "qbh_sync")
 
+    def major_order(self):
+        """qbh_csr_major_order: for an operator generated with qbh_opts.major_partition, the generator's (ascending pattern) major index
+        of every major index of this operator."""
+        n = int(self.info().ncols // self.info().kron_minor) if self.info().kron_minor else 0
+        if n == 0:
+            raise ValueError("major_order: not a product-basis operator")
+        out = np.empty(n, dtype=np.int32)
+        check(lib().qbh_csr_major_order(self.handle, _p(out), C.c_int64(n)), "qbh_csr_major_order")
+        return out
+
     def set_option(self, name, value):
         """qbh_csr_set_option: lanczos_pipeline / profile / tile_fold on an existing operator."""
         check(lib().qbh_csr_set_option(self.handle, name.encode(), int(value)), "qbh_csr_set_option")
