@@ -720,7 +720,9 @@ int qbh_mopr_c_hubrepr_dev(int n_sites, int n_up_old, int n_dn_old, int species,
  * H_ref = P D H_gen D P^T.  Full storage, columns ascending.  *out is a new handle; A is left untouched. */
 int qbh_csr_reference_order(qbh_csr **out, const qbh_csr *A, int kind, int n_sites, int n_up, int n_dn, const qbh_opts *opts);
 /* Copy the assembled shard back to host arrays (tests, CPU-baseline sample).  Any output
- * pointer may be NULL.  Rows [r0, r1) local to the shard; ia is rebased to 0. */
+ * pointer may be NULL.  Rows [r0, r1) local to the shard; ia is rebased to 0.  An operator held in another order than the
+ * caller's (qbh_csr_info.basis_internal != 0: a named / detected basis, a cut sector) returns the CALLER's rows, columns and
+ * signs through its map (host-side from the whole internal operator: 20 B of host memory per nonzero, QBH_ENOMEM otherwise). */
 int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1,
                      int64_t *ia /* [r1-r0+1] */, int32_t *ja, qbh_z *val);
 

@@ -1311,6 +1311,8 @@ int download_part(const qbh_csr *A, const int64_t *d_ia, const int32_t *d_ja, co
 }
 }  // namespace qbhapi
 
+static int download_rows_internal(const qbh_csr *A, int64_t r0, int64_t r1, int64_t *ia, int32_t *ja, qbh_z *val);
+
 extern "C" int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1, int64_t *ia, int32_t *ja, qbh_z *val)
 {
     if (!A || r0 < 0 || r1 < r0 || r1 > A->nrows) return QBH_EINVAL;
@@ -1318,11 +1320,67 @@ extern "C" int qbh_csr_download(const qbh_csr *A, int64_t r0, int64_t r1, int64_
         qbh::set_error("qbh_csr_download: the operator is matrix-free (no stored CSR)");
         return QBH_EUNSUPP;
     }
-    if (A->basis.kind != 0) {
-        qbh::set_error("qbh_csr_download: the operator is held in another basis order than the caller's (qbh_opts.basis_kind); "
-                       "its rows are not the caller's rows");
+    if (A->basis.kind == 0) return download_rows_internal(A, r0, r1, ia, ja, val);
+    // The operator is held in another order than the caller's (a named / detected basis, a cut sector): the CALLER's rows come
+    // back -- row r = internal row g(r), column c -> the caller index of that internal column, value times the two signs, columns
+    // ascending again (H_caller[r, c] = s_r s_c H_internal[g(r), g(c)]).  Done on the host from the whole internal operator: a
+    // seam for tests and tools, 20 B per nonzero of host memory (QBH_ENOMEM when that does not fit).
+    if (A->nrows != A->ncols) {
+        qbh::set_error("qbh_csr_download: a basis map on a row shard");
         return QBH_EUNSUPP;
     }
+    try {
+        const int64_t n = A->nrows;
+        std::vector<int64_t> iai((size_t)n + 1);
+        QBH_TRY(download_rows_internal(A, 0, n, iai.data(), nullptr, nullptr));
+        const int64_t nnz_i = iai[(size_t)n];
+        std::vector<int32_t> jai((size_t)std::max<int64_t>(nnz_i, 1));
+        std::vector<qbh_z> vai(val ? (size_t)std::max<int64_t>(nnz_i, 1) : 0);
+        QBH_TRY(download_rows_internal(A, 0, n, iai.data(), jai.data(), val ? vai.data() : nullptr));
+        std::vector<uint32_t> hm((size_t)n);
+        {
+            Bind bind(A);
+            QBH_HIP(hipMemcpy(hm.data(), A->basis.d_map, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        }
+        std::vector<int32_t> inv((size_t)n);
+        for (int64_t r = 0; r < n; ++r) inv[(size_t)(hm[(size_t)r] & 0x7FFFFFFFu)] = (int32_t)r;
+        std::vector<std::pair<int32_t, qbh_z>> row;
+        int64_t q = 0;
+        for (int64_t r = r0; r < r1; ++r) {
+            const uint32_t m = hm[(size_t)r];
+            const int64_t g = m & 0x7FFFFFFFu;
+            const bool sr = (m >> 31) != 0;
+            row.clear();
+            for (int64_t k = iai[(size_t)g]; k < iai[(size_t)g + 1]; ++k) {
+                const int32_t c = inv[(size_t)jai[(size_t)k]];
+                qbh_z v{0.0, 0.0};
+                if (val) {
+                    v = vai[(size_t)k];
+                    if (sr != ((hm[(size_t)c] >> 31) != 0)) {
+                        v.re = -v.re;
+                        v.im = -v.im;
+                    }
+                }
+                row.emplace_back(c, v);
+            }
+            std::sort(row.begin(), row.end(), [](const std::pair<int32_t, qbh_z> &a, const std::pair<int32_t, qbh_z> &b) { return a.first < b.first; });
+            if (ia) ia[r - r0] = q;
+            for (const auto &e : row) {
+                if (ja) ja[q] = e.first;
+                if (val) val[q] = e.second;
+                ++q;
+            }
+        }
+        if (ia) ia[r1 - r0] = q;
+    } catch (const std::bad_alloc &) {
+        qbh::set_error("qbh_csr_download: no host memory for the whole internal operator (basis-mapped download)");
+        return QBH_ENOMEM;
+    }
+    return QBH_OK;
+}
+
+static int download_rows_internal(const qbh_csr *A, int64_t r0, int64_t r1, int64_t *ia, int32_t *ja, qbh_z *val)
+{
     Bind bind(A);
     QBH_HIP(hipStreamSynchronize(A->stream));
     if (A->kron.active) {                    // split in place: the rows are merged back on the device (columns ascending)

@@ -71,8 +71,18 @@ def test_reference_ordered_host_arrays_run_on_the_split_with_the_hint_and_withou
     assert abs(r.E0 - ro["E0"]) <= 1e-11 * abs(ro["E0"])
     assert abs(abs(np.vdot(r.eigenvecs, ro["eigenvecs"])) - 1.0) < 1e-8
     assert np.abs(O.multmv(r.eigenvecs) - r.E0 * r.eigenvecs).max() < 1e-7
-    with pytest.raises(_lib.QbhError):                                 # its rows are not the caller's rows
-        A.download()
+    # qbh_csr_download gives the CALLER's rows back (through the map: H_caller[r, c] = s_r s_c H_internal[g(r), g(c)]): the full-storage
+    # form of the arrays that went in, entry by entry -- and row ranges of it
+    fia, fja, fval = A.download()
+    rows = np.repeat(np.arange(dim), np.diff(ia))
+    off = ja > rows                                                    # the stored strict upper triangle, mirrored (explicit zeros kept)
+    er, ec, ev = np.concatenate([rows, ja[off]]), np.concatenate([ja, rows[off]]), np.concatenate([val, np.conj(val[off])])
+    order = np.lexsort((ec, er))
+    assert np.array_equal(fia, np.concatenate([[0], np.cumsum(np.bincount(er, minlength=dim))]))
+    assert np.array_equal(fja, ec[order]) and np.array_equal(fval, ev[order])
+    r0, r1 = dim // 3, dim // 3 + 29
+    sia, sja, sval = A.download(r0, r1)
+    assert np.array_equal(sia, fia[r0:r1 + 1] - fia[r0]) and np.array_equal(sja, fja[fia[r0]:fia[r1]]) and np.array_equal(sval, fval[fia[r0]:fia[r1]])
     A.destroy()
 
 

@@ -46,6 +46,8 @@ def test_cut_sector_equals_the_unsplit_operator(name, h, cross_in_near):
         assert 0 < info.kron_far_nnz < info.nnz and (info.kron_cross_nnz == 0 if cross_in_near else 0 < info.kron_cross_nnz < 0.4 * info.nnz)
     elif crossing > 0.5:
         assert info.kron_classes == 0           # mostly unstructured: permuted, not split -- and still right (below)
+    kia, kja, kval = K.download()                                    # the CALLER's rows again, through the map (bit for bit)
+    assert np.array_equal(kia, ia) and np.array_equal(kja, ja) and np.array_equal(kval.view(np.float64), val.view(np.float64))
     x, y0 = _rand(dim, 1), _rand(dim, 2)
     want = O.multmv(x)
     scale = np.abs(want).max()
