@@ -145,7 +145,7 @@ def test_bench_two_ranks_on_one_gpu_through_the_native_communicator(rig):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, QBH_RCCL_LIB=STUB, QBH_DIST_BACKEND="gloo", TMPDIR=rig["tmp"], HSA_ENABLE_IPC_MODE_LEGACY="0")
-    common = ["--steps", "5", "--warmup", "2", "--workload", "hubbard_4x3_half", "--no-cpu-baseline", "--no-matrix-free", "--no-fast-path"]
+    common = ["--steps", "5", "--warmup", "2", "--workload", "hubbard_4x3_half", "--no-cpu-baseline", "--no-matrix-free", "--no-fast-path", "--processes", "1"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert one.returncode == 0, one.stdout + one.stderr
     ref = json.loads([ln for ln in one.stdout.strip().splitlines() if ln.startswith("{")][-1])
