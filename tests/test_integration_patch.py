@@ -28,7 +28,7 @@ def test_patch_applies_to_the_unchanged_reference():
         lz = open(os.path.join(tmp, "src", "lanczos.cc")).read()
         assert open(os.path.join(tmp, "src", "qbasis.h")).read() == before_h            # the public header is untouched
         # every binding of INTEGRATION.md is in place, and no MKL sparse call is left on the complex path
-        for needle in ("qbh_csr_create(", "qbh_csr_destroy(", "qbh_multmv2("):
+        for needle in ("qbh_csr_create(", "qbh_csr_destroy(", "qbh_multmv2(", "qbh_multmv("):
             assert needle in sp
         assert sp.count("create_handle(&handle, dim, nnz, sym, ia, ja, val)") == 2
         assert "mkl_sparse_z_mv" not in sp and "mkl_sparse_z_create_csr" not in sp
@@ -151,7 +151,7 @@ def test_patched_translation_units_compile_and_import_the_c_abi(device_iram):
             objs[tu] = _undefined(obj)
         sp, lz = objs["sparse"], objs["lanczos"]
         # sparse.o: the complex operator lives on the GPU -- created, applied and destroyed through the C ABI ...
-        for sym in ("qbh_csr_create", "qbh_csr_destroy", "qbh_multmv2", "qbh_last_error"):
+        for sym in ("qbh_csr_create", "qbh_csr_destroy", "qbh_multmv2", "qbh_multmv", "qbh_last_error"):
             assert sym in sp, sym
         # ... and no complex MKL sparse call is left (the double overloads stay: model<double> is not instantiated upstream)
         assert "mkl_sparse_z_mv" not in sp and "mkl_sparse_z_create_csr" not in sp
