@@ -565,6 +565,7 @@ def main():
     ap.add_argument("--cols16", type=int, default=1, help="qbh_opts.kron_cols16: 1 (library default) the parts of a split operator keep 2-byte columns, 0 int32 columns")
     ap.add_argument("--deterministic", action="store_true", help="qbh_opts.deterministic: static walks, nothing timed at creation (bit-identical a_j / b_j from run to run)")
     ap.add_argument("--no-pipeline", action="store_true", help="qbh_opts.lanczos_pipeline = 0: one host synchronisation per Lanczos step (the loop of ABI <= 501), for A/B runs")
+    ap.add_argument("--no-sparse-gather", action="store_true", help="N > 1: qbh_opts.sparse_gather = 0 (every rank's whole tiled block travels to everybody)")
     ap.add_argument("--no-partition", action="store_true", help="N > 1, hubbard workloads: keep the up configurations in ascending pattern order (qbh_opts.major_partition = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed run to convergence (E0)")
@@ -762,7 +763,7 @@ def main():
         opts = q.make_opts(device=local_rank, stream=stream.cuda_stream, spmv_kernel=args.kernel,
                            nnz_per_block=args.npb, xcd_swizzle=args.swizzle,
                            value_dict=value_dict, real_fast_path=real_fp, profile=1, deterministic=1 if args.deterministic else 0,
-                           kron_cols16=args.cols16, lanczos_pipeline=0 if args.no_pipeline else 1)
+                           kron_cols16=args.cols16, lanczos_pipeline=0 if args.no_pipeline else 1, sparse_gather=0 if args.no_sparse_gather else 1)
         if world > 1 and W["kind"] == "hubbard" and not args.matrix_free and not args.host_csr and value_dict == 0 and not args.no_partition:
             # the up configurations in the order of a recursive bisection of the hop graph into `world` parts: every rank's far part then reads
             # far fewer of its peers' major indices, which is what the personalised exchange carries (qbh_opts.major_partition)
