@@ -12,7 +12,7 @@
 // synchronises the device: a group of receives is a host function on the stream that holds it for (longest message) / link rate
 // + QBH_STUB_LATENCY_US (default 20; every peer has a link of its own) -- the receive buffers keep what they held (zeros: the
 // peers' blocks of x are zero, every number stays finite, the results mean nothing; QBH_STUB_SOLO_COPY=1 fills them with the
-// rank's own block by hipMemcpyAsync, which on this rig is an SDMA copy at ~80 GB/s and dominates the model) -- and an
+// rank's own block by hipMemcpyAsync, i.e. adds the HBM writes the arriving data would cause) -- and an
 // all-reduce returns nranks times the rank's own contribution (so the collective agreements of qbh_csr_set_comm come out as
 // they would with real peers) after the latency.  A rehearsal of the TIMING path -- events, side stream, what the near pass
 // hides of the gather -- on one GPU.
