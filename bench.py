@@ -884,7 +884,7 @@ def main():
         "data": "synthetic", "config": {"workload": args.workload, "dim": dim, "nnz_full": nnz_total,
                                          "rows_per_gpu": info.nrows, "parallelism": "row-shard x%d" % world,
                                          "exchange": exchange_kind,
-                                         "kernel": KERNEL_KEY[info.kernel], "format": "complex128 CSR values + int32 columns, complex128 vectors"
+                                         "kernel": KERNEL_KEY[info.kernel], "format": ("complex128 CSR values + %s, complex128 vectors" % ("2-byte columns held (int32 counted in the roofline bytes)" if (info.kron_minor and int(info.kron_cols16)) else "int32 columns"))
                                          if not (coded or real_used) else "value codes %s, real fast path %s" % (coded, real_used),
                                          "value_dict": info.value_dict, "real_gather": real_used, "deterministic": bool(args.deterministic),
                                          "kron_split": ({"minor": int(info.kron_minor), "band": int(info.kron_band), "far_nnz": int(info.kron_far_nnz), "far_sliced": bool(info.kron_sliced),
