@@ -27,8 +27,8 @@ def _hint(n, nu, nd, **kw):
     return q.make_opts(basis_kind=_lib.BASIS_REF_FERMION2, n_sites=n, n_up=nu, n_dn=nd, **kw)
 
 
-@pytest.mark.parametrize("hinted", [1, 0])
-@pytest.mark.parametrize("ly,nu,nd", [(2, 4, 4), (2, 3, 5), (3, 6, 6)])
+# (the 12-site operator once: its oracle Lanczos + CG on the host is 15 s of the GPU tier's budget per case)
+@pytest.mark.parametrize("ly,nu,nd,hinted", [(2, 4, 4, 1), (2, 4, 4, 0), (2, 3, 5, 1), (2, 3, 5, 0), (3, 6, 6, 0)])
 def test_reference_ordered_host_arrays_run_on_the_split_with_the_hint_and_without(ly, nu, nd, hinted):
     """hinted = 0: NOTHING is said about the basis -- what the reference's csr_mat(lil_mat&) (src/sparse.cc:202-260) can say.  The
     library looks for a two-species basis of this dimension by itself (qbh_opts.basis_detect; kron_split = 2 lifts the 1e8-nonzero

@@ -7,6 +7,7 @@ back when one rank cannot split, and the all-reduce of the Lanczos / CG scalars 
 where real RCCL would hang (a receive no send matches, element counts that differ).  Every rank must report the one-rank
 E0, a_j / b_j, step counts and its slice of the one-rank eigenvector.  (The matvec served: src/sparse.cc:262-289.)"""
 import json
+import math
 import os
 import subprocess
 import sys
@@ -40,11 +41,11 @@ def rig():
         yield {"tmp": tmp, "exe": exe, "csr": path, "dim": dim, "ref": {}}
 
 
-def _run(rig, nranks, args, tag):
+def _run(rig, nranks, args, tag, csr=None):
     uid = os.path.join(rig["tmp"], "uid_%s.bin" % tag)
     dump = os.path.join(rig["tmp"], "dump_%s" % tag)
     env = dict(os.environ, QBH_RCCL_LIB=STUB, TMPDIR=rig["tmp"], HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([rig["exe"], rig["csr"], str(r), str(nranks), uid] + args + ["dump=" + dump], stdout=subprocess.PIPE,
+    procs = [subprocess.Popen([rig["exe"], csr or rig["csr"], str(r), str(nranks), uid] + args + ["dump=" + dump], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True, env=env) for r in range(nranks)]
     outs = []
     for p in procs:
@@ -79,9 +80,9 @@ def _reference(rig, plain):
     return rig["ref"][key]
 
 
-def _check(rig, res, ref, nranks):
-    assert res[0]["r0"] == 0 and res[-1]["r1"] == rig["dim"] and all(res[i]["r1"] == res[i + 1]["r0"] for i in range(nranks - 1))
-    assert abs(ref["E0"] + 14.076058658879278) < 1e-9
+def _check(rig, res, ref, nranks, dim=None, e0=-14.076058658879278):
+    assert res[0]["r0"] == 0 and res[-1]["r1"] == (dim or rig["dim"]) and all(res[i]["r1"] == res[i + 1]["r0"] for i in range(nranks - 1))
+    assert abs(ref["E0"] - e0) < 1e-9                                 # SURVEY App. E (the rig's operator) / dense diagonalisation (others)
     full = np.concatenate([r["vec"] for r in res])
     for r in res:
         assert abs(r["E0"] - ref["E0"]) <= 1e-12 * abs(ref["E0"])
@@ -93,9 +94,11 @@ def _check(rig, res, ref, nranks):
     assert abs(abs(np.vdot(full, ref["vec"])) - 1.0) < 1e-8           # the slices ARE the one-rank eigenvector
 
 
-@pytest.mark.parametrize("nranks", [2, 3, 4])
-@pytest.mark.parametrize("parts", [1, 4, 7])
-@pytest.mark.parametrize("realwire,sparse", [(1, 1), (0, 1), (1, 0), (0, 0)])
+# a covering set of (ranks, parts, wire, personalised): every pair of values of two different options meets at least once (the full
+# 36-case product took 90 s of the GPU tier for one operator shape; the shapes below buy more)
+@pytest.mark.parametrize("nranks,parts,realwire,sparse", [(2, 1, 1, 1), (2, 4, 0, 1), (2, 7, 1, 0), (2, 4, 0, 0),
+                                                          (3, 1, 0, 1), (3, 4, 1, 1), (3, 7, 0, 0), (3, 1, 1, 0),
+                                                          (4, 1, 0, 0), (4, 4, 1, 0), (4, 7, 1, 1), (4, 7, 0, 1)])
 def test_split_shards_exchange_tiled_blocks_over_the_native_communicator(rig, nranks, parts, realwire, sparse):
     """complex128 shards of whole major indices, each split in place with 2-byte columns in BOTH parts (the one-GPU kernel: the far
     columns index the tiled order of the whole vector, the gathered blocks are moved there piece by piece), the TILED block of
@@ -111,6 +114,50 @@ def test_split_shards_exchange_tiled_blocks_over_the_native_communicator(rig, nr
     # destination, same band ranges), the receiver moves them to their place; sparse = 0: whole blocks to everybody
     assert all(r["sparse"] == sparse for r in res), res
     _check(rig, res, _reference(rig, True), nranks)
+
+
+# (lx, ly, n_up, n_dn): minor sizes 56 (whole bands only: no cross part), 28 (last band of 4), 6 (narrower than one band: bands of 2 / 4,
+# far part unsliced), 126 with 126 major indices, and 8 majors over 3 / 7 ranks (most ranks own ONE major index)
+OTHER_SHAPES = {"s56": (4, 2, 4, 3), "s28": (4, 2, 5, 2), "s6": (3, 2, 3, 1), "s126": (3, 3, 4, 4), "few_majors": (4, 2, 1, 4)}
+
+
+@pytest.fixture(scope="module")
+def other_ops(rig):
+    ops = {}
+    for name, (lx, ly, nu, nd) in OTHER_SHAPES.items():
+        n = lx * ly
+        G = q.csr_mat.hubbard(n, nu, nd, lattices.square(lx, ly), t=1.0, U=1.1, opts=q.make_opts(kron_split=0, value_dict=0, real_fast_path=0))
+        ia, ja, val = G.download()
+        dim, S = G.dim, math.comb(n, nd)
+        G.destroy()
+        path = os.path.join(rig["tmp"], "csr_%s.bin" % name)
+        with open(path, "wb") as f:
+            np.array([dim, len(ja), 0], dtype=np.int64).tofile(f)
+            ia.astype(np.int64).tofile(f), ja.astype(np.int64).tofile(f), val.tofile(f)
+        import scipy.sparse as sp
+        H = sp.csr_matrix((val, ja, ia), shape=(dim, dim))
+        e0 = float(np.linalg.eigvalsh(H.toarray())[0]) if dim <= 4000 else float(sp.linalg.eigsh(H, k=1, which="SA", tol=1e-13)[0][0])
+        ops[name] = {"csr": path, "dim": dim, "S": S, "e0": e0, "ref": None}
+    return ops
+
+
+@pytest.mark.parametrize("shape,nranks,parts,realwire,sparse", [
+    ("s56", 2, 4, 1, 1), ("s56", 3, 1, 0, 1), ("s56", 4, 7, 1, 0),
+    ("s28", 2, 1, 0, 0), ("s28", 3, 4, 1, 1), ("s28", 4, 4, 0, 1),
+    ("s6", 2, 4, 1, 1), ("s6", 3, 1, 1, 0), ("s6", 4, 2, 0, 1),
+    ("s126", 3, 4, 1, 1), ("s126", 4, 7, 0, 0),
+    ("few_majors", 3, 4, 1, 1), ("few_majors", 7, 1, 0, 1)])
+def test_other_shapes_of_split_shards_over_the_native_communicator(rig, other_ops, shape, nranks, parts, realwire, sparse):
+    """The exchange forms of the sharded headline on operators whose minor size is a whole number of bands (no cross part), ends in a
+    band of 4, is narrower than a band, and on shards of one or two major indices: every rank must report the one-rank run's E0 (which
+    must be the dense ground-state energy), its a_j / b_j and its slice of the eigenvector."""
+    op = other_ops[shape]
+    if op["ref"] is None:
+        op["ref"] = _run(rig, 1, ["plain=1"], "oref_" + shape, csr=op["csr"])[0]
+    res = _run(rig, nranks, ["plain=1", "kron=%d" % op["S"], "parts=%d" % parts, "realwire=%d" % realwire, "sparse=%d" % sparse],
+               "o_%s_%d_%d_%d_%d" % (shape, nranks, parts, realwire, sparse), csr=op["csr"])
+    assert all(r["kron"] == op["S"] and r["wire"] == (8 if realwire else 16) for r in res), res
+    _check(rig, res, op["ref"], nranks, dim=op["dim"], e0=op["e0"])
 
 
 @pytest.mark.parametrize("nranks,unsplit", [(2, 1), (3, 0)])
