@@ -46,7 +46,8 @@ static void parse_debug(const char *e, DebugSw &d)
                         {"force_ragged", &d.force_ragged, nullptr}, {"mf_row", &d.mf_row, nullptr}, {"mf_chunk", &d.mf_chunk, nullptr},
                         {"mf_window", &d.mf_window, nullptr}, {"kronc_abl", &d.kronc_abl, nullptr}, {"kronc_far_chunk", &d.kronc_far_chunk, nullptr},
                         {"kronc_far_ng", &d.kronc_far_ng, nullptr}, {"kronc_far_nt", &d.kronc_far_nt, nullptr}, {"no_far_align", &d.no_far_align, nullptr},
-                        {"no_defer", &d.no_defer, nullptr}, {"pipe_nospec", &d.pipe_nospec, nullptr}, {"host_delay_us", &d.host_delay_us, nullptr}};
+                        {"no_defer", &d.no_defer, nullptr}, {"pipe_nospec", &d.pipe_nospec, nullptr}, {"host_delay_us", &d.host_delay_us, nullptr},
+                        {"side_noprio", &d.side_noprio, nullptr}, {"comm_reserve", &d.comm_reserve, nullptr}};
     const std::string all(e);
     size_t pos = 0;
     while (pos <= all.size()) {

@@ -430,7 +430,19 @@ extern "C" int qbh_comm_create_rccl(qbh_csr *A, const void *uid128, int rank, in
         qbh::set_error("%s failed (qbh_comm_create_rccl)", #call);                        \
         return bail(QBH_EHIP);                                                            \
     }
-    QBH_C(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    // RCCL's stream takes the HIGHEST priority the device offers.  The two passes of a split shard are persistent launches that fill
+    // every CU with as many wavefronts as their registers allow; a send / receive kernel that becomes runnable at the same moment as
+    // the near pass (both wait for the pack kernel) must be placed FIRST, and the kernel of the next band range must get the CUs the
+    // previous one frees -- otherwise the exchange would start when the near pass ends and nothing would be hidden.  (The stand-in of
+    // the test rigs models the exchange as a delay on this stream and cannot see this; a node can.)
+    {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
+            (void)hipGetLastError();
+            least = greatest = 0;
+        }
+        QBH_C(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, qbh::debug_sw().side_noprio ? least : greatest));
+    }
     QBH_C(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
     QBH_C(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
     QBH_C(hipEventCreate(&c->t0));

@@ -41,6 +41,8 @@ struct DebugSw {
     int no_defer = 0;         // Lanczos: read <u, w> back every step instead of keeping it on the device
     int host_delay_us = 0;    // Lanczos: the host spins this long after every read-back of a step's scalars (models a slow / descheduled host)
     int pipe_nospec = 0;      // pipelined Lanczos loop: 1 = never enqueue a step before the one before it has been read back (debugging)
+    int side_noprio = 0;      // native communicator: RCCL's side stream at the default priority (A/B of the priority, tools/solo_rank.py)
+    int comm_reserve = 0;     // split shard under a communicator: workgroups the persistent passes leave out of their grids (room for RCCL's kernels; A/B only)
 };
 const DebugSw &debug_sw();
 void opts_builtin(qbh_opts *o);          // the built-in defaults, whatever qbh_opts_set_default says

@@ -464,7 +464,10 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
         }
         nr.far = nullptr;
         nr.partials = nullptr;
-        QBH_TRY(qbh::launch_spmv_wave2(nr, K.tpr_n, 1, K.grid_n, s));        // y = alpha H_near x + beta y + gamma x
+        // QBH_DEBUG=comm_reserve=W (A/B only): the persistent passes leave W workgroups out of their grids, multiples of 8 (one per XCD)
+        const int reserve = (A->dbg.comm_reserve / 8) * 8;
+        const int grid_n = std::max(8, K.grid_n - reserve), grid_f = std::max(8, K.grid_f - reserve);
+        QBH_TRY(qbh::launch_spmv_wave2(nr, K.tpr_n, 1, grid_n, s));          // y = alpha H_near x + beta y + gamma x
         if (prof) {
             QBH_HIP(hipEventRecord(A->ev1, s));
             A->ev_pending = true;
@@ -485,7 +488,7 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
                 fk.wd = K.wd_f + (np_used > 1 ? K.part_blk[k] : 0);
                 fk.n_wb = np_used > 1 ? K.part_blk[k + 1] - K.part_blk[k] : K.nwb_f;
                 fk.wctr = A->d_wctr ? A->d_wctr + (3 + k) * 128 : nullptr;
-                if (fk.n_wb > 0) QBH_TRY(qbh::launch_spmv_wave2(fk, K.tpr_f, 3, (int)std::min<int64_t>(K.grid_f, std::max<int64_t>(fk.n_wb, 8)), s));
+                if (fk.n_wb > 0) QBH_TRY(qbh::launch_spmv_wave2(fk, K.tpr_f, 3, (int)std::min<int64_t>(grid_f, std::max<int64_t>(fk.n_wb, 8)), s));
             }
         } else {
             if (async_gather && A->comm.allgather_wait(A->comm.ctx) != 0) {
@@ -495,7 +498,7 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
             if (prof) QBH_HIP(hipEventRecord(A->ev2, s));
             QBH_TRY(place(0));
             if (K.sliced) QBH_TRY(qbh::launch_zero_cut_groups(K.wd_f, K.nwb_f, f.nrows, K.d_far, s));
-            QBH_TRY(qbh::launch_spmv_wave2(f, K.tpr_f, K.sliced ? 3 : 0, K.grid_f, s));
+            QBH_TRY(qbh::launch_spmv_wave2(f, K.tpr_f, K.sliced ? 3 : 0, grid_f, s));
         }
         QBH_TRY(qbh::launch_kron_cross_rows(K.ia_x, K.xrow, K.n_xrows, K.ja_x, K.val_x, xt, K.t, K.d_far, s));
         QBH_TRY(qbh::launch_kron_combine(K.d_far, K.t, xl, y, A->nrows, alpha, red ? A->d_partials : nullptr, &nparts, s, A->ovr_coef));

@@ -204,9 +204,45 @@ void hold_stream(void *p)
     while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < h->us) { }
     delete h;
 }
+// QBH_STUB_SOLO_KERNEL=W[:ldsKB]: the hold is a KERNEL of W workgroups (256 threads, ldsKB of LDS each) that spin for the modelled
+// time from the moment they START -- like RCCL's send / receive kernels it needs CU resources, so it competes with the persistent
+// passes of a split shard for a place on the chip: what the near pass hides of the exchange then depends on who is dispatched
+// first (the priority of the communicator's side stream, qbh_comm.cpp), which the host-function hold cannot show.
+__global__ __launch_bounds__(256) void k_stub_occupy(unsigned long long ticks)
+{
+    extern __shared__ char lds[];
+    const unsigned long long t0 = wall_clock64();
+    if (threadIdx.x == 0) lds[0] = 1;
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+int g_occ_wg = -1, g_occ_lds_kb = 0;
+double g_wall_khz = 0.0;
+bool occupy_mode()
+{
+    if (g_occ_wg < 0) {
+        g_occ_wg = 0;
+        if (const char *e = getenv("QBH_STUB_SOLO_KERNEL")) {
+            g_occ_wg = atoi(e);
+            if (const char *c = strchr(e, ':')) g_occ_lds_kb = atoi(c + 1);
+            int dev = 0, khz = 0;
+            if (g_occ_wg > 0 && (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0 ||
+                                 hipFuncSetAttribute(reinterpret_cast<const void *>(k_stub_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, g_occ_lds_kb * 1024) != hipSuccess)) {
+                fprintf(stderr, "rccl_stub: QBH_STUB_SOLO_KERNEL cannot be set up (%s): host-function hold\n", hipGetErrorString(hipGetLastError()));
+                g_occ_wg = 0;
+            }
+            g_wall_khz = (double)khz;
+        }
+    }
+    return g_occ_wg > 0;
+}
 ncclResult_t solo_hold(hipStream_t s, double us)
 {
     if (us <= 0.0) return ncclSuccess;
+    if (occupy_mode()) {
+        hipLaunchKernelGGL(k_stub_occupy, dim3((unsigned)g_occ_wg), dim3(256), (size_t)g_occ_lds_kb * 1024, s, (unsigned long long)(us * g_wall_khz * 1e-3));
+        if (hipGetLastError() != hipSuccess) return fail("k_stub_occupy launch failed (solo mode)");
+        return ncclSuccess;
+    }
     if (hipLaunchHostFunc(s, hold_stream, new Hold{us}) != hipSuccess) return fail("hipLaunchHostFunc failed (solo mode)");
     return ncclSuccess;
 }
