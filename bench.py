@@ -566,6 +566,8 @@ def main():
     ap.add_argument("--deterministic", action="store_true", help="qbh_opts.deterministic: static walks, nothing timed at creation (bit-identical a_j / b_j from run to run)")
     ap.add_argument("--no-pipeline", action="store_true", help="qbh_opts.lanczos_pipeline = 0: one host synchronisation per Lanczos step (the loop of ABI <= 501), for A/B runs")
     ap.add_argument("--no-sparse-gather", action="store_true", help="N > 1: qbh_opts.sparse_gather = 0 (every rank's whole tiled block travels to everybody)")
+    ap.add_argument("--comm-reserve", type=int, default=0, help="N > 1, split shards (qbh_opts.comm_reserve): workgroups the persistent passes leave out of their grids so that "
+                    "RCCL's own kernels find a place beside them; 0 (library default) 64, -1 none")
     ap.add_argument("--no-partition", action="store_true", help="N > 1, hubbard workloads: keep the up configurations in ascending pattern order (qbh_opts.major_partition = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed run to convergence (E0)")
@@ -763,7 +765,8 @@ def main():
         opts = q.make_opts(device=local_rank, stream=stream.cuda_stream, spmv_kernel=args.kernel,
                            nnz_per_block=args.npb, xcd_swizzle=args.swizzle,
                            value_dict=value_dict, real_fast_path=real_fp, profile=1, deterministic=1 if args.deterministic else 0,
-                           kron_cols16=args.cols16, lanczos_pipeline=0 if args.no_pipeline else 1, sparse_gather=0 if args.no_sparse_gather else 1)
+                           kron_cols16=args.cols16, lanczos_pipeline=0 if args.no_pipeline else 1, sparse_gather=0 if args.no_sparse_gather else 1,
+                           comm_reserve=args.comm_reserve)
         if world > 1 and W["kind"] == "hubbard" and not args.matrix_free and not args.host_csr and value_dict == 0 and not args.no_partition:
             # the up configurations in the order of a recursive bisection of the hop graph into `world` parts: every rank's far part then reads
             # far fewer of its peers' major indices, which is what the personalised exchange carries (qbh_opts.major_partition)
@@ -958,6 +961,8 @@ def main():
                            # what the ranks agreed on when the communicator was attached (qbh_csr_set_comm is collective): split shards
                            # exchanging the tiled copies of their blocks, or the plain blocks of unsplit shards
                            "tiled_blocks_of_split_shards": bool(A.info().kron_minor),
+                           # qbh_opts.comm_reserve: workgroups the persistent passes of a split shard leave out of their grids (room for RCCL's kernels)
+                           "comm_reserve_workgroups": (0 if args.comm_reserve < 0 else (args.comm_reserve // 8) * 8 or 64) if A.info().kron_minor else None,
                            "allreduce": "<= 3 doubles per reduction point"}
         # per rank: SpMV kernel ms (both parts of a split shard), gather ms on the side stream, how much of the gather the
         # locally-owned columns hide, and the rank's own roofline on ITS algorithmic bytes (local nnz, rows, the whole x)

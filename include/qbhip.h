@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QBH_VERSION 600
+#define QBH_VERSION 601
 
 /* error codes */
 #define QBH_OK          0
@@ -213,6 +213,18 @@ typedef struct qbh_opts {
                                 near window inside it too) with the fewest bonds
                                 across it, the one nearest n_sites / 2 among equals; nothing feasible: the operator stays as generated.
                                 > 0: that h.  -1: never (the rows stay in ascending pattern order, the form of ABI <= 501)      */
+    int     comm_reserve;    /* [0] split shards under a communicator of more than one rank (ABI 601).  The two passes of a split shard are
+                                PERSISTENT launches that fill every CU with as many wavefronts as their registers allow (2 x 208 /
+                                3 x 168 of the 512 per SIMD lane); RCCL's own send / receive kernel (rcclGenericKernel, gfx950: 256
+                                threads, 261-280 registers per lane, 19.7 KB LDS) cannot be placed beside them, and a kernel that is
+                                not resident moves nothing: the exchange would start when the near pass ends.  So the passes leave
+                                this many workgroups OUT of their grids -- one CU per workgroup runs one wavefront per SIMD fewer, which
+                                is where a workgroup of RCCL fits -- and the far pass runs with at most 2 workgroups per CU.
+                                Measured with a kernel of RCCL's footprint in place of the exchange (tests/stub_rccl solo mode,
+                                profiles/r6_bench/solo_rank/occupancy_SUMMARY.txt): C3, 50 GB/s links, without: +17 % / +28 % / +20 %
+                                per Lanczos step at 8 / 4 / 2 ranks; with 32-64 workgroups left out: the step of the model that
+                                needs no CUs, at a cost of 0-2 %.  0: 64 workgroups (RCCL uses at most that many channels);
+                                > 0: that many (rounded down to a multiple of 8); -1: none                                      */
 } qbh_opts;
 
 void qbh_opts_default(qbh_opts *o);

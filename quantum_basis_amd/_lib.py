@@ -40,7 +40,7 @@ class Opts(C.Structure):
                 ("kron_sliced", C.c_int), ("kron_band", C.c_int), ("kron_cross_in_near", C.c_int), ("kron_coded", C.c_int),
                 ("kron_uniform", C.c_int), ("gather_parts", C.c_int), ("wave_walk", C.c_int), ("tile_fold", C.c_int),
                 ("autotune", C.c_int), ("shard_split", C.c_int), ("real_forms", C.c_int), ("basis_detect", C.c_int),
-                ("sector_orbit", C.c_int), ("lanczos_pipeline", C.c_int), ("real_wire", C.c_int), ("sparse_gather", C.c_int), ("major_partition", C.c_int), ("sector_cut", C.c_int)]
+                ("sector_orbit", C.c_int), ("lanczos_pipeline", C.c_int), ("real_wire", C.c_int), ("sparse_gather", C.c_int), ("major_partition", C.c_int), ("sector_cut", C.c_int), ("comm_reserve", C.c_int)]
 
 
 class CsrInfo(C.Structure):

@@ -47,7 +47,7 @@ static void parse_debug(const char *e, DebugSw &d)
                         {"mf_window", &d.mf_window, nullptr}, {"kronc_abl", &d.kronc_abl, nullptr}, {"kronc_far_chunk", &d.kronc_far_chunk, nullptr},
                         {"kronc_far_ng", &d.kronc_far_ng, nullptr}, {"kronc_far_nt", &d.kronc_far_nt, nullptr}, {"no_far_align", &d.no_far_align, nullptr},
                         {"no_defer", &d.no_defer, nullptr}, {"pipe_nospec", &d.pipe_nospec, nullptr}, {"host_delay_us", &d.host_delay_us, nullptr},
-                        {"side_noprio", &d.side_noprio, nullptr}, {"comm_reserve", &d.comm_reserve, nullptr}};
+                        {"side_noprio", &d.side_noprio, nullptr}, {"comm_reserve", &d.comm_reserve, nullptr}, {"comm_far_cap", &d.comm_far_cap, nullptr}};
     const std::string all(e);
     size_t pos = 0;
     while (pos <= all.size()) {
@@ -185,6 +185,7 @@ void qbh::opts_builtin(qbh_opts *o)
     o->lanczos_pipeline = 1;
     o->real_wire = 1;
     o->sector_cut = 0;
+    o->comm_reserve = 0;
     o->sparse_gather = 1;
     o->major_partition = 0;
     o->kron_minor = 0;

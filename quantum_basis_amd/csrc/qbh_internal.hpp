@@ -42,7 +42,8 @@ struct DebugSw {
     int host_delay_us = 0;    // Lanczos: the host spins this long after every read-back of a step's scalars (models a slow / descheduled host)
     int pipe_nospec = 0;      // pipelined Lanczos loop: 1 = never enqueue a step before the one before it has been read back (debugging)
     int side_noprio = 0;      // native communicator: RCCL's side stream at the default priority (A/B of the priority, tools/solo_rank.py)
-    int comm_reserve = 0;     // split shard under a communicator: workgroups the persistent passes leave out of their grids (room for RCCL's kernels; A/B only)
+    int comm_reserve = 0;     // split shard under a communicator: overrides qbh_opts.comm_reserve (> 0: that many workgroups, < 0: none; A/B only)
+    int comm_far_cap = 0;     // ... and the cap on the far pass's workgroups per CU (> 0: that many, < 0: none; A/B only)
 };
 const DebugSw &debug_sw();
 void opts_builtin(qbh_opts *o);          // the built-in defaults, whatever qbh_opts_set_default says
@@ -818,6 +819,7 @@ struct qbh_csr {
     qbh_stats stats{};
     bool      ev_pending = false;
     int       debug = 0;
+    int ncu = 0;                     // CUs of the handle's device (filled where a launch needs it)
     qbh::DebugSw dbg;                // QBH_DEBUG as it was when the handle was made (new_handle): set the variable before creating the operator
     const double *ovr_xr = nullptr;  // all-real operation requested by a driver for the next spmv_run: x and ...
     double       *ovr_yr = nullptr;  // ... y as packed doubles (the complex pointer arguments are ignored)

@@ -464,9 +464,21 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
         }
         nr.far = nullptr;
         nr.partials = nullptr;
-        // QBH_DEBUG=comm_reserve=W (A/B only): the persistent passes leave W workgroups out of their grids, multiples of 8 (one per XCD)
-        const int reserve = (A->dbg.comm_reserve / 8) * 8;
-        const int grid_n = std::max(8, K.grid_n - reserve), grid_f = std::max(8, K.grid_f - reserve);
+        // qbh_opts.comm_reserve: room for RCCL's own kernels beside the persistent passes -- workgroups left out of the grids (multiples
+        // of 8: one per XCD) and at most two far workgroups per CU (QBH_DEBUG=comm_reserve=W / comm_far_cap=C override both for A/B runs)
+        int reserve = 0, far_cap = K.grid_f;
+        if (A->comm.nranks > 1 && A->opts.comm_reserve >= 0) {
+            reserve = A->opts.comm_reserve > 0 ? (A->opts.comm_reserve / 8) * 8 : 64;
+            if (A->ncu <= 0) {
+                hipDeviceProp_t prop;
+                A->ncu = (hipGetDeviceProperties(&prop, A->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+            }
+            far_cap = std::min(K.grid_f, 2 * A->ncu);
+        }
+        if (A->dbg.comm_reserve != 0) reserve = A->dbg.comm_reserve > 0 ? (A->dbg.comm_reserve / 8) * 8 : 0;
+        if (A->dbg.comm_far_cap != 0) far_cap = A->dbg.comm_far_cap > 0 ? std::min(K.grid_f, A->dbg.comm_far_cap * std::max(A->ncu, 256)) : K.grid_f;
+        // (a small shard keeps at least half of either grid)
+        const int grid_n = std::max({8, K.grid_n / 2, K.grid_n - reserve}), grid_f = std::max({8, std::min(far_cap, K.grid_f) / 2, far_cap - reserve});
         QBH_TRY(qbh::launch_spmv_wave2(nr, K.tpr_n, 1, grid_n, s));          // y = alpha H_near x + beta y + gamma x
         if (prof) {
             QBH_HIP(hipEventRecord(A->ev1, s));
@@ -725,6 +737,23 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
     // stream from ONE region -- ordered eighths cost it 34 -> 43 ms on C3.  xcd_swizzle 3 / QBH_WAVE_SWIZZLE choose by name.
     int wave_swz = A->opts.xcd_swizzle, wave_grid_used = A->wgrid;
     if (A->opts.wave_walk >= 0) wave_swz = A->opts.wave_walk;
+    // qbh_opts.comm_reserve on a plain shard: the launch of the locally-owned columns runs while the gather is on the links; its
+    // grid is persistent (wave and row kernels), so it leaves room for RCCL's kernel (280 registers per lane, see the split path):
+    // at most c workgroups per CU, c - 1 on `reserve` of them, with c from the registers a wavefront of this launch can own at its
+    // occupancy (512 / occ, an upper bound) so that 512 - (c - 1) * v >= 280
+    auto comm_grid = [&](int g) -> int {
+        if (!(A->has_comm && A->has_rem && async_gather && A->comm.nranks > 1 && A->opts.comm_reserve >= 0)) return g;
+        if (A->ncu <= 0) {
+            hipDeviceProp_t prop;
+            A->ncu = (hipGetDeviceProperties(&prop, A->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }
+        const int occ = g / A->ncu;
+        if (occ < 1) return g;                   // does not fill the chip anyway
+        const int v = std::max(8, (512 / occ) / 8 * 8), c = std::max(1, std::min(occ, 1 + 232 / v));
+        const int reserve = A->opts.comm_reserve > 0 ? (A->opts.comm_reserve / 8) * 8 : 64;
+        const int capped = std::min(g, c * A->ncu);
+        return std::max({8, capped / 2, ((capped - reserve) / 8) * 8});
+    };
     if (wave && wave_swz == 3) {
         if (!A->d_wctr || A->opts.deterministic) wave_swz = 2;
         else QBH_HIP(hipMemsetAsync(A->d_wctr, 0, 3 * 128 * sizeof(unsigned long long), A->stream));
@@ -809,10 +838,10 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
             if (a.swizzle == 3) a.swizzle = 2;             // the experiment has no chunk-partial slots: static walk, per-workgroup partials
             QBH_TRY(qbh::launch_spmv_wave2(a, A->wtpr, 1, (int)g, A->stream));
         } else {
-            QBH_TRY(qbh::launch_spmv_wave(a, A->wtpr, A->wgrid, A->stream));
+            QBH_TRY(qbh::launch_spmv_wave(a, A->wtpr, comm_grid(A->wgrid), A->stream));
         }
     } else {
-        QBH_TRY(qbh::launch_spmv(a, A->kernel, A->npb, A->tpr, A->grid, A->stream));
+        QBH_TRY(qbh::launch_spmv(a, A->kernel, A->npb, A->tpr, A->kernel == QBH_KERNEL_ROWS ? comm_grid(A->grid) : A->grid, A->stream));
     }
     if (prof) {
         QBH_HIP(hipEventRecord(A->ev1, A->stream));

@@ -215,6 +215,18 @@ __global__ __launch_bounds__(256) void k_stub_occupy(unsigned long long ticks)
     if (threadIdx.x == 0) lds[0] = 1;
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
+// QBH_STUB_SOLO_KERNEL=W:rccl -- the footprint of RCCL's own kernel on gfx950 (rcclGenericKernel in the librccl this image ships:
+// 256 threads, 261-280 registers per lane of which 17-32 AGPRs, 19.7 KB of LDS; llvm-readelf --notes of the unbundled code object):
+// the clobbers make the compiler allocate that many registers
+__global__ __launch_bounds__(256) void k_stub_occupy_rccl(unsigned long long ticks)
+{
+    __shared__ volatile char lds[19744];
+    asm volatile("" ::: "v255", "a23");
+    const unsigned long long t0 = wall_clock64();
+    lds[threadIdx.x * 77] = 1;
+    while (wall_clock64() - t0 < ticks && lds[threadIdx.x * 77] == 1) __builtin_amdgcn_s_sleep(32);
+}
+bool g_occ_rccl = false;
 int g_occ_wg = -1, g_occ_lds_kb = 0;
 double g_wall_khz = 0.0;
 bool occupy_mode()
@@ -223,7 +235,10 @@ bool occupy_mode()
         g_occ_wg = 0;
         if (const char *e = getenv("QBH_STUB_SOLO_KERNEL")) {
             g_occ_wg = atoi(e);
-            if (const char *c = strchr(e, ':')) g_occ_lds_kb = atoi(c + 1);
+            if (const char *c = strchr(e, ':')) {
+                g_occ_rccl = strcmp(c + 1, "rccl") == 0;
+                g_occ_lds_kb = g_occ_rccl ? 0 : atoi(c + 1);
+            }
             int dev = 0, khz = 0;
             if (g_occ_wg > 0 && (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0 ||
                                  hipFuncSetAttribute(reinterpret_cast<const void *>(k_stub_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, g_occ_lds_kb * 1024) != hipSuccess)) {
@@ -239,7 +254,8 @@ ncclResult_t solo_hold(hipStream_t s, double us)
 {
     if (us <= 0.0) return ncclSuccess;
     if (occupy_mode()) {
-        hipLaunchKernelGGL(k_stub_occupy, dim3((unsigned)g_occ_wg), dim3(256), (size_t)g_occ_lds_kb * 1024, s, (unsigned long long)(us * g_wall_khz * 1e-3));
+        if (g_occ_rccl) hipLaunchKernelGGL(k_stub_occupy_rccl, dim3((unsigned)g_occ_wg), dim3(256), 0, s, (unsigned long long)(us * g_wall_khz * 1e-3));
+        else hipLaunchKernelGGL(k_stub_occupy, dim3((unsigned)g_occ_wg), dim3(256), (size_t)g_occ_lds_kb * 1024, s, (unsigned long long)(us * g_wall_khz * 1e-3));
         if (hipGetLastError() != hipSuccess) return fail("k_stub_occupy launch failed (solo mode)");
         return ncclSuccess;
     }

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert sorted(_lib.EXPORTS) == declared
-    assert L.qbh_version() == 600
+    assert L.qbh_version() == 601
 
 
 def test_struct_layouts_match_header():

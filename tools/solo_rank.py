@@ -8,7 +8,8 @@ gather and what the far pass waits for: the TIMING path of SURVEY 8(e), rehearse
 the peers "send" are the rank's own block, so E0 means nothing here (parity of the sharded path: tests/test_gpu_native_ranks.py).
 
 usage: QBH_RCCL_LIB=tests/stub_rccl/librccl_stub.so QBH_STUB_SOLO=50 python tools/solo_rank.py [workload] P rank [key=value ...]
-       steps=20 warmup=4 parts=0 realwire=1 pipeline=1 sparse=1 partition=1"""
+       steps=20 warmup=4 parts=0 realwire=1 pipeline=1 sparse=1 partition=1 reserve=0
+       QBH_STUB_SOLO_KERNEL=W:rccl holds the side stream with a KERNEL of W workgroups of RCCL's own footprint instead of a host function"""
 import ctypes as C
 import json
 import os
@@ -32,6 +33,8 @@ def main():
     steps, warmup = int(kv.get("steps", 20)), int(kv.get("warmup", 4))
     parts, realwire, pipeline, sparse = int(kv.get("parts", 0)), int(kv.get("realwire", 1)), int(kv.get("pipeline", 1)), int(kv.get("sparse", 1))
     partition = int(kv.get("partition", 1))
+    reserve = int(kv.get("reserve", 0))            # qbh_opts.comm_reserve (0: the library's default, -1: none)
+    split = int(kv.get("split", 1))                # 0: plain row shards (locally-owned / remote columns), the form of operators without a product basis
     if not os.environ.get("QBH_STUB_SOLO") or not os.environ.get("QBH_RCCL_LIB"):
         raise SystemExit("needs QBH_RCCL_LIB=<librccl_stub.so> and QBH_STUB_SOLO=<GB/s per link>")
     W = bench.workloads()[name]
@@ -39,7 +42,8 @@ def main():
     S = comb(W["n_sites"], W["n_dn"])
     cuts = qdist.kron_row_cuts(dim, S, P)
     r0, r1 = int(cuts[rank]), int(cuts[rank + 1])
-    opts = q.make_opts(value_dict=0, real_fast_path=0, profile=1, gather_parts=parts, real_wire=realwire, lanczos_pipeline=pipeline, sparse_gather=sparse, major_partition=P if partition else 0)
+    opts = q.make_opts(value_dict=0, real_fast_path=0, profile=1, gather_parts=parts, real_wire=realwire, lanczos_pipeline=pipeline, sparse_gather=sparse, major_partition=P if partition else 0, comm_reserve=reserve,
+                       kron_split=1 if split else 0)
     t0 = time.time()
     A = bench.build_operator(W, (r0, r1), opts)
     info = A.info()
@@ -75,7 +79,7 @@ def main():
     print(json.dumps({
         "tool": "tools/solo_rank.py", "workload": name, "ranks": P, "rank": rank, "rows": int(info.nrows), "nnz": int(info.nnz), "steps": int(nst),
         "columns": {0: "int32", 1: "near 2-byte, far int32", 2: "near int32, far 2-byte", 3: "2-byte in both parts"}[int(inf.kron_cols16)],
-        "gather_parts": int(inf.gather_parts), "element_bytes": elem, "gather_needed_frac": round(float(inf.gather_needed_frac), 4), "personalised_exchange": bool(inf.gather_sparse), "major_partition": int(inf.major_partition), "lanczos_pipeline": pipeline,
+        "gather_parts": int(inf.gather_parts), "element_bytes": elem, "gather_needed_frac": round(float(inf.gather_needed_frac), 4), "personalised_exchange": bool(inf.gather_sparse), "major_partition": int(inf.major_partition), "lanczos_pipeline": pipeline, "comm_reserve": reserve, "split": split,
         "link_model": {"GBps_per_link": rate, "latency_us": float(os.environ.get("QBH_STUB_LATENCY_US", 20)),
                        "modelled_ms_per_gather (longest block / link rate + latency per part)": round(block_bytes / rate / 1e6 + 0.02 * max(int(inf.gather_parts), 1), 3)},
         "ms_per_step": round(ms_step, 4), "ms_spmv_kernels (near + far + place + combine, event-timed on the operator's stream; the far pass's wait for its pieces is inside)": round(ms_spmv, 4),
