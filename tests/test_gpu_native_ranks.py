@@ -116,8 +116,10 @@ def test_split_shards_exchange_tiled_blocks_over_the_native_communicator(rig, nr
     _check(rig, res, _reference(rig, True), nranks)
 
 
-# (lx, ly, n_up, n_dn): minor sizes 56 (whole bands only: no cross part), 28 (last band of 4), 6 (narrower than one band: stays unsplit, plain exchange), 126 with 126 major indices, and 8 majors over 3 / 6 ranks (four of the six own ONE major index)
-OTHER_SHAPES = {"s56": (4, 2, 4, 3), "s28": (4, 2, 5, 2), "s6": (3, 2, 3, 1), "s126": (3, 3, 4, 4), "few_majors": (4, 2, 1, 4)}
+# (lx, ly, n_up, n_dn): minor sizes 56 (whole bands only: no cross part), 28 (last band of 4), 6 (narrower than one band: stays unsplit, plain exchange), 126 with 126 major indices, and 6 / 8 major indices over 3 / 4 / 5 ranks (ranks that own ONE major index).  Not more than 5 rank processes
+# on the one GPU: from 6 on their queues outnumber the hardware's and every stream synchronisation of the stand-in waits for a
+# scheduling quantum (the same 8-major case: 1 s with 5 ranks, 28-45 s with 6, 15 s with 7)
+OTHER_SHAPES = {"s56": (4, 2, 4, 3), "s28": (4, 2, 5, 2), "s6": (3, 2, 3, 1), "s126": (3, 3, 4, 4), "few_majors": (3, 2, 1, 3), "few8": (4, 2, 1, 4)}
 
 
 @pytest.fixture(scope="module")
@@ -145,7 +147,7 @@ def other_ops(rig):
     ("s28", 2, 1, 0, 0), ("s28", 3, 4, 1, 1), ("s28", 4, 4, 0, 1),
     ("s6", 2, 4, 1, 1), ("s6", 3, 1, 1, 0), ("s6", 4, 2, 0, 1),
     ("s126", 3, 4, 1, 1), ("s126", 4, 7, 0, 0),
-    ("few_majors", 3, 4, 1, 1), ("few_majors", 6, 1, 0, 1)])
+    ("few_majors", 3, 4, 1, 1), ("few_majors", 4, 1, 0, 1), ("few8", 5, 1, 0, 1)])
 def test_other_shapes_of_split_shards_over_the_native_communicator(rig, other_ops, shape, nranks, parts, realwire, sparse):
     """The exchange forms of the sharded headline on operators whose minor size is a whole number of bands (no cross part), ends in a
     band of 4, is narrower than a band, and on shards of one or two major indices: every rank must report the one-rank run's E0 (which
