@@ -600,7 +600,8 @@ int qbh_get_stats(const qbh_csr *A, qbh_stats *s, int reset);
  * without a reduction are asynchronous; needed before another operator/stream touches the vectors). */
 int qbh_sync(const qbh_csr *A);
 /* Change one of the options that do not touch the stored form of the operator, after creation (everything else in qbh_opts is
- * fixed when the handle is made): "lanczos_pipeline", "profile", "tile_fold".  QBH_EINVAL for any other name. */
+ * fixed when the handle is made): "lanczos_pipeline", "profile", "tile_fold", "comm_reserve" (ABI 601; the same value on every
+ * rank).  QBH_EINVAL for any other name. */
 int qbh_csr_set_option(qbh_csr *A, const char *name, int value);
 /* qbh_opts.major_partition: generator_major[i] = the major index the generator's ascending order gives the up configuration that
  * this operator holds at major index i (n_major entries, the same on every rank).  QBH_EUNSUPP for an operator in the generator's

@@ -1106,6 +1106,7 @@ extern "C" int qbh_csr_set_option(qbh_csr *A, const char *name, int value)
         A->opts.profile = value;
     }
     else if (nm == "tile_fold") A->opts.tile_fold = value;
+    else if (nm == "comm_reserve") A->opts.comm_reserve = value;          // a launch-geometry choice: read at every SpMV (every rank must set the same)
     else {
         qbh::set_error("qbh_csr_set_option: '%s' is not an option that can change after creation", name);
         return QBH_EINVAL;

@@ -367,7 +367,7 @@ class csr_mat:
         return out
 
     def set_option(self, name, value):
-        """qbh_csr_set_option: lanczos_pipeline / profile / tile_fold on an existing operator."""
+        """qbh_csr_set_option: lanczos_pipeline / profile / tile_fold / comm_reserve on an existing operator."""
         check(lib().qbh_csr_set_option(self.handle, name.encode(), int(value)), "qbh_csr_set_option")
 
     def stats(self, reset=False):
