@@ -652,6 +652,9 @@ def main():
     local_rank = dev_index
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL's send / receive kernel runs one workgroup per channel and every one of them needs a place beside the persistent passes
+        # (qbh_opts.comm_reserve, default 64 workgroups): keep its grid within that (a host's own setting wins)
+        os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", "64")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
         else:
