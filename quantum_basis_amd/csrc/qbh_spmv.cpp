@@ -477,8 +477,9 @@ int spmv_kron(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double 
         }
         if (A->dbg.comm_reserve != 0) reserve = A->dbg.comm_reserve > 0 ? (A->dbg.comm_reserve / 8) * 8 : 0;
         if (A->dbg.comm_far_cap != 0) far_cap = A->dbg.comm_far_cap > 0 ? std::min(K.grid_f, A->dbg.comm_far_cap * std::max(A->ncu, 256)) : K.grid_f;
-        // (a small shard keeps at least half of either grid)
-        const int grid_n = std::max({8, K.grid_n / 2, K.grid_n - reserve}), grid_f = std::max({8, std::min(far_cap, K.grid_f) / 2, far_cap - reserve});
+        // (a small shard keeps at least half of either grid; grids stay multiples of 8 -- the static walks count slots per XCD)
+        auto mult8 = [](int g) { return std::max(8, (g / 8) * 8); };
+        const int grid_n = mult8(std::max(K.grid_n / 2, K.grid_n - reserve)), grid_f = mult8(std::max(std::min(far_cap, K.grid_f) / 2, far_cap - reserve));
         QBH_TRY(qbh::launch_spmv_wave2(nr, K.tpr_n, 1, grid_n, s));          // y = alpha H_near x + beta y + gamma x
         if (prof) {
             QBH_HIP(hipEventRecord(A->ev1, s));
@@ -752,7 +753,7 @@ int spmv_run(qbh_csr *A, const d2 *x, d2 *y, double alpha, double beta, double g
         const int v = std::max(8, (512 / occ) / 8 * 8), c = std::max(1, std::min(occ, 1 + 232 / v));
         const int reserve = A->opts.comm_reserve > 0 ? (A->opts.comm_reserve / 8) * 8 : 64;
         const int capped = std::min(g, c * A->ncu);
-        return std::max({8, capped / 2, ((capped - reserve) / 8) * 8});
+        return std::max(8, (std::max(capped / 2, capped - reserve) / 8) * 8);
     };
     if (wave && wave_swz == 3) {
         if (!A->d_wctr || A->opts.deterministic) wave_swz = 2;

@@ -64,7 +64,7 @@ int main(int argc, char **argv)
     std::vector<int64_t> cuts(nranks + 1);
     bool uniform = false;
     int64_t kron = 0;
-    int parts = 0, unsplit = -1, plain = 0, realwire = 1, pipeline = 1, sparse = 1;
+    int parts = 0, unsplit = -1, plain = 0, realwire = 1, pipeline = 1, sparse = 1, det = 0;
     std::string dump, ckdir;
     long long every = 10, maxsteps = 0;
     for (int i = 5; i < argc; ++i) {
@@ -77,6 +77,7 @@ int main(int argc, char **argv)
         else if (a.rfind("realwire=", 0) == 0) realwire = std::atoi(a.c_str() + 9);
         else if (a.rfind("pipeline=", 0) == 0) pipeline = std::atoi(a.c_str() + 9);
         else if (a.rfind("sparse=", 0) == 0) sparse = std::atoi(a.c_str() + 7);
+        else if (a.rfind("det=", 0) == 0) det = std::atoi(a.c_str() + 4);
         else if (a.rfind("ckpt=", 0) == 0) ckdir = a.substr(5);
         else if (a.rfind("every=", 0) == 0) every = std::atoll(a.c_str() + 6);
         else if (a.rfind("maxsteps=", 0) == 0) maxsteps = std::atoll(a.c_str() + 9);
@@ -104,6 +105,7 @@ int main(int argc, char **argv)
     opts.real_wire = realwire;
     opts.lanczos_pipeline = pipeline;
     opts.sparse_gather = sparse;
+    opts.deterministic = det;                      // 1: static walks (their slot arithmetic needs grids that are multiples of 8)
     qbh_csr *A = nullptr;
     must(qbh_csr_create_rows(&A, dim, nnz, (int)sym, ia.data(), ja.data(), reinterpret_cast<const qbh_z *>(val.data()), cuts[rank],
                              cuts[rank + 1], &opts), "qbh_csr_create_rows");

@@ -164,6 +164,19 @@ def test_other_shapes_of_split_shards_over_the_native_communicator(rig, other_op
     _check(rig, res, op["ref"], nranks, dim=op["dim"], e0=op["e0"], kmax=20 if op["dim"] < 1000 else 40)     # (dim 120: the Krylov space is exhausted early)
 
 
+@pytest.mark.parametrize("shape,nranks", [("s126", 3), ("s56", 2)])
+def test_static_walks_under_ranks_with_workgroups_left_out(rig, other_ops, shape, nranks):
+    """qbh_opts.deterministic = 1 (static walks: every workgroup's blocks follow from its index and the grid size) on split shards under a
+    communicator, whose persistent passes run on REDUCED grids (qbh_opts.comm_reserve): the grids must stay multiples of 8 or blocks
+    are visited twice.  Same E0, coefficients and eigenvector as the one-rank run."""
+    op = other_ops[shape]
+    if op["ref"] is None:
+        op["ref"] = _run(rig, 1, ["plain=1"], "oref_" + shape, csr=op["csr"])[0]
+    res = _run(rig, nranks, ["plain=1", "kron=%d" % op["S"], "parts=4", "det=1"], "det_%s_%d" % (shape, nranks), csr=op["csr"])
+    assert all(r["kron"] == op["S"] for r in res), [(r["kron"], r["parts"]) for r in res]
+    _check(rig, res, op["ref"], nranks, dim=op["dim"], e0=op["e0"])
+
+
 @pytest.mark.parametrize("nranks,unsplit", [(2, 1), (3, 0)])
 def test_one_unsplit_rank_makes_every_rank_fall_back_together(rig, nranks, unsplit):
     """One rank keeps its shard unsplit: the collective qbh_csr_set_comm must end with EVERY rank on the plain exchange (the
