@@ -224,9 +224,14 @@ def test_bench_two_ranks_on_one_gpu_through_the_native_communicator(rig):
     assert len(pr) == 2 and all(set(("rank", "rows", "nnz", "ms_spmv", "ms_gather", "gather_hidden_frac", "roofline_frac")) <= set(p) for p in pr), pr
     assert all(p["ms_spmv"] > 0 and p["rows"] > 0 for p in pr) and sum(p["rows"] for p in pr) == got["config"]["dim"], pr
     # qbh_opts.comm_reserve: a few untimed steps with 64 / 128 / 32 workgroups left out of the persistent passes, the ranks agree on one
+    # (split shards only -- this 12-site operator is below the size the library splits by itself: the field is there and empty; C3 through
+    # the same path: profiles/r6_bench/ranks_stub/*_abi601.json)
     cal = got["exchange"]["comm_reserve_calibration"]
-    assert set(cal["ms_per_step_by_workgroups_left_out"]) == {"64", "128", "32"} and cal["chosen"] in (64, 128, 32)
-    assert got["exchange"]["comm_reserve_workgroups"] == cal["chosen"]
+    if got["config"].get("kron_split"):
+        assert set(cal["ms_per_step_by_workgroups_left_out"]) == {"64", "128", "32"} and cal["chosen"] in (64, 128, 32)
+        assert got["exchange"]["comm_reserve_workgroups"] == cal["chosen"]
+    else:
+        assert cal is None and got["exchange"]["comm_reserve_workgroups"] is None
 
 
 @pytest.mark.parametrize("kron", [0, 1])
