@@ -566,6 +566,7 @@ def main():
     ap.add_argument("--deterministic", action="store_true", help="qbh_opts.deterministic: static walks, nothing timed at creation (bit-identical a_j / b_j from run to run)")
     ap.add_argument("--no-pipeline", action="store_true", help="qbh_opts.lanczos_pipeline = 0: one host synchronisation per Lanczos step (the loop of ABI <= 501), for A/B runs")
     ap.add_argument("--no-sparse-gather", action="store_true", help="N > 1: qbh_opts.sparse_gather = 0 (every rank's whole tiled block travels to everybody)")
+    ap.add_argument("--force-split", action="store_true", help="qbh_opts.kron_split = 2: split a product-basis operator in place even below the 1e8 nonzeros at which the library does it by itself (test rigs)")
     ap.add_argument("--comm-reserve", type=int, default=0, help="N > 1, split shards (qbh_opts.comm_reserve): workgroups the persistent passes leave out of their grids so that "
                     "RCCL's own kernels find a place beside them; 0 (library default) 64, -1 none")
     ap.add_argument("--no-reserve-calibration", action="store_true", help="N > 1: keep qbh_opts.comm_reserve at the library's default instead of trying 64 / 128 / 32 in a few untimed steps")
@@ -775,6 +776,8 @@ def main():
             # the up configurations in the order of a recursive bisection of the hop graph into `world` parts: every rank's far part then reads
             # far fewer of its peers' major indices, which is what the personalised exchange carries (qbh_opts.major_partition)
             opts.major_partition = world
+        if args.force_split:
+            opts.kron_split = 2
         opts.sector_cut = args.site_cut if world == 1 else -1          # qbh_opts.sector_cut: 0 = the library picks the cut of a heisenberg sector, -1 never
         t_gen = time.time()
         hint = (not args.no_basis_hint) and W["kind"] == "hubbard" and world == 1 and value_dict == 0

@@ -291,7 +291,7 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did(rig):
     before it touches the GPU, relays rank 0's line and the ranks' exit code; --gpus 1 is unchanged."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(QBH_RCCL_LIB=STUB, QBH_DIST_BACKEND="gloo", TMPDIR=rig["tmp"], HSA_ENABLE_IPC_MODE_LEGACY="0")
-    common = ["--steps", "4", "--warmup", "2", "--workload", "hubbard_4x3_half", "--no-cpu-baseline", "--no-matrix-free", "--no-fast-path", "--processes", "1"]
+    common = ["--steps", "4", "--warmup", "2", "--workload", "hubbard_4x3_half", "--no-cpu-baseline", "--no-matrix-free", "--no-fast-path", "--processes", "1", "--force-split"]
     many = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
     assert many.returncode == 0, many.stdout + many.stderr
     lines = [ln for ln in many.stdout.strip().splitlines() if ln.startswith("{")]
@@ -299,6 +299,10 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did(rig):
     got = json.loads(lines[0])
     assert got["n_gpus"] == 2 and got["steps"] == 4 and len(got["per_rank"]) == 2 and "native RCCL" in got["config"]["exchange"], got
     assert abs(got["e0"] + 16.879382788684) < 1e-9
+    # split shards (--force-split): the comm_reserve calibration ran and the ranks agreed on one value
+    cal = got["exchange"]["comm_reserve_calibration"]
+    assert got["config"]["kron_split"] and set(cal["ms_per_step_by_workgroups_left_out"]) == {"64", "128", "32"}
+    assert cal["chosen"] in (64, 128, 32) and got["exchange"]["comm_reserve_workgroups"] == cal["chosen"]
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "hubbard_4x3_half", "--packed-real"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
     assert bad.returncode != 0                                             # the ranks' failure is the parent's exit code
 
