@@ -67,9 +67,13 @@ def test_reference_ordered_host_arrays_run_on_the_split_with_the_hint_and_withou
     assert np.allclose(q.vec_randomize(A, seed=1), qo.vec_randomize(dim, 1), rtol=1e-13, atol=0)
     # locate_E0_lanczos: E0 and the eigenvector, in the caller's order
     r = q.locate_E0_lanczos(A, nev=1, ncv=1, maxit=1000)
-    ro = qo.locate_E0_lanczos(O, nev=1, ncv=1, maxit=1000)
-    assert abs(r.E0 - ro["E0"]) <= 1e-11 * abs(ro["E0"])
-    assert abs(abs(np.vdot(r.eigenvecs, ro["eigenvecs"])) - 1.0) < 1e-8
+    if dim < 100000:
+        ro = qo.locate_E0_lanczos(O, nev=1, ncv=1, maxit=1000)
+        assert abs(r.E0 - ro["E0"]) <= 1e-11 * abs(ro["E0"])
+        assert abs(abs(np.vdot(r.eigenvecs, ro["eigenvecs"])) - 1.0) < 1e-8
+    else:           # 12 sites: the oracle's Lanczos above already gave E0 (its CG on the host is another 8 s of the GPU tier's budget); the eigenvector is checked by its residual
+        e0_o = qo.hess_eigen(hess_o, maxit, mo, "sr")[0][0]
+        assert abs(r.E0 - e0_o) <= 1e-11 * abs(e0_o)
     assert np.abs(O.multmv(r.eigenvecs) - r.E0 * r.eigenvecs).max() < 1e-7
     # qbh_csr_download gives the CALLER's rows back (through the map: H_caller[r, c] = s_r s_c H_internal[g(r), g(c)]): the full-storage
     # form of the arrays that went in, entry by entry -- and row ranges of it
