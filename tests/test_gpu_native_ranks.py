@@ -354,3 +354,20 @@ def test_headline_operator_on_four_ranks_through_the_native_communicator(rig):
     assert len(ran) == 4 and all(r[0] == "5" for r in ran), p.stdout
     # the one-rank coefficients of the same start vector (seed 1): tests/test_gpu_kron.py pins them through E0; here to 1e-9
     assert all(abs(float(r[1]) - 4.399209342849) < 1e-9 and abs(float(r[2]) - 5.951874544884) < 1e-9 for r in ran), ran
+
+
+@pytest.mark.parametrize("model", ["", "8:rccl"])
+def test_solo_rank_timing_model_runs(rig, model):
+    """tools/solo_rank.py: one rank of two alone on the GPU, its peer modelled by the stand-in's solo mode -- the hold of the side stream as a
+    host function or (QBH_STUB_SOLO_KERNEL=W:rccl) as a kernel with the register / LDS footprint of RCCL's own, which is what showed that the
+    persistent passes must leave room (qbh_opts.comm_reserve; profiles/r6_bench/solo_rank/occupancy_SUMMARY.txt).  The numbers of a 12-site
+    operator mean nothing; the tool and both hold paths must run and report the fields the summaries are made of."""
+    env = dict(os.environ, QBH_RCCL_LIB=STUB, QBH_STUB_SOLO="50", TMPDIR=rig["tmp"], PYTHONPATH=ROOT)
+    if model:
+        env["QBH_STUB_SOLO_KERNEL"] = model
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "solo_rank.py"), "hubbard_4x3_half", "2", "0", "steps=6", "warmup=2", "parts=4"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["ranks"] == 2 and d["rank"] == 0 and d["steps"] == 6 and d["ms_per_step"] > 0 and d["comm_reserve"] == 0
+    assert d["link_model"]["GBps_per_link"] == 50.0
