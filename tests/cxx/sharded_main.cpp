@@ -165,7 +165,7 @@ int main(int argc, char **argv)
         o.write((const char *)hess.data(), 8 * m);                 // b_j
         o.write((const char *)vec.data(), 16 * n);
     }
-    std::printf("OK %d %d %lld %lld %lld %.17g %lld %.3e %.15g kron %lld parts %d cols16 %d wire %d need %.4f sparse %d\n", rank, nranks, (long long)cuts[rank],
+    std::printf("OK %d %d %lld %lld %lld %.17g %lld %.17g %.15g kron %lld parts %d cols16 %d wire %d need %.4f sparse %d\n", rank, nranks, (long long)cuts[rank],
                 (long long)cuts[rank + 1], (long long)m, E0, (long long)mcg, accu, nrm, (long long)inf.kron_minor, inf.gather_parts, inf.kron_cols16,
                 inf.wire_element_bytes, inf.gather_needed_frac, inf.gather_sparse);
     qbh_vec_free(d_v);
