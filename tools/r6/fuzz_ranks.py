@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised campaign over the sharded exchange forms (round 6, outside the GPU tier): random two-species operators (lattice, fillings) x
+"""Randomised campaign over the sharded exchange forms (round 6, outside the GPU tier): random two-species operators (lattice, fillings, real or gauge-transformed to complex values) x
 2..5 rank processes x parts x wire format x personalised or not x static / dynamic walks, through tests/cxx/sharded_main.cpp and the
 librccl stand-in on one GPU.  Every rank must report the dense ground-state energy (1e-9), a converged eigenvector (CG residual
 < 2e-12), the one-rank run's first Lanczos coefficients, and the ranks' slices must tile the rows.
@@ -28,7 +28,7 @@ def main():
     cases, seed = int(kv.get("cases", 60)), int(kv.get("seed", 1))
     rng = np.random.default_rng(seed)
     _stub()
-    fails, done, t0, n_split, n_sparse = [], 0, time.time(), 0, 0
+    fails, done, t0, n_split, n_sparse, n_gauge = [], 0, time.time(), 0, 0, 0
     with tempfile.TemporaryDirectory() as tmp:
         rig = {"tmp": tmp, "exe": _build(tmp, "sharded_main"), "csr": None, "dim": 0, "ref": {}}
         ops = {}
@@ -39,14 +39,20 @@ def main():
             NU, S = math.comb(n, nu), math.comb(n, nd)
             if NU * S > 30000 or NU < 2:
                 continue
-            key = (lx, ly, nu, nd)
+            gauge = int(rng.integers(2))                 # 1: H -> D H D^+ with a random diagonal unitary D: complex values, same spectrum, same structure
+            key = (lx, ly, nu, nd, gauge)
             if key not in ops:
                 G = q.csr_mat.hubbard(n, nu, nd, lattices.square(lx, ly), t=1.0, U=float(rng.choice([0.0, 1.1, 4.0])),
                                       opts=q.make_opts(kron_split=0, value_dict=0, real_fast_path=0))
                 ia, ja, val = G.download()
                 dim = G.dim
                 G.destroy()
-                path = os.path.join(tmp, "csr_%d_%d_%d_%d.bin" % key)
+                if gauge:
+                    ph = np.exp(2j * np.pi * rng.random(dim))
+                    rows = np.repeat(np.arange(dim), np.diff(ia))
+                    val = val * ph[rows] * np.conj(ph[ja])
+                    val[rows == ja] = val[rows == ja].real           # the diagonal stays exactly real
+                path = os.path.join(tmp, "csr_%d_%d_%d_%d_%d.bin" % key)
                 with open(path, "wb") as f:
                     np.array([dim, len(ja), 0], dtype=np.int64).tofile(f)
                     ia.astype(np.int64).tofile(f), ja.astype(np.int64).tofile(f), val.tofile(f)
@@ -65,6 +71,9 @@ def main():
                     op["ref"] = T._run(rig, 1, ["plain=1"], "ref_" + tag, csr=op["csr"])[0]
                 ref = op["ref"]
                 res = T._run(rig, nranks, args, tag, csr=op["csr"])
+                if gauge and all(r["kron"] > 0 for r in res):
+                    assert all(r["wire"] == 16 for r in res), ("a complex operator must travel as complex elements", [r["wire"] for r in res])
+                    n_gauge += 1
                 n_split += int(all(r["kron"] > 0 for r in res))
                 n_sparse += int(all(r["sparse"] > 0 for r in res))
                 assert res[0]["r0"] == 0 and res[-1]["r1"] == op["dim"] and all(res[i]["r1"] == res[i + 1]["r0"] for i in range(nranks - 1)), "rows"
@@ -82,8 +91,8 @@ def main():
                 fails.append((key, nranks, args, repr(e)[:300]))
                 print("FAIL", key, "dim", op["dim"], "S", op["S"], "NU", op["NU"], "ranks", nranks, " ".join(args), "::", repr(e)[:300], flush=True)
             done += 1
-    print("fuzz_ranks: %d cases (%d on split shards, %d with the personalised exchange), %d distinct operators, %d failures, %.0f s (seed %d)" %
-          (done, n_split, n_sparse, len(ops), len(fails), time.time() - t0, seed))
+    print("fuzz_ranks: %d cases (%d on split shards, %d with the personalised exchange, %d complex-valued split operators), %d distinct operators, %d failures, %.0f s (seed %d)" %
+          (done, n_split, n_sparse, n_gauge, len(ops), len(fails), time.time() - t0, seed))
     return 1 if fails else 0
 
 
