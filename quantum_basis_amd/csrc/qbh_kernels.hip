@@ -3069,6 +3069,11 @@ __global__ __launch_bounds__(256) void k_scan_apply(const int32_t *cnt, int64_t 
 
 int exclusive_scan(const int32_t *d_cnt, int64_t n, int64_t *d_ia, hipStream_t s)
 {
+    if (n <= 0) {                                // an empty part (a cut sector's class without rows of that kind): ia = {0}; a launch of no
+        QBH_HIP(hipMemsetAsync(d_ia, 0, sizeof(int64_t), s));       // workgroups is an error that would stay behind as the "last error"
+        QBH_HIP(hipStreamSynchronize(s));
+        return QBH_OK;
+    }
     const int64_t nchunks = (n + kScanChunk - 1) / kScanChunk;
     int64_t *d_chunk = nullptr;
     QBH_HIP(qbh::dev_alloc(&d_chunk, (size_t)(nchunks + 1) * sizeof(int64_t)));

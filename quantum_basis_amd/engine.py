@@ -356,12 +356,13 @@ class csr_mat:
     def sync(self):
         check(lib().qbh_sync(self.handle), "qbh_sync")
 
-    def major_order(self):
+    def major_order(self, n_major=None):
         """qbh_csr_major_order: for an operator generated with qbh_opts.major_partition, the generator's (ascending pattern) major index
-        of every major index of this operator."""
-        n = int(self.info().ncols // self.info().kron_minor) if self.info().kron_minor else 0
+        of every major index of this operator.  n_major: the number of major indices (up configurations) -- taken from the split's
+        minor size where the operator is split in place, needed from the caller where it is not."""
+        n = int(n_major) if n_major else (int(self.info().ncols // self.info().kron_minor) if self.info().kron_minor else 0)
         if n == 0:
-            raise ValueError("major_order: not a product-basis operator")
+            raise ValueError("major_order: the operator is not split in place: name n_major")
         out = np.empty(n, dtype=np.int32)
         check(lib().qbh_csr_major_order(self.handle, _p(out), C.c_int64(n)), "qbh_csr_major_order")
         return out

@@ -170,3 +170,25 @@ def test_the_generator_picks_the_cut_by_itself(name):
     assert D.info().basis_internal == 0
     for A in (P, K, E, D):
         A.destroy()
+
+
+def test_a_cut_sector_with_an_empty_part():
+    """Found by tools/r6/fuzz_gen.py (round 6): 9 sites on a random bond graph, 3 down spins -- the cut the generator picks leaves one kind
+    of rows EMPTY in a class, and the scan of a zero-length count array launched no workgroups (an error that stayed behind as HIP's "last
+    error" and failed the next checked launch).  The operator must be created and equal the uncut one."""
+    bonds = [(0, 7), (3, 8), (4, 8), (7, 8), (5, 2), (4, 7), (5, 7), (3, 2), (3, 1), (4, 7), (8, 6), (8, 1), (8, 4), (7, 3), (0, 4), (2, 1), (0, 6)]
+    o = dict(kron_split=2, kron_sliced=2, kron_cols16=1, value_dict=0, real_fast_path=0, deterministic=1)
+    K = q.csr_mat.heisenberg(9, 3, bonds, J=2.5, opts=q.make_opts(sector_cut=0, **o))
+    P = q.csr_mat.heisenberg(9, 3, bonds, J=2.5, opts=q.make_opts(sector_cut=-1, **o))
+    assert K.info().basis_internal == _lib.BASIS_SPIN_SECTOR and P.info().basis_internal == 0 and K.dim == P.dim == 84
+    x = _rand(P.dim, 5)
+    yk, yp = np.empty(P.dim, dtype=np.complex128), np.empty(P.dim, dtype=np.complex128)
+    K.MultMv(x, yk)
+    P.MultMv(x, yp)
+    assert np.abs(yk - yp).max() <= 2e-13 * np.abs(yp).max()
+    ia, ja, val = P.download()
+    import scipy.sparse as sp
+    e0 = np.linalg.eigvalsh(sp.csr_matrix((val, ja, ia), shape=(84, 84)).toarray())[0]
+    assert abs(q.locate_E0_lanczos(K, nev=1, ncv=0).E0 - e0) <= 1e-10 * abs(e0)
+    K.destroy()
+    P.destroy()
