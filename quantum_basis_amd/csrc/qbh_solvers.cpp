@@ -888,6 +888,8 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
 
     std::vector<double> T((size_t)m * m, 0.0), Tw((size_t)m * m), theta((size_t)m), S((size_t)m * m);
     int k = 0;                          // vectors kept from the previous restart
+    d2 *d_fresh = nullptr;              // breakdown: a fresh random vector (allocated when the first one is needed)
+    int n_fresh = 0;
     int64_t restarts = 0, nconv = 0;
     double beta_last = 0.0;
     double red[16];
@@ -934,16 +936,41 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
             double alpha = 0.0, b2 = 0.0;
             rc = cgs_pass(w, j + 1, &alpha, &b2);
             if (rc != QBH_OK) break;
-            // DGKS-style correction, only when the removed components outweigh the remainder by more than
-            // 7x (error amplification |w|/|w'|); a Hamiltonian with a large diagonal would otherwise trigger
-            // it on every step because alpha^2 dominates |w|^2
-            if (b2 < 0.02 * wnorm2) {
+            // DGKS correction ("twice is enough"): a second pass whenever the first one removed more than half of |w|^2 -- ARPACK's own
+            // criterion (dsaitr step 4: rnorm1 <= 0.717 rnorm).  Until round 6 the second pass ran only below 0.02 |w|^2 ("a Hamiltonian with a
+            // large diagonal would otherwise trigger it on every step"): tools/r6/fuzz_solvers.py found operators whose spectrum lies to one side
+            // of zero (more than half filling: every state has doubly occupied sites) for which the basis then LOST its orthogonality over the
+            // restarts -- Ritz values far outside the spectrum, returned as converged.  A numpy emulation of this loop reproduces both the
+            // failure at 0.02 and its absence at 0.5.  The cost: for such operators every step pays the second pass.
+            bool broke = false;
+            if (b2 < 0.5 * wnorm2) {
+                const double b2_first = b2;
                 double corr = 0.0;
                 rc = cgs_pass(w, j + 1, &corr, &b2);
                 if (rc != QBH_OK) break;
                 alpha += corr;
+                broke = b2 < 0.5 * b2_first;                 // the second pass took most of what was left (ARPACK: rnorm1 <= 0.717 rnorm, dsaitr step 5): w lies in span(V)
             }
-            const double beta = std::sqrt(b2);
+            // BREAKDOWN: H v_j lies in span(V) to rounding -- the Krylov space of the start vector is an invariant subspace of fewer than ncv
+            // dimensions (a small or highly degenerate operator; found by tools/r6/fuzz_solvers.py: dividing the rounding noise by its norm gave
+            // a "basis vector" inside span(V) and Ritz values far outside the spectrum).  As ARPACK does (dsaitr -> dgetv0): beta_j = 0 and
+            // the basis continues with a fresh random vector orthogonalised against V; the Ritz pairs of the closed block are exact.
+            if (!(b2 > 1e-20 * wnorm2) || !(b2 > 0.0)) broke = true;
+            double beta = broke ? 0.0 : std::sqrt(b2);
+            if (broke) {
+                if (!d_fresh) QBH_HIP(qbh::dev_alloc(&d_fresh, (size_t)n * sizeof(d2)));
+                rc = qbh_vec_randomize(A, reinterpret_cast<qbh_z *>(d_fresh), (seed ? seed : 1u) + 7919u * (uint32_t)(++n_fresh));
+                if (rc != QBH_OK) break;
+                if (all_real) rc = qbh::launch_pack_real(d_fresh, rvec(j + 1), n, A->d_flag, A->stream);
+                else if (hipMemcpyAsync(w, d_fresh, (size_t)n * sizeof(d2), hipMemcpyDeviceToDevice, A->stream) != hipSuccess) rc = QBH_EHIP;
+                double dummy = 0.0, f2 = 0.0;
+                if (rc == QBH_OK) rc = cgs_pass(w, j + 1, &dummy, &f2);
+                if (rc == QBH_OK) rc = cgs_pass(w, j + 1, &dummy, &f2);
+                if (rc != QBH_OK) break;
+                if (f2 > 1e-24) rc = qbh::launch_scal(1.0 / std::sqrt(f2), w, nc, A->stream);
+                else if (hipMemsetAsync(w, 0, (size_t)ldc * sizeof(d2), A->stream) != hipSuccess) rc = QBH_EHIP;      // the basis spans the whole space: nothing left
+                if (rc != QBH_OK) break;
+            }
             T[(size_t)j * m + j] = alpha;
             beta_last = beta;
             if (j + 1 < m) T[(size_t)j * m + (j + 1)] = T[(size_t)(j + 1) * m + j] = beta;
@@ -999,6 +1026,7 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
     harvest_events(A);
     (void)hipFree(V);
     (void)hipFree(d_S);
+    if (d_fresh) (void)hipFree(d_fresh);
     if (info) {
         info->n_matvec = A->stats.n_spmv - spmv0;
         info->ms_spmv = A->stats.ms_spmv - ms_spmv0;

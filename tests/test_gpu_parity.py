@@ -328,6 +328,32 @@ def test_iram_device_resident_against_arpack_and_known_answers():
     assert np.allclose(w, dense[:4], atol=1e-9)
 
 
+def test_iram_on_an_operator_whose_spectrum_lies_to_one_side_of_zero():
+    """Found by tools/r6/fuzz_solvers.py (round 6): Hubbard on a random 8-site bond graph with 7 + 7 electrons (every state has six or seven
+    doubly occupied sites: spectrum [1.20, 12.97]).  qbh_iram re-orthogonalised a second time only when the first Gram-Schmidt pass had removed
+    more than 98 % of |w|^2; here a pass removes 86-97 %, the basis lost its orthogonality over the restarts and Ritz values such as -226 or
+    +75.9 came back as converged.  With ARPACK's own criterion (a second pass when more than half is removed) the eigenvalues are the
+    dense ones for every shift of the spectrum."""
+    import scipy.sparse as sp
+    import fastham
+    bonds = [(4, 1), (1, 0), (7, 6), (3, 5), (3, 4), (0, 2), (7, 2), (7, 2), (0, 4), (3, 7), (0, 6)]
+    H0 = fastham.hubbard_full(8, 7, 7, bonds, t=1.0, U=1.1)
+    for shift in (0.0, -20.0):
+        H = (H0 + shift * sp.identity(H0.shape[0])).tocsr()
+        H.sort_indices()
+        w = np.linalg.eigvalsh(H.toarray())
+        dim, ia, ja, val = fastham.to_ref_csr(H)
+        for vd, rf in ((0, 0), (1, 1)):
+            A = q.csr_mat(dim, ia, ja, val, sym=False, opts=q.make_opts(value_dict=vd, real_fast_path=rf))
+            for order, want in (("sr", w[0]), ("lr", w[-1])):
+                for ncv in (6, 14):
+                    nconv, ew, ez = q.iram(dim, A, None, 1, ncv, 3000, order=order, method="device")
+                    v = ez[:dim]
+                    assert nconv == 1 and abs(ew[0] - want) < 1e-10 * max(abs(want), 1.0), (shift, vd, order, ncv, ew, want)
+                    assert np.abs(H @ v - ew[0] * v).max() < 1e-10 and abs(np.linalg.norm(v) - 1.0) < 1e-12
+            A.destroy()
+
+
 def test_iram_device_resident_with_a_large_basis():
     """the reference's largest calls: iram(20, 30) (examples/trans_symmetric/latt_square/square_Kondo.cc:172) and
     iram(30, 40) (src/model.cc:2211) -- 40 basis vectors in HBM, eigenvalues against the dense spectrum"""
