@@ -26,7 +26,7 @@ def main():
     kv = dict(a.split("=", 1) for a in sys.argv[1:])
     cases, seed = int(kv.get("cases", 60)), int(kv.get("seed", 1))
     rng = np.random.default_rng(seed)
-    fails, done, t0, n_split, n_internal = [], 0, time.time(), 0, 0
+    fails, done, t0, n_split, n_internal, n_decoy = [], 0, time.time(), 0, 0, 0
     while done < cases:
         lx, ly = [(2, 2), (3, 2), (4, 2), (3, 3)][rng.integers(4)]
         n = lx * ly
@@ -36,6 +36,17 @@ def main():
             continue
         U = float(rng.choice([0.0, 1.1, 4.0]))
         dim, ia, ja, val, _ = refham.hubbard_csr(lx, ly, nu, nd, t=1.0, U=U)
+        decoy = int(rng.integers(4)) == 0                # a matrix of the same (colliding) dimension WITHOUT the product structure: must stay as given
+        if decoy:
+            import scipy.sparse as sp
+            R = sp.random(dim, dim, density=min(0.5, 8.0 / dim), random_state=int(rng.integers(1 << 30)), format="csr", dtype=np.float64)
+            R = R + 1j * sp.random(dim, dim, density=min(0.5, 4.0 / dim), random_state=int(rng.integers(1 << 30)), format="csr", dtype=np.float64)
+            Hd = sp.csr_matrix(R + R.conj().T + sp.diags(rng.normal(size=dim)))
+            Hd = sp.csr_matrix(sp.triu(Hd) + sp.diags(np.full(dim, 1e-300)))          # the reference stores every diagonal entry
+            Hd.sort_indices()
+            ia, ja, val = Hd.indptr.astype(np.int64), Hd.indices.astype(np.int64), Hd.data.astype(np.complex128)
+            val[np.repeat(np.arange(dim), np.diff(ia)) == ja] = val[np.repeat(np.arange(dim), np.diff(ia)) == ja].real
+            n_decoy += 1
         gauge = int(rng.integers(2))
         if gauge:
             ph = np.exp(2j * np.pi * rng.random(dim))
@@ -49,10 +60,12 @@ def main():
                  deterministic=int(rng.integers(2)), basis_detect=0 if hint == 2 else 1)
         if hint == 1:
             o.update(basis_kind=_lib.BASIS_REF_FERMION2, n_sites=n, n_up=nu, n_dn=nd)
-        tag = "%dx%d nu %d nd %d U %g gauge %d %s" % (lx, ly, nu, nd, U, gauge, o)
+        tag = "%dx%d nu %d nd %d U %g gauge %d decoy %d %s" % (lx, ly, nu, nd, U, gauge, int(decoy), o)
         try:
             A = q.csr_mat(dim, ia, ja, val, sym=True, opts=q.make_opts(**o))
             info = A.info()
+            if decoy:
+                assert info.kron_minor == 0 and info.basis_internal == 0, ("a matrix without the structure was permuted / split", info.kron_minor, info.basis_internal)
             n_split += int(info.kron_minor > 0)
             n_internal += int(info.basis_internal != 0)
             x = (rng.normal(size=dim) + 1j * rng.normal(size=dim)).astype(np.complex128)
@@ -85,7 +98,7 @@ def main():
             fails.append((tag, repr(e)[:300]))
             print("FAIL", tag, "::", repr(e)[:300], flush=True)
         done += 1
-    print("fuzz_hostcsr: %d cases (%d split in place, %d held in an internal order), %d failures, %.0f s (seed %d)" % (done, n_split, n_internal, len(fails), time.time() - t0, seed))
+    print("fuzz_hostcsr: %d cases (%d split in place, %d held in an internal order, %d decoys of a colliding dimension), %d failures, %.0f s (seed %d)" % (done, n_split, n_internal, n_decoy, len(fails), time.time() - t0, seed))
     return 1 if fails else 0
 
 
