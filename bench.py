@@ -46,7 +46,7 @@ KERNEL_KEY = {1: "stream", 2: "vector", 3: "rows", 4: "matrix_free", 5: "wave"}
 
 def workloads():
     from quantum_basis_amd import lattices
-    return {
+    W = {
         # BASELINE.json configs[2] / SURVEY 8(d) C3: the >=1e8-dim Hubbard the metric is quoted on
         "hubbard_4x4_half": dict(kind="hubbard", n_sites=16, n_up=8, n_dn=8, bonds=lattices.square(4, 4), t=1.0, U=1.1),
         # SURVEY 8(d) C4 substitute (4x5, N_up = N_dn = 5; half filling is 3.4e10-dim)
@@ -101,6 +101,14 @@ def workloads():
         "hubbard_4x4_half_k00": dict(kind="hubbard_repr", n_sites=16, n_up=8, n_dn=8, bonds=lattices.square(4, 4), t=1.0, U=1.1,
                                      trans=(4, 4), k=(0, 0)),
     }
+    # test rigs (tools/r6/fuzz_ranks_mid.py): further workloads as JSON in the environment, {"name": {"kind": "hubbard", "n_sites": ..., "bonds": [[a, b], ...], ...}}
+    extra = os.environ.get("QBH_WORKLOAD_JSON")
+    if extra:
+        for name, spec in json.loads(extra).items():
+            spec = dict(spec)
+            spec["bonds"] = [tuple(b) for b in spec["bonds"]]
+            W[name] = spec
+    return W
 
 
 def traffic_of(key):
