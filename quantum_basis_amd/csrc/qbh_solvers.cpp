@@ -958,7 +958,12 @@ extern "C" int qbh_iram(const qbh_csr *Ac, int64_t nev, int64_t ncv, int64_t max
             if (!(b2 > 1e-20 * wnorm2) || !(b2 > 0.0)) broke = true;
             double beta = broke ? 0.0 : std::sqrt(b2);
             if (broke) {
-                if (!d_fresh) QBH_HIP(qbh::dev_alloc(&d_fresh, (size_t)n * sizeof(d2)));
+                if (!d_fresh && qbh::dev_alloc(&d_fresh, (size_t)n * sizeof(d2)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    qbh::set_error("qbh_iram: no room for the fresh vector of a breakdown");
+                    rc = QBH_ENOMEM;               // (left through the common exit: the basis is released there)
+                    break;
+                }
                 rc = qbh_vec_randomize(A, reinterpret_cast<qbh_z *>(d_fresh), (seed ? seed : 1u) + 7919u * (uint32_t)(++n_fresh));
                 if (rc != QBH_OK) break;
                 if (all_real) rc = qbh::launch_pack_real(d_fresh, rvec(j + 1), n, A->d_flag, A->stream);
