@@ -5,7 +5,7 @@ far part sliced / padded / row-major, 2-byte or int32 columns, value codes, real
 configurations in a partition order) against an independent numpy / scipy assembly (tests/fastham.py): the stored entries (through the
 major-index map where the order is partitioned), device SpMVs with random (alpha, beta, gamma) and their fused reductions, MultMv, and
 the Lanczos ground-state energy against dense diagonalisation.
-usage: python tools/r6/fuzz_gen.py [cases=200] [seed=1]"""
+usage: python tools/r6/fuzz_gen.py [cases=200] [seed=1] [edge=0]"""
 import math
 import os
 import sys
@@ -24,11 +24,12 @@ import fastham  # noqa: E402
 def main():
     kv = dict(a.split("=", 1) for a in sys.argv[1:])
     cases, seed = int(kv.get("cases", 200)), int(kv.get("seed", 1))
+    edge = int(kv.get("edge", 0))          # 1: degenerate shapes too -- 2..10 sites, EMPTY or FULL species (one configuration: minor or major size 1), dim down to 1
     rng = np.random.default_rng(seed)
     fails, done, t0, n_split, n_part, n_heis = [], 0, time.time(), 0, 0, 0
     while done < cases:
-        n = int(rng.integers(4, 11))
-        nb = int(rng.integers(n - 1, 2 * n + 1))
+        n = int(rng.integers(2 if edge else 4, 11))
+        nb = int(rng.integers(max(1, n - 1), 2 * n + 1))
         bonds = []
         while len(bonds) < nb:
             a, b = int(rng.integers(n)), int(rng.integers(n))
@@ -39,7 +40,7 @@ def main():
                  real_fast_path=int(rng.choice([0, 0, 1])), deterministic=int(rng.integers(2)))
         try:
             if heis:
-                nd = int(rng.integers(1, n))
+                nd = int(rng.integers(0, n + 1)) if edge else int(rng.integers(1, n))
                 if math.comb(n, nd) > 20000:
                     continue
                 J = float(rng.choice([1.0, -0.7, 2.5]))
@@ -49,7 +50,7 @@ def main():
                 n_heis += 1
                 perm = None
             else:
-                nu, nd = int(rng.integers(1, n)), int(rng.integers(1, n))
+                nu, nd = (int(rng.integers(0, n + 1)), int(rng.integers(0, n + 1))) if edge else (int(rng.integers(1, n)), int(rng.integers(1, n)))
                 NU, S = math.comb(n, nu), math.comb(n, nd)
                 if NU * S > 20000:
                     continue
